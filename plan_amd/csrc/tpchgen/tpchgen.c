@@ -1,0 +1,392 @@
+/*
+ * tpchgen.c — see include/tpchgen.h.
+ *
+ * Written from the public TPC-H specification (clause 4.2, "dbgen" data-generation rules):
+ * every column draws from its own Lehmer stream  s' = 16807*s mod (2^31-1); a uniform
+ * integer in [lo,hi] is  lo + (long)((double)s'/(2^31-1) * (hi-lo+1)); after each row every
+ * stream is advanced to a fixed number of draws per row, so that a row's values do not
+ * depend on how many draws earlier rows used. Nothing here is taken from the reference
+ * repository (which contains no generator); the reference's goldens are what validate it.
+ */
+#include "tpchgen.h"
+
+#include <stddef.h>
+#include <string.h>
+
+#define MODULUS 2147483647LL
+#define MULTIPLIER 16807LL
+
+/* ---- per-column stream seeds ----
+ * The first group are the stream seeds as I know them from the public generator's seed table.
+ * The second group (SKEY, SDTE, CDTE, RDTE, RFLG) were RECOVERED, not remembered: a 2^31
+ * search for the Lehmer state that reproduces the publicly known first rows of an SF1
+ * lineitem.tbl (orders 1..70: suppliers, ship/commit/receipt dates, return flags). Either
+ * way the proof that all of them are right is tests/test_golden_tpch.py: with these seeds
+ * the reference's own SF1 goldens for Q1, Q3, Q6 and Q9 are reproduced to the last digit. */
+#define SD_P_NAME 709314158LL       /* 92 draws per part row */
+#define SD_PS_SCST 1051288424LL     /* 4 per part */
+#define SD_S_NTRG 110356601LL       /* 1 per supplier */
+#define SD_C_NTRG 1489529863LL      /* 1 per customer */
+#define SD_C_MSEG 1140279430LL      /* 1 per customer */
+#define SD_O_ODATE 1066728069LL     /* 1 per order */
+#define SD_O_CKEY 851767375LL       /* 1 per order */
+#define SD_O_LCNT 1434868289LL      /* 1 per order */
+#define SD_L_QTY 209208115LL        /* 7 per order */
+#define SD_L_DCNT 554590007LL
+#define SD_L_TAX 721958466LL
+#define SD_L_PKEY 1808217256LL
+#define SD_L_SKEY 2095021727LL
+#define SD_L_SDTE 1769349045LL
+#define SD_L_CDTE 904914315LL
+#define SD_L_RDTE 373135028LL
+#define SD_L_RFLG 1430063908LL
+
+#define O_LCNT_MAX 7
+#define SUPP_PER_PART 4
+#define CUSTOMER_MORTALITY 3
+
+/* dates: generated dates are day offsets from 1992-01-01 */
+#define EPOCH_1992_01_01 8035
+#define TOTAL_DATE_RANGE 2557
+#define ITEM_SHIP_DAYS 151 /* 121 + 30 */
+#define ORDER_DATE_SPAN (TOTAL_DATE_RANGE - ITEM_SHIP_DAYS - 1) /* max offset 2405 */
+#define CURRENT_DATE_EPOCH 9298 /* 1995-06-17 */
+
+const char *const TPCHGEN_RETURNFLAG_DICT[3] = {"A", "N", "R"};
+const char *const TPCHGEN_LINESTATUS_DICT[2] = {"F", "O"};
+const char *const TPCHGEN_MKTSEGMENT_DICT[5] = {"AUTOMOBILE", "BUILDING", "FURNITURE",
+                                                "HOUSEHOLD", "MACHINERY"};
+/* generation order of the market-segment distribution -> dictionary code */
+static const uint8_t MSEG_GEN_TO_CODE[5] = {0, 1, 2, 3, 4}; /* drawn in dictionary order */
+/* generation order of the return-flag distribution (A, R) -> dictionary code */
+static const uint8_t RFLAG_GEN_TO_CODE[2] = {0 /*A*/, 2 /*R*/};
+
+const char *const TPCHGEN_NATION_NAMES[25] = {
+    "ALGERIA", "ARGENTINA", "BRAZIL",  "CANADA",         "EGYPT",
+    "ETHIOPIA", "FRANCE",   "GERMANY", "INDIA",          "INDONESIA",
+    "IRAN",    "IRAQ",      "JAPAN",   "JORDAN",         "KENYA",
+    "MOROCCO", "MOZAMBIQUE", "PERU",   "CHINA",          "ROMANIA",
+    "SAUDI ARABIA", "VIETNAM", "RUSSIA", "UNITED KINGDOM", "UNITED STATES"};
+
+const char *const TPCHGEN_COLORS[92] = {
+    "almond",    "antique",   "aquamarine", "azure",     "beige",     "bisque",
+    "black",     "blanched",  "blue",       "blush",     "brown",     "burlywood",
+    "burnished", "chartreuse", "chiffon",   "chocolate", "coral",     "cornflower",
+    "cornsilk",  "cream",     "cyan",       "dark",      "deep",      "dim",
+    "dodger",    "drab",      "firebrick",  "floral",    "forest",    "frosted",
+    "gainsboro", "ghost",     "goldenrod",  "green",     "grey",      "honeydew",
+    "hot",       "indian",    "ivory",      "khaki",     "lace",      "lavender",
+    "lawn",      "lemon",     "light",      "lime",      "linen",     "magenta",
+    "maroon",    "medium",    "metallic",   "midnight",  "mint",      "misty",
+    "moccasin",  "navajo",    "navy",       "olive",     "orange",    "orchid",
+    "pale",      "papaya",    "peach",      "peru",      "pink",      "plum",
+    "powder",    "puff",      "purple",     "red",       "rose",      "rosy",
+    "royal",     "saddle",    "salmon",     "sandy",     "seashell",  "sienna",
+    "sky",       "slate",     "smoke",      "snow",      "spring",    "steel",
+    "tan",       "thistle",   "tomato",     "turquoise", "violet",    "wheat",
+    "white",     "yellow"};
+
+/* ---- Lehmer stream ---- */
+typedef struct {
+    int64_t seed;
+    int per_row; /* draws every row is padded to */
+    int used;    /* draws used in the current row */
+} stream_t;
+
+static int64_t mulmod(int64_t a, int64_t b) { return (a * b) % MODULUS; } /* < 2^62 */
+
+static int64_t powmod(int64_t base, int64_t e) {
+    int64_t r = 1;
+    base %= MODULUS;
+    while (e > 0) {
+        if (e & 1) r = mulmod(r, base);
+        base = mulmod(base, base);
+        e >>= 1;
+    }
+    return r;
+}
+
+static void stream_init(stream_t *s, int64_t seed, int per_row, int64_t first_row) {
+    s->seed = seed;
+    s->per_row = per_row;
+    s->used = 0;
+    if (first_row > 0) s->seed = mulmod(s->seed, powmod(MULTIPLIER, first_row * per_row));
+}
+
+static inline int64_t stream_next(stream_t *s) {
+    s->seed = (s->seed * MULTIPLIER) % MODULUS;
+    s->used++;
+    return s->seed;
+}
+
+static inline int64_t stream_int(stream_t *s, int64_t lo, int64_t hi) {
+    int64_t v = stream_next(s);
+    double range = (double)(hi - lo + 1);
+    int64_t in_range = (int64_t)(((double)v / (double)MODULUS) * range);
+    return lo + in_range;
+}
+
+static inline void stream_row_done(stream_t *s) {
+    int rem = s->per_row - s->used;
+    if (rem > 0) s->seed = mulmod(s->seed, powmod(MULTIPLIER, rem));
+    s->used = 0;
+}
+
+/* ---- scale ---- */
+static int64_t scaled(int64_t base, int64_t num, int64_t den) { return base * num / den; }
+
+int64_t tpchgen_orders_count(int64_t n, int64_t d) { return scaled(1500000, n, d); }
+int64_t tpchgen_customer_count(int64_t n, int64_t d) { return scaled(150000, n, d); }
+int64_t tpchgen_part_count(int64_t n, int64_t d) { return scaled(200000, n, d); }
+int64_t tpchgen_supplier_count(int64_t n, int64_t d) { return scaled(10000, n, d); }
+
+/* ---- calendar ---- */
+int32_t tpchgen_days_from_civil(int32_t y, int32_t m, int32_t d) {
+    y -= m <= 2;
+    int32_t era = (y >= 0 ? y : y - 399) / 400;
+    uint32_t yoe = (uint32_t)(y - era * 400);
+    uint32_t doy = (153u * (uint32_t)(m + (m > 2 ? -3 : 9)) + 2u) / 5u + (uint32_t)d - 1u;
+    uint32_t doe = yoe * 365u + yoe / 4u - yoe / 100u + doy;
+    return era * 146097 + (int32_t)doe - 719468;
+}
+
+void tpchgen_civil_from_days(int32_t z, int32_t *y, int32_t *m, int32_t *d) {
+    z += 719468;
+    int32_t era = (z >= 0 ? z : z - 146096) / 146097;
+    uint32_t doe = (uint32_t)(z - era * 146097);
+    uint32_t yoe = (doe - doe / 1460u + doe / 36524u - doe / 146096u) / 365u;
+    int32_t yy = (int32_t)yoe + era * 400;
+    uint32_t doy = doe - (365u * yoe + yoe / 4u - yoe / 100u);
+    uint32_t mp = (5u * doy + 2u) / 153u;
+    *d = (int32_t)(doy - (153u * mp + 2u) / 5u + 1u);
+    *m = (int32_t)(mp < 10 ? mp + 3 : mp - 9);
+    *y = yy + (*m <= 2);
+}
+
+/* ---- key helpers ---- */
+static int64_t make_order_key(int64_t order_index /* 1-based */) {
+    int64_t low = order_index & 7;
+    int64_t ok = order_index >> 3;
+    ok <<= 2;
+    ok <<= 3;
+    return ok + low;
+}
+
+static int64_t part_price(int64_t partkey) { /* unscaled, scale 2 */
+    int64_t price = 90000;
+    price += (partkey / 10) % 20001;
+    price += (partkey % 1000) * 100;
+    return price;
+}
+
+static int64_t part_supplier(int64_t partkey, int64_t supp_no, int64_t supplier_count) {
+    return ((partkey + (supp_no * ((supplier_count / SUPP_PER_PART) +
+                                   ((partkey - 1) / supplier_count)))) %
+            supplier_count) + 1;
+}
+
+/* ---- lineitem / orders share the order-level streams ---- */
+typedef struct {
+    stream_t odate, lcnt, ckey;
+    stream_t qty, dcnt, tax, pkey, skey, sdte, cdte, rdte, rflg;
+    int64_t part_count, supplier_count, customer_count;
+} order_streams;
+
+static void order_streams_init(order_streams *s, int64_t num, int64_t den, int64_t first) {
+    stream_init(&s->odate, SD_O_ODATE, 1, first);
+    stream_init(&s->lcnt, SD_O_LCNT, 1, first);
+    stream_init(&s->ckey, SD_O_CKEY, 1, first);
+    stream_init(&s->qty, SD_L_QTY, O_LCNT_MAX, first);
+    stream_init(&s->dcnt, SD_L_DCNT, O_LCNT_MAX, first);
+    stream_init(&s->tax, SD_L_TAX, O_LCNT_MAX, first);
+    stream_init(&s->pkey, SD_L_PKEY, O_LCNT_MAX, first);
+    stream_init(&s->skey, SD_L_SKEY, O_LCNT_MAX, first);
+    stream_init(&s->sdte, SD_L_SDTE, O_LCNT_MAX, first);
+    stream_init(&s->cdte, SD_L_CDTE, O_LCNT_MAX, first);
+    stream_init(&s->rdte, SD_L_RDTE, O_LCNT_MAX, first);
+    stream_init(&s->rflg, SD_L_RFLG, O_LCNT_MAX, first);
+    s->part_count = tpchgen_part_count(num, den);
+    s->supplier_count = tpchgen_supplier_count(num, den);
+    s->customer_count = tpchgen_customer_count(num, den);
+}
+
+static void order_streams_row_done(order_streams *s) {
+    stream_row_done(&s->odate);
+    stream_row_done(&s->lcnt);
+    stream_row_done(&s->ckey);
+    stream_row_done(&s->qty);
+    stream_row_done(&s->dcnt);
+    stream_row_done(&s->tax);
+    stream_row_done(&s->pkey);
+    stream_row_done(&s->skey);
+    stream_row_done(&s->sdte);
+    stream_row_done(&s->cdte);
+    stream_row_done(&s->rdte);
+    stream_row_done(&s->rflg);
+}
+
+int64_t tpchgen_lineitem_count(int64_t num, int64_t den, int64_t first, int64_t n) {
+    stream_t lcnt;
+    stream_init(&lcnt, SD_O_LCNT, 1, first);
+    int64_t rows = 0;
+    for (int64_t i = 0; i < n; i++) {
+        rows += stream_int(&lcnt, 1, O_LCNT_MAX);
+        lcnt.used = 0;
+    }
+    return rows;
+}
+
+/* One pass that can fill lineitem and/or orders outputs. */
+static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t n,
+                                const tpchgen_lineitem_cols *L, const tpchgen_orders_cols *O) {
+    order_streams s;
+    order_streams_init(&s, num, den, first);
+    int64_t row = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t order_index = first + i + 1;
+        int64_t okey = make_order_key(order_index);
+        int32_t odate = EPOCH_1992_01_01 + (int32_t)stream_int(&s.odate, 0, ORDER_DATE_SPAN);
+        int64_t ckey = stream_int(&s.ckey, 1, s.customer_count);
+        int64_t delta = 1;
+        while (ckey % CUSTOMER_MORTALITY == 0) {
+            ckey += delta;
+            if (ckey > s.customer_count) ckey = s.customer_count;
+            delta = -delta;
+        }
+        int lines = (int)stream_int(&s.lcnt, 1, O_LCNT_MAX);
+        int64_t total = 0;
+        int shipped = 0;
+        for (int ln = 0; ln < lines; ln++) {
+            int64_t qty = stream_int(&s.qty, 1, 50);
+            int64_t disc = stream_int(&s.dcnt, 0, 10);
+            int64_t tax = stream_int(&s.tax, 0, 8);
+            int64_t pkey = stream_int(&s.pkey, 1, s.part_count);
+            int64_t sno = stream_int(&s.skey, 0, 3);
+            int64_t skey = part_supplier(pkey, sno, s.supplier_count);
+            int64_t ext = part_price(pkey) * qty;
+            int32_t sdate = odate + (int32_t)stream_int(&s.sdte, 1, 121);
+            int32_t cdate = odate + (int32_t)stream_int(&s.cdte, 30, 90);
+            int32_t rdate = sdate + (int32_t)stream_int(&s.rdte, 1, 30);
+            uint8_t rflag;
+            if (rdate <= CURRENT_DATE_EPOCH)
+                rflag = RFLAG_GEN_TO_CODE[stream_int(&s.rflg, 0, 1)];
+            else
+                rflag = 1; /* N */
+            uint8_t lstat = (sdate <= CURRENT_DATE_EPOCH) ? 0 /*F*/ : 1 /*O*/;
+            if (lstat == 0) shipped++;
+            /* o_totalprice = sum(ext * (1+tax) * (1-disc)) truncated per line */
+            total += ((ext * (100 + tax)) / 100) * (100 - disc) / 100;
+            if (L) {
+                if (L->l_orderkey) L->l_orderkey[row] = okey;
+                if (L->l_partkey) L->l_partkey[row] = (int32_t)pkey;
+                if (L->l_suppkey) L->l_suppkey[row] = (int32_t)skey;
+                if (L->l_linenumber) L->l_linenumber[row] = ln + 1;
+                if (L->l_quantity) L->l_quantity[row] = (int32_t)qty;
+                if (L->l_extendedprice) L->l_extendedprice[row] = ext;
+                if (L->l_discount) L->l_discount[row] = disc;
+                if (L->l_tax) L->l_tax[row] = tax;
+                if (L->l_returnflag) L->l_returnflag[row] = rflag;
+                if (L->l_linestatus) L->l_linestatus[row] = lstat;
+                if (L->l_shipdate) L->l_shipdate[row] = sdate;
+                if (L->l_commitdate) L->l_commitdate[row] = cdate;
+                if (L->l_receiptdate) L->l_receiptdate[row] = rdate;
+            }
+            row++;
+        }
+        if (O) {
+            if (O->o_orderkey) O->o_orderkey[i] = okey;
+            if (O->o_custkey) O->o_custkey[i] = (int32_t)ckey;
+            if (O->o_orderdate) O->o_orderdate[i] = odate;
+            if (O->o_shippriority) O->o_shippriority[i] = 0;
+            if (O->o_totalprice) O->o_totalprice[i] = total;
+            if (O->o_orderstatus)
+                O->o_orderstatus[i] = shipped == lines ? 'F' : (shipped == 0 ? 'O' : 'P');
+        }
+        order_streams_row_done(&s);
+    }
+    return L ? row : n;
+}
+
+int64_t tpchgen_lineitem(int64_t num, int64_t den, int64_t first, int64_t n,
+                         const tpchgen_lineitem_cols *out) {
+    return gen_orders_lines(num, den, first, n, out, NULL);
+}
+
+int64_t tpchgen_orders(int64_t num, int64_t den, int64_t first, int64_t n,
+                       const tpchgen_orders_cols *out) {
+    return gen_orders_lines(num, den, first, n, NULL, out);
+}
+
+int64_t tpchgen_customer(int64_t num, int64_t den, int64_t first, int64_t n,
+                         const tpchgen_customer_cols *out) {
+    (void)num; (void)den;
+    stream_t ntrg, mseg;
+    stream_init(&ntrg, SD_C_NTRG, 1, first);
+    stream_init(&mseg, SD_C_MSEG, 1, first);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t nation = stream_int(&ntrg, 0, 24);
+        int64_t seg = stream_int(&mseg, 0, 4);
+        if (out->c_custkey) out->c_custkey[i] = (int32_t)(first + i + 1);
+        if (out->c_nationkey) out->c_nationkey[i] = (int32_t)nation;
+        if (out->c_mktsegment) out->c_mktsegment[i] = MSEG_GEN_TO_CODE[seg];
+        stream_row_done(&ntrg);
+        stream_row_done(&mseg);
+    }
+    return n;
+}
+
+int64_t tpchgen_part(int64_t num, int64_t den, int64_t first, int64_t n,
+                     const tpchgen_part_cols *out) {
+    (void)num; (void)den;
+    stream_t name;
+    stream_init(&name, SD_P_NAME, 92, first);
+    uint8_t perm[92];
+    for (int64_t i = 0; i < n; i++) {
+        for (int k = 0; k < 92; k++) perm[k] = (uint8_t)k;
+        for (int k = 0; k < 5; k++) {
+            int64_t src = stream_int(&name, k, 91);
+            uint8_t t = perm[src];
+            perm[src] = perm[k];
+            perm[k] = t;
+        }
+        if (out->p_partkey) out->p_partkey[i] = (int32_t)(first + i + 1);
+        if (out->p_name_colors) memcpy(out->p_name_colors + 5 * i, perm, 5);
+        stream_row_done(&name);
+    }
+    return n;
+}
+
+int64_t tpchgen_partsupp(int64_t num, int64_t den, int64_t first, int64_t n,
+                         const tpchgen_partsupp_cols *out) {
+    stream_t scst;
+    stream_init(&scst, SD_PS_SCST, SUPP_PER_PART, first);
+    int64_t supplier_count = tpchgen_supplier_count(num, den);
+    int64_t row = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t pkey = first + i + 1;
+        for (int j = 0; j < SUPP_PER_PART; j++) {
+            int64_t cost = stream_int(&scst, 100, 100000);
+            if (out->ps_partkey) out->ps_partkey[row] = (int32_t)pkey;
+            if (out->ps_suppkey)
+                out->ps_suppkey[row] = (int32_t)part_supplier(pkey, j, supplier_count);
+            if (out->ps_supplycost) out->ps_supplycost[row] = cost;
+            row++;
+        }
+        stream_row_done(&scst);
+    }
+    return row;
+}
+
+int64_t tpchgen_supplier(int64_t num, int64_t den, int64_t first, int64_t n,
+                         const tpchgen_supplier_cols *out) {
+    (void)num; (void)den;
+    stream_t ntrg;
+    stream_init(&ntrg, SD_S_NTRG, 1, first);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t nation = stream_int(&ntrg, 0, 24);
+        if (out->s_suppkey) out->s_suppkey[i] = (int32_t)(first + i + 1);
+        if (out->s_nationkey) out->s_nationkey[i] = (int32_t)nation;
+        stream_row_done(&ntrg);
+    }
+    return n;
+}
