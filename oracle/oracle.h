@@ -1,0 +1,283 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so.
+ * Nothing under plan_amd/ includes, links or calls it; the product path never routes here.
+ *
+ * What it is: a plain-C, single-threaded CPU restatement of the reference's hot path
+ * (pkg/compute: PhysicalScan -> Filter -> HashJoin build/probe -> HashAggregate over
+ * pkg/chunk vectors), chunk-at-a-time (2048 rows, pkg/util/util.go:123-125), with the
+ * reference's value semantics: selection vectors, decimal = (neg, coef, scale) exact integer
+ * arithmetic, Hugeint sums, float64 AVG for INTEGER input, salted linear-probing group table,
+ * chained-bucket join table, groups emitted in first-seen order, print-time decimal rounding.
+ * Each function cites the reference file:line it follows.
+ *
+ * Pinned by: the reference's own SF1 goldens cases/tpch/1g/plan/q{1,3,6,9}.txt (copied to
+ * tests/golden/plan_q*.txt), reproduced byte-for-byte by oracle_q*_text() on the data of
+ * include/tpchgen.h (tests/test_golden_tpch.py). The reference itself (Go 1.24 + cgo) cannot be
+ * built in this environment, so there is no oracle/_ref.
+ *
+ * Input columns use the narrow encodings the reference's own loader reads from parquet
+ * (executor_scan.go:410-466): INTEGER int32, BIGINT int64, DATE int32 days since 1970-01-01,
+ * DECIMAL int64 unscaled + scale, VARCHAR as uint8 dictionary code + dictionary.
+ * Validity: 1 bit per row, LSB first, NULL pointer = all valid (pkg/util/bitmap.go:27-44).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#include "odecimal.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_VECTOR_SIZE 2048
+
+typedef enum {
+    OT_INT32 = 1,
+    OT_INT64 = 2,
+    OT_DATE = 3,    /* int32 days since epoch; materialised as Date{Y,M,D} (pkg/common/date.go:8-12) */
+    OT_DECIMAL = 4, /* int64 unscaled, `scale` */
+    OT_CODE8 = 5,   /* uint8 dictionary code of a VARCHAR column */
+    OT_FLOAT = 6,   /* float32 */
+    OT_DOUBLE = 7,
+    OT_ODEC = 8,    /* array of odec (results of decimal expressions) */
+    OT_VARCHAR = 9, /* offsets(int32[n+1]) + bytes: data=offsets, dict=(const char*const*)bytes */
+    OT_CONST32 = 10 /* one int32 repeated for every row (CONST vector; the constant group key of
+                       an ungrouped aggregate, executor_aggr.go:37-48) */
+} otype;
+
+typedef struct {
+    int32_t type;
+    int32_t scale;
+    const void *data;
+    const uint8_t *validity;
+    const char *const *dict; /* OT_CODE8: code -> NUL-terminated string */
+    int32_t dict_size;
+} ocol;
+
+typedef enum { OP_EQ = 1, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOTLIKE } ocmp;
+
+typedef struct {
+    int32_t type; /* OT_INT32, OT_DATE (days), OT_FLOAT (f), OT_DECIMAL (i, scale), OT_VARCHAR (s) */
+    int32_t scale;
+    int64_t i;
+    double f;
+    const char *s;
+} oconst;
+
+/* Filter: one comparison `col OP const`, narrowing an optional input selection.
+ * Follows ExprExec.executeSelect/execSelectCompare (expr_exec.go:342-442) and
+ * selectOperation/selectFlat/selectFlatLoop (function_operator_boolean.go:393-521, 672-868),
+ * including which (type, op) pairs are implemented at all: an unsupported pair selects NOTHING
+ * (:447-459), e.g. `=` on BIGINT, `<` on FLOAT. A DECIMAL column compared with a FLOAT constant
+ * is cast decimal -> float64 -> float32 first (tryCastDecimalToFloat32, function_cast.go:349-354).
+ * sel_in == NULL means identity. Returns the number of rows written to sel_out (ascending). */
+int64_t oracle_select(const ocol *col, int32_t op, const oconst *k, const int64_t *sel_in,
+                      int64_t n_in, int64_t *sel_out);
+
+/* Chunk.Hash (pkg/chunk/chunk.go:160-166, hash.go:26-41, 182-413; util.HashBytes
+ * pkg/util/hash.go:13-65): hash of the first column, combined with the others. */
+void oracle_hash(const ocol *cols, int32_t ncols, int64_t n, uint64_t *out);
+
+/* Decimal expression programs (RPN) — ExprExec.execute/executeFunc (expr_exec.go:85-340) with
+ * binaryExecSwitch decimal ops (function_operator_binary.go:134-207, 267-481). */
+typedef enum {
+    OX_COL = 1,    /* push column `col` (DECIMAL as is; INT32 cast to decimal scale 0,
+                      tryCastInt32ToDecimal function_cast.go:337-347) */
+    OX_CONST_INT,  /* push integer literal ival cast to decimal (NewFromInt64(v,0,s) -> scale 0) */
+    OX_CONST_DEC,  /* push decimal literal (ival unscaled, scale) */
+    OX_ADD,
+    OX_SUB,
+    OX_MUL
+} oxop;
+
+typedef struct {
+    int32_t op;
+    int32_t col;
+    int64_t ival;
+    int32_t scale;
+} orpn;
+
+/* Evaluates prog for rows sel[0..n) (NULL = identity over n rows); out[i] is the value of
+ * row sel[i]. Returns 0, or an ODEC_* error code (the reference panics -> query error). */
+int oracle_eval_decimal(const ocol *cols, const orpn *prog, int32_t nprog, const int64_t *sel,
+                        int64_t n, odec *out);
+
+/* ---- hash aggregate ---- */
+typedef enum { OA_SUM = 1, OA_AVG, OA_COUNT, OA_MIN, OA_MAX } oaggkind;
+
+typedef struct {
+    int32_t kind;
+    int32_t arg; /* index into args */
+} oaggspec;
+
+typedef struct {
+    uint64_t lower;
+    int64_t upper;
+} ohuge; /* pkg/common/hugeint.go:8-11 */
+
+typedef enum { OV_NULL = 0, OV_HUGEINT, OV_DECIMAL, OV_DOUBLE } ovalkind;
+
+typedef struct {
+    int32_t kind;
+    ohuge h;
+    odec d;
+    double f;
+} oaggval;
+
+/* GroupedAggrHashTable (aggregate_hash.go:101-134 create, :136-199 AddChunk,
+ * :201-391 FindOrCreateGroups, :440-513 Resize) + aggregate states (function_aggr.go:420-1032)
+ * + FinalizeStates (:1330-1365).
+ * Incremental form (what aggExecutor.Execute drives chunk by chunk, executor_aggr.go:110-142):
+ * create -> sink(<=2048 positional rows)* -> read groups in first-seen (insertion) order.
+ * keys: OT_INT32/OT_INT64/OT_DATE/OT_DECIMAL/OT_CODE8/OT_CONST32; args: OT_INT32 or OT_ODEC. */
+typedef struct oagg oagg;
+oagg *oracle_agg_create(const ocol *key_proto, int32_t nkeys, const ocol *arg_proto,
+                        const oaggspec *aggs, int32_t naggs);
+/* keys[c].data / args[c].data are positional buffers of `cnt` rows; row_ids (optional) are
+ * reported back as group_first_row. Returns 0 or an error code. */
+int oracle_agg_sink(oagg *t, const ocol *keys, const ocol *args, const int64_t *row_ids,
+                    int64_t cnt);
+int64_t oracle_agg_count(const oagg *t);
+int oracle_agg_group(const oagg *t, int64_t g, int64_t *first_row, int64_t *key_vals,
+                     uint8_t *key_null, oaggval *vals);
+void oracle_agg_free(oagg *t);
+
+/* One-shot form over whole columns addressed by row id: rows sel[0..n) (NULL = identity) are
+ * consumed 2048 at a time. Outputs in first-seen order: group_first_row[g], group_keys[g*nkeys+c]
+ * (widened to int64; codes for OT_CODE8), group_key_null, vals[g*naggs+a].
+ * Returns the number of groups, or -1 on a decimal error. */
+int64_t oracle_groupby(const ocol *keys, int32_t nkeys, const ocol *args, int32_t nargs,
+                       const oaggspec *aggs, int32_t naggs, const int64_t *sel, int64_t n,
+                       int64_t *group_first_row, int64_t *group_keys, uint8_t *group_key_null,
+                       oaggval *vals, int64_t max_groups);
+
+/* ---- hash join ---- */
+typedef struct ojoin ojoin;
+
+/* JoinHashTable.Build/prepareKeys/hash/Finalize/InsertHashesLoop (join_table.go:85-288):
+ * rows with a NULL key are dropped, chains are head-inserted, cap = max(nextpow2(2n),1024). */
+ojoin *oracle_join_build(const ocol *keys, int32_t nkeys, const int64_t *sel, int64_t n);
+void oracle_join_free(ojoin *j);
+int64_t oracle_join_count(const ojoin *j);
+
+/* Inner probe: JoinHashTable.Probe (join_table.go:324-336), Scan.NextInnerJoin/InnerJoin/
+ * advancePointers (join_scan.go:182-278), Match (util_match.go:25-301). Emits (probe row id,
+ * build row id) pairs in the reference's order: per 2048-row probe chunk, per chain round.
+ * Returns the pair count (pairs beyond `max` are counted but not stored). */
+int64_t oracle_join_probe_inner(const ojoin *j, const ocol *keys, int32_t nkeys,
+                                const int64_t *sel, int64_t n, int64_t *out_probe,
+                                int64_t *out_build, int64_t max);
+
+/* Semi/anti/mark: found[i] = 1 when probe row sel[i] has a match (ScanKeyMatches,
+ * join_scan.go:166-180). */
+void oracle_join_probe_mark(const ojoin *j, const ocol *keys, int32_t nkeys, const int64_t *sel,
+                            int64_t n, uint8_t *found);
+
+/* ---- query drivers (the pipelines of SURVEY.md §3.2/3.3) ---- */
+typedef struct {
+    uint8_t returnflag, linestatus; /* dictionary codes */
+    ohuge sum_qty;
+    odec sum_base_price, sum_disc_price, sum_charge;
+    double avg_qty;
+    odec avg_price, avg_disc;
+    uint64_t count_order;
+} oracle_q1_row;
+
+typedef struct {
+    const int32_t *l_quantity;
+    const int64_t *l_extendedprice, *l_discount, *l_tax;
+    const uint8_t *l_returnflag, *l_linestatus;
+    const int32_t *l_shipdate;
+    const int64_t *l_orderkey;
+    const int32_t *l_partkey, *l_suppkey;
+    const char *const *returnflag_dict; /* code -> string, for the VARCHAR hash/compare */
+    const char *const *linestatus_dict;
+    int64_t n;
+} oracle_lineitem;
+
+/* Q1 (cases/tpch/query/q1.sql): rows in first-seen order; returns group count. */
+int32_t oracle_q1(const oracle_lineitem *L, int32_t shipdate_le, oracle_q1_row *out,
+                  int32_t max_groups);
+/* Q6: revenue = sum(l_extendedprice*l_discount); returns 0 ok / 1 when the sum is NULL. */
+int32_t oracle_q6(const oracle_lineitem *L, int32_t date_ge, int32_t date_lt, float disc_lo,
+                  float disc_hi, int32_t qty_lt, odec *revenue);
+
+typedef struct {
+    const int64_t *o_orderkey;
+    const int32_t *o_custkey, *o_orderdate, *o_shippriority;
+    int64_t n;
+} oracle_orders;
+
+typedef struct {
+    const int32_t *c_custkey;
+    const uint8_t *c_mktsegment;
+    const char *const *mktsegment_dict;
+    int32_t dict_size;
+    int64_t n;
+} oracle_customer;
+
+typedef struct {
+    int64_t l_orderkey;
+    odec revenue;
+    int32_t o_orderdate, o_shippriority;
+} oracle_q3_row;
+
+/* Q3 before ORDER BY/LIMIT: all groups in first-seen order. Returns the group count
+ * (rows beyond max are counted, not stored). */
+int64_t oracle_q3(const oracle_lineitem *L, const oracle_orders *O, const oracle_customer *C,
+                  const char *segment, int32_t date, oracle_q3_row *out, int64_t max);
+
+typedef struct {
+    const int32_t *p_partkey;
+    const int32_t *p_name_off; /* n+1 offsets */
+    const char *p_name_bytes;
+    int64_t n;
+} oracle_part;
+
+typedef struct {
+    const int32_t *ps_partkey, *ps_suppkey;
+    const int64_t *ps_supplycost;
+    int64_t n;
+} oracle_partsupp;
+
+typedef struct {
+    const int32_t *s_suppkey, *s_nationkey;
+    int64_t n;
+} oracle_supplier;
+
+typedef struct {
+    int32_t nationkey;
+    int32_t o_year;
+    odec sum_profit;
+} oracle_q9_row;
+
+int64_t oracle_q9(const oracle_lineitem *L, const oracle_orders *O, const oracle_part *P,
+                  const oracle_partsupp *PS, const oracle_supplier *S, const char *like_pattern,
+                  oracle_q9_row *out, int64_t max);
+
+/* ---- result text: Chunk.SaveToFile (pkg/chunk/chunk.go:196-220), Vector.GetValue
+ * (vector.go:76-186), Value.String (value.go:26-70), headline "#\t..." of execQuery
+ * (executor_bench.go:229-238). The ORDER BY / LIMIT tail of each query is applied here with a
+ * plain sort — the reference's sort operator is outside the hot path. */
+int oracle_format_decimal(odec d, int type_scale, char *buf);      /* GetValue DECIMAL + String */
+int oracle_format_double(double v, char *buf);                    /* Go %v of a float64 */
+int oracle_format_hugeint(ohuge h, char *buf);
+int oracle_format_date(int32_t days, char *buf);
+
+int64_t oracle_q1_text(const oracle_q1_row *rows, int32_t n, const char *const *rf_dict,
+                       const char *const *ls_dict, char *buf, int64_t cap);
+int64_t oracle_q6_text(const odec *revenue, int is_null, char *buf, int64_t cap);
+int64_t oracle_q3_text(oracle_q3_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);
+int64_t oracle_q9_text(oracle_q9_row *rows, int64_t n, const char *const *nation_names,
+                       char *buf, int64_t cap);
+
+/* LIKE with % and _ (wildcardMatch, function_operator_boolean.go) */
+int oracle_like(const char *s, int64_t slen, const char *pattern);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,156 @@
+"""ctypes front end of the clean-room TPC-H generator (include/tpchgen.h).
+
+Synthetic-data source for bench.py and the tests. Columns come back as numpy arrays in the
+device encodings of SURVEY.md §8(d): INTEGER int32, BIGINT int64, DECIMAL(15,2) int64 unscaled,
+DATE int32 days since 1970-01-01, VARCHAR(1)/c_mktsegment uint8 dictionary codes.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RETURNFLAG_DICT = ["A", "N", "R"]
+LINESTATUS_DICT = ["F", "O"]
+MKTSEGMENT_DICT = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]
+
+_i64 = ctypes.c_int64
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libtpchgen.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _LIB = ctypes.CDLL(path)
+        for f in ("tpchgen_orders_count", "tpchgen_customer_count", "tpchgen_part_count",
+                  "tpchgen_supplier_count", "tpchgen_lineitem_count", "tpchgen_lineitem",
+                  "tpchgen_orders", "tpchgen_customer", "tpchgen_part", "tpchgen_partsupp",
+                  "tpchgen_supplier"):
+            getattr(_LIB, f).restype = _i64
+        _LIB.tpchgen_days_from_civil.restype = ctypes.c_int32
+    return _LIB
+
+
+def _dict(sym, n):
+    arr = (ctypes.c_char_p * n).in_dll(lib(), sym)
+    return [arr[i].decode() for i in range(n)]
+
+
+def nation_names():
+    return _dict("TPCHGEN_NATION_NAMES", 25)
+
+
+def colors():
+    return _dict("TPCHGEN_COLORS", 92)
+
+
+def days(y, m, d):
+    """Civil date -> days since 1970-01-01."""
+    return int(lib().tpchgen_days_from_civil(ctypes.c_int32(y), ctypes.c_int32(m),
+                                             ctypes.c_int32(d)))
+
+
+_LINEITEM = [("l_orderkey", np.int64), ("l_partkey", np.int32), ("l_suppkey", np.int32),
+             ("l_linenumber", np.int32), ("l_quantity", np.int32),
+             ("l_extendedprice", np.int64), ("l_discount", np.int64), ("l_tax", np.int64),
+             ("l_returnflag", np.uint8), ("l_linestatus", np.uint8), ("l_shipdate", np.int32),
+             ("l_commitdate", np.int32), ("l_receiptdate", np.int32)]
+_ORDERS = [("o_orderkey", np.int64), ("o_custkey", np.int32), ("o_orderdate", np.int32),
+           ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8)]
+_CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8)]
+_PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8)]
+_PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64)]
+_SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32)]
+
+
+def _gen(fn, layout, nrows, sf, first, n, columns, width=None):
+    want = [c for c, _ in layout] if columns is None else list(columns)
+    cols = {}
+    ptrs = []
+    for name, dt in layout:
+        if name in want:
+            w = (width or {}).get(name, 1)
+            cols[name] = np.empty(nrows * w, dtype=dt)
+            ptrs.append(ctypes.c_void_p(cols[name].ctypes.data))
+        else:
+            ptrs.append(ctypes.c_void_p(None))
+    struct = (ctypes.c_void_p * len(layout))(*ptrs)
+    got = fn(_i64(sf[0]), _i64(sf[1]), _i64(first), _i64(n), struct)
+    assert got == nrows, (got, nrows)
+    return cols
+
+
+def orders_count(sf):
+    return int(lib().tpchgen_orders_count(_i64(sf[0]), _i64(sf[1])))
+
+
+def lineitem_count(sf, first_order=0, n_orders=None):
+    if n_orders is None:
+        n_orders = orders_count(sf) - first_order
+    return int(lib().tpchgen_lineitem_count(_i64(sf[0]), _i64(sf[1]), _i64(first_order),
+                                            _i64(n_orders)))
+
+
+def lineitem(sf, first_order=0, n_orders=None, columns=None):
+    """sf = (num, den). Rows of orders [first_order, first_order + n_orders)."""
+    if n_orders is None:
+        n_orders = orders_count(sf) - first_order
+    nrows = lineitem_count(sf, first_order, n_orders)
+    return _gen(lib().tpchgen_lineitem, _LINEITEM, nrows, sf, first_order, n_orders, columns)
+
+
+def orders(sf, first=0, n=None, columns=None):
+    if n is None:
+        n = orders_count(sf) - first
+    return _gen(lib().tpchgen_orders, _ORDERS, n, sf, first, n, columns)
+
+
+def customer(sf, first=0, n=None, columns=None):
+    if n is None:
+        n = int(lib().tpchgen_customer_count(_i64(sf[0]), _i64(sf[1]))) - first
+    return _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns)
+
+
+def part(sf, first=0, n=None):
+    """p_partkey plus p_name as (offsets int32[n+1], bytes uint8[]) built from the 5 colour words."""
+    if n is None:
+        n = int(lib().tpchgen_part_count(_i64(sf[0]), _i64(sf[1]))) - first
+    cols = _gen(lib().tpchgen_part, _PART, n, sf, first, n, None, width={"p_name_colors": 5})
+    words = colors()
+    wl = np.array([len(w) for w in words], dtype=np.int32)
+    codes = cols["p_name_colors"].reshape(n, 5)
+    lens = wl[codes].sum(axis=1) + 4
+    off = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=off[1:])
+    # assemble the bytes word by word (vectorised over rows)
+    buf = np.full(int(off[-1]), ord(" "), dtype=np.uint8)
+    wbytes = [np.frombuffer(w.encode(), dtype=np.uint8) for w in words]
+    pos = off[:-1].astype(np.int64).copy()
+    for k in range(5):
+        ck = codes[:, k]
+        for c in np.unique(ck):
+            rows = np.nonzero(ck == c)[0]
+            wb = wbytes[c]
+            idx = pos[rows][:, None] + np.arange(len(wb))[None, :]
+            buf[idx] = wb[None, :]
+        pos += wl[ck] + 1
+    cols["p_name_off"] = off
+    cols["p_name_bytes"] = buf
+    return cols
+
+
+def partsupp(sf, first_part=0, n_parts=None, columns=None):
+    if n_parts is None:
+        n_parts = int(lib().tpchgen_part_count(_i64(sf[0]), _i64(sf[1]))) - first_part
+    return _gen(lib().tpchgen_partsupp, _PARTSUPP, 4 * n_parts, sf, first_part, n_parts, columns)
+
+
+def supplier(sf, first=0, n=None, columns=None):
+    if n is None:
+        n = int(lib().tpchgen_supplier_count(_i64(sf[0]), _i64(sf[1]))) - first
+    return _gen(lib().tpchgen_supplier, _SUPPLIER, n, sf, first, n, columns)

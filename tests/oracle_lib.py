@@ -1,0 +1,359 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement used as the parity checker.
+Test infrastructure only: nothing under plan_amd/ imports this."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+OT_INT32, OT_INT64, OT_DATE, OT_DECIMAL, OT_CODE8, OT_FLOAT, OT_DOUBLE, OT_ODEC, OT_VARCHAR, OT_CONST32 = range(1, 11)
+OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOTLIKE = range(1, 9)
+OX_COL, OX_CONST_INT, OX_CONST_DEC, OX_ADD, OX_SUB, OX_MUL = range(1, 7)
+OA_SUM, OA_AVG, OA_COUNT, OA_MIN, OA_MAX = range(1, 6)
+OV_NULL, OV_HUGEINT, OV_DECIMAL, OV_DOUBLE = range(4)
+
+i64 = ctypes.c_int64
+i32 = ctypes.c_int32
+
+
+class ODec(ctypes.Structure):
+    _fields_ = [("neg", ctypes.c_uint8), ("scale", ctypes.c_int8), ("coef", ctypes.c_uint64)]
+
+    def unscaled(self, scale):
+        """Exact unscaled integer at `scale` (raises if not exact)."""
+        v = int(self.coef)
+        if scale >= self.scale:
+            v *= 10 ** (scale - self.scale)
+        else:
+            q, r = divmod(v, 10 ** (self.scale - scale))
+            assert r == 0
+            v = q
+        return -v if self.neg else v
+
+    def __str__(self):
+        buf = ctypes.create_string_buffer(64)
+        lib().odec_string(self, buf)
+        return buf.value.decode()
+
+
+ODEC_DTYPE = np.dtype([("neg", np.uint8), ("scale", np.int8), ("coef", np.uint64)], align=True)
+
+
+class OCol(ctypes.Structure):
+    _fields_ = [("type", i32), ("scale", i32), ("data", ctypes.c_void_p),
+                ("validity", ctypes.c_void_p), ("dict", ctypes.POINTER(ctypes.c_char_p)),
+                ("dict_size", i32)]
+
+
+class OConst(ctypes.Structure):
+    _fields_ = [("type", i32), ("scale", i32), ("i", i64), ("f", ctypes.c_double),
+                ("s", ctypes.c_char_p)]
+
+
+class ORpn(ctypes.Structure):
+    _fields_ = [("op", i32), ("col", i32), ("ival", i64), ("scale", i32)]
+
+
+class OAggSpec(ctypes.Structure):
+    _fields_ = [("kind", i32), ("arg", i32)]
+
+
+class OHuge(ctypes.Structure):
+    _fields_ = [("lower", ctypes.c_uint64), ("upper", ctypes.c_int64)]
+
+    def value(self):
+        return (int(self.upper) << 64) + int(self.lower)
+
+
+class OAggVal(ctypes.Structure):
+    _fields_ = [("kind", i32), ("h", OHuge), ("d", ODec), ("f", ctypes.c_double)]
+
+
+class Q1Row(ctypes.Structure):
+    _fields_ = [("returnflag", ctypes.c_uint8), ("linestatus", ctypes.c_uint8),
+                ("sum_qty", OHuge), ("sum_base_price", ODec), ("sum_disc_price", ODec),
+                ("sum_charge", ODec), ("avg_qty", ctypes.c_double), ("avg_price", ODec),
+                ("avg_disc", ODec), ("count_order", ctypes.c_uint64)]
+
+
+class Lineitem(ctypes.Structure):
+    _fields_ = [("l_quantity", ctypes.c_void_p), ("l_extendedprice", ctypes.c_void_p),
+                ("l_discount", ctypes.c_void_p), ("l_tax", ctypes.c_void_p),
+                ("l_returnflag", ctypes.c_void_p), ("l_linestatus", ctypes.c_void_p),
+                ("l_shipdate", ctypes.c_void_p), ("l_orderkey", ctypes.c_void_p),
+                ("l_partkey", ctypes.c_void_p), ("l_suppkey", ctypes.c_void_p),
+                ("returnflag_dict", ctypes.POINTER(ctypes.c_char_p)),
+                ("linestatus_dict", ctypes.POINTER(ctypes.c_char_p)), ("n", i64)]
+
+
+class Orders(ctypes.Structure):
+    _fields_ = [("o_orderkey", ctypes.c_void_p), ("o_custkey", ctypes.c_void_p),
+                ("o_orderdate", ctypes.c_void_p), ("o_shippriority", ctypes.c_void_p), ("n", i64)]
+
+
+class Customer(ctypes.Structure):
+    _fields_ = [("c_custkey", ctypes.c_void_p), ("c_mktsegment", ctypes.c_void_p),
+                ("mktsegment_dict", ctypes.POINTER(ctypes.c_char_p)), ("dict_size", i32),
+                ("n", i64)]
+
+
+class Q3Row(ctypes.Structure):
+    _fields_ = [("l_orderkey", i64), ("revenue", ODec), ("o_orderdate", i32),
+                ("o_shippriority", i32)]
+
+
+class Part(ctypes.Structure):
+    _fields_ = [("p_partkey", ctypes.c_void_p), ("p_name_off", ctypes.c_void_p),
+                ("p_name_bytes", ctypes.c_void_p), ("n", i64)]
+
+
+class PartSupp(ctypes.Structure):
+    _fields_ = [("ps_partkey", ctypes.c_void_p), ("ps_suppkey", ctypes.c_void_p),
+                ("ps_supplycost", ctypes.c_void_p), ("n", i64)]
+
+
+class Supplier(ctypes.Structure):
+    _fields_ = [("s_suppkey", ctypes.c_void_p), ("s_nationkey", ctypes.c_void_p), ("n", i64)]
+
+
+class Q9Row(ctypes.Structure):
+    _fields_ = [("nationkey", i32), ("o_year", i32), ("sum_profit", ODec)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        L = ctypes.CDLL(path)
+        for f in ("oracle_select", "oracle_groupby", "oracle_join_count", "oracle_join_probe_inner",
+                  "oracle_q3", "oracle_q9", "oracle_q1_text", "oracle_q6_text", "oracle_q3_text",
+                  "oracle_q9_text", "oracle_agg_count"):
+            getattr(L, f).restype = i64
+        L.oracle_join_build.restype = ctypes.c_void_p
+        L.oracle_agg_create.restype = ctypes.c_void_p
+        L.odec_float64.restype = ctypes.c_double
+        _LIB = L
+    return _LIB
+
+
+def cdict(strings):
+    arr = (ctypes.c_char_p * len(strings))(*[s.encode() for s in strings])
+    return arr
+
+
+def ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def col(typ, data, scale=0, validity=None, dictionary=None):
+    c = OCol()
+    c.type = typ
+    c.scale = scale
+    c.data = None if data is None else data.ctypes.data
+    c.validity = None if validity is None else validity.ctypes.data
+    if dictionary is not None:
+        if typ == OT_VARCHAR:  # dictionary = bytes array
+            c.dict = ctypes.cast(ctypes.c_void_p(dictionary.ctypes.data),
+                                 ctypes.POINTER(ctypes.c_char_p))
+        else:
+            c.dict = ctypes.cast(dictionary, ctypes.POINTER(ctypes.c_char_p))
+            c.dict_size = len(dictionary)
+    c._keep = (data, validity, dictionary)
+    return c
+
+
+def const(typ, i=0, f=0.0, s=None, scale=0):
+    k = OConst()
+    k.type, k.scale, k.i, k.f = typ, scale, int(i), float(f)
+    k.s = None if s is None else s.encode()
+    return k
+
+
+def select(c, op, k, sel_in=None, n=None):
+    if sel_in is not None:
+        n = len(sel_in)
+    out = np.empty(max(n, 1), dtype=np.int64)
+    m = lib().oracle_select(ctypes.byref(c), i32(op), ctypes.byref(k), ptr(sel_in), i64(n), ptr(out))
+    return out[:m].copy()
+
+
+def hash_cols(cols, n):
+    arr = (OCol * len(cols))(*cols)
+    out = np.empty(n, dtype=np.uint64)
+    lib().oracle_hash(arr, i32(len(cols)), i64(n), ptr(out))
+    return out
+
+
+def eval_decimal(cols, prog, sel, n):
+    arr = (OCol * len(cols))(*cols)
+    p = (ORpn * len(prog))(*[ORpn(*x) for x in prog])
+    out = np.zeros(n, dtype=ODEC_DTYPE)
+    rc = lib().oracle_eval_decimal(arr, p, i32(len(prog)), ptr(sel), i64(n), ptr(out))
+    return rc, out
+
+
+def odec_unscaled(arr, scale):
+    """numpy ODEC array -> python ints at `scale` (exact)."""
+    out = []
+    for neg, sc, coef in zip(arr["neg"], arr["scale"], arr["coef"]):
+        v = int(coef)
+        if scale >= sc:
+            v *= 10 ** (scale - int(sc))
+        else:
+            q, r = divmod(v, 10 ** (int(sc) - scale))
+            assert r == 0
+            v = q
+        out.append(-v if neg else v)
+    return out
+
+
+def groupby(keys, args, aggs, sel, n, max_groups):
+    ka = (OCol * len(keys))(*keys)
+    aa = (OCol * max(len(args), 1))(*args)
+    sp = (OAggSpec * len(aggs))(*[OAggSpec(k, a) for k, a in aggs])
+    first = np.zeros(max_groups, dtype=np.int64)
+    gk = np.zeros(max_groups * len(keys), dtype=np.int64)
+    gn = np.zeros(max_groups * len(keys), dtype=np.uint8)
+    vals = (OAggVal * (max_groups * len(aggs)))()
+    ng = lib().oracle_groupby(ka, i32(len(keys)), aa, i32(len(args)), sp, i32(len(aggs)),
+                              ptr(sel), i64(n), ptr(first), ptr(gk), ptr(gn), vals, i64(max_groups))
+    return ng, first, gk.reshape(max_groups, len(keys)), gn.reshape(max_groups, len(keys)), vals
+
+
+class Join:
+    def __init__(self, keys, sel, n):
+        self.keys = keys
+        arr = (OCol * len(keys))(*keys)
+        self.h = ctypes.c_void_p(lib().oracle_join_build(arr, i32(len(keys)), ptr(sel), i64(n)))
+        self.nkeys = len(keys)
+
+    def count(self):
+        return lib().oracle_join_count(self.h)
+
+    def probe_inner(self, keys, sel, n, cap):
+        arr = (OCol * len(keys))(*keys)
+        op = np.empty(max(cap, 1), dtype=np.int64)
+        ob = np.empty(max(cap, 1), dtype=np.int64)
+        m = lib().oracle_join_probe_inner(self.h, arr, i32(len(keys)), ptr(sel), i64(n), ptr(op),
+                                          ptr(ob), i64(cap))
+        return m, op[:min(m, cap)].copy(), ob[:min(m, cap)].copy()
+
+    def probe_mark(self, keys, sel, n):
+        arr = (OCol * len(keys))(*keys)
+        found = np.zeros(max(n, 1), dtype=np.uint8)
+        lib().oracle_join_probe_mark(self.h, arr, i32(len(keys)), ptr(sel), i64(n), ptr(found))
+        return found[:n]
+
+    def __del__(self):
+        if self.h:
+            lib().oracle_join_free(self.h)
+            self.h = None
+
+
+# ---- query drivers ----
+RF = ["A", "N", "R"]
+LS = ["F", "O"]
+SEG = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]
+
+
+def _lineitem(t):
+    L = Lineitem()
+    keep = [cdict(RF), cdict(LS)]
+    for name in ("l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag",
+                 "l_linestatus", "l_shipdate", "l_orderkey", "l_partkey", "l_suppkey"):
+        if name in t:
+            setattr(L, name, t[name].ctypes.data)
+    L.returnflag_dict = ctypes.cast(keep[0], ctypes.POINTER(ctypes.c_char_p))
+    L.linestatus_dict = ctypes.cast(keep[1], ctypes.POINTER(ctypes.c_char_p))
+    L.n = len(t["l_shipdate"])
+    L._keep = (keep, t)
+    return L
+
+
+def q1(lineitem, shipdate_le):
+    L = _lineitem(lineitem)
+    rows = (Q1Row * 16)()
+    n = lib().oracle_q1(ctypes.byref(L), i32(shipdate_le), rows, i32(16))
+    return [rows[i] for i in range(n)]
+
+
+def q1_text(rows):
+    arr = (Q1Row * max(len(rows), 1))(*rows)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib().oracle_q1_text(arr, i32(len(rows)), cdict(RF), cdict(LS), buf, i64(len(buf)))
+    return buf.value.decode()
+
+
+def q6(lineitem, date_ge, date_lt, lo, hi, qty_lt):
+    L = _lineitem(lineitem)
+    d = ODec()
+    rc = lib().oracle_q6(ctypes.byref(L), i32(date_ge), i32(date_lt), ctypes.c_float(lo),
+                         ctypes.c_float(hi), i32(qty_lt), ctypes.byref(d))
+    return rc, d
+
+
+def q6_text(rc, d):
+    buf = ctypes.create_string_buffer(256)
+    lib().oracle_q6_text(ctypes.byref(d), ctypes.c_int(rc), buf, i64(len(buf)))
+    return buf.value.decode()
+
+
+def q3(t, segment, date, cap=1 << 22):
+    L = _lineitem(t["lineitem"])
+    O = Orders()
+    for name in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"):
+        setattr(O, name, t["orders"][name].ctypes.data)
+    O.n = len(t["orders"]["o_orderkey"])
+    C = Customer()
+    C.c_custkey = t["customer"]["c_custkey"].ctypes.data
+    C.c_mktsegment = t["customer"]["c_mktsegment"].ctypes.data
+    seg = cdict(SEG)
+    C.mktsegment_dict = ctypes.cast(seg, ctypes.POINTER(ctypes.c_char_p))
+    C.dict_size = 5
+    C.n = len(t["customer"]["c_custkey"])
+    rows = (Q3Row * cap)()
+    n = lib().oracle_q3(ctypes.byref(L), ctypes.byref(O), ctypes.byref(C), segment.encode(),
+                        i32(date), rows, i64(cap))
+    return n, rows
+
+
+def q3_text(rows, n, limit=10):
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib().oracle_q3_text(rows, i64(n), i32(limit), buf, i64(len(buf)))
+    return buf.value.decode()
+
+
+def q9(t, pattern, cap=4096):
+    L = _lineitem(t["lineitem"])
+    O = Orders()
+    for name in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"):
+        setattr(O, name, t["orders"][name].ctypes.data)
+    O.n = len(t["orders"]["o_orderkey"])
+    P = Part()
+    P.p_partkey = t["part"]["p_partkey"].ctypes.data
+    P.p_name_off = t["part"]["p_name_off"].ctypes.data
+    P.p_name_bytes = t["part"]["p_name_bytes"].ctypes.data
+    P.n = len(t["part"]["p_partkey"])
+    PS = PartSupp()
+    for name in ("ps_partkey", "ps_suppkey", "ps_supplycost"):
+        setattr(PS, name, t["partsupp"][name].ctypes.data)
+    PS.n = len(t["partsupp"]["ps_partkey"])
+    S = Supplier()
+    S.s_suppkey = t["supplier"]["s_suppkey"].ctypes.data
+    S.s_nationkey = t["supplier"]["s_nationkey"].ctypes.data
+    S.n = len(t["supplier"]["s_suppkey"])
+    rows = (Q9Row * cap)()
+    n = lib().oracle_q9(ctypes.byref(L), ctypes.byref(O), ctypes.byref(P), ctypes.byref(PS),
+                        ctypes.byref(S), pattern.encode(), rows, i64(cap))
+    return n, rows
+
+
+def q9_text(rows, n, nation_names):
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib().oracle_q9_text(rows, i64(n), cdict(nation_names), buf, i64(len(buf)))
+    return buf.value.decode()

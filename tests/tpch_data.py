@@ -1,0 +1,20 @@
+"""Generates the TPC-H tables the hot path reads, as numpy columns (test/bench helper)."""
+from plan_amd import tpchgen
+
+
+def load(num, den, q9=True):
+    sf = (num, den)
+    t = {
+        "sf": sf,
+        "lineitem": tpchgen.lineitem(sf, columns=[
+            "l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice",
+            "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]),
+        "orders": tpchgen.orders(sf, columns=[
+            "o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]),
+        "customer": tpchgen.customer(sf),
+    }
+    if q9:
+        t["part"] = tpchgen.part(sf)
+        t["partsupp"] = tpchgen.partsupp(sf)
+        t["supplier"] = tpchgen.supplier(sf)
+    return t
