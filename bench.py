@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the hot path on MI355X, one process per GPU.
+
+A "step" is one pass of the fused Agg <- Scan(filter) pipeline (TPC-H Q1: filter + 4-group hash
+aggregate, 8 aggregates) over the rank's device-resident lineitem shard, plus — for N > 1 — the
+merge of the per-rank partial group rows (a few hundred bytes, all-gathered over RCCL).
+The data path needs no collective: lineitem is partitioned by order ranges across ranks
+(weak scaling: every rank holds an SF`--sf` shard of an SF(sf*N) database).
+
+Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
+  roofline     dominant kernel (lowcard_chain_kernel): algorithmic bytes (34 B/row) / its average
+               launch duration measured with HIP events on the launch stream
+  cpu_baseline the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q1_BYTES_PER_ROW = 34  # qty 4 + ext/disc/tax 3x8 + flag 1 + status 1 + shipdate 4
+Q6_BYTES_PER_ROW = 24
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sf", type=int, default=10, help="scale factor of each rank's lineitem shard")
+    ap.add_argument("--query", default="q1", choices=["q1", "q6"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=16_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run",
+                  file=sys.stderr)
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from plan_amd import hip, queries, tpchgen
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's shard: orders [rank*n, (rank+1)*n) of an SF(sf*world) database
+    sf_total = (args.sf * world, 1)
+    orders_per_rank = tpchgen.orders_count((args.sf, 1))
+    t0 = time.time()
+    cols = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag",
+            "l_linestatus", "l_shipdate"]
+    L = tpchgen.lineitem(sf_total, rank * orders_per_rank, orders_per_rank, columns=cols)
+    nrows = len(L["l_shipdate"])
+    gen_s = time.time() - t0
+
+    # a non-default torch stream, shared with the library so torch.cuda.Event sees its kernels
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = hip.Ctx(local_rank, stream=stream.cuda_stream)
+    t0 = time.time()
+    table = queries.lineitem_table(ctx, L)
+    load_s = time.time() - t0
+    if args.query == "q1":
+        plan = queries.q1_plan(ctx, table)
+        bytes_per_row = Q1_BYTES_PER_ROW
+    else:
+        plan = queries.q6_plan(ctx, table)
+        bytes_per_row = Q6_BYTES_PER_ROW
+
+    def merge_partials():
+        """cross-rank merge of the partial group rows (N>1): all-gather of the fetched rows"""
+        r = plan.fetch()
+        if world == 1:
+            return r
+        payload = [(tuple(int(x) for x in r["keys"][g]), r["sum"][g], r["count"][g])
+                   for g in range(r["ngroups"])]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+        merged = {}
+        for part in gathered:
+            for k, s, c in part:
+                if k not in merged:
+                    merged[k] = ([0] * len(s), [0] * len(c))
+                for a in range(len(s)):
+                    merged[k][0][a] += s[a]
+                    merged[k][1][a] += c[a]
+        return merged
+
+    def step():
+        plan.run()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    result = merge_partials()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        result = merge_partials()  # one merge closes the batch of steps' last query
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([nrows], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        total_rows = int(tot.item())
+    else:
+        total_rows = nrows
+
+    # ---- roofline: per-launch duration of the scan kernel sequence with HIP events on the
+    # launch stream (events bracket one ph_scan_plan_run = scan kernel + the 1-wave merge kernel)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    durs = sorted(a.elapsed_time(b) for a, b in ev)
+    avg_ms = sum(durs) / len(durs)
+    achieved = nrows * bytes_per_row / (avg_ms * 1e-3) / 1e9
+
+    # ---- sanity: the result of the timed query must be self-consistent
+    if world == 1:
+        ngroups = result["ngroups"]
+        rows_out = sum(c[-1] for c in result["count"]) if args.query == "q1" else None
+    else:
+        ngroups = len(result)
+        rows_out = sum(v[1][-1] for v in result.values()) if args.query == "q1" else None
+
+    out = None
+    if rank == 0:
+        value = total_rows * args.steps / elapsed
+        out = {
+            "metric": "rows/sec through hash-agg (Q1)" if args.query == "q1" else "rows/sec through filter+SUM (Q6)",
+            "value": value,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"TPC-H {args.query.upper()} fused filter+hash-aggregate over SF{args.sf} "
+                            f"lineitem per GPU ({nrows} rows on rank 0, {total_rows} total), "
+                            "table resident in HBM",
+                "rows_per_gpu": nrows,
+                "kernel_family": plan.kind,
+                "groups": ngroups,
+                "rows_aggregated": rows_out,
+                "parallelism": f"row-range shards x{world}, partial-group merge",
+                "generate_s": round(gen_s, 2),
+                "pcie_load_s": round(load_s, 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "lowcard_chain_kernel" if args.query == "q1" else "filter_sumprod_kernel",
+                "avg_launch_ms": avg_ms,
+                "min_launch_ms": durs[0],
+                "algorithmic_bytes_per_launch": nrows * bytes_per_row,
+            },
+        }
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same rows
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        m = min(nrows, args.cpu_rows)
+        sample = {k: v[:m] for k, v in L.items()}
+        t0 = time.perf_counter()
+        if args.query == "q1":
+            O.q1(sample, queries.q1_shipdate_cutoff())
+        else:
+            O.q6(sample, *queries.q6_constants())
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": m / dt,
+            "unit": "rows/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {m} rows of the same lineitem shard, oracle {args.query} pipeline "
+                      f"(chunked 2048-row CPU restatement of the reference path), {dt:.1f} s, "
+                      f"host has {os.cpu_count()} logical CPUs",
+        }
+    if rank == 0:
+        print(json.dumps(out))
+
+    plan.free()
+    table.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

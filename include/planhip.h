@@ -1,0 +1,270 @@
+/*
+ * planhip.h — C ABI of libplanhip.so, the MI355X (gfx950) execution backend for the hot path of
+ * daviszhen/plan:  PhysicalScan -> Filter -> HashJoin build/probe -> HashAggregate
+ * (pkg/compute executors over pkg/chunk vectors).
+ *
+ * This is the boundary a cgo shim binds (INTEGRATION.md shows the Go side). It replaces, inside
+ * the reference's `buildOperatorExec` switch (pkg/compute/executor.go:305-350), the bodies of
+ *   scanExecutor.Execute / runFilterExec        pkg/compute/executor_scan.go:144-241
+ *   filterExecutor.Execute                      pkg/compute/executor_filter.go:27-114
+ *   joinExecutor.Execute (build + probe)        pkg/compute/executor_join.go:54-264
+ *   aggExecutor.Execute (sink + finalize)       pkg/compute/executor_aggr.go:106-265
+ * while the OperatorExec interface itself (executor_operator.go:52-56) and pkg/chunk stay as they
+ * are. Plain pointers and sizes only; no C++ or torch types cross it.
+ *
+ * Conventions
+ *  - Every function returns 0 (PH_OK) or a negative PH_E* code; ph_last_error() gives the
+ *    thread-local message. Nothing aborts: the shim turns a code into a Go `error`, which is how
+ *    the reference reports operator failures (panic -> recover -> error, executor_bench.go:184-204).
+ *  - A ph_ctx is bound to one HIP device and one stream. Calls on one ctx are stream-ordered and
+ *    must come from one thread at a time (the reference drives a query from one goroutine).
+ *    Separate ctxs are independent (concurrent queries of the psql server path).
+ *  - Column encodings on the device = what the reference's loader reads from
+ *    parquet (executor_scan.go:410-466): INTEGER int32, BIGINT int64, DATE int32 days since
+ *    1970-01-01, DECIMAL int64 unscaled (+ scale), VARCHAR with <=256 distinct values as uint8
+ *    dictionary codes, other VARCHAR as int32 offsets + bytes.
+ *  - Validity is pkg/util/bitmap.go's: 1 bit per row, LSB first, NULL pointer = all valid.
+ *  - Row ids / selection vectors on the device are int32 (a device batch is < 2^31 rows); the
+ *    shim widens them to pkg/chunk's `[]int` (select_vector.go:7-9) when it hands them back.
+ *  - "dev" pointers are HIP device pointers owned by the caller unless stated otherwise.
+ */
+#ifndef PLANHIP_H
+#define PLANHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_OK 0
+#define PH_EINVAL (-1)      /* bad argument */
+#define PH_EHIP (-2)        /* a HIP runtime call failed */
+#define PH_EUNSUPPORTED (-3)/* expression / type shape outside the device path: caller falls back */
+#define PH_EOVERFLOW (-4)   /* decimal arithmetic would leave the exact int64/int128 domain */
+#define PH_ECAPACITY (-5)   /* an output buffer supplied by the caller is too small */
+
+typedef struct ph_ctx ph_ctx;
+
+const char *ph_last_error(void);
+const char *ph_version(void);
+
+int ph_ctx_create(int device, ph_ctx **out);
+/* Use an existing stream (e.g. the caller's torch stream) for all later calls; NULL = own stream */
+int ph_ctx_set_stream(ph_ctx *ctx, void *hip_stream);
+int ph_ctx_sync(ph_ctx *ctx);
+void ph_ctx_destroy(ph_ctx *ctx);
+
+/* ------------------------------------------------------------------ columns */
+typedef enum {
+    PH_I32 = 1,
+    PH_I64 = 2,
+    PH_DATE = 3,  /* int32 days since epoch */
+    PH_DEC64 = 4, /* int64 unscaled, `scale` fractional digits */
+    PH_CODE8 = 5, /* uint8 dictionary code */
+    PH_F32 = 6,
+    PH_F64 = 7,
+    PH_STR = 8    /* int32 offsets[n+1] in `data`, bytes in `aux` */
+} ph_type;
+
+typedef struct {
+    int32_t type;
+    int32_t scale;
+    const void *data;       /* host or device pointer, depending on the call */
+    const uint8_t *validity;/* bitmap or NULL */
+    const void *aux;        /* PH_STR: bytes */
+    int64_t aux_bytes;
+} ph_col;
+
+/* ------------------------------------------------------------------ table residency
+ * Replaces DataTable.Scan's per-chunk materialisation (pkg/storage/table.go:418-428 feeding
+ * scanRows, executor_scan.go:158-241): the pruned columns of a table are loaded once into HBM
+ * (pinned staging + hipMemcpyAsync) and stay resident across queries. */
+typedef struct ph_table ph_table;
+
+int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_cols, int64_t nrows,
+                    ph_table **out);
+int64_t ph_table_rows(const ph_table *t);
+int32_t ph_table_ncols(const ph_table *t);
+/* device view of column c (data/validity/aux are device pointers) */
+int ph_table_col(const ph_table *t, int32_t c, ph_col *out);
+/* per-column min/max gathered at load (int64 domain; used for overflow proofs) */
+int ph_table_col_range(const ph_table *t, int32_t c, int64_t *min, int64_t *max);
+void ph_table_free(ph_table *t);
+
+/* plain device buffers for callers without their own allocator */
+int ph_dev_alloc(ph_ctx *ctx, int64_t bytes, void **dev);
+int ph_dev_free(ph_ctx *ctx, void *dev);
+int ph_dev_upload(ph_ctx *ctx, void *dev, const void *host, int64_t bytes);
+int ph_dev_download(ph_ctx *ctx, void *host, const void *dev, int64_t bytes);
+int ph_dev_memset(ph_ctx *ctx, void *dev, int value, int64_t bytes);
+
+/* ------------------------------------------------------------------ filter
+ * ExprExec.executeSelect / selectOperation / selectFlatLoop
+ * (pkg/compute/expr_exec.go:342-486, function_operator_boolean.go:393-521, 780-868):
+ * one comparison `col OP const`, optionally narrowing an input selection (the AND chain of
+ * execSelectAnd). Output: ascending row ids, wavefront-ballot compacted.
+ * The (type, op) pairs the reference does not implement select nothing, as there. */
+typedef enum { PH_EQ = 1, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE } ph_cmp;
+
+typedef struct {
+    int32_t type;  /* PH_I32, PH_DATE, PH_F32 (decimal column vs float literal), PH_DEC64, PH_STR */
+    int32_t scale;
+    int64_t i;
+    double f;
+    const char *s; /* host string: '=' operand or LIKE pattern */
+} ph_const;
+
+/* col: device column of n rows. sel_in (dev, may be NULL = identity over n rows), n_in rows.
+ * sel_out: dev buffer of >= n_in int32. *n_out (host) receives the count (synchronises). */
+int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op, const ph_const *k,
+                     const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
+
+/* ------------------------------------------------------------------ hash
+ * Chunk.Hash / HashTypeSwitch / CombineHashTypeSwitch (pkg/chunk/chunk.go:160-166,
+ * hash.go:26-41, 182-413; util.HashBytes pkg/util/hash.go:13-65) — bit-identical values.
+ * PH_CODE8 columns need `dict_hashes` (dev uint64 per code = HashBytes of the string). */
+int ph_hash(ph_ctx *ctx, const ph_col *cols, const uint64_t *const *dict_hashes, int32_t ncols,
+            int64_t n, uint64_t *out_dev);
+/* host helper: HashBytes of one string (for building dict_hashes) */
+uint64_t ph_hash_bytes(const void *p, uint64_t len);
+
+/* ------------------------------------------------------------------ decimal expressions
+ * ExprExec.executeExprs over DECIMAL/INTEGER operands (expr_exec.go:85-340;
+ * function_operator_binary.go:134-207). Values are exact unscaled int64 at a scale fixed by the
+ * binder's typing rules (Mul: sum of scales, Add/Sub: max; function_scalar.go:37-84, 429-475).
+ * Program = RPN over columns and literals. */
+typedef enum { PH_X_COL = 1, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL } ph_xop;
+
+typedef struct {
+    int32_t op;
+    int32_t col;   /* PH_X_COL: index into cols (PH_DEC64 or PH_I32/PH_I64 = scale 0) */
+    int64_t ival;  /* PH_X_CONST: unscaled value */
+    int32_t scale; /* PH_X_CONST: its scale */
+} ph_rpn;
+
+/* result scale of a program (host side, no device work); PH_EUNSUPPORTED if malformed */
+int ph_expr_scale(const ph_col *cols, const ph_rpn *prog, int32_t nprog, int32_t *scale);
+/* out_dev[i] = value of row sel[i] (or i). Fails with PH_EOVERFLOW when column ranges cannot
+ * prove the int64 domain is never left (ranges: min/max per column, may be NULL = full int64). */
+int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const int64_t *col_min,
+                 const int64_t *col_max, const ph_rpn *prog, int32_t nprog, const int32_t *sel,
+                 int64_t n, int64_t *out_dev);
+
+/* ------------------------------------------------------------------ hash aggregate
+ * GroupedAggrHashTable.AddChunk/FindOrCreateGroups + UpdateStates + FinalizeStates
+ * (pkg/compute/aggregate_hash.go:136-391, aggregate_exec.go:456-475,
+ * function_aggr.go:420-1365). Device form: open-addressing table in HBM keyed by the packed
+ * group key, LDS-staged per workgroup, 128-bit integer sums, counts, min/max; first-seen row id
+ * per group so that groups come back in the reference's insertion order. */
+typedef enum { PH_A_SUM = 1, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR } ph_aggkind;
+
+typedef struct {
+    int32_t kind;
+    int32_t arg; /* index into the args given to sink; ignored for COUNT_STAR */
+} ph_aggspec;
+
+typedef struct ph_agg ph_agg;
+
+/* key_types: PH_I32/PH_I64/PH_DATE/PH_DEC64/PH_CODE8 per key column (<= 4 keys, packed width
+ * <= 128 bits). expected_groups sizes the table (it grows when needed). */
+int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_types, int32_t naggs,
+                  const ph_aggspec *aggs, int64_t expected_groups, ph_agg **out);
+/* keys/args: device columns addressed by row id; rows = sel[0..n) or 0..n. args are PH_I32 /
+ * PH_I64 / PH_DEC64 columns (validity honoured: NULL inputs are skipped, NULL keys group together).
+ * row_base is added to row ids when recording first-seen order across several sinks. */
+int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
+                const int32_t *sel, int64_t n, int64_t row_base);
+int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
+/* Host outputs, groups in first-seen order:
+ *   first_row[g]; keys[g*nkeys+c] (int64-widened), key_null[g*nkeys+c];
+ *   sum_lo/sum_hi[g*naggs+a] = 128-bit sum (SUM/AVG) or min/max value in sum_lo;
+ *   count[g*naggs+a] = non-NULL inputs seen (COUNT_STAR: rows). */
+int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
+                    uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
+void ph_agg_free(ph_agg *a);
+
+/* ------------------------------------------------------------------ hash join
+ * JoinHashTable.Build/Finalize/Probe + Scan.NextInnerJoin (pkg/compute/join_table.go:85-336,
+ * join_scan.go:30-300, util_match.go:25-301). Device form: bucket-head table + next[] chains
+ * (the reference's layout: head insertion with the previous head kept per row), built with
+ * atomic exchange; rows with a NULL key are dropped on both sides. */
+typedef struct ph_join ph_join;
+
+int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
+                  ph_join **out);
+int64_t ph_join_count(const ph_join *j);
+/* Inner probe: writes (probe row id, build row id) pairs to dev buffers of `cap` entries.
+ * *n_out (host) = number of matches (may exceed cap -> PH_ECAPACITY, nothing lost but the tail). */
+int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
+                        int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,
+                        int64_t *n_out);
+/* Semi/anti/mark: found_dev[i] = 1 when probe row sel[i] (or i) has a match */
+int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
+                       uint8_t *found_dev);
+void ph_join_free(ph_join *j);
+
+/* gather: out[i] = col[idx[i]] for fixed-width columns (join payload materialisation,
+ * TupleDataTemplatedGather join_collection.go:501-529) */
+int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev, int64_t n, void *out_dev);
+
+/* ------------------------------------------------------------------ fused pipelines
+ * The measured mode: Agg <- Scan(filter) collapsed into one pass over the resident table, which
+ * is what `gpuScanAggExecutor` calls when the sub-plan matches. */
+typedef struct {
+    int32_t col;  /* table column */
+    int32_t op;   /* ph_cmp */
+    ph_const k;
+} ph_pred; /* conjuncts, AND-ed in order */
+
+typedef struct {
+    int32_t kind;      /* ph_aggkind */
+    int32_t nprog;     /* 0 for COUNT_STAR */
+    ph_rpn prog[12];   /* argument expression over table columns */
+} ph_aggexpr;
+
+typedef struct {
+    int64_t ngroups;
+    /* arrays owned by the result, groups in first-seen order */
+    int64_t *first_row;
+    int64_t *keys;      /* ngroups * nkeys */
+    uint64_t *sum_lo;   /* ngroups * naggs */
+    int64_t *sum_hi;
+    uint64_t *count;
+    int32_t *scale;     /* naggs: scale of each aggregate's argument */
+    int32_t nkeys, naggs;
+} ph_agg_result;
+
+/* group_cols: table columns to group by (0 columns = one global group, the reference's
+ * constant-key ungrouped aggregate, executor_aggr.go:37-48).
+ * rows [row_begin,row_end) of the table are scanned. */
+int ph_scan_filter_agg(ph_ctx *ctx, const ph_table *t, int64_t row_begin, int64_t row_end,
+                       const ph_pred *preds, int32_t npreds, const int32_t *group_cols,
+                       int32_t ngroup_cols, const ph_aggexpr *aggs, int32_t naggs,
+                       ph_agg_result **out);
+/* the same launch sequence without the final download (bench inner loop); result stays on device
+ * until ph_scan_filter_agg_fetch */
+typedef struct ph_scan_plan ph_scan_plan;
+int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t npreds,
+                        const int32_t *group_cols, int32_t ngroup_cols, const ph_aggexpr *aggs,
+                        int32_t naggs, ph_scan_plan **out);
+int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_end);
+int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out);
+/* name of the kernel family the plan dispatches to ("q1_lowcard", "q6_scalar", "generic") */
+const char *ph_scan_plan_kind(const ph_scan_plan *p);
+void ph_scan_plan_free(ph_scan_plan *p);
+void ph_agg_result_free(ph_agg_result *r);
+
+/* ------------------------------------------------------------------ multi-GPU partitioning
+ * No reference counterpart (the reference is single-threaded): hash-partition
+ * rows by key so that join build/probe sides and group-by keys co-locate per GPU.
+ * dest = mix64(key) % nparts. Writes per-partition counts and a permutation of row ids grouped
+ * by destination (stable within a partition); the caller gathers columns with ph_gather and
+ * exchanges them (RCCL all-to-all over xGMI, one process per GPU). */
+int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
+                 int64_t *counts_host, int32_t *perm_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

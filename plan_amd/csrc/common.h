@@ -1,0 +1,92 @@
+// Internal declarations shared by the libplanhip.so translation units (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "planhip.h"
+
+namespace ph {
+
+void set_error(const char *fmt, ...);
+
+#define PH_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ph::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                          __LINE__);                                                     \
+            return PH_EHIP;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define PH_CHECK(expr)                 \
+    do {                                \
+        int rc_ = (expr);               \
+        if (rc_ != PH_OK) return rc_;   \
+    } while (0)
+
+#define PH_REQUIRE(cond, ...)           \
+    do {                                \
+        if (!(cond)) {                  \
+            ph::set_error(__VA_ARGS__); \
+            return PH_EINVAL;           \
+        }                               \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int CU_COUNT = 256;
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// element width of a fixed-width column type (0 for PH_STR)
+inline int type_width(int32_t t) {
+    switch (t) {
+    case PH_I32: case PH_DATE: case PH_F32: return 4;
+    case PH_I64: case PH_DEC64: case PH_F64: return 8;
+    case PH_CODE8: return 1;
+    default: return 0;
+    }
+}
+
+}  // namespace ph
+
+struct ph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // reusable device scratch (block partials, scan buffers, counters)
+    void *scratch = nullptr;
+    int64_t scratch_bytes = 0;
+    // pinned host staging for uploads / small downloads
+    void *pinned = nullptr;
+    int64_t pinned_bytes = 0;
+    int ensure_scratch(int64_t bytes);
+    int ensure_pinned(int64_t bytes);
+};
+
+struct ph_table {
+    ph_ctx *ctx = nullptr;
+    int64_t nrows = 0;
+    struct column {
+        int32_t type = 0, scale = 0;
+        void *data = nullptr;      // device, padded
+        uint8_t *validity = nullptr;
+        void *aux = nullptr;       // PH_STR bytes (device)
+        int64_t aux_bytes = 0;
+        std::vector<std::string> dict; // PH_CODE8 dictionary (host), from aux at load
+        int64_t min = 0, max = 0;
+        bool has_range = false;
+    };
+    std::vector<column> cols;
+};
+
+// rows a column allocation is padded to, so vector loads never leave the allocation
+constexpr int64_t PH_ROW_PAD = 8192;

@@ -1,0 +1,326 @@
+// Context, error reporting, device buffers and table residency.
+//
+// Table residency replaces the per-chunk materialisation of DataTable.Scan -> scanRows
+// (reference pkg/storage/table.go:418-428, pkg/compute/executor_scan.go:158-241, which allocates a
+// fresh 2048-row Chunk per call): the pruned columns are staged through pinned host memory and
+// copied once with hipMemcpyAsync into HBM, in the narrow encodings of SURVEY.md §8(d).
+#include "common.h"
+
+namespace ph {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace ph
+
+extern "C" const char *ph_last_error(void) { return ph::g_err; }
+extern "C" const char *ph_version(void) { return "planhip 0.1 (gfx950)"; }
+
+int ph_ctx::ensure_scratch(int64_t bytes) {
+    if (bytes <= scratch_bytes) return PH_OK;
+    if (scratch) {
+        PH_HIP(hipStreamSynchronize(stream));
+        PH_HIP(hipFree(scratch));
+        scratch = nullptr;
+        scratch_bytes = 0;
+    }
+    bytes = ph::round_up(bytes, 1 << 20);
+    PH_HIP(hipMalloc(&scratch, bytes));
+    scratch_bytes = bytes;
+    return PH_OK;
+}
+
+int ph_ctx::ensure_pinned(int64_t bytes) {
+    if (bytes <= pinned_bytes) return PH_OK;
+    if (pinned) {
+        PH_HIP(hipStreamSynchronize(stream));
+        PH_HIP(hipHostFree(pinned));
+        pinned = nullptr;
+        pinned_bytes = 0;
+    }
+    bytes = ph::round_up(bytes, 1 << 20);
+    PH_HIP(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+    pinned_bytes = bytes;
+    return PH_OK;
+}
+
+extern "C" int ph_ctx_create(int device, ph_ctx **out) {
+    PH_REQUIRE(out != nullptr, "ph_ctx_create: out is NULL");
+    int ndev = 0;
+    PH_HIP(hipGetDeviceCount(&ndev));
+    PH_REQUIRE(device >= 0 && device < ndev, "ph_ctx_create: device %d of %d", device, ndev);
+    PH_HIP(hipSetDevice(device));
+    ph_ctx *c = new ph_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        ph::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        return PH_EHIP;
+    }
+    c->own_stream = true;
+    *out = c;
+    return PH_OK;
+}
+
+extern "C" int ph_ctx_set_stream(ph_ctx *ctx, void *hip_stream) {
+    PH_REQUIRE(ctx != nullptr, "ph_ctx_set_stream: ctx is NULL");
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) PH_HIP(hipStreamDestroy(ctx->stream));
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        PH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return PH_OK;
+}
+
+extern "C" int ph_ctx_sync(ph_ctx *ctx) {
+    PH_REQUIRE(ctx != nullptr, "ph_ctx_sync: ctx is NULL");
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    return PH_OK;
+}
+
+extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ---------------------------------------------------------------- plain device buffers
+
+extern "C" int ph_dev_alloc(ph_ctx *ctx, int64_t bytes, void **dev) {
+    PH_REQUIRE(ctx && dev && bytes >= 0, "ph_dev_alloc: bad arguments");
+    PH_HIP(hipSetDevice(ctx->device));
+    PH_HIP(hipMalloc(dev, (size_t)(bytes > 0 ? bytes : 1)));
+    return PH_OK;
+}
+
+extern "C" int ph_dev_free(ph_ctx *ctx, void *dev) {
+    PH_REQUIRE(ctx != nullptr, "ph_dev_free: ctx is NULL");
+    if (!dev) return PH_OK;
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_HIP(hipFree(dev));
+    return PH_OK;
+}
+
+// Pageable host memory (Go heap / numpy) -> pinned staging -> device, double buffered.
+static int upload_staged(ph_ctx *ctx, void *dev, const void *host, int64_t bytes) {
+    const int64_t CH = 32ll << 20;
+    PH_CHECK(ctx->ensure_pinned(2 * CH));
+    hipEvent_t ev[2];
+    PH_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    PH_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int rc = PH_OK;
+    int k = 0;
+    for (int64_t off = 0; off < bytes; off += CH, k ^= 1) {
+        int64_t len = bytes - off < CH ? bytes - off : CH;
+        char *stage = (char *)ctx->pinned + (int64_t)k * CH;
+        if (off >= 2 * CH && hipEventSynchronize(ev[k]) != hipSuccess) { rc = PH_EHIP; break; }
+        memcpy(stage, (const char *)host + off, (size_t)len);
+        if (hipMemcpyAsync((char *)dev + off, stage, (size_t)len, hipMemcpyHostToDevice,
+                           ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[k], ctx->stream) != hipSuccess) {
+            rc = PH_EHIP;
+            break;
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PH_EHIP;
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc != PH_OK) ph::set_error("staged upload of %lld bytes failed", (long long)bytes);
+    return rc;
+}
+
+extern "C" int ph_dev_upload(ph_ctx *ctx, void *dev, const void *host, int64_t bytes) {
+    PH_REQUIRE(ctx && (bytes == 0 || (dev && host)), "ph_dev_upload: bad arguments");
+    if (bytes == 0) return PH_OK;
+    PH_HIP(hipSetDevice(ctx->device));
+    return upload_staged(ctx, dev, host, bytes);
+}
+
+extern "C" int ph_dev_download(ph_ctx *ctx, void *host, const void *dev, int64_t bytes) {
+    PH_REQUIRE(ctx && (bytes == 0 || (dev && host)), "ph_dev_download: bad arguments");
+    if (bytes == 0) return PH_OK;
+    PH_HIP(hipSetDevice(ctx->device));
+    PH_HIP(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    return PH_OK;
+}
+
+extern "C" int ph_dev_memset(ph_ctx *ctx, void *dev, int value, int64_t bytes) {
+    PH_REQUIRE(ctx && (bytes == 0 || dev), "ph_dev_memset: bad arguments");
+    if (bytes == 0) return PH_OK;
+    PH_HIP(hipMemsetAsync(dev, value, (size_t)bytes, ctx->stream));
+    return PH_OK;
+}
+
+// ---------------------------------------------------------------- column statistics
+
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_kernel(const T *__restrict__ v, int64_t n,
+                                                     long long *__restrict__ out) {
+    long long lo = INT64_MAX, hi = INT64_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        long long x = (long long)v[i];
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}
+
+static int column_range(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, int64_t *mn,
+                        int64_t *mx) {
+    PH_CHECK(ctx->ensure_scratch(64));
+    long long init[2] = {INT64_MAX, INT64_MIN};
+    PH_HIP(hipMemcpyAsync(ctx->scratch, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    long long *out = (long long *)ctx->scratch;
+    switch (type) {
+    case PH_I32: case PH_DATE:
+        minmax_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t *)dev, n, out);
+        break;
+    case PH_I64: case PH_DEC64:
+        minmax_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t *)dev, n, out);
+        break;
+    case PH_CODE8:
+        minmax_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)dev, n, out);
+        break;
+    default:
+        return PH_EUNSUPPORTED;
+    }
+    PH_HIP(hipGetLastError());
+    long long res[2];
+    PH_HIP(hipMemcpyAsync(res, ctx->scratch, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    *mn = res[0];
+    *mx = res[1];
+    return PH_OK;
+}
+
+// ---------------------------------------------------------------- tables
+
+extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_cols, int64_t nrows,
+                               ph_table **out) {
+    PH_REQUIRE(ctx && host_cols && out && ncols > 0 && nrows >= 0, "ph_table_create: bad arguments");
+    PH_REQUIRE(nrows < (1ll << 31), "ph_table_create: %lld rows exceed the int32 row-id domain",
+               (long long)nrows);
+    PH_HIP(hipSetDevice(ctx->device));
+    ph_table *t = new ph_table();
+    t->ctx = ctx;
+    t->nrows = nrows;
+    t->cols.resize((size_t)ncols);
+    int64_t padded = ph::round_up(nrows > 0 ? nrows : 1, PH_ROW_PAD);
+    int rc = PH_OK;
+    for (int32_t c = 0; c < ncols && rc == PH_OK; c++) {
+        const ph_col &h = host_cols[c];
+        ph_table::column &d = t->cols[(size_t)c];
+        d.type = h.type;
+        d.scale = h.scale;
+        if (h.type == PH_STR) {
+            int64_t off_bytes = (padded + 1) * 4;
+            if (hipMalloc(&d.data, (size_t)off_bytes) != hipSuccess ||
+                hipMemsetAsync(d.data, 0, (size_t)off_bytes, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+            rc = upload_staged(ctx, d.data, h.data, (nrows + 1) * 4);
+            if (rc != PH_OK) break;
+            d.aux_bytes = h.aux_bytes;
+            if (hipMalloc(&d.aux, (size_t)(h.aux_bytes + 64)) != hipSuccess) { rc = PH_EHIP; break; }
+            rc = upload_staged(ctx, d.aux, h.aux, h.aux_bytes);
+        } else {
+            int w = ph::type_width(h.type);
+            if (w == 0) { ph::set_error("ph_table_create: column %d has unknown type %d", c, h.type); rc = PH_EINVAL; break; }
+            if (hipMalloc(&d.data, (size_t)(padded * w)) != hipSuccess) { rc = PH_EHIP; break; }
+            // zero the padding so out-of-range lanes read defined values
+            if (hipMemsetAsync((char *)d.data + nrows * w, 0, (size_t)((padded - nrows) * w), ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+            rc = upload_staged(ctx, d.data, h.data, nrows * w);
+            if (rc != PH_OK) break;
+            if (h.type == PH_CODE8 && h.aux) { // dictionary: NUL-separated strings
+                const char *p = (const char *)h.aux, *end = p + h.aux_bytes;
+                while (p < end) {
+                    size_t len = strnlen(p, (size_t)(end - p));
+                    d.dict.emplace_back(p, len);
+                    p += len + 1;
+                }
+            }
+            if (nrows > 0 && (h.type == PH_I32 || h.type == PH_DATE || h.type == PH_I64 ||
+                              h.type == PH_DEC64 || h.type == PH_CODE8)) {
+                rc = column_range(ctx, h.type, d.data, nrows, &d.min, &d.max);
+                d.has_range = rc == PH_OK;
+            }
+        }
+        if (rc == PH_OK && h.validity) {
+            int64_t vb = padded / 8;
+            if (hipMalloc((void **)&d.validity, (size_t)vb) != hipSuccess ||
+                hipMemsetAsync(d.validity, 0, (size_t)vb, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+            rc = upload_staged(ctx, d.validity, h.validity, (nrows + 7) / 8);
+        }
+    }
+    if (rc != PH_OK) {
+        if (rc == PH_EHIP && ph_last_error()[0] == 0) ph::set_error("ph_table_create: HIP allocation/copy failed");
+        ph_table_free(t);
+        return rc;
+    }
+    *out = t;
+    return PH_OK;
+}
+
+extern "C" int64_t ph_table_rows(const ph_table *t) { return t ? t->nrows : -1; }
+extern "C" int32_t ph_table_ncols(const ph_table *t) { return t ? (int32_t)t->cols.size() : -1; }
+
+extern "C" int ph_table_col(const ph_table *t, int32_t c, ph_col *out) {
+    PH_REQUIRE(t && out && c >= 0 && c < (int32_t)t->cols.size(), "ph_table_col: bad column %d", c);
+    const ph_table::column &d = t->cols[(size_t)c];
+    out->type = d.type;
+    out->scale = d.scale;
+    out->data = d.data;
+    out->validity = d.validity;
+    out->aux = d.aux;
+    out->aux_bytes = d.aux_bytes;
+    return PH_OK;
+}
+
+extern "C" int ph_table_col_range(const ph_table *t, int32_t c, int64_t *mn, int64_t *mx) {
+    PH_REQUIRE(t && c >= 0 && c < (int32_t)t->cols.size(), "ph_table_col_range: bad column %d", c);
+    const ph_table::column &d = t->cols[(size_t)c];
+    if (!d.has_range) { ph::set_error("column %d has no range statistics", c); return PH_EUNSUPPORTED; }
+    if (mn) *mn = d.min;
+    if (mx) *mx = d.max;
+    return PH_OK;
+}
+
+extern "C" void ph_table_free(ph_table *t) {
+    if (!t) return;
+    if (t->ctx) {
+        (void)hipSetDevice(t->ctx->device);
+        (void)hipStreamSynchronize(t->ctx->stream);
+    }
+    for (auto &c : t->cols) {
+        if (c.data) (void)hipFree(c.data);
+        if (c.validity) (void)hipFree(c.validity);
+        if (c.aux) (void)hipFree(c.aux);
+    }
+    delete t;
+}

@@ -1,0 +1,583 @@
+// Fused Agg <- Scan(filter) plans: descriptor normalisation, shape matching, overflow proofs,
+// launch sequencing and result assembly for ph_scan_plan_* / ph_scan_filter_agg.
+//
+// What is normalised here are the reference's plan-time typing rules, because they decide which
+// integer kernel an SQL operator becomes:
+//  * a DECIMAL column compared with a FLOAT literal is compared as float32 after
+//    decimal -> float64 -> float32 (bindAConst builder_binder.go:264-273, MaxLType ltype.go:626-643,
+//    tryCastDecimalToFloat32 function_cast.go:349-354). That cast is monotone in the unscaled
+//    integer, so the predicate is lowered on the host to an integer threshold found by bisection
+//    with the exact cast; the device compares integers.
+//  * `<` on FLOAT, `=`/`<`/`<=`/`>=` on DECIMAL, `=` on BIGINT ... have no implementation in
+//    selectOperation (function_operator_boolean.go:393-504) and select nothing.
+//  * decimal Mul adds scales, Add/Sub takes the max (function_scalar.go:37-84, 429-475); integer
+//    literals enter at scale 0 (tryCastInt32ToDecimal function_cast.go:337-347).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "scan_kernels.h"
+
+namespace {
+
+using ph::set_error;
+
+struct Affine {  // A + B * col   (col < 0: constant A)
+    int64_t A = 0, B = 0;
+    int32_t col = -1;
+    bool operator==(const Affine &o) const { return A == o.A && B == o.B && col == o.col; }
+};
+
+struct Prod {  // product of factors at `scale` fractional digits
+    std::vector<Affine> f;
+    int32_t scale = 0;
+    bool operator==(const Prod &o) const { return f == o.f && scale == o.scale; }
+};
+
+bool mul_ok(int64_t a, int64_t b, int64_t *out) { return !__builtin_mul_overflow(a, b, out); }
+
+bool pow10_i64(int k, int64_t *out) {
+    int64_t r = 1;
+    for (int i = 0; i < k; i++)
+        if (!mul_ok(r, 10, &r)) return false;
+    *out = r;
+    return true;
+}
+
+// RPN -> product of affine factors; false = shape outside the fused kernels
+bool normalize(const ph_table *t, const ph_rpn *prog, int32_t n, Prod *out) {
+    std::vector<Prod> st;
+    for (int32_t i = 0; i < n; i++) {
+        const ph_rpn &o = prog[i];
+        switch (o.op) {
+        case PH_X_COL: {
+            if (o.col < 0 || o.col >= (int32_t)t->cols.size()) return false;
+            const auto &c = t->cols[(size_t)o.col];
+            if (c.validity) return false;  // NULL-able inputs take the generic path
+            Prod p;
+            Affine a;
+            a.B = 1;
+            a.col = o.col;
+            if (c.type == PH_DEC64) p.scale = c.scale;
+            else if (c.type == PH_I32 || c.type == PH_I64) p.scale = 0;
+            else return false;
+            p.f.push_back(a);
+            st.push_back(p);
+            break;
+        }
+        case PH_X_CONST: {
+            Prod p;
+            Affine a;
+            a.A = o.ival;
+            p.scale = o.scale;
+            p.f.push_back(a);
+            st.push_back(p);
+            break;
+        }
+        case PH_X_ADD: case PH_X_SUB: {
+            if (st.size() < 2) return false;
+            Prod y = st.back(); st.pop_back();
+            Prod x = st.back(); st.pop_back();
+            if (x.f.size() != 1 || y.f.size() != 1) return false;
+            Affine a = x.f[0], b = y.f[0];
+            if (a.col >= 0 && b.col >= 0) return false;
+            int32_t s = std::max(x.scale, y.scale);
+            int64_t mx, my;
+            if (!pow10_i64(s - x.scale, &mx) || !pow10_i64(s - y.scale, &my)) return false;
+            if (!mul_ok(a.A, mx, &a.A) || !mul_ok(a.B, mx, &a.B) || !mul_ok(b.A, my, &b.A) ||
+                !mul_ok(b.B, my, &b.B)) return false;
+            if (o.op == PH_X_SUB) { b.A = -b.A; b.B = -b.B; }
+            Affine r;
+            if (__builtin_add_overflow(a.A, b.A, &r.A)) return false;
+            r.B = a.col >= 0 ? a.B : b.B;
+            r.col = a.col >= 0 ? a.col : b.col;
+            Prod p;
+            p.scale = s;
+            p.f.push_back(r);
+            st.push_back(p);
+            break;
+        }
+        case PH_X_MUL: {
+            if (st.size() < 2) return false;
+            Prod y = st.back(); st.pop_back();
+            Prod x = st.back(); st.pop_back();
+            x.f.insert(x.f.end(), y.f.begin(), y.f.end());
+            x.scale += y.scale;
+            st.push_back(x);
+            break;
+        }
+        default: return false;
+        }
+    }
+    if (st.size() != 1) return false;
+    // fold constant factors into the first column factor
+    Prod p = st[0];
+    int64_t k = 1;
+    std::vector<Affine> cols;
+    for (auto &a : p.f) {
+        if (a.col < 0) { if (!mul_ok(k, a.A, &k)) return false; }
+        else cols.push_back(a);
+    }
+    if (cols.empty()) return false;
+    if (!mul_ok(cols[0].A, k, &cols[0].A) || !mul_ok(cols[0].B, k, &cols[0].B)) return false;
+    p.f = cols;
+    *out = p;
+    return true;
+}
+
+// inclusive integer range a predicate restricts a column to; never = selects nothing
+struct Range {
+    int32_t col = -1;
+    int64_t lo = INT64_MIN, hi = INT64_MAX;
+    bool never = false;
+};
+
+float dec_to_f32(int64_t d, int scale) {  // tryCastDecimalToFloat32 for |d| < 2^53
+    double p = 1;
+    for (int i = 0; i < scale; i++) p *= 10;
+    return (float)((double)d / p);
+}
+
+// smallest d in [lo,hi] with pred(d) true, for a monotone (false..true) predicate; hi+1 if none
+template <typename F> int64_t first_true(int64_t lo, int64_t hi, F pred) {
+    if (!pred(hi)) return hi == INT64_MAX ? hi : hi + 1;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        if (pred(mid)) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+int lower_pred(const ph_table *t, const ph_pred &p, Range *r) {
+    if (p.col < 0 || p.col >= (int32_t)t->cols.size()) { set_error("predicate column %d out of range", p.col); return PH_EINVAL; }
+    const auto &c = t->cols[(size_t)p.col];
+    if (c.validity) return PH_EUNSUPPORTED;
+    r->col = p.col;
+    int32_t op = p.op;
+    auto range_from = [&](int64_t k) {
+        switch (op) {
+        case PH_EQ: r->lo = r->hi = k; break;
+        case PH_LT: if (k == INT64_MIN) r->never = true; else r->hi = k - 1; break;
+        case PH_LE: r->hi = k; break;
+        case PH_GT: if (k == INT64_MAX) r->never = true; else r->lo = k + 1; break;
+        case PH_GE: r->lo = k; break;
+        default: break;
+        }
+    };
+    switch (c.type) {
+    case PH_I32:
+        if (p.k.type != PH_I32) return PH_EUNSUPPORTED;
+        if (op == PH_NE) return PH_EUNSUPPORTED;  // not a range: generic path
+        if (op < PH_EQ || op > PH_GE) { r->never = true; return PH_OK; }
+        range_from((int32_t)p.k.i);
+        return PH_OK;
+    case PH_DATE:
+        if (p.k.type != PH_DATE) return PH_EUNSUPPORTED;
+        if (op == PH_EQ || op == PH_NE || op < PH_EQ || op > PH_GE) { r->never = true; return PH_OK; }  // no DATE '='
+        range_from((int32_t)p.k.i);
+        return PH_OK;
+    case PH_I64:
+        r->never = true;  // no BIGINT comparison is implemented in selectOperation
+        return PH_OK;
+    case PH_CODE8: {
+        if (p.k.type != PH_STR || !p.k.s) return PH_EUNSUPPORTED;
+        if (op != PH_EQ) return PH_EUNSUPPORTED;
+        int code = -1;
+        for (size_t i = 0; i < c.dict.size(); i++)
+            if (c.dict[i] == p.k.s) code = (int)i;
+        if (code < 0) r->never = true; else r->lo = r->hi = code;
+        return PH_OK;
+    }
+    case PH_DEC64: {
+        if (p.k.type == PH_F32) {
+            // float32 comparison: >, >=, <= exist; <, =, != do not (FLOAT rows of selectOperation)
+            if (op != PH_GT && op != PH_GE && op != PH_LE) { r->never = true; return PH_OK; }
+            if (!c.has_range) return PH_EUNSUPPORTED;
+            const int64_t LIM = 1ll << 53;
+            if (c.min <= -LIM || c.max >= LIM) return PH_EUNSUPPORTED;
+            float kf = (float)p.k.f;
+            int sc = c.scale;
+            int64_t lo = c.min, hi = c.max;
+            if (op == PH_GE) {
+                int64_t d = first_true(lo, hi, [&](int64_t x) { return dec_to_f32(x, sc) >= kf; });
+                if (d > hi) r->never = true; else r->lo = d;
+            } else if (op == PH_GT) {
+                int64_t d = first_true(lo, hi, [&](int64_t x) { return dec_to_f32(x, sc) > kf; });
+                if (d > hi) r->never = true; else r->lo = d;
+            } else {  // LE: everything below the first value that is > kf
+                int64_t d = first_true(lo, hi, [&](int64_t x) { return dec_to_f32(x, sc) > kf; });
+                if (d == lo && dec_to_f32(lo, sc) > kf) r->never = true; else r->hi = d > hi ? hi : d - 1;
+            }
+            return PH_OK;
+        }
+        if (p.k.type == PH_DEC64) {
+            if (op != PH_GT) { r->never = true; return PH_OK; }  // only DECIMAL '>' exists
+            // align the literal to the column scale (exact when the literal has fewer digits)
+            if (p.k.scale > c.scale) return PH_EUNSUPPORTED;
+            int64_t m, k;
+            if (!pow10_i64(c.scale - p.k.scale, &m) || !mul_ok(p.k.i, m, &k)) return PH_EUNSUPPORTED;
+            range_from(k);
+            return PH_OK;
+        }
+        return PH_EUNSUPPORTED;
+    }
+    default:
+        return PH_EUNSUPPORTED;
+    }
+}
+
+// |A + B*x| over x in [mn,mx], as a long double bound
+long double affine_bound(const Affine &a, int64_t mn, int64_t mx) {
+    long double v1 = (long double)a.A + (long double)a.B * (long double)mn;
+    long double v2 = (long double)a.A + (long double)a.B * (long double)mx;
+    return std::max(fabsl(v1), fabsl(v2));
+}
+
+}  // namespace
+
+enum PlanKind { PK_FILTER_SUMPROD = 1, PK_LOWCARD_CHAIN = 2 };
+
+struct ph_scan_plan {
+    ph_ctx *ctx = nullptr;
+    const ph_table *t = nullptr;
+    int kind = 0;
+    bool never = false;  // some conjunct selects nothing
+    ph::FilterSumProdParams fs{};
+    ph::LowcardChainParams lc{};
+    int max_grid = 0;
+    int nacc = 0;  // accumulators per launch (nslots * LC_NACC, or 2)
+    // requested aggregates -> accumulator
+    struct AggMap { int32_t kind; int acc; int32_t scale; };
+    std::vector<AggMap> aggs;
+    int32_t nkeys = 0;
+    int32_t group_cols[2] = {-1, -1};
+    // device buffers
+    long long *partials = nullptr;
+    unsigned long long *out_lo = nullptr;
+    long long *out_hi = nullptr;
+    long double row_bound = 0;  // largest |per-row accumulator value|
+    int64_t last_rows = 0;
+    int last_grid = 0;
+};
+
+static int plan_alloc(ph_scan_plan *p) {
+    PH_HIP(hipMalloc((void **)&p->partials, (size_t)p->max_grid * p->nacc * sizeof(long long)));
+    PH_HIP(hipMalloc((void **)&p->out_lo, (size_t)p->nacc * sizeof(unsigned long long)));
+    PH_HIP(hipMalloc((void **)&p->out_hi, (size_t)p->nacc * sizeof(long long)));
+    return PH_OK;
+}
+
+extern "C" void ph_scan_plan_free(ph_scan_plan *p) {
+    if (!p) return;
+    if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->partials) (void)hipFree(p->partials);
+    if (p->out_lo) (void)hipFree(p->out_lo);
+    if (p->out_hi) (void)hipFree(p->out_hi);
+    delete p;
+}
+
+extern "C" const char *ph_scan_plan_kind(const ph_scan_plan *p) {
+    if (!p) return "";
+    return p->kind == PK_FILTER_SUMPROD ? "filter_sumprod" : "lowcard_chain";
+}
+
+extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred *preds,
+                                   int32_t npreds, const int32_t *group_cols, int32_t ngroup_cols,
+                                   const ph_aggexpr *aggs, int32_t naggs, ph_scan_plan **out) {
+    PH_REQUIRE(ctx && t && out && naggs > 0 && aggs && npreds >= 0 && ngroup_cols >= 0,
+               "ph_scan_plan_create: bad arguments");
+    // ---- predicates -> one range per column
+    std::vector<Range> ranges;
+    bool never = false;
+    for (int32_t i = 0; i < npreds; i++) {
+        Range r;
+        int rc = lower_pred(t, preds[i], &r);
+        if (rc == PH_EUNSUPPORTED) { set_error("predicate %d is outside the fused shapes", i); return rc; }
+        PH_CHECK(rc);
+        if (r.never) never = true;
+        bool merged = false;
+        for (auto &q : ranges)
+            if (q.col == r.col) { q.lo = std::max(q.lo, r.lo); q.hi = std::min(q.hi, r.hi); merged = true; }
+        if (!merged) ranges.push_back(r);
+    }
+    for (auto &q : ranges) if (q.lo > q.hi) never = true;
+
+    // ---- aggregates -> normalised products
+    struct Req { int32_t kind; Prod p; bool star; };
+    std::vector<Req> reqs;
+    for (int32_t a = 0; a < naggs; a++) {
+        Req r;
+        r.kind = aggs[a].kind;
+        r.star = aggs[a].kind == PH_A_COUNT_STAR;
+        if (!r.star) {
+            if (aggs[a].kind != PH_A_SUM && aggs[a].kind != PH_A_AVG && aggs[a].kind != PH_A_COUNT) {
+                set_error("aggregate %d: MIN/MAX take the generic path", a);
+                return PH_EUNSUPPORTED;
+            }
+            if (aggs[a].nprog <= 0 || aggs[a].nprog > 12 || !normalize(t, aggs[a].prog, aggs[a].nprog, &r.p)) {
+                set_error("aggregate %d: argument expression is outside the fused shapes", a);
+                return PH_EUNSUPPORTED;
+            }
+        }
+        reqs.push_back(r);
+    }
+
+    ph_scan_plan *p = new ph_scan_plan();
+    p->ctx = ctx;
+    p->t = t;
+    p->never = never;
+    auto fail = [&](int rc) { ph_scan_plan_free(p); return rc; };
+    auto col = [&](int32_t c) -> const ph_table::column & { return t->cols[(size_t)c]; };
+    auto is_i32 = [&](int32_t c) { return col(c).type == PH_I32 || col(c).type == PH_DATE; };
+    auto is_i64 = [&](int32_t c) { return col(c).type == PH_I64 || col(c).type == PH_DEC64; };
+    auto pure = [](const Affine &a) { return a.A == 0 && a.B == 1 && a.col >= 0; };
+
+    if (ngroup_cols == 0) {
+        // ---------------- filter_sumprod: SUM(a*b) [+ COUNT(*)], ranges on <=2 int32 + <=1 int64 col
+        p->kind = PK_FILTER_SUMPROD;
+        int32_t a_col = -1, b_col = -1;
+        for (size_t i = 0; i < reqs.size(); i++) {
+            ph_scan_plan::AggMap m{reqs[i].kind, 1, 0};
+            if (!reqs[i].star) {
+                const Prod &pr = reqs[i].p;
+                if (pr.f.size() != 2 || !pure(pr.f[0]) || !pure(pr.f[1]) || !is_i64(pr.f[0].col) || !is_i64(pr.f[1].col)) {
+                    set_error("aggregate %zu is not SUM(col*col) over 64-bit columns", i);
+                    return fail(PH_EUNSUPPORTED);
+                }
+                if (a_col >= 0 && !(a_col == pr.f[0].col && b_col == pr.f[1].col)) return fail(PH_EUNSUPPORTED);
+                a_col = pr.f[0].col;
+                b_col = pr.f[1].col;
+                m.acc = 0;
+                m.scale = pr.scale;
+            }
+            p->aggs.push_back(m);
+        }
+        if (a_col < 0) { set_error("filter_sumprod needs one SUM(col*col)"); return fail(PH_EUNSUPPORTED); }
+        std::vector<Range> r32, r64;
+        for (auto &r : ranges) (is_i32(r.col) ? r32 : r64).push_back(r);
+        for (auto &r : ranges) if (!is_i32(r.col) && !is_i64(r.col)) return fail(PH_EUNSUPPORTED);
+        if (r32.empty() || r32.size() > 2 || r64.size() > 1) { set_error("filter_sumprod: predicate columns do not fit (need 1-2 int32, 0-1 int64)"); return fail(PH_EUNSUPPORTED); }
+        if (!r64.empty()) {
+            // the 64-bit predicate column must be one of the factors; make it `b`
+            if (r64[0].col == a_col) std::swap(a_col, b_col);
+            if (r64[0].col != b_col) return fail(PH_EUNSUPPORTED);
+            p->fs.b_lo = r64[0].lo;
+            p->fs.b_hi = r64[0].hi;
+        } else {
+            p->fs.b_lo = INT64_MIN;
+            p->fs.b_hi = INT64_MAX;
+        }
+        auto clamp32 = [](int64_t v) { return (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)); };
+        p->fs.p0 = (const int32_t *)col(r32[0].col).data;
+        p->fs.p0_lo = clamp32(r32[0].lo);
+        p->fs.p0_hi = clamp32(r32[0].hi);
+        const Range &second = r32.size() > 1 ? r32[1] : r32[0];
+        p->fs.p2 = (const int32_t *)col(second.col).data;
+        p->fs.p2_lo = clamp32(second.lo);
+        p->fs.p2_hi = clamp32(second.hi);
+        p->fs.a = (const int64_t *)col(a_col).data;
+        p->fs.b = (const int64_t *)col(b_col).data;
+        if (!col(a_col).has_range || !col(b_col).has_range) return fail(PH_EUNSUPPORTED);
+        Affine one; one.B = 1;
+        p->row_bound = affine_bound(one, col(a_col).min, col(a_col).max) * affine_bound(one, col(b_col).min, col(b_col).max);
+        p->nacc = 2;
+        p->max_grid = ph::CU_COUNT * 8;
+    } else {
+        // ---------------- lowcard_chain: two dictionary-code group columns, one int32 range predicate
+        p->kind = PK_LOWCARD_CHAIN;
+        if (ngroup_cols != 2 || col(group_cols[0]).type != PH_CODE8 || col(group_cols[1]).type != PH_CODE8 ||
+            col(group_cols[0]).validity || col(group_cols[1]).validity) {
+            set_error("lowcard_chain needs two non-NULL dictionary-code group columns");
+            return fail(PH_EUNSUPPORTED);
+        }
+        int n0 = (int)col(group_cols[0]).dict.size(), n1 = (int)col(group_cols[1]).dict.size();
+        if (n0 == 0) n0 = (int)col(group_cols[0]).max + 1;
+        if (n1 == 0) n1 = (int)col(group_cols[1]).max + 1;
+        if (n0 * n1 > ph::LC_MAX_SLOTS || n0 * n1 <= 0) { set_error("lowcard_chain: %d group slots exceed %d", n0 * n1, ph::LC_MAX_SLOTS); return fail(PH_EUNSUPPORTED); }
+        p->nkeys = 2;
+        p->group_cols[0] = group_cols[0];
+        p->group_cols[1] = group_cols[1];
+        if (ranges.size() != 1 || !is_i32(ranges[0].col)) { set_error("lowcard_chain needs exactly one int32/date range predicate"); return fail(PH_EUNSUPPORTED); }
+        // roles: q (int32 sum), e, d, t with f1 = A1+B1*d, f2 = A2+B2*t
+        int32_t q = -1, e = -1, d = -1, tt = -1;
+        Affine f1, f2;
+        bool have_f1 = false, have_f2 = false;
+        // longest chain first
+        std::vector<size_t> order(reqs.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return reqs[x].p.f.size() > reqs[y].p.f.size(); });
+        p->aggs.resize(reqs.size());
+        int32_t singles64[2] = {-1, -1};
+        for (size_t oi : order) {
+            const Req &r = reqs[oi];
+            ph_scan_plan::AggMap m{r.kind, 5, 0};
+            if (!r.star) {
+                const Prod &pr = r.p;
+                m.scale = pr.scale;
+                if (pr.f.size() == 3) {
+                    if (!pure(pr.f[0]) || !is_i64(pr.f[0].col) || !is_i64(pr.f[1].col) || !is_i64(pr.f[2].col)) return fail(PH_EUNSUPPORTED);
+                    if (have_f2 && !(e == pr.f[0].col && f1 == pr.f[1] && f2 == pr.f[2])) return fail(PH_EUNSUPPORTED);
+                    e = pr.f[0].col; f1 = pr.f[1]; f2 = pr.f[2]; have_f1 = have_f2 = true;
+                    d = f1.col; tt = f2.col;
+                    m.acc = 3;
+                } else if (pr.f.size() == 2) {
+                    if (!pure(pr.f[0]) || !is_i64(pr.f[0].col) || !is_i64(pr.f[1].col)) return fail(PH_EUNSUPPORTED);
+                    if (have_f1 && !(e == pr.f[0].col && f1 == pr.f[1])) return fail(PH_EUNSUPPORTED);
+                    e = pr.f[0].col; f1 = pr.f[1]; have_f1 = true; d = f1.col;
+                    m.acc = 2;
+                } else if (pr.f.size() == 1 && pure(pr.f[0])) {
+                    int32_t c = pr.f[0].col;
+                    if (is_i32(c)) { if (q >= 0 && q != c) return fail(PH_EUNSUPPORTED); q = c; m.acc = 0; }
+                    else if (is_i64(c)) {
+                        if (c == e || (e < 0 && singles64[0] < 0)) { if (e < 0) { e = c; } m.acc = 1; singles64[0] = c; }
+                        else if (c == d || d < 0) { d = c; m.acc = 4; singles64[1] = c; }
+                        else return fail(PH_EUNSUPPORTED);
+                    } else return fail(PH_EUNSUPPORTED);
+                } else return fail(PH_EUNSUPPORTED);
+            }
+            p->aggs[oi] = m;
+        }
+        if (e < 0) { set_error("lowcard_chain needs at least one 64-bit summed column"); return fail(PH_EUNSUPPORTED); }
+        if (d < 0) d = e;
+        if (tt < 0) tt = e;
+        if (q < 0) q = ranges[0].col;
+        if (!have_f1) { f1 = Affine(); f1.A = 1; f1.col = d; }
+        if (!have_f2) { f2 = Affine(); f2.A = 1; f2.col = tt; }
+        // an accumulator 4 request must be over the SAME column as f1's (both called d)
+        for (auto &m : p->aggs) (void)m;
+        p->lc.p = (const int32_t *)col(ranges[0].col).data;
+        auto clamp32 = [](int64_t v) { return (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)); };
+        p->lc.p_lo = clamp32(ranges[0].lo);
+        p->lc.p_hi = clamp32(ranges[0].hi);
+        p->lc.q = (const int32_t *)col(q).data;
+        p->lc.e = (const int64_t *)col(e).data;
+        p->lc.d = (const int64_t *)col(d).data;
+        p->lc.t = (const int64_t *)col(tt).data;
+        p->lc.k0 = (const uint8_t *)col(group_cols[0]).data;
+        p->lc.k1 = (const uint8_t *)col(group_cols[1]).data;
+        p->lc.nk1 = n1;
+        p->lc.nslots = n0 * n1;
+        p->lc.A1 = f1.A; p->lc.B1 = f1.B; p->lc.A2 = f2.A; p->lc.B2 = f2.B;
+        for (int32_t c : {q, e, d, tt}) if (!col(c).has_range) return fail(PH_EUNSUPPORTED);
+        Affine one; one.B = 1;
+        long double be = affine_bound(one, col(e).min, col(e).max);
+        long double b1 = affine_bound(f1, col(d).min, col(d).max);
+        long double b2 = affine_bound(f2, col(tt).min, col(tt).max);
+        p->row_bound = std::max({be * b1 * b2, be * b1, be, affine_bound(one, col(d).min, col(d).max),
+                                 affine_bound(one, col(q).min, col(q).max)});
+        p->nacc = p->lc.nslots * (ph::LC_NACC + 1);  // + first_row
+        // 2 workgroups per CU fit the per-thread-private LDS accumulators (see kernel header)
+        p->max_grid = ph::CU_COUNT * 2;
+    }
+    int rc = plan_alloc(p);
+    if (rc != PH_OK) return fail(rc);
+    *out = p;
+    return PH_OK;
+}
+
+extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_end) {
+    PH_REQUIRE(p != nullptr, "ph_scan_plan_run: plan is NULL");
+    PH_REQUIRE(row_begin >= 0 && row_end >= row_begin && row_end <= p->t->nrows && row_begin % 4 == 0,
+               "ph_scan_plan_run: rows [%lld,%lld) invalid (begin must be a multiple of 4, table has %lld rows)",
+               (long long)row_begin, (long long)row_end, (long long)p->t->nrows);
+    int64_t rows = p->never ? 0 : row_end - row_begin;
+    int64_t tiles = (rows + 1023) / 1024;
+    int grid = (int)std::min<int64_t>(p->max_grid, std::max<int64_t>(tiles, 1));
+    // overflow proof: a workgroup's int64 partial sums at most rows_per_block values of
+    // magnitude <= row_bound
+    long double rows_per_block = (long double)((tiles + grid - 1) / grid) * 1024.0L;
+    if (p->row_bound * rows_per_block >= 4.0e18L) {
+        set_error("decimal overflow proof failed: per-row bound %.3Lg x %.0Lf rows per workgroup", p->row_bound, rows_per_block);
+        return PH_EOVERFLOW;
+    }
+    p->last_rows = rows;
+    p->last_grid = grid;
+    if (p->kind == PK_FILTER_SUMPROD) {
+        ph::FilterSumProdParams P = p->fs;
+        P.row_begin = row_begin;
+        P.row_end = row_begin + rows;
+        P.partials = p->partials;
+        PH_CHECK(ph::launch_filter_sumprod(p->ctx, P, grid));
+        PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, 2, 0, p->out_lo, p->out_hi));
+    } else {
+        ph::LowcardChainParams P = p->lc;
+        P.row_begin = row_begin;
+        P.row_end = row_begin + rows;
+        P.partials = p->partials;
+        PH_CHECK(ph::launch_lowcard_chain(p->ctx, P, grid));
+        PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, p->nacc, ph::LC_NACC + 1, p->out_lo, p->out_hi));
+    }
+    return PH_OK;
+}
+
+extern "C" void ph_agg_result_free(ph_agg_result *r) {
+    if (!r) return;
+    free(r->first_row); free(r->keys); free(r->sum_lo); free(r->sum_hi); free(r->count); free(r->scale);
+    free(r);
+}
+
+extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
+    PH_REQUIRE(p && out, "ph_scan_plan_fetch: bad arguments");
+    std::vector<unsigned long long> lo((size_t)p->nacc);
+    std::vector<long long> hi((size_t)p->nacc);
+    PH_HIP(hipMemcpyAsync(lo.data(), p->out_lo, lo.size() * 8, hipMemcpyDeviceToHost, p->ctx->stream));
+    PH_HIP(hipMemcpyAsync(hi.data(), p->out_hi, hi.size() * 8, hipMemcpyDeviceToHost, p->ctx->stream));
+    PH_HIP(hipStreamSynchronize(p->ctx->stream));
+    int naggs = (int)p->aggs.size();
+    struct G { int64_t first; int slot; };
+    std::vector<G> groups;
+    int stride = 0;
+    if (p->kind == PK_FILTER_SUMPROD) {
+        if (lo[1] > 0) groups.push_back({0, 0});
+        stride = 2;
+    } else {
+        stride = ph::LC_NACC + 1;
+        for (int s = 0; s < p->lc.nslots; s++)
+            if (lo[(size_t)s * stride + 5] > 0) groups.push_back({(int64_t)lo[(size_t)s * stride + ph::LC_NACC], s});
+        std::sort(groups.begin(), groups.end(), [](const G &a, const G &b) { return a.first < b.first; });
+    }
+    ph_agg_result *r = (ph_agg_result *)calloc(1, sizeof *r);
+    size_t ng = groups.size(), nk = (size_t)p->nkeys;
+    r->ngroups = (int64_t)ng;
+    r->nkeys = p->nkeys;
+    r->naggs = naggs;
+    r->first_row = (int64_t *)calloc(ng ? ng : 1, 8);
+    r->keys = (int64_t *)calloc((ng ? ng : 1) * (nk ? nk : 1), 8);
+    r->sum_lo = (uint64_t *)calloc((ng ? ng : 1) * naggs, 8);
+    r->sum_hi = (int64_t *)calloc((ng ? ng : 1) * naggs, 8);
+    r->count = (uint64_t *)calloc((ng ? ng : 1) * naggs, 8);
+    r->scale = (int32_t *)calloc((size_t)naggs, 4);
+    for (int a = 0; a < naggs; a++) r->scale[a] = p->aggs[(size_t)a].scale;
+    for (size_t g = 0; g < ng; g++) {
+        int s = groups[g].slot;
+        r->first_row[g] = groups[g].first;
+        if (p->kind == PK_LOWCARD_CHAIN) {
+            r->keys[g * 2 + 0] = s / p->lc.nk1;
+            r->keys[g * 2 + 1] = s % p->lc.nk1;
+        }
+        int cnt_idx = p->kind == PK_FILTER_SUMPROD ? 1 : 5;
+        uint64_t cnt = lo[(size_t)s * stride + cnt_idx];
+        for (int a = 0; a < naggs; a++) {
+            const auto &m = p->aggs[(size_t)a];
+            size_t idx = (size_t)s * stride + (size_t)m.acc;
+            r->count[g * naggs + a] = cnt;  // no NULL inputs on this path
+            if (m.kind == PH_A_COUNT_STAR || m.kind == PH_A_COUNT) continue;
+            r->sum_lo[g * naggs + a] = lo[idx];
+            r->sum_hi[g * naggs + a] = hi[idx];
+        }
+    }
+    *out = r;
+    return PH_OK;
+}
+
+extern "C" int ph_scan_filter_agg(ph_ctx *ctx, const ph_table *t, int64_t row_begin, int64_t row_end,
+                                  const ph_pred *preds, int32_t npreds, const int32_t *group_cols,
+                                  int32_t ngroup_cols, const ph_aggexpr *aggs, int32_t naggs,
+                                  ph_agg_result **out) {
+    ph_scan_plan *p = nullptr;
+    PH_CHECK(ph_scan_plan_create(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, &p));
+    int rc = ph_scan_plan_run(p, row_begin, row_end);
+    if (rc == PH_OK) rc = ph_scan_plan_fetch(p, out);
+    ph_scan_plan_free(p);
+    return rc;
+}

@@ -1,0 +1,264 @@
+"""ctypes binding of libplanhip.so (include/planhip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PH_OK, PH_EINVAL, PH_EHIP, PH_EUNSUPPORTED, PH_EOVERFLOW, PH_ECAPACITY = 0, -1, -2, -3, -4, -5
+PH_I32, PH_I64, PH_DATE, PH_DEC64, PH_CODE8, PH_F32, PH_F64, PH_STR = range(1, 9)
+PH_EQ, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE = range(1, 9)
+PH_X_COL, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL = range(1, 6)
+PH_A_SUM, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR = range(1, 7)
+
+i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+
+NP_TYPES = {PH_I32: np.int32, PH_I64: np.int64, PH_DATE: np.int32, PH_DEC64: np.int64,
+            PH_CODE8: np.uint8, PH_F32: np.float32, PH_F64: np.float64}
+
+
+class PlanHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"planhip error {code}: {msg}")
+        self.code = code
+
+
+class Col(ctypes.Structure):
+    _fields_ = [("type", i32), ("scale", i32), ("data", vp), ("validity", vp), ("aux", vp),
+                ("aux_bytes", i64)]
+
+
+class Const(ctypes.Structure):
+    _fields_ = [("type", i32), ("scale", i32), ("i", i64), ("f", ctypes.c_double),
+                ("s", ctypes.c_char_p)]
+
+
+class Pred(ctypes.Structure):
+    _fields_ = [("col", i32), ("op", i32), ("k", Const)]
+
+
+class Rpn(ctypes.Structure):
+    _fields_ = [("op", i32), ("col", i32), ("ival", i64), ("scale", i32)]
+
+
+class AggExpr(ctypes.Structure):
+    _fields_ = [("kind", i32), ("nprog", i32), ("prog", Rpn * 12)]
+
+
+class AggSpec(ctypes.Structure):
+    _fields_ = [("kind", i32), ("arg", i32)]
+
+
+class AggResult(ctypes.Structure):
+    _fields_ = [("ngroups", i64), ("first_row", ctypes.POINTER(i64)), ("keys", ctypes.POINTER(i64)),
+                ("sum_lo", ctypes.POINTER(ctypes.c_uint64)), ("sum_hi", ctypes.POINTER(i64)),
+                ("count", ctypes.POINTER(ctypes.c_uint64)), ("scale", ctypes.POINTER(i32)),
+                ("nkeys", i32), ("naggs", i32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libplanhip.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing — the HIP extension is required (no CPU fallback). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        L = ctypes.CDLL(path)
+        for name, rt in (("ph_last_error", ctypes.c_char_p), ("ph_version", ctypes.c_char_p),
+                         ("ph_scan_plan_kind", ctypes.c_char_p), ("ph_table_rows", i64),
+                         ("ph_hash_bytes", ctypes.c_uint64), ("ph_join_count", i64)):
+            getattr(L, name).restype = rt  # a missing symbol raises: the ABI must be complete
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != PH_OK:
+        raise PlanHipError(rc, lib().ph_last_error().decode())
+
+
+def const(typ, i=0, f=0.0, s=None, scale=0):
+    k = Const()
+    k.type, k.scale, k.i, k.f = typ, scale, int(i), float(f)
+    k.s = None if s is None else s.encode()
+    return k
+
+
+def pred(col, op, k):
+    p = Pred()
+    p.col, p.op, p.k = col, op, k
+    return p
+
+
+def aggexpr(kind, prog=()):
+    a = AggExpr()
+    a.kind = kind
+    a.nprog = len(prog)
+    for j, (op, col, ival, scale) in enumerate(prog):
+        a.prog[j] = Rpn(op, col, ival, scale)
+    return a
+
+
+def X_COL(c):
+    return (PH_X_COL, c, 0, 0)
+
+
+def X_CONST(v, scale=0):
+    return (PH_X_CONST, -1, v, scale)
+
+
+X_ADD = (PH_X_ADD, -1, 0, 0)
+X_SUB = (PH_X_SUB, -1, 0, 0)
+X_MUL = (PH_X_MUL, -1, 0, 0)
+
+
+class Ctx:
+    """One HIP device + one stream (ph_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = vp()
+        check(lib().ph_ctx_create(i32(device), ctypes.byref(self.h)))
+        self.device = device
+        if stream is not None:
+            check(lib().ph_ctx_set_stream(self.h, vp(stream)))
+
+    def sync(self):
+        check(lib().ph_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().ph_ctx_destroy(self.h)
+            self.h = None
+
+    # -- plain device buffers
+    def alloc(self, nbytes):
+        p = vp()
+        check(lib().ph_dev_alloc(self.h, i64(nbytes), ctypes.byref(p)))
+        return p
+
+    def free(self, p):
+        check(lib().ph_dev_free(self.h, p))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        check(lib().ph_dev_upload(self.h, p, vp(arr.ctypes.data), i64(arr.nbytes)))
+        return p
+
+    def download(self, p, dtype, n):
+        out = np.empty(n, dtype=dtype)
+        check(lib().ph_dev_download(self.h, vp(out.ctypes.data), p, i64(out.nbytes)))
+        return out
+
+
+def host_col(typ, arr, scale=0, validity=None, dictionary=None, aux=None):
+    """ph_col over host numpy memory (for ph_table_create). Returns (Col, keepalive)."""
+    c = Col()
+    c.type, c.scale = typ, scale
+    arr = np.ascontiguousarray(arr)
+    c.data = arr.ctypes.data
+    keep = [arr]
+    if validity is not None:
+        validity = np.ascontiguousarray(validity, dtype=np.uint8)
+        c.validity = validity.ctypes.data
+        keep.append(validity)
+    if dictionary is not None:
+        blob = b"".join(s.encode() + b"\0" for s in dictionary)
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        c.aux = ctypes.cast(buf, vp)
+        c.aux_bytes = len(blob)
+        keep.append(buf)
+    if aux is not None:
+        aux = np.ascontiguousarray(aux)
+        c.aux = aux.ctypes.data
+        c.aux_bytes = aux.nbytes
+        keep.append(aux)
+    return c, keep
+
+
+class Table:
+    """Device-resident table (ph_table). cols: list of (type, array, scale, dictionary|None)."""
+
+    def __init__(self, ctx, cols, nrows):
+        self.ctx = ctx
+        arr = (Col * len(cols))()
+        keep = []
+        for j, spec in enumerate(cols):
+            c, k = host_col(*spec) if not isinstance(spec, dict) else host_col(**spec)
+            arr[j] = c
+            keep.append(k)
+        self.h = vp()
+        check(lib().ph_table_create(ctx.h, i32(len(cols)), arr, i64(nrows), ctypes.byref(self.h)))
+        self.nrows = nrows
+        self.ncols = len(cols)
+
+    def col(self, c):
+        out = Col()
+        check(lib().ph_table_col(self.h, i32(c), ctypes.byref(out)))
+        return out
+
+    def col_range(self, c):
+        mn, mx = i64(), i64()
+        check(lib().ph_table_col_range(self.h, i32(c), ctypes.byref(mn), ctypes.byref(mx)))
+        return mn.value, mx.value
+
+    def free(self):
+        if self.h:
+            lib().ph_table_free(self.h)
+            self.h = None
+
+
+def _result(rp):
+    r = rp.contents
+    ng, nk, na = r.ngroups, r.nkeys, r.naggs
+    out = {
+        "ngroups": ng,
+        "first_row": np.array([r.first_row[g] for g in range(ng)], dtype=np.int64),
+        "keys": np.array([r.keys[i] for i in range(ng * nk)], dtype=np.int64).reshape(ng, nk),
+        "scale": [r.scale[a] for a in range(na)],
+        # python ints: exact 128-bit sums
+        "sum": [[(int(r.sum_hi[g * na + a]) << 64) + int(r.sum_lo[g * na + a]) for a in range(na)]
+                for g in range(ng)],
+        "count": [[int(r.count[g * na + a]) for a in range(na)] for g in range(ng)],
+    }
+    lib().ph_agg_result_free(rp)
+    return out
+
+
+class ScanPlan:
+    """Fused Agg <- Scan(filter) over a resident table (ph_scan_plan)."""
+
+    def __init__(self, ctx, table, preds, group_cols, aggs):
+        self.ctx, self.table = ctx, table
+        pa = (Pred * max(len(preds), 1))(*preds)
+        ga = (i32 * max(len(group_cols), 1))(*group_cols)
+        aa = (AggExpr * len(aggs))(*aggs)
+        self.h = vp()
+        check(lib().ph_scan_plan_create(ctx.h, table.h, pa, i32(len(preds)), ga,
+                                        i32(len(group_cols)), aa, i32(len(aggs)),
+                                        ctypes.byref(self.h)))
+        self._keep = (pa, ga, aa)
+
+    @property
+    def kind(self):
+        return lib().ph_scan_plan_kind(self.h).decode()
+
+    def run(self, row_begin=0, row_end=None):
+        if row_end is None:
+            row_end = self.table.nrows
+        check(lib().ph_scan_plan_run(self.h, i64(row_begin), i64(row_end)))
+
+    def fetch(self):
+        rp = ctypes.POINTER(AggResult)()
+        check(lib().ph_scan_plan_fetch(self.h, ctypes.byref(rp)))
+        return _result(rp)
+
+    def free(self):
+        if self.h:
+            lib().ph_scan_plan_free(self.h)
+            self.h = None

@@ -1,0 +1,145 @@
+"""GPU parity of the fused Agg <- Scan(filter) path (Q1 / Q6 shapes) against the oracle.
+Everything goes through the C-ABI (plan_amd.hip is a thin ctypes binding of include/planhip.h)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plan_amd import hip, queries, tpchgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+def oracle_q1_ints(L, cutoff):
+    rows = O.q1(L, cutoff)
+    out = []
+    for r in rows:
+        out.append(dict(key=(r.returnflag, r.linestatus), sum_qty=r.sum_qty.value(),
+                        sum_base=r.sum_base_price.unscaled(2), sum_disc=r.sum_disc_price.unscaled(4),
+                        sum_charge=r.sum_charge.unscaled(6), avg_qty=r.avg_qty,
+                        count=r.count_order))
+    return out
+
+
+def check_q1(ctx, L, cutoff, row_begin=0, row_end=None):
+    t = queries.lineitem_table(ctx, L)
+    p = queries.q1_plan(ctx, t, cutoff)
+    assert p.kind == "lowcard_chain"
+    p.run(row_begin, row_end)
+    r = p.fetch()
+    p.free()
+    t.free()
+    sl = slice(row_begin, row_end)
+    want = oracle_q1_ints({k: v[sl] for k, v in L.items()}, cutoff)
+    assert r["ngroups"] == len(want)
+    assert r["scale"][:4] == [0, 2, 4, 6]
+    for g, w in enumerate(want):  # same (first-seen) order, bit-exact integers
+        assert tuple(r["keys"][g]) == w["key"]
+        s, c = r["sum"][g], r["count"][g]
+        assert s[0] == w["sum_qty"] and s[1] == w["sum_base"]
+        assert s[2] == w["sum_disc"] and s[3] == w["sum_charge"]
+        assert c[7] == w["count"]
+        # avg(INTEGER) is float64 sum / float64 count in the reference; tolerance 1e-9 relative
+        assert abs(s[4] / c[4] - w["avg_qty"]) <= 1e-9 * abs(w["avg_qty"])
+    return r
+
+
+def test_q1_sf001(ctx, sf001):
+    check_q1(ctx, sf001["lineitem"], queries.q1_shipdate_cutoff())
+
+
+def test_q1_sf1(ctx, sf1):
+    r = check_q1(ctx, sf1["lineitem"], queries.q1_shipdate_cutoff())
+    assert sum(c[7] for c in r["count"]) == 5870362  # golden Σcount_order
+
+
+def test_q1_ragged_ranges(ctx, sf001):
+    L = sf001["lineitem"]
+    n = len(L["l_shipdate"])
+    for b, e in [(0, 1), (0, 3), (4, 1027), (1024, 1024), (0, n - 1), (60000, n), (8, 2049)]:
+        check_q1(ctx, L, queries.q1_shipdate_cutoff(), b, e)
+
+
+def test_q1_filter_extremes(ctx, sf001):
+    L = sf001["lineitem"]
+    check_q1(ctx, L, tpchgen.days(1990, 1, 1))   # selects nothing -> no groups
+    check_q1(ctx, L, tpchgen.days(2000, 1, 1))   # selects everything
+
+
+def oracle_q6(L, consts):
+    rc, d = O.q6(L, *consts)
+    return None if rc == 1 else d.unscaled(4)
+
+
+def check_q6(ctx, L, consts, row_begin=0, row_end=None):
+    t = queries.lineitem_table(ctx, L)
+    p = queries.q6_plan(ctx, t, consts)
+    assert p.kind == "filter_sumprod"
+    p.run(row_begin, row_end)
+    r = p.fetch()
+    p.free()
+    t.free()
+    sl = slice(row_begin, row_end)
+    want = oracle_q6({k: v[sl] for k, v in L.items()}, consts)
+    if want is None:
+        assert r["ngroups"] == 0
+    else:
+        assert r["ngroups"] == 1 and r["scale"] == [4]
+        assert r["sum"][0][0] == want
+    return r
+
+
+def test_q6_sf001(ctx, sf001):
+    check_q6(ctx, sf001["lineitem"], queries.q6_constants())
+
+
+def test_q6_sf1_matches_golden(ctx, sf1):
+    r = check_q6(ctx, sf1["lineitem"], queries.q6_constants())
+    assert r["sum"][0][0] == 616600517967  # cases/tpch/1g/plan/q6.txt: 61660051.7967
+
+
+def test_q6_ragged_and_empty(ctx, sf001):
+    L = sf001["lineitem"]
+    n = len(L["l_shipdate"])
+    c = queries.q6_constants()
+    for b, e in [(0, 0), (0, 5), (4, 1030), (0, n - 3), (59996, n)]:
+        check_q6(ctx, L, c, b, e)
+    # a year with no shipments -> the aggregate has no group
+    check_q6(ctx, L, (tpchgen.days(2001, 1, 1), tpchgen.days(2002, 1, 1)) + c[2:])
+
+
+def test_q6_float32_boundary_semantics(ctx):
+    """discount values straddling the float32 constants: 0.02 passes `>= float32(0.03)-float32(0.01)`,
+    0.04 passes `<= float32(0.03)+float32(0.01)`; checked row by row vs the oracle."""
+    n = 4096
+    rng = np.random.default_rng(7)
+    L = dict(l_quantity=rng.integers(1, 51, n).astype(np.int32),
+             l_extendedprice=rng.integers(90000, 10500000, n).astype(np.int64),
+             l_discount=rng.integers(-3, 12, n).astype(np.int64),
+             l_tax=rng.integers(0, 9, n).astype(np.int64),
+             l_returnflag=rng.integers(0, 3, n).astype(np.uint8),
+             l_linestatus=rng.integers(0, 2, n).astype(np.uint8),
+             l_shipdate=np.full(n, tpchgen.days(1994, 6, 1), dtype=np.int32))
+    check_q6(ctx, L, queries.q6_constants())
+
+
+def test_overflow_is_refused(ctx):
+    n = 2048
+    big = np.full(n, 3_000_000_000_000_000, dtype=np.int64)
+    L = dict(l_quantity=np.ones(n, np.int32), l_extendedprice=big, l_discount=big.copy(),
+             l_tax=np.zeros(n, np.int64), l_returnflag=np.zeros(n, np.uint8),
+             l_linestatus=np.zeros(n, np.uint8),
+             l_shipdate=np.full(n, tpchgen.days(1994, 6, 1), dtype=np.int32))
+    t = queries.lineitem_table(ctx, L)
+    p = queries.q6_plan(ctx, t, (0, 20000, -1e30, 1e30, 100))
+    with pytest.raises(hip.PlanHipError) as e:
+        p.run()
+    assert e.value.code == hip.PH_EOVERFLOW
+    p.free()
+    t.free()
