@@ -26,6 +26,23 @@ Q6_BYTES_PER_ROW = 24
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(args, world, nrows):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command; KiB units, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM). Only valid for
+    the exact workload those passes ran (SF10, 1 GPU); null otherwise."""
+    if world != 1 or args.sf != 10 or nrows != 59986052:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        kern = "lowcard_chain_kernel" if args.query == "q1" else "filter_sumprod_kernel"
+        fetch = [e["avg"] for e in d[f"{args.query} FETCH_SIZE"] if kern in e["kernel"]][0]
+        write = [e["avg"] for e in d.get(f"{args.query} WRITE_SIZE", []) if kern in e["kernel"]]
+        return fetch * 1024 * 2 + (write[0] * 1024 if write else 0)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +202,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, world, nrows),
                 "kernel": "lowcard_chain_kernel" if args.query == "q1" else "filter_sumprod_kernel",
                 "avg_launch_ms": avg_ms,
                 "min_launch_ms": durs[0],
