@@ -145,11 +145,14 @@ typedef struct {
 
 /* result scale of a program (host side, no device work); PH_EUNSUPPORTED if malformed */
 int ph_expr_scale(const ph_col *cols, const ph_rpn *prog, int32_t nprog, int32_t *scale);
-/* out_dev[i] = value of row sel[i] (or i). Fails with PH_EOVERFLOW when column ranges cannot
- * prove the int64 domain is never left (ranges: min/max per column, may be NULL = full int64). */
-int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const int64_t *col_min,
-                 const int64_t *col_max, const ph_rpn *prog, int32_t nprog, const int32_t *sel,
-                 int64_t n, int64_t *out_dev);
+/* out_dev[i] = value of row sel[i] (or i), unscaled at ph_expr_scale's scale. Every add/sub/mul
+ * is overflow-checked on the device; if any row leaves the int64 domain the call returns
+ * PH_EOVERFLOW (the reference's govalues arithmetic would start rounding there, so the caller
+ * must fall back). NULL inputs give a NULL result: out_validity_dev (bitmap, may be NULL when no
+ * input column has validity) receives the result validity. */
+int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *prog,
+                 int32_t nprog, const int32_t *sel, int64_t n, int64_t *out_dev,
+                 uint8_t *out_validity_dev);
 
 /* ------------------------------------------------------------------ hash aggregate
  * GroupedAggrHashTable.AddChunk/FindOrCreateGroups + UpdateStates + FinalizeStates
@@ -166,15 +169,18 @@ typedef struct {
 
 typedef struct ph_agg ph_agg;
 
-/* key_types: PH_I32/PH_I64/PH_DATE/PH_DEC64/PH_CODE8 per key column (<= 4 keys, packed width
- * <= 128 bits). expected_groups sizes the table (it grows when needed). */
+/* key_types: PH_I32/PH_I64/PH_DATE/PH_DEC64/PH_CODE8 per key column (<= 4 keys).
+ * expected_groups sizes the table initially; it is doubled when `capacity - groups <= incoming
+ * rows`, the reference's own Resize rule (aggregate_hash.go:214-217). */
 int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_types, int32_t naggs,
                   const ph_aggspec *aggs, int64_t expected_groups, ph_agg **out);
 /* keys/args: device columns addressed by row id; rows = sel[0..n) or 0..n. args are PH_I32 /
  * PH_I64 / PH_DEC64 columns (validity honoured: NULL inputs are skipped, NULL keys group together).
- * row_base is added to row ids when recording first-seen order across several sinks. */
+ * `positional` != 0: args are addressed by position i instead of row id sel[i] (expression
+ * results from ph_expr_eval). row_base is added to the position when recording first-seen
+ * order across several sinks. */
 int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
-                const int32_t *sel, int64_t n, int64_t row_base);
+                const int32_t *sel, int64_t n, int32_t positional, int64_t row_base);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
 /* Host outputs, groups in first-seen order:
  *   first_row[g]; keys[g*nkeys+c] (int64-widened), key_null[g*nkeys+c];

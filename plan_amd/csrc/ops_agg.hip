@@ -1,0 +1,425 @@
+// General hash aggregate: ph_agg_create / sink / finalize.
+//
+// Replaces GroupedAggrHashTable.AddChunk -> FindOrCreateGroups -> UpdateStates and FinalizeStates
+// (reference pkg/compute/aggregate_hash.go:136-391, aggregate_exec.go:456-475,
+// function_aggr.go:420-1365) for arbitrary group cardinality (Q3: ~114k groups at SF10, Q9: 175).
+//
+// Device layout (all in HBM, sized for 288 GB rather than for cache):
+//   slots[cap]           int32 group id, EMPTY/LOCKED sentinels; open addressing, linear probing,
+//                        cap a power of two — the reference's scheme minus the 16-bit salt (the
+//                        full key compare that the salt avoids is one 8-byte load per key here)
+//   gkeys[g][nkeys]      raw 64-bit key words, gnull[g] NULL bits (NULL keys form their own group,
+//                        as Match's NULL = NULL rule for group columns does, util_match.go:25-301)
+//   sum_lo/sum_hi[g][a]  128-bit two's-complement sums (Hugeint for INTEGER input, exact unscaled
+//                        DECIMAL sums), cnt[g][a] non-NULL inputs, first_row[g] for first-seen order
+// Inter-workgroup protocol: every access to slots/gkeys goes through agent-scope atomics (the L1 of
+// a CU is never refreshed by other CUs' stores and the per-XCD L2s are not coherent for plain
+// accesses); a creator stores the key words, fences, then publishes the group id.
+// State updates are fire-and-forget HBM atomics; the 128-bit add is a returning add on the low
+// word plus a carry/sign add on the high word, which commutes, so any interleaving gives the exact sum.
+#include <algorithm>
+
+#include "common.h"
+#include "device_util.h"
+#include "ops.h"
+
+namespace ph {
+
+constexpr int AGG_MAX_KEYS = 4;
+constexpr int AGG_MAX_AGGS = 16;
+constexpr int SLOT_EMPTY = -1;
+constexpr int SLOT_LOCKED = -2;
+
+struct AggCol {
+    int type;
+    const void *data;
+    const uint8_t *validity;
+};
+
+struct AggSinkParams {
+    int nkeys, naggs, nargs;
+    AggCol key[AGG_MAX_KEYS];
+    AggCol arg[AGG_MAX_AGGS];
+    int agg_kind[AGG_MAX_AGGS];
+    int agg_arg[AGG_MAX_AGGS];
+    const int32_t *sel;
+    int64_t n;
+    int positional;
+    int64_t row_base;
+    int32_t *slots;
+    uint64_t mask;
+    unsigned long long *gkeys;
+    unsigned *gnull;
+    unsigned long long *sum_lo;
+    long long *sum_hi;
+    unsigned long long *cnt;
+    long long *first_row;
+    int *ngroups;
+    int64_t gcap;
+    int *error_flag;
+};
+
+__device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
+    switch (c.type) {
+    case PH_I32: case PH_DATE: return (unsigned long long)(long long)((const int32_t *)c.data)[r];
+    case PH_CODE8: return ((const uint8_t *)c.data)[r];
+    default: return (unsigned long long)((const int64_t *)c.data)[r];
+    }
+}
+
+__device__ __forceinline__ uint64_t keys_hash(const unsigned long long *k, unsigned nullmask, int nkeys) {
+    uint64_t h = mix64((uint64_t)nullmask + 0x9e3779b97f4a7c15ULL);
+    for (int c = 0; c < nkeys; c++) h = mix64(h ^ k[c]);
+    return h;
+}
+
+__device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, long long v) {
+    unsigned long long old = atomicAdd(lo, (unsigned long long)v);
+    unsigned long long nw = old + (unsigned long long)v;
+    long long delta = (nw < old ? 1 : 0) + (v < 0 ? -1 : 0);
+    if (delta != 0) atomicAdd((unsigned long long *)hi, (unsigned long long)delta);
+}
+
+__global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
+        int64_t r = P.sel ? P.sel[i] : i;
+        unsigned long long k[AGG_MAX_KEYS];
+        unsigned nullmask = 0;
+#pragma unroll
+        for (int c = 0; c < AGG_MAX_KEYS; c++) {
+            k[c] = 0;
+            if (c < P.nkeys) {
+                if (bit_valid(P.key[c].validity, r)) k[c] = load_key(P.key[c], r);
+                else nullmask |= 1u << c;
+            }
+        }
+        uint64_t slot = keys_hash(k, nullmask, P.nkeys) & P.mask;
+        int gid = -1;
+        // find or create (FindOrCreateGroups :272-388). No lane ever waits inside a branch, so
+        // lanes of one wave racing for the same new key cannot deadlock: the winner publishes in
+        // the same iteration it locked the slot; the others see the id on a later iteration.
+        for (int guard = 0; gid < 0; guard++) {
+            int g = __hip_atomic_load(&P.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == SLOT_EMPTY) {
+                int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
+                if (old == SLOT_EMPTY) {
+                    int ng = atomicAdd(P.ngroups, 1);
+                    if (ng >= P.gcap) {  // cannot happen: the host grows before a batch (see sink)
+                        atomicOr(P.error_flag, 1);
+                        ng = 0;
+                    }
+                    for (int c = 0; c < P.nkeys; c++)
+                        __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&P.slots[slot], ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gid = ng;
+                }
+                // lost the race: look at the slot again
+            } else if (g == SLOT_LOCKED) {
+                if (guard > (1 << 22)) { atomicOr(P.error_flag, 2); break; }  // bounded spin
+            } else {
+                bool eq = __hip_atomic_load(&P.gnull[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nullmask;
+                for (int c = 0; eq && c < P.nkeys; c++)
+                    eq = __hip_atomic_load(&P.gkeys[(int64_t)g * P.nkeys + c], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT) == k[c];
+                if (eq) gid = g;
+                else slot = (slot + 1) & P.mask;  // linear probing (:376-384)
+            }
+        }
+        if (gid < 0) continue;
+        atomicMin(&P.first_row[gid], (long long)(P.row_base + i));
+        // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
+        for (int a = 0; a < P.naggs; a++) {
+            int64_t st = (int64_t)gid * P.naggs + a;
+            int kind = P.agg_kind[a];
+            if (kind == PH_A_COUNT_STAR) {
+                atomicAdd(&P.cnt[st], 1ull);
+                continue;
+            }
+            const AggCol &c = P.arg[P.agg_arg[a]];
+            int64_t ar = P.positional ? i : r;
+            if (!bit_valid(c.validity, ar)) continue;
+            long long v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar]
+                                           : ((const int64_t *)c.data)[ar];
+            atomicAdd(&P.cnt[st], 1ull);
+            if (kind == PH_A_SUM || kind == PH_A_AVG) add128(&P.sum_lo[st], &P.sum_hi[st], v);
+            else if (kind == PH_A_MIN) atomicMin((long long *)&P.sum_lo[st], v);
+            else if (kind == PH_A_MAX) atomicMax((long long *)&P.sum_lo[st], v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void agg_init_kernel(unsigned long long *sum_lo, long long *sum_hi,
+                                                       unsigned long long *cnt, long long *first_row,
+                                                       int64_t g_begin, int64_t g_end, int naggs,
+                                                       const int *kinds /* device copy */) {
+    int64_t total = (g_end - g_begin) * naggs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t st = g_begin * naggs + i;
+        int kind = kinds[i % naggs];
+        sum_lo[st] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
+                     : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+        sum_hi[st] = 0;
+        cnt[st] = 0;
+    }
+    for (int64_t g = g_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; g < g_end; g += (int64_t)gridDim.x * 256)
+        first_row[g] = INT64_MAX;
+}
+
+// re-insert groups [0, ng) into a fresh slot table (Resize, aggregate_hash.go:440-513)
+__global__ __launch_bounds__(256) void agg_rehash_kernel(int32_t *slots, uint64_t mask,
+                                                         const unsigned long long *gkeys, const unsigned *gnull,
+                                                         int nkeys, int ng) {
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+        for (int c = 0; c < nkeys; c++) k[c] = gkeys[(int64_t)g * nkeys + c];
+        uint64_t slot = keys_hash(k, gnull[g], nkeys) & mask;
+        while (atomicCAS(&slots[slot], SLOT_EMPTY, g) != SLOT_EMPTY) slot = (slot + 1) & mask;
+    }
+}
+
+}  // namespace ph
+
+struct ph_agg {
+    ph_ctx *ctx = nullptr;
+    int nkeys = 0, naggs = 0;
+    int key_types[ph::AGG_MAX_KEYS] = {0, 0, 0, 0};
+    ph_aggspec aggs[ph::AGG_MAX_AGGS] = {};
+    int64_t cap = 0, gcap = 0;
+    int32_t *slots = nullptr;
+    unsigned long long *gkeys = nullptr;
+    unsigned *gnull = nullptr;
+    unsigned long long *sum_lo = nullptr;
+    long long *sum_hi = nullptr;
+    unsigned long long *cnt = nullptr;
+    long long *first_row = nullptr;
+    int *counters = nullptr;  // [0] ngroups, [1] error flag
+    int *kinds_dev = nullptr;
+    int64_t rows_sunk = 0;
+};
+
+namespace {
+
+constexpr int64_t AGG_BATCH = 1 << 21;
+
+int64_t next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int agg_free_arrays(ph_agg *a) {
+    void *ptrs[] = {a->slots, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, a->first_row};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    a->slots = nullptr; a->gkeys = nullptr; a->gnull = nullptr; a->sum_lo = nullptr;
+    a->sum_hi = nullptr; a->cnt = nullptr; a->first_row = nullptr;
+    return PH_OK;
+}
+
+// (re)allocate for `cap` slots, carrying over `ng` existing groups
+int agg_resize(ph_agg *a, int64_t cap, int ng) {
+    ph_ctx *ctx = a->ctx;
+    int64_t gcap = cap / 2;
+    int32_t *slots = nullptr;
+    unsigned long long *gkeys = nullptr, *sum_lo = nullptr, *cnt = nullptr;
+    unsigned *gnull = nullptr;
+    long long *sum_hi = nullptr, *first_row = nullptr;
+    size_t na = (size_t)std::max(a->naggs, 1);
+    PH_HIP(hipMalloc((void **)&slots, (size_t)cap * 4));
+    PH_HIP(hipMalloc((void **)&gkeys, (size_t)gcap * a->nkeys * 8));
+    PH_HIP(hipMalloc((void **)&gnull, (size_t)gcap * 4));
+    PH_HIP(hipMalloc((void **)&sum_lo, (size_t)gcap * na * 8));
+    PH_HIP(hipMalloc((void **)&sum_hi, (size_t)gcap * na * 8));
+    PH_HIP(hipMalloc((void **)&cnt, (size_t)gcap * na * 8));
+    PH_HIP(hipMalloc((void **)&first_row, (size_t)gcap * 8));
+    PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
+    if (ng > 0) {
+        PH_HIP(hipMemcpyAsync(gkeys, a->gkeys, (size_t)ng * a->nkeys * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(gnull, a->gnull, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(sum_lo, a->sum_lo, (size_t)ng * na * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(sum_hi, a->sum_hi, (size_t)ng * na * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(cnt, a->cnt, (size_t)ng * na * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(first_row, a->first_row, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    int grid = (int)std::min<int64_t>(((gcap - ng) * (int64_t)na + 255) / 256 + 1, 2048);
+    ph::agg_init_kernel<<<grid, 256, 0, ctx->stream>>>(sum_lo, sum_hi, cnt, first_row, ng, gcap, a->naggs, a->kinds_dev);
+    PH_HIP(hipGetLastError());
+    if (ng > 0) {
+        ph::agg_rehash_kernel<<<std::min((ng + 255) / 256, 2048), 256, 0, ctx->stream>>>(slots, (uint64_t)cap - 1, gkeys, gnull, a->nkeys, ng);
+        PH_HIP(hipGetLastError());
+    }
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    agg_free_arrays(a);
+    a->slots = slots; a->gkeys = gkeys; a->gnull = gnull; a->sum_lo = sum_lo; a->sum_hi = sum_hi;
+    a->cnt = cnt; a->first_row = first_row;
+    a->cap = cap;
+    a->gcap = gcap;
+    return PH_OK;
+}
+
+}  // namespace
+
+extern "C" void ph_agg_free(ph_agg *a) {
+    if (!a) return;
+    if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
+    agg_free_arrays(a);
+    if (a->counters) (void)hipFree(a->counters);
+    if (a->kinds_dev) (void)hipFree(a->kinds_dev);
+    delete a;
+}
+
+extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_types, int32_t naggs,
+                             const ph_aggspec *aggs, int64_t expected_groups, ph_agg **out) {
+    PH_REQUIRE(ctx && out && key_types && nkeys >= 1 && nkeys <= ph::AGG_MAX_KEYS && naggs >= 0 &&
+                   naggs <= ph::AGG_MAX_AGGS && (naggs == 0 || aggs),
+               "ph_agg_create: bad arguments (1..%d keys, 0..%d aggregates)", ph::AGG_MAX_KEYS, ph::AGG_MAX_AGGS);
+    for (int c = 0; c < nkeys; c++) {
+        int t = key_types[c];
+        if (t != PH_I32 && t != PH_I64 && t != PH_DATE && t != PH_DEC64 && t != PH_CODE8) {
+            ph::set_error("ph_agg_create: key type %d cannot be a device group key", t);
+            return PH_EUNSUPPORTED;
+        }
+    }
+    ph_agg *a = new ph_agg();
+    a->ctx = ctx;
+    a->nkeys = nkeys;
+    a->naggs = naggs;
+    int kinds[ph::AGG_MAX_AGGS] = {};
+    for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
+    for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
+    int rc = PH_OK;
+    if (hipMalloc((void **)&a->counters, 8) != hipSuccess || hipMemsetAsync(a->counters, 0, 8, ctx->stream) != hipSuccess ||
+        hipMalloc((void **)&a->kinds_dev, sizeof kinds) != hipSuccess ||
+        hipMemcpyAsync(a->kinds_dev, kinds, sizeof kinds, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ph::set_error("ph_agg_create: device allocation failed");
+        rc = PH_EHIP;
+    }
+    // initial capacity: the reference starts at 2*2048 entries (aggregate_exec.go:332-339)
+    if (rc == PH_OK) rc = agg_resize(a, next_pow2(std::max<int64_t>(4096, 2 * expected_groups)), 0);
+    if (rc != PH_OK) { ph_agg_free(a); return rc; }
+    *out = a;
+    return PH_OK;
+}
+
+extern "C" int ph_agg_group_count(ph_agg *a, int64_t *ngroups) {
+    PH_REQUIRE(a && ngroups, "ph_agg_group_count: bad arguments");
+    int c[2] = {0, 0};
+    PH_HIP(hipMemcpyAsync(c, a->counters, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+    PH_HIP(hipStreamSynchronize(a->ctx->stream));
+    if (c[1]) { ph::set_error("ph_agg: device table error flag %d", c[1]); return PH_EHIP; }
+    *ngroups = c[0];
+    return PH_OK;
+}
+
+extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
+                           const int32_t *sel, int64_t n, int32_t positional, int64_t row_base) {
+    PH_REQUIRE(a && keys && n >= 0 && nargs >= 0 && nargs <= ph::AGG_MAX_AGGS && (nargs == 0 || args),
+               "ph_agg_sink: bad arguments");
+    ph::AggSinkParams P{};
+    P.nkeys = a->nkeys;
+    P.naggs = a->naggs;
+    P.nargs = nargs;
+    for (int c = 0; c < a->nkeys; c++) {
+        PH_REQUIRE(keys[c].type == a->key_types[c], "ph_agg_sink: key %d has type %d, table was created for %d", c, keys[c].type, a->key_types[c]);
+        P.key[c] = {keys[c].type, keys[c].data, keys[c].validity};
+    }
+    for (int c = 0; c < nargs; c++) {
+        int t = args[c].type;
+        if (t != PH_I32 && t != PH_I64 && t != PH_DEC64 && t != PH_DATE) { ph::set_error("ph_agg_sink: argument %d has type %d", c, t); return PH_EUNSUPPORTED; }
+        P.arg[c] = {t == PH_DATE ? PH_I32 : t, args[c].data, args[c].validity};
+    }
+    for (int i = 0; i < a->naggs; i++) {
+        P.agg_kind[i] = a->aggs[i].kind;
+        P.agg_arg[i] = a->aggs[i].arg;
+        PH_REQUIRE(a->aggs[i].kind == PH_A_COUNT_STAR || (a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs),
+                   "ph_agg_sink: aggregate %d refers to argument %d of %d", i, a->aggs[i].arg, nargs);
+    }
+    P.positional = positional;
+    P.ngroups = a->counters;
+    P.error_flag = a->counters + 1;
+    for (int64_t off = 0; off < n; off += AGG_BATCH) {
+        int64_t m = std::min(AGG_BATCH, n - off);
+        int64_t ng = 0;
+        PH_CHECK(ph_agg_group_count(a, &ng));
+        // the reference's Resize rule: grow while capacity - groups <= incoming rows
+        // (aggregate_hash.go:214-217); with gcap = cap/2 this also keeps the load factor <= 0.5
+        int64_t cap = a->cap;
+        while (cap / 2 - ng <= m) cap *= 2;
+        if (cap != a->cap) PH_CHECK(agg_resize(a, cap, (int)ng));
+        P.sel = sel ? sel + off : nullptr;
+        P.n = m;
+        P.row_base = row_base + off;
+        if (!sel || positional) {
+            // identity selection / positional args: shift the base pointers instead
+            for (int c = 0; c < a->nkeys && !sel; c++) {
+                int w = ph::type_width(keys[c].type);
+                P.key[c].data = (const char *)keys[c].data + off * w;
+                PH_REQUIRE(!keys[c].validity || off % 8 == 0, "ph_agg_sink: internal batch offset");
+                P.key[c].validity = keys[c].validity ? keys[c].validity + off / 8 : nullptr;
+            }
+            for (int c = 0; c < nargs && (!sel || positional); c++) {
+                int w = ph::type_width(args[c].type);
+                P.arg[c].data = (const char *)args[c].data + off * w;
+                P.arg[c].validity = args[c].validity ? args[c].validity + off / 8 : nullptr;
+            }
+        }
+        P.slots = a->slots;
+        P.mask = (uint64_t)a->cap - 1;
+        P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
+        P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
+        int grid = (int)std::min<int64_t>((m + 255) / 256, 256 * 8);
+        ph::agg_sink_kernel<<<grid, 256, 0, a->ctx->stream>>>(P);
+        PH_HIP(hipGetLastError());
+    }
+    a->rows_sunk += n;
+    return PH_OK;
+}
+
+extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
+                               uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && max_groups >= 0, "ph_agg_finalize: bad arguments");
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(a, &ng));
+    if (ng > max_groups) { ph::set_error("ph_agg_finalize: %lld groups, room for %lld", (long long)ng, (long long)max_groups); return PH_ECAPACITY; }
+    if (ng == 0) return PH_OK;
+    size_t na = (size_t)std::max(a->naggs, 1), g = (size_t)ng;
+    std::vector<long long> fr(g);
+    std::vector<unsigned long long> gk(g * a->nkeys), lo(g * na), cn(g * na);
+    std::vector<long long> hi(g * na);
+    std::vector<unsigned> gn(g);
+    hipStream_t s = a->ctx->stream;
+    PH_HIP(hipMemcpyAsync(fr.data(), a->first_row, g * 8, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipMemcpyAsync(gk.data(), a->gkeys, g * a->nkeys * 8, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipMemcpyAsync(gn.data(), a->gnull, g * 4, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipMemcpyAsync(lo.data(), a->sum_lo, g * na * 8, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipMemcpyAsync(hi.data(), a->sum_hi, g * na * 8, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipMemcpyAsync(cn.data(), a->cnt, g * na * 8, hipMemcpyDeviceToHost, s));
+    PH_HIP(hipStreamSynchronize(s));
+    // first-seen order = the reference's insertion order (GroupedAggrHashTable.Scan, :424-438)
+    std::vector<int64_t> order(g);
+    for (size_t i = 0; i < g; i++) order[i] = (int64_t)i;
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return fr[(size_t)x] < fr[(size_t)y]; });
+    for (size_t o = 0; o < g; o++) {
+        size_t src = (size_t)order[o];
+        if (first_row) first_row[o] = fr[src];
+        for (int c = 0; c < a->nkeys; c++) {
+            if (keys) keys[o * a->nkeys + c] = (int64_t)gk[src * a->nkeys + c];
+            if (key_null) key_null[o * a->nkeys + c] = (gn[src] >> c) & 1;
+        }
+        for (int i = 0; i < a->naggs; i++) {
+            if (sum_lo) sum_lo[o * a->naggs + i] = lo[src * na + i];
+            if (sum_hi) {
+                int kind = a->aggs[i].kind;
+                // MIN/MAX keep their value in the low word: sign-extend it for the caller
+                sum_hi[o * a->naggs + i] = (kind == PH_A_MIN || kind == PH_A_MAX)
+                                               ? ((long long)lo[src * na + i] < 0 ? -1 : 0) : hi[src * na + i];
+            }
+            if (count) count[o * a->naggs + i] = cn[src * na + i];
+        }
+    }
+    return PH_OK;
+}

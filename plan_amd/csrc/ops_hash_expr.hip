@@ -1,0 +1,264 @@
+// ph_hash (Chunk.Hash parity) and ph_expr_eval (decimal/integer expression programs).
+#include <algorithm>
+
+#include "common.h"
+#include "device_util.h"
+#include "ops.h"
+
+namespace ph {
+
+// ------------------------------------------------------------------ hash
+// Chunk.Hash = HashTypeSwitch on the first key column, CombineHashTypeSwitch on the rest
+// (reference pkg/chunk/chunk.go:160-166, hash.go:182-413). Values are bit-identical to the
+// reference so that a mixed CPU/GPU plan could share hash columns; the device tables themselves
+// use their own mixer for placement.
+
+struct HashCol {
+    int type, scale;
+    const void *data;
+    const uint8_t *validity;
+    const uint8_t *bytes;          // PH_STR
+    const uint64_t *dict_hashes;   // PH_CODE8
+};
+
+struct HashParams {
+    int ncols;
+    HashCol c[4];
+};
+
+__device__ __forceinline__ uint64_t hash_one(const HashCol &c, int64_t r) {
+    if (!bit_valid(c.validity, r)) return NULL_HASH;
+    switch (c.type) {
+    case PH_I32:  // HashFuncInt32: uint32 zero-extended (hash.go:53-55)
+        return murmurhash64((uint64_t)(uint32_t)((const int32_t *)c.data)[r]);
+    case PH_I64:
+        return murmurhash64((uint64_t)((const int64_t *)c.data)[r]);
+    case PH_DATE: {  // h(Y) ^ h(M) ^ h(D) (hash.go:127-129)
+        int32_t y, m, d;
+        civil_from_days(((const int32_t *)c.data)[r], &y, &m, &d);
+        return murmurhash64((uint64_t)(int64_t)y) ^ murmurhash64((uint64_t)(int64_t)m) ^
+               murmurhash64((uint64_t)(int64_t)d);
+    }
+    case PH_DEC64: {
+        // h(neg) ^ h(coef) ^ h(scale) (hash.go:144-151) of the value as the loader built it:
+        // NewFromInt64 drops the fraction's trailing zeros (pkg/chunk/vector.go:257-264)
+        long long v = ((const int64_t *)c.data)[r];
+        uint64_t coef = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        int s = c.scale;
+        while (s > 0 && coef % 10 == 0) {
+            coef /= 10;
+            s--;
+        }
+        return murmurhash64(v < 0 ? 1 : 0) ^ murmurhash64(coef) ^ murmurhash64((uint64_t)s);
+    }
+    case PH_CODE8:
+        return c.dict_hashes[((const uint8_t *)c.data)[r]];
+    case PH_STR: {
+        const int32_t *off = (const int32_t *)c.data;
+        return hash_bytes(c.bytes + off[r], (uint64_t)(off[r + 1] - off[r]));
+    }
+    default:
+        return 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void hash_kernel(HashParams P, int64_t n, uint64_t *__restrict__ out) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        uint64_t h = hash_one(P.c[0], r);
+        for (int k = 1; k < P.ncols; k++) h = combine_hash(h, hash_one(P.c[k], r));
+        out[r] = h;
+    }
+}
+
+// ------------------------------------------------------------------ expression programs
+
+constexpr int X_MAX_OPS = 24;
+constexpr int X_MAX_COLS = 8;
+constexpr int X_STACK = 8;
+
+struct XInstr {
+    int op;      // PH_X_*
+    int col;
+    long long k; // constant, already scaled
+    long long ma, mb;  // ADD/SUB: multipliers aligning the two operands' scales
+};
+
+struct XParams {
+    int nops, ncols;
+    XInstr ins[X_MAX_OPS];
+    struct { int type; const void *data; const uint8_t *validity; } c[X_MAX_COLS];
+};
+
+__global__ __launch_bounds__(256) void expr_kernel(XParams P, const int32_t *__restrict__ sel, int64_t n,
+                                                   long long *__restrict__ out, uint8_t *__restrict__ out_valid,
+                                                   int *__restrict__ overflow_flag) {
+    // operand stack in LDS: one column per thread, so dynamic stack indexing costs no registers
+    __shared__ long long stk[X_STACK][256];
+    const int t = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+        int64_t i = base + t;
+        bool live = i < n;
+        int64_t r = live ? (sel ? sel[i] : i) : 0;
+        bool null = false, ovf = false;
+        int sp = 0;
+        for (int p = 0; p < P.nops; p++) {
+            const XInstr &o = P.ins[p];
+            switch (o.op) {
+            case PH_X_COL: {
+                long long v = 0;
+                if (live) {
+                    if (!bit_valid(P.c[o.col].validity, r)) null = true;
+                    else if (P.c[o.col].type == PH_I32) v = ((const int32_t *)P.c[o.col].data)[r];
+                    else v = ((const int64_t *)P.c[o.col].data)[r];
+                }
+                stk[sp++][t] = v;
+                break;
+            }
+            case PH_X_CONST: stk[sp++][t] = o.k; break;
+            case PH_X_ADD: case PH_X_SUB: {
+                long long b = stk[--sp][t], a = stk[sp - 1][t], x, y, z;
+                ovf |= __builtin_mul_overflow(a, o.ma, &x);
+                ovf |= __builtin_mul_overflow(b, o.mb, &y);
+                ovf |= o.op == PH_X_ADD ? __builtin_add_overflow(x, y, &z) : __builtin_sub_overflow(x, y, &z);
+                stk[sp - 1][t] = z;
+                break;
+            }
+            case PH_X_MUL: {
+                long long b = stk[--sp][t], a = stk[sp - 1][t], z;
+                ovf |= __builtin_mul_overflow(a, b, &z);
+                stk[sp - 1][t] = z;
+                break;
+            }
+            default: break;
+            }
+        }
+        if (live) {
+            out[i] = null ? 0 : stk[0][t];
+            if (ovf && !null) atomicOr(overflow_flag, 1);
+        }
+        if (out_valid) {  // one validity byte per 8 rows: lanes 0,8,16.. assemble it via ballot
+            unsigned long long m = __ballot(live && !null);
+            int lane = t & 63;
+            if ((lane & 7) == 0 && base + (t & ~7) < n) out_valid[(base + t) >> 3] = (uint8_t)(m >> lane);
+        }
+    }
+}
+
+static bool pow10ll(int k, long long *out) {
+    long long r = 1;
+    for (int i = 0; i < k; i++)
+        if (__builtin_mul_overflow(r, 10ll, &r)) return false;
+    *out = r;
+    return true;
+}
+
+// scale bookkeeping of the binder's rules: Mul adds scales, Add/Sub takes the max
+// (BindDecimalMultiply function_scalar.go:429-475, BindDecimalAddSubstract :37-84)
+static int compile_expr(const ph_col *cols, int32_t ncols, const ph_rpn *prog, int32_t nprog, XParams *X,
+                        int32_t *result_scale) {
+    if (nprog <= 0 || nprog > X_MAX_OPS) { set_error("expression program of %d ops (max %d)", nprog, X_MAX_OPS); return PH_EUNSUPPORTED; }
+    int scales[X_STACK];
+    int sp = 0;
+    if (X) { X->nops = nprog; X->ncols = ncols; }
+    for (int32_t p = 0; p < nprog; p++) {
+        const ph_rpn &o = prog[p];
+        XInstr ins{};
+        ins.op = o.op;
+        ins.col = o.col;
+        ins.ma = ins.mb = 1;
+        switch (o.op) {
+        case PH_X_COL:
+            if (o.col < 0 || o.col >= ncols || sp >= X_STACK) return PH_EUNSUPPORTED;
+            if (cols[o.col].type == PH_DEC64) scales[sp++] = cols[o.col].scale;
+            else if (cols[o.col].type == PH_I32 || cols[o.col].type == PH_I64) scales[sp++] = 0;
+            else { set_error("expression over column type %d", cols[o.col].type); return PH_EUNSUPPORTED; }
+            break;
+        case PH_X_CONST:
+            if (sp >= X_STACK) return PH_EUNSUPPORTED;
+            ins.k = o.ival;
+            scales[sp++] = o.scale;
+            break;
+        case PH_X_ADD: case PH_X_SUB: {
+            if (sp < 2) return PH_EUNSUPPORTED;
+            int sb = scales[--sp], sa = scales[sp - 1], s = std::max(sa, sb);
+            if (!pow10ll(s - sa, &ins.ma) || !pow10ll(s - sb, &ins.mb)) return PH_EOVERFLOW;
+            scales[sp - 1] = s;
+            break;
+        }
+        case PH_X_MUL:
+            if (sp < 2) return PH_EUNSUPPORTED;
+            sp--;
+            scales[sp - 1] += scales[sp];
+            break;
+        default:
+            set_error("unknown expression op %d", o.op);
+            return PH_EUNSUPPORTED;
+        }
+        if (X) X->ins[p] = ins;
+    }
+    if (sp != 1) { set_error("expression program leaves %d values on the stack", sp); return PH_EUNSUPPORTED; }
+    if (scales[0] > 18) { set_error("result scale %d exceeds the int64 decimal domain", scales[0]); return PH_EOVERFLOW; }
+    *result_scale = scales[0];
+    return PH_OK;
+}
+
+}  // namespace ph
+
+extern "C" uint64_t ph_hash_bytes(const void *p, uint64_t len) { return ph::hash_bytes((const uint8_t *)p, len); }
+
+extern "C" int ph_hash(ph_ctx *ctx, const ph_col *cols, const uint64_t *const *dict_hashes, int32_t ncols,
+                       int64_t n, uint64_t *out_dev) {
+    PH_REQUIRE(ctx && cols && ncols >= 1 && ncols <= 4 && n >= 0, "ph_hash: bad arguments (1..4 key columns)");
+    if (n == 0) return PH_OK;
+    ph::HashParams P{};
+    P.ncols = ncols;
+    for (int c = 0; c < ncols; c++) {
+        P.c[c].type = cols[c].type;
+        P.c[c].scale = cols[c].scale;
+        P.c[c].data = cols[c].data;
+        P.c[c].validity = cols[c].validity;
+        P.c[c].bytes = (const uint8_t *)cols[c].aux;
+        P.c[c].dict_hashes = dict_hashes ? dict_hashes[c] : nullptr;
+        if (cols[c].type == PH_CODE8 && !P.c[c].dict_hashes) { ph::set_error("ph_hash: column %d is PH_CODE8 but has no dict_hashes", c); return PH_EINVAL; }
+        if (cols[c].type == PH_F32 || cols[c].type == PH_F64) { ph::set_error("ph_hash: no hash for float columns (the reference has none either)"); return PH_EUNSUPPORTED; }
+    }
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    ph::hash_kernel<<<grid, 256, 0, ctx->stream>>>(P, n, out_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+extern "C" int ph_expr_scale(const ph_col *cols, const ph_rpn *prog, int32_t nprog, int32_t *scale) {
+    PH_REQUIRE(cols && prog && scale, "ph_expr_scale: bad arguments");
+    int32_t maxcol = 0;
+    for (int32_t p = 0; p < nprog; p++) if (prog[p].op == PH_X_COL) maxcol = std::max(maxcol, prog[p].col + 1);
+    return ph::compile_expr(cols, maxcol, prog, nprog, nullptr, scale);
+}
+
+extern "C" int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *prog, int32_t nprog,
+                            const int32_t *sel, int64_t n, int64_t *out_dev, uint8_t *out_validity_dev) {
+    PH_REQUIRE(ctx && cols && prog && ncols >= 1 && ncols <= ph::X_MAX_COLS && n >= 0, "ph_expr_eval: bad arguments");
+    ph::XParams X{};
+    int32_t scale = 0;
+    PH_CHECK(ph::compile_expr(cols, ncols, prog, nprog, &X, &scale));
+    bool any_validity = false;
+    for (int c = 0; c < ncols; c++) {
+        X.c[c].type = cols[c].type;
+        X.c[c].data = cols[c].data;
+        X.c[c].validity = cols[c].validity;
+        any_validity |= cols[c].validity != nullptr;
+    }
+    if (any_validity && !out_validity_dev) { ph::set_error("ph_expr_eval: inputs carry validity but out_validity_dev is NULL"); return PH_EINVAL; }
+    if (n == 0) return PH_OK;
+    PH_CHECK(ctx->ensure_scratch(64));
+    int *flag = (int *)ctx->scratch;
+    PH_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    ph::expr_kernel<<<grid, 256, 0, ctx->stream>>>(X, sel, n, (long long *)out_dev, out_validity_dev, flag);
+    PH_HIP(hipGetLastError());
+    int host_flag = 0;
+    PH_HIP(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (host_flag) { ph::set_error("ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
+    return PH_OK;
+}

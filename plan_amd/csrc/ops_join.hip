@@ -1,0 +1,285 @@
+// Hash join: ph_join_build / ph_join_probe_inner / ph_join_probe_mark.
+//
+// Replaces JoinHashTable.Build -> Finalize/InsertHashesLoop and Probe -> Scan.NextInnerJoin /
+// ScanKeyMatches (reference pkg/compute/join_table.go:85-336, join_scan.go:30-300,
+// util_match.go:25-301). Same table shape as the reference: a bucket-head table with
+// cap = max(nextpow2(2n), 1024) and a per-row `next` link holding the previous head (the reference
+// stores it in the row's hash slot, join_table.go:268-288); heads are swapped in with atomicExch so
+// a whole build batch inserts in one launch. Rows with a NULL key never enter the table and never
+// probe (prepareKeys / filterNullValues, :152-195).
+// Probe output is deterministic: pairs ordered by probe position, then by chain order; a count
+// pass, a scan over workgroup totals and a write pass place them (no atomics on the output).
+#include <algorithm>
+
+#include "common.h"
+#include "device_util.h"
+#include "ops.h"
+
+namespace ph {
+
+constexpr int JOIN_MAX_KEYS = 4;
+
+struct JoinCol {
+    int type;
+    const void *data;
+    const uint8_t *validity;
+};
+
+struct JoinSide {
+    int nkeys;
+    JoinCol key[JOIN_MAX_KEYS];
+    const int32_t *sel;  // position -> row id (NULL = identity)
+    int64_t n;
+};
+
+__device__ __forceinline__ unsigned long long jkey(const JoinCol &c, int64_t r) {
+    switch (c.type) {
+    case PH_I32: case PH_DATE: return (unsigned long long)(long long)((const int32_t *)c.data)[r];
+    case PH_CODE8: return ((const uint8_t *)c.data)[r];
+    default: return (unsigned long long)((const int64_t *)c.data)[r];
+    }
+}
+
+__device__ __forceinline__ bool load_keys(const JoinSide &S, int64_t r, unsigned long long *k, uint64_t *h) {
+    uint64_t hh = 0x9e3779b97f4a7c15ULL;
+#pragma unroll
+    for (int c = 0; c < JOIN_MAX_KEYS; c++) {
+        k[c] = 0;
+        if (c < S.nkeys) {
+            if (!bit_valid(S.key[c].validity, r)) return false;
+            k[c] = jkey(S.key[c], r);
+            hh = mix64(hh ^ k[c]);
+        }
+    }
+    *h = hh;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__restrict__ head, uint64_t mask,
+                                                         int32_t *__restrict__ next, int *__restrict__ count) {
+    int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B.n; i += (int64_t)gridDim.x * 256) {
+        int64_t r = B.sel ? B.sel[i] : i;
+        unsigned long long k[JOIN_MAX_KEYS];
+        uint64_t h;
+        if (!load_keys(B, r, k, &h)) { next[i] = -2; continue; }  // NULL key: not inserted
+        next[i] = atomicExch(&head[h & mask], (int32_t)i);        // head insertion
+        local++;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+__device__ __forceinline__ bool keys_equal(const JoinSide &B, int64_t brow, const unsigned long long *k) {
+    for (int c = 0; c < B.nkeys; c++)
+        if (jkey(B.key[c], brow) != k[c]) return false;
+    return true;
+}
+
+// number of build rows matching probe position i
+__device__ __forceinline__ int probe_count(const JoinSide &B, const JoinSide &Pr, const int32_t *head, uint64_t mask,
+                                           const int32_t *next, int64_t i) {
+    int64_t r = Pr.sel ? Pr.sel[i] : i;
+    unsigned long long k[JOIN_MAX_KEYS];
+    uint64_t h;
+    if (!load_keys(Pr, r, k, &h)) return 0;
+    int c = 0;
+    for (int b = head[h & mask]; b >= 0; b = next[b]) {
+        int64_t brow = B.sel ? B.sel[b] : b;
+        c += keys_equal(B, brow, k) ? 1 : 0;
+    }
+    return c;
+}
+
+constexpr int JP_ROUNDS = 8;
+constexpr int JP_CHUNK = 256 * JP_ROUNDS;
+
+__global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
+                                                         uint64_t mask, const int32_t *__restrict__ next,
+                                                         int32_t *__restrict__ block_counts) {
+    int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    int cnt = 0;
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        int64_t i = base + rr * 256 + threadIdx.x;
+        if (i < Pr.n) cnt += probe_count(B, Pr, head, mask, next, i);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __shared__ int ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
+                                                         uint64_t mask, const int32_t *__restrict__ next,
+                                                         const int32_t *__restrict__ block_off, int64_t cap,
+                                                         int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build) {
+    int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    __shared__ int ws[4];
+    int64_t running = block_off[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        int64_t i = base + rr * 256 + threadIdx.x;
+        int c = i < Pr.n ? probe_count(B, Pr, head, mask, next, i) : 0;
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) ws[w] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; k++) woff += ws[k];
+        int total = ws[0] + ws[1] + ws[2] + ws[3];
+        if (c > 0) {
+            int64_t pos = running + woff + incl - c;
+            int64_t r = Pr.sel ? Pr.sel[i] : i;
+            unsigned long long k[JOIN_MAX_KEYS];
+            uint64_t h;
+            load_keys(Pr, r, k, &h);
+            for (int b = head[h & mask]; b >= 0; b = next[b]) {
+                int64_t brow = B.sel ? B.sel[b] : b;
+                if (keys_equal(B, brow, k)) {
+                    if (pos < cap) {
+                        out_probe[pos] = (int32_t)r;
+                        out_build[pos] = (int32_t)brow;
+                    }
+                    pos++;
+                }
+            }
+        }
+        running += total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void join_mark_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
+                                                        uint64_t mask, const int32_t *__restrict__ next,
+                                                        uint8_t *__restrict__ found) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < Pr.n; i += (int64_t)gridDim.x * 256)
+        found[i] = probe_count(B, Pr, head, mask, next, i) > 0 ? 1 : 0;
+}
+
+}  // namespace ph
+
+struct ph_join {
+    ph_ctx *ctx = nullptr;
+    ph::JoinSide build{};
+    int32_t *sel_copy = nullptr;
+    int32_t *head = nullptr, *next = nullptr;
+    int64_t cap = 0;
+    int64_t count = 0;
+};
+
+extern "C" void ph_join_free(ph_join *j) {
+    if (!j) return;
+    if (j->ctx) (void)hipStreamSynchronize(j->ctx->stream);
+    if (j->sel_copy) (void)hipFree(j->sel_copy);
+    if (j->head) (void)hipFree(j->head);
+    if (j->next) (void)hipFree(j->next);
+    delete j;
+}
+
+static int fill_side(ph::JoinSide *S, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n) {
+    S->nkeys = nkeys;
+    for (int c = 0; c < nkeys; c++) {
+        int t = keys[c].type;
+        if (t != PH_I32 && t != PH_I64 && t != PH_DATE && t != PH_DEC64 && t != PH_CODE8) {
+            ph::set_error("join key %d has type %d (device join keys are integers, dates, decimals and dictionary codes)", c, t);
+            return PH_EUNSUPPORTED;
+        }
+        S->key[c] = {t, keys[c].data, keys[c].validity};
+    }
+    S->sel = sel;
+    S->n = n;
+    return PH_OK;
+}
+
+extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
+                             ph_join **out) {
+    PH_REQUIRE(ctx && keys && out && nkeys >= 1 && nkeys <= ph::JOIN_MAX_KEYS && n >= 0 && n < (1ll << 31),
+               "ph_join_build: bad arguments (1..%d keys)", ph::JOIN_MAX_KEYS);
+    ph_join *j = new ph_join();
+    j->ctx = ctx;
+    int rc = fill_side(&j->build, keys, nkeys, sel, n);
+    if (rc != PH_OK) { delete j; return rc; }
+    // pointer table: cap = max(nextpow2(2n), 1024) (pointerTableCap, join_table.go:197-199)
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    j->cap = cap;
+    auto fail = [&](const char *what) { ph::set_error("ph_join_build: %s failed", what); ph_join_free(j); return PH_EHIP; };
+    if (hipMalloc((void **)&j->head, (size_t)cap * 4) != hipSuccess) return fail("hipMalloc(head)");
+    if (hipMalloc((void **)&j->next, (size_t)std::max<int64_t>(n, 1) * 4) != hipSuccess) return fail("hipMalloc(next)");
+    if (hipMemsetAsync(j->head, 0xff, (size_t)cap * 4, ctx->stream) != hipSuccess) return fail("memset");
+    if (sel && n > 0) {  // keep our own copy: the table outlives the caller's selection buffer
+        if (hipMalloc((void **)&j->sel_copy, (size_t)n * 4) != hipSuccess) return fail("hipMalloc(sel)");
+        if (hipMemcpyAsync(j->sel_copy, sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy sel");
+        j->build.sel = j->sel_copy;
+    }
+    if (ctx->ensure_scratch(64) != PH_OK) { ph_join_free(j); return PH_EHIP; }
+    int *count = (int *)ctx->scratch;
+    if (hipMemsetAsync(count, 0, 4, ctx->stream) != hipSuccess) return fail("memset");
+    if (n > 0) {
+        int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+        ph::join_build_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, j->head, (uint64_t)cap - 1, j->next, count);
+        if (hipGetLastError() != hipSuccess) return fail("join_build_kernel launch");
+    }
+    int c = 0;
+    if (hipMemcpyAsync(&c, count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("count readback");
+    j->count = c;
+    *out = j;
+    return PH_OK;
+}
+
+extern "C" int64_t ph_join_count(const ph_join *j) { return j ? j->count : -1; }
+
+static int check_probe(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, ph::JoinSide *P) {
+    PH_REQUIRE(j && keys && n >= 0, "ph_join_probe: bad arguments");
+    PH_CHECK(fill_side(P, keys, j->build.nkeys, sel, n));
+    for (int c = 0; c < j->build.nkeys; c++) {
+        int a = P->key[c].type, b = j->build.key[c].type;
+        bool w32a = a == PH_I32 || a == PH_DATE, w32b = b == PH_I32 || b == PH_DATE;
+        bool w64a = a == PH_I64 || a == PH_DEC64, w64b = b == PH_I64 || b == PH_DEC64;
+        PH_REQUIRE((w32a && w32b) || (w64a && w64b) || (a == PH_CODE8 && b == PH_CODE8),
+                   "ph_join_probe: key %d types differ (probe %d, build %d); cast on the host side first", c, a, b);
+    }
+    return PH_OK;
+}
+
+extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
+                                   int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    ph::JoinSide P{};
+    PH_CHECK(check_probe(j, keys, sel, n, &P));
+    PH_REQUIRE(n_out && cap >= 0 && (cap == 0 || (out_probe_dev && out_build_dev)), "ph_join_probe_inner: bad output arguments");
+    *n_out = 0;
+    if (n == 0 || j->count == 0) return PH_OK;
+    ph_ctx *ctx = j->ctx;
+    int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
+    int32_t *counts = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    uint64_t mask = (uint64_t)j->cap - 1;
+    ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts);
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cap, out_probe_dev, out_build_dev);
+    PH_HIP(hipGetLastError());
+    PH_HIP(hipMemcpyAsync(n_out, total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
+    return PH_OK;
+}
+
+extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, uint8_t *found_dev) {
+    ph::JoinSide P{};
+    PH_CHECK(check_probe(j, keys, sel, n, &P));
+    PH_REQUIRE(n == 0 || found_dev, "ph_join_probe_mark: found_dev is NULL");
+    if (n == 0) return PH_OK;
+    ph_ctx *ctx = j->ctx;
+    if (j->count == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    ph::join_mark_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, P, j->head, (uint64_t)j->cap - 1, j->next, found_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}

@@ -1,0 +1,399 @@
+// Operator-granular filter: ph_filter_select, plus the shared block-scan, gather and partition
+// kernels.
+//
+// Replaces ExprExec.executeSelect -> execSelectCompare -> selectOperation -> selectFlat ->
+// selectFlatLoop (reference pkg/compute/expr_exec.go:342-442,
+// function_operator_boolean.go:393-521, 672-868) for one `column OP constant` comparison over a
+// device batch, narrowing an optional input selection exactly as execSelectAnd chains conjuncts
+// (expr_exec.go:444-486). The output selection is ascending, like the reference's trueSel:
+// every workgroup owns a contiguous run of candidates, lanes evaluate consecutive candidates, a
+// wavefront ballot + popcount gives each passing lane its rank, and an exclusive scan over the
+// workgroup totals places the runs (count pass, scan, write pass — no atomics, deterministic).
+#include <algorithm>
+
+#include "common.h"
+#include "device_util.h"
+#include "ops.h"
+
+namespace ph {
+
+enum SelKind {
+    SK_NEVER = 0,
+    SK_RANGE_I32,   // lo <= v <= hi on int32 (INTEGER, DATE)
+    SK_NE_I32,
+    SK_RANGE_I64,   // DECIMAL '>' literal
+    SK_RANGE_U8,    // dictionary code = code of the literal
+    SK_NE_U8,
+    SK_F32_DEC,     // float32(decimal) OP float32 literal
+    SK_F32,         // float32 column
+    SK_F64,         // float64 column ('<' only)
+    SK_STR          // PH_STR: =, !=, LIKE, NOT LIKE on offsets+bytes
+};
+
+struct SelParams {
+    int kind;
+    int op;
+    const void *data;
+    const uint8_t *validity;
+    const char *bytes;
+    long long lo, hi;
+    float kf;
+    double kd;
+    double div;  // 10^scale
+    int plen;
+    char pat[96];
+};
+
+__device__ __forceinline__ bool fcmp(int op, double v, double k) {
+    switch (op) {
+    case PH_GT: return v > k;
+    case PH_GE: return v >= k;
+    case PH_LT: return v < k;
+    case PH_LE: return v <= k;
+    default: return false;
+    }
+}
+
+__device__ __forceinline__ bool sel_pred(const SelParams &P, int64_t r) {
+    if (!bit_valid(P.validity, r)) return false;  // NULL never selects (selectFlatLoop :842-866)
+    switch (P.kind) {
+    case SK_RANGE_I32: {
+        long long v = ((const int32_t *)P.data)[r];
+        return v >= P.lo && v <= P.hi;
+    }
+    case SK_NE_I32: return ((const int32_t *)P.data)[r] != (int32_t)P.lo;
+    case SK_RANGE_I64: {
+        long long v = ((const int64_t *)P.data)[r];
+        return v >= P.lo && v <= P.hi;
+    }
+    case SK_RANGE_U8: {
+        long long v = ((const uint8_t *)P.data)[r];
+        return v >= P.lo && v <= P.hi;
+    }
+    case SK_NE_U8: return ((const uint8_t *)P.data)[r] != (uint8_t)P.lo;
+    case SK_F32_DEC: {
+        // tryCastDecimalToFloat32 (function_cast.go:349-354): decimal -> float64 -> float32.
+        // IEEE division of two exactly representable doubles is the correctly rounded value of
+        // the decimal, which is what the reference's string round trip produces.
+        float v = (float)((double)((const int64_t *)P.data)[r] / P.div);
+        return fcmp(P.op, (double)v, (double)P.kf);
+    }
+    case SK_F32: return fcmp(P.op, (double)((const float *)P.data)[r], (double)P.kf);
+    case SK_F64: return fcmp(P.op, ((const double *)P.data)[r], P.kd);
+    case SK_STR: {
+        const int32_t *off = (const int32_t *)P.data;
+        const char *s = P.bytes + off[r];
+        int slen = off[r + 1] - off[r];
+        if (P.op == PH_LIKE) return like_match(s, slen, P.pat, P.plen);
+        if (P.op == PH_NOTLIKE) return !like_match(s, slen, P.pat, P.plen);
+        bool eq = slen == P.plen;
+        for (int i = 0; eq && i < slen; i++) eq = s[i] == P.pat[i];
+        return P.op == PH_EQ ? eq : !eq;
+    }
+    default: return false;
+    }
+}
+
+constexpr int SEL_ROUNDS = 8;
+constexpr int SEL_CHUNK = 256 * SEL_ROUNDS;
+
+__global__ __launch_bounds__(256) void select_count_kernel(SelParams P, const int32_t *__restrict__ sel_in,
+                                                           int64_t n_in, int32_t *__restrict__ block_counts) {
+    int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
+    int cnt = 0;
+    for (int r = 0; r < SEL_ROUNDS; r++) {
+        int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n_in) {
+            int64_t row = sel_in ? sel_in[i] : i;
+            cnt += sel_pred(P, row) ? 1 : 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __shared__ int ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of n ints in place, total to out_total; one workgroup
+__global__ __launch_bounds__(1024) void scan_kernel(int32_t *__restrict__ v, int64_t n,
+                                                    int64_t *__restrict__ out_total) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = 0; base < n; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        long long x = i < n ? v[i] : 0;
+        long long incl = x;
+        for (int o = 1; o < 64; o <<= 1) {
+            long long y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        long long woff = 0;
+        for (int k = 0; k < w; k++) woff += wsum[k];
+        long long c = carry;
+        if (i < n) v[i] = (int32_t)(c + woff + incl - x);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+__global__ __launch_bounds__(256) void select_write_kernel(SelParams P, const int32_t *__restrict__ sel_in,
+                                                           int64_t n_in, const int32_t *__restrict__ block_off,
+                                                           int32_t *__restrict__ sel_out) {
+    int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
+    __shared__ int ws[4];
+    int running = block_off[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = 0; r < SEL_ROUNDS; r++) {
+        int64_t i = base + r * 256 + threadIdx.x;
+        int64_t row = 0;
+        bool pass = false;
+        if (i < n_in) {
+            row = sel_in ? sel_in[i] : i;
+            pass = sel_pred(P, row);
+        }
+        unsigned long long m = __ballot(pass);
+        int rank = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) ws[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; k++) woff += ws[k];
+        int total = ws[0] + ws[1] + ws[2] + ws[3];
+        if (pass) sel_out[running + woff + rank] = (int32_t)row;
+        running += total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+static bool lower_select(const ph_col *col, int32_t op, const ph_const *k, SelParams *P) {
+    // which (type, op) pairs exist: selectOperation (function_operator_boolean.go:393-504)
+    memset(P, 0, sizeof *P);
+    P->kind = SK_NEVER;
+    P->op = op;
+    P->data = col->data;
+    P->validity = col->validity;
+    P->lo = INT64_MIN;
+    P->hi = INT64_MAX;
+    auto range = [&](long long v) {
+        switch (op) {
+        case PH_EQ: P->lo = P->hi = v; return true;
+        case PH_LT: if (v == INT64_MIN) return false; P->hi = v - 1; return true;
+        case PH_LE: P->hi = v; return true;
+        case PH_GT: if (v == INT64_MAX) return false; P->lo = v + 1; return true;
+        case PH_GE: P->lo = v; return true;
+        default: return false;
+        }
+    };
+    switch (col->type) {
+    case PH_I32:
+        if (k->type != PH_I32) return false;
+        if (op == PH_NE) { P->kind = SK_NE_I32; P->lo = (int32_t)k->i; return true; }
+        if (op >= PH_EQ && op <= PH_GE && range((int32_t)k->i)) P->kind = SK_RANGE_I32;
+        return true;
+    case PH_DATE:
+        if (k->type != PH_DATE) return false;
+        // DATE has <,<=,>,>= only ('=' falls in the default: return 0 branch)
+        if (op >= PH_LT && op <= PH_GE && range((int32_t)k->i)) P->kind = SK_RANGE_I32;
+        return true;
+    case PH_I64:
+        return true;  // no BIGINT comparison is implemented: selects nothing
+    case PH_CODE8:
+        // VARCHAR '=' / '!=' on a dictionary column: the caller resolves the literal to its
+        // code (PH_I32 constant; a code outside 0..255 = literal not in the dictionary)
+        if (k->type != PH_I32) return false;
+        if (op == PH_EQ) { if (k->i >= 0 && k->i <= 255) { P->lo = P->hi = k->i; P->kind = SK_RANGE_U8; } return true; }
+        if (op == PH_NE) { if (k->i >= 0 && k->i <= 255) { P->lo = k->i; P->kind = SK_NE_U8; } else { P->lo = 0; P->hi = 255; P->kind = SK_RANGE_U8; } return true; }
+        return true;
+    case PH_DEC64:
+        if (k->type == PH_F32) {
+            if (op == PH_GT || op == PH_GE || op == PH_LE) {  // FLOAT has no '<', '=' or '!='
+                P->kind = SK_F32_DEC;
+                P->kf = (float)k->f;
+                P->div = 1;
+                for (int i = 0; i < col->scale; i++) P->div *= 10;
+            }
+            return true;
+        }
+        if (k->type == PH_DEC64) {
+            if (op != PH_GT) return true;  // only DECIMAL '>' exists
+            if (k->scale > col->scale) return false;
+            long long v = k->i;
+            for (int i = k->scale; i < col->scale; i++)
+                if (__builtin_mul_overflow(v, 10ll, &v)) return false;
+            if (range(v)) P->kind = SK_RANGE_I64;
+            return true;
+        }
+        return false;
+    case PH_F32:
+        if (k->type != PH_F32) return false;
+        if (op == PH_GT || op == PH_GE || op == PH_LE) { P->kind = SK_F32; P->kf = (float)k->f; }
+        return true;
+    case PH_F64:
+        if (k->type != PH_F64 && k->type != PH_F32) return false;
+        if (op == PH_LT) { P->kind = SK_F64; P->kd = k->f; }
+        return true;
+    case PH_STR:
+        if (k->type != PH_STR || !k->s) return false;
+        if (op != PH_EQ && op != PH_NE && op != PH_LIKE && op != PH_NOTLIKE) return true;
+        P->plen = (int)strlen(k->s);
+        if (P->plen >= (int)sizeof P->pat) return false;
+        memcpy(P->pat, k->s, (size_t)P->plen);
+        P->bytes = (const char *)col->aux;
+        P->kind = SK_STR;
+        return true;
+    default:
+        return false;
+    }
+}
+
+int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev) {
+    scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+}  // namespace ph
+
+extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op,
+                                const ph_const *k, const int32_t *sel_in, int64_t n_in,
+                                int32_t *sel_out, int64_t *n_out) {
+    PH_REQUIRE(ctx && col && k && n_out && n >= 0 && n_in >= 0, "ph_filter_select: bad arguments");
+    PH_REQUIRE(sel_in || n_in == n, "ph_filter_select: without sel_in, n_in must equal n");
+    PH_REQUIRE(n_in == 0 || sel_out, "ph_filter_select: sel_out is NULL");
+    *n_out = 0;
+    if (n_in == 0) return PH_OK;
+    ph::SelParams P;
+    if (!ph::lower_select(col, op, k, &P)) {
+        ph::set_error("ph_filter_select: column type %d with constant type %d is outside the device path", col->type, k->type);
+        return PH_EUNSUPPORTED;
+    }
+    if (P.kind == ph::SK_NEVER) return PH_OK;
+    int64_t nb = (n_in + ph::SEL_CHUNK - 1) / ph::SEL_CHUNK;
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
+    int32_t *counts = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts);
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out);
+    PH_HIP(hipGetLastError());
+    PH_HIP(hipMemcpyAsync(n_out, total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    return PH_OK;
+}
+
+// ------------------------------------------------------------------ gather
+
+namespace ph {
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ src, const int32_t *__restrict__ idx,
+                                                     int64_t n, T *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = src[idx[i]];
+}
+}  // namespace ph
+
+extern "C" int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev, int64_t n, void *out_dev) {
+    PH_REQUIRE(ctx && col && (n == 0 || (idx_dev && out_dev)), "ph_gather: bad arguments");
+    if (n == 0) return PH_OK;
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    switch (ph::type_width(col->type)) {
+    case 1: ph::gather_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)col->data, idx_dev, n, (uint8_t *)out_dev); break;
+    case 4: ph::gather_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t *)col->data, idx_dev, n, (int32_t *)out_dev); break;
+    case 8: ph::gather_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t *)col->data, idx_dev, n, (int64_t *)out_dev); break;
+    default: ph::set_error("ph_gather: column type %d is not fixed width", col->type); return PH_EUNSUPPORTED;
+    }
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+// ------------------------------------------------------------------ partition (multi-GPU shuffle prep)
+// dest = mix64(key) % nparts. Three kernels: per-workgroup histogram (LDS atomics), exclusive scan
+// over [part][block], scatter of row ids. No reference counterpart.
+
+namespace ph {
+
+constexpr int PART_CHUNK = 2048;
+constexpr int PART_MAX = 64;
+
+__device__ __forceinline__ uint64_t part_key(const void *data, int width, int64_t r) {
+    return width == 8 ? (uint64_t)((const int64_t *)data)[r] : (uint64_t)(int64_t)((const int32_t *)data)[r];
+}
+
+__global__ __launch_bounds__(256) void part_hist_kernel(const void *data, int width, const int32_t *sel,
+                                                        int64_t n, int nparts, int nblocks,
+                                                        int32_t *__restrict__ hist /* [part][block] */) {
+    __shared__ int h[PART_MAX];
+    if (threadIdx.x < PART_MAX) h[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * PART_CHUNK;
+    for (int r = 0; r < PART_CHUNK / 256; r++) {
+        int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            int64_t row = sel ? sel[i] : i;
+            int d = (int)(mix64(part_key(data, width, row)) % (uint64_t)nparts);
+            atomicAdd(&h[d], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nparts) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void part_scatter_kernel(const void *data, int width, const int32_t *sel,
+                                                           int64_t n, int nparts, int nblocks,
+                                                           const int32_t *__restrict__ offs,
+                                                           int32_t *__restrict__ perm) {
+    __shared__ int cur[PART_MAX];
+    if (threadIdx.x < nparts) cur[threadIdx.x] = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * PART_CHUNK;
+    for (int r = 0; r < PART_CHUNK / 256; r++) {
+        int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n) {
+            int64_t row = sel ? sel[i] : i;
+            int d = (int)(mix64(part_key(data, width, row)) % (uint64_t)nparts);
+            int pos = atomicAdd(&cur[d], 1);
+            perm[pos] = (int32_t)row;
+        }
+    }
+}
+
+}  // namespace ph
+
+extern "C" int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
+                            int64_t *counts_host, int32_t *perm_dev) {
+    PH_REQUIRE(ctx && key && counts_host && nparts >= 1 && nparts <= ph::PART_MAX && n >= 0,
+               "ph_partition: bad arguments (1 <= nparts <= %d)", ph::PART_MAX);
+    int w = ph::type_width(key->type);
+    PH_REQUIRE(w == 4 || w == 8, "ph_partition: key must be a 32- or 64-bit integer column");
+    PH_REQUIRE(key->validity == nullptr, "ph_partition: NULL-able partition keys are not supported");
+    for (int p = 0; p < nparts; p++) counts_host[p] = 0;
+    if (n == 0) return PH_OK;
+    int64_t nb = (n + ph::PART_CHUNK - 1) / ph::PART_CHUNK;
+    int64_t cells = nb * nparts;
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(cells * 4, 8) + 64));
+    int32_t *hist = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(cells * 4, 8));
+    ph::part_hist_kernel<<<(int)nb, 256, 0, ctx->stream>>>(key->data, w, sel, n, nparts, (int)nb, hist);
+    PH_HIP(hipGetLastError());
+    // first block offset of each partition = exclusive scan over the part-major layout
+    std::vector<int32_t> first((size_t)nparts + 1);
+    PH_CHECK(ph::exclusive_scan_i32(ctx, hist, cells, total));
+    ph::part_scatter_kernel<<<(int)nb, 256, 0, ctx->stream>>>(key->data, w, sel, n, nparts, (int)nb, hist, perm_dev);
+    PH_HIP(hipGetLastError());
+    for (int p = 0; p < nparts; p++)
+        PH_HIP(hipMemcpyAsync(&first[(size_t)p], hist + (int64_t)p * nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PH_HIP(hipStreamSynchronize(ctx->stream));
+    first[(size_t)nparts] = (int32_t)n;
+    for (int p = 0; p < nparts; p++) counts_host[p] = first[(size_t)p + 1] - first[(size_t)p];
+    return PH_OK;
+}

@@ -262,3 +262,172 @@ class ScanPlan:
         if self.h:
             lib().ph_scan_plan_free(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- operator-granular API
+
+class DevColumn:
+    """A device-resident column built from a numpy array (ph_dev_alloc + ph_dev_upload)."""
+
+    def __init__(self, ctx, typ, arr, scale=0, validity=None, aux=None):
+        self.ctx, self.type, self.scale = ctx, typ, scale
+        arr = np.ascontiguousarray(arr)
+        self.n = len(arr) - 1 if typ == PH_STR else len(arr)
+        self.ptrs = []
+        self.data = ctx.upload(arr) if arr.nbytes else ctx.alloc(8)
+        self.ptrs.append(self.data)
+        self.validity = None
+        if validity is not None:
+            self.validity = ctx.upload(np.ascontiguousarray(validity, dtype=np.uint8))
+            self.ptrs.append(self.validity)
+        self.aux, self.aux_bytes = None, 0
+        if aux is not None:
+            aux = np.ascontiguousarray(aux)
+            self.aux = ctx.upload(aux) if aux.nbytes else ctx.alloc(8)
+            self.aux_bytes = aux.nbytes
+            self.ptrs.append(self.aux)
+
+    def col(self):
+        c = Col()
+        c.type, c.scale = self.type, self.scale
+        c.data = self.data
+        c.validity = self.validity
+        c.aux = self.aux
+        c.aux_bytes = self.aux_bytes
+        return c
+
+    def free(self):
+        for p in self.ptrs:
+            self.ctx.free(p)
+        self.ptrs = []
+
+
+def _cols(cols):
+    return (Col * max(len(cols), 1))(*[c.col() if isinstance(c, DevColumn) else c for c in cols])
+
+
+def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None):
+    """Returns (sel_out_dev, count). sel_in: device pointer or None."""
+    if n_in is None:
+        n_in = n
+    out = ctx.alloc(max(n_in, 1) * 4)
+    cnt = i64()
+    c = col.col() if isinstance(col, DevColumn) else col
+    check(lib().ph_filter_select(ctx.h, ctypes.byref(c), i64(n), i32(op), ctypes.byref(k),
+                                 sel_in, i64(n_in), out, ctypes.byref(cnt)))
+    return out, cnt.value
+
+
+def hash_cols(ctx, cols, n, dict_hashes=None):
+    out = ctx.alloc(max(n, 1) * 8)
+    dh = None
+    if dict_hashes is not None:
+        dh = (vp * len(cols))(*[d if d is not None else None for d in dict_hashes])
+    check(lib().ph_hash(ctx.h, _cols(cols), dh, i32(len(cols)), i64(n), out))
+    return out
+
+
+def hash_bytes(b):
+    return int(lib().ph_hash_bytes(ctypes.c_char_p(b), ctypes.c_uint64(len(b))))
+
+
+def expr_scale(cols, prog):
+    p = (Rpn * len(prog))(*[Rpn(*x) for x in prog])
+    s = i32()
+    check(lib().ph_expr_scale(_cols(cols), p, i32(len(prog)), ctypes.byref(s)))
+    return s.value
+
+
+def expr_eval(ctx, cols, prog, sel, n, want_validity=False):
+    p = (Rpn * len(prog))(*[Rpn(*x) for x in prog])
+    out = ctx.alloc(max(n, 1) * 8)
+    val = ctx.alloc((n + 7) // 8 + 8) if want_validity else None
+    check(lib().ph_expr_eval(ctx.h, _cols(cols), i32(len(cols)), p, i32(len(prog)), sel, i64(n),
+                             out, val))
+    return out, val
+
+
+class Agg:
+    def __init__(self, ctx, key_types, aggs, expected_groups=1024):
+        self.ctx = ctx
+        self.nkeys, self.naggs = len(key_types), len(aggs)
+        kt = (i32 * len(key_types))(*key_types)
+        sp = (AggSpec * max(len(aggs), 1))(*[AggSpec(k, a) for k, a in aggs])
+        self.h = vp()
+        check(lib().ph_agg_create(ctx.h, i32(len(key_types)), kt, i32(len(aggs)), sp,
+                                  i64(expected_groups), ctypes.byref(self.h)))
+
+    def sink(self, keys, args, sel, n, positional=False, row_base=0):
+        check(lib().ph_agg_sink(self.h, _cols(keys), _cols(args), i32(len(args)), sel, i64(n),
+                                i32(1 if positional else 0), i64(row_base)))
+
+    def group_count(self):
+        n = i64()
+        check(lib().ph_agg_group_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    def finalize(self):
+        ng = self.group_count()
+        m = max(ng, 1)
+        first = np.zeros(m, np.int64)
+        keys = np.zeros(m * self.nkeys, np.int64)
+        knull = np.zeros(m * self.nkeys, np.uint8)
+        na = max(self.naggs, 1)
+        lo = np.zeros(m * na, np.uint64)
+        hi = np.zeros(m * na, np.int64)
+        cnt = np.zeros(m * na, np.uint64)
+        P = lambda a: vp(a.ctypes.data)
+        check(lib().ph_agg_finalize(self.h, i64(m), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt)))
+        sums = [[(int(hi[g * na + a]) << 64) + int(lo[g * na + a]) for a in range(self.naggs)]
+                for g in range(ng)]
+        return dict(ngroups=ng, first_row=first[:ng], keys=keys.reshape(m, self.nkeys)[:ng],
+                    key_null=knull.reshape(m, self.nkeys)[:ng], sum=sums,
+                    count=cnt.reshape(m, na)[:ng, :self.naggs].astype(np.int64))
+
+    def free(self):
+        if self.h:
+            lib().ph_agg_free(self.h)
+            self.h = None
+
+
+class Join:
+    def __init__(self, ctx, keys, sel, n):
+        self.ctx = ctx
+        self.h = vp()
+        check(lib().ph_join_build(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), ctypes.byref(self.h)))
+
+    def count(self):
+        return int(lib().ph_join_count(self.h))
+
+    def probe_inner(self, keys, sel, n, cap):
+        op = self.ctx.alloc(max(cap, 1) * 4)
+        ob = self.ctx.alloc(max(cap, 1) * 4)
+        m = i64()
+        check(lib().ph_join_probe_inner(self.h, _cols(keys), sel, i64(n), op, ob, i64(cap), ctypes.byref(m)))
+        return m.value, op, ob
+
+    def probe_mark(self, keys, sel, n):
+        f = self.ctx.alloc(max(n, 1))
+        check(lib().ph_join_probe_mark(self.h, _cols(keys), sel, i64(n), f))
+        return f
+
+    def free(self):
+        if self.h:
+            lib().ph_join_free(self.h)
+            self.h = None
+
+
+def gather(ctx, col, idx_dev, n):
+    c = col.col() if isinstance(col, DevColumn) else col
+    w = {PH_CODE8: 1, PH_I32: 4, PH_DATE: 4, PH_F32: 4}.get(c.type, 8)
+    out = ctx.alloc(max(n, 1) * w)
+    check(lib().ph_gather(ctx.h, ctypes.byref(c), idx_dev, i64(n), out))
+    return out
+
+
+def partition(ctx, key, sel, n, nparts):
+    c = key.col() if isinstance(key, DevColumn) else key
+    counts = (i64 * nparts)()
+    perm = ctx.alloc(max(n, 1) * 4)
+    check(lib().ph_partition(ctx.h, ctypes.byref(c), sel, i64(n), i32(nparts), counts, perm))
+    return [counts[p] for p in range(nparts)], perm

@@ -1,0 +1,78 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/planhip.h declares,
+the generator library likewise, and the host-only entry points agree with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import oracle_lib as O
+from plan_amd import hip, tpchgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text)))
+
+
+def test_planhip_exports_every_declared_symbol():
+    lib = hip.lib()
+    names = declared("planhip.h", "ph_")
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"libplanhip.so does not export {n}"
+
+
+def test_tpchgen_exports_every_declared_symbol():
+    lib = tpchgen.lib()
+    for n in declared("tpchgen.h", "tpchgen_"):
+        assert hasattr(lib, n), f"libtpchgen.so does not export {n}"
+
+
+def test_errors_are_codes_not_aborts():
+    lib = hip.lib()
+    rc = lib.ph_ctx_sync(None)
+    assert rc == hip.PH_EINVAL and b"ctx is NULL" in lib.ph_last_error()
+    rc = lib.ph_table_col(None, 0, None)
+    assert rc == hip.PH_EINVAL
+
+
+def test_hash_bytes_matches_reference_hashbytes():
+    # util.HashBytes restated twice (oracle C, product C++): must agree on every length class
+    rng = np.random.default_rng(0)
+    for ln in list(range(0, 40)) + [63, 64, 65, 200]:
+        b = bytes(rng.integers(0, 256, ln, dtype=np.uint8))
+        off = np.array([0, ln], dtype=np.int32)
+        arr = np.frombuffer(b, dtype=np.uint8) if ln else np.zeros(1, np.uint8)
+        want = int(O.hash_cols([O.col(O.OT_VARCHAR, off, dictionary=arr)], 1)[0])
+        assert hip.hash_bytes(b) == want
+
+
+def test_expr_scale_follows_binder_rules():
+    c = hip.Col(); c.type, c.scale = hip.PH_DEC64, 2
+    q = hip.Col(); q.type, q.scale = hip.PH_I32, 0
+    cols = [c, c, c, q]
+    one = hip.X_CONST(1)
+    dp = [hip.X_COL(0), one, hip.X_COL(1), hip.X_SUB, hip.X_MUL]
+    assert hip.expr_scale(cols, dp) == 4                      # Mul: 2 + max(0, 2)
+    assert hip.expr_scale(cols, dp + [one, hip.X_COL(2), hip.X_ADD, hip.X_MUL]) == 6
+    assert hip.expr_scale(cols, dp + [hip.X_COL(2), hip.X_COL(3), hip.X_MUL, hip.X_SUB]) == 4
+    try:
+        hip.expr_scale(cols, [hip.X_COL(0), hip.X_MUL])
+        assert False
+    except hip.PlanHipError as e:
+        assert e.code == hip.PH_EUNSUPPORTED
+
+
+def test_generator_shards_equal_whole():
+    """ranged generation (what each rank does) reproduces the same rows as one pass"""
+    sf = (1, 100)
+    whole = tpchgen.lineitem(sf)
+    n_orders = tpchgen.orders_count(sf)
+    parts = [tpchgen.lineitem(sf, a, b - a) for a, b in [(0, 1), (1, 5000), (5000, 5003), (5003, n_orders)]]
+    for k in whole:
+        assert np.array_equal(whole[k], np.concatenate([p[k] for p in parts])), k
+    assert len(whole["l_orderkey"]) == 60175   # SF0.01 lineitem cardinality

@@ -1,0 +1,503 @@
+"""GPU parity of the operator-granular kernels (filter, hash, expressions, hash aggregate, hash
+join, gather, partition) against the oracle, through the C-ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plan_amd import hip, tpchgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+def rnd_validity(rng, n, p_null):
+    bits = rng.random(n) >= p_null
+    return np.packbits(bits, bitorder="little"), bits
+
+
+def dl(ctx, p, dtype, n):
+    return ctx.download(p, dtype, n) if n else np.empty(0, dtype)
+
+
+# ------------------------------------------------------------------ filter
+
+SEL_CASES = [
+    # (hip type, oracle type, scale, generator, [(op, hip const, oracle const)])
+    ("i32", hip.PH_I32, O.OT_INT32, 0),
+    ("date", hip.PH_DATE, O.OT_DATE, 0),
+    ("dec_float", hip.PH_DEC64, O.OT_DECIMAL, 2),
+    ("dec_dec", hip.PH_DEC64, O.OT_DECIMAL, 2),
+    ("i64", hip.PH_I64, O.OT_INT64, 0),
+]
+
+
+@pytest.mark.parametrize("name,ht,ot,scale", SEL_CASES)
+@pytest.mark.parametrize("n", [1, 63, 2048, 70001])
+def test_filter_select_all_ops(ctx, name, ht, ot, scale, n):
+    rng = np.random.default_rng(n * 7 + len(name))
+    if name in ("i32", "date"):
+        data = rng.integers(8000, 8100, n).astype(np.int32)
+        hk = lambda: hip.const(ht, i=8050)
+        ok = lambda: O.const(ot, i=8050)
+    elif name == "dec_float":
+        data = rng.integers(-2, 12, n).astype(np.int64)
+        kf = float(np.float32(0.03) + np.float32(0.01))
+        hk = lambda: hip.const(hip.PH_F32, f=kf)
+        ok = lambda: O.const(O.OT_FLOAT, f=kf)
+    elif name == "dec_dec":
+        data = rng.integers(0, 1000, n).astype(np.int64)
+        hk = lambda: hip.const(hip.PH_DEC64, i=5, scale=0)   # 5 == 5.00
+        ok = lambda: O.const(O.OT_DECIMAL, i=500, scale=2)
+    else:
+        data = rng.integers(0, 100, n).astype(np.int64)
+        hk = lambda: hip.const(hip.PH_I64, i=50)
+        ok = lambda: O.const(O.OT_INT64, i=50)
+    vbytes, _ = rnd_validity(rng, n, 0.1)
+    d = hip.DevColumn(ctx, ht, data, scale, validity=vbytes)
+    oc = O.col(ot, data, scale, validity=vbytes)
+    for op in (hip.PH_EQ, hip.PH_NE, hip.PH_LT, hip.PH_LE, hip.PH_GT, hip.PH_GE):
+        try:
+            sel, cnt = hip.filter_select(ctx, d, n, op, hk())
+        except hip.PlanHipError as e:
+            assert e.code == hip.PH_EUNSUPPORTED
+            continue
+        want = O.select(oc, op, ok(), n=n)   # includes "this (type, op) selects nothing" cases
+        got = dl(ctx, sel, np.int32, cnt)
+        assert cnt == len(want), (name, op)
+        assert np.array_equal(got.astype(np.int64), want), (name, op)
+        ctx.free(sel)
+    d.free()
+
+
+def test_filter_and_chain_and_strings(ctx, sf001):
+    L = sf001["lineitem"]
+    n = len(L["l_shipdate"])
+    ship = hip.DevColumn(ctx, hip.PH_DATE, L["l_shipdate"])
+    disc = hip.DevColumn(ctx, hip.PH_DEC64, L["l_discount"], 2)
+    qty = hip.DevColumn(ctx, hip.PH_I32, L["l_quantity"])
+    d1, d2 = tpchgen.days(1994, 1, 1), tpchgen.days(1995, 1, 1)
+    lo = float(np.float32(0.03) - np.float32(0.01))
+    hi_ = float(np.float32(0.03) + np.float32(0.01))
+    s1, c1 = hip.filter_select(ctx, ship, n, hip.PH_GE, hip.const(hip.PH_DATE, i=d1))
+    s2, c2 = hip.filter_select(ctx, ship, n, hip.PH_LT, hip.const(hip.PH_DATE, i=d2), s1, c1)
+    s3, c3 = hip.filter_select(ctx, disc, n, hip.PH_GE, hip.const(hip.PH_F32, f=lo), s2, c2)
+    s4, c4 = hip.filter_select(ctx, disc, n, hip.PH_LE, hip.const(hip.PH_F32, f=hi_), s3, c3)
+    s5, c5 = hip.filter_select(ctx, qty, n, hip.PH_LT, hip.const(hip.PH_I32, i=24), s4, c4)
+    w = O.select(O.col(O.OT_DATE, L["l_shipdate"]), O.OP_GE, O.const(O.OT_DATE, i=d1), n=n)
+    w = O.select(O.col(O.OT_DATE, L["l_shipdate"]), O.OP_LT, O.const(O.OT_DATE, i=d2), w)
+    w = O.select(O.col(O.OT_DECIMAL, L["l_discount"], 2), O.OP_GE, O.const(O.OT_FLOAT, f=lo), w)
+    w = O.select(O.col(O.OT_DECIMAL, L["l_discount"], 2), O.OP_LE, O.const(O.OT_FLOAT, f=hi_), w)
+    w = O.select(O.col(O.OT_INT32, L["l_quantity"]), O.OP_LT, O.const(O.OT_INT32, i=24), w)
+    assert c5 == len(w) and np.array_equal(dl(ctx, s5, np.int32, c5).astype(np.int64), w)
+    # strings: LIKE / NOT LIKE / = / != over offsets + bytes
+    P = sf001["part"]
+    npart = len(P["p_partkey"])
+    name = hip.DevColumn(ctx, hip.PH_STR, P["p_name_off"], aux=P["p_name_bytes"])
+    oname = O.col(O.OT_VARCHAR, P["p_name_off"], dictionary=P["p_name_bytes"])
+    first = bytes(P["p_name_bytes"][P["p_name_off"][0]:P["p_name_off"][1]]).decode()
+    for op, pat in [(hip.PH_LIKE, "%pink%"), (hip.PH_NOTLIKE, "%pink%"), (hip.PH_LIKE, "%"),
+                    (hip.PH_LIKE, "a%e_ %"), (hip.PH_LIKE, ""), (hip.PH_EQ, first), (hip.PH_NE, first),
+                    (hip.PH_LIKE, "%ss__%")]:
+        s, c = hip.filter_select(ctx, name, npart, op, hip.const(hip.PH_STR, s=pat))
+        want = O.select(oname, op, O.const(O.OT_VARCHAR, s=pat), n=npart)
+        assert c == len(want), (op, pat)
+        assert np.array_equal(dl(ctx, s, np.int32, c).astype(np.int64), want)
+        ctx.free(s)
+    for d in (ship, disc, qty, name):
+        d.free()
+
+
+def test_filter_dictionary_code_equality(ctx, sf001):
+    C = sf001["customer"]
+    n = len(C["c_custkey"])
+    seg = hip.DevColumn(ctx, hip.PH_CODE8, C["c_mktsegment"])
+    oseg = O.col(O.OT_CODE8, C["c_mktsegment"], dictionary=O.cdict(O.SEG))
+    for op in (hip.PH_EQ, hip.PH_NE):
+        for lit in ("HOUSEHOLD", "NOPE"):
+            code = O.SEG.index(lit) if lit in O.SEG else 999
+            s, c = hip.filter_select(ctx, seg, n, op, hip.const(hip.PH_I32, i=code))
+            want = O.select(oseg, op, O.const(O.OT_VARCHAR, s=lit), n=n)
+            assert c == len(want) and np.array_equal(dl(ctx, s, np.int32, c).astype(np.int64), want)
+            ctx.free(s)
+    seg.free()
+
+
+# ------------------------------------------------------------------ hash
+
+def test_hash_bit_identical(ctx):
+    n = 50000
+    rng = np.random.default_rng(3)
+    i32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    i64 = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    date = rng.integers(-30000, 60000, n).astype(np.int32)
+    dec = (rng.integers(-10**9, 10**9, n) * rng.choice([1, 10, 100, 1000], n)).astype(np.int64)
+    dec[:5] = [0, 100, -100, 1050, -7]
+    code = rng.integers(0, 3, n).astype(np.uint8)
+    v, _ = rnd_validity(rng, n, 0.05)
+    dh = np.array([hip.hash_bytes(s.encode()) for s in O.RF], dtype=np.uint64)
+    dh_dev = ctx.upload(dh)
+    specs = [
+        [(hip.PH_I32, O.OT_INT32, i32, 0, None)],
+        [(hip.PH_I64, O.OT_INT64, i64, 0, v)],
+        [(hip.PH_DATE, O.OT_DATE, date, 0, None)],
+        [(hip.PH_DEC64, O.OT_DECIMAL, dec, 4, None)],
+        [(hip.PH_CODE8, O.OT_CODE8, code, 0, None)],
+        [(hip.PH_I64, O.OT_INT64, i64, 0, None), (hip.PH_DATE, O.OT_DATE, date, 0, v),
+         (hip.PH_I32, O.OT_INT32, i32, 0, None), (hip.PH_CODE8, O.OT_CODE8, code, 0, None)],
+    ]
+    for spec in specs:
+        dcols = [hip.DevColumn(ctx, ht, a, sc, validity=val) for ht, _, a, sc, val in spec]
+        ocols = [O.col(ot, a, sc, validity=val, dictionary=O.cdict(O.RF) if ot == O.OT_CODE8 else None)
+                 for _, ot, a, sc, val in spec]
+        dhs = [dh_dev if ht == hip.PH_CODE8 else None for ht, *_ in spec]
+        out = hip.hash_cols(ctx, dcols, n, dhs)
+        got = ctx.download(out, np.uint64, n)
+        want = O.hash_cols(ocols, n)
+        assert np.array_equal(got, want)
+        ctx.free(out)
+        for d in dcols:
+            d.free()
+    # strings
+    words = ["", "a", "pink", "12345678", "123456789abcdef", "hello world, this is longer than 16"]
+    off = np.zeros(len(words) + 1, np.int32)
+    off[1:] = np.cumsum([len(w) for w in words])
+    b = np.frombuffer("".join(words).encode(), dtype=np.uint8)
+    sc = hip.DevColumn(ctx, hip.PH_STR, off, aux=b)
+    out = hip.hash_cols(ctx, [sc], len(words))
+    got = ctx.download(out, np.uint64, len(words))
+    want = O.hash_cols([O.col(O.OT_VARCHAR, off, dictionary=b)], len(words))
+    assert np.array_equal(got, want)
+    assert [int(x) for x in got] == [hip.hash_bytes(w.encode()) for w in words]
+    sc.free()
+
+
+# ------------------------------------------------------------------ expressions
+
+def test_expr_eval_matches_decimal_semantics(ctx):
+    n = 30000
+    rng = np.random.default_rng(11)
+    ext = rng.integers(90000, 10500000, n).astype(np.int64)
+    disc = rng.integers(0, 11, n).astype(np.int64)
+    tax = rng.integers(0, 9, n).astype(np.int64)
+    qty = rng.integers(1, 51, n).astype(np.int32)
+    cost = rng.integers(100, 100001, n).astype(np.int64)
+    sel = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+    dcols = [hip.DevColumn(ctx, hip.PH_DEC64, ext, 2), hip.DevColumn(ctx, hip.PH_DEC64, disc, 2),
+             hip.DevColumn(ctx, hip.PH_DEC64, tax, 2), hip.DevColumn(ctx, hip.PH_I32, qty),
+             hip.DevColumn(ctx, hip.PH_DEC64, cost, 2)]
+    ocols = [O.col(O.OT_DECIMAL, ext, 2), O.col(O.OT_DECIMAL, disc, 2), O.col(O.OT_DECIMAL, tax, 2),
+             O.col(O.OT_INT32, qty), O.col(O.OT_DECIMAL, cost, 2)]
+    progs = {
+        "disc_price": ([hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL],
+                       [(O.OX_COL, 0, 0, 0), (O.OX_CONST_INT, 0, 1, 0), (O.OX_COL, 1, 0, 0),
+                        (O.OX_SUB, 0, 0, 0), (O.OX_MUL, 0, 0, 0)], 4),
+        "charge": ([hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL, hip.X_CONST(1),
+                    hip.X_COL(2), hip.X_ADD, hip.X_MUL],
+                   [(O.OX_COL, 0, 0, 0), (O.OX_CONST_INT, 0, 1, 0), (O.OX_COL, 1, 0, 0), (O.OX_SUB, 0, 0, 0),
+                    (O.OX_MUL, 0, 0, 0), (O.OX_CONST_INT, 0, 1, 0), (O.OX_COL, 2, 0, 0), (O.OX_ADD, 0, 0, 0),
+                    (O.OX_MUL, 0, 0, 0)], 6),
+        "q9_amount": ([hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL, hip.X_COL(4),
+                       hip.X_COL(3), hip.X_MUL, hip.X_SUB],
+                      [(O.OX_COL, 0, 0, 0), (O.OX_CONST_INT, 0, 1, 0), (O.OX_COL, 1, 0, 0), (O.OX_SUB, 0, 0, 0),
+                       (O.OX_MUL, 0, 0, 0), (O.OX_COL, 4, 0, 0), (O.OX_COL, 3, 0, 0), (O.OX_MUL, 0, 0, 0),
+                       (O.OX_SUB, 0, 0, 0)], 4),
+    }
+    sel_dev = ctx.upload(sel)
+    for name, (hp, op, scale) in progs.items():
+        assert hip.expr_scale(dcols, hp) == scale
+        for s_dev, s_np, m in ((None, None, n), (sel_dev, sel.astype(np.int64), len(sel))):
+            out, _ = hip.expr_eval(ctx, dcols, hp, s_dev, m)
+            got = ctx.download(out, np.int64, m)
+            rc, want = O.eval_decimal(ocols, op, s_np, m)
+            assert rc == 0
+            assert [int(x) for x in got] == O.odec_unscaled(want, scale), name
+            ctx.free(out)
+    # overflow is detected, not wrapped
+    big = hip.DevColumn(ctx, hip.PH_DEC64, np.full(100, 4_000_000_000, np.int64), 2)
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.expr_eval(ctx, [big], [hip.X_COL(0), hip.X_COL(0), hip.X_MUL, hip.X_COL(0), hip.X_MUL], None, 100)
+    assert e.value.code == hip.PH_EOVERFLOW
+    # NULL in -> NULL out
+    v, bits = rnd_validity(rng, n, 0.2)
+    dn = hip.DevColumn(ctx, hip.PH_DEC64, disc, 2, validity=v)
+    out, val = hip.expr_eval(ctx, [dcols[0], dn], [hip.X_COL(0), hip.X_COL(1), hip.X_MUL], None, n, True)
+    gv = np.unpackbits(ctx.download(val, np.uint8, (n + 7) // 8), bitorder="little")[:n].astype(bool)
+    assert np.array_equal(gv, bits)
+    got = ctx.download(out, np.int64, n)
+    assert np.array_equal(got[bits], (ext * disc)[bits])
+    for d in dcols + [big, dn]:
+        d.free()
+
+
+# ------------------------------------------------------------------ hash aggregate
+
+def agg_compare(ctx, key_specs, arg_specs, aggs, n, sel=None, expected=16):
+    """key_specs/arg_specs: (hip type, oracle type, array, scale, validity)"""
+    dk = [hip.DevColumn(ctx, ht, a, sc, validity=v) for ht, _, a, sc, v in key_specs]
+    da = [hip.DevColumn(ctx, ht, a, sc, validity=v) for ht, _, a, sc, v in arg_specs]
+    ok = [O.col(ot, a, sc, validity=v, dictionary=O.cdict([str(i) for i in range(256)]) if ot == O.OT_CODE8 else None)
+          for _, ot, a, sc, v in key_specs]
+    # oracle args: decimals go in as ODEC arrays evaluated from the unscaled column
+    oa = []
+    keep = []
+    for _, ot, a, sc, v in arg_specs:
+        if ot == O.OT_DECIMAL:
+            rc, od = O.eval_decimal([O.col(O.OT_DECIMAL, a, sc)], [(O.OX_COL, 0, 0, 0)], None, len(a))
+            keep.append(od)
+            oa.append(O.col(O.OT_ODEC, od, validity=v))
+        else:
+            oa.append(O.col(ot, a, sc, validity=v))
+    agg = hip.Agg(ctx, [ht for ht, *_ in key_specs], aggs, expected)
+    sel_dev = ctx.upload(sel.astype(np.int32)) if sel is not None else None
+    m = len(sel) if sel is not None else n
+    agg.sink(dk, da, sel_dev, m)
+    r = agg.finalize()
+    oaggs = [(k if k != hip.PH_A_COUNT_STAR else O.OA_COUNT, a if k != hip.PH_A_COUNT_STAR else -1) for k, a in aggs]
+    ng, first, gk, gn, vals = O.groupby(ok, oa, oaggs, None if sel is None else sel.astype(np.int64), m,
+                                        max(r["ngroups"], 1) + 8)
+    assert r["ngroups"] == ng
+    # The device emits groups in strict first-seen order. The reference's insertion order is the
+    # same except where linear-probe collisions inside one 2048-row chunk defer an earlier row to
+    # a later probing round (FindOrCreateGroups :272-388), so groups are matched by key here and
+    # the first-seen row of every group is compared instead of the ordinal.
+    assert np.all(np.diff(r["first_row"]) > 0)
+    def keyof(nulls, vals_):
+        return tuple(None if nulls[c] else int(vals_[c]) for c in range(len(key_specs)))
+    gpu_index = {keyof(r["key_null"][g], r["keys"][g]): g for g in range(ng)}
+    assert len(gpu_index) == ng
+    for og in range(ng):
+        g = gpu_index[keyof(gn[og], gk[og])]
+        pos = int(r["first_row"][g])
+        assert (int(sel[pos]) if sel is not None else pos) == int(first[og])
+        for a, (kind, ai) in enumerate(aggs):
+            v = vals[og * len(aggs) + a]
+            cnt = int(r["count"][g][a])
+            if v.kind == O.OV_NULL:
+                assert cnt == 0
+                continue
+            scale = arg_specs[ai][3] if ai >= 0 else 0
+            if kind in (hip.PH_A_COUNT, hip.PH_A_COUNT_STAR):
+                assert cnt == v.h.value()
+            elif kind == hip.PH_A_SUM:
+                want = v.h.value() if v.kind == O.OV_HUGEINT else v.d.unscaled(scale)
+                assert r["sum"][g][a] == want
+            elif kind == hip.PH_A_AVG:
+                if v.kind == O.OV_DOUBLE:
+                    assert abs(r["sum"][g][a] / cnt - v.f) <= 1e-9 * max(abs(v.f), 1e-300)
+                else:  # decimal: sum/count compared exactly via cross-multiplication to 19 digits
+                    from fractions import Fraction
+                    exact = Fraction(r["sum"][g][a], cnt * 10 ** scale)
+                    got = Fraction(int(v.d.coef) * (-1 if v.d.neg else 1), 10 ** int(v.d.scale))
+                    assert abs(exact - got) <= abs(exact) * Fraction(1, 10 ** 18) + Fraction(1, 10 ** 19)
+            else:  # MIN / MAX
+                s = r["sum"][g][a]
+                assert s == v.d.unscaled(scale)
+    agg.free()
+    for d in dk + da:
+        d.free()
+    return r
+
+
+def test_agg_q3_like_keys(ctx):
+    rng = np.random.default_rng(5)
+    n = 200_000
+    okey = rng.integers(1, 40_000, n).astype(np.int64)
+    odate = (8000 + okey % 700).astype(np.int32)
+    prio = np.zeros(n, np.int32)
+    rev = rng.integers(-10**9, 10**11, n).astype(np.int64)
+    agg_compare(ctx,
+                [(hip.PH_I64, O.OT_INT64, okey, 0, None), (hip.PH_DATE, O.OT_DATE, odate, 0, None),
+                 (hip.PH_I32, O.OT_INT32, prio, 0, None)],
+                [(hip.PH_DEC64, O.OT_DECIMAL, rev, 4, None)],
+                [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1), (hip.PH_A_AVG, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 0)],
+                n)
+
+
+def test_agg_nulls_and_selection(ctx):
+    rng = np.random.default_rng(6)
+    n = 50_000
+    k0 = rng.integers(0, 7, n).astype(np.int32)
+    k1 = rng.integers(0, 3, n).astype(np.uint8)
+    q = rng.integers(-50, 51, n).astype(np.int32)
+    d = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    vk, _ = rnd_validity(rng, n, 0.1)
+    vq, _ = rnd_validity(rng, n, 0.3)
+    vd, _ = rnd_validity(rng, n, 0.3)
+    sel = np.sort(rng.choice(n, n // 2, replace=False))
+    for s in (None, sel):
+        agg_compare(ctx,
+                    [(hip.PH_I32, O.OT_INT32, k0, 0, vk), (hip.PH_CODE8, O.OT_CODE8, k1, 0, None)],
+                    [(hip.PH_I32, O.OT_INT32, q, 0, vq), (hip.PH_DEC64, O.OT_DECIMAL, d, 2, vd)],
+                    [(hip.PH_A_SUM, 0), (hip.PH_A_AVG, 0), (hip.PH_A_COUNT, 0), (hip.PH_A_SUM, 1),
+                     (hip.PH_A_AVG, 1), (hip.PH_A_MIN, 1), (hip.PH_A_MAX, 1), (hip.PH_A_COUNT_STAR, -1)],
+                    n, sel=s)
+
+
+def test_agg_many_groups_grows_table(ctx):
+    rng = np.random.default_rng(8)
+    n = 600_000
+    k = rng.integers(0, 300_000, n).astype(np.int64)   # ~260k groups from a 4096-slot start
+    v = rng.integers(0, 10**6, n).astype(np.int64)
+    r = agg_compare(ctx, [(hip.PH_I64, O.OT_INT64, k, 0, None)], [(hip.PH_DEC64, O.OT_DECIMAL, v, 2, None)],
+                    [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], n, expected=16)
+    assert r["ngroups"] == len(np.unique(k))
+
+
+def test_agg_single_hot_group_and_empty(ctx):
+    n = 300_000
+    k = np.zeros(n, np.int32)
+    v = np.full(n, 2**40, np.int64)   # sum needs more than 64 bits? 3e5 * 2^40 < 2^63; use 128-bit anyway
+    r = agg_compare(ctx, [(hip.PH_I32, O.OT_INT32, k, 0, None)], [(hip.PH_DEC64, O.OT_DECIMAL, v, 0, None)],
+                    [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], n)
+    assert r["ngroups"] == 1 and r["sum"][0][0] == n * 2**40
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_COUNT_STAR, -1)])
+    assert agg.finalize()["ngroups"] == 0
+    agg.free()
+
+
+def test_agg_128bit_sums(ctx):
+    """sums beyond int64: 128-bit accumulation must carry and borrow exactly"""
+    n = 4096
+    k = (np.arange(n) % 2).astype(np.int32)
+    v = np.where(np.arange(n) % 4 < 2, 2**62, -(2**62)).astype(np.int64)
+    v[0] = 2**62 + 12345
+    dk = hip.DevColumn(ctx, hip.PH_I32, k)
+    dv = hip.DevColumn(ctx, hip.PH_I64, v)
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_SUM, 0)])
+    agg.sink([dk], [dv], None, n)
+    r = agg.finalize()
+    for g in range(2):
+        assert r["sum"][g][0] == int(v[k == r["keys"][g][0]].astype(object).sum())
+    agg.free(); dk.free(); dv.free()
+
+
+# ------------------------------------------------------------------ hash join
+
+def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None):
+    """bkeys/pkeys: lists of (hip type, oracle type, array, validity)"""
+    db = [hip.DevColumn(ctx, ht, a, validity=v) for ht, _, a, v in bkeys]
+    dp = [hip.DevColumn(ctx, ht, a, validity=v) for ht, _, a, v in pkeys]
+    ob = [O.col(ot, a, validity=v) for _, ot, a, v in bkeys]
+    op = [O.col(ot, a, validity=v) for _, ot, a, v in pkeys]
+    nb, np_ = len(bkeys[0][2]), len(pkeys[0][2])
+    bs = ctx.upload(bsel.astype(np.int32)) if bsel is not None else None
+    ps = ctx.upload(psel.astype(np.int32)) if psel is not None else None
+    mb = len(bsel) if bsel is not None else nb
+    mp = len(psel) if psel is not None else np_
+    j = hip.Join(ctx, db, bs, mb)
+    oj = O.Join(ob, None if bsel is None else bsel.astype(np.int64), mb)
+    assert j.count() == oj.count()
+    cap = 1 << 22
+    m, opr, obd = j.probe_inner(dp, ps, mp, cap)
+    wm, wp, wb = oj.probe_inner(op, None if psel is None else psel.astype(np.int64), mp, cap)
+    assert m == wm
+    got = np.stack([dl(ctx, opr, np.int32, m), dl(ctx, obd, np.int32, m)], 1).astype(np.int64)
+    want = np.stack([wp, wb], 1)
+    # bit-exact row SET: same pairs; order differs (the reference emits per chain round)
+    assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))])
+    assert np.all(np.diff(got[:, 0]) >= 0) if psel is None else True   # device order: by probe row
+    f = j.probe_mark(dp, ps, mp)
+    gf = dl(ctx, f, np.uint8, mp)
+    wf = oj.probe_mark(op, None if psel is None else psel.astype(np.int64), mp)
+    assert np.array_equal(gf, wf)
+    j.free()
+    for d in db + dp:
+        d.free()
+    return m
+
+
+def test_join_unique_and_duplicate_keys(ctx):
+    rng = np.random.default_rng(21)
+    b = rng.permutation(200_000)[:120_000].astype(np.int64)           # unique build keys
+    p = rng.integers(0, 250_000, 400_000).astype(np.int64)
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)])
+    bd = rng.integers(0, 5000, 40_000).astype(np.int32)               # ~8 duplicates per key
+    pd_ = rng.integers(0, 6000, 30_000).astype(np.int32)
+    m = join_compare(ctx, [(hip.PH_I32, O.OT_INT32, bd, None)], [(hip.PH_I32, O.OT_INT32, pd_, None)])
+    assert m > 100_000
+
+
+def test_join_composite_nulls_selections_empty(ctx):
+    rng = np.random.default_rng(22)
+    nb, np_ = 30_000, 50_000
+    b0 = rng.integers(0, 300, nb).astype(np.int32); b1 = rng.integers(0, 40, nb).astype(np.int32)
+    p0 = rng.integers(0, 320, np_).astype(np.int32); p1 = rng.integers(0, 44, np_).astype(np.int32)
+    vb, _ = rnd_validity(rng, nb, 0.1)
+    vp, _ = rnd_validity(rng, np_, 0.1)
+    bsel = np.sort(rng.choice(nb, nb // 2, replace=False))
+    psel = np.sort(rng.choice(np_, np_ // 3, replace=False))
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, b0, vb), (hip.PH_I32, O.OT_INT32, b1, None)],
+                 [(hip.PH_I32, O.OT_INT32, p0, None), (hip.PH_I32, O.OT_INT32, p1, vp)], bsel, psel)
+    # nothing matches / empty build
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, np.arange(10, dtype=np.int32), None)],
+                 [(hip.PH_I32, O.OT_INT32, np.arange(100, 200, dtype=np.int32), None)])
+    j = hip.Join(ctx, [hip.DevColumn(ctx, hip.PH_I32, np.zeros(1, np.int32))], None, 0)
+    assert j.count() == 0
+    j.free()
+
+
+def test_q3_pipeline_operator_granular(ctx, sf001):
+    """Q3 assembled from the operator kernels: filter -> join -> join -> expr -> group by."""
+    L, Od, C = sf001["lineitem"], sf001["orders"], sf001["customer"]
+    date = tpchgen.days(1995, 3, 29)
+    nl, no, nc = len(L["l_orderkey"]), len(Od["o_orderkey"]), len(C["c_custkey"])
+    seg = hip.DevColumn(ctx, hip.PH_CODE8, C["c_mktsegment"])
+    ck = hip.DevColumn(ctx, hip.PH_I32, C["c_custkey"])
+    oc = hip.DevColumn(ctx, hip.PH_I32, Od["o_custkey"]); od = hip.DevColumn(ctx, hip.PH_DATE, Od["o_orderdate"])
+    ok = hip.DevColumn(ctx, hip.PH_I64, Od["o_orderkey"]); osp = hip.DevColumn(ctx, hip.PH_I32, Od["o_shippriority"])
+    lk = hip.DevColumn(ctx, hip.PH_I64, L["l_orderkey"]); ls = hip.DevColumn(ctx, hip.PH_DATE, L["l_shipdate"])
+    le = hip.DevColumn(ctx, hip.PH_DEC64, L["l_extendedprice"], 2); ld = hip.DevColumn(ctx, hip.PH_DEC64, L["l_discount"], 2)
+    cs, cn = hip.filter_select(ctx, seg, nc, hip.PH_EQ, hip.const(hip.PH_I32, i=O.SEG.index("HOUSEHOLD")))
+    j1 = hip.Join(ctx, [ck], cs, cn)
+    os_, on = hip.filter_select(ctx, od, no, hip.PH_LT, hip.const(hip.PH_DATE, i=date))
+    m1, p1, _b1 = j1.probe_inner([oc], os_, on, on)
+    j2 = hip.Join(ctx, [ok], p1, m1)            # build on the surviving orders rows
+    lsel, ln = hip.filter_select(ctx, ls, nl, hip.PH_GT, hip.const(hip.PH_DATE, i=date))
+    m2, lrow, orow = j2.probe_inner([lk], lsel, ln, ln)
+    rev, _ = hip.expr_eval(ctx, [le, ld], [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL], lrow, m2)
+    gk = hip.gather(ctx, lk, lrow, m2); gd = hip.gather(ctx, od, orow, m2); gp = hip.gather(ctx, osp, orow, m2)
+    mk = lambda t, p, sc=0: hip.Col(t, sc, p, None, None, 0)
+    agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_DATE, hip.PH_I32], [(hip.PH_A_SUM, 0)], 1024)
+    agg.sink([mk(hip.PH_I64, gk), mk(hip.PH_DATE, gd), mk(hip.PH_I32, gp)], [mk(hip.PH_DEC64, rev, 4)], None, m2,
+             positional=True)
+    r = agg.finalize()
+    n, rows = O.q3(sf001, "HOUSEHOLD", date)
+    want = {(rows[i].l_orderkey, rows[i].o_orderdate, rows[i].o_shippriority): rows[i].revenue.unscaled(4)
+            for i in range(n)}
+    got = {tuple(int(x) for x in r["keys"][g]): r["sum"][g][0] for g in range(r["ngroups"])}
+    assert got == want and n > 50
+
+
+# ------------------------------------------------------------------ gather / partition
+
+def test_gather_and_partition(ctx):
+    rng = np.random.default_rng(31)
+    n = 100_000
+    for ht, dt in ((hip.PH_CODE8, np.uint8), (hip.PH_I32, np.int32), (hip.PH_I64, np.int64)):
+        a = rng.integers(0, 200, n).astype(dt)
+        idx = rng.integers(0, n, 7777).astype(np.int32)
+        d = hip.DevColumn(ctx, ht, a)
+        out = hip.gather(ctx, d, ctx.upload(idx), len(idx))
+        assert np.array_equal(ctx.download(out, dt, len(idx)), a[idx])
+        d.free()
+    keys = rng.integers(0, 50_000, n).astype(np.int64)
+    dk = hip.DevColumn(ctx, hip.PH_I64, keys)
+    for nparts in (1, 2, 8):
+        counts, perm = hip.partition(ctx, dk, None, n, nparts)
+        p = ctx.download(perm, np.int32, n)
+        assert sum(counts) == n and sorted(p.tolist()) == list(range(n))   # a permutation
+        start = 0
+        owner = {}
+        for part, c in enumerate(counts):
+            for kv in np.unique(keys[p[start:start + c]]):
+                assert owner.setdefault(int(kv), part) == part                # a key lives in one partition
+            start += c
+    dk.free()
