@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,19 @@ struct ph_ctx {
     int64_t pinned_bytes = 0;
     int ensure_scratch(int64_t bytes);
     int ensure_pinned(int64_t bytes);
+    // Synchronous device -> host copy through pinned staging. Copying straight into pageable
+    // caller memory makes the runtime pin/unpin those pages on every call (milliseconds when the
+    // caller's buffers come and go, as numpy / Go-heap buffers do).
+    void *mailbox = nullptr;  // 64 KiB pinned, for counts / flags / small results
+    int download(void *host, const void *dev, int64_t bytes);
+    // Stream-ordered device memory pool: freed blocks are reused by later allocations of the
+    // same rounded size without hipFree/hipMalloc (both synchronise the device). Safe because
+    // every kernel and copy of a ctx runs on its one stream.
+    std::multimap<int64_t, void *> pool_free_blocks;
+    std::map<void *, int64_t> pool_sizes;
+    int pool_alloc(int64_t bytes, void **out);
+    void pool_release(void *p);
+    void pool_destroy();
 };
 
 struct ph_table {

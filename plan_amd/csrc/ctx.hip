@@ -4,6 +4,8 @@
 // (reference pkg/storage/table.go:418-428, pkg/compute/executor_scan.go:158-241, which allocates a
 // fresh 2048-row Chunk per call): the pruned columns are staged through pinned host memory and
 // copied once with hipMemcpyAsync into HBM, in the narrow encodings of SURVEY.md §8(d).
+#include <algorithm>
+
 #include "common.h"
 
 namespace ph {
@@ -50,6 +52,78 @@ int ph_ctx::ensure_pinned(int64_t bytes) {
     return PH_OK;
 }
 
+int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
+    if (bytes <= 0) return PH_OK;
+    const int64_t MB = 64 << 10;
+    if (!mailbox) PH_HIP(hipHostMalloc(&mailbox, (size_t)MB, hipHostMallocDefault));
+    if (bytes <= MB) {
+        PH_HIP(hipMemcpyAsync(mailbox, dev, (size_t)bytes, hipMemcpyDeviceToHost, stream));
+        PH_HIP(hipStreamSynchronize(stream));
+        memcpy(host, mailbox, (size_t)bytes);
+        return PH_OK;
+    }
+    const int64_t CH = 32ll << 20;
+    PH_CHECK(ensure_pinned(2 * CH));
+    // double buffered: the copy of chunk k+1 overlaps the memcpy of chunk k out of staging
+    hipEvent_t ev[2];
+    PH_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    PH_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int rc = PH_OK;
+    int64_t nchunks = (bytes + CH - 1) / CH;
+    for (int64_t c = 0; c <= nchunks && rc == PH_OK; c++) {
+        if (c < nchunks) {
+            int64_t off = c * CH, len = std::min(CH, bytes - off);
+            if (hipMemcpyAsync((char *)pinned + (c & 1) * CH, (const char *)dev + off, (size_t)len,
+                               hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipEventRecord(ev[c & 1], stream) != hipSuccess) rc = PH_EHIP;
+        }
+        if (c > 0 && rc == PH_OK) {
+            int64_t off = (c - 1) * CH, len = std::min(CH, bytes - off);
+            if (hipEventSynchronize(ev[(c - 1) & 1]) != hipSuccess) rc = PH_EHIP;
+            else memcpy((char *)host + off, (char *)pinned + ((c - 1) & 1) * CH, (size_t)len);
+        }
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc != PH_OK) ph::set_error("device-to-host copy of %lld bytes failed", (long long)bytes);
+    return rc;
+}
+
+int ph_ctx::pool_alloc(int64_t bytes, void **out) {
+    int64_t sz = ph::round_up(bytes > 0 ? bytes : 1, bytes > (1 << 20) ? (2 << 20) : 4096);
+    auto it = pool_free_blocks.find(sz);
+    if (it != pool_free_blocks.end()) {
+        *out = it->second;
+        pool_free_blocks.erase(it);
+        return PH_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)sz);
+    if (e != hipSuccess) {
+        // give cached blocks back to the driver and retry once
+        PH_HIP(hipStreamSynchronize(stream));
+        for (auto &kv : pool_free_blocks) { pool_sizes.erase(kv.second); (void)hipFree(kv.second); }
+        pool_free_blocks.clear();
+        PH_HIP(hipMalloc(&p, (size_t)sz));
+    }
+    pool_sizes[p] = sz;
+    *out = p;
+    return PH_OK;
+}
+
+void ph_ctx::pool_release(void *p) {
+    if (!p) return;
+    auto it = pool_sizes.find(p);
+    if (it == pool_sizes.end()) { (void)hipFree(p); return; }
+    pool_free_blocks.emplace(it->second, p);
+}
+
+void ph_ctx::pool_destroy() {
+    for (auto &kv : pool_sizes) (void)hipFree(kv.first);
+    pool_sizes.clear();
+    pool_free_blocks.clear();
+}
+
 extern "C" int ph_ctx_create(int device, ph_ctx **out) {
     PH_REQUIRE(out != nullptr, "ph_ctx_create: out is NULL");
     int ndev = 0;
@@ -93,8 +167,10 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool_destroy();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -104,15 +180,12 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
 extern "C" int ph_dev_alloc(ph_ctx *ctx, int64_t bytes, void **dev) {
     PH_REQUIRE(ctx && dev && bytes >= 0, "ph_dev_alloc: bad arguments");
     PH_HIP(hipSetDevice(ctx->device));
-    PH_HIP(hipMalloc(dev, (size_t)(bytes > 0 ? bytes : 1)));
-    return PH_OK;
+    return ctx->pool_alloc(bytes, dev);
 }
 
 extern "C" int ph_dev_free(ph_ctx *ctx, void *dev) {
     PH_REQUIRE(ctx != nullptr, "ph_dev_free: ctx is NULL");
-    if (!dev) return PH_OK;
-    PH_HIP(hipStreamSynchronize(ctx->stream));
-    PH_HIP(hipFree(dev));
+    ctx->pool_release(dev);  // stream-ordered reuse; no synchronisation needed
     return PH_OK;
 }
 
@@ -155,9 +228,7 @@ extern "C" int ph_dev_download(ph_ctx *ctx, void *host, const void *dev, int64_t
     PH_REQUIRE(ctx && (bytes == 0 || (dev && host)), "ph_dev_download: bad arguments");
     if (bytes == 0) return PH_OK;
     PH_HIP(hipSetDevice(ctx->device));
-    PH_HIP(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
-    return PH_OK;
+    return ctx->download(host, dev, bytes);
 }
 
 extern "C" int ph_dev_memset(ph_ctx *ctx, void *dev, int value, int64_t bytes) {
@@ -214,8 +285,7 @@ static int column_range(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, i
     }
     PH_HIP(hipGetLastError());
     long long res[2];
-    PH_HIP(hipMemcpyAsync(res, ctx->scratch, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(ctx->download(res, ctx->scratch, sizeof res));
     *mn = res[0];
     *mx = res[1];
     return PH_OK;

@@ -213,7 +213,7 @@ int64_t next_pow2(int64_t v) {
 
 int agg_free_arrays(ph_agg *a) {
     void *ptrs[] = {a->slots, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, a->first_row};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) a->ctx->pool_release(p);
     a->slots = nullptr; a->gkeys = nullptr; a->gnull = nullptr; a->sum_lo = nullptr;
     a->sum_hi = nullptr; a->cnt = nullptr; a->first_row = nullptr;
     return PH_OK;
@@ -228,13 +228,13 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
     unsigned *gnull = nullptr;
     long long *sum_hi = nullptr, *first_row = nullptr;
     size_t na = (size_t)std::max(a->naggs, 1);
-    PH_HIP(hipMalloc((void **)&slots, (size_t)cap * 4));
-    PH_HIP(hipMalloc((void **)&gkeys, (size_t)gcap * a->nkeys * 8));
-    PH_HIP(hipMalloc((void **)&gnull, (size_t)gcap * 4));
-    PH_HIP(hipMalloc((void **)&sum_lo, (size_t)gcap * na * 8));
-    PH_HIP(hipMalloc((void **)&sum_hi, (size_t)gcap * na * 8));
-    PH_HIP(hipMalloc((void **)&cnt, (size_t)gcap * na * 8));
-    PH_HIP(hipMalloc((void **)&first_row, (size_t)gcap * 8));
+    PH_CHECK(ctx->pool_alloc(cap * 4, (void **)&slots));
+    PH_CHECK(ctx->pool_alloc(gcap * a->nkeys * 8, (void **)&gkeys));
+    PH_CHECK(ctx->pool_alloc(gcap * 4, (void **)&gnull));
+    PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&sum_lo));
+    PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&sum_hi));
+    PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&cnt));
+    PH_CHECK(ctx->pool_alloc(gcap * 8, (void **)&first_row));
     PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
     if (ng > 0) {
         PH_HIP(hipMemcpyAsync(gkeys, a->gkeys, (size_t)ng * a->nkeys * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -251,8 +251,7 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
         ph::agg_rehash_kernel<<<std::min((ng + 255) / 256, 2048), 256, 0, ctx->stream>>>(slots, (uint64_t)cap - 1, gkeys, gnull, a->nkeys, ng);
         PH_HIP(hipGetLastError());
     }
-    PH_HIP(hipStreamSynchronize(ctx->stream));
-    agg_free_arrays(a);
+    agg_free_arrays(a);  // stream-ordered: the copies above are already queued
     a->slots = slots; a->gkeys = gkeys; a->gnull = gnull; a->sum_lo = sum_lo; a->sum_hi = sum_hi;
     a->cnt = cnt; a->first_row = first_row;
     a->cap = cap;
@@ -264,10 +263,9 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
 
 extern "C" void ph_agg_free(ph_agg *a) {
     if (!a) return;
-    if (a->ctx) (void)hipStreamSynchronize(a->ctx->stream);
     agg_free_arrays(a);
-    if (a->counters) (void)hipFree(a->counters);
-    if (a->kinds_dev) (void)hipFree(a->kinds_dev);
+    if (a->counters) a->ctx->pool_release(a->counters);
+    if (a->kinds_dev) a->ctx->pool_release(a->kinds_dev);
     delete a;
 }
 
@@ -291,8 +289,8 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
-    if (hipMalloc((void **)&a->counters, 8) != hipSuccess || hipMemsetAsync(a->counters, 0, 8, ctx->stream) != hipSuccess ||
-        hipMalloc((void **)&a->kinds_dev, sizeof kinds) != hipSuccess ||
+    if (ctx->pool_alloc(8, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 8, ctx->stream) != hipSuccess ||
+        ctx->pool_alloc(sizeof kinds, (void **)&a->kinds_dev) != PH_OK ||
         hipMemcpyAsync(a->kinds_dev, kinds, sizeof kinds, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         ph::set_error("ph_agg_create: device allocation failed");
@@ -308,8 +306,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
 extern "C" int ph_agg_group_count(ph_agg *a, int64_t *ngroups) {
     PH_REQUIRE(a && ngroups, "ph_agg_group_count: bad arguments");
     int c[2] = {0, 0};
-    PH_HIP(hipMemcpyAsync(c, a->counters, 8, hipMemcpyDeviceToHost, a->ctx->stream));
-    PH_HIP(hipStreamSynchronize(a->ctx->stream));
+    PH_CHECK(a->ctx->download(c, a->counters, 8));
     if (c[1]) { ph::set_error("ph_agg: device table error flag %d", c[1]); return PH_EHIP; }
     *ngroups = c[0];
     return PH_OK;
@@ -391,14 +388,13 @@ extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row
     std::vector<unsigned long long> gk(g * a->nkeys), lo(g * na), cn(g * na);
     std::vector<long long> hi(g * na);
     std::vector<unsigned> gn(g);
-    hipStream_t s = a->ctx->stream;
-    PH_HIP(hipMemcpyAsync(fr.data(), a->first_row, g * 8, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipMemcpyAsync(gk.data(), a->gkeys, g * a->nkeys * 8, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipMemcpyAsync(gn.data(), a->gnull, g * 4, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipMemcpyAsync(lo.data(), a->sum_lo, g * na * 8, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipMemcpyAsync(hi.data(), a->sum_hi, g * na * 8, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipMemcpyAsync(cn.data(), a->cnt, g * na * 8, hipMemcpyDeviceToHost, s));
-    PH_HIP(hipStreamSynchronize(s));
+    ph_ctx *cx = a->ctx;
+    PH_CHECK(cx->download(fr.data(), a->first_row, (int64_t)(g * 8)));
+    PH_CHECK(cx->download(gk.data(), a->gkeys, (int64_t)(g * a->nkeys * 8)));
+    PH_CHECK(cx->download(gn.data(), a->gnull, (int64_t)(g * 4)));
+    PH_CHECK(cx->download(lo.data(), a->sum_lo, (int64_t)(g * na * 8)));
+    PH_CHECK(cx->download(hi.data(), a->sum_hi, (int64_t)(g * na * 8)));
+    PH_CHECK(cx->download(cn.data(), a->cnt, (int64_t)(g * na * 8)));
     // first-seen order = the reference's insertion order (GroupedAggrHashTable.Scan, :424-438)
     std::vector<int64_t> order(g);
     for (size_t i = 0; i < g; i++) order[i] = (int64_t)i;

@@ -257,8 +257,7 @@ extern "C" int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, cons
     ph::expr_kernel<<<grid, 256, 0, ctx->stream>>>(X, sel, n, (long long *)out_dev, out_validity_dev, flag);
     PH_HIP(hipGetLastError());
     int host_flag = 0;
-    PH_HIP(hipMemcpyAsync(&host_flag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(ctx->download(&host_flag, flag, 4));
     if (host_flag) { ph::set_error("ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
     return PH_OK;
 }

@@ -94,14 +94,23 @@ __device__ __forceinline__ int probe_count(const JoinSide &B, const JoinSide &Pr
 constexpr int JP_ROUNDS = 8;
 constexpr int JP_CHUNK = 256 * JP_ROUNDS;
 
+// Count pass. Besides the workgroup totals it leaves each probe row's match count (saturated at
+// 255) in cnt8, so the write pass walks chains only for rows that matched — on selective joins
+// (Q3: 1 % of the probes match) that makes the second pass almost free instead of a second full
+// round of random bucket reads.
 __global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
-                                                         int32_t *__restrict__ block_counts) {
+                                                         int32_t *__restrict__ block_counts,
+                                                         uint8_t *__restrict__ cnt8) {
     int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
     int cnt = 0;
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
         int64_t i = base + rr * 256 + threadIdx.x;
-        if (i < Pr.n) cnt += probe_count(B, Pr, head, mask, next, i);
+        if (i < Pr.n) {
+            int c = probe_count(B, Pr, head, mask, next, i);
+            cnt8[i] = (uint8_t)(c > 255 ? 255 : c);
+            cnt += c;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     __shared__ int ws[4];
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr
 
 __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
-                                                         const int32_t *__restrict__ block_off, int64_t cap,
+                                                         const int32_t *__restrict__ block_off,
+                                                         const uint8_t *__restrict__ cnt8, int64_t cap,
                                                          int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build) {
     int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
     __shared__ int ws[4];
@@ -120,7 +130,8 @@ __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
         int64_t i = base + rr * 256 + threadIdx.x;
-        int c = i < Pr.n ? probe_count(B, Pr, head, mask, next, i) : 0;
+        int c = i < Pr.n ? cnt8[i] : 0;
+        if (c == 255) c = probe_count(B, Pr, head, mask, next, i);  // saturated: recount
         int incl = c;
         for (int o = 1; o < 64; o <<= 1) {
             int y = __shfl_up(incl, o);
@@ -173,10 +184,9 @@ struct ph_join {
 
 extern "C" void ph_join_free(ph_join *j) {
     if (!j) return;
-    if (j->ctx) (void)hipStreamSynchronize(j->ctx->stream);
-    if (j->sel_copy) (void)hipFree(j->sel_copy);
-    if (j->head) (void)hipFree(j->head);
-    if (j->next) (void)hipFree(j->next);
+    if (j->sel_copy) j->ctx->pool_release(j->sel_copy);
+    if (j->head) j->ctx->pool_release(j->head);
+    if (j->next) j->ctx->pool_release(j->next);
     delete j;
 }
 
@@ -208,11 +218,11 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     while (cap < 2 * n) cap <<= 1;
     j->cap = cap;
     auto fail = [&](const char *what) { ph::set_error("ph_join_build: %s failed", what); ph_join_free(j); return PH_EHIP; };
-    if (hipMalloc((void **)&j->head, (size_t)cap * 4) != hipSuccess) return fail("hipMalloc(head)");
-    if (hipMalloc((void **)&j->next, (size_t)std::max<int64_t>(n, 1) * 4) != hipSuccess) return fail("hipMalloc(next)");
+    if (ctx->pool_alloc(cap * 4, (void **)&j->head) != PH_OK) return fail("alloc(head)");
+    if (ctx->pool_alloc(std::max<int64_t>(n, 1) * 4, (void **)&j->next) != PH_OK) return fail("alloc(next)");
     if (hipMemsetAsync(j->head, 0xff, (size_t)cap * 4, ctx->stream) != hipSuccess) return fail("memset");
     if (sel && n > 0) {  // keep our own copy: the table outlives the caller's selection buffer
-        if (hipMalloc((void **)&j->sel_copy, (size_t)n * 4) != hipSuccess) return fail("hipMalloc(sel)");
+        if (ctx->pool_alloc(n * 4, (void **)&j->sel_copy) != PH_OK) return fail("alloc(sel)");
         if (hipMemcpyAsync(j->sel_copy, sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy sel");
         j->build.sel = j->sel_copy;
     }
@@ -225,8 +235,7 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
         if (hipGetLastError() != hipSuccess) return fail("join_build_kernel launch");
     }
     int c = 0;
-    if (hipMemcpyAsync(&c, count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) return fail("count readback");
+    if (ctx->download(&c, count, 4) != PH_OK) return fail("count readback");
     j->count = c;
     *out = j;
     return PH_OK;
@@ -256,17 +265,17 @@ extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t
     if (n == 0 || j->count == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
     int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
-    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64 + n));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    uint8_t *cnt8 = (uint8_t *)ctx->scratch + ph::round_up(nb * 4, 8) + 64;
     uint64_t mask = (uint64_t)j->cap - 1;
-    ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts);
+    ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8);
     PH_HIP(hipGetLastError());
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-    ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cap, out_probe_dev, out_build_dev);
+    ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, cap, out_probe_dev, out_build_dev);
     PH_HIP(hipGetLastError());
-    PH_HIP(hipMemcpyAsync(n_out, total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(ctx->download(n_out, total, 8));
     if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
     return PH_OK;
 }

@@ -286,8 +286,7 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
     ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out);
     PH_HIP(hipGetLastError());
-    PH_HIP(hipMemcpyAsync(n_out, total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(ctx->download(n_out, total, 8));
     return PH_OK;
 }
 
@@ -390,9 +389,7 @@ extern "C" int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, 
     PH_CHECK(ph::exclusive_scan_i32(ctx, hist, cells, total));
     ph::part_scatter_kernel<<<(int)nb, 256, 0, ctx->stream>>>(key->data, w, sel, n, nparts, (int)nb, hist, perm_dev);
     PH_HIP(hipGetLastError());
-    for (int p = 0; p < nparts; p++)
-        PH_HIP(hipMemcpyAsync(&first[(size_t)p], hist + (int64_t)p * nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < nparts; p++) PH_CHECK(ctx->download(&first[(size_t)p], hist + (int64_t)p * nb, 4));
     first[(size_t)nparts] = (int32_t)n;
     for (int p = 0; p < nparts; p++) counts_host[p] = first[(size_t)p + 1] - first[(size_t)p];
     return PH_OK;

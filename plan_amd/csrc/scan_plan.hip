@@ -520,9 +520,8 @@ extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
     PH_REQUIRE(p && out, "ph_scan_plan_fetch: bad arguments");
     std::vector<unsigned long long> lo((size_t)p->nacc);
     std::vector<long long> hi((size_t)p->nacc);
-    PH_HIP(hipMemcpyAsync(lo.data(), p->out_lo, lo.size() * 8, hipMemcpyDeviceToHost, p->ctx->stream));
-    PH_HIP(hipMemcpyAsync(hi.data(), p->out_hi, hi.size() * 8, hipMemcpyDeviceToHost, p->ctx->stream));
-    PH_HIP(hipStreamSynchronize(p->ctx->stream));
+    PH_CHECK(p->ctx->download(lo.data(), p->out_lo, (int64_t)lo.size() * 8));
+    PH_CHECK(p->ctx->download(hi.data(), p->out_hi, (int64_t)hi.size() * 8));
     int naggs = (int)p->aggs.size();
     struct G { int64_t first; int slot; };
     std::vector<G> groups;

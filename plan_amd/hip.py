@@ -366,7 +366,7 @@ class Agg:
         check(lib().ph_agg_group_count(self.h, ctypes.byref(n)))
         return n.value
 
-    def finalize(self):
+    def finalize(self, python_ints=True):
         ng = self.group_count()
         m = max(ng, 1)
         first = np.zeros(m, np.int64)
@@ -378,11 +378,14 @@ class Agg:
         cnt = np.zeros(m * na, np.uint64)
         P = lambda a: vp(a.ctypes.data)
         check(lib().ph_agg_finalize(self.h, i64(m), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt)))
-        sums = [[(int(hi[g * na + a]) << 64) + int(lo[g * na + a]) for a in range(self.naggs)]
-                for g in range(ng)]
-        return dict(ngroups=ng, first_row=first[:ng], keys=keys.reshape(m, self.nkeys)[:ng],
-                    key_null=knull.reshape(m, self.nkeys)[:ng], sum=sums,
-                    count=cnt.reshape(m, na)[:ng, :self.naggs].astype(np.int64))
+        out = dict(ngroups=ng, first_row=first[:ng], keys=keys.reshape(m, self.nkeys)[:ng],
+                   key_null=knull.reshape(m, self.nkeys)[:ng],
+                   sum_lo=lo.reshape(m, na)[:ng, :self.naggs], sum_hi=hi.reshape(m, na)[:ng, :self.naggs],
+                   count=cnt.reshape(m, na)[:ng, :self.naggs].astype(np.int64))
+        if python_ints:  # exact 128-bit python ints (slow for many groups)
+            out["sum"] = [[(int(hi[g * na + a]) << 64) + int(lo[g * na + a]) for a in range(self.naggs)]
+                          for g in range(ng)]
+        return out
 
     def free(self):
         if self.h:

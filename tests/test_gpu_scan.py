@@ -143,3 +143,19 @@ def test_overflow_is_refused(ctx):
     assert e.value.code == hip.PH_EOVERFLOW
     p.free()
     t.free()
+
+
+def test_q3_pipeline_sf1_matches_reference_golden(ctx, sf1):
+    """Q3 through the device operators: all 11 378 groups equal the oracle's, and the
+    ORDER BY revenue DESC, o_orderdate LIMIT 10 tail equals cases/tpch/1g/plan/q3.txt."""
+    import os
+    from plan_amd import pipelines
+    p = pipelines.Q3Pipeline(ctx, sf1["lineitem"], sf1["orders"], sf1["customer"])
+    r = p.run(want_groups=True)
+    p.free()
+    n, rows = O.q3(sf1, "HOUSEHOLD", tpchgen.days(1995, 3, 29))
+    want = {(rows[i].l_orderkey, rows[i].revenue.unscaled(4), rows[i].o_orderdate, rows[i].o_shippriority)
+            for i in range(n)}
+    assert r["ngroups"] == n == 11378 and set(r["groups"]) == want
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
+    assert pipelines.q3_text(r["top"]) == golden
