@@ -159,3 +159,58 @@ def test_q3_pipeline_sf1_matches_reference_golden(ctx, sf1):
     assert r["ngroups"] == n == 11378 and set(r["groups"]) == want
     golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
     assert pipelines.q3_text(r["top"]) == golden
+
+
+def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
+    """The N>1 form of Q3 (broadcast customer keys, hash-partition orders' and lineitem rows by
+    order key, exchange, local build/probe/aggregate, top-10 merge) with 2 ranks run as 2 threads
+    on this GPU (plan_amd.dist.ThreadGroup stands in for the RCCL process group). Each rank owns
+    half of the orders (and their lineitems) and half of the customers; the union of the ranks'
+    groups must equal the single-GPU/oracle result and the merged top-10 the reference golden."""
+    import os
+    import threading
+    import torch
+    from plan_amd import dist as pd, pipelines
+    N = 2
+    L, Od, C = sf1["lineitem"], sf1["orders"], sf1["customer"]
+    no, nc = len(Od["o_orderkey"]), len(C["c_custkey"])
+    # lineitem rows of an order range: order keys are ascending in both tables
+    def shard(r):
+        o0, o1 = r * no // N, (r + 1) * no // N
+        k0 = Od["o_orderkey"][o0]
+        k1 = Od["o_orderkey"][o1] if o1 < no else np.iinfo(np.int64).max
+        l0, l1 = np.searchsorted(L["l_orderkey"], [k0, k1])
+        c0, c1 = r * nc // N, (r + 1) * nc // N
+        return ({k: v[l0:l1] for k, v in L.items()}, {k: v[o0:o1] for k, v in Od.items()},
+                {k: v[c0:c1] for k, v in C.items()})
+    grp = pd.ThreadGroup(N)
+    results, errors = [None] * N, []
+
+    def run(r):
+        try:
+            grp.bind(r)
+            torch.cuda.set_device(0)
+            c = hip.Ctx(0)
+            Ls, Os, Cs = shard(r)
+            p = pipelines.Q3Pipeline(c, Ls, Os, Cs)
+            results[r] = p.run(want_groups=True)
+            p.free()
+            c.close()
+        except Exception as e:   # noqa: BLE001 - surface any rank's failure in the main thread
+            errors.append(e)
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(N)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    n, rows = O.q3(sf1, "HOUSEHOLD", tpchgen.days(1995, 3, 29))
+    want = {(rows[i].l_orderkey, rows[i].revenue.unscaled(4), rows[i].o_orderdate, rows[i].o_shippriority)
+            for i in range(n)}
+    got0, got1 = set(results[0]["groups"]), set(results[1]["groups"])
+    assert not (got0 & got1)                     # groups are disjoint across ranks
+    assert got0 | got1 == want
+    assert min(len(got0), len(got1)) > n // 4    # and reasonably balanced
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
+    assert pipelines.q3_text(results[0]["top"]) == golden == pipelines.q3_text(results[1]["top"])
+    assert results[0]["timings"]["exchange_bytes_sent"] > 0
