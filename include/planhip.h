@@ -154,6 +154,12 @@ int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *p
                  int32_t nprog, const int32_t *sel, int64_t n, int64_t *out_dev,
                  uint8_t *out_validity_dev);
 
+/* extract(year|month|day from date) — ExtractFunc (pkg/compute/function_scalar.go:1509-1563) over a
+ * PH_DATE column: out_dev[i] (int32) for row sel[i] (or i). */
+typedef enum { PH_PART_YEAR = 1, PH_PART_MONTH = 2, PH_PART_DAY = 3 } ph_datepart;
+int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, const int32_t *sel, int64_t n,
+                    int32_t *out_dev);
+
 /* ------------------------------------------------------------------ hash aggregate
  * GroupedAggrHashTable.AddChunk/FindOrCreateGroups + UpdateStates + FinalizeStates
  * (pkg/compute/aggregate_hash.go:136-391, aggregate_exec.go:456-475,

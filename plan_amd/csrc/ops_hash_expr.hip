@@ -261,3 +261,29 @@ extern "C" int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, cons
     if (host_flag) { ph::set_error("ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
     return PH_OK;
 }
+
+// ------------------------------------------------------------------ extract(part from date)
+namespace ph {
+__global__ __launch_bounds__(256) void date_extract_kernel(int part, const int32_t *__restrict__ days,
+                                                           const int32_t *__restrict__ sel, int64_t n,
+                                                           int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int32_t y, m, d;
+        civil_from_days(days[sel ? sel[i] : i], &y, &m, &d);
+        out[i] = part == PH_PART_YEAR ? y : (part == PH_PART_MONTH ? m : d);
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, const int32_t *sel, int64_t n,
+                               int32_t *out_dev) {
+    PH_REQUIRE(ctx && col && n >= 0 && (n == 0 || out_dev), "ph_date_extract: bad arguments");
+    PH_REQUIRE(col->type == PH_DATE, "ph_date_extract: column type %d is not PH_DATE", col->type);
+    PH_REQUIRE(part >= PH_PART_YEAR && part <= PH_PART_DAY, "ph_date_extract: unknown part %d", part);
+    if (col->validity) { ph::set_error("ph_date_extract: NULL-able dates are not supported on the device"); return PH_EUNSUPPORTED; }
+    if (n == 0) return PH_OK;
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    ph::date_extract_kernel<<<grid, 256, 0, ctx->stream>>>(part, (const int32_t *)col->data, sel, n, out_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}

@@ -434,3 +434,13 @@ def partition(ctx, key, sel, n, nparts):
     perm = ctx.alloc(max(n, 1) * 4)
     check(lib().ph_partition(ctx.h, ctypes.byref(c), sel, i64(n), i32(nparts), counts, perm))
     return [counts[p] for p in range(nparts)], perm
+
+
+PH_PART_YEAR, PH_PART_MONTH, PH_PART_DAY = 1, 2, 3
+
+
+def date_extract(ctx, part, col, sel, n):
+    c = col.col() if isinstance(col, DevColumn) else col
+    out = ctx.alloc(max(n, 1) * 4)
+    check(lib().ph_date_extract(ctx.h, i32(part), ctypes.byref(c), sel, i64(n), out))
+    return out

@@ -201,3 +201,132 @@ def q3_text(top):
         d = datetime.date(1970, 1, 1) + datetime.timedelta(days=odate)
         lines.append(f"{okey}\t{dec}\t{d.isoformat()}\t{prio}")
     return "\n".join(lines) + "\n"
+
+
+class Q9Pipeline:
+    """TPC-H Q9 (cases/tpch/query/q9.sql) on one GPU: LIKE filter on part, four N:1 hash joins from
+    lineitem (part, partsupp on the composite key, supplier, orders), the profit expression
+    l_extendedprice*(1-l_discount) - ps_supplycost*l_quantity, group by (nation, year).
+    The nation join (25 rows, key = s_nationkey) is the identity on the key and is folded into the
+    group key; names are attached when the result text is produced.
+    The intermediate result is carried as aligned arrays of base-table row ids; after each join the
+    earlier arrays are re-gathered by the probe positions that survived."""
+
+    def __init__(self, ctx, L, O, P, PS, S, pattern="%pink%"):
+        self.ctx, self.pattern = ctx, pattern
+        D = hip.DevColumn
+        self.n = dict(l=len(L["l_orderkey"]), o=len(O["o_orderkey"]), p=len(P["p_partkey"]),
+                      ps=len(PS["ps_partkey"]), s=len(S["s_suppkey"]))
+        self.p_key = D(ctx, hip.PH_I32, P["p_partkey"])
+        self.p_name = D(ctx, hip.PH_STR, P["p_name_off"], aux=P["p_name_bytes"])
+        self.ps_part = D(ctx, hip.PH_I32, PS["ps_partkey"])
+        self.ps_supp = D(ctx, hip.PH_I32, PS["ps_suppkey"])
+        self.ps_cost = D(ctx, hip.PH_DEC64, PS["ps_supplycost"], 2)
+        self.s_key = D(ctx, hip.PH_I32, S["s_suppkey"])
+        self.s_nat = D(ctx, hip.PH_I32, S["s_nationkey"])
+        self.o_key = D(ctx, hip.PH_I64, O["o_orderkey"])
+        self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
+        self.l_key = D(ctx, hip.PH_I64, L["l_orderkey"])
+        self.l_part = D(ctx, hip.PH_I32, L["l_partkey"])
+        self.l_supp = D(ctx, hip.PH_I32, L["l_suppkey"])
+        self.l_qty = D(ctx, hip.PH_I32, L["l_quantity"])
+        self.l_ext = D(ctx, hip.PH_DEC64, L["l_extendedprice"], 2)
+        self.l_disc = D(ctx, hip.PH_DEC64, L["l_discount"], 2)
+        self.cols = [self.p_key, self.p_name, self.ps_part, self.ps_supp, self.ps_cost, self.s_key,
+                     self.s_nat, self.o_key, self.o_date, self.l_key, self.l_part, self.l_supp,
+                     self.l_qty, self.l_ext, self.l_disc]
+        # amount = ext*(1-disc) - cost*qty  over positional columns [ext, disc, cost, qty]
+        self.amount_prog = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL,
+                            hip.X_COL(2), hip.X_COL(3), hip.X_MUL, hip.X_SUB]
+
+    def free(self):
+        for c in self.cols:
+            c.free()
+
+    def run(self):
+        ctx = self.ctx
+        t, frees = {}, []
+        tic = time.perf_counter
+
+        def stage(name, t0):
+            ctx.sync()
+            t[name] = tic() - t0
+
+        def gat(col, idx, n):
+            p = hip.gather(ctx, col, idx, n)
+            frees.append(p)
+            return p
+
+        t0 = tic()
+        psel, np_ = hip.filter_select(ctx, self.p_name, self.n["p"], hip.PH_LIKE,
+                                      hip.const(hip.PH_STR, s=self.pattern))
+        frees.append(psel)
+        j = hip.Join(ctx, [self.p_key], psel, np_)
+        stage("part_like_build", t0)
+        t0 = tic()
+        n1, lrow, _ = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
+        frees += [lrow, _]
+        j.free()
+        stage("lineitem_probe_part", t0)
+
+        t0 = tic()
+        j = hip.Join(ctx, [self.ps_part, self.ps_supp], None, self.n["ps"])
+        k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
+        n2, pos2, psrow = j.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+        frees += [pos2, psrow]
+        j.free()
+        lrow2 = gat(_raw(hip.PH_I32, lrow), pos2, n2)
+        stage("partsupp_join", t0)
+
+        t0 = tic()
+        j = hip.Join(ctx, [self.s_key], None, self.n["s"])
+        ks = gat(self.l_supp, lrow2, n2)
+        n3, pos3, srow = j.probe_inner([_raw(hip.PH_I32, ks)], None, n2, n2)
+        frees += [pos3, srow]
+        j.free()
+        lrow3 = gat(_raw(hip.PH_I32, lrow2), pos3, n3)
+        psrow3 = gat(_raw(hip.PH_I32, psrow), pos3, n3)
+        stage("supplier_join", t0)
+
+        t0 = tic()
+        j = hip.Join(ctx, [self.o_key], None, self.n["o"])
+        ko = gat(self.l_key, lrow3, n3)
+        n4, pos4, orow = j.probe_inner([_raw(hip.PH_I64, ko)], None, n3, n3)
+        frees += [pos4, orow]
+        j.free()
+        lrow4 = gat(_raw(hip.PH_I32, lrow3), pos4, n4)
+        psrow4 = gat(_raw(hip.PH_I32, psrow3), pos4, n4)
+        srow4 = gat(_raw(hip.PH_I32, srow), pos4, n4)
+        stage("orders_join", t0)
+
+        t0 = tic()
+        ext, disc = gat(self.l_ext, lrow4, n4), gat(self.l_disc, lrow4, n4)
+        qty, cost = gat(self.l_qty, lrow4, n4), gat(self.ps_cost, psrow4, n4)
+        amount, _v = hip.expr_eval(ctx, [_raw(hip.PH_DEC64, ext, 2), _raw(hip.PH_DEC64, disc, 2),
+                                         _raw(hip.PH_DEC64, cost, 2), _raw(hip.PH_I32, qty)],
+                                   self.amount_prog, None, n4)
+        frees.append(amount)
+        nat = gat(self.s_nat, srow4, n4)
+        year = hip.date_extract(ctx, hip.PH_PART_YEAR, self.o_date, orow, n4)
+        frees.append(year)
+        agg = hip.Agg(ctx, [hip.PH_I32, hip.PH_I32], [(hip.PH_A_SUM, 0)], 1024)
+        agg.sink([_raw(hip.PH_I32, nat), _raw(hip.PH_I32, year)], [_raw(hip.PH_DEC64, amount, 4)], None, n4,
+                 positional=True)
+        r = agg.finalize()
+        agg.free()
+        stage("expr_aggregate", t0)
+        for p in frees:
+            ctx.free(p)
+        rows = [(int(r["keys"][g][0]), int(r["keys"][g][1]), r["sum"][g][0]) for g in range(r["ngroups"])]
+        return dict(ngroups=r["ngroups"], rows=rows, join_rows=n4, timings=t)
+
+
+def q9_text(rows, nation_names):
+    """ORDER BY nation, o_year DESC + the reference's text format (sum_profit at scale 4)."""
+    out = ["#\t\t"]
+    for nat, year, s in sorted(rows, key=lambda x: (nation_names[x[0]], -x[1])):
+        neg = "-" if s < 0 else ""
+        w, f = divmod(abs(s), 10000)
+        frac = ("%04d" % f).rstrip("0")
+        out.append(f"{nation_names[nat]}\t{year}\t{neg}{w}" + (f".{frac}" if frac else ""))
+    return "\n".join(out) + "\n"

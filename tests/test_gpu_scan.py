@@ -214,3 +214,19 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
     golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
     assert pipelines.q3_text(results[0]["top"]) == golden == pipelines.q3_text(results[1]["top"])
     assert results[0]["timings"]["exchange_bytes_sent"] > 0
+
+
+def test_q9_pipeline_sf1_matches_reference_golden(ctx, sf1):
+    """Q9: LIKE filter + four hash joins (one on a composite key) + profit expression + group by
+    (nation, year) on the device; the 175 rows must equal cases/tpch/1g/plan/q9.txt."""
+    import os
+    from plan_amd import pipelines
+    p = pipelines.Q9Pipeline(ctx, sf1["lineitem"], sf1["orders"], sf1["part"], sf1["partsupp"], sf1["supplier"])
+    r = p.run()
+    p.free()
+    assert r["ngroups"] == 175
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q9.txt")).read()
+    assert pipelines.q9_text(r["rows"], tpchgen.nation_names()) == golden
+    n, rows = O.q9(sf1, "%pink%")
+    want = {(rows[i].nationkey, rows[i].o_year): rows[i].sum_profit.unscaled(4) for i in range(n)}
+    assert {(a, b): c for a, b, c in r["rows"]} == want
