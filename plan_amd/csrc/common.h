@@ -61,6 +61,7 @@ inline int type_width(int32_t t) {
 
 struct ph_ctx {
     int device = 0;
+    int cu_count = ph::CU_COUNT;  // multiProcessorCount of the device
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // reusable device scratch (block partials, scan buffers, counters)

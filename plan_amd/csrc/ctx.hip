@@ -132,6 +132,9 @@ extern "C" int ph_ctx_create(int device, ph_ctx **out) {
     PH_HIP(hipSetDevice(device));
     ph_ctx *c = new ph_ctx();
     c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->cu_count = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

@@ -31,6 +31,31 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
 struct alignas(16) i64x2 { long long x, y; };
 struct alignas(16) i32x4 { int x, y, z, w; };
 
+typedef long long v2i64 __attribute__((ext_vector_type(2)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Streaming loads: every byte of these columns is read exactly once per launch, so the loads are
+// marked non-temporal (global_load_dwordx4 ... nt) to keep them from displacing anything useful in
+// L2/MALL. NT = false keeps the default cache policy (A/B switch: PH_SCAN_NT=0).
+template <bool NT> __device__ __forceinline__ i64x2 ld_i64x2(const int64_t *p) {
+    if (NT) {
+        v2i64 v = __builtin_nontemporal_load(reinterpret_cast<const v2i64 *>(p));
+        return i64x2{v.x, v.y};
+    }
+    return *reinterpret_cast<const i64x2 *>(p);
+}
+template <bool NT> __device__ __forceinline__ i32x4 ld_i32x4(const int32_t *p) {
+    if (NT) {
+        v4i32 v = __builtin_nontemporal_load(reinterpret_cast<const v4i32 *>(p));
+        return i32x4{v.x, v.y, v.z, v.w};
+    }
+    return *reinterpret_cast<const i32x4 *>(p);
+}
+template <bool NT> __device__ __forceinline__ unsigned ld_u32(const uint8_t *p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    return *reinterpret_cast<const unsigned *>(p);
+}
+
 // ------------------------------------------------------------------ filter_sumprod (Q6 shape)
 
 struct FsTile {
@@ -40,14 +65,14 @@ struct FsTile {
     i64x2 a0, a1;  // int64 first factor (extendedprice)
 };
 
-__device__ __forceinline__ FsTile fs_load(const FilterSumProdParams &P, int64_t row) {
+template <bool NT> __device__ __forceinline__ FsTile fs_load(const FilterSumProdParams &P, int64_t row) {
     FsTile t;
-    t.p0 = *reinterpret_cast<const i32x4 *>(P.p0 + row);
-    t.p2 = *reinterpret_cast<const i32x4 *>(P.p2 + row);
-    t.b0 = *reinterpret_cast<const i64x2 *>(P.b + row);
-    t.b1 = *reinterpret_cast<const i64x2 *>(P.b + row + 2);
-    t.a0 = *reinterpret_cast<const i64x2 *>(P.a + row);
-    t.a1 = *reinterpret_cast<const i64x2 *>(P.a + row + 2);
+    t.p0 = ld_i32x4<NT>(P.p0 + row);
+    t.p2 = ld_i32x4<NT>(P.p2 + row);
+    t.b0 = ld_i64x2<NT>(P.b + row);
+    t.b1 = ld_i64x2<NT>(P.b + row + 2);
+    t.a0 = ld_i64x2<NT>(P.a + row);
+    t.a1 = ld_i64x2<NT>(P.a + row + 2);
     return t;
 }
 
@@ -61,7 +86,7 @@ __device__ __forceinline__ void fs_row(const FilterSumProdParams &P, bool in_ran
     }
 }
 
-__global__ __launch_bounds__(256) void filter_sumprod_kernel(FilterSumProdParams P) {
+template <bool NT> __global__ __launch_bounds__(256) void filter_sumprod_kernel(FilterSumProdParams P) {
     // tile = 1024 rows per workgroup iteration, 4 consecutive rows per lane
     const int64_t tile_rows = 1024;
     long long sum = 0;
@@ -71,11 +96,11 @@ __global__ __launch_bounds__(256) void filter_sumprod_kernel(FilterSumProdParams
     // row_begin is a multiple of 4 and columns are padded to PH_ROW_PAD rows, so a 4-row vector
     // load that starts below row_end stays inside the allocation.
     if (first < P.row_end) {
-        FsTile cur = fs_load(P, first);
+        FsTile cur = fs_load<NT>(P, first);
         for (int64_t row = first; row < P.row_end; row += stride) {
             int64_t nrow = row + stride;
             FsTile nxt = cur;
-            if (nrow < P.row_end) nxt = fs_load(P, nrow);
+            if (nrow < P.row_end) nxt = fs_load<NT>(P, nrow);
             fs_row(P, row + 0 < P.row_end, cur.p0.x, cur.p2.x, cur.b0.x, cur.a0.x, sum, cnt);
             fs_row(P, row + 1 < P.row_end, cur.p0.y, cur.p2.y, cur.b0.y, cur.a0.y, sum, cnt);
             fs_row(P, row + 2 < P.row_end, cur.p0.z, cur.p2.z, cur.b1.x, cur.a1.x, sum, cnt);
@@ -109,18 +134,18 @@ struct LcTile {
     unsigned k0, k1;  // 4 code bytes each
 };
 
-__device__ __forceinline__ LcTile lc_load(const LowcardChainParams &P, int64_t row) {
+template <bool NT> __device__ __forceinline__ LcTile lc_load(const LowcardChainParams &P, int64_t row) {
     LcTile t;
-    t.p = *reinterpret_cast<const i32x4 *>(P.p + row);
-    t.q = *reinterpret_cast<const i32x4 *>(P.q + row);
-    t.e0 = *reinterpret_cast<const i64x2 *>(P.e + row);
-    t.e1 = *reinterpret_cast<const i64x2 *>(P.e + row + 2);
-    t.d0 = *reinterpret_cast<const i64x2 *>(P.d + row);
-    t.d1 = *reinterpret_cast<const i64x2 *>(P.d + row + 2);
-    t.t0 = *reinterpret_cast<const i64x2 *>(P.t + row);
-    t.t1 = *reinterpret_cast<const i64x2 *>(P.t + row + 2);
-    t.k0 = *reinterpret_cast<const unsigned *>(P.k0 + row);
-    t.k1 = *reinterpret_cast<const unsigned *>(P.k1 + row);
+    t.p = ld_i32x4<NT>(P.p + row);
+    t.q = ld_i32x4<NT>(P.q + row);
+    t.e0 = ld_i64x2<NT>(P.e + row);
+    t.e1 = ld_i64x2<NT>(P.e + row + 2);
+    t.d0 = ld_i64x2<NT>(P.d + row);
+    t.d1 = ld_i64x2<NT>(P.d + row + 2);
+    t.t0 = ld_i64x2<NT>(P.t + row);
+    t.t1 = ld_i64x2<NT>(P.t + row + 2);
+    t.k0 = ld_u32<NT>(P.k0 + row);
+    t.k1 = ld_u32<NT>(P.k1 + row);
     return t;
 }
 
@@ -150,7 +175,7 @@ __device__ __forceinline__ void lc_row(const LowcardChainParams &P, unsigned lon
     }
 }
 
-__global__ __launch_bounds__(256) void lowcard_chain_kernel(LowcardChainParams P) {
+template <bool NT, int U> __global__ __launch_bounds__(256) void lowcard_chain_kernel(LowcardChainParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_acc[];
     const int ns = P.nslots;
     unsigned long long *lds64 = lds_acc;
@@ -164,25 +189,40 @@ __global__ __launch_bounds__(256) void lowcard_chain_kernel(LowcardChainParams P
     unsigned long long *acc64 = lds64 + threadIdx.x;
     unsigned *acc32 = lds32 + threadIdx.x;
 
+    // U tiles of 1024 rows per iteration (a lane owns 4 consecutive rows of each), register
+    // double buffered: the loads of iteration i+1 are in flight while iteration i is aggregated.
     const int64_t tile_rows = 1024;
-    int64_t first = P.row_begin + (int64_t)blockIdx.x * tile_rows + threadIdx.x * 4;
-    const int64_t stride = (int64_t)gridDim.x * tile_rows;
+    int64_t first = P.row_begin + (int64_t)blockIdx.x * tile_rows * U + threadIdx.x * 4;
+    const int64_t stride = (int64_t)gridDim.x * tile_rows * U;
     if (first < P.row_end) {
-        LcTile cur = lc_load(P, first);
-        for (int64_t row = first; row < P.row_end; row += stride) {
-            int64_t nrow = row + stride;
-            LcTile nxt = cur;
-            if (nrow < P.row_end) nxt = lc_load(P, nrow);
-            unsigned r = (unsigned)row;
-            lc_row(P, acc64, acc32, row + 0 < P.row_end, r + 0, cur.p.x, cur.q.x, cur.e0.x,
-                   cur.d0.x, cur.t0.x, cur.k0 & 0xff, cur.k1 & 0xff);
-            lc_row(P, acc64, acc32, row + 1 < P.row_end, r + 1, cur.p.y, cur.q.y, cur.e0.y,
-                   cur.d0.y, cur.t0.y, (cur.k0 >> 8) & 0xff, (cur.k1 >> 8) & 0xff);
-            lc_row(P, acc64, acc32, row + 2 < P.row_end, r + 2, cur.p.z, cur.q.z, cur.e1.x,
-                   cur.d1.x, cur.t1.x, (cur.k0 >> 16) & 0xff, (cur.k1 >> 16) & 0xff);
-            lc_row(P, acc64, acc32, row + 3 < P.row_end, r + 3, cur.p.w, cur.q.w, cur.e1.y,
-                   cur.d1.y, cur.t1.y, cur.k0 >> 24, cur.k1 >> 24);
-            cur = nxt;
+        LcTile cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (first + u * tile_rows < P.row_end) cur[u] = lc_load<NT>(P, first + u * tile_rows);
+        for (int64_t row0 = first; row0 < P.row_end; row0 += stride) {
+            int64_t nrow = row0 + stride;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                nxt[u] = cur[u];
+                if (nrow + u * tile_rows < P.row_end) nxt[u] = lc_load<NT>(P, nrow + u * tile_rows);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int64_t row = row0 + u * tile_rows;
+                if (row >= P.row_end) break;
+                const LcTile &c = cur[u];
+                unsigned r = (unsigned)row;
+                lc_row(P, acc64, acc32, row + 0 < P.row_end, r + 0, c.p.x, c.q.x, c.e0.x, c.d0.x, c.t0.x,
+                       c.k0 & 0xff, c.k1 & 0xff);
+                lc_row(P, acc64, acc32, row + 1 < P.row_end, r + 1, c.p.y, c.q.y, c.e0.y, c.d0.y, c.t0.y,
+                       (c.k0 >> 8) & 0xff, (c.k1 >> 8) & 0xff);
+                lc_row(P, acc64, acc32, row + 2 < P.row_end, r + 2, c.p.z, c.q.z, c.e1.x, c.d1.x, c.t1.x,
+                       (c.k0 >> 16) & 0xff, (c.k1 >> 16) & 0xff);
+                lc_row(P, acc64, acc32, row + 3 < P.row_end, r + 3, c.p.w, c.q.w, c.e1.y, c.d1.y, c.t1.y,
+                       c.k0 >> 24, c.k1 >> 24);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = nxt[u];
         }
     }
     __syncthreads();
@@ -259,8 +299,18 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__r
     }
 }
 
+static bool scan_nt() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PH_SCAN_NT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int launch_filter_sumprod(ph_ctx *ctx, const FilterSumProdParams &P, int grid) {
-    filter_sumprod_kernel<<<grid, 256, 0, ctx->stream>>>(P);
+    if (scan_nt()) filter_sumprod_kernel<true><<<grid, 256, 0, ctx->stream>>>(P);
+    else filter_sumprod_kernel<false><<<grid, 256, 0, ctx->stream>>>(P);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }
@@ -269,11 +319,18 @@ int launch_lowcard_chain(ph_ctx *ctx, const LowcardChainParams &P, int grid) {
     size_t lds = (size_t)P.nslots * (5 * 256 * sizeof(unsigned long long) + 2 * 256 * sizeof(unsigned));
     static bool attr_set = false;
     if (!attr_set) {
-        PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    lowcard_chain_kernel<<<grid, 256, lds, ctx->stream>>>(P);
+    int u = 1;
+    if (const char *e = getenv("PH_SCAN_UNROLL")) u = atoi(e);
+    if (!scan_nt()) lowcard_chain_kernel<false, 1><<<grid, 256, lds, ctx->stream>>>(P);
+    else if (u == 3) lowcard_chain_kernel<true, 3><<<grid, 256, lds, ctx->stream>>>(P);
+    else if (u == 2) lowcard_chain_kernel<true, 2><<<grid, 256, lds, ctx->stream>>>(P);
+    else lowcard_chain_kernel<true, 1><<<grid, 256, lds, ctx->stream>>>(P);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }

@@ -261,7 +261,7 @@ struct ph_scan_plan {
 };
 
 static int plan_alloc(ph_scan_plan *p) {
-    PH_HIP(hipMalloc((void **)&p->partials, (size_t)p->max_grid * p->nacc * sizeof(long long)));
+    PH_HIP(hipMalloc((void **)&p->partials, (size_t)std::max(p->max_grid, 8192) * p->nacc * sizeof(long long)));
     PH_HIP(hipMalloc((void **)&p->out_lo, (size_t)p->nacc * sizeof(unsigned long long)));
     PH_HIP(hipMalloc((void **)&p->out_hi, (size_t)p->nacc * sizeof(long long)));
     return PH_OK;
@@ -381,7 +381,10 @@ extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred
         Affine one; one.B = 1;
         p->row_bound = affine_bound(one, col(a_col).min, col(a_col).max) * affine_bound(one, col(b_col).min, col(b_col).max);
         p->nacc = 2;
-        p->max_grid = ph::CU_COUNT * 8;
+        // one 256-thread workgroup per CU (1 wave per SIMD) streams fastest: measured on MI355X,
+        // SF10: 6.48 TB/s at grid 256 vs 5.95 at 2048 and 4.6-5.4 at grids that are not a
+        // multiple of the CU count (tail imbalance); scripts/ab_scan2.sh
+        p->max_grid = ctx->cu_count;
     } else {
         // ---------------- lowcard_chain: two dictionary-code group columns, one int32 range predicate
         p->kind = PK_LOWCARD_CHAIN;
@@ -466,8 +469,9 @@ extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred
         p->row_bound = std::max({be * b1 * b2, be * b1, be, affine_bound(one, col(d).min, col(d).max),
                                  affine_bound(one, col(q).min, col(q).max)});
         p->nacc = p->lc.nslots * (ph::LC_NACC + 1);  // + first_row
-        // 2 workgroups per CU fit the per-thread-private LDS accumulators (see kernel header)
-        p->max_grid = ph::CU_COUNT * 2;
+        // one workgroup per CU: 6.35 TB/s at grid 256 vs 6.0 at 512 (2 per CU is what the
+        // per-thread-private LDS accumulators would still allow); scripts/ab_scan2.sh
+        p->max_grid = ctx->cu_count;
     }
     int rc = plan_alloc(p);
     if (rc != PH_OK) return fail(rc);
@@ -482,7 +486,9 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
                (long long)row_begin, (long long)row_end, (long long)p->t->nrows);
     int64_t rows = p->never ? 0 : row_end - row_begin;
     int64_t tiles = (rows + 1023) / 1024;
-    int grid = (int)std::min<int64_t>(p->max_grid, std::max<int64_t>(tiles, 1));
+    int max_grid = p->max_grid;
+    if (const char *e = getenv("PH_SCAN_GRID")) { int g = atoi(e); if (g > 0) max_grid = g; }  // tuning knob
+    int grid = (int)std::min<int64_t>(max_grid, std::max<int64_t>(tiles, 1));
     // overflow proof: a workgroup's int64 partial sums at most rows_per_block values of
     // magnitude <= row_bound
     long double rows_per_block = (long double)((tiles + grid - 1) / grid) * 1024.0L;
