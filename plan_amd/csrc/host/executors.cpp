@@ -1,0 +1,599 @@
+// See operator_exec.h. GPU executors behind the reference's OperatorExec interface (compat mode:
+// 2048-row chunks in and out, device work batched across many chunks).
+#include "operator_exec.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace plan {
+
+static std::string herr(const char *what) { return std::string(what) + ": " + ph_last_error(); }
+
+static void ensureOutputChunk(const std::vector<LType> &types, Chunk *out) {  // executor.go:201-210
+    if (out->ColumnCount() == 0) out->Init(types, DefaultVectorSize);
+}
+
+// ------------------------------------------------------------------ stub / source
+
+OperatorResult stubExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (pos_ >= blob_.size()) return Done;
+    if (!output->Deserialize(blob_, &pos_, err)) return InvalidOpResult;
+    if (output->Card() == 0) return Done;
+    return haveMoreOutput;
+}
+
+OperatorResult sourceExecutor::Execute(Chunk *, Chunk *output, std::string *) {
+    ensureOutputChunk(types_, output);
+    if (!fn_(output)) return Done;
+    return haveMoreOutput;
+}
+
+void CopyCell(const Vector &src, int srcRow, Vector *dst, int dstRow) {
+    Vector::Unified u;
+    src.ToUnifiedFormat(srcRow + 1, &u);
+    int64_t idx = u.sel->GetIndex(srcRow);
+    if (!u.mask->RowIsValid((uint64_t)idx)) {
+        dst->Mask.SetInvalid((uint64_t)dstRow, DefaultVectorSize);
+        return;
+    }
+    size_t w = src._Typ.Size();
+    if (src._Typ.GetInternalType() == PT_VARCHAR) {
+        const String &s = reinterpret_cast<const String *>(u.data)[idx];
+        dst->SetString(dstRow, s.Data, s.Len);
+    } else {
+        memcpy(dst->Data.data() + (size_t)dstRow * w, u.data + (size_t)idx * w, w);
+    }
+}
+
+// ------------------------------------------------------------------ DeviceBatch
+
+static int staged_width(const LType &t) {
+    switch (t.GetInternalType()) {
+    case PT_INT32: case PT_DATE: return 4;
+    case PT_INT64: case PT_DECIMAL: return 8;
+    case PT_VARCHAR: return 1;
+    default: return 0;
+    }
+}
+
+static int staged_phtype(const LType &t) {
+    switch (t.GetInternalType()) {
+    case PT_INT32: return PH_I32;
+    case PT_INT64: return PH_I64;
+    case PT_DATE: return PH_DATE;
+    case PT_DECIMAL: return PH_DEC64;
+    case PT_VARCHAR: return PH_CODE8;
+    default: return 0;
+    }
+}
+
+DeviceBatch::DeviceBatch(ph_ctx *ctx, std::vector<LType> types, std::vector<int> cols)
+    : ctx_(ctx), types_(std::move(types)), cols_(std::move(cols)) {
+    size_t n = cols_.size();
+    host_.resize(n); valid_.resize(n); has_null_.assign(n, false); dicts_.resize(n); dict_index_.resize(n);
+    dev_.resize(n); dev_data_.assign(n, nullptr); dev_valid_.assign(n, nullptr);
+}
+
+DeviceBatch::~DeviceBatch() { Reset(); }
+
+void DeviceBatch::Reset() {
+    for (size_t k = 0; k < cols_.size(); k++) {
+        if (dev_data_[k]) ph_dev_free(ctx_, dev_data_[k]);
+        if (dev_valid_[k]) ph_dev_free(ctx_, dev_valid_[k]);
+        dev_data_[k] = dev_valid_[k] = nullptr;
+        host_[k].clear();
+        valid_[k].clear();
+        has_null_[k] = false;
+    }
+    rows_ = 0;
+}
+
+int DeviceBatch::code_of(int k, const std::string &s) const {
+    auto it = dict_index_[(size_t)k].find(s);
+    return it == dict_index_[(size_t)k].end() ? -1 : it->second;
+}
+
+std::string DeviceBatch::Append(const Chunk &c) {
+    int card = c.Card();
+    for (size_t k = 0; k < cols_.size(); k++) {
+        const Vector &v = *c.Data[(size_t)cols_[k]];
+        const LType &t = types_[(size_t)cols_[k]];
+        int w = staged_width(t);
+        if (w == 0) return "column type " + std::to_string(t.Id) + " cannot be staged to the device";
+        Vector::Unified u;
+        v.ToUnifiedFormat(card, &u);
+        size_t base = host_[k].size();
+        host_[k].resize(base + (size_t)card * (size_t)w);
+        valid_[k].resize((size_t)(rows_ + card + 7) / 8 + 1, 0);
+        for (int i = 0; i < card; i++) {
+            int64_t idx = u.sel->GetIndex(i);
+            int64_t row = rows_ + i;
+            bool ok = u.mask->RowIsValid((uint64_t)idx);
+            if (ok) valid_[k][(size_t)row >> 3] |= (uint8_t)(1u << (row & 7)); else has_null_[k] = true;
+            uint8_t *dst = host_[k].data() + base + (size_t)i * (size_t)w;
+            if (!ok) { memset(dst, 0, (size_t)w); continue; }
+            switch (t.GetInternalType()) {
+            case PT_INT32: memcpy(dst, u.data + (size_t)idx * 4, 4); break;
+            case PT_INT64: memcpy(dst, u.data + (size_t)idx * 8, 8); break;
+            case PT_DATE: { int32_t d = DaysFromDate(reinterpret_cast<const Date *>(u.data)[idx]); memcpy(dst, &d, 4); break; }
+            case PT_DECIMAL: {
+                int64_t x;
+                if (!DecimalToUnscaled(reinterpret_cast<const Decimal *>(u.data)[idx], t.Scale, &x))
+                    return "decimal value does not fit DECIMAL(18," + std::to_string(t.Scale) + ") on the device";
+                memcpy(dst, &x, 8);
+                break;
+            }
+            case PT_VARCHAR: {
+                const String &s = reinterpret_cast<const String *>(u.data)[idx];
+                std::string key(s.Data, (size_t)s.Len);
+                auto it = dict_index_[k].find(key);
+                int code;
+                if (it == dict_index_[k].end()) {
+                    code = (int)dicts_[k].size();
+                    if (code > 255) return "VARCHAR column has more than 256 distinct values: not a dictionary-code column";
+                    dicts_[k].push_back(key);
+                    dict_index_[k][key] = code;
+                } else code = it->second;
+                *dst = (uint8_t)code;
+                break;
+            }
+            default: break;
+            }
+        }
+    }
+    rows_ += card;
+    return "";
+}
+
+std::string DeviceBatch::Upload() {
+    for (size_t k = 0; k < cols_.size(); k++) {
+        const LType &t = types_[(size_t)cols_[k]];
+        if (dev_data_[k]) { ph_dev_free(ctx_, dev_data_[k]); dev_data_[k] = nullptr; }
+        if (dev_valid_[k]) { ph_dev_free(ctx_, dev_valid_[k]); dev_valid_[k] = nullptr; }
+        if (ph_dev_alloc(ctx_, (int64_t)host_[k].size() + 64, &dev_data_[k]) != PH_OK) return herr("ph_dev_alloc");
+        if (ph_dev_upload(ctx_, dev_data_[k], host_[k].data(), (int64_t)host_[k].size()) != PH_OK) return herr("ph_dev_upload");
+        ph_col c{};
+        c.type = staged_phtype(t);
+        c.scale = t.Scale;
+        c.data = dev_data_[k];
+        if (has_null_[k]) {
+            int64_t nb = (rows_ + 7) / 8;
+            if (ph_dev_alloc(ctx_, nb + 64, &dev_valid_[k]) != PH_OK) return herr("ph_dev_alloc");
+            if (ph_dev_upload(ctx_, dev_valid_[k], valid_[k].data(), nb) != PH_OK) return herr("ph_dev_upload");
+            c.validity = (const uint8_t *)dev_valid_[k];
+        }
+        dev_[k] = c;
+    }
+    return "";
+}
+
+// ------------------------------------------------------------------ filter
+
+gpuFilterExecutor::gpuFilterExecutor(ph_ctx *ctx, std::vector<Compare> conjuncts, OperatorExec *child, int batchChunks)
+    : ctx_(ctx), conj_(std::move(conjuncts)), child_(child), batchChunks_(batchChunks) {}
+
+std::string gpuFilterExecutor::Init() {
+    for (auto &c : conj_)
+        if (std::find(cols_.begin(), cols_.end(), c.col) == cols_.end()) cols_.push_back(c.col);
+    batch_.reset(new DeviceBatch(ctx_, child_->OutputTypes(), cols_));
+    return "";
+}
+
+std::string gpuFilterExecutor::Close() { batch_.reset(); ready_.clear(); return ""; }
+
+std::string gpuFilterExecutor::fill() {
+    std::vector<std::shared_ptr<Chunk>> chunks;
+    batch_->Reset();
+    while ((int)chunks.size() < batchChunks_) {
+        auto c = std::make_shared<Chunk>();
+        std::string err;
+        OperatorResult r = child_->Execute(nullptr, c.get(), &err);
+        if (r == InvalidOpResult) return err.empty() ? "child failed" : err;
+        if (r == Done) { childDone_ = true; break; }
+        if (c->Card() == 0) continue;
+        std::string e = batch_->Append(*c);
+        if (!e.empty()) return e;
+        chunks.push_back(c);
+    }
+    int64_t n = batch_->rows();
+    if (n == 0) return "";
+    std::string e = batch_->Upload();
+    if (!e.empty()) return e;
+    // execSelectAnd (expr_exec.go:444-486): each conjunct narrows the previous selection
+    void *selA = nullptr, *selB = nullptr;
+    if (ph_dev_alloc(ctx_, n * 4, &selA) != PH_OK || ph_dev_alloc(ctx_, n * 4, &selB) != PH_OK) return herr("ph_dev_alloc");
+    const int32_t *cur = nullptr;
+    int64_t cnt = n;
+    for (size_t ci = 0; ci < conj_.size() && cnt > 0; ci++) {
+        const Compare &cmp = conj_[ci];
+        int k = (int)(std::find(cols_.begin(), cols_.end(), cmp.col) - cols_.begin());
+        ph_col col = batch_->col(k);
+        ph_const kc{};
+        switch (cmp.k.kind) {
+        case Literal::Int: kc.type = PH_I32; kc.i = cmp.k.i; break;
+        case Literal::Float: kc.type = PH_F32; kc.f = cmp.k.f; break;
+        case Literal::DateDays: kc.type = PH_DATE; kc.i = cmp.k.i; break;
+        case Literal::Dec: kc.type = PH_DEC64; kc.i = cmp.k.i; kc.scale = cmp.k.scale; break;
+        case Literal::Str: {  // VARCHAR =/!= on a dictionary column: literal -> code
+            kc.type = PH_I32;
+            int code = batch_->code_of(k, cmp.k.s);
+            kc.i = code < 0 ? 999 : code;
+            break;
+        }
+        }
+        int32_t *out = (int32_t *)((ci & 1) ? selB : selA);
+        int64_t m = 0;
+        if (ph_filter_select(ctx_, &col, n, cmp.op, &kc, cur, cnt, out, &m) != PH_OK) {
+            ph_dev_free(ctx_, selA); ph_dev_free(ctx_, selB);
+            return herr("ph_filter_select");
+        }
+        cur = out;
+        cnt = m;
+    }
+    std::vector<int32_t> sel((size_t)cnt);
+    bool all = conj_.empty();
+    if (!all && cnt > 0 && ph_dev_download(ctx_, sel.data(), cur, cnt * 4) != PH_OK) {
+        ph_dev_free(ctx_, selA); ph_dev_free(ctx_, selB);
+        return herr("ph_dev_download");
+    }
+    ph_dev_free(ctx_, selA);
+    ph_dev_free(ctx_, selB);
+    // split the batch selection back into per-chunk selection vectors
+    size_t p = 0;
+    int64_t start = 0;
+    for (auto &c : chunks) {
+        auto sv = std::make_shared<SelectVector>();
+        if (all) { sv->identity = true; ready_.push_back({c, sv}); start += c->Card(); continue; }
+        sv->identity = false;
+        while (p < sel.size() && sel[p] < start + c->Card()) sv->SelVec.push_back(sel[p++] - start);
+        start += c->Card();
+        if (!sv->SelVec.empty()) ready_.push_back({c, sv});
+    }
+    return "";
+}
+
+OperatorResult gpuFilterExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    while (ready_.empty() && !childDone_) {
+        std::string e = fill();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+    }
+    if (ready_.empty()) return Done;
+    auto item = ready_.front();
+    ready_.pop_front();
+    ensureOutputChunk(OutputTypes(), output);
+    std::vector<int> indice;
+    for (int i = 0; i < item.first->ColumnCount(); i++) indice.push_back(i);
+    int count = item.second->identity ? item.first->Card() : (int)item.second->SelVec.size();
+    output->SliceIndice(*item.first, item.second, count, 0, indice);  // DICT views, no copy (executor_filter.go)
+    return haveMoreOutput;
+}
+
+// ------------------------------------------------------------------ aggregate
+
+gpuAggExecutor::gpuAggExecutor(ph_ctx *ctx, std::vector<int> groupCols, std::vector<AggExpr> aggs, OperatorExec *child,
+                               int64_t batchRows)
+    : ctx_(ctx), groupCols_(std::move(groupCols)), aggs_(std::move(aggs)), child_(child), batchRows_(batchRows) {}
+
+std::string gpuAggExecutor::Init() {
+    childTypes_ = child_->OutputTypes();
+    auto stage = [&](int col) {
+        auto it = std::find(stagedCols_.begin(), stagedCols_.end(), col);
+        if (it == stagedCols_.end()) { stagedCols_.push_back(col); return (int)stagedCols_.size() - 1; }
+        return (int)(it - stagedCols_.begin());
+    };
+    for (int g : groupCols_) stage(g);
+    // remap expression columns from child columns to staged positions
+    for (auto &a : aggs_)
+        for (auto &o : a.prog)
+            if (o.op == PH_X_COL) o.col = stage(o.col);
+    batch_.reset(new DeviceBatch(ctx_, childTypes_, stagedCols_));
+    // output: group columns (child types) then one column per aggregate (FinalizeStates types)
+    for (int g : groupCols_) outTypes_.push_back(childTypes_[(size_t)g]);
+    std::vector<ph_col> protos;
+    for (int c : stagedCols_) { ph_col p{}; p.type = staged_phtype(childTypes_[(size_t)c]); p.scale = childTypes_[(size_t)c].Scale; protos.push_back(p); }
+    std::vector<ph_aggspec> specs;
+    for (size_t i = 0; i < aggs_.size(); i++) {
+        const AggExpr &a = aggs_[i];
+        int32_t scale = 0;
+        LType at = IntegerType();
+        if (a.kind != PH_A_COUNT_STAR) {
+            if (a.prog.empty()) return "aggregate without an argument";
+            if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) {
+                at = childTypes_[(size_t)stagedCols_[(size_t)a.prog[0].col]];
+                scale = at.Scale;
+            } else {
+                if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
+                at = DecimalType(38, scale);
+            }
+        }
+        argScale_.push_back(scale);
+        argType_.push_back(at);
+        bool dec = at.Id == LTID_DECIMAL;
+        switch (a.kind) {
+        case PH_A_SUM: outTypes_.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;   // BindDecimalSum / GetSumAggr
+        case PH_A_AVG: outTypes_.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;    // BindDecimalAvg / GetAvgAggr
+        case PH_A_COUNT: case PH_A_COUNT_STAR: outTypes_.push_back(HugeintType()); break;
+        case PH_A_MIN: case PH_A_MAX: outTypes_.push_back(dec ? DecimalType(at.Width, scale) : at); break;
+        default: return "unknown aggregate kind";
+        }
+        specs.push_back(ph_aggspec{a.kind, (int32_t)i});
+    }
+    std::vector<int32_t> keyTypes;
+    for (int g : groupCols_) keyTypes.push_back(staged_phtype(childTypes_[(size_t)g]));
+    if (keyTypes.empty()) keyTypes.push_back(PH_I32);  // ungrouped: constant key (executor_aggr.go:37-48)
+    if (ph_agg_create(ctx_, (int32_t)keyTypes.size(), keyTypes.data(), (int32_t)specs.size(), specs.data(), 1024, &agg_) != PH_OK)
+        return herr("ph_agg_create");
+    return "";
+}
+
+std::string gpuAggExecutor::Close() {
+    if (agg_) { ph_agg_free(agg_); agg_ = nullptr; }
+    batch_.reset();
+    results_.clear();
+    return "";
+}
+
+std::string gpuAggExecutor::sinkBatch() {
+    int64_t n = batch_->rows();
+    if (n == 0) return "";
+    std::string e = batch_->Upload();
+    if (!e.empty()) return e;
+    std::vector<ph_col> staged;
+    for (size_t k = 0; k < stagedCols_.size(); k++) staged.push_back(batch_->col((int)k));
+    std::vector<void *> temps;
+    auto cleanup = [&]() { for (void *p : temps) ph_dev_free(ctx_, p); };
+    // keys
+    std::vector<ph_col> keys;
+    for (size_t g = 0; g < groupCols_.size(); g++) keys.push_back(staged[g]);
+    if (keys.empty()) {
+        void *zero = nullptr;
+        if (ph_dev_alloc(ctx_, n * 4, &zero) != PH_OK || ph_dev_memset(ctx_, zero, 0, n * 4) != PH_OK) { cleanup(); return herr("constant key"); }
+        temps.push_back(zero);
+        ph_col c{}; c.type = PH_I32; c.data = zero;
+        keys.push_back(c);
+    }
+    // arguments: a bare column is used as is, anything else is evaluated (executeExprs)
+    std::vector<ph_col> args(aggs_.size());
+    bool anyValidity = false;
+    for (auto &c : staged) anyValidity |= c.validity != nullptr;
+    for (size_t i = 0; i < aggs_.size(); i++) {
+        const AggExpr &a = aggs_[i];
+        if (a.kind == PH_A_COUNT_STAR) { args[i] = keys[0]; continue; }
+        if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { args[i] = staged[(size_t)a.prog[0].col]; continue; }
+        void *out = nullptr, *val = nullptr;
+        if (ph_dev_alloc(ctx_, n * 8, &out) != PH_OK) { cleanup(); return herr("ph_dev_alloc"); }
+        temps.push_back(out);
+        if (anyValidity) { if (ph_dev_alloc(ctx_, (n + 7) / 8 + 64, &val) != PH_OK) { cleanup(); return herr("ph_dev_alloc"); } temps.push_back(val); }
+        if (ph_expr_eval(ctx_, staged.data(), (int32_t)staged.size(), a.prog.data(), (int32_t)a.prog.size(), nullptr, n,
+                         (int64_t *)out, (uint8_t *)val) != PH_OK) { cleanup(); return herr("ph_expr_eval"); }
+        ph_col c{}; c.type = PH_DEC64; c.scale = argScale_[i]; c.data = out; c.validity = (const uint8_t *)val;
+        args[i] = c;
+    }
+    int rc = ph_agg_sink(agg_, keys.data(), args.data(), (int32_t)args.size(), nullptr, n, 0, rowBase_);
+    std::string err = rc == PH_OK ? "" : herr("ph_agg_sink");
+    if (rc == PH_OK && ph_ctx_sync(ctx_) != PH_OK) err = herr("ph_ctx_sync");
+    cleanup();
+    rowBase_ += n;
+    batch_->Reset();   // dictionaries persist across batches; staged rows do not
+    return err;
+}
+
+std::string gpuAggExecutor::finalize() {
+    int64_t ng = 0;
+    if (ph_agg_group_count(agg_, &ng) != PH_OK) return herr("ph_agg_group_count");
+    int nk = std::max<int>((int)groupCols_.size(), 1), na = (int)aggs_.size();
+    size_t g = (size_t)std::max<int64_t>(ng, 1);
+    std::vector<int64_t> keys(g * (size_t)nk), hi(g * (size_t)std::max(na, 1));
+    std::vector<uint8_t> knull(g * (size_t)nk);
+    std::vector<uint64_t> lo(g * (size_t)std::max(na, 1)), cnt(g * (size_t)std::max(na, 1));
+    if (ph_agg_finalize(agg_, (int64_t)g, nullptr, keys.data(), knull.data(), lo.data(), hi.data(), cnt.data()) != PH_OK)
+        return herr("ph_agg_finalize");
+    for (int64_t base = 0; base < ng; base += DefaultVectorSize) {
+        int card = (int)std::min<int64_t>(DefaultVectorSize, ng - base);
+        auto out = std::make_shared<Chunk>();
+        out->Init(outTypes_, DefaultVectorSize);
+        for (int r = 0; r < card; r++) {
+            size_t gi = (size_t)(base + r);
+            for (size_t c = 0; c < groupCols_.size(); c++) {
+                Vector &v = *out->Data[c];
+                if (knull[gi * (size_t)nk + c]) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+                int64_t kv = keys[gi * (size_t)nk + c];
+                switch (v._Typ.GetInternalType()) {
+                case PT_INT32: v.Slice<int32_t>()[r] = (int32_t)kv; break;
+                case PT_INT64: v.Slice<int64_t>()[r] = kv; break;
+                case PT_DATE: v.Slice<Date>()[r] = DateFromDays((int32_t)kv); break;
+                case PT_DECIMAL: v.Slice<Decimal>()[r] = DecimalFromUnscaled(kv, v._Typ.Scale); break;
+                case PT_VARCHAR: { const std::string &s = batch_->dict((int)c)[(size_t)kv]; v.SetString(r, s.data(), (int64_t)s.size()); break; }
+                default: break;
+                }
+            }
+            for (int a = 0; a < na; a++) {
+                Vector &v = *out->Data[groupCols_.size() + (size_t)a];
+                size_t si = gi * (size_t)na + (size_t)a;
+                __int128 sum = ((__int128)hi[si] << 64) + (__int128)(unsigned __int128)lo[si];
+                uint64_t n = cnt[si];
+                bool dec = argType_[(size_t)a].Id == LTID_DECIMAL;
+                auto null = [&]() { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); };
+                switch (aggs_[(size_t)a].kind) {
+                case PH_A_SUM:  // SumOp.Finalize: NULL when never set (function_aggr.go:813-823)
+                    if (n == 0) { null(); break; }
+                    if (dec) { Decimal d; if (!DecimalFromInt128(sum, argScale_[(size_t)a], &d)) return "decimal sum exceeds 19 digits"; v.Slice<Decimal>()[r] = d; }
+                    else v.Slice<Hugeint>()[r] = Hugeint{lo[si], hi[si]};
+                    break;
+                case PH_A_AVG:  // AvgOp.Finalize (:873-900)
+                    if (n == 0) { null(); break; }
+                    if (dec) { Decimal d; if (!DecimalQuoCount(sum, argScale_[(size_t)a], n, &d)) return "decimal average failed"; v.Slice<Decimal>()[r] = d; }
+                    else v.Slice<double>()[r] = (double)sum / (double)n;
+                    break;
+                case PH_A_COUNT: case PH_A_COUNT_STAR:  // CountOp.Finalize: NULL when 0 (:950-962)
+                    if (n == 0) { null(); break; }
+                    v.Slice<Hugeint>()[r] = Hugeint{n, 0};
+                    break;
+                case PH_A_MIN: case PH_A_MAX:
+                    if (n == 0) { null(); break; }
+                    if (dec) v.Slice<Decimal>()[r] = DecimalFromUnscaled((int64_t)lo[si], argScale_[(size_t)a]);
+                    else if (v._Typ.GetInternalType() == PT_INT32) v.Slice<int32_t>()[r] = (int32_t)(int64_t)lo[si];
+                    else v.Slice<int64_t>()[r] = (int64_t)lo[si];
+                    break;
+                default: break;
+                }
+            }
+        }
+        out->SetCard(card);
+        results_.push_back(out);
+    }
+    return "";
+}
+
+OperatorResult gpuAggExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!built_) {  // pipeline breaker: drain the child (HAS_INIT loop, executor_aggr.go:110-142)
+        for (;;) {
+            Chunk c;
+            OperatorResult r = child_->Execute(nullptr, &c, err);
+            if (r == InvalidOpResult) return InvalidOpResult;
+            if (r == Done) break;
+            if (c.Card() == 0) continue;
+            std::string e = batch_->Append(c);
+            if (e.empty() && batch_->rows() >= batchRows_) e = sinkBatch();
+            if (!e.empty()) { *err = e; return InvalidOpResult; }
+        }
+        std::string e = sinkBatch();
+        if (e.empty()) e = finalize();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        built_ = true;
+    }
+    if (next_ >= results_.size()) return Done;
+    *output = *results_[next_++];
+    return haveMoreOutput;
+}
+
+// ------------------------------------------------------------------ join
+
+gpuJoinExecutor::gpuJoinExecutor(ph_ctx *ctx, OperatorExec *probe, OperatorExec *build, std::vector<int> probeKeys,
+                                 std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks)
+    : ctx_(ctx), probe_(probe), build_(build), probeKeys_(std::move(probeKeys)), buildKeys_(std::move(buildKeys)),
+      buildPayload_(std::move(buildPayload)), batchChunks_(batchChunks) {}
+
+std::string gpuJoinExecutor::Init() {
+    if (probeKeys_.size() != buildKeys_.size() || probeKeys_.empty()) return "join needs matching key lists";
+    auto pt = probe_->OutputTypes(), bt = build_->OutputTypes();
+    for (size_t i = 0; i < probeKeys_.size(); i++) {
+        PhyType a = pt[(size_t)probeKeys_[i]].GetInternalType(), b = bt[(size_t)buildKeys_[i]].GetInternalType();
+        if (a == PT_VARCHAR || b == PT_VARCHAR) return "VARCHAR join keys stay on the CPU executor";
+        if (staged_width(pt[(size_t)probeKeys_[i]]) != staged_width(bt[(size_t)buildKeys_[i]])) return "join key widths differ";
+    }
+    outTypes_ = pt;
+    for (int c : buildPayload_) outTypes_.push_back(bt[(size_t)c]);
+    buildBatch_.reset(new DeviceBatch(ctx_, bt, buildKeys_));
+    probeBatch_.reset(new DeviceBatch(ctx_, pt, probeKeys_));
+    return "";
+}
+
+std::string gpuJoinExecutor::Close() {
+    if (join_) { ph_join_free(join_); join_ = nullptr; }
+    buildBatch_.reset(); probeBatch_.reset(); buildChunks_.clear(); ready_.clear();
+    return "";
+}
+
+std::string gpuJoinExecutor::buildTable() {  // joinBuildHashTable (executor_join.go:237-264)
+    int64_t total = 0;
+    for (;;) {
+        auto c = std::make_shared<Chunk>();
+        std::string err;
+        OperatorResult r = build_->Execute(nullptr, c.get(), &err);
+        if (r == InvalidOpResult) return err.empty() ? "build child failed" : err;
+        if (r == Done) break;
+        if (c->Card() == 0) continue;
+        std::string e = buildBatch_->Append(*c);
+        if (!e.empty()) return e;
+        buildStart_.push_back(total);
+        buildChunks_.push_back(c);
+        total += c->Card();
+    }
+    std::string e = buildBatch_->Upload();
+    if (!e.empty()) return e;
+    std::vector<ph_col> keys;
+    for (size_t k = 0; k < buildKeys_.size(); k++) keys.push_back(buildBatch_->col((int)k));
+    if (ph_join_build(ctx_, keys.data(), (int32_t)keys.size(), nullptr, total, &join_) != PH_OK) return herr("ph_join_build");
+    return "";
+}
+
+std::string gpuJoinExecutor::probeBatch() {
+    std::vector<std::shared_ptr<Chunk>> chunks;
+    std::vector<int64_t> starts;
+    probeBatch_->Reset();
+    while ((int)chunks.size() < batchChunks_) {
+        auto c = std::make_shared<Chunk>();
+        std::string err;
+        OperatorResult r = probe_->Execute(nullptr, c.get(), &err);
+        if (r == InvalidOpResult) return err.empty() ? "probe child failed" : err;
+        if (r == Done) { probeDone_ = true; break; }
+        if (c->Card() == 0) continue;
+        starts.push_back(probeBatch_->rows());
+        std::string e = probeBatch_->Append(*c);
+        if (!e.empty()) return e;
+        chunks.push_back(c);
+    }
+    int64_t n = probeBatch_->rows();
+    if (n == 0 || ph_join_count(join_) == 0) return "";
+    std::string e = probeBatch_->Upload();
+    if (!e.empty()) return e;
+    std::vector<ph_col> keys;
+    for (size_t k = 0; k < probeKeys_.size(); k++) keys.push_back(probeBatch_->col((int)k));
+    int64_t cap = n + 1024, m = 0;
+    void *op = nullptr, *ob = nullptr;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (ph_dev_alloc(ctx_, cap * 4, &op) != PH_OK || ph_dev_alloc(ctx_, cap * 4, &ob) != PH_OK) return herr("ph_dev_alloc");
+        int rc = ph_join_probe_inner(join_, keys.data(), nullptr, n, (int32_t *)op, (int32_t *)ob, cap, &m);
+        if (rc == PH_OK) break;
+        ph_dev_free(ctx_, op); ph_dev_free(ctx_, ob);
+        op = ob = nullptr;
+        if (rc != PH_ECAPACITY || attempt == 1) return herr("ph_join_probe_inner");
+        cap = m;  // duplicate build keys: retry with the exact size
+    }
+    std::vector<int32_t> pr((size_t)m), br((size_t)m);
+    if (m > 0 && (ph_dev_download(ctx_, pr.data(), op, m * 4) != PH_OK || ph_dev_download(ctx_, br.data(), ob, m * 4) != PH_OK)) {
+        ph_dev_free(ctx_, op); ph_dev_free(ctx_, ob);
+        return herr("ph_dev_download");
+    }
+    ph_dev_free(ctx_, op);
+    ph_dev_free(ctx_, ob);
+    // materialise <= 2048-row result chunks: probe columns, then the build payload (gatherResult)
+    std::shared_ptr<Chunk> out;
+    int np = (int)probe_->OutputTypes().size();
+    for (int64_t i = 0; i < m; i++) {
+        if (!out || out->Card() == DefaultVectorSize) {
+            if (out) ready_.push_back(out);
+            out = std::make_shared<Chunk>();
+            out->Init(outTypes_, DefaultVectorSize);
+        }
+        size_t pc = (size_t)(std::upper_bound(starts.begin(), starts.end(), (int64_t)pr[(size_t)i]) - starts.begin()) - 1;
+        size_t bc = (size_t)(std::upper_bound(buildStart_.begin(), buildStart_.end(), (int64_t)br[(size_t)i]) - buildStart_.begin()) - 1;
+        int prow = (int)(pr[(size_t)i] - starts[pc]), brow = (int)(br[(size_t)i] - buildStart_[bc]);
+        int r = out->Card();
+        for (int c = 0; c < np; c++) CopyCell(*chunks[pc]->Data[(size_t)c], prow, out->Data[(size_t)c].get(), r);
+        for (size_t c = 0; c < buildPayload_.size(); c++)
+            CopyCell(*buildChunks_[bc]->Data[(size_t)buildPayload_[c]], brow, out->Data[(size_t)np + c].get(), r);
+        out->SetCard(r + 1);
+    }
+    if (out && out->Card() > 0) ready_.push_back(out);
+    return "";
+}
+
+OperatorResult gpuJoinExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!built_) {
+        std::string e = buildTable();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        built_ = true;
+    }
+    while (ready_.empty() && !probeDone_) {
+        std::string e = probeBatch();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+    }
+    if (ready_.empty()) return Done;
+    *output = *ready_.front();
+    ready_.pop_front();
+    return haveMoreOutput;
+}
+
+}  // namespace plan

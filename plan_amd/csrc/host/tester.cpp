@@ -1,0 +1,242 @@
+// host_tester — drives the GPU executors through the reference's pull protocol (the loop of
+// execOps, pkg/compute/executor.go:151-188) on generated TPC-H data and prints the result in the
+// reference's text format (headline "#\t..." of execQuery, executor_bench.go:229-238; rows via
+// Chunk.SaveToFile). The role `tester tpch1g --query_id N` plays for the reference.
+//   host_tester roundtrip
+//   host_tester q1|q6|q3 <sf_num> <sf_den> [stub]
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "operator_exec.h"
+#include "tpchgen.h"
+
+using namespace plan;
+
+static void die(const std::string &m) { fprintf(stderr, "host_tester: %s\n", m.c_str()); exit(1); }
+
+struct Lineitem {
+    int64_t n = 0;
+    std::vector<int64_t> okey, ext, disc, tax;
+    std::vector<int32_t> qty, ship;
+    std::vector<uint8_t> rf, ls;
+};
+
+static Lineitem gen_lineitem(int64_t num, int64_t den) {
+    Lineitem L;
+    int64_t no = tpchgen_orders_count(num, den);
+    L.n = tpchgen_lineitem_count(num, den, 0, no);
+    size_t n = (size_t)L.n;
+    L.okey.resize(n); L.ext.resize(n); L.disc.resize(n); L.tax.resize(n); L.qty.resize(n); L.ship.resize(n); L.rf.resize(n); L.ls.resize(n);
+    tpchgen_lineitem_cols c{};
+    c.l_orderkey = L.okey.data(); c.l_quantity = L.qty.data(); c.l_extendedprice = L.ext.data(); c.l_discount = L.disc.data();
+    c.l_tax = L.tax.data(); c.l_returnflag = L.rf.data(); c.l_linestatus = L.ls.data(); c.l_shipdate = L.ship.data();
+    tpchgen_lineitem(num, den, 0, no, &c);
+    return L;
+}
+
+// lineitem as the scan would hand it over: reference in-memory types, 2048 rows per chunk
+static std::vector<LType> lineitem_types() {
+    return {IntegerType(), DecimalType(15, 2), DecimalType(15, 2), DecimalType(15, 2), VarcharType(), VarcharType(),
+            DateType(), BigintType()};
+}
+
+static bool fill_lineitem(const Lineitem &L, int64_t *pos, Chunk *out) {
+    if (*pos >= L.n) return false;
+    int card = (int)std::min<int64_t>(DefaultVectorSize, L.n - *pos);
+    out->Init(lineitem_types(), DefaultVectorSize);
+    for (int i = 0; i < card; i++) {
+        size_t r = (size_t)(*pos + i);
+        out->Data[0]->Slice<int32_t>()[i] = L.qty[r];
+        out->Data[1]->Slice<Decimal>()[i] = DecimalFromUnscaled(L.ext[r], 2);
+        out->Data[2]->Slice<Decimal>()[i] = DecimalFromUnscaled(L.disc[r], 2);
+        out->Data[3]->Slice<Decimal>()[i] = DecimalFromUnscaled(L.tax[r], 2);
+        out->Data[4]->SetString(i, TPCHGEN_RETURNFLAG_DICT[L.rf[r]], 1);
+        out->Data[5]->SetString(i, TPCHGEN_LINESTATUS_DICT[L.ls[r]], 1);
+        out->Data[6]->Slice<Date>()[i] = DateFromDays(L.ship[r]);
+        out->Data[7]->Slice<int64_t>()[i] = L.okey[r];
+    }
+    out->SetCard(card);
+    *pos += card;
+    return true;
+}
+
+static std::unique_ptr<OperatorExec> lineitem_source(const Lineitem &L, bool stub) {
+    if (stub) {  // through Chunk.Serialize / Deserialize, like Test_q18_with_stub
+        std::string blob;
+        int64_t pos = 0;
+        Chunk c;
+        while (fill_lineitem(L, &pos, &c)) c.Serialize(&blob);
+        return std::unique_ptr<OperatorExec>(new stubExecutor(lineitem_types(), std::move(blob)));
+    }
+    auto pos = std::make_shared<int64_t>(0);
+    return std::unique_ptr<OperatorExec>(new sourceExecutor(lineitem_types(), [&L, pos](Chunk *out) { return fill_lineitem(L, pos.get(), out); }));
+}
+
+static ph_rpn X_COL(int c) { return ph_rpn{PH_X_COL, c, 0, 0}; }
+static ph_rpn X_CONST(int64_t v, int s) { return ph_rpn{PH_X_CONST, -1, v, s}; }
+static ph_rpn X_OP(int op) { return ph_rpn{op, -1, 0, 0}; }
+
+// pull loop of execOps; returns the rows as text lines
+static std::vector<std::string> run(OperatorExec *root) {
+    std::string e = root->Init();
+    if (!e.empty()) die("Init: " + e);
+    std::vector<std::string> lines;
+    for (;;) {
+        Chunk out;
+        std::string err;
+        OperatorResult r = root->Execute(nullptr, &out, &err);
+        if (r == InvalidOpResult) die("Execute: " + err);
+        if (r == Done) break;
+        std::string text;
+        out.AppendText(&text);
+        size_t p = 0;
+        while (p < text.size()) {
+            size_t q = text.find('\n', p);
+            lines.push_back(text.substr(p, q - p));
+            p = q + 1;
+        }
+    }
+    e = root->Close();
+    if (!e.empty()) die("Close: " + e);
+    return lines;
+}
+
+static void print(int ncols, const std::vector<std::string> &lines) {
+    std::string head = "#";
+    for (int i = 1; i < ncols; i++) head += "\t";
+    printf("%s\n", head.c_str());
+    for (auto &l : lines) printf("%s\n", l.c_str());
+}
+
+static int roundtrip() {
+    Chunk c;
+    c.Init({IntegerType(), BigintType(), DecimalType(15, 2), VarcharType(), DateType(), DoubleType(), HugeintType()}, DefaultVectorSize);
+    for (int i = 0; i < 5; i++) {
+        c.Data[0]->Slice<int32_t>()[i] = i - 2;
+        c.Data[1]->Slice<int64_t>()[i] = (int64_t)i * 10000000000ll;
+        c.Data[2]->Slice<Decimal>()[i] = DecimalFromUnscaled(1050 * i - 7, 2);
+        std::string s = i == 3 ? "" : std::string((size_t)i + 1, (char)('a' + i));
+        c.Data[3]->SetString(i, s.data(), (int64_t)s.size());
+        c.Data[4]->Slice<Date>()[i] = DateFromDays(8035 + 400 * i);
+        c.Data[5]->Slice<double>()[i] = 25.5 + i / 3.0;
+        c.Data[6]->Slice<Hugeint>()[i] = Hugeint{(uint64_t)i * 7, i == 4 ? -1 : 0};
+    }
+    c.Data[0]->Mask.SetInvalid(1, DefaultVectorSize);
+    c.Data[3]->Mask.SetInvalid(2, DefaultVectorSize);
+    c.SetCard(5);
+    std::string blob, err, a, b;
+    c.Serialize(&blob);
+    Chunk d;
+    size_t pos = 0;
+    if (!d.Deserialize(blob, &pos, &err)) die(err);
+    c.AppendText(&a);
+    d.AppendText(&b);
+    if (a != b || pos != blob.size()) die("round trip mismatch");
+    printf("%s", b.c_str());
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "roundtrip")) return roundtrip();
+    if (argc < 4) die("usage: host_tester roundtrip | q1|q6|q3 <sf_num> <sf_den> [stub]");
+    std::string q = argv[1];
+    int64_t num = atoll(argv[2]), den = atoll(argv[3]);
+    bool stub = argc > 4 && !strcmp(argv[4], "stub");
+    ph_ctx *ctx = nullptr;
+    if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
+    Lineitem L = gen_lineitem(num, den);
+    auto scan = lineitem_source(L, stub);
+    auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
+
+    if (q == "q1") {
+        // Order <- Project <- Agg <- Scan(filter l_shipdate <= date '1998-12-01' - 112 days)
+        Compare c{6, PH_LE, lit_date(tpchgen_days_from_civil(1998, 12, 1) - 112)};
+        gpuFilterExecutor filt(ctx, {c}, scan.get());
+        std::vector<ph_rpn> dp = {X_COL(1), X_CONST(1, 0), X_COL(2), X_OP(PH_X_SUB), X_OP(PH_X_MUL)};
+        std::vector<ph_rpn> ch = dp;
+        ch.push_back(X_CONST(1, 0)); ch.push_back(X_COL(3)); ch.push_back(X_OP(PH_X_ADD)); ch.push_back(X_OP(PH_X_MUL));
+        std::vector<AggExpr> aggs = {{PH_A_SUM, {X_COL(0)}}, {PH_A_SUM, {X_COL(1)}}, {PH_A_SUM, dp}, {PH_A_SUM, ch},
+                                     {PH_A_AVG, {X_COL(0)}}, {PH_A_AVG, {X_COL(1)}}, {PH_A_AVG, {X_COL(2)}}, {PH_A_COUNT_STAR, {}}};
+        gpuAggExecutor agg(ctx, {4, 5}, aggs, &filt);
+        if (!filt.Init().empty()) die("filter init");
+        auto lines = run(&agg);
+        std::sort(lines.begin(), lines.end());  // ORDER BY l_returnflag, l_linestatus (the row prefix)
+        print(10, lines);
+        filt.Close();
+    } else if (q == "q6") {
+        Literal lo, hi, qty;
+        lo.kind = hi.kind = Literal::Float;
+        lo.f = (double)(0.03f - 0.01f);   // folded in float32 (rule_constant_folding.go:34-70)
+        hi.f = (double)(0.03f + 0.01f);
+        qty.kind = Literal::Int; qty.i = 24;
+        std::vector<Compare> conj = {{6, PH_GE, lit_date(tpchgen_days_from_civil(1994, 1, 1))},
+                                     {6, PH_LT, lit_date(tpchgen_days_from_civil(1995, 1, 1))},
+                                     {2, PH_GE, lo}, {2, PH_LE, hi}, {0, PH_LT, qty}};
+        gpuFilterExecutor filt(ctx, conj, scan.get());
+        gpuAggExecutor agg(ctx, {}, {{PH_A_SUM, {X_COL(1), X_COL(2), X_OP(PH_X_MUL)}}}, &filt);
+        if (!filt.Init().empty()) die("filter init");
+        print(1, run(&agg));
+        filt.Close();
+    } else if (q == "q3") {
+        int32_t date = tpchgen_days_from_civil(1995, 3, 29);
+        // customer
+        int64_t nc = tpchgen_customer_count(num, den), no = tpchgen_orders_count(num, den);
+        std::vector<int32_t> ckey((size_t)nc), ocust((size_t)no), odate((size_t)no), oprio((size_t)no);
+        std::vector<uint8_t> cseg((size_t)nc);
+        std::vector<int64_t> okey((size_t)no);
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data(); cc.c_mktsegment = cseg.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        tpchgen_orders_cols oc{}; oc.o_orderkey = okey.data(); oc.o_custkey = ocust.data(); oc.o_orderdate = odate.data(); oc.o_shippriority = oprio.data();
+        tpchgen_orders(num, den, 0, no, &oc);
+        auto cpos = std::make_shared<int64_t>(0), opos = std::make_shared<int64_t>(0);
+        std::vector<LType> ctypes = {IntegerType(), VarcharType()}, otypes = {BigintType(), IntegerType(), DateType(), IntegerType()};
+        sourceExecutor csrc(ctypes, [&](Chunk *out) {
+            if (*cpos >= nc) return false;
+            int card = (int)std::min<int64_t>(DefaultVectorSize, nc - *cpos);
+            out->Init(ctypes, DefaultVectorSize);
+            for (int i = 0; i < card; i++) {
+                size_t r = (size_t)(*cpos + i);
+                out->Data[0]->Slice<int32_t>()[i] = ckey[r];
+                const char *s = TPCHGEN_MKTSEGMENT_DICT[cseg[r]];
+                out->Data[1]->SetString(i, s, (int64_t)strlen(s));
+            }
+            out->SetCard(card);
+            *cpos += card;
+            return true;
+        });
+        sourceExecutor osrc(otypes, [&](Chunk *out) {
+            if (*opos >= no) return false;
+            int card = (int)std::min<int64_t>(DefaultVectorSize, no - *opos);
+            out->Init(otypes, DefaultVectorSize);
+            for (int i = 0; i < card; i++) {
+                size_t r = (size_t)(*opos + i);
+                out->Data[0]->Slice<int64_t>()[i] = okey[r];
+                out->Data[1]->Slice<int32_t>()[i] = ocust[r];
+                out->Data[2]->Slice<Date>()[i] = DateFromDays(odate[r]);
+                out->Data[3]->Slice<int32_t>()[i] = oprio[r];
+            }
+            out->SetCard(card);
+            *opos += card;
+            return true;
+        });
+        Literal seg; seg.kind = Literal::Str; seg.s = "HOUSEHOLD";
+        gpuFilterExecutor cf(ctx, {{1, PH_EQ, seg}}, &csrc);
+        gpuFilterExecutor of(ctx, {{2, PH_LT, lit_date(date)}}, &osrc);
+        gpuFilterExecutor lf(ctx, {{6, PH_GT, lit_date(date)}}, scan.get());
+        // join1: orders (probe) x customer (build) on o_custkey = c_custkey
+        gpuJoinExecutor j1(ctx, &of, &cf, {1}, {0}, {});
+        // join2: lineitem (probe) x join1 (build) on l_orderkey = o_orderkey, payload o_orderdate, o_shippriority
+        gpuJoinExecutor j2(ctx, &lf, &j1, {7}, {0}, {2, 3});
+        // group by l_orderkey (7), o_orderdate (8), o_shippriority (9); sum(ext*(1-disc))
+        gpuAggExecutor agg(ctx, {7, 8, 9}, {{PH_A_SUM, {X_COL(1), X_CONST(1, 0), X_COL(2), X_OP(PH_X_SUB), X_OP(PH_X_MUL)}}}, &j2);
+        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2})
+            if (!e->Init().empty()) die("init");
+        print(4, run(&agg));   // all groups, unordered; ORDER BY/LIMIT are outside the hot path
+        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2}) e->Close();
+    } else die("unknown query " + q);
+    ph_ctx_destroy(ctx);
+    return 0;
+}

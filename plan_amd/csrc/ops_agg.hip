@@ -324,7 +324,11 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
         PH_REQUIRE(keys[c].type == a->key_types[c], "ph_agg_sink: key %d has type %d, table was created for %d", c, keys[c].type, a->key_types[c]);
         P.key[c] = {keys[c].type, keys[c].data, keys[c].validity};
     }
+    bool used[ph::AGG_MAX_AGGS] = {};
+    for (int i = 0; i < a->naggs; i++)
+        if (a->aggs[i].kind != PH_A_COUNT_STAR && a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs) used[a->aggs[i].arg] = true;
     for (int c = 0; c < nargs; c++) {
+        if (!used[c]) continue;  // placeholders of count(*) are never read
         int t = args[c].type;
         if (t != PH_I32 && t != PH_I64 && t != PH_DEC64 && t != PH_DATE) { ph::set_error("ph_agg_sink: argument %d has type %d", c, t); return PH_EUNSUPPORTED; }
         P.arg[c] = {t == PH_DATE ? PH_I32 : t, args[c].data, args[c].validity};
@@ -359,6 +363,7 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
                 P.key[c].validity = keys[c].validity ? keys[c].validity + off / 8 : nullptr;
             }
             for (int c = 0; c < nargs && (!sel || positional); c++) {
+                if (!used[c]) continue;
                 int w = ph::type_width(args[c].type);
                 P.arg[c].data = (const char *)args[c].data + off * w;
                 P.arg[c].validity = args[c].validity ? args[c].validity + off / 8 : nullptr;
