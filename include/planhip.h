@@ -194,6 +194,16 @@ int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
  *   count[g*naggs+a] = non-NULL inputs seen (COUNT_STAR: rows). */
 int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
                     uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
+/* Top-N pre-selection for an `ORDER BY <aggregate> [DESC] ... LIMIT k` tail (the reference's
+ * orderExecutor + limit, executor_order.go:56-138, executor_limit.go:105-238, sort over all group
+ * rows on the host). A one-workgroup radix select finds the k-th best value
+ * of aggregate `agg_index` on the device and only the groups at least that good come back
+ * (>= k of them when ties exist, fewer when there are fewer groups), in first-seen order, in the
+ * same layout as ph_agg_finalize. The caller applies the full ORDER BY (tie-breaks) and LIMIT to
+ * those few rows. Sums must fit int64 (PH_EOVERFLOW otherwise: use ph_agg_finalize). */
+int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int64_t k, int64_t max_groups,
+                int64_t *n_out, int64_t *first_row, int64_t *keys, uint8_t *key_null,
+                uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
 void ph_agg_free(ph_agg *a);
 
 /* ------------------------------------------------------------------ hash join

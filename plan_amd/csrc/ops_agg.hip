@@ -181,6 +181,66 @@ __global__ __launch_bounds__(256) void agg_rehash_kernel(int32_t *slots, uint64_
     }
 }
 
+// ---- top-N pre-selection: one workgroup, 8 radix passes over the 64-bit order keys, then a
+// compaction of the groups on the good side of the k-th value.
+__device__ __forceinline__ unsigned long long order_key(long long v, int descending) {
+    unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ull;  // signed -> unsigned order
+    return descending ? ~u : u;                                            // smaller key = better
+}
+
+__global__ __launch_bounds__(1024) void agg_topk_kernel(const unsigned long long *__restrict__ sum_lo,
+                                                        const long long *__restrict__ sum_hi, int naggs, int a,
+                                                        int ng, int descending, long long k,
+                                                        int *__restrict__ out_ids, int *__restrict__ out_count,
+                                                        int cap, int *__restrict__ flags) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long prefix_s;
+    __shared__ long long remaining_s;
+    __shared__ int out_n;
+    if (threadIdx.x == 0) { prefix_s = 0; remaining_s = k; out_n = 0; }
+    __syncthreads();
+    // values must fit int64 (high word = sign extension of the low word)
+    for (int g = threadIdx.x; g < ng; g += 1024) {
+        long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
+        if (sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) atomicOr(flags, 1);
+    }
+    // find the k-th smallest order key, most significant byte first
+    for (int pass = 7; pass >= 0; pass--) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long prefix = prefix_s;
+        unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+        for (int g = threadIdx.x; g < ng; g += 1024) {
+            unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
+            if ((key & mask) == (prefix & mask)) atomicAdd(&hist[(key >> (8 * pass)) & 0xff], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long rem = remaining_s;
+            int b = 0;
+            for (; b < 256; b++) {
+                if ((long long)hist[b] >= rem) break;
+                rem -= hist[b];
+            }
+            if (b == 256) b = 255;  // k > ng: everything qualifies
+            prefix_s = prefix | ((unsigned long long)b << (8 * pass));
+            remaining_s = rem;
+        }
+        __syncthreads();
+    }
+    unsigned long long kth = prefix_s;
+    bool all = k >= ng;
+    for (int g = threadIdx.x; g < ng; g += 1024) {
+        unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
+        if (all || key <= kth) {
+            int pos = atomicAdd(&out_n, 1);
+            if (pos < cap) out_ids[pos] = g;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *out_count = out_n;
+}
+
 }  // namespace ph
 
 struct ph_agg {
@@ -422,5 +482,72 @@ extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row
             if (count) count[o * a->naggs + i] = cn[src * na + i];
         }
     }
+    return PH_OK;
+}
+
+extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int64_t k, int64_t max_groups,
+                           int64_t *n_out, int64_t *first_row, int64_t *keys, uint8_t *key_null,
+                           uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && n_out && k >= 0 && max_groups >= 0 && agg_index >= 0 && agg_index < a->naggs,
+               "ph_agg_topk: bad arguments");
+    int kind = a->aggs[agg_index].kind;
+    PH_REQUIRE(kind == PH_A_SUM || kind == PH_A_MIN || kind == PH_A_MAX || kind == PH_A_AVG,
+               "ph_agg_topk: aggregate %d is not ordered by its sum/min/max value", agg_index);
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(a, &ng));
+    *n_out = 0;
+    if (ng == 0 || k == 0) return PH_OK;
+    ph_ctx *ctx = a->ctx;
+    int cap = (int)std::min<int64_t>(max_groups, ng);
+    int *ids = nullptr, *meta = nullptr;
+    PH_CHECK(ctx->pool_alloc((int64_t)std::max(cap, 1) * 4, (void **)&ids));
+    PH_CHECK(ctx->pool_alloc(8, (void **)&meta));
+    PH_HIP(hipMemsetAsync(meta, 0, 8, ctx->stream));
+    ph::agg_topk_kernel<<<1, 1024, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, descending,
+                                                      (long long)k, ids, meta, cap, meta + 1);
+    PH_HIP(hipGetLastError());
+    int m[2] = {0, 0};
+    int rc = ctx->download(m, meta, 8);
+    if (rc == PH_OK && m[1]) { ph::set_error("ph_agg_topk: a sum does not fit int64; use ph_agg_finalize"); rc = PH_EOVERFLOW; }
+    if (rc == PH_OK && m[0] > cap) { ph::set_error("ph_agg_topk: %d qualifying groups, room for %d", m[0], cap); rc = PH_ECAPACITY; }
+    std::vector<int> host_ids;
+    if (rc == PH_OK) {
+        host_ids.resize((size_t)m[0]);
+        rc = ctx->download(host_ids.data(), ids, (int64_t)m[0] * 4);
+    }
+    ctx->pool_release(ids);
+    ctx->pool_release(meta);
+    if (rc != PH_OK) return rc;
+    // fetch the selected groups (few): per-group small copies through the pinned mailbox
+    size_t n = host_ids.size(), na = (size_t)a->naggs, nk = (size_t)a->nkeys;
+    struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
+    std::vector<Row> rows(n);
+    for (size_t i = 0; i < n && rc == PH_OK; i++) {
+        int g = host_ids[i];
+        Row &r = rows[i];
+        r.k.resize(nk); r.lo.resize(na); r.hi.resize(na); r.cn.resize(na);
+        rc = ctx->download(&r.fr, a->first_row + g, 8);
+        if (rc == PH_OK) rc = ctx->download(r.k.data(), a->gkeys + (int64_t)g * a->nkeys, (int64_t)nk * 8);
+        if (rc == PH_OK) rc = ctx->download(&r.null, a->gnull + g, 4);
+        if (rc == PH_OK) rc = ctx->download(r.lo.data(), a->sum_lo + (int64_t)g * a->naggs, (int64_t)na * 8);
+        if (rc == PH_OK) rc = ctx->download(r.hi.data(), a->sum_hi + (int64_t)g * a->naggs, (int64_t)na * 8);
+        if (rc == PH_OK) rc = ctx->download(r.cn.data(), a->cnt + (int64_t)g * a->naggs, (int64_t)na * 8);
+    }
+    if (rc != PH_OK) return rc;
+    std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.fr < y.fr; });
+    for (size_t o = 0; o < n; o++) {
+        const Row &r = rows[o];
+        if (first_row) first_row[o] = r.fr;
+        for (size_t c = 0; c < nk; c++) {
+            if (keys) keys[o * nk + c] = (int64_t)r.k[c];
+            if (key_null) key_null[o * nk + c] = (r.null >> c) & 1;
+        }
+        for (size_t i = 0; i < na; i++) {
+            if (sum_lo) sum_lo[o * na + i] = r.lo[i];
+            if (sum_hi) sum_hi[o * na + i] = r.hi[i];
+            if (count) count[o * na + i] = r.cn[i];
+        }
+    }
+    *n_out = (int64_t)n;
     return PH_OK;
 }

@@ -60,6 +60,27 @@ class AggResult(ctypes.Structure):
                 ("nkeys", i32), ("naggs", i32)]
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and its libraries ask for it by the unversioned name, so if ROCm's copy were
+    loaded first (through libplanhip.so's NEEDED entry) a later `import torch` would bring in a
+    second runtime, whose device discovery then fails ("No HIP GPUs are available"). Loading
+    torch's copy first makes libplanhip.so resolve to it by SONAME, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -68,6 +89,7 @@ def lib():
             raise RuntimeError(
                 f"{path} is missing — the HIP extension is required (no CPU fallback). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(path)
         for name, rt in (("ph_last_error", ctypes.c_char_p), ("ph_version", ctypes.c_char_p),
                          ("ph_scan_plan_kind", ctypes.c_char_p), ("ph_table_rows", i64),
@@ -386,6 +408,25 @@ class Agg:
             out["sum"] = [[(int(hi[g * na + a]) << 64) + int(lo[g * na + a]) for a in range(self.naggs)]
                           for g in range(ng)]
         return out
+
+    def topk(self, agg_index, k, descending=True, cap=4096):
+        """Groups whose aggregate `agg_index` is at least as good as the k-th best (>= k with ties)."""
+        first = np.zeros(cap, np.int64)
+        keys = np.zeros(cap * self.nkeys, np.int64)
+        knull = np.zeros(cap * self.nkeys, np.uint8)
+        na = max(self.naggs, 1)
+        lo = np.zeros(cap * na, np.uint64)
+        hi = np.zeros(cap * na, np.int64)
+        cnt = np.zeros(cap * na, np.uint64)
+        n = i64()
+        P = lambda a: vp(a.ctypes.data)
+        check(lib().ph_agg_topk(self.h, i32(agg_index), i32(1 if descending else 0), i64(k), i64(cap),
+                                ctypes.byref(n), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt)))
+        m = n.value
+        return dict(ngroups=m, first_row=first[:m], keys=keys.reshape(cap, self.nkeys)[:m],
+                    key_null=knull.reshape(cap, self.nkeys)[:m], sum_lo=lo.reshape(cap, na)[:m, :self.naggs],
+                    sum_hi=hi.reshape(cap, na)[:m, :self.naggs],
+                    count=cnt.reshape(cap, na)[:m, :self.naggs].astype(np.int64))
 
     def free(self):
         if self.h:

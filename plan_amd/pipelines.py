@@ -159,7 +159,11 @@ class Q3Pipeline:
                  [_raw(hip.PH_DEC64, rev, 4)], None, m2, positional=True)
         stage("expr_aggregate", t0)
         t0 = tic()
-        r = agg.finalize(python_ints=False)
+        ngroups_total = agg.group_count()
+        if want_groups:
+            r = agg.finalize(python_ints=False)
+        else:   # ORDER BY revenue DESC ... LIMIT: only the groups at least as good as the k-th
+            r = agg.topk(0, limit, descending=True)
         stage("finalize_download", t0)
 
         # ORDER BY revenue DESC, o_orderdate LIMIT k over this rank's groups (vectorised; the
@@ -185,7 +189,7 @@ class Q3Pipeline:
         for p in frees:
             ctx.free(p)
         self._keep = self._keep2 = self._keep3 = None
-        return dict(ngroups=r["ngroups"], groups=groups, top=top, join_rows=m2, timings=t)
+        return dict(ngroups=ngroups_total, groups=groups, top=top, join_rows=m2, timings=t)
 
 
 def q3_text(top):

@@ -501,3 +501,29 @@ def test_gather_and_partition(ctx):
                 assert owner.setdefault(int(kv), part) == part                # a key lives in one partition
             start += c
     dk.free()
+
+
+def test_agg_topk_preselection(ctx):
+    """ph_agg_topk returns exactly the groups whose aggregate is >= (<=) the k-th best value."""
+    rng = np.random.default_rng(41)
+    n = 400_000
+    k = rng.integers(0, 90_000, n).astype(np.int64)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    v[rng.integers(0, n, 5000)] = 0          # ties around zero
+    dk, dv = hip.DevColumn(ctx, hip.PH_I64, k), hip.DevColumn(ctx, hip.PH_I64, v)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)])
+    agg.sink([dk], [dv], None, n)
+    full = agg.finalize(python_ints=False)
+    sums = full["sum_lo"][:, 0].view(np.int64)
+    for kk, desc in [(10, True), (10, False), (1, True), (1000, True), (10**7, True)]:
+        r = agg.topk(0, kk, descending=desc, cap=full["ngroups"])
+        order = np.sort(sums)[::-1] if desc else np.sort(sums)
+        kth = order[min(kk, len(order)) - 1]
+        want = set(full["keys"][:, 0][(sums >= kth) if desc else (sums <= kth)].tolist())
+        assert set(r["keys"][:, 0].tolist()) == want and r["ngroups"] == len(want)
+        assert np.all(np.diff(r["first_row"]) > 0)
+        got_sum = dict(zip(r["keys"][:, 0].tolist(), r["sum_lo"][:, 0].view(np.int64).tolist()))
+        for key, s_ in zip(full["keys"][:, 0].tolist(), sums.tolist()):
+            if key in got_sum:
+                assert got_sum[key] == s_
+    agg.free(); dk.free(); dv.free()
