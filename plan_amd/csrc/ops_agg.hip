@@ -57,6 +57,7 @@ struct AggSinkParams {
     int *ngroups;
     int64_t gcap;
     int *error_flag;
+    int lds_slots;  // power of two; per-workgroup staging table entries
 };
 
 __device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
@@ -81,6 +82,23 @@ __device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, lo
 }
 
 __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
+    // [first S x i64][sum S*na x u64][gid S x i32][cnt S*na x u32]
+    long long *l_first = reinterpret_cast<long long *>(agg_lds);
+    unsigned long long *l_sum = reinterpret_cast<unsigned long long *>(l_first + P.lds_slots);
+    int *l_gid = reinterpret_cast<int *>(l_sum + (size_t)P.lds_slots * P.naggs);
+    unsigned *l_cnt = reinterpret_cast<unsigned *>(l_gid + P.lds_slots);
+    for (int e = threadIdx.x; e < P.lds_slots; e += 256) {
+        l_gid[e] = -1;
+        l_first[e] = INT64_MAX;
+        for (int a = 0; a < P.naggs; a++) {
+            int kind = P.agg_kind[a];
+            l_sum[e * P.naggs + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
+                                     : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+            l_cnt[e * P.naggs + a] = 0;
+        }
+    }
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
         int64_t r = P.sel ? P.sel[i] : i;
         unsigned long long k[AGG_MAX_KEYS];
@@ -130,13 +148,32 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
             }
         }
         if (gid < 0) continue;
-        atomicMin(&P.first_row[gid], (long long)(P.row_base + i));
+        // ---- LDS staging (per workgroup, direct mapped by group id): rows of a group that owns
+        // its LDS entry accumulate with ds atomics and reach HBM once per workgroup, so a hot
+        // group (Q9: 175 groups, Q1-like inputs: 4) no longer serialises every row on one HBM
+        // atomic. Groups that lose the entry to another id, and values too large for a bounded
+        // int64 partial, update HBM directly.
+        const int e = gid & (P.lds_slots - 1);
+        bool staged = false;
+        {
+            int cur = l_gid[e];
+            if (cur == gid) staged = true;
+            else if (cur == -1) {
+                int old = atomicCAS(&l_gid[e], -1, gid);
+                staged = old == -1 || old == gid;
+            }
+        }
+        long long frow = (long long)(P.row_base + i);
+        if (staged) atomicMin(&l_first[e], frow);
+        else atomicMin(&P.first_row[gid], frow);
         // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
         for (int a = 0; a < P.naggs; a++) {
             int64_t st = (int64_t)gid * P.naggs + a;
+            int ls = e * P.naggs + a;
             int kind = P.agg_kind[a];
             if (kind == PH_A_COUNT_STAR) {
-                atomicAdd(&P.cnt[st], 1ull);
+                if (staged) atomicAdd(&l_cnt[ls], 1u);
+                else atomicAdd(&P.cnt[st], 1ull);
                 continue;
             }
             const AggCol &c = P.arg[P.agg_arg[a]];
@@ -144,7 +181,41 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
             if (!bit_valid(c.validity, ar)) continue;
             long long v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar]
                                            : ((const int64_t *)c.data)[ar];
-            atomicAdd(&P.cnt[st], 1ull);
+            if (kind == PH_A_SUM || kind == PH_A_AVG) {
+                // a workgroup sees at most 2^21 rows per launch: |v| < 2^40 keeps the partial in int64
+                bool small = v > -(1ll << 40) && v < (1ll << 40);
+                if (staged && small) {
+                    atomicAdd(&l_sum[ls], (unsigned long long)v);
+                    atomicAdd(&l_cnt[ls], 1u);
+                } else {
+                    atomicAdd(&P.cnt[st], 1ull);
+                    add128(&P.sum_lo[st], &P.sum_hi[st], v);
+                }
+            } else if (kind == PH_A_COUNT) {
+                if (staged) atomicAdd(&l_cnt[ls], 1u);
+                else atomicAdd(&P.cnt[st], 1ull);
+            } else if (kind == PH_A_MIN) {
+                if (staged) { atomicMin((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
+                else { atomicAdd(&P.cnt[st], 1ull); atomicMin((long long *)&P.sum_lo[st], v); }
+            } else if (kind == PH_A_MAX) {
+                if (staged) { atomicMax((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
+                else { atomicAdd(&P.cnt[st], 1ull); atomicMax((long long *)&P.sum_lo[st], v); }
+            }
+        }
+    }
+    // ---- flush the staging table: one HBM update per (group, aggregate) per workgroup
+    __syncthreads();
+    for (int e = threadIdx.x; e < P.lds_slots; e += 256) {
+        int gid = l_gid[e];
+        if (gid < 0) continue;
+        if (l_first[e] != INT64_MAX) atomicMin(&P.first_row[gid], l_first[e]);
+        for (int a = 0; a < P.naggs; a++) {
+            unsigned n = l_cnt[e * P.naggs + a];
+            if (n == 0) continue;
+            int64_t st = (int64_t)gid * P.naggs + a;
+            int kind = P.agg_kind[a];
+            atomicAdd(&P.cnt[st], (unsigned long long)n);
+            long long v = (long long)l_sum[e * P.naggs + a];
             if (kind == PH_A_SUM || kind == PH_A_AVG) add128(&P.sum_lo[st], &P.sum_hi[st], v);
             else if (kind == PH_A_MIN) atomicMin((long long *)&P.sum_lo[st], v);
             else if (kind == PH_A_MAX) atomicMax((long long *)&P.sum_lo[st], v);
@@ -239,6 +310,26 @@ __global__ __launch_bounds__(1024) void agg_topk_kernel(const unsigned long long
     }
     __syncthreads();
     if (threadIdx.x == 0) *out_count = out_n;
+}
+
+// pack the selected groups' records contiguously so they come back in six copies
+__global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ ids, int n, int nkeys, int naggs,
+                                                       const long long *first_row, const unsigned long long *gkeys,
+                                                       const unsigned *gnull, const unsigned long long *sum_lo,
+                                                       const long long *sum_hi, const unsigned long long *cnt,
+                                                       long long *o_first, unsigned long long *o_keys, unsigned *o_null,
+                                                       unsigned long long *o_lo, long long *o_hi, unsigned long long *o_cnt) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int g = ids[i];
+        o_first[i] = first_row[g];
+        o_null[i] = gnull[g];
+        for (int c = 0; c < nkeys; c++) o_keys[(int64_t)i * nkeys + c] = gkeys[(int64_t)g * nkeys + c];
+        for (int a = 0; a < naggs; a++) {
+            o_lo[(int64_t)i * naggs + a] = sum_lo[(int64_t)g * naggs + a];
+            o_hi[(int64_t)i * naggs + a] = sum_hi[(int64_t)g * naggs + a];
+            o_cnt[(int64_t)i * naggs + a] = cnt[(int64_t)g * naggs + a];
+        }
+    }
 }
 
 }  // namespace ph
@@ -433,8 +524,15 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
         P.mask = (uint64_t)a->cap - 1;
         P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
         P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
-        int grid = (int)std::min<int64_t>((m + 255) / 256, 256 * 8);
-        ph::agg_sink_kernel<<<grid, 256, 0, a->ctx->stream>>>(P);
+        // staging table: as many entries as fit 48 KiB (12 B + 12 B per aggregate each)
+        int per_entry = 12 + 12 * std::max(a->naggs, 1);
+        int slots = 64;
+        while (slots * 2 * per_entry <= 48 * 1024 && slots < 4096) slots *= 2;
+        P.lds_slots = slots;
+        size_t lds = (size_t)slots * (8 + 4) + (size_t)slots * a->naggs * (8 + 4);
+        // few long-lived workgroups: every flush costs one HBM atomic per live entry
+        int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)a->ctx->cu_count * 4);
+        ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
         PH_HIP(hipGetLastError());
     }
     a->rows_sunk += n;
@@ -510,29 +608,44 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     int rc = ctx->download(m, meta, 8);
     if (rc == PH_OK && m[1]) { ph::set_error("ph_agg_topk: a sum does not fit int64; use ph_agg_finalize"); rc = PH_EOVERFLOW; }
     if (rc == PH_OK && m[0] > cap) { ph::set_error("ph_agg_topk: %d qualifying groups, room for %d", m[0], cap); rc = PH_ECAPACITY; }
-    std::vector<int> host_ids;
-    if (rc == PH_OK) {
-        host_ids.resize((size_t)m[0]);
-        rc = ctx->download(host_ids.data(), ids, (int64_t)m[0] * 4);
+    if (rc != PH_OK) { ctx->pool_release(ids); ctx->pool_release(meta); return rc; }
+    size_t n = (size_t)m[0], na = (size_t)a->naggs, nk = (size_t)a->nkeys;
+    struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
+    std::vector<Row> rows(n);
+    if (n > 0) {
+        // one packed device buffer: [first n][null n (padded to 8)][keys n*nk][lo n*na][hi n*na][cnt n*na]
+        size_t words = n + n + n * nk + 3 * n * na;
+        unsigned long long *pack = nullptr;
+        rc = ctx->pool_alloc((int64_t)words * 8, (void **)&pack);
+        if (rc == PH_OK) {
+            long long *o_first = (long long *)pack;
+            unsigned *o_null = (unsigned *)(pack + n);
+            unsigned long long *o_keys = pack + 2 * n, *o_lo = o_keys + n * nk;
+            long long *o_hi = (long long *)(o_lo + n * na);
+            unsigned long long *o_cnt = (unsigned long long *)(o_hi + n * na);
+            ph::agg_pack_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(ids, (int)n, a->nkeys, a->naggs, a->first_row,
+                a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, o_first, o_keys, o_null, o_lo, o_hi, o_cnt);
+            std::vector<unsigned long long> host(words);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+            if (rc == PH_OK) rc = ctx->download(host.data(), pack, (int64_t)words * 8);
+            if (rc == PH_OK) {
+                const unsigned *hn = (const unsigned *)(host.data() + n);
+                const unsigned long long *hk = host.data() + 2 * n, *hl = hk + n * nk, *hh = hl + n * na, *hc = hh + n * na;
+                for (size_t i = 0; i < n; i++) {
+                    Row &r = rows[i];
+                    r.fr = (long long)host[i];
+                    r.null = hn[i];
+                    r.k.assign(hk + i * nk, hk + (i + 1) * nk);
+                    r.lo.assign(hl + i * na, hl + (i + 1) * na);
+                    r.hi.assign((const long long *)hh + i * na, (const long long *)hh + (i + 1) * na);
+                    r.cn.assign(hc + i * na, hc + (i + 1) * na);
+                }
+            }
+            ctx->pool_release(pack);
+        }
     }
     ctx->pool_release(ids);
     ctx->pool_release(meta);
-    if (rc != PH_OK) return rc;
-    // fetch the selected groups (few): per-group small copies through the pinned mailbox
-    size_t n = host_ids.size(), na = (size_t)a->naggs, nk = (size_t)a->nkeys;
-    struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
-    std::vector<Row> rows(n);
-    for (size_t i = 0; i < n && rc == PH_OK; i++) {
-        int g = host_ids[i];
-        Row &r = rows[i];
-        r.k.resize(nk); r.lo.resize(na); r.hi.resize(na); r.cn.resize(na);
-        rc = ctx->download(&r.fr, a->first_row + g, 8);
-        if (rc == PH_OK) rc = ctx->download(r.k.data(), a->gkeys + (int64_t)g * a->nkeys, (int64_t)nk * 8);
-        if (rc == PH_OK) rc = ctx->download(&r.null, a->gnull + g, 4);
-        if (rc == PH_OK) rc = ctx->download(r.lo.data(), a->sum_lo + (int64_t)g * a->naggs, (int64_t)na * 8);
-        if (rc == PH_OK) rc = ctx->download(r.hi.data(), a->sum_hi + (int64_t)g * a->naggs, (int64_t)na * 8);
-        if (rc == PH_OK) rc = ctx->download(r.cn.data(), a->cnt + (int64_t)g * a->naggs, (int64_t)na * 8);
-    }
     if (rc != PH_OK) return rc;
     std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.fr < y.fr; });
     for (size_t o = 0; o < n; o++) {
