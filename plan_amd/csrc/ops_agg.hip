@@ -259,57 +259,62 @@ __device__ __forceinline__ unsigned long long order_key(long long v, int descend
     return descending ? ~u : u;                                            // smaller key = better
 }
 
-__global__ __launch_bounds__(1024) void agg_topk_kernel(const unsigned long long *__restrict__ sum_lo,
-                                                        const long long *__restrict__ sum_hi, int naggs, int a,
-                                                        int ng, int descending, long long k,
-                                                        int *__restrict__ out_ids, int *__restrict__ out_count,
-                                                        int cap, int *__restrict__ flags) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned long long prefix_s;
-    __shared__ long long remaining_s;
-    __shared__ int out_n;
-    if (threadIdx.x == 0) { prefix_s = 0; remaining_s = k; out_n = 0; }
-    __syncthreads();
-    // values must fit int64 (high word = sign extension of the low word)
-    for (int g = threadIdx.x; g < ng; g += 1024) {
+// state[0] = prefix, state[1] = remaining k, hist[256] in global memory; no host round trips
+__global__ __launch_bounds__(256) void topk_check_kernel(const unsigned long long *__restrict__ sum_lo,
+                                                         const long long *__restrict__ sum_hi, int naggs, int a, int ng,
+                                                         int *__restrict__ flags) {
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
         long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
         if (sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) atomicOr(flags, 1);
     }
-    // find the k-th smallest order key, most significant byte first
-    for (int pass = 7; pass >= 0; pass--) {
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned long long prefix = prefix_s;
-        unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
-        for (int g = threadIdx.x; g < ng; g += 1024) {
-            unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
-            if ((key & mask) == (prefix & mask)) atomicAdd(&hist[(key >> (8 * pass)) & 0xff], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long rem = remaining_s;
-            int b = 0;
-            for (; b < 256; b++) {
-                if ((long long)hist[b] >= rem) break;
-                rem -= hist[b];
-            }
-            if (b == 256) b = 255;  // k > ng: everything qualifies
-            prefix_s = prefix | ((unsigned long long)b << (8 * pass));
-            remaining_s = rem;
-        }
-        __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
+                                                        int ng, int descending, int pass,
+                                                        const unsigned long long *__restrict__ state,
+                                                        unsigned *__restrict__ hist) {
+    __shared__ unsigned lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long prefix = state[0];
+    unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
+        unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
+        if ((key & mask) == (prefix & mask)) atomicAdd(&lh[(key >> (8 * pass)) & 0xff], 1u);
     }
-    unsigned long long kth = prefix_s;
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void topk_resolve_kernel(unsigned long long *__restrict__ state, unsigned *__restrict__ hist, int pass) {
+    if (threadIdx.x == 0) {
+        long long rem = (long long)state[1];
+        int b = 0;
+        for (; b < 256; b++) {
+            if ((long long)hist[b] >= rem) break;
+            rem -= hist[b];
+        }
+        if (b == 256) b = 255;  // k > ng: everything qualifies
+        state[0] |= (unsigned long long)b << (8 * pass);
+        state[1] = (unsigned long long)rem;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
+                                                           int ng, int descending, long long k,
+                                                           const unsigned long long *__restrict__ state,
+                                                           int *__restrict__ out_ids, int *__restrict__ out_count, int cap) {
+    unsigned long long kth = state[0];
     bool all = k >= ng;
-    for (int g = threadIdx.x; g < ng; g += 1024) {
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
         unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
         if (all || key <= kth) {
-            int pos = atomicAdd(&out_n, 1);
+            int pos = atomicAdd(out_count, 1);
             if (pos < cap) out_ids[pos] = g;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *out_count = out_n;
 }
 
 // pack the selected groups' records contiguously so they come back in six copies
@@ -598,12 +603,25 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     ph_ctx *ctx = a->ctx;
     int cap = (int)std::min<int64_t>(max_groups, ng);
     int *ids = nullptr, *meta = nullptr;
+    unsigned long long *state = nullptr;  // [0] prefix [1] remaining k, then 256 x u32 histogram
     PH_CHECK(ctx->pool_alloc((int64_t)std::max(cap, 1) * 4, (void **)&ids));
     PH_CHECK(ctx->pool_alloc(8, (void **)&meta));
+    PH_CHECK(ctx->pool_alloc(16 + 1024, (void **)&state));
     PH_HIP(hipMemsetAsync(meta, 0, 8, ctx->stream));
-    ph::agg_topk_kernel<<<1, 1024, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, descending,
-                                                      (long long)k, ids, meta, cap, meta + 1);
+    PH_HIP(hipMemsetAsync(state, 0, 16 + 1024, ctx->stream));
+    unsigned long long kk = (unsigned long long)k;
+    PH_HIP(hipMemcpyAsync(state + 1, &kk, 8, hipMemcpyHostToDevice, ctx->stream));
+    unsigned *hist = (unsigned *)(state + 2);
+    int tg = (int)std::min<int64_t>((ng + 255) / 256, ctx->cu_count * 2);
+    ph::topk_check_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, meta + 1);
+    for (int pass = 7; pass >= 0; pass--) {  // radix select, most significant byte first
+        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, (int)ng, descending, pass, state, hist);
+        ph::topk_resolve_kernel<<<1, 256, 0, ctx->stream>>>(state, hist, pass);
+    }
+    ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, (int)ng, descending, (long long)k,
+                                                          state, ids, meta, cap);
     PH_HIP(hipGetLastError());
+    ctx->pool_release(state);
     int m[2] = {0, 0};
     int rc = ctx->download(m, meta, 8);
     if (rc == PH_OK && m[1]) { ph::set_error("ph_agg_topk: a sum does not fit int64; use ph_agg_finalize"); rc = PH_EOVERFLOW; }
