@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
             }
         }
         long long frow = (long long)(P.row_base + i);
-        if (staged) atomicMin(&l_first[e], frow);
-        else atomicMin(&P.first_row[gid], frow);
+        // first-seen row: almost every row is later than the recorded one, so test with a load
+        // (L2-served, agent scope) and only issue the HBM atomic when it would lower the minimum
+        if (staged) { if (frow < l_first[e]) atomicMin(&l_first[e], frow); }
+        else if (frow < __hip_atomic_load(&P.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(&P.first_row[gid], frow);
         // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
         for (int a = 0; a < P.naggs; a++) {
             int64_t st = (int64_t)gid * P.naggs + a;
