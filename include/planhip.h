@@ -183,8 +183,8 @@ int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_types, int32_t 
 /* keys/args: device columns addressed by row id; rows = sel[0..n) or 0..n. args are PH_I32 /
  * PH_I64 / PH_DEC64 columns (validity honoured: NULL inputs are skipped, NULL keys group together).
  * `positional` != 0: args are addressed by position i instead of row id sel[i] (expression
- * results from ph_expr_eval). row_base is added to the position when recording first-seen
- * order across several sinks. */
+ * results from ph_expr_eval). The first-seen row recorded for a group is row_base + the row id
+ * (sel[i], or i without a selection); give row_base the rows consumed by earlier sinks. */
 int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
                 const int32_t *sel, int64_t n, int32_t positional, int64_t row_base);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
                 staged = old == -1 || old == gid;
             }
         }
-        long long frow = (long long)(P.row_base + i);
+        long long frow = (long long)(P.row_base + (P.sel ? r : i));  // row id (ascending with i)
         // first-seen row: almost every row is later than the recorded one, so test with a load
         // (L2-served, agent scope) and only issue the HBM atomic when it would lower the minimum
         if (staged) { if (frow < l_first[e]) atomicMin(&l_first[e], frow); }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void hash_kernel(HashParams P, int64_t n, uint
 // ------------------------------------------------------------------ expression programs
 
 constexpr int X_MAX_OPS = 24;
-constexpr int X_MAX_COLS = 8;
+constexpr int X_MAX_COLS = 32;
 constexpr int X_STACK = 8;
 
 struct XInstr {

@@ -235,7 +235,7 @@ long double affine_bound(const Affine &a, int64_t mn, int64_t mx) {
 
 }  // namespace
 
-enum PlanKind { PK_FILTER_SUMPROD = 1, PK_LOWCARD_CHAIN = 2 };
+enum PlanKind { PK_FILTER_SUMPROD = 1, PK_LOWCARD_CHAIN = 2, PK_GENERIC = 3 };
 
 struct ph_scan_plan {
     ph_ctx *ctx = nullptr;
@@ -258,6 +258,12 @@ struct ph_scan_plan {
     long double row_bound = 0;  // largest |per-row accumulator value|
     int64_t last_rows = 0;
     int last_grid = 0;
+    // PK_GENERIC: the descriptor itself, run through the operator-granular kernels
+    std::vector<ph_pred> g_preds;
+    std::vector<std::string> g_pred_strs;
+    std::vector<int32_t> g_groups;
+    std::vector<ph_aggexpr> g_aggs;
+    ph_agg *g_agg = nullptr;
 };
 
 static int plan_alloc(ph_scan_plan *p) {
@@ -273,19 +279,18 @@ extern "C" void ph_scan_plan_free(ph_scan_plan *p) {
     if (p->partials) (void)hipFree(p->partials);
     if (p->out_lo) (void)hipFree(p->out_lo);
     if (p->out_hi) (void)hipFree(p->out_hi);
+    if (p->g_agg) ph_agg_free(p->g_agg);
     delete p;
 }
 
 extern "C" const char *ph_scan_plan_kind(const ph_scan_plan *p) {
     if (!p) return "";
-    return p->kind == PK_FILTER_SUMPROD ? "filter_sumprod" : "lowcard_chain";
+    return p->kind == PK_FILTER_SUMPROD ? "filter_sumprod" : (p->kind == PK_LOWCARD_CHAIN ? "lowcard_chain" : "generic");
 }
 
-extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred *preds,
-                                   int32_t npreds, const int32_t *group_cols, int32_t ngroup_cols,
-                                   const ph_aggexpr *aggs, int32_t naggs, ph_scan_plan **out) {
-    PH_REQUIRE(ctx && t && out && naggs > 0 && aggs && npreds >= 0 && ngroup_cols >= 0,
-               "ph_scan_plan_create: bad arguments");
+static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t npreds,
+                     const int32_t *group_cols, int32_t ngroup_cols, const ph_aggexpr *aggs, int32_t naggs,
+                     ph_scan_plan **out) {
     // ---- predicates -> one range per column
     std::vector<Range> ranges;
     bool never = false;
@@ -479,11 +484,165 @@ extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred
     return PH_OK;
 }
 
+
+// ---------------------------------------------------------------- generic plans
+// Any Agg <- Scan(filter) descriptor outside the fused shapes still runs on the device, as the
+// chain the operator-granular executors would run: ph_filter_select per conjunct (narrowing the
+// selection) -> ph_expr_eval per aggregate argument -> ph_agg_sink -> ph_agg_finalize.
+
+extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred *preds,
+                                   int32_t npreds, const int32_t *group_cols, int32_t ngroup_cols,
+                                   const ph_aggexpr *aggs, int32_t naggs, ph_scan_plan **out) {
+    PH_REQUIRE(ctx && t && out && naggs > 0 && aggs && npreds >= 0 && ngroup_cols >= 0,
+               "ph_scan_plan_create: bad arguments");
+    int rc = try_fused(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, out);
+    if (rc != PH_EUNSUPPORTED) return rc;
+    PH_REQUIRE(ngroup_cols <= 4 && naggs <= 16, "ph_scan_plan_create: at most 4 group columns and 16 aggregates");
+    ph_scan_plan *p = new ph_scan_plan();
+    p->ctx = ctx;
+    p->t = t;
+    p->kind = PK_GENERIC;
+    p->g_pred_strs.resize((size_t)npreds);
+    for (int32_t i = 0; i < npreds; i++) {
+        p->g_preds.push_back(preds[i]);
+        if (preds[i].k.s) p->g_pred_strs[(size_t)i] = preds[i].k.s;
+        if (preds[i].col < 0 || preds[i].col >= (int32_t)t->cols.size()) { delete p; set_error("predicate column %d out of range", preds[i].col); return PH_EINVAL; }
+    }
+    for (int32_t i = 0; i < ngroup_cols; i++) {
+        if (group_cols[i] < 0 || group_cols[i] >= (int32_t)t->cols.size()) { delete p; set_error("group column %d out of range", group_cols[i]); return PH_EINVAL; }
+        p->g_groups.push_back(group_cols[i]);
+    }
+    p->nkeys = ngroup_cols;
+    std::vector<ph_col> protos(t->cols.size());
+    for (size_t c = 0; c < t->cols.size(); c++) { protos[c].type = t->cols[c].type; protos[c].scale = t->cols[c].scale; }
+    for (int32_t a = 0; a < naggs; a++) {
+        p->g_aggs.push_back(aggs[a]);
+        ph_scan_plan::AggMap m{aggs[a].kind, a, 0};
+        if (aggs[a].kind != PH_A_COUNT_STAR) {
+            int rc2 = ph_expr_scale(protos.data(), aggs[a].prog, aggs[a].nprog, &m.scale);
+            if (rc2 != PH_OK) { delete p; return rc2; }
+        }
+        p->aggs.push_back(m);
+    }
+    *out = p;
+    return PH_OK;
+}
+
+static int generic_run(ph_scan_plan *p, int64_t row_begin, int64_t row_end) {
+    ph_ctx *ctx = p->ctx;
+    const ph_table *t = p->t;
+    int64_t n = row_end - row_begin;
+    // device views of the table columns, shifted to row_begin
+    std::vector<ph_col> cols(t->cols.size());
+    for (size_t c = 0; c < t->cols.size(); c++) {
+        const auto &d = t->cols[c];
+        ph_col v{};
+        v.type = d.type; v.scale = d.scale; v.aux = d.aux; v.aux_bytes = d.aux_bytes;
+        int w = d.type == PH_STR ? 4 : ph::type_width(d.type);
+        v.data = (const char *)d.data + row_begin * w;
+        if (d.validity) {
+            PH_REQUIRE(row_begin % 8 == 0, "generic plan over NULL-able columns needs row_begin %% 8 == 0");
+            v.validity = d.validity + row_begin / 8;
+        }
+        cols[c] = v;
+    }
+    if (p->g_agg) { ph_agg_free(p->g_agg); p->g_agg = nullptr; }
+    std::vector<int32_t> key_types;
+    for (int32_t g : p->g_groups) key_types.push_back(t->cols[(size_t)g].type);
+    if (key_types.empty()) key_types.push_back(PH_I32);
+    std::vector<ph_aggspec> specs;
+    for (size_t a = 0; a < p->g_aggs.size(); a++) specs.push_back(ph_aggspec{p->g_aggs[a].kind, (int32_t)a});
+    PH_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), 1024, &p->g_agg));
+    if (n <= 0) return PH_OK;
+    std::vector<void *> temps;
+    auto cleanup = [&]() { for (void *q : temps) ctx->pool_release(q); };
+    auto fail = [&](int rc) { cleanup(); return rc; };
+    // ---- conjuncts narrow the selection one after the other (execSelectAnd)
+    int32_t *sel = nullptr;
+    int64_t cnt = n;
+    for (size_t i = 0; i < p->g_preds.size() && cnt > 0; i++) {
+        ph_pred pr = p->g_preds[i];
+        pr.k.s = p->g_pred_strs[i].empty() ? nullptr : p->g_pred_strs[i].c_str();
+        const auto &d = t->cols[(size_t)pr.col];
+        if (d.type == PH_CODE8 && pr.k.type == PH_STR) {  // literal -> dictionary code
+            int code = 999;
+            for (size_t k = 0; k < d.dict.size(); k++) if (pr.k.s && d.dict[k] == pr.k.s) code = (int)k;
+            pr.k.type = PH_I32;
+            pr.k.i = code;
+        }
+        int32_t *out = nullptr;
+        if (ctx->pool_alloc(cnt * 4, (void **)&out) != PH_OK) return fail(PH_EHIP);
+        temps.push_back(out);
+        int64_t m = 0;
+        int rc = ph_filter_select(ctx, &cols[(size_t)pr.col], n, pr.op, &pr.k, sel, cnt, out, &m);
+        if (rc != PH_OK) return fail(rc);
+        sel = out;
+        cnt = m;
+    }
+    if (cnt == 0) { cleanup(); return PH_OK; }
+    // ---- keys
+    std::vector<ph_col> keys;
+    for (int32_t g : p->g_groups) keys.push_back(cols[(size_t)g]);
+    if (keys.empty()) {
+        void *zero = nullptr;
+        int64_t span = sel ? n : cnt;  // addressed by row id
+        if (ctx->pool_alloc(span * 4, &zero) != PH_OK) return fail(PH_EHIP);
+        temps.push_back(zero);
+        if (hipMemsetAsync(zero, 0, (size_t)span * 4, ctx->stream) != hipSuccess) return fail(PH_EHIP);
+        ph_col c{}; c.type = PH_I32; c.data = zero;
+        keys.push_back(c);
+    }
+    // ---- aggregate arguments, evaluated positionally over the selected rows
+    bool any_validity = false;
+    for (auto &c : cols) any_validity |= c.validity != nullptr;
+    std::vector<ph_col> args(p->g_aggs.size());
+    for (size_t a = 0; a < p->g_aggs.size(); a++) {
+        const ph_aggexpr &ax = p->g_aggs[a];
+        if (ax.kind == PH_A_COUNT_STAR) continue;
+        void *out = nullptr, *val = nullptr;
+        if (ctx->pool_alloc(cnt * 8, &out) != PH_OK) return fail(PH_EHIP);
+        temps.push_back(out);
+        if (any_validity) { if (ctx->pool_alloc((cnt + 7) / 8 + 64, &val) != PH_OK) return fail(PH_EHIP); temps.push_back(val); }
+        int rc = ph_expr_eval(ctx, cols.data(), (int32_t)cols.size(), ax.prog, ax.nprog, sel, cnt, (int64_t *)out, (uint8_t *)val);
+        if (rc != PH_OK) return fail(rc);
+        ph_col c{}; c.type = PH_DEC64; c.scale = p->aggs[a].scale; c.data = out; c.validity = (const uint8_t *)val;
+        args[a] = c;
+    }
+    int rc = ph_agg_sink(p->g_agg, keys.data(), args.data(), (int32_t)args.size(), sel, cnt, 1, 0);
+    if (rc == PH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PH_EHIP;
+    cleanup();
+    return rc;
+}
+
+static int generic_fetch(ph_scan_plan *p, ph_agg_result **out) {
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(p->g_agg, &ng));
+    int naggs = (int)p->aggs.size();
+    size_t g = (size_t)std::max<int64_t>(ng, 1), nk = (size_t)std::max<int>(p->nkeys, 1);
+    ph_agg_result *r = (ph_agg_result *)calloc(1, sizeof *r);
+    r->ngroups = ng;
+    r->nkeys = p->nkeys;
+    r->naggs = naggs;
+    r->first_row = (int64_t *)calloc(g, 8);
+    r->keys = (int64_t *)calloc(g * nk, 8);
+    r->sum_lo = (uint64_t *)calloc(g * naggs, 8);
+    r->sum_hi = (int64_t *)calloc(g * naggs, 8);
+    r->count = (uint64_t *)calloc(g * naggs, 8);
+    r->scale = (int32_t *)calloc((size_t)naggs, 4);
+    for (int a = 0; a < naggs; a++) r->scale[a] = p->aggs[(size_t)a].scale;
+    std::vector<uint8_t> knull(g * nk);
+    int rc = ph_agg_finalize(p->g_agg, (int64_t)g, r->first_row, r->keys, knull.data(), r->sum_lo, r->sum_hi, r->count);
+    if (rc != PH_OK) { ph_agg_result_free(r); return rc; }
+    *out = r;
+    return PH_OK;
+}
+
 extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_end) {
     PH_REQUIRE(p != nullptr, "ph_scan_plan_run: plan is NULL");
     PH_REQUIRE(row_begin >= 0 && row_end >= row_begin && row_end <= p->t->nrows && row_begin % 4 == 0,
                "ph_scan_plan_run: rows [%lld,%lld) invalid (begin must be a multiple of 4, table has %lld rows)",
                (long long)row_begin, (long long)row_end, (long long)p->t->nrows);
+    if (p->kind == PK_GENERIC) return generic_run(p, row_begin, row_end);
     int64_t rows = p->never ? 0 : row_end - row_begin;
     int64_t tiles = (rows + 1023) / 1024;
     int max_grid = p->max_grid;
@@ -524,6 +683,10 @@ extern "C" void ph_agg_result_free(ph_agg_result *r) {
 
 extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
     PH_REQUIRE(p && out, "ph_scan_plan_fetch: bad arguments");
+    if (p->kind == PK_GENERIC) {
+        PH_REQUIRE(p->g_agg != nullptr, "ph_scan_plan_fetch: run the plan first");
+        return generic_fetch(p, out);
+    }
     std::vector<unsigned long long> lo((size_t)p->nacc);
     std::vector<long long> hi((size_t)p->nacc);
     PH_CHECK(p->ctx->download(lo.data(), p->out_lo, (int64_t)lo.size() * 8));

@@ -275,8 +275,7 @@ def agg_compare(ctx, key_specs, arg_specs, aggs, n, sel=None, expected=16):
     assert len(gpu_index) == ng
     for og in range(ng):
         g = gpu_index[keyof(gn[og], gk[og])]
-        pos = int(r["first_row"][g])
-        assert (int(sel[pos]) if sel is not None else pos) == int(first[og])
+        assert int(r["first_row"][g]) == int(first[og])      # row id of the group's first row
         for a, (kind, ai) in enumerate(aggs):
             v = vals[og * len(aggs) + a]
             cnt = int(r["count"][g][a])

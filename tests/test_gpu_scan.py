@@ -230,3 +230,53 @@ def test_q9_pipeline_sf1_matches_reference_golden(ctx, sf1):
     n, rows = O.q9(sf1, "%pink%")
     want = {(rows[i].nationkey, rows[i].o_year): rows[i].sum_profit.unscaled(4) for i in range(n)}
     assert {(a, b): c for a, b, c in r["rows"]} == want
+
+
+def test_generic_scan_plan_runs_unfused_shapes(ctx, sf001):
+    """Descriptors outside the two fused shapes run as the operator chain on the device
+    (ph_scan_plan_kind == "generic") and must agree with the oracle's group-by."""
+    L = sf001["lineitem"]
+    n = len(L["l_shipdate"])
+    t = queries.lineitem_table(ctx, L, keys=True)
+    # group by l_suppkey (INTEGER, ~100 groups), filters incl. '!=' and a dictionary-string '=',
+    # aggregates incl. MIN/MAX and an expression with two column factors in one term
+    preds = [hip.pred(queries.L_SHIPDATE, hip.PH_GE, hip.const(hip.PH_DATE, i=tpchgen.days(1994, 1, 1))),
+             hip.pred(queries.L_QUANTITY, hip.PH_NE, hip.const(hip.PH_I32, i=25)),
+             hip.pred(queries.L_RETURNFLAG, hip.PH_EQ, hip.const(hip.PH_STR, s="N"))]
+    e, d, tx = hip.X_COL(queries.L_EXTENDEDPRICE), hip.X_COL(queries.L_DISCOUNT), hip.X_COL(queries.L_TAX)
+    aggs = [hip.aggexpr(hip.PH_A_SUM, [e, d, hip.X_MUL, tx, hip.X_ADD]),      # ext*disc + tax  (scale 4)
+            hip.aggexpr(hip.PH_A_MIN, [e]), hip.aggexpr(hip.PH_A_MAX, [e]),
+            hip.aggexpr(hip.PH_A_AVG, [hip.X_COL(queries.L_QUANTITY)]), hip.aggexpr(hip.PH_A_COUNT_STAR)]
+    p = hip.ScanPlan(ctx, t, preds, [queries.L_SUPPKEY], aggs)
+    assert p.kind == "generic"
+    p.run()
+    r = p.fetch()
+    assert r["scale"][:3] == [4, 2, 2]
+    # oracle: same filters, expression, group-by
+    sel = O.select(O.col(O.OT_DATE, L["l_shipdate"]), O.OP_GE, O.const(O.OT_DATE, i=tpchgen.days(1994, 1, 1)), n=n)
+    sel = O.select(O.col(O.OT_INT32, L["l_quantity"]), O.OP_NE, O.const(O.OT_INT32, i=25), sel)
+    sel = O.select(O.col(O.OT_CODE8, L["l_returnflag"], dictionary=O.cdict(O.RF)), O.OP_EQ, O.const(O.OT_VARCHAR, s="N"), sel)
+    cols = [O.col(O.OT_DECIMAL, L["l_extendedprice"], 2), O.col(O.OT_DECIMAL, L["l_discount"], 2), O.col(O.OT_DECIMAL, L["l_tax"], 2)]
+    rc, v = O.eval_decimal(cols, [(O.OX_COL, 0, 0, 0), (O.OX_COL, 1, 0, 0), (O.OX_MUL, 0, 0, 0), (O.OX_COL, 2, 0, 0), (O.OX_ADD, 0, 0, 0)], None, n)
+    rc2, ve = O.eval_decimal(cols, [(O.OX_COL, 0, 0, 0)], None, n)
+    args = [O.col(O.OT_ODEC, v), O.col(O.OT_ODEC, ve), O.col(O.OT_INT32, L["l_quantity"])]
+    ng, first, gk, gn, vals = O.groupby([O.col(O.OT_INT32, L["l_suppkey"])], args,
+                                        [(O.OA_SUM, 0), (O.OA_MIN, 1), (O.OA_MAX, 1), (O.OA_AVG, 2), (O.OA_COUNT, -1)], sel, len(sel), 4096)
+    assert r["ngroups"] == ng > 50
+    got = {int(r["keys"][g][0]): g for g in range(ng)}
+    for og in range(ng):
+        g = got[int(gk[og][0])]
+        assert int(r["first_row"][g]) == int(first[og])
+        assert r["sum"][g][0] == vals[og * 5 + 0].d.unscaled(4)
+        assert r["sum"][g][1] == vals[og * 5 + 1].d.unscaled(2) and r["sum"][g][2] == vals[og * 5 + 2].d.unscaled(2)
+        assert abs(r["sum"][g][3] / r["count"][g][3] - vals[og * 5 + 3].f) <= 1e-9 * vals[og * 5 + 3].f
+        assert r["count"][g][4] == vals[og * 5 + 4].h.value()
+    # ungrouped generic plan over a row range that selects nothing
+    p2 = hip.ScanPlan(ctx, t, [hip.pred(queries.L_QUANTITY, hip.PH_NE, hip.const(hip.PH_I32, i=7))], [],
+                      [hip.aggexpr(hip.PH_A_MAX, [e])])
+    assert p2.kind == "generic"
+    p2.run(0, 4096)
+    r2 = p2.fetch()
+    m = L["l_quantity"][:4096] != 7
+    assert r2["ngroups"] == 1 and r2["sum"][0][0] == int(L["l_extendedprice"][:4096][m].max())
+    p.free(); p2.free(); t.free()
