@@ -378,6 +378,71 @@ std::string gpuAggExecutor::sinkBatch() {
     return err;
 }
 
+std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector<LType> &keyTypes,
+                           const std::vector<const std::vector<std::string> *> &keyDicts,
+                           const std::vector<int> &aggKinds, const std::vector<LType> &argTypes,
+                           const std::vector<int> &argScales, int64_t ng, const int64_t *keys,
+                           const uint8_t *knull, const uint64_t *lo, const int64_t *hi, const uint64_t *cnt,
+                           std::vector<std::shared_ptr<Chunk>> *results) {
+    size_t nkOut = keyTypes.size();
+    int nk = std::max<int>((int)nkOut, 1), na = (int)aggKinds.size();
+    for (int64_t base = 0; base < ng; base += DefaultVectorSize) {
+        int card = (int)std::min<int64_t>(DefaultVectorSize, ng - base);
+        auto out = std::make_shared<Chunk>();
+        out->Init(outTypes, DefaultVectorSize);
+        for (int r = 0; r < card; r++) {
+            size_t gi = (size_t)(base + r);
+            for (size_t c = 0; c < nkOut; c++) {
+                Vector &v = *out->Data[c];
+                if (knull && knull[gi * (size_t)nk + c]) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+                int64_t kv = keys[gi * (size_t)nk + c];
+                switch (v._Typ.GetInternalType()) {
+                case PT_INT32: v.Slice<int32_t>()[r] = (int32_t)kv; break;
+                case PT_INT64: v.Slice<int64_t>()[r] = kv; break;
+                case PT_DATE: v.Slice<Date>()[r] = DateFromDays((int32_t)kv); break;
+                case PT_DECIMAL: v.Slice<Decimal>()[r] = DecimalFromUnscaled(kv, v._Typ.Scale); break;
+                case PT_VARCHAR: { const std::string &s = (*keyDicts[c])[(size_t)kv]; v.SetString(r, s.data(), (int64_t)s.size()); break; }
+                default: break;
+                }
+            }
+            for (int a = 0; a < na; a++) {
+                Vector &v = *out->Data[nkOut + (size_t)a];
+                size_t si = gi * (size_t)na + (size_t)a;
+                __int128 sum = ((__int128)hi[si] << 64) + (__int128)(unsigned __int128)lo[si];
+                uint64_t n = cnt[si];
+                bool dec = argTypes[(size_t)a].Id == LTID_DECIMAL;
+                auto null = [&]() { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); };
+                switch (aggKinds[(size_t)a]) {
+                case PH_A_SUM:  // SumOp.Finalize: NULL when never set (function_aggr.go:813-823)
+                    if (n == 0) { null(); break; }
+                    if (dec) { Decimal d; if (!DecimalFromInt128(sum, argScales[(size_t)a], &d)) return "decimal sum exceeds 19 digits"; v.Slice<Decimal>()[r] = d; }
+                    else v.Slice<Hugeint>()[r] = Hugeint{lo[si], hi[si]};
+                    break;
+                case PH_A_AVG:  // AvgOp.Finalize (:873-900)
+                    if (n == 0) { null(); break; }
+                    if (dec) { Decimal d; if (!DecimalQuoCount(sum, argScales[(size_t)a], n, &d)) return "decimal average failed"; v.Slice<Decimal>()[r] = d; }
+                    else v.Slice<double>()[r] = (double)sum / (double)n;
+                    break;
+                case PH_A_COUNT: case PH_A_COUNT_STAR:  // CountOp.Finalize: NULL when 0 (:950-962)
+                    if (n == 0) { null(); break; }
+                    v.Slice<Hugeint>()[r] = Hugeint{n, 0};
+                    break;
+                case PH_A_MIN: case PH_A_MAX:
+                    if (n == 0) { null(); break; }
+                    if (dec) v.Slice<Decimal>()[r] = DecimalFromUnscaled((int64_t)lo[si], argScales[(size_t)a]);
+                    else if (v._Typ.GetInternalType() == PT_INT32) v.Slice<int32_t>()[r] = (int32_t)(int64_t)lo[si];
+                    else v.Slice<int64_t>()[r] = (int64_t)lo[si];
+                    break;
+                default: break;
+                }
+            }
+        }
+        out->SetCard(card);
+        results->push_back(out);
+    }
+    return "";
+}
+
 std::string gpuAggExecutor::finalize() {
     int64_t ng = 0;
     if (ph_agg_group_count(agg_, &ng) != PH_OK) return herr("ph_agg_group_count");
@@ -388,61 +453,13 @@ std::string gpuAggExecutor::finalize() {
     std::vector<uint64_t> lo(g * (size_t)std::max(na, 1)), cnt(g * (size_t)std::max(na, 1));
     if (ph_agg_finalize(agg_, (int64_t)g, nullptr, keys.data(), knull.data(), lo.data(), hi.data(), cnt.data()) != PH_OK)
         return herr("ph_agg_finalize");
-    for (int64_t base = 0; base < ng; base += DefaultVectorSize) {
-        int card = (int)std::min<int64_t>(DefaultVectorSize, ng - base);
-        auto out = std::make_shared<Chunk>();
-        out->Init(outTypes_, DefaultVectorSize);
-        for (int r = 0; r < card; r++) {
-            size_t gi = (size_t)(base + r);
-            for (size_t c = 0; c < groupCols_.size(); c++) {
-                Vector &v = *out->Data[c];
-                if (knull[gi * (size_t)nk + c]) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
-                int64_t kv = keys[gi * (size_t)nk + c];
-                switch (v._Typ.GetInternalType()) {
-                case PT_INT32: v.Slice<int32_t>()[r] = (int32_t)kv; break;
-                case PT_INT64: v.Slice<int64_t>()[r] = kv; break;
-                case PT_DATE: v.Slice<Date>()[r] = DateFromDays((int32_t)kv); break;
-                case PT_DECIMAL: v.Slice<Decimal>()[r] = DecimalFromUnscaled(kv, v._Typ.Scale); break;
-                case PT_VARCHAR: { const std::string &s = batch_->dict((int)c)[(size_t)kv]; v.SetString(r, s.data(), (int64_t)s.size()); break; }
-                default: break;
-                }
-            }
-            for (int a = 0; a < na; a++) {
-                Vector &v = *out->Data[groupCols_.size() + (size_t)a];
-                size_t si = gi * (size_t)na + (size_t)a;
-                __int128 sum = ((__int128)hi[si] << 64) + (__int128)(unsigned __int128)lo[si];
-                uint64_t n = cnt[si];
-                bool dec = argType_[(size_t)a].Id == LTID_DECIMAL;
-                auto null = [&]() { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); };
-                switch (aggs_[(size_t)a].kind) {
-                case PH_A_SUM:  // SumOp.Finalize: NULL when never set (function_aggr.go:813-823)
-                    if (n == 0) { null(); break; }
-                    if (dec) { Decimal d; if (!DecimalFromInt128(sum, argScale_[(size_t)a], &d)) return "decimal sum exceeds 19 digits"; v.Slice<Decimal>()[r] = d; }
-                    else v.Slice<Hugeint>()[r] = Hugeint{lo[si], hi[si]};
-                    break;
-                case PH_A_AVG:  // AvgOp.Finalize (:873-900)
-                    if (n == 0) { null(); break; }
-                    if (dec) { Decimal d; if (!DecimalQuoCount(sum, argScale_[(size_t)a], n, &d)) return "decimal average failed"; v.Slice<Decimal>()[r] = d; }
-                    else v.Slice<double>()[r] = (double)sum / (double)n;
-                    break;
-                case PH_A_COUNT: case PH_A_COUNT_STAR:  // CountOp.Finalize: NULL when 0 (:950-962)
-                    if (n == 0) { null(); break; }
-                    v.Slice<Hugeint>()[r] = Hugeint{n, 0};
-                    break;
-                case PH_A_MIN: case PH_A_MAX:
-                    if (n == 0) { null(); break; }
-                    if (dec) v.Slice<Decimal>()[r] = DecimalFromUnscaled((int64_t)lo[si], argScale_[(size_t)a]);
-                    else if (v._Typ.GetInternalType() == PT_INT32) v.Slice<int32_t>()[r] = (int32_t)(int64_t)lo[si];
-                    else v.Slice<int64_t>()[r] = (int64_t)lo[si];
-                    break;
-                default: break;
-                }
-            }
-        }
-        out->SetCard(card);
-        results_.push_back(out);
-    }
-    return "";
+    std::vector<LType> keyTypes;
+    std::vector<const std::vector<std::string> *> dicts;
+    for (size_t c = 0; c < groupCols_.size(); c++) { keyTypes.push_back(childTypes_[(size_t)groupCols_[c]]); dicts.push_back(&batch_->dict((int)c)); }
+    std::vector<int> kinds;
+    for (auto &a : aggs_) kinds.push_back(a.kind);
+    return BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, argScale_, ng, keys.data(), knull.data(), lo.data(),
+                          hi.data(), cnt.data(), &results_);
 }
 
 OperatorResult gpuAggExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
@@ -459,6 +476,93 @@ OperatorResult gpuAggExecutor::Execute(Chunk *, Chunk *output, std::string *err)
         }
         std::string e = sinkBatch();
         if (e.empty()) e = finalize();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        built_ = true;
+    }
+    if (next_ >= results_.size()) return Done;
+    *output = *results_[next_++];
+    return haveMoreOutput;
+}
+
+// ------------------------------------------------------------------ scan + aggregate over a resident table
+
+gpuScanAggExecutor::gpuScanAggExecutor(ph_ctx *ctx, const ph_table *table, std::vector<ResidentColumn> columns,
+                                       std::vector<Compare> conjuncts, std::vector<int> groupCols, std::vector<AggExpr> aggs)
+    : ctx_(ctx), table_(table), cols_(std::move(columns)), conj_(std::move(conjuncts)), groupCols_(std::move(groupCols)),
+      aggs_(std::move(aggs)) {}
+
+std::string gpuScanAggExecutor::Init() {
+    std::vector<ph_pred> preds;
+    for (auto &c : conj_) {
+        ph_pred p{};
+        p.col = c.col;
+        p.op = c.op;
+        switch (c.k.kind) {
+        case Literal::Int: p.k.type = PH_I32; p.k.i = c.k.i; break;
+        case Literal::Float: p.k.type = PH_F32; p.k.f = c.k.f; break;
+        case Literal::DateDays: p.k.type = PH_DATE; p.k.i = c.k.i; break;
+        case Literal::Dec: p.k.type = PH_DEC64; p.k.i = c.k.i; p.k.scale = c.k.scale; break;
+        case Literal::Str: p.k.type = PH_STR; p.k.s = c.k.s.c_str(); break;
+        }
+        preds.push_back(p);
+    }
+    std::vector<ph_col> protos(cols_.size());
+    for (size_t c = 0; c < cols_.size(); c++) { protos[c].type = staged_phtype(cols_[c].type); protos[c].scale = cols_[c].type.Scale; }
+    std::vector<ph_aggexpr> ax(aggs_.size());
+    for (int g : groupCols_) outTypes_.push_back(cols_[(size_t)g].type);
+    for (size_t i = 0; i < aggs_.size(); i++) {
+        const AggExpr &a = aggs_[i];
+        ax[i].kind = a.kind;
+        ax[i].nprog = (int32_t)a.prog.size();
+        if (a.prog.size() > 12) return "aggregate argument program too long";
+        for (size_t k = 0; k < a.prog.size(); k++) ax[i].prog[k] = a.prog[k];
+        LType at = IntegerType();
+        int32_t scale = 0;
+        if (a.kind != PH_A_COUNT_STAR) {
+            if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { at = cols_[(size_t)a.prog[0].col].type; scale = at.Scale; }
+            else {
+                if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
+                at = DecimalType(38, scale);
+            }
+        }
+        argType_.push_back(at);
+        bool dec = at.Id == LTID_DECIMAL;
+        switch (a.kind) {
+        case PH_A_SUM: outTypes_.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;
+        case PH_A_AVG: outTypes_.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;
+        case PH_A_COUNT: case PH_A_COUNT_STAR: outTypes_.push_back(HugeintType()); break;
+        case PH_A_MIN: case PH_A_MAX: outTypes_.push_back(dec ? DecimalType(at.Width, scale) : at); break;
+        default: return "unknown aggregate kind";
+        }
+    }
+    std::vector<int32_t> groups(groupCols_.begin(), groupCols_.end());
+    if (ph_scan_plan_create(ctx_, table_, preds.data(), (int32_t)preds.size(), groups.data(), (int32_t)groups.size(), ax.data(),
+                            (int32_t)ax.size(), &plan_) != PH_OK)
+        return herr("ph_scan_plan_create");
+    return "";
+}
+
+std::string gpuScanAggExecutor::Close() {
+    if (plan_) { ph_scan_plan_free(plan_); plan_ = nullptr; }
+    results_.clear();
+    return "";
+}
+
+OperatorResult gpuScanAggExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!built_) {
+        ph_agg_result *r = nullptr;
+        if (ph_scan_plan_run(plan_, 0, ph_table_rows(table_)) != PH_OK || ph_scan_plan_fetch(plan_, &r) != PH_OK) {
+            *err = herr("ph_scan_plan_run/fetch");
+            return InvalidOpResult;
+        }
+        std::vector<LType> keyTypes;
+        std::vector<const std::vector<std::string> *> dicts;
+        for (int g : groupCols_) { keyTypes.push_back(cols_[(size_t)g].type); dicts.push_back(&cols_[(size_t)g].dict); }
+        std::vector<int> kinds, scales;
+        for (size_t i = 0; i < aggs_.size(); i++) { kinds.push_back(aggs_[i].kind); scales.push_back(r->scale[i]); }
+        std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo,
+                                       r->sum_hi, r->count, &results_);
+        ph_agg_result_free(r);
         if (!e.empty()) { *err = e; return InvalidOpResult; }
         built_ = true;
     }

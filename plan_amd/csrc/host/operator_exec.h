@@ -182,6 +182,46 @@ private:
     std::deque<std::shared_ptr<Chunk>> ready_;
 };
 
+// Agg <- Scan(filter) over a RESIDENT table — the measured mode behind the operator interface
+// (INTEGRATION.md's gpuScanAggExecutor): nothing is staged per chunk; Init builds the
+// ph_scan_plan (fused kernel when the shape matches, operator chain otherwise), the first
+// Execute runs it over the whole table, later calls hand out <= 2048 group rows each.
+struct ResidentColumn {
+    LType type;                      // SQL type of the column (what the scan would emit)
+    std::vector<std::string> dict;   // VARCHAR dictionary columns: code -> string
+};
+
+class gpuScanAggExecutor : public OperatorExec {
+public:
+    gpuScanAggExecutor(ph_ctx *ctx, const ph_table *table, std::vector<ResidentColumn> columns,
+                       std::vector<Compare> conjuncts, std::vector<int> groupCols, std::vector<AggExpr> aggs);
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override;
+    std::vector<LType> OutputTypes() const override { return outTypes_; }
+    const char *kind() const { return plan_ ? ph_scan_plan_kind(plan_) : ""; }
+private:
+    ph_ctx *ctx_;
+    const ph_table *table_;
+    std::vector<ResidentColumn> cols_;
+    std::vector<Compare> conj_;
+    std::vector<int> groupCols_;
+    std::vector<AggExpr> aggs_;
+    std::vector<LType> outTypes_, argType_;
+    ph_scan_plan *plan_ = nullptr;
+    std::vector<std::shared_ptr<Chunk>> results_;
+    size_t next_ = 0;
+    bool built_ = false;
+};
+
+// builds the output chunks of an aggregate from the device result arrays (FinalizeStates typing)
+std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector<LType> &keyTypes,
+                           const std::vector<const std::vector<std::string> *> &keyDicts,
+                           const std::vector<int> &aggKinds, const std::vector<LType> &argTypes,
+                           const std::vector<int> &argScales, int64_t ngroups, const int64_t *keys,
+                           const uint8_t *keyNull, const uint64_t *lo, const int64_t *hi, const uint64_t *cnt,
+                           std::vector<std::shared_ptr<Chunk>> *out);
+
 // copies one cell (any supported type) between flat vectors; src may be any format
 void CopyCell(const Vector &src, int srcRow, Vector *dst, int dstRow);
 

@@ -3,7 +3,7 @@
 // reference's text format (headline "#\t..." of execQuery, executor_bench.go:229-238; rows via
 // Chunk.SaveToFile). The role `tester tpch1g --query_id N` plays for the reference.
 //   host_tester roundtrip
-//   host_tester q1|q6|q3 <sf_num> <sf_den> [stub]
+//   host_tester q1|q6|q3 <sf_num> <sf_den> [stub|resident]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -151,7 +151,50 @@ int main(int argc, char **argv) {
     auto scan = lineitem_source(L, stub);
     auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
 
-    if (q == "q1") {
+    bool resident = argc > 4 && !strcmp(argv[4], "resident");
+    if (resident && (q == "q1" || q == "q6")) {
+        // the measured mode behind the same interface: columns loaded once with ph_table_create,
+        // Agg <- Scan(filter) collapsed into a ph_scan_plan (fused kernel)
+        std::string rfd, lsd;
+        for (auto s : TPCHGEN_RETURNFLAG_DICT) { rfd += s; rfd.push_back('\0'); }
+        for (auto s : TPCHGEN_LINESTATUS_DICT) { lsd += s; lsd.push_back('\0'); }
+        ph_col hc[7] = {};
+        hc[0].type = PH_I32; hc[0].data = L.qty.data();
+        hc[1].type = PH_DEC64; hc[1].scale = 2; hc[1].data = L.ext.data();
+        hc[2].type = PH_DEC64; hc[2].scale = 2; hc[2].data = L.disc.data();
+        hc[3].type = PH_DEC64; hc[3].scale = 2; hc[3].data = L.tax.data();
+        hc[4].type = PH_CODE8; hc[4].data = L.rf.data(); hc[4].aux = rfd.data(); hc[4].aux_bytes = (int64_t)rfd.size();
+        hc[5].type = PH_CODE8; hc[5].data = L.ls.data(); hc[5].aux = lsd.data(); hc[5].aux_bytes = (int64_t)lsd.size();
+        hc[6].type = PH_DATE; hc[6].data = L.ship.data();
+        ph_table *tab = nullptr;
+        if (ph_table_create(ctx, 7, hc, L.n, &tab) != PH_OK) die(std::string("ph_table_create: ") + ph_last_error());
+        std::vector<ResidentColumn> rc = {{IntegerType(), {}}, {DecimalType(15, 2), {}}, {DecimalType(15, 2), {}}, {DecimalType(15, 2), {}},
+                                          {VarcharType(), {"A", "N", "R"}}, {VarcharType(), {"F", "O"}}, {DateType(), {}}};
+        if (q == "q1") {
+            Compare c{6, PH_LE, lit_date(tpchgen_days_from_civil(1998, 12, 1) - 112)};
+            std::vector<ph_rpn> dp = {X_COL(1), X_CONST(1, 0), X_COL(2), X_OP(PH_X_SUB), X_OP(PH_X_MUL)};
+            std::vector<ph_rpn> ch = dp;
+            ch.push_back(X_CONST(1, 0)); ch.push_back(X_COL(3)); ch.push_back(X_OP(PH_X_ADD)); ch.push_back(X_OP(PH_X_MUL));
+            std::vector<AggExpr> aggs = {{PH_A_SUM, {X_COL(0)}}, {PH_A_SUM, {X_COL(1)}}, {PH_A_SUM, dp}, {PH_A_SUM, ch},
+                                         {PH_A_AVG, {X_COL(0)}}, {PH_A_AVG, {X_COL(1)}}, {PH_A_AVG, {X_COL(2)}}, {PH_A_COUNT_STAR, {}}};
+            gpuScanAggExecutor agg(ctx, tab, rc, {c}, {4, 5}, aggs);
+            auto lines = run(&agg);
+            std::sort(lines.begin(), lines.end());
+            print(10, lines);
+        } else {
+            Literal lo, hi, qty;
+            lo.kind = hi.kind = Literal::Float;
+            lo.f = (double)(0.03f - 0.01f);
+            hi.f = (double)(0.03f + 0.01f);
+            qty.kind = Literal::Int; qty.i = 24;
+            std::vector<Compare> conj = {{6, PH_GE, lit_date(tpchgen_days_from_civil(1994, 1, 1))},
+                                         {6, PH_LT, lit_date(tpchgen_days_from_civil(1995, 1, 1))},
+                                         {2, PH_GE, lo}, {2, PH_LE, hi}, {0, PH_LT, qty}};
+            gpuScanAggExecutor agg(ctx, tab, rc, conj, {}, {{PH_A_SUM, {X_COL(1), X_COL(2), X_OP(PH_X_MUL)}}});
+            print(1, run(&agg));
+        }
+        ph_table_free(tab);
+    } else if (q == "q1") {
         // Order <- Project <- Agg <- Scan(filter l_shipdate <= date '1998-12-01' - 112 days)
         Compare c{6, PH_LE, lit_date(tpchgen_days_from_civil(1998, 12, 1) - 112)};
         gpuFilterExecutor filt(ctx, {c}, scan.get());

@@ -60,3 +60,12 @@ def test_q3_two_joins_through_operator_interface_matches_reference_golden():
     rows.sort(key=lambda r: (-Decimal(r[1]), r[2]))      # ORDER BY revenue DESC, o_orderdate
     text = "#\t\t\t\n" + "".join("\t".join(r) + "\n" for r in rows[:10])
     assert text == open(os.path.join(G, "plan_q3.txt")).read()
+
+
+@pytest.mark.gpu
+def test_resident_scan_agg_executor_matches_reference_golden():
+    """gpuScanAggExecutor: table loaded once, Agg <- Scan(filter) as one fused plan, group rows
+    finalised into pkg/chunk types (Hugeint / Decimal / double) — the measured mode behind the
+    operator interface."""
+    assert run("q1", "1", "1", "resident") == open(os.path.join(G, "plan_q1.txt")).read()
+    assert run("q6", "1", "1", "resident") == open(os.path.join(G, "plan_q6.txt")).read()
