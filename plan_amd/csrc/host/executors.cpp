@@ -574,9 +574,9 @@ OperatorResult gpuScanAggExecutor::Execute(Chunk *, Chunk *output, std::string *
 // ------------------------------------------------------------------ join
 
 gpuJoinExecutor::gpuJoinExecutor(ph_ctx *ctx, OperatorExec *probe, OperatorExec *build, std::vector<int> probeKeys,
-                                 std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks)
+                                 std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks, JoinType type)
     : ctx_(ctx), probe_(probe), build_(build), probeKeys_(std::move(probeKeys)), buildKeys_(std::move(buildKeys)),
-      buildPayload_(std::move(buildPayload)), batchChunks_(batchChunks) {}
+      buildPayload_(std::move(buildPayload)), batchChunks_(batchChunks), type_(type) {}
 
 std::string gpuJoinExecutor::Init() {
     if (probeKeys_.size() != buildKeys_.size() || probeKeys_.empty()) return "join needs matching key lists";
@@ -587,7 +587,7 @@ std::string gpuJoinExecutor::Init() {
         if (staged_width(pt[(size_t)probeKeys_[i]]) != staged_width(bt[(size_t)buildKeys_[i]])) return "join key widths differ";
     }
     outTypes_ = pt;
-    for (int c : buildPayload_) outTypes_.push_back(bt[(size_t)c]);
+    if (type_ == JoinInner) for (int c : buildPayload_) outTypes_.push_back(bt[(size_t)c]);
     buildBatch_.reset(new DeviceBatch(ctx_, bt, buildKeys_));
     probeBatch_.reset(new DeviceBatch(ctx_, pt, probeKeys_));
     return "";
@@ -639,11 +639,37 @@ std::string gpuJoinExecutor::probeBatch() {
         chunks.push_back(c);
     }
     int64_t n = probeBatch_->rows();
-    if (n == 0 || ph_join_count(join_) == 0) return "";
+    if (n == 0) return "";
+    if (ph_join_count(join_) == 0 && type_ != JoinAnti) return "";
     std::string e = probeBatch_->Upload();
     if (!e.empty()) return e;
     std::vector<ph_col> keys;
     for (size_t k = 0; k < probeKeys_.size(); k++) keys.push_back(probeBatch_->col((int)k));
+    if (type_ != JoinInner) {
+        // ScanKeyMatches + NextSemiOrAntiJoin (join_scan.go:120-180): found flag per probe row,
+        // then the probe chunk sliced by the rows with found == (type is SEMI)
+        void *fd = nullptr;
+        if (ph_dev_alloc(ctx_, n, &fd) != PH_OK) return herr("ph_dev_alloc");
+        std::vector<uint8_t> found((size_t)n);
+        if (ph_join_probe_mark(join_, keys.data(), nullptr, n, (uint8_t *)fd) != PH_OK ||
+            ph_dev_download(ctx_, found.data(), fd, n) != PH_OK) { ph_dev_free(ctx_, fd); return herr("ph_join_probe_mark"); }
+        ph_dev_free(ctx_, fd);
+        uint8_t want = type_ == JoinSemi ? 1 : 0;
+        for (size_t ci = 0; ci < chunks.size(); ci++) {
+            auto sv = std::make_shared<SelectVector>();
+            sv->identity = false;
+            for (int i = 0; i < chunks[ci]->Card(); i++)
+                if (found[(size_t)(starts[ci] + i)] == want) sv->SelVec.push_back(i);
+            if (sv->SelVec.empty()) continue;
+            auto out = std::make_shared<Chunk>();
+            out->Init(outTypes_, DefaultVectorSize);
+            std::vector<int> indice;
+            for (int c = 0; c < chunks[ci]->ColumnCount(); c++) indice.push_back(c);
+            out->SliceIndice(*chunks[ci], sv, (int)sv->SelVec.size(), 0, indice);
+            ready_.push_back(out);
+        }
+        return "";
+    }
     int64_t cap = n + 1024, m = 0;
     void *op = nullptr, *ob = nullptr;
     for (int attempt = 0; attempt < 2; attempt++) {

@@ -156,12 +156,17 @@ private:
     size_t next_ = 0;
 };
 
+// join types of the hot path (LOT_JoinType*, join_scan.go:47-165); SEMI / ANTI emit the probe
+// rows that have / lack a match (NextSemiOrAntiJoin :120-140), MARK is their building block
+enum JoinType { JoinInner, JoinSemi, JoinAnti };
+
 class gpuJoinExecutor : public OperatorExec {
 public:
-    // children[0] probes, children[1] is built (executor_join.go:237-264); output = all probe
-    // columns followed by buildPayload columns of the build side; inner join.
+    // children[0] probes, children[1] is built (executor_join.go:237-264); inner: output = all
+    // probe columns followed by buildPayload columns of the build side; semi/anti: probe columns.
     gpuJoinExecutor(ph_ctx *ctx, OperatorExec *probe, OperatorExec *build, std::vector<int> probeKeys,
-                    std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks = 512);
+                    std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks = 512,
+                    JoinType type = JoinInner);
     std::string Init() override;
     OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
     std::string Close() override;
@@ -179,6 +184,7 @@ private:
     std::vector<int64_t> buildStart_;                   // first row id of each build chunk
     ph_join *join_ = nullptr;
     bool built_ = false, probeDone_ = false;
+    JoinType type_ = JoinInner;
     std::deque<std::shared_ptr<Chunk>> ready_;
 };
 

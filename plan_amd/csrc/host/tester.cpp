@@ -147,7 +147,8 @@ int main(int argc, char **argv) {
     bool stub = argc > 4 && !strcmp(argv[4], "stub");
     ph_ctx *ctx = nullptr;
     if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
-    Lineitem L = gen_lineitem(num, den);
+    Lineitem L;
+    if (q != "semi" && q != "anti") L = gen_lineitem(num, den);
     auto scan = lineitem_source(L, stub);
     auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
 
@@ -279,6 +280,30 @@ int main(int argc, char **argv) {
             if (!e->Init().empty()) die("init");
         print(4, run(&agg));   // all groups, unordered; ORDER BY/LIMIT are outside the hot path
         for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2}) e->Close();
+    } else if (q == "semi" || q == "anti") {
+        // customer SEMI/ANTI JOIN orders ON c_custkey = o_custkey: customers with / without orders
+        int64_t nc = tpchgen_customer_count(num, den), no = tpchgen_orders_count(num, den);
+        std::vector<int32_t> ckey((size_t)nc), ocust((size_t)no);
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        tpchgen_orders_cols oc{}; oc.o_custkey = ocust.data();
+        tpchgen_orders(num, den, 0, no, &oc);
+        auto cpos = std::make_shared<int64_t>(0), opos = std::make_shared<int64_t>(0);
+        auto int_source = [](const std::vector<int32_t> &v, std::shared_ptr<int64_t> pos) {
+            return [&v, pos](Chunk *out) {
+                int64_t n = (int64_t)v.size();
+                if (*pos >= n) return false;
+                int card = (int)std::min<int64_t>(DefaultVectorSize, n - *pos);
+                out->Init({IntegerType()}, DefaultVectorSize);
+                memcpy(out->Data[0]->Data.data(), v.data() + *pos, (size_t)card * 4);
+                out->SetCard(card);
+                *pos += card;
+                return true;
+            };
+        };
+        sourceExecutor csrc({IntegerType()}, int_source(ckey, cpos)), osrc({IntegerType()}, int_source(ocust, opos));
+        gpuJoinExecutor j(ctx, &csrc, &osrc, {0}, {0}, {}, 512, q == "semi" ? JoinSemi : JoinAnti);
+        print(1, run(&j));
     } else die("unknown query " + q);
     ph_ctx_destroy(ctx);
     return 0;

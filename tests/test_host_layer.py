@@ -69,3 +69,16 @@ def test_resident_scan_agg_executor_matches_reference_golden():
     operator interface."""
     assert run("q1", "1", "1", "resident") == open(os.path.join(G, "plan_q1.txt")).read()
     assert run("q6", "1", "1", "resident") == open(os.path.join(G, "plan_q6.txt")).read()
+
+
+@pytest.mark.gpu
+def test_semi_and_anti_join_executors(sf001):
+    """customer SEMI / ANTI JOIN orders on the customer key: the emitted customer keys are exactly
+    those with / without an order (in TPC-H every third customer key never orders)."""
+    import numpy as np
+    ck = sf001["customer"]["c_custkey"]
+    has = np.isin(ck, sf001["orders"]["o_custkey"])
+    semi = [int(x) for x in run("semi", "1", "100").split("\n")[1:] if x]
+    anti = [int(x) for x in run("anti", "1", "100").split("\n")[1:] if x]
+    assert semi == ck[has].tolist() and anti == ck[~has].tolist()
+    assert all(k % 3 == 0 for k in anti[:50]) and len(anti) >= len(ck) // 3
