@@ -71,9 +71,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # Rehearsal knob for a one-GPU box: PH_BENCH_BACKEND=gloo puts every rank on device 0 and runs
+    # the collectives over gloo on CPU tensors (the real runs use nccl = RCCL, one GPU per rank).
+    backend = os.environ.get("PH_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if args.query == "q3":
         return bench_q3(args, rank, local_rank, world)
@@ -103,23 +112,14 @@ def main():
         bytes_per_row = Q6_BYTES_PER_ROW
 
     def merge_partials():
-        """cross-rank merge of the partial group rows (N>1): all-gather of the fetched rows"""
+        """cross-rank merge of the partial group rows (N>1): plan_amd.dist.merge_group_partials
+        all-gathers the few-hundred-byte partial rows and sums them (tests/test_dist_gloo.py)"""
         r = plan.fetch()
         if world == 1:
             return r
-        payload = [(tuple(int(x) for x in r["keys"][g]), r["sum"][g], r["count"][g])
-                   for g in range(r["ngroups"])]
-        gathered = [None] * world
-        dist.all_gather_object(gathered, payload)
-        merged = {}
-        for part in gathered:
-            for k, s, c in part:
-                if k not in merged:
-                    merged[k] = ([0] * len(s), [0] * len(c))
-                for a in range(len(s)):
-                    merged[k][0][a] += s[a]
-                    merged[k][1][a] += c[a]
-        return merged
+        from plan_amd import dist as pdist
+        mine = {tuple(int(x) for x in r["keys"][g]): (r["sum"][g], r["count"][g]) for g in range(r["ngroups"])}
+        return pdist.merge_group_partials(mine)
 
     def step():
         plan.run()
@@ -141,10 +141,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([nrows], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([nrows], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_rows = int(tot.item())
     else:
