@@ -247,10 +247,26 @@ class Q9Pipeline:
         for c in self.cols:
             c.free()
 
+    def _tensor_gather(self, col, idx_ptr, n, dtype):
+        import torch
+        out = torch.empty(max(n, 1), dtype=dtype, device="cuda")
+        if n:
+            c = col.col() if isinstance(col, hip.DevColumn) else col
+            hip.check(hip.lib().ph_gather(self.ctx.h, hip.ctypes.byref(c), idx_ptr, hip.i64(n), hip.vp(out.data_ptr())))
+        return out[:n]
+
     def run(self):
+        """N == 1: everything local. N > 1 (one process per GPU, tables sharded by row ranges):
+        the small build sides are broadcast — pink part keys, the partsupp rows of pink parts (found
+        with a semi-join against the broadcast part keys), supplier — and the one large join,
+        lineitem x orders, is hash-partitioned by order key on both sides and exchanged with an
+        all-to-all each (multi-stage: part-key stage local after the broadcasts, order-key stage
+        partitioned). The 175 partial groups are merged at the end."""
         ctx = self.ctx
+        N = dist.world()
         t, frees = {}, []
         tic = time.perf_counter
+        keep = []   # torch tensors that back device columns
 
         def stage(name, t0):
             ctx.sync()
@@ -261,57 +277,128 @@ class Q9Pipeline:
             frees.append(p)
             return p
 
+        def bcast(col, idx, n, dtype):
+            """gather rows idx of col and all-gather them over the ranks -> (ph_col-able ptr, count)"""
+            import torch
+            mine = self._tensor_gather(col, idx, n, dtype)
+            ctx.sync()
+            allv = dist.allgather_rows(mine)
+            torch.cuda.synchronize()
+            keep.append(allv)
+            return allv
+
         t0 = tic()
         psel, np_ = hip.filter_select(ctx, self.p_name, self.n["p"], hip.PH_LIKE,
                                       hip.const(hip.PH_STR, s=self.pattern))
         frees.append(psel)
-        j = hip.Join(ctx, [self.p_key], psel, np_)
+        if N == 1:
+            j = hip.Join(ctx, [self.p_key], psel, np_)
+        else:
+            import torch
+            pk = bcast(self.p_key, psel, np_, torch.int32)
+            j = hip.Join(ctx, [_raw(hip.PH_I32, pk.data_ptr())], None, pk.numel())
         stage("part_like_build", t0)
         t0 = tic()
         n1, lrow, _ = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
         frees += [lrow, _]
-        j.free()
         stage("lineitem_probe_part", t0)
 
         t0 = tic()
-        j = hip.Join(ctx, [self.ps_part, self.ps_supp], None, self.n["ps"])
+        if N == 1:
+            j.free()
+            jps = hip.Join(ctx, [self.ps_part, self.ps_supp], None, self.n["ps"])
+            ps_cost = self.ps_cost
+        else:
+            import torch
+            # semi-join: local partsupp rows of pink parts, then broadcast (4 rows per pink part)
+            f = j.probe_mark([self.ps_part], None, self.n["ps"])
+            frees.append(f)
+            fsel, fn = hip.filter_select(ctx, _raw(hip.PH_CODE8, f), self.n["ps"], hip.PH_EQ, hip.const(hip.PH_I32, i=1))
+            frees.append(fsel)
+            j.free()
+            bp = bcast(self.ps_part, fsel, fn, torch.int32)
+            bs = bcast(self.ps_supp, fsel, fn, torch.int32)
+            bc = bcast(self.ps_cost, fsel, fn, torch.int64)
+            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp.data_ptr()), _raw(hip.PH_I32, bs.data_ptr())], None, bp.numel())
+            ps_cost = _raw(hip.PH_DEC64, bc.data_ptr(), 2)
         k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
-        n2, pos2, psrow = j.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+        n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
         frees += [pos2, psrow]
-        j.free()
+        jps.free()
         lrow2 = gat(_raw(hip.PH_I32, lrow), pos2, n2)
         stage("partsupp_join", t0)
 
         t0 = tic()
-        j = hip.Join(ctx, [self.s_key], None, self.n["s"])
+        if N == 1:
+            js = hip.Join(ctx, [self.s_key], None, self.n["s"])
+            s_nat = self.s_nat
+        else:
+            import torch
+            ident = ctx.upload(np.arange(self.n["s"], dtype=np.int32))
+            frees.append(ident)
+            sk = bcast(self.s_key, ident, self.n["s"], torch.int32)
+            sn = bcast(self.s_nat, ident, self.n["s"], torch.int32)
+            js = hip.Join(ctx, [_raw(hip.PH_I32, sk.data_ptr())], None, sk.numel())
+            s_nat = _raw(hip.PH_I32, sn.data_ptr())
         ks = gat(self.l_supp, lrow2, n2)
-        n3, pos3, srow = j.probe_inner([_raw(hip.PH_I32, ks)], None, n2, n2)
+        n3, pos3, srow = js.probe_inner([_raw(hip.PH_I32, ks)], None, n2, n2)
         frees += [pos3, srow]
-        j.free()
+        js.free()
         lrow3 = gat(_raw(hip.PH_I32, lrow2), pos3, n3)
         psrow3 = gat(_raw(hip.PH_I32, psrow), pos3, n3)
         stage("supplier_join", t0)
 
+        # ---- columns of the surviving lineitem rows (positional from here on)
         t0 = tic()
-        j = hip.Join(ctx, [self.o_key], None, self.n["o"])
-        ko = gat(self.l_key, lrow3, n3)
-        n4, pos4, orow = j.probe_inner([_raw(hip.PH_I64, ko)], None, n3, n3)
+        c_okey = gat(self.l_key, lrow3, n3)
+        c_ext, c_disc = gat(self.l_ext, lrow3, n3), gat(self.l_disc, lrow3, n3)
+        c_qty, c_cost = gat(self.l_qty, lrow3, n3), gat(ps_cost, psrow3, n3)
+        c_nat = gat(s_nat, srow, n3)
+        if N == 1:
+            jo = hip.Join(ctx, [self.o_key], None, self.n["o"])
+            o_date = self.o_date.col()
+            m = n3
+        else:
+            import torch
+            # order-key stage: both sides hash-partitioned by order key and exchanged
+            counts, perm = hip.partition(ctx, _raw(hip.PH_I64, c_okey), None, n3, N)
+            frees.append(perm)
+            send = [self._tensor_gather(_raw(hip.PH_I64, c_okey), perm, n3, torch.int64),
+                    self._tensor_gather(_raw(hip.PH_DEC64, c_ext), perm, n3, torch.int64),
+                    self._tensor_gather(_raw(hip.PH_DEC64, c_disc), perm, n3, torch.int64),
+                    self._tensor_gather(_raw(hip.PH_I32, c_qty), perm, n3, torch.int32),
+                    self._tensor_gather(_raw(hip.PH_DEC64, c_cost), perm, n3, torch.int64),
+                    self._tensor_gather(_raw(hip.PH_I32, c_nat), perm, n3, torch.int32)]
+            ctx.sync()
+            recv, _rc = dist.exchange_columns(send, counts)
+            ocounts, operm = hip.partition(ctx, self.o_key, None, self.n["o"], N)
+            frees.append(operm)
+            osend = [self._tensor_gather(self.o_key, operm, self.n["o"], torch.int64),
+                     self._tensor_gather(self.o_date, operm, self.n["o"], torch.int32)]
+            ctx.sync()
+            orecv, _rc2 = dist.exchange_columns(osend, ocounts)
+            torch.cuda.synchronize()
+            keep += recv + orecv
+            t["exchange_bytes_sent"] = int(sum(counts) - counts[dist.rank()]) * 40 + \
+                int(sum(ocounts) - ocounts[dist.rank()]) * 12
+            c_okey, c_ext, c_disc, c_qty, c_cost, c_nat = [x.data_ptr() for x in recv]
+            m = recv[0].numel()
+            jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0].data_ptr())], None, orecv[0].numel())
+            o_date = _raw(hip.PH_DATE, orecv[1].data_ptr())
+        n4, pos4, orow = jo.probe_inner([_raw(hip.PH_I64, c_okey)], None, m, max(m, 1))
         frees += [pos4, orow]
-        j.free()
-        lrow4 = gat(_raw(hip.PH_I32, lrow3), pos4, n4)
-        psrow4 = gat(_raw(hip.PH_I32, psrow3), pos4, n4)
-        srow4 = gat(_raw(hip.PH_I32, srow), pos4, n4)
+        jo.free()
         stage("orders_join", t0)
 
         t0 = tic()
-        ext, disc = gat(self.l_ext, lrow4, n4), gat(self.l_disc, lrow4, n4)
-        qty, cost = gat(self.l_qty, lrow4, n4), gat(self.ps_cost, psrow4, n4)
+        ext, disc = gat(_raw(hip.PH_DEC64, c_ext, 2), pos4, n4), gat(_raw(hip.PH_DEC64, c_disc, 2), pos4, n4)
+        qty, cost = gat(_raw(hip.PH_I32, c_qty), pos4, n4), gat(_raw(hip.PH_DEC64, c_cost, 2), pos4, n4)
         amount, _v = hip.expr_eval(ctx, [_raw(hip.PH_DEC64, ext, 2), _raw(hip.PH_DEC64, disc, 2),
                                          _raw(hip.PH_DEC64, cost, 2), _raw(hip.PH_I32, qty)],
                                    self.amount_prog, None, n4)
         frees.append(amount)
-        nat = gat(self.s_nat, srow4, n4)
-        year = hip.date_extract(ctx, hip.PH_PART_YEAR, self.o_date, orow, n4)
+        nat = gat(_raw(hip.PH_I32, c_nat), pos4, n4)
+        year = hip.date_extract(ctx, hip.PH_PART_YEAR, o_date, orow, n4)
         frees.append(year)
         agg = hip.Agg(ctx, [hip.PH_I32, hip.PH_I32], [(hip.PH_A_SUM, 0)], 1024)
         agg.sink([_raw(hip.PH_I32, nat), _raw(hip.PH_I32, year)], [_raw(hip.PH_DEC64, amount, 4)], None, n4,
@@ -321,8 +408,11 @@ class Q9Pipeline:
         stage("expr_aggregate", t0)
         for p in frees:
             ctx.free(p)
-        rows = [(int(r["keys"][g][0]), int(r["keys"][g][1]), r["sum"][g][0]) for g in range(r["ngroups"])]
-        return dict(ngroups=r["ngroups"], rows=rows, join_rows=n4, timings=t)
+        mine = {(int(r["keys"][g][0]), int(r["keys"][g][1])): ([r["sum"][g][0]], [int(r["count"][g][0])])
+                for g in range(r["ngroups"])}
+        merged = dist.merge_group_partials(mine)
+        rows = [(k[0], k[1], v[0][0]) for k, v in merged.items()]
+        return dict(ngroups=len(rows), rows=rows, join_rows=n4, timings=t)
 
 
 def q9_text(rows, nation_names):

@@ -280,3 +280,56 @@ def test_generic_scan_plan_runs_unfused_shapes(ctx, sf001):
     m = L["l_quantity"][:4096] != 7
     assert r2["ngroups"] == 1 and r2["sum"][0][0] == int(L["l_extendedprice"][:4096][m].max())
     p.free(); p2.free(); t.free()
+
+
+def test_q9_partitioned_two_ranks_on_one_gpu(sf1):
+    """Q9's N>1 form: pink part keys, their partsupp rows and supplier are broadcast, lineitem x
+    orders is hash-partitioned by order key and exchanged; 2 ranks as 2 threads on this GPU, every
+    table sharded by row ranges. The merged 175 rows must equal the reference golden."""
+    import os
+    import threading
+    import torch
+    from plan_amd import dist as pd, pipelines
+    N = 2
+    L, Od, P, PS, S = sf1["lineitem"], sf1["orders"], sf1["part"], sf1["partsupp"], sf1["supplier"]
+    no, npart, ns = len(Od["o_orderkey"]), len(P["p_partkey"]), len(S["s_suppkey"])
+
+    def shard(r):
+        o0, o1 = r * no // N, (r + 1) * no // N
+        k0 = Od["o_orderkey"][o0]
+        k1 = Od["o_orderkey"][o1] if o1 < no else np.iinfo(np.int64).max
+        l0, l1 = np.searchsorted(L["l_orderkey"], [k0, k1])
+        p0, p1 = r * npart // N, (r + 1) * npart // N
+        s0, s1 = r * ns // N, (r + 1) * ns // N
+        off = P["p_name_off"][p0:p1 + 1]
+        Pr = {"p_partkey": P["p_partkey"][p0:p1], "p_name_off": (off - off[0]).astype(np.int32),
+              "p_name_bytes": P["p_name_bytes"][off[0]:off[-1]]}
+        return ({k: v[l0:l1] for k, v in L.items()}, {k: v[o0:o1] for k, v in Od.items()}, Pr,
+                {k: v[4 * p0:4 * p1] for k, v in PS.items()}, {k: v[s0:s1] for k, v in S.items()})
+    grp = pd.ThreadGroup(N)
+    results, errors = [None] * N, []
+
+    def run(r):
+        try:
+            grp.bind(r)
+            torch.cuda.set_device(0)
+            c = hip.Ctx(0)
+            p = pipelines.Q9Pipeline(c, *shard(r))
+            results[r] = p.run()
+            p.free()
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(N)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, "\n".join(errors)
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q9.txt")).read()
+    for r in range(N):
+        assert results[r]["ngroups"] == 175
+        assert pipelines.q9_text(results[r]["rows"], tpchgen.nation_names()) == golden
+    assert results[0]["timings"]["exchange_bytes_sent"] > 0
+    assert results[0]["join_rows"] + results[1]["join_rows"] > 300000   # both ranks did real work
