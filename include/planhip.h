@@ -272,6 +272,14 @@ int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, in
                         int32_t naggs, ph_scan_plan **out);
 int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_end);
 int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out);
+/* Multi-GPU merge of fused plans (row-range sharded tables, no data-path collective): the raw
+ * partial result of the last run is 2*nacc 64-bit words on the device (ph_scan_plan_partials_dev);
+ * the ranks all-gather those few hundred bytes and any rank turns the concatenation of all ranks'
+ * words (host memory, rank-major) into the merged result: 128-bit sums and counts add, the
+ * first-seen row of a group is the one of the lowest rank that saw it. */
+int ph_scan_plan_partials_dev(ph_scan_plan *p, void **dev, int32_t *nwords);
+int ph_scan_plan_fetch_merged(ph_scan_plan *p, const uint64_t *words, int32_t nranks,
+                              ph_agg_result **out);
 /* name of the kernel family the plan dispatches to ("q1_lowcard", "q6_scalar", "generic") */
 const char *ph_scan_plan_kind(const ph_scan_plan *p);
 void ph_scan_plan_free(ph_scan_plan *p);

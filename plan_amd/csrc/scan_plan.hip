@@ -268,8 +268,9 @@ struct ph_scan_plan {
 
 static int plan_alloc(ph_scan_plan *p) {
     PH_HIP(hipMalloc((void **)&p->partials, (size_t)std::max(p->max_grid, 8192) * p->nacc * sizeof(long long)));
-    PH_HIP(hipMalloc((void **)&p->out_lo, (size_t)p->nacc * sizeof(unsigned long long)));
-    PH_HIP(hipMalloc((void **)&p->out_hi, (size_t)p->nacc * sizeof(long long)));
+    // one allocation, lo[nacc] then hi[nacc]: the raw partial result other ranks all-gather
+    PH_HIP(hipMalloc((void **)&p->out_lo, (size_t)p->nacc * 2 * sizeof(unsigned long long)));
+    p->out_hi = (long long *)(p->out_lo + p->nacc);
     return PH_OK;
 }
 
@@ -278,7 +279,6 @@ extern "C" void ph_scan_plan_free(ph_scan_plan *p) {
     if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
     if (p->partials) (void)hipFree(p->partials);
     if (p->out_lo) (void)hipFree(p->out_lo);
-    if (p->out_hi) (void)hipFree(p->out_hi);
     if (p->g_agg) ph_agg_free(p->g_agg);
     delete p;
 }
@@ -681,16 +681,9 @@ extern "C" void ph_agg_result_free(ph_agg_result *r) {
     free(r);
 }
 
-extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
-    PH_REQUIRE(p && out, "ph_scan_plan_fetch: bad arguments");
-    if (p->kind == PK_GENERIC) {
-        PH_REQUIRE(p->g_agg != nullptr, "ph_scan_plan_fetch: run the plan first");
-        return generic_fetch(p, out);
-    }
-    std::vector<unsigned long long> lo((size_t)p->nacc);
-    std::vector<long long> hi((size_t)p->nacc);
-    PH_CHECK(p->ctx->download(lo.data(), p->out_lo, (int64_t)lo.size() * 8));
-    PH_CHECK(p->ctx->download(hi.data(), p->out_hi, (int64_t)hi.size() * 8));
+// result rows from raw accumulator words (lo[nacc], hi[nacc]); first-row words are global ids
+static int assemble(ph_scan_plan *p, const std::vector<unsigned long long> &lo, const std::vector<long long> &hi,
+                    ph_agg_result **out) {
     int naggs = (int)p->aggs.size();
     struct G { int64_t first; int slot; };
     std::vector<G> groups;
@@ -736,6 +729,55 @@ extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
     }
     *out = r;
     return PH_OK;
+}
+
+extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
+    PH_REQUIRE(p && out, "ph_scan_plan_fetch: bad arguments");
+    if (p->kind == PK_GENERIC) {
+        PH_REQUIRE(p->g_agg != nullptr, "ph_scan_plan_fetch: run the plan first");
+        return generic_fetch(p, out);
+    }
+    std::vector<unsigned long long> lo((size_t)p->nacc);
+    std::vector<long long> hi((size_t)p->nacc);
+    PH_CHECK(p->ctx->download(lo.data(), p->out_lo, (int64_t)lo.size() * 8));
+    PH_CHECK(p->ctx->download(hi.data(), p->out_hi, (int64_t)hi.size() * 8));
+    return assemble(p, lo, hi, out);
+}
+
+extern "C" int ph_scan_plan_partials_dev(ph_scan_plan *p, void **dev, int32_t *nwords) {
+    PH_REQUIRE(p && dev && nwords, "ph_scan_plan_partials_dev: bad arguments");
+    if (p->kind == PK_GENERIC) { set_error("generic plans keep their state in a hash table, not in a fixed partial array"); return PH_EUNSUPPORTED; }
+    *dev = p->out_lo;
+    *nwords = 2 * p->nacc;
+    return PH_OK;
+}
+
+extern "C" int ph_scan_plan_fetch_merged(ph_scan_plan *p, const uint64_t *words, int32_t nranks, ph_agg_result **out) {
+    PH_REQUIRE(p && words && out && nranks >= 1, "ph_scan_plan_fetch_merged: bad arguments");
+    if (p->kind == PK_GENERIC) { set_error("ph_scan_plan_fetch_merged: fused plans only"); return PH_EUNSUPPORTED; }
+    size_t n = (size_t)p->nacc;
+    std::vector<unsigned long long> lo(n, 0);
+    std::vector<long long> hi(n, 0);
+    int stride = p->kind == PK_FILTER_SUMPROD ? 0 : ph::LC_NACC + 1;
+    for (size_t j = 0; j < n; j++) {
+        bool is_min = stride > 0 && (int)(j % (size_t)stride) == stride - 1;
+        if (is_min) lo[j] = ~0ull;
+        for (int32_t r = 0; r < nranks; r++) {
+            const uint64_t *w = words + (size_t)r * 2 * n;
+            if (is_min) {
+                // first-seen row across ranks: rank r's rows come after rank r-1's
+                if (w[j] != 0xffffffffull && w[j] != (uint64_t)INT64_MAX) {
+                    unsigned long long gfirst = ((unsigned long long)r << 40) + w[j];
+                    if (gfirst < lo[j]) lo[j] = gfirst;
+                }
+            } else {
+                unsigned long long nl = lo[j] + w[j];
+                hi[j] += (long long)w[n + j] + (nl < lo[j] ? 1 : 0);
+                lo[j] = nl;
+            }
+        }
+    }
+    return assemble(p, lo, hi, out);
 }
 
 extern "C" int ph_scan_filter_agg(ph_ctx *ctx, const ph_table *t, int64_t row_begin, int64_t row_end,

@@ -280,6 +280,19 @@ class ScanPlan:
         check(lib().ph_scan_plan_fetch(self.h, ctypes.byref(rp)))
         return _result(rp)
 
+    def partials_dev(self):
+        """(device pointer, number of 64-bit words) of the raw partial result of the last run."""
+        dev, n = vp(), i32()
+        check(lib().ph_scan_plan_partials_dev(self.h, ctypes.byref(dev), ctypes.byref(n)))
+        return dev.value, n.value
+
+    def fetch_merged(self, words, nranks):
+        """words: uint64 numpy array, the ranks' raw partials concatenated rank-major."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        rp = ctypes.POINTER(AggResult)()
+        check(lib().ph_scan_plan_fetch_merged(self.h, vp(words.ctypes.data), i32(nranks), ctypes.byref(rp)))
+        return _result(rp)
+
     def free(self):
         if self.h:
             lib().ph_scan_plan_free(self.h)

@@ -333,3 +333,33 @@ def test_q9_partitioned_two_ranks_on_one_gpu(sf1):
         assert pipelines.q9_text(results[r]["rows"], tpchgen.nation_names()) == golden
     assert results[0]["timings"]["exchange_bytes_sent"] > 0
     assert results[0]["join_rows"] + results[1]["join_rows"] > 300000   # both ranks did real work
+
+
+def test_fused_plan_partials_merge_across_shards(ctx, sf001):
+    """The multi-GPU merge of fused plans: three row-range shards (three 'ranks') run Q1 and Q6
+    separately, their raw device partials are concatenated rank-major and ph_scan_plan_fetch_merged
+    must give the whole table's result, groups in global first-seen order."""
+    L = sf001["lineitem"]
+    n = len(L["l_shipdate"])
+    cuts = [0, 20000, 41000, n]
+    for make, check_full in ((queries.q1_plan, True), (queries.q6_plan, False)):
+        words, plans, tabs = [], [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            t = queries.lineitem_table(ctx, {k: v[a:b] for k, v in L.items()})
+            p = make(ctx, t)
+            p.run()
+            ptr, nw = p.partials_dev()
+            words.append(ctx.download(hip.vp(ptr), np.uint64, nw))
+            plans.append(p); tabs.append(t)
+        merged = plans[0].fetch_merged(np.concatenate(words), 3)
+        tw = queries.lineitem_table(ctx, L)
+        pw = make(ctx, tw)
+        pw.run()
+        whole = pw.fetch()
+        assert merged["ngroups"] == whole["ngroups"]
+        assert merged["keys"].tolist() == whole["keys"].tolist()      # same first-seen order
+        assert merged["sum"] == whole["sum"] and merged["count"] == whole["count"]
+        for x in plans + [pw]:
+            x.free()
+        for x in tabs + [tw]:
+            x.free()
