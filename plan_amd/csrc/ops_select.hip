@@ -390,7 +390,11 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
         return PH_EUNSUPPORTED;
     }
     if (P.kind == ph::SK_NEVER) return PH_OK;
-    bool vec = sel_in == nullptr && (P.kind == ph::SK_RANGE_I32 || P.kind == ph::SK_RANGE_I64 || P.kind == ph::SK_RANGE_U8);
+    // the 4-values-per-lane path needs 16-byte (uint8: 4-byte) aligned column data
+    uintptr_t addr = (uintptr_t)P.data;
+    bool aligned = P.kind == ph::SK_RANGE_U8 ? addr % 4 == 0 : addr % 16 == 0;
+    bool vec = aligned && sel_in == nullptr &&
+               (P.kind == ph::SK_RANGE_I32 || P.kind == ph::SK_RANGE_I64 || P.kind == ph::SK_RANGE_U8);
     int64_t chunk = vec ? ph::VSEL_CHUNK : ph::SEL_CHUNK;
     int64_t nb = (n_in + chunk - 1) / chunk;
     PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));

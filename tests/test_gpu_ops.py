@@ -526,3 +526,18 @@ def test_agg_topk_preselection(ctx):
             if key in got_sum:
                 assert got_sum[key] == s_
     agg.free(); dk.free(); dv.free()
+
+
+def test_filter_select_unaligned_column_pointer(ctx):
+    """a column view that starts in the middle of an allocation (not 16-byte aligned) must take the
+    scalar path and still give the right, ordered selection"""
+    rng = np.random.default_rng(77)
+    n = 10007
+    data = rng.integers(0, 100, n + 3).astype(np.int32)
+    d = hip.DevColumn(ctx, hip.PH_I32, data)
+    c = d.col()
+    c.data = c.data + 4 * 3          # skip 3 values: 12-byte offset
+    sel, cnt = hip.filter_select(ctx, c, n, hip.PH_LT, hip.const(hip.PH_I32, i=50))
+    want = np.nonzero(data[3:] < 50)[0]
+    assert cnt == len(want) and np.array_equal(dl(ctx, sel, np.int32, cnt), want.astype(np.int32))
+    d.free()
