@@ -58,6 +58,8 @@ struct AggSinkParams {
     int64_t gcap;
     int *error_flag;
     int lds_slots;  // power of two; per-workgroup staging table entries
+    const int *skip_from;  // batches with index >= *skip_from were refused by the growth guard
+    int batch_index;
 };
 
 __device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
@@ -81,7 +83,18 @@ __device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, lo
     if (delta != 0) atomicAdd((unsigned long long *)hi, (unsigned long long)delta);
 }
 
+// Growth guard, one tiny launch in front of every batch: a batch may only run when the table can
+// take all of its rows as new groups (the reference's Resize rule). The first batch that cannot is
+// recorded and it and all later batches return immediately; the host then grows the table and
+// re-enqueues from there. Batches are enqueued back to back without a host round trip per batch.
+__global__ void agg_guard_kernel(const int *__restrict__ ngroups, long long gcap, long long m, int batch,
+                                 int *__restrict__ skip_from) {
+    if (batch >= *skip_from) return;
+    if (gcap - (long long)*ngroups <= m) atomicMin(skip_from, batch);
+}
+
 __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
+    if (P.batch_index >= __hip_atomic_load(P.skip_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
     // [first S x i64][sum S*na x u64][gid S x i32][cnt S*na x u32]
     long long *l_first = reinterpret_cast<long long *>(agg_lds);
@@ -355,7 +368,7 @@ struct ph_agg {
     long long *sum_hi = nullptr;
     unsigned long long *cnt = nullptr;
     long long *first_row = nullptr;
-    int *counters = nullptr;  // [0] ngroups, [1] error flag
+    int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] first refused batch (growth guard)
     int *kinds_dev = nullptr;
     int64_t rows_sunk = 0;
 };
@@ -448,7 +461,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
-    if (ctx->pool_alloc(8, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 8, ctx->stream) != hipSuccess ||
+    if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 16, ctx->stream) != hipSuccess ||
         ctx->pool_alloc(sizeof kinds, (void **)&a->kinds_dev) != PH_OK ||
         hipMemcpyAsync(a->kinds_dev, kinds, sizeof kinds, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -501,47 +514,61 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
     P.positional = positional;
     P.ngroups = a->counters;
     P.error_flag = a->counters + 1;
-    for (int64_t off = 0; off < n; off += AGG_BATCH) {
-        int64_t m = std::min(AGG_BATCH, n - off);
+    P.skip_from = a->counters + 2;
+    const int nbatches = (int)((n + AGG_BATCH - 1) / AGG_BATCH);
+    int start = 0;
+    while (start < nbatches) {
+        // make room for the first batch of this round, then enqueue every remaining batch behind
+        // its growth guard; only one host round trip per round
         int64_t ng = 0;
         PH_CHECK(ph_agg_group_count(a, &ng));
-        // the reference's Resize rule: grow while capacity - groups <= incoming rows
-        // (aggregate_hash.go:214-217); with gcap = cap/2 this also keeps the load factor <= 0.5
+        int64_t m0 = std::min(AGG_BATCH, n - (int64_t)start * AGG_BATCH);
         int64_t cap = a->cap;
-        while (cap / 2 - ng <= m) cap *= 2;
+        while (cap / 2 - ng <= m0) cap *= 2;   // Resize rule (aggregate_hash.go:214-217); gcap = cap/2
         if (cap != a->cap) PH_CHECK(agg_resize(a, cap, (int)ng));
-        P.sel = sel ? sel + off : nullptr;
-        P.n = m;
-        P.row_base = row_base + off;
-        if (!sel || positional) {
-            // identity selection / positional args: shift the base pointers instead
-            for (int c = 0; c < a->nkeys && !sel; c++) {
-                int w = ph::type_width(keys[c].type);
-                P.key[c].data = (const char *)keys[c].data + off * w;
-                PH_REQUIRE(!keys[c].validity || off % 8 == 0, "ph_agg_sink: internal batch offset");
-                P.key[c].validity = keys[c].validity ? keys[c].validity + off / 8 : nullptr;
+        const int big = 0x7fffffff;
+        PH_HIP(hipMemcpyAsync(a->counters + 2, &big, 4, hipMemcpyHostToDevice, a->ctx->stream));
+        for (int b = start; b < nbatches; b++) {
+            int64_t off = (int64_t)b * AGG_BATCH;
+            int64_t m = std::min(AGG_BATCH, n - off);
+            P.sel = sel ? sel + off : nullptr;
+            P.n = m;
+            P.row_base = row_base + off;
+            P.batch_index = b;
+            if (!sel || positional) {
+                // identity selection / positional args: shift the base pointers instead
+                for (int c = 0; c < a->nkeys && !sel; c++) {
+                    int w = ph::type_width(keys[c].type);
+                    P.key[c].data = (const char *)keys[c].data + off * w;
+                    P.key[c].validity = keys[c].validity ? keys[c].validity + off / 8 : nullptr;
+                }
+                for (int c = 0; c < nargs && (!sel || positional); c++) {
+                    if (!used[c]) continue;
+                    int w = ph::type_width(args[c].type);
+                    P.arg[c].data = (const char *)args[c].data + off * w;
+                    P.arg[c].validity = args[c].validity ? args[c].validity + off / 8 : nullptr;
+                }
             }
-            for (int c = 0; c < nargs && (!sel || positional); c++) {
-                if (!used[c]) continue;
-                int w = ph::type_width(args[c].type);
-                P.arg[c].data = (const char *)args[c].data + off * w;
-                P.arg[c].validity = args[c].validity ? args[c].validity + off / 8 : nullptr;
-            }
+            P.slots = a->slots;
+            P.mask = (uint64_t)a->cap - 1;
+            P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
+            P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
+            // staging table: as many entries as fit 48 KiB (12 B + 12 B per aggregate each)
+            int per_entry = 12 + 12 * std::max(a->naggs, 1);
+            int slots = 64;
+            while (slots * 2 * per_entry <= 48 * 1024 && slots < 4096) slots *= 2;
+            P.lds_slots = slots;
+            size_t lds = (size_t)slots * (8 + 4) + (size_t)slots * a->naggs * (8 + 4);
+            if (b > start)
+                ph::agg_guard_kernel<<<1, 1, 0, a->ctx->stream>>>(a->counters, a->gcap, m, b, a->counters + 2);
+            // few long-lived workgroups: every flush costs one HBM atomic per live entry
+            int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)a->ctx->cu_count * 4);
+            ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
+            PH_HIP(hipGetLastError());
         }
-        P.slots = a->slots;
-        P.mask = (uint64_t)a->cap - 1;
-        P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
-        P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
-        // staging table: as many entries as fit 48 KiB (12 B + 12 B per aggregate each)
-        int per_entry = 12 + 12 * std::max(a->naggs, 1);
-        int slots = 64;
-        while (slots * 2 * per_entry <= 48 * 1024 && slots < 4096) slots *= 2;
-        P.lds_slots = slots;
-        size_t lds = (size_t)slots * (8 + 4) + (size_t)slots * a->naggs * (8 + 4);
-        // few long-lived workgroups: every flush costs one HBM atomic per live entry
-        int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)a->ctx->cu_count * 4);
-        ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
-        PH_HIP(hipGetLastError());
+        int refused = big;
+        if (nbatches - start > 1) PH_CHECK(a->ctx->download(&refused, a->counters + 2, 4));
+        start = refused == big ? nbatches : refused;
     }
     a->rows_sunk += n;
     return PH_OK;
