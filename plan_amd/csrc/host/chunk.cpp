@@ -41,20 +41,54 @@ size_t LType::Size() const {
 Vector::Vector(LType t, int cap) : _Typ(t) { Data.assign(t.Size() * (size_t)cap, 0); }
 
 void Vector::ToUnifiedFormat(int count, Unified *u) const {
-    (void)count;
     switch (_PhyFormat) {
     case PF_DICT:
         u->data = Child->Data.data();
         u->sel = Sel.get();
         u->mask = &Child->Mask;
         break;
-    default:  // FLAT (CONST/SEQUENCE are flattened by their producers in this mirror)
+    case PF_CONST:  // ZeroSelectVectorInPhyFormatConst: every row reads slot 0
+        u->ident.identity = false;
+        u->ident.SelVec.assign((size_t)(count > 0 ? count : 1), 0);
+        u->data = Data.data();
+        u->sel = &u->ident;
+        u->mask = &Mask;
+        break;
+    case PF_SEQUENCE: {  // Flatten (vector.go:85-92): materialise start + i*incr
+        const int64_t *seq = reinterpret_cast<const int64_t *>(Data.data());
+        size_t w = _Typ.Size();
+        u->flat.assign(w * (size_t)(count > 0 ? count : 1), 0);
+        for (int i = 0; i < count; i++) {
+            int64_t v = seq[0] + seq[1] * (int64_t)i;
+            if (w == 4) { int32_t x = (int32_t)v; memcpy(u->flat.data() + (size_t)i * 4, &x, 4); }
+            else memcpy(u->flat.data() + (size_t)i * 8, &v, 8);
+        }
+        u->ident.identity = true;
+        u->data = u->flat.data();
+        u->sel = &u->ident;
+        u->mask = &Mask;
+        break;
+    }
+    default:
         u->ident.identity = true;
         u->data = Data.data();
         u->sel = &u->ident;
         u->mask = &Mask;
         break;
     }
+}
+
+void Vector::SetConstNull() {
+    _PhyFormat = PF_CONST;
+    if (Data.size() < _Typ.Size()) Data.assign(_Typ.Size(), 0);
+    Mask.Bits.assign(1, 0xFE);  // slot 0 invalid
+}
+
+void Vector::Sequence(int64_t start, int64_t incr, int64_t count) {
+    _PhyFormat = PF_SEQUENCE;
+    Data.assign(3 * sizeof(int64_t), 0);
+    int64_t seq[3] = {start, incr, count};
+    memcpy(Data.data(), seq, sizeof seq);
 }
 
 void Vector::SetString(int idx, const char *s, int64_t len) {
@@ -76,11 +110,41 @@ void Chunk::SliceIndice(const Chunk &other, const std::shared_ptr<SelectVector> 
                         const std::vector<int> &indice) {
     for (size_t i = 0; i < indice.size(); i++) {
         auto v = std::make_shared<Vector>();
-        const auto &src = other.Data[(size_t)indice[i]];
+        std::shared_ptr<Vector> src = other.Data[(size_t)indice[i]];
         v->_Typ = src->_Typ;
+        if (src->_PhyFormat == PF_CONST) {  // Slice of a constant stays that constant (vector.go Slice)
+            *v = Vector(src->_Typ, 1);
+            v->_PhyFormat = PF_CONST;
+            memcpy(v->Data.data(), src->Data.data(), std::min(v->Data.size(), src->Data.size()));
+            v->Mask = src->Mask;
+            if (src->_Typ.GetInternalType() == PT_VARCHAR && src->Mask.RowIsValid(0)) {
+                const String &str = src->Slice<String>()[0];
+                v->SetString(0, str.Data, str.Len);
+            }
+            Data[(size_t)colOffset + i] = v;
+            continue;
+        }
         v->_PhyFormat = PF_DICT;
-        v->Sel = sel;
-        v->Child = src;
+        if (src->_PhyFormat == PF_DICT) {  // selection of a selection: merge, share the flat child
+            auto merged = std::make_shared<SelectVector>();
+            merged->identity = false;
+            merged->SelVec.resize((size_t)count);
+            for (int r = 0; r < count; r++) merged->SelVec[(size_t)r] = src->Sel->GetIndex(sel->GetIndex(r));
+            v->Sel = merged;
+            v->Child = src->Child;
+        } else if (src->_PhyFormat == PF_SEQUENCE) {  // flatten first (Flatten, vector.go:85-92)
+            Vector::Unified u;
+            int64_t n = reinterpret_cast<const int64_t *>(src->Data.data())[2];
+            src->ToUnifiedFormat((int)n, &u);
+            auto flat = std::make_shared<Vector>();
+            flat->_Typ = src->_Typ;
+            flat->Data = std::move(u.flat);
+            v->Sel = sel;
+            v->Child = flat;
+        } else {
+            v->Sel = sel;
+            v->Child = src;
+        }
         Data[(size_t)colOffset + i] = v;
     }
     _count = count;

@@ -81,8 +81,13 @@ struct Vector {
     template <typename T> T *Slice() { return reinterpret_cast<T *>(Data.data()); }
     template <typename T> const T *Slice() const { return reinterpret_cast<const T *>(Data.data()); }
     // ToUnifiedFormat (vector_format.go:64-97): data pointer + selection + mask for any format
-    struct Unified { const uint8_t *data; const SelectVector *sel; const Bitmap *mask; SelectVector ident; };
+    // `ident` backs the incremental / all-zero selection, `flat` the materialised SEQUENCE
+    struct Unified { const uint8_t *data; const SelectVector *sel; const Bitmap *mask; SelectVector ident; std::vector<uint8_t> flat; };
     void ToUnifiedFormat(int count, Unified *u) const;
+    // PF_CONST: one value (slot 0) for every row (vector.go:189-200); null = every row NULL
+    void SetConstNull();
+    // PF_SEQUENCE: start, start+incr, ... (vector.go:303-313); INTEGER / BIGINT only
+    void Sequence(int64_t start, int64_t incr, int64_t count);
     void SetString(int idx, const char *s, int64_t len);
 };
 

@@ -587,7 +587,7 @@ std::string gpuJoinExecutor::Init() {
         if (staged_width(pt[(size_t)probeKeys_[i]]) != staged_width(bt[(size_t)buildKeys_[i]])) return "join key widths differ";
     }
     outTypes_ = pt;
-    if (type_ == JoinInner) for (int c : buildPayload_) outTypes_.push_back(bt[(size_t)c]);
+    if (type_ == JoinInner || type_ == JoinLeft) for (int c : buildPayload_) outTypes_.push_back(bt[(size_t)c]);
     buildBatch_.reset(new DeviceBatch(ctx_, bt, buildKeys_));
     probeBatch_.reset(new DeviceBatch(ctx_, pt, probeKeys_));
     return "";
@@ -640,12 +640,12 @@ std::string gpuJoinExecutor::probeBatch() {
     }
     int64_t n = probeBatch_->rows();
     if (n == 0) return "";
-    if (ph_join_count(join_) == 0 && type_ != JoinAnti) return "";
+    if (ph_join_count(join_) == 0 && type_ != JoinAnti && type_ != JoinLeft) return "";
     std::string e = probeBatch_->Upload();
     if (!e.empty()) return e;
     std::vector<ph_col> keys;
     for (size_t k = 0; k < probeKeys_.size(); k++) keys.push_back(probeBatch_->col((int)k));
-    if (type_ != JoinInner) {
+    if (type_ == JoinSemi || type_ == JoinAnti) {
         // ScanKeyMatches + NextSemiOrAntiJoin (join_scan.go:120-180): found flag per probe row,
         // then the probe chunk sliced by the rows with found == (type is SEMI)
         void *fd = nullptr;
@@ -707,6 +707,26 @@ std::string gpuJoinExecutor::probeBatch() {
         out->SetCard(r + 1);
     }
     if (out && out->Card() > 0) ready_.push_back(out);
+    if (type_ == JoinLeft) {
+        // NextLeftJoin (join_scan.go:67-88): the probe rows no pair mentions, sliced out of their
+        // chunk, with every build-side column a constant NULL
+        std::vector<uint8_t> matched((size_t)n, 0);
+        for (int64_t i = 0; i < m; i++) matched[(size_t)pr[(size_t)i]] = 1;
+        for (size_t ci = 0; ci < chunks.size(); ci++) {
+            auto sv = std::make_shared<SelectVector>();
+            sv->identity = false;
+            for (int i = 0; i < chunks[ci]->Card(); i++)
+                if (!matched[(size_t)(starts[ci] + i)]) sv->SelVec.push_back(i);
+            if (sv->SelVec.empty()) continue;
+            auto rest = std::make_shared<Chunk>();
+            rest->Init(outTypes_, DefaultVectorSize);
+            std::vector<int> indice;
+            for (int c = 0; c < np; c++) indice.push_back(c);
+            rest->SliceIndice(*chunks[ci], sv, (int)sv->SelVec.size(), 0, indice);
+            for (size_t c = 0; c < buildPayload_.size(); c++) rest->Data[(size_t)np + c]->SetConstNull();
+            ready_.push_back(rest);
+        }
+    }
     return "";
 }
 

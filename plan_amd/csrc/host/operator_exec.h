@@ -157,13 +157,16 @@ private:
 };
 
 // join types of the hot path (LOT_JoinType*, join_scan.go:47-165); SEMI / ANTI emit the probe
-// rows that have / lack a match (NextSemiOrAntiJoin :120-140), MARK is their building block
-enum JoinType { JoinInner, JoinSemi, JoinAnti };
+// rows that have / lack a match (NextSemiOrAntiJoin :102-120), MARK is their building block;
+// LEFT is the inner result followed by the unmatched probe rows with an all-NULL (PF_CONST)
+// build side (NextLeftJoin :67-88)
+enum JoinType { JoinInner, JoinSemi, JoinAnti, JoinLeft };
 
 class gpuJoinExecutor : public OperatorExec {
 public:
     // children[0] probes, children[1] is built (executor_join.go:237-264); inner: output = all
-    // probe columns followed by buildPayload columns of the build side; semi/anti: probe columns.
+    // probe columns followed by buildPayload columns of the build side (also LEFT); semi/anti:
+    // probe columns.
     gpuJoinExecutor(ph_ctx *ctx, OperatorExec *probe, OperatorExec *build, std::vector<int> probeKeys,
                     std::vector<int> buildKeys, std::vector<int> buildPayload, int batchChunks = 512,
                     JoinType type = JoinInner);

@@ -2,7 +2,8 @@
 // execOps, pkg/compute/executor.go:151-188) on generated TPC-H data and prints the result in the
 // reference's text format (headline "#\t..." of execQuery, executor_bench.go:229-238; rows via
 // Chunk.SaveToFile). The role `tester tpch1g --query_id N` plays for the reference.
-//   host_tester roundtrip
+//   host_tester roundtrip | formats
+//   host_tester semi|anti|left <sf_num> <sf_den>
 //   host_tester q1|q6|q3 <sf_num> <sf_den> [stub|resident]
 #include <algorithm>
 #include <cstdio>
@@ -139,8 +140,50 @@ static int roundtrip() {
     return 0;
 }
 
+// every physical format through ToUnifiedFormat / SliceIndice / Serialize (vector_format.go:64-97)
+static int formats() {
+    Chunk c;
+    c.Init({IntegerType(), VarcharType(), DecimalType(15, 2), BigintType(), IntegerType()}, DefaultVectorSize);
+    c.Data[0]->Sequence(5, 3, 6);                       // 5 8 11 14 17 20
+    c.Data[1]->_PhyFormat = PF_CONST;
+    c.Data[1]->SetString(0, "k", 1);
+    c.Data[2]->SetConstNull();
+    c.Data[3]->Sequence(-10000000000ll, 10000000000ll, 6);
+    for (int i = 0; i < 6; i++) c.Data[4]->Slice<int32_t>()[i] = 100 + i;
+    c.Data[4]->Mask.SetInvalid(3, DefaultVectorSize);
+    c.SetCard(6);
+    std::string out;
+    c.AppendText(&out);
+    auto pick = [](std::initializer_list<int64_t> l) {
+        auto s = std::make_shared<SelectVector>();
+        s->identity = false;
+        s->SelVec.assign(l);
+        return s;
+    };
+    std::vector<int> all = {0, 1, 2, 3, 4};
+    Chunk d, e, f;
+    std::vector<LType> types = {IntegerType(), VarcharType(), DecimalType(15, 2), BigintType(), IntegerType()};
+    d.Init(types, DefaultVectorSize);
+    d.SliceIndice(c, pick({4, 1, 3, 0}), 4, 0, all);   // DICT over SEQUENCE / CONST / FLAT
+    out += "--\n";
+    d.AppendText(&out);
+    e.Init(types, DefaultVectorSize);
+    e.SliceIndice(d, pick({2, 0}), 2, 0, all);         // selection of a selection
+    out += "--\n";
+    e.AppendText(&out);
+    std::string blob, err;
+    e.Serialize(&blob);
+    size_t pos = 0;
+    if (!f.Deserialize(blob, &pos, &err)) die(err);
+    out += "--\n";
+    f.AppendText(&out);
+    printf("%s", out.c_str());
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "roundtrip")) return roundtrip();
+    if (argc >= 2 && !strcmp(argv[1], "formats")) return formats();
     if (argc < 4) die("usage: host_tester roundtrip | q1|q6|q3 <sf_num> <sf_den> [stub]");
     std::string q = argv[1];
     int64_t num = atoll(argv[2]), den = atoll(argv[3]);
@@ -148,7 +191,7 @@ int main(int argc, char **argv) {
     ph_ctx *ctx = nullptr;
     if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
     Lineitem L;
-    if (q != "semi" && q != "anti") L = gen_lineitem(num, den);
+    if (q != "semi" && q != "anti" && q != "left") L = gen_lineitem(num, den);
     auto scan = lineitem_source(L, stub);
     auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
 
@@ -304,6 +347,38 @@ int main(int argc, char **argv) {
         sourceExecutor csrc({IntegerType()}, int_source(ckey, cpos)), osrc({IntegerType()}, int_source(ocust, opos));
         gpuJoinExecutor j(ctx, &csrc, &osrc, {0}, {0}, {}, 512, q == "semi" ? JoinSemi : JoinAnti);
         print(1, run(&j));
+    } else if (q == "left") {
+        // customer LEFT JOIN orders ON c_custkey = o_custkey, payload o_orderkey: one row per order
+        // plus one (custkey, NULL) row per customer that never ordered
+        int64_t nc = tpchgen_customer_count(num, den), no = tpchgen_orders_count(num, den);
+        std::vector<int32_t> ckey((size_t)nc), ocust((size_t)no);
+        std::vector<int64_t> okey((size_t)no);
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        tpchgen_orders_cols oc{}; oc.o_custkey = ocust.data(); oc.o_orderkey = okey.data();
+        tpchgen_orders(num, den, 0, no, &oc);
+        int64_t cpos = 0, opos = 0;
+        sourceExecutor csrc({IntegerType()}, [&](Chunk *out) {
+            if (cpos >= nc) return false;
+            int card = (int)std::min<int64_t>(DefaultVectorSize, nc - cpos);
+            out->Init({IntegerType()}, DefaultVectorSize);
+            memcpy(out->Data[0]->Data.data(), ckey.data() + cpos, (size_t)card * 4);
+            out->SetCard(card);
+            cpos += card;
+            return true;
+        });
+        sourceExecutor osrc({IntegerType(), BigintType()}, [&](Chunk *out) {
+            if (opos >= no) return false;
+            int card = (int)std::min<int64_t>(DefaultVectorSize, no - opos);
+            out->Init({IntegerType(), BigintType()}, DefaultVectorSize);
+            memcpy(out->Data[0]->Data.data(), ocust.data() + opos, (size_t)card * 4);
+            memcpy(out->Data[1]->Data.data(), okey.data() + opos, (size_t)card * 8);
+            out->SetCard(card);
+            opos += card;
+            return true;
+        });
+        gpuJoinExecutor j(ctx, &csrc, &osrc, {0}, {0}, {1}, 512, JoinLeft);
+        print(2, run(&j));
     } else die("unknown query " + q);
     ph_ctx_destroy(ctx);
     return 0;

@@ -58,9 +58,16 @@ struct AggSinkParams {
     int64_t gcap;
     int *error_flag;
     int lds_slots;  // power of two; per-workgroup staging table entries
-    const int *skip_from;  // batches with index >= *skip_from were refused by the growth guard
-    int batch_index;
+    int *need_grow;     // set when a workgroup stopped early because the table may fill up
+    int *progress;      // per workgroup: chunk iterations already done (resume point after a growth)
+    long long slack;    // groups all workgroups together may still create = gridDim.x * (AGG_CHUNK + lds_slots / 2)
+    int combine;        // wave-level combining allowed (no MIN/MAX aggregate)
+    unsigned arg_used;  // bit c: argument column c is read by some aggregate
 };
+
+constexpr int AGG_CHUNK = 2048;  // rows a workgroup takes between two growth checks
+constexpr int AGG_U = 4;         // rows per thread in flight
+constexpr int AGG_PRE = 4;       // argument columns read ahead for them
 
 __device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
     switch (c.type) {
@@ -76,6 +83,18 @@ __device__ __forceinline__ uint64_t keys_hash(const unsigned long long *k, unsig
     return h;
 }
 
+// sum of x over the 64 lanes of a wave, same value returned to every lane: four DPP adds make
+// every lane of a 16-lane row hold its row's total (xor 1, xor 2 inside quads, then half-row and
+// row mirrors), four readlanes add the rows. Needs the whole wave active.
+__device__ __forceinline__ int wave_sum32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);  // row_mirror
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) +
+           __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+
 __device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, long long v) {
     unsigned long long old = atomicAdd(lo, (unsigned long long)v);
     unsigned long long nw = old + (unsigned long long)v;
@@ -83,155 +102,316 @@ __device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, lo
     if (delta != 0) atomicAdd((unsigned long long *)hi, (unsigned long long)delta);
 }
 
-// Growth guard, one tiny launch in front of every batch: a batch may only run when the table can
-// take all of its rows as new groups (the reference's Resize rule). The first batch that cannot is
-// recorded and it and all later batches return immediately; the host then grows the table and
-// re-enqueues from there. Batches are enqueued back to back without a host round trip per batch.
-__global__ void agg_guard_kernel(const int *__restrict__ ngroups, long long gcap, long long m, int batch,
-                                 int *__restrict__ skip_from) {
-    if (batch >= *skip_from) return;
-    if (gcap - (long long)*ngroups <= m) atomicMin(skip_from, batch);
+// Find or create the group of one key in the global table (FindOrCreateGroups,
+// aggregate_hash.go:272-388). No lane ever waits inside a branch, so lanes of one wave racing for
+// the same new key cannot deadlock: the winner publishes in the same iteration it locked the slot;
+// the others see the id on a later iteration. Every access is an agent-scope atomic: these loads
+// bypass the per-XCD L2, so they are slow (all CUs reading one hot line are bound by that line's
+// memory channel) — which is why the sink kernel below only comes here once per (workgroup,
+// group) when it can.
+__device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsigned long long *k, unsigned nullmask,
+                                              uint64_t h) {
+    uint64_t slot = h & P.mask;
+    int gid = -1;
+    for (int guard = 0; gid < 0; guard++) {
+        int g = __hip_atomic_load(&P.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == SLOT_EMPTY) {
+            int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
+            if (old == SLOT_EMPTY) {
+                int ng = atomicAdd(P.ngroups, 1);
+                if (ng >= P.gcap) {  // cannot happen: see the growth check
+                    atomicOr(P.error_flag, 1);
+                    ng = 0;
+                }
+                for (int c = 0; c < P.nkeys; c++)
+                    __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&P.slots[slot], ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gid = ng;
+            }
+            // lost the race: look at the slot again
+        } else if (g == SLOT_LOCKED) {
+            if (guard > (1 << 22)) { atomicOr(P.error_flag, 2); break; }  // bounded spin
+        } else {
+            bool eq = __hip_atomic_load(&P.gnull[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nullmask;
+            for (int c = 0; eq && c < P.nkeys; c++)
+                eq = __hip_atomic_load(&P.gkeys[(int64_t)g * P.nkeys + c], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT) == k[c];
+            if (eq) gid = g;
+            else slot = (slot + 1) & P.mask;  // linear probing (:376-384)
+        }
+    }
+    return gid;
 }
 
+// One launch covers a whole sink call. Workgroup w takes the row chunks w, w+G, w+2G, ... and
+// pre-aggregates them in an LDS hash table keyed by the group key (open addressing, linear
+// probing, at most half full): a row whose key is in the LDS table costs its column reads and a
+// few ds operations, nothing else. The global table is touched once per (workgroup, group) when
+// the LDS table is flushed at the end, and row by row only for keys that found no room in LDS
+// (high-cardinality inputs).
+// Growth (the reference's Resize rule, aggregate_hash.go:214-217) is checked in front of every
+// chunk: a chunk starts only while the global table could still take, as new groups, every row
+// all workgroups may have in flight plus every entry their LDS tables may still flush. The check
+// is an agent-scope load served where the counter's atomic adds execute, so it sees every group
+// created before it: after the last check that passed, each
+// workgroup creates at most one chunk of groups row by row and half an LDS table at its flush, so
+// the count stays below gcap. A workgroup that fails the check records where it stopped, flushes
+// and leaves; the host grows the table and relaunches, every workgroup resuming at its chunk.
+constexpr int L_EMPTY = -1, L_LOCKED = -2;   // LDS entry states; >= 0: ready, value = NULL mask
+
 __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
-    if (P.batch_index >= __hip_atomic_load(P.skip_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    __shared__ int s_go, s_nent;
     extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
-    // [first S x i64][sum S*na x u64][gid S x i32][cnt S*na x u32]
+    const int T = P.lds_slots, na = P.naggs, nk = P.nkeys;
+    // [first T x i64][key nk*T x u64][sum T*na x u64][state T x i32][cnt T*na x u32]
     long long *l_first = reinterpret_cast<long long *>(agg_lds);
-    unsigned long long *l_sum = reinterpret_cast<unsigned long long *>(l_first + P.lds_slots);
-    int *l_gid = reinterpret_cast<int *>(l_sum + (size_t)P.lds_slots * P.naggs);
-    unsigned *l_cnt = reinterpret_cast<unsigned *>(l_gid + P.lds_slots);
-    for (int e = threadIdx.x; e < P.lds_slots; e += 256) {
-        l_gid[e] = -1;
+    unsigned long long *l_key = reinterpret_cast<unsigned long long *>(l_first + T);
+    unsigned long long *l_sum = l_key + (size_t)nk * T;
+    int *l_state = reinterpret_cast<int *>(l_sum + (size_t)T * na);
+    unsigned *l_cnt = reinterpret_cast<unsigned *>(l_state + T);
+    for (int e = threadIdx.x; e < T; e += 256) {
+        l_state[e] = L_EMPTY;
         l_first[e] = INT64_MAX;
-        for (int a = 0; a < P.naggs; a++) {
+        for (int a = 0; a < na; a++) {
             int kind = P.agg_kind[a];
-            l_sum[e * P.naggs + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
-                                     : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
-            l_cnt[e * P.naggs + a] = 0;
+            l_sum[e * na + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
+                                : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+            l_cnt[e * na + a] = 0;
         }
     }
+    if (threadIdx.x == 0) s_nent = 0;
+    const int lane = threadIdx.x & 63;
+    int it = P.progress[blockIdx.x];
+    for (;; it++) {
+    const int64_t c0 = ((int64_t)it * gridDim.x + blockIdx.x) * AGG_CHUNK;
+    if (c0 >= P.n) break;
+    __syncthreads();  // LDS initialised / everyone has read the previous s_go
+    if (threadIdx.x == 0) {
+        int ng = __hip_atomic_load(P.ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_go = P.gcap - (long long)ng > P.slack;
+        if (!s_go) __hip_atomic_store(P.need_grow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
-        int64_t r = P.sel ? P.sel[i] : i;
-        unsigned long long k[AGG_MAX_KEYS];
-        unsigned nullmask = 0;
+    if (!s_go) break;
+    const int64_t c1 = c0 + AGG_CHUNK < P.n ? c0 + AGG_CHUNK : P.n;
+    // every lane stays in this loop (dead lanes carry ent -1): the wave-level combining below
+    // needs the whole wave converged. AGG_U rows per thread are in flight: all their column
+    // reads (selection, keys, the first AGG_PRE argument columns) are issued before the first
+    // row is processed, so one HBM latency is paid per AGG_U rows instead of two per row.
+    for (int64_t ib = c0; ib < c1; ib += 256 * AGG_U) {
+      int64_t ii[AGG_U], rr[AGG_U];
+      unsigned long long kk[AGG_U][AGG_MAX_KEYS];
+      unsigned nmask[AGG_U], pvalid[AGG_U];
+      long long pv[AGG_U][AGG_PRE];
 #pragma unroll
-        for (int c = 0; c < AGG_MAX_KEYS; c++) {
-            k[c] = 0;
-            if (c < P.nkeys) {
-                if (bit_valid(P.key[c].validity, r)) k[c] = load_key(P.key[c], r);
-                else nullmask |= 1u << c;
-            }
-        }
-        uint64_t slot = keys_hash(k, nullmask, P.nkeys) & P.mask;
-        int gid = -1;
-        // find or create (FindOrCreateGroups :272-388). No lane ever waits inside a branch, so
-        // lanes of one wave racing for the same new key cannot deadlock: the winner publishes in
-        // the same iteration it locked the slot; the others see the id on a later iteration.
-        for (int guard = 0; gid < 0; guard++) {
-            int g = __hip_atomic_load(&P.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == SLOT_EMPTY) {
-                int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
-                if (old == SLOT_EMPTY) {
-                    int ng = atomicAdd(P.ngroups, 1);
-                    if (ng >= P.gcap) {  // cannot happen: the host grows before a batch (see sink)
-                        atomicOr(P.error_flag, 1);
-                        ng = 0;
+      for (int u = 0; u < AGG_U; u++) {
+          ii[u] = ib + u * 256 + threadIdx.x;
+          rr[u] = ii[u] < c1 ? (P.sel ? (int64_t)P.sel[ii[u]] : ii[u]) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < AGG_U; u++) {
+          nmask[u] = 0;
+#pragma unroll
+          for (int c = 0; c < AGG_MAX_KEYS; c++) {
+              kk[u][c] = 0;
+              if (c < nk && rr[u] >= 0) {
+                  if (bit_valid(P.key[c].validity, rr[u])) kk[u][c] = load_key(P.key[c], rr[u]);
+                  else nmask[u] |= 1u << c;
+              }
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < AGG_U; u++) {
+          pvalid[u] = 0;
+#pragma unroll
+          for (int c = 0; c < AGG_PRE; c++) {
+              pv[u][c] = 0;
+              if (((P.arg_used >> c) & 1) && rr[u] >= 0) {
+                  const int64_t ar = P.positional ? ii[u] : rr[u];
+                  if (bit_valid(P.arg[c].validity, ar)) {
+                      pvalid[u] |= 1u << c;
+                      pv[u][c] = P.arg[c].type == PH_I32 ? (long long)((const int32_t *)P.arg[c].data)[ar]
+                                                         : ((const int64_t *)P.arg[c].data)[ar];
+                  }
+              }
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < AGG_U; u++) {
+        if (ib + u * 256 >= c1) break;  // wave-uniform: no row of this slice is live
+        const int64_t i = ii[u];
+        const bool live = rr[u] >= 0;
+        const int64_t r = live ? rr[u] : 0;
+        int ent = -1;   // LDS entry of this row's group
+        int gid = -1;   // global group id, only looked up for rows without an LDS entry
+        if (live) {
+            const unsigned long long *k = kk[u];
+            const unsigned nullmask = nmask[u];
+            const uint64_t h = keys_hash(k, nullmask, nk);
+            int idx = (int)(h >> 40) & (T - 1);
+            // same no-waiting-inside-a-branch protocol as the global table, on LDS
+            for (int probes = 0, spins = 0; probes < 16 && spins < (1 << 16);) {
+                int st = __hip_atomic_load(&l_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (st == L_EMPTY) {
+                    if (__hip_atomic_load(&s_nent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= T / 2) break;
+                    int old = atomicCAS(&l_state[idx], L_EMPTY, L_LOCKED);
+                    if (old == L_EMPTY) {
+                        atomicAdd(&s_nent, 1);
+                        for (int c = 0; c < nk; c++) l_key[c * T + idx] = k[c];
+                        __hip_atomic_store(&l_state[idx], (int)nullmask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ent = idx;
+                        break;
                     }
-                    for (int c = 0; c < P.nkeys; c++)
-                        __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __threadfence();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&P.slots[slot], ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gid = ng;
-                }
-                // lost the race: look at the slot again
-            } else if (g == SLOT_LOCKED) {
-                if (guard > (1 << 22)) { atomicOr(P.error_flag, 2); break; }  // bounded spin
-            } else {
-                bool eq = __hip_atomic_load(&P.gnull[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nullmask;
-                for (int c = 0; eq && c < P.nkeys; c++)
-                    eq = __hip_atomic_load(&P.gkeys[(int64_t)g * P.nkeys + c], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT) == k[c];
-                if (eq) gid = g;
-                else slot = (slot + 1) & P.mask;  // linear probing (:376-384)
-            }
-        }
-        if (gid < 0) continue;
-        // ---- LDS staging (per workgroup, direct mapped by group id): rows of a group that owns
-        // its LDS entry accumulate with ds atomics and reach HBM once per workgroup, so a hot
-        // group (Q9: 175 groups, Q1-like inputs: 4) no longer serialises every row on one HBM
-        // atomic. Groups that lose the entry to another id, and values too large for a bounded
-        // int64 partial, update HBM directly.
-        const int e = gid & (P.lds_slots - 1);
-        bool staged = false;
-        {
-            int cur = l_gid[e];
-            if (cur == gid) staged = true;
-            else if (cur == -1) {
-                int old = atomicCAS(&l_gid[e], -1, gid);
-                staged = old == -1 || old == gid;
-            }
-        }
-        long long frow = (long long)(P.row_base + (P.sel ? r : i));  // row id (ascending with i)
-        // first-seen row: almost every row is later than the recorded one, so test with a load
-        // (L2-served, agent scope) and only issue the HBM atomic when it would lower the minimum
-        if (staged) { if (frow < l_first[e]) atomicMin(&l_first[e], frow); }
-        else if (frow < __hip_atomic_load(&P.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMin(&P.first_row[gid], frow);
-        // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
-        for (int a = 0; a < P.naggs; a++) {
-            int64_t st = (int64_t)gid * P.naggs + a;
-            int ls = e * P.naggs + a;
-            int kind = P.agg_kind[a];
-            if (kind == PH_A_COUNT_STAR) {
-                if (staged) atomicAdd(&l_cnt[ls], 1u);
-                else atomicAdd(&P.cnt[st], 1ull);
-                continue;
-            }
-            const AggCol &c = P.arg[P.agg_arg[a]];
-            int64_t ar = P.positional ? i : r;
-            if (!bit_valid(c.validity, ar)) continue;
-            long long v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar]
-                                           : ((const int64_t *)c.data)[ar];
-            if (kind == PH_A_SUM || kind == PH_A_AVG) {
-                // a workgroup sees at most 2^21 rows per launch: |v| < 2^40 keeps the partial in int64
-                bool small = v > -(1ll << 40) && v < (1ll << 40);
-                if (staged && small) {
-                    atomicAdd(&l_sum[ls], (unsigned long long)v);
-                    atomicAdd(&l_cnt[ls], 1u);
+                    spins++;  // someone else took it: look again
+                } else if (st == L_LOCKED) {
+                    spins++;
                 } else {
-                    atomicAdd(&P.cnt[st], 1ull);
-                    add128(&P.sum_lo[st], &P.sum_hi[st], v);
+                    bool eq = st == (int)nullmask;
+                    for (int c = 0; eq && c < nk; c++) eq = l_key[c * T + idx] == k[c];
+                    if (eq) { ent = idx; break; }
+                    idx = (idx + 1) & (T - 1);
+                    probes++;
                 }
-            } else if (kind == PH_A_COUNT) {
-                if (staged) atomicAdd(&l_cnt[ls], 1u);
-                else atomicAdd(&P.cnt[st], 1ull);
-            } else if (kind == PH_A_MIN) {
-                if (staged) { atomicMin((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
-                else { atomicAdd(&P.cnt[st], 1ull); atomicMin((long long *)&P.sum_lo[st], v); }
-            } else if (kind == PH_A_MAX) {
-                if (staged) { atomicMax((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
-                else { atomicAdd(&P.cnt[st], 1ull); atomicMax((long long *)&P.sum_lo[st], v); }
+            }
+            if (ent < 0) gid = find_or_create(P, k, nullmask, h);
+        }
+        // ---- wave-level combining. When few groups are hot (Q1-like inputs: 4), 64 lanes hit a
+        // handful of LDS words and the ds atomics serialise lane by lane. Groups that hold >= 8
+        // lanes of this wave are summed across the wave first (DPP adds, no LDS) and only their
+        // lowest lane — the leader, which also carries the smallest row id — touches the
+        // accumulators. Everything else (high-cardinality inputs, MIN/MAX) goes lane by lane.
+        unsigned long long comb = 0;
+        bool leader = false;
+        if (P.combine) {
+            unsigned long long t = __ballot(ent >= 0);
+            for (int round = 0; t != 0 && round < 8; round++) {
+                int lead = __ffsll((long long)t) - 1;
+                int g = __builtin_amdgcn_readlane(ent, lead);
+                unsigned long long m = __ballot(ent == g);
+                if (__popcll(m) < 8) break;
+                comb |= m;
+                t &= ~m;
+                if (lane == lead) leader = true;
             }
         }
+        const bool in_comb = (comb >> lane) & 1;
+        const bool staged = ent >= 0;
+        if ((staged && (!in_comb || leader)) || gid >= 0) {
+            long long frow = (long long)(P.row_base + (P.sel ? r : i));  // row id (ascending with i)
+            // first-seen row: almost every row is later than the recorded one, so test with a load
+            // and only issue the atomic when it would lower the minimum
+            if (staged) { if (frow < l_first[ent]) atomicMin(&l_first[ent], frow); }
+            else if (frow < __hip_atomic_load(&P.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMin(&P.first_row[gid], frow);
+        }
+        // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
+        for (int a = 0; a < na; a++) {
+            const int64_t st = (int64_t)gid * na + a;
+            const int ls = ent * na + a;
+            const int kind = P.agg_kind[a];
+            const bool is_sum = kind == PH_A_SUM || kind == PH_A_AVG;
+            bool valid = staged || gid >= 0;
+            long long v = 0;
+            if (kind != PH_A_COUNT_STAR && valid) {
+                const int ac = P.agg_arg[a];
+                if (ac < AGG_PRE) {  // read ahead of time
+                    valid = (pvalid[u] >> ac) & 1;
+#pragma unroll
+                    for (int c = 0; c < AGG_PRE; c++) if (c == ac) v = pv[u][c];
+                } else {
+                    const AggCol &c = P.arg[ac];
+                    int64_t ar = P.positional ? i : r;
+                    valid = bit_valid(c.validity, ar);
+                    if (valid) v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+                }
+            }
+            // |v| < 2^40 keeps a workgroup's partial in int64 (the host caps a workgroup at 2^22 rows)
+            const bool small = v > -(1ll << 40) && v < (1ll << 40);
+            if (valid && staged && is_sum && !small) {
+                // too large for the bounded LDS partial: this one value goes to the global table
+                if (gid < 0) {
+                    unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+                    for (int c = 0; c < nk; c++) k[c] = l_key[c * T + ent];
+                    unsigned nm = (unsigned)l_state[ent];
+                    gid = find_or_create(P, k, nm, keys_hash(k, nm, nk));
+                }
+                if (gid >= 0) {
+                    atomicAdd(&P.cnt[(int64_t)gid * na + a], 1ull);
+                    add128(&P.sum_lo[(int64_t)gid * na + a], &P.sum_hi[(int64_t)gid * na + a], v);
+                }
+            } else if (valid && !in_comb) {
+                // lane-by-lane update
+                if (kind == PH_A_COUNT_STAR || kind == PH_A_COUNT) {
+                    if (staged) atomicAdd(&l_cnt[ls], 1u);
+                    else atomicAdd(&P.cnt[st], 1ull);
+                } else if (is_sum) {
+                    if (staged) {
+                        atomicAdd(&l_sum[ls], (unsigned long long)v);
+                        atomicAdd(&l_cnt[ls], 1u);
+                    } else {
+                        atomicAdd(&P.cnt[st], 1ull);
+                        add128(&P.sum_lo[st], &P.sum_hi[st], v);
+                    }
+                } else if (kind == PH_A_MIN) {
+                    if (staged) { atomicMin((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
+                    else { atomicAdd(&P.cnt[st], 1ull); atomicMin((long long *)&P.sum_lo[st], v); }
+                } else if (kind == PH_A_MAX) {
+                    if (staged) { atomicMax((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
+                    else { atomicAdd(&P.cnt[st], 1ull); atomicMax((long long *)&P.sum_lo[st], v); }
+                }
+            }
+            if (comb != 0) {  // wave-uniform; combined lanes all have an LDS entry
+                const bool contrib = in_comb && valid && (!is_sum || small);
+                const unsigned long long cb = __ballot(contrib);
+                // biased to unsigned and split 21 + 20 bits so 64 lanes add up inside 32-bit DPP adds
+                const unsigned long long u = contrib && is_sum ? (unsigned long long)(v + (1ll << 40)) : 0ull;
+                const int ulo = (int)(u & 0x1FFFFFu), uhi = (int)(u >> 21);
+                unsigned long long t = comb;
+                while (t != 0) {
+                    int lead = __ffsll((long long)t) - 1;
+                    int g = __builtin_amdgcn_readlane(ent, lead);
+                    unsigned long long m = __ballot(ent == g);
+                    t &= ~m;
+                    const unsigned n = (unsigned)__popcll(m & cb);
+                    long long sum = 0;
+                    if (is_sum) {
+                        const bool mine = ent == g;
+                        unsigned long long su = (unsigned long long)(unsigned)wave_sum32(mine ? ulo : 0) +
+                                                ((unsigned long long)(unsigned)wave_sum32(mine ? uhi : 0) << 21);
+                        sum = (long long)su - ((long long)n << 40);
+                    }
+                    if (lane == lead && n != 0) {
+                        atomicAdd(&l_cnt[ls], n);
+                        if (is_sum) atomicAdd(&l_sum[ls], (unsigned long long)sum);
+                    }
+                }
+            }
+        }
+      }  // rows in flight
     }
-    // ---- flush the staging table: one HBM update per (group, aggregate) per workgroup
+    }  // chunk loop
+    if (threadIdx.x == 0) P.progress[blockIdx.x] = it;
+    // ---- flush: one find-or-create and one HBM update per state for every group this workgroup saw
     __syncthreads();
-    for (int e = threadIdx.x; e < P.lds_slots; e += 256) {
-        int gid = l_gid[e];
+    for (int e = threadIdx.x; e < T; e += 256) {
+        int stt = l_state[e];
+        if (stt < 0) continue;
+        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+        for (int c = 0; c < nk; c++) k[c] = l_key[c * T + e];
+        int gid = find_or_create(P, k, (unsigned)stt, keys_hash(k, (unsigned)stt, nk));
         if (gid < 0) continue;
         if (l_first[e] != INT64_MAX) atomicMin(&P.first_row[gid], l_first[e]);
-        for (int a = 0; a < P.naggs; a++) {
-            unsigned n = l_cnt[e * P.naggs + a];
+        for (int a = 0; a < na; a++) {
+            unsigned n = l_cnt[e * na + a];
             if (n == 0) continue;
-            int64_t st = (int64_t)gid * P.naggs + a;
+            int64_t st = (int64_t)gid * na + a;
             int kind = P.agg_kind[a];
             atomicAdd(&P.cnt[st], (unsigned long long)n);
-            long long v = (long long)l_sum[e * P.naggs + a];
+            long long v = (long long)l_sum[e * na + a];
             if (kind == PH_A_SUM || kind == PH_A_AVG) add128(&P.sum_lo[st], &P.sum_hi[st], v);
             else if (kind == PH_A_MIN) atomicMin((long long *)&P.sum_lo[st], v);
             else if (kind == PH_A_MAX) atomicMax((long long *)&P.sum_lo[st], v);
@@ -368,14 +548,13 @@ struct ph_agg {
     long long *sum_hi = nullptr;
     unsigned long long *cnt = nullptr;
     long long *first_row = nullptr;
-    int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] first refused batch (growth guard)
+    int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] need-grow flag of the running sink
     int *kinds_dev = nullptr;
     int64_t rows_sunk = 0;
 };
 
 namespace {
 
-constexpr int64_t AGG_BATCH = 1 << 21;
 
 int64_t next_pow2(int64_t v) {
     int64_t p = 1;
@@ -514,62 +693,59 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
     P.positional = positional;
     P.ngroups = a->counters;
     P.error_flag = a->counters + 1;
-    P.skip_from = a->counters + 2;
-    const int nbatches = (int)((n + AGG_BATCH - 1) / AGG_BATCH);
-    int start = 0;
-    while (start < nbatches) {
-        // make room for the first batch of this round, then enqueue every remaining batch behind
-        // its growth guard; only one host round trip per round
+    P.need_grow = a->counters + 2;
+    for (int c = 0; c < nargs; c++) if (used[c]) P.arg_used |= 1u << c;
+    P.combine = 1;
+    for (int i = 0; i < a->naggs; i++)
+        if (a->aggs[i].kind == PH_A_MIN || a->aggs[i].kind == PH_A_MAX) P.combine = 0;
+    P.sel = sel;
+    P.n = n;
+    P.row_base = row_base;
+    if (n == 0) return PH_OK;
+    // LDS table: as many entries as fit 32 KiB (at most 1024): state 4 B, first row 8 B, 8 B per
+    // key column, 12 B per aggregate
+    int per_entry = 12 + 8 * a->nkeys + 12 * a->naggs;
+    int slots = 64;
+    while (slots * 2 * per_entry <= 32 * 1024 && slots < 1024) slots *= 2;
+    P.lds_slots = slots;
+    size_t lds = (size_t)slots * per_entry;
+    // as many workgroups as are resident at once (static chunk assignment: a workgroup that had to
+    // wait for a free CU would double the run time), each alive for the whole call
+    int occ = 0;
+    PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ph::agg_sink_kernel, 256, lds));
+    occ = std::max(1, std::min(occ, 4));
+    const int64_t nchunks = (n + ph::AGG_CHUNK - 1) / ph::AGG_CHUNK;
+    // staged partials are int64 sums of |v| < 2^40 and u32 counts: at most 2^22 rows per workgroup
+    const int64_t min_grid = (n + (1ll << 22) - 1) >> 22;
+    const int grid = (int)std::max<int64_t>(std::min<int64_t>(nchunks, (int64_t)a->ctx->cu_count * occ), min_grid);
+    P.slack = (long long)grid * (ph::AGG_CHUNK + slots / 2);
+    int *progress = nullptr;
+    PH_CHECK(a->ctx->pool_alloc((int64_t)grid * 4, (void **)&progress));
+    P.progress = progress;
+
+    int rc = PH_OK;
+    if (hipMemsetAsync(progress, 0, (size_t)grid * 4, a->ctx->stream) != hipSuccess ||
+        hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
+    while (rc == PH_OK) {
         int64_t ng = 0;
-        PH_CHECK(ph_agg_group_count(a, &ng));
-        int64_t m0 = std::min(AGG_BATCH, n - (int64_t)start * AGG_BATCH);
+        if ((rc = ph_agg_group_count(a, &ng)) != PH_OK) break;
         int64_t cap = a->cap;
-        while (cap / 2 - ng <= m0) cap *= 2;   // Resize rule (aggregate_hash.go:214-217); gcap = cap/2
-        if (cap != a->cap) PH_CHECK(agg_resize(a, cap, (int)ng));
-        const int big = 0x7fffffff;
-        PH_HIP(hipMemcpyAsync(a->counters + 2, &big, 4, hipMemcpyHostToDevice, a->ctx->stream));
-        for (int b = start; b < nbatches; b++) {
-            int64_t off = (int64_t)b * AGG_BATCH;
-            int64_t m = std::min(AGG_BATCH, n - off);
-            P.sel = sel ? sel + off : nullptr;
-            P.n = m;
-            P.row_base = row_base + off;
-            P.batch_index = b;
-            if (!sel || positional) {
-                // identity selection / positional args: shift the base pointers instead
-                for (int c = 0; c < a->nkeys && !sel; c++) {
-                    int w = ph::type_width(keys[c].type);
-                    P.key[c].data = (const char *)keys[c].data + off * w;
-                    P.key[c].validity = keys[c].validity ? keys[c].validity + off / 8 : nullptr;
-                }
-                for (int c = 0; c < nargs && (!sel || positional); c++) {
-                    if (!used[c]) continue;
-                    int w = ph::type_width(args[c].type);
-                    P.arg[c].data = (const char *)args[c].data + off * w;
-                    P.arg[c].validity = args[c].validity ? args[c].validity + off / 8 : nullptr;
-                }
-            }
-            P.slots = a->slots;
-            P.mask = (uint64_t)a->cap - 1;
-            P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
-            P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
-            // staging table: as many entries as fit 48 KiB (12 B + 12 B per aggregate each)
-            int per_entry = 12 + 12 * std::max(a->naggs, 1);
-            int slots = 64;
-            while (slots * 2 * per_entry <= 48 * 1024 && slots < 4096) slots *= 2;
-            P.lds_slots = slots;
-            size_t lds = (size_t)slots * (8 + 4) + (size_t)slots * a->naggs * (8 + 4);
-            if (b > start)
-                ph::agg_guard_kernel<<<1, 1, 0, a->ctx->stream>>>(a->counters, a->gcap, m, b, a->counters + 2);
-            // few long-lived workgroups: every flush costs one HBM atomic per live entry
-            int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)a->ctx->cu_count * 4);
-            ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
-            PH_HIP(hipGetLastError());
-        }
-        int refused = big;
-        if (nbatches - start > 1) PH_CHECK(a->ctx->download(&refused, a->counters + 2, 4));
-        start = refused == big ? nbatches : refused;
+        while (cap / 2 - ng <= P.slack) cap *= 2;   // gcap = cap/2 must exceed the in-flight rows
+        if (cap != a->cap && (rc = agg_resize(a, cap, (int)ng)) != PH_OK) break;
+        P.slots = a->slots;
+        P.mask = (uint64_t)a->cap - 1;
+        P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
+        P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
+        ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
+        if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
+        if (a->gcap - ng - n > P.slack) break;  // even all-new groups cannot trip the check
+        int grow = 0;
+        if ((rc = a->ctx->download(&grow, a->counters + 2, 4)) != PH_OK || !grow) break;
+        if (hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
     }
+    a->ctx->pool_release(progress);
+    if (rc == PH_EHIP) ph::set_error("ph_agg_sink: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+    if (rc != PH_OK) return rc;
     a->rows_sunk += n;
     return PH_OK;
 }

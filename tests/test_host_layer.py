@@ -82,3 +82,26 @@ def test_semi_and_anti_join_executors(sf001):
     anti = [int(x) for x in run("anti", "1", "100").split("\n")[1:] if x]
     assert semi == ck[has].tolist() and anti == ck[~has].tolist()
     assert all(k % 3 == 0 for k in anti[:50]) and len(anti) >= len(ck) // 3
+
+
+def test_vector_formats_unify_slice_and_serialize():
+    """FLAT / CONST / DICT / SEQUENCE vectors through ToUnifiedFormat, Slice (selection of a
+    selection included) and Serialize (vector_format.go:64-97, chunk.go:82-93)."""
+    full = [f"{5 + 3 * i}\tk\tNULL\t{-10000000000 + 10000000000 * i}\t{'NULL' if i == 3 else 100 + i}" for i in range(6)]
+    first = [full[i] for i in (4, 1, 3, 0)]
+    second = [first[i] for i in (2, 0)]
+    want = "\n".join(full + ["--"] + first + ["--"] + second + ["--"] + second) + "\n"
+    assert run("formats") == want
+
+
+@pytest.mark.gpu
+def test_left_join_executor(sf001):
+    """customer LEFT JOIN orders: every (custkey, orderkey) pair plus one (custkey, NULL) row per
+    customer without orders (NextLeftJoin, join_scan.go:67-88)."""
+    ck = sf001["customer"]["c_custkey"]
+    oc, ok = sf001["orders"]["o_custkey"], sf001["orders"]["o_orderkey"]
+    got = sorted(tuple(l.split("\t")) for l in run("left", "1", "100").split("\n")[1:] if l)
+    import numpy as np
+    never = ck[~np.isin(ck, oc)]
+    want = sorted([(str(int(c)), str(int(o))) for c, o in zip(oc, ok)] + [(str(int(c)), "NULL") for c in never])
+    assert got == want and len(never) > 0
