@@ -60,13 +60,14 @@ struct AggSinkParams {
     int lds_slots;  // power of two; per-workgroup staging table entries
     int *need_grow;     // set when a workgroup stopped early because the table may fill up
     int *progress;      // per workgroup: chunk iterations already done (resume point after a growth)
-    long long slack;    // groups all workgroups together may still create = gridDim.x * (AGG_CHUNK + lds_slots / 2)
+    long long slack;    // groups all workgroups together may still create = gridDim.x * (chunk + lds_slots / 2)
+    int chunk;          // rows a workgroup takes between two growth checks (256 .. AGG_CHUNK)
     int combine;        // wave-level combining allowed (no MIN/MAX aggregate)
     unsigned arg_used;  // bit c: argument column c is read by some aggregate
 };
 
-constexpr int AGG_CHUNK = 2048;  // rows a workgroup takes between two growth checks
-constexpr int AGG_U = 4;         // rows per thread in flight
+constexpr int AGG_CHUNK = 2048;  // most rows a workgroup takes between two growth checks
+constexpr int AGG_U = 2;         // rows per thread in flight
 constexpr int AGG_PRE = 4;       // argument columns read ahead for them
 
 __device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
@@ -118,7 +119,15 @@ __device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsi
         if (g == SLOT_EMPTY) {
             int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
             if (old == SLOT_EMPTY) {
-                int ng = atomicAdd(P.ngroups, 1);
+                // group ids for all lanes of this wave that won a slot in this iteration come from
+                // ONE add on the counter: it is a single address for the whole device, and inputs
+                // that are mostly new groups (Q3: 113k groups from 298k rows) were bound by it
+                const unsigned long long winners = __ballot(1);
+                const int first = __ffsll((long long)winners) - 1, me = (int)(threadIdx.x & 63);
+                int base = 0;
+                if (me == first) base = atomicAdd(P.ngroups, __popcll(winners));
+                base = __shfl(base, first);
+                int ng = base + __popcll(winners & ((1ull << me) - 1ull));
                 if (ng >= P.gcap) {  // cannot happen: see the growth check
                     atomicOr(P.error_flag, 1);
                     ng = 0;
@@ -126,8 +135,14 @@ __device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsi
                 for (int c = 0; c < P.nkeys; c++)
                     __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
+                if (nullmask)  // gnull is zeroed when the arrays are (re)allocated
+                    __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // Publication order: the key words above are agent-scope atomic stores (sc1: written
+                // through to the device coherence point, never parked dirty in this XCD's L2), and
+                // on gfx9 vmcnt counts stores, so waiting for vmcnt(0) means they are performed
+                // before the id below is stored. A full release fence would add buffer_wbl2 — a
+                // write-back of the whole L2 per new group, which doubled the cost of inputs that
+                // are mostly new groups — and is only needed for ordinary (non-atomic) stores.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&P.slots[slot], ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 gid = ng;
@@ -163,10 +178,28 @@ __device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsi
 // and leaves; the host grows the table and relaunches, every workgroup resuming at its chunk.
 constexpr int L_EMPTY = -1, L_LOCKED = -2;   // LDS entry states; >= 0: ready, value = NULL mask
 
+// index hash of the LDS table: 32-bit multiplies only (a 64-bit mix costs ~8 quarter-rate
+// multiplies per key on CDNA); the 64-bit hash of the global table is computed only for rows
+// that go there
+template <int NK>
+__device__ __forceinline__ unsigned lds_hash(const unsigned long long *k, unsigned nullmask) {
+    unsigned h = nullmask * 0x9E3779B1u;
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+        h ^= (unsigned)k[c];
+        h *= 0x85EBCA6Bu;
+        h ^= (unsigned)(k[c] >> 32) + (h >> 15);
+        h *= 0xC2B2AE35u;
+    }
+    return h ^ (h >> 16);
+}
+
+template <int NK>
 __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
     __shared__ int s_go, s_nent;
     extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
-    const int T = P.lds_slots, na = P.naggs, nk = P.nkeys;
+    const int T = P.lds_slots, na = P.naggs;
+    constexpr int nk = NK;
     // [first T x i64][key nk*T x u64][sum T*na x u64][state T x i32][cnt T*na x u32]
     long long *l_first = reinterpret_cast<long long *>(agg_lds);
     unsigned long long *l_key = reinterpret_cast<unsigned long long *>(l_first + T);
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
     const int lane = threadIdx.x & 63;
     int it = P.progress[blockIdx.x];
     for (;; it++) {
-    const int64_t c0 = ((int64_t)it * gridDim.x + blockIdx.x) * AGG_CHUNK;
+    const int64_t c0 = ((int64_t)it * gridDim.x + blockIdx.x) * P.chunk;
     if (c0 >= P.n) break;
     __syncthreads();  // LDS initialised / everyone has read the previous s_go
     if (threadIdx.x == 0) {
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
     }
     __syncthreads();
     if (!s_go) break;
-    const int64_t c1 = c0 + AGG_CHUNK < P.n ? c0 + AGG_CHUNK : P.n;
+    const int64_t c1 = c0 + P.chunk < P.n ? c0 + P.chunk : P.n;
     // every lane stays in this loop (dead lanes carry ent -1): the wave-level combining below
     // needs the whole wave converged. AGG_U rows per thread are in flight: all their column
     // reads (selection, keys, the first AGG_PRE argument columns) are issued before the first
@@ -251,8 +284,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
         if (live) {
             const unsigned long long *k = kk[u];
             const unsigned nullmask = nmask[u];
-            const uint64_t h = keys_hash(k, nullmask, nk);
-            int idx = (int)(h >> 40) & (T - 1);
+            int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
             // same no-waiting-inside-a-branch protocol as the global table, on LDS
             for (int probes = 0, spins = 0; probes < 16 && spins < (1 << 16);) {
                 int st = __hip_atomic_load(&l_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -277,7 +309,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
                     probes++;
                 }
             }
-            if (ent < 0) gid = find_or_create(P, k, nullmask, h);
+            if (ent < 0) gid = find_or_create(P, k, nullmask, keys_hash(k, nullmask, nk));
         }
         // ---- wave-level combining. When few groups are hot (Q1-like inputs: 4), 64 lanes hit a
         // handful of LDS words and the ds atomics serialise lane by lane. Groups that hold >= 8
@@ -587,6 +619,7 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
     PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&cnt));
     PH_CHECK(ctx->pool_alloc(gcap * 8, (void **)&first_row));
     PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
+    PH_HIP(hipMemsetAsync(gnull, 0, (size_t)gcap * 4, ctx->stream));
     if (ng > 0) {
         PH_HIP(hipMemcpyAsync(gkeys, a->gkeys, (size_t)ng * a->nkeys * 8, hipMemcpyDeviceToDevice, ctx->stream));
         PH_HIP(hipMemcpyAsync(gnull, a->gnull, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -712,33 +745,48 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
     // as many workgroups as are resident at once (static chunk assignment: a workgroup that had to
     // wait for a free CU would double the run time), each alive for the whole call
     int occ = 0;
-    PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ph::agg_sink_kernel, 256, lds));
+    void (*kernel)(ph::AggSinkParams) = a->nkeys == 1 ? ph::agg_sink_kernel<1> : a->nkeys == 2 ? ph::agg_sink_kernel<2>
+                                        : a->nkeys == 3 ? ph::agg_sink_kernel<3> : ph::agg_sink_kernel<4>;
+    PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds));
     occ = std::max(1, std::min(occ, 4));
-    const int64_t nchunks = (n + ph::AGG_CHUNK - 1) / ph::AGG_CHUNK;
+    // small inputs are latency bound (a new group costs a chain of dependent HBM atomics): give
+    // every thread one row before giving any thread a second one
+    const int64_t resident = (int64_t)a->ctx->cu_count * occ;
+    int chunk = 256;
+    while (chunk < ph::AGG_CHUNK && (n + chunk - 1) / chunk > resident) chunk *= 2;
+    P.chunk = chunk;
+    const int64_t nchunks = (n + chunk - 1) / chunk;
     // staged partials are int64 sums of |v| < 2^40 and u32 counts: at most 2^22 rows per workgroup
     const int64_t min_grid = (n + (1ll << 22) - 1) >> 22;
-    const int grid = (int)std::max<int64_t>(std::min<int64_t>(nchunks, (int64_t)a->ctx->cu_count * occ), min_grid);
-    P.slack = (long long)grid * (ph::AGG_CHUNK + slots / 2);
+    const int grid = (int)std::max<int64_t>(std::min<int64_t>(nchunks, resident), min_grid);
+    // this call creates at most n groups in total, so a slack of n is always enough
+    P.slack = std::min<long long>((long long)grid * (chunk + slots / 2), n);
     int *progress = nullptr;
     PH_CHECK(a->ctx->pool_alloc((int64_t)grid * 4, (void **)&progress));
     P.progress = progress;
-
     int rc = PH_OK;
     if (hipMemsetAsync(progress, 0, (size_t)grid * 4, a->ctx->stream) != hipSuccess ||
         hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
+    // the table cannot hold more groups than rows were sunk into it: while that bound plus this
+    // call's rows fits, no growth is possible and neither the group count nor the need-grow flag
+    // has to cross PCIe
+    const bool sure = a->gcap - a->rows_sunk > n;
+    if (sure) P.slack = -1;  // the in-kernel check can never be needed: switch it off
     while (rc == PH_OK) {
-        int64_t ng = 0;
-        if ((rc = ph_agg_group_count(a, &ng)) != PH_OK) break;
-        int64_t cap = a->cap;
-        while (cap / 2 - ng <= P.slack) cap *= 2;   // gcap = cap/2 must exceed the in-flight rows
-        if (cap != a->cap && (rc = agg_resize(a, cap, (int)ng)) != PH_OK) break;
+        int64_t ng = a->rows_sunk;
+        if (!sure) {
+            if ((rc = ph_agg_group_count(a, &ng)) != PH_OK) break;
+            int64_t cap = a->cap;
+            while (cap / 2 - ng <= P.slack) cap *= 2;   // gcap = cap/2 must exceed the in-flight rows
+            if (cap != a->cap && (rc = agg_resize(a, cap, (int)ng)) != PH_OK) break;
+        }
         P.slots = a->slots;
         P.mask = (uint64_t)a->cap - 1;
         P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
         P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
-        ph::agg_sink_kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
+        kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
         if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
-        if (a->gcap - ng - n > P.slack) break;  // even all-new groups cannot trip the check
+        if (sure || a->gcap - ng - n > P.slack) break;  // even all-new groups cannot trip the check
         int grow = 0;
         if ((rc = a->ctx->download(&grow, a->counters + 2, 4)) != PH_OK || !grow) break;
         if (hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;

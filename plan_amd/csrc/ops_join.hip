@@ -55,18 +55,23 @@ __device__ __forceinline__ bool load_keys(const JoinSide &S, int64_t r, unsigned
     return true;
 }
 
-// Bloom bitmap (1 hash, >= 8 bits per build key, only for build sides small enough that it stays
-// L2-resident): a selective probe (Q3: 1 % of the probe rows match) rejects most rows with one
-// cached 4-byte read instead of a random read of the 4n-entry head table.
+// Bloom bitmap (two bits per key inside ONE 32-bit word, >= 16 bits per build key, ~1 % false
+// positives; only for build sides small enough that it stays cache-resident): a selective probe
+// (Q3: 1 % of the probe rows match) rejects most rows with one cached 4-byte read instead of a
+// random read of the 4n-entry head table — every false positive costs one to four random HBM
+// reads in the chain walk, which is what bounds the probe.
 struct Bloom {
     unsigned *bits;      // NULL = no filter
     uint64_t word_mask;  // number of 32-bit words - 1
 };
 
+__device__ __forceinline__ unsigned bloom_mask(uint64_t b) { return (1u << (b & 31)) | (1u << ((b >> 5) & 31)); }
+
 __device__ __forceinline__ bool bloom_maybe(const Bloom &bl, uint64_t h) {
     if (!bl.bits) return true;
     uint64_t b = h >> 24;  // bits disjoint from the low bits that pick the bucket
-    return (bl.bits[(b >> 5) & bl.word_mask] >> (b & 31)) & 1u;
+    const unsigned m = bloom_mask(b);
+    return (bl.bits[(b >> 10) & bl.word_mask] & m) == m;
 }
 
 __global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__restrict__ head, uint64_t mask,
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__
         next[i] = atomicExch(&head[h & mask], (int32_t)i);        // head insertion
         if (bl.bits) {
             uint64_t b = h >> 24;
-            atomicOr(&bl.bits[(b >> 5) & bl.word_mask], 1u << (b & 31));
+            atomicOr(&bl.bits[(b >> 10) & bl.word_mask], bloom_mask(b));
         }
         local++;
     }
@@ -139,48 +144,180 @@ __global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr
     if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+// Write pass. A thread owns JP_ROUNDS CONSECUTIVE probe positions (one 8-byte read of their match
+// counts), so the workgroup needs a single scan for its 2048 rows and output order = probe order.
+// Only rows that matched walk their chain again.
 __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
                                                          const int32_t *__restrict__ block_off,
                                                          const uint8_t *__restrict__ cnt8, int64_t cap,
                                                          int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build) {
-    int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    static_assert(JP_ROUNDS == 8, "one 64-bit load of match counts per thread");
+    const int64_t i0 = (int64_t)blockIdx.x * JP_CHUNK + (int64_t)threadIdx.x * JP_ROUNDS;
+    int c[JP_ROUNDS];
+    if (i0 + JP_ROUNDS <= Pr.n) {
+        unsigned long long w = *reinterpret_cast<const unsigned long long *>(cnt8 + i0);
+#pragma unroll
+        for (int j = 0; j < JP_ROUNDS; j++) c[j] = (int)((w >> (8 * j)) & 0xFF);
+    } else {
+#pragma unroll
+        for (int j = 0; j < JP_ROUNDS; j++) c[j] = i0 + j < Pr.n ? cnt8[i0 + j] : 0;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < JP_ROUNDS; j++) {
+        if (c[j] == 255) c[j] = probe_count(B, Pr, head, mask, next, i0 + j, Bloom{nullptr, 0});  // saturated: recount
+        mine += c[j];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
     __shared__ int ws[4];
-    int64_t running = block_off[blockIdx.x];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        int64_t i = base + rr * 256 + threadIdx.x;
-        int c = i < Pr.n ? cnt8[i] : 0;
-        if (c == 255) c = probe_count(B, Pr, head, mask, next, i, Bloom{nullptr, 0});  // saturated: recount
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            int y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
+    if (lane == 63) ws[wv] = incl;
+    __syncthreads();
+    if (mine == 0) return;
+    int64_t pos = block_off[blockIdx.x] + incl - mine;
+    for (int k = 0; k < wv; k++) pos += ws[k];
+#pragma unroll
+    for (int j = 0; j < JP_ROUNDS; j++) {
+        if (c[j] == 0) continue;
+        const int64_t i = i0 + j;
+        int64_t r = Pr.sel ? Pr.sel[i] : i;
+        unsigned long long k[JOIN_MAX_KEYS];
+        uint64_t h;
+        load_keys(Pr, r, k, &h);
+        for (int b = head[h & mask]; b >= 0; b = next[b]) {
+            int64_t brow = B.sel ? B.sel[b] : b;
+            if (keys_equal(B, brow, k)) {
+                if (pos < cap) {
+                    out_probe[pos] = (int32_t)r;
+                    out_build[pos] = (int32_t)brow;
+                }
+                pos++;
+            }
         }
-        if (lane == 63) ws[w] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < w; k++) woff += ws[k];
-        int total = ws[0] + ws[1] + ws[2] + ws[3];
-        if (c > 0) {
-            int64_t pos = running + woff + incl - c;
+    }
+}
+
+// ---- selective probes (a Bloom bitmap exists). In the two-pass kernels above a lane that has to
+// walk a chain (three or four dependent random reads) holds up its wave while the other lanes
+// idle, and both passes pay for it. Here the work is split by density, with no same-address
+// atomics anywhere (one returning atomic per workgroup on a shared counter costs ~7 ns each,
+// serialised — 0.1 ms for a 32M-row probe):
+//   join_cand_kernel   streams the probe keys, tests the bitmap and writes the surviving
+//                      positions of its 2048-row block, in order, to the block's own slice of
+//                      the candidate array
+//   join_chain_kernel  one wave per block slice: walks the candidates' chains, stores each
+//                      candidate's match count and the block total
+//   (scan of the block totals)
+//   join_emit_kernel   one wave per block slice: prefix-sums the counts and writes the pairs
+// Output order is probe order, as before.
+__global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, uint16_t *__restrict__ cand,
+                                                        int32_t *__restrict__ ccount) {
+    // round rr covers positions base + rr*256 + thread (lane-consecutive rows: coalesced reads);
+    // ordered output = round-major, so the slot of a survivor is the number of survivors in
+    // earlier rounds and earlier waves plus those in lower lanes of its own ballot
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int wc[JP_ROUNDS][4];
+    unsigned long long bal[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const int64_t i = base + rr * 256 + threadIdx.x;
+        bool take = false;
+        if (i < Pr.n) {
             int64_t r = Pr.sel ? Pr.sel[i] : i;
             unsigned long long k[JOIN_MAX_KEYS];
             uint64_t h;
-            load_keys(Pr, r, k, &h);
-            for (int b = head[h & mask]; b >= 0; b = next[b]) {
-                int64_t brow = B.sel ? B.sel[b] : b;
-                if (keys_equal(B, brow, k)) {
-                    if (pos < cap) {
-                        out_probe[pos] = (int32_t)r;
-                        out_build[pos] = (int32_t)brow;
+            take = load_keys(Pr, r, k, &h) && bloom_maybe(bl, h);
+        }
+        bal[rr] = __ballot(take);
+        if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
+    }
+    __syncthreads();
+    uint16_t *dst = cand + base;
+    int before = 0;
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        int off = before;
+        for (int k = 0; k < wv; k++) off += wc[rr][k];
+        if ((bal[rr] >> lane) & 1) dst[off + __popcll(bal[rr] & ((1ull << lane) - 1ull))] = (uint16_t)(rr * 256 + threadIdx.x);
+        before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
+    }
+    if (threadIdx.x == 0) ccount[blockIdx.x] = before;
+}
+
+__global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
+                                                         uint64_t mask, const int32_t *__restrict__ next,
+                                                         const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
+                                                         uint16_t *__restrict__ ccnt, int32_t *__restrict__ block_counts,
+                                                         int64_t nb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        const int cnt = ccount[blk];
+        int total = 0;
+        for (int t0 = 0; t0 < cnt; t0 += 64) {
+            const int t = t0 + lane;
+            int c = 0;
+            if (t < cnt) {
+                c = probe_count(B, Pr, head, mask, next, blk * JP_CHUNK + cand[blk * JP_CHUNK + t], Bloom{nullptr, 0});
+                ccnt[blk * JP_CHUNK + t] = (uint16_t)(c > 65535 ? 65535 : c);
+            }
+            total += c;
+        }
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        if (lane == 0) block_counts[blk] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void join_emit_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
+                                                        uint64_t mask, const int32_t *__restrict__ next,
+                                                        const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
+                                                        const uint16_t *__restrict__ ccnt, const int32_t *__restrict__ block_off,
+                                                        int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
+                                                        int32_t *__restrict__ out_build) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        const int cnt = ccount[blk];
+        int64_t running = block_off[blk];
+        for (int t0 = 0; t0 < cnt; t0 += 64) {
+            const int t = t0 + lane;
+            int c = 0;
+            int64_t i = 0;
+            if (t < cnt) {
+                i = blk * JP_CHUNK + cand[blk * JP_CHUNK + t];
+                c = ccnt[blk * JP_CHUNK + t];
+                if (c == 65535) c = probe_count(B, Pr, head, mask, next, i, Bloom{nullptr, 0});  // saturated: recount
+            }
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (c > 0) {
+                int64_t pos = running + incl - c;
+                int64_t r = Pr.sel ? Pr.sel[i] : i;
+                unsigned long long k[JOIN_MAX_KEYS];
+                uint64_t h;
+                load_keys(Pr, r, k, &h);
+                for (int b = head[h & mask]; b >= 0; b = next[b]) {
+                    int64_t brow = B.sel ? B.sel[b] : b;
+                    if (keys_equal(B, brow, k)) {
+                        if (pos < cap) {
+                            out_probe[pos] = (int32_t)r;
+                            out_build[pos] = (int32_t)brow;
+                        }
+                        pos++;
                     }
-                    pos++;
                 }
             }
+            running += __shfl(incl, 63);
         }
-        running += total;
-        __syncthreads();
     }
 }
 
@@ -199,7 +336,8 @@ struct ph_join {
     int32_t *sel_copy = nullptr;
     int32_t *head = nullptr, *next = nullptr;
     int64_t cap = 0;
-    int64_t count = 0;
+    int64_t count = 0;       // -1 = not fetched from count_dev yet
+    int *count_dev = nullptr;
     ph::Bloom bloom{nullptr, 0};
 };
 
@@ -209,6 +347,7 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->head) j->ctx->pool_release(j->head);
     if (j->next) j->ctx->pool_release(j->next);
     if (j->bloom.bits) j->ctx->pool_release(j->bloom.bits);
+    if (j->count_dev) j->ctx->pool_release(j->count_dev);
     delete j;
 }
 
@@ -248,29 +387,38 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
         if (hipMemcpyAsync(j->sel_copy, sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy sel");
         j->build.sel = j->sel_copy;
     }
-    if (n > 0 && n <= (4ll << 20)) {  // bitmap of >= 8 bits per key, at most 8 MiB
+    if (n > 0 && n <= (4ll << 20)) {  // bitmap of >= 16 bits per key, at most 16 MiB
         int64_t bits = 1 << 16;
-        while (bits < 8 * n) bits <<= 1;
+        while (bits < 16 * n) bits <<= 1;
         if (ctx->pool_alloc(bits / 8, (void **)&j->bloom.bits) != PH_OK) return fail("alloc(bloom)");
         if (hipMemsetAsync(j->bloom.bits, 0, (size_t)(bits / 8), ctx->stream) != hipSuccess) return fail("memset");
         j->bloom.word_mask = (uint64_t)(bits / 32) - 1;
     }
-    if (ctx->ensure_scratch(64) != PH_OK) { ph_join_free(j); return PH_EHIP; }
-    int *count = (int *)ctx->scratch;
+    // number of inserted (non-NULL-key) rows: stays on the device until ph_join_count asks, so
+    // building a table costs no host round trip
+    if (ctx->pool_alloc(16, (void **)&j->count_dev) != PH_OK) return fail("alloc(count)");
+    int *count = j->count_dev;
     if (hipMemsetAsync(count, 0, 4, ctx->stream) != hipSuccess) return fail("memset");
     if (n > 0) {
         int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
         ph::join_build_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, j->head, (uint64_t)cap - 1, j->next, count, j->bloom);
         if (hipGetLastError() != hipSuccess) return fail("join_build_kernel launch");
     }
-    int c = 0;
-    if (ctx->download(&c, count, 4) != PH_OK) return fail("count readback");
-    j->count = c;
+    j->count = n == 0 ? 0 : -1;
     *out = j;
     return PH_OK;
 }
 
-extern "C" int64_t ph_join_count(const ph_join *j) { return j ? j->count : -1; }
+extern "C" int64_t ph_join_count(const ph_join *cj) {
+    ph_join *j = const_cast<ph_join *>(cj);
+    if (!j) return -1;
+    if (j->count < 0) {
+        int c = 0;
+        if (j->ctx->download(&c, j->count_dev, 4) != PH_OK) return -1;
+        j->count = c;
+    }
+    return j->count;
+}
 
 static int check_probe(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, ph::JoinSide *P) {
     PH_REQUIRE(j && keys && n >= 0, "ph_join_probe: bad arguments");
@@ -291,19 +439,35 @@ extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t
     PH_CHECK(check_probe(j, keys, sel, n, &P));
     PH_REQUIRE(n_out && cap >= 0 && (cap == 0 || (out_probe_dev && out_build_dev)), "ph_join_probe_inner: bad output arguments");
     *n_out = 0;
-    if (n == 0 || j->count == 0) return PH_OK;
+    if (n == 0 || j->build.n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
     int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
-    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64 + n));
+    const bool selective = j->bloom.bits != nullptr;  // candidate lists pay off when most probes miss
+    const int64_t o_cnt8 = ph::round_up(nb * 4, 8) + 64, o_ccount = o_cnt8;
+    const int64_t o_cand = ph::round_up(o_ccount + nb * 4, 8), o_ccnt = o_cand + nb * ph::JP_CHUNK * 2;
+    PH_CHECK(ctx->ensure_scratch(selective ? o_ccnt + nb * ph::JP_CHUNK * 2 : o_cnt8 + n));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
-    uint8_t *cnt8 = (uint8_t *)ctx->scratch + ph::round_up(nb * 4, 8) + 64;
+    uint8_t *cnt8 = (uint8_t *)ctx->scratch + o_cnt8;
     uint64_t mask = (uint64_t)j->cap - 1;
-    ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, j->bloom);
-    PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-    ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, cap, out_probe_dev, out_build_dev);
-    PH_HIP(hipGetLastError());
+    if (selective) {
+        int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
+        uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
+        const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
+        ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, cand, ccount);
+        ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, counts, nb);
+        PH_HIP(hipGetLastError());
+        PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+        ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, counts, nb, cap,
+                                                                 out_probe_dev, out_build_dev);
+        PH_HIP(hipGetLastError());
+    } else {
+        ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, j->bloom);
+        PH_HIP(hipGetLastError());
+        PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+        ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, cap, out_probe_dev, out_build_dev);
+        PH_HIP(hipGetLastError());
+    }
     PH_CHECK(ctx->download(n_out, total, 8));
     if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
     return PH_OK;
@@ -315,7 +479,7 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
     PH_REQUIRE(n == 0 || found_dev, "ph_join_probe_mark: found_dev is NULL");
     if (n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
-    if (j->count == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
     int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
     ph::join_mark_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, P, j->head, (uint64_t)j->cap - 1, j->next, found_dev, j->bloom);
     PH_HIP(hipGetLastError());
