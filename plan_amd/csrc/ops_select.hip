@@ -97,15 +97,25 @@ __device__ __forceinline__ bool sel_pred(const SelParams &P, int64_t r) {
 constexpr int SEL_ROUNDS = 8;
 constexpr int SEL_CHUNK = 256 * SEL_ROUNDS;
 
+// `flags` (optional): the count pass leaves every wave's ballot there ([block][round][wave]) and
+// the write pass reads it back instead of evaluating the predicate a second time — used for the
+// string predicates, where a LIKE match costs far more than the 1 bit per row of the memo.
 __global__ __launch_bounds__(256) void select_count_kernel(SelParams P, const int32_t *__restrict__ sel_in,
-                                                           int64_t n_in, int32_t *__restrict__ block_counts) {
+                                                           int64_t n_in, int32_t *__restrict__ block_counts,
+                                                           unsigned long long *__restrict__ flags) {
     int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
     int cnt = 0;
     for (int r = 0; r < SEL_ROUNDS; r++) {
         int64_t i = base + r * 256 + threadIdx.x;
+        bool pass = false;
         if (i < n_in) {
             int64_t row = sel_in ? sel_in[i] : i;
-            cnt += sel_pred(P, row) ? 1 : 0;
+            pass = sel_pred(P, row);
+        }
+        cnt += pass ? 1 : 0;
+        if (flags) {
+            unsigned long long m = __ballot(pass);
+            if ((threadIdx.x & 63) == 0) flags[((int64_t)blockIdx.x * SEL_ROUNDS + r) * 4 + (threadIdx.x >> 6)] = m;
         }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -146,7 +156,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(int32_t *__restrict__ v, int
 
 __global__ __launch_bounds__(256) void select_write_kernel(SelParams P, const int32_t *__restrict__ sel_in,
                                                            int64_t n_in, const int32_t *__restrict__ block_off,
-                                                           int32_t *__restrict__ sel_out) {
+                                                           int32_t *__restrict__ sel_out,
+                                                           const unsigned long long *__restrict__ flags) {
     int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
     __shared__ int ws[4];
     int running = block_off[blockIdx.x];
@@ -155,11 +166,18 @@ __global__ __launch_bounds__(256) void select_write_kernel(SelParams P, const in
         int64_t i = base + r * 256 + threadIdx.x;
         int64_t row = 0;
         bool pass = false;
-        if (i < n_in) {
-            row = sel_in ? sel_in[i] : i;
-            pass = sel_pred(P, row);
+        unsigned long long m;
+        if (flags) {
+            m = flags[((int64_t)blockIdx.x * SEL_ROUNDS + r) * 4 + w];
+            pass = (m >> lane) & 1;
+            if (pass) row = sel_in ? sel_in[i] : i;
+        } else {
+            if (i < n_in) {
+                row = sel_in ? sel_in[i] : i;
+                pass = sel_pred(P, row);
+            }
+            m = __ballot(pass);
         }
-        unsigned long long m = __ballot(pass);
         int rank = __popcll(m & ((1ull << lane) - 1));
         if (lane == 0) ws[w] = __popcll(m);
         __syncthreads();
@@ -397,9 +415,11 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
                (P.kind == ph::SK_RANGE_I32 || P.kind == ph::SK_RANGE_I64 || P.kind == ph::SK_RANGE_U8);
     int64_t chunk = vec ? ph::VSEL_CHUNK : ph::SEL_CHUNK;
     int64_t nb = (n_in + chunk - 1) / chunk;
-    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
+    const bool memo = P.kind == ph::SK_STR;
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64 + (memo ? nb * ph::SEL_ROUNDS * 4 * 8 : 0)));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    unsigned long long *flags = memo ? (unsigned long long *)((char *)ctx->scratch + ph::round_up(nb * 4, 8) + 64) : nullptr;
     if (vec) {
         int rc = P.kind == ph::SK_RANGE_I32   ? ph::run_vsel<int32_t>(ctx, P, n_in, sel_out, counts, nb, total)
                  : P.kind == ph::SK_RANGE_I64 ? ph::run_vsel<int64_t>(ctx, P, n_in, sel_out, counts, nb, total)
@@ -408,10 +428,10 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
         PH_CHECK(ctx->download(n_out, total, 8));
         return PH_OK;
     }
-    ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts);
+    ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, flags);
     PH_HIP(hipGetLastError());
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-    ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out);
+    ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, flags);
     PH_HIP(hipGetLastError());
     PH_CHECK(ctx->download(n_out, total, 8));
     return PH_OK;

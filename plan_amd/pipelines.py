@@ -306,7 +306,7 @@ class Q9Pipeline:
         t0 = tic()
         if N == 1:
             j.free()
-            jps = hip.Join(ctx, [self.ps_part, self.ps_supp], None, self.n["ps"])
+            jps = None   # built on the (smaller) intermediate below, probed with partsupp
             ps_cost = self.ps_cost
         else:
             import torch
@@ -322,9 +322,17 @@ class Q9Pipeline:
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp.data_ptr()), _raw(hip.PH_I32, bs.data_ptr())], None, bp.numel())
             ps_cost = _raw(hip.PH_DEC64, bc.data_ptr(), 2)
         k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
-        n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+        if jps is None:
+            # build side = the ~5 % of lineitem that survived the part join, probe side = partsupp:
+            # the table is smaller than one over all of partsupp, and the probe is selective, so
+            # the Bloom bitmap rejects the ~95 % of partsupp rows that belong to other parts
+            jint = hip.Join(ctx, [_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1)
+            n2, psrow, pos2 = jint.probe_inner([self.ps_part, self.ps_supp], None, self.n["ps"], max(n1, 1))
+            jint.free()
+        else:
+            n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+            jps.free()
         frees += [pos2, psrow]
-        jps.free()
         lrow2 = gat(_raw(hip.PH_I32, lrow), pos2, n2)
         stage("partsupp_join", t0)
 
@@ -355,7 +363,7 @@ class Q9Pipeline:
         c_qty, c_cost = gat(self.l_qty, lrow3, n3), gat(ps_cost, psrow3, n3)
         c_nat = gat(s_nat, srow, n3)
         if N == 1:
-            jo = hip.Join(ctx, [self.o_key], None, self.n["o"])
+            jo = None    # built on the intermediate (n3 rows), probed with the 5x larger orders
             o_date = self.o_date.col()
             m = n3
         else:
@@ -385,9 +393,14 @@ class Q9Pipeline:
             m = recv[0].numel()
             jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0].data_ptr())], None, orecv[0].numel())
             o_date = _raw(hip.PH_DATE, orecv[1].data_ptr())
-        n4, pos4, orow = jo.probe_inner([_raw(hip.PH_I64, c_okey)], None, m, max(m, 1))
+        if jo is None:
+            jint = hip.Join(ctx, [_raw(hip.PH_I64, c_okey)], None, m)
+            n4, orow, pos4 = jint.probe_inner([self.o_key], None, self.n["o"], max(m, 1))
+            jint.free()
+        else:
+            n4, pos4, orow = jo.probe_inner([_raw(hip.PH_I64, c_okey)], None, m, max(m, 1))
+            jo.free()
         frees += [pos4, orow]
-        jo.free()
         stage("orders_join", t0)
 
         t0 = tic()
