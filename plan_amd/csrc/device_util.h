@@ -79,7 +79,7 @@ __device__ __host__ __forceinline__ void civil_from_days(int32_t z, int32_t *y, 
 
 // LIKE with % and _ (same greedy/backtracking matcher as wildcardMatch,
 // function_operator_boolean.go:336-377)
-__device__ __host__ inline bool like_match(const char *s, int slen, const char *pat, int plen) {
+__device__ __host__ __forceinline__ bool like_match(const char *s, int slen, const char *pat, int plen) {
     int p = 0, t = 0, after_pct = -1, t_at_pct = -1;
     while (t < slen) {
         if (p < plen && pat[p] == '%') {

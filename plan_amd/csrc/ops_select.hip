@@ -41,6 +41,7 @@ struct SelParams {
     double kd;
     double div;  // 10^scale
     int plen;
+    int contains;  // LIKE / NOT LIKE pattern is %literal% (no _ and no inner %): substring search
     char pat[96];
 };
 
@@ -96,6 +97,7 @@ __device__ __forceinline__ bool sel_pred(const SelParams &P, int64_t r) {
 
 constexpr int SEL_ROUNDS = 8;
 constexpr int SEL_CHUNK = 256 * SEL_ROUNDS;
+constexpr int SEL_STR_LDS = 24 * 1024;  // staged string bytes per round (256 rows)
 
 // `flags` (optional): the count pass leaves every wave's ballot there ([block][round][wave]) and
 // the write pass reads it back instead of evaluating the predicate a second time — used for the
@@ -105,10 +107,94 @@ __global__ __launch_bounds__(256) void select_count_kernel(SelParams P, const in
                                                            unsigned long long *__restrict__ flags) {
     int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
     int cnt = 0;
+    // string predicates over consecutive rows: the 256 strings of a round are one contiguous byte
+    // range, copied to LDS with coalesced 4-byte reads so the matcher's byte-by-byte walk never
+    // touches global memory (a LIKE over 2M part names was bound by 1-byte global loads)
+    __shared__ __attribute__((aligned(16))) char sbuf[SEL_STR_LDS];
+    __shared__ int soff[257];   // string offsets of the round's rows
+    __shared__ char spat[96];   // the pattern too: indexing the kernel argument costs a global load per character
+    const bool stage = P.kind == SK_STR && sel_in == nullptr;
+    if (stage) {
+        if (threadIdx.x < 96) spat[threadIdx.x] = P.pat[threadIdx.x];
+        __syncthreads();
+    }
     for (int r = 0; r < SEL_ROUNDS; r++) {
         int64_t i = base + r * 256 + threadIdx.x;
         bool pass = false;
-        if (i < n_in) {
+        bool staged = false;
+        if (stage) {
+            const int64_t first = base + r * 256;
+            if (first < n_in) {   // workgroup-uniform
+                const int64_t last = first + 256 < n_in ? first + 256 : n_in;
+                const int nrow = (int)(last - first);
+                __syncthreads();  // previous round's readers are done
+                if (threadIdx.x <= nrow) soff[threadIdx.x] = ((const int32_t *)P.data)[first + threadIdx.x];
+                if (threadIdx.x == 0) soff[nrow] = ((const int32_t *)P.data)[last];
+                __syncthreads();
+                const int64_t b0 = soff[0] & ~3, b1 = soff[nrow];
+                if (b1 - b0 <= SEL_STR_LDS) {
+                    for (int64_t w = threadIdx.x; w < (b1 - b0 + 3) / 4; w += 256)
+                        reinterpret_cast<int *>(sbuf)[w] = *reinterpret_cast<const int *>(P.bytes + b0 + w * 4);
+                    __syncthreads();
+                    staged = true;
+                    if (P.contains) {
+                        // %literal%: every thread tests byte positions of the whole staged range
+                        // (no per-string loop, no divergence); a hit marks the row that owns the
+                        // position unless the literal would run past that row's end
+                        __shared__ unsigned rowhit[8];
+                        if (threadIdx.x < 8) rowhit[threadIdx.x] = 0;
+                        __syncthreads();
+                        const int L = P.plen - 2;
+                        const int64_t s0 = soff[0] - b0, s1 = b1 - b0;
+                        // four positions per step from two aligned LDS words, compared against the
+                        // literal's first (up to) four bytes at once: the slow path (rest of the
+                        // literal, row lookup) runs only on real prefix hits, so waves rarely
+                        // diverge into it
+                        unsigned lit4 = 0;
+                        for (int c = 0; c < 4 && c < L; c++) lit4 |= (unsigned)(unsigned char)spat[1 + c] << (8 * c);
+                        const unsigned m4 = L >= 4 ? 0xFFFFFFFFu : (1u << (8 * L)) - 1u;
+                        const unsigned *sw = reinterpret_cast<const unsigned *>(sbuf);
+                        const int nword = (int)((s1 + 3) / 4);
+                        for (int j = threadIdx.x; j < nword; j += 256) {
+                            const unsigned long long win =
+                                (unsigned long long)sw[j] | ((unsigned long long)(j + 1 < SEL_STR_LDS / 4 ? sw[j + 1] : 0u) << 32);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if ((((unsigned)(win >> (8 * k)) ^ lit4) & m4) != 0) continue;
+                                const int64_t x = (int64_t)j * 4 + k;
+                                if (x < s0 || x + L > s1) continue;
+                                bool m = true;
+                                for (int c = 4; m && c < L; c++) m = sbuf[x + c] == spat[1 + c];
+                                if (!m) continue;
+                                int lo = 0, hi = nrow;   // last row with offset <= position
+                                while (hi - lo > 1) {
+                                    int mid = (lo + hi) >> 1;
+                                    if (soff[mid] - b0 <= x) lo = mid; else hi = mid;
+                                }
+                                if (x + L <= soff[lo + 1] - b0) atomicOr(&rowhit[lo >> 5], 1u << (lo & 31));
+                            }
+                        }
+                        __syncthreads();
+                        if (i < n_in && bit_valid(P.validity, i)) {
+                            bool hit = (rowhit[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1;
+                            pass = hit == (P.op == PH_LIKE);
+                        }
+                    } else if (i < n_in && bit_valid(P.validity, i)) {
+                        const char *str = sbuf + (soff[threadIdx.x] - b0);
+                        const int slen = soff[threadIdx.x + 1] - soff[threadIdx.x];
+                        bool m;
+                        if (P.op == PH_LIKE || P.op == PH_NOTLIKE) m = like_match(str, slen, spat, P.plen) == (P.op == PH_LIKE);
+                        else {
+                            bool eq = slen == P.plen;
+                            for (int c = 0; eq && c < slen; c++) eq = str[c] == spat[c];
+                            m = P.op == PH_EQ ? eq : !eq;
+                        }
+                        pass = m;
+                    }
+                }
+            } else staged = true;
+        }
+        if (!staged && i < n_in) {
             int64_t row = sel_in ? sel_in[i] : i;
             pass = sel_pred(P, row);
         }
@@ -378,6 +464,11 @@ static bool lower_select(const ph_col *col, int32_t op, const ph_const *k, SelPa
         P->plen = (int)strlen(k->s);
         if (P->plen >= (int)sizeof P->pat) return false;
         memcpy(P->pat, k->s, (size_t)P->plen);
+        if ((op == PH_LIKE || op == PH_NOTLIKE) && P->plen >= 3 && P->pat[0] == '%' && P->pat[P->plen - 1] == '%') {
+            P->contains = 1;
+            for (int c = 1; c < P->plen - 1; c++)
+                if (P->pat[c] == '%' || P->pat[c] == '_') P->contains = 0;
+        }
         P->bytes = (const char *)col->aux;
         P->kind = SK_STR;
         return true;

@@ -115,6 +115,33 @@ def test_filter_and_chain_and_strings(ctx, sf001):
         d.free()
 
 
+def test_filter_like_contains_edge_cases(ctx):
+    """%literal% takes the position-parallel substring path: literals that span two rows must not
+    match, matches at the first/last byte of a row must, empty and shorter-than-literal rows never
+    do, NULL rows never select, and rows too long for the LDS stage fall back to the generic
+    matcher (wildcardMatch, function_operator_boolean.go:336-377) with the same answers."""
+    rng = np.random.default_rng(5)
+    base = ["pi", "nk", "pink", "", "xpink", "pinkx", "p", "ink", "pinpink", "pin", "kpi", "nkp", "PINK", "pi nk",
+            "a" * 30000 + "pink", "b" * 40, "pink" + "c" * 26000, "nk"]
+    words = base + [("".join(rng.choice(list("pinkx "), int(rng.integers(0, 12))))) for _ in range(3000)]
+    off = np.zeros(len(words) + 1, np.int32)
+    off[1:] = np.cumsum([len(w) for w in words])
+    b = np.frombuffer("".join(words).encode(), dtype=np.uint8)
+    valid = np.ones(len(words), bool)
+    valid[[4, 100, 101]] = False
+    vb = np.packbits(valid, bitorder="little")
+    col = hip.DevColumn(ctx, hip.PH_STR, off, aux=b, validity=vb)
+    ocol = O.col(O.OT_VARCHAR, off, validity=vb, dictionary=b)
+    for op, pat in [(hip.PH_LIKE, "%pink%"), (hip.PH_NOTLIKE, "%pink%"), (hip.PH_LIKE, "%k%"), (hip.PH_LIKE, "%pi nk%"),
+                    (hip.PH_LIKE, "%nkp%"), (hip.PH_LIKE, "%p_nk%"), (hip.PH_LIKE, "%pin%pink%")]:
+        s, c = hip.filter_select(ctx, col, len(words), op, hip.const(hip.PH_STR, s=pat))
+        want = O.select(ocol, op, O.const(O.OT_VARCHAR, s=pat), n=len(words))
+        assert c == len(want), (op, pat, c, len(want))
+        assert np.array_equal(dl(ctx, s, np.int32, c).astype(np.int64), want), (op, pat)
+        ctx.free(s)
+    col.free()
+
+
 def test_filter_dictionary_code_equality(ctx, sf001):
     C = sf001["customer"]
     n = len(C["c_custkey"])
