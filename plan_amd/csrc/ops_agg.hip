@@ -488,46 +488,59 @@ __device__ __forceinline__ unsigned long long order_key(long long v, int descend
 }
 
 // state[0] = prefix, state[1] = remaining k, hist[256] in global memory; no host round trips
-__global__ __launch_bounds__(256) void topk_check_kernel(const unsigned long long *__restrict__ sum_lo,
-                                                         const long long *__restrict__ sum_hi, int naggs, int a, int ng,
-                                                         int *__restrict__ flags) {
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
-        long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
-        if (sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) atomicOr(flags, 1);
-    }
-}
-
-__global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
-                                                        int ng, int descending, int pass,
-                                                        const unsigned long long *__restrict__ state,
-                                                        unsigned *__restrict__ hist) {
+// One pass of the radix select (most significant byte first). Every workgroup histograms the
+// byte of the keys that still match the prefix; the LAST workgroup to finish (a ticket counter)
+// folds the histogram into the prefix / remaining-k state and clears it for the next pass, so a
+// pass is one launch. Pass 7 also checks that every sum fits int64 (flags |= 1 otherwise).
+__global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long *__restrict__ sum_lo,
+                                                        const long long *__restrict__ sum_hi, int naggs, int a,
+                                                        int ng, int descending, int pass, long long k,
+                                                        unsigned long long *__restrict__ state,
+                                                        unsigned *__restrict__ hist, int *__restrict__ done,
+                                                        int *__restrict__ flags) {
     __shared__ unsigned lh[256];
+    __shared__ int s_last;
     lh[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long prefix = state[0];
-    unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    const unsigned long long prefix = state[0];
+    const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    bool wide = false;
     for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
-        unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
+        const long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
+        if (pass == 7 && sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) wide = true;
+        unsigned long long key = order_key(lo, descending);
         if ((key & mask) == (prefix & mask)) atomicAdd(&lh[(key >> (8 * pass)) & 0xff], 1u);
     }
+    if (wide) atomicOr(flags, 1);
     __syncthreads();
     if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-}
-
-__global__ void topk_resolve_kernel(unsigned long long *__restrict__ state, unsigned *__restrict__ hist, int pass) {
-    if (threadIdx.x == 0) {
-        long long rem = (long long)state[1];
-        int b = 0;
-        for (; b < 256; b++) {
-            if ((long long)hist[b] >= rem) break;
-            rem -= hist[b];
-        }
-        if (b == 256) b = 255;  // k > ng: everything qualifies
-        state[0] |= (unsigned long long)b << (8 * pass);
-        state[1] = (unsigned long long)rem;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's histogram adds are performed
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // fold: bin b with (count of bins < b) < remaining <= (count of bins <= b); a 256-wide scan, not
+    // a serial walk (256 dependent LDS reads by one thread cost more than the histogram itself)
+    const unsigned v = atomicExch(&hist[threadIdx.x], 0u);  // read at the coherence point and clear
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long rem = pass == 7 ? k : (long long)state[1];  // every thread reads it before the barrier below
+    long long incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        long long y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    __shared__ long long wtot[4];
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    for (int w = 0; w < wv; w++) incl += wtot[w];
+    if (incl >= rem && incl - (long long)v < rem) {
+        state[0] = prefix | ((unsigned long long)threadIdx.x << (8 * pass));
+        state[1] = (unsigned long long)(rem - (incl - (long long)v));
+    } else if (threadIdx.x == 255 && incl < rem) {  // k exceeds the number of groups: everything qualifies
+        state[0] = prefix | (255ull << (8 * pass));
+        state[1] = (unsigned long long)(rem - incl);
+    }
+    if (threadIdx.x == 0) *done = 0;
 }
 
 __global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
@@ -856,31 +869,26 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     if (ng == 0 || k == 0) return PH_OK;
     ph_ctx *ctx = a->ctx;
     int cap = (int)std::min<int64_t>(max_groups, ng);
-    int *ids = nullptr, *meta = nullptr;
-    unsigned long long *state = nullptr;  // [0] prefix [1] remaining k, then 256 x u32 histogram
+    int *ids = nullptr;
+    unsigned long long *state = nullptr;  // [0] prefix [1] remaining k [2] ticket + pad [3] meta (count, flag), then 256 x u32 histogram
     PH_CHECK(ctx->pool_alloc((int64_t)std::max(cap, 1) * 4, (void **)&ids));
-    PH_CHECK(ctx->pool_alloc(8, (void **)&meta));
-    PH_CHECK(ctx->pool_alloc(16 + 1024, (void **)&state));
-    PH_HIP(hipMemsetAsync(meta, 0, 8, ctx->stream));
-    PH_HIP(hipMemsetAsync(state, 0, 16 + 1024, ctx->stream));
-    unsigned long long kk = (unsigned long long)k;
-    PH_HIP(hipMemcpyAsync(state + 1, &kk, 8, hipMemcpyHostToDevice, ctx->stream));
-    unsigned *hist = (unsigned *)(state + 2);
+    PH_CHECK(ctx->pool_alloc(32 + 1024, (void **)&state));
+    PH_HIP(hipMemsetAsync(state, 0, 32 + 1024, ctx->stream));
+    int *done = (int *)(state + 2), *meta = (int *)(state + 3);
+    unsigned *hist = (unsigned *)(state + 4);
     int tg = (int)std::min<int64_t>((ng + 255) / 256, ctx->cu_count * 2);
-    ph::topk_check_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, meta + 1);
-    for (int pass = 7; pass >= 0; pass--) {  // radix select, most significant byte first
-        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, (int)ng, descending, pass, state, hist);
-        ph::topk_resolve_kernel<<<1, 256, 0, ctx->stream>>>(state, hist, pass);
-    }
+    for (int pass = 7; pass >= 0; pass--)  // radix select, most significant byte first
+        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, descending, pass,
+                                                          (long long)k, state, hist, done, meta + 1);
     ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, (int)ng, descending, (long long)k,
                                                           state, ids, meta, cap);
     PH_HIP(hipGetLastError());
-    ctx->pool_release(state);
     int m[2] = {0, 0};
     int rc = ctx->download(m, meta, 8);
+    ctx->pool_release(state);
     if (rc == PH_OK && m[1]) { ph::set_error("ph_agg_topk: a sum does not fit int64; use ph_agg_finalize"); rc = PH_EOVERFLOW; }
     if (rc == PH_OK && m[0] > cap) { ph::set_error("ph_agg_topk: %d qualifying groups, room for %d", m[0], cap); rc = PH_ECAPACITY; }
-    if (rc != PH_OK) { ctx->pool_release(ids); ctx->pool_release(meta); return rc; }
+    if (rc != PH_OK) { ctx->pool_release(ids); return rc; }
     size_t n = (size_t)m[0], na = (size_t)a->naggs, nk = (size_t)a->nkeys;
     struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
     std::vector<Row> rows(n);
@@ -917,7 +925,6 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
         }
     }
     ctx->pool_release(ids);
-    ctx->pool_release(meta);
     if (rc != PH_OK) return rc;
     std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.fr < y.fr; });
     for (size_t o = 0; o < n; o++) {
