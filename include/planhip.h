@@ -187,6 +187,21 @@ int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_types, int32_t 
  * (sel[i], or i without a selection); give row_base the rows consumed by earlier sinks. */
 int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
                 const int32_t *sel, int64_t n, int32_t positional, int64_t row_base);
+/* Same, but only the aggregates whose bit is set in agg_mask are updated (groups are still found
+ * or created for every row) — AddChunk's `filter []int` (aggregate_hash.go:155-199), which the
+ * reference uses to feed non-DISTINCT aggregates from the raw rows and each DISTINCT aggregate
+ * from its own (group keys + argument) table (aggregate_exec.go:74-99, 201-304). */
+int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
+                       const int32_t *sel, int64_t n, int32_t positional, int64_t row_base,
+                       uint32_t agg_mask);
+/* Key column `key_index` of all current groups, in group-id order, as a dense DEVICE column of
+ * the key's own element width (4 B for PH_I32/PH_DATE, 1 B for PH_CODE8, else 8 B) plus an
+ * optional validity bitmap (1 bit per group, LSB first, at least (ngroups+7)/8 bytes; NULL keys
+ * clear their bit). This is RadixPartitionedHashTable.GetData for the DISTINCT tables
+ * (aggregate_exec.go:266-279): the distinct (group keys, argument) rows, re-sunk into the main
+ * table with ph_agg_sink_masked. Returns the group count through *ngroups. */
+int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev, uint8_t *out_validity_dev,
+                    int64_t capacity, int64_t *ngroups);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
 /* Host outputs, groups in first-seen order:
  *   first_row[g]; keys[g*nkeys+c] (int64-widened), key_null[g*nkeys+c];

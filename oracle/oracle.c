@@ -536,6 +536,11 @@ static void agg_grow(oagg *t) {
 
 int oracle_agg_sink(oagg *t, const ocol *keys, const ocol *args, const int64_t *row_ids,
                     int64_t cnt) {
+    return oracle_agg_sink_filtered(t, keys, args, row_ids, cnt, 0xFFFFFFFFu);
+}
+
+int oracle_agg_sink_filtered(oagg *t, const ocol *keys, const ocol *args, const int64_t *row_ids,
+                             int64_t cnt, uint32_t agg_mask) {
     uint64_t hashes[VS];
     uint64_t ht_off[VS];
     int64_t addr[VS]; /* group ordinal per row (the reference keeps row pointers) */
@@ -596,6 +601,8 @@ int oracle_agg_sink(oagg *t, const ocol *keys, const ocol *args, const int64_t *
     }
     /* update loop (:176-198): one pass per aggregate over the chunk */
     for (int32_t a = 0; a < t->naggs; a++) {
+        /* AddChunk's filter (:178-197): aggregates not listed are skipped, their states untouched */
+        if (!((agg_mask >> a) & 1)) continue;
         const ocol *arg = t->aggs[a].arg >= 0 ? &args[t->aggs[a].arg] : NULL;
         for (int64_t j = 0; j < cnt; j++) {
             agg_state *s = &t->states[addr[j] * t->naggs + a];

@@ -140,6 +140,13 @@ oagg *oracle_agg_create(const ocol *key_proto, int32_t nkeys, const ocol *arg_pr
  * reported back as group_first_row. Returns 0 or an error code. */
 int oracle_agg_sink(oagg *t, const ocol *keys, const ocol *args, const int64_t *row_ids,
                     int64_t cnt);
+/* AddChunk with its `filter []int` (aggregate_hash.go:155-199): groups are found or created for
+ * every row, but only the aggregates whose bit is set in agg_mask are updated. The reference
+ * sinks raw rows with the non-DISTINCT aggregates' filter and, at finalize, the rows of each
+ * DISTINCT aggregate's own (group keys + argument) table with filter {i}
+ * (aggregate_exec.go:74-99 SinkDistinctGrouping, :201-304 FinalizeDistinct/DistinctGrouping). */
+int oracle_agg_sink_filtered(oagg *t, const ocol *keys, const ocol *args, const int64_t *row_ids,
+                             int64_t cnt, uint32_t agg_mask);
 int64_t oracle_agg_count(const oagg *t);
 int oracle_agg_group(const oagg *t, int64_t g, int64_t *first_row, int64_t *key_vals,
                      uint8_t *key_null, oaggval *vals);

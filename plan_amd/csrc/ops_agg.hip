@@ -64,6 +64,7 @@ struct AggSinkParams {
     int chunk;          // rows a workgroup takes between two growth checks (256 .. AGG_CHUNK)
     int combine;        // wave-level combining allowed (no MIN/MAX aggregate)
     unsigned arg_used;  // bit c: argument column c is read by some aggregate
+    unsigned agg_mask;  // bit a: aggregate a is updated by this call (AddChunk's filter)
 };
 
 constexpr int AGG_CHUNK = 2048;  // most rows a workgroup takes between two growth checks
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
         }
         // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
         for (int a = 0; a < na; a++) {
+            if (!((P.agg_mask >> a) & 1)) continue;  // wave-uniform
             const int64_t st = (int64_t)gid * na + a;
             const int ls = ent * na + a;
             const int kind = P.agg_kind[a];
@@ -578,6 +580,24 @@ __global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ i
     }
 }
 
+// key column c of all groups -> dense column + validity bits; a thread converts 8 groups
+__global__ __launch_bounds__(256) void agg_keys_kernel(const unsigned long long *__restrict__ gkeys,
+                                                       const unsigned *__restrict__ gnull, int nkeys, int c, int type,
+                                                       int ng, void *__restrict__ out, uint8_t *__restrict__ valid) {
+    const int g0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (g0 >= ng) return;
+    unsigned bits = 0;
+    for (int j = 0; j < 8 && g0 + j < ng; j++) {
+        const int g = g0 + j;
+        const unsigned long long k = gkeys[(int64_t)g * nkeys + c];
+        if (!((gnull[g] >> c) & 1)) bits |= 1u << j;
+        if (type == PH_I32 || type == PH_DATE) ((int32_t *)out)[g] = (int32_t)k;
+        else if (type == PH_CODE8) ((uint8_t *)out)[g] = (uint8_t)k;
+        else ((unsigned long long *)out)[g] = k;
+    }
+    if (valid) valid[g0 >> 3] = (uint8_t)bits;
+}
+
 }  // namespace ph
 
 struct ph_agg {
@@ -711,9 +731,32 @@ extern "C" int ph_agg_group_count(ph_agg *a, int64_t *ngroups) {
 
 extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
                            const int32_t *sel, int64_t n, int32_t positional, int64_t row_base) {
+    return ph_agg_sink_masked(a, keys, args, nargs, sel, n, positional, row_base, 0xFFFFFFFFu);
+}
+
+extern "C" int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev, uint8_t *out_validity_dev,
+                               int64_t capacity, int64_t *ngroups) {
+    PH_REQUIRE(a && ngroups && key_index >= 0 && key_index < a->nkeys && capacity >= 0, "ph_agg_keys_dev: bad arguments");
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(a, &ng));
+    *ngroups = ng;
+    if (ng > capacity) { ph::set_error("ph_agg_keys_dev: %lld groups, room for %lld", (long long)ng, (long long)capacity); return PH_ECAPACITY; }
+    if (ng == 0) return PH_OK;
+    PH_REQUIRE(out_data_dev, "ph_agg_keys_dev: out_data_dev is NULL");
+    ph::agg_keys_kernel<<<(int)((ng + 2047) / 2048), 256, 0, a->ctx->stream>>>(a->gkeys, a->gnull, a->nkeys, key_index,
+                                                                              a->key_types[key_index], (int)ng, out_data_dev,
+                                                                              out_validity_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
+                                  const int32_t *sel, int64_t n, int32_t positional, int64_t row_base,
+                                  uint32_t agg_mask) {
     PH_REQUIRE(a && keys && n >= 0 && nargs >= 0 && nargs <= ph::AGG_MAX_AGGS && (nargs == 0 || args),
                "ph_agg_sink: bad arguments");
     ph::AggSinkParams P{};
+    P.agg_mask = agg_mask;
     P.nkeys = a->nkeys;
     P.naggs = a->naggs;
     P.nargs = nargs;
@@ -723,7 +766,8 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
     }
     bool used[ph::AGG_MAX_AGGS] = {};
     for (int i = 0; i < a->naggs; i++)
-        if (a->aggs[i].kind != PH_A_COUNT_STAR && a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs) used[a->aggs[i].arg] = true;
+        if (((agg_mask >> i) & 1) && a->aggs[i].kind != PH_A_COUNT_STAR && a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs)
+            used[a->aggs[i].arg] = true;
     for (int c = 0; c < nargs; c++) {
         if (!used[c]) continue;  // placeholders of count(*) are never read
         int t = args[c].type;
@@ -733,7 +777,7 @@ extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, in
     for (int i = 0; i < a->naggs; i++) {
         P.agg_kind[i] = a->aggs[i].kind;
         P.agg_arg[i] = a->aggs[i].arg;
-        PH_REQUIRE(a->aggs[i].kind == PH_A_COUNT_STAR || (a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs),
+        PH_REQUIRE(!((agg_mask >> i) & 1) || a->aggs[i].kind == PH_A_COUNT_STAR || (a->aggs[i].arg >= 0 && a->aggs[i].arg < nargs),
                    "ph_agg_sink: aggregate %d refers to argument %d of %d", i, a->aggs[i].arg, nargs);
     }
     P.positional = positional;

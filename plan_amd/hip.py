@@ -392,9 +392,26 @@ class Agg:
         check(lib().ph_agg_create(ctx.h, i32(len(key_types)), kt, i32(len(aggs)), sp,
                                   i64(expected_groups), ctypes.byref(self.h)))
 
-    def sink(self, keys, args, sel, n, positional=False, row_base=0):
-        check(lib().ph_agg_sink(self.h, _cols(keys), _cols(args), i32(len(args)), sel, i64(n),
-                                i32(1 if positional else 0), i64(row_base)))
+    def sink(self, keys, args, sel, n, positional=False, row_base=0, mask=None):
+        """mask: bit a set = aggregate a is updated (AddChunk's filter); None = all"""
+        if mask is None:
+            check(lib().ph_agg_sink(self.h, _cols(keys), _cols(args), i32(len(args)), sel, i64(n),
+                                    i32(1 if positional else 0), i64(row_base)))
+        else:
+            check(lib().ph_agg_sink_masked(self.h, _cols(keys), _cols(args), i32(len(args)), sel, i64(n),
+                                           i32(1 if positional else 0), i64(row_base), ctypes.c_uint32(mask)))
+
+    def key_column(self, c, key_type, scale=0):
+        """key column c of all groups as a device column (data ptr, validity ptr, ngroups, ph_col)"""
+        ng = self.group_count()
+        w = 4 if key_type in (PH_I32, PH_DATE) else 1 if key_type == PH_CODE8 else 8
+        data = self.ctx.alloc(max(ng, 1) * w)
+        valid = self.ctx.alloc((max(ng, 1) + 7) // 8 + 8)
+        n = i64()
+        check(lib().ph_agg_keys_dev(self.h, i32(c), data, valid, i64(ng), ctypes.byref(n)))
+        col = Col()
+        col.type, col.scale, col.data, col.validity = key_type, scale, data, valid
+        return data, valid, n.value, col
 
     def group_count(self):
         n = i64()

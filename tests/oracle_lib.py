@@ -225,6 +225,56 @@ def groupby(keys, args, aggs, sel, n, max_groups):
     return ng, first, gk.reshape(max_groups, len(keys)), gn.reshape(max_groups, len(keys)), vals
 
 
+class Agg:
+    """Incremental GroupedAggrHashTable of the oracle (create -> sink(<= 2048 rows, filter)* ->
+    groups), i.e. what aggExecutor and the DISTINCT finalisation drive chunk by chunk.
+    Columns are given as (type, numpy array, scale, bool validity array or None)."""
+
+    def __init__(self, key_specs, arg_specs, aggs):
+        self.key_specs, self.arg_specs, self.aggs = key_specs, arg_specs, aggs
+        kp = (OCol * len(key_specs))(*[col(t, None, sc) for t, sc in key_specs])
+        ap = (OCol * max(len(arg_specs), 1))(*[col(t, None, sc) for t, sc in arg_specs])
+        sp = (OAggSpec * max(len(aggs), 1))(*[OAggSpec(k, a) for k, a in aggs])
+        self.h = ctypes.c_void_p(lib().oracle_agg_create(kp, i32(len(key_specs)), ap, sp, i32(len(aggs))))
+
+    def sink(self, keys, args, mask=0xFFFFFFFF, row_base=0):
+        """keys/args: lists of (numpy array, bool validity or None) for the same n rows"""
+        n = len(keys[0][0])
+        for base in range(0, n, 2048):
+            cnt = min(2048, n - base)
+
+            def mk(specs, cols):
+                out = []
+                for (t, sc), (arr, valid) in zip(specs, cols):
+                    a = np.ascontiguousarray(arr[base:base + cnt])
+                    v = None if valid is None else np.packbits(valid[base:base + cnt], bitorder="little")
+                    out.append(col(t, a, sc, validity=v))
+                return out
+            kc, ac = mk(self.key_specs, keys), mk(self.arg_specs, args)
+            rid = np.arange(row_base + base, row_base + base + cnt, dtype=np.int64)
+            rc = lib().oracle_agg_sink_filtered(self.h, (OCol * len(kc))(*kc), (OCol * max(len(ac), 1))(*ac),
+                                                ptr(rid), i64(cnt), ctypes.c_uint32(mask))
+            assert rc == 0, rc
+
+    def groups(self):
+        ng = lib().oracle_agg_count(self.h)
+        nk, na = len(self.key_specs), len(self.aggs)
+        out = []
+        for g in range(ng):
+            first = i64()
+            kv = (i64 * nk)()
+            kn = (ctypes.c_uint8 * nk)()
+            vals = (OAggVal * max(na, 1))()
+            assert lib().oracle_agg_group(self.h, i64(g), ctypes.byref(first), kv, kn, vals) == 0
+            out.append((first.value, [None if kn[c] else int(kv[c]) for c in range(nk)], [vals[a] for a in range(na)]))
+        return out
+
+    def __del__(self):
+        if self.h:
+            lib().oracle_agg_free(self.h)
+            self.h = None
+
+
 class Join:
     def __init__(self, keys, sel, n):
         self.keys = keys

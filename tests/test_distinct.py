@@ -1,0 +1,88 @@
+"""DISTINCT aggregates: the reference keeps, per DISTINCT aggregate, a table grouped
+by (group keys + argument) and re-sinks its rows into the main table with filter {i}
+(aggregate_exec.go:74-99, 201-304; AddChunk's filter, aggregate_hash.go:155-199). The oracle
+composition below follows that; numpy's np.unique is the independent check; the device path is the
+same composition over ph_agg_sink_masked + ph_agg_keys_dev."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def make_data(n=50000, seed=3):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 37, n).astype(np.int32)             # group key
+    x = rng.integers(0, 400, n).astype(np.int32)            # distinct argument (many repeats)
+    xv = rng.random(n) > 0.1                                # 10 % NULL arguments
+    y = rng.integers(-5000, 5000, n).astype(np.int32)       # ordinary SUM argument
+    gv = rng.random(n) > 0.02                               # a few NULL group keys (their own group)
+    return g, gv, x, xv, y
+
+
+def numpy_answer(g, gv, x, xv, y):
+    """{group or None: (count(distinct x), sum(distinct x), sum(y), count(*))}"""
+    out = {}
+    keys = np.where(gv, g, -1)
+    for k in np.unique(keys):
+        m = keys == k
+        d = np.unique(x[m & xv])
+        out[None if k == -1 else int(k)] = (len(d), int(d.sum()), int(y[m].sum()), int(m.sum()))
+    return out
+
+
+def oracle_answer(g, gv, x, xv, y):
+    # main table: count(distinct x), sum(distinct x), sum(y), count(*); raw rows feed aggregates 2,3
+    aggs = [(O.OA_COUNT, 0), (O.OA_SUM, 0), (O.OA_SUM, 1), (O.OA_COUNT, -1)]
+    main = O.Agg([(O.OT_INT32, 0)], [(O.OT_INT32, 0), (O.OT_INT32, 0)], aggs)
+    dist = O.Agg([(O.OT_INT32, 0), (O.OT_INT32, 0)], [], [])          # (group key, x), no aggregates
+    main.sink([(g, gv)], [(x, xv), (y, None)], mask=0b1100)
+    dist.sink([(g, gv), (x, xv)], [])
+    rows = dist.groups()
+    dg = np.array([0 if r[1][0] is None else r[1][0] for r in rows], np.int32)
+    dgv = np.array([r[1][0] is not None for r in rows])
+    dx = np.array([0 if r[1][1] is None else r[1][1] for r in rows], np.int32)
+    dxv = np.array([r[1][1] is not None for r in rows])
+    main.sink([(dg, dgv)], [(dx, dxv), (dx, None)], mask=0b0011)
+    out = {}
+    for first, keys, vals in main.groups():
+        out[keys[0]] = (vals[0].h.value(), vals[1].h.value() if vals[1].kind != O.OV_NULL else 0,
+                        vals[2].h.value() if vals[2].kind != O.OV_NULL else 0, vals[3].h.value())
+    return out
+
+
+def test_oracle_filtered_sink_distinct_composition_matches_numpy():
+    d = make_data()
+    assert oracle_answer(*d) == numpy_answer(*d)
+
+
+@pytest.mark.gpu
+def test_device_distinct_aggregates_match_oracle():
+    from plan_amd import hip
+    ctx = hip.Ctx(0)
+    g, gv, x, xv, y = make_data(n=300000, seed=8)
+    want = oracle_answer(g, gv, x, xv, y)
+    n = len(g)
+    vb = lambda v: np.packbits(v, bitorder="little")
+    dg = hip.DevColumn(ctx, hip.PH_I32, g, validity=vb(gv))
+    dx = hip.DevColumn(ctx, hip.PH_I32, x, validity=vb(xv))
+    dy = hip.DevColumn(ctx, hip.PH_I32, y)
+    main = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_COUNT, 0), (hip.PH_A_SUM, 0), (hip.PH_A_SUM, 1), (hip.PH_A_COUNT_STAR, -1)], 64)
+    dist = hip.Agg(ctx, [hip.PH_I32, hip.PH_I32], [], 1024)
+    main.sink([dg], [dx, dy], None, n, mask=0b1100)
+    dist.sink([dg, dx], [], None, n)
+    p0, v0, nd, c0 = dist.key_column(0, hip.PH_I32)
+    p1, v1, nd1, c1 = dist.key_column(1, hip.PH_I32)
+    assert nd == nd1 == len({(None if not a else int(b), None if not c else int(e)) for a, b, c, e in zip(gv, g, xv, x)})
+    main.sink([c0], [c1, c1], None, nd, mask=0b0011)
+    r = main.finalize()
+    got = {}
+    for i in range(r["ngroups"]):
+        k = None if r["key_null"][i][0] else int(r["keys"][i][0])
+        got[k] = (int(r["count"][i][0]), r["sum"][i][1], r["sum"][i][2], int(r["count"][i][3]))
+    assert got == want
+    for p in (p0, v0, p1, v1):
+        ctx.free(p)
+    main.free(); dist.free()
+    for d in (dg, dx, dy):
+        d.free()
+    ctx.close()
