@@ -120,6 +120,15 @@ typedef struct {
 int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op, const ph_const *k,
                      const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
 
+/* OR of predicates = union of their selections: execSelectOr (expr_exec.go:488-530), which is
+ * also how `a IN (x, y, ...)` runs (in(a,x) OR in(a,y) ..., `in` selecting like `=`,
+ * function_operator_boolean.go:419-429). sels_dev[i] (device, counts[i] ascending row ids < n_rows)
+ * are the children's selections, each produced by ph_filter_select over the same input; the
+ * output is their union in ascending order (the reference emits it child by child; the row set
+ * is the same). out_sel_dev: >= min(n_rows, sum counts) int32. */
+int ph_sel_union(ph_ctx *ctx, const int32_t *const *sels_dev, const int64_t *counts, int32_t k,
+                 int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out);
+
 /* ------------------------------------------------------------------ hash
  * Chunk.Hash / HashTypeSwitch / CombineHashTypeSwitch (pkg/chunk/chunk.go:160-166,
  * hash.go:26-41, 182-413; util.HashBytes pkg/util/hash.go:13-65) — bit-identical values.

@@ -691,6 +691,31 @@ int64_t oracle_groupby(const ocol *keys, int32_t nkeys, const ocol *args, int32_
     return ng;
 }
 
+/* ------------------------------------------------------------------ OR of comparisons */
+
+int64_t oracle_select_or(const ocol *cols, const int32_t *ops, const oconst *ks, int32_t k,
+                         const int64_t *sel_in, int64_t n_in, int64_t *sel_out) {
+    /* curSel / curCount (expr_exec.go:490-491): the rows no child has accepted yet */
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_in ? n_in : 1));
+    int64_t *t = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_in ? n_in : 1));
+    int64_t cur_n = n_in, res = 0;
+    for (int64_t i = 0; i < n_in; i++) cur[i] = sel_in ? sel_in[i] : i;
+    for (int32_t c = 0; c < k; c++) {
+        int64_t tn = oracle_select(&cols[c], ops[c], &ks[c], cur, cur_n, t);
+        if (tn > 0) { /* :517-526: append the true rows, continue on the false ones */
+            int64_t w = 0, ti = 0;
+            for (int64_t i = 0; i < cur_n; i++) {
+                if (ti < tn && t[ti] == cur[i]) { sel_out[res++] = cur[i]; ti++; }
+                else cur[w++] = cur[i];
+            }
+            cur_n = w;
+        }
+    }
+    free(cur);
+    free(t);
+    return res;
+}
+
 /* ------------------------------------------------------------------ hash join */
 
 struct ojoin {

@@ -77,6 +77,14 @@ typedef struct {
 int64_t oracle_select(const ocol *col, int32_t op, const oconst *k, const int64_t *sel_in,
                       int64_t n_in, int64_t *sel_out);
 
+/* OR of k comparisons (`a IN (x, y)` binds to in(a,x) OR in(a,y); `in` selects like `=` for
+ * INTEGER and VARCHAR and nothing for other types, function_operator_boolean.go:419-429).
+ * execSelectOr (expr_exec.go:488-530): child i is evaluated on the rows every earlier child
+ * rejected, and its true rows are appended — so the output is child-major, not ascending.
+ * Returns the number of rows written to sel_out. */
+int64_t oracle_select_or(const ocol *cols, const int32_t *ops, const oconst *ks, int32_t k,
+                         const int64_t *sel_in, int64_t n_in, int64_t *sel_out);
+
 /* Chunk.Hash (pkg/chunk/chunk.go:160-166, hash.go:26-41, 182-413; util.HashBytes
  * pkg/util/hash.go:13-65): hash of the first column, combined with the others. */
 void oracle_hash(const ocol *cols, int32_t ncols, int64_t n, uint64_t *out);

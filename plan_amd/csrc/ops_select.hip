@@ -528,6 +528,47 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
     return PH_OK;
 }
 
+// ------------------------------------------------------------------ union (OR / IN lists)
+
+namespace ph {
+__global__ __launch_bounds__(256) void sel_flag_kernel(const int32_t *__restrict__ sel, int64_t n, uint8_t *__restrict__ flags) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) flags[sel[i]] = 1;
+}
+}  // namespace ph
+
+extern "C" int ph_sel_union(ph_ctx *ctx, const int32_t *const *sels_dev, const int64_t *counts, int32_t k,
+                            int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out) {
+    PH_REQUIRE(ctx && n_out && k >= 0 && n_rows >= 0 && (k == 0 || (sels_dev && counts)), "ph_sel_union: bad arguments");
+    *n_out = 0;
+    int64_t total = 0;
+    for (int i = 0; i < k; i++) { PH_REQUIRE(counts[i] >= 0 && (counts[i] == 0 || sels_dev[i]), "ph_sel_union: bad selection %d", i); total += counts[i]; }
+    if (total == 0 || n_rows == 0) return PH_OK;
+    PH_REQUIRE(out_sel_dev, "ph_sel_union: out_sel_dev is NULL");
+    // one flag byte per row, set by every child's rows, compacted by the vectorised byte filter
+    uint8_t *flags = nullptr;
+    PH_CHECK(ctx->pool_alloc(ph::round_up(n_rows, 16) + 16, (void **)&flags));
+    int rc = PH_OK;
+    if (hipMemsetAsync(flags, 0, (size_t)n_rows, ctx->stream) != hipSuccess) rc = PH_EHIP;
+    for (int i = 0; i < k && rc == PH_OK; i++) {
+        if (counts[i] == 0) continue;
+        int grid = (int)std::min<int64_t>((counts[i] + 255) / 256, (int64_t)ctx->cu_count * 8);
+        ph::sel_flag_kernel<<<grid, 256, 0, ctx->stream>>>(sels_dev[i], counts[i], flags);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    if (rc == PH_OK) {
+        ph_col c{};
+        c.type = PH_CODE8;
+        c.data = flags;
+        ph_const one{};
+        one.type = PH_I32;
+        one.i = 1;
+        rc = ph_filter_select(ctx, &c, n_rows, PH_EQ, &one, nullptr, n_rows, out_sel_dev, n_out);
+    }
+    ctx->pool_release(flags);
+    if (rc == PH_EHIP && ph_last_error()[0] == 0) ph::set_error("ph_sel_union: HIP failure");
+    return rc;
+}
+
 // ------------------------------------------------------------------ gather
 
 namespace ph {

@@ -353,6 +353,18 @@ def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None):
     return out, cnt.value
 
 
+def sel_union(ctx, sels, counts, n_rows):
+    """OR of predicates: ascending union of the children's selections (device pointers).
+    Returns (sel_out_dev, count)."""
+    k = len(sels)
+    arr = (vp * max(k, 1))(*sels)
+    cnts = (i64 * max(k, 1))(*[int(c) for c in counts])
+    out = ctx.alloc(max(min(n_rows, sum(int(c) for c in counts)), 1) * 4)
+    n = i64()
+    check(lib().ph_sel_union(ctx.h, arr, cnts, i32(k), i64(n_rows), out, ctypes.byref(n)))
+    return out, n.value
+
+
 def hash_cols(ctx, cols, n, dict_hashes=None):
     out = ctx.alloc(max(n, 1) * 8)
     dh = None

@@ -132,7 +132,7 @@ def lib():
         L = ctypes.CDLL(path)
         for f in ("oracle_select", "oracle_groupby", "oracle_join_count", "oracle_join_probe_inner",
                   "oracle_q3", "oracle_q9", "oracle_q1_text", "oracle_q6_text", "oracle_q3_text",
-                  "oracle_q9_text", "oracle_agg_count"):
+                  "oracle_q9_text", "oracle_agg_count", "oracle_select_or"):
             getattr(L, f).restype = i64
         L.oracle_join_build.restype = ctypes.c_void_p
         L.oracle_agg_create.restype = ctypes.c_void_p
@@ -210,6 +210,18 @@ def odec_unscaled(arr, scale):
             v = q
         out.append(-v if neg else v)
     return out
+
+
+def select_or(children, sel_in=None, n=None):
+    """children: list of (ocol, op, oconst). Returns the selected rows in the reference's order."""
+    k = len(children)
+    cols = (OCol * k)(*[c for c, _, _ in children])
+    ops = (i32 * k)(*[o for _, o, _ in children])
+    ks = (OConst * k)(*[kk for _, _, kk in children])
+    n_in = len(sel_in) if sel_in is not None else n
+    out = np.empty(max(n_in, 1), dtype=np.int64)
+    m = lib().oracle_select_or(cols, ops, ks, i32(k), ptr(sel_in), i64(n_in), ptr(out))
+    return out[:m].copy()
 
 
 def groupby(keys, args, aggs, sel, n, max_groups):

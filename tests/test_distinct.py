@@ -86,3 +86,70 @@ def test_device_distinct_aggregates_match_oracle():
     for d in (dg, dx, dy):
         d.free()
     ctx.close()
+
+
+# ------------------------------------------------------------------ OR / IN lists
+
+def in_list_data(n=100000, seed=21):
+    rng = np.random.default_rng(seed)
+    size = rng.integers(1, 51, n).astype(np.int32)
+    sv = rng.random(n) > 0.05
+    mode = rng.integers(0, 7, n).astype(np.uint8)   # dictionary codes of l_shipmode-like strings
+    return size, sv, mode
+
+
+MODES = ["AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"]
+
+
+def test_oracle_select_or_is_the_union_in_child_major_order():
+    size, sv, mode = in_list_data()
+    n = len(size)
+    c = O.col(O.OT_INT32, size, validity=np.packbits(sv, bitorder="little"))
+    kids = [(c, O.OP_EQ, O.const(O.OT_INT32, i=v)) for v in (49, 14, 23, 14)]
+    got = O.select_or(kids, n=n)
+    want = np.concatenate([np.flatnonzero(sv & (size == v)) for v in (49, 14, 23)])   # the repeated 14 adds nothing
+    assert np.array_equal(got, want)
+    # `in` on BIGINT is not implemented by the reference: selects nothing
+    big = O.col(O.OT_INT64, size.astype(np.int64))
+    assert len(O.select_or([(big, O.OP_EQ, O.const(O.OT_INT64, i=14))], n=n)) == 0
+
+
+@pytest.mark.gpu
+def test_device_in_list_union_matches_oracle():
+    from plan_amd import hip
+    ctx = hip.Ctx(0)
+    size, sv, mode = in_list_data(n=1_000_003, seed=4)
+    n = len(size)
+    vb = np.packbits(sv, bitorder="little")
+    dsize = hip.DevColumn(ctx, hip.PH_I32, size, validity=vb)
+    osize = O.col(O.OT_INT32, size, validity=vb)
+    dmode = hip.DevColumn(ctx, hip.PH_CODE8, mode)
+    omode = O.col(O.OT_CODE8, mode, dictionary=O.cdict(MODES))
+    # p_size IN (49, 14, 23, 45, 19, 3, 36, 9) (Q16), l_shipmode IN ('MAIL', 'SHIP') (Q12), and a mix
+    cases = [[(dsize, osize, hip.PH_I32, O.OT_INT32, v) for v in (49, 14, 23, 45, 19, 3, 36, 9)],
+             [(dmode, omode, "code", O.OT_VARCHAR, s) for s in ("MAIL", "SHIP")],
+             [(dsize, osize, hip.PH_I32, O.OT_INT32, 7), (dmode, omode, "code", O.OT_VARCHAR, "TRUCK"),
+              (dsize, osize, hip.PH_I32, O.OT_INT32, 1000)]]
+    for case in cases:
+        sels, counts, kids = [], [], []
+        for dcol, ocol, dt, ot, v in case:
+            if dt == "code":
+                k = hip.const(hip.PH_I32, i=MODES.index(v))
+                kids.append((ocol, O.OP_EQ, O.const(O.OT_VARCHAR, s=v)))
+            else:
+                k = hip.const(dt, i=v)
+                kids.append((ocol, O.OP_EQ, O.const(ot, i=v)))
+            s, c = hip.filter_select(ctx, dcol, n, hip.PH_EQ, k)
+            sels.append(s); counts.append(c)
+        out, m = hip.sel_union(ctx, sels, counts, n)
+        want = np.sort(O.select_or(kids, n=n))
+        got = ctx.download(out, np.int32, m).astype(np.int64)
+        assert m == len(want) and np.array_equal(got, want)
+        for s in sels + [out]:
+            ctx.free(s)
+    # no children / nothing selected
+    out, m = hip.sel_union(ctx, [], [], n)
+    assert m == 0
+    ctx.free(out)
+    dsize.free(); dmode.free()
+    ctx.close()
