@@ -129,6 +129,20 @@ int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op, cons
 int ph_sel_union(ph_ctx *ctx, const int32_t *const *sels_dev, const int64_t *counts, int32_t k,
                  int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out);
 
+/* falseSel of a predicate: the rows of the parent selection (NULL = identity over n_rows) that
+ * the child selection does not contain, ascending — what execSelectExpr hands back next to the
+ * true rows and executeCase continues with (expr_exec.go:144-246: curSel = curFalseSel). */
+int ph_sel_difference(ph_ctx *ctx, const int32_t *parent_dev, int64_t n_parent, const int32_t *child_dev,
+                      int64_t n_child, int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out);
+/* FillSwitch / TemplatedFillLoop (expr_exec.go:559-606): out[sel[i]] = values[i] for a positional
+ * value column (PH_I32 or PH_DEC64 — the two result types FillSwitch handles; n rows), i.e. a CASE branch's THEN/ELSE results written
+ * back at the rows the branch selected. out_validity_dev (optional bitmap, zeroed by the caller
+ * before the first branch) gets the bit of every row whose value is non-NULL. CASE on the device
+ * = ph_filter_select (WHEN) -> ph_expr_eval over the true rows -> ph_scatter, then the same for
+ * the next WHEN / the ELSE over ph_sel_difference's rows. */
+int ph_scatter(ph_ctx *ctx, const ph_col *values, const int32_t *sel_dev, int64_t n, void *out_data_dev,
+               uint8_t *out_validity_dev);
+
 /* ------------------------------------------------------------------ hash
  * Chunk.Hash / HashTypeSwitch / CombineHashTypeSwitch (pkg/chunk/chunk.go:160-166,
  * hash.go:26-41, 182-413; util.HashBytes pkg/util/hash.go:13-65) — bit-identical values.

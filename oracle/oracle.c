@@ -691,6 +691,44 @@ int64_t oracle_groupby(const ocol *keys, int32_t nkeys, const ocol *args, int32_
     return ng;
 }
 
+/* ------------------------------------------------------------------ CASE */
+
+int oracle_case_decimal(const ocol *cols, const ocol *when_col, int32_t when_op, const oconst *when_k,
+                        const orpn *then_prog, int32_t nthen, const orpn *else_prog, int32_t nelse,
+                        int64_t n, odec *out, uint8_t *out_null) {
+    int64_t *tsel = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    int64_t *fsel = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    odec *tmp = (odec *)malloc(sizeof(odec) * (size_t)(n ? n : 1));
+    int rc = 0;
+    /* execSelectExpr on the WHEN (:156-166): true rows, the rest are the false rows */
+    int64_t tn = oracle_select(when_col, when_op, when_k, NULL, n, tsel), fn = 0, ti = 0;
+    for (int64_t r = 0; r < n; r++) {
+        if (ti < tn && tsel[ti] == r) ti++;
+        else fsel[fn++] = r;
+    }
+    for (int64_t r = 0; r < n; r++) out_null[r] = 1;
+    /* THEN on the true rows, filled at those rows (:182-204); ELSE on the others (:212-241).
+     * A NULL input makes the value NULL: FillSwitch copies the validity bit (:603) */
+    for (int pass = 0; pass < 2 && rc == 0; pass++) {
+        const int64_t *sel = pass == 0 ? tsel : fsel;
+        int64_t cnt = pass == 0 ? tn : fn;
+        if (cnt == 0) continue;
+        rc = oracle_eval_decimal(cols, pass == 0 ? then_prog : else_prog, pass == 0 ? nthen : nelse, sel, cnt, tmp);
+        if (rc) break;
+        const orpn *prog = pass == 0 ? then_prog : else_prog;
+        int np = pass == 0 ? nthen : nelse;
+        for (int64_t i = 0; i < cnt; i++) {
+            int valid = 1;
+            for (int p = 0; p < np; p++)
+                if (prog[p].op == OX_COL && !row_valid(cols[prog[p].col].validity, sel[i])) valid = 0;
+            out[sel[i]] = tmp[i];
+            out_null[sel[i]] = (uint8_t)!valid;
+        }
+    }
+    free(tsel); free(fsel); free(tmp);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ OR of comparisons */
 
 int64_t oracle_select_or(const ocol *cols, const int32_t *ops, const oconst *ks, int32_t k,

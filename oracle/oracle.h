@@ -113,6 +113,14 @@ typedef struct {
 int oracle_eval_decimal(const ocol *cols, const orpn *prog, int32_t nprog, const int64_t *sel,
                         int64_t n, odec *out);
 
+/* CASE WHEN <col OP const> THEN <then_prog> ELSE <else_prog> END over rows 0..n
+ * (executeCase, expr_exec.go:144-246; FillSwitch/TemplatedFillLoop :559-606): the WHEN is a
+ * select; THEN is evaluated on its true rows and filled into the result at those rows, ELSE on
+ * the remaining rows. out[r] / out_null[r] per row. Returns 0 or an ODEC_* error. */
+int oracle_case_decimal(const ocol *cols, const ocol *when_col, int32_t when_op, const oconst *when_k,
+                        const orpn *then_prog, int32_t nthen, const orpn *else_prog, int32_t nelse,
+                        int64_t n, odec *out, uint8_t *out_null);
+
 /* ---- hash aggregate ---- */
 typedef enum { OA_SUM = 1, OA_AVG, OA_COUNT, OA_MIN, OA_MAX } oaggkind;
 

@@ -569,6 +569,79 @@ extern "C" int ph_sel_union(ph_ctx *ctx, const int32_t *const *sels_dev, const i
     return rc;
 }
 
+// ------------------------------------------------------------------ CASE building blocks
+
+namespace ph {
+__global__ __launch_bounds__(256) void sel_set_kernel(const int32_t *__restrict__ sel, int64_t n, uint8_t *__restrict__ flags, uint8_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) flags[sel[i]] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_kernel(const T *__restrict__ vals, const uint8_t *__restrict__ vvalid,
+                                                      const int32_t *__restrict__ sel, int64_t n, T *__restrict__ out,
+                                                      unsigned *__restrict__ ovalid) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = sel ? sel[i] : i;
+        const bool ok = bit_valid(vvalid, i);
+        if (ok) out[r] = vals[i];
+        if (ovalid && ok) atomicOr(&ovalid[r >> 5], 1u << (r & 31));
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_sel_difference(ph_ctx *ctx, const int32_t *parent_dev, int64_t n_parent, const int32_t *child_dev,
+                                 int64_t n_child, int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out) {
+    PH_REQUIRE(ctx && n_out && n_rows >= 0 && n_child >= 0 && (n_child == 0 || child_dev) && (parent_dev || n_parent == n_rows),
+               "ph_sel_difference: bad arguments");
+    *n_out = 0;
+    if (n_rows == 0 || n_parent == 0) return PH_OK;
+    PH_REQUIRE(out_sel_dev, "ph_sel_difference: out_sel_dev is NULL");
+    uint8_t *flags = nullptr;
+    PH_CHECK(ctx->pool_alloc(ph::round_up(n_rows, 16) + 16, (void **)&flags));
+    int rc = PH_OK;
+    auto grid = [&](int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8); };
+    if (hipMemsetAsync(flags, parent_dev ? 0 : 1, (size_t)n_rows, ctx->stream) != hipSuccess) rc = PH_EHIP;
+    if (rc == PH_OK && parent_dev) ph::sel_set_kernel<<<grid(n_parent), 256, 0, ctx->stream>>>(parent_dev, n_parent, flags, 1);
+    if (rc == PH_OK && n_child) ph::sel_set_kernel<<<grid(n_child), 256, 0, ctx->stream>>>(child_dev, n_child, flags, 0);
+    if (rc == PH_OK && hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    if (rc == PH_OK) {
+        ph_col c{};
+        c.type = PH_CODE8;
+        c.data = flags;
+        ph_const one{};
+        one.type = PH_I32;
+        one.i = 1;
+        rc = ph_filter_select(ctx, &c, n_rows, PH_EQ, &one, nullptr, n_rows, out_sel_dev, n_out);
+    }
+    ctx->pool_release(flags);
+    if (rc == PH_EHIP && ph_last_error()[0] == 0) ph::set_error("ph_sel_difference: HIP failure");
+    return rc;
+}
+
+extern "C" int ph_scatter(ph_ctx *ctx, const ph_col *values, const int32_t *sel_dev, int64_t n, void *out_data_dev,
+                          uint8_t *out_validity_dev) {
+    PH_REQUIRE(ctx && values && n >= 0, "ph_scatter: bad arguments");
+    if (n == 0) return PH_OK;
+    PH_REQUIRE(values->data && out_data_dev, "ph_scatter: NULL buffer");
+    PH_REQUIRE(((uintptr_t)out_validity_dev & 3) == 0, "ph_scatter: validity bitmap must be 4-byte aligned");
+    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
+    switch (values->type) {
+    case PH_I32:
+        ph::scatter_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t *)values->data, values->validity, sel_dev, n,
+                                                                   (int32_t *)out_data_dev, (unsigned *)out_validity_dev);
+        break;
+    case PH_DEC64:
+        ph::scatter_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t *)values->data, values->validity, sel_dev, n,
+                                                                   (int64_t *)out_data_dev, (unsigned *)out_validity_dev);
+        break;
+    default:
+        ph::set_error("ph_scatter: value type %d (FillSwitch fills INTEGER and DECIMAL results only, expr_exec.go:565-572)", values->type);
+        return PH_EUNSUPPORTED;
+    }
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 // ------------------------------------------------------------------ gather
 
 namespace ph {

@@ -365,6 +365,20 @@ def sel_union(ctx, sels, counts, n_rows):
     return out, n.value
 
 
+def sel_difference(ctx, parent, n_parent, child, n_child, n_rows):
+    """falseSel: rows of parent (None = identity over n_rows) not in child. Returns (sel_dev, count)."""
+    out = ctx.alloc(max(n_parent, 1) * 4)
+    n = i64()
+    check(lib().ph_sel_difference(ctx.h, parent, i64(n_parent), child, i64(n_child), i64(n_rows), out, ctypes.byref(n)))
+    return out, n.value
+
+
+def scatter(ctx, values, sel, n, out_data, out_validity=None):
+    """FillSwitch: out[sel[i]] = values[i] (values: positional ph_col / DevColumn)"""
+    c = values.col() if isinstance(values, DevColumn) else values
+    check(lib().ph_scatter(ctx.h, ctypes.byref(c), sel, i64(n), out_data, out_validity))
+
+
 def hash_cols(ctx, cols, n, dict_hashes=None):
     out = ctx.alloc(max(n, 1) * 8)
     dh = None

@@ -197,6 +197,18 @@ def eval_decimal(cols, prog, sel, n):
     return rc, out
 
 
+def case_decimal(cols, when_col, when_op, when_k, then_prog, else_prog, n):
+    """CASE WHEN when_col OP when_k THEN then_prog ELSE else_prog END -> (rc, odec array, null flags)"""
+    arr = (OCol * len(cols))(*cols)
+    tp = (ORpn * len(then_prog))(*[ORpn(*x) for x in then_prog])
+    ep = (ORpn * len(else_prog))(*[ORpn(*x) for x in else_prog])
+    out = np.zeros(n, dtype=ODEC_DTYPE)
+    nul = np.zeros(n, dtype=np.uint8)
+    rc = lib().oracle_case_decimal(arr, ctypes.byref(when_col), i32(when_op), ctypes.byref(when_k), tp, i32(len(then_prog)),
+                                   ep, i32(len(else_prog)), i64(n), ptr(out), ptr(nul))
+    return rc, out, nul
+
+
 def odec_unscaled(arr, scale):
     """numpy ODEC array -> python ints at `scale` (exact)."""
     out = []

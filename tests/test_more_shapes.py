@@ -1,4 +1,6 @@
-"""DISTINCT aggregates: the reference keeps, per DISTINCT aggregate, a table grouped
+"""More operator shapes: DISTINCT aggregates, OR / IN lists, CASE.
+
+DISTINCT aggregates: the reference keeps, per DISTINCT aggregate, a table grouped
 by (group keys + argument) and re-sinks its rows into the main table with filter {i}
 (aggregate_exec.go:74-99, 201-304; AddChunk's filter, aggregate_hash.go:155-199). The oracle
 composition below follows that; numpy's np.unique is the independent check; the device path is the
@@ -152,4 +154,56 @@ def test_device_in_list_union_matches_oracle():
     assert m == 0
     ctx.free(out)
     dsize.free(); dmode.free()
+    ctx.close()
+
+
+# ------------------------------------------------------------------ CASE
+
+@pytest.mark.gpu
+def test_device_case_when_matches_oracle():
+    """sum(case when l_shipdate < D then ext * (1 - disc) else 0.0000 end)-style CASE (Q14/Q12/Q8):
+    WHEN -> ph_filter_select, THEN/ELSE -> ph_expr_eval over the true / false rows, results filled
+    back with ph_scatter (executeCase + FillSwitch, expr_exec.go:144-246, 559-606)."""
+    from plan_amd import hip
+    ctx = hip.Ctx(0)
+    rng = np.random.default_rng(17)
+    n = 200_000
+    ext = rng.integers(90000, 10500000, n).astype(np.int64)
+    disc = rng.integers(0, 11, n).astype(np.int64)
+    ship = rng.integers(8000, 10600, n).astype(np.int32)
+    ev = rng.random(n) > 0.03           # NULL prices
+    evb = np.packbits(ev, bitorder="little")
+    D = 9500
+    d_ext = hip.DevColumn(ctx, hip.PH_DEC64, ext, 2, validity=evb)
+    d_disc = hip.DevColumn(ctx, hip.PH_DEC64, disc, 2)
+    d_ship = hip.DevColumn(ctx, hip.PH_DATE, ship)
+    ocols = [O.col(O.OT_DECIMAL, ext, 2, validity=evb), O.col(O.OT_DECIMAL, disc, 2)]
+    then_o = [(O.OX_COL, 0, 0, 0), (O.OX_CONST_INT, 0, 1, 0), (O.OX_COL, 1, 0, 0), (O.OX_SUB, 0, 0, 0), (O.OX_MUL, 0, 0, 0)]
+    else_o = [(O.OX_CONST_DEC, 0, 0, 4)]
+    rc, want, wnull = O.case_decimal(ocols, O.col(O.OT_DATE, ship), O.OP_LT, O.const(O.OT_DATE, i=D), then_o, else_o, n)
+    assert rc == 0
+    # device
+    tsel, tn = hip.filter_select(ctx, d_ship, n, hip.PH_LT, hip.const(hip.PH_DATE, i=D))
+    fsel, fn = hip.sel_difference(ctx, None, n, tsel, tn, n)
+    assert tn + fn == n and tn == int((ship < D).sum())
+    then_p = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]
+    else_p = [hip.X_CONST(0, 4)]
+    out = ctx.alloc(n * 8)
+    oval = ctx.upload(np.zeros((n + 31) // 32 * 4, np.uint8))
+    for sel, cnt, prog in ((tsel, tn, then_p), (fsel, fn, else_p)):
+        v, vv = hip.expr_eval(ctx, [d_ext, d_disc], prog, sel, cnt, want_validity=True)
+        c = hip.Col()
+        c.type, c.scale, c.data, c.validity = hip.PH_DEC64, 4, v, vv
+        hip.scatter(ctx, c, sel, cnt, out, oval)
+        ctx.free(v); ctx.free(vv)
+    got = ctx.download(out, np.int64, n)
+    gvalid = np.unpackbits(ctx.download(oval, np.uint8, (n + 31) // 32 * 4), bitorder="little")[:n].astype(bool)
+    assert np.array_equal(~gvalid, wnull.astype(bool))
+    assert np.array_equal(gvalid, ev | (ship >= D))        # NULL only where THEN read a NULL price
+    wu = np.array(O.odec_unscaled(want, 4), dtype=np.int64)
+    assert np.array_equal(got[gvalid], wu[gvalid])
+    for p in (tsel, fsel, out, oval):
+        ctx.free(p)
+    for d in (d_ext, d_disc, d_ship):
+        d.free()
     ctx.close()
