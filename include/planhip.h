@@ -259,6 +259,17 @@ int64_t ph_join_count(const ph_join *j);
 int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                         int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,
                         int64_t *n_out);
+/* Filter -> HashJoin probe in one pass: the same pairs as ph_filter_select(where) followed by
+ * ph_join_probe_inner over its selection (filterExecutor under joinExecutor's probe child,
+ * executor_filter.go:27-114 + executor_join.go:54-264), without materialising the selection: the
+ * kernel that streams the probe keys tests the comparison first. Only comparisons that lower to
+ * an integer range (INTEGER / DATE / DECIMAL-vs-integer / dictionary-code columns, not `!=`) and
+ * tables that carry a Bloom bitmap (build side <= 4 M keys); PH_EUNSUPPORTED otherwise, and the
+ * caller runs the two calls. `sel` narrows the probe rows first, as in ph_join_probe_inner. */
+int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
+                              const ph_const *where_k, const int32_t *sel, int64_t n,
+                              int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,
+                              int64_t *n_out);
 /* Semi/anti/mark: found_dev[i] = 1 when probe row sel[i] (or i) has a match */
 int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                        uint8_t *found_dev);

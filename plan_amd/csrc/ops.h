@@ -5,4 +5,16 @@
 namespace ph {
 // in-place exclusive scan of n int32 on the ctx stream; *total_dev receives the sum
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev);
+
+// A `column OP constant` comparison lowered to an integer range test, for kernels that evaluate a
+// pushed-down filter inline (the fused filter+probe). kind 0 = no predicate.
+struct RangePred {
+    int kind;  // 0 none, 1 int32, 2 int64, 3 uint8 (dictionary code), -1 never true
+    const void *data;
+    const uint8_t *validity;
+    long long lo, hi;
+};
+// false when the comparison does not lower to a range (strings, float compares, !=): the caller
+// falls back to ph_filter_select + the plain probe
+bool lower_range_pred(const ph_col *col, int32_t op, const ph_const *k, RangePred *out);
 }  // namespace ph

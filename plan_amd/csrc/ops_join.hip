@@ -116,6 +116,14 @@ __device__ __forceinline__ int probe_count(const JoinSide &B, const JoinSide &Pr
     return c;
 }
 
+__device__ __forceinline__ bool range_pred(const RangePred &W, int64_t r) {
+    if (W.kind == 0) return true;
+    if (W.kind < 0 || !bit_valid(W.validity, r)) return false;  // NULL never selects
+    long long v = W.kind == 1 ? (long long)((const int32_t *)W.data)[r]
+                  : W.kind == 2 ? ((const int64_t *)W.data)[r] : (long long)((const uint8_t *)W.data)[r];
+    return v >= W.lo && v <= W.hi;
+}
+
 constexpr int JP_ROUNDS = 8;
 constexpr int JP_CHUNK = 256 * JP_ROUNDS;
 
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr
 //   (scan of the block totals)
 //   join_emit_kernel   one wave per block slice: prefix-sums the counts and writes the pairs
 // Output order is probe order, as before.
-__global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, uint16_t *__restrict__ cand,
+__global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, RangePred where, uint16_t *__restrict__ cand,
                                                         int32_t *__restrict__ ccount) {
     // round rr covers positions base + rr*256 + thread (lane-consecutive rows: coalesced reads);
     // ordered output = round-major, so the slot of a survivor is the number of survivors in
@@ -216,16 +224,32 @@ __global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, u
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int wc[JP_ROUNDS][4];
     unsigned long long bal[JP_ROUNDS];
+    // Stage by stage over all 8 rounds, every load unconditional (rows that dropped out read row
+    // 0): the 8 loads of a stage are independent and go out back to back, so a wave pays three
+    // or four memory latencies in total instead of three or four per round — the kernel was
+    // latency bound (PMC: 77 % of wave cycles waiting), not byte bound.
+    int64_t r[JP_ROUNDS];
+    bool ok[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
         const int64_t i = base + rr * 256 + threadIdx.x;
-        bool take = false;
-        if (i < Pr.n) {
-            int64_t r = Pr.sel ? Pr.sel[i] : i;
-            unsigned long long k[JOIN_MAX_KEYS];
-            uint64_t h;
-            take = load_keys(Pr, r, k, &h) && bloom_maybe(bl, h);
-        }
+        ok[rr] = i < Pr.n;
+        const int64_t ic = ok[rr] ? i : 0;
+        r[rr] = Pr.sel ? (int64_t)Pr.sel[ic] : ic;
+    }
+    if (where.kind != 0) {
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) ok[rr] = range_pred(where, r[rr]) && ok[rr];
+    }
+    uint64_t h[JP_ROUNDS] = {};
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        unsigned long long k[JOIN_MAX_KEYS];
+        ok[rr] = load_keys(Pr, ok[rr] ? r[rr] : 0, k, &h[rr]) && ok[rr];
+    }
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const bool take = bloom_maybe(bl, h[rr]) && ok[rr];
         bal[rr] = __ballot(take);
         if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
     }
@@ -240,6 +264,101 @@ __global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, u
         before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
     }
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
+}
+
+// The common probe shape — one key column without NULLs, optional integer-range filter without
+// NULLs — compiled without any per-row type dispatch: with the switches of jkey()/range_pred()
+// in the way every load sat in its own basic block behind an s_waitcnt vmcnt(0), so the "stages"
+// of join_cand_kernel still paid one memory latency per load. Here the 8 loads of a stage are
+// straight-line code and are issued back to back.
+template <int KW, int WK, bool SEL>
+__global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restrict__ keycol, const int32_t *__restrict__ sel,
+                                                             int64_t n, Bloom bl, const void *__restrict__ wdata, long long wlo,
+                                                             long long whi, uint16_t *__restrict__ cand,
+                                                             int32_t *__restrict__ ccount) {
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int wc[JP_ROUNDS][4];
+    unsigned long long bal[JP_ROUNDS];
+    int64_t r[JP_ROUNDS];
+    bool ok[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const int64_t i = base + rr * 256 + threadIdx.x;
+        ok[rr] = i < n;
+        const int64_t ic = ok[rr] ? i : 0;
+        r[rr] = SEL ? (int64_t)sel[ic] : ic;
+    }
+    if (WK != 0) {
+        long long w[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++)
+            w[rr] = WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
+                    : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            ok[rr] = ok[rr] && w[rr] >= wlo && w[rr] <= whi;
+            if (!ok[rr]) r[rr] = 0;
+        }
+    }
+    unsigned long long k[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++)
+        k[rr] = KW == 4 ? (unsigned long long)(long long)((const int32_t *)keycol)[r[rr]]
+                : KW == 1 ? (unsigned long long)((const uint8_t *)keycol)[r[rr]] : ((const unsigned long long *)keycol)[r[rr]];
+    unsigned word[JP_ROUNDS], msk[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const uint64_t b = mix64(0x9e3779b97f4a7c15ULL ^ k[rr]) >> 24;   // load_keys' hash for one key
+        msk[rr] = bloom_mask(b);
+        word[rr] = bl.bits[(b >> 10) & bl.word_mask];
+    }
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        bal[rr] = __ballot(ok[rr] && (word[rr] & msk[rr]) == msk[rr]);
+        if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
+    }
+    __syncthreads();
+    uint16_t *dst = cand + base;
+    int before = 0;
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        int off = before;
+        for (int q = 0; q < wv; q++) off += wc[rr][q];
+        if ((bal[rr] >> lane) & 1) dst[off + __popcll(bal[rr] & ((1ull << lane) - 1ull))] = (uint16_t)(rr * 256 + threadIdx.x);
+        before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
+    }
+    if (threadIdx.x == 0) ccount[blockIdx.x] = before;
+}
+
+template <int KW, int WK>
+static void launch_cand_fast(bool has_sel, int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w,
+                             uint16_t *cand, int32_t *ccount) {
+    if (has_sel) join_cand_fast_kernel<KW, WK, true><<<nb, 256, 0, st>>>(P.key[0].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
+    else join_cand_fast_kernel<KW, WK, false><<<nb, 256, 0, st>>>(P.key[0].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
+}
+
+template <int KW>
+static void launch_cand_fast_k(int wk, bool has_sel, int nb, hipStream_t st, const JoinSide &P, const Bloom &bl,
+                               const RangePred &w, uint16_t *cand, int32_t *ccount) {
+    switch (wk) {
+    case 0: launch_cand_fast<KW, 0>(has_sel, nb, st, P, bl, w, cand, ccount); break;
+    case 1: launch_cand_fast<KW, 1>(has_sel, nb, st, P, bl, w, cand, ccount); break;
+    case 2: launch_cand_fast<KW, 2>(has_sel, nb, st, P, bl, w, cand, ccount); break;
+    default: launch_cand_fast<KW, 3>(has_sel, nb, st, P, bl, w, cand, ccount); break;
+    }
+}
+
+// true when the fast kernel took the launch
+static bool try_cand_fast(int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w, uint16_t *cand,
+                          int32_t *ccount) {
+    if (P.nkeys != 1 || P.key[0].validity || w.kind < 0 || (w.kind != 0 && w.validity)) return false;
+    const int t = P.key[0].type;
+    const int kw = (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8;
+    if (kw == 4) launch_cand_fast_k<4>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
+    else if (kw == 1) launch_cand_fast_k<1>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
+    else launch_cand_fast_k<8>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
+    return true;
 }
 
 __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
@@ -425,8 +544,29 @@ static int check_probe(ph_join *j, const ph_col *keys, const int32_t *sel, int64
     return PH_OK;
 }
 
+static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, const ph::RangePred &where,
+                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out);
+
 extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                                    int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    return probe_inner_impl(j, keys, sel, n, ph::RangePred{0, nullptr, nullptr, 0, 0}, out_probe_dev, out_build_dev, cap, n_out);
+}
+
+extern "C" int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
+                                         const ph_const *where_k, const int32_t *sel, int64_t n, int32_t *out_probe_dev,
+                                         int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    PH_REQUIRE(j && where_col && where_k, "ph_join_probe_inner_where: bad arguments");
+    ph::RangePred where{};
+    if (!j->bloom.bits || !ph::lower_range_pred(where_col, where_op, where_k, &where)) {
+        ph::set_error("ph_join_probe_inner_where: only integer-range predicates over a probe of a table with a Bloom bitmap are "
+                      "fused; run ph_filter_select and ph_join_probe_inner");
+        return PH_EUNSUPPORTED;
+    }
+    return probe_inner_impl(j, keys, sel, n, where, out_probe_dev, out_build_dev, cap, n_out);
+}
+
+static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, const ph::RangePred &where,
+                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
     ph::JoinSide P{};
     PH_CHECK(check_probe(j, keys, sel, n, &P));
     PH_REQUIRE(n_out && cap >= 0 && (cap == 0 || (out_probe_dev && out_build_dev)), "ph_join_probe_inner: bad output arguments");
@@ -446,7 +586,8 @@ extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t
         int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
         uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
-        ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, cand, ccount);
+        if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
+            ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, where, cand, ccount);
         ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, counts, nb);
         PH_HIP(hipGetLastError());
         PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));

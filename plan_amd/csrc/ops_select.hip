@@ -477,6 +477,22 @@ static bool lower_select(const ph_col *col, int32_t op, const ph_const *k, SelPa
     }
 }
 
+bool lower_range_pred(const ph_col *col, int32_t op, const ph_const *k, RangePred *out) {
+    SelParams P;
+    if (!lower_select(col, op, k, &P)) return false;
+    out->data = P.data;
+    out->validity = P.validity;
+    out->lo = P.lo;
+    out->hi = P.hi;
+    switch (P.kind) {
+    case SK_NEVER: out->kind = -1; return true;
+    case SK_RANGE_I32: out->kind = 1; return true;
+    case SK_RANGE_I64: out->kind = 2; return true;
+    case SK_RANGE_U8: out->kind = 3; return true;
+    default: return false;
+    }
+}
+
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev) {
     scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
     PH_HIP(hipGetLastError());

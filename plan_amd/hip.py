@@ -506,6 +506,22 @@ class Join:
         check(lib().ph_join_probe_inner(self.h, _cols(keys), sel, i64(n), op, ob, i64(cap), ctypes.byref(m)))
         return m.value, op, ob
 
+    def probe_inner_where(self, keys, where_col, where_op, where_k, sel, n, cap):
+        """Filter -> probe in one pass; returns None when the shape is not fused (caller runs
+        filter_select + probe_inner)"""
+        op = self.ctx.alloc(max(cap, 1) * 4)
+        ob = self.ctx.alloc(max(cap, 1) * 4)
+        m = i64()
+        w = where_col.col() if isinstance(where_col, DevColumn) else where_col
+        rc = lib().ph_join_probe_inner_where(self.h, _cols(keys), ctypes.byref(w), i32(where_op), ctypes.byref(where_k),
+                                             sel, i64(n), op, ob, i64(cap), ctypes.byref(m))
+        if rc == PH_EUNSUPPORTED:
+            self.ctx.free(op)
+            self.ctx.free(ob)
+            return None
+        check(rc)
+        return m.value, op, ob
+
     def probe_mark(self, keys, sel, n):
         f = self.ctx.alloc(max(n, 1))
         check(lib().ph_join_probe_mark(self.h, _cols(keys), sel, i64(n), f))

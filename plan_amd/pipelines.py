@@ -59,6 +59,12 @@ class Q3Pipeline:
                                           hip.vp(out.data_ptr())))
         return out[:n]
 
+    def lineitem_filter_rows(self):
+        """rows of this rank's lineitem that pass l_shipdate > date (reporting only)"""
+        s, c = hip.filter_select(self.ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=self.date))
+        self.ctx.free(s)
+        return c
+
     def run(self, limit=10, want_groups=False):
         import ctypes
         ctx, date = self.ctx, self.date
@@ -89,9 +95,17 @@ class Q3Pipeline:
 
         # ---- orders filter + probe join 1
         t0 = tic()
-        os_, on = hip.filter_select(ctx, self.o_date, self.no, hip.PH_LT, hip.const(hip.PH_DATE, i=date))
-        m1, orow, _c = j1.probe_inner([self.o_cust], os_, on, max(on, 1))
-        frees += [os_, orow, _c]
+        # Filter(o_orderdate < date) under the probe child, fused into the probe when the shape
+        # allows (one pass over o_orderdate/o_custkey, no selection vector)
+        fused = j1.probe_inner_where([self.o_cust], self.o_date, hip.PH_LT, hip.const(hip.PH_DATE, i=date),
+                                     None, self.no, self.no)
+        if fused is not None:
+            m1, orow, _c = fused
+            frees += [orow, _c]
+        else:
+            os_, on = hip.filter_select(ctx, self.o_date, self.no, hip.PH_LT, hip.const(hip.PH_DATE, i=date))
+            m1, orow, _c = j1.probe_inner([self.o_cust], os_, on, max(on, 1))
+            frees += [os_, orow, _c]
         stage("orders_filter_probe", t0)
 
         # ---- build side of join 2 (partitioned by o_orderkey when N > 1)
@@ -116,10 +130,21 @@ class Q3Pipeline:
 
         # ---- lineitem filter (+ partition/exchange) + probe join 2
         t0 = tic()
-        lsel, ln = hip.filter_select(ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=date))
-        frees.append(lsel)
-        stage("lineitem_filter", t0)
+        fused2 = None
         if N == 1:
+            p_key, p_ext, p_disc = self.l_key, self.l_ext, self.l_disc
+            fused2 = j2.probe_inner_where([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date),
+                                          None, self.nl, self.nl)
+            if fused2 is not None:
+                stage("lineitem_filter_probe", t0)
+                t["probe_rows"] = self.nl   # rows streamed by the fused filter+probe
+        if fused2 is None:
+            lsel, ln = hip.filter_select(ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=date))
+            frees.append(lsel)
+            stage("lineitem_filter", t0)
+        if fused2 is not None:
+            pass
+        elif N == 1:
             p_key, p_ext, p_disc, p_sel, p_n = self.l_key, self.l_ext, self.l_disc, lsel, ln
         else:
             import torch
@@ -141,11 +166,15 @@ class Q3Pipeline:
             p_key = _raw(hip.PH_I64, lk.data_ptr())
             p_ext, p_disc = _raw(hip.PH_DEC64, le.data_ptr(), 2), _raw(hip.PH_DEC64, ld.data_ptr(), 2)
             p_sel, p_n = None, lk.numel()
-        t0 = tic()
-        m2, prow, brow = j2.probe_inner([p_key], p_sel, p_n, max(p_n, 1))
-        frees += [prow, brow]
-        stage("lineitem_probe", t0)
-        t["probe_rows"] = p_n
+        if fused2 is not None:
+            m2, prow, brow = fused2
+            frees += [prow, brow]
+        else:
+            t0 = tic()
+            m2, prow, brow = j2.probe_inner([p_key], p_sel, p_n, max(p_n, 1))
+            frees += [prow, brow]
+            stage("lineitem_probe", t0)
+            t["probe_rows"] = p_n
 
         # ---- revenue expression + aggregate
         t0 = tic()

@@ -207,3 +207,41 @@ def test_device_case_when_matches_oracle():
     for d in (d_ext, d_disc, d_ship):
         d.free()
     ctx.close()
+
+
+# ------------------------------------------------------------------ fused Filter -> probe
+
+@pytest.mark.gpu
+def test_fused_filter_probe_equals_filter_then_probe(sf001):
+    """ph_join_probe_inner_where = ph_filter_select + ph_join_probe_inner (same pairs, same order),
+    and refuses shapes it does not fuse."""
+    from plan_amd import hip, tpchgen
+    ctx = hip.Ctx(0)
+    Od, L = sf001["orders"], sf001["lineitem"]
+    no, nl = len(Od["o_orderkey"]), len(L["l_orderkey"])
+    okey = hip.DevColumn(ctx, hip.PH_I64, Od["o_orderkey"])
+    lkey = hip.DevColumn(ctx, hip.PH_I64, L["l_orderkey"])
+    ship = hip.DevColumn(ctx, hip.PH_DATE, L["l_shipdate"])
+    disc = hip.DevColumn(ctx, hip.PH_DEC64, L["l_discount"], 2)
+    bsel = ctx.upload(np.arange(0, no, 7, dtype=np.int32))          # every 7th order is built
+    j = hip.Join(ctx, [okey], bsel, (no + 6) // 7)
+    for wcol, op, k in ((ship, hip.PH_GT, hip.const(hip.PH_DATE, i=tpchgen.days(1995, 3, 15))),
+                        (ship, hip.PH_LE, hip.const(hip.PH_DATE, i=tpchgen.days(1992, 1, 1))),     # nothing passes
+                        (disc, hip.PH_EQ, hip.const(hip.PH_DEC64, i=5, scale=2))):
+        s, c = hip.filter_select(ctx, wcol, nl, op, k)
+        m0, p0, b0 = j.probe_inner([lkey], s, c, max(c, 1))
+        got = j.probe_inner_where([lkey], wcol, op, k, None, nl, nl)
+        assert got is not None
+        m1, p1, b1 = got
+        assert m0 == m1
+        assert np.array_equal(ctx.download(p0, np.int32, m0), ctx.download(p1, np.int32, m1))
+        assert np.array_equal(ctx.download(b0, np.int32, m0), ctx.download(b1, np.int32, m1))
+        for p in (s, p0, b0, p1, b1):
+            ctx.free(p)
+    # a float comparison is not an integer range: not fused
+    assert j.probe_inner_where([lkey], disc, hip.PH_GE, hip.const(hip.PH_F32, f=0.05), None, nl, nl) is None
+    j.free()
+    ctx.free(bsel)
+    for d in (okey, lkey, ship, disc):
+        d.free()
+    ctx.close()
