@@ -364,8 +364,8 @@ static bool try_cand_fast(int nb, hipStream_t st, const JoinSide &P, const Bloom
 __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
                                                          const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
-                                                         uint16_t *__restrict__ ccnt, int32_t *__restrict__ block_counts,
-                                                         int64_t nb) {
+                                                         uint16_t *__restrict__ ccnt, int32_t *__restrict__ cmatch,
+                                                         int32_t *__restrict__ block_counts, int64_t nb) {
     const int lane = threadIdx.x & 63;
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
@@ -375,8 +375,21 @@ __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr
             const int t = t0 + lane;
             int c = 0;
             if (t < cnt) {
-                c = probe_count(B, Pr, head, mask, next, blk * JP_CHUNK + cand[blk * JP_CHUNK + t], Bloom{nullptr, 0});
+                // probe_count, also remembering the matching build row: with a unique build key
+                // (the usual N:1 join) the emit pass then writes the pair without a second walk
+                const int64_t i = blk * JP_CHUNK + cand[blk * JP_CHUNK + t];
+                const int64_t r = Pr.sel ? Pr.sel[i] : i;
+                unsigned long long k[JOIN_MAX_KEYS];
+                uint64_t h;
+                int32_t hit = -1;
+                if (load_keys(Pr, r, k, &h)) {
+                    for (int b = head[h & mask]; b >= 0; b = next[b]) {
+                        int64_t brow = B.sel ? B.sel[b] : b;
+                        if (keys_equal(B, brow, k)) { c++; hit = (int32_t)brow; }
+                    }
+                }
                 ccnt[blk * JP_CHUNK + t] = (uint16_t)(c > 65535 ? 65535 : c);
+                cmatch[blk * JP_CHUNK + t] = hit;
             }
             total += c;
         }
@@ -388,7 +401,8 @@ __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr
 __global__ __launch_bounds__(256) void join_emit_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                         uint64_t mask, const int32_t *__restrict__ next,
                                                         const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
-                                                        const uint16_t *__restrict__ ccnt, const int32_t *__restrict__ block_off,
+                                                        const uint16_t *__restrict__ ccnt, const int32_t *__restrict__ cmatch,
+                                                        const int32_t *__restrict__ block_off,
                                                         int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
                                                         int32_t *__restrict__ out_build) {
     const int lane = threadIdx.x & 63;
@@ -410,7 +424,13 @@ __global__ __launch_bounds__(256) void join_emit_kernel(JoinSide B, JoinSide Pr,
                 int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
-            if (c > 0) {
+            if (c == 1) {  // the chain pass already found the one matching build row
+                const int64_t pos = running + incl - 1;
+                if (pos < cap) {
+                    out_probe[pos] = (int32_t)(Pr.sel ? Pr.sel[i] : i);
+                    out_build[pos] = cmatch[blk * JP_CHUNK + t];
+                }
+            } else if (c > 1) {
                 int64_t pos = running + incl - c;
                 int64_t r = Pr.sel ? Pr.sel[i] : i;
                 unsigned long long k[JOIN_MAX_KEYS];
@@ -577,7 +597,8 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     const bool selective = j->bloom.bits != nullptr;  // candidate lists pay off when most probes miss
     const int64_t o_cnt8 = ph::round_up(nb * 4, 8) + 64, o_ccount = o_cnt8;
     const int64_t o_cand = ph::round_up(o_ccount + nb * 4, 8), o_ccnt = o_cand + nb * ph::JP_CHUNK * 2;
-    PH_CHECK(ctx->ensure_scratch(selective ? o_ccnt + nb * ph::JP_CHUNK * 2 : o_cnt8 + n));
+    const int64_t o_cmatch = o_ccnt + nb * ph::JP_CHUNK * 2;
+    PH_CHECK(ctx->ensure_scratch(selective ? o_cmatch + nb * ph::JP_CHUNK * 4 : o_cnt8 + n));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
     uint8_t *cnt8 = (uint8_t *)ctx->scratch + o_cnt8;
@@ -585,13 +606,14 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     if (selective) {
         int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
         uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
+        int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
         if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
             ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, where, cand, ccount);
-        ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, counts, nb);
+        ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
         PH_HIP(hipGetLastError());
         PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-        ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, counts, nb, cap,
+        ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb, cap,
                                                                  out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     } else {
