@@ -134,14 +134,27 @@ constexpr int JP_CHUNK = 256 * JP_ROUNDS;
 __global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
                                                          int32_t *__restrict__ block_counts,
-                                                         uint8_t *__restrict__ cnt8, Bloom bl) {
+                                                         uint8_t *__restrict__ cnt8, int32_t *__restrict__ match32, Bloom bl) {
     int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
     int cnt = 0;
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
         int64_t i = base + rr * 256 + threadIdx.x;
         if (i < Pr.n) {
-            int c = probe_count(B, Pr, head, mask, next, i, bl);
+            // probe_count, remembering the matching build row: a unique match (N:1 joins) is
+            // written by the second pass without walking the chain again
+            int c = 0;
+            int32_t hit = -1;
+            int64_t r = Pr.sel ? Pr.sel[i] : i;
+            unsigned long long k[JOIN_MAX_KEYS];
+            uint64_t h;
+            if (load_keys(Pr, r, k, &h) && bloom_maybe(bl, h)) {
+                for (int b = head[h & mask]; b >= 0; b = next[b]) {
+                    int64_t brow = B.sel ? B.sel[b] : b;
+                    if (keys_equal(B, brow, k)) { c++; hit = (int32_t)brow; }
+                }
+            }
             cnt8[i] = (uint8_t)(c > 255 ? 255 : c);
+            if (c) match32[i] = hit;
             cnt += c;
         }
     }
@@ -159,8 +172,9 @@ __global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr
 __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                          uint64_t mask, const int32_t *__restrict__ next,
                                                          const int32_t *__restrict__ block_off,
-                                                         const uint8_t *__restrict__ cnt8, int64_t cap,
-                                                         int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build) {
+                                                         const uint8_t *__restrict__ cnt8, const int32_t *__restrict__ match32,
+                                                         int64_t cap, int32_t *__restrict__ out_probe,
+                                                         int32_t *__restrict__ out_build) {
     int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
     __shared__ int ws[4];
     int64_t running = block_off[blockIdx.x];
@@ -179,7 +193,13 @@ __global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr
         int woff = 0;
         for (int k = 0; k < w; k++) woff += ws[k];
         int total = ws[0] + ws[1] + ws[2] + ws[3];
-        if (c > 0) {
+        if (c == 1) {
+            const int64_t pos = running + woff + incl - 1;
+            if (pos < cap) {
+                out_probe[pos] = (int32_t)(Pr.sel ? Pr.sel[i] : i);
+                out_build[pos] = match32[i];
+            }
+        } else if (c > 1) {
             int64_t pos = running + woff + incl - c;
             int64_t r = Pr.sel ? Pr.sel[i] : i;
             unsigned long long k[JOIN_MAX_KEYS];
@@ -598,7 +618,8 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     const int64_t o_cnt8 = ph::round_up(nb * 4, 8) + 64, o_ccount = o_cnt8;
     const int64_t o_cand = ph::round_up(o_ccount + nb * 4, 8), o_ccnt = o_cand + nb * ph::JP_CHUNK * 2;
     const int64_t o_cmatch = o_ccnt + nb * ph::JP_CHUNK * 2;
-    PH_CHECK(ctx->ensure_scratch(selective ? o_cmatch + nb * ph::JP_CHUNK * 4 : o_cnt8 + n));
+    const int64_t o_m32 = ph::round_up(o_cnt8 + n, 8);
+    PH_CHECK(ctx->ensure_scratch(selective ? o_cmatch + nb * ph::JP_CHUNK * 4 : o_m32 + n * 4));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
     uint8_t *cnt8 = (uint8_t *)ctx->scratch + o_cnt8;
@@ -617,10 +638,11 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
                                                                  out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     } else {
-        ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, j->bloom);
+        int32_t *match32 = (int32_t *)((char *)ctx->scratch + o_m32);
+        ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, match32, j->bloom);
         PH_HIP(hipGetLastError());
         PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-        ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, cap, out_probe_dev, out_build_dev);
+        ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, match32, cap, out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     }
     PH_CHECK(ctx->download(n_out, total, 8));
