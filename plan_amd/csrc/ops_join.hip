@@ -418,6 +418,120 @@ __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr
     }
 }
 
+// Chain walks for CU candidates per lane at once, without type dispatch: one key column without
+// NULLs on both sides, same key width (check_probe guarantees the width class). Every stage's
+// loads (keys, bucket heads, then per chain step the node's row id / key / link) are issued for
+// all CU candidates before any is used; finished candidates keep reading node 0 so the code stays
+// straight-line. Same results as the generic loop in join_chain_kernel.
+template <int KW> __device__ __forceinline__ unsigned long long load_kw(const void *col, int64_t r) {
+    return KW == 4 ? (unsigned long long)(long long)((const int32_t *)col)[r]
+           : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
+}
+
+constexpr int CU = 4;
+
+template <int KW, bool SELP, bool SELB>
+__global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__restrict__ bkey, const int32_t *__restrict__ bsel,
+                                                              const void *__restrict__ pkey, const int32_t *__restrict__ psel,
+                                                              const int32_t *__restrict__ head, uint64_t mask,
+                                                              const int32_t *__restrict__ next,
+                                                              const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
+                                                              uint16_t *__restrict__ ccnt, int32_t *__restrict__ cmatch,
+                                                              int32_t *__restrict__ block_counts, int64_t nb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        const int cnt = ccount[blk];
+        int total = 0;
+        for (int t0 = 0; t0 < cnt; t0 += 64 * CU) {
+            int t[CU], c[CU], b[CU];
+            int32_t hit[CU];
+            int64_t r[CU];
+            unsigned long long k[CU];
+            bool ok[CU];
+#pragma unroll
+            for (int u = 0; u < CU; u++) {
+                t[u] = t0 + u * 64 + lane;
+                ok[u] = t[u] < cnt;
+                c[u] = 0;
+                hit[u] = -1;
+                r[u] = blk * JP_CHUNK + cand[blk * JP_CHUNK + (ok[u] ? t[u] : 0)];
+            }
+            if (SELP) {
+#pragma unroll
+                for (int u = 0; u < CU; u++) r[u] = psel[r[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; u++) k[u] = load_kw<KW>(pkey, r[u]);
+#pragma unroll
+            for (int u = 0; u < CU; u++) {
+                const int hb = head[mix64(0x9e3779b97f4a7c15ULL ^ k[u]) & mask];
+                b[u] = ok[u] ? hb : -1;
+            }
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < CU; u++) more = more || b[u] >= 0;
+            while (more) {
+                int64_t brow[CU];
+                int nx[CU];
+                unsigned long long bk[CU];
+#pragma unroll
+                for (int u = 0; u < CU; u++) {
+                    const int bb = b[u] >= 0 ? b[u] : 0;
+                    nx[u] = next[bb];
+                    brow[u] = SELB ? (int64_t)bsel[bb] : (int64_t)bb;
+                }
+#pragma unroll
+                for (int u = 0; u < CU; u++) bk[u] = load_kw<KW>(bkey, brow[u]);
+                more = false;
+#pragma unroll
+                for (int u = 0; u < CU; u++) {
+                    if (b[u] >= 0) {
+                        if (bk[u] == k[u]) { c[u]++; hit[u] = (int32_t)brow[u]; }
+                        b[u] = nx[u];   // -1 ends the chain, -2 cannot occur on a chain (NULL keys are never linked)
+                    }
+                    more = more || b[u] >= 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CU; u++) {
+                if (ok[u]) {
+                    ccnt[blk * JP_CHUNK + t[u]] = (uint16_t)(c[u] > 65535 ? 65535 : c[u]);
+                    cmatch[blk * JP_CHUNK + t[u]] = hit[u];
+                    total += c[u];
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        if (lane == 0) block_counts[blk] = total;
+    }
+}
+
+template <int KW>
+static void launch_chain_fast(int grid, hipStream_t st, const JoinSide &B, const JoinSide &P, const int32_t *head, uint64_t mask,
+                              const int32_t *next, const uint16_t *cand, const int32_t *ccount, uint16_t *ccnt, int32_t *cmatch,
+                              int32_t *counts, int64_t nb) {
+#define PH_CHAIN_ARGS B.key[0].data, B.sel, P.key[0].data, P.sel, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb
+    if (P.sel && B.sel) join_chain_fast_kernel<KW, true, true><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
+    else if (P.sel) join_chain_fast_kernel<KW, true, false><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
+    else if (B.sel) join_chain_fast_kernel<KW, false, true><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
+    else join_chain_fast_kernel<KW, false, false><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
+#undef PH_CHAIN_ARGS
+}
+
+static bool try_chain_fast(int grid, hipStream_t st, const JoinSide &B, const JoinSide &P, const int32_t *head, uint64_t mask,
+                           const int32_t *next, const uint16_t *cand, const int32_t *ccount, uint16_t *ccnt, int32_t *cmatch,
+                           int32_t *counts, int64_t nb) {
+    if (P.nkeys != 1 || P.key[0].validity || B.key[0].validity) return false;
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+    const int kw = width(P.key[0].type);
+    if (kw != width(B.key[0].type)) return false;
+    if (kw == 4) launch_chain_fast<4>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
+    else if (kw == 1) launch_chain_fast<1>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
+    else launch_chain_fast<8>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void join_emit_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
                                                         uint64_t mask, const int32_t *__restrict__ next,
                                                         const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
@@ -631,7 +745,8 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
         if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
             ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, where, cand, ccount);
-        ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
+        if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
+            ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
         PH_HIP(hipGetLastError());
         PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
         ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb, cap,
