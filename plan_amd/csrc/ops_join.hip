@@ -286,13 +286,19 @@ __global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, R
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
 }
 
+template <int KW> __device__ __forceinline__ unsigned long long load_kw(const void *col, int64_t r) {
+    return KW == 4 ? (unsigned long long)(long long)((const int32_t *)col)[r]
+           : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
+}
+
 // The common probe shape — one key column without NULLs, optional integer-range filter without
 // NULLs — compiled without any per-row type dispatch: with the switches of jkey()/range_pred()
 // in the way every load sat in its own basic block behind an s_waitcnt vmcnt(0), so the "stages"
 // of join_cand_kernel still paid one memory latency per load. Here the 8 loads of a stage are
 // straight-line code and are issued back to back.
-template <int KW, int WK, bool SEL>
-__global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restrict__ keycol, const int32_t *__restrict__ sel,
+template <int KW, int WK, bool SEL, int NK>
+__global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restrict__ keycol, const void *__restrict__ keycol2,
+                                                             const int32_t *__restrict__ sel,
                                                              int64_t n, Bloom bl, const void *__restrict__ wdata, long long wlo,
                                                              long long whi, uint16_t *__restrict__ cand,
                                                              int32_t *__restrict__ ccount) {
@@ -321,15 +327,18 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
             if (!ok[rr]) r[rr] = 0;
         }
     }
-    unsigned long long k[JP_ROUNDS];
+    unsigned long long k[JP_ROUNDS], k2[JP_ROUNDS];
 #pragma unroll
-    for (int rr = 0; rr < JP_ROUNDS; rr++)
-        k[rr] = KW == 4 ? (unsigned long long)(long long)((const int32_t *)keycol)[r[rr]]
-                : KW == 1 ? (unsigned long long)((const uint8_t *)keycol)[r[rr]] : ((const unsigned long long *)keycol)[r[rr]];
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        k[rr] = load_kw<KW>(keycol, r[rr]);
+        k2[rr] = NK == 2 ? load_kw<KW>(keycol2, r[rr]) : 0ull;
+    }
     unsigned word[JP_ROUNDS], msk[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        const uint64_t b = mix64(0x9e3779b97f4a7c15ULL ^ k[rr]) >> 24;   // load_keys' hash for one key
+        uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[rr]);   // load_keys' hash
+        if (NK == 2) hh = mix64(hh ^ k2[rr]);
+        const uint64_t b = hh >> 24;
         msk[rr] = bloom_mask(b);
         word[rr] = bl.bits[(b >> 10) & bl.word_mask];
     }
@@ -354,8 +363,15 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
 template <int KW, int WK>
 static void launch_cand_fast(bool has_sel, int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w,
                              uint16_t *cand, int32_t *ccount) {
-    if (has_sel) join_cand_fast_kernel<KW, WK, true><<<nb, 256, 0, st>>>(P.key[0].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
-    else join_cand_fast_kernel<KW, WK, false><<<nb, 256, 0, st>>>(P.key[0].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
+#define PH_CAND_ARGS P.key[0].data, P.key[1].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount
+    if (P.nkeys == 2) {
+        if (has_sel) join_cand_fast_kernel<KW, WK, true, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
+        else join_cand_fast_kernel<KW, WK, false, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
+    } else {
+        if (has_sel) join_cand_fast_kernel<KW, WK, true, 1><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
+        else join_cand_fast_kernel<KW, WK, false, 1><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
+    }
+#undef PH_CAND_ARGS
 }
 
 template <int KW>
@@ -372,9 +388,10 @@ static void launch_cand_fast_k(int wk, bool has_sel, int nb, hipStream_t st, con
 // true when the fast kernel took the launch
 static bool try_cand_fast(int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w, uint16_t *cand,
                           int32_t *ccount) {
-    if (P.nkeys != 1 || P.key[0].validity || w.kind < 0 || (w.kind != 0 && w.validity)) return false;
-    const int t = P.key[0].type;
-    const int kw = (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8;
+    if (P.nkeys > 2 || P.key[0].validity || w.kind < 0 || (w.kind != 0 && w.validity)) return false;
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+    const int kw = width(P.key[0].type);
+    if (P.nkeys == 2 && (P.key[1].validity || width(P.key[1].type) != kw)) return false;
     if (kw == 4) launch_cand_fast_k<4>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
     else if (kw == 1) launch_cand_fast_k<1>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
     else launch_cand_fast_k<8>(w.kind, P.sel != nullptr, nb, st, P, bl, w, cand, ccount);
@@ -423,16 +440,13 @@ __global__ __launch_bounds__(256) void join_chain_kernel(JoinSide B, JoinSide Pr
 // loads (keys, bucket heads, then per chain step the node's row id / key / link) are issued for
 // all CU candidates before any is used; finished candidates keep reading node 0 so the code stays
 // straight-line. Same results as the generic loop in join_chain_kernel.
-template <int KW> __device__ __forceinline__ unsigned long long load_kw(const void *col, int64_t r) {
-    return KW == 4 ? (unsigned long long)(long long)((const int32_t *)col)[r]
-           : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
-}
-
 constexpr int CU = 4;
 
-template <int KW, bool SELP, bool SELB>
-__global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__restrict__ bkey, const int32_t *__restrict__ bsel,
-                                                              const void *__restrict__ pkey, const int32_t *__restrict__ psel,
+template <int KW, bool SELP, bool SELB, int NK>
+__global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__restrict__ bkey, const void *__restrict__ bkey2,
+                                                              const int32_t *__restrict__ bsel,
+                                                              const void *__restrict__ pkey, const void *__restrict__ pkey2,
+                                                              const int32_t *__restrict__ psel,
                                                               const int32_t *__restrict__ head, uint64_t mask,
                                                               const int32_t *__restrict__ next,
                                                               const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__rest
             int t[CU], c[CU], b[CU];
             int32_t hit[CU];
             int64_t r[CU];
-            unsigned long long k[CU];
+            unsigned long long k[CU], k2[CU];
             bool ok[CU];
 #pragma unroll
             for (int u = 0; u < CU; u++) {
@@ -462,10 +476,15 @@ __global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__rest
                 for (int u = 0; u < CU; u++) r[u] = psel[r[u]];
             }
 #pragma unroll
-            for (int u = 0; u < CU; u++) k[u] = load_kw<KW>(pkey, r[u]);
+            for (int u = 0; u < CU; u++) {
+                k[u] = load_kw<KW>(pkey, r[u]);
+                k2[u] = NK == 2 ? load_kw<KW>(pkey2, r[u]) : 0ull;
+            }
 #pragma unroll
             for (int u = 0; u < CU; u++) {
-                const int hb = head[mix64(0x9e3779b97f4a7c15ULL ^ k[u]) & mask];
+                uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[u]);
+                if (NK == 2) hh = mix64(hh ^ k2[u]);
+                const int hb = head[hh & mask];
                 b[u] = ok[u] ? hb : -1;
             }
             bool more = false;
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__rest
             while (more) {
                 int64_t brow[CU];
                 int nx[CU];
-                unsigned long long bk[CU];
+                unsigned long long bk[CU], bk2[CU];
 #pragma unroll
                 for (int u = 0; u < CU; u++) {
                     const int bb = b[u] >= 0 ? b[u] : 0;
@@ -482,12 +501,15 @@ __global__ __launch_bounds__(256) void join_chain_fast_kernel(const void *__rest
                     brow[u] = SELB ? (int64_t)bsel[bb] : (int64_t)bb;
                 }
 #pragma unroll
-                for (int u = 0; u < CU; u++) bk[u] = load_kw<KW>(bkey, brow[u]);
+                for (int u = 0; u < CU; u++) {
+                    bk[u] = load_kw<KW>(bkey, brow[u]);
+                    bk2[u] = NK == 2 ? load_kw<KW>(bkey2, brow[u]) : 0ull;
+                }
                 more = false;
 #pragma unroll
                 for (int u = 0; u < CU; u++) {
                     if (b[u] >= 0) {
-                        if (bk[u] == k[u]) { c[u]++; hit[u] = (int32_t)brow[u]; }
+                        if (bk[u] == k[u] && bk2[u] == k2[u]) { c[u]++; hit[u] = (int32_t)brow[u]; }
                         b[u] = nx[u];   // -1 ends the chain, -2 cannot occur on a chain (NULL keys are never linked)
                     }
                     more = more || b[u] >= 0;
@@ -511,21 +533,28 @@ template <int KW>
 static void launch_chain_fast(int grid, hipStream_t st, const JoinSide &B, const JoinSide &P, const int32_t *head, uint64_t mask,
                               const int32_t *next, const uint16_t *cand, const int32_t *ccount, uint16_t *ccnt, int32_t *cmatch,
                               int32_t *counts, int64_t nb) {
-#define PH_CHAIN_ARGS B.key[0].data, B.sel, P.key[0].data, P.sel, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb
-    if (P.sel && B.sel) join_chain_fast_kernel<KW, true, true><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
-    else if (P.sel) join_chain_fast_kernel<KW, true, false><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
-    else if (B.sel) join_chain_fast_kernel<KW, false, true><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
-    else join_chain_fast_kernel<KW, false, false><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);
+#define PH_CHAIN_ARGS B.key[0].data, B.key[1].data, B.sel, P.key[0].data, P.key[1].data, P.sel, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb
+#define PH_CHAIN_LAUNCH(NKV)                                                                                   \
+    do {                                                                                                       \
+        if (P.sel && B.sel) join_chain_fast_kernel<KW, true, true, NKV><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);   \
+        else if (P.sel) join_chain_fast_kernel<KW, true, false, NKV><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);      \
+        else if (B.sel) join_chain_fast_kernel<KW, false, true, NKV><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);      \
+        else join_chain_fast_kernel<KW, false, false, NKV><<<grid, 256, 0, st>>>(PH_CHAIN_ARGS);                \
+    } while (0)
+    if (P.nkeys == 2) PH_CHAIN_LAUNCH(2);
+    else PH_CHAIN_LAUNCH(1);
+#undef PH_CHAIN_LAUNCH
 #undef PH_CHAIN_ARGS
 }
 
 static bool try_chain_fast(int grid, hipStream_t st, const JoinSide &B, const JoinSide &P, const int32_t *head, uint64_t mask,
                            const int32_t *next, const uint16_t *cand, const int32_t *ccount, uint16_t *ccnt, int32_t *cmatch,
                            int32_t *counts, int64_t nb) {
-    if (P.nkeys != 1 || P.key[0].validity || B.key[0].validity) return false;
+    if (P.nkeys > 2 || P.key[0].validity || B.key[0].validity) return false;
     auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
     const int kw = width(P.key[0].type);
     if (kw != width(B.key[0].type)) return false;
+    if (P.nkeys == 2 && (P.key[1].validity || B.key[1].validity || width(P.key[1].type) != kw || width(B.key[1].type) != kw)) return false;
     if (kw == 4) launch_chain_fast<4>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
     else if (kw == 1) launch_chain_fast<1>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
     else launch_chain_fast<8>(grid, st, B, P, head, mask, next, cand, ccount, ccnt, cmatch, counts, nb);
