@@ -470,6 +470,36 @@ def test_join_composite_nulls_selections_empty(ctx):
     j.free()
 
 
+def test_join_partitioned_build_and_fast_kernels(ctx):
+    """Build sides of 128 K .. 4 M rows take the atomic-free partitioned build (rows grouped by
+    bucket range, linked in LDS) and one-/two-key probes without NULLs take the type-specialised
+    candidate / chain kernels: duplicates, a skewed key, NULL keys and selections on both sides."""
+    rng = np.random.default_rng(23)
+    nb, np_ = 400_000, 900_000
+    # unique keys, selections on both sides (fast 8-byte kernels, SELP/SELB variants)
+    b = rng.permutation(1_000_000)[:nb].astype(np.int64)
+    p = rng.integers(0, 1_200_000, np_).astype(np.int64)
+    bsel = np.sort(rng.choice(nb, 300_000, replace=False))
+    psel = np.sort(rng.choice(np_, 500_000, replace=False))
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], bsel, psel)
+    # duplicates plus one heavily repeated key (a whole partition's worth of rows in one bucket)
+    bd = rng.integers(0, 60_000, 200_000).astype(np.int32)
+    bd[:20_000] = 7
+    pd_ = rng.integers(0, 90_000, 150_000).astype(np.int32)
+    pd_[:3] = 7
+    m = join_compare(ctx, [(hip.PH_I32, O.OT_INT32, bd, None)], [(hip.PH_I32, O.OT_INT32, pd_, None)])
+    assert m > 60_000
+    # two keys: fast path without NULLs, generic kernels with NULLs on either side
+    b0 = rng.integers(0, 3000, 180_000).astype(np.int32); b1 = rng.integers(0, 200, 180_000).astype(np.int32)
+    p0 = rng.integers(0, 3200, 260_000).astype(np.int32); p1 = rng.integers(0, 220, 260_000).astype(np.int32)
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, b0, None), (hip.PH_I32, O.OT_INT32, b1, None)],
+                 [(hip.PH_I32, O.OT_INT32, p0, None), (hip.PH_I32, O.OT_INT32, p1, None)])
+    vb, _ = rnd_validity(rng, 180_000, 0.05)
+    vp, _ = rnd_validity(rng, 260_000, 0.05)
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, b0, vb), (hip.PH_I32, O.OT_INT32, b1, None)],
+                 [(hip.PH_I32, O.OT_INT32, p0, None), (hip.PH_I32, O.OT_INT32, p1, vp)])
+
+
 def test_q3_pipeline_operator_granular(ctx, sf001):
     """Q3 assembled from the operator kernels: filter -> join -> join -> expr -> group by."""
     L, Od, C = sf001["lineitem"], sf001["orders"], sf001["customer"]
