@@ -116,6 +116,9 @@ __device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsi
     uint64_t slot = h & P.mask;
     int gid = -1;
     for (int guard = 0; gid < 0; guard++) {
+        // a table that ran out of group ids (only the bulk build can get there: it starts from the
+        // caller's hint) also runs out of free slots; probing must not go round it for ever
+        if ((guard & 255) == 255 && __hip_atomic_load(P.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         int g = __hip_atomic_load(&P.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g == SLOT_EMPTY) {
             int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
@@ -580,6 +583,255 @@ __global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ i
     }
 }
 
+// ------------------------------------------------------------------ bulk build of an empty table
+// First sink into an EMPTY table that the caller expects to hold many groups (Q3: 113 k groups from
+// 298 k rows). Creating a group in the global table costs ~9 coherent memory operations, and
+// scattered device atomics run at ~20 G/s on this part, so such inputs were bound by creation.
+// Here the rows are first grouped by bits of their key hash (count -> scan -> scatter of the key
+// words, row id and argument values: plain stores), then ONE workgroup per partition aggregates
+// its rows in a private LDS hash table (all rows of a key are in one partition) and writes every
+// finished group once: group ids reserved with one counter add per workgroup, state arrays with
+// plain stores, the slot claimed with one CAS (all keys are distinct, so no key is compared).
+// Rows that find no room in LDS go through find_or_create as in the ordinary sink.
+constexpr int BK_MAX_ARGS = 4;   // argument columns carried in the partition records
+
+struct BulkParams {
+    AggSinkParams S;             // keys, args, selection, table pointers (as in the ordinary sink)
+    int nparts, nused;           // partitions; argument columns carried (S.arg_used bits, in order)
+    int used_col[BK_MAX_ARGS];   // argument column of carried value j
+    int64_t rows_per_wg;
+    int32_t *counts;             // [nparts][nwg] -> offsets after the scan
+    const int64_t *total;        // rows after the scan
+    unsigned long long *rk;      // [nkeys][n] key words by partition order
+    long long *rv;               // [nused][n] argument values
+    long long *rrow;             // [n] first-row ids
+    uint8_t *rnull, *rvalid;     // [n] key NULL mask, argument validity bits
+    int lds_entries;             // T (power of two)
+    int *overflow;               // set when the reserved ids run past gcap (host grows and reruns the build)
+};
+
+template <int NK>
+__device__ __forceinline__ void bulk_row_keys(const AggSinkParams &S, int64_t r, unsigned long long *k, unsigned *nullmask) {
+    *nullmask = 0;
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+        k[c] = 0;
+        if (bit_valid(S.key[c].validity, r)) k[c] = load_key(S.key[c], r);
+        else *nullmask |= 1u << c;
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void bulk_count_kernel(BulkParams B) {
+    extern __shared__ int hist[];
+    for (int e = threadIdx.x; e < B.nparts; e += 256) hist[e] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < B.S.n ? i0 + B.rows_per_wg : B.S.n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int64_t r = B.S.sel ? B.S.sel[i] : i;
+        unsigned long long k[AGG_MAX_KEYS];
+        unsigned nm;
+        bulk_row_keys<NK>(B.S, r, k, &nm);
+        atomicAdd(&hist[(keys_hash(k, nm, NK) >> 40) & (B.nparts - 1)], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B.nparts; e += 256) B.counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
+    extern __shared__ int cursor[];
+    for (int e = threadIdx.x; e < B.nparts; e += 256) cursor[e] = B.counts[(int64_t)e * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int64_t n = B.S.n;
+    const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < n ? i0 + B.rows_per_wg : n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int64_t r = B.S.sel ? B.S.sel[i] : i;
+        unsigned long long k[AGG_MAX_KEYS];
+        unsigned nm;
+        bulk_row_keys<NK>(B.S, r, k, &nm);
+        const int pos = atomicAdd(&cursor[(keys_hash(k, nm, NK) >> 40) & (B.nparts - 1)], 1);
+#pragma unroll
+        for (int c = 0; c < NK; c++) B.rk[(int64_t)c * n + pos] = k[c];
+        B.rnull[pos] = (uint8_t)nm;
+        B.rrow[pos] = (long long)(B.S.row_base + (B.S.sel ? r : i));
+        unsigned vbits = 0;
+        const int64_t ar = B.S.positional ? i : r;
+        for (int j = 0; j < B.nused; j++) {
+            const AggCol &c = B.S.arg[B.used_col[j]];
+            long long v = 0;
+            if (bit_valid(c.validity, ar)) {
+                vbits |= 1u << j;
+                v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+            }
+            B.rv[(int64_t)j * n + pos] = v;
+        }
+        B.rvalid[pos] = (uint8_t)vbits;
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
+    __shared__ int s_nent, s_base, s_wsum[16];
+    const AggSinkParams &S = B.S;
+    const int T = B.lds_entries, na = S.naggs;
+    const int64_t n = S.n;
+    // [first T x i64][key NK*T x u64][lo T*na x u64][hi T*na x i64][state T x i32][cnt T*na x u32]
+    long long *l_first = reinterpret_cast<long long *>(bk_lds);
+    unsigned long long *l_key = reinterpret_cast<unsigned long long *>(l_first + T);
+    unsigned long long *l_lo = l_key + (size_t)NK * T;
+    long long *l_hi = reinterpret_cast<long long *>(l_lo + (size_t)T * na);
+    int *l_state = reinterpret_cast<int *>(l_hi + (size_t)T * na);
+    unsigned *l_cnt = reinterpret_cast<unsigned *>(l_state + T);
+    for (int e = threadIdx.x; e < T; e += 1024) {
+        l_state[e] = L_EMPTY;
+        l_first[e] = INT64_MAX;
+        for (int a = 0; a < na; a++) {
+            const int kind = S.agg_kind[a];
+            l_lo[e * na + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+            l_hi[e * na + a] = 0;
+            l_cnt[e * na + a] = 0;
+        }
+    }
+    if (threadIdx.x == 0) s_nent = 0;
+    __syncthreads();
+    const int p = blockIdx.x, nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
+    const int64_t start = B.counts[(int64_t)p * nwg];
+    const int64_t end = p + 1 < B.nparts ? (int64_t)B.counts[(int64_t)(p + 1) * nwg] : *B.total;
+    for (int64_t t = start + threadIdx.x; t < end; t += 1024) {
+        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NK; c++) k[c] = B.rk[(int64_t)c * n + t];
+        const unsigned nullmask = B.rnull[t];
+        const unsigned vbits = B.rvalid[t];
+        const long long frow = B.rrow[t];
+        int ent = -1;
+        int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
+        for (int probes = 0, spins = 0; probes < 32 && spins < (1 << 16);) {
+            int st = __hip_atomic_load(&l_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (st == L_EMPTY) {
+                if (__hip_atomic_load(&s_nent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= T - T / 4) break;
+                int old = atomicCAS(&l_state[idx], L_EMPTY, L_LOCKED);
+                if (old == L_EMPTY) {
+                    atomicAdd(&s_nent, 1);
+#pragma unroll
+                    for (int c = 0; c < NK; c++) l_key[c * T + idx] = k[c];
+                    __hip_atomic_store(&l_state[idx], (int)nullmask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ent = idx;
+                    break;
+                }
+                spins++;
+            } else if (st == L_LOCKED) {
+                spins++;
+            } else {
+                bool eq = st == (int)nullmask;
+#pragma unroll
+                for (int c = 0; c < NK; c++) eq = eq && l_key[c * T + idx] == k[c];
+                if (eq) { ent = idx; break; }
+                idx = (idx + 1) & (T - 1);
+                probes++;
+            }
+        }
+        int gid = -1;
+        if (ent < 0) {  // no room in LDS: the ordinary global path for this row
+            // once the table has run out of ids this attempt is void (the host grows the table and
+            // runs the build again): stop creating
+            if (__hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                __hip_atomic_load(B.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+            gid = find_or_create(S, k, nullmask, keys_hash(k, nullmask, NK));
+            if (gid < 0) continue;
+            if (frow < __hip_atomic_load(&S.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&S.first_row[gid], frow);
+        } else if (frow < l_first[ent]) atomicMin(&l_first[ent], frow);
+        for (int a = 0; a < na; a++) {
+            if (!((S.agg_mask >> a) & 1)) continue;
+            const int kind = S.agg_kind[a];
+            bool valid = true;
+            long long v = 0;
+            if (kind != PH_A_COUNT_STAR) {
+                int j = 0;
+                for (; j < B.nused; j++) if (B.used_col[j] == S.agg_arg[a]) break;
+                valid = (vbits >> j) & 1;
+                v = B.rv[(int64_t)j * n + t];
+            }
+            if (!valid) continue;
+            if (ent >= 0) {
+                const int ls = ent * na + a;
+                atomicAdd(&l_cnt[ls], 1u);
+                if (kind == PH_A_SUM || kind == PH_A_AVG) {   // exact 128-bit in LDS: returning add + carry
+                    unsigned long long old = atomicAdd(&l_lo[ls], (unsigned long long)v);
+                    long long delta = (old + (unsigned long long)v < old ? 1 : 0) + (v < 0 ? -1 : 0);
+                    if (delta) atomicAdd((unsigned long long *)&l_hi[ls], (unsigned long long)delta);
+                } else if (kind == PH_A_MIN) atomicMin((long long *)&l_lo[ls], v);
+                else if (kind == PH_A_MAX) atomicMax((long long *)&l_lo[ls], v);
+            } else {
+                const int64_t st = (int64_t)gid * na + a;
+                atomicAdd(&S.cnt[st], 1ull);
+                if (kind == PH_A_SUM || kind == PH_A_AVG) add128(&S.sum_lo[st], &S.sum_hi[st], v);
+                else if (kind == PH_A_MIN) atomicMin((long long *)&S.sum_lo[st], v);
+                else if (kind == PH_A_MAX) atomicMax((long long *)&S.sum_lo[st], v);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- write the finished groups: rank the ready entries, reserve their ids with ONE add
+    const int per = T / 1024 > 0 ? T / 1024 : 1;
+    int mine = 0;
+    for (int q = 0; q < per; q++) {
+        const int e = threadIdx.x * per + q;
+        if (e < T && l_state[e] >= 0) mine++;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int rank = incl - mine, total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wv) rank += s_wsum[w];
+        total += s_wsum[w];
+    }
+    if (threadIdx.x == 0) {
+        s_base = total ? atomicAdd(S.ngroups, total) : 0;
+        if (total && (long long)s_base + total > S.gcap) { atomicOr(B.overflow, 1); s_base = -1; }
+    }
+    __syncthreads();
+    if (s_base < 0) return;   // the table is too small: the host grows it and runs this kernel again
+    for (int q = 0; q < per; q++) {
+        const int e = threadIdx.x * per + q;
+        if (e >= T || l_state[e] < 0) continue;
+        const int gid = s_base + rank++;
+        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+        const unsigned nullmask = (unsigned)l_state[e];
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            k[c] = l_key[c * T + e];
+            __hip_atomic_store(&S.gkeys[(int64_t)gid * NK + c], k[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (nullmask) __hip_atomic_store(&S.gnull[gid], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.first_row[gid] = l_first[e];
+        for (int a = 0; a < na; a++) {
+            const int kind = S.agg_kind[a];
+            const unsigned long long lo = l_lo[e * na + a];
+            S.cnt[(int64_t)gid * na + a] = l_cnt[e * na + a];
+            S.sum_lo[(int64_t)gid * na + a] = lo;
+            S.sum_hi[(int64_t)gid * na + a] = (kind == PH_A_SUM || kind == PH_A_AVG) ? l_hi[e * na + a] : 0;
+        }
+        // keys visible before the id (same publication rule as find_or_create); every key of this
+        // build is distinct, so the first free slot of the probe sequence is claimed without a compare
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t slot = keys_hash(k, nullmask, NK) & S.mask;
+        for (int guard = 0; guard < (1 << 24); guard++) {
+            if (atomicCAS(&S.slots[slot], SLOT_EMPTY, gid) == SLOT_EMPTY) break;
+            if ((guard & 255) == 255 && __hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            slot = (slot + 1) & S.mask;
+        }
+    }
+}
+
 // key column c of all groups -> dense column + validity bits; a thread converts 8 groups
 __global__ __launch_bounds__(256) void agg_keys_kernel(const unsigned long long *__restrict__ gkeys,
                                                        const unsigned *__restrict__ gnull, int nkeys, int c, int type,
@@ -616,6 +868,7 @@ struct ph_agg {
     int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] need-grow flag of the running sink
     int *kinds_dev = nullptr;
     int64_t rows_sunk = 0;
+    int64_t expected_groups = 0;   // ph_agg_create's hint: selects the bulk build of the first sink
 };
 
 namespace {
@@ -714,6 +967,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
         rc = PH_EHIP;
     }
     // initial capacity: the reference starts at 2*2048 entries (aggregate_exec.go:332-339)
+    a->expected_groups = expected_groups;
     if (rc == PH_OK) rc = agg_resize(a, next_pow2(std::max<int64_t>(4096, 2 * expected_groups)), 0);
     if (rc != PH_OK) { ph_agg_free(a); return rc; }
     *out = a;
@@ -728,6 +982,95 @@ extern "C" int ph_agg_group_count(ph_agg *a, int64_t *ngroups) {
     *ngroups = c[0];
     return PH_OK;
 }
+
+namespace {
+
+template <int NK>
+int bulk_launch(ph_agg *a, ph::BulkParams &B, int nwg, size_t lds, int64_t nc, int64_t *total_dev, bool build_only) {
+    hipStream_t st = a->ctx->stream;
+    if (!build_only) {
+        ph::bulk_count_kernel<NK><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+        PH_CHECK(ph::exclusive_scan_i32(a->ctx, B.counts, nc, total_dev));
+        ph::bulk_scatter_kernel<NK><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+    }
+    // up to 120 KiB of LDS per workgroup: above the default dynamic limit
+    PH_HIP(hipFuncSetAttribute((const void *)ph::bulk_build_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ph::bulk_build_kernel<NK><<<B.nparts, 1024, lds, st>>>(B);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+// First sink into an empty table with a high expected cardinality: see bulk_build_kernel.
+// Returns PH_EUNSUPPORTED when the shape is not handled (the caller runs the ordinary sink).
+int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n) {
+    ph_ctx *ctx = a->ctx;
+    ph::BulkParams B{};
+    B.S = P;
+    for (int c = 0; c < P.nargs; c++) {
+        if (!used[c]) continue;
+        if (B.nused == ph::BK_MAX_ARGS) return PH_EUNSUPPORTED;
+        B.used_col[B.nused++] = c;
+    }
+    const int nk = a->nkeys, na = a->naggs;
+    const int per_entry = 4 + 8 * nk + 8 + 20 * na;
+    int T = 256;
+    while (T * 2 * per_entry <= 120 * 1024 && T < 4096) T *= 2;
+    if (T * per_entry > 120 * 1024) return PH_EUNSUPPORTED;
+    B.lds_entries = T;
+    int64_t want_parts = (a->expected_groups + T / 4 - 1) / (T / 4);
+    int nparts = 8;
+    while (nparts < want_parts && nparts < 4096) nparts *= 2;
+    B.nparts = nparts;
+    B.rows_per_wg = std::max<int64_t>(4096, ph::round_up((n + 511) / 512, 256));
+    const int nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
+    const int64_t nc = (int64_t)nparts * nwg;
+    // capacity: when it is affordable make growth impossible (capacity > rows), else start from
+    // the hint and let the build report an overflow
+    const bool sure = n <= (4ll << 20);
+    int64_t cap = a->cap;
+    if (sure) while (cap / 2 <= n) cap *= 2;
+    else cap = std::max(cap, next_pow2(4 * a->expected_groups));
+    if (cap != a->cap) PH_CHECK(agg_resize(a, cap, 0));
+    // partition records
+    char *tmp = nullptr;
+    const int64_t o_rk = ph::round_up(nc * 4, 16), o_rv = o_rk + (int64_t)nk * n * 8, o_rrow = o_rv + (int64_t)B.nused * n * 8;
+    const int64_t o_rnull = o_rrow + n * 8, o_rvalid = o_rnull + ph::round_up(n, 16), o_total = o_rvalid + ph::round_up(n, 16);
+    PH_CHECK(ctx->pool_alloc(o_total + 16, (void **)&tmp));
+    B.counts = (int32_t *)tmp;
+    B.rk = (unsigned long long *)(tmp + o_rk);
+    B.rv = (long long *)(tmp + o_rv);
+    B.rrow = (long long *)(tmp + o_rrow);
+    B.rnull = (uint8_t *)(tmp + o_rnull);
+    B.rvalid = (uint8_t *)(tmp + o_rvalid);
+    int64_t *total_dev = (int64_t *)(tmp + o_total);
+    B.total = total_dev;
+    B.overflow = a->counters + 2;
+    const size_t lds = (size_t)T * per_entry;
+    int rc = PH_OK;
+    for (int attempt = 0; attempt < 6 && rc == PH_OK; attempt++) {
+        B.S.slots = a->slots;
+        B.S.mask = (uint64_t)a->cap - 1;
+        B.S.gkeys = a->gkeys; B.S.gnull = a->gnull; B.S.sum_lo = a->sum_lo; B.S.sum_hi = a->sum_hi;
+        B.S.cnt = a->cnt; B.S.first_row = a->first_row; B.S.gcap = a->gcap;
+        if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+        switch (nk) {
+        case 1: rc = bulk_launch<1>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
+        case 2: rc = bulk_launch<2>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
+        case 3: rc = bulk_launch<3>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
+        default: rc = bulk_launch<4>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
+        }
+        if (rc != PH_OK || sure) break;
+        int c[3] = {0, 0, 0};
+        if ((rc = ctx->download(c, a->counters, 12)) != PH_OK) break;
+        if (!c[1] && !c[2]) break;   // neither the row-by-row path nor a partition ran out of ids
+        // c[0] = ids asked for so far (every partition adds its need even when it then backs off)
+        rc = agg_resize(a, next_pow2(4 * std::max<int64_t>(c[0], a->gcap)), 0);
+    }
+    ctx->pool_release(tmp);
+    return rc;
+}
+
+}  // namespace
 
 extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
                            const int32_t *sel, int64_t n, int32_t positional, int64_t row_base) {
@@ -784,6 +1127,17 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     P.ngroups = a->counters;
     P.error_flag = a->counters + 1;
     P.need_grow = a->counters + 2;
+    P.sel = sel;
+    P.n = n;
+    P.row_base = row_base;
+    static const bool no_bulk = getenv("PH_AGG_NO_BULK") != nullptr;
+    if (!no_bulk && a->rows_sunk == 0 && a->expected_groups >= 32768 && n >= 65536) {
+        int brc = bulk_sink(a, P, used, n);
+        if (brc != PH_EUNSUPPORTED) {
+            if (brc == PH_OK) a->rows_sunk += n;
+            return brc;
+        }
+    }
     for (int c = 0; c < nargs; c++) if (used[c]) P.arg_used |= 1u << c;
     P.combine = 1;
     for (int i = 0; i < a->naggs; i++)

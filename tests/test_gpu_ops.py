@@ -377,6 +377,80 @@ def test_agg_many_groups_grows_table(ctx):
     assert r["ngroups"] == len(np.unique(k))
 
 
+def test_agg_bulk_build_of_an_empty_table(ctx):
+    """A first sink with a high expected cardinality takes the partitioned bulk build (rows grouped
+    by key hash, one workgroup aggregates a partition in LDS and writes every group once): three
+    keys with NULLs, NULL arguments, every aggregate kind, a selection; then a wrong hint (few
+    groups: all rows land in a handful of partitions and most overflow the LDS tables' ids into
+    the row-by-row path) and a second, ordinary sink into the table the bulk build produced."""
+    rng = np.random.default_rng(31)
+    n = 700_000
+    k0 = rng.integers(0, 90_000, n).astype(np.int64)
+    k1 = rng.integers(9000, 9030, n).astype(np.int32)
+    k2 = rng.integers(0, 3, n).astype(np.int32)
+    vk, _ = rnd_validity(rng, n, 0.02)
+    va, _ = rnd_validity(rng, n, 0.1)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    q = rng.integers(1, 51, n).astype(np.int32)
+    sel = np.sort(rng.choice(n, 500_000, replace=False))
+    keys = [(hip.PH_I64, O.OT_INT64, k0, 0, vk), (hip.PH_DATE, O.OT_DATE, k1, 0, None), (hip.PH_I32, O.OT_INT32, k2, 0, None)]
+    args = [(hip.PH_DEC64, O.OT_DECIMAL, v, 2, va), (hip.PH_I32, O.OT_INT32, q, 0, None)]
+    aggs = [(hip.PH_A_SUM, 0), (hip.PH_A_AVG, 1), (hip.PH_A_COUNT, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 0), (hip.PH_A_COUNT_STAR, -1)]
+    r = agg_compare(ctx, keys, args, aggs, n, sel=sel, expected=200_000)
+    assert r["ngroups"] > 300_000
+    # wrong hint: 5 groups
+    k5 = rng.integers(0, 5, n).astype(np.int64)
+    r = agg_compare(ctx, [(hip.PH_I64, O.OT_INT64, k5, 0, None)], [(hip.PH_DEC64, O.OT_DECIMAL, v, 2, None)],
+                    [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], n, expected=100_000)
+    assert r["ngroups"] == 5
+    # bulk build, then an ordinary sink that mostly revisits its groups and adds some
+    ka = rng.integers(0, 150_000, 400_000).astype(np.int64)
+    kb = rng.integers(100_000, 200_000, 100_000).astype(np.int64)
+    va_ = rng.integers(0, 1000, 400_000).astype(np.int64)
+    vb_ = rng.integers(0, 1000, 100_000).astype(np.int64)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], 100_000)
+    da, dva = hip.DevColumn(ctx, hip.PH_I64, ka), hip.DevColumn(ctx, hip.PH_I64, va_)
+    db, dvb = hip.DevColumn(ctx, hip.PH_I64, kb), hip.DevColumn(ctx, hip.PH_I64, vb_)
+    agg.sink([da], [dva], None, len(ka))
+    agg.sink([db], [dvb], None, len(kb), row_base=len(ka))
+    r = agg.finalize()
+    allk, allv = np.concatenate([ka, kb]), np.concatenate([va_, vb_])
+    uk, inv = np.unique(allk, return_inverse=True)
+    sums = np.bincount(inv, weights=allv.astype(np.float64)).astype(np.int64)
+    cnts = np.bincount(inv)
+    firsts = np.full(len(uk), len(allk)); np.minimum.at(firsts, inv, np.arange(len(allk)))
+    assert r["ngroups"] == len(uk)
+    order = np.argsort(firsts)
+    assert np.array_equal(r["keys"][:, 0], uk[order]) and np.array_equal(r["first_row"], firsts[order])
+    assert [x[0] for x in r["sum"]] == sums[order].tolist() and np.array_equal(r["count"][:, 1], cnts[order])
+    agg.free()
+    for d in (da, dva, db, dvb):
+        d.free()
+
+
+def test_agg_bulk_build_outgrows_its_hint(ctx):
+    """More than 4 M rows: the bulk build starts from the caller's hint instead of a table that
+    could hold a group per row, partitions that cannot reserve their ids back off, the host grows
+    the table and reruns the build over the same partition records."""
+    rng = np.random.default_rng(32)
+    n = 4_600_000
+    k = rng.integers(0, 1_200_000, n).astype(np.int64)
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], 40_000)   # hint 30x too low
+    dk, dv = hip.DevColumn(ctx, hip.PH_I64, k), hip.DevColumn(ctx, hip.PH_I64, v)
+    agg.sink([dk], [dv], None, n)
+    r = agg.finalize(python_ints=False)
+    uk, first, inv = np.unique(k, return_index=True, return_inverse=True)
+    order = np.argsort(first)
+    assert r["ngroups"] == len(uk)
+    assert np.array_equal(r["keys"][:, 0], uk[order]) and np.array_equal(r["first_row"], first[order])
+    sums = np.zeros(len(uk), np.int64); np.add.at(sums, inv, v)
+    assert np.array_equal(r["sum_lo"][:, 0].astype(np.int64), sums[order])
+    assert np.array_equal(r["sum_hi"][:, 0], np.where(sums[order] < 0, -1, 0))
+    assert np.array_equal(r["count"][:, 1], np.bincount(inv)[order])
+    agg.free(); dk.free(); dv.free()
+
+
 def test_agg_single_hot_group_and_empty(ctx):
     n = 300_000
     k = np.zeros(n, np.int32)
