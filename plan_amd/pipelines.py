@@ -28,6 +28,7 @@ class Q3Pipeline:
     def __init__(self, ctx, L, O, C, segment="HOUSEHOLD", date=None):
         self.ctx = ctx
         self.time_stages = True   # sync + time every stage (reporting); off in measured steps
+        self.probe_events = None  # (start, end) torch events recorded around the lineitem probe calls
         self.date = tpchgen.days(1995, 3, 29) if date is None else date
         self.seg_code = tpchgen.MKTSEGMENT_DICT.index(segment) if segment in tpchgen.MKTSEGMENT_DICT else 999
         D = hip.DevColumn
@@ -135,9 +136,13 @@ class Q3Pipeline:
         fused2 = None
         if N == 1:
             p_key, p_ext, p_disc = self.l_key, self.l_ext, self.l_disc
+            if self.probe_events:
+                self.probe_events[0].record()
             fused2 = j2.probe_inner_where([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date),
                                           None, self.nl, self.nl)
             if fused2 is not None:
+                if self.probe_events:
+                    self.probe_events[1].record()
                 stage("lineitem_filter_probe", t0)
                 t["probe_rows"] = self.nl   # rows streamed by the fused filter+probe
         if fused2 is None:
