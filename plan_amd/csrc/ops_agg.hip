@@ -499,12 +499,13 @@ __device__ __forceinline__ unsigned long long order_key(long long v, int descend
 // pass is one launch. Pass 7 also checks that every sum fits int64 (flags |= 1 otherwise).
 __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long *__restrict__ sum_lo,
                                                         const long long *__restrict__ sum_hi, int naggs, int a,
-                                                        int ng, int descending, int pass, long long k,
+                                                        const int *__restrict__ ngroups, int descending, int pass, long long k,
                                                         unsigned long long *__restrict__ state,
                                                         unsigned *__restrict__ hist, int *__restrict__ done,
                                                         int *__restrict__ flags) {
     __shared__ unsigned lh[256];
     __shared__ int s_last;
+    const int ng = *ngroups;   // read on the device: the host does not fetch the group count first
     lh[threadIdx.x] = 0;
     __syncthreads();
     const unsigned long long prefix = state[0];
@@ -549,9 +550,10 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long
 }
 
 __global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
-                                                           int ng, int descending, long long k,
+                                                           const int *__restrict__ ngroups, int descending, long long k,
                                                            const unsigned long long *__restrict__ state,
                                                            int *__restrict__ out_ids, int *__restrict__ out_count, int cap) {
+    const int ng = *ngroups;
     unsigned long long kth = state[0];
     bool all = k >= ng;
     for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
@@ -563,22 +565,31 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long l
     }
 }
 
-// pack the selected groups' records contiguously so they come back in six copies
-__global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ ids, int n, int nkeys, int naggs,
+// Records of the selected groups, contiguous, behind a 4-int header {count, sum-too-wide flag,
+// group count, table error flag}: header and the first records come back in ONE copy.
+// record = [first_row][null mask][keys nkeys][sum_lo naggs][sum_hi naggs][count naggs] (8-byte words)
+__global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ ids, const int *__restrict__ meta,
+                                                       const int *__restrict__ counters, int cap, int nkeys, int naggs,
                                                        const long long *first_row, const unsigned long long *gkeys,
                                                        const unsigned *gnull, const unsigned long long *sum_lo,
                                                        const long long *sum_hi, const unsigned long long *cnt,
-                                                       long long *o_first, unsigned long long *o_keys, unsigned *o_null,
-                                                       unsigned long long *o_lo, long long *o_hi, unsigned long long *o_cnt) {
+                                                       unsigned long long *__restrict__ out) {
+    const int n = meta[0] < cap ? meta[0] : cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int *h = reinterpret_cast<int *>(out);
+        h[0] = meta[0]; h[1] = meta[1]; h[2] = counters[0]; h[3] = counters[1];
+    }
+    const int rec = 2 + nkeys + 3 * naggs;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        int g = ids[i];
-        o_first[i] = first_row[g];
-        o_null[i] = gnull[g];
-        for (int c = 0; c < nkeys; c++) o_keys[(int64_t)i * nkeys + c] = gkeys[(int64_t)g * nkeys + c];
+        const int g = ids[i];
+        unsigned long long *o = out + 2 + (int64_t)i * rec;
+        o[0] = (unsigned long long)first_row[g];
+        o[1] = gnull[g];
+        for (int c = 0; c < nkeys; c++) o[2 + c] = gkeys[(int64_t)g * nkeys + c];
         for (int a = 0; a < naggs; a++) {
-            o_lo[(int64_t)i * naggs + a] = sum_lo[(int64_t)g * naggs + a];
-            o_hi[(int64_t)i * naggs + a] = sum_hi[(int64_t)g * naggs + a];
-            o_cnt[(int64_t)i * naggs + a] = cnt[(int64_t)g * naggs + a];
+            o[2 + nkeys + a] = sum_lo[(int64_t)g * naggs + a];
+            o[2 + nkeys + naggs + a] = (unsigned long long)sum_hi[(int64_t)g * naggs + a];
+            o[2 + nkeys + 2 * naggs + a] = cnt[(int64_t)g * naggs + a];
         }
     }
 }
@@ -869,6 +880,7 @@ struct ph_agg {
     int *kinds_dev = nullptr;
     int64_t rows_sunk = 0;
     int64_t expected_groups = 0;   // ph_agg_create's hint: selects the bulk build of the first sink
+    int kinds_host[ph::AGG_MAX_AGGS] = {};  // source of the asynchronous upload to kinds_dev
 };
 
 namespace {
@@ -955,14 +967,13 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     a->ctx = ctx;
     a->nkeys = nkeys;
     a->naggs = naggs;
-    int kinds[ph::AGG_MAX_AGGS] = {};
+    int *kinds = a->kinds_host;   // lives as long as the handle: the upload below needs no sync
     for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
     if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 16, ctx->stream) != hipSuccess ||
-        ctx->pool_alloc(sizeof kinds, (void **)&a->kinds_dev) != PH_OK ||
-        hipMemcpyAsync(a->kinds_dev, kinds, sizeof kinds, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ctx->pool_alloc(sizeof a->kinds_host, (void **)&a->kinds_dev) != PH_OK ||
+        hipMemcpyAsync(a->kinds_dev, kinds, sizeof a->kinds_host, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
         ph::set_error("ph_agg_create: device allocation failed");
         rc = PH_EHIP;
     }
@@ -1261,69 +1272,61 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     int kind = a->aggs[agg_index].kind;
     PH_REQUIRE(kind == PH_A_SUM || kind == PH_A_MIN || kind == PH_A_MAX || kind == PH_A_AVG,
                "ph_agg_topk: aggregate %d is not ordered by its sum/min/max value", agg_index);
-    int64_t ng = 0;
-    PH_CHECK(ph_agg_group_count(a, &ng));
     *n_out = 0;
-    if (ng == 0 || k == 0) return PH_OK;
+    if (k == 0 || max_groups == 0) return PH_OK;
     ph_ctx *ctx = a->ctx;
-    int cap = (int)std::min<int64_t>(max_groups, ng);
+    // The group count stays on the device: every kernel reads it there, grids are sized from the
+    // table's capacity, and the header + first records come back in one copy (one host round trip
+    // for the whole call when <= 256 groups qualify, which is the LIMIT case this is for).
+    const int cap = (int)std::min<int64_t>(max_groups, a->gcap);
+    const size_t na = (size_t)a->naggs, nk = (size_t)a->nkeys, rec = 2 + nk + 3 * na;
     int *ids = nullptr;
     unsigned long long *state = nullptr;  // [0] prefix [1] remaining k [2] ticket + pad [3] meta (count, flag), then 256 x u32 histogram
+    unsigned long long *pack = nullptr;   // header (2 words) + cap records
     PH_CHECK(ctx->pool_alloc((int64_t)std::max(cap, 1) * 4, (void **)&ids));
     PH_CHECK(ctx->pool_alloc(32 + 1024, (void **)&state));
+    PH_CHECK(ctx->pool_alloc((int64_t)(2 + (size_t)cap * rec) * 8, (void **)&pack));
     PH_HIP(hipMemsetAsync(state, 0, 32 + 1024, ctx->stream));
     int *done = (int *)(state + 2), *meta = (int *)(state + 3);
     unsigned *hist = (unsigned *)(state + 4);
-    int tg = (int)std::min<int64_t>((ng + 255) / 256, ctx->cu_count * 2);
+    const int tg = (int)std::min<int64_t>((a->gcap + 255) / 256, ctx->cu_count * 2);
     for (int pass = 7; pass >= 0; pass--)  // radix select, most significant byte first
-        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, (int)ng, descending, pass,
+        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, a->counters, descending, pass,
                                                           (long long)k, state, hist, done, meta + 1);
-    ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, (int)ng, descending, (long long)k,
+    ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, a->counters, descending, (long long)k,
                                                           state, ids, meta, cap);
-    PH_HIP(hipGetLastError());
-    int m[2] = {0, 0};
-    int rc = ctx->download(m, meta, 8);
-    ctx->pool_release(state);
+    ph::agg_pack_kernel<<<std::max(1, std::min((cap + 255) / 256, 64)), 256, 0, ctx->stream>>>(
+        ids, meta, a->counters, cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
+    int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
+    const size_t first_recs = std::min<size_t>((size_t)cap, 256);
+    std::vector<unsigned long long> host(2 + first_recs * rec);
+    if (rc == PH_OK) rc = ctx->download(host.data(), pack, (int64_t)host.size() * 8);
+    int m[4] = {0, 0, 0, 0};
+    memcpy(m, host.data(), sizeof m);
+    if (rc == PH_OK && m[3]) { ph::set_error("ph_agg: device table error flag %d", m[3]); rc = PH_EHIP; }
     if (rc == PH_OK && m[1]) { ph::set_error("ph_agg_topk: a sum does not fit int64; use ph_agg_finalize"); rc = PH_EOVERFLOW; }
     if (rc == PH_OK && m[0] > cap) { ph::set_error("ph_agg_topk: %d qualifying groups, room for %d", m[0], cap); rc = PH_ECAPACITY; }
-    if (rc != PH_OK) { ctx->pool_release(ids); return rc; }
-    size_t n = (size_t)m[0], na = (size_t)a->naggs, nk = (size_t)a->nkeys;
+    const size_t n = rc == PH_OK ? (size_t)m[0] : 0;
+    if (rc == PH_OK && n > first_recs) {  // many ties / a large k: fetch the remaining records
+        host.resize(2 + n * rec);
+        rc = ctx->download(host.data() + 2 + first_recs * rec, pack + 2 + first_recs * rec, (int64_t)((n - first_recs) * rec) * 8);
+    }
+    ctx->pool_release(state);
+    ctx->pool_release(ids);
+    ctx->pool_release(pack);
+    if (rc != PH_OK) return rc;
     struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
     std::vector<Row> rows(n);
-    if (n > 0) {
-        // one packed device buffer: [first n][null n (padded to 8)][keys n*nk][lo n*na][hi n*na][cnt n*na]
-        size_t words = n + n + n * nk + 3 * n * na;
-        unsigned long long *pack = nullptr;
-        rc = ctx->pool_alloc((int64_t)words * 8, (void **)&pack);
-        if (rc == PH_OK) {
-            long long *o_first = (long long *)pack;
-            unsigned *o_null = (unsigned *)(pack + n);
-            unsigned long long *o_keys = pack + 2 * n, *o_lo = o_keys + n * nk;
-            long long *o_hi = (long long *)(o_lo + n * na);
-            unsigned long long *o_cnt = (unsigned long long *)(o_hi + n * na);
-            ph::agg_pack_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(ids, (int)n, a->nkeys, a->naggs, a->first_row,
-                a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, o_first, o_keys, o_null, o_lo, o_hi, o_cnt);
-            std::vector<unsigned long long> host(words);
-            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
-            if (rc == PH_OK) rc = ctx->download(host.data(), pack, (int64_t)words * 8);
-            if (rc == PH_OK) {
-                const unsigned *hn = (const unsigned *)(host.data() + n);
-                const unsigned long long *hk = host.data() + 2 * n, *hl = hk + n * nk, *hh = hl + n * na, *hc = hh + n * na;
-                for (size_t i = 0; i < n; i++) {
-                    Row &r = rows[i];
-                    r.fr = (long long)host[i];
-                    r.null = hn[i];
-                    r.k.assign(hk + i * nk, hk + (i + 1) * nk);
-                    r.lo.assign(hl + i * na, hl + (i + 1) * na);
-                    r.hi.assign((const long long *)hh + i * na, (const long long *)hh + (i + 1) * na);
-                    r.cn.assign(hc + i * na, hc + (i + 1) * na);
-                }
-            }
-            ctx->pool_release(pack);
-        }
+    for (size_t i = 0; i < n; i++) {
+        const unsigned long long *o = host.data() + 2 + i * rec;
+        Row &r = rows[i];
+        r.fr = (long long)o[0];
+        r.null = (unsigned)o[1];
+        r.k.assign(o + 2, o + 2 + nk);
+        r.lo.assign(o + 2 + nk, o + 2 + nk + na);
+        r.hi.assign((const long long *)(o + 2 + nk + na), (const long long *)(o + 2 + nk + 2 * na));
+        r.cn.assign(o + 2 + nk + 2 * na, o + 2 + nk + 3 * na);
     }
-    ctx->pool_release(ids);
-    if (rc != PH_OK) return rc;
     std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.fr < y.fr; });
     for (size_t o = 0; o < n; o++) {
         const Row &r = rows[o];
