@@ -710,18 +710,28 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
     const int p = blockIdx.x, nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
     const int64_t start = B.counts[(int64_t)p * nwg];
     const int64_t end = p + 1 < B.nparts ? (int64_t)B.counts[(int64_t)(p + 1) * nwg] : *B.total;
+    // Two phases over the partition's rows. Phase 0 inserts into / accumulates in the LDS table and
+    // only FLAGS rows that found no room (table closed or probe window exhausted). Phase 1 runs
+    // with the table frozen: a flagged row looks its key up again and accumulates in LDS when the
+    // key got in after all, else takes the global path. Deciding "not in LDS" while other lanes
+    // may still be inserting that very key would create the group twice (once by find_or_create,
+    // once by the write-out below, which claims slots without comparing keys).
+    for (int phase = 0; phase < 2; phase++) {
     for (int64_t t = start + threadIdx.x; t < end; t += 1024) {
+        const unsigned vraw = B.rvalid[t];
+        if (phase == 1 && !(vraw & 0x80u)) continue;
         unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < NK; c++) k[c] = B.rk[(int64_t)c * n + t];
         const unsigned nullmask = B.rnull[t];
-        const unsigned vbits = B.rvalid[t];
+        const unsigned vbits = vraw & 0x7Fu;
         const long long frow = B.rrow[t];
         int ent = -1;
         int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
         for (int probes = 0, spins = 0; probes < 32 && spins < (1 << 16);) {
             int st = __hip_atomic_load(&l_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (st == L_EMPTY) {
+                if (phase == 1) break;   // frozen table: an empty slot ends the probe sequence, the key is not here
                 if (__hip_atomic_load(&s_nent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= T - T / 4) break;
                 int old = atomicCAS(&l_state[idx], L_EMPTY, L_LOCKED);
                 if (old == L_EMPTY) {
@@ -745,15 +755,21 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             }
         }
         int gid = -1;
-        if (ent < 0) {  // no room in LDS: the ordinary global path for this row
-            // once the table has run out of ids this attempt is void (the host grows the table and
-            // runs the build again): stop creating
+        if (ent < 0) {
+            if (phase == 0) { B.rvalid[t] = (uint8_t)(vraw | 0x80u); continue; }   // decided in phase 1
+            // no room in LDS: the ordinary global path for this row. Once the table has run out of
+            // ids this attempt is void (the host grows the table and runs the build again).
             if (__hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
                 __hip_atomic_load(B.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
             gid = find_or_create(S, k, nullmask, keys_hash(k, nullmask, NK));
             if (gid < 0) continue;
             if (frow < __hip_atomic_load(&S.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&S.first_row[gid], frow);
-        } else if (frow < l_first[ent]) atomicMin(&l_first[ent], frow);
+        } else {
+            if (frow < l_first[ent]) atomicMin(&l_first[ent], frow);
+            // a flag left by an earlier, voided attempt over the same records must not send the row
+            // through phase 1 a second time
+            if (phase == 0 && (vraw & 0x80u)) B.rvalid[t] = (uint8_t)vbits;
+        }
         for (int a = 0; a < na; a++) {
             if (!((S.agg_mask >> a) & 1)) continue;
             const int kind = S.agg_kind[a];
@@ -784,7 +800,8 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             }
         }
     }
-    __syncthreads();
+    __syncthreads();   // phase 0 done: the table takes no more keys
+    }
     // ---- write the finished groups: rank the ready entries, reserve their ids with ONE add
     const int per = T / 1024 > 0 ? T / 1024 : 1;
     int mine = 0;

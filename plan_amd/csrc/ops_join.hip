@@ -699,6 +699,19 @@ __global__ __launch_bounds__(256) void join_mark_kernel(JoinSide B, JoinSide Pr,
         found[i] = probe_count(B, Pr, head, mask, next, i, bl) > 0 ? 1 : 0;
 }
 
+// MARK / SEMI / ANTI over a selective probe: the candidates' match counts decide the flags
+__global__ __launch_bounds__(256) void join_mark_set_kernel(const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
+                                                            const uint16_t *__restrict__ ccnt, uint8_t *__restrict__ found,
+                                                            int64_t nb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        const int cnt = ccount[blk];
+        for (int t = lane; t < cnt; t += 64)
+            if (ccnt[blk * JP_CHUNK + t]) found[blk * JP_CHUNK + cand[blk * JP_CHUNK + t]] = 1;
+    }
+}
+
 }  // namespace ph
 
 struct ph_join {
@@ -921,8 +934,30 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
     if (n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
     if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    const uint64_t mask = (uint64_t)j->cap - 1;
+    if (j->bloom.bits) {
+        // selective probe: same candidate slices + chain pass as ph_join_probe_inner (a lane that
+        // walks a chain no longer holds up 63 idle ones); the flags follow from the match counts
+        const int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
+        const int64_t o_ccount = ph::round_up(nb * 4, 8) + 64, o_cand = ph::round_up(o_ccount + nb * 4, 8);
+        const int64_t o_ccnt = o_cand + nb * ph::JP_CHUNK * 2, o_cmatch = o_ccnt + nb * ph::JP_CHUNK * 2;
+        PH_CHECK(ctx->ensure_scratch(o_cmatch + nb * ph::JP_CHUNK * 4));
+        int32_t *counts = (int32_t *)ctx->scratch, *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
+        uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
+        int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
+        const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
+        const ph::RangePred none{0, nullptr, nullptr, 0, 0};
+        PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream));
+        if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, none, cand, ccount))
+            ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, none, cand, ccount);
+        if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
+            ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
+        ph::join_mark_set_kernel<<<wave_grid, 256, 0, ctx->stream>>>(cand, ccount, ccnt, found_dev, nb);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
     int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
-    ph::join_mark_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, P, j->head, (uint64_t)j->cap - 1, j->next, found_dev, j->bloom);
+    ph::join_mark_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, found_dev, j->bloom);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }
