@@ -27,4 +27,19 @@ int main(void){
   int32_t *ssk=malloc(ns*4),*sn=malloc(ns*4); tpchgen_supplier_cols sx={ssk,sn}; tpchgen_supplier(num,den,0,ns,&sx);
   oracle_part P={ppk,off,bytes,np}; oracle_partsupp PS={psp,pss,psc,np*4}; oracle_supplier S={ssk,sn,ns};
   oracle_q9_row q9[512]; int64_t n9=oracle_q9(&L,&O,&P,&PS,&S,"%pink%",q9,512); char big[65536]; oracle_q9_text(q9,n9,TPCHGEN_NATION_NAMES,big,sizeof big); printf("%lld q9 groups\n",(long long)n9);
+  /* the shapes added after the four queries: OR / IN lists, CASE, filtered (DISTINCT) sinks */
+  { ocol sc; memset(&sc,0,sizeof sc); sc.type=OT_INT32; sc.data=qty;
+    oconst k1; memset(&k1,0,sizeof k1); k1.type=OT_INT32; k1.i=7; oconst k2=k1; k2.i=49; oconst ks[2]={k1,k2};
+    ocol cols2[2]={sc,sc}; int32_t ops[2]={OP_EQ,OP_EQ}; int64_t *selo=malloc(n*8);
+    int64_t m=oracle_select_or(cols2,ops,ks,2,NULL,n,selo); printf("%lld rows IN (7,49)\n",(long long)m); free(selo);
+    ocol dc[2]; memset(dc,0,sizeof dc); dc[0].type=OT_DECIMAL; dc[0].scale=2; dc[0].data=ext; dc[1].type=OT_DECIMAL; dc[1].scale=2; dc[1].data=disc;
+    ocol wc; memset(&wc,0,sizeof wc); wc.type=OT_DATE; wc.data=ship; oconst wk; memset(&wk,0,sizeof wk); wk.type=OT_DATE; wk.i=tpchgen_days_from_civil(1995,6,17);
+    orpn tp[5]; memset(tp,0,sizeof tp); tp[0].op=OX_COL; tp[0].col=0; tp[1].op=OX_CONST_INT; tp[1].ival=1; tp[2].op=OX_COL; tp[2].col=1; tp[3].op=OX_SUB; tp[4].op=OX_MUL;
+    orpn ep[1]; memset(ep,0,sizeof ep); ep[0].op=OX_CONST_DEC; ep[0].ival=0; ep[0].scale=4;
+    odec *co=malloc(sizeof(odec)*n); uint8_t *cn=malloc(n);
+    int rcx=oracle_case_decimal(dc,&wc,OP_LT,&wk,tp,5,ep,1,n,co,cn); printf("case rc %d\n",rcx); free(co); free(cn);
+    ocol kp; memset(&kp,0,sizeof kp); kp.type=OT_INT32; ocol ap; memset(&ap,0,sizeof ap); ap.type=OT_INT32;
+    oaggspec sp[2]={{OA_COUNT,0},{OA_SUM,0}}; oagg *t=oracle_agg_create(&kp,1,&ap,sp,2);
+    for(int64_t b=0;b<n && b<20480;b+=2048){ int64_t cnt=n-b<2048?n-b:2048; ocol kc=kp; kc.data=pk+b; ocol ac=ap; ac.data=qty+b; oracle_agg_sink_filtered(t,&kc,&ac,NULL,cnt,b?1u:2u); }
+    printf("%lld filtered groups\n",(long long)oracle_agg_count(t)); oracle_agg_free(t); }
   return 0; }
