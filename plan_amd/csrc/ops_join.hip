@@ -205,101 +205,6 @@ __device__ __forceinline__ bool range_pred(const RangePred &W, int64_t r) {
 constexpr int JP_ROUNDS = 8;
 constexpr int JP_CHUNK = 256 * JP_ROUNDS;
 
-// Count pass. Besides the workgroup totals it leaves each probe row's match count (saturated at
-// 255) in cnt8, so the write pass walks chains only for rows that matched — on selective joins
-// (Q3: 1 % of the probes match) that makes the second pass almost free instead of a second full
-// round of random bucket reads.
-__global__ __launch_bounds__(256) void join_count_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
-                                                         uint64_t mask, const int32_t *__restrict__ next,
-                                                         int32_t *__restrict__ block_counts,
-                                                         uint8_t *__restrict__ cnt8, int32_t *__restrict__ match32, Bloom bl) {
-    int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
-    int cnt = 0;
-    for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        int64_t i = base + rr * 256 + threadIdx.x;
-        if (i < Pr.n) {
-            // probe_count, remembering the matching build row: a unique match (N:1 joins) is
-            // written by the second pass without walking the chain again
-            int c = 0;
-            int32_t hit = -1;
-            int64_t r = Pr.sel ? Pr.sel[i] : i;
-            unsigned long long k[JOIN_MAX_KEYS];
-            uint64_t h;
-            if (load_keys(Pr, r, k, &h) && bloom_maybe(bl, h)) {
-                for (int b = head[h & mask]; b >= 0; b = next[b]) {
-                    int64_t brow = B.sel ? B.sel[b] : b;
-                    if (keys_equal(B, brow, k)) { c++; hit = (int32_t)brow; }
-                }
-            }
-            cnt8[i] = (uint8_t)(c > 255 ? 255 : c);
-            if (c) match32[i] = hit;
-            cnt += c;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    __shared__ int ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// Write pass of the two-pass probe (probes without a Bloom bitmap, i.e. large build sides where
-// most rows match): rounds of lane-consecutive rows like the count pass, a workgroup scan per
-// round. (A variant where a thread owned 8 consecutive rows and the workgroup scanned once was
-// 4x slower on dense matches: eight chain walks back to back per thread, uncoalesced key reads.)
-__global__ __launch_bounds__(256) void join_write_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head,
-                                                         uint64_t mask, const int32_t *__restrict__ next,
-                                                         const int32_t *__restrict__ block_off,
-                                                         const uint8_t *__restrict__ cnt8, const int32_t *__restrict__ match32,
-                                                         int64_t cap, int32_t *__restrict__ out_probe,
-                                                         int32_t *__restrict__ out_build) {
-    int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
-    __shared__ int ws[4];
-    int64_t running = block_off[blockIdx.x];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        int64_t i = base + rr * 256 + threadIdx.x;
-        int c = i < Pr.n ? cnt8[i] : 0;
-        if (c == 255) c = probe_count(B, Pr, head, mask, next, i, Bloom{});  // saturated: recount
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            int y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) ws[w] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < w; k++) woff += ws[k];
-        int total = ws[0] + ws[1] + ws[2] + ws[3];
-        if (c == 1) {
-            const int64_t pos = running + woff + incl - 1;
-            if (pos < cap) {
-                out_probe[pos] = (int32_t)(Pr.sel ? Pr.sel[i] : i);
-                out_build[pos] = match32[i];
-            }
-        } else if (c > 1) {
-            int64_t pos = running + woff + incl - c;
-            int64_t r = Pr.sel ? Pr.sel[i] : i;
-            unsigned long long k[JOIN_MAX_KEYS];
-            uint64_t h;
-            load_keys(Pr, r, k, &h);
-            for (int b = head[h & mask]; b >= 0; b = next[b]) {
-                int64_t brow = B.sel ? B.sel[b] : b;
-                if (keys_equal(B, brow, k)) {
-                    if (pos < cap) {
-                        out_probe[pos] = (int32_t)r;
-                        out_build[pos] = (int32_t)brow;
-                    }
-                    pos++;
-                }
-            }
-        }
-        running += total;
-        __syncthreads();
-    }
-}
-
-
 // ---- selective probes (a Bloom bitmap exists). In the two-pass kernels above a lane that has to
 // walk a chain (three or four dependent random reads) holds up its wave while the other lanes
 // idle, and both passes pay for it. Here the work is split by density, with no same-address
@@ -699,6 +604,14 @@ __global__ __launch_bounds__(256) void join_mark_kernel(JoinSide B, JoinSide Pr,
         found[i] = probe_count(B, Pr, head, mask, next, i, bl) > 0 ? 1 : 0;
 }
 
+// Dense probes (no bitmap): every position is a candidate. Filling the slices with the identity lets
+// them share the chain / emit kernels (and their straight-line fast forms) with selective probes.
+__global__ __launch_bounds__(256) void join_cand_all_kernel(int64_t n, uint16_t *__restrict__ cand, int32_t *__restrict__ ccount) {
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    for (int t = threadIdx.x; t < JP_CHUNK; t += 256) cand[base + t] = (uint16_t)t;
+    if (threadIdx.x == 0) ccount[blockIdx.x] = (int32_t)(n - base < JP_CHUNK ? n - base : JP_CHUNK);
+}
+
 // MARK / SEMI / ANTI over a selective probe: the candidates' match counts decide the flags
 __global__ __launch_bounds__(256) void join_mark_set_kernel(const uint16_t *__restrict__ cand, const int32_t *__restrict__ ccount,
                                                             const uint16_t *__restrict__ ccnt, uint8_t *__restrict__ found,
@@ -891,21 +804,20 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     ph_ctx *ctx = j->ctx;
     int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
     const bool selective = j->bloom.bits != nullptr;  // candidate lists pay off when most probes miss
-    const int64_t o_cnt8 = ph::round_up(nb * 4, 8) + 64, o_ccount = o_cnt8;
+    const int64_t o_ccount = ph::round_up(nb * 4, 8) + 64;
     const int64_t o_cand = ph::round_up(o_ccount + nb * 4, 8), o_ccnt = o_cand + nb * ph::JP_CHUNK * 2;
     const int64_t o_cmatch = o_ccnt + nb * ph::JP_CHUNK * 2;
-    const int64_t o_m32 = ph::round_up(o_cnt8 + n, 8);
-    PH_CHECK(ctx->ensure_scratch(selective ? o_cmatch + nb * ph::JP_CHUNK * 4 : o_m32 + n * 4));
+    PH_CHECK(ctx->ensure_scratch(o_cmatch + nb * ph::JP_CHUNK * 4));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
-    uint8_t *cnt8 = (uint8_t *)ctx->scratch + o_cnt8;
     uint64_t mask = (uint64_t)j->cap - 1;
-    if (selective) {
+    {
         int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
         uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
         int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
-        if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
+        if (!selective) ph::join_cand_all_kernel<<<(int)nb, 256, 0, ctx->stream>>>(n, cand, ccount);
+        else if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
             ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, where, cand, ccount);
         if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
             ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
@@ -913,13 +825,6 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
         PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
         ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb, cap,
                                                                  out_probe_dev, out_build_dev);
-        PH_HIP(hipGetLastError());
-    } else {
-        int32_t *match32 = (int32_t *)((char *)ctx->scratch + o_m32);
-        ph::join_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, match32, j->bloom);
-        PH_HIP(hipGetLastError());
-        PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-        ph::join_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, counts, cnt8, match32, cap, out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     }
     PH_CHECK(ctx->download(n_out, total, 8));

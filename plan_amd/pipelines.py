@@ -344,7 +344,11 @@ class Q9Pipeline:
         t0 = tic()
         if N == 1:
             j.free()
-            jps = None   # built on the (smaller) intermediate below, probed with partsupp
+            # partsupp (8 M rows) is the build side although the intermediate is smaller: probing
+            # WITH the intermediate keeps it in lineitem order, and every later gather by its row
+            # ids then walks the base columns forwards (measured: 3.13 ms vs 3.42 ms per query with
+            # the sides swapped, the difference all in the later stages' gathers)
+            jps = hip.Join(ctx, [self.ps_part, self.ps_supp], None, self.n["ps"])
             ps_cost = self.ps_cost
         else:
             import torch
@@ -360,16 +364,8 @@ class Q9Pipeline:
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp.data_ptr()), _raw(hip.PH_I32, bs.data_ptr())], None, bp.numel())
             ps_cost = _raw(hip.PH_DEC64, bc.data_ptr(), 2)
         k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
-        if jps is None:
-            # build side = the ~5 % of lineitem that survived the part join, probe side = partsupp:
-            # the table is smaller than one over all of partsupp, and the probe is selective, so
-            # the Bloom bitmap rejects the ~95 % of partsupp rows that belong to other parts
-            jint = hip.Join(ctx, [_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1)
-            n2, psrow, pos2 = jint.probe_inner([self.ps_part, self.ps_supp], None, self.n["ps"], max(n1, 1))
-            jint.free()
-        else:
-            n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
-            jps.free()
+        n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+        jps.free()
         frees += [pos2, psrow]
         lrow2 = gat(_raw(hip.PH_I32, lrow), pos2, n2)
         stage("partsupp_join", t0)
@@ -401,7 +397,8 @@ class Q9Pipeline:
         c_qty, c_cost = gat(self.l_qty, lrow3, n3), gat(ps_cost, psrow3, n3)
         c_nat = gat(s_nat, srow, n3)
         if N == 1:
-            jo = None    # built on the intermediate (n3 rows), probed with the 5x larger orders
+            jo = None    # built on the intermediate (n3 rows), probed with the 5x larger orders: the
+            # last join, so the order of its output costs only the final gathers (3.13 vs 3.47 ms)
             o_date = self.o_date.col()
             m = n3
         else:
