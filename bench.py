@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--sf", type=int, default=10, help="scale factor of each rank's lineitem shard")
     ap.add_argument("--query", default="q1", choices=["q1", "q6", "q3", "q9"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-q3", action="store_true", help="skip the Q3 companion measurement of the default (q1, N=1) run")
     ap.add_argument("--cpu-rows", type=int, default=16_000_000)
     args = ap.parse_args()
 
@@ -269,18 +270,31 @@ def main():
                       f"(chunked 2048-row CPU restatement of the reference path), {dt:.1f} s, "
                       f"host has {os.cpu_count()} logical CPUs",
         }
-    if rank == 0:
-        print(json.dumps(out))
-
     for pl in plans:
         pl.free()
     table.free()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    # ---- the metric's second half (hash-join probe, Q3) on the same GPU, N = 1 only: extra fields of
+    # the same line, measured after (outside) the Q1 timing; a failure here never costs the Q1 line
+    if rank == 0 and world == 1 and args.query == "q1" and not args.no_q3:
+        try:
+            del L
+            a3 = argparse.Namespace(**vars(args))
+            a3.query, a3.steps, a3.warmup = "q3", min(args.steps, 30), min(args.warmup, 3)
+            q3 = bench_q3(a3, 0, local_rank, 1, emit=False)
+            out["q3_single_gpu"] = {"metric": q3["metric"], "value": q3["value"], "unit": q3["unit"],
+                                    "ms_per_step": q3["ms_per_step"], "steps": q3["steps"],
+                                    "probe_rows_per_s": q3["config"]["probe_rows_per_s"],
+                                    "stage_ms": q3["config"]["stage_ms"], "roofline": q3["roofline"]}
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the Q1 line
+            out["q3_single_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
 
 
-def bench_q3(args, rank, local_rank, world):
+def bench_q3(args, rank, local_rank, world, emit=True):
     """Q3: customer |x| orders |x| lineitem hash joins + 3-column group-by, assembled from the
     operator-granular kernels; for N > 1 the join sides are hash-partitioned by order key and
     exchanged with RCCL all-to-all (plan_amd/pipelines.py). A step = one whole Q3."""
@@ -381,11 +395,15 @@ def bench_q3(args, rank, local_rank, world):
                          "avg_launch_ms": probe_ms, "timing": "HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
                          "host_timed_stage_ms": host_probe_ms},
         }
-        print(json.dumps(out))
+        if emit:
+            print(json.dumps(out))
+    else:
+        out = None
     pipe.free()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return out
 
 
 def bench_q9(args, rank, local_rank, world):

@@ -3,6 +3,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 q=$1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$q -o p -- python3 $R/bench.py --query $q --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$q.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$q -o p -- python3 $R/bench.py --query $q --steps 20 --warmup 3 --no-cpu-baseline --no-q3 > $R/gpurun_out/prof_$q.log 2>&1 < /dev/null
 f=$(find $R/gpurun_out/prof_$q -name '*kernel_stats.csv' | head -1)
 if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${q}_kernel_stats.csv; cut -d, -f1-4 "$f" | head -24; else tail -5 $R/gpurun_out/prof_$q.log; fi
