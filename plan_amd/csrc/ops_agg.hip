@@ -1049,7 +1049,7 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     int nparts = 8;
     while (nparts < want_parts && nparts < 4096) nparts *= 2;
     B.nparts = nparts;
-    B.rows_per_wg = std::max<int64_t>(4096, ph::round_up((n + 511) / 512, 256));
+    B.rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
     const int nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
     const int64_t nc = (int64_t)nparts * nwg;
     // capacity: when it is affordable make growth impossible (capacity > rows), else start from

@@ -711,7 +711,7 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     int *count = j->count_dev;
     if (hipMemsetAsync(count, 0, 16, ctx->stream) != hipSuccess) return fail("memset");
     if (partitioned) {
-        const int64_t rows_per_wg = std::max<int64_t>(4096, ph::round_up((n + 511) / 512, 256));
+        const int64_t rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
         const int nwg = (int)((n + rows_per_wg - 1) / rows_per_wg);
         int32_t *counts = nullptr, *part_i = nullptr;
         unsigned long long *part_h = nullptr;
