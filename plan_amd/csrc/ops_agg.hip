@@ -62,7 +62,6 @@ struct AggSinkParams {
     int *progress;      // per workgroup: chunk iterations already done (resume point after a growth)
     long long slack;    // groups all workgroups together may still create = gridDim.x * (chunk + lds_slots / 2)
     int chunk;          // rows a workgroup takes between two growth checks (256 .. AGG_CHUNK)
-    int combine;        // wave-level combining allowed (no MIN/MAX aggregate)
     unsigned arg_used;  // bit c: argument column c is read by some aggregate
     unsigned agg_mask;  // bit a: aggregate a is updated by this call (AddChunk's filter)
 };
@@ -83,18 +82,6 @@ __device__ __forceinline__ uint64_t keys_hash(const unsigned long long *k, unsig
     uint64_t h = mix64((uint64_t)nullmask + 0x9e3779b97f4a7c15ULL);
     for (int c = 0; c < nkeys; c++) h = mix64(h ^ k[c]);
     return h;
-}
-
-// sum of x over the 64 lanes of a wave, same value returned to every lane: four DPP adds make
-// every lane of a 16-lane row hold its row's total (xor 1, xor 2 inside quads, then half-row and
-// row mirrors), four readlanes add the rows. Needs the whole wave active.
-__device__ __forceinline__ int wave_sum32(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);  // row_mirror
-    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) +
-           __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 
 __device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, long long v) {
@@ -221,7 +208,6 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
         }
     }
     if (threadIdx.x == 0) s_nent = 0;
-    const int lane = threadIdx.x & 63;
     int it = P.progress[blockIdx.x];
     for (;; it++) {
     const int64_t c0 = ((int64_t)it * gridDim.x + blockIdx.x) * P.chunk;
@@ -235,8 +221,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
     __syncthreads();
     if (!s_go) break;
     const int64_t c1 = c0 + P.chunk < P.n ? c0 + P.chunk : P.n;
-    // every lane stays in this loop (dead lanes carry ent -1): the wave-level combining below
-    // needs the whole wave converged. AGG_U rows per thread are in flight: all their column
+    // AGG_U rows per thread are in flight: all their column
     // reads (selection, keys, the first AGG_PRE argument columns) are issued before the first
     // row is processed, so one HBM latency is paid per AGG_U rows instead of two per row.
     for (int64_t ib = c0; ib < c1; ib += 256 * AGG_U) {
@@ -315,28 +300,11 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
             }
             if (ent < 0) gid = find_or_create(P, k, nullmask, keys_hash(k, nullmask, nk));
         }
-        // ---- wave-level combining. When few groups are hot (Q1-like inputs: 4), 64 lanes hit a
-        // handful of LDS words and the ds atomics serialise lane by lane. Groups that hold >= 8
-        // lanes of this wave are summed across the wave first (DPP adds, no LDS) and only their
-        // lowest lane — the leader, which also carries the smallest row id — touches the
-        // accumulators. Everything else (high-cardinality inputs, MIN/MAX) goes lane by lane.
-        unsigned long long comb = 0;
-        bool leader = false;
-        if (P.combine) {
-            unsigned long long t = __ballot(ent >= 0);
-            for (int round = 0; t != 0 && round < 8; round++) {
-                int lead = __ffsll((long long)t) - 1;
-                int g = __builtin_amdgcn_readlane(ent, lead);
-                unsigned long long m = __ballot(ent == g);
-                if (__popcll(m) < 8) break;
-                comb |= m;
-                t &= ~m;
-                if (lane == lead) leader = true;
-            }
-        }
-        const bool in_comb = (comb >> lane) & 1;
+        // (Summing a hot group's lanes across the wave with DPP adds before touching LDS was tried:
+        // with the table in LDS the same-address ds atomics of 4 hot groups cost 0.40 ms per 32 M
+        // rows, the combining code 0.62 ms. Rows update their LDS entry lane by lane.)
         const bool staged = ent >= 0;
-        if ((staged && (!in_comb || leader)) || gid >= 0) {
+        if (staged || gid >= 0) {
             long long frow = (long long)(P.row_base + (P.sel ? r : i));  // row id (ascending with i)
             // first-seen row: almost every row is later than the recorded one, so test with a load
             // and only issue the atomic when it would lower the minimum
@@ -380,8 +348,7 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
                     atomicAdd(&P.cnt[(int64_t)gid * na + a], 1ull);
                     add128(&P.sum_lo[(int64_t)gid * na + a], &P.sum_hi[(int64_t)gid * na + a], v);
                 }
-            } else if (valid && !in_comb) {
-                // lane-by-lane update
+            } else if (valid) {
                 if (kind == PH_A_COUNT_STAR || kind == PH_A_COUNT) {
                     if (staged) atomicAdd(&l_cnt[ls], 1u);
                     else atomicAdd(&P.cnt[st], 1ull);
@@ -399,32 +366,6 @@ __global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
                 } else if (kind == PH_A_MAX) {
                     if (staged) { atomicMax((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
                     else { atomicAdd(&P.cnt[st], 1ull); atomicMax((long long *)&P.sum_lo[st], v); }
-                }
-            }
-            if (comb != 0) {  // wave-uniform; combined lanes all have an LDS entry
-                const bool contrib = in_comb && valid && (!is_sum || small);
-                const unsigned long long cb = __ballot(contrib);
-                // biased to unsigned and split 21 + 20 bits so 64 lanes add up inside 32-bit DPP adds
-                const unsigned long long u = contrib && is_sum ? (unsigned long long)(v + (1ll << 40)) : 0ull;
-                const int ulo = (int)(u & 0x1FFFFFu), uhi = (int)(u >> 21);
-                unsigned long long t = comb;
-                while (t != 0) {
-                    int lead = __ffsll((long long)t) - 1;
-                    int g = __builtin_amdgcn_readlane(ent, lead);
-                    unsigned long long m = __ballot(ent == g);
-                    t &= ~m;
-                    const unsigned n = (unsigned)__popcll(m & cb);
-                    long long sum = 0;
-                    if (is_sum) {
-                        const bool mine = ent == g;
-                        unsigned long long su = (unsigned long long)(unsigned)wave_sum32(mine ? ulo : 0) +
-                                                ((unsigned long long)(unsigned)wave_sum32(mine ? uhi : 0) << 21);
-                        sum = (long long)su - ((long long)n << 40);
-                    }
-                    if (lane == lead && n != 0) {
-                        atomicAdd(&l_cnt[ls], n);
-                        if (is_sum) atomicAdd(&l_sum[ls], (unsigned long long)sum);
-                    }
                 }
             }
         }
@@ -1167,9 +1108,6 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
         }
     }
     for (int c = 0; c < nargs; c++) if (used[c]) P.arg_used |= 1u << c;
-    P.combine = 1;
-    for (int i = 0; i < a->naggs; i++)
-        if (a->aggs[i].kind == PH_A_MIN || a->aggs[i].kind == PH_A_MAX) P.combine = 0;
     P.sel = sel;
     P.n = n;
     P.row_base = row_base;
