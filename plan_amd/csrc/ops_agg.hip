@@ -554,10 +554,12 @@ struct BulkParams {
     int64_t rows_per_wg;
     int32_t *counts;             // [nparts][nwg] -> offsets after the scan
     const int64_t *total;        // rows after the scan
-    unsigned long long *rk;      // [nkeys][n] key words by partition order
-    long long *rv;               // [nused][n] argument values
-    long long *rrow;             // [n] first-row ids
-    uint8_t *rnull, *rvalid;     // [n] key NULL mask, argument validity bits
+    // partition records, one per row, rec_words 8-byte words each (one contiguous store per row:
+    // separate column arrays cost five scattered 1-8 byte stores per row and made the scatter the
+    // slowest kernel of the build): [keys nkeys][first-row id][values nused][flags]
+    // flags = key NULL mask | argument validity bits << 8 | bit 63: "found no room" (phase 0 -> 1)
+    unsigned long long *rec;
+    int rec_words;
     int lds_entries;             // T (power of two)
     int *overflow;               // set when the reserved ids run past gcap (host grows and reruns the build)
 };
@@ -603,10 +605,10 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
         unsigned nm;
         bulk_row_keys<NK>(B.S, r, k, &nm);
         const int pos = atomicAdd(&cursor[(keys_hash(k, nm, NK) >> 40) & (B.nparts - 1)], 1);
+        unsigned long long *rec = B.rec + (int64_t)pos * B.rec_words;
 #pragma unroll
-        for (int c = 0; c < NK; c++) B.rk[(int64_t)c * n + pos] = k[c];
-        B.rnull[pos] = (uint8_t)nm;
-        B.rrow[pos] = (long long)(B.S.row_base + (B.S.sel ? r : i));
+        for (int c = 0; c < NK; c++) rec[c] = k[c];
+        rec[NK] = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
         unsigned vbits = 0;
         const int64_t ar = B.S.positional ? i : r;
         for (int j = 0; j < B.nused; j++) {
@@ -616,9 +618,9 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
                 vbits |= 1u << j;
                 v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
             }
-            B.rv[(int64_t)j * n + pos] = v;
+            rec[NK + 1 + j] = (unsigned long long)v;
         }
-        B.rvalid[pos] = (uint8_t)vbits;
+        rec[NK + 1 + B.nused] = (unsigned long long)nm | ((unsigned long long)vbits << 8);
     }
 }
 
@@ -659,14 +661,16 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
     // once by the write-out below, which claims slots without comparing keys).
     for (int phase = 0; phase < 2; phase++) {
     for (int64_t t = start + threadIdx.x; t < end; t += 1024) {
-        const unsigned vraw = B.rvalid[t];
-        if (phase == 1 && !(vraw & 0x80u)) continue;
+        unsigned long long *rec = B.rec + t * B.rec_words;
+        const unsigned long long flags = rec[NK + 1 + B.nused];
+        const bool no_room = flags >> 63;
+        if (phase == 1 && !no_room) continue;
         unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < NK; c++) k[c] = B.rk[(int64_t)c * n + t];
-        const unsigned nullmask = B.rnull[t];
-        const unsigned vbits = vraw & 0x7Fu;
-        const long long frow = B.rrow[t];
+        for (int c = 0; c < NK; c++) k[c] = rec[c];
+        const unsigned nullmask = (unsigned)(flags & 0xFF);
+        const unsigned vbits = (unsigned)((flags >> 8) & 0xFF);
+        const long long frow = (long long)rec[NK];
         int ent = -1;
         int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
         for (int probes = 0, spins = 0; probes < 32 && spins < (1 << 16);) {
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
         }
         int gid = -1;
         if (ent < 0) {
-            if (phase == 0) { B.rvalid[t] = (uint8_t)(vraw | 0x80u); continue; }   // decided in phase 1
+            if (phase == 0) { rec[NK + 1 + B.nused] = flags | (1ull << 63); continue; }   // decided in phase 1
             // no room in LDS: the ordinary global path for this row. Once the table has run out of
             // ids this attempt is void (the host grows the table and runs the build again).
             if (__hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             if (frow < l_first[ent]) atomicMin(&l_first[ent], frow);
             // a flag left by an earlier, voided attempt over the same records must not send the row
             // through phase 1 a second time
-            if (phase == 0 && (vraw & 0x80u)) B.rvalid[t] = (uint8_t)vbits;
+            if (phase == 0 && no_room) rec[NK + 1 + B.nused] = flags & ~(1ull << 63);
         }
         for (int a = 0; a < na; a++) {
             if (!((S.agg_mask >> a) & 1)) continue;
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
                 int j = 0;
                 for (; j < B.nused; j++) if (B.used_col[j] == S.agg_arg[a]) break;
                 valid = (vbits >> j) & 1;
-                v = B.rv[(int64_t)j * n + t];
+                v = (long long)rec[NK + 1 + j];
             }
             if (!valid) continue;
             if (ent >= 0) {
@@ -1002,15 +1006,11 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     if (cap != a->cap) PH_CHECK(agg_resize(a, cap, 0));
     // partition records
     char *tmp = nullptr;
-    const int64_t o_rk = ph::round_up(nc * 4, 16), o_rv = o_rk + (int64_t)nk * n * 8, o_rrow = o_rv + (int64_t)B.nused * n * 8;
-    const int64_t o_rnull = o_rrow + n * 8, o_rvalid = o_rnull + ph::round_up(n, 16), o_total = o_rvalid + ph::round_up(n, 16);
+    B.rec_words = nk + 1 + B.nused + 1;
+    const int64_t o_rec = ph::round_up(nc * 4, 16), o_total = o_rec + (int64_t)B.rec_words * n * 8;
     PH_CHECK(ctx->pool_alloc(o_total + 16, (void **)&tmp));
     B.counts = (int32_t *)tmp;
-    B.rk = (unsigned long long *)(tmp + o_rk);
-    B.rv = (long long *)(tmp + o_rv);
-    B.rrow = (long long *)(tmp + o_rrow);
-    B.rnull = (uint8_t *)(tmp + o_rnull);
-    B.rvalid = (uint8_t *)(tmp + o_rvalid);
+    B.rec = (unsigned long long *)(tmp + o_rec);
     int64_t *total_dev = (int64_t *)(tmp + o_total);
     B.total = total_dev;
     B.overflow = a->counters + 2;
