@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void part_count_kernel(JoinSide B, uint64_t ma
 }
 
 __global__ __launch_bounds__(256) void part_scatter_kernel(JoinSide B, uint64_t mask, int nparts, int64_t rows_per_wg,
-                                                           const int32_t *__restrict__ offsets, int32_t *__restrict__ part_i,
-                                                           unsigned long long *__restrict__ part_h, int32_t *__restrict__ next) {
+                                                           const int32_t *__restrict__ offsets, ulonglong2 *__restrict__ part_rec,
+                                                           int32_t *__restrict__ next) {
     extern __shared__ int cursor[];
     for (int e = threadIdx.x; e < nparts; e += 256) cursor[e] = offsets[(int64_t)e * gridDim.x + blockIdx.x];
     __syncthreads();
@@ -140,15 +140,13 @@ __global__ __launch_bounds__(256) void part_scatter_kernel(JoinSide B, uint64_t 
         uint64_t h;
         if (!load_keys(B, r, k, &h)) { next[i] = -2; continue; }  // NULL key: not inserted
         const int pos = atomicAdd(&cursor[(h & mask) >> PB_SLICE_LOG], 1);
-        part_i[pos] = (int32_t)i;
-        part_h[pos] = h;
+        part_rec[pos] = make_ulonglong2(h, (unsigned long long)i);   // one 16-byte store per row
     }
 }
 
 __global__ __launch_bounds__(1024) void part_build_kernel(const int32_t *__restrict__ offsets, int nwg, int nparts,
                                                           const int64_t *__restrict__ total,
-                                                          const int32_t *__restrict__ part_i,
-                                                          const unsigned long long *__restrict__ part_h,
+                                                          const ulonglong2 *__restrict__ part_rec,
                                                           int32_t *__restrict__ head, int32_t *__restrict__ next, Bloom bl,
                                                           int bloom_words) {
     extern __shared__ int lds[];
@@ -161,8 +159,9 @@ __global__ __launch_bounds__(1024) void part_build_kernel(const int32_t *__restr
     const int64_t start = offsets[(int64_t)p * nwg];
     const int64_t end = p + 1 < nparts ? (int64_t)offsets[(int64_t)(p + 1) * nwg] : *total;
     for (int64_t t = start + threadIdx.x; t < end; t += 1024) {
-        const int32_t i = part_i[t];
-        const unsigned long long h = part_h[t];
+        const ulonglong2 rec = part_rec[t];
+        const int32_t i = (int32_t)rec.y;
+        const unsigned long long h = rec.x;
         next[i] = atomicExch(&lhead[h & (PB_SLICE - 1)], i);   // head insertion, as the atomic build does
         if (bl.bits) atomicOr(&lbloom[(h >> 34) & bl.inner_mask], bloom_mask(h >> 24));
     }
@@ -713,16 +712,16 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     if (partitioned) {
         const int64_t rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
         const int nwg = (int)((n + rows_per_wg - 1) / rows_per_wg);
-        int32_t *counts = nullptr, *part_i = nullptr;
-        unsigned long long *part_h = nullptr;
+        int32_t *counts = nullptr;
+        ulonglong2 *part_rec = nullptr;
         const int64_t nc = (int64_t)nparts * nwg;
-        if (ctx->pool_alloc(nc * 4, (void **)&counts) != PH_OK || ctx->pool_alloc(n * 4, (void **)&part_i) != PH_OK ||
-            ctx->pool_alloc(n * 8, (void **)&part_h) != PH_OK) return fail("alloc(partition scratch)");
+        if (ctx->pool_alloc(nc * 4, (void **)&counts) != PH_OK || ctx->pool_alloc(n * 16, (void **)&part_rec) != PH_OK)
+            return fail("alloc(partition scratch)");
         const uint64_t mask = (uint64_t)cap - 1;
         ph::part_count_kernel<<<nwg, 256, (size_t)nparts * 4, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts);
         int rc2 = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)count);   // total = inserted rows (low word read as int)
-        ph::part_scatter_kernel<<<nwg, 256, (size_t)nparts * 4, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts, part_i,
-                                                                              part_h, j->next);
+        ph::part_scatter_kernel<<<nwg, 256, (size_t)nparts * 4, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts, part_rec,
+                                                                              j->next);
         const int bloom_words = bits ? (int)((bits / 32) / nparts) : 0;
         static bool lds_raised = false;
         if (!lds_raised) {  // 64 KiB head slice + up to 32 KiB bitmap slice: above the default dynamic LDS limit
@@ -731,9 +730,9 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
             lds_raised = true;
         }
         ph::part_build_kernel<<<nparts, 1024, (size_t)(ph::PB_SLICE + bloom_words) * 4, ctx->stream>>>(
-            counts, nwg, nparts, (const int64_t *)count, part_i, part_h, j->head, j->next, j->bloom, bloom_words);
+            counts, nwg, nparts, (const int64_t *)count, part_rec, j->head, j->next, j->bloom, bloom_words);
         const bool bad = rc2 != PH_OK || hipGetLastError() != hipSuccess;
-        ctx->pool_release(counts); ctx->pool_release(part_i); ctx->pool_release(part_h);
+        ctx->pool_release(counts); ctx->pool_release(part_rec);
         if (bad) return fail("partitioned build launch");
     } else {
         if (hipMemsetAsync(j->head, 0xff, (size_t)cap * 4, ctx->stream) != hipSuccess) return fail("memset");
