@@ -111,6 +111,83 @@ constexpr int PB_SLICE_LOG = 14;              // head entries per partition: 163
 constexpr int PB_SLICE = 1 << PB_SLICE_LOG;
 constexpr int PB_MAX_PARTS = 4096;
 
+template <int KW> __device__ __forceinline__ unsigned long long load_kw(const void *col, int64_t r) {
+    return KW == 4 ? (unsigned long long)(long long)((const int32_t *)col)[r]
+           : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
+}
+
+// Straight-line forms of the two partition passes for the common build shape (one or two key
+// columns of one width, no NULL keys): PU rows per thread, their selection / key reads issued
+// together (the generic kernels below pay two or three dependent memory latencies per row).
+constexpr int PU = 4;
+
+template <int KW, int NK, bool SEL>
+__device__ __forceinline__ void part_hashes(const void *k0, const void *k1, const int32_t *sel, int64_t base, int64_t i1,
+                                            uint64_t (&h)[PU], bool (&ok)[PU]) {
+    int64_t r[PU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        ok[u] = i < i1;
+        const int64_t ic = ok[u] ? i : i1 - 1;
+        r[u] = SEL ? (int64_t)sel[ic] : ic;
+    }
+    unsigned long long a[PU], b[PU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        a[u] = load_kw<KW>(k0, r[u]);
+        b[u] = NK == 2 ? load_kw<KW>(k1, r[u]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ a[u]);   // load_keys' hash
+        if (NK == 2) hh = mix64(hh ^ b[u]);
+        h[u] = hh;
+    }
+}
+
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(256) void part_count_fast_kernel(const void *k0, const void *k1, const int32_t *sel, int64_t n,
+                                                              uint64_t mask, int nparts, int64_t rows_per_wg,
+                                                              int32_t *__restrict__ counts) {
+    extern __shared__ int hist[];
+    for (int e = threadIdx.x; e < nparts; e += 256) hist[e] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
+    for (int64_t base = i0; base < i1; base += 256 * PU) {
+        uint64_t h[PU];
+        bool ok[PU];
+        part_hashes<KW, NK, SEL>(k0, k1, sel, base, i1, h, ok);
+#pragma unroll
+        for (int u = 0; u < PU; u++)
+            if (ok[u]) atomicAdd(&hist[(h[u] & mask) >> PB_SLICE_LOG], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nparts; e += 256) counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
+}
+
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(256) void part_scatter_fast_kernel(const void *k0, const void *k1, const int32_t *sel, int64_t n,
+                                                                uint64_t mask, int nparts, int64_t rows_per_wg,
+                                                                const int32_t *__restrict__ offsets,
+                                                                ulonglong2 *__restrict__ part_rec) {
+    extern __shared__ int cursor[];
+    for (int e = threadIdx.x; e < nparts; e += 256) cursor[e] = offsets[(int64_t)e * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
+    for (int64_t base = i0; base < i1; base += 256 * PU) {
+        uint64_t h[PU];
+        bool ok[PU];
+        part_hashes<KW, NK, SEL>(k0, k1, sel, base, i1, h, ok);
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if (!ok[u]) continue;
+            const int pos = atomicAdd(&cursor[(h[u] & mask) >> PB_SLICE_LOG], 1);
+            part_rec[pos] = make_ulonglong2(h[u], (unsigned long long)(base + u * 256 + threadIdx.x));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void part_count_kernel(JoinSide B, uint64_t mask, int nparts, int64_t rows_per_wg,
                                                          int32_t *__restrict__ counts) {
     extern __shared__ int hist[];
@@ -266,11 +343,6 @@ __global__ __launch_bounds__(256) void join_cand_kernel(JoinSide Pr, Bloom bl, R
         before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
     }
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
-}
-
-template <int KW> __device__ __forceinline__ unsigned long long load_kw(const void *col, int64_t r) {
-    return KW == 4 ? (unsigned long long)(long long)((const int32_t *)col)[r]
-           : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
 }
 
 // The common probe shape — one key column without NULLs, optional integer-range filter without
@@ -718,10 +790,37 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
         if (ctx->pool_alloc(nc * 4, (void **)&counts) != PH_OK || ctx->pool_alloc(n * 16, (void **)&part_rec) != PH_OK)
             return fail("alloc(partition scratch)");
         const uint64_t mask = (uint64_t)cap - 1;
-        ph::part_count_kernel<<<nwg, 256, (size_t)nparts * 4, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts);
-        int rc2 = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)count);   // total = inserted rows (low word read as int)
-        ph::part_scatter_kernel<<<nwg, 256, (size_t)nparts * 4, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts, part_rec,
-                                                                              j->next);
+        // common shape (one or two keys of one width, no NULL keys): straight-line passes
+        const ph::JoinSide &Bs = j->build;
+        auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+        const int kw = width(Bs.key[0].type);
+        const bool fast = Bs.nkeys <= 2 && !Bs.key[0].validity && kw != 1 &&
+                          (Bs.nkeys == 1 || (!Bs.key[1].validity && width(Bs.key[1].type) == kw));
+        const size_t hl = (size_t)nparts * 4;
+        int rc2 = PH_OK;
+#define PH_PART_FAST(KWV, NKV, SELV)                                                                                      \
+    do {                                                                                                                  \
+        ph::part_count_fast_kernel<KWV, NKV, SELV><<<nwg, 256, hl, ctx->stream>>>(Bs.key[0].data, Bs.key[1].data, Bs.sel, Bs.n, \
+                                                                                 mask, nparts, rows_per_wg, counts);     \
+        rc2 = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)count);                                                  \
+        ph::part_scatter_fast_kernel<KWV, NKV, SELV><<<nwg, 256, hl, ctx->stream>>>(Bs.key[0].data, Bs.key[1].data, Bs.sel,    \
+                                                                                   Bs.n, mask, nparts, rows_per_wg, counts, \
+                                                                                   part_rec);                             \
+    } while (0)
+        if (fast && kw == 4 && Bs.nkeys == 1 && Bs.sel) PH_PART_FAST(4, 1, true);
+        else if (fast && kw == 4 && Bs.nkeys == 1) PH_PART_FAST(4, 1, false);
+        else if (fast && kw == 4 && Bs.sel) PH_PART_FAST(4, 2, true);
+        else if (fast && kw == 4) PH_PART_FAST(4, 2, false);
+        else if (fast && Bs.nkeys == 1 && Bs.sel) PH_PART_FAST(8, 1, true);
+        else if (fast && Bs.nkeys == 1) PH_PART_FAST(8, 1, false);
+        else if (fast && Bs.sel) PH_PART_FAST(8, 2, true);
+        else if (fast) PH_PART_FAST(8, 2, false);
+        else {
+            ph::part_count_kernel<<<nwg, 256, hl, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts);
+            rc2 = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)count);   // total = inserted rows (low word read as int)
+            ph::part_scatter_kernel<<<nwg, 256, hl, ctx->stream>>>(j->build, mask, nparts, rows_per_wg, counts, part_rec, j->next);
+        }
+#undef PH_PART_FAST
         const int bloom_words = bits ? (int)((bits / 32) / nparts) : 0;
         static bool lds_raised = false;
         if (!lds_raised) {  // 64 KiB head slice + up to 32 KiB bitmap slice: above the default dynamic LDS limit
