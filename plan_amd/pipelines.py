@@ -85,7 +85,11 @@ class Q3Pipeline:
         cs, cn = hip.filter_select(ctx, self.c_seg, self.nc, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code))
         frees.append(cs)
         if N == 1:
-            j1 = hip.Join(ctx, [self.c_key], cs, cn)
+            # build on the gathered keys (no selection inside the table: one dependent read less per
+            # chain step of the probe); the build-side row ids of this join are never used
+            ck = hip.gather(ctx, self.c_key, cs, cn)
+            frees.append(ck)
+            j1 = hip.Join(ctx, [_raw(hip.PH_I32, ck)], None, cn)
         else:
             import torch
             mine = self._gather_t(self.c_key, cs, cn, torch.int32)
@@ -330,7 +334,9 @@ class Q9Pipeline:
                                       hip.const(hip.PH_STR, s=self.pattern))
         frees.append(psel)
         if N == 1:
-            j = hip.Join(ctx, [self.p_key], psel, np_)
+            pk = hip.gather(ctx, self.p_key, psel, np_)   # as in Q3: no selection inside the table
+            frees.append(pk)
+            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, np_)
         else:
             import torch
             pk = bcast(self.p_key, psel, np_, torch.int32)
