@@ -66,3 +66,46 @@ def test_random_joins(ctx, seed):
     bsel = np.sort(rng.choice(nb, max(1, nb * 3 // 4), replace=False)) if rng.random() < 0.5 else None
     psel = np.sort(rng.choice(np_, max(1, np_ // 2), replace=False)) if rng.random() < 0.5 else None
     join_compare(ctx, b, p, bsel, psel)
+
+
+def test_error_codes_and_capacity_reports(ctx):
+    """Every entry point answers a shape it does not run, or a buffer that is too small, with an
+    error code (never a different result): join output capacity, top-k room, scatter value type,
+    key-type mismatch, too many keys."""
+    rng = np.random.default_rng(77)
+    b = hip.DevColumn(ctx, hip.PH_I32, rng.integers(0, 100, 5000).astype(np.int32))       # ~50 duplicates per key
+    p = hip.DevColumn(ctx, hip.PH_I32, rng.integers(0, 100, 4000).astype(np.int32))
+    j = hip.Join(ctx, [b], None, 5000)
+    with pytest.raises(hip.PlanHipError) as e:
+        j.probe_inner([p], None, 4000, 1000)          # ~200 000 pairs do not fit 1000
+    assert e.value.code == hip.PH_ECAPACITY
+    m, op, ob = j.probe_inner([p], None, 4000, 400_000)
+    assert m > 150_000
+    ctx.free(op); ctx.free(ob)
+    p64 = hip.DevColumn(ctx, hip.PH_I64, np.arange(10, dtype=np.int64))
+    with pytest.raises(hip.PlanHipError) as e:
+        j.probe_inner([p64], None, 10, 10)            # 64-bit probe key against a 32-bit build key
+    assert e.value.code == hip.PH_EINVAL
+    j.free()
+    with pytest.raises(hip.PlanHipError):
+        hip.Join(ctx, [b, b, b, b, b], None, 5000)    # more than 4 key columns
+    # top-k: more qualifying groups than the caller has room for
+    k = hip.DevColumn(ctx, hip.PH_I32, np.arange(3000, dtype=np.int32))
+    v = hip.DevColumn(ctx, hip.PH_I64, np.ones(3000, np.int64))                            # 3000 groups tie
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_SUM, 0)], 4096)
+    agg.sink([k], [v], None, 3000)
+    with pytest.raises(hip.PlanHipError) as e:
+        agg.topk(0, 10, cap=100)
+    assert e.value.code == hip.PH_ECAPACITY
+    assert len(agg.topk(0, 10, cap=4096)["first_row"]) == 3000                             # all tie for the top
+    agg.free()
+    # FillSwitch fills INTEGER and DECIMAL results only
+    c = hip.Col()
+    c.type, c.data = hip.PH_I64, v.data
+    out = ctx.alloc(3000 * 8)
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.scatter(ctx, c, None, 3000, out)
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    ctx.free(out)
+    for d in (b, p, p64, k, v):
+        d.free()
