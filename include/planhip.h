@@ -343,6 +343,19 @@ void ph_agg_result_free(ph_agg_result *r);
 int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
                  int64_t *counts_host, int32_t *perm_dev);
 
+/* ------------------------------------------------------------------ ORDER BY
+ * LocalSort over fixed-size keys (sort_local.go:64-250; key layout sort_layout.go:29-88; encoders
+ * sort_encoder.go:33-114; RadixScatter sort_radix.go:242-380): rows sel[0..n) (or 0..n) ordered
+ * by the ORDER BY columns `keys` (first = most significant), descending[c] != 0 for DESC.
+ * As in the reference NULLs always sort first (sort_layout.go:46), DECIMAL keys compare by their
+ * value rounded half-even to two decimals (decimalEncoder: dec.Int64(2)), DATE by (year, month,
+ * day), INTEGER as int32; PH_CODE8 keys compare by code and therefore need a dictionary in
+ * ascending byte order (the loader's dictionaries are). BIGINT / DOUBLE keys: PH_EUNSUPPORTED (the
+ * reference's RadixScatter has no case for them either). Rows with equal keys keep their input
+ * order (the reference leaves their order undefined). out_rows_dev: n int32 row ids, sorted. */
+int ph_sort_rows(ph_ctx *ctx, const ph_col *keys, const int32_t *descending, int32_t nkeys,
+                 const int32_t *sel, int64_t n, int32_t *out_rows_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -754,6 +754,90 @@ int64_t oracle_select_or(const ocol *cols, const int32_t *ops, const oconst *ks,
     return res;
 }
 
+/* ------------------------------------------------------------------ ORDER BY */
+
+static void enc_be32(uint8_t *p, int32_t v) { /* encodeInt32 (sort_encoder.go:98-101) */
+    uint32_t u = (uint32_t)v;
+    p[0] = (uint8_t)(u >> 24) ^ 0x80; p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
+}
+static void enc_be64(uint8_t *p, int64_t v) { /* encodeInt64 (:107-110) */
+    uint64_t u = (uint64_t)v;
+    for (int b = 0; b < 8; b++) p[b] = (uint8_t)(u >> (56 - 8 * b));
+    p[0] ^= 0x80;
+}
+static void civil_from_days(int32_t z, int32_t *y, int32_t *m, int32_t *d) {
+    z += 719468;
+    int32_t era = (z >= 0 ? z : z - 146096) / 146097;
+    uint32_t doe = (uint32_t)(z - era * 146097);
+    uint32_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    int32_t yy = (int32_t)yoe + era * 400;
+    uint32_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    uint32_t mp = (5 * doy + 2) / 153;
+    *d = (int32_t)(doy - (153 * mp + 2) / 5 + 1);
+    *m = (int32_t)(mp < 10 ? mp + 3 : mp - 9);
+    *y = yy + (*m <= 2);
+}
+
+typedef struct { const uint8_t *key; int64_t pos; int32_t len; } sort_ref;
+static int sort_ref_cmp(const void *a, const void *b) {
+    const sort_ref *x = (const sort_ref *)a, *y = (const sort_ref *)b;
+    int c = memcmp(x->key, y->key, (size_t)x->len);
+    if (c) return c;
+    return x->pos < y->pos ? -1 : x->pos > y->pos;
+}
+
+int oracle_sort_rows(const ocol *cols, const int32_t *descending, int32_t nkeys, const int64_t *sel,
+                     int64_t n, int64_t *rows_out, int32_t *key_len_out, uint8_t *keys_out) {
+    int32_t width = 0;
+    for (int32_t c = 0; c < nkeys; c++) {
+        switch (cols[c].type) {
+        case OT_INT32: width += 1 + 4; break;
+        case OT_CODE8: width += 1 + 1; break;
+        case OT_DATE: width += 1 + 12; break;
+        case OT_DECIMAL: width += 1 + 16; break;
+        default: return -2;
+        }
+    }
+    if (key_len_out) *key_len_out = width;
+    uint8_t *keys = (uint8_t *)calloc((size_t)(n ? n : 1), (size_t)width);
+    sort_ref *refs = (sort_ref *)malloc(sizeof(sort_ref) * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) {
+        int64_t r = sel ? sel[i] : i;
+        uint8_t *p = keys + (size_t)i * (size_t)width;
+        for (int32_t c = 0; c < nkeys; c++) {
+            const ocol *k = &cols[c];
+            int vw = k->type == OT_INT32 ? 4 : k->type == OT_CODE8 ? 1 : k->type == OT_DATE ? 12 : 16;
+            if (!row_valid(k->validity, r)) { p[0] = 0; memset(p + 1, 0, (size_t)vw); p += 1 + vw; continue; }
+            p[0] = 1;
+            if (k->type == OT_INT32) enc_be32(p + 1, ((const int32_t *)k->data)[r]);
+            else if (k->type == OT_CODE8) p[1] = ((const uint8_t *)k->data)[r];
+            else if (k->type == OT_DATE) {
+                int32_t y, m, d;
+                civil_from_days(((const int32_t *)k->data)[r], &y, &m, &d);
+                enc_be32(p + 1, y); enc_be32(p + 5, m); enc_be32(p + 9, d);
+            } else {
+                odec v = dec_from_unscaled(((const int64_t *)k->data)[r], k->scale);
+                int64_t whole, frac;
+                if (!odec_int64(v, 2, &whole, &frac)) { free(keys); free(refs); return -1; } /* `ok` of dec.Int64 */
+                enc_be64(p + 1, whole); enc_be64(p + 9, frac);
+            }
+            if (descending[c]) for (int b = 1; b <= vw; b++) p[b] = (uint8_t)~p[b];
+            p += 1 + vw;
+        }
+        refs[i].key = keys + (size_t)i * (size_t)width;
+        refs[i].pos = i;
+        refs[i].len = width;
+    }
+    qsort(refs, (size_t)n, sizeof(sort_ref), sort_ref_cmp);
+    for (int64_t i = 0; i < n; i++) {
+        rows_out[i] = sel ? sel[refs[i].pos] : refs[i].pos;
+        if (keys_out) memcpy(keys_out + (size_t)i * (size_t)width, refs[i].key, (size_t)width);
+    }
+    free(keys);
+    free(refs);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ hash join */
 
 struct ojoin {

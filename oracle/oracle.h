@@ -177,6 +177,20 @@ int64_t oracle_groupby(const ocol *keys, int32_t nkeys, const ocol *args, int32_
                        int64_t *group_first_row, int64_t *group_keys, uint8_t *group_key_null,
                        oaggval *vals, int64_t max_groups);
 
+/* ---- ORDER BY ----
+ * LocalSort for fixed-size keys: every row's key is the concatenation, per ORDER BY column, of
+ * [1 = value / 0 = NULL (NULLs first, sort_layout.go:46)] + the encoder's bytes (INT32: big-endian
+ * with the sign bit flipped; DATE: year, month, day as such int32s; DECIMAL: dec.Int64(2) ->
+ * whole and frac as such int64s, sort_encoder.go:33-114), value bytes inverted for DESC
+ * (TemplatedRadixScatter, sort_radix.go:324-380; a NULL's value bytes are zero). Rows are ordered
+ * by memcmp of the keys (the reference's radix sort + pdqsort over the same bytes,
+ * sort_local.go:128-250); equal keys are returned in input order here (undefined there).
+ * key_len_out (optional) receives the key width; keys_out (optional, n * width bytes) the sorted keys.
+ * Column types: OT_INT32, OT_DATE (days), OT_DECIMAL (unscaled int64 + scale), OT_CODE8 (compared
+ * by code: what a VARCHAR key with a dictionary in ascending byte order amounts to). */
+int oracle_sort_rows(const ocol *cols, const int32_t *descending, int32_t nkeys, const int64_t *sel,
+                     int64_t n, int64_t *rows_out, int32_t *key_len_out, uint8_t *keys_out);
+
 /* ---- hash join ---- */
 typedef struct ojoin ojoin;
 

@@ -379,6 +379,14 @@ def scatter(ctx, values, sel, n, out_data, out_validity=None):
     check(lib().ph_scatter(ctx.h, ctypes.byref(c), sel, i64(n), out_data, out_validity))
 
 
+def sort_rows(ctx, keys, descending, sel, n):
+    """ORDER BY: device array of the n row ids (sel[i] or i) in sorted order."""
+    out = ctx.alloc(max(n, 1) * 4)
+    desc = (i32 * len(keys))(*[1 if d else 0 for d in descending])
+    check(lib().ph_sort_rows(ctx.h, _cols(keys), desc, i32(len(keys)), sel, i64(n), out))
+    return out
+
+
 def hash_cols(ctx, cols, n, dict_hashes=None):
     out = ctx.alloc(max(n, 1) * 8)
     dh = None

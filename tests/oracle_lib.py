@@ -236,6 +236,20 @@ def select_or(children, sel_in=None, n=None):
     return out[:m].copy()
 
 
+def sort_rows(cols, descending, sel=None, n=None):
+    """ORDER BY restatement: (sorted row ids, sorted key bytes [n, width])"""
+    k = len(cols)
+    arr = (OCol * k)(*cols)
+    desc = (i32 * k)(*[1 if d else 0 for d in descending])
+    n_in = len(sel) if sel is not None else n
+    rows = np.empty(max(n_in, 1), dtype=np.int64)
+    width = i32()
+    keys = np.zeros(max(n_in, 1) * 80, dtype=np.uint8)
+    rc = lib().oracle_sort_rows(arr, desc, i32(k), ptr(sel), i64(n_in), ptr(rows), ctypes.byref(width), ptr(keys))
+    assert rc == 0, rc
+    return rows[:n_in].copy(), keys[:n_in * width.value].reshape(n_in, width.value).copy()
+
+
 def groupby(keys, args, aggs, sel, n, max_groups):
     ka = (OCol * len(keys))(*keys)
     aa = (OCol * max(len(args), 1))(*args)
