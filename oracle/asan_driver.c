@@ -41,5 +41,8 @@ int main(void){
     ocol kp; memset(&kp,0,sizeof kp); kp.type=OT_INT32; ocol ap; memset(&ap,0,sizeof ap); ap.type=OT_INT32;
     oaggspec sp[2]={{OA_COUNT,0},{OA_SUM,0}}; oagg *t=oracle_agg_create(&kp,1,&ap,sp,2);
     for(int64_t b=0;b<n && b<20480;b+=2048){ int64_t cnt=n-b<2048?n-b:2048; ocol kc=kp; kc.data=pk+b; ocol ac=ap; ac.data=qty+b; oracle_agg_sink_filtered(t,&kc,&ac,NULL,cnt,b?1u:2u); }
-    printf("%lld filtered groups\n",(long long)oracle_agg_count(t)); oracle_agg_free(t); }
+    printf("%lld filtered groups\n",(long long)oracle_agg_count(t)); oracle_agg_free(t);
+    ocol sk[3]; memset(sk,0,sizeof sk); sk[0].type=OT_DECIMAL; sk[0].scale=2; sk[0].data=ext; sk[1].type=OT_DATE; sk[1].data=ship; sk[2].type=OT_INT32; sk[2].data=qty;
+    int32_t dsc[3]={1,0,1}; int64_t ns=n<20000?n:20000; int64_t *so=malloc(ns*8); int32_t kl=0; uint8_t *kb=malloc((size_t)ns*40);
+    int rs=oracle_sort_rows(sk,dsc,3,NULL,ns,so,&kl,kb); printf("sort rc %d key bytes %d first row %lld\n",rs,kl,(long long)so[0]); free(so); free(kb); }
   return 0; }
