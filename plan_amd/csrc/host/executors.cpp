@@ -746,4 +746,101 @@ OperatorResult gpuJoinExecutor::Execute(Chunk *, Chunk *output, std::string *err
     return haveMoreOutput;
 }
 
+// ------------------------------------------------------------------ order
+
+gpuOrderExecutor::gpuOrderExecutor(ph_ctx *ctx, std::vector<OrderKey> keys, OperatorExec *child)
+    : ctx_(ctx), keys_(std::move(keys)), child_(child) {}
+
+std::string gpuOrderExecutor::Init() {
+    auto t = child_->OutputTypes();
+    for (auto &k : keys_) {
+        if (k.col < 0 || k.col >= (int)t.size()) return "order key column out of range";
+        PhyType p = t[(size_t)k.col].GetInternalType();
+        if (p != PT_INT32 && p != PT_DATE && p != PT_DECIMAL && p != PT_VARCHAR)
+            return "ORDER BY key type stays on the CPU executor";   // no RadixScatter case (sort_radix.go:257-321)
+    }
+    return "";
+}
+
+std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return ""; }
+
+std::string gpuOrderExecutor::sortAll() {
+    std::vector<int> cols;
+    for (auto &k : keys_) cols.push_back(k.col);
+    DeviceBatch batch(ctx_, child_->OutputTypes(), cols);
+    int64_t total = 0;
+    for (;;) {   // SinkChunk for every child chunk (executor_order.go:75-99)
+        auto c = std::make_shared<Chunk>();
+        std::string err;
+        OperatorResult r = child_->Execute(nullptr, c.get(), &err);
+        if (r == InvalidOpResult) return err.empty() ? "child failed" : err;
+        if (r == Done) break;
+        if (c->Card() == 0) continue;
+        std::string e = batch.Append(*c);
+        if (!e.empty()) return e;
+        start_.push_back(total);
+        chunks_.push_back(c);
+        total += c->Card();
+    }
+    if (total == 0) return "";
+    std::string e = batch.Upload();
+    if (!e.empty()) return e;
+    // VARCHAR keys arrive as codes in first-seen order: re-code by the dictionary's byte order so
+    // that code order = string order (what the reference's prefix + full compare yields)
+    std::vector<ph_col> kc;
+    std::vector<int32_t> desc;
+    std::vector<void *> recoded;
+    for (size_t k = 0; k < keys_.size(); k++) {
+        ph_col c = batch.col((int)k);
+        if (c.type == PH_CODE8) {
+            const auto &dict = batch.dict((int)k);
+            std::vector<int> idx(dict.size());
+            for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
+            std::sort(idx.begin(), idx.end(), [&](int a, int b) { return dict[(size_t)a] < dict[(size_t)b]; });
+            std::vector<uint8_t> rank(256, 0);
+            for (size_t i = 0; i < idx.size(); i++) rank[(size_t)idx[i]] = (uint8_t)i;
+            std::vector<uint8_t> codes((size_t)total);
+            if (ph_dev_download(ctx_, codes.data(), c.data, total) != PH_OK) return herr("ph_dev_download");
+            for (auto &x : codes) x = rank[x];
+            void *d = nullptr;
+            if (ph_dev_alloc(ctx_, total, &d) != PH_OK || ph_dev_upload(ctx_, d, codes.data(), total) != PH_OK) return herr("ph_dev_upload");
+            recoded.push_back(d);
+            c.data = d;
+        }
+        kc.push_back(c);
+        desc.push_back(keys_[k].descending ? 1 : 0);
+    }
+    void *out = nullptr;
+    std::string err;
+    order_.resize((size_t)total);
+    if (ph_dev_alloc(ctx_, total * 4, &out) != PH_OK) err = herr("ph_dev_alloc");
+    else if (ph_sort_rows(ctx_, kc.data(), desc.data(), (int32_t)kc.size(), nullptr, total, (int32_t *)out) != PH_OK) err = herr("ph_sort_rows");
+    else if (ph_dev_download(ctx_, order_.data(), out, total * 4) != PH_OK) err = herr("ph_dev_download");
+    if (out) ph_dev_free(ctx_, out);
+    for (void *d : recoded) ph_dev_free(ctx_, d);
+    return err;
+}
+
+OperatorResult gpuOrderExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!sorted_) {
+        std::string e = sortAll();
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        sorted_ = true;
+    }
+    if (next_ >= order_.size()) return Done;
+    // PayloadScanner (executor_order.go:101-138): the next <= 2048 rows in sorted order
+    output->Init(OutputTypes(), DefaultVectorSize);
+    int card = (int)std::min<size_t>((size_t)DefaultVectorSize, order_.size() - next_);
+    int ncol = (int)OutputTypes().size();
+    for (int r = 0; r < card; r++) {
+        int64_t row = order_[next_ + (size_t)r];
+        size_t ci = (size_t)(std::upper_bound(start_.begin(), start_.end(), row) - start_.begin()) - 1;
+        int local = (int)(row - start_[ci]);
+        for (int c = 0; c < ncol; c++) CopyCell(*chunks_[ci]->Data[(size_t)c], local, output->Data[(size_t)c].get(), r);
+    }
+    output->SetCard(card);
+    next_ += (size_t)card;
+    return haveMoreOutput;
+}
+
 }  // namespace plan

@@ -9,6 +9,7 @@
 //   gpuFilterExecutor  <- filterExecutor    executor_filter.go:27-114
 //   gpuAggExecutor     <- aggExecutor       executor_aggr.go:37-265
 //   gpuJoinExecutor    <- joinExecutor      executor_join.go:27-264
+//   gpuOrderExecutor   <- orderExecutor     executor_order.go:56-138 (LocalSort sort_local.go:64-250)
 //
 // The Go shim of INTEGRATION.md has exactly this shape; this C++ form exists because the build
 // environment has no Go toolchain, and it is what the host-level tests drive.
@@ -189,6 +190,35 @@ private:
     bool built_ = false, probeDone_ = false;
     JoinType type_ = JoinInner;
     std::deque<std::shared_ptr<Chunk>> ready_;
+};
+
+// ORDER BY: drains the child (orderExecutor.Execute sinks every chunk into LocalSort, then scans
+// the sorted rows, executor_order.go:56-138), sorts the row ids on the device by the ORDER BY
+// columns (ph_sort_rows: the reference's key encoding, NULLs first) and emits the child's rows in
+// that order, 2048 per chunk. VARCHAR keys must be dictionary columns whose codes are assigned in
+// ascending byte order of the strings; the executor re-codes them so before uploading.
+struct OrderKey {
+    int col;          // child column
+    bool descending;
+};
+
+class gpuOrderExecutor : public OperatorExec {
+public:
+    gpuOrderExecutor(ph_ctx *ctx, std::vector<OrderKey> keys, OperatorExec *child);
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override;
+    std::vector<LType> OutputTypes() const override { return child_->OutputTypes(); }
+private:
+    std::string sortAll();
+    ph_ctx *ctx_;
+    std::vector<OrderKey> keys_;
+    OperatorExec *child_;
+    std::vector<std::shared_ptr<Chunk>> chunks_;
+    std::vector<int64_t> start_;          // first row id of each chunk
+    std::vector<int32_t> order_;          // sorted row ids
+    size_t next_ = 0;
+    bool sorted_ = false;
 };
 
 // Agg <- Scan(filter) over a RESIDENT table — the measured mode behind the operator interface

@@ -3,7 +3,7 @@
 // reference's text format (headline "#\t..." of execQuery, executor_bench.go:229-238; rows via
 // Chunk.SaveToFile). The role `tester tpch1g --query_id N` plays for the reference.
 //   host_tester roundtrip | formats
-//   host_tester semi|anti|left <sf_num> <sf_den>
+//   host_tester semi|anti|left|order <sf_num> <sf_den>
 //   host_tester q1|q6|q3 <sf_num> <sf_den> [stub|resident]
 #include <algorithm>
 #include <cstdio>
@@ -191,7 +191,7 @@ int main(int argc, char **argv) {
     ph_ctx *ctx = nullptr;
     if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
     Lineitem L;
-    if (q != "semi" && q != "anti" && q != "left") L = gen_lineitem(num, den);
+    if (q != "semi" && q != "anti" && q != "left" && q != "order") L = gen_lineitem(num, den);
     auto scan = lineitem_source(L, stub);
     auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
 
@@ -379,6 +379,32 @@ int main(int argc, char **argv) {
         });
         gpuJoinExecutor j(ctx, &csrc, &osrc, {0}, {0}, {1}, 512, JoinLeft);
         print(2, run(&j));
+    } else if (q == "order") {
+        // SELECT c_mktsegment, c_custkey FROM customer ORDER BY c_mktsegment DESC, c_custkey % 97, c_custkey DESC
+        // (a VARCHAR key, an INTEGER key with many ties, a tie-breaker): gpuOrderExecutor over 2048-row chunks
+        int64_t nc = tpchgen_customer_count(num, den);
+        std::vector<int32_t> ckey((size_t)nc);
+        std::vector<uint8_t> seg((size_t)nc);
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data(); cc.c_mktsegment = seg.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        int64_t pos = 0;
+        std::vector<LType> types = {VarcharType(), IntegerType(), IntegerType()};
+        sourceExecutor src(types, [&](Chunk *out) {
+            if (pos >= nc) return false;
+            int card = (int)std::min<int64_t>(DefaultVectorSize, nc - pos);
+            out->Init(types, DefaultVectorSize);
+            for (int i = 0; i < card; i++) {
+                const char *sname = TPCHGEN_MKTSEGMENT_DICT[seg[(size_t)(pos + i)]];
+                out->Data[0]->SetString(i, sname, (int64_t)strlen(sname));
+                out->Data[1]->Slice<int32_t>()[i] = ckey[(size_t)(pos + i)] % 97;
+                out->Data[2]->Slice<int32_t>()[i] = ckey[(size_t)(pos + i)];
+            }
+            out->SetCard(card);
+            pos += card;
+            return true;
+        });
+        gpuOrderExecutor ord(ctx, {{0, true}, {1, false}, {2, true}}, &src);
+        print(3, run(&ord));
     } else die("unknown query " + q);
     ph_ctx_destroy(ctx);
     return 0;

@@ -105,3 +105,15 @@ def test_left_join_executor(sf001):
     never = ck[~np.isin(ck, oc)]
     want = sorted([(str(int(c)), str(int(o))) for c, o in zip(oc, ok)] + [(str(int(c)), "NULL") for c in never])
     assert got == want and len(never) > 0
+
+
+@pytest.mark.gpu
+def test_order_executor(sf001):
+    """gpuOrderExecutor (orderExecutor, executor_order.go:56-138): customer ordered by
+    c_mktsegment DESC (VARCHAR key), c_custkey % 97, c_custkey DESC."""
+    C = sf001["customer"]
+    segs = [tpchgen.MKTSEGMENT_DICT[c] for c in C["c_mktsegment"]]
+    rows = sorted(zip(segs, (C["c_custkey"] % 97).tolist(), C["c_custkey"].tolist()),
+                  key=lambda r: ([-b for b in r[0].encode()] + [1], r[1], -r[2]))
+    got = [tuple(l.split("\t")) for l in run("order", "1", "100").split("\n")[1:] if l]
+    assert got == [(s, str(a), str(b)) for s, a, b in rows]
