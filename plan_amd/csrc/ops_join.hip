@@ -68,7 +68,15 @@ struct Bloom {
     // bitmap so one workgroup can build both in LDS; pmask = 0 (inner_mask = word_mask) otherwise
     uint32_t pmask, pshift, hi_shift;
     uint64_t inner_mask;
+    // small build sides (<= 256 K keys) also get a 1 Mbit single-hash bitmap that a probe workgroup
+    // copies into LDS (128 KiB): it rejects most non-matching probes on the CU, so only the
+    // survivors read the bitmap above through L2 (whose request rate bounded the candidate kernel)
+    unsigned *coarse;
 };
+
+constexpr int CO_WORDS = 32768;   // 1 Mbit
+static int g_cu_count = 256;       // set from the context before the coarse kernel is launched
+__device__ __forceinline__ unsigned coarse_bit(uint64_t h) { return (unsigned)(h >> 40) & (CO_WORDS * 32 - 1); }
 
 __device__ __forceinline__ unsigned bloom_mask(uint64_t b) { return (1u << (b & 31)) | (1u << ((b >> 5) & 31)); }
 
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__
         next[i] = atomicExch(&head[h & mask], (int32_t)i);        // head insertion
         if (bl.bits) {
             atomicOr(&bl.bits[bloom_word(bl, h)], bloom_mask(h >> 24));
+            if (bl.coarse) atomicOr(&bl.coarse[coarse_bit(h) >> 5], 1u << (coarse_bit(h) & 31));
         }
         local++;
     }
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(1024) void part_build_kernel(const int32_t *__restr
         const unsigned long long h = rec.x;
         next[i] = atomicExch(&lhead[h & (PB_SLICE - 1)], i);   // head insertion, as the atomic build does
         if (bl.bits) atomicOr(&lbloom[(h >> 34) & bl.inner_mask], bloom_mask(h >> 24));
+        if (bl.coarse) atomicOr(&bl.coarse[coarse_bit(h) >> 5], 1u << (coarse_bit(h) & 31));
     }
     __syncthreads();
     for (int e = threadIdx.x; e < PB_SLICE; e += 1024) head[(int64_t)p * PB_SLICE + e] = lhead[e];
@@ -413,11 +423,107 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
 }
 
+// The same kernel for tiny build sides: 1024 threads = four 256-thread groups, each owning one
+// 2048-row block per step; the workgroup first copies the coarse bitmap into LDS (one workgroup per
+// CU, so 128 KiB x 256 of traffic in all) and a probe reads the L2 bitmap only when its coarse
+// bit is set (the others read word 0: one request per wave instead of one per lane).
+template <int KW, int WK, bool SEL, int NK>
+__global__ __launch_bounds__(1024) void join_cand_coarse_kernel(const void *__restrict__ keycol, const void *__restrict__ keycol2,
+                                                                const int32_t *__restrict__ sel, int64_t n, Bloom bl,
+                                                                const void *__restrict__ wdata, long long wlo, long long whi,
+                                                                uint16_t *__restrict__ cand, int32_t *__restrict__ ccount,
+                                                                int64_t nb) {
+    extern __shared__ unsigned co_lds[];          // CO_WORDS words, then the per-group wave counts
+    int (*wc)[JP_ROUNDS][4] = reinterpret_cast<int (*)[JP_ROUNDS][4]>(co_lds + CO_WORDS);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bl.coarse);
+        uint4 *dst = reinterpret_cast<uint4 *>(co_lds);
+        for (int e = threadIdx.x; e < CO_WORDS / 4; e += 1024) dst[e] = src[e];
+    }
+    __syncthreads();
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int64_t it = 0; (it * gridDim.x + blockIdx.x) * 4 < nb; it++) {
+        const int64_t blk = (it * gridDim.x + blockIdx.x) * 4 + grp;
+        const bool have = blk < nb;
+        const int64_t base = blk * JP_CHUNK;
+        unsigned long long bal[JP_ROUNDS];
+        int64_t r[JP_ROUNDS];
+        bool ok[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            const int64_t i = base + rr * 256 + tid;
+            ok[rr] = have && i < n;
+            const int64_t ic = ok[rr] ? i : 0;
+            r[rr] = SEL ? (int64_t)sel[ic] : ic;
+        }
+        if (WK != 0) {
+            long long w[JP_ROUNDS];
+#pragma unroll
+            for (int rr = 0; rr < JP_ROUNDS; rr++)
+                w[rr] = WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
+                        : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]];
+#pragma unroll
+            for (int rr = 0; rr < JP_ROUNDS; rr++) {
+                ok[rr] = ok[rr] && w[rr] >= wlo && w[rr] <= whi;
+                if (!ok[rr]) r[rr] = 0;
+            }
+        }
+        unsigned long long k[JP_ROUNDS], k2[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            k[rr] = load_kw<KW>(keycol, r[rr]);
+            k2[rr] = NK == 2 ? load_kw<KW>(keycol2, r[rr]) : 0ull;
+        }
+        unsigned word[JP_ROUNDS], msk[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[rr]);   // load_keys' hash
+            if (NK == 2) hh = mix64(hh ^ k2[rr]);
+            msk[rr] = bloom_mask(hh >> 24);
+            const unsigned cb = coarse_bit(hh);
+            ok[rr] = ok[rr] && ((co_lds[cb >> 5] >> (cb & 31)) & 1u);
+            word[rr] = bl.bits[ok[rr] ? bloom_word(bl, hh) : 0];
+        }
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            bal[rr] = __ballot(ok[rr] && (word[rr] & msk[rr]) == msk[rr]);
+            if (lane == 0) wc[grp][rr][wv] = __popcll(bal[rr]);
+        }
+        __syncthreads();
+        if (have) {
+            uint16_t *dst = cand + base;
+            int before = 0;
+#pragma unroll
+            for (int rr = 0; rr < JP_ROUNDS; rr++) {
+                int off = before;
+                for (int q = 0; q < wv; q++) off += wc[grp][rr][q];
+                if ((bal[rr] >> lane) & 1) dst[off + __popcll(bal[rr] & ((1ull << lane) - 1ull))] = (uint16_t)(rr * 256 + tid);
+                before += wc[grp][rr][0] + wc[grp][rr][1] + wc[grp][rr][2] + wc[grp][rr][3];
+            }
+            if (tid == 0) ccount[blk] = before;
+        }
+        __syncthreads();   // the counts are rewritten in the next step
+    }
+}
+
 template <int KW, int WK>
 static void launch_cand_fast(bool has_sel, int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w,
                              uint16_t *cand, int32_t *ccount) {
 #define PH_CAND_ARGS P.key[0].data, P.key[1].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount
-    if (P.nkeys == 2) {
+    if (bl.coarse) {   // tiny build side: coarse bitmap in LDS, one 1024-thread workgroup per CU
+        const size_t lds = (size_t)CO_WORDS * 4 + 4 * JP_ROUNDS * 4 * sizeof(int);
+        const int grid = std::min((nb + 3) / 4, g_cu_count);
+#define PH_COARSE(SELV, NKV)                                                                                            \
+    do {                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)join_cand_coarse_kernel<KW, WK, SELV, NKV>,                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+        join_cand_coarse_kernel<KW, WK, SELV, NKV><<<grid, 1024, lds, st>>>(PH_CAND_ARGS, (int64_t)nb);                 \
+    } while (0)
+        if (P.nkeys == 2) { if (has_sel) PH_COARSE(true, 2); else PH_COARSE(false, 2); }
+        else { if (has_sel) PH_COARSE(true, 1); else PH_COARSE(false, 1); }
+#undef PH_COARSE
+    } else if (P.nkeys == 2) {
         if (has_sel) join_cand_fast_kernel<KW, WK, true, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
         else join_cand_fast_kernel<KW, WK, false, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
     } else {
@@ -715,6 +821,7 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->head) j->ctx->pool_release(j->head);
     if (j->next) j->ctx->pool_release(j->next);
     if (j->bloom.bits) j->ctx->pool_release(j->bloom.bits);
+    if (j->bloom.coarse) j->ctx->pool_release(j->bloom.coarse);
     if (j->count_dev) j->ctx->pool_release(j->count_dev);
     delete j;
 }
@@ -775,6 +882,10 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
             j->bloom.hi_shift = (uint32_t)(logw - logp);
             j->bloom.inner_mask = ((uint64_t)(bits / 32) >> logp) - 1;
         }
+    }
+    if (bits && n <= (256ll << 10)) {   // tiny build side: the LDS-resident coarse bitmap of the probe
+        if (ctx->pool_alloc(ph::CO_WORDS * 4, (void **)&j->bloom.coarse) != PH_OK) return fail("alloc(coarse)");
+        if (hipMemsetAsync(j->bloom.coarse, 0, (size_t)ph::CO_WORDS * 4, ctx->stream) != hipSuccess) return fail("memset");
     }
     // number of inserted (non-NULL-key) rows: stays on the device until ph_join_count asks, so
     // building a table costs no host round trip
@@ -915,7 +1026,7 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
         int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
         if (!selective) ph::join_cand_all_kernel<<<(int)nb, 256, 0, ctx->stream>>>(n, cand, ccount);
-        else if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount))
+        else if ((ph::g_cu_count = ctx->cu_count, !ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, where, cand, ccount)))
             ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, where, cand, ccount);
         if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
             ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
@@ -951,6 +1062,7 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
         const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
         const ph::RangePred none{0, nullptr, nullptr, 0, 0};
         PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream));
+        ph::g_cu_count = ctx->cu_count;
         if (!ph::try_cand_fast((int)nb, ctx->stream, P, j->bloom, none, cand, ccount))
             ph::join_cand_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, j->bloom, none, cand, ccount);
         if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
