@@ -144,7 +144,14 @@ def main():
         plans[b].run()
         if world > 1:
             if backend == "nccl":
-                works[b] = dist.all_gather_into_tensor(gaths[b], locals_[b], async_op=True)
+                if state.get("sync_only"):
+                    dist.all_gather_into_tensor(gaths[b], locals_[b])
+                else:
+                    try:
+                        works[b] = dist.all_gather_into_tensor(gaths[b], locals_[b], async_op=True)
+                    except (RuntimeError, TypeError):   # every rank fails alike: fall back to the blocking form
+                        state["sync_only"] = True
+                        dist.all_gather_into_tensor(gaths[b], locals_[b])
             else:  # gloo rehearsal: through host memory
                 torch.cuda.synchronize()
                 works[b] = dist.all_gather_into_tensor(gaths[b], locals_[b].cpu(), async_op=True)
