@@ -575,52 +575,96 @@ __device__ __forceinline__ void bulk_row_keys(const AggSinkParams &S, int64_t r,
     }
 }
 
-template <int NK>
+// BU rows per thread with their key reads issued together: keys without NULLs (PLAINK) sit behind
+// one wave-uniform branch per column on its width instead of a per-row type switch.
+constexpr int BU = 4;
+
+template <int NK, bool PLAINK>
+__device__ __forceinline__ void bulk_keys_batch(const AggSinkParams &S, int64_t base, int64_t i1, int64_t (&ii)[BU], int64_t (&rr)[BU],
+                                                unsigned long long (&k)[BU][AGG_MAX_KEYS], unsigned (&nm)[BU]) {
+#pragma unroll
+    for (int u = 0; u < BU; u++) {
+        ii[u] = base + u * 256 + threadIdx.x;
+        const int64_t ic = ii[u] < i1 ? ii[u] : i1 - 1;
+        rr[u] = S.sel ? (int64_t)S.sel[ic] : ic;
+        nm[u] = 0;
+#pragma unroll
+        for (int c = 0; c < AGG_MAX_KEYS; c++) k[u][c] = 0;
+    }
+    if (PLAINK) {
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            const int t = S.key[c].type;
+            if (t == PH_I32 || t == PH_DATE) {
+#pragma unroll
+                for (int u = 0; u < BU; u++) k[u][c] = (unsigned long long)(long long)((const int32_t *)S.key[c].data)[rr[u]];
+            } else if (t == PH_CODE8) {
+#pragma unroll
+                for (int u = 0; u < BU; u++) k[u][c] = ((const uint8_t *)S.key[c].data)[rr[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < BU; u++) k[u][c] = ((const unsigned long long *)S.key[c].data)[rr[u]];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < BU; u++) bulk_row_keys<NK>(S, rr[u], k[u], &nm[u]);
+    }
+}
+
+template <int NK, bool PLAINK>
 __global__ __launch_bounds__(256) void bulk_count_kernel(BulkParams B) {
     extern __shared__ int hist[];
     for (int e = threadIdx.x; e < B.nparts; e += 256) hist[e] = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < B.S.n ? i0 + B.rows_per_wg : B.S.n;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const int64_t r = B.S.sel ? B.S.sel[i] : i;
-        unsigned long long k[AGG_MAX_KEYS];
-        unsigned nm;
-        bulk_row_keys<NK>(B.S, r, k, &nm);
-        atomicAdd(&hist[(keys_hash(k, nm, NK) >> 40) & (B.nparts - 1)], 1);
+    for (int64_t base = i0; base < i1; base += 256 * BU) {
+        int64_t ii[BU], rr[BU];
+        unsigned long long k[BU][AGG_MAX_KEYS];
+        unsigned nm[BU];
+        bulk_keys_batch<NK, PLAINK>(B.S, base, i1, ii, rr, k, nm);
+#pragma unroll
+        for (int u = 0; u < BU; u++)
+            if (ii[u] < i1) atomicAdd(&hist[(keys_hash(k[u], nm[u], NK) >> 40) & (B.nparts - 1)], 1);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < B.nparts; e += 256) B.counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
 }
 
-template <int NK>
+template <int NK, bool PLAINK>
 __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
     extern __shared__ int cursor[];
     for (int e = threadIdx.x; e < B.nparts; e += 256) cursor[e] = B.counts[(int64_t)e * gridDim.x + blockIdx.x];
     __syncthreads();
     const int64_t n = B.S.n;
     const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < n ? i0 + B.rows_per_wg : n;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const int64_t r = B.S.sel ? B.S.sel[i] : i;
-        unsigned long long k[AGG_MAX_KEYS];
-        unsigned nm;
-        bulk_row_keys<NK>(B.S, r, k, &nm);
-        const int pos = atomicAdd(&cursor[(keys_hash(k, nm, NK) >> 40) & (B.nparts - 1)], 1);
-        unsigned long long *rec = B.rec + (int64_t)pos * B.rec_words;
+    for (int64_t base = i0; base < i1; base += 256 * BU) {
+        int64_t ii[BU], rr[BU];
+        unsigned long long k[BU][AGG_MAX_KEYS];
+        unsigned nm[BU];
+        bulk_keys_batch<NK, PLAINK>(B.S, base, i1, ii, rr, k, nm);
 #pragma unroll
-        for (int c = 0; c < NK; c++) rec[c] = k[c];
-        rec[NK] = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
-        unsigned vbits = 0;
-        const int64_t ar = B.S.positional ? i : r;
-        for (int j = 0; j < B.nused; j++) {
-            const AggCol &c = B.S.arg[B.used_col[j]];
-            long long v = 0;
-            if (bit_valid(c.validity, ar)) {
-                vbits |= 1u << j;
-                v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+        for (int u = 0; u < BU; u++) {
+            if (ii[u] >= i1) continue;
+            const int64_t i = ii[u], r = rr[u];
+            const int pos = atomicAdd(&cursor[(keys_hash(k[u], nm[u], NK) >> 40) & (B.nparts - 1)], 1);
+            unsigned long long *rec = B.rec + (int64_t)pos * B.rec_words;
+#pragma unroll
+            for (int c = 0; c < NK; c++) rec[c] = k[u][c];
+            rec[NK] = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
+            unsigned vbits = 0;
+            const int64_t ar = B.S.positional ? i : r;
+            for (int j = 0; j < B.nused; j++) {
+                const AggCol &c = B.S.arg[B.used_col[j]];
+                long long v = 0;
+                if (bit_valid(c.validity, ar)) {
+                    vbits |= 1u << j;
+                    v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+                }
+                rec[NK + 1 + j] = (unsigned long long)v;
             }
-            rec[NK + 1 + j] = (unsigned long long)v;
+            rec[NK + 1 + B.nused] = (unsigned long long)nm[u] | ((unsigned long long)vbits << 8);
         }
-        rec[NK + 1 + B.nused] = (unsigned long long)nm | ((unsigned long long)vbits << 8);
     }
 }
 
@@ -962,9 +1006,13 @@ template <int NK>
 int bulk_launch(ph_agg *a, ph::BulkParams &B, int nwg, size_t lds, int64_t nc, int64_t *total_dev, bool build_only) {
     hipStream_t st = a->ctx->stream;
     if (!build_only) {
-        ph::bulk_count_kernel<NK><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+        bool plaink = true;
+        for (int c = 0; c < NK; c++) plaink = plaink && !B.S.key[c].validity;
+        if (plaink) ph::bulk_count_kernel<NK, true><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+        else ph::bulk_count_kernel<NK, false><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
         PH_CHECK(ph::exclusive_scan_i32(a->ctx, B.counts, nc, total_dev));
-        ph::bulk_scatter_kernel<NK><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+        if (plaink) ph::bulk_scatter_kernel<NK, true><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
+        else ph::bulk_scatter_kernel<NK, false><<<nwg, 256, (size_t)B.nparts * 4, st>>>(B);
     }
     // up to 120 KiB of LDS per workgroup: above the default dynamic limit
     PH_HIP(hipFuncSetAttribute((const void *)ph::bulk_build_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
