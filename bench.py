@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the hot path on MI355X, one process per GPU.
 
-A "step" is one pass of the fused Agg <- Scan(filter) pipeline (TPC-H Q1: filter + 4-group hash
-aggregate, 8 aggregates) over the rank's device-resident lineitem shard, plus — for N > 1 — the
-merge of the per-rank partial group rows (a few hundred bytes, all-gathered over RCCL).
-The data path needs no collective: lineitem is partitioned by order ranges across ranks
-(weak scaling: every rank holds an SF`--sf` shard of an SF(sf*N) database).
+Headline: a "step" is one pass of the fused Agg <- Scan(filter) pipeline (TPC-H Q1: filter +
+4-group hash aggregate, 8 aggregates) over the rank's device-resident lineitem shard, plus — for
+N > 1 — the merge of the per-rank partial group rows (a few hundred bytes, all-gathered over RCCL
+through the C ABI's ph_comm_allgather, asynchronously behind the next step's scan).
+The Q1/Q6 data path needs no collective: lineitem is partitioned by order ranges across ranks.
+  --scaling weak   (default) every rank holds an SF`--sf` shard of an SF(sf*N) database
+  --scaling strong the SF`--sf` database is split N ways
 
-Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
-  roofline     dominant kernel (lowcard_chain_kernel): algorithmic bytes (34 B/row) / its average
-               launch duration measured with HIP events on the launch stream
-  cpu_baseline the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
+`python bench.py --gpus N` without a launcher starts the N ranks itself (a torch.distributed.run
+child, before anything touches the GPU in this process).
+
+ONE JSON line on rank 0 (driver contract). Besides the contract's fields:
+  roofline       dominant kernel of the headline: algorithmic bytes / average launch duration from
+                 HIP events on the launch stream; peak_measured = streaming-read ceiling measured in
+                 this run (ph_dev_read_reduce); traffic = HBM bytes of the committed PMC passes
+  cpu_baseline   the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
+  N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu (every BASELINE.json
+         config, each with its own roofline; Q3 with its own cpu_baseline)
+  N > 1: companion q3_partitioned — Q3 over an SF`--sf` database split N ways (strong scaling,
+         BASELINE.json config 4), join sides hash-partitioned by order key and exchanged with
+         ph_comm_exchange_columns; probe rows/s and exchange bytes against the xGMI peak
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,23 +38,431 @@ sys.path.insert(0, ROOT)
 Q1_BYTES_PER_ROW = 34  # qty 4 + ext/disc/tax 3x8 + flag 1 + status 1 + shipdate 4
 Q6_BYTES_PER_ROW = 24
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+XGMI_PEAK_GBS = 7 * 153.0  # per GPU, all 7 links busy (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(args, world, nrows):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command; KiB units, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM). Only valid for
-    the exact workload those passes ran (SF10, 1 GPU); null otherwise."""
-    if world != 1 or args.sf != 10 or nrows != 59986052:
-        return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        kern = "lowcard_chain_kernel" if args.query == "q1" else "filter_sumprod_kernel"
-        fetch = [e["avg"] for e in d[f"{args.query} FETCH_SIZE"] if kern in e["kernel"]][0]
-        write = [e["avg"] for e in d.get(f"{args.query} WRITE_SIZE", []) if kern in e["kernel"]]
-        return fetch * 1024 * 2 + (write[0] * 1024 if write else 0)
-    except Exception:
-        return None
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_summary.json, newest
+    round first: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py; KiB units,
+    FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM). Valid for the SF10 one-GPU workload
+    those passes ran; the caller passes None otherwise."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            q, kern = kernel_key
+            fetch = [e["avg"] for e in d[f"{q} FETCH_SIZE"] if kern in e["kernel"]][0]
+            write = [e["avg"] for e in d.get(f"{q} WRITE_SIZE", []) if kern in e["kernel"]]
+            return fetch * 1024 * 2 + (write[0] * 1024 if write else 0)
+        except Exception:  # noqa: BLE001 - an older summary without this kernel: try the next
+            continue
+    return None
+
+
+def spawn_ranks(args):
+    """--gpus N without WORLD_SIZE: start the N ranks as a child torch.distributed.run. Nothing in
+    this process has touched torch or HIP yet, and the launcher is a child, not an exec."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+class Harness:
+    """per-process state shared by the query benches"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from plan_amd import dist as pdist, hip
+        self.args, self.torch, self.dist, self.pdist, self.hip = args, torch, dist, pdist, hip
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+        # Rehearsal knob for a one-GPU box: PH_BENCH_BACKEND=gloo puts every rank on device 0 and
+        # carries the exchange protocol over gloo (the real runs: RCCL through the C ABI).
+        self.backend = os.environ.get("PH_BENCH_BACKEND", "nccl")
+        self.local_rank = local_rank if self.backend == "nccl" else 0
+        torch.cuda.set_device(self.local_rank)
+        # a non-default torch stream, shared with the library so torch.cuda.Event sees its kernels
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        self.ctx = hip.Ctx(self.local_rank, stream=self.stream.cuda_stream)
+        self.comm = None
+        if self.world > 1:
+            # torch.distributed over gloo is only the host side channel (communicator id, object
+            # gathers of the rehearsal); the data path is ph_comm = RCCL through the C ABI
+            dist.init_process_group("gloo")
+            if self.backend == "nccl":
+                self.comm = pdist.init_rccl(self.ctx)
+
+    def barrier(self):
+        if self.comm is not None:
+            self.comm.wait()
+            self.comm.barrier()
+        elif self.world > 1:
+            self.torch.cuda.synchronize()
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def allreduce(self, vals, op):
+        if self.world == 1:
+            return list(vals)
+        if self.comm is not None:
+            return self.comm.allreduce(vals, op)
+        t = self.torch.tensor(vals, dtype=self.torch.int64)
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}[op])
+        return [int(x) for x in t.tolist()]
+
+    def max_elapsed(self, seconds):
+        return self.allreduce([int(seconds * 1e9)], "max")[0] / 1e9
+
+    def events_ms(self, fn, reps):
+        """average / min duration of fn() from HIP events on the launch stream"""
+        T = self.torch
+        ev = [(T.cuda.Event(enable_timing=True), T.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(self.stream)
+            fn()
+            b.record(self.stream)
+        T.cuda.synchronize()
+        d = sorted(a.elapsed_time(b) for a, b in ev)
+        return sum(d) / len(d), d[0]
+
+    def peak_measured(self):
+        """streaming-read ceiling: read-only reduce over 2 GiB (>> the 256 MiB Infinity Cache)"""
+        nbytes = 2 << 30
+        buf = self.ctx.alloc(nbytes)
+        out = self.ctx.alloc(8 * 4096)
+        self.hip.check(self.hip.lib().ph_dev_memset(self.ctx.h, buf, 1, self.hip.i64(nbytes)))
+        best = 0.0
+        for grid in (256, 512, 1024):
+            self.hip.read_reduce(self.ctx, buf, nbytes, out, grid)
+            avg, _ = self.events_ms(lambda: self.hip.read_reduce(self.ctx, buf, nbytes, out, grid), 10)
+            best = max(best, nbytes / (avg * 1e-3) / 1e9)
+        self.ctx.free(buf)
+        self.ctx.free(out)
+        return best
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.ctx.close()
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def shard_orders(h, sf, scaling):
+    """(sf_total, first order, number of orders) of this rank's shard"""
+    from plan_amd import tpchgen
+    if scaling == "weak":
+        n = tpchgen.orders_count((sf, 1))
+        return (sf * h.world, 1), h.rank * n, n
+    n = tpchgen.orders_count((sf, 1))
+    a, b = h.rank * n // h.world, (h.rank + 1) * n // h.world
+    return (sf, 1), a, b - a
+
+
+def roofline(achieved, **extra):
+    d = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    d.update(extra)
+    return d
+
+
+# ---------------------------------------------------------------------------------- Q1 / Q6
+
+def bench_scan(h, query, sf, steps, warmup, scaling, L=None, table=None, with_exchange=True):
+    """fused scan plan over this rank's lineitem shard; returns (line dict, L, table)"""
+    import numpy as np
+    from plan_amd import queries, tpchgen
+    ctx, hip = h.ctx, h.hip
+    gen_s = load_s = 0.0
+    if table is None:
+        sf_total, first, n_ord = shard_orders(h, sf, scaling)
+        t0 = time.time()
+        L = tpchgen.lineitem(sf_total, first, n_ord, columns=["l_quantity", "l_extendedprice", "l_discount", "l_tax",
+                                                               "l_returnflag", "l_linestatus", "l_shipdate"])
+        gen_s = time.time() - t0
+        t0 = time.time()
+        table = queries.lineitem_table(ctx, L)
+        load_s = time.time() - t0
+    nrows = table.nrows
+    make = (lambda: queries.q1_plan(ctx, table)) if query == "q1" else (lambda: queries.q6_plan(ctx, table))
+    bytes_per_row = Q1_BYTES_PER_ROW if query == "q1" else Q6_BYTES_PER_ROW
+    exchange = with_exchange and h.world > 1
+    # N > 1: two plans (two partial-result buffers) alternate; the all-gather of step i runs on the
+    # communicator's stream and overlaps the scan of step i+1, which writes the OTHER buffer; a
+    # buffer's collective is waited for (stream-side) before its plan runs again.
+    plans = [make()] + ([make()] if exchange else [])
+    gath, nwords = [], 0
+    if exchange:
+        for pl in plans:
+            ptr, nwords = pl.partials_dev()
+            gath.append((hip.vp(ptr), ctx.alloc(h.world * nwords * 8)))
+    state = {"i": 0}
+
+    def step():
+        b = state["i"] % len(plans)
+        state["i"] += 1
+        if exchange and h.comm is not None:
+            h.comm.wait(keep=1)   # the collective that read THIS buffer (two steps ago) is done; the last one may still run
+        plans[b].run()
+        if exchange:
+            if h.comm is not None:
+                h.comm.allgather(gath[b][0], gath[b][1], nwords * 8, async_=True)
+            else:  # gloo rehearsal: through host memory
+                mine = ctx.download(gath[b][0], np.uint64, nwords)
+                state["host"] = np.concatenate(h.pdist._gather_objects(mine))
+
+    def merged_result():
+        if not exchange:
+            return plans[0].fetch()
+        last = (state["i"] - 1) % len(plans)
+        if h.comm is not None:
+            h.comm.wait()
+            words = ctx.download(gath[last][1], np.uint64, h.world * nwords)
+        else:
+            words = state["host"]
+        return plans[last].fetch_merged(words, h.world)
+
+    for _ in range(warmup):
+        step()
+    result = merged_result()
+    h.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    h.barrier()
+    elapsed = h.max_elapsed(time.perf_counter() - t0)
+    result = merged_result()
+    total_rows = h.allreduce([nrows], "sum")[0] if with_exchange else nrows
+
+    # roofline: per-launch duration of one ph_scan_plan_run (scan kernel + the 1-wave merge kernel)
+    avg_ms, min_ms = h.events_ms(plans[0].run, steps)
+    achieved = nrows * bytes_per_row / (avg_ms * 1e-3) / 1e9
+    kern = "lowcard_chain_kernel" if query == "q1" else "filter_sumprod_kernel"
+    traffic = pmc_traffic((query, kern)) if (h.world == 1 and nrows == 59986052) else None
+    line = {
+        "metric": "rows/sec through hash-agg (Q1)" if query == "q1" else "rows/sec through filter+SUM (Q6)",
+        "value": total_rows * steps / elapsed, "unit": "rows/s", "n_gpus": h.world if with_exchange else 1,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {
+            "workload": f"TPC-H {query.upper()} fused filter+hash-aggregate over lineitem, {nrows} rows on rank 0, "
+                        f"{total_rows} in total ({'SF%d per GPU' % sf if scaling == 'weak' else 'SF%d split %d ways' % (sf, h.world)}), "
+                        "table resident in HBM",
+            "rows_per_gpu": nrows, "kernel_family": plans[0].kind, "groups": result["ngroups"],
+            "rows_aggregated": sum(c[-1] for c in result["count"]) if query == "q1" else result["count"][0][0] if result["ngroups"] else 0,
+            "parallelism": (f"row-range shards x{h.world}; per step the raw partial group rows ({nwords * 8} B) are "
+                            f"all-gathered with ph_comm_allgather ({'RCCL' if h.comm is not None else 'gloo rehearsal'}) "
+                            "asynchronously behind the next step's scan") if exchange else "single GPU",
+            "generate_s": round(gen_s, 2), "pcie_load_s": round(load_s, 2),
+        },
+        "roofline": roofline(achieved, traffic=traffic, kernel=kern, avg_launch_ms=avg_ms, min_launch_ms=min_ms,
+                             algorithmic_bytes_per_launch=nrows * bytes_per_row),
+    }
+    for pl in plans:
+        pl.free()
+    for _, g in gath:
+        ctx.free(g)
+    return line, L, table
+
+
+# ---------------------------------------------------------------------------------- Q3
+
+def bench_q3(h, sf, steps, warmup, scaling):
+    """Q3: customer |x| orders |x| lineitem hash joins + 3-column group-by from the operator-granular
+    kernels; N > 1: join sides hash-partitioned by order key and exchanged (plan_amd/pipelines.py).
+    A step = one whole Q3, tables resident, top-10 rows on the host at the end."""
+    from plan_amd import pipelines, tpchgen
+    T = h.torch
+    sf_total, first, n_ord = shard_orders(h, sf, scaling)
+    tot_ord = tpchgen.orders_count(sf_total)
+    tot_cust = tot_ord // 10
+    c0, c1 = h.rank * tot_cust // h.world, (h.rank + 1) * tot_cust // h.world
+    L = tpchgen.lineitem(sf_total, first, n_ord, columns=["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
+    Od = tpchgen.orders(sf_total, first, n_ord, columns=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+    C = tpchgen.customer(sf_total, c0, c1 - c0)
+    nrows, n_o, n_c = len(L["l_orderkey"]), len(Od["o_orderkey"]), len(C["c_custkey"])
+    pipe = pipelines.Q3Pipeline(h.ctx, L, Od, C)
+    pipe.time_stages = False   # the measured steps run without a host sync per stage
+    for _ in range(warmup):
+        r = pipe.run()
+    h.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = pipe.run()
+    h.barrier()
+    elapsed = h.max_elapsed(time.perf_counter() - t0)
+    # stage times for the report: a few extra steps, outside the timed region, with a sync per stage
+    pipe.time_stages = True
+    ev = (T.cuda.Event(enable_timing=True), T.cuda.Event(enable_timing=True))
+    pipe.probe_events = ev
+    probe_dev_ms, agg_t, stage_steps = 0.0, {}, min(steps, 10)
+    for _ in range(stage_steps):
+        r = pipe.run()
+        for k, v in r["timings"].items():
+            agg_t[k] = agg_t.get(k, 0) + v
+        if "lineitem_filter_probe" in r["timings"]:
+            T.cuda.synchronize()
+            probe_dev_ms += ev[0].elapsed_time(ev[1])
+    h.barrier()
+    total_rows = h.allreduce([nrows], "sum")[0]
+    probe_rows = agg_t["probe_rows"] / stage_steps
+    fused = "lineitem_filter_probe" in agg_t
+    probe_ms = agg_t["lineitem_filter_probe" if fused else "lineitem_probe"] / stage_steps * 1e3
+    host_probe_ms = probe_ms
+    if fused and probe_dev_ms > 0:
+        probe_ms = probe_dev_ms / stage_steps   # HIP events on the launch stream: the stage's kernels only
+    pairs = r["join_rows"]
+    kept = pipe.lineitem_filter_rows()
+    # probe-stage algorithmic bytes, counted once (BASELINE.md's Q3 row): fused Filter -> probe reads
+    # every lineitem row's l_shipdate (4 B) and 16 B per row the filter keeps (selection entry 4 + key
+    # 8 + bucket head 4), plus per output pair next 4 + build key 8 + the pair 8 + its selection
+    # entry 4. Implementation passes (candidate slices, the emit kernel's second walk) are NOT counted.
+    probe_bytes = (nrows * 4 + kept * 16 + pairs * 24) if fused else (probe_rows * 16 + pairs * 24)
+    # whole query (SURVEY §8d): inputs read once + 16 B per build row written + 16 B per probe row
+    # read + 32 B per join-output row for the group table
+    build_rows = r.get("build_rows", 0)
+    whole_bytes = n_c * 5 + n_o * 20 + nrows * 28 + build_rows * 16 + (kept + pipe.orders_filter_rows()) * 16 + pairs * 32
+    ms_step = elapsed / steps * 1e3
+    sent = agg_t.get("exchange_bytes_sent", 0) / stage_steps
+    exch_ms = agg_t.get("lineitem_exchange", 0) / stage_steps * 1e3
+    line = {
+        "metric": "rows/sec through hash-join probe + hash-agg (Q3)",
+        "value": total_rows * steps / elapsed, "unit": "rows/s", "n_gpus": h.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"TPC-H Q3 over customer/orders/lineitem, {nrows} lineitem rows on rank 0, {total_rows} in total "
+                        f"({'SF%d per GPU' % sf if scaling == 'weak' else 'SF%d split %d ways' % (sf, h.world)}), tables resident in HBM",
+            "groups_rank0": r["ngroups"], "join_rows_rank0": pairs,
+            "parallelism": (f"customer keys broadcast (ph_comm_allgather_rows), orders and lineitem rows hash-partitioned by order key "
+                            f"x{h.world} (ph_partition_dev) and exchanged with ph_comm_exchange_columns "
+                            f"({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if h.world > 1 else "single GPU",
+            "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk not in ("probe_rows", "exchange_bytes_sent")},
+            "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage (the timed steps have none)",
+            "probe_rows_per_s": probe_rows / (probe_ms * 1e-3),
+            "top1": list(r["top"][0]) if r["top"] else None,
+        },
+        "roofline": roofline(probe_bytes / (probe_ms * 1e-3) / 1e9,
+                             traffic=pmc_traffic(("q3", "join_cand_fast_kernel")) if (h.world == 1 and nrows == 59986052) else None,
+                             kernel="join_cand_fast_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
+                             avg_launch_ms=probe_ms, algorithmic_bytes_per_launch=probe_bytes,
+                             timing="HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
+                             host_timed_stage_ms=host_probe_ms,
+                             whole_query={"algorithmic_bytes": whole_bytes, "achieved": whole_bytes / (ms_step * 1e-3) / 1e9,
+                                          "frac": whole_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}),
+    }
+    if h.world > 1:
+        line["exchange"] = {"bytes_sent_rank0_per_step": sent, "lineitem_exchange_ms": exch_ms,
+                            "achieved_GBps": sent / (exch_ms * 1e-3) / 1e9 if exch_ms > 0 else None,
+                            "xgmi_peak_GBps": XGMI_PEAK_GBS, "note": "lineitem side of the order-key stage: 24 B per row sent to other ranks"}
+    pipe.free()
+    return line
+
+
+# ---------------------------------------------------------------------------------- Q9
+
+def bench_q9(h, sf, steps, warmup):
+    """Q9: LIKE + four hash joins (one composite) + profit expression + 175-group aggregate
+    (plan_amd/pipelines.py Q9Pipeline). A step = one whole Q9. One GPU."""
+    from plan_amd import pipelines, tpchgen
+    sf_total = (sf, 1)
+    L = tpchgen.lineitem(sf_total, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"])
+    Od = tpchgen.orders(sf_total, columns=["o_orderkey", "o_orderdate"])
+    P, PS, S = tpchgen.part(sf_total), tpchgen.partsupp(sf_total), tpchgen.supplier(sf_total)
+    nrows = len(L["l_orderkey"])
+    pipe = pipelines.Q9Pipeline(h.ctx, L, Od, P, PS, S)
+    pipe.time_stages = False
+    for _ in range(warmup):
+        r = pipe.run()
+    h.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = pipe.run()
+    h.torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pipe.time_stages = True
+    agg_t, stage_steps = {}, min(steps, 10)
+    for _ in range(stage_steps):
+        r = pipe.run()
+        for k, v in r["timings"].items():
+            agg_t[k] = agg_t.get(k, 0) + v
+    # algorithmic bytes, SURVEY §8(d)'s accounting over the six inputs, each read once:
+    # lineitem (partkey 4 + suppkey 4 + orderkey 8 + ext 8 + disc 8 + qty 4 = 36 B), part (key 4 +
+    # name offsets 4 + name bytes), partsupp (4+4+8), supplier (4+4), orders (8+4), nation negligible
+    inputs = (nrows * 36 + len(P["p_partkey"]) * 8 + len(P["p_name_bytes"]) + len(PS["ps_partkey"]) * 16 +
+              len(S["s_suppkey"]) * 8 + len(Od["o_orderkey"]) * 12)
+    ms_step = elapsed / steps * 1e3
+    line = {
+        "metric": "rows/sec through 4 hash joins + hash-agg (Q9)", "value": nrows * steps / elapsed, "unit": "rows/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "config": {"workload": f"TPC-H Q9 at SF{sf} ({nrows} lineitem rows), tables resident in HBM",
+                   "groups": r["ngroups"], "join_rows": r["join_rows"],
+                   "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk != "exchange_bytes_sent"},
+                   "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage"},
+        "roofline": roofline(inputs / (ms_step * 1e-3) / 1e9, traffic=None, kernel="whole query (all kernels of one Q9)",
+                             avg_launch_ms=ms_step, algorithmic_bytes_per_launch=inputs,
+                             timing="host clock around the timed steps (one query = ~40 launches)"),
+    }
+    pipe.free()
+    return line
+
+
+# ---------------------------------------------------------------------------------- CPU baselines
+
+def cpu_baselines(L, max_rows):
+    """the oracle (CPU restatement of the reference path) on the GPU box's host cores"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import tpch_data
+    from plan_amd import queries, tpchgen
+    out = {}
+    n = len(L["l_shipdate"])
+    m = min(n, max_rows)
+    sample = {k: v[:m] for k, v in L.items()}
+    t0 = time.perf_counter()
+    O.q1(sample, queries.q1_shipdate_cutoff())
+    dt = time.perf_counter() - t0
+    ncpu = os.cpu_count()
+    out["q1"] = {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+                 "sample": f"first {m} rows of the same lineitem shard, oracle q1 pipeline (chunked 2048-row CPU restatement of the "
+                           f"reference path, single thread like the reference), {dt:.1f} s, host has {ncpu} logical CPUs"}
+    # all cores, NOT reference-faithful (the reference runs one goroutine): the same pipeline on
+    # disjoint row slices from a thread pool (the oracle calls release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    k = max(1, min(64, ncpu or 1))
+    per = min(n // k, 2_000_000)
+    if per >= 4096:
+        slices = [{c: v[i * per:(i + 1) * per] for c, v in L.items()} for i in range(k)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(k) as ex:
+            list(ex.map(lambda s: O.q1(s, queries.q1_shipdate_cutoff()), slices))
+        dt2 = time.perf_counter() - t0
+        out["q1_all_cores"] = {"value": k * per / dt2, "unit": "rows/s", "cores": k, "kind": "port",
+                               "sample": f"{k} threads x {per} rows, {dt2:.1f} s — not reference-faithful (the reference is single-threaded)"}
+    t0 = time.perf_counter()
+    O.q6(sample, *queries.q6_constants())
+    dt = time.perf_counter() - t0
+    out["q6"] = {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": f"first {m} rows, oracle q6 pipeline, {dt:.1f} s"}
+    t1 = tpch_data.load(1, 1, q9=False)
+    t0 = time.perf_counter()
+    O.q3(t1, "HOUSEHOLD", tpchgen.days(1995, 3, 29))
+    dt = time.perf_counter() - t0
+    nl = len(t1["lineitem"]["l_orderkey"])
+    out["q3"] = {"value": nl / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+                 "sample": f"oracle q3 pipeline at SF1 ({nl} lineitem rows; the SF10 run would take ~10x), {dt:.1f} s"}
+    return out
 
 
 def main():
@@ -48,440 +470,93 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sf", type=int, default=10, help="scale factor of each rank's lineitem shard")
+    ap.add_argument("--sf", type=int, default=10, help="scale factor (per GPU for weak scaling, total for strong)")
     ap.add_argument("--query", default="q1", choices=["q1", "q6", "q3", "q9"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-q3", action="store_true", help="skip the Q3 companion measurement of the default (q1, N=1) run")
+    ap.add_argument("--no-companions", action="store_true", help="headline query only")
     ap.add_argument("--cpu-rows", type=int, default=16_000_000)
+    ap.add_argument("--companion-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    from plan_amd import hip, queries, tpchgen
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    # Rehearsal knob for a one-GPU box: PH_BENCH_BACKEND=gloo puts every rank on device 0 and runs
-    # the collectives over gloo on CPU tensors (the real runs use nccl = RCCL, one GPU per rank).
-    backend = os.environ.get("PH_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    cdev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    if args.query == "q3":
-        return bench_q3(args, rank, local_rank, world)
-    if args.query == "q9":
-        return bench_q9(args, rank, local_rank, world)
-
-    # ---- this rank's shard: orders [rank*n, (rank+1)*n) of an SF(sf*world) database
-    sf_total = (args.sf * world, 1)
-    orders_per_rank = tpchgen.orders_count((args.sf, 1))
-    t0 = time.time()
-    cols = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag",
-            "l_linestatus", "l_shipdate"]
-    L = tpchgen.lineitem(sf_total, rank * orders_per_rank, orders_per_rank, columns=cols)
-    nrows = len(L["l_shipdate"])
-    gen_s = time.time() - t0
-
-    # a non-default torch stream, shared with the library so torch.cuda.Event sees its kernels
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    ctx = hip.Ctx(local_rank, stream=stream.cuda_stream)
-    t0 = time.time()
-    table = queries.lineitem_table(ctx, L)
-    load_s = time.time() - t0
-    if args.query == "q1":
-        plan = queries.q1_plan(ctx, table)
-        bytes_per_row = Q1_BYTES_PER_ROW
+    h = Harness(args)
+    rank0 = h.rank == 0
+    comp_steps, comp_warm = min(args.steps, 30), min(args.warmup, 3)
+    if args.query in ("q1", "q6"):
+        out, L, table = bench_scan(h, args.query, args.sf, args.steps, args.warmup, args.scaling)
+    elif args.query == "q3":
+        out, L, table = bench_q3(h, args.sf, args.steps, args.warmup, args.scaling), None, None
     else:
-        plan = queries.q6_plan(ctx, table)
-        bytes_per_row = Q6_BYTES_PER_ROW
+        if world != 1:
+            raise SystemExit("--query q9 is a one-GPU bench")
+        out, L, table = bench_q9(h, args.sf, args.steps, args.warmup), None, None
+    out["roofline"]["peak_measured"] = h.peak_measured()
+    out["roofline"]["frac_of_measured"] = out["roofline"]["achieved"] / out["roofline"]["peak_measured"]
+    out["config"]["rccl_ranks"] = h.comm.n if h.comm is not None else (1 if world == 1 else f"gloo rehearsal x{world}")
 
-    # ---- N > 1: every step ends with the cross-rank exchange of the raw partial result (a few
-    # hundred bytes, all-gathered on the device over RCCL behind the scan kernels). Two plans
-    # (two partial-result buffers) alternate, and the all-gather of step i is asynchronous: it
-    # overlaps the scan of step i+1, which writes the OTHER buffer; a buffer's collective is waited
-    # for (stream-side) before its plan runs again, and all are drained before the closing barrier.
-    # The merged group rows are decoded once after the timed loop, like the N = 1 case fetches its
-    # result once after the loop.
-    make_plan = (lambda: queries.q1_plan(ctx, table)) if args.query == "q1" else (lambda: queries.q6_plan(ctx, table))
-    plans = [plan] + ([make_plan()] if world > 1 else [])
-    nbuf = len(plans)
-    locals_, gaths, works = [], [], [None] * nbuf
-    if world > 1:
-        for pl in plans:
-            ptr, nwords = pl.partials_dev()
+    # ---- companions: never fatal for the headline, and bounded in time (a wedged collective on
+    # one rank must not cost the line): a watchdog prints what is there and ends every rank
+    done = threading.Event()
 
-            class _DevView:  # zero-copy torch view of the plan's device result words
-                __cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i8", "data": (ptr, False), "version": 2}
-            locals_.append(torch.as_tensor(_DevView(), device="cuda"))
-            gaths.append(torch.empty(world * nwords, dtype=torch.int64, device=cdev if backend != "nccl" else "cuda"))
-    state = {"i": 0}
+    def watchdog():
+        if not done.wait(args.companion_timeout):
+            if rank0:
+                out.setdefault("companion_error", f"companions exceeded {args.companion_timeout:.0f} s; stopped")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
 
-    def step():
-        b = state["i"] % nbuf
-        state["i"] += 1
-        if works[b] is not None:      # the exchange that read this plan's partials must be done
-            works[b].wait()
-            works[b] = None
-        plans[b].run()
-        if world > 1:
-            if backend == "nccl":
-                if state.get("sync_only"):
-                    dist.all_gather_into_tensor(gaths[b], locals_[b])
-                else:
-                    try:
-                        works[b] = dist.all_gather_into_tensor(gaths[b], locals_[b], async_op=True)
-                    except (RuntimeError, TypeError):   # every rank fails alike: fall back to the blocking form
-                        state["sync_only"] = True
-                        dist.all_gather_into_tensor(gaths[b], locals_[b])
-            else:  # gloo rehearsal: through host memory
-                torch.cuda.synchronize()
-                works[b] = dist.all_gather_into_tensor(gaths[b], locals_[b].cpu(), async_op=True)
+    companions = args.query == "q1" and not args.no_companions
+    if companions:
+        threading.Thread(target=watchdog, daemon=True).start()
 
-    def drain():
-        for b in range(nbuf):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
-
-    def merged_result():
-        if world == 1:
-            return plan.fetch()
-        drain()
-        torch.cuda.synchronize()
-        last = (state["i"] - 1) % nbuf
-        return plans[last].fetch_merged(gaths[last].cpu().numpy().view(np.uint64), world)
-
-    def barrier():
-        drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    result = merged_result()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    result = merged_result()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([nrows], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tot)
-        total_rows = int(tot.item())
-    else:
-        total_rows = nrows
-
-    # ---- roofline: per-launch duration of the scan kernel sequence with HIP events on the
-    # launch stream (events bracket one ph_scan_plan_run = scan kernel + the 1-wave merge kernel;
-    # no exchange inside the bracket)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    for a, b in ev:
-        a.record(stream)
-        plan.run()
-        b.record(stream)
-    torch.cuda.synchronize()
-    durs = sorted(a.elapsed_time(b) for a, b in ev)
-    avg_ms = sum(durs) / len(durs)
-    achieved = nrows * bytes_per_row / (avg_ms * 1e-3) / 1e9
-
-    # ---- sanity: the result of the timed query must be self-consistent
-    ngroups = result["ngroups"]
-    rows_out = sum(c[-1] for c in result["count"]) if args.query == "q1" else None
-
-    out = None
-    if rank == 0:
-        value = total_rows * args.steps / elapsed
-        out = {
-            "metric": "rows/sec through hash-agg (Q1)" if args.query == "q1" else "rows/sec through filter+SUM (Q6)",
-            "value": value,
-            "unit": "rows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"TPC-H {args.query.upper()} fused filter+hash-aggregate over SF{args.sf} "
-                            f"lineitem per GPU ({nrows} rows on rank 0, {total_rows} total), "
-                            "table resident in HBM",
-                "rows_per_gpu": nrows,
-                "kernel_family": plan.kind,
-                "groups": ngroups,
-                "rows_aggregated": rows_out,
-                "parallelism": f"row-range shards x{world}, per-step all-gather of the partial group rows (asynchronous, double-buffered: it overlaps the next step's scan)",
-                "generate_s": round(gen_s, 2),
-                "pcie_load_s": round(load_s, 2),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args, world, nrows),
-                "kernel": "lowcard_chain_kernel" if args.query == "q1" else "filter_sumprod_kernel",
-                "avg_launch_ms": avg_ms,
-                "min_launch_ms": durs[0],
-                "algorithmic_bytes_per_launch": nrows * bytes_per_row,
-            },
-        }
-
-    # ---- CPU baseline (rank 0, N=1 only): the oracle on a bounded sample of the same rows
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        m = min(nrows, args.cpu_rows)
-        sample = {k: v[:m] for k, v in L.items()}
-        t0 = time.perf_counter()
-        if args.query == "q1":
-            O.q1(sample, queries.q1_shipdate_cutoff())
-        else:
-            O.q6(sample, *queries.q6_constants())
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": m / dt,
-            "unit": "rows/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": f"first {m} rows of the same lineitem shard, oracle {args.query} pipeline "
-                      f"(chunked 2048-row CPU restatement of the reference path), {dt:.1f} s, "
-                      f"host has {os.cpu_count()} logical CPUs",
-        }
-    for pl in plans:
-        pl.free()
-    table.free()
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    # ---- the metric's second half (hash-join probe, Q3) on the same GPU, N = 1 only: extra fields of
-    # the same line, measured after (outside) the Q1 timing; a failure here never costs the Q1 line
-    if rank == 0 and world == 1 and args.query == "q1" and not args.no_q3:
+    def attempt(name, fn):
         try:
-            del L
-            a3 = argparse.Namespace(**vars(args))
-            a3.query, a3.steps, a3.warmup = "q3", min(args.steps, 30), min(args.warmup, 3)
-            q3 = bench_q3(a3, 0, local_rank, 1, emit=False)
-            out["q3_single_gpu"] = {"metric": q3["metric"], "value": q3["value"], "unit": q3["unit"],
-                                    "ms_per_step": q3["ms_per_step"], "steps": q3["steps"],
-                                    "probe_rows_per_s": q3["config"]["probe_rows_per_s"],
-                                    "stage_ms": q3["config"]["stage_ms"], "roofline": q3["roofline"]}
-        except Exception as e:  # noqa: BLE001 - reported, never fatal for the Q1 line
-            out["q3_single_gpu"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0:
-        print(json.dumps(out))
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    def brief(line):
+        return {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "scaling", "config", "roofline", "exchange") if k in line}
 
-def bench_q3(args, rank, local_rank, world, emit=True):
-    """Q3: customer |x| orders |x| lineitem hash joins + 3-column group-by, assembled from the
-    operator-granular kernels; for N > 1 the join sides are hash-partitioned by order key and
-    exchanged with RCCL all-to-all (plan_amd/pipelines.py). A step = one whole Q3."""
-    import torch
-    import torch.distributed as dist
-
-    from plan_amd import hip, pipelines, tpchgen
-
-    sf_total = (args.sf * world, 1)
-    n_ord = tpchgen.orders_count((args.sf, 1))
-    n_cust = n_ord // 10
-    L = tpchgen.lineitem(sf_total, rank * n_ord, n_ord,
-                         columns=["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"])
-    Od = tpchgen.orders(sf_total, rank * n_ord, n_ord,
-                        columns=["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
-    C = tpchgen.customer(sf_total, rank * n_cust, n_cust)
-    nrows = len(L["l_orderkey"])
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)   # the library launches on this stream, so torch events time its kernels
-    ctx = hip.Ctx(local_rank, stream=stream.cuda_stream)
-    pipe = pipelines.Q3Pipeline(ctx, L, Od, C)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
-
-    pipe.time_stages = False   # the measured steps run without a host sync per stage
-    for _ in range(args.warmup):
-        r = pipe.run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = pipe.run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # stage times for the report: a few extra steps, outside the timed region, with a sync per stage
-    pipe.time_stages = True
-    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    pipe.probe_events = ev
-    probe_dev_ms = 0.0
-    agg_t, stage_steps = {}, min(args.steps, 10)
-    for _ in range(stage_steps):
-        r = pipe.run()
-        for k, v in r["timings"].items():
-            agg_t[k] = agg_t.get(k, 0) + v
-        if "lineitem_filter_probe" in r["timings"]:
-            torch.cuda.synchronize()
-            probe_dev_ms += ev[0].elapsed_time(ev[1])
-    barrier()
-    total_rows = nrows
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([nrows], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot)
-        total_rows = int(tot.item())
-    if rank == 0:
-        k = args.steps
-        probe_rows = agg_t["probe_rows"] / stage_steps
-        fused = "lineitem_filter_probe" in agg_t
-        probe_ms = agg_t["lineitem_filter_probe" if fused else "lineitem_probe"] / stage_steps * 1e3
-        host_probe_ms = probe_ms
-        if fused and probe_dev_ms > 0:
-            probe_ms = probe_dev_ms / stage_steps   # HIP events on the launch stream: the stage's kernels only
-        pairs = r["join_rows"]
-        # probe algorithmic bytes, counted once (BASELINE.md's Q3 row: 16 B per probe row read =
-        # selection entry 4 + key 8 + bucket head 4); per output pair next 4 + build key 8 + the
-        # pair 8 + its selection entry 4. Implementation passes (candidate slices, the second
-        # chain walk of the emit kernel) are NOT counted.
-        probe_bytes = probe_rows * 16 + pairs * 24
-        if fused:
-            # fused Filter -> probe: every lineitem row's l_shipdate (4 B) is read, and the 16 B of
-            # a probe only for the rows the filter keeps (counted once, outside the timed loop)
-            kept = pipe.lineitem_filter_rows()
-            probe_bytes = nrows * 4 + kept * 16 + pairs * 24
-        out = {
-            "metric": "rows/sec through hash-join probe + hash-agg (Q3)",
-            "value": total_rows * k / elapsed, "unit": "rows/s", "n_gpus": world, "steps": k,
-            "warmup": args.warmup, "ms_per_step": elapsed / k * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {
-                "workload": f"TPC-H Q3 over SF{args.sf} customer/orders/lineitem shards per GPU "
-                            f"({nrows} lineitem rows on rank 0), tables resident in HBM",
-                "groups_rank0": r["ngroups"], "join_rows_rank0": pairs,
-                "parallelism": f"hash-partition by order key x{world}, all-to-all over RCCL" if world > 1 else "single GPU",
-                "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk not in ("probe_rows", "exchange_bytes_sent")},
-                "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage (the timed steps have none)",
-                "exchange_bytes_sent_rank0": agg_t.get("exchange_bytes_sent", 0) / stage_steps,
-                "probe_rows_per_s": probe_rows / (probe_ms * 1e-3),
-                "top1": list(r["top"][0]) if r["top"] else None,
-            },
-            "roofline": {"bound": "hbm", "achieved": probe_bytes / (probe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": probe_bytes / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "join_cand_fast_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
-                         "avg_launch_ms": probe_ms, "timing": "HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
-                         "host_timed_stage_ms": host_probe_ms},
-        }
-        if emit:
-            print(json.dumps(out))
-    else:
-        out = None
-    pipe.free()
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return out
-
-
-def bench_q9(args, rank, local_rank, world):
-    """Q9: LIKE + four hash joins (one composite) + profit expression + 175-group aggregate from the
-    operator-granular kernels (plan_amd/pipelines.py Q9Pipeline). A step = one whole Q9."""
-    import torch
-    import torch.distributed as dist
-
-    from plan_amd import hip, pipelines, tpchgen
-
-    sf_total = (args.sf * world, 1)
-    n_ord = tpchgen.orders_count((args.sf, 1))
-    n_part, n_supp = n_ord * 2 // 15, n_ord // 150
-    L = tpchgen.lineitem(sf_total, rank * n_ord, n_ord, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity",
-                                                                  "l_extendedprice", "l_discount"])
-    Od = tpchgen.orders(sf_total, rank * n_ord, n_ord, columns=["o_orderkey", "o_orderdate"])
-    P = tpchgen.part(sf_total, rank * n_part, n_part)
-    PS = tpchgen.partsupp(sf_total, rank * n_part, n_part)
-    S = tpchgen.supplier(sf_total, rank * n_supp, n_supp)
-    nrows = len(L["l_orderkey"])
-    ctx = hip.Ctx(local_rank)
-    pipe = pipelines.Q9Pipeline(ctx, L, Od, P, PS, S)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
-
-    pipe.time_stages = False   # the measured steps run without a host sync per stage
-    for _ in range(args.warmup):
-        r = pipe.run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = pipe.run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # stage times for the report: a few extra steps, outside the timed region, with a sync per stage
-    pipe.time_stages = True
-    agg_t, stage_steps = {}, min(args.steps, 10)
-    for _ in range(stage_steps):
-        r = pipe.run()
-        for k, v in r["timings"].items():
-            agg_t[k] = agg_t.get(k, 0) + v
-    barrier()
-    total_rows = nrows
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([nrows], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot)
-        total_rows = int(tot.item())
-    if rank == 0:
-        k = args.steps
-        out = {
-            "metric": "rows/sec through 4 hash joins + hash-agg (Q9)", "value": total_rows * k / elapsed,
-            "unit": "rows/s", "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": elapsed / k * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"TPC-H Q9 over SF{args.sf} shards per GPU ({nrows} lineitem rows on rank 0), tables resident in HBM",
-                       "groups": r["ngroups"], "join_rows_rank0": r["join_rows"],
-                       "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk != "exchange_bytes_sent"},
-                       "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage"},
-            "roofline": None,
-        }
-        print(json.dumps(out))
-    pipe.free()
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if companions and world == 1:
+        attempt("q6_single_gpu", lambda: brief(bench_scan(h, "q6", args.sf, comp_steps, comp_warm, "weak", L=L, table=table)[0]))
+        if not args.no_cpu_baseline:
+            cb = cpu_baselines(L, args.cpu_rows)
+            out["cpu_baseline"] = cb["q1"]
+            if "q1_all_cores" in cb:
+                out["cpu_baseline_all_cores"] = cb["q1_all_cores"]
+        table.free()
+        del L
+        attempt("q1_sf1", lambda: brief(bench_scan(h, "q1", 1, max(args.steps, 100), comp_warm, "weak")[0]))
+        attempt("q3_single_gpu", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "weak")))
+        attempt("q9_single_gpu", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm)))
+        if not args.no_cpu_baseline:
+            if "error" not in out["q6_single_gpu"]:
+                out["q6_single_gpu"]["cpu_baseline"] = cb["q6"]
+            if "error" not in out["q3_single_gpu"]:
+                out["q3_single_gpu"]["cpu_baseline"] = cb["q3"]
+    elif companions:
+        table.free()
+        del L
+        # BASELINE.json config 4: Q3 at SF`--sf`, hash-partitioned across the N GPUs (strong scaling)
+        attempt("q3_partitioned", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "strong")))
+    elif rank0 and world == 1 and not args.no_cpu_baseline and L is not None:
+        cb = cpu_baselines(L, args.cpu_rows)
+        out["cpu_baseline"] = cb[args.query]
+    done.set()
+    if rank0:
+        print(json.dumps(out), flush=True)
+    try:
+        h.barrier()
+        h.close()
+    except Exception:  # noqa: BLE001 - the line is out; teardown problems are not results
+        pass
 
 
 if __name__ == "__main__":

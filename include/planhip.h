@@ -338,10 +338,69 @@ void ph_agg_result_free(ph_agg_result *r);
  * No reference counterpart (the reference is single-threaded): hash-partition
  * rows by key so that join build/probe sides and group-by keys co-locate per GPU.
  * dest = mix64(key) % nparts. Writes per-partition counts and a permutation of row ids grouped
- * by destination (stable within a partition); the caller gathers columns with ph_gather and
- * exchanges them (RCCL all-to-all over xGMI, one process per GPU). */
+ * by destination, input order kept inside every partition (reproducible); the caller gathers
+ * columns with ph_gather and exchanges them (ph_comm_* below). */
 int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
                  int64_t *counts_host, int32_t *perm_dev);
+/* Same, with the nparts counts left on the device (int64 each) and no host round trip: what the
+ * exchange below consumes (ph_comm_exchange_counts reads them there). */
+int ph_partition_dev(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
+                     int64_t *counts_dev, int32_t *perm_dev);
+
+/* ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
+ * One process (or goroutine-pinned OS thread) per GPU; SURVEY.md §8(e). No reference counterpart.
+ * The plug point that drives it is the same one that builds the executors (buildOperatorExec,
+ * pkg/compute/executor.go:305-350): a partitioned gpuJoinExecutor partitions its build and probe
+ * batches with ph_partition_dev, gathers the needed columns (ph_gather) and exchanges them.
+ * Everything is stream-ordered on the ctx stream; a stage makes ONE host round trip (the count
+ * matrix), none between the partition, the gathers and the all-to-all. */
+#define PH_COMM_ID_BYTES 128
+typedef struct ph_comm ph_comm;
+typedef enum { PH_RED_SUM = 1, PH_RED_MAX = 2, PH_RED_MIN = 3 } ph_redop;
+/* rank 0 creates the id (ncclGetUniqueId) and ships its 128 bytes to the other ranks by any host
+ * channel (the Go side: the coordinator's RPC; the tests: a file / torch.distributed store) */
+int ph_comm_unique_id(void *id_out);
+int ph_comm_init(ph_ctx *ctx, int32_t nranks, int32_t rank, const void *id, ph_comm **out);
+int32_t ph_comm_nranks(const ph_comm *c);
+int32_t ph_comm_rank(const ph_comm *c);
+void ph_comm_destroy(ph_comm *c);
+/* every rank contributes `bytes` from send_dev; recv_dev gets nranks*bytes, rank-major. async != 0:
+ * the collective runs on the communicator's own stream behind everything already queued on the ctx
+ * stream, so later kernels on the ctx stream overlap it; ph_comm_wait makes the ctx stream wait for
+ * it (stream-side, no host block). Used for the per-step merge of fused-plan partials. */
+int ph_comm_allgather(ph_comm *c, const void *send_dev, void *recv_dev, int64_t bytes, int32_t async);
+int ph_comm_wait(ph_comm *c);
+/* same, except that the newest `keep` (0..3) asynchronous collectives may still be running: with
+ * two alternating result buffers, `keep` = 1 before a step lets the previous step's collective
+ * overlap this step's kernels while the buffer about to be overwritten is safe */
+int ph_comm_wait_keep(ph_comm *c, int32_t keep);
+/* n <= 64 host values reduced over all ranks, result on every rank (timings, row totals, flags) */
+int ph_comm_allreduce_i64(ph_comm *c, int64_t *host_vals, int32_t n, int32_t op);
+int ph_comm_barrier(ph_comm *c);
+/* send_counts_dev: this rank's nranks per-destination row counts (ph_partition_dev's output).
+ * matrix_host[s*nranks + d] = rows rank s sends to rank d, on every rank: one all-gather and the
+ * stage's one device->host copy. */
+int ph_comm_exchange_counts(ph_comm *c, const int64_t *send_counts_dev, int64_t *matrix_host);
+/* host-only (no device, no RCCL): offsets of every peer's rows in this rank's send buffers (rows
+ * ordered by destination, as ph_partition orders them) and receive buffers (ordered by source rank).
+ * send_off / recv_off: nranks+1 entries; recv_off[nranks] = rows this rank ends up with. */
+int ph_exchange_layout(const int64_t *matrix, int32_t nranks, int32_t rank, int64_t *send_off, int64_t *recv_off);
+/* all-to-all of ncols column buffers (elem_bytes[k] bytes per row) as one group of
+ * ncclSend/ncclRecv pairs: every peer pair and every column concurrently. recv_dev[k] needs
+ * recv_off[nranks]*elem_bytes[k] bytes. */
+int ph_comm_exchange_columns(ph_comm *c, int32_t ncols, const void *const *send_dev, void *const *recv_dev,
+                             const int32_t *elem_bytes, const int64_t *matrix_host);
+/* variable-length all-gather of one column (broadcast of a small build side): counts_host[r] =
+ * rows of rank r, recv_dev = all rows in rank order (PH_ECAPACITY when recv_capacity is too small;
+ * counts_host is valid then) */
+int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
+                           int64_t recv_capacity, int64_t *counts_host);
+
+/* ------------------------------------------------------------------ measurement
+ * streaming-read ceiling: a read-only reduce over `bytes` of device memory with the fused scan
+ * kernels' access pattern (grid workgroups of 256 threads, 16-byte non-temporal loads); one word
+ * per workgroup is written to out_words_dev. The caller times it (HIP events on the ctx stream). */
+int ph_dev_read_reduce(ph_ctx *ctx, const void *dev, int64_t bytes, uint64_t *out_words_dev, int32_t grid);
 
 /* ------------------------------------------------------------------ ORDER BY
  * LocalSort over fixed-size keys (sort_local.go:64-250; key layout sort_layout.go:29-88; encoders

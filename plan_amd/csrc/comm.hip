@@ -1,0 +1,229 @@
+// Multi-GPU exchange behind the C ABI: one process per GPU, RCCL over xGMI.
+//
+// No reference counterpart — the reference drives a query from one goroutine on one CPU
+// (SURVEY.md §2, §8e). What a Go host needs to run the partitioned join queries is here as plain
+// C entry points: communicator set-up from a 128-byte id the ranks share over any host channel,
+// the count exchange, the all-to-all of column buffers as ONE group of ncclSend/ncclRecv pairs on
+// the ctx stream (no host synchronisation between a partition's gathers and the exchange), a
+// variable-length all-gather (broadcast of small build sides) and small reductions for merges.
+//
+// xGMI is point to point (7 links per GPU): a balanced all-to-all drives all links at once, so all
+// columns of a stage go into one group call and RCCL schedules every peer pair concurrently.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+struct ph_comm {
+    ph_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    // asynchronous collectives (ph_comm_allgather with async != 0) run on their own stream so that
+    // the next kernels on the ctx stream overlap them
+    hipStream_t cstream = nullptr;
+    hipEvent_t ready = nullptr;
+    static constexpr int RING = 4;
+    hipEvent_t done[RING] = {};     // done[i % RING] = end of the i-th asynchronous collective
+    int64_t issued = 0, waited = 0; // collectives issued / already waited for by the ctx stream
+    int64_t *dev_words = nullptr;   // nranks*nranks + 64 words of device scratch
+};
+
+#define PH_NCCL(call)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            ph::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+            return PH_EHIP;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+extern "C" int ph_comm_unique_id(void *id_out) {
+    PH_REQUIRE(id_out != nullptr, "ph_comm_unique_id: id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) == PH_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    PH_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return PH_OK;
+}
+
+extern "C" int ph_comm_init(ph_ctx *ctx, int32_t nranks, int32_t rank, const void *id, ph_comm **out) {
+    PH_REQUIRE(ctx && id && out && nranks >= 1 && rank >= 0 && rank < nranks, "ph_comm_init: bad arguments");
+    PH_HIP(hipSetDevice(ctx->device));
+    ph_comm *c = new ph_comm();
+    c->ctx = ctx;
+    c->nranks = nranks;
+    c->rank = rank;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        ph::set_error("ncclCommInitRank(%d of %d) failed: %s", rank, nranks, ncclGetErrorString(r));
+        delete c;
+        return PH_EHIP;
+    }
+    if (hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done[3], hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&c->dev_words, ((size_t)nranks * nranks + 64) * 8) != hipSuccess) {
+        ph::set_error("ph_comm_init: stream/event/scratch creation failed");
+        ph_comm_destroy(c);
+        return PH_EHIP;
+    }
+    *out = c;
+    return PH_OK;
+}
+
+extern "C" void ph_comm_destroy(ph_comm *c) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->cstream) (void)hipStreamSynchronize(c->cstream);
+    if (c->ctx) (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    for (hipEvent_t e : c->done) if (e) (void)hipEventDestroy(e);
+    if (c->cstream) (void)hipStreamDestroy(c->cstream);
+    if (c->dev_words) (void)hipFree(c->dev_words);
+    delete c;
+}
+
+extern "C" int32_t ph_comm_nranks(const ph_comm *c) { return c ? c->nranks : 0; }
+extern "C" int32_t ph_comm_rank(const ph_comm *c) { return c ? c->rank : -1; }
+
+extern "C" int ph_comm_wait_keep(ph_comm *c, int32_t keep) {
+    PH_REQUIRE(c != nullptr && keep >= 0 && keep < ph_comm::RING, "ph_comm_wait_keep: bad arguments (0 <= keep < %d)", ph_comm::RING);
+    // collectives complete in issue order on the side stream: waiting for the newest one that must
+    // be finished covers the older ones
+    const int64_t upto = c->issued - keep;   // wait for collectives [waited, upto)
+    if (upto <= c->waited) return PH_OK;
+    PH_HIP(hipStreamWaitEvent(c->ctx->stream, c->done[(upto - 1) % ph_comm::RING], 0));
+    c->waited = upto;
+    return PH_OK;
+}
+
+extern "C" int ph_comm_wait(ph_comm *c) { return ph_comm_wait_keep(c, 0); }
+
+extern "C" int ph_comm_allgather(ph_comm *c, const void *send_dev, void *recv_dev, int64_t bytes, int32_t async) {
+    PH_REQUIRE(c && bytes >= 0 && (bytes == 0 || (send_dev && recv_dev)), "ph_comm_allgather: bad arguments");
+    if (bytes == 0) return PH_OK;
+    if (!async) {
+        PH_CHECK(ph_comm_wait(c));
+        PH_NCCL(ncclAllGather(send_dev, recv_dev, (size_t)bytes, ncclChar, c->comm, c->ctx->stream));
+        return PH_OK;
+    }
+    // the previous asynchronous collective (if any) runs on the same side stream: ordered before this one
+    PH_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    PH_HIP(hipStreamWaitEvent(c->cstream, c->ready, 0));
+    PH_NCCL(ncclAllGather(send_dev, recv_dev, (size_t)bytes, ncclChar, c->comm, c->cstream));
+    // an event of the ring may only be re-recorded once the ctx stream has waited for its last use
+    if (c->issued - c->waited >= ph_comm::RING) PH_CHECK(ph_comm_wait_keep(c, ph_comm::RING - 1));
+    PH_HIP(hipEventRecord(c->done[c->issued % ph_comm::RING], c->cstream));
+    c->issued++;
+    return PH_OK;
+}
+
+extern "C" int ph_comm_allreduce_i64(ph_comm *c, int64_t *host_vals, int32_t n, int32_t op) {
+    PH_REQUIRE(c && host_vals && n >= 1 && n <= 64 && op >= PH_RED_SUM && op <= PH_RED_MIN, "ph_comm_allreduce_i64: bad arguments (n <= 64)");
+    PH_CHECK(ph_comm_wait(c));
+    hipStream_t st = c->ctx->stream;
+    int64_t *d = c->dev_words + (size_t)c->nranks * c->nranks;
+    PH_HIP(hipMemcpyAsync(d, host_vals, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    ncclRedOp_t rop = op == PH_RED_SUM ? ncclSum : op == PH_RED_MAX ? ncclMax : ncclMin;
+    PH_NCCL(ncclAllReduce(d, d, (size_t)n, ncclInt64, rop, c->comm, st));
+    return c->ctx->download(host_vals, d, (int64_t)n * 8);
+}
+
+extern "C" int ph_comm_barrier(ph_comm *c) {
+    int64_t one = 1;
+    return ph_comm_allreduce_i64(c, &one, 1, PH_RED_SUM);
+}
+
+extern "C" int ph_comm_exchange_counts(ph_comm *c, const int64_t *send_counts_dev, int64_t *matrix_host) {
+    PH_REQUIRE(c && send_counts_dev && matrix_host, "ph_comm_exchange_counts: bad arguments");
+    PH_CHECK(ph_comm_wait(c));
+    PH_NCCL(ncclAllGather(send_counts_dev, c->dev_words, (size_t)c->nranks, ncclInt64, c->comm, c->ctx->stream));
+    return c->ctx->download(matrix_host, c->dev_words, (int64_t)c->nranks * c->nranks * 8);   // the stage's one round trip
+}
+
+extern "C" int ph_exchange_layout(const int64_t *matrix, int32_t nranks, int32_t rank, int64_t *send_off, int64_t *recv_off) {
+    PH_REQUIRE(matrix && nranks >= 1 && rank >= 0 && rank < nranks && send_off && recv_off, "ph_exchange_layout: bad arguments");
+    send_off[0] = recv_off[0] = 0;
+    for (int r = 0; r < nranks; r++) {
+        int64_t s = matrix[(size_t)rank * nranks + r], v = matrix[(size_t)r * nranks + rank];
+        PH_REQUIRE(s >= 0 && v >= 0, "ph_exchange_layout: negative count");
+        send_off[r + 1] = send_off[r] + s;      // rows this rank sends to rank r (its row of the matrix)
+        recv_off[r + 1] = recv_off[r] + v;      // rows arriving from rank r (its column), in rank order
+    }
+    return PH_OK;
+}
+
+extern "C" int ph_comm_exchange_columns(ph_comm *c, int32_t ncols, const void *const *send_dev, void *const *recv_dev,
+                                        const int32_t *elem_bytes, const int64_t *matrix_host) {
+    PH_REQUIRE(c && ncols >= 0 && (ncols == 0 || (send_dev && recv_dev && elem_bytes)) && matrix_host,
+               "ph_comm_exchange_columns: bad arguments");
+    PH_CHECK(ph_comm_wait(c));
+    std::vector<int64_t> so((size_t)c->nranks + 1), ro((size_t)c->nranks + 1);
+    PH_CHECK(ph_exchange_layout(matrix_host, c->nranks, c->rank, so.data(), ro.data()));
+    hipStream_t st = c->ctx->stream;
+    PH_NCCL(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int32_t k = 0; k < ncols && bad == ncclSuccess; k++) {
+        const int64_t w = elem_bytes[k];
+        for (int r = 0; r < c->nranks && bad == ncclSuccess; r++) {
+            const int64_t ns = so[(size_t)r + 1] - so[(size_t)r], nr = ro[(size_t)r + 1] - ro[(size_t)r];
+            if (r == c->rank) {   // own rows: a device copy, no link involved
+                if (ns > 0 && hipMemcpyAsync((char *)recv_dev[k] + ro[(size_t)r] * w, (const char *)send_dev[k] + so[(size_t)r] * w,
+                                             (size_t)(ns * w), hipMemcpyDeviceToDevice, st) != hipSuccess) bad = ncclUnhandledCudaError;
+                continue;
+            }
+            if (ns > 0) bad = ncclSend((const char *)send_dev[k] + so[(size_t)r] * w, (size_t)(ns * w), ncclChar, r, c->comm, st);
+            if (nr > 0 && bad == ncclSuccess) bad = ncclRecv((char *)recv_dev[k] + ro[(size_t)r] * w, (size_t)(nr * w), ncclChar, r, c->comm, st);
+        }
+    }
+    ncclResult_t endr = ncclGroupEnd();
+    if (bad != ncclSuccess || endr != ncclSuccess) {
+        ph::set_error("ph_comm_exchange_columns: %s", ncclGetErrorString(bad != ncclSuccess ? bad : endr));
+        return PH_EHIP;
+    }
+    return PH_OK;
+}
+
+extern "C" int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
+                                      int64_t recv_capacity, int64_t *counts_host) {
+    PH_REQUIRE(c && count >= 0 && elem_bytes > 0 && counts_host && (count == 0 || send_dev), "ph_comm_allgather_rows: bad arguments");
+    PH_CHECK(ph_comm_wait(c));
+    hipStream_t st = c->ctx->stream;
+    int64_t *d = c->dev_words;
+    PH_HIP(hipMemcpyAsync(d + c->nranks, &count, 8, hipMemcpyHostToDevice, st));
+    PH_NCCL(ncclAllGather(d + c->nranks, d, 1, ncclInt64, c->comm, st));
+    PH_CHECK(c->ctx->download(counts_host, d, (int64_t)c->nranks * 8));
+    int64_t total = 0;
+    for (int r = 0; r < c->nranks; r++) total += counts_host[r];
+    if (total > recv_capacity) { ph::set_error("ph_comm_allgather_rows: %lld rows, room for %lld", (long long)total, (long long)recv_capacity); return PH_ECAPACITY; }
+    if (total == 0) return PH_OK;
+    PH_REQUIRE(recv_dev != nullptr, "ph_comm_allgather_rows: recv_dev is NULL");
+    // every rank sends its rows to every other rank; one group, all peer pairs concurrently
+    PH_NCCL(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    int64_t off = 0;
+    for (int r = 0; r < c->nranks && bad == ncclSuccess; r++) {
+        const int64_t nr = counts_host[r];
+        if (r == c->rank) {
+            if (nr > 0 && hipMemcpyAsync((char *)recv_dev + off * elem_bytes, send_dev, (size_t)(nr * elem_bytes),
+                                         hipMemcpyDeviceToDevice, st) != hipSuccess) bad = ncclUnhandledCudaError;
+        } else {
+            if (count > 0) bad = ncclSend(send_dev, (size_t)(count * elem_bytes), ncclChar, r, c->comm, st);
+            if (nr > 0 && bad == ncclSuccess) bad = ncclRecv((char *)recv_dev + off * elem_bytes, (size_t)(nr * elem_bytes), ncclChar, r, c->comm, st);
+        }
+        off += nr;
+    }
+    ncclResult_t endr = ncclGroupEnd();
+    if (bad != ncclSuccess || endr != ncclSuccess) {
+        ph::set_error("ph_comm_allgather_rows: %s", ncclGetErrorString(bad != ncclSuccess ? bad : endr));
+        return PH_EHIP;
+    }
+    return PH_OK;
+}

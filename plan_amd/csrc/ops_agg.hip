@@ -119,14 +119,15 @@ __device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsi
                 if (me == first) base = atomicAdd(P.ngroups, __popcll(winners));
                 base = __shfl(base, first);
                 int ng = base + __popcll(winners & ((1ull << me) - 1ull));
-                if (ng >= P.gcap) {  // cannot happen: see the growth check
-                    atomicOr(P.error_flag, 1);
+                const bool room = ng < P.gcap;
+                if (!room) {  // only an overflowing bulk build gets here (its attempt is void): the
+                    atomicOr(P.error_flag, 1);   // key is not stored, group 0 only absorbs the row
                     ng = 0;
                 }
-                for (int c = 0; c < P.nkeys; c++)
+                for (int c = 0; room && c < P.nkeys; c++)
                     __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
-                if (nullmask)  // gnull is zeroed when the arrays are (re)allocated
+                if (room && nullmask)  // gnull is zeroed when the arrays are (re)allocated
                     __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // Publication order: the key words above are agent-scope atomic stores (sc1: written
                 // through to the device coherence point, never parked dirty in this XCD's L2), and
@@ -439,7 +440,8 @@ __device__ __forceinline__ unsigned long long order_key(long long v, int descend
 // folds the histogram into the prefix / remaining-k state and clears it for the next pass, so a
 // pass is one launch. Pass 7 also checks that every sum fits int64 (flags |= 1 otherwise).
 __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long *__restrict__ sum_lo,
-                                                        const long long *__restrict__ sum_hi, int naggs, int a,
+                                                        const long long *__restrict__ sum_hi,
+                                                        const unsigned long long *__restrict__ cnt, int naggs, int a,
                                                         const int *__restrict__ ngroups, int descending, int pass, long long k,
                                                         unsigned long long *__restrict__ state,
                                                         unsigned *__restrict__ hist, int *__restrict__ done,
@@ -455,7 +457,9 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long
     for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
         const long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
         if (pass == 7 && sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) wide = true;
-        unsigned long long key = order_key(lo, descending);
+        // an aggregate no input ever reached is NULL, and NULLs sort first whatever the direction
+        // (sort_layout.go:46): the best possible key
+        unsigned long long key = cnt[(int64_t)g * naggs + a] ? order_key(lo, descending) : 0ull;
         if ((key & mask) == (prefix & mask)) atomicAdd(&lh[(key >> (8 * pass)) & 0xff], 1u);
     }
     if (wide) atomicOr(flags, 1);
@@ -490,7 +494,8 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long
     if (threadIdx.x == 0) *done = 0;
 }
 
-__global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long long *__restrict__ sum_lo, int naggs, int a,
+__global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long long *__restrict__ sum_lo,
+                                                           const unsigned long long *__restrict__ cnt, int naggs, int a,
                                                            const int *__restrict__ ngroups, int descending, long long k,
                                                            const unsigned long long *__restrict__ state,
                                                            int *__restrict__ out_ids, int *__restrict__ out_count, int cap) {
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const unsigned long l
     unsigned long long kth = state[0];
     bool all = k >= ng;
     for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
-        unsigned long long key = order_key((long long)sum_lo[(int64_t)g * naggs + a], descending);
+        unsigned long long key = cnt[(int64_t)g * naggs + a] ? order_key((long long)sum_lo[(int64_t)g * naggs + a], descending) : 0ull;
         if (all || key <= kth) {
             int pos = atomicAdd(out_count, 1);
             if (pos < cap) out_ids[pos] = g;
@@ -1064,6 +1069,7 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     B.overflow = a->counters + 2;
     const size_t lds = (size_t)T * per_entry;
     int rc = PH_OK;
+    bool settled = false;   // the last attempt ran without running out of ids
     for (int attempt = 0; attempt < 6 && rc == PH_OK; attempt++) {
         B.S.slots = a->slots;
         B.S.mask = (uint64_t)a->cap - 1;
@@ -1076,14 +1082,22 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
         case 3: rc = bulk_launch<3>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
         default: rc = bulk_launch<4>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
         }
-        if (rc != PH_OK || sure) break;
+        if (rc != PH_OK) break;
+        if (sure) { settled = true; break; }
         int c[3] = {0, 0, 0};
         if ((rc = ctx->download(c, a->counters, 12)) != PH_OK) break;
-        if (!c[1] && !c[2]) break;   // neither the row-by-row path nor a partition ran out of ids
+        if (!c[1] && !c[2]) { settled = true; break; }   // neither the row-by-row path nor a partition ran out of ids
         // c[0] = ids asked for so far (every partition adds its need even when it then backs off)
         rc = agg_resize(a, next_pow2(4 * std::max<int64_t>(c[0], a->gcap)), 0);
     }
     ctx->pool_release(tmp);
+    if (rc == PH_OK && !settled) {
+        // every attempt overflowed (a hint too small by orders of magnitude): the table was just
+        // replaced by an empty, larger one. Clear the voided attempt's counters and let the caller
+        // run the ordinary growing sink over the same rows; nothing has been sunk.
+        if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) return PH_EHIP;
+        return PH_EUNSUPPORTED;
+    }
     return rc;
 }
 
@@ -1273,8 +1287,11 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     PH_REQUIRE(a && n_out && k >= 0 && max_groups >= 0 && agg_index >= 0 && agg_index < a->naggs,
                "ph_agg_topk: bad arguments");
     int kind = a->aggs[agg_index].kind;
-    PH_REQUIRE(kind == PH_A_SUM || kind == PH_A_MIN || kind == PH_A_MAX || kind == PH_A_AVG,
-               "ph_agg_topk: aggregate %d is not ordered by its sum/min/max value", agg_index);
+    if (kind != PH_A_SUM && kind != PH_A_MIN && kind != PH_A_MAX) {
+        // AVG orders by sum/count, COUNT by the count word: neither is the raw sum word ranked here
+        ph::set_error("ph_agg_topk: aggregate %d (kind %d) is not ordered by its sum/min/max word; use ph_agg_finalize", agg_index, kind);
+        return PH_EUNSUPPORTED;
+    }
     *n_out = 0;
     if (k == 0 || max_groups == 0) return PH_OK;
     ph_ctx *ctx = a->ctx;
@@ -1294,9 +1311,9 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     unsigned *hist = (unsigned *)(state + 4);
     const int tg = (int)std::min<int64_t>((a->gcap + 255) / 256, ctx->cu_count * 2);
     for (int pass = 7; pass >= 0; pass--)  // radix select, most significant byte first
-        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->naggs, agg_index, a->counters, descending, pass,
+        ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, a->counters, descending, pass,
                                                           (long long)k, state, hist, done, meta + 1);
-    ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->naggs, agg_index, a->counters, descending, (long long)k,
+    ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->cnt, a->naggs, agg_index, a->counters, descending, (long long)k,
                                                           state, ids, meta, cap);
     ph::agg_pack_kernel<<<std::max(1, std::min((cap + 255) / 256, 64)), 256, 0, ctx->stream>>>(
         ids, meta, a->counters, cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);

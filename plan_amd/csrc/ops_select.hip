@@ -782,36 +782,78 @@ __global__ __launch_bounds__(256) void part_hist_kernel(const void *data, int wi
     if (threadIdx.x < nparts) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Stable scatter: a row's slot = partition cursor + same-partition rows of earlier waves in this
+// 256-row round + same-partition lower lanes (six ballots give every lane the mask of the lanes that
+// share its partition), so rows keep their input order inside every partition and the permutation
+// is reproducible run to run (first-seen group order survives an exchange).
 __global__ __launch_bounds__(256) void part_scatter_kernel(const void *data, int width, const int32_t *sel,
                                                            int64_t n, int nparts, int nblocks,
                                                            const int32_t *__restrict__ offs,
                                                            int32_t *__restrict__ perm) {
     __shared__ int cur[PART_MAX];
-    if (threadIdx.x < nparts) cur[threadIdx.x] = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+    __shared__ int wcount[4][PART_MAX];
+    if (threadIdx.x < PART_MAX) {
+        cur[threadIdx.x] = threadIdx.x < nparts ? offs[(int64_t)threadIdx.x * nblocks + blockIdx.x] : 0;
+        for (int w = 0; w < 4; w++) wcount[w][threadIdx.x] = 0;
+    }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int64_t base = (int64_t)blockIdx.x * PART_CHUNK;
     for (int r = 0; r < PART_CHUNK / 256; r++) {
         int64_t i = base + r * 256 + threadIdx.x;
-        if (i < n) {
-            int64_t row = sel ? sel[i] : i;
-            int d = (int)(mix64(part_key(data, width, row)) % (uint64_t)nparts);
-            int pos = atomicAdd(&cur[d], 1);
+        const bool live = i < n;
+        int64_t row = 0;
+        int d = 0;
+        if (live) {
+            row = sel ? sel[i] : i;
+            d = (int)(mix64(part_key(data, width, row)) % (uint64_t)nparts);
+        }
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            unsigned long long m = __ballot((d >> b) & 1);
+            same &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(same & lt);
+        if (live && rank == 0) wcount[wv][d] = __popcll(same);
+        __syncthreads();
+        if (live) {
+            int pos = cur[d] + rank;
+            for (int w = 0; w < wv; w++) pos += wcount[w][d];
             perm[pos] = (int32_t)row;
         }
+        __syncthreads();
+        if (threadIdx.x < PART_MAX) {
+            int t = 0;
+            for (int w = 0; w < 4; w++) { t += wcount[w][threadIdx.x]; wcount[w][threadIdx.x] = 0; }
+            cur[threadIdx.x] += t;
+        }
+        __syncthreads();
     }
+}
+
+// counts[p] = first offset of partition p+1 - first offset of partition p (after the scan)
+__global__ void part_counts_kernel(const int32_t *__restrict__ offs, int nblocks, int nparts, int64_t n,
+                                   int64_t *__restrict__ counts) {
+    int p = threadIdx.x;
+    if (p >= nparts) return;
+    int64_t a = offs[(int64_t)p * nblocks];
+    int64_t b = p + 1 < nparts ? offs[(int64_t)(p + 1) * nblocks] : n;
+    counts[p] = b - a;
 }
 
 }  // namespace ph
 
-extern "C" int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
-                            int64_t *counts_host, int32_t *perm_dev) {
-    PH_REQUIRE(ctx && key && counts_host && nparts >= 1 && nparts <= ph::PART_MAX && n >= 0,
+extern "C" int ph_partition_dev(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
+                                int64_t *counts_dev, int32_t *perm_dev) {
+    PH_REQUIRE(ctx && key && counts_dev && nparts >= 1 && nparts <= ph::PART_MAX && n >= 0 && n < (1ll << 31),
                "ph_partition: bad arguments (1 <= nparts <= %d)", ph::PART_MAX);
     int w = ph::type_width(key->type);
     PH_REQUIRE(w == 4 || w == 8, "ph_partition: key must be a 32- or 64-bit integer column");
     PH_REQUIRE(key->validity == nullptr, "ph_partition: NULL-able partition keys are not supported");
-    for (int p = 0; p < nparts; p++) counts_host[p] = 0;
-    if (n == 0) return PH_OK;
+    if (n == 0) { PH_HIP(hipMemsetAsync(counts_dev, 0, (size_t)nparts * 8, ctx->stream)); return PH_OK; }
+    PH_REQUIRE(perm_dev != nullptr, "ph_partition: perm_dev is NULL");
     int64_t nb = (n + ph::PART_CHUNK - 1) / ph::PART_CHUNK;
     int64_t cells = nb * nparts;
     PH_CHECK(ctx->ensure_scratch(ph::round_up(cells * 4, 8) + 64));
@@ -820,12 +862,20 @@ extern "C" int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, 
     ph::part_hist_kernel<<<(int)nb, 256, 0, ctx->stream>>>(key->data, w, sel, n, nparts, (int)nb, hist);
     PH_HIP(hipGetLastError());
     // first block offset of each partition = exclusive scan over the part-major layout
-    std::vector<int32_t> first((size_t)nparts + 1);
     PH_CHECK(ph::exclusive_scan_i32(ctx, hist, cells, total));
+    ph::part_counts_kernel<<<1, 64, 0, ctx->stream>>>(hist, (int)nb, nparts, n, counts_dev);
     ph::part_scatter_kernel<<<(int)nb, 256, 0, ctx->stream>>>(key->data, w, sel, n, nparts, (int)nb, hist, perm_dev);
     PH_HIP(hipGetLastError());
-    for (int p = 0; p < nparts; p++) PH_CHECK(ctx->download(&first[(size_t)p], hist + (int64_t)p * nb, 4));
-    first[(size_t)nparts] = (int32_t)n;
-    for (int p = 0; p < nparts; p++) counts_host[p] = first[(size_t)p + 1] - first[(size_t)p];
     return PH_OK;
+}
+
+extern "C" int ph_partition(ph_ctx *ctx, const ph_col *key, const int32_t *sel, int64_t n, int32_t nparts,
+                            int64_t *counts_host, int32_t *perm_dev) {
+    PH_REQUIRE(ctx && counts_host && nparts >= 1 && nparts <= ph::PART_MAX, "ph_partition: bad arguments (1 <= nparts <= %d)", ph::PART_MAX);
+    int64_t *counts_dev = nullptr;
+    PH_CHECK(ctx->pool_alloc((int64_t)nparts * 8, (void **)&counts_dev));
+    int rc = ph_partition_dev(ctx, key, sel, n, nparts, counts_dev, perm_dev);
+    if (rc == PH_OK) rc = ctx->download(counts_host, counts_dev, (int64_t)nparts * 8);   // one round trip
+    ctx->pool_release(counts_dev);
+    return rc;
 }

@@ -16,6 +16,8 @@
 //       34 B/row algorithmic (qty 4 + ext/disc/tax 3x8 + 2 code bytes + shipdate 4).
 //       Group state is a per-thread-private column of LDS (ds_add_u64, conflict-free because
 //       consecutive lanes hit consecutive banks), merged once per workgroup at the end.
+#include <mutex>
+
 #include "common.h"
 #include "scan_kernels.h"
 
@@ -317,7 +319,12 @@ int launch_filter_sumprod(ph_ctx *ctx, const FilterSumProdParams &P, int grid) {
 
 int launch_lowcard_chain(ph_ctx *ctx, const LowcardChainParams &P, int grid) {
     size_t lds = (size_t)P.nslots * (5 * 256 * sizeof(unsigned long long) + 2 * 256 * sizeof(unsigned));
-    static bool attr_set = false;
+    // the attribute belongs to the device's copy of the function: once per device, under a lock
+    // (several ctxs / threads may launch concurrently)
+    static std::mutex mu;
+    static bool attr_set_dev[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    bool &attr_set = attr_set_dev[ctx->device & 63];
     if (!attr_set) {
         PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PH_HIP(hipFuncSetAttribute((const void *)lowcard_chain_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -401,6 +401,14 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
         int n0 = (int)col(group_cols[0]).dict.size(), n1 = (int)col(group_cols[1]).dict.size();
         if (n0 == 0) n0 = (int)col(group_cols[0]).max + 1;
         if (n1 == 0) n1 = (int)col(group_cols[1]).max + 1;
+        // every code must index inside the LDS slots sized from n0*n1: the recorded maxima prove it
+        for (int gi = 0; gi < 2; gi++) {
+            const auto &gc = col(group_cols[gi]);
+            if (!gc.has_range || gc.min < 0 || gc.max >= (gi == 0 ? n0 : n1)) {
+                set_error("lowcard_chain: group column %d holds codes outside its dictionary", group_cols[gi]);
+                return fail(PH_EUNSUPPORTED);
+            }
+        }
         if (n0 * n1 > ph::LC_MAX_SLOTS || n0 * n1 <= 0) { set_error("lowcard_chain: %d group slots exceed %d", n0 * n1, ph::LC_MAX_SLOTS); return fail(PH_EUNSUPPORTED); }
         p->nkeys = 2;
         p->group_cols[0] = group_cols[0];
@@ -646,7 +654,8 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
     int64_t rows = p->never ? 0 : row_end - row_begin;
     int64_t tiles = (rows + 1023) / 1024;
     int max_grid = p->max_grid;
-    if (const char *e = getenv("PH_SCAN_GRID")) { int g = atoi(e); if (g > 0) max_grid = g; }  // tuning knob
+    // tuning knob, clamped to the workgroups `partials` was allocated for (plan_alloc)
+    if (const char *e = getenv("PH_SCAN_GRID")) { int g = atoi(e); if (g > 0) max_grid = std::min(g, std::max(p->max_grid, 8192)); }
     int grid = (int)std::min<int64_t>(max_grid, std::max<int64_t>(tiles, 1));
     // overflow proof: a workgroup's int64 partial sums at most rows_per_block values of
     // magnitude <= row_bound

@@ -14,6 +14,8 @@ PH_I32, PH_I64, PH_DATE, PH_DEC64, PH_CODE8, PH_F32, PH_F64, PH_STR = range(1, 9
 PH_EQ, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE = range(1, 9)
 PH_X_COL, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL = range(1, 6)
 PH_A_SUM, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR = range(1, 7)
+PH_COMM_ID_BYTES = 128
+PH_RED_SUM, PH_RED_MAX, PH_RED_MIN = 1, 2, 3
 
 i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -73,12 +75,15 @@ def _preload_torch_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass
+    # libplanhip.so also needs librccl.so.1 and libhiprtc.so.7: torch bundles its own builds of both
+    # against ITS runtime, so they are taken from the same place, in dependency order
+    for name in ("libamdhip64.so", "libhiprtc.so", "librccl.so"):
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def lib():
@@ -93,7 +98,8 @@ def lib():
         L = ctypes.CDLL(path)
         for name, rt in (("ph_last_error", ctypes.c_char_p), ("ph_version", ctypes.c_char_p),
                          ("ph_scan_plan_kind", ctypes.c_char_p), ("ph_table_rows", i64),
-                         ("ph_hash_bytes", ctypes.c_uint64), ("ph_join_count", i64)):
+                         ("ph_hash_bytes", ctypes.c_uint64), ("ph_join_count", i64),
+                         ("ph_comm_nranks", i32), ("ph_comm_rank", i32)):
             getattr(L, name).restype = rt  # a missing symbol raises: the ABI must be complete
         _LIB = L
     return _LIB
@@ -555,6 +561,19 @@ def partition(ctx, key, sel, n, nparts):
     perm = ctx.alloc(max(n, 1) * 4)
     check(lib().ph_partition(ctx.h, ctypes.byref(c), sel, i64(n), i32(nparts), counts, perm))
     return [counts[p] for p in range(nparts)], perm
+
+
+def partition_dev(ctx, key, sel, n, nparts):
+    """ph_partition_dev: (device int64[nparts] counts, device permutation); no host round trip."""
+    c = key.col() if isinstance(key, DevColumn) else key
+    counts = ctx.alloc(max(nparts, 1) * 8)
+    perm = ctx.alloc(max(n, 1) * 4)
+    check(lib().ph_partition_dev(ctx.h, ctypes.byref(c), sel, i64(n), i32(nparts), counts, perm))
+    return counts, perm
+
+
+def read_reduce(ctx, dev, nbytes, out_words_dev, grid=256):
+    check(lib().ph_dev_read_reduce(ctx.h, dev, i64(nbytes), out_words_dev, i32(grid)))
 
 
 PH_PART_YEAR, PH_PART_MONTH, PH_PART_DAY = 1, 2, 3

@@ -51,19 +51,15 @@ class Q3Pipeline:
         for c in self.cols:
             c.free()
 
-    # -- helpers for the partitioned path (torch tensors as exchange buffers)
-    def _gather_t(self, col, idx_ptr, n, dtype):
-        import torch
-        out = torch.empty(max(n, 1), dtype=dtype, device="cuda")
-        if n:
-            c = col.col() if isinstance(col, hip.DevColumn) else col
-            hip.check(hip.lib().ph_gather(self.ctx.h, hip.ctypes.byref(c), idx_ptr, hip.i64(n),
-                                          hip.vp(out.data_ptr())))
-        return out[:n]
-
     def lineitem_filter_rows(self):
         """rows of this rank's lineitem that pass l_shipdate > date (reporting only)"""
         s, c = hip.filter_select(self.ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=self.date))
+        self.ctx.free(s)
+        return c
+
+    def orders_filter_rows(self):
+        """rows of this rank's orders that pass o_orderdate < date (reporting only)"""
+        s, c = hip.filter_select(self.ctx, self.o_date, self.no, hip.PH_LT, hip.const(hip.PH_DATE, i=self.date))
         self.ctx.free(s)
         return c
 
@@ -91,13 +87,10 @@ class Q3Pipeline:
             frees.append(ck)
             j1 = hip.Join(ctx, [_raw(hip.PH_I32, ck)], None, cn)
         else:
-            import torch
-            mine = self._gather_t(self.c_key, cs, cn, torch.int32)
-            ctx.sync()
-            allkeys = dist.allgather_rows(mine)       # broadcast of the small build side
-            torch.cuda.synchronize()
-            self._keep = allkeys
-            j1 = hip.Join(ctx, [_raw(hip.PH_I32, allkeys.data_ptr())], None, allkeys.numel())
+            mine = hip.gather(ctx, self.c_key, cs, cn)
+            allkeys, nall = dist.allgather_rows(ctx, mine, cn, np.int32)   # broadcast of the small build side
+            frees += [mine, allkeys]
+            j1 = hip.Join(ctx, [_raw(hip.PH_I32, allkeys)], None, nall)
         stage("customer_filter_build", t0)
 
         # ---- orders filter + probe join 1
@@ -121,18 +114,16 @@ class Q3Pipeline:
             j2 = hip.Join(ctx, [self.o_key], orow, m1)
             b_date, b_prio = self.o_date.col(), self.o_prio.col()   # addressed by orders row id
         else:
-            import torch
-            counts, perm = hip.partition(ctx, self.o_key, orow, m1, N)
-            frees.append(perm)
-            send = [self._gather_t(self.o_key, perm, m1, torch.int64),
-                    self._gather_t(self.o_date, perm, m1, torch.int32),
-                    self._gather_t(self.o_prio, perm, m1, torch.int32)]
-            ctx.sync()
-            (rk, rd, rp), _ = dist.exchange_columns(send, counts)
-            torch.cuda.synchronize()
-            self._keep2 = (rk, rd, rp)
-            j2 = hip.Join(ctx, [_raw(hip.PH_I64, rk.data_ptr())], None, rk.numel())
-            b_date, b_prio = _raw(hip.PH_DATE, rd.data_ptr()), _raw(hip.PH_I32, rp.data_ptr())
+            # partition -> gathers -> count matrix -> all-to-all, all stream-ordered; the count
+            # matrix is the stage's one host round trip
+            counts_dev, perm = hip.partition_dev(ctx, self.o_key, orow, m1, N)
+            send = [(hip.gather(ctx, self.o_key, perm, m1), np.int64),
+                    (hip.gather(ctx, self.o_date, perm, m1), np.int32),
+                    (hip.gather(ctx, self.o_prio, perm, m1), np.int32)]
+            (rk, rd, rp), nrecv, _sent = dist.exchange(ctx, send, counts_dev, m1)
+            frees += [counts_dev, perm, rk, rd, rp] + [p for p, _ in send]
+            j2 = hip.Join(ctx, [_raw(hip.PH_I64, rk)], None, nrecv)
+            b_date, b_prio = _raw(hip.PH_DATE, rd), _raw(hip.PH_I32, rp)
         stage("orders_partition_build", t0)
 
         # ---- lineitem filter (+ partition/exchange) + probe join 2
@@ -158,25 +149,20 @@ class Q3Pipeline:
         elif N == 1:
             p_key, p_ext, p_disc, p_sel, p_n = self.l_key, self.l_ext, self.l_disc, lsel, ln
         else:
-            import torch
             t0 = tic()
-            counts, perm = hip.partition(ctx, self.l_key, lsel, ln, N)
-            frees.append(perm)
-            send = [self._gather_t(self.l_key, perm, ln, torch.int64),
-                    self._gather_t(self.l_ext, perm, ln, torch.int64),
-                    self._gather_t(self.l_disc, perm, ln, torch.int64)]
-            ctx.sync()
+            counts_dev, perm = hip.partition_dev(ctx, self.l_key, lsel, ln, N)
+            send = [(hip.gather(ctx, self.l_key, perm, ln), np.int64),
+                    (hip.gather(ctx, self.l_ext, perm, ln), np.int64),
+                    (hip.gather(ctx, self.l_disc, perm, ln), np.int64)]
             stage("lineitem_partition", t0)
             t0 = tic()
-            (lk, le, ld), _ = dist.exchange_columns(send, counts)
-            import torch as _t
-            _t.cuda.synchronize()
-            t["lineitem_exchange"] = tic() - t0
-            t["exchange_bytes_sent"] = int(sum(counts) - counts[dist.rank()]) * 24
-            self._keep3 = (lk, le, ld)
-            p_key = _raw(hip.PH_I64, lk.data_ptr())
-            p_ext, p_disc = _raw(hip.PH_DEC64, le.data_ptr(), 2), _raw(hip.PH_DEC64, ld.data_ptr(), 2)
-            p_sel, p_n = None, lk.numel()
+            (lk, le, ld), nrecv, sent = dist.exchange(ctx, send, counts_dev, ln)
+            stage("lineitem_exchange", t0)
+            t["exchange_bytes_sent"] = sent * 24
+            frees += [counts_dev, perm, lk, le, ld] + [p for p, _ in send]
+            p_key = _raw(hip.PH_I64, lk)
+            p_ext, p_disc = _raw(hip.PH_DEC64, le, 2), _raw(hip.PH_DEC64, ld, 2)
+            p_sel, p_n = None, nrecv
         if fused2 is not None:
             m2, prow, brow = fused2
             frees += [prow, brow]
@@ -219,7 +205,7 @@ class Q3Pipeline:
             pick = np.arange(ng)
         order = pick[np.lexsort((keys[pick, 1], -rev_lo[pick]))][:limit]
         cand = [(int(keys[g, 0]), int(rev_lo[g]), int(keys[g, 1]), int(keys[g, 2])) for g in order]
-        top = dist.merge_topk(cand, limit, key=lambda x: (-x[1], x[2]))   # revenue desc, o_orderdate
+        top = dist.merge_topk(cand, limit, key=lambda x: (-x[1], x[2]), ctx=ctx)   # revenue desc, o_orderdate
         groups = None
         if want_groups:
             groups = list(zip(keys[:, 0].tolist(), rev_lo.tolist(), keys[:, 1].tolist(), keys[:, 2].tolist()))
@@ -228,8 +214,7 @@ class Q3Pipeline:
         j2.free()
         for p in frees:
             ctx.free(p)
-        self._keep = self._keep2 = self._keep3 = None
-        return dict(ngroups=ngroups_total, groups=groups, top=top, join_rows=m2, timings=t)
+        return dict(ngroups=ngroups_total, groups=groups, top=top, join_rows=m2, build_rows=cn + m1, timings=t)
 
 
 def q3_text(top):
@@ -285,14 +270,6 @@ class Q9Pipeline:
         for c in self.cols:
             c.free()
 
-    def _tensor_gather(self, col, idx_ptr, n, dtype):
-        import torch
-        out = torch.empty(max(n, 1), dtype=dtype, device="cuda")
-        if n:
-            c = col.col() if isinstance(col, hip.DevColumn) else col
-            hip.check(hip.lib().ph_gather(self.ctx.h, hip.ctypes.byref(c), idx_ptr, hip.i64(n), hip.vp(out.data_ptr())))
-        return out[:n]
-
     def run(self):
         """N == 1: everything local. N > 1 (one process per GPU, tables sharded by row ranges):
         the small build sides are broadcast — pink part keys, the partsupp rows of pink parts (found
@@ -304,7 +281,6 @@ class Q9Pipeline:
         N = dist.world()
         t, frees = {}, []
         tic = time.perf_counter
-        keep = []   # torch tensors that back device columns
 
         def stage(name, t0):
             if self.time_stages:
@@ -317,14 +293,11 @@ class Q9Pipeline:
             return p
 
         def bcast(col, idx, n, dtype):
-            """gather rows idx of col and all-gather them over the ranks -> (ph_col-able ptr, count)"""
-            import torch
-            mine = self._tensor_gather(col, idx, n, dtype)
-            ctx.sync()
-            allv = dist.allgather_rows(mine)
-            torch.cuda.synchronize()
-            keep.append(allv)
-            return allv
+            """gather rows idx of col and all-gather them over the ranks -> (device pointer, count)"""
+            mine = gat(col, idx, n)
+            allv, total = dist.allgather_rows(ctx, mine, n, dtype)
+            frees.append(allv)
+            return allv, total
 
         t0 = tic()
         psel, np_ = hip.filter_select(ctx, self.p_name, self.n["p"], hip.PH_LIKE,
@@ -335,9 +308,8 @@ class Q9Pipeline:
             frees.append(pk)
             j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, np_)
         else:
-            import torch
-            pk = bcast(self.p_key, psel, np_, torch.int32)
-            j = hip.Join(ctx, [_raw(hip.PH_I32, pk.data_ptr())], None, pk.numel())
+            pk, npk = bcast(self.p_key, psel, np_, np.int32)
+            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, npk)
         stage("part_like_build", t0)
         t0 = tic()
         n1, lrow, _ = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
@@ -362,13 +334,12 @@ class Q9Pipeline:
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, fn)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
         else:
-            import torch
             # ... and broadcast, so every rank can resolve its own lineitem rows
-            bp = bcast(self.ps_part, fsel, fn, torch.int32)
-            bs = bcast(self.ps_supp, fsel, fn, torch.int32)
-            bc = bcast(self.ps_cost, fsel, fn, torch.int64)
-            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp.data_ptr()), _raw(hip.PH_I32, bs.data_ptr())], None, bp.numel())
-            ps_cost = _raw(hip.PH_DEC64, bc.data_ptr(), 2)
+            bp, nb = bcast(self.ps_part, fsel, fn, np.int32)
+            bs, _ = bcast(self.ps_supp, fsel, fn, np.int32)
+            bc, _ = bcast(self.ps_cost, fsel, fn, np.int64)
+            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, nb)
+            ps_cost = _raw(hip.PH_DEC64, bc, 2)
         k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
         n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
         jps.free()
@@ -381,13 +352,12 @@ class Q9Pipeline:
             js = hip.Join(ctx, [self.s_key], None, self.n["s"])
             s_nat = self.s_nat
         else:
-            import torch
             ident = ctx.upload(np.arange(self.n["s"], dtype=np.int32))
             frees.append(ident)
-            sk = bcast(self.s_key, ident, self.n["s"], torch.int32)
-            sn = bcast(self.s_nat, ident, self.n["s"], torch.int32)
-            js = hip.Join(ctx, [_raw(hip.PH_I32, sk.data_ptr())], None, sk.numel())
-            s_nat = _raw(hip.PH_I32, sn.data_ptr())
+            sk, nsk = bcast(self.s_key, ident, self.n["s"], np.int32)
+            sn, _ = bcast(self.s_nat, ident, self.n["s"], np.int32)
+            js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk)
+            s_nat = _raw(hip.PH_I32, sn)
         ks = gat(self.l_supp, lrow2, n2)
         n3, pos3, srow = js.probe_inner([_raw(hip.PH_I32, ks)], None, n2, n2)
         frees += [pos3, srow]
@@ -417,29 +387,20 @@ class Q9Pipeline:
             o_date = self.o_date.col()
             m = n3
         else:
-            import torch
             # order-key stage: both sides hash-partitioned by order key and exchanged
-            counts, perm = hip.partition(ctx, _raw(hip.PH_I64, c_okey), None, n3, N)
-            frees.append(perm)
-            send = [self._tensor_gather(_raw(hip.PH_I64, c_okey), perm, n3, torch.int64),
-                    self._tensor_gather(_raw(hip.PH_DEC64, c_amount), perm, n3, torch.int64),
-                    self._tensor_gather(_raw(hip.PH_I32, c_nat), perm, n3, torch.int32)]
-            ctx.sync()
-            recv, _rc = dist.exchange_columns(send, counts)
-            ocounts, operm = hip.partition(ctx, self.o_key, None, self.n["o"], N)
-            frees.append(operm)
-            osend = [self._tensor_gather(self.o_key, operm, self.n["o"], torch.int64),
-                     self._tensor_gather(self.o_date, operm, self.n["o"], torch.int32)]
-            ctx.sync()
-            orecv, _rc2 = dist.exchange_columns(osend, ocounts)
-            torch.cuda.synchronize()
-            keep += recv + orecv
-            t["exchange_bytes_sent"] = int(sum(counts) - counts[dist.rank()]) * 20 + \
-                int(sum(ocounts) - ocounts[dist.rank()]) * 12
-            c_okey, c_amount, c_nat = [x.data_ptr() for x in recv]
-            m = recv[0].numel()
-            jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0].data_ptr())], None, orecv[0].numel())
-            o_date = _raw(hip.PH_DATE, orecv[1].data_ptr())
+            counts_dev, perm = hip.partition_dev(ctx, _raw(hip.PH_I64, c_okey), None, n3, N)
+            send = [(gat(_raw(hip.PH_I64, c_okey), perm, n3), np.int64),
+                    (gat(_raw(hip.PH_DEC64, c_amount), perm, n3), np.int64),
+                    (gat(_raw(hip.PH_I32, c_nat), perm, n3), np.int32)]
+            recv, m, sent = dist.exchange(ctx, send, counts_dev, n3)
+            ocounts_dev, operm = hip.partition_dev(ctx, self.o_key, None, self.n["o"], N)
+            osend = [(gat(self.o_key, operm, self.n["o"]), np.int64), (gat(self.o_date, operm, self.n["o"]), np.int32)]
+            orecv, mo, osent = dist.exchange(ctx, osend, ocounts_dev, self.n["o"])
+            frees += [counts_dev, perm, ocounts_dev, operm] + recv + orecv
+            t["exchange_bytes_sent"] = sent * 20 + osent * 12
+            c_okey, c_amount, c_nat = recv
+            jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0])], None, mo)
+            o_date = _raw(hip.PH_DATE, orecv[1])
         if jo is None:
             jint = hip.Join(ctx, [_raw(hip.PH_I64, c_okey)], None, m)
             n4, orow, pos4 = jint.probe_inner([self.o_key], None, self.n["o"], max(m, 1))
@@ -465,7 +426,7 @@ class Q9Pipeline:
             ctx.free(p)
         mine = {(int(r["keys"][g][0]), int(r["keys"][g][1])): ([r["sum"][g][0]], [int(r["count"][g][0])])
                 for g in range(r["ngroups"])}
-        merged = dist.merge_group_partials(mine)
+        merged = dist.merge_group_partials(mine, ctx=ctx)
         rows = [(k[0], k[1], v[0][0]) for k, v in merged.items()]
         return dict(ngroups=len(rows), rows=rows, join_rows=n4, timings=t)
 

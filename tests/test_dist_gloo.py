@@ -1,7 +1,8 @@
 """world_size-2 gloo (CPU) tests of the N>1 path: the partition/all-to-all exchange plumbing and
 the partial-group / top-k merges used by bench.py and the Q3 pipeline. The device kernels are
 replaced by numpy stand-ins here (same dest = mix64(key) % N rule as ph_partition); what is
-under test is the exchange protocol itself."""
+under test is the exchange protocol itself, with the send/receive offsets computed by the C ABI's
+host routine ph_exchange_layout (the one the RCCL path uses)."""
 import os
 import socket
 
@@ -44,9 +45,15 @@ def worker(rank, world, port, out):
         dest = (mix64(keys) % np.uint64(world)).astype(np.int64)
         order = np.argsort(dest, kind="stable")
         counts = [int((dest == d).sum()) for d in range(world)]
-        (rk, rv), rc = pd.exchange_columns([torch.from_numpy(keys[order]), torch.from_numpy(vals[order])], counts)
-        rk, rv = rk.numpy(), rv.numpy()
-        assert len(rk) == sum(rc)
+        (rk, rv), rc = pd.exchange_columns([keys[order], vals[order]], counts)
+        assert len(rk) == len(rv) == sum(rc)
+        # the offsets come from the ABI's host routine: this rank's column of the count matrix
+        matrix = np.array(pd._gather_objects(counts), dtype=np.int64)
+        so, ro = pd.layout(matrix, rank)
+        assert so[-1] == n and ro[-1] == len(rk) and [ro[s + 1] - ro[s] for s in range(world)] == rc
+        # rows arrive grouped by source rank, each group in the sender's (stable) order
+        mine = keys[order][so[rank]:so[rank + 1]]
+        assert np.array_equal(rk[ro[rank]:ro[rank + 1]], mine)
         # every received key belongs to this rank's partition
         assert np.all((mix64(rk) % np.uint64(world)).astype(np.int64) == rank)
         # local aggregate on disjoint keys; the union over ranks must equal the global aggregate
@@ -54,8 +61,8 @@ def worker(rank, world, port, out):
         for k, v in zip(rk.tolist(), rv.tolist()):
             s, c = local.get((k,), ([0], [0]))
             local[(k,)] = ([s[0] + v], [c[0] + 1])
-        allk = pd.allgather_rows(torch.from_numpy(keys)).numpy()
-        allv = pd.allgather_rows(torch.from_numpy(vals)).numpy()
+        allk = pd.allgather_rows_host(keys)
+        allv = pd.allgather_rows_host(vals)
         merged = pd.merge_group_partials(local)
         want = {}
         for k, v in zip(allk.tolist(), allv.tolist()):
@@ -79,7 +86,8 @@ def test_partition_exchange_merge_world2():
 
 
 def test_single_process_paths_are_identity():
-    cols, rc = pd.exchange_columns([torch.arange(5)], [5])
+    cols, rc = pd.exchange_columns([np.arange(5)], [5])
     assert rc == [5] and cols[0].tolist() == [0, 1, 2, 3, 4]
-    assert pd.allgather_rows(torch.arange(3)).tolist() == [0, 1, 2]
+    assert pd.allgather_rows_host(np.arange(3)).tolist() == [0, 1, 2]
+    assert pd.merge_topk([(3, 1), (1, 2)], 1, key=lambda x: x[0]) == [(1, 2)]
     assert pd.merge_group_partials({(1,): ([2], [3])}) == {(1,): ([2], [3])}

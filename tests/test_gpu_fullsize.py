@@ -98,3 +98,48 @@ def test_q3_sf10_join_rows_match_numpy(ctx, sf10):
     assert len(got) == len(uk) == r["ngroups"]
     assert all(got[int(k)] == int(v) for k, v in zip(uk[:50000], want[:50000]))
     assert sum(got.values()) == int(rev.sum())          # checksum of all groups
+
+
+def test_q9_sf10_join_rows_and_profit_match_numpy(ctx, sf10):
+    """Q9 at SF10 (the size bench.py's Q9 figure is quoted on; the LDS coarse-bitmap candidate
+    kernel and the semi-join reduction of partsupp are selected by these build-side sizes): the
+    join-row count, the 175 (nation, year) keys and the exact profit sum of every group against
+    numpy lookups (np.isin / searchsorted / np.add.at), independent of the oracle."""
+    sf = (10, 1)
+    L = tpchgen.lineitem(sf, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity",
+                                      "l_extendedprice", "l_discount"])
+    Od = tpchgen.orders(sf, columns=["o_orderkey", "o_orderdate"])
+    P, PS, S = tpchgen.part(sf), tpchgen.partsupp(sf), tpchgen.supplier(sf)
+    assert len(L["l_orderkey"]) == 59986052 and np.array_equal(L["l_orderkey"], sf10["l_orderkey"])
+    pipe = pipelines.Q9Pipeline(ctx, L, Od, P, PS, S)
+    r = pipe.run()
+    pipe.free()
+    # p_name like '%pink%': a name is five colour words joined by blanks, the pattern has no blank
+    pink_words = [i for i, w in enumerate(tpchgen.colors()) if "pink" in w]
+    pink = P["p_partkey"][np.isin(P["p_name_colors"].reshape(-1, 5), pink_words).any(axis=1)]
+    lm = np.isin(L["l_partkey"], pink)
+    lp, ls = L["l_partkey"][lm], L["l_suppkey"][lm]
+    # partsupp on (partkey, suppkey), supplier on suppkey, orders on orderkey: each N:1
+    pskey = PS["ps_partkey"].astype(np.int64) << 32 | PS["ps_suppkey"].astype(np.int64)
+    order = np.argsort(pskey, kind="stable")
+    want_ps = lp.astype(np.int64) << 32 | ls.astype(np.int64)
+    pos = np.searchsorted(pskey[order], want_ps)
+    assert np.array_equal(pskey[order][pos], want_ps)            # every lineitem has its partsupp row
+    cost = PS["ps_supplycost"][order][pos]
+    so = np.argsort(S["s_suppkey"], kind="stable")
+    spos = np.searchsorted(S["s_suppkey"][so], ls)
+    assert np.array_equal(S["s_suppkey"][so][spos], ls)
+    nat = S["s_nationkey"][so][spos]
+    opos = np.searchsorted(Od["o_orderkey"], L["l_orderkey"][lm])   # o_orderkey ascends
+    assert np.array_equal(Od["o_orderkey"][opos], L["l_orderkey"][lm])
+    year = (Od["o_orderdate"][opos].astype("datetime64[D]").astype("datetime64[Y]").astype(np.int64) + 1970)
+    # amount = l_extendedprice*(1-l_discount) [scale 4] - ps_supplycost*l_quantity [scale 2 -> 4]
+    amount = L["l_extendedprice"][lm] * (100 - L["l_discount"][lm]) - cost * L["l_quantity"][lm].astype(np.int64) * 100
+    assert r["join_rows"] == int(lm.sum())
+    gid = nat.astype(np.int64) * 4096 + year
+    uk, inv = np.unique(gid, return_inverse=True)
+    want = np.zeros(len(uk), np.int64)
+    np.add.at(want, inv, amount)
+    got = {a * 4096 + b: c for a, b, c in r["rows"]}
+    assert r["ngroups"] == len(uk) == 175
+    assert got == {int(k): int(v) for k, v in zip(uk, want)}

@@ -672,3 +672,107 @@ def test_filter_select_unaligned_column_pointer(ctx):
     want = np.nonzero(data[3:] < 50)[0]
     assert cnt == len(want) and np.array_equal(dl(ctx, sel, np.int32, cnt), want.astype(np.int32))
     d.free()
+
+
+def test_partition_is_stable_and_device_counts_match(ctx):
+    """ph_partition_dev: rows keep their input order inside every partition (the permutation is
+    reproducible, so first-seen group order survives an exchange), with and without a selection;
+    the device counts equal the host counts of ph_partition."""
+    rng = np.random.default_rng(5)
+    n = 300_001
+    keys = rng.integers(0, 1 << 40, n).astype(np.int64)
+    dk = hip.DevColumn(ctx, hip.PH_I64, keys)
+    sel = np.sort(rng.choice(n, 123_457, replace=False)).astype(np.int32)
+    dsel = ctx.upload(sel)
+    for nparts in (2, 3, 8, 64):
+        for s, rows in ((None, np.arange(n, dtype=np.int32)), (dsel, sel)):
+            m = len(rows)
+            cdev, perm = hip.partition_dev(ctx, dk, s, m, nparts)
+            counts = ctx.download(cdev, np.int64, nparts)
+            p = ctx.download(perm, np.int32, m)
+            hc, perm2 = hip.partition(ctx, dk, s, m, nparts)
+            assert counts.tolist() == hc and np.array_equal(p, ctx.download(perm2, np.int32, m))   # reproducible
+            start = 0
+            seen = np.zeros(n, bool)
+            for c in counts:
+                part = p[start:start + c]
+                assert np.all(np.diff(part) > 0)          # input order kept inside the partition
+                seen[part] = True
+                start += c
+            assert start == m and seen[rows].all() and seen.sum() == m
+            for q in (cdev, perm, perm2):
+                ctx.free(q)
+    dk.free()
+
+
+def test_agg_topk_null_groups_and_avg(ctx):
+    """a SUM/MIN/MAX no input ever reached is NULL and NULLs sort first, so such groups
+    must always be among the preselected ones; AVG is not ranked by its sum word and is refused."""
+    rng = np.random.default_rng(43)
+    n = 50_000
+    k = rng.integers(0, 2000, n).astype(np.int64)
+    v = rng.integers(1, 10**6, n).astype(np.int64)
+    valid = np.ones(n, bool)
+    valid[np.isin(k, [7, 8, 9])] = False          # three groups whose every input is NULL
+    bits = np.packbits(valid, bitorder="little")
+    dk = hip.DevColumn(ctx, hip.PH_I64, k)
+    dv = hip.DevColumn(ctx, hip.PH_I64, v, validity=bits)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_MAX, 0), (hip.PH_A_AVG, 0)])
+    agg.sink([dk], [dv], None, n)
+    full = agg.finalize(python_ints=False)
+    nullkeys = set(full["keys"][:, 0][full["count"][:, 0] == 0].tolist())
+    assert nullkeys == {7, 8, 9}
+    live = full["count"][:, 0] > 0
+    for a in (0, 1):
+        vals = full["sum_lo"][:, a].view(np.int64)[live]
+        for desc in (True, False):
+            r = agg.topk(a, 5, descending=desc, cap=full["ngroups"])
+            got = set(r["keys"][:, 0].tolist())
+            assert nullkeys <= got                     # NULLs first, whatever the direction
+            # the 5 best rows are the 3 NULL groups and then the 2 best live ones: all preselected
+            order = np.sort(vals)[::-1] if desc else np.sort(vals)
+            best2 = set(full["keys"][:, 0][live][(vals >= order[1]) if desc else (vals <= order[1])].tolist())
+            assert best2 <= got and len(got) <= 3 + len(best2) + 3
+    with pytest.raises(hip.PlanHipError) as e:
+        agg.topk(2, 5)
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    agg.free(); dk.free(); dv.free()
+
+
+def test_rccl_communicator_single_rank_roundtrip(ctx):
+    """The multi-GPU entry points of the C ABI on real hardware with a 1-rank RCCL communicator
+    (a one-GPU box cannot hold two RCCL ranks): id -> init, count matrix, the grouped all-to-all
+    (self copy), variable all-gather, reductions and an asynchronous all-gather with wait_keep."""
+    from plan_amd import dist as pd
+    g = pd.RcclGroup(ctx, 1, 0, pd.RcclGroup.unique_id())
+    try:
+        assert hip.lib().ph_comm_nranks(g.h) == 1 and hip.lib().ph_comm_rank(g.h) == 0
+        rng = np.random.default_rng(9)
+        n = 70_001
+        keys = rng.integers(0, 1 << 30, n).astype(np.int64)
+        vals = rng.integers(0, 1 << 20, n).astype(np.int32)
+        dk, dv = hip.DevColumn(ctx, hip.PH_I64, keys), hip.DevColumn(ctx, hip.PH_I32, vals)
+        cdev, perm = hip.partition_dev(ctx, dk, None, n, 1)
+        matrix = g.exchange_counts(cdev)
+        assert matrix.tolist() == [[n]]
+        sk, sv = hip.gather(ctx, dk, perm, n), hip.gather(ctx, dv, perm, n)
+        rk, rv = ctx.alloc(n * 8), ctx.alloc(n * 4)
+        g.exchange_columns([sk, sv], [rk, rv], [8, 4], matrix)
+        assert np.array_equal(ctx.download(rk, np.int64, n), keys) and np.array_equal(ctx.download(rv, np.int32, n), vals)
+        out = ctx.alloc(n * 8)
+        rc, counts = g.allgather_rows(dk.data, n, 8, out, n)
+        assert rc == 0 and counts == [n] and np.array_equal(ctx.download(out, np.int64, n), keys)
+        rc, counts = g.allgather_rows(dk.data, n, 8, out, n - 1)
+        assert rc == hip.PH_ECAPACITY and counts == [n]
+        assert g.allreduce([5, -7], "sum") == [5, -7] and g.allreduce([5], "max") == [5]
+        g.barrier()
+        for i in range(6):        # more asynchronous collectives than the event ring holds
+            g.wait(keep=1)
+            g.allgather(dk.data, out, 4096, async_=True)
+        g.wait()
+        assert np.array_equal(ctx.download(out, np.int64, 512), keys[:512])
+        for q in (cdev, perm, sk, sv, rk, rv, out):
+            ctx.free(q)
+        dk.free(); dv.free()
+    finally:
+        g.close()
