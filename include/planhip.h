@@ -329,7 +329,15 @@ int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out);
 int ph_scan_plan_partials_dev(ph_scan_plan *p, void **dev, int32_t *nwords);
 int ph_scan_plan_fetch_merged(ph_scan_plan *p, const uint64_t *words, int32_t nranks,
                               ph_agg_result **out);
-/* name of the kernel family the plan dispatches to ("q1_lowcard", "q6_scalar", "generic") */
+/* Build check of the plan-specialised path without a device: generates the kernel source of canned
+ * shape `which` (0 Q1, 1 Q6, 2 three keys + MIN/MAX + `!=`, 3 predicate-only COUNT) and compiles it
+ * with hiprtc for gfx950; src_out (optional, cap bytes) receives the source. */
+int ph_scan_jit_selfcheck(int32_t which, char *src_out, int64_t cap);
+/* name of the kernel family the plan dispatches to: "lowcard_chain" / "filter_sumprod" (the two
+ * precompiled fused kernels), "jit" (a kernel generated from the plan's shape and compiled with
+ * hiprtc at plan creation: any range / != conjunction over NULL-free columns, <= 4 dictionary-code
+ * group columns whose slots fit LDS, SUM/AVG/COUNT of products of affine column factors, MIN/MAX of
+ * a column), "generic" (the operator chain: filter -> expression -> aggregate sink) */
 const char *ph_scan_plan_kind(const ph_scan_plan *p);
 void ph_scan_plan_free(ph_scan_plan *p);
 void ph_agg_result_free(ph_agg_result *r);

@@ -456,10 +456,12 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long
     bool wide = false;
     for (int g = blockIdx.x * 256 + threadIdx.x; g < ng; g += gridDim.x * 256) {
         const long long lo = (long long)sum_lo[(int64_t)g * naggs + a];
-        if (pass == 7 && sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) wide = true;
+        const bool live = cnt[(int64_t)g * naggs + a] != 0;
+        // sums only (k < 0 marks a MIN/MAX aggregate, whose value lives in the low word alone)
+        if (pass == 7 && live && k > 0 && sum_hi[(int64_t)g * naggs + a] != (lo >> 63)) wide = true;
         // an aggregate no input ever reached is NULL, and NULLs sort first whatever the direction
         // (sort_layout.go:46): the best possible key
-        unsigned long long key = cnt[(int64_t)g * naggs + a] ? order_key(lo, descending) : 0ull;
+        unsigned long long key = live ? order_key(lo, descending) : 0ull;
         if ((key & mask) == (prefix & mask)) atomicAdd(&lh[(key >> (8 * pass)) & 0xff], 1u);
     }
     if (wide) atomicOr(flags, 1);
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const unsigned long long
     // a serial walk (256 dependent LDS reads by one thread cost more than the histogram itself)
     const unsigned v = atomicExch(&hist[threadIdx.x], 0u);  // read at the coherence point and clear
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long rem = pass == 7 ? k : (long long)state[1];  // every thread reads it before the barrier below
+    const long long rem = pass == 7 ? (k < 0 ? -k : k) : (long long)state[1];  // every thread reads it before the barrier below
     long long incl = v;
     for (int o = 1; o < 64; o <<= 1) {
         long long y = __shfl_up(incl, o);
@@ -1312,7 +1314,7 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     const int tg = (int)std::min<int64_t>((a->gcap + 255) / 256, ctx->cu_count * 2);
     for (int pass = 7; pass >= 0; pass--)  // radix select, most significant byte first
         ph::topk_hist_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, a->counters, descending, pass,
-                                                          (long long)k, state, hist, done, meta + 1);
+                                                          kind == PH_A_SUM ? (long long)k : -(long long)k, state, hist, done, meta + 1);
     ph::topk_collect_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->cnt, a->naggs, agg_index, a->counters, descending, (long long)k,
                                                           state, ids, meta, cap);
     ph::agg_pack_kernel<<<std::max(1, std::min((cap + 255) / 256, 64)), 256, 0, ctx->stream>>>(

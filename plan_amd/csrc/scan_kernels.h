@@ -36,4 +36,7 @@ int launch_lowcard_chain(ph_ctx *ctx, const LowcardChainParams &P, int grid);
 int launch_merge_partials(ph_ctx *ctx, const long long *partials, int nblocks, int nacc,
                           int min_stride, unsigned long long *out_lo, long long *out_hi);
 
+int launch_merge_partials_ops(ph_ctx *ctx, const long long *partials, int nblocks, int nacc, int stride,
+                              unsigned long long opmask, unsigned long long *out_lo, long long *out_hi);
+
 }  // namespace ph

@@ -301,6 +301,51 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__r
     }
 }
 
+// out[j] over blocks with a per-word operation: op = (opmask >> 2*(j % stride)) & 3 — 0: 128-bit sum,
+// 1: signed min, 2: signed max (MIN/MAX accumulators and first-row ids of the generated kernels)
+__global__ __launch_bounds__(64) void merge_partials_ops_kernel(const long long *__restrict__ partials,
+                                                                int nblocks, int nacc, int stride, unsigned long long opmask,
+                                                                unsigned long long *__restrict__ out_lo,
+                                                                long long *__restrict__ out_hi) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int op = (int)((opmask >> (2 * (j % stride))) & 3);
+    if (op != 0) {
+        long long m = op == 1 ? INT64_MAX : INT64_MIN;
+        for (int b = lane; b < nblocks; b += 64) {
+            long long v = partials[(int64_t)b * nacc + j];
+            m = op == 1 ? (v < m ? v : m) : (v > m ? v : m);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            long long v = __shfl_xor(m, o);
+            m = op == 1 ? (v < m ? v : m) : (v > m ? v : m);
+        }
+        if (lane == 0) {
+            out_lo[j] = (unsigned long long)m;
+            out_hi[j] = m < 0 ? -1 : 0;
+        }
+        return;
+    }
+    unsigned long long lo = 0;
+    long long hi = 0;
+    for (int b = lane; b < nblocks; b += 64) {
+        long long v = partials[(int64_t)b * nacc + j];
+        unsigned long long nlo = lo + (unsigned long long)v;
+        hi += (nlo < lo ? 1 : 0) + (v < 0 ? -1 : 0);
+        lo = nlo;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long olo = __shfl_xor(lo, o);
+        long long ohi = __shfl_xor(hi, o);
+        unsigned long long nlo = lo + olo;
+        hi = hi + ohi + (nlo < lo ? 1 : 0);
+        lo = nlo;
+    }
+    if (lane == 0) {
+        out_lo[j] = lo;
+        out_hi[j] = hi;
+    }
+}
+
 static bool scan_nt() {
     static int v = -1;
     if (v < 0) {
@@ -346,6 +391,14 @@ int launch_merge_partials(ph_ctx *ctx, const long long *partials, int nblocks, i
                           int min_stride, unsigned long long *out_lo, long long *out_hi) {
     merge_partials_kernel<<<nacc, 64, 0, ctx->stream>>>(partials, nblocks, nacc, min_stride, out_lo,
                                                         out_hi);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+
+int launch_merge_partials_ops(ph_ctx *ctx, const long long *partials, int nblocks, int nacc, int stride,
+                              unsigned long long opmask, unsigned long long *out_lo, long long *out_hi) {
+    merge_partials_ops_kernel<<<nacc, 64, 0, ctx->stream>>>(partials, nblocks, nacc, stride, opmask, out_lo, out_hi);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }

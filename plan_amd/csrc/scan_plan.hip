@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "scan_jit.h"
 #include "scan_kernels.h"
 
 namespace {
@@ -235,7 +236,7 @@ long double affine_bound(const Affine &a, int64_t mn, int64_t mx) {
 
 }  // namespace
 
-enum PlanKind { PK_FILTER_SUMPROD = 1, PK_LOWCARD_CHAIN = 2, PK_GENERIC = 3 };
+enum PlanKind { PK_FILTER_SUMPROD = 1, PK_LOWCARD_CHAIN = 2, PK_GENERIC = 3, PK_JIT = 4 };
 
 struct ph_scan_plan {
     ph_ctx *ctx = nullptr;
@@ -250,7 +251,16 @@ struct ph_scan_plan {
     struct AggMap { int32_t kind; int acc; int32_t scale; };
     std::vector<AggMap> aggs;
     int32_t nkeys = 0;
-    int32_t group_cols[2] = {-1, -1};
+    int32_t group_cols[4] = {-1, -1, -1, -1};
+    // layout of the raw accumulator words of the fused kinds: per group slot `stride` words, the
+    // count at cnt_idx, the first-seen row id at first_idx (-1: none), ops[j] = how word j merges
+    // (0 sum, 1 min, 2 max); slot = dense index over gcard
+    int nslots = 1, stride = 0, cnt_idx = 0, first_idx = -1;
+    std::vector<int> ops, gcard;
+    // PK_JIT: the plan-specialised kernel
+    ph::JitShape jshape;
+    ph::JitKernel jkernel;
+    ph::JitParams jparams{};
     // device buffers
     long long *partials = nullptr;
     unsigned long long *out_lo = nullptr;
@@ -285,7 +295,7 @@ extern "C" void ph_scan_plan_free(ph_scan_plan *p) {
 
 extern "C" const char *ph_scan_plan_kind(const ph_scan_plan *p) {
     if (!p) return "";
-    return p->kind == PK_FILTER_SUMPROD ? "filter_sumprod" : (p->kind == PK_LOWCARD_CHAIN ? "lowcard_chain" : "generic");
+    return p->kind == PK_FILTER_SUMPROD ? "filter_sumprod" : p->kind == PK_LOWCARD_CHAIN ? "lowcard_chain" : p->kind == PK_JIT ? "jit" : "generic";
 }
 
 static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t npreds,
@@ -386,6 +396,7 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
         Affine one; one.B = 1;
         p->row_bound = affine_bound(one, col(a_col).min, col(a_col).max) * affine_bound(one, col(b_col).min, col(b_col).max);
         p->nacc = 2;
+        p->nslots = 1; p->stride = 2; p->cnt_idx = 1; p->first_idx = -1; p->ops = {0, 0};
         // one 256-thread workgroup per CU (1 wave per SIMD) streams fastest: measured on MI355X,
         // SF10: 6.48 TB/s at grid 256 vs 5.95 at 2048 and 4.6-5.4 at grids that are not a
         // multiple of the CU count (tail imbalance); scripts/ab_scan2.sh
@@ -482,6 +493,9 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
         p->row_bound = std::max({be * b1 * b2, be * b1, be, affine_bound(one, col(d).min, col(d).max),
                                  affine_bound(one, col(q).min, col(q).max)});
         p->nacc = p->lc.nslots * (ph::LC_NACC + 1);  // + first_row
+        p->nslots = p->lc.nslots; p->stride = ph::LC_NACC + 1; p->cnt_idx = 5; p->first_idx = ph::LC_NACC;
+        p->ops = {0, 0, 0, 0, 0, 0, 1};
+        p->gcard = {n0, n1};
         // one workgroup per CU: 6.35 TB/s at grid 256 vs 6.0 at 512 (2 per CU is what the
         // per-thread-private LDS accumulators would still allow); scripts/ab_scan2.sh
         p->max_grid = ctx->cu_count;
@@ -493,6 +507,145 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
 }
 
 
+
+// ---------------------------------------------------------------- plan-specialised (hiprtc) plans
+// Any conjunction of range / `!=` predicates over NULL-free fixed-width columns, grouped by up to
+// four dictionary-code columns (dense slots that fit the CU's LDS as per-thread-private
+// accumulator columns) and aggregated with SUM/AVG/COUNT over products of affine column factors or
+// MIN/MAX of a column, becomes one generated kernel (scan_jit.h): only the columns the plan names
+// are read, each byte once.
+static int try_jit(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t npreds,
+                   const int32_t *group_cols, int32_t ngroup_cols, const ph_aggexpr *aggs, int32_t naggs,
+                   ph_scan_plan **out) {
+    auto unsupported = [&](const char *why) { set_error("plan-specialised kernel: %s", why); return PH_EUNSUPPORTED; };
+    if (ngroup_cols > 4) return unsupported("more than 4 group columns");
+    ph::JitShape S;
+    std::vector<long long> consts;
+    std::vector<int32_t> tcol;   // loaded column slot -> table column
+    auto slot_of = [&](int32_t c) -> int {
+        for (size_t i = 0; i < tcol.size(); i++) if (tcol[i] == c) return (int)i;
+        const auto &d = t->cols[(size_t)c];
+        int w = d.type == PH_CODE8 ? 1 : (d.type == PH_I32 || d.type == PH_DATE) ? 4 : (d.type == PH_I64 || d.type == PH_DEC64) ? 8 : 0;
+        if (w == 0 || d.validity) return -1;
+        tcol.push_back(c);
+        S.col_width.push_back(w);
+        return (int)tcol.size() - 1;
+    };
+    // ---- predicates: one merged range per column, `!=` separately
+    bool never = false;
+    std::vector<Range> ranges;
+    struct Ne { int32_t col; long long k; };
+    std::vector<Ne> nes;
+    for (int32_t i = 0; i < npreds; i++) {
+        const ph_pred &pr = preds[i];
+        if (pr.col < 0 || pr.col >= (int32_t)t->cols.size()) { set_error("predicate column %d out of range", pr.col); return PH_EINVAL; }
+        const auto &c = t->cols[(size_t)pr.col];
+        if (pr.op == PH_NE && c.type == PH_I32 && pr.k.type == PH_I32 && !c.validity) { nes.push_back({pr.col, (int32_t)pr.k.i}); continue; }
+        Range r;
+        int rc = lower_pred(t, pr, &r);
+        if (rc == PH_EUNSUPPORTED) return unsupported("a predicate does not lower to an integer range");
+        PH_CHECK(rc);
+        if (r.never) never = true;
+        bool merged = false;
+        for (auto &q : ranges) if (q.col == r.col) { q.lo = std::max(q.lo, r.lo); q.hi = std::min(q.hi, r.hi); merged = true; }
+        if (!merged) ranges.push_back(r);
+    }
+    for (auto &q : ranges) if (q.lo > q.hi) never = true;
+    for (auto &q : ranges) {
+        int sl = slot_of(q.col);
+        if (sl < 0) return unsupported("predicate column type");
+        S.preds.push_back({sl, false});
+        consts.push_back(q.lo);
+        consts.push_back(q.hi);
+    }
+    for (auto &q : nes) {
+        int sl = slot_of(q.col);
+        if (sl < 0) return unsupported("predicate column type");
+        S.preds.push_back({sl, true});
+        consts.push_back(q.k);
+    }
+    // ---- group columns: dense slot over dictionary codes
+    ph_scan_plan *p = new ph_scan_plan();
+    p->ctx = ctx; p->t = t; p->kind = PK_JIT; p->never = never;
+    auto fail = [&](int rc) { ph_scan_plan_free(p); return rc; };
+    int64_t ns = 1;
+    for (int32_t g = 0; g < ngroup_cols; g++) {
+        int32_t gc = group_cols[g];
+        if (gc < 0 || gc >= (int32_t)t->cols.size()) { set_error("group column %d out of range", gc); return fail(PH_EINVAL); }
+        const auto &c = t->cols[(size_t)gc];
+        if (c.type != PH_CODE8 || c.validity || !c.has_range || c.min < 0) return fail(unsupported("group columns must be NULL-free dictionary codes"));
+        int card = (int)std::max<int64_t>((int64_t)c.dict.size(), c.max + 1);
+        ns *= card;
+        if (ns > 4096) return fail(unsupported("too many group slots"));
+        S.group_col.push_back(slot_of(gc));
+        S.group_card.push_back(card);
+        p->group_cols[g] = gc;
+        p->gcard.push_back(card);
+    }
+    p->nkeys = ngroup_cols;
+    S.nslots = (int)ns;
+    // ---- aggregates -> deduplicated accumulators
+    struct AccReq { int op; Prod pr; };
+    std::vector<AccReq> accs;
+    long double row_bound = 0;
+    for (int32_t a = 0; a < naggs; a++) {
+        ph_scan_plan::AggMap m{aggs[a].kind, -1, 0};
+        if (aggs[a].kind != PH_A_COUNT_STAR) {
+            Prod pr;
+            if (aggs[a].nprog <= 0 || aggs[a].nprog > 12 || !normalize(t, aggs[a].prog, aggs[a].nprog, &pr)) return fail(unsupported("an aggregate argument is not a product of affine column factors"));
+            m.scale = pr.scale;
+            int op = aggs[a].kind == PH_A_MIN ? 1 : aggs[a].kind == PH_A_MAX ? 2 : 0;
+            if (aggs[a].kind != PH_A_COUNT) {
+                if (op != 0 && !(pr.f.size() == 1 && pr.f[0].A == 0 && pr.f[0].B == 1)) return fail(unsupported("MIN/MAX of an expression"));
+                if (pr.f.size() > 4) return fail(unsupported("more than 4 factors"));
+                int found = -1;
+                for (size_t i = 0; i < accs.size(); i++) if (accs[i].op == op && accs[i].pr == pr) found = (int)i;
+                if (found < 0) { accs.push_back({op, pr}); found = (int)accs.size() - 1; }
+                m.acc = found;
+            }
+        }
+        p->aggs.push_back(m);
+    }
+    if (accs.size() > 16) return fail(unsupported("more than 16 distinct accumulators"));
+    for (auto &aq : accs) {
+        ph::JitShape::Acc A;
+        A.op = aq.op;
+        long double b = 1;
+        for (auto &f : aq.pr.f) {
+            const auto &c = t->cols[(size_t)f.col];
+            if (!c.has_range) return fail(unsupported("a summed column has no range statistics"));
+            int sl = slot_of(f.col);
+            if (sl < 0) return fail(unsupported("aggregate column type"));
+            bool pure = f.A == 0 && f.B == 1;
+            A.factors.push_back({sl, pure});
+            if (!pure) { consts.push_back(f.A); consts.push_back(f.B); }
+            b *= affine_bound(f, c.min, c.max);
+        }
+        if (aq.op == 0) row_bound = std::max(row_bound, b);
+        S.accs.push_back(A);
+    }
+    if (tcol.empty()) return fail(unsupported("the plan reads no column"));   // count(*) without predicates
+    if ((int)tcol.size() > ph::JIT_MAX_COLS || (int)consts.size() > ph::JIT_MAX_CONSTS) return fail(unsupported("too many columns / constants"));
+    const int na = (int)S.accs.size();
+    if ((int64_t)S.nslots * (na * 8 + 8) * 256 > 158 * 1024) return fail(unsupported("group slots x accumulators exceed the CU's LDS"));
+    p->row_bound = row_bound;
+    p->jshape = S;
+    for (size_t i = 0; i < tcol.size(); i++) p->jparams.col[i] = t->cols[(size_t)tcol[i]].data;
+    for (size_t i = 0; i < consts.size(); i++) p->jparams.k[i] = consts[i];
+    p->nslots = S.nslots; p->stride = na + 2; p->cnt_idx = na; p->first_idx = na + 1;
+    for (auto &A : S.accs) p->ops.push_back(A.op);
+    p->ops.push_back(0);
+    p->ops.push_back(1);
+    p->nacc = p->nslots * p->stride;
+    p->max_grid = ctx->cu_count;
+    int rc = ph::jit_get(ctx, S, &p->jkernel);
+    if (rc != PH_OK) return fail(rc == PH_EHIP ? PH_EUNSUPPORTED : rc);   // no hiprtc / compile trouble: the generic chain still runs
+    rc = plan_alloc(p);
+    if (rc != PH_OK) return fail(rc);
+    *out = p;
+    return PH_OK;
+}
+
 // ---------------------------------------------------------------- generic plans
 // Any Agg <- Scan(filter) descriptor outside the fused shapes still runs on the device, as the
 // chain the operator-granular executors would run: ph_filter_select per conjunct (narrowing the
@@ -503,7 +656,14 @@ extern "C" int ph_scan_plan_create(ph_ctx *ctx, const ph_table *t, const ph_pred
                                    const ph_aggexpr *aggs, int32_t naggs, ph_scan_plan **out) {
     PH_REQUIRE(ctx && t && out && naggs > 0 && aggs && npreds >= 0 && ngroup_cols >= 0,
                "ph_scan_plan_create: bad arguments");
-    int rc = try_fused(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, out);
+    // PH_SCAN_JIT=1: prefer the plan-specialised kernel even for the two precompiled shapes (A/B);
+    // PH_SCAN_JIT=0: never generate code
+    const char *je = getenv("PH_SCAN_JIT");
+    const int jit_mode = je ? atoi(je) : -1;
+    int rc = PH_EUNSUPPORTED;
+    if (jit_mode == 1) rc = try_jit(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, out);
+    if (rc == PH_EUNSUPPORTED) rc = try_fused(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, out);
+    if (rc == PH_EUNSUPPORTED && jit_mode != 0 && jit_mode != 1) rc = try_jit(ctx, t, preds, npreds, group_cols, ngroup_cols, aggs, naggs, out);
     if (rc != PH_EUNSUPPORTED) return rc;
     PH_REQUIRE(ngroup_cols <= 4 && naggs <= 16, "ph_scan_plan_create: at most 4 group columns and 16 aggregates");
     ph_scan_plan *p = new ph_scan_plan();
@@ -673,6 +833,15 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
         P.partials = p->partials;
         PH_CHECK(ph::launch_filter_sumprod(p->ctx, P, grid));
         PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, 2, 0, p->out_lo, p->out_hi));
+    } else if (p->kind == PK_JIT) {
+        ph::JitParams P = p->jparams;
+        P.row_begin = row_begin;
+        P.row_end = row_begin + rows;
+        P.partials = p->partials;
+        PH_CHECK(ph::jit_launch(p->ctx, p->jkernel, P, grid));
+        unsigned long long opmask = 0;
+        for (int j = 0; j < p->stride; j++) opmask |= (unsigned long long)p->ops[(size_t)j] << (2 * j);
+        PH_CHECK(ph::launch_merge_partials_ops(p->ctx, p->partials, grid, p->nacc, p->stride, opmask, p->out_lo, p->out_hi));
     } else {
         ph::LowcardChainParams P = p->lc;
         P.row_begin = row_begin;
@@ -696,16 +865,11 @@ static int assemble(ph_scan_plan *p, const std::vector<unsigned long long> &lo, 
     int naggs = (int)p->aggs.size();
     struct G { int64_t first; int slot; };
     std::vector<G> groups;
-    int stride = 0;
-    if (p->kind == PK_FILTER_SUMPROD) {
-        if (lo[1] > 0) groups.push_back({0, 0});
-        stride = 2;
-    } else {
-        stride = ph::LC_NACC + 1;
-        for (int s = 0; s < p->lc.nslots; s++)
-            if (lo[(size_t)s * stride + 5] > 0) groups.push_back({(int64_t)lo[(size_t)s * stride + ph::LC_NACC], s});
-        std::sort(groups.begin(), groups.end(), [](const G &a, const G &b) { return a.first < b.first; });
-    }
+    const int stride = p->stride;
+    for (int s = 0; s < p->nslots; s++)
+        if (lo[(size_t)s * stride + p->cnt_idx] > 0)
+            groups.push_back({p->first_idx >= 0 ? (int64_t)lo[(size_t)s * stride + p->first_idx] : 0, s});
+    std::sort(groups.begin(), groups.end(), [](const G &a, const G &b) { return a.first < b.first; });
     ph_agg_result *r = (ph_agg_result *)calloc(1, sizeof *r);
     size_t ng = groups.size(), nk = (size_t)p->nkeys;
     r->ngroups = (int64_t)ng;
@@ -721,17 +885,17 @@ static int assemble(ph_scan_plan *p, const std::vector<unsigned long long> &lo, 
     for (size_t g = 0; g < ng; g++) {
         int s = groups[g].slot;
         r->first_row[g] = groups[g].first;
-        if (p->kind == PK_LOWCARD_CHAIN) {
-            r->keys[g * 2 + 0] = s / p->lc.nk1;
-            r->keys[g * 2 + 1] = s % p->lc.nk1;
+        int rem = s;   // slot = dense index over the group columns' dictionaries, last column fastest
+        for (int c = (int)nk - 1; c >= 0; c--) {
+            r->keys[g * nk + (size_t)c] = rem % p->gcard[(size_t)c];
+            rem /= p->gcard[(size_t)c];
         }
-        int cnt_idx = p->kind == PK_FILTER_SUMPROD ? 1 : 5;
-        uint64_t cnt = lo[(size_t)s * stride + cnt_idx];
+        uint64_t cnt = lo[(size_t)s * stride + p->cnt_idx];
         for (int a = 0; a < naggs; a++) {
             const auto &m = p->aggs[(size_t)a];
-            size_t idx = (size_t)s * stride + (size_t)m.acc;
             r->count[g * naggs + a] = cnt;  // no NULL inputs on this path
             if (m.kind == PH_A_COUNT_STAR || m.kind == PH_A_COUNT) continue;
+            size_t idx = (size_t)s * stride + (size_t)m.acc;
             r->sum_lo[g * naggs + a] = lo[idx];
             r->sum_hi[g * naggs + a] = hi[idx];
         }
@@ -767,23 +931,34 @@ extern "C" int ph_scan_plan_fetch_merged(ph_scan_plan *p, const uint64_t *words,
     size_t n = (size_t)p->nacc;
     std::vector<unsigned long long> lo(n, 0);
     std::vector<long long> hi(n, 0);
-    int stride = p->kind == PK_FILTER_SUMPROD ? 0 : ph::LC_NACC + 1;
     for (size_t j = 0; j < n; j++) {
-        bool is_min = stride > 0 && (int)(j % (size_t)stride) == stride - 1;
-        if (is_min) lo[j] = ~0ull;
-        for (int32_t r = 0; r < nranks; r++) {
-            const uint64_t *w = words + (size_t)r * 2 * n;
-            if (is_min) {
+        const int wi = (int)(j % (size_t)p->stride);
+        const int op = p->ops[(size_t)wi];
+        if (wi == p->first_idx) {
+            lo[j] = ~0ull;
+            for (int32_t r = 0; r < nranks; r++) {
+                const uint64_t *w = words + (size_t)r * 2 * n;
                 // first-seen row across ranks: rank r's rows come after rank r-1's
                 if (w[j] != 0xffffffffull && w[j] != (uint64_t)INT64_MAX) {
                     unsigned long long gfirst = ((unsigned long long)r << 40) + w[j];
                     if (gfirst < lo[j]) lo[j] = gfirst;
                 }
-            } else {
+            }
+        } else if (op == 0) {
+            for (int32_t r = 0; r < nranks; r++) {
+                const uint64_t *w = words + (size_t)r * 2 * n;
                 unsigned long long nl = lo[j] + w[j];
                 hi[j] += (long long)w[n + j] + (nl < lo[j] ? 1 : 0);
                 lo[j] = nl;
             }
+        } else {   // MIN / MAX words are plain int64 values (identity when a rank saw no row)
+            long long best = op == 1 ? INT64_MAX : INT64_MIN;
+            for (int32_t r = 0; r < nranks; r++) {
+                long long v = (long long)words[(size_t)r * 2 * n + j];
+                best = op == 1 ? std::min(best, v) : std::max(best, v);
+            }
+            lo[j] = (unsigned long long)best;
+            hi[j] = best < 0 ? -1 : 0;
         }
     }
     return assemble(p, lo, hi, out);

@@ -76,3 +76,19 @@ def test_generator_shards_equal_whole():
     for k in whole:
         assert np.array_equal(whole[k], np.concatenate([p[k] for p in parts])), k
     assert len(whole["l_orderkey"]) == 60175   # SF0.01 lineitem cardinality
+
+
+def test_plan_specialised_kernels_generate_and_compile_for_gfx950():
+    """The hiprtc path needs no device to compile: every canned plan shape must generate a source
+    that compiles for gfx950 (the generated source is what ph_scan_plan_create builds on the GPU)."""
+    lib = hip.lib()
+    buf = ctypes.create_string_buffer(1 << 16)
+    for which in range(4):
+        rc = lib.ph_scan_jit_selfcheck(which, buf, 1 << 16)
+        assert rc == hip.PH_OK, lib.ph_last_error().decode()
+        src = buf.value.decode()
+        assert 'extern "C" __global__' in src and "__builtin_nontemporal_load" in src
+    lib.ph_scan_jit_selfcheck(0, buf, 1 << 16)
+    q1 = buf.value.decode()
+    assert q1.count("__builtin_nontemporal_load") == 4 + 3 * 2   # 2 int32 + 2 byte columns, 3 int64 columns x 2
+    assert lib.ph_scan_jit_selfcheck(9, None, 0) == hip.PH_EINVAL
