@@ -27,6 +27,13 @@ struct JitShape {
     std::vector<int> group_col;            // loaded-column slots of the group keys (code bytes)
     std::vector<int> group_card;           // dictionary size of each
     int nslots = 1;                        // product of group_card (1 = ungrouped)
+    int lds_cols = 256;                    // accumulator columns per (slot, accumulator): 256 = one per thread
+    // largest power-of-two column count (256..16) whose accumulators fit the CU's LDS; 0 = none does
+    static int fit_lds_cols(int nslots, int naccs) {
+        for (int c = 256; c >= 16; c >>= 1)
+            if ((int64_t)nslots * (naccs * 8 + 8) * c <= 156 * 1024) return c;
+        return 0;
+    }
     // accumulators: op 0 = SUM of a product of affine factors, 1 = MIN, 2 = MAX of one column
     struct Acc { int op; std::vector<std::pair<int, bool>> factors; };  // (column slot, pure: A=0,B=1)
     std::vector<Acc> accs;

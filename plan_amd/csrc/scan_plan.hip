@@ -627,7 +627,8 @@ static int try_jit(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t
     if (tcol.empty()) return fail(unsupported("the plan reads no column"));   // count(*) without predicates
     if ((int)tcol.size() > ph::JIT_MAX_COLS || (int)consts.size() > ph::JIT_MAX_CONSTS) return fail(unsupported("too many columns / constants"));
     const int na = (int)S.accs.size();
-    if ((int64_t)S.nslots * (na * 8 + 8) * 256 > 158 * 1024) return fail(unsupported("group slots x accumulators exceed the CU's LDS"));
+    S.lds_cols = ph::JitShape::fit_lds_cols(S.nslots, na);
+    if (S.lds_cols == 0) return fail(unsupported("group slots x accumulators exceed the CU's LDS"));
     p->row_bound = row_bound;
     p->jshape = S;
     for (size_t i = 0; i < tcol.size(); i++) p->jparams.col[i] = t->cols[(size_t)tcol[i]].data;

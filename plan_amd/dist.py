@@ -56,7 +56,7 @@ class RcclGroup:
 
     # -- thin wrappers
     def allgather(self, send_ptr, recv_ptr, nbytes, async_=False):
-        hip.check(hip.lib().ph_comm_allgather(self.h, hip.vp(send_ptr), hip.vp(recv_ptr), hip.i64(nbytes),
+        hip.check(hip.lib().ph_comm_allgather(self.h, hip.vp(_addr(send_ptr)), hip.vp(_addr(recv_ptr)), hip.i64(nbytes),
                                               hip.i32(1 if async_ else 0)))
 
     def wait(self, keep=0):
