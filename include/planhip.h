@@ -183,6 +183,17 @@ typedef enum { PH_PART_YEAR = 1, PH_PART_MONTH = 2, PH_PART_DAY = 3 } ph_datepar
 int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, const int32_t *sel, int64_t n,
                     int32_t *out_dev);
 
+/* substring(s FROM offset FOR length) — substringFunc / substringStartEnd
+ * (pkg/compute/function_operator_binary.go:553-625; SubstringFunc function_scalar.go:1530-1563): byte
+ * positions, 1-based, a negative offset counts from the end, a negative length reads leftwards,
+ * offset 0 shortens the length by one; NULL rows give the empty string (and stay NULL through the
+ * column's validity). `length` = INT64_MAX is the two-argument form. Result: a PH_STR column over
+ * rows sel[0..n) (or 0..n): out_offsets_dev (n+1 int32) and out_bytes_dev; *out_bytes = bytes
+ * written (PH_ECAPACITY when out_bytes_capacity is too small; the source's aux_bytes always is
+ * enough for lengths >= 0 without repeated rows). */
+int ph_substring(ph_ctx *ctx, const ph_col *col, int64_t offset, int64_t length, const int32_t *sel, int64_t n,
+                 int32_t *out_offsets_dev, uint8_t *out_bytes_dev, int64_t out_bytes_capacity, int64_t *out_bytes);
+
 /* ------------------------------------------------------------------ hash aggregate
  * GroupedAggrHashTable.AddChunk/FindOrCreateGroups + UpdateStates + FinalizeStates
  * (pkg/compute/aggregate_hash.go:136-391, aggregate_exec.go:456-475,
@@ -274,6 +285,12 @@ int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *wher
 int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                        uint8_t *found_dev);
 void ph_join_free(ph_join *j);
+
+/* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:
+ * for every right row, all left rows in order — the order the reference emits (one output chunk
+ * per (left chunk, right row)) — so that both sides materialise with ph_gather like a join's
+ * output. n_left * n_right must stay below 2^31. */
+int ph_cross_pairs(ph_ctx *ctx, int64_t n_left, int64_t n_right, int32_t *out_left_dev, int32_t *out_right_dev);
 
 /* gather: out[i] = col[idx[i]] for fixed-width columns (join payload materialisation,
  * TupleDataTemplatedGather join_collection.go:501-529) */

@@ -988,3 +988,45 @@ void oracle_join_probe_mark(const ojoin *j, const ocol *keys, int32_t nkeys, con
         probe_chunk(j, keys, nkeys, sel, base, cnt, NULL, NULL, 0, &total, found);
     }
 }
+
+/* ---- substring: substringStartEnd / substringFunc, function_operator_binary.go:553-625 ---- */
+static int substring_start_end(int64_t slen, int64_t offset, int64_t length, int64_t *start, int64_t *end) {
+    if (length == 0) return 0;
+    if (offset > 0) {
+        *start = slen < offset - 1 ? slen : offset - 1;       /* from the start */
+    } else if (offset < 0) {
+        *start = slen + offset > 0 ? slen + offset : 0;       /* from the end */
+    } else {
+        *start = 0;
+        length--;
+        if (length <= 0) return 0;
+    }
+    if (length > 0) {
+        *end = slen < *start + length ? slen : *start + length;   /* left -> right */
+    } else {
+        *end = *start;                                            /* right -> left */
+        *start = *start + length > 0 ? *start + length : 0;
+    }
+    return *start != *end;
+}
+
+int64_t oracle_substring(const char *s, int64_t slen, int64_t offset, int64_t length, char *out) {
+    int64_t start = 0, end = 0;
+    if (!substring_start_end(slen, offset, length, &start, &end)) return 0;
+    memcpy(out, s + start, (size_t)(end - start));
+    return end - start;
+}
+
+/* ---- cross product: CrossProductExec.Execute, join_cross.go:109-230 ---- */
+void oracle_cross_pairs(int64_t n_left, int64_t n_right, int64_t chunk, int64_t *out_l, int64_t *out_r) {
+    int64_t k = 0;
+    for (int64_t base = 0; base < n_left; base += chunk) {           /* one LHS chunk at a time */
+        int64_t card = n_left - base < chunk ? n_left - base : chunk;
+        for (int64_t r = 0; r < n_right; r++)                         /* NextValue: the next RHS row */
+            for (int64_t i = 0; i < card; i++) {                      /* LHS columns referenced, RHS row constant */
+                out_l[k] = base + i;
+                out_r[k] = r;
+                k++;
+            }
+    }
+}

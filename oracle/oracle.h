@@ -311,6 +311,16 @@ int64_t oracle_q3_text(oracle_q3_row *rows, int64_t n, int32_t limit, char *buf,
 int64_t oracle_q9_text(oracle_q9_row *rows, int64_t n, const char *const *nation_names,
                        char *buf, int64_t cap);
 
+/* substring(s FROM offset FOR length): substringFunc + substringStartEnd
+ * (pkg/compute/function_operator_binary.go:553-625). Writes the result bytes to out (caller gives
+ * at least slen bytes) and returns their count. */
+int64_t oracle_substring(const char *s, int64_t slen, int64_t offset, int64_t length, char *out);
+
+/* CrossProductExec.Execute (pkg/compute/join_cross.go:109-230) as row-id pairs in the order the
+ * reference emits rows: for every left chunk of `chunk` rows, for every right row, the chunk's left
+ * rows. out_l / out_r: n_left * n_right entries. */
+void oracle_cross_pairs(int64_t n_left, int64_t n_right, int64_t chunk, int64_t *out_l, int64_t *out_r);
+
 /* LIKE with % and _ (wildcardMatch, function_operator_boolean.go) */
 int oracle_like(const char *s, int64_t slen, const char *pattern);
 

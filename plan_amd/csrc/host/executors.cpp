@@ -51,6 +51,7 @@ static int staged_width(const LType &t) {
     switch (t.GetInternalType()) {
     case PT_INT32: case PT_DATE: return 4;
     case PT_INT64: case PT_DECIMAL: return 8;
+    case PT_INT128: return 8;   // HUGEINT aggregate results (HAVING operands): exact when they fit int64
     case PT_VARCHAR: return 1;
     default: return 0;
     }
@@ -62,16 +63,20 @@ static int staged_phtype(const LType &t) {
     case PT_INT64: return PH_I64;
     case PT_DATE: return PH_DATE;
     case PT_DECIMAL: return PH_DEC64;
+    // INT128 has exactly one comparison in selectOperation, '>' (function_operator_boolean.go:435-436),
+    // which is also the one DECIMAL has: a scale-0 decimal column selects the same rows
+    case PT_INT128: return PH_DEC64;
     case PT_VARCHAR: return PH_CODE8;
     default: return 0;
     }
 }
 
-DeviceBatch::DeviceBatch(ph_ctx *ctx, std::vector<LType> types, std::vector<int> cols)
-    : ctx_(ctx), types_(std::move(types)), cols_(std::move(cols)) {
+DeviceBatch::DeviceBatch(ph_ctx *ctx, std::vector<LType> types, std::vector<int> cols, std::vector<bool> asString)
+    : ctx_(ctx), types_(std::move(types)), cols_(std::move(cols)), as_string_(std::move(asString)) {
     size_t n = cols_.size();
-    host_.resize(n); valid_.resize(n); has_null_.assign(n, false); dicts_.resize(n); dict_index_.resize(n);
-    dev_.resize(n); dev_data_.assign(n, nullptr); dev_valid_.assign(n, nullptr);
+    as_string_.resize(n, false);
+    host_.resize(n); valid_.resize(n); bytes_.resize(n); has_null_.assign(n, false); dicts_.resize(n); dict_index_.resize(n);
+    dev_.resize(n); dev_data_.assign(n, nullptr); dev_valid_.assign(n, nullptr); dev_aux_.assign(n, nullptr);
 }
 
 DeviceBatch::~DeviceBatch() { Reset(); }
@@ -80,8 +85,10 @@ void DeviceBatch::Reset() {
     for (size_t k = 0; k < cols_.size(); k++) {
         if (dev_data_[k]) ph_dev_free(ctx_, dev_data_[k]);
         if (dev_valid_[k]) ph_dev_free(ctx_, dev_valid_[k]);
-        dev_data_[k] = dev_valid_[k] = nullptr;
+        if (dev_aux_[k]) ph_dev_free(ctx_, dev_aux_[k]);
+        dev_data_[k] = dev_valid_[k] = dev_aux_[k] = nullptr;
         host_[k].clear();
+        bytes_[k].clear();
         valid_[k].clear();
         has_null_[k] = false;
     }
@@ -102,6 +109,24 @@ std::string DeviceBatch::Append(const Chunk &c) {
         if (w == 0) return "column type " + std::to_string(t.Id) + " cannot be staged to the device";
         Vector::Unified u;
         v.ToUnifiedFormat(card, &u);
+        if (as_string_[k] && t.GetInternalType() == PT_VARCHAR) {
+            // offsets + bytes (PH_STR): int32 offsets[rows+1], the first one written with the first row
+            if (host_[k].empty()) host_[k].assign(4, 0);
+            valid_[k].resize((size_t)(rows_ + card + 7) / 8 + 1, 0);
+            for (int i = 0; i < card; i++) {
+                int64_t idx = u.sel->GetIndex(i), row = rows_ + i;
+                bool ok = u.mask->RowIsValid((uint64_t)idx);
+                if (ok) {
+                    valid_[k][(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
+                    const String &sv = reinterpret_cast<const String *>(u.data)[idx];
+                    bytes_[k].insert(bytes_[k].end(), (const uint8_t *)sv.Data, (const uint8_t *)sv.Data + sv.Len);
+                } else has_null_[k] = true;
+                if (bytes_[k].size() > 0x7fffffffu) return "VARCHAR batch exceeds 2 GiB of bytes";
+                int32_t end = (int32_t)bytes_[k].size();
+                host_[k].insert(host_[k].end(), (const uint8_t *)&end, (const uint8_t *)&end + 4);
+            }
+            continue;
+        }
         size_t base = host_[k].size();
         host_[k].resize(base + (size_t)card * (size_t)w);
         valid_[k].resize((size_t)(rows_ + card + 7) / 8 + 1, 0);
@@ -115,6 +140,12 @@ std::string DeviceBatch::Append(const Chunk &c) {
             switch (t.GetInternalType()) {
             case PT_INT32: memcpy(dst, u.data + (size_t)idx * 4, 4); break;
             case PT_INT64: memcpy(dst, u.data + (size_t)idx * 8, 8); break;
+            case PT_INT128: {
+                const Hugeint &hg = reinterpret_cast<const Hugeint *>(u.data)[idx];
+                if (hg.Upper != ((int64_t)hg.Lower >> 63)) return "HUGEINT value does not fit int64 on the device";
+                memcpy(dst, &hg.Lower, 8);
+                break;
+            }
             case PT_DATE: { int32_t d = DaysFromDate(reinterpret_cast<const Date *>(u.data)[idx]); memcpy(dst, &d, 4); break; }
             case PT_DECIMAL: {
                 int64_t x;
@@ -154,8 +185,16 @@ std::string DeviceBatch::Upload() {
         if (ph_dev_upload(ctx_, dev_data_[k], host_[k].data(), (int64_t)host_[k].size()) != PH_OK) return herr("ph_dev_upload");
         ph_col c{};
         c.type = staged_phtype(t);
-        c.scale = t.Scale;
+        c.scale = t.GetInternalType() == PT_INT128 ? 0 : t.Scale;
         c.data = dev_data_[k];
+        if (as_string_[k] && t.GetInternalType() == PT_VARCHAR) {
+            c.type = PH_STR;
+            if (dev_aux_[k]) { ph_dev_free(ctx_, dev_aux_[k]); dev_aux_[k] = nullptr; }
+            if (ph_dev_alloc(ctx_, (int64_t)bytes_[k].size() + 64, &dev_aux_[k]) != PH_OK) return herr("ph_dev_alloc");
+            if (!bytes_[k].empty() && ph_dev_upload(ctx_, dev_aux_[k], bytes_[k].data(), (int64_t)bytes_[k].size()) != PH_OK) return herr("ph_dev_upload");
+            c.aux = dev_aux_[k];
+            c.aux_bytes = (int64_t)bytes_[k].size();
+        }
         if (has_null_[k]) {
             int64_t nb = (rows_ + 7) / 8;
             if (ph_dev_alloc(ctx_, nb + 64, &dev_valid_[k]) != PH_OK) return herr("ph_dev_alloc");
@@ -175,7 +214,11 @@ gpuFilterExecutor::gpuFilterExecutor(ph_ctx *ctx, std::vector<Compare> conjuncts
 std::string gpuFilterExecutor::Init() {
     for (auto &c : conj_)
         if (std::find(cols_.begin(), cols_.end(), c.col) == cols_.end()) cols_.push_back(c.col);
-    batch_.reset(new DeviceBatch(ctx_, child_->OutputTypes(), cols_));
+    // a VARCHAR column under LIKE / NOT LIKE is staged as offsets + bytes, otherwise as dictionary codes
+    std::vector<bool> asString(cols_.size(), false);
+    for (auto &c : conj_)
+        if (c.op == PH_LIKE || c.op == PH_NOTLIKE) asString[(size_t)(std::find(cols_.begin(), cols_.end(), c.col) - cols_.begin())] = true;
+    batch_.reset(new DeviceBatch(ctx_, child_->OutputTypes(), cols_, asString));
     return "";
 }
 
@@ -210,16 +253,21 @@ std::string gpuFilterExecutor::fill() {
         ph_col col = batch_->col(k);
         ph_const kc{};
         switch (cmp.k.kind) {
-        case Literal::Int: kc.type = PH_I32; kc.i = cmp.k.i; break;
+        case Literal::Int:   // against a HUGEINT / DECIMAL column the literal is cast to the column's type
+            if (col.type == PH_DEC64) { kc.type = PH_DEC64; kc.i = cmp.k.i; kc.scale = 0; }
+            else { kc.type = PH_I32; kc.i = cmp.k.i; }
+            break;
         case Literal::Float: kc.type = PH_F32; kc.f = cmp.k.f; break;
         case Literal::DateDays: kc.type = PH_DATE; kc.i = cmp.k.i; break;
         case Literal::Dec: kc.type = PH_DEC64; kc.i = cmp.k.i; kc.scale = cmp.k.scale; break;
-        case Literal::Str: {  // VARCHAR =/!= on a dictionary column: literal -> code
-            kc.type = PH_I32;
-            int code = batch_->code_of(k, cmp.k.s);
-            kc.i = code < 0 ? 999 : code;
+        case Literal::Str:
+            if (col.type == PH_STR) { kc.type = PH_STR; kc.s = cmp.k.s.c_str(); }   // LIKE pattern / '=' operand
+            else {  // VARCHAR =/!= on a dictionary column: literal -> code
+                kc.type = PH_I32;
+                int code = batch_->code_of(k, cmp.k.s);
+                kc.i = code < 0 ? 999 : code;
+            }
             break;
-        }
         }
         int32_t *out = (int32_t *)((ci & 1) ? selB : selA);
         int64_t m = 0;
@@ -323,6 +371,8 @@ std::string gpuAggExecutor::Init() {
     if (keyTypes.empty()) keyTypes.push_back(PH_I32);  // ungrouped: constant key (executor_aggr.go:37-48)
     if (ph_agg_create(ctx_, (int32_t)keyTypes.size(), keyTypes.data(), (int32_t)specs.size(), specs.data(), 1024, &agg_) != PH_OK)
         return herr("ph_agg_create");
+    for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
+    if (!outputs_.empty()) { std::string e = gpuProjectExecutor::Types(outputs_, outTypes_, &finalTypes_); if (!e.empty()) return e; }
     return "";
 }
 
@@ -458,8 +508,47 @@ std::string gpuAggExecutor::finalize() {
     for (size_t c = 0; c < groupCols_.size(); c++) { keyTypes.push_back(childTypes_[(size_t)groupCols_[c]]); dicts.push_back(&batch_->dict((int)c)); }
     std::vector<int> kinds;
     for (auto &a : aggs_) kinds.push_back(a.kind);
-    return BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, argScale_, ng, keys.data(), knull.data(), lo.data(),
-                          hi.data(), cnt.data(), &results_);
+    std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, argScale_, ng, keys.data(), knull.data(), lo.data(),
+                                   hi.data(), cnt.data(), &results_);
+    if (e.empty()) e = ApplyAggOutputPhase(ctx_, having_, outputs_, outTypes_, finalTypes_, &results_);
+    return e;
+}
+
+// The output phase of aggExecutor.Execute (executor_aggr.go:143-263) over the finalised
+// [group columns | aggregate results] chunks: HAVING = the conjuncts' selection per chunk
+// (filterExec.executeSelect + SliceIndice), then the output expressions (outputExec.executeExprs).
+std::string ApplyAggOutputPhase(ph_ctx *ctx, const std::vector<Compare> &having, const std::vector<ProjExpr> &outputs,
+                                const std::vector<LType> &rowTypes, const std::vector<LType> &finalTypes,
+                                std::vector<std::shared_ptr<Chunk>> *chunks) {
+    if (!having.empty()) {
+        size_t next = 0;
+        sourceExecutor src(rowTypes, [&](Chunk *out) {
+            if (next >= chunks->size()) return false;
+            *out = *(*chunks)[next++];
+            return true;
+        });
+        gpuFilterExecutor filt(ctx, having, &src);
+        std::string e = filt.Init();
+        if (!e.empty()) return e;
+        std::vector<std::shared_ptr<Chunk>> kept;
+        for (;;) {
+            auto c = std::make_shared<Chunk>();
+            std::string err;
+            OperatorResult r = filt.Execute(nullptr, c.get(), &err);
+            if (r == InvalidOpResult) return err.empty() ? "HAVING failed" : err;
+            if (r == Done) break;
+            if (c->Card() > 0) kept.push_back(c);
+        }
+        filt.Close();
+        *chunks = kept;
+    }
+    if (!outputs.empty()) {
+        std::vector<std::shared_ptr<Chunk>> out;
+        std::string e = gpuProjectExecutor::Evaluate(ctx, outputs, rowTypes, finalTypes, *chunks, &out);
+        if (!e.empty()) return e;
+        *chunks = out;
+    }
+    return "";
 }
 
 OperatorResult gpuAggExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
@@ -539,6 +628,8 @@ std::string gpuScanAggExecutor::Init() {
     if (ph_scan_plan_create(ctx_, table_, preds.data(), (int32_t)preds.size(), groups.data(), (int32_t)groups.size(), ax.data(),
                             (int32_t)ax.size(), &plan_) != PH_OK)
         return herr("ph_scan_plan_create");
+    for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
+    if (!outputs_.empty()) { std::string e = gpuProjectExecutor::Types(outputs_, outTypes_, &finalTypes_); if (!e.empty()) return e; }
     return "";
 }
 
@@ -563,6 +654,7 @@ OperatorResult gpuScanAggExecutor::Execute(Chunk *, Chunk *output, std::string *
         std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo,
                                        r->sum_hi, r->count, &results_);
         ph_agg_result_free(r);
+        if (e.empty()) e = ApplyAggOutputPhase(ctx_, having_, outputs_, outTypes_, finalTypes_, &results_);
         if (!e.empty()) { *err = e; return InvalidOpResult; }
         built_ = true;
     }
@@ -841,6 +933,255 @@ OperatorResult gpuOrderExecutor::Execute(Chunk *, Chunk *output, std::string *er
     output->SetCard(card);
     next_ += (size_t)card;
     return haveMoreOutput;
+}
+
+}  // namespace plan
+
+namespace plan {
+
+// ------------------------------------------------------------------ project
+
+std::string gpuProjectExecutor::Types(const std::vector<ProjExpr> &exprs, const std::vector<LType> &childTypes, std::vector<LType> *out) {
+    out->clear();
+    std::vector<ph_col> protos;
+    for (auto &t : childTypes) { ph_col p{}; p.type = staged_phtype(t); p.scale = t.GetInternalType() == PT_INT128 ? 0 : t.Scale; protos.push_back(p); }
+    for (auto &e : exprs) {
+        switch (e.kind) {
+        case ProjExpr::ColRef:
+            if (e.col < 0 || e.col >= (int)childTypes.size()) return "project: column out of range";
+            out->push_back(childTypes[(size_t)e.col]);
+            break;
+        case ProjExpr::Decimal: {
+            for (auto &o : e.prog)
+                if (o.op == PH_X_COL && (o.col < 0 || o.col >= (int)childTypes.size() || protos[(size_t)o.col].type == 0 || protos[(size_t)o.col].type == PH_CODE8))
+                    return "project: expression column cannot be evaluated on the device";
+            int32_t scale = 0;
+            if (ph_expr_scale(protos.data(), e.prog.data(), (int32_t)e.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
+            out->push_back(DecimalType(38, scale));   // BindDecimalMultiply / AddSubstract widen to the cap
+            break;
+        }
+        case ProjExpr::ExtractYear:
+            if (e.col < 0 || e.col >= (int)childTypes.size() || childTypes[(size_t)e.col].GetInternalType() != PT_DATE) return "extract(year ...) needs a DATE column";
+            out->push_back(IntegerType());            // ExtractFunc returns INTEGER (function_scalar.go:1509-1528)
+            break;
+        case ProjExpr::Substring:
+            if (e.col < 0 || e.col >= (int)childTypes.size() || childTypes[(size_t)e.col].GetInternalType() != PT_VARCHAR) return "substring needs a VARCHAR column";
+            out->push_back(VarcharType());
+            break;
+        }
+    }
+    return "";
+}
+
+// evaluates every non-reference expression over ALL rows of `in` in one device batch
+std::string gpuProjectExecutor::Evaluate(ph_ctx *ctx, const std::vector<ProjExpr> &exprs, const std::vector<LType> &childTypes,
+                                         const std::vector<LType> &outTypes, const std::vector<std::shared_ptr<Chunk>> &in,
+                                         std::vector<std::shared_ptr<Chunk>> *out) {
+    // columns the device needs
+    std::vector<int> cols;
+    std::vector<bool> asString;
+    auto stage = [&](int c, bool str) {
+        for (size_t i = 0; i < cols.size(); i++) if (cols[i] == c) { asString[i] = asString[i] || str; return (int)i; }
+        cols.push_back(c); asString.push_back(str);
+        return (int)cols.size() - 1;
+    };
+    std::vector<std::vector<ph_rpn>> progs(exprs.size());
+    std::vector<int> arg(exprs.size(), -1);
+    for (size_t i = 0; i < exprs.size(); i++) {
+        const ProjExpr &e = exprs[i];
+        if (e.kind == ProjExpr::Decimal) {
+            progs[i] = e.prog;
+            for (auto &o : progs[i]) if (o.op == PH_X_COL) o.col = stage(o.col, false);
+        } else if (e.kind == ProjExpr::ExtractYear) arg[i] = stage(e.col, false);
+        else if (e.kind == ProjExpr::Substring) arg[i] = stage(e.col, true);
+    }
+    int64_t total = 0;
+    for (auto &c : in) total += c->Card();
+    // device results, downloaded per expression
+    std::vector<std::vector<int64_t>> dec(exprs.size());
+    std::vector<std::vector<uint8_t>> decValid(exprs.size());
+    std::vector<std::vector<int32_t>> i32(exprs.size()), soff(exprs.size());
+    std::vector<std::vector<uint8_t>> sbytes(exprs.size());
+    std::vector<bool> nullable(exprs.size(), false);
+    if (!cols.empty() && total > 0) {
+        DeviceBatch batch(ctx, childTypes, cols, asString);
+        for (auto &c : in) { std::string e = batch.Append(*c); if (!e.empty()) return e; }
+        std::string e = batch.Upload();
+        if (!e.empty()) return e;
+        std::vector<ph_col> staged;
+        bool anyValidity = false;
+        for (size_t k = 0; k < cols.size(); k++) { staged.push_back(batch.col((int)k)); anyValidity |= staged.back().validity != nullptr; }
+        for (size_t i = 0; i < exprs.size(); i++) {
+            const ProjExpr &ex = exprs[i];
+            if (ex.kind == ProjExpr::Decimal) {
+                void *o = nullptr, *v = nullptr;
+                if (ph_dev_alloc(ctx, total * 8, &o) != PH_OK) return herr("ph_dev_alloc");
+                if (anyValidity && ph_dev_alloc(ctx, (total + 7) / 8 + 64, &v) != PH_OK) { ph_dev_free(ctx, o); return herr("ph_dev_alloc"); }
+                int rc = ph_expr_eval(ctx, staged.data(), (int32_t)staged.size(), progs[i].data(), (int32_t)progs[i].size(), nullptr, total,
+                                      (int64_t *)o, (uint8_t *)v);
+                dec[i].resize((size_t)total);
+                if (rc == PH_OK) rc = ph_dev_download(ctx, dec[i].data(), o, total * 8);
+                if (rc == PH_OK && v) { decValid[i].resize((size_t)(total + 7) / 8); rc = ph_dev_download(ctx, decValid[i].data(), v, (total + 7) / 8); nullable[i] = true; }
+                ph_dev_free(ctx, o);
+                if (v) ph_dev_free(ctx, v);
+                if (rc != PH_OK) return herr("ph_expr_eval");
+            } else if (ex.kind == ProjExpr::ExtractYear) {
+                const ph_col &c = staged[(size_t)arg[i]];
+                if (c.validity) return "extract over a NULL-able date stays on the CPU executor";
+                void *o = nullptr;
+                if (ph_dev_alloc(ctx, total * 4, &o) != PH_OK) return herr("ph_dev_alloc");
+                i32[i].resize((size_t)total);
+                int rc = ph_date_extract(ctx, PH_PART_YEAR, &c, nullptr, total, (int32_t *)o);
+                if (rc == PH_OK) rc = ph_dev_download(ctx, i32[i].data(), o, total * 4);
+                ph_dev_free(ctx, o);
+                if (rc != PH_OK) return herr("ph_date_extract");
+            } else if (ex.kind == ProjExpr::Substring) {
+                const ph_col &c = staged[(size_t)arg[i]];
+                void *o = nullptr, *b = nullptr;
+                int64_t cap = c.aux_bytes + 64, nb = 0;
+                if (ph_dev_alloc(ctx, (total + 1) * 4, &o) != PH_OK || ph_dev_alloc(ctx, cap, &b) != PH_OK) return herr("ph_dev_alloc");
+                int rc = ph_substring(ctx, &c, ex.offset, ex.length, nullptr, total, (int32_t *)o, (uint8_t *)b, cap, &nb);
+                soff[i].resize((size_t)total + 1);
+                sbytes[i].resize((size_t)nb);
+                if (rc == PH_OK) rc = ph_dev_download(ctx, soff[i].data(), o, (total + 1) * 4);
+                if (rc == PH_OK && nb > 0) rc = ph_dev_download(ctx, sbytes[i].data(), b, nb);
+                ph_dev_free(ctx, o); ph_dev_free(ctx, b);
+                if (rc != PH_OK) return herr("ph_substring");
+            }
+        }
+    }
+    int64_t base = 0;
+    for (auto &c : in) {
+        auto oc = std::make_shared<Chunk>();
+        oc->Init(outTypes, DefaultVectorSize);
+        int card = c->Card();
+        for (size_t i = 0; i < exprs.size(); i++) {
+            const ProjExpr &ex = exprs[i];
+            Vector &v = *oc->Data[i];
+            if (ex.kind == ProjExpr::ColRef) { oc->Data[i] = c->Data[(size_t)ex.col]; continue; }   // Reference: no copy
+            for (int r = 0; r < card; r++) {
+                size_t g = (size_t)(base + r);
+                if (ex.kind == ProjExpr::Decimal) {
+                    if (nullable[i] && !((decValid[i][g >> 3] >> (g & 7)) & 1)) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+                    v.Slice<Decimal>()[r] = DecimalFromUnscaled(dec[i][g], outTypes[i].Scale);
+                } else if (ex.kind == ProjExpr::ExtractYear) v.Slice<int32_t>()[r] = i32[i][g];
+                else {
+                    Vector::Unified u;
+                    c->Data[(size_t)ex.col]->ToUnifiedFormat(card, &u);
+                    if (!u.mask->RowIsValid((uint64_t)u.sel->GetIndex(r))) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+                    v.SetString(r, (const char *)sbytes[i].data() + soff[i][g], soff[i][g + 1] - soff[i][g]);
+                }
+            }
+        }
+        oc->SetCard(card);
+        out->push_back(oc);
+        base += card;
+    }
+    return "";
+}
+
+gpuProjectExecutor::gpuProjectExecutor(ph_ctx *ctx, std::vector<ProjExpr> exprs, OperatorExec *child, int batchChunks)
+    : ctx_(ctx), exprs_(std::move(exprs)), child_(child), batchChunks_(batchChunks) {}
+
+std::string gpuProjectExecutor::Init() { return Types(exprs_, child_->OutputTypes(), &outTypes_); }
+std::string gpuProjectExecutor::Close() { ready_.clear(); return ""; }
+
+OperatorResult gpuProjectExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    while (ready_.empty() && !childDone_) {
+        std::vector<std::shared_ptr<Chunk>> in, out;
+        while ((int)in.size() < batchChunks_) {
+            auto c = std::make_shared<Chunk>();
+            OperatorResult r = child_->Execute(nullptr, c.get(), err);
+            if (r == InvalidOpResult) return InvalidOpResult;
+            if (r == Done) { childDone_ = true; break; }
+            if (c->Card() > 0) in.push_back(c);
+        }
+        std::string e = Evaluate(ctx_, exprs_, child_->OutputTypes(), outTypes_, in, &out);
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        for (auto &c : out) ready_.push_back(c);
+    }
+    if (ready_.empty()) return Done;
+    *output = *ready_.front();
+    ready_.pop_front();
+    return haveMoreOutput;
+}
+
+// ------------------------------------------------------------------ limit
+
+OperatorResult limitExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    // Limit.Sink caps what is collected at offset+limit rows, GetData / HandleOffset skips the
+    // offset: rows [offset, offset+limit) of the child, in the child's order
+    const uint64_t maxElement = limit_ == UINT64_MAX ? UINT64_MAX : limit_ + offset_;
+    for (;;) {
+        if (limit_ == 0 || seen_ >= maxElement) return Done;
+        Chunk c;
+        OperatorResult r = child_->Execute(nullptr, &c, err);
+        if (r == InvalidOpResult) return InvalidOpResult;
+        if (r == Done) return Done;
+        uint64_t card = (uint64_t)c.Card(), start = seen_;
+        seen_ += card;
+        if (card == 0 || seen_ <= offset_) continue;
+        uint64_t from = start < offset_ ? offset_ - start : 0;
+        uint64_t to = std::min<uint64_t>(card, maxElement - start);
+        if (from == 0 && to == card) { *output = c; return haveMoreOutput; }
+        auto sv = std::make_shared<SelectVector>();
+        sv->identity = false;
+        for (uint64_t i = from; i < to; i++) sv->SelVec.push_back((int64_t)i);
+        auto keep = std::make_shared<Chunk>(c);
+        output->Init(OutputTypes(), DefaultVectorSize);
+        std::vector<int> indice;
+        for (int i = 0; i < keep->ColumnCount(); i++) indice.push_back(i);
+        output->SliceIndice(*keep, sv, (int)(to - from), 0, indice);
+        return haveMoreOutput;
+    }
+}
+
+// ------------------------------------------------------------------ cross product
+
+std::string crossProductExecutor::Init() {
+    outTypes_ = left_->OutputTypes();
+    for (auto &t : right_->OutputTypes()) outTypes_.push_back(t);
+    return "";
+}
+
+OperatorResult crossProductExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!collected_) {   // CrossProduct.Sink: the whole right side
+        for (;;) {
+            auto c = std::make_shared<Chunk>();
+            OperatorResult r = right_->Execute(nullptr, c.get(), err);
+            if (r == InvalidOpResult) return InvalidOpResult;
+            if (r == Done) break;
+            if (c->Card() > 0) rhs_.push_back(c);
+        }
+        collected_ = true;
+    }
+    if (rhs_.empty()) return Done;   // no RHS, empty result (join_cross.go:111-114)
+    for (;;) {
+        if (!cur_) {
+            if (leftDone_) return Done;
+            auto c = std::make_shared<Chunk>();
+            OperatorResult r = left_->Execute(nullptr, c.get(), err);
+            if (r == InvalidOpResult) return InvalidOpResult;
+            if (r == Done) { leftDone_ = true; return Done; }
+            if (c->Card() == 0) continue;
+            cur_ = c;
+            rchunk_ = 0;
+            rrow_ = 0;
+        }
+        if (rchunk_ >= rhs_.size()) { cur_.reset(); continue; }   // RHS read over: next LHS chunk
+        const Chunk &rc = *rhs_[rchunk_];
+        int nl = cur_->ColumnCount();
+        output->Init(outTypes_, DefaultVectorSize);
+        for (int c = 0; c < nl; c++) output->Data[(size_t)c] = cur_->Data[(size_t)c];              // Reference
+        for (int c = 0; c < rc.ColumnCount(); c++) {                                                   // ReferenceInPhyFormatConst
+            Vector &v = *output->Data[(size_t)(nl + c)];
+            v._PhyFormat = PF_CONST;
+            CopyCell(*rc.Data[(size_t)c], rrow_, &v, 0);
+        }
+        output->SetCard(cur_->Card());
+        if (++rrow_ >= rc.Card()) { rrow_ = 0; rchunk_++; }
+        return haveMoreOutput;
+    }
 }
 
 }  // namespace plan

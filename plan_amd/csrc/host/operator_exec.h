@@ -10,6 +10,9 @@
 //   gpuAggExecutor     <- aggExecutor       executor_aggr.go:37-265
 //   gpuJoinExecutor    <- joinExecutor      executor_join.go:27-264
 //   gpuOrderExecutor   <- orderExecutor     executor_order.go:56-138 (LocalSort sort_local.go:64-250)
+//   gpuProjectExecutor <- projectExecutor   executor_project.go:24-85 (ExprExec over the child chunk)
+//   limitExecutor      <- limitExecutor     executor_limit.go:27-238 (Limit.Sink / GetData / HandleOffset)
+//   crossProductExecutor <- CrossProduct    join_cross.go:34-230
 //
 // The Go shim of INTEGRATION.md has exactly this shape; this C++ form exists because the build
 // environment has no Go toolchain, and it is what the host-level tests drive.
@@ -57,6 +60,20 @@ struct AggExpr {
     std::vector<ph_rpn> prog;  // argument over child columns (empty for count(*))
 };
 
+// one output expression of a Project / of the aggregate's output phase: a column reference (zero
+// copy, like executeColumnRef), a decimal expression (RPN over child columns, evaluated on the
+// device: executeFunc over the binary decimal operators), extract(year ...) or substring
+struct ProjExpr {
+    enum Kind { ColRef, Decimal, ExtractYear, Substring } kind = ColRef;
+    int col = -1;                 // ColRef / ExtractYear / Substring: child column
+    std::vector<ph_rpn> prog;     // Decimal: RPN over child columns
+    int64_t offset = 1, length = 0;   // Substring(col FROM offset FOR length)
+    static ProjExpr Col(int c) { ProjExpr e; e.kind = ColRef; e.col = c; return e; }
+    static ProjExpr Dec(std::vector<ph_rpn> p) { ProjExpr e; e.kind = Decimal; e.prog = std::move(p); return e; }
+    static ProjExpr Year(int c) { ProjExpr e; e.kind = ExtractYear; e.col = c; return e; }
+    static ProjExpr Substr(int c, int64_t off, int64_t len) { ProjExpr e; e.kind = Substring; e.col = c; e.offset = off; e.length = len; return e; }
+};
+
 // replays serialized chunks (the reference's fixture mechanism)
 class stubExecutor : public OperatorExec {
 public:
@@ -88,7 +105,9 @@ private:
 // Stages columns of many 2048-row chunks into one device batch in the narrow encodings.
 class DeviceBatch {
 public:
-    DeviceBatch(ph_ctx *ctx, std::vector<LType> types, std::vector<int> cols);
+    // asString[k]: stage VARCHAR column k as offsets + bytes (PH_STR: LIKE / substring operands)
+    // instead of a <= 256-entry dictionary code (group keys, '=' on low-cardinality columns)
+    DeviceBatch(ph_ctx *ctx, std::vector<LType> types, std::vector<int> cols, std::vector<bool> asString = {});
     ~DeviceBatch();
     std::string Append(const Chunk &c);      // copies rows of the selected columns (host staging)
     std::string Upload();                    // -> device columns
@@ -101,12 +120,12 @@ private:
     ph_ctx *ctx_;
     std::vector<LType> types_;
     std::vector<int> cols_;
-    std::vector<std::vector<uint8_t>> host_, valid_;
-    std::vector<bool> has_null_;
+    std::vector<std::vector<uint8_t>> host_, valid_, bytes_;
+    std::vector<bool> has_null_, as_string_;
     std::vector<std::vector<std::string>> dicts_;
     std::vector<std::map<std::string, int>> dict_index_;
     std::vector<ph_col> dev_;
-    std::vector<void *> dev_data_, dev_valid_;
+    std::vector<void *> dev_data_, dev_valid_, dev_aux_;
     int64_t rows_ = 0;
 };
 
@@ -136,10 +155,18 @@ public:
     std::string Init() override;
     OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
     std::string Close() override;
-    std::vector<LType> OutputTypes() const override { return outTypes_; }
+    std::vector<LType> OutputTypes() const override { return finalTypes_.empty() ? outTypes_ : finalTypes_; }
+    // the output phase of aggExecutor.Execute (executor_aggr.go:143-263): HAVING conjuncts over the
+    // [group columns | aggregate results] rows (filterExec.executeSelect), then the output
+    // expressions over the surviving rows (outputExec.executeExprs). Both optional; call before Init.
+    void SetHaving(std::vector<Compare> conjuncts) { having_ = std::move(conjuncts); }
+    void SetOutputs(std::vector<ProjExpr> outputs) { outputs_ = std::move(outputs); }
 private:
     std::string sinkBatch();
     std::string finalize();
+    std::vector<Compare> having_;
+    std::vector<ProjExpr> outputs_;
+    std::vector<LType> finalTypes_;
     ph_ctx *ctx_;
     std::vector<int> groupCols_;
     std::vector<AggExpr> aggs_;
@@ -221,6 +248,63 @@ private:
     bool sorted_ = false;
 };
 
+// Project: evaluates its expressions for every child chunk. Column references are zero-copy; decimal
+// expressions, extract and substring run on the device over batches of child chunks.
+class gpuProjectExecutor : public OperatorExec {
+public:
+    gpuProjectExecutor(ph_ctx *ctx, std::vector<ProjExpr> exprs, OperatorExec *child, int batchChunks = 512);
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override;
+    std::vector<LType> OutputTypes() const override { return outTypes_; }
+    // evaluates the expressions over already materialised chunks (used by the aggregate's output phase)
+    static std::string Evaluate(ph_ctx *ctx, const std::vector<ProjExpr> &exprs, const std::vector<LType> &childTypes,
+                                const std::vector<LType> &outTypes, const std::vector<std::shared_ptr<Chunk>> &in,
+                                std::vector<std::shared_ptr<Chunk>> *out);
+    static std::string Types(const std::vector<ProjExpr> &exprs, const std::vector<LType> &childTypes, std::vector<LType> *out);
+private:
+    ph_ctx *ctx_;
+    std::vector<ProjExpr> exprs_;
+    OperatorExec *child_;
+    int batchChunks_;
+    std::vector<LType> outTypes_;
+    std::deque<std::shared_ptr<Chunk>> ready_;
+    bool childDone_ = false;
+};
+
+// LIMIT / OFFSET (Limit.Sink + GetData + HandleOffset): passes child rows [offset, offset+limit)
+class limitExecutor : public OperatorExec {
+public:
+    limitExecutor(uint64_t limit, uint64_t offset, OperatorExec *child) : limit_(limit), offset_(offset), child_(child) {}
+    std::string Init() override { seen_ = 0; return ""; }
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override { return ""; }
+    std::vector<LType> OutputTypes() const override { return child_->OutputTypes(); }
+private:
+    uint64_t limit_, offset_, seen_ = 0;
+    OperatorExec *child_;
+};
+
+// Cross product (join_cross.go:34-230): the right child is collected first (Sink); then for every
+// left chunk and every right ROW one output chunk: the left columns referenced as they are, the
+// right row's values as constant vectors (ReferenceInPhyFormatConst) — no row is copied.
+class crossProductExecutor : public OperatorExec {
+public:
+    crossProductExecutor(OperatorExec *left, OperatorExec *right) : left_(left), right_(right) {}
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override { rhs_.clear(); cur_.reset(); return ""; }
+    std::vector<LType> OutputTypes() const override { return outTypes_; }
+private:
+    OperatorExec *left_, *right_;
+    std::vector<LType> outTypes_;
+    std::vector<std::shared_ptr<Chunk>> rhs_;
+    std::shared_ptr<Chunk> cur_;       // current left chunk
+    size_t rchunk_ = 0;
+    int rrow_ = 0;
+    bool collected_ = false, leftDone_ = false;
+};
+
 // Agg <- Scan(filter) over a RESIDENT table — the measured mode behind the operator interface
 // (INTEGRATION.md's gpuScanAggExecutor): nothing is staged per chunk; Init builds the
 // ph_scan_plan (fused kernel when the shape matches, operator chain otherwise), the first
@@ -237,9 +321,14 @@ public:
     std::string Init() override;
     OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
     std::string Close() override;
-    std::vector<LType> OutputTypes() const override { return outTypes_; }
+    std::vector<LType> OutputTypes() const override { return finalTypes_.empty() ? outTypes_ : finalTypes_; }
     const char *kind() const { return plan_ ? ph_scan_plan_kind(plan_) : ""; }
+    void SetHaving(std::vector<Compare> conjuncts) { having_ = std::move(conjuncts); }
+    void SetOutputs(std::vector<ProjExpr> outputs) { outputs_ = std::move(outputs); }
 private:
+    std::vector<Compare> having_;
+    std::vector<ProjExpr> outputs_;
+    std::vector<LType> finalTypes_;
     ph_ctx *ctx_;
     const ph_table *table_;
     std::vector<ResidentColumn> cols_;
@@ -260,6 +349,11 @@ std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector
                            const std::vector<int> &argScales, int64_t ngroups, const int64_t *keys,
                            const uint8_t *keyNull, const uint64_t *lo, const int64_t *hi, const uint64_t *cnt,
                            std::vector<std::shared_ptr<Chunk>> *out);
+
+// HAVING + output expressions over finalised aggregate rows (executor_aggr.go:143-263)
+std::string ApplyAggOutputPhase(ph_ctx *ctx, const std::vector<Compare> &having, const std::vector<ProjExpr> &outputs,
+                                const std::vector<LType> &rowTypes, const std::vector<LType> &finalTypes,
+                                std::vector<std::shared_ptr<Chunk>> *chunks);
 
 // copies one cell (any supported type) between flat vectors; src may be any format
 void CopyCell(const Vector &src, int srcRow, Vector *dst, int dstRow);

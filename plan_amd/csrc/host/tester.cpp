@@ -3,12 +3,16 @@
 // reference's text format (headline "#\t..." of execQuery, executor_bench.go:229-238; rows via
 // Chunk.SaveToFile). The role `tester tpch1g --query_id N` plays for the reference.
 //   host_tester roundtrip | formats
-//   host_tester semi|anti|left|order <sf_num> <sf_den>
-//   host_tester q1|q6|q3 <sf_num> <sf_den> [stub|resident]
+//   host_tester semi|anti|left|order|having|cross <sf_num> <sf_den>
+//   host_tester substr <sf_num> <sf_den> <offset> <length>
+//   host_tester q1|q6|q3|q9 <sf_num> <sf_den> [stub|resident]
+// q1 / q3 / q9 run the whole plan tail on the library: gpuOrderExecutor (ORDER BY) and limitExecutor
+// (LIMIT), so their output is the reference's result file byte for byte with no sorting here.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 
 #include "operator_exec.h"
@@ -74,6 +78,47 @@ static std::unique_ptr<OperatorExec> lineitem_source(const Lineitem &L, bool stu
     }
     auto pos = std::make_shared<int64_t>(0);
     return std::unique_ptr<OperatorExec>(new sourceExecutor(lineitem_types(), [&L, pos](Chunk *out) { return fill_lineitem(L, pos.get(), out); }));
+}
+
+// a table as the scan would hand it over: typed column arrays -> 2048-row chunks of the reference's
+// in-memory types (Decimal / Date / String structs)
+struct SrcCol {
+    LType type;
+    const void *data = nullptr;                 // int32 / int64 / unscaled int64 / days / uint8 codes
+    const char *const *dict = nullptr;          // VARCHAR from dictionary codes
+    std::function<std::string(int64_t)> str;    // VARCHAR from a generator
+};
+
+static std::unique_ptr<OperatorExec> table_source(std::vector<SrcCol> cols, int64_t n) {
+    std::vector<LType> types;
+    for (auto &c : cols) types.push_back(c.type);
+    auto pos = std::make_shared<int64_t>(0);
+    return std::unique_ptr<OperatorExec>(new sourceExecutor(types, [cols, types, n, pos](Chunk *out) {
+        if (*pos >= n) return false;
+        int card = (int)std::min<int64_t>(DefaultVectorSize, n - *pos);
+        out->Init(types, DefaultVectorSize);
+        for (size_t c = 0; c < cols.size(); c++) {
+            Vector &v = *out->Data[c];
+            for (int i = 0; i < card; i++) {
+                size_t r = (size_t)(*pos + i);
+                switch (types[c].GetInternalType()) {
+                case PT_INT32: v.Slice<int32_t>()[i] = ((const int32_t *)cols[c].data)[r]; break;
+                case PT_INT64: v.Slice<int64_t>()[i] = ((const int64_t *)cols[c].data)[r]; break;
+                case PT_DECIMAL: v.Slice<Decimal>()[i] = DecimalFromUnscaled(((const int64_t *)cols[c].data)[r], types[c].Scale); break;
+                case PT_DATE: v.Slice<Date>()[i] = DateFromDays(((const int32_t *)cols[c].data)[r]); break;
+                case PT_VARCHAR: {
+                    std::string sv = cols[c].str ? cols[c].str((int64_t)r) : std::string(cols[c].dict[((const uint8_t *)cols[c].data)[r]]);
+                    v.SetString(i, sv.data(), (int64_t)sv.size());
+                    break;
+                }
+                default: break;
+                }
+            }
+        }
+        out->SetCard(card);
+        *pos += card;
+        return true;
+    }));
 }
 
 static ph_rpn X_COL(int c) { return ph_rpn{PH_X_COL, c, 0, 0}; }
@@ -191,7 +236,7 @@ int main(int argc, char **argv) {
     ph_ctx *ctx = nullptr;
     if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
     Lineitem L;
-    if (q != "semi" && q != "anti" && q != "left" && q != "order") L = gen_lineitem(num, den);
+    if (q == "q1" || q == "q6" || q == "q3") L = gen_lineitem(num, den);
     auto scan = lineitem_source(L, stub);
     auto lit_date = [](int32_t d) { Literal k; k.kind = Literal::DateDays; k.i = d; return k; };
 
@@ -222,9 +267,10 @@ int main(int argc, char **argv) {
             std::vector<AggExpr> aggs = {{PH_A_SUM, {X_COL(0)}}, {PH_A_SUM, {X_COL(1)}}, {PH_A_SUM, dp}, {PH_A_SUM, ch},
                                          {PH_A_AVG, {X_COL(0)}}, {PH_A_AVG, {X_COL(1)}}, {PH_A_AVG, {X_COL(2)}}, {PH_A_COUNT_STAR, {}}};
             gpuScanAggExecutor agg(ctx, tab, rc, {c}, {4, 5}, aggs);
-            auto lines = run(&agg);
-            std::sort(lines.begin(), lines.end());
-            print(10, lines);
+            if (!agg.Init().empty()) die("agg init");
+            gpuOrderExecutor ord(ctx, {{0, false}, {1, false}}, &agg);   // ORDER BY l_returnflag, l_linestatus
+            print(10, run(&ord));
+            agg.Close();
         } else {
             Literal lo, hi, qty;
             lo.kind = hi.kind = Literal::Float;
@@ -248,10 +294,10 @@ int main(int argc, char **argv) {
         std::vector<AggExpr> aggs = {{PH_A_SUM, {X_COL(0)}}, {PH_A_SUM, {X_COL(1)}}, {PH_A_SUM, dp}, {PH_A_SUM, ch},
                                      {PH_A_AVG, {X_COL(0)}}, {PH_A_AVG, {X_COL(1)}}, {PH_A_AVG, {X_COL(2)}}, {PH_A_COUNT_STAR, {}}};
         gpuAggExecutor agg(ctx, {4, 5}, aggs, &filt);
-        if (!filt.Init().empty()) die("filter init");
-        auto lines = run(&agg);
-        std::sort(lines.begin(), lines.end());  // ORDER BY l_returnflag, l_linestatus (the row prefix)
-        print(10, lines);
+        if (!filt.Init().empty() || !agg.Init().empty()) die("init");
+        gpuOrderExecutor ord(ctx, {{0, false}, {1, false}}, &agg);   // ORDER BY l_returnflag, l_linestatus
+        print(10, run(&ord));
+        agg.Close();
         filt.Close();
     } else if (q == "q6") {
         Literal lo, hi, qty;
@@ -319,10 +365,20 @@ int main(int argc, char **argv) {
         gpuJoinExecutor j2(ctx, &lf, &j1, {7}, {0}, {2, 3});
         // group by l_orderkey (7), o_orderdate (8), o_shippriority (9); sum(ext*(1-disc))
         gpuAggExecutor agg(ctx, {7, 8, 9}, {{PH_A_SUM, {X_COL(1), X_CONST(1, 0), X_COL(2), X_OP(PH_X_SUB), X_OP(PH_X_MUL)}}}, &j2);
-        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2})
+        // the aggregate's output expressions put the row in select-list order: l_orderkey, revenue,
+        // o_orderdate, o_shippriority (executor_aggr.go:229-247); then ORDER BY revenue DESC,
+        // o_orderdate LIMIT 10 (orderExecutor + limitExecutor), all through the library
+        agg.SetOutputs({ProjExpr::Col(0), ProjExpr::Col(3), ProjExpr::Col(1), ProjExpr::Col(2)});
+        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2, &agg})
             if (!e->Init().empty()) die("init");
-        print(4, run(&agg));   // all groups, unordered; ORDER BY/LIMIT are outside the hot path
-        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2}) e->Close();
+        bool all = argc > 4 && !strcmp(argv[4], "groups");
+        if (all) print(4, run(&agg));   // every group, unordered (what the aggregate itself emits)
+        else {
+            gpuOrderExecutor ord(ctx, {{1, true}, {2, false}}, &agg);
+            limitExecutor lim(10, 0, &ord);
+            print(4, run(&lim));
+        }
+        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2, &agg}) e->Close();
     } else if (q == "semi" || q == "anti") {
         // customer SEMI/ANTI JOIN orders ON c_custkey = o_custkey: customers with / without orders
         int64_t nc = tpchgen_customer_count(num, den), no = tpchgen_orders_count(num, den);
@@ -405,6 +461,98 @@ int main(int argc, char **argv) {
         });
         gpuOrderExecutor ord(ctx, {{0, true}, {1, false}, {2, true}}, &src);
         print(3, run(&ord));
+    } else if (q == "q9") {
+        // cases/tpch/query/q9.sql through the operator interface: LIKE filter on part, the join chain
+        // lineitem |x| part |x| partsupp (composite key) |x| supplier |x| orders |x| nation, a Project with
+        // extract(year ...) and the profit expression, the aggregate, ORDER BY nation, o_year DESC
+        int64_t no = tpchgen_orders_count(num, den), npart = tpchgen_part_count(num, den), ns = tpchgen_supplier_count(num, den);
+        int64_t nl = tpchgen_lineitem_count(num, den, 0, no);
+        std::vector<int64_t> lokey((size_t)nl), lext((size_t)nl), ldisc((size_t)nl), okey((size_t)no), pscost((size_t)npart * 4);
+        std::vector<int32_t> lpart((size_t)nl), lsupp((size_t)nl), lqty((size_t)nl), odate((size_t)no), pkey((size_t)npart),
+            pspart((size_t)npart * 4), pssupp((size_t)npart * 4), skey((size_t)ns), snat((size_t)ns), nkey(25);
+        std::vector<uint8_t> pcolors((size_t)npart * 5), ncode(25);
+        tpchgen_lineitem_cols lc{}; lc.l_orderkey = lokey.data(); lc.l_partkey = lpart.data(); lc.l_suppkey = lsupp.data();
+        lc.l_quantity = lqty.data(); lc.l_extendedprice = lext.data(); lc.l_discount = ldisc.data();
+        tpchgen_lineitem(num, den, 0, no, &lc);
+        tpchgen_orders_cols oc{}; oc.o_orderkey = okey.data(); oc.o_orderdate = odate.data();
+        tpchgen_orders(num, den, 0, no, &oc);
+        tpchgen_part_cols pc{}; pc.p_partkey = pkey.data(); pc.p_name_colors = pcolors.data();
+        tpchgen_part(num, den, 0, npart, &pc);
+        tpchgen_partsupp_cols psc{}; psc.ps_partkey = pspart.data(); psc.ps_suppkey = pssupp.data(); psc.ps_supplycost = pscost.data();
+        tpchgen_partsupp(num, den, 0, npart, &psc);
+        tpchgen_supplier_cols sc{}; sc.s_suppkey = skey.data(); sc.s_nationkey = snat.data();
+        tpchgen_supplier(num, den, 0, ns, &sc);
+        for (int i = 0; i < 25; i++) { nkey[(size_t)i] = i; ncode[(size_t)i] = (uint8_t)i; }
+        auto pname = [&pcolors](int64_t r) {
+            std::string s;
+            for (int k = 0; k < 5; k++) { if (k) s += ' '; s += TPCHGEN_COLORS[pcolors[(size_t)r * 5 + (size_t)k]]; }
+            return s;
+        };
+        LType dec = DecimalType(15, 2);
+        auto lsrc = table_source({{BigintType(), lokey.data()}, {IntegerType(), lpart.data()}, {IntegerType(), lsupp.data()},
+                                  {IntegerType(), lqty.data()}, {dec, lext.data()}, {dec, ldisc.data()}}, nl);
+        auto psrc = table_source({{IntegerType(), pkey.data()}, {VarcharType(), nullptr, nullptr, pname}}, npart);
+        auto pssrc = table_source({{IntegerType(), pspart.data()}, {IntegerType(), pssupp.data()}, {dec, pscost.data()}}, npart * 4);
+        auto ssrc = table_source({{IntegerType(), skey.data()}, {IntegerType(), snat.data()}}, ns);
+        auto osrc = table_source({{BigintType(), okey.data()}, {DateType(), odate.data()}}, no);
+        auto nsrc = table_source({{IntegerType(), nkey.data()}, {VarcharType(), ncode.data(), TPCHGEN_NATION_NAMES}}, 25);
+        Literal pat; pat.kind = Literal::Str; pat.s = "%pink%";
+        gpuFilterExecutor pf(ctx, {{1, PH_LIKE, pat}}, psrc.get());
+        // lineitem: 0 l_orderkey 1 l_partkey 2 l_suppkey 3 l_quantity 4 l_extendedprice 5 l_discount
+        gpuJoinExecutor j1(ctx, lsrc.get(), &pf, {1}, {0}, {});                 // p_partkey = l_partkey
+        gpuJoinExecutor j2(ctx, &j1, pssrc.get(), {1, 2}, {0, 1}, {2});         // + 6 ps_supplycost
+        gpuJoinExecutor j3(ctx, &j2, ssrc.get(), {2}, {0}, {1});                // + 7 s_nationkey
+        gpuJoinExecutor j4(ctx, &j3, osrc.get(), {0}, {0}, {1});                // + 8 o_orderdate
+        gpuJoinExecutor j5(ctx, &j4, nsrc.get(), {7}, {0}, {1});                // + 9 n_name
+        // nation, o_year, amount = l_extendedprice * (1 - l_discount) - ps_supplycost * l_quantity
+        gpuProjectExecutor proj(ctx, {ProjExpr::Col(9), ProjExpr::Year(8),
+                                      ProjExpr::Dec({X_COL(4), X_CONST(1, 0), X_COL(5), X_OP(PH_X_SUB), X_OP(PH_X_MUL),
+                                                     X_COL(6), X_COL(3), X_OP(PH_X_MUL), X_OP(PH_X_SUB)})}, &j5);
+        gpuAggExecutor agg(ctx, {0, 1}, {{PH_A_SUM, {X_COL(2)}}}, &proj);
+        std::vector<OperatorExec *> ops = {&pf, &j1, &j2, &j3, &j4, &j5, &proj, &agg};
+        for (OperatorExec *e : ops) { std::string er = e->Init(); if (!er.empty()) die("init: " + er); }
+        gpuOrderExecutor ord(ctx, {{0, false}, {1, true}}, &agg);               // ORDER BY nation, o_year DESC
+        print(3, run(&ord));
+        for (OperatorExec *e : ops) e->Close();
+    } else if (q == "having") {
+        // SELECT l_suppkey, sum(l_extendedprice) * 2, count(*) FROM lineitem GROUP BY l_suppkey
+        // HAVING sum(l_extendedprice) > 20000000.00 AND count(*) > 600  — DECIMAL '>' and HUGEINT '>' are
+        // the comparisons HAVING can use (function_operator_boolean.go:431-442); the output list is
+        // evaluated over the surviving group rows
+        int64_t no = tpchgen_orders_count(num, den);
+        int64_t nl = tpchgen_lineitem_count(num, den, 0, no);
+        std::vector<int32_t> lsupp((size_t)nl);
+        std::vector<int64_t> lext((size_t)nl);
+        tpchgen_lineitem_cols lc{}; lc.l_suppkey = lsupp.data(); lc.l_extendedprice = lext.data();
+        tpchgen_lineitem(num, den, 0, no, &lc);
+        auto src = table_source({{IntegerType(), lsupp.data()}, {DecimalType(15, 2), lext.data()}}, nl);
+        gpuAggExecutor agg(ctx, {0}, {{PH_A_SUM, {X_COL(1)}}, {PH_A_COUNT_STAR, {}}}, src.get());
+        Literal lim; lim.kind = Literal::Dec; lim.i = 2000000000; lim.scale = 2;
+        Literal cnt; cnt.kind = Literal::Int; cnt.i = 600;
+        agg.SetHaving({{1, PH_GT, lim}, {2, PH_GT, cnt}});
+        agg.SetOutputs({ProjExpr::Col(0), ProjExpr::Dec({X_COL(1), X_CONST(2, 0), X_OP(PH_X_MUL)}), ProjExpr::Col(2)});
+        print(3, run(&agg));
+    } else if (q == "cross") {
+        // (first 5000 customers) x (3 constant rows): CrossProduct emits, per left chunk, one chunk per right row
+        int64_t nc = std::min<int64_t>(tpchgen_customer_count(num, den), 5000);
+        std::vector<int32_t> ckey((size_t)nc), rv = {7, 8, 9};
+        std::vector<uint8_t> cseg((size_t)nc), rcode = {2, 0, 4};
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data(); cc.c_mktsegment = cseg.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        auto left = table_source({{IntegerType(), ckey.data()}, {VarcharType(), cseg.data(), TPCHGEN_MKTSEGMENT_DICT}}, nc);
+        auto right = table_source({{IntegerType(), rv.data()}, {VarcharType(), rcode.data(), TPCHGEN_MKTSEGMENT_DICT}}, 3);
+        crossProductExecutor cross(left.get(), right.get());
+        print(4, run(&cross));
+    } else if (q == "substr") {
+        if (argc < 6) die("usage: host_tester substr <sf_num> <sf_den> <offset> <length>");
+        int64_t nc = tpchgen_customer_count(num, den);
+        std::vector<int32_t> ckey((size_t)nc);
+        std::vector<uint8_t> cseg((size_t)nc);
+        tpchgen_customer_cols cc{}; cc.c_custkey = ckey.data(); cc.c_mktsegment = cseg.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        auto src = table_source({{IntegerType(), ckey.data()}, {VarcharType(), cseg.data(), TPCHGEN_MKTSEGMENT_DICT}}, nc);
+        gpuProjectExecutor proj(ctx, {ProjExpr::Col(0), ProjExpr::Substr(1, atoll(argv[4]), atoll(argv[5]))}, src.get());
+        print(2, run(&proj));
     } else die("unknown query " + q);
     ph_ctx_destroy(ctx);
     return 0;

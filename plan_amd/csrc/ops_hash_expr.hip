@@ -287,3 +287,107 @@ extern "C" int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, con
     PH_HIP(hipGetLastError());
     return PH_OK;
 }
+
+// ------------------------------------------------------------------ substring(s from offset for length)
+// substringFunc / substringStartEnd (pkg/compute/function_operator_binary.go:553-625, registered by
+// SubstringFunc function_scalar.go:1530-1563): byte positions, 1-based offset, negative offsets count
+// from the end, a negative length reads leftwards, offset 0 shortens the length by one. Two passes:
+// every row's (start, length) -> exclusive scan of the lengths -> byte copy.
+namespace ph {
+int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev);
+
+__device__ __forceinline__ bool substr_range(long long slen, long long offset, long long length, long long *start, long long *end) {
+    if (length == 0) return false;
+    if (offset > 0) *start = slen < offset - 1 ? slen : offset - 1;
+    else if (offset < 0) *start = slen + offset > 0 ? slen + offset : 0;
+    else {
+        *start = 0;
+        length--;
+        if (length <= 0) return false;
+    }
+    if (length > 0) *end = slen < *start + length ? slen : *start + length;
+    else {
+        *end = *start;
+        *start = *start + length > 0 ? *start + length : 0;
+    }
+    return *start != *end;
+}
+
+__global__ __launch_bounds__(256) void substr_len_kernel(const int32_t *__restrict__ off, const uint8_t *validity,
+                                                         const int32_t *__restrict__ sel, int64_t n, long long offset,
+                                                         long long length, int32_t *__restrict__ out_len,
+                                                         int32_t *__restrict__ out_start) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = sel ? sel[i] : i;
+        long long s = 0, e = 0;
+        const bool ok = bit_valid(validity, r) && substr_range(off[r + 1] - off[r], offset, length, &s, &e);
+        out_len[i] = ok ? (int32_t)(e - s) : 0;
+        out_start[i] = off[r] + (int32_t)s;
+    }
+}
+
+__global__ __launch_bounds__(256) void substr_copy_kernel(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ start,
+                                                          const int32_t *__restrict__ out_off, int64_t n,
+                                                          uint8_t *__restrict__ out_bytes) {
+    // one wave per row batch: results are short (a few bytes), so a thread copies its own row
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int32_t o = out_off[i], len = out_off[i + 1] - o, s = start[i];
+        for (int32_t k = 0; k < len; k++) out_bytes[o + k] = bytes[s + k];
+    }
+}
+
+__global__ void substr_total_kernel(const int64_t *total, int32_t *out_off, int64_t n) { out_off[n] = (int32_t)*total; }
+
+__global__ __launch_bounds__(256) void cross_pairs_kernel(int64_t nl, int64_t nr, int32_t *__restrict__ out_l, int32_t *__restrict__ out_r) {
+    const int64_t total = nl * nr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        out_l[i] = (int32_t)(i % nl);   // for every right row, all left rows: the order CrossProductExec emits
+        out_r[i] = (int32_t)(i / nl);
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_substring(ph_ctx *ctx, const ph_col *col, int64_t offset, int64_t length, const int32_t *sel, int64_t n,
+                            int32_t *out_offsets_dev, uint8_t *out_bytes_dev, int64_t out_bytes_capacity, int64_t *out_bytes) {
+    PH_REQUIRE(ctx && col && n >= 0 && out_bytes && (n == 0 || out_offsets_dev), "ph_substring: bad arguments");
+    PH_REQUIRE(col->type == PH_STR && col->data && (col->aux || col->aux_bytes == 0), "ph_substring: column type %d is not PH_STR", col->type);
+    *out_bytes = 0;
+    if (n == 0) return PH_OK;
+    int32_t *start = nullptr;
+    int64_t *total = nullptr;
+    PH_CHECK(ctx->pool_alloc(n * 4, (void **)&start));
+    PH_CHECK(ctx->pool_alloc(8, (void **)&total));
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    ph::substr_len_kernel<<<grid, 256, 0, ctx->stream>>>((const int32_t *)col->data, col->validity, sel, n, (long long)offset,
+                                                         (long long)length, out_offsets_dev, start);
+    int rc = ph::exclusive_scan_i32(ctx, out_offsets_dev, n, total);
+    long long tot = 0;
+    if (rc == PH_OK) {
+        ph::substr_total_kernel<<<1, 1, 0, ctx->stream>>>(total, out_offsets_dev, n);
+        rc = ctx->download(&tot, total, 8);
+    }
+    if (rc == PH_OK && tot > out_bytes_capacity) {
+        ph::set_error("ph_substring: %lld result bytes, room for %lld", tot, (long long)out_bytes_capacity);
+        rc = PH_ECAPACITY;
+    }
+    *out_bytes = tot;
+    if (rc == PH_OK && tot > 0) {
+        ph::substr_copy_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)col->aux, start, out_offsets_dev, n, out_bytes_dev);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    ctx->pool_release(start);
+    ctx->pool_release(total);
+    return rc;
+}
+
+extern "C" int ph_cross_pairs(ph_ctx *ctx, int64_t n_left, int64_t n_right, int32_t *out_left_dev, int32_t *out_right_dev) {
+    PH_REQUIRE(ctx && n_left >= 0 && n_right >= 0 && n_left < (1ll << 31) && n_right < (1ll << 31) && n_left * n_right < (1ll << 31),
+               "ph_cross_pairs: bad arguments (the product must stay below 2^31 rows)");
+    const int64_t total = n_left * n_right;
+    if (total == 0) return PH_OK;
+    PH_REQUIRE(out_left_dev && out_right_dev, "ph_cross_pairs: output is NULL");
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    ph::cross_pairs_kernel<<<grid, 256, 0, ctx->stream>>>(n_left, n_right, out_left_dev, out_right_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}

@@ -584,3 +584,21 @@ def date_extract(ctx, part, col, sel, n):
     out = ctx.alloc(max(n, 1) * 4)
     check(lib().ph_date_extract(ctx.h, i32(part), ctypes.byref(c), sel, i64(n), out))
     return out
+
+
+def substring(ctx, col, offset, length, sel, n):
+    """ph_substring: (offsets dev int32[n+1], bytes dev, nbytes) of substring(col FROM offset FOR length)"""
+    c = col.col() if isinstance(col, DevColumn) else col
+    cap = max(int(c.aux_bytes), 1) + 64
+    off = ctx.alloc((max(n, 0) + 1) * 4)
+    out = ctx.alloc(cap)
+    nb = i64()
+    check(lib().ph_substring(ctx.h, ctypes.byref(c), i64(offset), i64(length), sel, i64(n), off, out, i64(cap), ctypes.byref(nb)))
+    return off, out, nb.value
+
+
+def cross_pairs(ctx, n_left, n_right):
+    tot = max(n_left * n_right, 1)
+    ol, orr = ctx.alloc(tot * 4), ctx.alloc(tot * 4)
+    check(lib().ph_cross_pairs(ctx.h, i64(n_left), i64(n_right), ol, orr))
+    return ol, orr

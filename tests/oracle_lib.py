@@ -445,3 +445,18 @@ def q9_text(rows, n, nation_names):
     buf = ctypes.create_string_buffer(1 << 16)
     lib().oracle_q9_text(rows, i64(n), cdict(nation_names), buf, i64(len(buf)))
     return buf.value.decode()
+
+
+def substring(b, offset, length):
+    """oracle_substring over python bytes"""
+    out = ctypes.create_string_buffer(max(len(b), 1))
+    lib().oracle_substring.restype = i64
+    n = lib().oracle_substring(ctypes.c_char_p(b), i64(len(b)), i64(offset), i64(length), out)
+    return out.raw[:n]
+
+
+def cross_pairs(n_left, n_right, chunk=2048):
+    ol = np.empty(max(n_left * n_right, 1), np.int64)
+    orr = np.empty(max(n_left * n_right, 1), np.int64)
+    lib().oracle_cross_pairs(i64(n_left), i64(n_right), i64(chunk), ptr(ol), ptr(orr))
+    return ol[:n_left * n_right], orr[:n_left * n_right]

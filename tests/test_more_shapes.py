@@ -312,3 +312,37 @@ def test_device_sort_matches_oracle():
     assert e.value.code == hip.PH_EUNSUPPORTED
     big.free()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_substring_and_cross_pairs_match_oracle():
+    """ph_substring over a PH_STR column (NULL rows, a selection, every branch of substringStartEnd)
+    and ph_cross_pairs against their oracle restatements. No reference fixture exercises either
+    (parity unpinned beyond the Go source the oracle restates)."""
+    ctx = hip.Ctx(0)
+    rng = np.random.default_rng(17)
+    n = 5000
+    words = [bytes(rng.integers(97, 123, rng.integers(0, 30)).astype(np.uint8)) for _ in range(n)]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(w) for w in words])
+    data = np.frombuffer(b"".join(words), dtype=np.uint8)
+    valid = rng.random(n) > 0.1
+    col = hip.DevColumn(ctx, hip.PH_STR, off, validity=np.packbits(valid, bitorder="little"), aux=data)
+    sel = np.sort(rng.choice(n, 1777, replace=False)).astype(np.int32)
+    dsel = ctx.upload(sel)
+    for o, ln in ((1, 2), (3, 100), (-3, 2), (0, 3), (0, 1), (4, -2), (40, 3), (-40, 3), (5, 0), (2, 2**62)):
+        for s, rows in ((None, np.arange(n)), (dsel, sel)):
+            po, pb, nb = hip.substring(ctx, col, o, ln, s, len(rows))
+            goff = ctx.download(po, np.int32, len(rows) + 1)
+            gb = ctx.download(pb, np.uint8, nb).tobytes() if nb else b""
+            want = [O.substring(words[r], o, ln) if valid[r] else b"" for r in rows]
+            assert goff[0] == 0 and goff[-1] == nb == sum(len(w) for w in want)
+            assert [gb[goff[i]:goff[i + 1]] for i in range(len(rows))] == want
+            ctx.free(po); ctx.free(pb)
+    for nl, nr in ((7, 3), (2048, 2), (1, 1), (0, 5), (300, 0)):
+        ol, orr = hip.cross_pairs(ctx, nl, nr)
+        wl, wr = O.cross_pairs(nl, nr, chunk=max(nl, 1))     # one device batch = one left chunk
+        assert np.array_equal(ctx.download(ol, np.int32, nl * nr), wl) and np.array_equal(ctx.download(orr, np.int32, nl * nr), wr)
+        ctx.free(ol); ctx.free(orr)
+    col.free()
+    ctx.close()
