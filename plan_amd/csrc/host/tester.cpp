@@ -369,11 +369,12 @@ int main(int argc, char **argv) {
         // o_orderdate, o_shippriority (executor_aggr.go:229-247); then ORDER BY revenue DESC,
         // o_orderdate LIMIT 10 (orderExecutor + limitExecutor), all through the library
         agg.SetOutputs({ProjExpr::Col(0), ProjExpr::Col(3), ProjExpr::Col(1), ProjExpr::Col(2)});
-        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2, &agg})
+        for (OperatorExec *e : std::vector<OperatorExec *>{&cf, &of, &lf, &j1, &j2})
             if (!e->Init().empty()) die("init");
         bool all = argc > 4 && !strcmp(argv[4], "groups");
         if (all) print(4, run(&agg));   // every group, unordered (what the aggregate itself emits)
         else {
+            if (!agg.Init().empty()) die("agg init");
             gpuOrderExecutor ord(ctx, {{1, true}, {2, false}}, &agg);
             limitExecutor lim(10, 0, &ord);
             print(4, run(&lim));

@@ -319,6 +319,7 @@ def test_device_substring_and_cross_pairs_match_oracle():
     """ph_substring over a PH_STR column (NULL rows, a selection, every branch of substringStartEnd)
     and ph_cross_pairs against their oracle restatements. No reference fixture exercises either
     (parity unpinned beyond the Go source the oracle restates)."""
+    from plan_amd import hip
     ctx = hip.Ctx(0)
     rng = np.random.default_rng(17)
     n = 5000
