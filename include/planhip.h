@@ -284,6 +284,16 @@ int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *wher
 /* Semi/anti/mark: found_dev[i] = 1 when probe row sel[i] (or i) has a match */
 int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                        uint8_t *found_dev);
+/* Lookup probe for N:1 joins (unique build keys: a primary key — the shape of every join of Q9 and of
+ * the foreign-key joins generally): out_build_dev[i] = the build row matching probe row sel[i] (or
+ * i), or -1. One kernel and no compaction, so a chain of such joins keeps ONE row-id array for the
+ * probe side (late materialisation: columns are gathered once, after the last join, instead of
+ * after every join as Scan.gatherResult does per chunk, join_scan.go:250-278). When a build key is
+ * not unique the LAST row of its chain that matches is reported; stats_dev (optional, 2 int32 the
+ * caller zeroes) receives the number of probe rows without a match and with more than one, so a
+ * caller can verify the uniqueness it assumed with one read at the end of a pipeline. */
+int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev,
+                   int32_t *stats_dev);
 void ph_join_free(ph_join *j);
 
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:

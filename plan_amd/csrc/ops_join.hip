@@ -781,6 +781,125 @@ __global__ __launch_bounds__(256) void join_mark_kernel(JoinSide B, JoinSide Pr,
         found[i] = probe_count(B, Pr, head, mask, next, i, bl) > 0 ? 1 : 0;
 }
 
+// ---- lookup probe (N:1 joins: the build keys are unique, a primary key). One kernel, no
+// candidate / scan / emit pipeline: out[i] = the matching build row of probe position i, or -1.
+// The intermediate of a join chain stays positional (late materialisation): every further N:1 join
+// is one such lookup addressed through the SAME row-id array, and columns are gathered once at
+// the end instead of after every join. Straight-line like join_chain_fast_kernel: the LU probes of
+// a lane issue their key reads, then their head reads, then walk their chains together.
+constexpr int LU = 4;
+
+template <int KW, bool SELP, bool SELB, int NK>
+__global__ __launch_bounds__(256) void join_lookup_fast_kernel(const void *__restrict__ bkey, const void *__restrict__ bkey2,
+                                                               const int32_t *__restrict__ bsel,
+                                                               const void *__restrict__ pkey, const void *__restrict__ pkey2,
+                                                               const int32_t *__restrict__ psel, int64_t n,
+                                                               const int32_t *__restrict__ head, uint64_t mask,
+                                                               const int32_t *__restrict__ next, Bloom bl,
+                                                               int32_t *__restrict__ out, int *__restrict__ stats) {
+    int misses = 0, multi = 0;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * LU; base < n; base += (int64_t)gridDim.x * 256 * LU) {
+        int64_t i[LU], r[LU];
+        bool ok[LU];
+        unsigned long long k[LU], k2[LU];
+        int b[LU], c[LU];
+        int32_t hit[LU];
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            i[u] = base + u * 256 + threadIdx.x;
+            ok[u] = i[u] < n;
+            r[u] = ok[u] ? i[u] : 0;
+            c[u] = 0;
+            hit[u] = -1;
+        }
+        if (SELP) {
+#pragma unroll
+            for (int u = 0; u < LU; u++) r[u] = psel[r[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            k[u] = load_kw<KW>(pkey, r[u]);
+            k2[u] = NK == 2 ? load_kw<KW>(pkey2, r[u]) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[u]);
+            if (NK == 2) hh = mix64(hh ^ k2[u]);
+            const bool maybe = ok[u] && bloom_maybe(bl, hh);
+            const int hb = head[hh & mask];
+            b[u] = maybe ? hb : -1;
+        }
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < LU; u++) more = more || b[u] >= 0;
+        while (more) {
+            int64_t brow[LU];
+            int nx[LU];
+            unsigned long long bk[LU], bk2[LU];
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                const int bb = b[u] >= 0 ? b[u] : 0;
+                nx[u] = next[bb];
+                brow[u] = SELB ? (int64_t)bsel[bb] : (int64_t)bb;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                bk[u] = load_kw<KW>(bkey, brow[u]);
+                bk2[u] = NK == 2 ? load_kw<KW>(bkey2, brow[u]) : 0ull;
+            }
+            more = false;
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                if (b[u] >= 0) {
+                    if (bk[u] == k[u] && bk2[u] == k2[u]) { c[u]++; hit[u] = (int32_t)brow[u]; }
+                    b[u] = nx[u];
+                }
+                more = more || b[u] >= 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            if (ok[u]) {
+                out[i[u]] = hit[u];
+                misses += c[u] == 0;
+                multi += c[u] > 1;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (misses) atomicAdd(stats, misses);
+        if (multi) atomicAdd(stats + 1, multi);
+    }
+}
+
+// any key shape (NULL-able keys, three or four key columns, mixed widths)
+__global__ __launch_bounds__(256) void join_lookup_kernel(JoinSide B, JoinSide Pr, const int32_t *__restrict__ head, uint64_t mask,
+                                                          const int32_t *__restrict__ next, Bloom bl, int32_t *__restrict__ out,
+                                                          int *__restrict__ stats) {
+    int misses = 0, multi = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < Pr.n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = Pr.sel ? Pr.sel[i] : i;
+        unsigned long long k[JOIN_MAX_KEYS];
+        uint64_t h;
+        int c = 0;
+        int32_t hit = -1;
+        if (load_keys(Pr, r, k, &h) && bloom_maybe(bl, h))
+            for (int b = head[h & mask]; b >= 0; b = next[b]) {
+                const int64_t brow = B.sel ? B.sel[b] : b;
+                if (keys_equal(B, brow, k)) { c++; hit = (int32_t)brow; }
+            }
+        out[i] = hit;
+        misses += c == 0;
+        multi += c > 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (misses) atomicAdd(stats, misses);
+        if (multi) atomicAdd(stats + 1, multi);
+    }
+}
+
 // Dense probes (no bitmap): every position is a candidate. Filling the slices with the identity lets
 // them share the chain / emit kernels (and their straight-line fast forms) with selective probes.
 __global__ __launch_bounds__(256) void join_cand_all_kernel(int64_t n, uint16_t *__restrict__ cand, int32_t *__restrict__ ccount) {
@@ -1074,5 +1193,56 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
     int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
     ph::join_mark_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, found_dev, j->bloom);
     PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+// ------------------------------------------------------------------ lookup probe (N:1)
+template <int KW>
+static void launch_lookup_fast(int grid, hipStream_t st, const ph::JoinSide &B, const ph::JoinSide &P, int64_t n, const int32_t *head,
+                               uint64_t mask, const int32_t *next, const ph::Bloom &bl, int32_t *out, int *stats) {
+#define PH_LU_ARGS B.key[0].data, B.key[1].data, B.sel, P.key[0].data, P.key[1].data, P.sel, n, head, mask, next, bl, out, stats
+#define PH_LU_LAUNCH(NKV)                                                                                       \
+    do {                                                                                                        \
+        if (P.sel && B.sel) ph::join_lookup_fast_kernel<KW, true, true, NKV><<<grid, 256, 0, st>>>(PH_LU_ARGS);  \
+        else if (P.sel) ph::join_lookup_fast_kernel<KW, true, false, NKV><<<grid, 256, 0, st>>>(PH_LU_ARGS);     \
+        else if (B.sel) ph::join_lookup_fast_kernel<KW, false, true, NKV><<<grid, 256, 0, st>>>(PH_LU_ARGS);     \
+        else ph::join_lookup_fast_kernel<KW, false, false, NKV><<<grid, 256, 0, st>>>(PH_LU_ARGS);               \
+    } while (0)
+    if (P.nkeys == 2) PH_LU_LAUNCH(2);
+    else PH_LU_LAUNCH(1);
+#undef PH_LU_LAUNCH
+#undef PH_LU_ARGS
+}
+
+extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev,
+                              int32_t *stats_dev) {
+    ph::JoinSide P{};
+    PH_CHECK(check_probe(j, keys, sel, n, &P));
+    if (n == 0) return PH_OK;
+    PH_REQUIRE(out_build_dev != nullptr, "ph_join_lookup: out_build_dev is NULL");
+    ph_ctx *ctx = j->ctx;
+    int *stats = stats_dev;
+    int *scratch = nullptr;
+    if (!stats) {   // the kernel always counts; without a caller buffer the counts are dropped
+        PH_CHECK(ctx->pool_alloc(8, (void **)&scratch));
+        stats = scratch;
+    }
+    const ph::JoinSide &B = j->build;
+    const uint64_t mask = (uint64_t)j->cap - 1;
+    const int grid = (int)std::min<int64_t>((n + 256 * ph::LU - 1) / (256 * ph::LU), (int64_t)ctx->cu_count * 8);
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+    const int kw = width(P.key[0].type);
+    bool fast = B.n > 0 && P.nkeys <= 2 && !P.key[0].validity && !B.key[0].validity && kw == width(B.key[0].type) && kw != 1;
+    if (fast && P.nkeys == 2)
+        fast = !P.key[1].validity && !B.key[1].validity && width(P.key[1].type) == kw && width(B.key[1].type) == kw;
+    if (B.n == 0) {
+        ph::JoinSide Bz = B;
+        ph::join_lookup_kernel<<<std::min<int64_t>((n + 255) / 256, 2048), 256, 0, ctx->stream>>>(Bz, P, j->head, mask, j->next, j->bloom, out_build_dev, stats);
+    } else if (fast && kw == 4) launch_lookup_fast<4>(grid, ctx->stream, B, P, n, j->head, mask, j->next, j->bloom, out_build_dev, stats);
+    else if (fast) launch_lookup_fast<8>(grid, ctx->stream, B, P, n, j->head, mask, j->next, j->bloom, out_build_dev, stats);
+    else ph::join_lookup_kernel<<<(int)std::min<int64_t>((n + 255) / 256, 2048), 256, 0, ctx->stream>>>(B, P, j->head, mask, j->next, j->bloom, out_build_dev, stats);
+    const bool bad = hipGetLastError() != hipSuccess;
+    if (scratch) ctx->pool_release(scratch);
+    if (bad) { ph::set_error("ph_join_lookup: kernel launch failed"); return PH_EHIP; }
     return PH_OK;
 }

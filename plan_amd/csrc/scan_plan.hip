@@ -465,6 +465,11 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
             p->aggs[oi] = m;
         }
         if (e < 0) { set_error("lowcard_chain needs at least one 64-bit summed column"); return fail(PH_EUNSUPPORTED); }
+        // The precompiled kernel always loads its four roles; a plan that names fewer columns would
+        // re-read a stand-in (measured: 3.5 TB/s of useful bytes instead of 6.3). Such plans get a
+        // generated kernel that reads only what they name — unless code generation is switched off.
+        static const bool nojit = getenv("PH_SCAN_JIT") && atoi(getenv("PH_SCAN_JIT")) == 0;
+        if ((d < 0 || tt < 0 || q < 0) && !nojit) { set_error("lowcard_chain: the plan names fewer columns than the kernel reads"); return fail(PH_EUNSUPPORTED); }
         if (d < 0) d = e;
         if (tt < 0) tt = e;
         if (q < 0) q = ranges[0].col;
@@ -629,6 +634,15 @@ static int try_jit(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t
     const int na = (int)S.accs.size();
     S.lds_cols = ph::JitShape::fit_lds_cols(S.nslots, na);
     if (S.lds_cols == 0) return fail(unsupported("group slots x accumulators exceed the CU's LDS"));
+    // Bytes in flight: a workgroup keeps one 1024-row tile prefetched, i.e. 1024 x (row bytes). The
+    // 34 B/row of Q1 (34 KiB per CU) covers the HBM latency-bandwidth product with one workgroup
+    // per CU; narrower plans need proportionally more resident workgroups (measured: 9 B/row at one
+    // workgroup per CU reads 4.0 TB/s, latency bound), as far as their LDS accumulators allow.
+    int row_bytes = 0;
+    for (int w : S.col_width) row_bytes += w;
+    int per_cu = std::max(1, std::min(8, (34 + row_bytes - 1) / row_bytes));
+    const int64_t lds_bytes = (int64_t)S.nslots * (na * 8 + 8) * S.lds_cols;
+    while (per_cu > 1 && per_cu * lds_bytes > 150 * 1024) per_cu--;
     p->row_bound = row_bound;
     p->jshape = S;
     for (size_t i = 0; i < tcol.size(); i++) p->jparams.col[i] = t->cols[(size_t)tcol[i]].data;
@@ -638,7 +652,7 @@ static int try_jit(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32_t
     p->ops.push_back(0);
     p->ops.push_back(1);
     p->nacc = p->nslots * p->stride;
-    p->max_grid = ctx->cu_count;
+    p->max_grid = ctx->cu_count * per_cu;
     int rc = ph::jit_get(ctx, S, &p->jkernel);
     if (rc != PH_OK) return fail(rc == PH_EHIP ? PH_EUNSUPPORTED : rc);   // no hiprtc / compile trouble: the generic chain still runs
     rc = plan_alloc(p);

@@ -536,6 +536,13 @@ class Join:
         check(rc)
         return m.value, op, ob
 
+    def lookup(self, keys, sel, n, stats=None):
+        """N:1 lookup probe: device int32[n] of matching build rows (-1 = none); stats: optional
+        device int32[2] (misses, multi-matches), zeroed by the caller"""
+        out = self.ctx.alloc(max(n, 1) * 4)
+        check(lib().ph_join_lookup(self.h, _cols(keys), sel, i64(n), out, stats))
+        return out
+
     def probe_mark(self, keys, sel, n):
         f = self.ctx.alloc(max(n, 1))
         check(lib().ph_join_probe_mark(self.h, _cols(keys), sel, i64(n), f))

@@ -340,11 +340,16 @@ class Q9Pipeline:
             bc, _ = bcast(self.ps_cost, fsel, fn, np.int64)
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, nb)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
-        k0, k1 = gat(self.l_part, lrow, n1), gat(self.l_supp, lrow, n1)
-        n2, pos2, psrow = jps.probe_inner([_raw(hip.PH_I32, k0), _raw(hip.PH_I32, k1)], None, n1, n1)
+        # The two joins below are N:1 (partsupp's composite primary key, supplier's key): LOOKUP
+        # probes addressed through the SAME lineitem row ids (late materialisation) — one kernel each,
+        # no key gathers, no candidate/scan/emit pipeline, no re-gather of the earlier row-id arrays
+        # (the per-join materialisation of Scan.gatherResult, join_scan.go:250-278, done once instead).
+        stats = ctx.alloc(8)
+        frees.append(stats)
+        hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
+        psrow = jps.lookup([self.l_part, self.l_supp], lrow, n1, stats)
         jps.free()
-        frees += [pos2, psrow]
-        lrow2 = gat(_raw(hip.PH_I32, lrow), pos2, n2)
+        frees.append(psrow)
         stage("partsupp_join", t0)
 
         t0 = tic()
@@ -358,12 +363,20 @@ class Q9Pipeline:
             sn, _ = bcast(self.s_nat, ident, self.n["s"], np.int32)
             js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk)
             s_nat = _raw(hip.PH_I32, sn)
-        ks = gat(self.l_supp, lrow2, n2)
-        n3, pos3, srow = js.probe_inner([_raw(hip.PH_I32, ks)], None, n2, n2)
-        frees += [pos3, srow]
+        srow = js.lookup([self.l_supp], lrow, n1, stats)
+        frees.append(srow)
         js.free()
-        lrow3 = gat(_raw(hip.PH_I32, lrow2), pos3, n3)
-        psrow3 = gat(_raw(hip.PH_I32, psrow), pos3, n3)
+        # one read for both joins: rows without a match (none in TPC-H: foreign keys) would have to
+        # leave the intermediate, rows with several matches would need the pair-emitting probe
+        misses, multi = ctx.download(stats, np.int32, 2).tolist()
+        if multi:
+            raise hip.PlanHipError(hip.PH_EUNSUPPORTED, "Q9: partsupp / supplier keys are not unique; use probe_inner")
+        lrow3, psrow3, n3 = lrow, psrow, n1
+        if misses:   # inner-join semantics: keep the positions both lookups resolved
+            okp, c1 = hip.filter_select(ctx, _raw(hip.PH_I32, psrow), n1, hip.PH_GE, hip.const(hip.PH_I32, i=0))
+            ok2, n3 = hip.filter_select(ctx, _raw(hip.PH_I32, srow), n1, hip.PH_GE, hip.const(hip.PH_I32, i=0), okp, c1)
+            frees += [okp, ok2]
+            lrow3, psrow3, srow = gat(_raw(hip.PH_I32, lrow), ok2, n3), gat(_raw(hip.PH_I32, psrow), ok2, n3), gat(_raw(hip.PH_I32, srow), ok2, n3)
         stage("supplier_join", t0)
 
         # ---- columns of the surviving lineitem rows (positional from here on)

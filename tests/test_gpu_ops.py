@@ -776,3 +776,48 @@ def test_rccl_communicator_single_rank_roundtrip(ctx):
         dk.free(); dv.free()
     finally:
         g.close()
+
+
+def test_join_lookup_matches_inner_probe_on_unique_keys(ctx):
+    """ph_join_lookup (N:1 lookup probe): for unique build keys out[i] is the build row the pair-
+    emitting probe reports for probe row i, -1 where there is none; the stats words count misses and
+    multi-matches. One and two key columns, 4- and 8-byte keys, selections on both sides, a Bloom-
+    filtered (small) and a plain (large) table."""
+    rng = np.random.default_rng(123)
+    for nb, npr, dt, ht in ((50_000, 300_000, np.int32, hip.PH_I32), (5_000_000, 400_000, np.int64, hip.PH_I64)):
+        bk = rng.permutation(nb * 3).astype(dt)[:nb]            # unique
+        pk = rng.integers(0, nb * 3, npr).astype(dt)
+        dbk, dpk = hip.DevColumn(ctx, ht, bk), hip.DevColumn(ctx, ht, pk)
+        bsel = np.sort(rng.choice(nb, nb // 2, replace=False)).astype(np.int32)
+        psel = np.sort(rng.choice(npr, npr // 3, replace=False)).astype(np.int32)
+        for bs, ps in ((None, None), (bsel, psel)):
+            brows = np.arange(nb) if bs is None else bs
+            prows = np.arange(npr) if ps is None else ps
+            j = hip.Join(ctx, [dbk], None if bs is None else ctx.upload(bs), len(brows))
+            stats = ctx.upload(np.zeros(2, np.int32))
+            out = j.lookup([dpk], None if ps is None else ctx.upload(ps), len(prows), stats)
+            got = ctx.download(out, np.int32, len(prows))
+            where = {int(k): int(r) for k, r in zip(bk[brows], brows)}
+            want = np.array([where.get(int(k), -1) for k in pk[prows]], np.int32)
+            assert np.array_equal(got, want)
+            assert ctx.download(stats, np.int32, 2).tolist() == [int((want < 0).sum()), 0]
+            j.free()
+        dbk.free(); dpk.free()
+    # composite key + a duplicated build key (multi-match is counted, a matching row is still reported)
+    a = rng.integers(0, 1000, 20_000).astype(np.int32)
+    b = rng.integers(0, 50, 20_000).astype(np.int32)
+    pairs = np.unique(np.stack([a, b], 1), axis=0)
+    ba, bb = pairs[:, 0].copy(), pairs[:, 1].copy()
+    ba = np.concatenate([ba, ba[:7]]); bb = np.concatenate([bb, bb[:7]])      # 7 duplicated keys
+    da, db = hip.DevColumn(ctx, hip.PH_I32, ba), hip.DevColumn(ctx, hip.PH_I32, bb)
+    pa, pb = hip.DevColumn(ctx, hip.PH_I32, a), hip.DevColumn(ctx, hip.PH_I32, b)
+    j = hip.Join(ctx, [da, db], None, len(ba))
+    stats = ctx.upload(np.zeros(2, np.int32))
+    got = ctx.download(j.lookup([pa, pb], None, len(a), stats), np.int32, len(a))
+    assert np.all(got >= 0) and np.array_equal(ba[got], a) and np.array_equal(bb[got], b)
+    dup = set(zip(ba[:7].tolist(), bb[:7].tolist()))
+    st = ctx.download(stats, np.int32, 2).tolist()
+    assert st == [0, sum((x, y) in dup for x, y in zip(a.tolist(), b.tolist()))]
+    j.free()
+    for c in (da, db, pa, pb):
+        c.free()
