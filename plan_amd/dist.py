@@ -129,8 +129,9 @@ def _rccl():
 
 
 def _td():
-    import torch.distributed as td
-    return td if td.is_available() and td.is_initialized() else None
+    import sys
+    td = sys.modules.get("torch.distributed")   # never imported from here: a process that has not
+    return td if td is not None and td.is_available() and td.is_initialized() else None   # set it up is one rank
 
 
 def world():

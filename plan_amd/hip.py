@@ -63,11 +63,15 @@ class AggResult(ctypes.Structure):
 
 
 def _preload_torch_hip_runtime():
-    """One HIP runtime per process. PyTorch-ROCm bundles its own libamdhip64.so (SONAME
-    libamdhip64.so.7) and its libraries ask for it by the unversioned name, so if ROCm's copy were
-    loaded first (through libplanhip.so's NEEDED entry) a later `import torch` would bring in a
-    second runtime, whose device discovery then fails ("No HIP GPUs are available"). Loading
-    torch's copy first makes libplanhip.so resolve to it by SONAME, whatever the import order."""
+    """One HIP runtime per process. PyTorch-ROCm bundles its own libamdhip64.so / libhiprtc.so /
+    librccl.so (SONAMEs libamdhip64.so.7, libhiprtc.so.7, librccl.so.1 — the ones libplanhip.so
+    asks for), and its libraries ask for them by the unversioned names: if ROCm's copies were loaded
+    first (through libplanhip.so's NEEDED entries) a later `import torch` would bring in a second
+    runtime, whose device discovery then fails ("No HIP GPUs are available").
+    So when torch is installed it is imported FIRST, and libplanhip.so then binds to the copies torch
+    has loaded, by SONAME. Loading only torch's .so files here and importing torch later was tried:
+    the process then aborts at exit ("double free or corruption") because the libraries' static
+    destructors run in an order torch never sees (measured on the GPU box, round 2)."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -75,8 +79,10 @@ def _preload_torch_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    # libplanhip.so also needs librccl.so.1 and libhiprtc.so.7: torch bundles its own builds of both
-    # against ITS runtime, so they are taken from the same place, in dependency order
+    try:
+        import torch  # noqa: F401  (initialises torch's bundled ROCm libraries in torch's own order)
+    except Exception:  # noqa: BLE001 - a broken torch install: fall back to its bare libraries
+        pass
     for name in ("libamdhip64.so", "libhiprtc.so", "librccl.so"):
         cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
         if os.path.exists(cand):
