@@ -237,6 +237,11 @@ int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *args, int32_
 int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev, uint8_t *out_validity_dev,
                     int64_t capacity, int64_t *ngroups);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
+/* Build check without a device of the plan-specialised sink: ph_agg_sink calls of >= 2^20 rows run
+ * the sink kernel compiled (hiprtc, cached per shape) with the key types / aggregate kinds /
+ * argument types / NULL-ability of THIS call as constants instead of interpreting them per row
+ * (PH_AGG_JIT=0 switches it off). Compiles canned shape `which` (0, 1) for gfx950. */
+int ph_agg_jit_selfcheck(int32_t which);
 /* Host outputs, groups in first-seen order:
  *   first_row[g]; keys[g*nkeys+c] (int64-widened), key_null[g*nkeys+c];
  *   sum_lo/sum_hi[g*naggs+a] = 128-bit sum (SUM/AVG) or min/max value in sum_lo;

@@ -19,384 +19,19 @@
 // word plus a carry/sign add on the high word, which commutes, so any interleaving gives the exact sum.
 #include <algorithm>
 
+#include <sstream>
+
+#include "agg_sink_src.h"
 #include "common.h"
 #include "device_util.h"
 #include "ops.h"
+#include "scan_jit.h"
 
 namespace ph {
 
-constexpr int AGG_MAX_KEYS = 4;
-constexpr int AGG_MAX_AGGS = 16;
-constexpr int SLOT_EMPTY = -1;
-constexpr int SLOT_LOCKED = -2;
-
-struct AggCol {
-    int type;
-    const void *data;
-    const uint8_t *validity;
-};
-
-struct AggSinkParams {
-    int nkeys, naggs, nargs;
-    AggCol key[AGG_MAX_KEYS];
-    AggCol arg[AGG_MAX_AGGS];
-    int agg_kind[AGG_MAX_AGGS];
-    int agg_arg[AGG_MAX_AGGS];
-    const int32_t *sel;
-    int64_t n;
-    int positional;
-    int64_t row_base;
-    int32_t *slots;
-    uint64_t mask;
-    unsigned long long *gkeys;
-    unsigned *gnull;
-    unsigned long long *sum_lo;
-    long long *sum_hi;
-    unsigned long long *cnt;
-    long long *first_row;
-    int *ngroups;
-    int64_t gcap;
-    int *error_flag;
-    int lds_slots;  // power of two; per-workgroup staging table entries
-    int *need_grow;     // set when a workgroup stopped early because the table may fill up
-    int *progress;      // per workgroup: chunk iterations already done (resume point after a growth)
-    long long slack;    // groups all workgroups together may still create = gridDim.x * (chunk + lds_slots / 2)
-    int chunk;          // rows a workgroup takes between two growth checks (256 .. AGG_CHUNK)
-    unsigned arg_used;  // bit c: argument column c is read by some aggregate
-    unsigned agg_mask;  // bit a: aggregate a is updated by this call (AddChunk's filter)
-};
-
-constexpr int AGG_CHUNK = 2048;  // most rows a workgroup takes between two growth checks
-constexpr int AGG_U = 2;         // rows per thread in flight
-constexpr int AGG_PRE = 4;       // argument columns read ahead for them
-
-__device__ __forceinline__ unsigned long long load_key(const AggCol &c, int64_t r) {
-    switch (c.type) {
-    case PH_I32: case PH_DATE: return (unsigned long long)(long long)((const int32_t *)c.data)[r];
-    case PH_CODE8: return ((const uint8_t *)c.data)[r];
-    default: return (unsigned long long)((const int64_t *)c.data)[r];
-    }
-}
-
-__device__ __forceinline__ uint64_t keys_hash(const unsigned long long *k, unsigned nullmask, int nkeys) {
-    uint64_t h = mix64((uint64_t)nullmask + 0x9e3779b97f4a7c15ULL);
-    for (int c = 0; c < nkeys; c++) h = mix64(h ^ k[c]);
-    return h;
-}
-
-__device__ __forceinline__ void add128(unsigned long long *lo, long long *hi, long long v) {
-    unsigned long long old = atomicAdd(lo, (unsigned long long)v);
-    unsigned long long nw = old + (unsigned long long)v;
-    long long delta = (nw < old ? 1 : 0) + (v < 0 ? -1 : 0);
-    if (delta != 0) atomicAdd((unsigned long long *)hi, (unsigned long long)delta);
-}
-
-// Find or create the group of one key in the global table (FindOrCreateGroups,
-// aggregate_hash.go:272-388). No lane ever waits inside a branch, so lanes of one wave racing for
-// the same new key cannot deadlock: the winner publishes in the same iteration it locked the slot;
-// the others see the id on a later iteration. Every access is an agent-scope atomic: these loads
-// bypass the per-XCD L2, so they are slow (all CUs reading one hot line are bound by that line's
-// memory channel) — which is why the sink kernel below only comes here once per (workgroup,
-// group) when it can.
-__device__ __forceinline__ int find_or_create(const AggSinkParams &P, const unsigned long long *k, unsigned nullmask,
-                                              uint64_t h) {
-    uint64_t slot = h & P.mask;
-    int gid = -1;
-    for (int guard = 0; gid < 0; guard++) {
-        // a table that ran out of group ids (only the bulk build can get there: it starts from the
-        // caller's hint) also runs out of free slots; probing must not go round it for ever
-        if ((guard & 255) == 255 && __hip_atomic_load(P.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        int g = __hip_atomic_load(&P.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g == SLOT_EMPTY) {
-            int old = atomicCAS(&P.slots[slot], SLOT_EMPTY, SLOT_LOCKED);
-            if (old == SLOT_EMPTY) {
-                // group ids for all lanes of this wave that won a slot in this iteration come from
-                // ONE add on the counter: it is a single address for the whole device, and inputs
-                // that are mostly new groups (Q3: 113k groups from 298k rows) were bound by it
-                const unsigned long long winners = __ballot(1);
-                const int first = __ffsll((long long)winners) - 1, me = (int)(threadIdx.x & 63);
-                int base = 0;
-                if (me == first) base = atomicAdd(P.ngroups, __popcll(winners));
-                base = __shfl(base, first);
-                int ng = base + __popcll(winners & ((1ull << me) - 1ull));
-                const bool room = ng < P.gcap;
-                if (!room) {  // only an overflowing bulk build gets here (its attempt is void): the
-                    atomicOr(P.error_flag, 1);   // key is not stored, group 0 only absorbs the row
-                    ng = 0;
-                }
-                for (int c = 0; room && c < P.nkeys; c++)
-                    __hip_atomic_store(&P.gkeys[(int64_t)ng * P.nkeys + c], k[c], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                if (room && nullmask)  // gnull is zeroed when the arrays are (re)allocated
-                    __hip_atomic_store(&P.gnull[ng], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // Publication order: the key words above are agent-scope atomic stores (sc1: written
-                // through to the device coherence point, never parked dirty in this XCD's L2), and
-                // on gfx9 vmcnt counts stores, so waiting for vmcnt(0) means they are performed
-                // before the id below is stored. A full release fence would add buffer_wbl2 — a
-                // write-back of the whole L2 per new group, which doubled the cost of inputs that
-                // are mostly new groups — and is only needed for ordinary (non-atomic) stores.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&P.slots[slot], ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gid = ng;
-            }
-            // lost the race: look at the slot again
-        } else if (g == SLOT_LOCKED) {
-            if (guard > (1 << 22)) { atomicOr(P.error_flag, 2); break; }  // bounded spin
-        } else {
-            bool eq = __hip_atomic_load(&P.gnull[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nullmask;
-            for (int c = 0; eq && c < P.nkeys; c++)
-                eq = __hip_atomic_load(&P.gkeys[(int64_t)g * P.nkeys + c], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT) == k[c];
-            if (eq) gid = g;
-            else slot = (slot + 1) & P.mask;  // linear probing (:376-384)
-        }
-    }
-    return gid;
-}
-
-// One launch covers a whole sink call. Workgroup w takes the row chunks w, w+G, w+2G, ... and
-// pre-aggregates them in an LDS hash table keyed by the group key (open addressing, linear
-// probing, at most half full): a row whose key is in the LDS table costs its column reads and a
-// few ds operations, nothing else. The global table is touched once per (workgroup, group) when
-// the LDS table is flushed at the end, and row by row only for keys that found no room in LDS
-// (high-cardinality inputs).
-// Growth (the reference's Resize rule, aggregate_hash.go:214-217) is checked in front of every
-// chunk: a chunk starts only while the global table could still take, as new groups, every row
-// all workgroups may have in flight plus every entry their LDS tables may still flush. The check
-// is an agent-scope load served where the counter's atomic adds execute, so it sees every group
-// created before it: after the last check that passed, each
-// workgroup creates at most one chunk of groups row by row and half an LDS table at its flush, so
-// the count stays below gcap. A workgroup that fails the check records where it stopped, flushes
-// and leaves; the host grows the table and relaunches, every workgroup resuming at its chunk.
-constexpr int L_EMPTY = -1, L_LOCKED = -2;   // LDS entry states; >= 0: ready, value = NULL mask
-
-// index hash of the LDS table: 32-bit multiplies only (a 64-bit mix costs ~8 quarter-rate
-// multiplies per key on CDNA); the 64-bit hash of the global table is computed only for rows
-// that go there
-template <int NK>
-__device__ __forceinline__ unsigned lds_hash(const unsigned long long *k, unsigned nullmask) {
-    unsigned h = nullmask * 0x9E3779B1u;
-#pragma unroll
-    for (int c = 0; c < NK; c++) {
-        h ^= (unsigned)k[c];
-        h *= 0x85EBCA6Bu;
-        h ^= (unsigned)(k[c] >> 32) + (h >> 15);
-        h *= 0xC2B2AE35u;
-    }
-    return h ^ (h >> 16);
-}
-
-template <int NK>
-__global__ __launch_bounds__(256) void agg_sink_kernel(AggSinkParams P) {
-    __shared__ int s_go, s_nent;
-    extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
-    const int T = P.lds_slots, na = P.naggs;
-    constexpr int nk = NK;
-    // [first T x i64][key nk*T x u64][sum T*na x u64][state T x i32][cnt T*na x u32]
-    long long *l_first = reinterpret_cast<long long *>(agg_lds);
-    unsigned long long *l_key = reinterpret_cast<unsigned long long *>(l_first + T);
-    unsigned long long *l_sum = l_key + (size_t)nk * T;
-    int *l_state = reinterpret_cast<int *>(l_sum + (size_t)T * na);
-    unsigned *l_cnt = reinterpret_cast<unsigned *>(l_state + T);
-    for (int e = threadIdx.x; e < T; e += 256) {
-        l_state[e] = L_EMPTY;
-        l_first[e] = INT64_MAX;
-        for (int a = 0; a < na; a++) {
-            int kind = P.agg_kind[a];
-            l_sum[e * na + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
-                                : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
-            l_cnt[e * na + a] = 0;
-        }
-    }
-    if (threadIdx.x == 0) s_nent = 0;
-    int it = P.progress[blockIdx.x];
-    for (;; it++) {
-    const int64_t c0 = ((int64_t)it * gridDim.x + blockIdx.x) * P.chunk;
-    if (c0 >= P.n) break;
-    __syncthreads();  // LDS initialised / everyone has read the previous s_go
-    if (threadIdx.x == 0) {
-        int ng = __hip_atomic_load(P.ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_go = P.gcap - (long long)ng > P.slack;
-        if (!s_go) __hip_atomic_store(P.need_grow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_go) break;
-    const int64_t c1 = c0 + P.chunk < P.n ? c0 + P.chunk : P.n;
-    // AGG_U rows per thread are in flight: all their column
-    // reads (selection, keys, the first AGG_PRE argument columns) are issued before the first
-    // row is processed, so one HBM latency is paid per AGG_U rows instead of two per row.
-    for (int64_t ib = c0; ib < c1; ib += 256 * AGG_U) {
-      int64_t ii[AGG_U], rr[AGG_U];
-      unsigned long long kk[AGG_U][AGG_MAX_KEYS];
-      unsigned nmask[AGG_U], pvalid[AGG_U];
-      long long pv[AGG_U][AGG_PRE];
-#pragma unroll
-      for (int u = 0; u < AGG_U; u++) {
-          ii[u] = ib + u * 256 + threadIdx.x;
-          rr[u] = ii[u] < c1 ? (P.sel ? (int64_t)P.sel[ii[u]] : ii[u]) : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < AGG_U; u++) {
-          nmask[u] = 0;
-#pragma unroll
-          for (int c = 0; c < AGG_MAX_KEYS; c++) {
-              kk[u][c] = 0;
-              if (c < nk && rr[u] >= 0) {
-                  if (bit_valid(P.key[c].validity, rr[u])) kk[u][c] = load_key(P.key[c], rr[u]);
-                  else nmask[u] |= 1u << c;
-              }
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < AGG_U; u++) {
-          pvalid[u] = 0;
-#pragma unroll
-          for (int c = 0; c < AGG_PRE; c++) {
-              pv[u][c] = 0;
-              if (((P.arg_used >> c) & 1) && rr[u] >= 0) {
-                  const int64_t ar = P.positional ? ii[u] : rr[u];
-                  if (bit_valid(P.arg[c].validity, ar)) {
-                      pvalid[u] |= 1u << c;
-                      pv[u][c] = P.arg[c].type == PH_I32 ? (long long)((const int32_t *)P.arg[c].data)[ar]
-                                                         : ((const int64_t *)P.arg[c].data)[ar];
-                  }
-              }
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < AGG_U; u++) {
-        if (ib + u * 256 >= c1) break;  // wave-uniform: no row of this slice is live
-        const int64_t i = ii[u];
-        const bool live = rr[u] >= 0;
-        const int64_t r = live ? rr[u] : 0;
-        int ent = -1;   // LDS entry of this row's group
-        int gid = -1;   // global group id, only looked up for rows without an LDS entry
-        if (live) {
-            const unsigned long long *k = kk[u];
-            const unsigned nullmask = nmask[u];
-            int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
-            // same no-waiting-inside-a-branch protocol as the global table, on LDS
-            for (int probes = 0, spins = 0; probes < 16 && spins < (1 << 16);) {
-                int st = __hip_atomic_load(&l_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (st == L_EMPTY) {
-                    if (__hip_atomic_load(&s_nent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= T / 2) break;
-                    int old = atomicCAS(&l_state[idx], L_EMPTY, L_LOCKED);
-                    if (old == L_EMPTY) {
-                        atomicAdd(&s_nent, 1);
-                        for (int c = 0; c < nk; c++) l_key[c * T + idx] = k[c];
-                        __hip_atomic_store(&l_state[idx], (int)nullmask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        ent = idx;
-                        break;
-                    }
-                    spins++;  // someone else took it: look again
-                } else if (st == L_LOCKED) {
-                    spins++;
-                } else {
-                    bool eq = st == (int)nullmask;
-                    for (int c = 0; eq && c < nk; c++) eq = l_key[c * T + idx] == k[c];
-                    if (eq) { ent = idx; break; }
-                    idx = (idx + 1) & (T - 1);
-                    probes++;
-                }
-            }
-            if (ent < 0) gid = find_or_create(P, k, nullmask, keys_hash(k, nullmask, nk));
-        }
-        // (Summing a hot group's lanes across the wave with DPP adds before touching LDS was tried:
-        // with the table in LDS the same-address ds atomics of 4 hot groups cost 0.40 ms per 32 M
-        // rows, the combining code 0.62 ms. Rows update their LDS entry lane by lane.)
-        const bool staged = ent >= 0;
-        if (staged || gid >= 0) {
-            long long frow = (long long)(P.row_base + (P.sel ? r : i));  // row id (ascending with i)
-            // first-seen row: almost every row is later than the recorded one, so test with a load
-            // and only issue the atomic when it would lower the minimum
-            if (staged) { if (frow < l_first[ent]) atomicMin(&l_first[ent], frow); }
-            else if (frow < __hip_atomic_load(&P.first_row[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMin(&P.first_row[gid], frow);
-        }
-        // UpdateStates (aggregate_exec.go:456-475): NULL inputs are skipped (IgnoreNull)
-        for (int a = 0; a < na; a++) {
-            if (!((P.agg_mask >> a) & 1)) continue;  // wave-uniform
-            const int64_t st = (int64_t)gid * na + a;
-            const int ls = ent * na + a;
-            const int kind = P.agg_kind[a];
-            const bool is_sum = kind == PH_A_SUM || kind == PH_A_AVG;
-            bool valid = staged || gid >= 0;
-            long long v = 0;
-            if (kind != PH_A_COUNT_STAR && valid) {
-                const int ac = P.agg_arg[a];
-                if (ac < AGG_PRE) {  // read ahead of time
-                    valid = (pvalid[u] >> ac) & 1;
-#pragma unroll
-                    for (int c = 0; c < AGG_PRE; c++) if (c == ac) v = pv[u][c];
-                } else {
-                    const AggCol &c = P.arg[ac];
-                    int64_t ar = P.positional ? i : r;
-                    valid = bit_valid(c.validity, ar);
-                    if (valid) v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
-                }
-            }
-            // |v| < 2^40 keeps a workgroup's partial in int64 (the host caps a workgroup at 2^22 rows)
-            const bool small = v > -(1ll << 40) && v < (1ll << 40);
-            if (valid && staged && is_sum && !small) {
-                // too large for the bounded LDS partial: this one value goes to the global table
-                if (gid < 0) {
-                    unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
-                    for (int c = 0; c < nk; c++) k[c] = l_key[c * T + ent];
-                    unsigned nm = (unsigned)l_state[ent];
-                    gid = find_or_create(P, k, nm, keys_hash(k, nm, nk));
-                }
-                if (gid >= 0) {
-                    atomicAdd(&P.cnt[(int64_t)gid * na + a], 1ull);
-                    add128(&P.sum_lo[(int64_t)gid * na + a], &P.sum_hi[(int64_t)gid * na + a], v);
-                }
-            } else if (valid) {
-                if (kind == PH_A_COUNT_STAR || kind == PH_A_COUNT) {
-                    if (staged) atomicAdd(&l_cnt[ls], 1u);
-                    else atomicAdd(&P.cnt[st], 1ull);
-                } else if (is_sum) {
-                    if (staged) {
-                        atomicAdd(&l_sum[ls], (unsigned long long)v);
-                        atomicAdd(&l_cnt[ls], 1u);
-                    } else {
-                        atomicAdd(&P.cnt[st], 1ull);
-                        add128(&P.sum_lo[st], &P.sum_hi[st], v);
-                    }
-                } else if (kind == PH_A_MIN) {
-                    if (staged) { atomicMin((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
-                    else { atomicAdd(&P.cnt[st], 1ull); atomicMin((long long *)&P.sum_lo[st], v); }
-                } else if (kind == PH_A_MAX) {
-                    if (staged) { atomicMax((long long *)&l_sum[ls], v); atomicAdd(&l_cnt[ls], 1u); }
-                    else { atomicAdd(&P.cnt[st], 1ull); atomicMax((long long *)&P.sum_lo[st], v); }
-                }
-            }
-        }
-      }  // rows in flight
-    }
-    }  // chunk loop
-    if (threadIdx.x == 0) P.progress[blockIdx.x] = it;
-    // ---- flush: one find-or-create and one HBM update per state for every group this workgroup saw
-    __syncthreads();
-    for (int e = threadIdx.x; e < T; e += 256) {
-        int stt = l_state[e];
-        if (stt < 0) continue;
-        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
-        for (int c = 0; c < nk; c++) k[c] = l_key[c * T + e];
-        int gid = find_or_create(P, k, (unsigned)stt, keys_hash(k, (unsigned)stt, nk));
-        if (gid < 0) continue;
-        if (l_first[e] != INT64_MAX) atomicMin(&P.first_row[gid], l_first[e]);
-        for (int a = 0; a < na; a++) {
-            unsigned n = l_cnt[e * na + a];
-            if (n == 0) continue;
-            int64_t st = (int64_t)gid * na + a;
-            int kind = P.agg_kind[a];
-            atomicAdd(&P.cnt[st], (unsigned long long)n);
-            long long v = (long long)l_sum[e * na + a];
-            if (kind == PH_A_SUM || kind == PH_A_AVG) add128(&P.sum_lo[st], &P.sum_hi[st], v);
-            else if (kind == PH_A_MIN) atomicMin((long long *)&P.sum_lo[st], v);
-            else if (kind == PH_A_MAX) atomicMax((long long *)&P.sum_lo[st], v);
-        }
-    }
-}
+}  // namespace ph
+#include "agg_sink.inc"
+namespace ph {
 
 __global__ __launch_bounds__(256) void agg_init_kernel(unsigned long long *sum_lo, long long *sum_hi,
                                                        unsigned long long *cnt, long long *first_row,
@@ -445,7 +80,19 @@ __device__ unsigned long long wg_radix_select(const unsigned long long *keys, in
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     long long *wtot = reinterpret_cast<long long *>(s_state + 2);
     *all = false;
+    if (n < k) { *all = true; return ~0ull; }   // uniform over the workgroup
+    // bytes no key differs in need no pass: all keys would land in ONE histogram bin, i.e. n
+    // same-address LDS atomics (aggregate values rarely use the top bytes: 4 of 8 passes for Q3)
+    unsigned long long diff = 0;
+    const unsigned long long k0 = keys[0];
+    for (int i = threadIdx.x; i < n; i += 256) diff |= keys[i] ^ k0;
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
+    if (lane == 0) s_state[4 + wv] = diff;
+    __syncthreads();
+    diff = s_state[4] | s_state[5] | s_state[6] | s_state[7];
+    __syncthreads();
     for (int pass = 7; pass >= 0; pass--) {
+        if (((diff >> (8 * pass)) & 0xff) == 0) { prefix |= k0 & (0xffull << (8 * pass)); continue; }
         lh[threadIdx.x] = 0;
         __syncthreads();
         const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
@@ -1144,6 +791,71 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
 
 }  // namespace
 
+namespace {
+
+// ---- plan-specialised sink: the same device source (agg_sink.inc), compiled through hiprtc with
+// the sink's shape as compile-time constants. Key = everything the SK_* macros fold.
+std::string agg_spec_defines(const ph::AggSinkParams &P, std::string *key) {
+    std::ostringstream d, k;
+    auto list = [&](const char *name, int n, auto f) {
+        d << "#define " << name << " ";
+        for (int i = 0; i < n; i++) d << (i ? "," : "") << f(i);
+        if (n == 0) d << "0";
+        d << "\n";
+    };
+    d << "#define PH_SPEC 1\n#define SPEC_NK " << P.nkeys << "\n#define SPEC_NA " << P.naggs << "\n"
+      << "#define SPEC_HAS_SEL " << (P.sel ? 1 : 0) << "\n#define SPEC_POSITIONAL " << (P.positional ? 1 : 0) << "\n"
+      << "#define SPEC_AGG_MASK " << (P.agg_mask & ((1u << P.naggs) - 1u)) << "u\n#define SPEC_ARG_USED " << P.arg_used << "u\n";
+    list("SPEC_KINDS", P.naggs, [&](int i) { return P.agg_kind[i]; });
+    list("SPEC_ARGOFS", P.naggs, [&](int i) { return P.agg_kind[i] == PH_A_COUNT_STAR ? 0 : P.agg_arg[i]; });
+    list("SPEC_KEYTYPES", P.nkeys, [&](int i) { return P.key[i].type; });
+    list("SPEC_KEYNULLS", P.nkeys, [&](int i) { return P.key[i].validity ? 1 : 0; });
+    list("SPEC_ARGTYPES", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) ? P.arg[i].type : 0; });
+    list("SPEC_ARGNULLS", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) && P.arg[i].validity ? 1 : 0; });
+    *key = "aggsink:" + d.str();
+    return d.str();
+}
+
+// the specialised kernel of this sink shape, or PH_EUNSUPPORTED (no hiprtc, PH_AGG_JIT=0, compile trouble)
+int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, ph::JitKernel *out) {
+    const char *e = getenv("PH_AGG_JIT");   // read per call: tests compare both kernels in one process
+    if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
+    std::string key;
+    std::string src = agg_spec_defines(P, &key) + AGG_SINK_SRC;
+    int rc = ph::jit_module(ctx, key, src, "agg_sink_spec", out);
+    return rc == PH_OK ? PH_OK : PH_EUNSUPPORTED;
+}
+
+}  // namespace
+
+// Build check without a device: the sink source specialised for a Q9-like shape (two INTEGER keys,
+// SUM of a decimal, positional arguments) and a nullable two-aggregate shape compile for gfx950.
+extern "C" int ph_agg_jit_selfcheck(int32_t which) {
+    ph::AggSinkParams P{};
+    if (which == 0) {
+        P.nkeys = 2; P.naggs = 1; P.nargs = 1;
+        P.key[0].type = PH_I32; P.key[1].type = PH_I32;
+        P.arg[0].type = PH_DEC64;
+        P.agg_kind[0] = PH_A_SUM; P.agg_arg[0] = 0;
+        P.positional = 1; P.agg_mask = ~0u; P.arg_used = 1;
+    } else if (which == 1) {
+        static const uint8_t dummy = 0;
+        P.nkeys = 3; P.naggs = 4; P.nargs = 2;
+        P.key[0].type = PH_I64; P.key[1].type = PH_DATE; P.key[2].type = PH_CODE8; P.key[1].validity = &dummy;
+        P.arg[0].type = PH_I32; P.arg[1].type = PH_DEC64; P.arg[1].validity = &dummy;
+        P.agg_kind[0] = PH_A_MIN; P.agg_kind[1] = PH_A_AVG; P.agg_kind[2] = PH_A_COUNT_STAR; P.agg_kind[3] = PH_A_MAX;
+        P.agg_arg[0] = 0; P.agg_arg[1] = 1; P.agg_arg[2] = -1; P.agg_arg[3] = 1;
+        P.sel = reinterpret_cast<const int32_t *>(&dummy);
+        P.agg_mask = 0xb; P.arg_used = 3;
+    } else {
+        ph::set_error("ph_agg_jit_selfcheck: shapes 0..1");
+        return PH_EINVAL;
+    }
+    std::string key, log;
+    std::string src = agg_spec_defines(P, &key) + AGG_SINK_SRC;
+    return ph::jit_compile_only(src, "gfx950", &log);
+}
+
 extern "C" int ph_agg_sink(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs,
                            const int32_t *sel, int64_t n, int32_t positional, int64_t row_base) {
     return ph_agg_sink_masked(a, keys, args, nargs, sel, n, positional, row_base, 0xFFFFFFFFu);
@@ -1252,6 +964,10 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     // has to cross PCIe
     const bool sure = a->gcap - a->rows_sunk > n;
     if (sure) P.slack = -1;  // the in-kernel check can never be needed: switch it off
+    // sinks large enough to repay a one-time compile (~0.5 s per shape and process) run the kernel
+    // specialised for this shape; small ones, and everything when hiprtc is unavailable, the generic one
+    ph::JitKernel spec{};
+    const bool have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, P, &spec) == PH_OK;
     while (rc == PH_OK) {
         int64_t ng = a->rows_sunk;
         if (!sure) {
@@ -1264,8 +980,15 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
         P.mask = (uint64_t)a->cap - 1;
         P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
         P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
-        kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
-        if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
+        if (have_spec) {
+            ph::AggSinkParams copy = P;
+            size_t size = sizeof copy;
+            void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+            if (hipModuleLaunchKernel(spec.fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, a->ctx->stream, nullptr, config) != hipSuccess) { rc = PH_EHIP; break; }
+        } else {
+            kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
+            if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
+        }
         if (sure || a->gcap - ng - n > P.slack) break;  // even all-new groups cannot trip the check
         int grow = 0;
         if ((rc = a->ctx->download(&grow, a->counters + 2, 4)) != PH_OK || !grow) break;

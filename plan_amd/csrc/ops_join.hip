@@ -825,9 +825,8 @@ __global__ __launch_bounds__(256) void join_lookup_fast_kernel(const void *__res
         for (int u = 0; u < LU; u++) {
             uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[u]);
             if (NK == 2) hh = mix64(hh ^ k2[u]);
-            const bool maybe = ok[u] && bloom_maybe(bl, hh);
-            const int hb = head[hh & mask];
-            b[u] = maybe ? hb : -1;
+            const int hb = head[hh & mask];   // no bitmap test: a lookup expects its rows to match (foreign keys)
+            b[u] = ok[u] ? hb : -1;
         }
         bool more = false;
 #pragma unroll

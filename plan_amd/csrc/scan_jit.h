@@ -61,5 +61,8 @@ int jit_get(ph_ctx *ctx, const JitShape &s, JitKernel *out);
 // compile only (no device needed): status + log, for the CPU-side build check
 int jit_compile_check(const JitShape &s, const char *arch, std::string *log);
 int jit_launch(ph_ctx *ctx, const JitKernel &k, const JitParams &p, int grid);
+// generic: compile `src` for the ctx's device (cached by key for the process lifetime) and return `entry`
+int jit_module(ph_ctx *ctx, const std::string &key, const std::string &src, const char *entry, JitKernel *out);
+int jit_compile_only(const std::string &src, const char *arch, std::string *log);
 
 }  // namespace ph

@@ -92,3 +92,12 @@ def test_plan_specialised_kernels_generate_and_compile_for_gfx950():
     q1 = buf.value.decode()
     assert q1.count("__builtin_nontemporal_load") == 4 + 3 * 2   # 2 int32 + 2 byte columns, 3 int64 columns x 2
     assert lib.ph_scan_jit_selfcheck(9, None, 0) == hip.PH_EINVAL
+
+
+def test_specialised_aggregate_sink_source_compiles_for_gfx950():
+    """agg_sink.inc through hiprtc with a sink shape as compile-time constants (what ph_agg_sink
+    does for calls of >= 2^20 rows): both canned shapes compile for gfx950 without a device."""
+    lib = hip.lib()
+    for which in (0, 1):
+        assert lib.ph_agg_jit_selfcheck(which) == hip.PH_OK, lib.ph_last_error().decode()
+    assert lib.ph_agg_jit_selfcheck(7) == hip.PH_EINVAL

@@ -821,3 +821,53 @@ def test_join_lookup_matches_inner_probe_on_unique_keys(ctx):
     j.free()
     for c in (da, db, pa, pb):
         c.free()
+
+
+def test_specialised_sink_equals_generic_sink_and_numpy(ctx):
+    """ph_agg_sink calls of >= 2^20 rows run the hiprtc-specialised form of the sink kernel (same
+    source, the shape as constants): for several shapes — NULL-able keys and arguments, selections,
+    positional arguments, MIN/MAX/AVG/COUNT, low and high cardinality — its groups equal the generic
+    kernel's (PH_AGG_JIT=0) word for word, and the sums equal numpy's."""
+    import os
+    rng = np.random.default_rng(77)
+    n = (1 << 20) + 12345
+    shapes = [dict(card=4, nullable=False, sel=False), dict(card=175, nullable=True, sel=False),
+              dict(card=3000, nullable=False, sel=True), dict(card=400_000, nullable=True, sel=True)]
+    for sh in shapes:
+        k0 = rng.integers(0, sh["card"], n).astype(np.int32)
+        k1 = rng.integers(0, 3, n).astype(np.int64)
+        v0 = rng.integers(-10**6, 10**6, n).astype(np.int64)
+        v1 = rng.integers(0, 1000, n).astype(np.int32)
+        kvalid = rng.random(n) > 0.05 if sh["nullable"] else np.ones(n, bool)
+        vvalid = rng.random(n) > 0.1 if sh["nullable"] else np.ones(n, bool)
+        bits = lambda m: np.packbits(m, bitorder="little") if sh["nullable"] else None
+        d0 = hip.DevColumn(ctx, hip.PH_I32, k0, validity=bits(kvalid)); d1 = hip.DevColumn(ctx, hip.PH_I64, k1)
+        a0 = hip.DevColumn(ctx, hip.PH_DEC64, v0, 2, validity=bits(vvalid)); a1 = hip.DevColumn(ctx, hip.PH_I32, v1)
+        rows = np.sort(rng.choice(n, n - 1000, replace=False)).astype(np.int32) if sh["sel"] else None
+        dsel = ctx.upload(rows) if rows is not None else None
+        m = len(rows) if rows is not None else n
+        aggs = [(hip.PH_A_SUM, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 1), (hip.PH_A_AVG, 1), (hip.PH_A_COUNT_STAR, -1), (hip.PH_A_COUNT, 0)]
+        res = {}
+        for mode in ("1", "0"):
+            os.environ["PH_AGG_JIT"] = mode
+            agg = hip.Agg(ctx, [hip.PH_I32, hip.PH_I64], aggs, 1024)
+            agg.sink([d0, d1], [a0, a1], dsel, m)
+            r = agg.finalize(python_ints=False)
+            order = np.lexsort((r["keys"][:, 1], r["keys"][:, 0], r["key_null"][:, 0]))
+            res[mode] = {k: np.asarray(r[k])[order] for k in ("first_row", "keys", "key_null", "sum_lo", "sum_hi", "count")}
+            agg.free()
+        os.environ.pop("PH_AGG_JIT")
+        for k in res["1"]:
+            assert np.array_equal(res["1"][k], res["0"][k]), (sh, k)
+        # numpy: SUM(v0) and COUNT(*) per group over the sunk rows
+        sl = rows if rows is not None else np.arange(n)
+        key = np.where(kvalid[sl], k0[sl].astype(np.int64), -1) * 4 + k1[sl]
+        uk, inv = np.unique(key, return_inverse=True)
+        sums = np.zeros(len(uk), np.int64); np.add.at(sums, inv, np.where(vvalid[sl], v0[sl], 0))
+        cnts = np.bincount(inv)
+        got_key = np.where(res["1"]["key_null"][:, 0] == 1, -1, res["1"]["keys"][:, 0]) * 4 + res["1"]["keys"][:, 1]
+        o2 = np.argsort(got_key)
+        assert np.array_equal(got_key[o2], uk)
+        assert np.array_equal(res["1"]["sum_lo"][:, 0].view(np.int64)[o2], sums) and np.array_equal(res["1"]["count"][:, 4][o2], cnts)
+        for c in (d0, d1, a0, a1):
+            c.free()
