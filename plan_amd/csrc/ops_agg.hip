@@ -33,23 +33,6 @@ namespace ph {
 #include "agg_sink.inc"
 namespace ph {
 
-__global__ __launch_bounds__(256) void agg_init_kernel(unsigned long long *sum_lo, long long *sum_hi,
-                                                       unsigned long long *cnt, long long *first_row,
-                                                       int64_t g_begin, int64_t g_end, int naggs,
-                                                       const int *kinds /* device copy */) {
-    int64_t total = (g_end - g_begin) * naggs;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int64_t st = g_begin * naggs + i;
-        int kind = kinds[i % naggs];
-        sum_lo[st] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX
-                     : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
-        sum_hi[st] = 0;
-        cnt[st] = 0;
-    }
-    for (int64_t g = g_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; g < g_end; g += (int64_t)gridDim.x * 256)
-        first_row[g] = INT64_MAX;
-}
-
 // re-insert groups [0, ng) into a fresh slot table (Resize, aggregate_hash.go:440-513)
 __global__ __launch_bounds__(256) void agg_rehash_kernel(int32_t *slots, uint64_t mask,
                                                          const unsigned long long *gkeys, const unsigned *gnull,
@@ -521,7 +504,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             k[c] = l_key[c * T + e];
             __hip_atomic_store(&S.gkeys[(int64_t)gid * NK + c], k[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (nullmask) __hip_atomic_store(&S.gnull[gid], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&S.gnull[gid], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arrays are not pre-initialised
         S.first_row[gid] = l_first[e];
         for (int a = 0; a < na; a++) {
             const int kind = S.agg_kind[a];
@@ -616,7 +599,6 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
     PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&cnt));
     PH_CHECK(ctx->pool_alloc(gcap * 8, (void **)&first_row));
     PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
-    PH_HIP(hipMemsetAsync(gnull, 0, (size_t)gcap * 4, ctx->stream));
     if (ng > 0) {
         PH_HIP(hipMemcpyAsync(gkeys, a->gkeys, (size_t)ng * a->nkeys * 8, hipMemcpyDeviceToDevice, ctx->stream));
         PH_HIP(hipMemcpyAsync(gnull, a->gnull, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -625,9 +607,7 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
         PH_HIP(hipMemcpyAsync(cnt, a->cnt, (size_t)ng * na * 8, hipMemcpyDeviceToDevice, ctx->stream));
         PH_HIP(hipMemcpyAsync(first_row, a->first_row, (size_t)ng * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    int grid = (int)std::min<int64_t>(((gcap - ng) * (int64_t)na + 255) / 256 + 1, 2048);
-    ph::agg_init_kernel<<<grid, 256, 0, ctx->stream>>>(sum_lo, sum_hi, cnt, first_row, ng, gcap, a->naggs, a->kinds_dev);
-    PH_HIP(hipGetLastError());
+    // group state is initialised by whoever creates the group (find_or_create / the bulk build), not here
     if (ng > 0) {
         ph::agg_rehash_kernel<<<std::min((ng + 255) / 256, 2048), 256, 0, ctx->stream>>>(slots, (uint64_t)cap - 1, gkeys, gnull, a->nkeys, ng);
         PH_HIP(hipGetLastError());
@@ -671,8 +651,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
     if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 16, ctx->stream) != hipSuccess ||
-        ctx->pool_alloc(sizeof a->kinds_host, (void **)&a->kinds_dev) != PH_OK ||
-        hipMemcpyAsync(a->kinds_dev, kinds, sizeof a->kinds_host, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        false) {
         ph::set_error("ph_agg_create: device allocation failed");
         rc = PH_EHIP;
     }
