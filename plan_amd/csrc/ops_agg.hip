@@ -19,6 +19,7 @@
 // word plus a carry/sign add on the high word, which commutes, so any interleaving gives the exact sum.
 #include <algorithm>
 
+#include <chrono>
 #include <sstream>
 
 #include "agg_sink_src.h"
@@ -776,21 +777,20 @@ namespace {
 // the sink's shape as compile-time constants. Key = everything the SK_* macros fold.
 std::string agg_spec_defines(const ph::AggSinkParams &P, std::string *key) {
     std::ostringstream d, k;
-    auto list = [&](const char *name, int n, auto f) {
-        d << "#define " << name << " ";
-        for (int i = 0; i < n; i++) d << (i ? "," : "") << f(i);
-        if (n == 0) d << "0";
-        d << "\n";
+    auto list = [&](const char *name, int n, auto f) {   // #define name(i) ((i)==0?v0:(i)==1?v1:...:0)
+        d << "#define " << name << "(i) (";
+        for (int i = 0; i < n; i++) d << "(i)==" << i << "?" << f(i) << ":";
+        d << "0)\n";
     };
     d << "#define PH_SPEC 1\n#define SPEC_NK " << P.nkeys << "\n#define SPEC_NA " << P.naggs << "\n"
       << "#define SPEC_HAS_SEL " << (P.sel ? 1 : 0) << "\n#define SPEC_POSITIONAL " << (P.positional ? 1 : 0) << "\n"
       << "#define SPEC_AGG_MASK " << (P.agg_mask & ((1u << P.naggs) - 1u)) << "u\n#define SPEC_ARG_USED " << P.arg_used << "u\n";
-    list("SPEC_KINDS", P.naggs, [&](int i) { return P.agg_kind[i]; });
-    list("SPEC_ARGOFS", P.naggs, [&](int i) { return P.agg_kind[i] == PH_A_COUNT_STAR ? 0 : P.agg_arg[i]; });
-    list("SPEC_KEYTYPES", P.nkeys, [&](int i) { return P.key[i].type; });
-    list("SPEC_KEYNULLS", P.nkeys, [&](int i) { return P.key[i].validity ? 1 : 0; });
-    list("SPEC_ARGTYPES", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) ? P.arg[i].type : 0; });
-    list("SPEC_ARGNULLS", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) && P.arg[i].validity ? 1 : 0; });
+    list("SPEC_KIND_OF", P.naggs, [&](int i) { return P.agg_kind[i]; });
+    list("SPEC_ARG_OF", P.naggs, [&](int i) { return P.agg_kind[i] == PH_A_COUNT_STAR ? 0 : P.agg_arg[i]; });
+    list("SPEC_KEYTYPE_OF", P.nkeys, [&](int i) { return P.key[i].type; });
+    list("SPEC_KEYNULL_OF", P.nkeys, [&](int i) { return P.key[i].validity ? 1 : 0; });
+    list("SPEC_ARGTYPE_OF", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) ? P.arg[i].type : 0; });
+    list("SPEC_ARGNULL_OF", P.nargs, [&](int i) { return ((P.arg_used >> i) & 1) && P.arg[i].validity ? 1 : 0; });
     *key = "aggsink:" + d.str();
     return d.str();
 }
@@ -918,7 +918,18 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     int occ = 0;
     void (*kernel)(ph::AggSinkParams) = a->nkeys == 1 ? ph::agg_sink_kernel<1> : a->nkeys == 2 ? ph::agg_sink_kernel<2>
                                         : a->nkeys == 3 ? ph::agg_sink_kernel<3> : ph::agg_sink_kernel<4>;
-    PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds));
+    // sinks large enough to repay a one-time compile (~0.5 s per shape and process) run the kernel
+    // specialised for this shape; small ones, and everything when hiprtc is unavailable, the generic one
+    ph::JitKernel spec{};
+    bool have_spec = false;
+    {
+        ph::AggSinkParams Q = P;   // the shape is complete at this point (pointers do not enter the key)
+        for (int c = 0; c < nargs; c++) if (used[c]) Q.arg_used |= 1u << c;
+        have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, Q, &spec) == PH_OK;
+    }
+    if (have_spec) PH_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spec.fn, 256, lds));
+    else PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds));
+    const int occ_raw = occ;
     occ = std::max(1, std::min(occ, 4));
     // small inputs are latency bound (a new group costs a chain of dependent HBM atomics): give
     // every thread one row before giving any thread a second one
@@ -943,10 +954,11 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     // has to cross PCIe
     const bool sure = a->gcap - a->rows_sunk > n;
     if (sure) P.slack = -1;  // the in-kernel check can never be needed: switch it off
-    // sinks large enough to repay a one-time compile (~0.5 s per shape and process) run the kernel
-    // specialised for this shape; small ones, and everything when hiprtc is unavailable, the generic one
-    ph::JitKernel spec{};
-    const bool have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, P, &spec) == PH_OK;
+    static const bool timing = getenv("PH_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    const double t_b = now();
+    double t_c = 0, t_d = 0, t_e = 0;
     while (rc == PH_OK) {
         int64_t ng = a->rows_sunk;
         if (!sure) {
@@ -959,6 +971,9 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
         P.mask = (uint64_t)a->cap - 1;
         P.gkeys = a->gkeys; P.gnull = a->gnull; P.sum_lo = a->sum_lo; P.sum_hi = a->sum_hi;
         P.cnt = a->cnt; P.first_row = a->first_row; P.gcap = a->gcap;
+        t_c = now();
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (timing) { (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventRecord(ev0, a->ctx->stream); }
         if (have_spec) {
             ph::AggSinkParams copy = P;
             size_t size = sizeof copy;
@@ -968,11 +983,23 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
             kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
             if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
         }
+        if (timing) {
+            (void)hipEventRecord(ev1, a->ctx->stream);
+            (void)hipEventSynchronize(ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            fprintf(stderr, "[ph_agg_sink] kernel %.1f us by events (grid %d, lds %zu, chunk %d, occupancy %d)\n", ms * 1e3, grid, lds, chunk, occ_raw);
+            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        }
+        t_d = now();
         if (sure || a->gcap - ng - n > P.slack) break;  // even all-new groups cannot trip the check
         int grow = 0;
         if ((rc = a->ctx->download(&grow, a->counters + 2, 4)) != PH_OK || !grow) break;
         if (hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
     }
+    t_e = now();
+    if (timing) fprintf(stderr, "[ph_agg_sink] spec lookup %.0f us, resize/count %.0f us, launch %.0f us, after %.0f us (spec=%d sure=%d)\n",
+                        t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, (int)have_spec, (int)sure);
     a->ctx->pool_release(progress);
     if (rc == PH_EHIP) ph::set_error("ph_agg_sink: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
     if (rc != PH_OK) return rc;
