@@ -10,6 +10,7 @@
 // Probe output is deterministic: pairs ordered by probe position, then by chain order; a count
 // pass, a scan over workgroup totals and a write pass place them (no atomics on the output).
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "device_util.h"
@@ -258,6 +259,268 @@ __global__ __launch_bounds__(1024) void part_build_kernel(const int32_t *__restr
         for (int e = threadIdx.x; e < bloom_words; e += 1024) bl.bits[((uint64_t)p << bl.hi_shift) + e] = lbloom[e];
 }
 
+constexpr int JP_ROUNDS = 8;
+constexpr int JP_CHUNK = 256 * JP_ROUNDS;
+
+// ---- large build sides (no bitmap; > 4 M keys): the NODE TABLE.
+// The atomic build above issues one scattered device atomic per row (~20 G/s on this part: 15 M keys
+// 0.65 ms), and a chain step of a probe costs three dependent random reads (head, next, build key).
+// Here the build is partitioned by head slice like part_build_kernel, but the partition records ARE
+// the table: node p = {packed key, build row id, next node} (16 bytes, partition order), written by
+// the scatter pass, linked by ONE workgroup per 128 KiB head slice in LDS (ds atomics) which fills
+// the `next` fields of its own contiguous records and writes the head slice whole — no global
+// atomics, no scattered 4-byte stores (the per-row next[] of the small-table path is addressed by
+// original row position: 15 M scattered stores made part_build_kernel take 0.35 ms here). A probe's
+// chain step is head -> node: two random reads instead of three, the key compare needs no third.
+// Keys: one column (any integer width) or two 4-byte columns, packed into 64 bits.
+struct BigNode {
+    unsigned long long key;
+    int32_t row;    // build row id (sel applied)
+    int32_t next;   // next node of the bucket, -1 = end
+};
+
+constexpr int BG_SLICE_LOG = 15;               // head entries per partition: 32768 = 128 KiB of LDS
+constexpr int BG_SLICE = 1 << BG_SLICE_LOG;
+constexpr int BG_MAX_PARTS = 8192;
+
+template <int KW, int NK> __device__ __forceinline__ unsigned long long big_pack(unsigned long long a, unsigned long long b) {
+    return NK == 2 ? ((a << 32) | (b & 0xffffffffull)) : a;
+}
+__device__ __forceinline__ uint64_t big_hash(unsigned long long key) { return mix64(0x9e3779b97f4a7c15ULL ^ key); }
+
+// rows of one workgroup, PU at a time: packed key + validity (NULL keys never enter the table)
+template <int KW, int NK, bool SEL>
+__device__ __forceinline__ void big_keys(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1, const int32_t *sel,
+                                         int64_t base, int64_t i1, unsigned long long (&key)[PU], int32_t (&row)[PU], bool (&ok)[PU]) {
+    int64_t r[PU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        ok[u] = i < i1;
+        const int64_t ic = ok[u] ? i : i1 - 1;
+        r[u] = SEL ? (int64_t)sel[ic] : ic;
+        row[u] = (int32_t)r[u];
+    }
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const unsigned long long a = load_kw<KW>(k0, r[u]);
+        const unsigned long long b = NK == 2 ? load_kw<KW>(k1, r[u]) : 0ull;
+        key[u] = big_pack<KW, NK>(a, b);
+        if (v0) ok[u] = ok[u] && bit_valid(v0, r[u]);
+        if (NK == 2 && v1) ok[u] = ok[u] && bit_valid(v1, r[u]);
+    }
+}
+
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(256) void big_count_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
+                                                        const int32_t *sel, int64_t n, uint64_t mask, int nparts, int64_t rows_per_wg,
+                                                        int32_t *__restrict__ counts) {
+    extern __shared__ int hist[];
+    for (int e = threadIdx.x; e < nparts; e += 256) hist[e] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
+    for (int64_t base = i0; base < i1; base += 256 * PU) {
+        unsigned long long key[PU];
+        int32_t row[PU];
+        bool ok[PU];
+        big_keys<KW, NK, SEL>(k0, k1, v0, v1, sel, base, i1, key, row, ok);
+#pragma unroll
+        for (int u = 0; u < PU; u++)
+            if (ok[u]) atomicAdd(&hist[(big_hash(key[u]) & mask) >> BG_SLICE_LOG], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nparts; e += 256) counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
+}
+
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(256) void big_scatter_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
+                                                          const int32_t *sel, int64_t n, uint64_t mask, int nparts, int64_t rows_per_wg,
+                                                          const int32_t *__restrict__ offsets, BigNode *__restrict__ nodes) {
+    extern __shared__ int cursor[];
+    for (int e = threadIdx.x; e < nparts; e += 256) cursor[e] = offsets[(int64_t)e * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
+    for (int64_t base = i0; base < i1; base += 256 * PU) {
+        unsigned long long key[PU];
+        int32_t row[PU];
+        bool ok[PU];
+        big_keys<KW, NK, SEL>(k0, k1, v0, v1, sel, base, i1, key, row, ok);
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if (!ok[u]) continue;
+            const int pos = atomicAdd(&cursor[(big_hash(key[u]) & mask) >> BG_SLICE_LOG], 1);
+            BigNode nd;
+            nd.key = key[u]; nd.row = row[u]; nd.next = -1;
+            nodes[pos] = nd;   // one 16-byte store; a workgroup's records of a partition are contiguous
+        }
+    }
+}
+
+// one workgroup per head slice: links the partition's (contiguous) nodes in LDS, writes head + next
+__global__ __launch_bounds__(1024) void big_build_kernel(const int32_t *__restrict__ offsets, int nwg, int nparts,
+                                                         const int64_t *__restrict__ total, BigNode *__restrict__ nodes,
+                                                         int32_t *__restrict__ head) {
+    extern __shared__ int lhead[];
+    for (int e = threadIdx.x; e < BG_SLICE; e += 1024) lhead[e] = -1;
+    __syncthreads();
+    const int p = blockIdx.x;
+    const int64_t b0 = offsets[(int64_t)p * nwg];
+    const int64_t b1 = p + 1 < nparts ? (int64_t)offsets[(int64_t)(p + 1) * nwg] : *total;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 1024) {
+        const unsigned long long key = nodes[i].key;
+        nodes[i].next = atomicExch(&lhead[big_hash(key) & (BG_SLICE - 1)], (int)i);   // head insertion, as everywhere
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < BG_SLICE; e += 1024) head[(int64_t)p * BG_SLICE + e] = lhead[e];
+}
+
+// probe side of the node table. BU probes per lane issue their key reads, then their head reads,
+// then walk their chains together (every chain step is ONE 16-byte node read).
+constexpr int BU = 4;
+
+// MODE 0: lookup (out[i] = last matching build row or -1; stats: misses, multi-matches)
+// MODE 1: count pass of the inner probe (ccnt[i] = matches, saturating at 65535; cmatch[i] = a
+//         matching build row; block_counts[blk] = matches of the 2048-row block)
+// MODE 2: mark (found[i] = 0 / 1)
+template <int KW, int NK, bool SELP, int MODE>
+__global__ __launch_bounds__(256) void big_probe_kernel(const void *__restrict__ pk0, const void *__restrict__ pk1,
+                                                        const uint8_t *__restrict__ pv0, const uint8_t *__restrict__ pv1,
+                                                        const int32_t *__restrict__ psel, int64_t n,
+                                                        const int32_t *__restrict__ head, uint64_t mask,
+                                                        const BigNode *__restrict__ nodes, int32_t *__restrict__ out,
+                                                        uint16_t *__restrict__ ccnt, int32_t *__restrict__ block_counts,
+                                                        uint8_t *__restrict__ found, int *__restrict__ stats) {
+    static_assert(JP_CHUNK == 256 * 2 * BU, "a workgroup iteration covers half a block");
+    int misses = 0, multi = 0;
+    __shared__ int s_tot[4];
+    // MODE 1 runs one workgroup per 2048-row block (its total is a plain store); the others grid-stride
+    const int64_t step = MODE == 1 ? (int64_t)gridDim.x * JP_CHUNK : (int64_t)gridDim.x * 256 * BU;
+    for (int64_t base0 = (int64_t)blockIdx.x * (MODE == 1 ? JP_CHUNK : 256 * BU); base0 < n; base0 += step) {
+        int blocktotal = 0;
+        for (int half = 0; half < (MODE == 1 ? 2 : 1); half++) {
+            const int64_t base = base0 + half * 256 * BU;
+            int64_t i[BU], r[BU];
+            bool ok[BU];
+            unsigned long long k[BU];
+            int b[BU], c[BU];
+            int32_t hit[BU];
+#pragma unroll
+            for (int u = 0; u < BU; u++) {
+                i[u] = base + u * 256 + threadIdx.x;
+                ok[u] = i[u] < n;
+                r[u] = ok[u] ? i[u] : 0;
+                c[u] = 0;
+                hit[u] = -1;
+            }
+            if (SELP) {
+#pragma unroll
+                for (int u = 0; u < BU; u++) r[u] = psel[r[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < BU; u++) {
+                const unsigned long long a = load_kw<KW>(pk0, r[u]);
+                const unsigned long long bb = NK == 2 ? load_kw<KW>(pk1, r[u]) : 0ull;
+                k[u] = big_pack<KW, NK>(a, bb);
+                if (pv0) ok[u] = ok[u] && bit_valid(pv0, r[u]);      // NULL keys never match
+                if (NK == 2 && pv1) ok[u] = ok[u] && bit_valid(pv1, r[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BU; u++) {
+                const int hb = head[big_hash(k[u]) & mask];
+                b[u] = ok[u] ? hb : -1;
+            }
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < BU; u++) more = more || b[u] >= 0;
+            while (more) {
+                BigNode nd[BU];
+#pragma unroll
+                for (int u = 0; u < BU; u++) nd[u] = nodes[b[u] >= 0 ? b[u] : 0];
+                more = false;
+#pragma unroll
+                for (int u = 0; u < BU; u++) {
+                    if (b[u] >= 0) {
+                        if (nd[u].key == k[u]) { c[u]++; hit[u] = nd[u].row; }
+                        b[u] = nd[u].next;
+                    }
+                    more = more || b[u] >= 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BU; u++) {
+                if (i[u] >= n) continue;
+                if (MODE == 0) { out[i[u]] = hit[u]; misses += c[u] == 0; multi += c[u] > 1; }
+                else if (MODE == 1) { ccnt[i[u]] = (uint16_t)(c[u] > 65535 ? 65535 : c[u]); out[i[u]] = hit[u]; blocktotal += c[u]; }
+                else found[i[u]] = c[u] > 0 ? 1 : 0;
+            }
+        }
+        if (MODE == 1) {
+            for (int o = 32; o > 0; o >>= 1) blocktotal += __shfl_xor(blocktotal, o);
+            if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = blocktotal;
+            __syncthreads();
+            if (threadIdx.x == 0) block_counts[base0 / JP_CHUNK] = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            __syncthreads();
+        }
+    }
+    if (MODE == 0) {
+        for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (misses) atomicAdd(stats, misses);
+            if (multi) atomicAdd(stats + 1, multi);
+        }
+    }
+}
+
+// emit pass of the inner probe: one wave per 2048-row block, pairs ordered by probe position then
+// chain order; single matches come from the count pass, multi-matches walk their chain again
+template <int KW, int NK, bool SELP>
+__global__ __launch_bounds__(256) void big_emit_kernel(const void *__restrict__ pk0, const void *__restrict__ pk1,
+                                                       const int32_t *__restrict__ psel, int64_t n,
+                                                       const int32_t *__restrict__ head, uint64_t mask,
+                                                       const BigNode *__restrict__ nodes, const uint16_t *__restrict__ ccnt,
+                                                       const int32_t *__restrict__ cmatch, const int32_t *__restrict__ block_off,
+                                                       int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
+                                                       int32_t *__restrict__ out_build) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        int64_t running = block_off[blk];
+        const int64_t i0 = blk * JP_CHUNK, i1 = i0 + JP_CHUNK < n ? i0 + JP_CHUNK : n;
+        for (int64_t t0 = i0; t0 < i1; t0 += 64) {
+            const int64_t i = t0 + lane;
+            int c = i < i1 ? (int)ccnt[i] : 0;
+            const int64_t r = i < i1 ? (SELP ? (int64_t)psel[i] : i) : 0;
+            unsigned long long key = 0;
+            if (c > 1) {   // rare: walk the chain again (also recounts a saturated counter)
+                const unsigned long long a = load_kw<KW>(pk0, r);
+                const unsigned long long bb = NK == 2 ? load_kw<KW>(pk1, r) : 0ull;
+                key = big_pack<KW, NK>(a, bb);
+                if (c == 65535) {
+                    c = 0;
+                    for (int b = head[big_hash(key) & mask]; b >= 0; b = nodes[b].next) c += nodes[b].key == key;
+                }
+            }
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (c == 1) {
+                const int64_t pos = running + incl - 1;
+                if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = cmatch[i]; }
+            } else if (c > 1) {
+                int64_t pos = running + incl - c;
+                for (int b = head[big_hash(key) & mask]; b >= 0; b = nodes[b].next)
+                    if (nodes[b].key == key) {
+                        if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = nodes[b].row; }
+                        pos++;
+                    }
+            }
+            running += __shfl(incl, 63);
+        }
+    }
+}
+
 __device__ __forceinline__ bool keys_equal(const JoinSide &B, int64_t brow, const unsigned long long *k) {
     for (int c = 0; c < B.nkeys; c++)
         if (jkey(B.key[c], brow) != k[c]) return false;
@@ -288,8 +551,6 @@ __device__ __forceinline__ bool range_pred(const RangePred &W, int64_t r) {
     return v >= W.lo && v <= W.hi;
 }
 
-constexpr int JP_ROUNDS = 8;
-constexpr int JP_CHUNK = 256 * JP_ROUNDS;
 
 // ---- selective probes (a Bloom bitmap exists). In the two-pass kernels above a lane that has to
 // walk a chain (three or four dependent random reads) holds up its wave while the other lanes
@@ -931,6 +1192,8 @@ struct ph_join {
     int64_t count = 0;       // -1 = not fetched from count_dev yet
     int *count_dev = nullptr;
     ph::Bloom bloom{};
+    ph::BigNode *nodes = nullptr;   // node table (large build sides): replaces next[]
+    int big_kw = 0, big_nk = 0;     // key width / count of the node table's packed key
 };
 
 extern "C" void ph_join_free(ph_join *j) {
@@ -941,6 +1204,7 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->bloom.bits) j->ctx->pool_release(j->bloom.bits);
     if (j->bloom.coarse) j->ctx->pool_release(j->bloom.coarse);
     if (j->count_dev) j->ctx->pool_release(j->count_dev);
+    if (j->nodes) j->ctx->pool_release(j->nodes);
     delete j;
 }
 
@@ -959,6 +1223,103 @@ static int fill_side(ph::JoinSide *S, const ph_col *keys, int32_t nkeys, const i
     return PH_OK;
 }
 
+// node-table build: count -> scan -> scatter (records = nodes) -> link per 128 KiB head slice
+static int build_big(ph_join *j, int kw, int nparts) {
+    ph_ctx *ctx = j->ctx;
+    const ph::JoinSide &B = j->build;
+    const int64_t n = B.n;
+    j->big_kw = kw;
+    j->big_nk = B.nkeys;
+    // 256-thread workgroups, a multiple of the CU count; long runs per (workgroup, partition) keep
+    // the scatter's 16-byte stores in whole lines
+    const int nwg = (int)std::min<int64_t>(ctx->cu_count * 2, std::max<int64_t>(1, n / 4096));
+    const int64_t rows_per_wg = ph::round_up((n + nwg - 1) / nwg, 1024);
+    const int nwg_used = (int)((n + rows_per_wg - 1) / rows_per_wg);
+    const int64_t nc = (int64_t)nparts * nwg_used;
+    int32_t *counts = nullptr;
+    PH_CHECK(ctx->pool_alloc(nc * 4, (void **)&counts));
+    if (ctx->pool_alloc(std::max<int64_t>(n, 1) * (int64_t)sizeof(ph::BigNode), (void **)&j->nodes) != PH_OK ||
+        ctx->pool_alloc(16, (void **)&j->count_dev) != PH_OK) { ctx->pool_release(counts); return PH_EHIP; }
+    const uint64_t mask = (uint64_t)j->cap - 1;
+    const size_t hl = (size_t)nparts * 4;
+    int rc = PH_OK;
+#define PH_BIG_ARGS B.key[0].data, B.key[1].data, B.key[0].validity, B.key[1].validity, B.sel, n, mask, nparts, rows_per_wg
+#define PH_BIG_BUILD(KWV, NKV, SELV)                                                                               \
+    do {                                                                                                           \
+        ph::big_count_kernel<KWV, NKV, SELV><<<nwg_used, 256, hl, ctx->stream>>>(PH_BIG_ARGS, counts);             \
+        rc = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)j->count_dev);                                     \
+        ph::big_scatter_kernel<KWV, NKV, SELV><<<nwg_used, 256, hl, ctx->stream>>>(PH_BIG_ARGS, counts, j->nodes); \
+    } while (0)
+    if (B.nkeys == 2) { if (B.sel) PH_BIG_BUILD(4, 2, true); else PH_BIG_BUILD(4, 2, false); }
+    else if (kw == 4) { if (B.sel) PH_BIG_BUILD(4, 1, true); else PH_BIG_BUILD(4, 1, false); }
+    else { if (B.sel) PH_BIG_BUILD(8, 1, true); else PH_BIG_BUILD(8, 1, false); }
+#undef PH_BIG_BUILD
+#undef PH_BIG_ARGS
+    static std::mutex mu;
+    static bool raised[64] = {};
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!raised[ctx->device & 63]) {   // 128 KiB head slice: above the default dynamic LDS limit
+            if (hipFuncSetAttribute((const void *)ph::big_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) rc = PH_EHIP;
+            raised[ctx->device & 63] = true;
+        }
+    }
+    if (rc == PH_OK) {
+        ph::big_build_kernel<<<nparts, 1024, (size_t)ph::BG_SLICE * 4, ctx->stream>>>(counts, nwg_used, nparts, (const int64_t *)j->count_dev,
+                                                                                   j->nodes, j->head);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    ctx->pool_release(counts);
+    if (rc != PH_OK) ph::set_error("ph_join_build: node-table build failed");
+    return rc;
+}
+
+// probe-side shape check of a node table: same packing as the build side, no other key shape
+static bool big_probe_ok(const ph_join *j, const ph::JoinSide &P) {
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+    if (P.nkeys != j->big_nk) return false;
+    for (int c = 0; c < P.nkeys; c++) if (width(P.key[c].type) != j->big_kw) return false;
+    return true;
+}
+
+template <int MODE>
+static void launch_big_probe(ph_join *j, const ph::JoinSide &P, int64_t n, int grid, int32_t *out, uint16_t *ccnt, int32_t *block_counts,
+                             uint8_t *found, int *stats) {
+    hipStream_t st = j->ctx->stream;
+    const uint64_t mask = (uint64_t)j->cap - 1;
+#define PH_BP_ARGS P.key[0].data, P.key[1].data, P.key[0].validity, P.key[1].validity, P.sel, n, j->head, mask, j->nodes, out, ccnt, block_counts, found, stats
+    if (j->big_nk == 2) { if (P.sel) ph::big_probe_kernel<4, 2, true, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); else ph::big_probe_kernel<4, 2, false, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); }
+    else if (j->big_kw == 4) { if (P.sel) ph::big_probe_kernel<4, 1, true, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); else ph::big_probe_kernel<4, 1, false, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); }
+    else { if (P.sel) ph::big_probe_kernel<8, 1, true, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); else ph::big_probe_kernel<8, 1, false, MODE><<<grid, 256, 0, st>>>(PH_BP_ARGS); }
+#undef PH_BP_ARGS
+}
+
+static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,
+                           int64_t *n_out) {
+    ph_ctx *ctx = j->ctx;
+    const int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
+    const int64_t o_total = ph::round_up(nb * 4, 8), o_ccnt = o_total + 64, o_cmatch = ph::round_up(o_ccnt + nb * ph::JP_CHUNK * 2, 8);
+    PH_CHECK(ctx->ensure_scratch(o_cmatch + nb * ph::JP_CHUNK * 4));
+    int32_t *counts = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + o_total);
+    uint16_t *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
+    int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
+    launch_big_probe<1>(j, P, n, (int)std::min<int64_t>(nb, (int64_t)ctx->cu_count * 16), cmatch, ccnt, counts, nullptr, nullptr);
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
+    const uint64_t mask = (uint64_t)j->cap - 1;
+#define PH_BE_ARGS P.key[0].data, P.key[1].data, P.sel, n, j->head, mask, j->nodes, ccnt, cmatch, counts, nb, cap, out_probe_dev, out_build_dev
+    if (j->big_nk == 2) { if (P.sel) ph::big_emit_kernel<4, 2, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); else ph::big_emit_kernel<4, 2, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); }
+    else if (j->big_kw == 4) { if (P.sel) ph::big_emit_kernel<4, 1, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); else ph::big_emit_kernel<4, 1, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); }
+    else { if (P.sel) ph::big_emit_kernel<8, 1, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); else ph::big_emit_kernel<8, 1, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); }
+#undef PH_BE_ARGS
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ctx->download(n_out, total, 8));
+    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
+    return PH_OK;
+}
+
 extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
                              ph_join **out) {
     PH_REQUIRE(ctx && keys && out && nkeys >= 1 && nkeys <= ph::JOIN_MAX_KEYS && n >= 0 && n < (1ll << 31),
@@ -973,6 +1334,22 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     j->cap = cap;
     auto fail = [&](const char *what) { ph::set_error("ph_join_build: %s failed", what); ph_join_free(j); return PH_EHIP; };
     if (ctx->pool_alloc(cap * 4, (void **)&j->head) != PH_OK) return fail("alloc(head)");
+    {   // large build sides with a packable key: the node table (see BigNode)
+        const char *bm = getenv("PH_JOIN_BIG_MIN");   // read per call: the tests lower it to cover this path at small sizes
+        const int64_t big_min = bm ? atoll(bm) : (4ll << 20) + 1;
+        auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+        const ph::JoinSide &Bs = j->build;
+        const int kw = width(Bs.key[0].type);
+        const bool packable = (Bs.nkeys == 1 && kw != 1) || (Bs.nkeys == 2 && kw == 4 && width(Bs.key[1].type) == 4);
+        const int bparts = (int)(cap >> ph::BG_SLICE_LOG);
+        if (n >= big_min && packable && bparts >= 2 && bparts <= ph::BG_MAX_PARTS) {
+            int rcb = build_big(j, kw, bparts);
+            if (rcb != PH_OK) { ph_join_free(j); return rcb; }
+            j->count = -1;
+            *out = j;
+            return PH_OK;
+        }
+    }
     if (ctx->pool_alloc(std::max<int64_t>(n, 1) * 4, (void **)&j->next) != PH_OK) return fail("alloc(next)");
     if (sel && n > 0) {  // keep our own copy: the table outlives the caller's selection buffer
         if (ctx->pool_alloc(n * 4, (void **)&j->sel_copy) != PH_OK) return fail("alloc(sel)");
@@ -983,7 +1360,8 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     static const bool no_part = getenv("PH_JOIN_ATOMIC_BUILD") != nullptr;
     // only where the atomic build needs two atomics per row (a bitmap is built): without one it runs
     // at ~21 G rows/s, faster than the three passes of the partitioned build (~12 G rows/s)
-    const bool partitioned = !no_part && n >= (128 << 10) && n <= (4ll << 20) && nparts >= 2 && nparts <= ph::PB_MAX_PARTS;
+    static const int64_t part_max = getenv("PH_JOIN_PART_MAX") ? atoll(getenv("PH_JOIN_PART_MAX")) : (4ll << 20);
+    const bool partitioned = !no_part && n >= (128 << 10) && n <= part_max && nparts >= 2 && nparts <= ph::PB_MAX_PARTS;
     int64_t bits = 0;
     if (n > 0 && n <= (4ll << 20)) {  // bitmap of >= 16 bits per key, at most 16 MiB
         bits = 1 << 16;
@@ -1129,6 +1507,10 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     *n_out = 0;
     if (n == 0 || j->build.n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
+    if (j->nodes) {
+        if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
+        return big_probe_inner(j, P, n, out_probe_dev, out_build_dev, cap, n_out);
+    }
     int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
     const bool selective = j->bloom.bits != nullptr;  // candidate lists pay off when most probes miss
     const int64_t o_ccount = ph::round_up(nb * 4, 8) + 64;
@@ -1166,6 +1548,12 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
     if (n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
     if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    if (j->nodes) {
+        if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_mark: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
+        launch_big_probe<2>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), nullptr, nullptr, nullptr, found_dev, nullptr);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
     const uint64_t mask = (uint64_t)j->cap - 1;
     if (j->bloom.bits) {
         // selective probe: same candidate slices + chain pass as ph_join_probe_inner (a lane that
@@ -1225,6 +1613,16 @@ extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel
     if (!stats) {   // the kernel always counts; without a caller buffer the counts are dropped
         PH_CHECK(ctx->pool_alloc(8, (void **)&scratch));
         stats = scratch;
+    }
+    if (j->nodes) {
+        int rcb = PH_OK;
+        if (!big_probe_ok(j, P)) { ph::set_error("ph_join_lookup: probe key shape differs from the node table's"); rcb = PH_EUNSUPPORTED; }
+        else {
+            launch_big_probe<0>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), out_build_dev, nullptr, nullptr, nullptr, stats);
+            if (hipGetLastError() != hipSuccess) { ph::set_error("ph_join_lookup: kernel launch failed"); rcb = PH_EHIP; }
+        }
+        if (scratch) ctx->pool_release(scratch);
+        return rcb;
     }
     const ph::JoinSide &B = j->build;
     const uint64_t mask = (uint64_t)j->cap - 1;

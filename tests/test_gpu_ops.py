@@ -871,3 +871,58 @@ def test_specialised_sink_equals_generic_sink_and_numpy(ctx):
         assert np.array_equal(res["1"]["sum_lo"][:, 0].view(np.int64)[o2], sums) and np.array_equal(res["1"]["count"][:, 4][o2], cnts)
         for c in (d0, d1, a0, a1):
             c.free()
+
+
+def test_node_table_join_matches_chained_table(ctx):
+    """Large build sides (> 4 M keys) use the node table (partitioned build, 16-byte nodes). With
+    PH_JOIN_BIG_MIN lowered the same joins run through both table forms: inner pairs (duplicate
+    build keys, misses, selections on both sides, NULL keys), marks and lookups must be identical
+    sets — and equal to numpy for the single-key case. One 8-byte key, one 4-byte key, two 4-byte keys."""
+    import os
+    rng = np.random.default_rng(2024)
+    nb, npr = 300_000, 700_000
+    cases = []
+    k8 = rng.integers(0, 400_000, nb).astype(np.int64)
+    cases.append(([(hip.PH_I64, k8)], [(hip.PH_I64, rng.integers(0, 450_000, npr).astype(np.int64))]))
+    k4 = rng.integers(0, 400_000, nb).astype(np.int32)
+    cases.append(([(hip.PH_I32, k4)], [(hip.PH_I32, rng.integers(0, 450_000, npr).astype(np.int32))]))
+    a, b = rng.integers(0, 2000, nb).astype(np.int32), rng.integers(0, 300, nb).astype(np.int32)
+    cases.append(([(hip.PH_I32, a), (hip.PH_I32, b)],
+                  [(hip.PH_I32, rng.integers(0, 2100, npr).astype(np.int32)), (hip.PH_I32, rng.integers(0, 310, npr).astype(np.int32))]))
+    bvalid = rng.random(nb) > 0.03
+    pvalid = rng.random(npr) > 0.03
+    bsel = np.sort(rng.choice(nb, nb * 2 // 3, replace=False)).astype(np.int32)
+    psel = np.sort(rng.choice(npr, npr // 2, replace=False)).astype(np.int32)
+    for bcols, pcols in cases:
+        for nullable, use_sel in ((False, False), (True, True)):
+            bdev = [hip.DevColumn(ctx, t, v, validity=np.packbits(bvalid, bitorder="little") if nullable else None) for t, v in bcols]
+            pdev = [hip.DevColumn(ctx, t, v, validity=np.packbits(pvalid, bitorder="little") if nullable else None) for t, v in pcols]
+            bs = ctx.upload(bsel) if use_sel else None
+            ps = ctx.upload(psel) if use_sel else None
+            nbb, npp = (len(bsel), len(psel)) if use_sel else (nb, npr)
+            res = {}
+            for mode in ("1000", "1000000000"):     # node table / chained table
+                os.environ["PH_JOIN_BIG_MIN"] = mode
+                j = hip.Join(ctx, bdev, bs, nbb)
+                cnt = j.count()
+                m, op, ob = j.probe_inner(pdev, ps, npp, npp * 4)
+                pairs = np.stack([ctx.download(op, np.int32, m), ctx.download(ob, np.int32, m)], 1)
+                assert np.all(np.diff(pairs[:, 0]) >= 0)                       # ordered by probe row
+                mark = ctx.download(j.probe_mark(pdev, ps, npp), np.uint8, npp)
+                stats = ctx.upload(np.zeros(2, np.int32))
+                look = ctx.download(j.lookup(pdev, ps, npp, stats), np.int32, npp)
+                st = ctx.download(stats, np.int32, 2).tolist()
+                res[mode] = (cnt, set(map(tuple, pairs.tolist())), mark, look >= 0, st)
+                j.free()
+            os.environ.pop("PH_JOIN_BIG_MIN")
+            big, old = res["1000"], res["1000000000"]
+            assert big[0] == old[0] and big[1] == old[1] and np.array_equal(big[2], old[2])
+            assert np.array_equal(big[3], old[3]) and big[4] == old[4]
+            assert np.array_equal(big[2].astype(bool), big[3]) and len(big[1]) > 1000
+            if len(bcols) == 1 and not nullable:       # independent check against numpy
+                bk, pk = bcols[0][1], pcols[0][1]
+                assert np.array_equal(big[2].astype(bool), np.isin(pk, bk))
+                uk, cnts = np.unique(bk, return_counts=True)
+                assert len(big[1]) == int(cnts[np.searchsorted(uk, pk[np.isin(pk, bk)])].sum())
+            for c in bdev + pdev:
+                c.free()
