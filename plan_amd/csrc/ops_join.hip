@@ -288,6 +288,8 @@ template <int KW, int NK> __device__ __forceinline__ unsigned long long big_pack
 }
 __device__ __forceinline__ uint64_t big_hash(unsigned long long key) { return mix64(0x9e3779b97f4a7c15ULL ^ key); }
 
+constexpr int BG_T = 1024;   // threads of a partition-pass workgroup: one workgroup per CU, 16 waves in flight
+
 // rows of one workgroup, PU at a time: packed key + validity (NULL keys never enter the table)
 template <int KW, int NK, bool SEL>
 __device__ __forceinline__ void big_keys(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1, const int32_t *sel,
@@ -295,7 +297,7 @@ __device__ __forceinline__ void big_keys(const void *k0, const void *k1, const u
     int64_t r[PU];
 #pragma unroll
     for (int u = 0; u < PU; u++) {
-        const int64_t i = base + u * 256 + threadIdx.x;
+        const int64_t i = base + u * BG_T + threadIdx.x;
         ok[u] = i < i1;
         const int64_t ic = ok[u] ? i : i1 - 1;
         r[u] = SEL ? (int64_t)sel[ic] : ic;
@@ -312,14 +314,14 @@ __device__ __forceinline__ void big_keys(const void *k0, const void *k1, const u
 }
 
 template <int KW, int NK, bool SEL>
-__global__ __launch_bounds__(256) void big_count_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
+__global__ __launch_bounds__(BG_T) void big_count_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
                                                         const int32_t *sel, int64_t n, uint64_t mask, int nparts, int64_t rows_per_wg,
                                                         int32_t *__restrict__ counts) {
     extern __shared__ int hist[];
-    for (int e = threadIdx.x; e < nparts; e += 256) hist[e] = 0;
+    for (int e = threadIdx.x; e < nparts; e += BG_T) hist[e] = 0;
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
-    for (int64_t base = i0; base < i1; base += 256 * PU) {
+    for (int64_t base = i0; base < i1; base += BG_T * PU) {
         unsigned long long key[PU];
         int32_t row[PU];
         bool ok[PU];
@@ -329,18 +331,18 @@ __global__ __launch_bounds__(256) void big_count_kernel(const void *k0, const vo
             if (ok[u]) atomicAdd(&hist[(big_hash(key[u]) & mask) >> BG_SLICE_LOG], 1);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nparts; e += 256) counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
+    for (int e = threadIdx.x; e < nparts; e += BG_T) counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
 }
 
 template <int KW, int NK, bool SEL>
-__global__ __launch_bounds__(256) void big_scatter_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
+__global__ __launch_bounds__(BG_T) void big_scatter_kernel(const void *k0, const void *k1, const uint8_t *v0, const uint8_t *v1,
                                                           const int32_t *sel, int64_t n, uint64_t mask, int nparts, int64_t rows_per_wg,
                                                           const int32_t *__restrict__ offsets, BigNode *__restrict__ nodes) {
     extern __shared__ int cursor[];
-    for (int e = threadIdx.x; e < nparts; e += 256) cursor[e] = offsets[(int64_t)e * gridDim.x + blockIdx.x];
+    for (int e = threadIdx.x; e < nparts; e += BG_T) cursor[e] = offsets[(int64_t)e * gridDim.x + blockIdx.x];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg, i1 = i0 + rows_per_wg < n ? i0 + rows_per_wg : n;
-    for (int64_t base = i0; base < i1; base += 256 * PU) {
+    for (int64_t base = i0; base < i1; base += BG_T * PU) {
         unsigned long long key[PU];
         int32_t row[PU];
         bool ok[PU];
@@ -1232,8 +1234,10 @@ static int build_big(ph_join *j, int kw, int nparts) {
     j->big_nk = B.nkeys;
     // 256-thread workgroups, a multiple of the CU count; long runs per (workgroup, partition) keep
     // the scatter's 16-byte stores in whole lines
-    const int nwg = (int)std::min<int64_t>(ctx->cu_count * 2, std::max<int64_t>(1, n / 4096));
-    const int64_t rows_per_wg = ph::round_up((n + nwg - 1) / nwg, 1024);
+    // one 1024-thread workgroup per CU: with 1024 partitions a (workgroup, partition) run is ~57 nodes
+    // = 0.9 KiB of consecutive 16-byte stores (whole lines except at the two ends)
+    const int nwg = (int)std::min<int64_t>(ctx->cu_count, std::max<int64_t>(1, n / 4096));
+    const int64_t rows_per_wg = ph::round_up((n + nwg - 1) / nwg, ph::BG_T * ph::PU);
     const int nwg_used = (int)((n + rows_per_wg - 1) / rows_per_wg);
     const int64_t nc = (int64_t)nparts * nwg_used;
     int32_t *counts = nullptr;
@@ -1246,9 +1250,9 @@ static int build_big(ph_join *j, int kw, int nparts) {
 #define PH_BIG_ARGS B.key[0].data, B.key[1].data, B.key[0].validity, B.key[1].validity, B.sel, n, mask, nparts, rows_per_wg
 #define PH_BIG_BUILD(KWV, NKV, SELV)                                                                               \
     do {                                                                                                           \
-        ph::big_count_kernel<KWV, NKV, SELV><<<nwg_used, 256, hl, ctx->stream>>>(PH_BIG_ARGS, counts);             \
+        ph::big_count_kernel<KWV, NKV, SELV><<<nwg_used, ph::BG_T, hl, ctx->stream>>>(PH_BIG_ARGS, counts);             \
         rc = ph::exclusive_scan_i32(ctx, counts, nc, (int64_t *)j->count_dev);                                     \
-        ph::big_scatter_kernel<KWV, NKV, SELV><<<nwg_used, 256, hl, ctx->stream>>>(PH_BIG_ARGS, counts, j->nodes); \
+        ph::big_scatter_kernel<KWV, NKV, SELV><<<nwg_used, ph::BG_T, hl, ctx->stream>>>(PH_BIG_ARGS, counts, j->nodes); \
     } while (0)
     if (B.nkeys == 2) { if (B.sel) PH_BIG_BUILD(4, 2, true); else PH_BIG_BUILD(4, 2, false); }
     else if (kw == 4) { if (B.sel) PH_BIG_BUILD(4, 1, true); else PH_BIG_BUILD(4, 1, false); }
