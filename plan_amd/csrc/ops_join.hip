@@ -126,6 +126,15 @@ template <int KW> __device__ __forceinline__ unsigned long long load_kw(const vo
            : KW == 1 ? (unsigned long long)((const uint8_t *)col)[r] : ((const unsigned long long *)col)[r];
 }
 
+// streaming form: the probe columns are read once, front to back; marking the loads non-temporal
+// keeps them from evicting the Bloom bitmap (4 MiB for Q3's 1.46 M order keys: the size of one
+// XCD's L2) that every surviving row reads at random
+template <int KW> __device__ __forceinline__ unsigned long long load_kw_nt(const void *col, int64_t r) {
+    return KW == 4 ? (unsigned long long)(long long)__builtin_nontemporal_load((const int32_t *)col + r)
+           : KW == 1 ? (unsigned long long)__builtin_nontemporal_load((const uint8_t *)col + r)
+                     : __builtin_nontemporal_load((const unsigned long long *)col + r);
+}
+
 // Straight-line forms of the two partition passes for the common build shape (one or two key
 // columns of one width, no NULL keys): PU rows per thread, their selection / key reads issued
 // together (the generic kernels below pay two or three dependent memory latencies per row).
@@ -646,8 +655,11 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
         long long w[JP_ROUNDS];
 #pragma unroll
         for (int rr = 0; rr < JP_ROUNDS; rr++)
-            w[rr] = WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
-                    : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]];
+            w[rr] = SEL ? (WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
+                           : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]])
+                        : (WK == 1 ? (long long)__builtin_nontemporal_load((const int32_t *)wdata + r[rr])
+                           : WK == 2 ? (long long)__builtin_nontemporal_load((const int64_t *)wdata + r[rr])
+                                     : (long long)__builtin_nontemporal_load((const uint8_t *)wdata + r[rr]));
 #pragma unroll
         for (int rr = 0; rr < JP_ROUNDS; rr++) {
             ok[rr] = ok[rr] && w[rr] >= wlo && w[rr] <= whi;
@@ -657,8 +669,8 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
     unsigned long long k[JP_ROUNDS], k2[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        k[rr] = load_kw<KW>(keycol, r[rr]);
-        k2[rr] = NK == 2 ? load_kw<KW>(keycol2, r[rr]) : 0ull;
+        k[rr] = SEL ? load_kw<KW>(keycol, r[rr]) : load_kw_nt<KW>(keycol, r[rr]);
+        k2[rr] = NK == 2 ? (SEL ? load_kw<KW>(keycol2, r[rr]) : load_kw_nt<KW>(keycol2, r[rr])) : 0ull;
     }
     unsigned word[JP_ROUNDS], msk[JP_ROUNDS];
 #pragma unroll
