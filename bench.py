@@ -43,9 +43,9 @@ XGMI_PEAK_GBS = 7 * 153.0  # per GPU, all 7 links busy (MI355X_MICROARCH.md)
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_summary.json, newest
-    round first: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py; KiB units,
-    FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM). Valid for the SF10 one-GPU workload
-    those passes ran; the caller passes None otherwise."""
+    round first: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py,
+    scripts/pmc_r2.sh; KiB units, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM). Valid for
+    the SF10 one-GPU workload those passes ran; the caller passes None otherwise."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
@@ -354,7 +354,11 @@ def bench_q3(h, sf, steps, warmup, scaling):
             "top1": list(r["top"][0]) if r["top"] else None,
         },
         "roofline": roofline(probe_bytes / (probe_ms * 1e-3) / 1e9,
-                             traffic=pmc_traffic(("q3", "join_cand_fast_kernel")) if (h.world == 1 and nrows == 59986052) else None,
+                             traffic=pmc_traffic(("q3", "join_cand_fast_kernel<8")) if (h.world == 1 and nrows == 59986052) else None,
+                             traffic_note="PMC traffic of join_cand_fast_kernel<8,...> (the stage's dominant kernel: 166 of ~250 us); "
+                                          "traffic_stage_kernels has the stage's other kernels",
+                             traffic_stage_kernels=({k: pmc_traffic(("q3", k)) for k in ("join_chain_fast_kernel<8", "join_emit_kernel")}
+                                                    if (h.world == 1 and nrows == 59986052) else None),
                              kernel="join_cand_fast_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
                              avg_launch_ms=probe_ms, algorithmic_bytes_per_launch=probe_bytes,
                              timing="HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
