@@ -177,6 +177,11 @@ int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *p
                  int32_t nprog, const int32_t *sel, int64_t n, int64_t *out_dev,
                  uint8_t *out_validity_dev);
 
+/* Build check without a device of the generated expression kernels (ph_expr_eval compiles the RPN
+ * of batches >= 2^18 rows into straight-line code with hiprtc, cached per expression shape;
+ * PH_EXPR_JIT=0 keeps the interpreter): canned shape `which` (0..2) compiles for gfx950. */
+int ph_expr_jit_selfcheck(int32_t which);
+
 /* extract(year|month|day from date) — ExtractFunc (pkg/compute/function_scalar.go:1509-1563) over a
  * PH_DATE column: out_dev[i] (int32) for row sel[i] (or i). */
 typedef enum { PH_PART_YEAR = 1, PH_PART_MONTH = 2, PH_PART_DAY = 3 } ph_datepart;

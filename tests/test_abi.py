@@ -101,3 +101,10 @@ def test_specialised_aggregate_sink_source_compiles_for_gfx950():
     for which in (0, 1):
         assert lib.ph_agg_jit_selfcheck(which) == hip.PH_OK, lib.ph_last_error().decode()
     assert lib.ph_agg_jit_selfcheck(7) == hip.PH_EINVAL
+
+
+def test_generated_expression_kernels_compile_for_gfx950():
+    lib = hip.lib()
+    for which in range(3):
+        assert lib.ph_expr_jit_selfcheck(which) == hip.PH_OK, lib.ph_last_error().decode()
+    assert lib.ph_expr_jit_selfcheck(5) == hip.PH_EINVAL

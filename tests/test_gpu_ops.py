@@ -926,3 +926,47 @@ def test_node_table_join_matches_chained_table(ctx):
                 assert len(big[1]) == int(cnts[np.searchsorted(uk, pk[np.isin(pk, bk)])].sum())
             for c in bdev + pdev:
                 c.free()
+
+
+def test_generated_expression_kernel_equals_interpreter(ctx):
+    """ph_expr_eval batches of >= 2^18 rows run a kernel generated from the RPN (hiprtc); its values,
+    result validity and overflow refusal must equal the interpreting kernel's (PH_EXPR_JIT=0), whose
+    decimal semantics test_expr_eval_matches_decimal_semantics pins to the oracle."""
+    import os
+    rng = np.random.default_rng(31)
+    n = (1 << 18) + 777
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    b = rng.integers(0, 11, n).astype(np.int64)
+    q = rng.integers(1, 51, n).astype(np.int32)
+    va, vb = rng.random(n) > 0.05, rng.random(n) > 0.05
+    sel = np.sort(rng.choice(n, n - 5000, replace=False)).astype(np.int32)
+    progs = [[hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL],                       # a * (1 - b)
+             [hip.X_COL(0), hip.X_COL(1), hip.X_COL(2), hip.X_MUL, hip.X_SUB],                          # a - b * q
+             [hip.X_COL(0), hip.X_CONST(25, 1), hip.X_ADD, hip.X_COL(2), hip.X_MUL, hip.X_COL(1), hip.X_ADD]]
+    for nullable in (False, True):
+        bits = lambda m: np.packbits(m, bitorder="little") if nullable else None
+        cols = [hip.DevColumn(ctx, hip.PH_DEC64, a, 2, validity=bits(va)), hip.DevColumn(ctx, hip.PH_DEC64, b, 2, validity=bits(vb)),
+                hip.DevColumn(ctx, hip.PH_I32, q)]
+        for prog in progs:
+            for s, m in ((None, n), (ctx.upload(sel), len(sel))):
+                got = {}
+                for mode in ("1", "0"):
+                    os.environ["PH_EXPR_JIT"] = mode
+                    out, val = hip.expr_eval(ctx, cols, prog, s, m, want_validity=nullable)
+                    got[mode] = (ctx.download(out, np.int64, m), ctx.download(val, np.uint8, (m + 7) // 8) if nullable else None)
+                    ctx.free(out)
+                os.environ.pop("PH_EXPR_JIT")
+                assert np.array_equal(got["1"][0], got["0"][0])
+                if nullable:
+                    assert np.array_equal(got["1"][1], got["0"][1]) and got["1"][1].sum() > 0
+        for c in cols:
+            c.free()
+    # a product that leaves int64 is refused by both kernels
+    big = hip.DevColumn(ctx, hip.PH_DEC64, np.full(n, 4 * 10**9, np.int64), 2)
+    for mode in ("1", "0"):
+        os.environ["PH_EXPR_JIT"] = mode
+        with pytest.raises(hip.PlanHipError) as e:
+            hip.expr_eval(ctx, [big], [hip.X_COL(0), hip.X_COL(0), hip.X_MUL, hip.X_COL(0), hip.X_MUL], None, n)
+        assert e.value.code == hip.PH_EOVERFLOW
+    os.environ.pop("PH_EXPR_JIT")
+    big.free()
