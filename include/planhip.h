@@ -316,6 +316,12 @@ int ph_cross_pairs(ph_ctx *ctx, int64_t n_left, int64_t n_right, int32_t *out_le
  * TupleDataTemplatedGather join_collection.go:501-529) */
 int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev, int64_t n, void *out_dev);
 
+/* the same for up to 8 columns through one row-id array, in one pass: the late materialisation of a
+ * join chain's probe side (all column reads of a row are in flight together, the index is read
+ * once). out_dev[c]: n elements of column c's width. */
+int ph_gather_multi(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n,
+                    void *const *out_dev);
+
 /* ------------------------------------------------------------------ fused pipelines
  * The measured mode: Agg <- Scan(filter) collapsed into one pass over the resident table, which
  * is what `gpuScanAggExecutor` calls when the sub-plan matches. */

@@ -750,6 +750,74 @@ extern "C" int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev,
     return PH_OK;
 }
 
+// Several columns through ONE row-id array in one pass (late materialisation of a join chain's probe
+// side: Q9 needs six lineitem columns at the rows that survived the first join). A gather is two
+// dependent memory latencies per element; one launch per column pays them once per column, here
+// the index read is shared and every column's value read of a row is in flight together.
+namespace ph {
+constexpr int GM_MAX = 8;
+struct GatherMulti {
+    const void *src[GM_MAX];
+    void *dst[GM_MAX];
+    int width[GM_MAX];
+    int ncols;
+};
+
+__global__ __launch_bounds__(256) void gather_multi_kernel(GatherMulti G, const int32_t *__restrict__ idx, int64_t n) {
+    constexpr int U = 2;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U; base < n; base += (int64_t)gridDim.x * 256 * U) {
+        int32_t ix[U];
+        unsigned long long v[U][GM_MAX];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            ix[u] = idx[i < n ? i : 0];
+        }
+#pragma unroll
+        for (int c = 0; c < GM_MAX; c++) {
+            if (c >= G.ncols) break;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                v[u][c] = G.width[c] == 8 ? ((const unsigned long long *)G.src[c])[ix[u]]
+                          : G.width[c] == 4 ? (unsigned long long)((const uint32_t *)G.src[c])[ix[u]]
+                                            : (unsigned long long)((const uint8_t *)G.src[c])[ix[u]];
+        }
+#pragma unroll
+        for (int c = 0; c < GM_MAX; c++) {
+            if (c >= G.ncols) break;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + u * 256 + threadIdx.x;
+                if (i >= n) continue;
+                if (G.width[c] == 8) ((unsigned long long *)G.dst[c])[i] = v[u][c];
+                else if (G.width[c] == 4) ((uint32_t *)G.dst[c])[i] = (uint32_t)v[u][c];
+                else ((uint8_t *)G.dst[c])[i] = (uint8_t)v[u][c];
+            }
+        }
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_gather_multi(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n,
+                               void *const *out_dev) {
+    PH_REQUIRE(ctx && ncols >= 1 && ncols <= ph::GM_MAX && cols && out_dev && (n == 0 || idx_dev),
+               "ph_gather_multi: bad arguments (1..%d columns)", ph::GM_MAX);
+    if (n == 0) return PH_OK;
+    ph::GatherMulti G{};
+    G.ncols = ncols;
+    for (int c = 0; c < ncols; c++) {
+        G.width[c] = ph::type_width(cols[c].type);
+        if (G.width[c] == 0) { ph::set_error("ph_gather_multi: column %d (type %d) is not fixed width", c, cols[c].type); return PH_EUNSUPPORTED; }
+        PH_REQUIRE(cols[c].data && out_dev[c], "ph_gather_multi: column %d has a NULL pointer", c);
+        G.src[c] = cols[c].data;
+        G.dst[c] = out_dev[c];
+    }
+    int grid = (int)std::min<int64_t>((n + 511) / 512, 256 * 16);
+    ph::gather_multi_kernel<<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 // ------------------------------------------------------------------ partition (multi-GPU shuffle prep)
 // dest = mix64(key) % nparts. Three kernels: per-workgroup histogram (LDS atomics), exclusive scan
 // over [part][block], scatter of row ids. No reference counterpart.

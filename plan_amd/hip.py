@@ -568,6 +568,17 @@ def gather(ctx, col, idx_dev, n):
     return out
 
 
+def gather_multi(ctx, cols, idx_dev, n):
+    """ph_gather_multi: several columns through one row-id array in one pass -> list of device pointers"""
+    cs = [c.col() if isinstance(c, DevColumn) else c for c in cols]
+    w = [{PH_CODE8: 1, PH_I32: 4, PH_DATE: 4, PH_F32: 4}.get(c.type, 8) for c in cs]
+    outs = [ctx.alloc(max(n, 1) * wi) for wi in w]
+    arr = (Col * len(cs))(*cs)
+    po = (vp * len(cs))(*[vp(o.value) for o in outs])
+    check(lib().ph_gather_multi(ctx.h, i32(len(cs)), arr, idx_dev, i64(n), po))
+    return outs
+
+
 def partition(ctx, key, sel, n, nparts):
     c = key.col() if isinstance(key, DevColumn) else key
     counts = (i64 * nparts)()

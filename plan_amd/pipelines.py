@@ -340,14 +340,20 @@ class Q9Pipeline:
             bc, _ = bcast(self.ps_cost, fsel, fn, np.int64)
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, nb)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
+        # LATE MATERIALISATION, ONCE: the six lineitem columns the rest of the query needs are fetched
+        # at the surviving rows in one pass (ph_gather_multi: every column read of a row in flight
+        # together; one launch per column — or a selection inside every later kernel — paid the two
+        # dependent latencies of a gather per column). From here on the intermediate is positional
+        # and dense: the per-join materialisation of Scan.gatherResult (join_scan.go:250-278), done once.
+        d_part, d_supp, c_okey, d_ext, d_disc, d_qty = hip.gather_multi(
+            ctx, [self.l_part, self.l_supp, self.l_key, self.l_ext, self.l_disc, self.l_qty], lrow, n1)
+        frees += [d_part, d_supp, c_okey, d_ext, d_disc, d_qty]
         # The two joins below are N:1 (partsupp's composite primary key, supplier's key): LOOKUP
-        # probes addressed through the SAME lineitem row ids (late materialisation) — one kernel each,
-        # no key gathers, no candidate/scan/emit pipeline, no re-gather of the earlier row-id arrays
-        # (the per-join materialisation of Scan.gatherResult, join_scan.go:250-278, done once instead).
+        # probes — one kernel each, no candidate/scan/emit pipeline, no re-gather of earlier columns.
         stats = ctx.alloc(8)
         frees.append(stats)
         hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
-        psrow = jps.lookup([self.l_part, self.l_supp], lrow, n1, stats)
+        psrow = jps.lookup([_raw(hip.PH_I32, d_part), _raw(hip.PH_I32, d_supp)], None, n1, stats)
         jps.free()
         frees.append(psrow)
         stage("partsupp_join", t0)
@@ -363,7 +369,7 @@ class Q9Pipeline:
             sn, _ = bcast(self.s_nat, ident, self.n["s"], np.int32)
             js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk)
             s_nat = _raw(hip.PH_I32, sn)
-        srow = js.lookup([self.l_supp], lrow, n1, stats)
+        srow = js.lookup([_raw(hip.PH_I32, d_supp)], None, n1, stats)
         frees.append(srow)
         js.free()
         # one read for both joins: rows without a match (none in TPC-H: foreign keys) would have to
@@ -371,29 +377,26 @@ class Q9Pipeline:
         misses, multi = ctx.download(stats, np.int32, 2).tolist()
         if multi:
             raise hip.PlanHipError(hip.PH_EUNSUPPORTED, "Q9: partsupp / supplier keys are not unique; use probe_inner")
-        lrow3, psrow3, n3 = lrow, psrow, n1
+        n3 = n1
         if misses:   # inner-join semantics: keep the positions both lookups resolved
             okp, c1 = hip.filter_select(ctx, _raw(hip.PH_I32, psrow), n1, hip.PH_GE, hip.const(hip.PH_I32, i=0))
             ok2, n3 = hip.filter_select(ctx, _raw(hip.PH_I32, srow), n1, hip.PH_GE, hip.const(hip.PH_I32, i=0), okp, c1)
             frees += [okp, ok2]
-            lrow3, psrow3, srow = gat(_raw(hip.PH_I32, lrow), ok2, n3), gat(_raw(hip.PH_I32, psrow), ok2, n3), gat(_raw(hip.PH_I32, srow), ok2, n3)
+            psrow, srow = gat(_raw(hip.PH_I32, psrow), ok2, n3), gat(_raw(hip.PH_I32, srow), ok2, n3)
+            c_okey, d_ext, d_disc, d_qty = hip.gather_multi(
+                ctx, [_raw(hip.PH_I64, c_okey), _raw(hip.PH_DEC64, d_ext, 2), _raw(hip.PH_DEC64, d_disc, 2), _raw(hip.PH_I32, d_qty)], ok2, n3)
+            frees += [c_okey, d_ext, d_disc, d_qty]
         stage("supplier_join", t0)
 
-        # ---- columns of the surviving lineitem rows (positional from here on)
+        # ---- the profit expression, positional: l_extendedprice * (1 - l_discount) - ps_supplycost *
+        # l_quantity in ONE program (scale 4), evaluated before the orders join so that the join (and,
+        # on several GPUs, the exchange) carries one 8-byte amount instead of four columns
         t0 = tic()
-        c_okey = gat(self.l_key, lrow3, n3)
-        # The profit expression needs only lineitem and partsupp columns, so it is evaluated HERE,
-        # before the orders join: ext*(1-disc) straight from the base columns through the row ids
-        # (no gather), then minus cost*qty. The orders join then carries one 8-byte amount instead
-        # of four columns (fewer gathers on one GPU, half the exchange volume on several); the
-        # arithmetic, its scales and its overflow checks are those of the one-step program.
-        rev_a, _va = hip.expr_eval(ctx, [self.l_ext, self.l_disc],
-                                   [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL], lrow3, n3)
-        c_qty, c_cost = gat(self.l_qty, lrow3, n3), gat(ps_cost, psrow3, n3)
-        c_amount, _vb = hip.expr_eval(ctx, [_raw(hip.PH_DEC64, rev_a, 4), _raw(hip.PH_DEC64, c_cost, 2), _raw(hip.PH_I32, c_qty)],
-                                      [hip.X_COL(0), hip.X_COL(1), hip.X_COL(2), hip.X_MUL, hip.X_SUB], None, n3)
-        frees += [rev_a, c_amount]
-        c_nat = gat(s_nat, srow, n3)
+        c_cost, c_nat = gat(ps_cost, psrow, n3), gat(s_nat, srow, n3)
+        c_amount, _vb = hip.expr_eval(ctx, [_raw(hip.PH_DEC64, d_ext, 2), _raw(hip.PH_DEC64, d_disc, 2), _raw(hip.PH_DEC64, c_cost, 2), _raw(hip.PH_I32, d_qty)],
+                                      [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL,
+                                       hip.X_COL(2), hip.X_COL(3), hip.X_MUL, hip.X_SUB], None, n3)
+        frees.append(c_amount)
         if N == 1:
             jo = None    # built below on this rank's orders
             o_date = self.o_date.col()

@@ -970,3 +970,26 @@ def test_generated_expression_kernel_equals_interpreter(ctx):
         assert e.value.code == hip.PH_EOVERFLOW
     os.environ.pop("PH_EXPR_JIT")
     big.free()
+
+
+def test_gather_multi_equals_per_column_gathers(ctx):
+    """ph_gather_multi (several columns through one row-id array in one pass) against numpy, for
+    1-, 4- and 8-byte columns, 1..8 columns, ragged sizes."""
+    rng = np.random.default_rng(8)
+    nsrc = 123_457
+    srcs = [(hip.PH_CODE8, rng.integers(0, 200, nsrc).astype(np.uint8)), (hip.PH_I32, rng.integers(-9, 9**9, nsrc).astype(np.int32)),
+            (hip.PH_I64, rng.integers(-9**15, 9**15, nsrc).astype(np.int64)), (hip.PH_DATE, rng.integers(0, 20000, nsrc).astype(np.int32)),
+            (hip.PH_DEC64, rng.integers(0, 10**12, nsrc).astype(np.int64)), (hip.PH_I32, rng.integers(0, 50, nsrc).astype(np.int32)),
+            (hip.PH_I64, rng.integers(0, 9, nsrc).astype(np.int64)), (hip.PH_CODE8, rng.integers(0, 3, nsrc).astype(np.uint8))]
+    dev = [hip.DevColumn(ctx, t, v) for t, v in srcs]
+    for n in (0, 1, 511, 512, 70_001):
+        idx = rng.integers(0, nsrc, max(n, 1)).astype(np.int32)
+        didx = ctx.upload(idx)
+        for k in (1, 3, 8):
+            outs = hip.gather_multi(ctx, dev[:k], didx, n)
+            for (t, v), o in zip(srcs[:k], outs):
+                assert np.array_equal(ctx.download(o, v.dtype, n), v[idx[:n]])
+                ctx.free(o)
+        ctx.free(didx)
+    for c in dev:
+        c.free()
