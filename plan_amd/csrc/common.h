@@ -76,6 +76,11 @@ struct ph_ctx {
     // caller memory makes the runtime pin/unpin those pages on every call (milliseconds when the
     // caller's buffers come and go, as numpy / Go-heap buffers do).
     void *mailbox = nullptr;  // 64 KiB pinned, for counts / flags / small results
+    // single-pass scan (ops_select.hip): tile states + ticket counter, reused across calls by epoch
+    void *scan_state = nullptr;
+    int64_t scan_tiles = 0;
+    unsigned scan_ticket_base = 0;
+    unsigned long long scan_epoch = 0;
     int download(void *host, const void *dev, int64_t bytes);
     // Stream-ordered device memory pool: freed blocks are reused by later allocations of the
     // same rounded size without hipFree/hipMalloc (both synchronise the device). Safe because

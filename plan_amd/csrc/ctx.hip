@@ -174,6 +174,7 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

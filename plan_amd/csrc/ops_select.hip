@@ -531,6 +531,77 @@ __global__ __launch_bounds__(1024) void scan_add_kernel(int32_t *__restrict__ v,
         if (base + j < n) v[base + j] += add;
 }
 
+// Single-pass form (decoupled look-back): ONE launch for any n. A workgroup takes the next tile
+// from a ticket counter (tiles start in order, so a tile only ever waits for tiles already running),
+// scans its 4096 elements, publishes its aggregate, walks back over the predecessors' published
+// aggregates / inclusive prefixes, publishes its own inclusive prefix and writes its elements.
+// The tile states live in a per-context buffer that is never cleared: every entry carries the
+// epoch of the call that wrote it ((epoch << 34) | (flag << 32) | value), stale entries read as
+// "not yet published", and the ticket counter keeps counting across calls (the host passes its
+// base). A scan of Q3's 29 k candidate-block counts was three launches (tile sums, their scan,
+// add-back: ~15 us); row counts stay below 2^31, so 32 value bits are enough.
+constexpr unsigned long long SC_AGG = 1ull, SC_INCL = 2ull;
+
+__global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ state,
+                                                             unsigned *__restrict__ ticket, unsigned ticket_base,
+                                                             unsigned long long epoch, int64_t *__restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ unsigned s_tile;
+    __shared__ long long s_prefix;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * 4;
+    int x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = base + j < n ? v[base + j] : 0;
+    const int mine = x[0] + x[1] + x[2] + x[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int off = incl - mine, agg = 0;
+    for (int k = 0; k < 16; k++) {
+        if (k < w) off += wsum[k];
+        agg += wsum[k];
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long tag = epoch << 34;
+        long long prefix = 0;
+        if (tile == 0) {
+            __hip_atomic_store(&state[0], tag | (SC_INCL << 32) | (unsigned)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&state[tile], tag | (SC_AGG << 32) | (unsigned)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            for (long long p = (long long)tile - 1; p >= 0;) {
+                const unsigned long long st = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long flag = (st >> 32) & 3ull;
+                if ((st >> 34) != epoch || flag == 0) {          // not published in this call yet: look again
+                    if (++spins > (1u << 27)) break;             // never reached in practice: every wave must terminate
+                    continue;
+                }
+                prefix += (long long)(unsigned)st;
+                if (flag == SC_INCL) break;
+                p--;
+            }
+            __hip_atomic_store(&state[tile], tag | (SC_INCL << 32) | (unsigned)(prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_prefix = prefix;
+        if ((int64_t)(tile + 1) * SCAN_TILE >= n) *total = prefix + agg;   // the last tile
+    }
+    __syncthreads();
+    off += (int)s_prefix;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j < n) v[base + j] = off;
+        off += x[j];
+    }
+}
+
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev) {
     if (n <= 4 * SCAN_TILE) {
         scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
@@ -538,6 +609,24 @@ int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev)
         return PH_OK;
     }
     const int64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+    static const bool three_pass = getenv("PH_SCAN_THREE_PASS") != nullptr;
+    if (!three_pass && nt < (1ll << 31)) {
+        if (nt > ctx->scan_tiles) {   // (re)allocate the state buffer: zero = epoch 0, which no call uses
+            if (ctx->scan_state) { PH_HIP(hipStreamSynchronize(ctx->stream)); PH_HIP(hipFree(ctx->scan_state)); ctx->scan_state = nullptr; }
+            const int64_t cap = std::max<int64_t>(nt * 2, 4096);
+            PH_HIP(hipMalloc(&ctx->scan_state, (size_t)cap * 8 + 64));
+            PH_HIP(hipMemsetAsync(ctx->scan_state, 0, (size_t)cap * 8 + 64, ctx->stream));
+            ctx->scan_tiles = cap;
+            ctx->scan_ticket_base = 0;
+        }
+        unsigned long long *state = (unsigned long long *)ctx->scan_state;
+        unsigned *ticket = (unsigned *)(state + ctx->scan_tiles);
+        ctx->scan_epoch = (ctx->scan_epoch % ((1ull << 30) - 1)) + 1;   // 1 .. 2^30-1, never 0
+        scan_lookback_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, state, ticket, ctx->scan_ticket_base, ctx->scan_epoch, total_dev);
+        PH_HIP(hipGetLastError());
+        ctx->scan_ticket_base += (unsigned)nt;   // wraps like the device counter
+        return PH_OK;
+    }
     int32_t *tiles = nullptr;
     PH_CHECK(ctx->pool_alloc(nt * 4, (void **)&tiles));
     scan_tile_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, tiles);

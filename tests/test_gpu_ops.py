@@ -993,3 +993,20 @@ def test_gather_multi_equals_per_column_gathers(ctx):
         ctx.free(didx)
     for c in dev:
         c.free()
+
+
+def test_single_pass_scan_through_large_selections(ctx):
+    """The decoupled look-back scan (one launch, tile states reused across calls by epoch) places
+    the rows of every count/scan/write operator: filter selections far beyond 4 x 4096 blocks must
+    stay exact and ordered over many consecutive calls of different sizes on one context."""
+    rng = np.random.default_rng(12)
+    for n in (40_000_000, 17_000_001, 40_000_000, 9_999_999, 33_333_333):
+        v = rng.integers(0, 100, n).astype(np.int32)
+        d = hip.DevColumn(ctx, hip.PH_I32, v)
+        for thr in (1, 37, 99):
+            sel, cnt = hip.filter_select(ctx, d, n, hip.PH_LT, hip.const(hip.PH_I32, i=thr))
+            want = np.nonzero(v < thr)[0]
+            got = ctx.download(sel, np.int32, cnt)
+            assert cnt == len(want) and np.array_equal(got, want.astype(np.int32))
+            ctx.free(sel)
+        d.free()
