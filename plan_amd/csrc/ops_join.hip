@@ -698,67 +698,6 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
 }
 
-// Streaming form for probes without a selection: persistent workgroups (a few per CU) walk the
-// 2048-row blocks and keep the NEXT block's filter-column and key reads in flight while the current
-// block's bitmap words (random, L2) come back — one workgroup per block paid the three dependent
-// stages (filter column -> keys -> bitmap) back to back with nothing else in flight from it.
-template <int KW, int WK, int NK>
-__global__ __launch_bounds__(256) void join_cand_stream_kernel(const void *__restrict__ keycol, const void *__restrict__ keycol2,
-                                                               int64_t n, Bloom bl, const void *__restrict__ wdata, long long wlo,
-                                                               long long whi, uint16_t *__restrict__ cand,
-                                                               int32_t *__restrict__ ccount, int64_t nb) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int wc[JP_ROUNDS][4];
-    long long w[JP_ROUNDS];
-    unsigned long long k[JP_ROUNDS], k2[JP_ROUNDS];
-    auto load = [&](int64_t blk) {
-#pragma unroll
-        for (int rr = 0; rr < JP_ROUNDS; rr++) {
-            const int64_t i = blk * JP_CHUNK + rr * 256 + threadIdx.x;
-            const int64_t ic = i < n ? i : n - 1;     // in bounds; the row is masked out below
-            w[rr] = WK == 0 ? 0 : WK == 1 ? (long long)__builtin_nontemporal_load((const int32_t *)wdata + ic)
-                              : WK == 2 ? (long long)__builtin_nontemporal_load((const int64_t *)wdata + ic)
-                                        : (long long)__builtin_nontemporal_load((const uint8_t *)wdata + ic);
-            k[rr] = load_kw_nt<KW>(keycol, ic);
-            k2[rr] = NK == 2 ? load_kw_nt<KW>(keycol2, ic) : 0ull;
-        }
-    };
-    int64_t blk = blockIdx.x;
-    if (blk < nb) load(blk);
-    for (; blk < nb; blk += gridDim.x) {
-        const int64_t base = blk * JP_CHUNK;
-        bool ok[JP_ROUNDS];
-        unsigned word[JP_ROUNDS], msk[JP_ROUNDS];
-#pragma unroll
-        for (int rr = 0; rr < JP_ROUNDS; rr++) {
-            ok[rr] = base + rr * 256 + threadIdx.x < n && (WK == 0 || (w[rr] >= wlo && w[rr] <= whi));
-            uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ k[rr]);   // load_keys' hash
-            if (NK == 2) hh = mix64(hh ^ k2[rr]);
-            msk[rr] = bloom_mask(hh >> 24);
-            word[rr] = bl.bits[ok[rr] ? bloom_word(bl, hh) : 0];   // filtered-out rows share word 0: one request per wave
-        }
-        if (blk + gridDim.x < nb) load(blk + gridDim.x);            // next block's streams overlap the bitmap reads
-        unsigned long long bal[JP_ROUNDS];
-#pragma unroll
-        for (int rr = 0; rr < JP_ROUNDS; rr++) {
-            bal[rr] = __ballot(ok[rr] && (word[rr] & msk[rr]) == msk[rr]);
-            if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
-        }
-        __syncthreads();
-        uint16_t *dst = cand + base;
-        int before = 0;
-#pragma unroll
-        for (int rr = 0; rr < JP_ROUNDS; rr++) {
-            int off = before;
-            for (int q = 0; q < wv; q++) off += wc[rr][q];
-            if ((bal[rr] >> lane) & 1) dst[off + __popcll(bal[rr] & ((1ull << lane) - 1ull))] = (uint16_t)(rr * 256 + threadIdx.x);
-            before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
-        }
-        if (threadIdx.x == 0) ccount[blk] = before;
-        __syncthreads();   // the counts are rewritten in the next block
-    }
-}
-
 // The same kernel for tiny build sides: 1024 threads = four 256-thread groups, each owning one
 // 2048-row block per step; the workgroup first copies the coarse bitmap into LDS (one workgroup per
 // CU, so 128 KiB x 256 of traffic in all) and a probe reads the L2 bitmap only when its coarse
@@ -859,10 +798,6 @@ static void launch_cand_fast(bool has_sel, int nb, hipStream_t st, const JoinSid
         if (P.nkeys == 2) { if (has_sel) PH_COARSE(true, 2); else PH_COARSE(false, 2); }
         else { if (has_sel) PH_COARSE(true, 1); else PH_COARSE(false, 1); }
 #undef PH_COARSE
-    } else if (!has_sel && P.n > 0 && !getenv("PH_JOIN_CAND_BLOCK")) {   // streaming form: persistent workgroups with prefetch
-        const int grid = std::min(nb, g_cu_count * 8);
-        if (P.nkeys == 2) join_cand_stream_kernel<KW, WK, 2><<<grid, 256, 0, st>>>(P.key[0].data, P.key[1].data, P.n, bl, w.data, w.lo, w.hi, cand, ccount, (int64_t)nb);
-        else join_cand_stream_kernel<KW, WK, 1><<<grid, 256, 0, st>>>(P.key[0].data, P.key[1].data, P.n, bl, w.data, w.lo, w.hi, cand, ccount, (int64_t)nb);
     } else if (P.nkeys == 2) {
         if (has_sel) join_cand_fast_kernel<KW, WK, true, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
         else join_cand_fast_kernel<KW, WK, false, 2><<<nb, 256, 0, st>>>(PH_CAND_ARGS);
