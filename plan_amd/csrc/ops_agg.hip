@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ i
     }
     const int rec = 2 + nkeys + 3 * naggs;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int g = ids[i];
+        const int g = ids ? ids[i] : i;   // no id list: groups 0..n-1 (ph_agg_finalize)
         unsigned long long *o = out + 2 + (int64_t)i * rec;
         o[0] = (unsigned long long)first_row[g];
         o[1] = gnull[g];
@@ -1020,12 +1020,30 @@ extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row
     std::vector<long long> hi(g * na);
     std::vector<unsigned> gn(g);
     ph_ctx *cx = a->ctx;
-    PH_CHECK(cx->download(fr.data(), a->first_row, (int64_t)(g * 8)));
-    PH_CHECK(cx->download(gk.data(), a->gkeys, (int64_t)(g * a->nkeys * 8)));
-    PH_CHECK(cx->download(gn.data(), a->gnull, (int64_t)(g * 4)));
-    PH_CHECK(cx->download(lo.data(), a->sum_lo, (int64_t)(g * na * 8)));
-    PH_CHECK(cx->download(hi.data(), a->sum_hi, (int64_t)(g * na * 8)));
-    PH_CHECK(cx->download(cn.data(), a->cnt, (int64_t)(g * na * 8)));
+    {
+        // the group records are packed on the device and come back in ONE copy (six per-array copies
+        // were six stream synchronisations: ~0.12 ms of a 2 ms Q9)
+        const size_t rec = 2 + (size_t)a->nkeys + 3 * (size_t)a->naggs;
+        unsigned long long *pack = nullptr;
+        PH_CHECK(cx->pool_alloc((int64_t)(2 + g * rec) * 8, (void **)&pack));
+        ph::agg_pack_kernel<<<(int)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024)), 256, 0, cx->stream>>>(
+            nullptr, a->counters, a->counters, (int)ng, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
+        std::vector<unsigned long long> host(2 + g * rec);
+        int rc = hipGetLastError() == hipSuccess ? cx->download(host.data(), pack, (int64_t)host.size() * 8) : PH_EHIP;
+        cx->pool_release(pack);
+        if (rc != PH_OK) return rc;
+        for (size_t i = 0; i < g; i++) {
+            const unsigned long long *o = host.data() + 2 + i * rec;
+            fr[i] = (long long)o[0];
+            gn[i] = (unsigned)o[1];
+            for (int c = 0; c < a->nkeys; c++) gk[i * a->nkeys + c] = o[2 + c];
+            for (int q = 0; q < a->naggs; q++) {
+                lo[i * na + q] = o[2 + a->nkeys + q];
+                hi[i * na + q] = (long long)o[2 + a->nkeys + a->naggs + q];
+                cn[i * na + q] = o[2 + a->nkeys + 2 * a->naggs + q];
+            }
+        }
+    }
     // first-seen order = the reference's insertion order (GroupedAggrHashTable.Scan, :424-438)
     std::vector<int64_t> order(g);
     for (size_t i = 0; i < g; i++) order[i] = (int64_t)i;

@@ -111,6 +111,23 @@ __global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
 }
 
+// clears what a build needs cleared in ONE launch: head table (-1) and Bloom bitmap of the atomic
+// build, the coarse bitmap of tiny build sides, the inserted-row counter
+__global__ __launch_bounds__(256) void join_init_kernel(int32_t *__restrict__ head, int64_t cap, unsigned *__restrict__ bits,
+                                                        int64_t words, unsigned *__restrict__ coarse, int *__restrict__ count) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    if (head) {
+        int4 *h4 = reinterpret_cast<int4 *>(head);   // cap is a power of two >= 1024
+        for (int64_t i = t; i < cap / 4; i += step) h4[i] = make_int4(-1, -1, -1, -1);
+    }
+    if (bits) {
+        uint4 *b4 = reinterpret_cast<uint4 *>(bits);  // words is a power of two >= 2048
+        for (int64_t i = t; i < words / 4; i += step) b4[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (coarse) for (int64_t i = t; i < CO_WORDS; i += step) coarse[i] = 0;
+    if (t < 4) count[t] = 0;
+}
+
 // ---- partitioned build (no global atomics). Scattered device atomics run at ~20 G/s on this
 // part (they execute at the memory side, one 64-B request each), which bounded the atomicExch
 // build at ~10 G rows/s with a bitmap and ~20 G rows/s without. Here rows are first grouped by
@@ -1397,13 +1414,21 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     }
     if (bits && n <= (256ll << 10)) {   // tiny build side: the LDS-resident coarse bitmap of the probe
         if (ctx->pool_alloc(ph::CO_WORDS * 4, (void **)&j->bloom.coarse) != PH_OK) return fail("alloc(coarse)");
-        if (hipMemsetAsync(j->bloom.coarse, 0, (size_t)ph::CO_WORDS * 4, ctx->stream) != hipSuccess) return fail("memset");
     }
     // number of inserted (non-NULL-key) rows: stays on the device until ph_join_count asks, so
     // building a table costs no host round trip
     if (ctx->pool_alloc(16, (void **)&j->count_dev) != PH_OK) return fail("alloc(count)");
     int *count = j->count_dev;
-    if (hipMemsetAsync(count, 0, 16, ctx->stream) != hipSuccess) return fail("memset");
+    // one initialisation launch for whatever this build needs cleared (the coarse bitmap, the row
+    // counter and — for the atomic build — the head table and the bitmap): up to four memsets before
+    if (n > 0) {
+        const bool atomic_build = !partitioned;
+        ph::join_init_kernel<<<ctx->cu_count * 2, 256, 0, ctx->stream>>>(atomic_build ? j->head : nullptr, cap,
+                                                                          atomic_build && bits ? j->bloom.bits : nullptr, bits / 32,
+                                                                          j->bloom.coarse, count);
+        if (hipGetLastError() != hipSuccess) return fail("join_init_kernel launch");
+    } else if (hipMemsetAsync(count, 0, 16, ctx->stream) != hipSuccess || hipMemsetAsync(j->head, 0xff, (size_t)cap * 4, ctx->stream) != hipSuccess)
+        return fail("memset");
     if (partitioned) {
         const int64_t rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
         const int nwg = (int)((n + rows_per_wg - 1) / rows_per_wg);
@@ -1457,8 +1482,6 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
         ctx->pool_release(counts); ctx->pool_release(part_rec);
         if (bad) return fail("partitioned build launch");
     } else {
-        if (hipMemsetAsync(j->head, 0xff, (size_t)cap * 4, ctx->stream) != hipSuccess) return fail("memset");
-        if (bits && hipMemsetAsync(j->bloom.bits, 0, (size_t)(bits / 8), ctx->stream) != hipSuccess) return fail("memset");
         if (n > 0) {
             int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
             ph::join_build_kernel<<<grid, 256, 0, ctx->stream>>>(j->build, j->head, (uint64_t)cap - 1, j->next, count, j->bloom);

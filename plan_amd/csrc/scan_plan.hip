@@ -468,7 +468,8 @@ static int try_fused(ph_ctx *ctx, const ph_table *t, const ph_pred *preds, int32
         // The precompiled kernel always loads its four roles; a plan that names fewer columns would
         // re-read a stand-in (measured: 3.5 TB/s of useful bytes instead of 6.3). Such plans get a
         // generated kernel that reads only what they name — unless code generation is switched off.
-        static const bool nojit = getenv("PH_SCAN_JIT") && atoi(getenv("PH_SCAN_JIT")) == 0;
+        const char *je = getenv("PH_SCAN_JIT");
+        const bool nojit = je && atoi(je) == 0;
         if ((d < 0 || tt < 0 || q < 0) && !nojit) { set_error("lowcard_chain: the plan names fewer columns than the kernel reads"); return fail(PH_EUNSUPPORTED); }
         if (d < 0) d = e;
         if (tt < 0) tt = e;

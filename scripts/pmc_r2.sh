@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=${1:-r02}
-rm -rf $R/gpurun_out/pmc_$tag
+rm -rf $R/gpurun_out/pmc_$tag; mkdir -p $R/gpurun_out/pmc_$tag
 for q in q1 q6 q3 q9; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag/${q}_$c -o p -- python3 $R/bench.py --query $q --steps 5 --warmup 1 --no-cpu-baseline --no-companions > $R/gpurun_out/pmc_$tag/${q}_$c.log 2>&1 < /dev/null
