@@ -274,6 +274,19 @@ typedef struct ph_join ph_join;
 
 int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
                   ph_join **out);
+/* ph_join_build with the value range of the (single, integer) key column, as column statistics
+ * give it (ph_table_col_range; any superset of the build keys' range). When the build side fills
+ * the range densely (at most 8 slots per build row: a primary-key column, possibly filtered) the
+ * table is a DIRECT table addressed by key - key_lo: no hashing, no key compares, one 4-byte read
+ * per probe, and probes in key order read it front to back. The reference has no counterpart (it
+ * always hashes, join_table.go:197-288); every probe call returns what it returns for
+ * ph_join_build's tables. Sparse ranges, several key columns and 1-byte keys fall back to
+ * ph_join_build. A build key outside [key_lo, key_hi] is an error, reported by ph_join_count
+ * (-1 + ph_last_error) — the build itself makes no host round trip. */
+int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
+                        int64_t key_lo, int64_t key_hi, ph_join **out);
+/* the table form a build chose: "direct", "nodes", "chained+bloom" or "chained" */
+const char *ph_join_kind(const ph_join *j);
 int64_t ph_join_count(const ph_join *j);
 /* Inner probe: writes (probe row id, build row id) pairs to dev buffers of `cap` entries.
  * *n_out (host) = number of matches (may exceed cap -> PH_ECAPACITY, nothing lost but the tail). */
@@ -285,8 +298,8 @@ int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int6
  * executor_filter.go:27-114 + executor_join.go:54-264), without materialising the selection: the
  * kernel that streams the probe keys tests the comparison first. Only comparisons that lower to
  * an integer range (INTEGER / DATE / DECIMAL-vs-integer / dictionary-code columns, not `!=`) and
- * tables that carry a Bloom bitmap (build side <= 4 M keys); PH_EUNSUPPORTED otherwise, and the
- * caller runs the two calls. `sel` narrows the probe rows first, as in ph_join_probe_inner. */
+ * tables that carry a Bloom bitmap (build side <= 4 M keys) or are direct tables; PH_EUNSUPPORTED
+ * otherwise, and the caller runs the two calls. `sel` narrows the probe rows first, as in ph_join_probe_inner. */
 int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
                               const ph_const *where_k, const int32_t *sel, int64_t n,
                               int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,

@@ -107,8 +107,12 @@ __global__ __launch_bounds__(256) void join_build_kernel(JoinSide B, int32_t *__
         }
         local++;
     }
+    // one counter update per workgroup: same-address device atomics serialise at ~10 ns each
+    __shared__ int s_local[4];
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+    if ((threadIdx.x & 63) == 0) s_local[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_local[0] + s_local[1] + s_local[2] + s_local[3]) atomicAdd(count, s_local[0] + s_local[1] + s_local[2] + s_local[3]);
 }
 
 // clears what a build needs cleared in ONE launch: head table (-1) and Bloom bitmap of the atomic
@@ -1212,6 +1216,334 @@ __global__ __launch_bounds__(256) void join_mark_set_kernel(const uint16_t *__re
     }
 }
 
+
+// ---- dense integer keys: the DIRECT table (ph_join_build_range).
+// When the caller knows the key column's value range (column statistics) and the build side fills
+// that range densely — a primary-key column: orders 15 M keys over a 60 M range, supplier, customer
+// — the bucket-head table is addressed by key - lo instead of by a hash: no hash arithmetic, no key
+// compare (a chain holds one key's rows only), no collisions, one random 4-byte read per probe, and
+// probes in key order (lineitem by l_orderkey) read the table front to back. The reference always
+// hashes (join_table.go:197-288); the result is the same pair set. Build, no global atomics for
+// unique keys: scatter positions with plain stores (counting the rows stored) -> count the occupied
+// slots in one streaming pass: fewer slots than rows means some rows lost a duplicate key, and only
+// then the two kernels after it do any work — verify (a row that does not find itself in its slot
+// gets next = -3) and link (the losers are chained in front of the winner with atomicExch).
+// count[0] rows stored, count[1] occupied slots, count[2] keys outside [lo, hi].
+template <int KW, bool SEL>
+__device__ __forceinline__ bool direct_key(const void *__restrict__ kcol, const uint8_t *__restrict__ valid, const int32_t *__restrict__ sel,
+                                           int64_t i, long long lo, unsigned long long range, unsigned long long *off, bool *oor) {
+    const int64_t r = SEL ? (int64_t)sel[i] : i;
+    if (valid && !bit_valid(valid, r)) { *oor = false; return false; }   // NULL key: never inserted, never matches
+    const long long k = (long long)load_kw<KW>(kcol, r);
+    const unsigned long long o = (unsigned long long)(k - lo);
+    *off = o;
+    *oor = o >= range;
+    return o < range;
+}
+
+// (same-address device atomics cost ~10 ns each, serialised: one per WORKGROUP and one workgroup per
+// CU, not one per wave — 8192 of them made this kernel 60 us slower)
+constexpr int DT = 1024;
+
+__device__ __forceinline__ void direct_block_add(int v0, int v1, int *__restrict__ c0, int *__restrict__ c1) {
+    __shared__ int part[2][DT / 64];
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = v0; part[1][threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int w = 0; w < DT / 64; w++) { a += part[0][w]; b += part[1][w]; }
+        if (a) atomicAdd(c0, a);
+        if (b && c1) atomicAdd(c1, b);
+    }
+}
+
+template <int KW, bool SEL>
+__global__ __launch_bounds__(DT) void direct_scatter_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
+                                                             const int32_t *__restrict__ sel, int64_t n, long long lo,
+                                                             unsigned long long range, int32_t *__restrict__ direct,
+                                                             int *__restrict__ count) {
+    constexpr int U = 4;
+    int ins = 0, out = 0;
+    for (int64_t base = (int64_t)blockIdx.x * DT * U; base < n; base += (int64_t)gridDim.x * DT * U) {
+        unsigned long long off[U];
+        bool ok[U], oor[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * DT + threadIdx.x;
+            oor[u] = false;
+            ok[u] = i < n && direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off[u], &oor[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (ok[u]) direct[off[u]] = (int32_t)(base + u * DT + threadIdx.x);
+            ins += ok[u];
+            out += oor[u];
+        }
+    }
+    direct_block_add(ins, out, count, count + 2);
+}
+
+// occupied slots of the table (cap4 is a multiple of 4; the padding slots are -1)
+__global__ __launch_bounds__(DT) void direct_occupied_kernel(const int32_t *__restrict__ direct, int64_t cap4, int *__restrict__ count) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i *d4 = reinterpret_cast<const v4i *>(direct);
+    int occ = 0;
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < cap4 / 4; i += (int64_t)gridDim.x * DT) {
+        const v4i v = __builtin_nontemporal_load(d4 + i);
+        occ += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+    }
+    direct_block_add(occ, 0, count + 1, nullptr);
+}
+
+template <int KW, bool SEL>
+__global__ __launch_bounds__(256) void direct_verify_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
+                                                            const int32_t *__restrict__ sel, int64_t n, long long lo,
+                                                            unsigned long long range, const int32_t *__restrict__ direct,
+                                                            int32_t *__restrict__ next, const int *__restrict__ count) {
+    constexpr int U = 4;
+    if (count[0] == count[1]) return;   // every stored row owns its slot: unique keys (the expected case)
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U; base < n; base += (int64_t)gridDim.x * 256 * U) {
+        unsigned long long off[U];
+        bool ok[U], oor[U];
+        int32_t d[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            oor[u] = false;
+            ok[u] = i < n && direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off[u], &oor[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) d[u] = direct[ok[u] ? off[u] : 0];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            if (i >= n) continue;
+            const bool mine = ok[u] && d[u] == (int32_t)i;
+            next[i] = !ok[u] ? -2 : mine ? -1 : -3;
+        }
+    }
+}
+
+template <int KW, bool SEL>
+__global__ __launch_bounds__(256) void direct_dups_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
+                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
+                                                          unsigned long long range, int32_t *__restrict__ direct,
+                                                          int32_t *__restrict__ next, const int *__restrict__ count) {
+    if (count[0] == count[1]) return;   // unique keys: nothing to link
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (next[i] != -3) continue;
+        unsigned long long off;
+        bool oor;
+        if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) next[i] = atomicExch(&direct[off], (int32_t)i);
+    }
+}
+
+// probe side, lookup (MODE 0) and mark (MODE 2): DU probes per lane issue their key reads, then
+// their table reads together.
+constexpr int DU = 4;
+
+template <int KW, bool SELP, bool SELB, int MODE>
+__global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restrict__ pkey, const uint8_t *__restrict__ pvalid,
+                                                           const int32_t *__restrict__ psel, int64_t n, long long lo,
+                                                           unsigned long long range, const int32_t *__restrict__ direct,
+                                                           const int32_t *__restrict__ next, const int32_t *__restrict__ bsel,
+                                                           const int *__restrict__ bcount, int32_t *__restrict__ out,
+                                                           uint8_t *__restrict__ found, int *__restrict__ stats) {
+    const bool dups = bcount[0] != bcount[1];   // rows stored vs slots occupied
+    int misses = 0, multi = 0;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * DU; base < n; base += (int64_t)gridDim.x * 256 * DU) {
+        int64_t r[DU];
+        bool ok[DU];
+        long long k[DU];
+        int32_t b[DU];
+        int c[DU];
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            ok[u] = i < n;
+            r[u] = ok[u] ? i : 0;
+        }
+        if (SELP) {
+#pragma unroll
+            for (int u = 0; u < DU; u++) r[u] = psel[r[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+            k[u] = (long long)load_kw<KW>(pkey, r[u]);
+            if (pvalid) ok[u] = ok[u] && bit_valid(pvalid, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+            const unsigned long long off = (unsigned long long)(k[u] - lo);
+            ok[u] = ok[u] && off < range;
+            const int32_t d = direct[ok[u] ? off : 0];
+            b[u] = ok[u] ? d : -1;
+            c[u] = b[u] >= 0 ? 1 : 0;
+        }
+        if (dups) {   // duplicate build keys: a chain holds every row of the key; report the last, count all
+#pragma unroll
+            for (int u = 0; u < DU; u++)
+                if (b[u] >= 0)
+                    for (int32_t x = next[b[u]]; x >= 0; x = next[x]) { c[u]++; if (MODE == 0) b[u] = x; }
+        }
+        if (SELB) {
+#pragma unroll
+            for (int u = 0; u < DU; u++) b[u] = b[u] >= 0 ? bsel[b[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            if (i >= n) continue;
+            if (MODE == 0) { out[i] = b[u]; misses += c[u] == 0; multi += c[u] > 1; }
+            else found[i] = c[u] > 0 ? 1 : 0;
+        }
+    }
+    if (MODE == 0) {
+        for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (misses) atomicAdd(stats, misses);
+            if (multi) atomicAdd(stats + 1, multi);
+        }
+    }
+}
+
+// inner probe, pass 1: one workgroup per 2048-row block streams the probe keys (after the pushed-down
+// range filter WK: 0 none, 1 int32, 2 int64, 3 uint8 column), reads the table, and writes the block's
+// matching positions in order (ballot ranks, no atomics) with the slot's chain head beside them —
+// the shape of join_cand_fast_kernel, but the table read IS the exact test, so there is no chain pass.
+template <int KW, int WK, bool SEL>
+__global__ __launch_bounds__(256) void direct_cand_kernel(const void *__restrict__ keycol, const uint8_t *__restrict__ pvalid,
+                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
+                                                          unsigned long long range, const int32_t *__restrict__ direct,
+                                                          const int32_t *__restrict__ next, const int *__restrict__ bcount,
+                                                          const void *__restrict__ wdata, long long wlo, long long whi,
+                                                          uint16_t *__restrict__ cand, int32_t *__restrict__ cmatch,
+                                                          uint16_t *__restrict__ ccnt, int32_t *__restrict__ ccount,
+                                                          int32_t *__restrict__ block_counts) {
+    const bool dups = bcount[0] != bcount[1];
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int wc[JP_ROUNDS][4];
+    __shared__ int wtot[4];
+    unsigned long long bal[JP_ROUNDS];
+    int64_t r[JP_ROUNDS];
+    bool ok[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const int64_t i = base + rr * 256 + threadIdx.x;
+        ok[rr] = i < n;
+        const int64_t ic = ok[rr] ? i : 0;
+        r[rr] = SEL ? (int64_t)sel[ic] : ic;
+    }
+    if (WK != 0) {
+        long long w[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++)
+            w[rr] = SEL ? (WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
+                           : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]])
+                        : (WK == 1 ? (long long)__builtin_nontemporal_load((const int32_t *)wdata + r[rr])
+                           : WK == 2 ? (long long)__builtin_nontemporal_load((const int64_t *)wdata + r[rr])
+                                     : (long long)__builtin_nontemporal_load((const uint8_t *)wdata + r[rr]));
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            ok[rr] = ok[rr] && w[rr] >= wlo && w[rr] <= whi;
+            if (!ok[rr]) r[rr] = 0;
+        }
+    }
+    long long k[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        k[rr] = (long long)(SEL ? load_kw<KW>(keycol, r[rr]) : load_kw_nt<KW>(keycol, r[rr]));
+        if (pvalid) ok[rr] = ok[rr] && bit_valid(pvalid, r[rr]);
+    }
+    int32_t d[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const unsigned long long off = (unsigned long long)(k[rr] - lo);
+        ok[rr] = ok[rr] && off < range;
+        d[rr] = direct[ok[rr] ? off : 0];
+    }
+    int total = 0;
+    int c[JP_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        const bool take = ok[rr] && d[rr] >= 0;
+        c[rr] = take ? 1 : 0;
+        if (dups && take)
+            for (int32_t x = next[d[rr]]; x >= 0; x = next[x]) c[rr]++;
+        total += c[rr];
+        bal[rr] = __ballot(take);
+        if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0) wtot[wv] = total;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) {
+        int off = before;
+        for (int q = 0; q < wv; q++) off += wc[rr][q];
+        if ((bal[rr] >> lane) & 1) {
+            const int64_t slot = base + off + __popcll(bal[rr] & ((1ull << lane) - 1ull));
+            cand[slot] = (uint16_t)(rr * 256 + threadIdx.x);
+            cmatch[slot] = d[rr];
+            ccnt[slot] = (uint16_t)(c[rr] > 65535 ? 65535 : c[rr]);
+        }
+        before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
+    }
+    if (threadIdx.x == 0) {
+        ccount[blockIdx.x] = before;
+        block_counts[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    }
+}
+
+// inner probe, pass 2: one wave per block writes the pairs at the block's offset, ordered by probe
+// position then chain order; a candidate of a unique key is one pair straight from cmatch
+template <bool SELP, bool SELB>
+__global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restrict__ psel, const int32_t *__restrict__ next,
+                                                          const int32_t *__restrict__ bsel, const uint16_t *__restrict__ cand,
+                                                          const int32_t *__restrict__ cmatch, const uint16_t *__restrict__ ccnt,
+                                                          const int32_t *__restrict__ ccount, const int32_t *__restrict__ block_off,
+                                                          int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
+                                                          int32_t *__restrict__ out_build) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
+        const int cnt = ccount[blk];
+        int64_t running = block_off[blk];
+        for (int t0 = 0; t0 < cnt; t0 += 64) {
+            const int t = t0 + lane;
+            int c = 0;
+            int32_t first = -1;
+            int64_t r = 0;
+            if (t < cnt) {
+                const int64_t i = blk * JP_CHUNK + cand[blk * JP_CHUNK + t];
+                r = SELP ? (int64_t)psel[i] : i;
+                c = ccnt[blk * JP_CHUNK + t];
+                first = cmatch[blk * JP_CHUNK + t];
+                if (c == 65535) { c = 0; for (int32_t x = first; x >= 0; x = next[x]) c++; }   // saturated: recount
+            }
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (c == 1) {
+                const int64_t pos = running + incl - 1;
+                if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = SELB ? bsel[first] : first; }
+            } else if (c > 1) {
+                int64_t pos = running + incl - c;
+                for (int32_t x = first; x >= 0; x = next[x]) {
+                    if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = SELB ? bsel[x] : x; }
+                    pos++;
+                }
+            }
+            running += __shfl(incl, 63);
+        }
+    }
+}
+
 }  // namespace ph
 
 struct ph_join {
@@ -1225,6 +1557,10 @@ struct ph_join {
     ph::Bloom bloom{};
     ph::BigNode *nodes = nullptr;   // node table (large build sides): replaces next[]
     int big_kw = 0, big_nk = 0;     // key width / count of the node table's packed key
+    int32_t *direct = nullptr;      // direct table (dense integer keys): replaces head[], addressed by key - dlo
+    int64_t dlo = 0;
+    unsigned long long drange = 0;
+    int dkw = 0;
 };
 
 extern "C" void ph_join_free(ph_join *j) {
@@ -1236,6 +1572,7 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->bloom.coarse) j->ctx->pool_release(j->bloom.coarse);
     if (j->count_dev) j->ctx->pool_release(j->count_dev);
     if (j->nodes) j->ctx->pool_release(j->nodes);
+    if (j->direct) j->ctx->pool_release(j->direct);
     delete j;
 }
 
@@ -1307,6 +1644,118 @@ static int build_big(ph_join *j, int kw, int nparts) {
     return rc;
 }
 
+
+// ---- direct table (dense integer keys): host side
+#define PH_DIRECT_KS(KERNEL, GRID, THREADS, ...)                                                            \
+    do {                                                                                                    \
+        if (kw == 4) { if (B.sel) KERNEL<4, true><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); else KERNEL<4, false><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); } \
+        else { if (B.sel) KERNEL<8, true><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); else KERNEL<8, false><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); }         \
+    } while (0)
+
+static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
+    ph_ctx *ctx = j->ctx;
+    const int64_t n = j->build.n;
+    const int64_t cap4 = ph::round_up(range, 4);
+    j->dkw = kw;
+    j->dlo = lo;
+    j->drange = (unsigned long long)range;
+    if (ctx->pool_alloc(cap4 * 4, (void **)&j->direct) != PH_OK || ctx->pool_alloc(std::max<int64_t>(n, 1) * 4, (void **)&j->next) != PH_OK ||
+        ctx->pool_alloc(16, (void **)&j->count_dev) != PH_OK) { ph::set_error("ph_join_build_range: allocation failed"); return PH_EHIP; }
+    if (j->build.sel && n > 0) {   // own copy: the table outlives the caller's selection buffer
+        PH_CHECK(ctx->pool_alloc(n * 4, (void **)&j->sel_copy));
+        PH_HIP(hipMemcpyAsync(j->sel_copy, j->build.sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        j->build.sel = j->sel_copy;
+    }
+    const ph::JoinSide &B = j->build;
+    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, nullptr, 0, nullptr, j->count_dev);
+    if (n > 0) {
+        const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
+        const void *kcol = B.key[0].data;
+        const uint8_t *valid = B.key[0].validity;
+        // one 1024-thread workgroup per CU for the two passes that end in a counter update
+        const int gridc = (int)std::min<int64_t>((n + ph::DT * 4 - 1) / (ph::DT * 4), (int64_t)ctx->cu_count);
+        const int grido = (int)std::min<int64_t>((cap4 / 4 + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
+        PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->count_dev);
+        ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev);
+        PH_DIRECT_KS(ph::direct_verify_kernel, grid, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+        const int grid1 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
+        PH_DIRECT_KS(ph::direct_dups_kernel, grid1, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+    }
+    PH_HIP(hipGetLastError());
+    j->count = n == 0 ? 0 : -1;
+    return PH_OK;
+}
+#undef PH_DIRECT_KS
+
+static bool direct_probe_ok(const ph_join *j, const ph::JoinSide &P) {
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+    return P.nkeys == 1 && width(P.key[0].type) == j->dkw;
+}
+
+template <int MODE>
+static void launch_direct_probe(ph_join *j, const ph::JoinSide &P, int64_t n, int grid, int32_t *out, uint8_t *found, int *stats) {
+    hipStream_t st = j->ctx->stream;
+    const int32_t *bsel = j->build.sel;
+#define PH_DP_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, bsel, j->count_dev, out, found, stats
+#define PH_DP_LAUNCH(KWV)                                                                                                      \
+    do {                                                                                                                       \
+        if (P.sel && bsel) ph::direct_probe_kernel<KWV, true, true, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                   \
+        else if (P.sel) ph::direct_probe_kernel<KWV, true, false, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                     \
+        else if (bsel) ph::direct_probe_kernel<KWV, false, true, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                      \
+        else ph::direct_probe_kernel<KWV, false, false, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                               \
+    } while (0)
+    if (j->dkw == 4) PH_DP_LAUNCH(4); else PH_DP_LAUNCH(8);
+#undef PH_DP_LAUNCH
+#undef PH_DP_ARGS
+}
+
+template <int KW, int WK>
+static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, uint16_t *cand, int32_t *cmatch,
+                               uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
+#define PH_DC_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev, w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts
+    if (P.sel) ph::direct_cand_kernel<KW, WK, true><<<nb, 256, 0, j->ctx->stream>>>(PH_DC_ARGS);
+    else ph::direct_cand_kernel<KW, WK, false><<<nb, 256, 0, j->ctx->stream>>>(PH_DC_ARGS);
+#undef PH_DC_ARGS
+}
+
+static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, const ph::RangePred &where, int32_t *out_probe_dev,
+                              int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    ph_ctx *ctx = j->ctx;
+    const int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
+    const int64_t o_ccount = ph::round_up(nb * 4, 8) + 64;
+    const int64_t o_cand = ph::round_up(o_ccount + nb * 4, 8), o_ccnt = o_cand + nb * ph::JP_CHUNK * 2;
+    const int64_t o_cmatch = o_ccnt + nb * ph::JP_CHUNK * 2;
+    PH_CHECK(ctx->ensure_scratch(o_cmatch + nb * ph::JP_CHUNK * 4));
+    int32_t *counts = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
+    uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
+    int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
+#define PH_DC_K(KWV)                                                                                                 \
+    switch (where.kind) {                                                                                            \
+    case 0: launch_direct_cand<KWV, 0>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
+    case 1: launch_direct_cand<KWV, 1>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
+    case 2: launch_direct_cand<KWV, 2>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
+    default: launch_direct_cand<KWV, 3>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;         \
+    }
+    if (j->dkw == 4) { PH_DC_K(4) } else { PH_DC_K(8) }
+#undef PH_DC_K
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
+    const int32_t *bsel = j->build.sel;
+#define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, nb, cap, out_probe_dev, out_build_dev
+    if (P.sel && bsel) ph::direct_emit_kernel<true, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
+    else if (P.sel) ph::direct_emit_kernel<true, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
+    else if (bsel) ph::direct_emit_kernel<false, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
+    else ph::direct_emit_kernel<false, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
+#undef PH_DE_ARGS
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ctx->download(n_out, total, 8));
+    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
+    return PH_OK;
+}
+
 // probe-side shape check of a node table: same packing as the build side, no other key shape
 static bool big_probe_ok(const ph_join *j, const ph::JoinSide &P) {
     auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
@@ -1353,14 +1802,29 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
     return PH_OK;
 }
 
-extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
-                             ph_join **out) {
+static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, bool have_range,
+                           int64_t key_lo, int64_t key_hi, ph_join **out) {
     PH_REQUIRE(ctx && keys && out && nkeys >= 1 && nkeys <= ph::JOIN_MAX_KEYS && n >= 0 && n < (1ll << 31),
                "ph_join_build: bad arguments (1..%d keys)", ph::JOIN_MAX_KEYS);
     ph_join *j = new ph_join();
     j->ctx = ctx;
     int rc = fill_side(&j->build, keys, nkeys, sel, n);
     if (rc != PH_OK) { delete j; return rc; }
+    if (have_range && nkeys == 1 && n > 0 && key_hi >= key_lo) {
+        // dense keys: a direct table when the range is at most 8 slots per build row (a primary-key
+        // column, possibly filtered) and at most 2^30 slots; sparse build sides keep the hash tables,
+        // whose Bloom bitmap rejects most probes from cache
+        const char *dz = getenv("PH_JOIN_DIRECT");   // read per call: the tests build both forms over the same keys
+        const int t = keys[0].type;
+        const int kw = (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8;
+        const unsigned long long span = (unsigned long long)key_hi - (unsigned long long)key_lo;
+        if (!(dz && atoi(dz) == 0) && kw != 1 && span < (1ull << 30) && (int64_t)span + 1 <= std::max<int64_t>(8 * n, 4096)) {
+            int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1);
+            if (rcd != PH_OK) { ph_join_free(j); return rcd; }
+            *out = j;
+            return PH_OK;
+        }
+    }
     // pointer table: cap = max(nextpow2(2n), 1024) (pointerTableCap, join_table.go:197-199)
     int64_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
@@ -1493,9 +1957,32 @@ extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, con
     return PH_OK;
 }
 
+extern "C" int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, ph_join **out) {
+    return join_build_impl(ctx, keys, nkeys, sel, n, false, 0, 0, out);
+}
+
+extern "C" int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int64_t key_lo,
+                                   int64_t key_hi, ph_join **out) {
+    return join_build_impl(ctx, keys, nkeys, sel, n, true, key_lo, key_hi, out);
+}
+
+extern "C" const char *ph_join_kind(const ph_join *j) {
+    return !j ? "" : j->direct ? "direct" : j->nodes ? "nodes" : j->bloom.bits ? "chained+bloom" : "chained";
+}
+
 extern "C" int64_t ph_join_count(const ph_join *cj) {
     ph_join *j = const_cast<ph_join *>(cj);
     if (!j) return -1;
+    if (j->count < 0 && j->direct) {
+        int c[4] = {0, 0, 0, 0};
+        if (j->ctx->download(c, j->count_dev, 16) != PH_OK) return -1;
+        if (c[2] != 0) {
+            ph::set_error("ph_join_build_range: %d build keys lie outside the stated range [%lld, %lld]", c[2], (long long)j->dlo,
+                          (long long)(j->dlo + (int64_t)j->drange - 1));
+            return -1;
+        }
+        j->count = c[0];
+    }
     if (j->count < 0) {
         int c = 0;
         if (j->ctx->download(&c, j->count_dev, 4) != PH_OK) return -1;
@@ -1530,9 +2017,10 @@ extern "C" int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const p
                                          int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
     PH_REQUIRE(j && where_col && where_k, "ph_join_probe_inner_where: bad arguments");
     ph::RangePred where{};
-    if (!j->bloom.bits || !ph::lower_range_pred(where_col, where_op, where_k, &where)) {
-        ph::set_error("ph_join_probe_inner_where: only integer-range predicates over a probe of a table with a Bloom bitmap are "
-                      "fused; run ph_filter_select and ph_join_probe_inner");
+    if ((!j->bloom.bits && !j->direct) || !ph::lower_range_pred(where_col, where_op, where_k, &where) ||
+        (j->direct && (where.validity || where.kind < 0))) {
+        ph::set_error("ph_join_probe_inner_where: only integer-range predicates over a probe of a table with a Bloom bitmap (or of a "
+                      "direct table, over a column without NULLs) are fused; run ph_filter_select and ph_join_probe_inner");
         return PH_EUNSUPPORTED;
     }
     return probe_inner_impl(j, keys, sel, n, where, out_probe_dev, out_build_dev, cap, n_out);
@@ -1546,6 +2034,10 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     *n_out = 0;
     if (n == 0 || j->build.n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
+    if (j->direct) {
+        if (!direct_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the direct table's"); return PH_EUNSUPPORTED; }
+        return direct_probe_inner(j, P, n, where, out_probe_dev, out_build_dev, cap, n_out);
+    }
     if (j->nodes) {
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
         return big_probe_inner(j, P, n, out_probe_dev, out_build_dev, cap, n_out);
@@ -1587,6 +2079,12 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
     if (n == 0) return PH_OK;
     ph_ctx *ctx = j->ctx;
     if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    if (j->direct) {
+        if (!direct_probe_ok(j, P)) { ph::set_error("ph_join_probe_mark: probe key shape differs from the direct table's"); return PH_EUNSUPPORTED; }
+        launch_direct_probe<2>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), nullptr, found_dev, nullptr);
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
     if (j->nodes) {
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_mark: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
         launch_big_probe<2>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), nullptr, nullptr, nullptr, found_dev, nullptr);
@@ -1652,6 +2150,16 @@ extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel
     if (!stats) {   // the kernel always counts; without a caller buffer the counts are dropped
         PH_CHECK(ctx->pool_alloc(8, (void **)&scratch));
         stats = scratch;
+    }
+    if (j->direct) {
+        int rcb = PH_OK;
+        if (!direct_probe_ok(j, P)) { ph::set_error("ph_join_lookup: probe key shape differs from the direct table's"); rcb = PH_EUNSUPPORTED; }
+        else {
+            launch_direct_probe<0>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), out_build_dev, nullptr, stats);
+            if (hipGetLastError() != hipSuccess) { ph::set_error("ph_join_lookup: kernel launch failed"); rcb = PH_EHIP; }
+        }
+        if (scratch) ctx->pool_release(scratch);
+        return rcb;
     }
     if (j->nodes) {
         int rcb = PH_OK;

@@ -103,12 +103,16 @@ def lib():
         _preload_torch_hip_runtime()
         L = ctypes.CDLL(path)
         for name, rt in (("ph_last_error", ctypes.c_char_p), ("ph_version", ctypes.c_char_p),
-                         ("ph_scan_plan_kind", ctypes.c_char_p), ("ph_table_rows", i64),
+                         ("ph_scan_plan_kind", ctypes.c_char_p), ("ph_join_kind", ctypes.c_char_p), ("ph_table_rows", i64),
                          ("ph_hash_bytes", ctypes.c_uint64), ("ph_join_count", i64),
                          ("ph_comm_nranks", i32), ("ph_comm_rank", i32)):
             getattr(L, name).restype = rt  # a missing symbol raises: the ABI must be complete
         _LIB = L
     return _LIB
+
+
+def last_error():
+    return lib().ph_last_error().decode()
 
 
 def check(rc):
@@ -511,10 +515,20 @@ class Agg:
 
 
 class Join:
-    def __init__(self, ctx, keys, sel, n):
+    def __init__(self, ctx, keys, sel, n, key_range=None):
+        """key_range = (lo, hi) of the single key column from column statistics (Table.col_range):
+        ph_join_build_range, which picks a direct table for dense keys"""
         self.ctx = ctx
         self.h = vp()
-        check(lib().ph_join_build(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), ctypes.byref(self.h)))
+        if key_range is None:
+            check(lib().ph_join_build(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), ctypes.byref(self.h)))
+        else:
+            check(lib().ph_join_build_range(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), i64(key_range[0]),
+                                            i64(key_range[1]), ctypes.byref(self.h)))
+
+    @property
+    def kind(self):
+        return lib().ph_join_kind(self.h).decode()
 
     def count(self):
         return int(lib().ph_join_count(self.h))

@@ -34,6 +34,8 @@ class Q3Pipeline:
         D = hip.DevColumn
         self.nc, self.no, self.nl = len(C["c_custkey"]), len(O["o_orderkey"]), len(L["l_orderkey"])
         self.c_key = D(ctx, hip.PH_I32, C["c_custkey"])
+        # column statistics (what ph_table_col_range keeps for a table): dense primary keys build direct tables
+        self.c_key_range = (int(C["c_custkey"].min()), int(C["c_custkey"].max())) if self.nc else None
         self.c_seg = D(ctx, hip.PH_CODE8, C["c_mktsegment"])
         self.o_key = D(ctx, hip.PH_I64, O["o_orderkey"])
         self.o_cust = D(ctx, hip.PH_I32, O["o_custkey"])
@@ -85,7 +87,7 @@ class Q3Pipeline:
             # chain step of the probe); the build-side row ids of this join are never used
             ck = hip.gather(ctx, self.c_key, cs, cn)
             frees.append(ck)
-            j1 = hip.Join(ctx, [_raw(hip.PH_I32, ck)], None, cn)
+            j1 = hip.Join(ctx, [_raw(hip.PH_I32, ck)], None, cn, key_range=self.c_key_range)
         else:
             mine = hip.gather(ctx, self.c_key, cs, cn)
             allkeys, nall = dist.allgather_rows(ctx, mine, cn, np.int32)   # broadcast of the small build side
@@ -253,6 +255,9 @@ class Q9Pipeline:
         self.ps_supp = D(ctx, hip.PH_I32, PS["ps_suppkey"])
         self.ps_cost = D(ctx, hip.PH_DEC64, PS["ps_supplycost"], 2)
         self.s_key = D(ctx, hip.PH_I32, S["s_suppkey"])
+        # column statistics: dense primary keys (supplier, orders) build direct tables
+        self.s_key_range = (int(S["s_suppkey"].min()), int(S["s_suppkey"].max())) if self.n["s"] else None
+        self.o_key_range = (int(O["o_orderkey"].min()), int(O["o_orderkey"].max())) if self.n["o"] else None
         self.s_nat = D(ctx, hip.PH_I32, S["s_nationkey"])
         self.o_key = D(ctx, hip.PH_I64, O["o_orderkey"])
         self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
@@ -360,7 +365,7 @@ class Q9Pipeline:
 
         t0 = tic()
         if N == 1:
-            js = hip.Join(ctx, [self.s_key], None, self.n["s"])
+            js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range)
             s_nat = self.s_nat
         else:
             ident = ctx.upload(np.arange(self.n["s"], dtype=np.int32))
@@ -422,7 +427,7 @@ class Q9Pipeline:
         # node table (was 0.65 ms with one atomic per row, which is why round 1 built the 3.3 M-row
         # intermediate instead and probed it with all 15 M orders: 0.83 ms for the stage).
         if jo is None:
-            jo = hip.Join(ctx, [self.o_key], None, self.n["o"])
+            jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range)
         hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
         orow = jo.lookup([_raw(hip.PH_I64, c_okey)], None, m, stats)
         jo.free()

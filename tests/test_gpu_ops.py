@@ -481,7 +481,7 @@ def test_agg_128bit_sums(ctx):
 
 # ------------------------------------------------------------------ hash join
 
-def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None):
+def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None, key_range=None, kind=None):
     """bkeys/pkeys: lists of (hip type, oracle type, array, validity)"""
     db = [hip.DevColumn(ctx, ht, a, validity=v) for ht, _, a, v in bkeys]
     dp = [hip.DevColumn(ctx, ht, a, validity=v) for ht, _, a, v in pkeys]
@@ -492,7 +492,9 @@ def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None):
     ps = ctx.upload(psel.astype(np.int32)) if psel is not None else None
     mb = len(bsel) if bsel is not None else nb
     mp = len(psel) if psel is not None else np_
-    j = hip.Join(ctx, db, bs, mb)
+    j = hip.Join(ctx, db, bs, mb, key_range=key_range)
+    if kind is not None:
+        assert j.kind == kind
     oj = O.Join(ob, None if bsel is None else bsel.astype(np.int64), mb)
     assert j.count() == oj.count()
     cap = 1 << 22
@@ -572,6 +574,65 @@ def test_join_partitioned_build_and_fast_kernels(ctx):
     vp, _ = rnd_validity(rng, 260_000, 0.05)
     join_compare(ctx, [(hip.PH_I32, O.OT_INT32, b0, vb), (hip.PH_I32, O.OT_INT32, b1, None)],
                  [(hip.PH_I32, O.OT_INT32, p0, None), (hip.PH_I32, O.OT_INT32, p1, vp)])
+
+
+def test_join_direct_table_dense_keys(ctx):
+    """ph_join_build_range: a dense key range (<= 8 slots per build row) builds a direct table
+    addressed by key - lo. Every probe form returns what the hash tables return (oracle = the
+    reference's chained table): unique keys with selections on both sides, duplicate build keys
+    (linked after the plain-store scatter), NULL keys on both sides, a negative lower bound, probe
+    keys outside the range, the fused Filter -> probe, the lookup probe; sparse ranges and
+    PH_JOIN_DIRECT=0 keep the hash tables; a build key outside the stated range is an error."""
+    import os
+    rng = np.random.default_rng(31)
+    nb, np_ = 300_000, 700_000
+    b = (rng.permutation(1_000_000)[:nb] + 5_000).astype(np.int64)          # unique, range 1e6 <= 8 * nb
+    p = rng.integers(0, 1_100_000, np_).astype(np.int64)                     # some below lo, some above hi
+    bsel = np.sort(rng.choice(nb, 200_000, replace=False))
+    psel = np.sort(rng.choice(np_, 400_000, replace=False))
+    rngk = (5_000, 1_004_999)
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="direct")
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], bsel, psel, key_range=rngk, kind="direct")
+    # duplicates (~8 per key, one key 5000 times), int32 keys, negative lower bound, NULLs on both sides
+    bd = (rng.integers(0, 5000, 40_000) - 2500).astype(np.int32)
+    bd[:5000] = 17
+    pd_ = (rng.integers(0, 6000, 30_000) - 3000).astype(np.int32)
+    vb, _ = rnd_validity(rng, len(bd), 0.1)
+    vp, _ = rnd_validity(rng, len(pd_), 0.1)
+    m = join_compare(ctx, [(hip.PH_I32, O.OT_INT32, bd, None)], [(hip.PH_I32, O.OT_INT32, pd_, None)], key_range=(-2500, 2499), kind="direct")
+    assert m > 100_000
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, bd, vb)], [(hip.PH_I32, O.OT_INT32, pd_, vp)],
+                 np.sort(rng.choice(len(bd), 30_000, replace=False)), np.sort(rng.choice(len(pd_), 20_000, replace=False)),
+                 key_range=(-2500, 2499), kind="direct")
+    # sparse range / switched off: the hash tables, same results
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b[:1000], None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="chained+bloom")
+    os.environ["PH_JOIN_DIRECT"] = "0"
+    try:
+        join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="chained+bloom")
+    finally:
+        os.environ.pop("PH_JOIN_DIRECT")
+    # lookup probe + fused Filter -> probe against the hash table's answers
+    db, dp = hip.DevColumn(ctx, hip.PH_I64, b), hip.DevColumn(ctx, hip.PH_I64, p)
+    w = rng.integers(0, 100, np_).astype(np.int32)
+    dw = hip.DevColumn(ctx, hip.PH_I32, w)
+    jd, jh = hip.Join(ctx, [db], None, nb, key_range=rngk), hip.Join(ctx, [db], None, nb)
+    assert jd.kind == "direct" and jh.kind == "chained+bloom" and jd.count() == jh.count() == nb
+    st = ctx.upload(np.zeros(2, np.int32))
+    got = ctx.download(jd.lookup([dp], None, np_, st), np.int32, np_)
+    want = ctx.download(jh.lookup([dp], None, np_), np.int32, np_)
+    assert np.array_equal(got, want) and ctx.download(st, np.int32, 2).tolist() == [int((want < 0).sum()), 0]
+    rd = jd.probe_inner_where([dp], dw, hip.PH_LT, hip.const(hip.PH_I32, i=40), None, np_, np_)
+    rh = jh.probe_inner_where([dp], dw, hip.PH_LT, hip.const(hip.PH_I32, i=40), None, np_, np_)
+    assert rd is not None and rh is not None and rd[0] == rh[0] == int(((want >= 0) & (w < 40)).sum())
+    for x, y in ((rd[1], rh[1]), (rd[2], rh[2])):
+        assert np.array_equal(ctx.download(x, np.int32, rd[0]), ctx.download(y, np.int32, rd[0]))
+    jd.free(); jh.free()
+    # a build key outside the stated range: reported by ph_join_count
+    jbad = hip.Join(ctx, [db], None, nb, key_range=(5_000, 900_000))
+    assert jbad.kind == "direct" and jbad.count() == -1 and "outside the stated range" in hip.last_error()
+    jbad.free()
+    for c in (db, dp, dw):
+        c.free()
 
 
 def test_q3_pipeline_operator_granular(ctx, sf001):
