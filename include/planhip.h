@@ -43,6 +43,7 @@ extern "C" {
 #define PH_EUNSUPPORTED (-3)/* expression / type shape outside the device path: caller falls back */
 #define PH_EOVERFLOW (-4)   /* decimal arithmetic would leave the exact int64/int128 domain */
 #define PH_ECAPACITY (-5)   /* an output buffer supplied by the caller is too small */
+#define PH_ECONSTRAINT (-6) /* a strict lookup met a probe row without exactly one build row */
 
 typedef struct ph_ctx ph_ctx;
 
@@ -53,6 +54,17 @@ int ph_ctx_create(int device, ph_ctx **out);
 /* Use an existing stream (e.g. the caller's torch stream) for all later calls; NULL = own stream */
 int ph_ctx_set_stream(ph_ctx *ctx, void *hip_stream);
 int ph_ctx_sync(ph_ctx *ctx);
+/* Deferred errors. A call that only reads a FLAG back (ph_expr_eval's overflow flag) stalls the
+ * stream for a host round trip (~25-45 us of idle GPU) although the flag is almost never set. With
+ * `on` != 0 such flags stay on the device and the NEXT call on this ctx that reads anything back
+ * (a count, a result download, ph_ctx_check_deferred) fetches them in the same synchronisation and
+ * returns the deferred error (PH_EOVERFLOW / PH_ECONSTRAINT, ph_last_error names the origin)
+ * instead of its own success: everything computed since the failing call must be discarded, which
+ * is what a query does with PH_EOVERFLOW anyway (it falls back as a whole). Off by default: every
+ * call then reports its own errors, like the reference's operators do per chunk. */
+int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on);
+/* synchronise and report a pending deferred error (PH_OK when none is pending) */
+int ph_ctx_check_deferred(ph_ctx *ctx);
 void ph_ctx_destroy(ph_ctx *ctx);
 
 /* ------------------------------------------------------------------ columns */
@@ -171,7 +183,8 @@ int ph_expr_scale(const ph_col *cols, const ph_rpn *prog, int32_t nprog, int32_t
 /* out_dev[i] = value of row sel[i] (or i), unscaled at ph_expr_scale's scale. Every add/sub/mul
  * is overflow-checked on the device; if any row leaves the int64 domain the call returns
  * PH_EOVERFLOW (the reference's govalues arithmetic would start rounding there, so the caller
- * must fall back). NULL inputs give a NULL result: out_validity_dev (bitmap, may be NULL when no
+ * must fall back; with ph_ctx_set_deferred_errors the error is reported by the next call that
+ * reads back instead). NULL inputs give a NULL result: out_validity_dev (bitmap, may be NULL when no
  * input column has validity) receives the result validity. */
 int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *prog,
                  int32_t nprog, const int32_t *sel, int64_t n, int64_t *out_dev,
@@ -253,6 +266,12 @@ int ph_agg_jit_selfcheck(int32_t which);
  *   count[g*naggs+a] = non-NULL inputs seen (COUNT_STAR: rows). */
 int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
                     uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
+/* ph_agg_finalize that also reports the group count, so a caller with room for max_groups groups
+ * needs no ph_agg_group_count first: ONE host round trip for the whole result when header + records
+ * fit 64 KiB (the records are packed on the device, which reads the count there). *ngroups is set
+ * even when it exceeds max_groups (PH_ECAPACITY: call again with room). */
+int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
+                 uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
 /* Top-N pre-selection for an `ORDER BY <aggregate> [DESC] ... LIMIT k` tail (the reference's
  * orderExecutor + limit, executor_order.go:56-138, executor_limit.go:105-238, sort over all group
  * rows on the host). A one-workgroup radix select finds the k-th best value
@@ -317,6 +336,14 @@ int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64
  * caller can verify the uniqueness it assumed with one read at the end of a pipeline. */
 int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev,
                    int32_t *stats_dev);
+/* ph_join_lookup for foreign keys the plan trusts (every probe row has exactly one build row): no
+ * statistics buffer and no host read. A probe row without a match (out = -1) or with several is a
+ * DEFERRED error: the next call on this ctx that reads anything back from the device (a count, a
+ * result download, ph_ctx_check_deferred) fails with PH_ECONSTRAINT instead, and the caller reruns
+ * the stage with ph_join_lookup / ph_join_probe_inner. ph_gather, ph_gather_multi and ph_date_extract
+ * read row 0 for a negative row id, so the positional pipeline behind a strict lookup stays in
+ * bounds until the error is seen. */
+int ph_join_lookup_strict(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev);
 void ph_join_free(ph_join *j);
 
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:

@@ -82,6 +82,15 @@ struct ph_ctx {
     unsigned scan_ticket_base = 0;
     unsigned long long scan_epoch = 0;
     int download(void *host, const void *dev, int64_t bytes);
+    // Deferred errors (ph_ctx_set_deferred_errors): device words that kernels of calls which would
+    // otherwise read a flag back (ph_expr_eval's overflow flag, ph_join_lookup_strict's miss / multi-
+    // match counts) OR / add into; the next download() of this ctx fetches them in the same stream
+    // synchronisation and fails with the deferred error. [0] overflow, [1] lookup misses, [2] lookup
+    // multi-matches.
+    int *deferred_dev = nullptr;
+    bool defer_errors = false, deferred_pending = false;
+    int deferred_words(int **out);   // allocates (zeroed) on first use
+    int finish_deferred();           // after a sync that also copied the words into the mailbox tail
     // Stream-ordered device memory pool: freed blocks are reused by later allocations of the
     // same rounded size without hipFree/hipMalloc (both synchronise the device). Safe because
     // every kernel and copy of a ctx runs on its one stream.

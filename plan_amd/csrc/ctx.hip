@@ -52,15 +52,39 @@ int ph_ctx::ensure_pinned(int64_t bytes) {
     return PH_OK;
 }
 
+constexpr int64_t PH_MAILBOX = 64 << 10;   // + 64 bytes behind it for the deferred-error words
+
+int ph_ctx::deferred_words(int **out) {
+    if (!deferred_dev) {
+        PH_HIP(hipMalloc((void **)&deferred_dev, 64));
+        PH_HIP(hipMemsetAsync(deferred_dev, 0, 64, stream));
+    }
+    *out = deferred_dev;
+    return PH_OK;
+}
+
+int ph_ctx::finish_deferred() {
+    deferred_pending = false;
+    const int *d = reinterpret_cast<const int *>((const char *)mailbox + PH_MAILBOX);
+    if (!d[0] && !d[1] && !d[2]) return PH_OK;
+    const int ovf = d[0], miss = d[1], multi = d[2];
+    PH_HIP(hipMemsetAsync(deferred_dev, 0, 64, stream));
+    if (ovf) { ph::set_error("deferred from ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
+    ph::set_error("deferred from ph_join_lookup_strict: %d probe rows without a match, %d with more than one", miss, multi);
+    return PH_ECONSTRAINT;
+}
+
 int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
     if (bytes <= 0) return PH_OK;
-    const int64_t MB = 64 << 10;
-    if (!mailbox) PH_HIP(hipHostMalloc(&mailbox, (size_t)MB, hipHostMallocDefault));
+    const int64_t MB = PH_MAILBOX;
+    if (!mailbox) PH_HIP(hipHostMalloc(&mailbox, (size_t)MB + 64, hipHostMallocDefault));
+    const bool chk = deferred_pending && deferred_dev;
+    if (chk) PH_HIP(hipMemcpyAsync((char *)mailbox + MB, deferred_dev, 16, hipMemcpyDeviceToHost, stream));
     if (bytes <= MB) {
         PH_HIP(hipMemcpyAsync(mailbox, dev, (size_t)bytes, hipMemcpyDeviceToHost, stream));
         PH_HIP(hipStreamSynchronize(stream));
         memcpy(host, mailbox, (size_t)bytes);
-        return PH_OK;
+        return chk ? finish_deferred() : PH_OK;
     }
     const int64_t CH = 32ll << 20;
     PH_CHECK(ensure_pinned(2 * CH));
@@ -86,7 +110,21 @@ int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc != PH_OK) ph::set_error("device-to-host copy of %lld bytes failed", (long long)bytes);
+    if (rc == PH_OK && chk) rc = finish_deferred();
     return rc;
+}
+
+extern "C" int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on) {
+    PH_REQUIRE(ctx, "ph_ctx_set_deferred_errors: ctx is NULL");
+    ctx->defer_errors = on != 0;
+    return PH_OK;
+}
+
+extern "C" int ph_ctx_check_deferred(ph_ctx *ctx) {
+    PH_REQUIRE(ctx, "ph_ctx_check_deferred: ctx is NULL");
+    if (!ctx->deferred_pending || !ctx->deferred_dev) return PH_OK;
+    int d[4];
+    return ctx->download(d, ctx->deferred_dev, 16);
 }
 
 int ph_ctx::pool_alloc(int64_t bytes, void **out) {
@@ -175,6 +213,7 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
+    if (ctx->deferred_dev) (void)hipFree(ctx->deferred_dev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

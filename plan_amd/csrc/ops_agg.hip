@@ -621,6 +621,12 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
     return PH_OK;
 }
 
+// initial capacity: the reference starts at 2*2048 entries (aggregate_exec.go:332-339)
+int agg_ensure(ph_agg *a, int64_t min_cap = 0) {
+    if (a->cap != 0) return PH_OK;
+    return agg_resize(a, std::max(min_cap, next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups))), 0);
+}
+
 }  // namespace
 
 extern "C" void ph_agg_free(ph_agg *a) {
@@ -657,8 +663,9 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
         rc = PH_EHIP;
     }
     // initial capacity: the reference starts at 2*2048 entries (aggregate_exec.go:332-339)
+    // the table itself is allocated by the first call that needs it (agg_ensure): the first sink knows
+    // its row count and sizes the table once instead of replacing the hint-sized one
     a->expected_groups = expected_groups;
-    if (rc == PH_OK) rc = agg_resize(a, next_pow2(std::max<int64_t>(4096, 2 * expected_groups)), 0);
     if (rc != PH_OK) { ph_agg_free(a); return rc; }
     *out = a;
     return PH_OK;
@@ -666,6 +673,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
 
 extern "C" int ph_agg_group_count(ph_agg *a, int64_t *ngroups) {
     PH_REQUIRE(a && ngroups, "ph_agg_group_count: bad arguments");
+    if (a->cap == 0) { *ngroups = 0; return PH_OK; }   // nothing sunk yet
     int c[2] = {0, 0};
     PH_CHECK(a->ctx->download(c, a->counters, 8));
     if (c[1]) { ph::set_error("ph_agg: device table error flag %d", c[1]); return PH_EHIP; }
@@ -721,7 +729,7 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     // capacity: when it is affordable make growth impossible (capacity > rows), else start from
     // the hint and let the build report an overflow
     const bool sure = n <= (4ll << 20);
-    int64_t cap = a->cap;
+    int64_t cap = a->cap ? a->cap : next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups));
     if (sure) while (cap / 2 <= n) cap *= 2;
     else cap = std::max(cap, next_pow2(4 * a->expected_groups));
     if (cap != a->cap) PH_CHECK(agg_resize(a, cap, 0));
@@ -800,8 +808,9 @@ int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, ph::JitKernel *out)
     const char *e = getenv("PH_AGG_JIT");   // read per call: tests compare both kernels in one process
     if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
     std::string key;
-    std::string src = agg_spec_defines(P, &key) + AGG_SINK_SRC;
-    int rc = ph::jit_module(ctx, key, src, "agg_sink_spec", out);
+    std::string defs = agg_spec_defines(P, &key);
+    if (ph::jit_cached(ctx, key, out)) return PH_OK;   // no 20 KB source concatenation on a hit
+    int rc = ph::jit_module(ctx, key, defs + AGG_SINK_SRC, "agg_sink_spec", out);
     return rc == PH_OK ? PH_OK : PH_EUNSUPPORTED;
 }
 
@@ -949,6 +958,15 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     int rc = PH_OK;
     if (hipMemsetAsync(progress, 0, (size_t)grid * 4, a->ctx->stream) != hipSuccess ||
         hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
+    // First sink into an empty table of up to 8 M rows: size the table so that growth is impossible
+    // (capacity/2 > rows). The group count and the need-grow flag then never cross PCIe — two host
+    // round trips (~50 us of idle GPU) against one larger memset of the slot array (32 MiB: 9 us).
+    if (rc == PH_OK && a->rows_sunk == 0 && n <= (8ll << 20)) {
+        int64_t want = a->cap ? a->cap : next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups));
+        while (want / 2 <= n) want *= 2;
+        if (want != a->cap) rc = agg_resize(a, want, 0);
+    }
+    if (rc == PH_OK) rc = agg_ensure(a);
     // the table cannot hold more groups than rows were sunk into it: while that bound plus this
     // call's rows fits, no growth is possible and neither the group count nor the need-grow flag
     // has to cross PCIe
@@ -962,7 +980,8 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     while (rc == PH_OK) {
         int64_t ng = a->rows_sunk;
         if (!sure) {
-            if ((rc = ph_agg_group_count(a, &ng)) != PH_OK) break;
+            if (a->rows_sunk == 0) ng = 0;   // an empty table: nothing to ask the device
+            else if ((rc = ph_agg_group_count(a, &ng)) != PH_OK) break;
             int64_t cap = a->cap;
             while (cap / 2 - ng <= P.slack) cap *= 2;   // gcap = cap/2 must exceed the in-flight rows
             if (cap != a->cap && (rc = agg_resize(a, cap, (int)ng)) != PH_OK) break;
@@ -1007,41 +1026,50 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     return PH_OK;
 }
 
-extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
-                               uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
-    PH_REQUIRE(a && max_groups >= 0, "ph_agg_finalize: bad arguments");
+// One host round trip: the records of up to max_groups groups are packed on the device (the kernel
+// reads the group count there) and header + records come back in one copy when they fit the mailbox
+// (64 KiB; otherwise the header first, then exactly the records that exist).
+extern "C" int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
+                            uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && ngroups && max_groups >= 0, "ph_agg_fetch: bad arguments");
+    *ngroups = 0;
+    if (a->cap == 0) return PH_OK;   // nothing sunk yet
+    ph_ctx *cx = a->ctx;
+    const size_t rec = 2 + (size_t)a->nkeys + 3 * (size_t)a->naggs;
+    const int64_t cap = std::min<int64_t>(max_groups, a->gcap);
+    unsigned long long *pack = nullptr;
+    PH_CHECK(cx->pool_alloc((int64_t)(2 + (size_t)cap * rec) * 8, (void **)&pack));
+    ph::agg_pack_kernel<<<(int)std::max<int64_t>(1, std::min<int64_t>((cap + 255) / 256, 1024)), 256, 0, cx->stream>>>(
+        nullptr, a->counters, a->counters, (int)cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
+    std::vector<unsigned long long> host(2 + (size_t)cap * rec);
+    int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
+    const bool one_copy = (int64_t)host.size() * 8 <= (64 << 10);
+    if (rc == PH_OK) rc = cx->download(host.data(), pack, one_copy ? (int64_t)host.size() * 8 : 16);
     int64_t ng = 0;
-    PH_CHECK(ph_agg_group_count(a, &ng));
-    if (ng > max_groups) { ph::set_error("ph_agg_finalize: %lld groups, room for %lld", (long long)ng, (long long)max_groups); return PH_ECAPACITY; }
-    if (ng == 0) return PH_OK;
+    if (rc == PH_OK) {
+        const int *h = reinterpret_cast<const int *>(host.data());   // {group count, error flag, group count, error flag}
+        ng = h[0];
+        *ngroups = ng;
+        if (h[1]) { ph::set_error("ph_agg: device table error flag %d", h[1]); rc = PH_EHIP; }
+        else if (ng > max_groups) { ph::set_error("ph_agg_fetch: %lld groups, room for %lld", (long long)ng, (long long)max_groups); rc = PH_ECAPACITY; }
+        else if (!one_copy && ng > 0) rc = cx->download(host.data() + 2, pack + 2, (int64_t)((size_t)ng * rec) * 8);
+    }
+    cx->pool_release(pack);
+    if (rc != PH_OK || ng == 0) return rc;
     size_t na = (size_t)std::max(a->naggs, 1), g = (size_t)ng;
     std::vector<long long> fr(g);
     std::vector<unsigned long long> gk(g * a->nkeys), lo(g * na), cn(g * na);
     std::vector<long long> hi(g * na);
     std::vector<unsigned> gn(g);
-    ph_ctx *cx = a->ctx;
-    {
-        // the group records are packed on the device and come back in ONE copy (six per-array copies
-        // were six stream synchronisations: ~0.12 ms of a 2 ms Q9)
-        const size_t rec = 2 + (size_t)a->nkeys + 3 * (size_t)a->naggs;
-        unsigned long long *pack = nullptr;
-        PH_CHECK(cx->pool_alloc((int64_t)(2 + g * rec) * 8, (void **)&pack));
-        ph::agg_pack_kernel<<<(int)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024)), 256, 0, cx->stream>>>(
-            nullptr, a->counters, a->counters, (int)ng, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
-        std::vector<unsigned long long> host(2 + g * rec);
-        int rc = hipGetLastError() == hipSuccess ? cx->download(host.data(), pack, (int64_t)host.size() * 8) : PH_EHIP;
-        cx->pool_release(pack);
-        if (rc != PH_OK) return rc;
-        for (size_t i = 0; i < g; i++) {
-            const unsigned long long *o = host.data() + 2 + i * rec;
-            fr[i] = (long long)o[0];
-            gn[i] = (unsigned)o[1];
-            for (int c = 0; c < a->nkeys; c++) gk[i * a->nkeys + c] = o[2 + c];
-            for (int q = 0; q < a->naggs; q++) {
-                lo[i * na + q] = o[2 + a->nkeys + q];
-                hi[i * na + q] = (long long)o[2 + a->nkeys + a->naggs + q];
-                cn[i * na + q] = o[2 + a->nkeys + 2 * a->naggs + q];
-            }
+    for (size_t i = 0; i < g; i++) {
+        const unsigned long long *o = host.data() + 2 + i * rec;
+        fr[i] = (long long)o[0];
+        gn[i] = (unsigned)o[1];
+        for (int c = 0; c < a->nkeys; c++) gk[i * a->nkeys + c] = o[2 + c];
+        for (int q = 0; q < a->naggs; q++) {
+            lo[i * na + q] = o[2 + a->nkeys + q];
+            hi[i * na + q] = (long long)o[2 + a->nkeys + a->naggs + q];
+            cn[i * na + q] = o[2 + a->nkeys + 2 * a->naggs + q];
         }
     }
     // first-seen order = the reference's insertion order (GroupedAggrHashTable.Scan, :424-438)
@@ -1069,6 +1097,13 @@ extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row
     return PH_OK;
 }
 
+extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,
+                               uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && max_groups >= 0, "ph_agg_finalize: bad arguments");
+    int64_t ng = 0;
+    return ph_agg_fetch(a, max_groups, &ng, first_row, keys, key_null, sum_lo, sum_hi, count);
+}
+
 extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int64_t k, int64_t max_groups,
                            int64_t *n_out, int64_t *first_row, int64_t *keys, uint8_t *key_null,
                            uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
@@ -1081,7 +1116,7 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
         return PH_EUNSUPPORTED;
     }
     *n_out = 0;
-    if (k == 0 || max_groups == 0) return PH_OK;
+    if (k == 0 || max_groups == 0 || a->cap == 0) return PH_OK;
     ph_ctx *ctx = a->ctx;
     // The group count stays on the device: every kernel reads it there, grids are sized from the
     // table's capacity, and the header + first records come back in one copy (one host round trip

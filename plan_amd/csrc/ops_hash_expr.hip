@@ -256,12 +256,18 @@ struct ExprJitParams {
     long long k[ph::X_MAX_OPS * 2];
 };
 
+std::string expr_jit_key(const ph::XParams &X, bool has_sel, bool out_valid) {
+    std::string k = "expr:";
+    k += has_sel ? 's' : '-';
+    k += out_valid ? 'v' : '-';
+    for (int c = 0; c < X.ncols; c++) { k += '|'; k += std::to_string(X.c[c].type); if (X.c[c].validity) k += 'n'; }
+    for (int p = 0; p < X.nops; p++) { k += ','; k += std::to_string(X.ins[p].op); k += ':'; k += std::to_string(X.ins[p].col); }
+    return k;
+}
+
 std::string expr_jit_source(const ph::XParams &X, bool has_sel, bool out_valid, std::string *key) {
-    std::ostringstream o, kk;
-    kk << "expr:" << (has_sel ? "s" : "-") << (out_valid ? "v" : "-");
-    for (int c = 0; c < X.ncols; c++) kk << "|" << X.c[c].type << (X.c[c].validity ? "n" : "");
-    for (int p = 0; p < X.nops; p++) kk << "," << X.ins[p].op << ":" << X.ins[p].col;
-    *key = kk.str();
+    std::ostringstream o;
+    *key = expr_jit_key(X, has_sel, out_valid);
     constexpr int U = 4;
     o << "typedef long long i64;\n"
       << "struct EP { const void *c[" << ph::X_MAX_COLS << "]; const unsigned char *v[" << ph::X_MAX_COLS << "]; const int *sel; i64 n; i64 *out; "
@@ -324,10 +330,12 @@ int expr_jit_run(ph_ctx *ctx, const ph::XParams &X, const ph_col *cols, const in
                  uint8_t *out_valid, int *flag) {
     const char *e = getenv("PH_EXPR_JIT");
     if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
-    std::string key;
-    std::string src = expr_jit_source(X, sel != nullptr, out_valid != nullptr, &key);
+    std::string key = expr_jit_key(X, sel != nullptr, out_valid != nullptr);
     ph::JitKernel kn;
-    if (ph::jit_module(ctx, key, src, "expr_jit", &kn) != PH_OK) return PH_EUNSUPPORTED;
+    if (!ph::jit_cached(ctx, key, &kn)) {   // the source is only generated on a miss
+        std::string src = expr_jit_source(X, sel != nullptr, out_valid != nullptr, &key);
+        if (ph::jit_module(ctx, key, src, "expr_jit", &kn) != PH_OK) return PH_EUNSUPPORTED;
+    }
     ExprJitParams P{};
     for (int c = 0; c < X.ncols; c++) { P.c[c] = cols[c].data; P.v[c] = cols[c].validity; }
     P.sel = sel; P.n = n; P.out = out; P.out_valid = out_valid; P.flag = flag;
@@ -388,15 +396,22 @@ extern "C" int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, cons
     }
     if (any_validity && !out_validity_dev) { ph::set_error("ph_expr_eval: inputs carry validity but out_validity_dev is NULL"); return PH_EINVAL; }
     if (n == 0) return PH_OK;
-    PH_CHECK(ctx->ensure_scratch(64));
-    int *flag = (int *)ctx->scratch;
-    PH_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    // deferred errors: the overflow flag is one of the ctx's deferred words, read back by the next
+    // call that synchronises anyway — no memset, no round trip here (~45 us of idle GPU per call)
+    int *flag = nullptr;
+    if (ctx->defer_errors) PH_CHECK(ctx->deferred_words(&flag));
+    else {
+        PH_CHECK(ctx->ensure_scratch(64));
+        flag = (int *)ctx->scratch;
+        PH_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    }
     // batches large enough to repay a one-time compile run the kernel generated for this expression
     if (n < (1 << 18) || expr_jit_run(ctx, X, cols, sel, n, (long long *)out_dev, out_validity_dev, flag) != PH_OK) {
         int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
         ph::expr_kernel<<<grid, 256, 0, ctx->stream>>>(X, sel, n, (long long *)out_dev, out_validity_dev, flag);
         PH_HIP(hipGetLastError());
     }
+    if (ctx->defer_errors) { ctx->deferred_pending = true; return PH_OK; }
     int host_flag = 0;
     PH_CHECK(ctx->download(&host_flag, flag, 4));
     if (host_flag) { ph::set_error("ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
@@ -410,7 +425,8 @@ __global__ __launch_bounds__(256) void date_extract_kernel(int part, const int32
                                                            int32_t *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         int32_t y, m, d;
-        civil_from_days(days[sel ? sel[i] : i], &y, &m, &d);
+        const int64_t r = sel ? (int64_t)sel[i] : i;
+        civil_from_days(days[r < 0 ? 0 : r], &y, &m, &d);   // a negative row id (a strict lookup's miss, reported later) reads row 0
         out[i] = part == PH_PART_YEAR ? y : (part == PH_PART_MONTH ? m : d);
     }
 }

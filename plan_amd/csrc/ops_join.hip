@@ -1247,6 +1247,7 @@ constexpr int DT = 1024;
 
 __device__ __forceinline__ void direct_block_add(int v0, int v1, int *__restrict__ c0, int *__restrict__ c1) {
     __shared__ int part[2][DT / 64];
+    __syncthreads();   // a second call in one kernel reuses the array
     for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = v0; part[1][threadIdx.x >> 6] = v1; }
     __syncthreads();
@@ -1282,6 +1283,30 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(const void *__restri
         }
     }
     direct_block_add(ins, out, count, count + 2);
+}
+
+// small build sides (<= 256 K rows): ONE kernel after the initialisation — head insertion with
+// atomicExch as in join_build_kernel (a few microseconds of scattered atomics at this size, against
+// four more launches at ~5 us each), which links duplicate keys on the spot
+template <int KW, bool SEL>
+__global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
+                                                         const int32_t *__restrict__ sel, int64_t n, long long lo,
+                                                         unsigned long long range, int32_t *__restrict__ direct,
+                                                         int32_t *__restrict__ next, int *__restrict__ count) {
+    int ins = 0, first = 0, out = 0;
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
+        unsigned long long off;
+        bool oor = false;
+        if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) {
+            const int32_t old = atomicExch(&direct[off], (int32_t)i);
+            next[i] = old;
+            ins++;
+            first += old < 0;
+        } else next[i] = -2;
+        out += oor;
+    }
+    direct_block_add(ins, first, count, count + 1);   // rows stored, slots occupied
+    direct_block_add(out, 0, count + 2, nullptr);
 }
 
 // occupied slots of the table (cap4 is a multiple of 4; the padding slots are -1)
@@ -1672,6 +1697,13 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
         const void *kcol = B.key[0].data;
         const uint8_t *valid = B.key[0].validity;
+        if (n <= (256 << 10)) {
+            const int grids = (int)std::min<int64_t>((n + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
+            PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+            PH_HIP(hipGetLastError());
+            j->count = -1;
+            return PH_OK;
+        }
         // one 1024-thread workgroup per CU for the two passes that end in a counter update
         const int gridc = (int)std::min<int64_t>((n + ph::DT * 4 - 1) / (ph::DT * 4), (int64_t)ctx->cu_count);
         const int grido = (int)std::min<int64_t>((cap4 / 4 + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
@@ -2136,6 +2168,17 @@ static void launch_lookup_fast(int grid, hipStream_t st, const ph::JoinSide &B, 
     else PH_LU_LAUNCH(1);
 #undef PH_LU_LAUNCH
 #undef PH_LU_ARGS
+}
+
+extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev, int32_t *stats_dev);
+
+extern "C" int ph_join_lookup_strict(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev) {
+    PH_REQUIRE(j, "ph_join_lookup_strict: join is NULL");
+    int *words = nullptr;
+    PH_CHECK(j->ctx->deferred_words(&words));
+    int rc = ph_join_lookup(j, keys, sel, n, out_build_dev, words + 1);   // [1] misses, [2] multi-matches
+    if (rc == PH_OK && n > 0) j->ctx->deferred_pending = true;
+    return rc;
 }
 
 extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev,

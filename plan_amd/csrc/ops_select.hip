@@ -813,6 +813,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ src, 
         for (int u = 0; u < U; u++) {
             const int64_t i = base + u * 256 + threadIdx.x;
             ix[u] = idx[i < n ? i : 0];
+            ix[u] = ix[u] < 0 ? 0 : ix[u];   // a negative row id (a strict lookup's miss, reported later) reads row 0
         }
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = src[ix[u]];
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherMulti G, const 
         for (int u = 0; u < U; u++) {
             const int64_t i = base + u * 256 + threadIdx.x;
             ix[u] = idx[i < n ? i : 0];
+            ix[u] = ix[u] < 0 ? 0 : ix[u];
         }
 #pragma unroll
         for (int c = 0; c < GM_MAX; c++) {

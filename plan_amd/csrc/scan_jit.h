@@ -64,5 +64,7 @@ int jit_launch(ph_ctx *ctx, const JitKernel &k, const JitParams &p, int grid);
 // generic: compile `src` for the ctx's device (cached by key for the process lifetime) and return `entry`
 int jit_module(ph_ctx *ctx, const std::string &key, const std::string &src, const char *entry, JitKernel *out);
 int jit_compile_only(const std::string &src, const char *arch, std::string *log);
+// cache probe by key alone: a hit skips generating the source (tens of microseconds per call)
+bool jit_cached(ph_ctx *ctx, const std::string &key, JitKernel *out);
 
 }  // namespace ph

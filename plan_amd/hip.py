@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-PH_OK, PH_EINVAL, PH_EHIP, PH_EUNSUPPORTED, PH_EOVERFLOW, PH_ECAPACITY = 0, -1, -2, -3, -4, -5
+PH_OK, PH_EINVAL, PH_EHIP, PH_EUNSUPPORTED, PH_EOVERFLOW, PH_ECAPACITY, PH_ECONSTRAINT = 0, -1, -2, -3, -4, -5, -6
 PH_I32, PH_I64, PH_DATE, PH_DEC64, PH_CODE8, PH_F32, PH_F64, PH_STR = range(1, 9)
 PH_EQ, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE = range(1, 9)
 PH_X_COL, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL = range(1, 6)
@@ -167,6 +167,14 @@ class Ctx:
 
     def sync(self):
         check(lib().ph_ctx_sync(self.h))
+
+    def set_deferred_errors(self, on=True):
+        """flags that would cost a host round trip each (expression overflow) are reported by the next
+        call that reads anything back (ph_ctx_set_deferred_errors)"""
+        check(lib().ph_ctx_set_deferred_errors(self.h, i32(1 if on else 0)))
+
+    def check_deferred(self):
+        check(lib().ph_ctx_check_deferred(self.h))
 
     def close(self):
         if self.h:
@@ -468,18 +476,27 @@ class Agg:
         check(lib().ph_agg_group_count(self.h, ctypes.byref(n)))
         return n.value
 
-    def finalize(self, python_ints=True):
-        ng = self.group_count()
-        m = max(ng, 1)
-        first = np.zeros(m, np.int64)
-        keys = np.zeros(m * self.nkeys, np.int64)
-        knull = np.zeros(m * self.nkeys, np.uint8)
+    def finalize(self, python_ints=True, room=1024):
+        """ph_agg_fetch with room for `room` groups first (one host round trip when they fit), again
+        with the reported count when there are more"""
         na = max(self.naggs, 1)
-        lo = np.zeros(m * na, np.uint64)
-        hi = np.zeros(m * na, np.int64)
-        cnt = np.zeros(m * na, np.uint64)
         P = lambda a: vp(a.ctypes.data)
-        check(lib().ph_agg_finalize(self.h, i64(m), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt)))
+        m = max(room, 1)
+        while True:
+            first = np.zeros(m, np.int64)
+            keys = np.zeros(m * self.nkeys, np.int64)
+            knull = np.zeros(m * self.nkeys, np.uint8)
+            lo = np.zeros(m * na, np.uint64)
+            hi = np.zeros(m * na, np.int64)
+            cnt = np.zeros(m * na, np.uint64)
+            n = i64()
+            rc = lib().ph_agg_fetch(self.h, i64(m), ctypes.byref(n), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt))
+            if rc == PH_ECAPACITY and n.value > m:
+                m = n.value
+                continue
+            check(rc)
+            break
+        ng = n.value
         out = dict(ngroups=ng, first_row=first[:ng], keys=keys.reshape(m, self.nkeys)[:ng],
                    key_null=knull.reshape(m, self.nkeys)[:ng],
                    sum_lo=lo.reshape(m, na)[:ng, :self.naggs], sum_hi=hi.reshape(m, na)[:ng, :self.naggs],
@@ -561,6 +578,12 @@ class Join:
         device int32[2] (misses, multi-matches), zeroed by the caller"""
         out = self.ctx.alloc(max(n, 1) * 4)
         check(lib().ph_join_lookup(self.h, _cols(keys), sel, i64(n), out, stats))
+        return out
+
+    def lookup_strict(self, keys, sel, n):
+        """ph_join_lookup_strict: a miss / multi-match is a deferred PH_ECONSTRAINT error of the ctx"""
+        out = self.ctx.alloc(max(n, 1) * 4)
+        check(lib().ph_join_lookup_strict(self.h, _cols(keys), sel, i64(n), out))
         return out
 
     def probe_mark(self, keys, sel, n):

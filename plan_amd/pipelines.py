@@ -66,7 +66,14 @@ class Q3Pipeline:
         return c
 
     def run(self, limit=10, want_groups=False):
-        import ctypes
+        """the revenue expression's overflow flag is a deferred error (seen at the result download)"""
+        self.ctx.set_deferred_errors(True)
+        try:
+            return self._run(limit, want_groups)
+        finally:
+            self.ctx.set_deferred_errors(False)
+
+    def _run(self, limit, want_groups):
         ctx, date = self.ctx, self.date
         N = dist.world()
         t = {}
@@ -179,15 +186,15 @@ class Q3Pipeline:
         t0 = tic()
         rev, _ = hip.expr_eval(ctx, [p_ext, p_disc], self.revenue_prog, prow, m2)
         gk = hip.gather(ctx, p_key, prow, m2)
-        gd = hip.gather(ctx, b_date, brow, m2)
-        gp = hip.gather(ctx, b_prio, brow, m2)
+        gd, gp = hip.gather_multi(ctx, [b_date, b_prio], brow, m2)
         frees += [rev, gk, gd, gp]
         agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_DATE, hip.PH_I32], [(hip.PH_A_SUM, 0)], max(m2 // 2, 1024))
         agg.sink([_raw(hip.PH_I64, gk), _raw(hip.PH_DATE, gd), _raw(hip.PH_I32, gp)],
                  [_raw(hip.PH_DEC64, rev, 4)], None, m2, positional=True)
         stage("expr_aggregate", t0)
         t0 = tic()
-        ngroups_total = agg.group_count()
+        # the total group count is reporting only (one more host round trip): not in measured steps
+        ngroups_total = agg.group_count() if (self.time_stages or want_groups) else None
         if want_groups:
             r = agg.finalize(python_ints=False)
         else:   # ORDER BY revenue DESC ... LIMIT: only the groups at least as good as the k-th
@@ -276,6 +283,22 @@ class Q9Pipeline:
             c.free()
 
     def run(self):
+        """The three N:1 joins first run as STRICT lookups (foreign keys into primary keys: no
+        statistics read-back; a violation is a deferred PH_ECONSTRAINT, seen at the final download)
+        with the expression's overflow flag deferred the same way — then, only if that error came,
+        again with the counted lookups, which drop unmatched rows as an inner join must."""
+        self.ctx.set_deferred_errors(True)
+        try:
+            try:
+                return self._run(strict=True)
+            except hip.PlanHipError as e:
+                if e.code != hip.PH_ECONSTRAINT:
+                    raise
+            return self._run(strict=False)
+        finally:
+            self.ctx.set_deferred_errors(False)
+
+    def _run(self, strict):
         """N == 1: everything local. N > 1 (one process per GPU, tables sharded by row ranges):
         the small build sides are broadcast — pink part keys, the partsupp rows of pink parts (found
         with a semi-join against the broadcast part keys), supplier — and the one large join,
@@ -335,7 +358,8 @@ class Q9Pipeline:
         frees.append(fsel)
         j.free()
         if N == 1:
-            bp, bs, bc = gat(self.ps_part, fsel, fn), gat(self.ps_supp, fsel, fn), gat(self.ps_cost, fsel, fn)
+            bp, bs, bc = hip.gather_multi(ctx, [self.ps_part, self.ps_supp, self.ps_cost], fsel, fn)
+            frees += [bp, bs, bc]
             jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, fn)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
         else:
@@ -355,10 +379,13 @@ class Q9Pipeline:
         frees += [d_part, d_supp, c_okey, d_ext, d_disc, d_qty]
         # The two joins below are N:1 (partsupp's composite primary key, supplier's key): LOOKUP
         # probes — one kernel each, no candidate/scan/emit pipeline, no re-gather of earlier columns.
-        stats = ctx.alloc(8)
-        frees.append(stats)
-        hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
-        psrow = jps.lookup([_raw(hip.PH_I32, d_part), _raw(hip.PH_I32, d_supp)], None, n1, stats)
+        stats = None
+        if not strict:
+            stats = ctx.alloc(8)
+            frees.append(stats)
+            hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
+        lookup = (lambda j, keys, n: j.lookup_strict(keys, None, n)) if strict else (lambda j, keys, n: j.lookup(keys, None, n, stats))
+        psrow = lookup(jps, [_raw(hip.PH_I32, d_part), _raw(hip.PH_I32, d_supp)], n1)
         jps.free()
         frees.append(psrow)
         stage("partsupp_join", t0)
@@ -374,12 +401,12 @@ class Q9Pipeline:
             sn, _ = bcast(self.s_nat, ident, self.n["s"], np.int32)
             js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk)
             s_nat = _raw(hip.PH_I32, sn)
-        srow = js.lookup([_raw(hip.PH_I32, d_supp)], None, n1, stats)
+        srow = lookup(js, [_raw(hip.PH_I32, d_supp)], n1)
         frees.append(srow)
         js.free()
         # one read for both joins: rows without a match (none in TPC-H: foreign keys) would have to
         # leave the intermediate, rows with several matches would need the pair-emitting probe
-        misses, multi = ctx.download(stats, np.int32, 2).tolist()
+        misses, multi = (0, 0) if strict else ctx.download(stats, np.int32, 2).tolist()
         if multi:
             raise hip.PlanHipError(hip.PH_EUNSUPPORTED, "Q9: partsupp / supplier keys are not unique; use probe_inner")
         n3 = n1
@@ -428,11 +455,12 @@ class Q9Pipeline:
         # intermediate instead and probed it with all 15 M orders: 0.83 ms for the stage).
         if jo is None:
             jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range)
-        hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
-        orow = jo.lookup([_raw(hip.PH_I64, c_okey)], None, m, stats)
+        if not strict:
+            hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
+        orow = lookup(jo, [_raw(hip.PH_I64, c_okey)], m)
         jo.free()
         frees.append(orow)
-        misses, multi = ctx.download(stats, np.int32, 2).tolist()
+        misses, multi = (0, 0) if strict else ctx.download(stats, np.int32, 2).tolist()
         if multi:
             raise hip.PlanHipError(hip.PH_EUNSUPPORTED, "Q9: order keys are not unique; use probe_inner")
         amount, nat, n4 = c_amount, c_nat, m

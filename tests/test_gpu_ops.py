@@ -635,6 +635,57 @@ def test_join_direct_table_dense_keys(ctx):
         c.free()
 
 
+def test_deferred_errors_and_strict_lookup(ctx):
+    """ph_ctx_set_deferred_errors: an overflowing ph_expr_eval returns PH_OK and the NEXT call that
+    reads back fails with PH_EOVERFLOW, once; ph_join_lookup_strict reports a missing / duplicated
+    build key the same way (PH_ECONSTRAINT) and ph_gather / ph_date_extract stay in bounds for the
+    -1 rows it produced; without violations nothing is reported. Off again: errors are immediate."""
+    big = hip.DevColumn(ctx, hip.PH_DEC64, np.full(1000, 2**62, np.int64), 2)
+    ok = hip.DevColumn(ctx, hip.PH_DEC64, np.arange(1000, dtype=np.int64), 2)
+    prog = [hip.X_COL(0), hip.X_COL(0), hip.X_MUL]
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.expr_eval(ctx, [big], prog, None, 1000)
+    assert e.value.code == hip.PH_EOVERFLOW
+    ctx.set_deferred_errors(True)
+    try:
+        out, _ = hip.expr_eval(ctx, [ok], prog, None, 1000)            # no overflow: nothing pending afterwards
+        assert ctx.download(out, np.int64, 3).tolist() == [0, 1, 4]
+        out2, _ = hip.expr_eval(ctx, [big], prog, None, 1000)          # overflow: reported by the next read-back
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(out2, np.int64, 1)
+        assert e.value.code == hip.PH_EOVERFLOW and "deferred" in str(e.value)
+        assert ctx.download(out, np.int64, 2).tolist() == [0, 1]       # reported once
+        ctx.check_deferred()
+        # strict lookup: build keys 0..99 except 7, probe 0..99 -> one miss
+        bk = np.array([k for k in range(100) if k != 7], np.int32)
+        pk = np.arange(100, dtype=np.int32)
+        dbk, dpk = hip.DevColumn(ctx, hip.PH_I32, bk), hip.DevColumn(ctx, hip.PH_I32, pk)
+        dates = hip.DevColumn(ctx, hip.PH_DATE, np.arange(99, dtype=np.int32) + 9000)
+        for key_range in (None, (0, 99)):
+            j = hip.Join(ctx, [dbk], None, len(bk), key_range=key_range)
+            rows = j.lookup_strict([dpk], None, 100)
+            g = hip.gather(ctx, dbk, rows, 100)                         # row -1 reads row 0: in bounds
+            y = hip.date_extract(ctx, hip.PH_PART_YEAR, dates, rows, 100)
+            with pytest.raises(hip.PlanHipError) as e:
+                ctx.download(g, np.int32, 100)
+            assert e.value.code == hip.PH_ECONSTRAINT and "1 probe rows without a match" in str(e.value)
+            got = ctx.download(rows, np.int32, 100)
+            assert got[7] == -1 and np.array_equal(bk[got[got >= 0]], pk[got >= 0])
+            rows2 = j.lookup_strict([dbk], None, len(bk))               # every key present: clean
+            assert np.array_equal(ctx.download(rows2, np.int32, len(bk)), np.arange(len(bk)))
+            ctx.check_deferred()
+            j.free()
+            for q in (rows, rows2, g, y):
+                ctx.free(q)
+        for c in (dbk, dpk, dates):
+            c.free()
+    finally:
+        ctx.set_deferred_errors(False)
+    with pytest.raises(hip.PlanHipError):
+        hip.expr_eval(ctx, [big], prog, None, 1000)
+    big.free(); ok.free()
+
+
 def test_q3_pipeline_operator_granular(ctx, sf001):
     """Q3 assembled from the operator kernels: filter -> join -> join -> expr -> group by."""
     L, Od, C = sf001["lineitem"], sf001["orders"], sf001["customer"]
