@@ -1292,13 +1292,15 @@ template <int KW, bool SEL>
 __global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
                                                          unsigned long long range, int32_t *__restrict__ direct,
-                                                         int32_t *__restrict__ next, int *__restrict__ count) {
+                                                         int32_t *__restrict__ next, int *__restrict__ count,
+                                                         unsigned *__restrict__ coarse, int cshift) {
     int ins = 0, first = 0, out = 0;
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
         unsigned long long off;
         bool oor = false;
         if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) {
             const int32_t old = atomicExch(&direct[off], (int32_t)i);
+            if (coarse) { const unsigned cb = (unsigned)(off >> cshift); atomicOr(&coarse[cb >> 5], 1u << (cb & 31)); }
             next[i] = old;
             ins++;
             first += old < 0;
@@ -1433,61 +1435,66 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
     }
 }
 
-// inner probe, pass 1: one workgroup per 2048-row block streams the probe keys (after the pushed-down
-// range filter WK: 0 none, 1 int32, 2 int64, 3 uint8 column), reads the table, and writes the block's
+// inner probe, pass 1: 256 threads per 2048-row block stream the probe keys (after the pushed-down
+// range filter WK: 0 none, 1 int32, 2 int64, 3 uint8 column), read the table, and write the block's
 // matching positions in order (ballot ranks, no atomics) with the slot's chain head beside them —
 // the shape of join_cand_fast_kernel, but the table read IS the exact test, so there is no chain pass.
-template <int KW, int WK, bool SEL>
-__global__ __launch_bounds__(256) void direct_cand_kernel(const void *__restrict__ keycol, const uint8_t *__restrict__ pvalid,
-                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
-                                                          unsigned long long range, const int32_t *__restrict__ direct,
-                                                          const int32_t *__restrict__ next, const int *__restrict__ bcount,
-                                                          const void *__restrict__ wdata, long long wlo, long long whi,
-                                                          uint16_t *__restrict__ cand, int32_t *__restrict__ cmatch,
-                                                          uint16_t *__restrict__ ccnt, int32_t *__restrict__ ccount,
-                                                          int32_t *__restrict__ block_counts) {
-    const bool dups = bcount[0] != bcount[1];
-    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int wc[JP_ROUNDS][4];
-    __shared__ int wtot[4];
+// COARSE: a sparse table (few build keys in a small range: Q9's 109 k pink parts of 2 M) also has a
+// 1 Mbit bitmap of occupied slot groups that the probe workgroup keeps in LDS; only probes whose
+// group is occupied read the table through L2 (the others read slot 0: one request per wave).
+struct DirectCand {
+    const void *keycol; const uint8_t *pvalid; const int32_t *sel; int64_t n; long long lo; unsigned long long range;
+    const int32_t *direct; const int32_t *next; const int *bcount; const void *wdata; long long wlo, whi;
+    uint16_t *cand; int32_t *cmatch; uint16_t *ccnt; int32_t *ccount; int32_t *block_counts;
+    int cshift;   // coarse bit = slot >> cshift
+};
+
+template <int KW, int WK, bool SEL, bool COARSE>
+__device__ __forceinline__ void direct_cand_block(const DirectCand &D, int64_t blk, bool have, int tid, int (*wc)[4], int *wtot,
+                                                  const unsigned *co_lds, bool dups) {
+    const int64_t base = blk * JP_CHUNK;
+    const int lane = tid & 63, wv = tid >> 6;
     unsigned long long bal[JP_ROUNDS];
     int64_t r[JP_ROUNDS];
     bool ok[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        const int64_t i = base + rr * 256 + threadIdx.x;
-        ok[rr] = i < n;
+        const int64_t i = base + rr * 256 + tid;
+        ok[rr] = have && i < D.n;
         const int64_t ic = ok[rr] ? i : 0;
-        r[rr] = SEL ? (int64_t)sel[ic] : ic;
+        r[rr] = SEL ? (int64_t)D.sel[ic] : ic;
     }
     if (WK != 0) {
         long long w[JP_ROUNDS];
 #pragma unroll
         for (int rr = 0; rr < JP_ROUNDS; rr++)
-            w[rr] = SEL ? (WK == 1 ? (long long)((const int32_t *)wdata)[r[rr]]
-                           : WK == 2 ? ((const int64_t *)wdata)[r[rr]] : (long long)((const uint8_t *)wdata)[r[rr]])
-                        : (WK == 1 ? (long long)__builtin_nontemporal_load((const int32_t *)wdata + r[rr])
-                           : WK == 2 ? (long long)__builtin_nontemporal_load((const int64_t *)wdata + r[rr])
-                                     : (long long)__builtin_nontemporal_load((const uint8_t *)wdata + r[rr]));
+            w[rr] = SEL ? (WK == 1 ? (long long)((const int32_t *)D.wdata)[r[rr]]
+                           : WK == 2 ? ((const int64_t *)D.wdata)[r[rr]] : (long long)((const uint8_t *)D.wdata)[r[rr]])
+                        : (WK == 1 ? (long long)__builtin_nontemporal_load((const int32_t *)D.wdata + r[rr])
+                           : WK == 2 ? (long long)__builtin_nontemporal_load((const int64_t *)D.wdata + r[rr])
+                                     : (long long)__builtin_nontemporal_load((const uint8_t *)D.wdata + r[rr]));
 #pragma unroll
         for (int rr = 0; rr < JP_ROUNDS; rr++) {
-            ok[rr] = ok[rr] && w[rr] >= wlo && w[rr] <= whi;
+            ok[rr] = ok[rr] && w[rr] >= D.wlo && w[rr] <= D.whi;
             if (!ok[rr]) r[rr] = 0;
         }
     }
     long long k[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        k[rr] = (long long)(SEL ? load_kw<KW>(keycol, r[rr]) : load_kw_nt<KW>(keycol, r[rr]));
-        if (pvalid) ok[rr] = ok[rr] && bit_valid(pvalid, r[rr]);
+        k[rr] = (long long)(SEL ? load_kw<KW>(D.keycol, r[rr]) : load_kw_nt<KW>(D.keycol, r[rr]));
+        if (D.pvalid) ok[rr] = ok[rr] && bit_valid(D.pvalid, r[rr]);
     }
     int32_t d[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        const unsigned long long off = (unsigned long long)(k[rr] - lo);
-        ok[rr] = ok[rr] && off < range;
-        d[rr] = direct[ok[rr] ? off : 0];
+        const unsigned long long off = (unsigned long long)(k[rr] - D.lo);
+        ok[rr] = ok[rr] && off < D.range;
+        if (COARSE) {
+            const unsigned cb = (unsigned)((ok[rr] ? off : 0) >> D.cshift);
+            ok[rr] = ok[rr] && ((co_lds[cb >> 5] >> (cb & 31)) & 1u);
+        }
+        d[rr] = D.direct[ok[rr] ? off : 0];
     }
     int total = 0;
     int c[JP_ROUNDS];
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(256) void direct_cand_kernel(const void *__restrict
         const bool take = ok[rr] && d[rr] >= 0;
         c[rr] = take ? 1 : 0;
         if (dups && take)
-            for (int32_t x = next[d[rr]]; x >= 0; x = next[x]) c[rr]++;
+            for (int32_t x = D.next[d[rr]]; x >= 0; x = D.next[x]) c[rr]++;
         total += c[rr];
         bal[rr] = __ballot(take);
         if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
@@ -1504,22 +1511,52 @@ __global__ __launch_bounds__(256) void direct_cand_kernel(const void *__restrict
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     if (lane == 0) wtot[wv] = total;
     __syncthreads();
-    int before = 0;
+    if (have) {
+        int before = 0;
 #pragma unroll
-    for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        int off = before;
-        for (int q = 0; q < wv; q++) off += wc[rr][q];
-        if ((bal[rr] >> lane) & 1) {
-            const int64_t slot = base + off + __popcll(bal[rr] & ((1ull << lane) - 1ull));
-            cand[slot] = (uint16_t)(rr * 256 + threadIdx.x);
-            cmatch[slot] = d[rr];
-            ccnt[slot] = (uint16_t)(c[rr] > 65535 ? 65535 : c[rr]);
+        for (int rr = 0; rr < JP_ROUNDS; rr++) {
+            int off = before;
+            for (int q = 0; q < wv; q++) off += wc[rr][q];
+            if ((bal[rr] >> lane) & 1) {
+                const int64_t slot = base + off + __popcll(bal[rr] & ((1ull << lane) - 1ull));
+                D.cand[slot] = (uint16_t)(rr * 256 + tid);
+                D.cmatch[slot] = d[rr];
+                D.ccnt[slot] = (uint16_t)(c[rr] > 65535 ? 65535 : c[rr]);
+            }
+            before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
         }
-        before += wc[rr][0] + wc[rr][1] + wc[rr][2] + wc[rr][3];
+        if (tid == 0) {
+            D.ccount[blk] = before;
+            D.block_counts[blk] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        }
     }
-    if (threadIdx.x == 0) {
-        ccount[blockIdx.x] = before;
-        block_counts[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
+template <int KW, int WK, bool SEL>
+__global__ __launch_bounds__(256) void direct_cand_kernel(DirectCand D) {
+    __shared__ int wc[JP_ROUNDS][4];
+    __shared__ int wtot[4];
+    direct_cand_block<KW, WK, SEL, false>(D, blockIdx.x, true, threadIdx.x, wc, wtot, nullptr, D.bcount[0] != D.bcount[1]);
+}
+
+// one 1024-thread workgroup per CU = four 256-thread groups, each owning one block per step
+template <int KW, int WK, bool SEL>
+__global__ __launch_bounds__(1024) void direct_cand_coarse_kernel(DirectCand D, const unsigned *__restrict__ coarse, int64_t nb) {
+    extern __shared__ unsigned dco_lds[];          // CO_WORDS words, then the per-group wave counts
+    int (*wc)[JP_ROUNDS][4] = reinterpret_cast<int (*)[JP_ROUNDS][4]>(dco_lds + CO_WORDS);
+    int (*wtot)[4] = reinterpret_cast<int (*)[4]>(dco_lds + CO_WORDS + 4 * JP_ROUNDS * 4);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coarse);
+        uint4 *dst = reinterpret_cast<uint4 *>(dco_lds);
+        for (int e = threadIdx.x; e < CO_WORDS / 4; e += 1024) dst[e] = src[e];
+    }
+    __syncthreads();
+    const bool dups = D.bcount[0] != D.bcount[1];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    for (int64_t it = 0; (it * gridDim.x + blockIdx.x) * 4 < nb; it++) {
+        const int64_t blk = (it * gridDim.x + blockIdx.x) * 4 + grp;
+        direct_cand_block<KW, WK, SEL, true>(D, blk, blk < nb, tid, wc[grp], wtot[grp], dco_lds, dups);
+        __syncthreads();   // the counts are rewritten in the next step
     }
 }
 
@@ -1586,6 +1623,7 @@ struct ph_join {
     int64_t dlo = 0;
     unsigned long long drange = 0;
     int dkw = 0;
+    int dcshift = 0;                // sparse direct tables: bloom.coarse bit = slot >> dcshift (occupied slot groups)
 };
 
 extern "C" void ph_join_free(ph_join *j) {
@@ -1692,14 +1730,21 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         j->build.sel = j->sel_copy;
     }
     const ph::JoinSide &B = j->build;
-    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, nullptr, 0, nullptr, j->count_dev);
+    // sparse small build side (the range check in join_build_impl let it in because the range itself is
+    // small): bitmap of occupied slot groups for the LDS filter of big selective probes
+    if (n <= (256 << 10) && range > 8 * n) {
+        PH_CHECK(ctx->pool_alloc(ph::CO_WORDS * 4, (void **)&j->bloom.coarse));
+        while (((range - 1) >> j->dcshift) >= (int64_t)ph::CO_WORDS * 32) j->dcshift++;
+    }
+    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, nullptr, 0, j->bloom.coarse, j->count_dev);
     if (n > 0) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
         const void *kcol = B.key[0].data;
         const uint8_t *valid = B.key[0].validity;
         if (n <= (256 << 10)) {
             const int grids = (int)std::min<int64_t>((n + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
-            PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+            PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev,
+                         j->bloom.coarse, j->dcshift);
             PH_HIP(hipGetLastError());
             j->count = -1;
             return PH_OK;
@@ -1744,10 +1789,23 @@ static void launch_direct_probe(ph_join *j, const ph::JoinSide &P, int64_t n, in
 template <int KW, int WK>
 static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, uint16_t *cand, int32_t *cmatch,
                                uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
-#define PH_DC_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev, w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts
-    if (P.sel) ph::direct_cand_kernel<KW, WK, true><<<nb, 256, 0, j->ctx->stream>>>(PH_DC_ARGS);
-    else ph::direct_cand_kernel<KW, WK, false><<<nb, 256, 0, j->ctx->stream>>>(PH_DC_ARGS);
-#undef PH_DC_ARGS
+    ph::DirectCand D{P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev,
+                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift};
+    hipStream_t st = j->ctx->stream;
+    if (j->bloom.coarse && nb >= 64) {   // sparse table: occupied-group bitmap in LDS, one 1024-thread workgroup per CU
+        const size_t lds = (size_t)ph::CO_WORDS * 4 + 4 * ph::JP_ROUNDS * 4 * sizeof(int) + 4 * 4 * sizeof(int);
+        const int grid = std::min((nb + 3) / 4, j->ctx->cu_count);
+        if (P.sel) {
+            (void)hipFuncSetAttribute((const void *)ph::direct_cand_coarse_kernel<KW, WK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ph::direct_cand_coarse_kernel<KW, WK, true><<<grid, 1024, lds, st>>>(D, j->bloom.coarse, (int64_t)nb);
+        } else {
+            (void)hipFuncSetAttribute((const void *)ph::direct_cand_coarse_kernel<KW, WK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ph::direct_cand_coarse_kernel<KW, WK, false><<<grid, 1024, lds, st>>>(D, j->bloom.coarse, (int64_t)nb);
+        }
+        return;
+    }
+    if (P.sel) ph::direct_cand_kernel<KW, WK, true><<<nb, 256, 0, st>>>(D);
+    else ph::direct_cand_kernel<KW, WK, false><<<nb, 256, 0, st>>>(D);
 }
 
 static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, const ph::RangePred &where, int32_t *out_probe_dev,
@@ -1850,7 +1908,11 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
         const int t = keys[0].type;
         const int kw = (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8;
         const unsigned long long span = (unsigned long long)key_hi - (unsigned long long)key_lo;
-        if (!(dz && atoi(dz) == 0) && kw != 1 && span < (1ull << 30) && (int64_t)span + 1 <= std::max<int64_t>(8 * n, 4096)) {
+        // ... or the range itself is small (<= 4 M slots = 16 MiB, and the build side <= 256 K rows so that it
+        // gets the occupied-group bitmap): the table read is the exact test, no chain pass
+        const bool dense = (int64_t)span + 1 <= std::max<int64_t>(8 * n, 4096);
+        const bool small_range = span < (4ull << 20) && n <= (256 << 10);
+        if (!(dz && atoi(dz) == 0) && kw != 1 && span < (1ull << 30) && (dense || small_range)) {
             int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1);
             if (rcd != PH_OK) { ph_join_free(j); return rcd; }
             *out = j;

@@ -257,6 +257,7 @@ class Q9Pipeline:
         self.n = dict(l=len(L["l_orderkey"]), o=len(O["o_orderkey"]), p=len(P["p_partkey"]),
                       ps=len(PS["ps_partkey"]), s=len(S["s_suppkey"]))
         self.p_key = D(ctx, hip.PH_I32, P["p_partkey"])
+        self.p_key_range = (int(P["p_partkey"].min()), int(P["p_partkey"].max())) if self.n["p"] else None
         self.p_name = D(ctx, hip.PH_STR, P["p_name_off"], aux=P["p_name_bytes"])
         self.ps_part = D(ctx, hip.PH_I32, PS["ps_partkey"])
         self.ps_supp = D(ctx, hip.PH_I32, PS["ps_suppkey"])
@@ -334,7 +335,7 @@ class Q9Pipeline:
         if N == 1:
             pk = hip.gather(ctx, self.p_key, psel, np_)   # as in Q3: no selection inside the table
             frees.append(pk)
-            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, np_)
+            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, np_, key_range=self.p_key_range)
         else:
             pk, npk = bcast(self.p_key, psel, np_, np.int32)
             j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, npk)

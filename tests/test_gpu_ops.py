@@ -604,8 +604,11 @@ def test_join_direct_table_dense_keys(ctx):
     join_compare(ctx, [(hip.PH_I32, O.OT_INT32, bd, vb)], [(hip.PH_I32, O.OT_INT32, pd_, vp)],
                  np.sort(rng.choice(len(bd), 30_000, replace=False)), np.sort(rng.choice(len(pd_), 20_000, replace=False)),
                  key_range=(-2500, 2499), kind="direct")
-    # sparse range / switched off: the hash tables, same results
-    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b[:1000], None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="chained+bloom")
+    # a sparse build side in a SMALL range (<= 4 M slots) is direct too, with the occupied-group bitmap
+    # that big probes keep in LDS; sparse in a large range / switched off: the hash tables, same results
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b[:1000], None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="direct")
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b[:20_000], None)], [(hip.PH_I64, O.OT_INT64, p, None)], None, psel, key_range=(0, 3_999_999), kind="direct")
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b[:1000], None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=(0, 2**31), kind="chained+bloom")
     os.environ["PH_JOIN_DIRECT"] = "0"
     try:
         join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="chained+bloom")
