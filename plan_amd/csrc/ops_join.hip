@@ -156,6 +156,106 @@ template <int KW> __device__ __forceinline__ unsigned long long load_kw_nt(const
                      : __builtin_nontemporal_load((const unsigned long long *)col + r);
 }
 
+// The vectorised candidate kernels: a wave covers 512 consecutive probe rows in G = 8/R groups of
+// 64*R rows; in a group a lane owns R = 16/KW CONSECUTIVE rows, so its key read is ONE 16-byte
+// non-temporal load and the wave's load instruction covers 1 KiB without gaps (a lane that owned 8
+// consecutive 8-byte keys read them with four loads at a 64-byte stride: every sector was fetched four
+// times through the non-temporal path and the kernel ran twice as long as the scalar form).
+// Slot s = g*R + e of a lane is local row (g*64 + lane)*R + e of the wave's 512.
+typedef int dc_v4i __attribute__((ext_vector_type(4)));
+typedef int dc_v2i __attribute__((ext_vector_type(2)));
+typedef long long dc_v2l __attribute__((ext_vector_type(2)));
+
+template <int W, int R>   // R consecutive elements of width W (4, 8 signed; 1 unsigned) starting at element i0 (i0 % R == 0)
+__device__ __forceinline__ void dc_loadr(const void *col, int64_t i0, long long *v) {
+    if (W == 8) {
+        const dc_v2l a = __builtin_nontemporal_load(reinterpret_cast<const dc_v2l *>((const long long *)col + i0));
+        v[0] = a.x; v[1] = a.y;
+        if (R == 4) {   // an 8-byte filter column beside 4-byte keys: two loads (32-byte stride, half of each used per instruction)
+            const dc_v2l b = __builtin_nontemporal_load(reinterpret_cast<const dc_v2l *>((const long long *)col + i0) + 1);
+            v[2] = b.x; v[3] = b.y;
+        }
+    } else if (W == 4 && R == 4) {
+        const dc_v4i a = __builtin_nontemporal_load(reinterpret_cast<const dc_v4i *>((const int32_t *)col + i0));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else if (W == 4) {   // R == 2
+        const dc_v2i a = __builtin_nontemporal_load(reinterpret_cast<const dc_v2i *>((const int32_t *)col + i0));
+        v[0] = a.x; v[1] = a.y;
+    } else if (R == 4) {   // W == 1
+        const unsigned x = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>((const uint8_t *)col + i0));
+        v[0] = x & 0xff; v[1] = (x >> 8) & 0xff; v[2] = (x >> 16) & 0xff; v[3] = x >> 24;
+    } else {
+        const unsigned x = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>((const uint8_t *)col + i0));
+        v[0] = x & 0xff; v[1] = x >> 8;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ long long dc_load1(const void *col, int64_t i) {
+    return W == 4 ? (long long)((const int32_t *)col)[i] : W == 8 ? ((const long long *)col)[i] : (long long)((const uint8_t *)col)[i];
+}
+
+// keys (and the pushed-down range filter) of a lane's 8 slots; `full` = the whole 2048-row block is inside n
+template <int KW, int WK, int NK>
+__device__ __forceinline__ void dc_block_keys(const void *keycol, const void *keycol2, const void *wdata, long long wlo, long long whi,
+                                              int64_t wave_row0, int lane, bool full, bool have, int64_t n, long long (&k)[8],
+                                              long long (&k2)[8], bool (&ok)[8]) {
+    constexpr int R = 16 / KW, G = 8 / R;
+    constexpr int WW = WK == 1 ? 4 : WK == 2 ? 8 : 1;
+    if (full) {
+        if (WK != 0) {
+            long long w[8];
+#pragma unroll
+            for (int g = 0; g < G; g++) dc_loadr<WW, R>(wdata, wave_row0 + (int64_t)(g * 64 + lane) * R, &w[g * R]);
+#pragma unroll
+            for (int s = 0; s < 8; s++) ok[s] = w[s] >= wlo && w[s] <= whi;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; s++) ok[s] = true;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            dc_loadr<KW, R>(keycol, wave_row0 + (int64_t)(g * 64 + lane) * R, &k[g * R]);
+            if (NK == 2) dc_loadr<KW, R>(keycol2, wave_row0 + (int64_t)(g * 64 + lane) * R, &k2[g * R]);
+        }
+        if (NK != 2) {
+#pragma unroll
+            for (int s = 0; s < 8; s++) k2[s] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int64_t i = wave_row0 + (int64_t)((s / R) * 64 + lane) * R + (s % R);
+            ok[s] = have && i < n;
+            const int64_t ic = ok[s] ? i : 0;
+            if (WK != 0) { const long long w = dc_load1<WW>(wdata, ic); ok[s] = ok[s] && w >= wlo && w <= whi; }
+            k[s] = dc_load1<KW>(keycol, ic);
+            k2[s] = NK == 2 ? dc_load1<KW>(keycol2, ic) : 0;
+        }
+    }
+}
+
+// rank of a lane's surviving slots inside its wave in ascending row order (group, lane, element):
+// first[g] = survivors of the wave that precede this lane's slots of group g; returns the wave's total
+template <int R>
+__device__ __forceinline__ int dc_wave_ranks(const bool (&take)[8], int (&first)[8 / R]) {
+    constexpr int G = 8 / R;
+    int before = 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        int below = 0, tot = 0;
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const unsigned long long bal = __ballot(take[g * R + e]);
+            below += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+            tot += __popcll(bal);
+        }
+        first[g] = before + below;
+        before += tot;
+    }
+    return before;
+}
+
 // Straight-line forms of the two partition passes for the common build shape (one or two key
 // columns of one width, no NULL keys): PU rows per thread, their selection / key reads issued
 // together (the generic kernels below pay two or three dependent memory latencies per row).
@@ -719,6 +819,47 @@ __global__ __launch_bounds__(256) void join_cand_fast_kernel(const void *__restr
     if (threadIdx.x == 0) ccount[blockIdx.x] = before;
 }
 
+// Vectorised form of join_cand_fast_kernel for the identity selection over 16-byte aligned columns
+// (see dc_block_keys): the round-per-row form spends ~85 VALU instructions per row beside the hash
+// and was VALU bound (Q3: 60 M rows in 165 us; its columns stream in ~115).
+template <int KW, int WK, int NK>
+__global__ __launch_bounds__(256) void join_cand_vec_kernel(const void *__restrict__ keycol, const void *__restrict__ keycol2, int64_t n,
+                                                            Bloom bl, const void *__restrict__ wdata, long long wlo, long long whi,
+                                                            uint16_t *__restrict__ cand, int32_t *__restrict__ ccount) {
+    constexpr int R = 16 / KW, G = 8 / R;
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int wcv[4];
+    long long k[8], k2[8];
+    bool ok[8];
+    dc_block_keys<KW, WK, NK>(keycol, keycol2, wdata, wlo, whi, base + wv * 512, lane, base + JP_CHUNK <= n, true, n, k, k2, ok);
+    unsigned word[8], msk[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        uint64_t hh = mix64(0x9e3779b97f4a7c15ULL ^ (unsigned long long)k[s]);   // load_keys' hash
+        if (NK == 2) hh = mix64(hh ^ (unsigned long long)k2[s]);
+        msk[s] = bloom_mask(hh >> 24);
+        word[s] = bl.bits[ok[s] ? bloom_word(bl, hh) : 0];   // filtered rows read word 0: one request per wave
+    }
+    bool take[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) take[s] = ok[s] && (word[s] & msk[s]) == msk[s];
+    int first[G];
+    const int wave_cands = dc_wave_ranks<R>(take, first);
+    if (lane == 0) wcv[wv] = wave_cands;
+    __syncthreads();
+    int off = 0;
+    for (int q = 0; q < wv; q++) off += wcv[q];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        uint16_t *dst = cand + base + off + first[g];
+#pragma unroll
+        for (int e = 0; e < R; e++)
+            if (take[g * R + e]) *dst++ = (uint16_t)(wv * 512 + (g * 64 + lane) * R + e);
+    }
+    if (threadIdx.x == 0) ccount[blockIdx.x] = wcv[0] + wcv[1] + wcv[2] + wcv[3];
+}
+
 // The same kernel for tiny build sides: 1024 threads = four 256-thread groups, each owning one
 // 2048-row block per step; the workgroup first copies the coarse bitmap into LDS (one workgroup per
 // CU, so 128 KiB x 256 of traffic in all) and a probe reads the L2 bitmap only when its coarse
@@ -807,6 +948,13 @@ template <int KW, int WK>
 static void launch_cand_fast(bool has_sel, int nb, hipStream_t st, const JoinSide &P, const Bloom &bl, const RangePred &w,
                              uint16_t *cand, int32_t *ccount) {
 #define PH_CAND_ARGS P.key[0].data, P.key[1].data, P.sel, P.n, bl, w.data, w.lo, w.hi, cand, ccount
+    auto aligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    static const bool no_vec = getenv("PH_JOIN_CAND_VEC") && atoi(getenv("PH_JOIN_CAND_VEC")) == 0;
+    if (!no_vec && !bl.coarse && !has_sel && KW != 1 && aligned(P.key[0].data) && (P.nkeys == 1 || aligned(P.key[1].data)) && (WK == 0 || aligned(w.data))) {
+        if (P.nkeys == 2) join_cand_vec_kernel<KW == 1 ? 4 : KW, WK, 2><<<nb, 256, 0, st>>>(P.key[0].data, P.key[1].data, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
+        else join_cand_vec_kernel<KW == 1 ? 4 : KW, WK, 1><<<nb, 256, 0, st>>>(P.key[0].data, P.key[1].data, P.n, bl, w.data, w.lo, w.hi, cand, ccount);
+        return;
+    }
     if (bl.coarse) {   // tiny build side: coarse bitmap in LDS, one 1024-thread workgroup per CU
         const size_t lds = (size_t)CO_WORDS * 4 + 4 * JP_ROUNDS * 4 * sizeof(int);
         const int grid = std::min((nb + 3) / 4, g_cu_count);
@@ -1293,7 +1441,7 @@ __global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict
                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
                                                          unsigned long long range, int32_t *__restrict__ direct,
                                                          int32_t *__restrict__ next, int *__restrict__ count,
-                                                         unsigned *__restrict__ coarse, int cshift) {
+                                                         unsigned *__restrict__ coarse, int cshift, unsigned *__restrict__ dbits) {
     int ins = 0, first = 0, out = 0;
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
         unsigned long long off;
@@ -1301,6 +1449,7 @@ __global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict
         if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) {
             const int32_t old = atomicExch(&direct[off], (int32_t)i);
             if (coarse) { const unsigned cb = (unsigned)(off >> cshift); atomicOr(&coarse[cb >> 5], 1u << (cb & 31)); }
+            if (dbits) atomicOr(&dbits[off >> 5], 1u << (off & 31));
             next[i] = old;
             ins++;
             first += old < 0;
@@ -1312,13 +1461,24 @@ __global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict
 }
 
 // occupied slots of the table (cap4 is a multiple of 4; the padding slots are -1)
-__global__ __launch_bounds__(DT) void direct_occupied_kernel(const int32_t *__restrict__ direct, int64_t cap4, int *__restrict__ count) {
+// ... and, for tables of <= 8 M slots, the occupancy bitmap: a thread's 4 slots are a nibble, 8 lanes a word
+__global__ __launch_bounds__(DT) void direct_occupied_kernel(const int32_t *__restrict__ direct, int64_t cap4, int *__restrict__ count,
+                                                            unsigned *__restrict__ dbits) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i *d4 = reinterpret_cast<const v4i *>(direct);
+    const int64_t nq = cap4 / 4;
     int occ = 0;
-    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < cap4 / 4; i += (int64_t)gridDim.x * DT) {
-        const v4i v = __builtin_nontemporal_load(d4 + i);
+    for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i - (threadIdx.x & 63) < nq; i += (int64_t)gridDim.x * DT) {   // wave-uniform trip count
+        v4i v = {-1, -1, -1, -1};
+        if (i < nq) v = __builtin_nontemporal_load(d4 + i);
         occ += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+        if (dbits) {
+            unsigned w = ((v.x >= 0) | ((v.y >= 0) << 1) | ((v.z >= 0) << 2) | ((v.w >= 0) << 3)) << (4 * (threadIdx.x & 7));
+            w |= __shfl_xor(w, 1);
+            w |= __shfl_xor(w, 2);
+            w |= __shfl_xor(w, 4);
+            if ((threadIdx.x & 7) == 0 && i < nq) dbits[i >> 3] = w;   // slots 4i .. 4i+31
+        }
     }
     direct_block_add(occ, 0, count + 1, nullptr);
 }
@@ -1447,6 +1607,7 @@ struct DirectCand {
     const int32_t *direct; const int32_t *next; const int *bcount; const void *wdata; long long wlo, whi;
     uint16_t *cand; int32_t *cmatch; uint16_t *ccnt; int32_t *ccount; int32_t *block_counts;
     int cshift;   // coarse bit = slot >> cshift
+    const unsigned *dbits;   // one bit per slot (tables of <= 8 M slots: L2 resident) or NULL
 };
 
 template <int KW, int WK, bool SEL, bool COARSE>
@@ -1494,8 +1655,17 @@ __device__ __forceinline__ void direct_cand_block(const DirectCand &D, int64_t b
             const unsigned cb = (unsigned)((ok[rr] ? off : 0) >> D.cshift);
             ok[rr] = ok[rr] && ((co_lds[cb >> 5] >> (cb & 31)) & 1u);
         }
-        d[rr] = D.direct[ok[rr] ? off : 0];
+        k[rr] = (long long)(ok[rr] ? off : 0);
     }
+    if (D.dbits) {   // exact occupancy bit from L2 first: only real matches read the (much larger) slot array
+        unsigned bw[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) bw[rr] = D.dbits[k[rr] >> 5];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) { ok[rr] = ok[rr] && ((bw[rr] >> (k[rr] & 31)) & 1u); if (!ok[rr]) k[rr] = 0; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < JP_ROUNDS; rr++) d[rr] = D.direct[k[rr]];
     int total = 0;
     int c[JP_ROUNDS];
 #pragma unroll
@@ -1560,6 +1730,106 @@ __global__ __launch_bounds__(1024) void direct_cand_coarse_kernel(DirectCand D, 
     }
 }
 
+// Vectorised form for the common probe shape (identity selection, no NULLs, 16-byte aligned columns):
+// a lane owns 8 CONSECUTIVE rows and reads them with 16-byte non-temporal loads; ranks come from 8
+// ballots. The round-per-row form above spends ~75 VALU instructions per row (64-bit index
+// arithmetic, a scalar load and a ballot round per row) and was VALU bound: 60 M 4-byte keys took
+// 174 us where the key column streams in 40.
+template <int KW, int WK, bool COARSE>
+__device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64_t blk, bool have, int tid, int *wcv, int *wtot,
+                                                      const unsigned *co_lds, bool dups) {
+    constexpr int R = 16 / KW, G = 8 / R;
+    const int64_t base = blk * JP_CHUNK;
+    const int lane = tid & 63, wv = tid >> 6;
+    long long k[8], k2[8];
+    bool ok[8];
+    dc_block_keys<KW, WK, 1>(D.keycol, nullptr, D.wdata, D.wlo, D.whi, base + wv * 512, lane, have && base + JP_CHUNK <= D.n, have, D.n, k, k2, ok);
+    int32_t d[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const unsigned long long off = (unsigned long long)(k[s] - D.lo);
+        ok[s] = ok[s] && off < D.range;
+        if (COARSE) {
+            const unsigned cb = (unsigned)((ok[s] ? off : 0) >> D.cshift);
+            ok[s] = ok[s] && ((co_lds[cb >> 5] >> (cb & 31)) & 1u);
+        }
+        k[s] = (long long)(ok[s] ? off : 0);
+    }
+    if (D.dbits) {   // exact occupancy bit from L2 first: only real matches read the (much larger) slot array
+        unsigned bw[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) bw[s] = D.dbits[k[s] >> 5];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { ok[s] = ok[s] && ((bw[s] >> (k[s] & 31)) & 1u); if (!ok[s]) k[s] = 0; }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) d[s] = D.direct[k[s]];
+    int total = 0;
+    int c[8];
+    bool take[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        take[s] = ok[s] && d[s] >= 0;
+        c[s] = take[s] ? 1 : 0;
+        if (dups && take[s])
+            for (int32_t x = D.next[d[s]]; x >= 0; x = D.next[x]) c[s]++;
+        total += c[s];
+    }
+    int first[G];
+    const int wave_cands = dc_wave_ranks<R>(take, first);
+    if (dups) { for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o); } else total = wave_cands;
+    if (lane == 0) { wcv[wv] = wave_cands; wtot[wv] = total; }
+    __syncthreads();
+    if (have) {
+        int off = 0;
+        for (int q = 0; q < wv; q++) off += wcv[q];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            int64_t slot = base + off + first[g];
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                const int s = g * R + e;
+                if (take[s]) {
+                    D.cand[slot] = (uint16_t)(wv * 512 + (g * 64 + lane) * R + e);
+                    D.cmatch[slot] = d[s];
+                    if (dups) D.ccnt[slot] = (uint16_t)(c[s] > 65535 ? 65535 : c[s]);
+                    slot++;
+                }
+            }
+        }
+        if (tid == 0) {
+            D.ccount[blk] = wcv[0] + wcv[1] + wcv[2] + wcv[3];
+            D.block_counts[blk] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        }
+    }
+}
+
+template <int KW, int WK>
+__global__ __launch_bounds__(256) void direct_cand_vec_kernel(DirectCand D) {
+    __shared__ int wcv[4], wtot[4];
+    direct_cand_block_vec<KW, WK, false>(D, blockIdx.x, true, threadIdx.x, wcv, wtot, nullptr, D.bcount[0] != D.bcount[1]);
+}
+
+template <int KW, int WK>
+__global__ __launch_bounds__(1024) void direct_cand_coarse_vec_kernel(DirectCand D, const unsigned *__restrict__ coarse, int64_t nb) {
+    extern __shared__ unsigned dcv_lds[];          // CO_WORDS words, then the per-group wave counts
+    int (*wcv)[4] = reinterpret_cast<int (*)[4]>(dcv_lds + CO_WORDS);
+    int (*wtot)[4] = reinterpret_cast<int (*)[4]>(dcv_lds + CO_WORDS + 16);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coarse);
+        uint4 *dst = reinterpret_cast<uint4 *>(dcv_lds);
+        for (int e = threadIdx.x; e < CO_WORDS / 4; e += 1024) dst[e] = src[e];
+    }
+    __syncthreads();
+    const bool dups = D.bcount[0] != D.bcount[1];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    for (int64_t it = 0; (it * gridDim.x + blockIdx.x) * 4 < nb; it++) {
+        const int64_t blk = (it * gridDim.x + blockIdx.x) * 4 + grp;
+        direct_cand_block_vec<KW, WK, true>(D, blk, blk < nb, tid, wcv[grp], wtot[grp], dcv_lds, dups);
+        __syncthreads();   // the counts are rewritten in the next step
+    }
+}
+
 // inner probe, pass 2: one wave per block writes the pairs at the block's offset, ordered by probe
 // position then chain order; a candidate of a unique key is one pair straight from cmatch
 template <bool SELP, bool SELB>
@@ -1567,9 +1837,11 @@ __global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ bsel, const uint16_t *__restrict__ cand,
                                                           const int32_t *__restrict__ cmatch, const uint16_t *__restrict__ ccnt,
                                                           const int32_t *__restrict__ ccount, const int32_t *__restrict__ block_off,
+                                                          const int *__restrict__ bcount,
                                                           int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
                                                           int32_t *__restrict__ out_build) {
     const int lane = threadIdx.x & 63;
+    const bool dups = bcount[0] != bcount[1];
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
         const int cnt = ccount[blk];
@@ -1582,7 +1854,7 @@ __global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restr
             if (t < cnt) {
                 const int64_t i = blk * JP_CHUNK + cand[blk * JP_CHUNK + t];
                 r = SELP ? (int64_t)psel[i] : i;
-                c = ccnt[blk * JP_CHUNK + t];
+                c = dups ? (int)ccnt[blk * JP_CHUNK + t] : 1;   // the candidate pass only writes counts when chains exist
                 first = cmatch[blk * JP_CHUNK + t];
                 if (c == 65535) { c = 0; for (int32_t x = first; x >= 0; x = next[x]) c++; }   // saturated: recount
             }
@@ -1624,6 +1896,7 @@ struct ph_join {
     unsigned long long drange = 0;
     int dkw = 0;
     int dcshift = 0;                // sparse direct tables: bloom.coarse bit = slot >> dcshift (occupied slot groups)
+    unsigned *dbits = nullptr;      // direct tables of <= 8 M slots: one occupancy bit per slot
 };
 
 extern "C" void ph_join_free(ph_join *j) {
@@ -1636,6 +1909,7 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->count_dev) j->ctx->pool_release(j->count_dev);
     if (j->nodes) j->ctx->pool_release(j->nodes);
     if (j->direct) j->ctx->pool_release(j->direct);
+    if (j->dbits) j->ctx->pool_release(j->dbits);
     delete j;
 }
 
@@ -1736,7 +2010,14 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         PH_CHECK(ctx->pool_alloc(ph::CO_WORDS * 4, (void **)&j->bloom.coarse));
         while (((range - 1) >> j->dcshift) >= (int64_t)ph::CO_WORDS * 32) j->dcshift++;
     }
-    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, nullptr, 0, j->bloom.coarse, j->count_dev);
+    // occupancy bitmap for the candidate pass of inner probes: 1 MiB at most, so that it stays in L2 while
+    // the slot array (32 x larger) is only read for rows that match
+    int64_t dwords = 0;
+    if (range <= (8ll << 20)) {
+        dwords = ph::round_up(cap4, 128) / 32;   // the occupied kernel writes whole words up to cap4
+        PH_CHECK(ctx->pool_alloc(dwords * 4, (void **)&j->dbits));
+    }
+    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->dbits, dwords, j->bloom.coarse, j->count_dev);
     if (n > 0) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
         const void *kcol = B.key[0].data;
@@ -1744,7 +2025,7 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         if (n <= (256 << 10)) {
             const int grids = (int)std::min<int64_t>((n + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
             PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev,
-                         j->bloom.coarse, j->dcshift);
+                         j->bloom.coarse, j->dcshift, j->dbits);
             PH_HIP(hipGetLastError());
             j->count = -1;
             return PH_OK;
@@ -1753,7 +2034,7 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         const int gridc = (int)std::min<int64_t>((n + ph::DT * 4 - 1) / (ph::DT * 4), (int64_t)ctx->cu_count);
         const int grido = (int)std::min<int64_t>((cap4 / 4 + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
         PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->count_dev);
-        ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev);
+        ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev, j->dbits);
         PH_DIRECT_KS(ph::direct_verify_kernel, grid, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
         const int grid1 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
         PH_DIRECT_KS(ph::direct_dups_kernel, grid1, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
@@ -1790,8 +2071,21 @@ template <int KW, int WK>
 static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, uint16_t *cand, int32_t *cmatch,
                                uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
     ph::DirectCand D{P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev,
-                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift};
+                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift, j->dbits};
     hipStream_t st = j->ctx->stream;
+    auto aligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = !P.sel && !P.key[0].validity && aligned(P.key[0].data) && (WK == 0 || aligned(w.data));
+    // the LDS bitmap of occupied slot groups already rejects most probes: a second filter stage (one more
+    // dependent L2 read per survivor) made the kernel slower (Q9: 119 -> 151 us)
+    if (j->bloom.coarse && nb >= 64) D.dbits = nullptr;
+    if (vec && j->bloom.coarse && nb >= 64) {
+        const size_t lds = (size_t)ph::CO_WORDS * 4 + 2 * 16 * sizeof(int);
+        const int grid = std::min((nb + 3) / 4, j->ctx->cu_count);
+        (void)hipFuncSetAttribute((const void *)ph::direct_cand_coarse_vec_kernel<KW, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ph::direct_cand_coarse_vec_kernel<KW, WK><<<grid, 1024, lds, st>>>(D, j->bloom.coarse, (int64_t)nb);
+        return;
+    }
+    if (vec) { ph::direct_cand_vec_kernel<KW, WK><<<nb, 256, 0, st>>>(D); return; }
     if (j->bloom.coarse && nb >= 64) {   // sparse table: occupied-group bitmap in LDS, one 1024-thread workgroup per CU
         const size_t lds = (size_t)ph::CO_WORDS * 4 + 4 * ph::JP_ROUNDS * 4 * sizeof(int) + 4 * 4 * sizeof(int);
         const int grid = std::min((nb + 3) / 4, j->ctx->cu_count);
@@ -1834,7 +2128,7 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
     const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
     const int32_t *bsel = j->build.sel;
-#define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, nb, cap, out_probe_dev, out_build_dev
+#define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, j->count_dev, nb, cap, out_probe_dev, out_build_dev
     if (P.sel && bsel) ph::direct_emit_kernel<true, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
     else if (P.sel) ph::direct_emit_kernel<true, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
     else if (bsel) ph::direct_emit_kernel<false, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
