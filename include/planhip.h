@@ -304,6 +304,18 @@ int ph_join_build(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t 
  * (-1 + ph_last_error) — the build itself makes no host round trip. */
 int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n,
                         int64_t key_lo, int64_t key_hi, ph_join **out);
+/* ph_join_build with what the planner knows about the join:
+ *   PH_JOIN_KEY_RANGE  key_lo / key_hi hold the key column's value range (as ph_join_build_range)
+ *   PH_JOIN_FK_PROBES  the probe side is a foreign key into this side's key: nearly every probe row
+ *                      matches, so a Bloom bitmap would reject nothing. Build sides of >= 32 K rows with
+ *                      one key column or two 4-byte ones then take the NODE table (16-byte {key, row,
+ *                      next} records: a chain step is one read instead of next + one per key column)
+ *                      at every size, not only above 4 M rows.
+ * Every probe call works on every table form; the flags only pick the faster one. */
+#define PH_JOIN_KEY_RANGE 1
+#define PH_JOIN_FK_PROBES 2
+int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int32_t flags,
+                     int64_t key_lo, int64_t key_hi, ph_join **out);
 /* the table form a build chose: "direct", "nodes", "chained+bloom" or "chained" */
 const char *ph_join_kind(const ph_join *j);
 int64_t ph_join_count(const ph_join *j);

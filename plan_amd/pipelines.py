@@ -341,8 +341,8 @@ class Q9Pipeline:
             j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, npk)
         stage("part_like_build", t0)
         t0 = tic()
-        n1, lrow, _ = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
-        frees += [lrow, _]
+        n1, lrow, prow_part = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
+        frees += [lrow, prow_part]
         stage("lineitem_probe_part", t0)
 
         t0 = tic()
@@ -361,7 +361,7 @@ class Q9Pipeline:
         if N == 1:
             bp, bs, bc = hip.gather_multi(ctx, [self.ps_part, self.ps_supp, self.ps_cost], fsel, fn)
             frees += [bp, bs, bc]
-            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, fn)
+            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, fn, fk_probes=True)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
         else:
             # ... and broadcast, so every rank can resolve its own lineitem rows
@@ -375,9 +375,12 @@ class Q9Pipeline:
         # together; one launch per column — or a selection inside every later kernel — paid the two
         # dependent latencies of a gather per column). From here on the intermediate is positional
         # and dense: the per-join materialisation of Scan.gatherResult (join_scan.go:250-278), done once.
-        d_part, d_supp, c_okey, d_ext, d_disc, d_qty = hip.gather_multi(
-            ctx, [self.l_part, self.l_supp, self.l_key, self.l_ext, self.l_disc, self.l_qty], lrow, n1)
-        frees += [d_part, d_supp, c_okey, d_ext, d_disc, d_qty]
+        # (l_partkey of a surviving row is its matched part's key: read through the pair's build row from
+        # the 109 k gathered part keys, cache resident, instead of one more 64-byte sector per row of lineitem)
+        d_part = gat(_raw(hip.PH_I32, pk), prow_part, n1)
+        d_supp, c_okey, d_ext, d_disc, d_qty = hip.gather_multi(
+            ctx, [self.l_supp, self.l_key, self.l_ext, self.l_disc, self.l_qty], lrow, n1)
+        frees += [d_supp, c_okey, d_ext, d_disc, d_qty]
         # The two joins below are N:1 (partsupp's composite primary key, supplier's key): LOOKUP
         # probes — one kernel each, no candidate/scan/emit pipeline, no re-gather of earlier columns.
         stats = None

@@ -638,6 +638,41 @@ def test_join_direct_table_dense_keys(ctx):
         c.free()
 
 
+def test_join_fk_probe_hint_takes_node_table(ctx):
+    """ph_join_build_ex with PH_JOIN_FK_PROBES: build sides of >= 32 K rows take the node table (no
+    Bloom bitmap); lookups, pairs and marks equal the default table's (composite 4-byte keys and one
+    8-byte key)."""
+    rng = np.random.default_rng(41)
+    a = rng.integers(0, 200_000, 300_000).astype(np.int32)
+    b = rng.integers(0, 8, 300_000).astype(np.int32)
+    pairs = np.unique(np.stack([a, b], 1), axis=0)
+    ba, bb = pairs[:, 0].copy(), pairs[:, 1].copy()
+    pa = np.concatenate([ba[::3], rng.integers(0, 200_000, 50_000).astype(np.int32)])
+    pb = np.concatenate([bb[::3], rng.integers(0, 9, 50_000).astype(np.int32)])
+    da, db, dpa, dpb = (hip.DevColumn(ctx, hip.PH_I32, x) for x in (ba, bb, pa, pb))
+    jn, jd = hip.Join(ctx, [da, db], None, len(ba), fk_probes=True), hip.Join(ctx, [da, db], None, len(ba))
+    assert jn.kind == "nodes" and jd.kind == "chained+bloom" and jn.count() == jd.count() == len(ba)
+    n = len(pa)
+    assert np.array_equal(ctx.download(jn.lookup([dpa, dpb], None, n), np.int32, n), ctx.download(jd.lookup([dpa, dpb], None, n), np.int32, n))
+    assert np.array_equal(ctx.download(jn.probe_mark([dpa, dpb], None, n), np.uint8, n), ctx.download(jd.probe_mark([dpa, dpb], None, n), np.uint8, n))
+    mn, pn, bn = jn.probe_inner([dpa, dpb], None, n, n)
+    md, pd_, bd = jd.probe_inner([dpa, dpb], None, n, n)
+    assert mn == md and np.array_equal(ctx.download(pn, np.int32, mn), ctx.download(pd_, np.int32, md))
+    assert np.array_equal(ctx.download(bn, np.int32, mn), ctx.download(bd, np.int32, md))
+    jn.free(); jd.free()
+    k8 = rng.permutation(500_000)[:100_000].astype(np.int64) * 1000
+    d8 = hip.DevColumn(ctx, hip.PH_I64, k8)
+    j8 = hip.Join(ctx, [d8], None, len(k8), key_range=(0, int(k8.max())), fk_probes=True)   # sparse range: not direct
+    assert j8.kind == "nodes"
+    assert np.array_equal(ctx.download(j8.lookup([d8], None, len(k8)), np.int32, len(k8)), np.arange(len(k8)))
+    j8.free()
+    small = hip.Join(ctx, [d8], None, 1000, fk_probes=True)                                 # below 32 K rows: default tables
+    assert small.kind == "chained+bloom"
+    small.free()
+    for c in (da, db, dpa, dpb, d8):
+        c.free()
+
+
 def test_deferred_errors_and_strict_lookup(ctx):
     """ph_ctx_set_deferred_errors: an overflowing ph_expr_eval returns PH_OK and the NEXT call that
     reads back fails with PH_EOVERFLOW, once; ph_join_lookup_strict reports a missing / duplicated
