@@ -316,6 +316,16 @@ int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const in
 #define PH_JOIN_FK_PROBES 2
 int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int32_t flags,
                      int64_t key_lo, int64_t key_hi, ph_join **out);
+/* Filter -> HashJoin build in one pass (filterExecutor under joinExecutor's build child): the rows
+ * sel[0..n) / 0..n that pass the comparison are built, without a selection vector and WITHOUT a
+ * host read of how many pass — possible because a direct table is sized by the key range, not by
+ * the row count. Only where ph_join_build_range picks a direct table (the test uses n, an upper
+ * bound of the rows built) and the comparison lowers to an integer range over a column without
+ * NULLs; PH_EUNSUPPORTED otherwise, and the caller runs ph_filter_select + ph_join_build_range.
+ * Build row ids reported by probes are positions in the UNFILTERED input (sel[i] or i). */
+int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
+                        const ph_const *where_k, const int32_t *sel, int64_t n, int64_t key_lo, int64_t key_hi,
+                        ph_join **out);
 /* the table form a build chose: "direct", "nodes", "chained+bloom" or "chained" */
 const char *ph_join_kind(const ph_join *j);
 int64_t ph_join_count(const ph_join *j);

@@ -1377,12 +1377,27 @@ __global__ __launch_bounds__(256) void join_mark_set_kernel(const uint16_t *__re
 // then the two kernels after it do any work — verify (a row that does not find itself in its slot
 // gets next = -3) and link (the losers are chained in front of the winner with atomicExch).
 // count[0] rows stored, count[1] occupied slots, count[2] keys outside [lo, hi].
+// build-side rows: key column, validity, selection and an optional pushed-down range filter (Filter ->
+// build in one pass: a direct table is sized by the key RANGE, so the number of rows that pass need
+// not be known on the host — no selection vector, no count read-back before the build)
+struct DirectSrc {
+    const void *kcol; const uint8_t *valid; const int32_t *sel;
+    int wkind;   // 0 none, 1 int32, 2 int64, 3 uint8 column wdata, rows with wlo <= value <= whi are built
+    const void *wdata; long long wlo, whi;
+};
+
 template <int KW, bool SEL>
-__device__ __forceinline__ bool direct_key(const void *__restrict__ kcol, const uint8_t *__restrict__ valid, const int32_t *__restrict__ sel,
-                                           int64_t i, long long lo, unsigned long long range, unsigned long long *off, bool *oor) {
-    const int64_t r = SEL ? (int64_t)sel[i] : i;
-    if (valid && !bit_valid(valid, r)) { *oor = false; return false; }   // NULL key: never inserted, never matches
-    const long long k = (long long)load_kw<KW>(kcol, r);
+__device__ __forceinline__ bool direct_key(const DirectSrc &S, int64_t i, long long lo, unsigned long long range, unsigned long long *off,
+                                           bool *oor) {
+    const int64_t r = SEL ? (int64_t)S.sel[i] : i;
+    *oor = false;
+    if (S.valid && !bit_valid(S.valid, r)) return false;   // NULL key: never inserted, never matches
+    if (S.wkind) {
+        const long long w = S.wkind == 1 ? (long long)((const int32_t *)S.wdata)[r] : S.wkind == 2 ? ((const long long *)S.wdata)[r]
+                                                                                                     : (long long)((const uint8_t *)S.wdata)[r];
+        if (w < S.wlo || w > S.whi) return false;
+    }
+    const long long k = (long long)load_kw<KW>(S.kcol, r);
     const unsigned long long o = (unsigned long long)(k - lo);
     *off = o;
     *oor = o >= range;
@@ -1408,8 +1423,7 @@ __device__ __forceinline__ void direct_block_add(int v0, int v1, int *__restrict
 }
 
 template <int KW, bool SEL>
-__global__ __launch_bounds__(DT) void direct_scatter_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
-                                                             const int32_t *__restrict__ sel, int64_t n, long long lo,
+__global__ __launch_bounds__(DT) void direct_scatter_kernel(DirectSrc S, int64_t n, long long lo,
                                                              unsigned long long range, int32_t *__restrict__ direct,
                                                              int *__restrict__ count) {
     constexpr int U = 4;
@@ -1421,7 +1435,7 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(const void *__restri
         for (int u = 0; u < U; u++) {
             const int64_t i = base + u * DT + threadIdx.x;
             oor[u] = false;
-            ok[u] = i < n && direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off[u], &oor[u]);
+            ok[u] = i < n && direct_key<KW, SEL>(S, i, lo, range, &off[u], &oor[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1437,8 +1451,7 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(const void *__restri
 // atomicExch as in join_build_kernel (a few microseconds of scattered atomics at this size, against
 // four more launches at ~5 us each), which links duplicate keys on the spot
 template <int KW, bool SEL>
-__global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
-                                                         const int32_t *__restrict__ sel, int64_t n, long long lo,
+__global__ __launch_bounds__(DT) void direct_small_kernel(DirectSrc S, int64_t n, long long lo,
                                                          unsigned long long range, int32_t *__restrict__ direct,
                                                          int32_t *__restrict__ next, int *__restrict__ count,
                                                          unsigned *__restrict__ coarse, int cshift, unsigned *__restrict__ dbits) {
@@ -1446,7 +1459,7 @@ __global__ __launch_bounds__(DT) void direct_small_kernel(const void *__restrict
     for (int64_t i = (int64_t)blockIdx.x * DT + threadIdx.x; i < n; i += (int64_t)gridDim.x * DT) {
         unsigned long long off;
         bool oor = false;
-        if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) {
+        if (direct_key<KW, SEL>(S, i, lo, range, &off, &oor)) {
             const int32_t old = atomicExch(&direct[off], (int32_t)i);
             if (coarse) { const unsigned cb = (unsigned)(off >> cshift); atomicOr(&coarse[cb >> 5], 1u << (cb & 31)); }
             if (dbits) atomicOr(&dbits[off >> 5], 1u << (off & 31));
@@ -1484,8 +1497,7 @@ __global__ __launch_bounds__(DT) void direct_occupied_kernel(const int32_t *__re
 }
 
 template <int KW, bool SEL>
-__global__ __launch_bounds__(256) void direct_verify_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
-                                                            const int32_t *__restrict__ sel, int64_t n, long long lo,
+__global__ __launch_bounds__(256) void direct_verify_kernel(DirectSrc S, int64_t n, long long lo,
                                                             unsigned long long range, const int32_t *__restrict__ direct,
                                                             int32_t *__restrict__ next, const int *__restrict__ count) {
     constexpr int U = 4;
@@ -1498,7 +1510,7 @@ __global__ __launch_bounds__(256) void direct_verify_kernel(const void *__restri
         for (int u = 0; u < U; u++) {
             const int64_t i = base + u * 256 + threadIdx.x;
             oor[u] = false;
-            ok[u] = i < n && direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off[u], &oor[u]);
+            ok[u] = i < n && direct_key<KW, SEL>(S, i, lo, range, &off[u], &oor[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) d[u] = direct[ok[u] ? off[u] : 0];
@@ -1513,8 +1525,7 @@ __global__ __launch_bounds__(256) void direct_verify_kernel(const void *__restri
 }
 
 template <int KW, bool SEL>
-__global__ __launch_bounds__(256) void direct_dups_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
-                                                          const int32_t *__restrict__ sel, int64_t n, long long lo,
+__global__ __launch_bounds__(256) void direct_dups_kernel(DirectSrc S, int64_t n, long long lo,
                                                           unsigned long long range, int32_t *__restrict__ direct,
                                                           int32_t *__restrict__ next, const int *__restrict__ count) {
     if (count[0] == count[1]) return;   // unique keys: nothing to link
@@ -1522,7 +1533,7 @@ __global__ __launch_bounds__(256) void direct_dups_kernel(const void *__restrict
         if (next[i] != -3) continue;
         unsigned long long off;
         bool oor;
-        if (direct_key<KW, SEL>(kcol, valid, sel, i, lo, range, &off, &oor)) next[i] = atomicExch(&direct[off], (int32_t)i);
+        if (direct_key<KW, SEL>(S, i, lo, range, &off, &oor)) next[i] = atomicExch(&direct[off], (int32_t)i);
     }
 }
 
@@ -1989,7 +2000,7 @@ static int build_big(ph_join *j, int kw, int nparts) {
         else { if (B.sel) KERNEL<8, true><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); else KERNEL<8, false><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); }         \
     } while (0)
 
-static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
+static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where) {
     ph_ctx *ctx = j->ctx;
     const int64_t n = j->build.n;
     const int64_t cap4 = ph::round_up(range, 4);
@@ -2020,11 +2031,10 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
     ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->dbits, dwords, j->bloom.coarse, j->count_dev);
     if (n > 0) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
-        const void *kcol = B.key[0].data;
-        const uint8_t *valid = B.key[0].validity;
+        const ph::DirectSrc S{B.key[0].data, B.key[0].validity, B.sel, where.kind, where.data, where.lo, where.hi};
         if (n <= (256 << 10)) {
             const int grids = (int)std::min<int64_t>((n + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
-            PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev,
+            PH_DIRECT_KS(ph::direct_small_kernel, grids, ph::DT, S, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev,
                          j->bloom.coarse, j->dcshift, j->dbits);
             PH_HIP(hipGetLastError());
             j->count = -1;
@@ -2033,11 +2043,11 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range) {
         // one 1024-thread workgroup per CU for the two passes that end in a counter update
         const int gridc = (int)std::min<int64_t>((n + ph::DT * 4 - 1) / (ph::DT * 4), (int64_t)ctx->cu_count);
         const int grido = (int)std::min<int64_t>((cap4 / 4 + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
-        PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->count_dev);
+        PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, S, n, (long long)lo, j->drange, j->direct, j->count_dev);
         ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev, j->dbits);
-        PH_DIRECT_KS(ph::direct_verify_kernel, grid, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+        PH_DIRECT_KS(ph::direct_verify_kernel, grid, 256, S, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
         const int grid1 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
-        PH_DIRECT_KS(ph::direct_dups_kernel, grid1, 256, kcol, valid, B.sel, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
+        PH_DIRECT_KS(ph::direct_dups_kernel, grid1, 256, S, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
     }
     PH_HIP(hipGetLastError());
     j->count = n == 0 ? 0 : -1;
@@ -2187,7 +2197,8 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
 }
 
 static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, bool have_range,
-                           int64_t key_lo, int64_t key_hi, bool fk_probes, ph_join **out) {
+                           int64_t key_lo, int64_t key_hi, bool fk_probes, ph_join **out,
+                           const ph::RangePred &where = ph::RangePred{0, nullptr, nullptr, 0, 0}) {
     PH_REQUIRE(ctx && keys && out && nkeys >= 1 && nkeys <= ph::JOIN_MAX_KEYS && n >= 0 && n < (1ll << 31),
                "ph_join_build: bad arguments (1..%d keys)", ph::JOIN_MAX_KEYS);
     ph_join *j = new ph_join();
@@ -2207,11 +2218,17 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
         const bool dense = (int64_t)span + 1 <= std::max<int64_t>(8 * n, 4096);
         const bool small_range = span < (4ull << 20) && n <= (256 << 10);
         if (!(dz && atoi(dz) == 0) && kw != 1 && span < (1ull << 30) && (dense || small_range)) {
-            int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1);
+            int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1, where);
             if (rcd != PH_OK) { ph_join_free(j); return rcd; }
             *out = j;
             return PH_OK;
         }
+    }
+    if (where.kind != 0) {   // only the direct table is built through a filter: its size does not depend on how many rows pass
+        ph::set_error("ph_join_build_where: the key range [%lld, %lld] does not give a direct table for %lld build rows; run "
+                      "ph_filter_select and ph_join_build", (long long)key_lo, (long long)key_hi, (long long)n);
+        ph_join_free(j);
+        return PH_EUNSUPPORTED;
     }
     // pointer table: cap = max(nextpow2(2n), 1024) (pointerTableCap, join_table.go:197-199)
     int64_t cap = 1024;
@@ -2361,6 +2378,19 @@ extern "C" int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, 
                                 int64_t key_lo, int64_t key_hi, ph_join **out) {
     PH_REQUIRE((flags & ~(PH_JOIN_KEY_RANGE | PH_JOIN_FK_PROBES)) == 0, "ph_join_build_ex: unknown flags %d", flags);
     return join_build_impl(ctx, keys, nkeys, sel, n, (flags & PH_JOIN_KEY_RANGE) != 0, key_lo, key_hi, (flags & PH_JOIN_FK_PROBES) != 0, out);
+}
+
+extern "C" int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
+                                   const ph_const *where_k, const int32_t *sel, int64_t n, int64_t key_lo, int64_t key_hi,
+                                   ph_join **out) {
+    PH_REQUIRE(where_col && where_k, "ph_join_build_where: bad arguments");
+    ph::RangePred where{};
+    if (!ph::lower_range_pred(where_col, where_op, where_k, &where) || where.validity) {
+        ph::set_error("ph_join_build_where: only integer-range predicates over a column without NULLs are fused into the build");
+        return PH_EUNSUPPORTED;
+    }
+    if (where.kind < 0) { where.kind = 1; where.data = keys[0].data; where.lo = 1; where.hi = 0; }   // never true: an empty range over any column
+    return join_build_impl(ctx, keys, nkeys, sel, n, true, key_lo, key_hi, false, out, where);
 }
 
 extern "C" const char *ph_join_kind(const ph_join *j) {

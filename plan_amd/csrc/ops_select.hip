@@ -853,8 +853,8 @@ struct GatherMulti {
     int ncols;
 };
 
+template <int U>
 __global__ __launch_bounds__(256) void gather_multi_kernel(GatherMulti G, const int32_t *__restrict__ idx, int64_t n) {
-    constexpr int U = 2;
     for (int64_t base = (int64_t)blockIdx.x * 256 * U; base < n; base += (int64_t)gridDim.x * 256 * U) {
         int32_t ix[U];
         unsigned long long v[U][GM_MAX];
@@ -903,8 +903,11 @@ extern "C" int ph_gather_multi(ph_ctx *ctx, int32_t ncols, const ph_col *cols, c
         G.src[c] = cols[c].data;
         G.dst[c] = out_dev[c];
     }
+    // 1, 2, 4 or 8 rows per thread and 4 .. 64 workgroups per CU all run within 8 % of each other on Q9's
+    // shape (5 columns at 5.4 % of 60 M ascending row ids: 245-265 us): the kernel is bound by the rate of
+    // 64-byte sector reads (~4.2 TB/s of sectors for 0.1 TB/s of values), not by latency
     int grid = (int)std::min<int64_t>((n + 511) / 512, 256 * 16);
-    ph::gather_multi_kernel<<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    ph::gather_multi_kernel<2><<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }

@@ -87,15 +87,28 @@ class Q3Pipeline:
 
         # ---- customer filter, build side of join 1
         t0 = tic()
-        cs, cn = hip.filter_select(ctx, self.c_seg, self.nc, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code))
-        frees.append(cs)
-        if N == 1:
+        j1 = None
+        if N == 1 and self.c_key_range is not None:
+            # Filter(c_mktsegment = ..) under the build child, fused into the build: c_custkey is a dense
+            # primary key, so the table is a direct table sized by the key range and the number of
+            # customers that pass never has to reach the host (no selection vector, no read-back)
+            j1 = hip.Join.build_where(ctx, [self.c_key], self.c_seg, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code),
+                                      None, self.nc, self.c_key_range)
+            if j1 is not None:
+                cn = j1.count() if self.time_stages else 0   # reporting only
+        if j1 is not None:
+            pass
+        elif N == 1:
+            cs, cn = hip.filter_select(ctx, self.c_seg, self.nc, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code))
+            frees.append(cs)
             # build on the gathered keys (no selection inside the table: one dependent read less per
             # chain step of the probe); the build-side row ids of this join are never used
             ck = hip.gather(ctx, self.c_key, cs, cn)
             frees.append(ck)
             j1 = hip.Join(ctx, [_raw(hip.PH_I32, ck)], None, cn, key_range=self.c_key_range)
         else:
+            cs, cn = hip.filter_select(ctx, self.c_seg, self.nc, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code))
+            frees.append(cs)
             mine = hip.gather(ctx, self.c_key, cs, cn)
             allkeys, nall = dist.allgather_rows(ctx, mine, cn, np.int32)   # broadcast of the small build side
             frees += [mine, allkeys]

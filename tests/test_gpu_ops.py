@@ -638,6 +638,40 @@ def test_join_direct_table_dense_keys(ctx):
         c.free()
 
 
+def test_join_build_where_equals_filter_then_build(ctx):
+    """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
+    row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
+    of the unfiltered input in both); duplicates among the passing rows; a predicate nothing passes;
+    PH_EUNSUPPORTED (None) where the range gives no direct table."""
+    rng = np.random.default_rng(51)
+    nb, np_ = 600_000, 900_000
+    bk = (rng.permutation(1_000_000)[:nb] + 10).astype(np.int32)
+    bk[:50] = bk[100:150]                                             # duplicate keys
+    seg = rng.integers(0, 5, nb).astype(np.uint8)
+    pk = rng.integers(0, 1_000_100, np_).astype(np.int32)
+    dbk, dseg, dpk = hip.DevColumn(ctx, hip.PH_I32, bk), hip.DevColumn(ctx, hip.PH_CODE8, seg), hip.DevColumn(ctx, hip.PH_I32, pk)
+    rngk = (10, 1_000_009)
+    for code in (2, 9):                                               # 9: nothing passes
+        jw = hip.Join.build_where(ctx, [dbk], dseg, hip.PH_EQ, hip.const(hip.PH_I32, i=code), None, nb, rngk)
+        assert jw is not None and jw.kind == "direct"
+        fs, fn = hip.filter_select(ctx, dseg, nb, hip.PH_EQ, hip.const(hip.PH_I32, i=code))
+        jf = hip.Join(ctx, [dbk], fs, fn, key_range=rngk)
+        assert jw.count() == jf.count() == int((seg == code).sum())
+        mw, pw, bw = jw.probe_inner([dpk], None, np_, 2 * np_)
+        mf, pf, bf = jf.probe_inner([dpk], None, np_, 2 * np_)
+        assert mw == mf
+        a = np.stack([ctx.download(pw, np.int32, mw), ctx.download(bw, np.int32, mw)], 1)
+        b = np.stack([ctx.download(pf, np.int32, mf), ctx.download(bf, np.int32, mf)], 1)
+        assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b[np.lexsort((b[:, 1], b[:, 0]))])
+        if mw:
+            assert np.all(seg[a[:, 1]] == code) and np.array_equal(bk[a[:, 1]], pk[a[:, 0]])
+        assert np.array_equal(ctx.download(jw.probe_mark([dpk], None, np_), np.uint8, np_), ctx.download(jf.probe_mark([dpk], None, np_), np.uint8, np_))
+        jw.free(); jf.free()
+    assert hip.Join.build_where(ctx, [dbk], dseg, hip.PH_EQ, hip.const(hip.PH_I32, i=2), None, nb, (0, 2**31)) is None
+    for c in (dbk, dseg, dpk):
+        c.free()
+
+
 def test_join_fk_probe_hint_takes_node_table(ctx):
     """ph_join_build_ex with PH_JOIN_FK_PROBES: build sides of >= 32 K rows take the node table (no
     Bloom bitmap); lookups, pairs and marks equal the default table's (composite 4-byte keys and one
