@@ -41,6 +41,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 XGMI_PEAK_GBS = 7 * 153.0  # per GPU, all 7 links busy (MI355X_MICROARCH.md)
 
 
+def pmc_traffic_any(q, names):
+    """first of several kernel names (a kernel renamed between rounds) that a committed PMC summary knows"""
+    for nm in names:
+        t = pmc_traffic((q, nm))
+        if t is not None:
+            return t
+    return None
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_summary.json, newest
     round first: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py,
@@ -354,12 +363,12 @@ def bench_q3(h, sf, steps, warmup, scaling):
             "top1": list(r["top"][0]) if r["top"] else None,
         },
         "roofline": roofline(probe_bytes / (probe_ms * 1e-3) / 1e9,
-                             traffic=pmc_traffic(("q3", "join_cand_fast_kernel<8")) if (h.world == 1 and nrows == 59986052) else None,
-                             traffic_note="PMC traffic of join_cand_fast_kernel<8,...> (the stage's dominant kernel: 166 of ~250 us); "
-                                          "traffic_stage_kernels has the stage's other kernels",
+                             traffic=pmc_traffic_any("q3", ("join_cand_vec_kernel<8", "join_cand_fast_kernel<8")) if (h.world == 1 and nrows == 59986052) else None,
+                             traffic_note="PMC traffic of the lineitem candidate kernel (join_cand_vec_kernel<8,...>, the stage's dominant kernel: "
+                                          "~165 of ~240 us); traffic_stage_kernels has the stage's other kernels",
                              traffic_stage_kernels=({k: pmc_traffic(("q3", k)) for k in ("join_chain_fast_kernel<8", "join_emit_kernel")}
                                                     if (h.world == 1 and nrows == 59986052) else None),
-                             kernel="join_cand_fast_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
+                             kernel="join_cand_vec_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
                              avg_launch_ms=probe_ms, algorithmic_bytes_per_launch=probe_bytes,
                              timing="HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
                              host_timed_stage_ms=host_probe_ms,
@@ -407,6 +416,27 @@ def bench_q9(h, sf, steps, warmup):
     inputs = (nrows * 36 + len(P["p_partkey"]) * 8 + len(P["p_name_bytes"]) + len(PS["ps_partkey"]) * 16 +
               len(S["s_suppkey"]) * 8 + len(Od["o_orderkey"]) * 12)
     ms_step = elapsed / steps * 1e3
+    # the dominant kernel, timed live with HIP events on the launch stream over the same row ids: the late
+    # materialisation of five lineitem columns at the rows that survive the part join (ph_gather_multi)
+    pipe.keep_gather_ids = True
+    pipe.time_stages = False
+    pipe.run()
+    pipe.keep_gather_ids = False
+    ids, n1 = pipe.kept_gather_ids
+    gcols = [pipe.l_supp, pipe.l_key, pipe.l_ext, pipe.l_disc, pipe.l_qty]
+    T = h.torch
+    ev = [T.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 20
+    for w in range(2):
+        ev[0].record()
+        for _ in range(reps):
+            for o in h.hip.gather_multi(h.ctx, gcols, ids, n1):
+                h.ctx.free(o)
+        ev[1].record()
+        T.cuda.synchronize()
+    gm_ms = ev[0].elapsed_time(ev[1]) / reps
+    h.ctx.free(ids)
+    gm_bytes = n1 * (4 + 2 * (4 + 8 + 8 + 8 + 4))   # row id + the five values read and written once
     line = {
         "metric": "rows/sec through 4 hash joins + hash-agg (Q9)", "value": nrows * steps / elapsed, "unit": "rows/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
@@ -414,9 +444,16 @@ def bench_q9(h, sf, steps, warmup):
                    "groups": r["ngroups"], "join_rows": r["join_rows"],
                    "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk != "exchange_bytes_sent"},
                    "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage"},
-        "roofline": roofline(inputs / (ms_step * 1e-3) / 1e9, traffic=None, kernel="whole query (all kernels of one Q9)",
-                             avg_launch_ms=ms_step, algorithmic_bytes_per_launch=inputs,
-                             timing="host clock around the timed steps (one query = ~40 launches)"),
+        "roofline": roofline(gm_bytes / (gm_ms * 1e-3) / 1e9,
+                             traffic=pmc_traffic(("q9", "gather_multi_kernel")) if nrows == 59986052 else None,
+                             kernel="gather_multi_kernel (largest kernel of the query: five lineitem columns at the ~5 % of rows that survive the part join)",
+                             avg_launch_ms=gm_ms, algorithmic_bytes_per_launch=gm_bytes,
+                             timing="HIP events on the launch stream around 20 launches over the query's own row ids",
+                             note="bound by 64-byte sector reads: every gathered 4- or 8-byte value costs one sector (traffic >> algorithmic bytes); "
+                                  "1, 2, 4, 8 rows per thread and 4..64 workgroups per CU all run within 8 % of each other",
+                             whole_query={"algorithmic_bytes": inputs, "achieved": inputs / (ms_step * 1e-3) / 1e9,
+                                          "frac": inputs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "timing": "host clock around the timed steps (one query = ~45 launches)"}),
     }
     pipe.free()
     return line

@@ -240,6 +240,36 @@ __global__ __launch_bounds__(1024) void scan_kernel(int32_t *__restrict__ v, int
     if (threadIdx.x == 0) *out_total = carry;
 }
 
+// the same for n <= 16384 in ONE step: a thread owns 16 consecutive elements (the loop above pays three
+// barriers per 1024 elements: 12 us for the 7 324 block totals of a 15 M-row probe, 3 us here)
+__global__ __launch_bounds__(1024) void scan_small_kernel(int32_t *__restrict__ v, int n, int64_t *__restrict__ out_total) {
+    constexpr int E = 16;
+    __shared__ long long wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = threadIdx.x * E;
+    int x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = i0 + e < n ? v[i0 + e] : 0;
+    long long mine = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) mine += x[e];
+    long long incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        long long y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    long long run = incl - mine;
+    for (int k = 0; k < w; k++) run += wsum[k];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        if (i0 + e < n) v[i0 + e] = (int32_t)run;
+        run += x[e];
+    }
+    if (threadIdx.x == 1023) *out_total = run;
+}
+
 __global__ __launch_bounds__(256) void select_write_kernel(SelParams P, const int32_t *__restrict__ sel_in,
                                                            int64_t n_in, const int32_t *__restrict__ block_off,
                                                            int32_t *__restrict__ sel_out,
@@ -604,7 +634,8 @@ __global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict
 
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev) {
     if (n <= 4 * SCAN_TILE) {
-        scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
+        if (n > 1024) scan_small_kernel<<<1, 1024, 0, ctx->stream>>>(dev, (int)n, total_dev);
+        else scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
         PH_HIP(hipGetLastError());
         return PH_OK;
     }

@@ -394,6 +394,8 @@ class Q9Pipeline:
         d_supp, c_okey, d_ext, d_disc, d_qty = hip.gather_multi(
             ctx, [self.l_supp, self.l_key, self.l_ext, self.l_disc, self.l_qty], lrow, n1)
         frees += [d_supp, c_okey, d_ext, d_disc, d_qty]
+        if getattr(self, "keep_gather_ids", False):   # bench.py times this kernel on the very same row ids afterwards
+            self.kept_gather_ids = (ctx.upload(ctx.download(lrow, np.int32, n1)), n1)
         # The two joins below are N:1 (partsupp's composite primary key, supplier's key): LOOKUP
         # probes — one kernel each, no candidate/scan/emit pipeline, no re-gather of earlier columns.
         stats = None
