@@ -334,6 +334,20 @@ type stagedCol struct {
 	hasNull   bool
 	dict      []string
 	dictIndex map[string]int
+	// value range of the non-NULL integer values staged so far: the column statistics ph_join_build_ex
+	// wants for a direct (dense-key) join table. Staging touches every value anyway.
+	lo, hi  int64
+	ranged  bool
+}
+
+func (sc *stagedCol) note(v int64) {
+	if !sc.ranged {
+		sc.lo, sc.hi, sc.ranged = v, v, true
+	} else if v < sc.lo {
+		sc.lo = v
+	} else if v > sc.hi {
+		sc.hi = v
+	}
 }
 
 func phTypeOf(t common.LType, asString bool) (C.int32_t, int, bool) {
@@ -407,9 +421,13 @@ func (sc *stagedCol) append(vec *chunk.Vector, card int, rowBase int) error {
 		}
 		switch sc.typ.GetInternalType() {
 		case common.INT32:
-			*(*int32)(dst) = chunk.GetSliceInPhyFormatUnifiedFormat[int32](&uni)[idx]
+			v := chunk.GetSliceInPhyFormatUnifiedFormat[int32](&uni)[idx]
+			*(*int32)(dst) = v
+			sc.note(int64(v))
 		case common.INT64:
-			*(*int64)(dst) = chunk.GetSliceInPhyFormatUnifiedFormat[int64](&uni)[idx]
+			v := chunk.GetSliceInPhyFormatUnifiedFormat[int64](&uni)[idx]
+			*(*int64)(dst) = v
+			sc.note(v)
 		case common.DATE:
 			d := chunk.GetSliceInPhyFormatUnifiedFormat[common.Date](&uni)[idx]
 			*(*int32)(dst) = daysFromCivil(int(d.Year), int(d.Month), int(d.Day))
@@ -489,6 +507,7 @@ func (b *deviceBatch) reset() {
 		sc.bytes.reset()
 		sc.valid = sc.valid[:0]
 		sc.hasNull = false
+		sc.ranged = false
 	}
 	b.rows = 0
 }
@@ -1310,7 +1329,14 @@ func (e *gpuJoinExecutor) buildTable() error {
 	if err := e.buildBatch.upload(); err != nil {
 		return err
 	}
-	return phErr(C.ph_join_build(e.ctx, &e.buildBatch.dev[0], C.int32_t(len(e.buildKeys)), nil, C.int64_t(total), &e.join))
+	// One INTEGER / BIGINT key: hand the library the key range seen while staging. A dense range (a
+	// primary key: customer, supplier, orders) then builds a direct table addressed by key - lo instead
+	// of a hash table; anything else falls back inside the library to what ph_join_build builds.
+	flags, lo, hi := C.int32_t(0), C.int64_t(0), C.int64_t(0)
+	if len(e.buildKeys) == 1 && e.buildBatch.sc[0].ranged {
+		flags, lo, hi = C.PH_JOIN_KEY_RANGE, C.int64_t(e.buildBatch.sc[0].lo), C.int64_t(e.buildBatch.sc[0].hi)
+	}
+	return phErr(C.ph_join_build_ex(e.ctx, &e.buildBatch.dev[0], C.int32_t(len(e.buildKeys)), nil, C.int64_t(total), flags, lo, hi, &e.join))
 }
 
 func chunkOf(starts []int, row int) int { // last chunk whose first row <= row
