@@ -92,6 +92,7 @@ void DeviceBatch::Reset() {
         valid_[k].clear();
         has_null_[k] = false;
     }
+    std::fill(ranged_.begin(), ranged_.end(), false);
     rows_ = 0;
 }
 
@@ -138,8 +139,8 @@ std::string DeviceBatch::Append(const Chunk &c) {
             uint8_t *dst = host_[k].data() + base + (size_t)i * (size_t)w;
             if (!ok) { memset(dst, 0, (size_t)w); continue; }
             switch (t.GetInternalType()) {
-            case PT_INT32: memcpy(dst, u.data + (size_t)idx * 4, 4); break;
-            case PT_INT64: memcpy(dst, u.data + (size_t)idx * 8, 8); break;
+            case PT_INT32: { int32_t v; memcpy(&v, u.data + (size_t)idx * 4, 4); memcpy(dst, &v, 4); note_range((int)k, v); break; }
+            case PT_INT64: { int64_t v; memcpy(&v, u.data + (size_t)idx * 8, 8); memcpy(dst, &v, 8); note_range((int)k, v); break; }
             case PT_INT128: {
                 const Hugeint &hg = reinterpret_cast<const Hugeint *>(u.data)[idx];
                 if (hg.Upper != ((int64_t)hg.Lower >> 63)) return "HUGEINT value does not fit int64 on the device";
@@ -710,7 +711,11 @@ std::string gpuJoinExecutor::buildTable() {  // joinBuildHashTable (executor_joi
     if (!e.empty()) return e;
     std::vector<ph_col> keys;
     for (size_t k = 0; k < buildKeys_.size(); k++) keys.push_back(buildBatch_->col((int)k));
-    if (ph_join_build(ctx_, keys.data(), (int32_t)keys.size(), nullptr, total, &join_) != PH_OK) return herr("ph_join_build");
+    // one INTEGER / BIGINT key: the key range noted while staging lets the library build a direct table for
+    // dense keys (a primary key); anything else builds what ph_join_build builds
+    int64_t lo = 0, hi = 0;
+    const int32_t flags = keys.size() == 1 && buildBatch_->key_range(0, &lo, &hi) ? PH_JOIN_KEY_RANGE : 0;
+    if (ph_join_build_ex(ctx_, keys.data(), (int32_t)keys.size(), nullptr, total, flags, lo, hi, &join_) != PH_OK) return herr("ph_join_build_ex");
     return "";
 }
 

@@ -116,7 +116,21 @@ public:
     ph_col col(int k) const { return dev_[(size_t)k]; }  // k-th selected column, device view
     const std::vector<std::string> &dict(int k) const { return dicts_[(size_t)k]; }
     int code_of(int k, const std::string &s) const;      // -1 when not in the dictionary
+    // value range of the non-NULL INTEGER / BIGINT values staged in column k (column statistics for
+    // ph_join_build_ex); false when the column has another type or no value yet
+    bool key_range(int k, int64_t *lo, int64_t *hi) const {
+        if ((size_t)k >= ranged_.size() || !ranged_[(size_t)k]) return false;
+        *lo = lo_[(size_t)k]; *hi = hi_[(size_t)k];
+        return true;
+    }
 private:
+    void note_range(int k, int64_t v) {
+        if (ranged_.size() <= (size_t)k) { ranged_.resize((size_t)k + 1, false); lo_.resize((size_t)k + 1, 0); hi_.resize((size_t)k + 1, 0); }
+        if (!ranged_[(size_t)k]) { ranged_[(size_t)k] = true; lo_[(size_t)k] = hi_[(size_t)k] = v; }
+        else { if (v < lo_[(size_t)k]) lo_[(size_t)k] = v; if (v > hi_[(size_t)k]) hi_[(size_t)k] = v; }
+    }
+    std::vector<bool> ranged_;
+    std::vector<int64_t> lo_, hi_;
     ph_ctx *ctx_;
     std::vector<LType> types_;
     std::vector<int> cols_;

@@ -11,11 +11,17 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
-    acc = collections.defaultdict(list)
+    # a kernel launched over several shapes in one run (ph_gather_multi over 3.3 M and over 0.4 M rows) is
+    # reported per launch shape (grid size); the entry of a kernel is its shape with the most traffic
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(files[0])):
         if row["Counter_Name"] == counter:
-            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-    res[f"{run} {counter}"] = [{"kernel": k, "counter": counter, "dispatches": len(v), "avg": sum(v) / len(v)}
-                               for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))]
+            acc[row["Kernel_Name"]][row.get("Grid_Size", "")].append(float(row["Counter_Value"]))
+    entries = []
+    for k, shapes in acc.items():
+        g, v = max(shapes.items(), key=lambda kv: sum(kv[1]))
+        entries.append({"kernel": k, "counter": counter, "dispatches": len(v), "avg": sum(v) / len(v), "grid_size": g,
+                        "other_shapes": {gg: {"dispatches": len(vv), "avg": sum(vv) / len(vv)} for gg, vv in shapes.items() if gg != g}})
+    res[f"{run} {counter}"] = sorted(entries, key=lambda e: -e["avg"] * e["dispatches"])
 json.dump(res, open(out, "w"), indent=1)
 print("wrote", out, "runs:", list(res.keys()))
