@@ -1425,8 +1425,9 @@ __device__ __forceinline__ void direct_block_add(int v0, int v1, int *__restrict
 template <int KW, bool SEL>
 __global__ __launch_bounds__(DT) void direct_scatter_kernel(DirectSrc S, int64_t n, long long lo,
                                                              unsigned long long range, int32_t *__restrict__ direct,
-                                                             int *__restrict__ count) {
+                                                             int *__restrict__ count, const int *__restrict__ gate) {
     constexpr int U = 4;
+    if (gate && *gate == 0) return;   // the sorted fill already built the table
     int ins = 0, out = 0;
     for (int64_t base = (int64_t)blockIdx.x * DT * U; base < n; base += (int64_t)gridDim.x * DT * U) {
         unsigned long long off[U];
@@ -1445,6 +1446,115 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(DirectSrc S, int64_t
         }
     }
     direct_block_add(ins, out, count, count + 2);
+}
+
+// SORTED build keys (a primary-key column in storage order: orders by o_orderkey) need neither the
+// initialisation pass nor the scatter: a workgroup that owns rows [r0, r1) owns the slots from
+// key[r0] - lo up to key[r1] - lo, composes them 16 K at a time in LDS (-1, then its rows' positions)
+// and writes them out whole — one streaming write of the table instead of a fill, a scatter of
+// partial lines and a counting read (60 M slots: 40 us against 36 + 96 + 56). Rows of equal keys are
+// adjacent, so the occupied-slot count is known here too. The kernel VERIFIES the order it relies on:
+// on the first descending pair (or key outside the range) it raises count[3], and the general passes,
+// which otherwise leave at once, run instead.
+constexpr int SF_ROWS = 512;     // rows per step of a 256-thread workgroup (eight workgroups per CU overlap each other's latencies)
+constexpr int SF_TILE = 4096;    // slots composed in LDS at a time
+
+template <int KW>
+__global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__restrict__ kcol, int64_t n, long long lo,
+                                                                unsigned long long range, int64_t cap4, int32_t *__restrict__ direct,
+                                                                int *__restrict__ count, int *__restrict__ partials) {
+    __shared__ int tile[SF_TILE];
+    __shared__ long long kk[SF_ROWS + 2];   // key[r0 - 1] (the run test of the first row), the chunk's keys, key[r1]
+    long long *keys = kk + 1;
+    __shared__ int s_bad;
+    int stored = 0, runs = 0;
+    const int64_t nchunks = (n + SF_ROWS - 1) / SF_ROWS;
+    const long long beyond = (long long)(lo + (long long)range);   // above every valid key: the "next key" of the last row
+    // software pipeline: the keys of the NEXT chunk are in flight while this one is composed
+    constexpr int KR = (SF_ROWS + 2 + 255) / 256;
+    long long kreg[KR];
+    auto fetch = [&](int64_t c) {
+        const int64_t r0 = c * SF_ROWS;
+#pragma unroll
+        for (int q = 0; q < KR; q++) {
+            const int64_t i = r0 - 1 + q * 256 + threadIdx.x;
+            kreg[q] = (c < nchunks && i >= 0 && i < n && q * 256 + (int)threadIdx.x < SF_ROWS + 2) ? (long long)load_kw<KW>(kcol, i) : beyond;
+        }
+    };
+    fetch(blockIdx.x);
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t r0 = c * SF_ROWS, r1 = r0 + SF_ROWS < n ? r0 + SF_ROWS : n;
+        const int m = (int)(r1 - r0);
+        __syncthreads();   // the previous chunk's readers are done
+        if (threadIdx.x == 0) s_bad = 0;
+#pragma unroll
+        for (int q = 0; q < KR; q++)
+            if (q * 256 + (int)threadIdx.x < SF_ROWS + 2) kk[q * 256 + threadIdx.x] = kreg[q];
+        fetch(c + gridDim.x);
+        __syncthreads();
+        bool bad = false;
+        for (int e = threadIdx.x; e < m; e += 256) {
+            const unsigned long long off = (unsigned long long)(keys[e] - lo);
+            bad = bad || off >= range || keys[e] > keys[e + 1];
+            runs += (r0 + e == 0) || keys[e - 1] != keys[e];
+            stored++;
+        }
+        if (bad) s_bad = 1;
+        __syncthreads();
+        if (s_bad) { if (threadIdx.x == 0) atomicOr(count + 3, 1); continue; }   // nothing written for this chunk: the general passes rebuild everything
+        const int64_t s0 = c == 0 ? 0 : keys[0] - lo;
+        const int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+        for (int64_t t = s0; t < s1; t += SF_TILE) {
+            const int w = (int)(s1 - t < SF_TILE ? s1 - t : SF_TILE);
+            __syncthreads();
+            for (int e = threadIdx.x; e < w; e += 256) tile[e] = -1;
+            __syncthreads();
+            for (int e = threadIdx.x; e < m; e += 256) {
+                const int64_t off = keys[e] - lo - t;
+                if (off >= 0 && off < w) tile[off] = (int32_t)(r0 + e);   // equal keys: any of them; the chains are linked afterwards
+            }
+            __syncthreads();
+            // 16-byte stores over the part of [t, t + w) that is 16-byte aligned in the table, 4-byte stores at the ends
+            const int head = (int)((4 - (t & 3)) & 3) < w ? (int)((4 - (t & 3)) & 3) : w;
+            const int nq = (w - head) / 4;
+            if ((int)threadIdx.x < head) direct[t + threadIdx.x] = tile[threadIdx.x];
+            int4 *d4 = reinterpret_cast<int4 *>(direct + t + head);
+            for (int q = threadIdx.x; q < nq; q += 256) {
+                const int e = head + 4 * q;
+                d4[q] = make_int4(tile[e], tile[e + 1], tile[e + 2], tile[e + 3]);
+            }
+            for (int e = head + 4 * nq + threadIdx.x; e < w; e += 256) direct[t + e] = tile[e];
+        }
+    }
+    // per-workgroup partial counts (2048 workgroups adding to one counter would serialise: ~10 ns each)
+    __shared__ int part[2][4];
+    for (int o = 32; o > 0; o >>= 1) { stored += __shfl_xor(stored, o); runs += __shfl_xor(runs, o); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = stored; part[1][threadIdx.x >> 6] = runs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        partials[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    }
+}
+
+// the general passes' initialisation when the sorted fill gave up
+__global__ __launch_bounds__(256) void direct_refill_kernel(int32_t *__restrict__ direct, int64_t cap4, const int *__restrict__ count) {
+    if (count[3] == 0) return;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    int4 *d4 = reinterpret_cast<int4 *>(direct);
+    for (int64_t i = t; i < cap4 / 4; i += step) d4[i] = make_int4(-1, -1, -1, -1);
+}
+// one workgroup: the fill's partial counts -> count[0] (rows stored), count[1] (slots occupied), or nothing
+// when the fill gave up (the general passes count for themselves)
+__global__ __launch_bounds__(256) void direct_recount_kernel(int *__restrict__ count, const int *__restrict__ partials, int nparts) {
+    if (count[3] != 0) return;
+    int a = 0, b = 0;
+    for (int e = threadIdx.x; e < nparts; e += 256) { a += partials[2 * e]; b += partials[2 * e + 1]; }
+    __shared__ int sa[4], sb[4];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { count[0] = sa[0] + sa[1] + sa[2] + sa[3]; count[1] = sb[0] + sb[1] + sb[2] + sb[3]; }
 }
 
 // small build sides (<= 256 K rows): ONE kernel after the initialisation — head insertion with
@@ -1476,8 +1586,9 @@ __global__ __launch_bounds__(DT) void direct_small_kernel(DirectSrc S, int64_t n
 // occupied slots of the table (cap4 is a multiple of 4; the padding slots are -1)
 // ... and, for tables of <= 8 M slots, the occupancy bitmap: a thread's 4 slots are a nibble, 8 lanes a word
 __global__ __launch_bounds__(DT) void direct_occupied_kernel(const int32_t *__restrict__ direct, int64_t cap4, int *__restrict__ count,
-                                                            unsigned *__restrict__ dbits) {
+                                                            unsigned *__restrict__ dbits, const int *__restrict__ gate) {
     typedef int v4i __attribute__((ext_vector_type(4)));
+    if (gate && *gate == 0) return;
     const v4i *d4 = reinterpret_cast<const v4i *>(direct);
     const int64_t nq = cap4 / 4;
     int occ = 0;
@@ -2028,7 +2139,14 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
         dwords = ph::round_up(cap4, 128) / 32;   // the occupied kernel writes whole words up to cap4
         PH_CHECK(ctx->pool_alloc(dwords * 4, (void **)&j->dbits));
     }
-    ph::join_init_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->dbits, dwords, j->bloom.coarse, j->count_dev);
+    // sorted keys (verified on the device): one streaming fill instead of initialisation + scatter + count.
+    // Plain shapes only (no selection, NULLs or pushed-down filter; no occupancy bitmap to derive).
+    const char *sfe = getenv("PH_JOIN_SORTED_FILL");   // read per call: the test builds both ways in one process
+    const bool no_sorted = sfe && atoi(sfe) == 0;
+    const bool try_sorted = !no_sorted && n > (256 << 10) && !B.sel && !B.key[0].validity && where.kind == 0 && !j->dbits;
+    // (the sorted fill writes every slot itself: only the counters are cleared here)
+    ph::join_init_kernel<<<try_sorted ? 1 : ctx->cu_count * 4, 256, 0, ctx->stream>>>(try_sorted ? nullptr : j->direct, cap4, j->dbits, dwords,
+                                                                                     j->bloom.coarse, j->count_dev);
     if (n > 0) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
         const ph::DirectSrc S{B.key[0].data, B.key[0].validity, B.sel, where.kind, where.data, where.lo, where.hi};
@@ -2040,11 +2158,23 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
             j->count = -1;
             return PH_OK;
         }
+        const int *gate = nullptr;
+        int *partials = nullptr;
+        if (try_sorted) {
+            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * 8);
+            PH_CHECK(ctx->pool_alloc((int64_t)gridf * 8, (void **)&partials));
+            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials);
+            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials);
+            ph::direct_recount_kernel<<<1, 256, 0, ctx->stream>>>(j->count_dev, partials, gridf);
+            ph::direct_refill_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->count_dev);
+            ctx->pool_release(partials);   // stream-ordered reuse
+            gate = j->count_dev + 3;
+        }
         // one 1024-thread workgroup per CU for the two passes that end in a counter update
         const int gridc = (int)std::min<int64_t>((n + ph::DT * 4 - 1) / (ph::DT * 4), (int64_t)ctx->cu_count);
         const int grido = (int)std::min<int64_t>((cap4 / 4 + ph::DT - 1) / ph::DT, (int64_t)ctx->cu_count);
-        PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, S, n, (long long)lo, j->drange, j->direct, j->count_dev);
-        ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev, j->dbits);
+        PH_DIRECT_KS(ph::direct_scatter_kernel, gridc, ph::DT, S, n, (long long)lo, j->drange, j->direct, j->count_dev, gate);
+        ph::direct_occupied_kernel<<<grido, ph::DT, 0, ctx->stream>>>(j->direct, cap4, j->count_dev, j->dbits, gate);
         PH_DIRECT_KS(ph::direct_verify_kernel, grid, 256, S, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);
         const int grid1 = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
         PH_DIRECT_KS(ph::direct_dups_kernel, grid1, 256, S, n, (long long)lo, j->drange, j->direct, j->next, j->count_dev);

@@ -638,6 +638,41 @@ def test_join_direct_table_dense_keys(ctx):
         c.free()
 
 
+def test_join_direct_table_sorted_fill(ctx):
+    """Build keys in storage order (sorted) and a range above 8 M slots take the one-pass sorted fill of
+    the direct table; the kernel verifies the order, so unsorted keys of the same shape fall back to
+    the general passes: sorted unique keys, sorted keys with duplicate runs (one across a 2048-row
+    chunk boundary), one descending pair in the middle, and PH_JOIN_SORTED_FILL=0 all give the
+    reference's pairs / marks / counts."""
+    import os
+    rng = np.random.default_rng(61)
+    n, np_ = 1_300_000, 600_000
+    uniq = np.sort(rng.choice(10_000_000, n, replace=False)).astype(np.int64) + 77
+    dup = np.sort(rng.integers(0, 9_500_000, n)).astype(np.int64) + 77
+    dup[2046:2051] = dup[2046]                                         # a run across the first chunk boundary
+    dup[-3:] = dup[-1]
+    swapped = uniq.copy()
+    swapped[700_000], swapped[700_001] = uniq[700_001], uniq[700_000]  # one descending pair
+    p = rng.integers(0, 10_000_200, np_).astype(np.int64)
+    p[:1000] = dup[2046]
+    rngk = (77, 10_000_076)
+    for keys in (uniq, dup, swapped):
+        join_compare(ctx, [(hip.PH_I64, O.OT_INT64, keys, None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="direct")
+    os.environ["PH_JOIN_SORTED_FILL"] = "0"
+    try:
+        join_compare(ctx, [(hip.PH_I64, O.OT_INT64, dup, None)], [(hip.PH_I64, O.OT_INT64, p, None)], key_range=rngk, kind="direct")
+    finally:
+        os.environ.pop("PH_JOIN_SORTED_FILL")
+    # int32 keys, lookup of every build key finds a row of its run
+    k32 = np.sort(rng.integers(0, 9_000_000, 1_200_000)).astype(np.int32)
+    d32 = hip.DevColumn(ctx, hip.PH_I32, k32)
+    j = hip.Join(ctx, [d32], None, len(k32), key_range=(0, 9_000_000))
+    assert j.kind == "direct" and j.count() == len(k32)
+    got = ctx.download(j.lookup([d32], None, len(k32)), np.int32, len(k32))
+    assert np.all(got >= 0) and np.array_equal(k32[got], k32)
+    j.free(); d32.free()
+
+
 def test_join_build_where_equals_filter_then_build(ctx):
     """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
     row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
