@@ -783,14 +783,14 @@ namespace {
 
 // ---- plan-specialised sink: the same device source (agg_sink.inc), compiled through hiprtc with
 // the sink's shape as compile-time constants. Key = everything the SK_* macros fold.
-std::string agg_spec_defines(const ph::AggSinkParams &P, std::string *key) {
+std::string agg_spec_defines(const ph::AggSinkParams &P, int threads, std::string *key) {
     std::ostringstream d, k;
     auto list = [&](const char *name, int n, auto f) {   // #define name(i) ((i)==0?v0:(i)==1?v1:...:0)
         d << "#define " << name << "(i) (";
         for (int i = 0; i < n; i++) d << "(i)==" << i << "?" << f(i) << ":";
         d << "0)\n";
     };
-    d << "#define PH_SPEC 1\n#define SPEC_NK " << P.nkeys << "\n#define SPEC_NA " << P.naggs << "\n"
+    d << "#define PH_SPEC 1\n#define SPEC_T " << threads << "\n#define SPEC_NK " << P.nkeys << "\n#define SPEC_NA " << P.naggs << "\n"
       << "#define SPEC_HAS_SEL " << (P.sel ? 1 : 0) << "\n#define SPEC_POSITIONAL " << (P.positional ? 1 : 0) << "\n"
       << "#define SPEC_AGG_MASK " << (P.agg_mask & ((1u << P.naggs) - 1u)) << "u\n#define SPEC_ARG_USED " << P.arg_used << "u\n";
     list("SPEC_KIND_OF", P.naggs, [&](int i) { return P.agg_kind[i]; });
@@ -804,11 +804,11 @@ std::string agg_spec_defines(const ph::AggSinkParams &P, std::string *key) {
 }
 
 // the specialised kernel of this sink shape, or PH_EUNSUPPORTED (no hiprtc, PH_AGG_JIT=0, compile trouble)
-int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, ph::JitKernel *out) {
+int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, int threads, ph::JitKernel *out) {
     const char *e = getenv("PH_AGG_JIT");   // read per call: tests compare both kernels in one process
     if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
     std::string key;
-    std::string defs = agg_spec_defines(P, &key);
+    std::string defs = agg_spec_defines(P, threads, &key);
     if (ph::jit_cached(ctx, key, out)) return PH_OK;   // no 20 KB source concatenation on a hit
     int rc = ph::jit_module(ctx, key, defs + AGG_SINK_SRC, "agg_sink_spec", out);
     return rc == PH_OK ? PH_OK : PH_EUNSUPPORTED;
@@ -840,7 +840,7 @@ extern "C" int ph_agg_jit_selfcheck(int32_t which) {
         return PH_EINVAL;
     }
     std::string key, log;
-    std::string src = agg_spec_defines(P, &key) + AGG_SINK_SRC;
+    std::string src = agg_spec_defines(P, which == 0 ? 1024 : 256, &key) + AGG_SINK_SRC;
     return ph::jit_compile_only(src, "gfx950", &log);
 }
 
@@ -931,19 +931,30 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     // specialised for this shape; small ones, and everything when hiprtc is unavailable, the generic one
     ph::JitKernel spec{};
     bool have_spec = false;
+    int spec_threads = 256;
     {
         ph::AggSinkParams Q = P;   // the shape is complete at this point (pointers do not enter the key)
         for (int c = 0; c < nargs; c++) if (used[c]) Q.arg_used |= 1u << c;
-        have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, Q, &spec) == PH_OK;
+        // 512-thread workgroups share one LDS table among 8 waves: half of the flushes (every workgroup pays
+        // one find-or-create + state update of device-scope atomics per group it saw: 800 workgroups x 175
+        // groups cost more than the 3.3 M rows of Q9's aggregate themselves). Measured, two int32 keys /
+        // 175 groups / one sum: 3.3 M rows 100 -> 78 us, 32 M rows 370 -> 309 us; 1024 threads (one
+        // workgroup per CU by registers) 74 / 409 us.
+        const char *te = getenv("PH_AGG_T");
+        spec_threads = te ? atoi(te) : 512;
+        if (spec_threads != 256 && spec_threads != 512 && spec_threads != 1024) spec_threads = 256;
+        have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, Q, spec_threads, &spec) == PH_OK;
     }
-    if (have_spec) PH_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spec.fn, 256, lds));
+    const int threads = have_spec ? spec_threads : 256;
+    if (have_spec) PH_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spec.fn, threads, lds));
     else PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds));
     const int occ_raw = occ;
     occ = std::max(1, std::min(occ, 4));
+    if (const char *oe = getenv("PH_AGG_OCC")) occ = std::max(1, std::min(atoi(oe), 8));   // tuning knob (workgroups per CU)
     // small inputs are latency bound (a new group costs a chain of dependent HBM atomics): give
     // every thread one row before giving any thread a second one
     const int64_t resident = (int64_t)a->ctx->cu_count * occ;
-    int chunk = 256;
+    int chunk = threads;
     while (chunk < ph::AGG_CHUNK && (n + chunk - 1) / chunk > resident) chunk *= 2;
     P.chunk = chunk;
     const int64_t nchunks = (n + chunk - 1) / chunk;
@@ -997,7 +1008,7 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
             ph::AggSinkParams copy = P;
             size_t size = sizeof copy;
             void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-            if (hipModuleLaunchKernel(spec.fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, a->ctx->stream, nullptr, config) != hipSuccess) { rc = PH_EHIP; break; }
+            if (hipModuleLaunchKernel(spec.fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, a->ctx->stream, nullptr, config) != hipSuccess) { rc = PH_EHIP; break; }
         } else {
             kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
             if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
