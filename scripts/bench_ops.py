@@ -60,3 +60,21 @@ for frac, label in ((0.1, "10% of orders built"), (1.0, "all orders built")):
     tp = best(probe, 3)
     print(f"join build {m/1e6:.1f}M keys: {tb*1e3:.3f} ms; probe {nl/1e6:.0f}M rows ({label}): {tp*1e3:.3f} ms  {nl/tp/1e9:.1f} Grows/s")
     j.free(); ctx.free(sel)
+
+# the same 15 M order keys as a DIRECT table (ph_join_build_range with the column's value range): keys in
+# storage order take the verified one-pass sorted fill; a random permutation the general passes
+krange = (int(O["o_orderkey"].min()), int(O["o_orderkey"].max()))
+perm = hip.DevColumn(ctx, hip.PH_I64, rng.permutation(O["o_orderkey"]))
+for label, col in (("storage order", ok), ("random order", perm)):
+    tb = best(lambda: hip.Join(ctx, [col], None, no, key_range=krange).free(), 3)
+    j = hip.Join(ctx, [col], None, no, key_range=krange)
+    assert j.kind == "direct"
+    def lookup():
+        ctx.free(j.lookup([lk], None, nl))
+    tl = best(lookup, 3)
+    def probe():
+        mm, a, b = j.probe_inner([lk], None, nl, nl)
+        ctx.free(a); ctx.free(b)
+    tp = best(probe, 3)
+    print(f"direct table {no/1e6:.1f}M keys ({label}): build {tb*1e3:.3f} ms; lookup of {nl/1e6:.0f}M rows {tl*1e3:.3f} ms; inner probe {tp*1e3:.3f} ms")
+    j.free()
