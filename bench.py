@@ -449,8 +449,9 @@ def bench_q9(h, sf, steps, warmup):
                              kernel="gather_multi_kernel (largest kernel of the query: five lineitem columns at the ~5 % of rows that survive the part join)",
                              avg_launch_ms=gm_ms, algorithmic_bytes_per_launch=gm_bytes,
                              timing="HIP events on the launch stream around 20 launches over the query's own row ids",
-                             note="bound by 64-byte sector reads: every gathered 4- or 8-byte value costs one sector (traffic >> algorithmic bytes); "
-                                  "1, 2, 4, 8 rows per thread and 4..64 workgroups per CU all run within 8 % of each other",
+                             note="every gathered 4- or 8-byte value costs one 128-byte line: traffic = the distinct lines the row ids touch "
+                                  "(83 % of a 4-byte column's lines at 5.4 % row density); 1, 2, 4, 8 rows per thread and 4..64 workgroups per CU "
+                                  "all run within 8 % of each other",
                              whole_query={"algorithmic_bytes": inputs, "achieved": inputs / (ms_step * 1e-3) / 1e9,
                                           "frac": inputs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "timing": "host clock around the timed steps (one query = ~45 launches)"}),
