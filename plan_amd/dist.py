@@ -303,6 +303,18 @@ def allgather_records(ctx, records):
     return np.concatenate(_gather_objects(records)).reshape(-1, width)
 
 
+def global_range(ctx, lo_hi):
+    """(min, max) over all ranks of a column's value range — column statistics of a table whose rows
+    are sharded over the ranks (computed once per table, not per query). None when any rank has none."""
+    if world() == 1:
+        return lo_hi
+    rec = np.array([[1, lo_hi[0], lo_hi[1]]] if lo_hi is not None else [[0, 0, 0]], dtype=np.int64)
+    allr = allgather_records(ctx, rec)
+    if not np.all(allr[:, 0] == 1):
+        return None
+    return int(allr[:, 1].min()), int(allr[:, 2].max())
+
+
 def merge_group_partials(groups, ctx=None):
     """groups: {key tuple of ints: (sums list of python ints < 2^127, counts list)} of this rank.
     Returns the merged dict on every rank (Q1/Q9-style tiny merges). Records travel as int64 words:

@@ -112,7 +112,9 @@ class Q3Pipeline:
             mine = hip.gather(ctx, self.c_key, cs, cn)
             allkeys, nall = dist.allgather_rows(ctx, mine, cn, np.int32)   # broadcast of the small build side
             frees += [mine, allkeys]
-            j1 = hip.Join(ctx, [_raw(hip.PH_I32, allkeys)], None, nall)
+            if not hasattr(self, "_c_key_range_all"):   # column statistics over all shards, once per table
+                self._c_key_range_all = dist.global_range(ctx, self.c_key_range)
+            j1 = hip.Join(ctx, [_raw(hip.PH_I32, allkeys)], None, nall, key_range=self._c_key_range_all)
         stage("customer_filter_build", t0)
 
         # ---- orders filter + probe join 1
@@ -351,7 +353,10 @@ class Q9Pipeline:
             j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, np_, key_range=self.p_key_range)
         else:
             pk, npk = bcast(self.p_key, psel, np_, np.int32)
-            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, npk)
+            if not hasattr(self, "_ranges_all"):   # column statistics over all shards, once per table
+                self._ranges_all = {k: dist.global_range(ctx, r) for k, r in
+                                    (("p", self.p_key_range), ("s", self.s_key_range), ("o", self.o_key_range))}
+            j = hip.Join(ctx, [_raw(hip.PH_I32, pk)], None, npk, key_range=self._ranges_all["p"])
         stage("part_like_build", t0)
         t0 = tic()
         n1, lrow, prow_part = j.probe_inner([self.l_part], None, self.n["l"], self.n["l"])
@@ -381,7 +386,7 @@ class Q9Pipeline:
             bp, nb = bcast(self.ps_part, fsel, fn, np.int32)
             bs, _ = bcast(self.ps_supp, fsel, fn, np.int32)
             bc, _ = bcast(self.ps_cost, fsel, fn, np.int64)
-            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, nb)
+            jps = hip.Join(ctx, [_raw(hip.PH_I32, bp), _raw(hip.PH_I32, bs)], None, nb, fk_probes=True)
             ps_cost = _raw(hip.PH_DEC64, bc, 2)
         # LATE MATERIALISATION, ONCE: the six lineitem columns the rest of the query needs are fetched
         # at the surviving rows in one pass (ph_gather_multi: every column read of a row in flight
@@ -418,7 +423,7 @@ class Q9Pipeline:
             frees.append(ident)
             sk, nsk = bcast(self.s_key, ident, self.n["s"], np.int32)
             sn, _ = bcast(self.s_nat, ident, self.n["s"], np.int32)
-            js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk)
+            js = hip.Join(ctx, [_raw(hip.PH_I32, sk)], None, nsk, key_range=self._ranges_all["s"])
             s_nat = _raw(hip.PH_I32, sn)
         srow = lookup(js, [_raw(hip.PH_I32, d_supp)], n1)
         frees.append(srow)
@@ -465,7 +470,7 @@ class Q9Pipeline:
             frees += [counts_dev, perm, ocounts_dev, operm] + recv + orecv
             t["exchange_bytes_sent"] = sent * 20 + osent * 12
             c_okey, c_amount, c_nat = recv
-            jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0])], None, mo)
+            jo = hip.Join(ctx, [_raw(hip.PH_I64, orecv[0])], None, mo, key_range=self._ranges_all["o"])
             o_date = _raw(hip.PH_DATE, orecv[1])
         # orders is the BUILD side (o_orderkey is its primary key) and the intermediate looks its order
         # up: N:1 again, so one lookup kernel and the intermediate stays positional — no pair emission,

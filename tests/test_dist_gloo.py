@@ -72,6 +72,9 @@ def worker(rank, world, port, out):
         top = pd.merge_topk([(k[0], s[0]) for k, (s, c) in local.items()], 10, key=lambda x: (-x[1], x[0]))
         wtop = sorted([(k[0], s[0]) for k, (s, c) in want.items()], key=lambda x: (-x[1], x[0]))[:10]
         assert top == wtop
+        # column statistics over all shards (key ranges for the direct join tables of the N > 1 pipelines)
+        assert pd.global_range(None, (10 * rank - 3, 10 * rank + 5)) == (-3, 10 * (world - 1) + 5)
+        assert pd.global_range(None, None if rank == 1 else (0, 1)) is None
         out[rank] = 1
     finally:
         dist.destroy_process_group()
