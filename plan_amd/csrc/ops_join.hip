@@ -2143,7 +2143,8 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
     // Plain shapes only (no selection, NULLs or pushed-down filter; no occupancy bitmap to derive).
     const char *sfe = getenv("PH_JOIN_SORTED_FILL");   // read per call: the test builds both ways in one process
     const bool no_sorted = sfe && atoi(sfe) == 0;
-    const bool try_sorted = !no_sorted && n > (256 << 10) && !B.sel && !B.key[0].validity && where.kind == 0 && !j->dbits;
+    const bool try_sorted = !no_sorted && n > (256 << 10) && !B.sel && !B.key[0].validity && where.kind == 0 && !j->dbits &&
+                            lo <= INT64_MAX - range - 1;   // the kernel uses lo + range as the "key after the last"
     // (the sorted fill writes every slot itself: only the counters are cleared here)
     ph::join_init_kernel<<<try_sorted ? 1 : ctx->cu_count * 4, 256, 0, ctx->stream>>>(try_sorted ? nullptr : j->direct, cap4, j->dbits, dwords,
                                                                                      j->bloom.coarse, j->count_dev);
