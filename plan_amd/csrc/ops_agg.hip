@@ -564,6 +564,7 @@ struct ph_agg {
     int64_t rows_sunk = 0;
     int64_t expected_groups = 0;   // ph_agg_create's hint: selects the bulk build of the first sink
     int kinds_host[ph::AGG_MAX_AGGS] = {};  // source of the asynchronous upload to kinds_dev
+    bool fresh = true;             // counters not cleared yet (the first sink's one clearing launch does it)
 };
 
 namespace {
@@ -583,8 +584,30 @@ int agg_free_arrays(ph_agg *a) {
     return PH_OK;
 }
 
-// (re)allocate for `cap` slots, carrying over `ng` existing groups
-int agg_resize(ph_agg *a, int64_t cap, int ng) {
+// everything a sink needs cleared, in ONE launch (four memsets before): the slot array of a new table
+// (-1), counter words [c0, c0 + nc), the per-workgroup progress words
+__global__ __launch_bounds__(256) void agg_clear_kernel(int32_t *__restrict__ slots, int64_t cap, int *__restrict__ counters, int c0, int nc,
+                                                        int *__restrict__ progress, int nprog) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    if (slots) {
+        int4 *s4 = reinterpret_cast<int4 *>(slots);   // cap is a power of two >= 4096
+        for (int64_t i = t; i < cap / 4; i += step) s4[i] = make_int4(-1, -1, -1, -1);
+    }
+    if (progress) for (int64_t i = t; i < nprog; i += step) progress[i] = 0;
+    if (t < nc) counters[c0 + t] = 0;
+}
+
+int agg_clear(ph_agg *a, bool slots, int c0, int nc, int *progress, int nprog) {
+    const int64_t work = std::max<int64_t>(slots ? a->cap / 4 : 0, nprog);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((work + 255) / 256, (int64_t)a->ctx->cu_count * 4));
+    agg_clear_kernel<<<grid, 256, 0, a->ctx->stream>>>(slots ? a->slots : nullptr, a->cap, a->counters, c0, nc, progress, nprog);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+// (re)allocate for `cap` slots, carrying over `ng` existing groups; clear_slots = false leaves the new
+// slot array to the caller's agg_clear (first sinks: one launch for slots + counters + progress)
+int agg_resize(ph_agg *a, int64_t cap, int ng, bool clear_slots = true) {
     ph_ctx *ctx = a->ctx;
     int64_t gcap = cap / 2;
     int32_t *slots = nullptr;
@@ -599,7 +622,7 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
     PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&sum_hi));
     PH_CHECK(ctx->pool_alloc(gcap * (int64_t)na * 8, (void **)&cnt));
     PH_CHECK(ctx->pool_alloc(gcap * 8, (void **)&first_row));
-    PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
+    if (clear_slots || ng > 0) PH_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, ctx->stream));
     if (ng > 0) {
         PH_HIP(hipMemcpyAsync(gkeys, a->gkeys, (size_t)ng * a->nkeys * 8, hipMemcpyDeviceToDevice, ctx->stream));
         PH_HIP(hipMemcpyAsync(gnull, a->gnull, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -624,7 +647,10 @@ int agg_resize(ph_agg *a, int64_t cap, int ng) {
 // initial capacity: the reference starts at 2*2048 entries (aggregate_exec.go:332-339)
 int agg_ensure(ph_agg *a, int64_t min_cap = 0) {
     if (a->cap != 0) return PH_OK;
-    return agg_resize(a, std::max(min_cap, next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups))), 0);
+    PH_CHECK(agg_resize(a, std::max(min_cap, next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups))), 0, false));
+    PH_CHECK(agg_clear(a, true, 0, a->fresh ? 4 : 0, nullptr, 0));
+    a->fresh = false;
+    return PH_OK;
 }
 
 }  // namespace
@@ -657,8 +683,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
-    if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK || hipMemsetAsync(a->counters, 0, 16, ctx->stream) != hipSuccess ||
-        false) {
+    if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK) {   // cleared by the first sink's clearing launch (a->fresh)
         ph::set_error("ph_agg_create: device allocation failed");
         rc = PH_EHIP;
     }
@@ -732,7 +757,8 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     int64_t cap = a->cap ? a->cap : next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups));
     if (sure) while (cap / 2 <= n) cap *= 2;
     else cap = std::max(cap, next_pow2(4 * a->expected_groups));
-    if (cap != a->cap) PH_CHECK(agg_resize(a, cap, 0));
+    bool new_table = false;
+    if (cap != a->cap) { PH_CHECK(agg_resize(a, cap, 0, false)); new_table = true; }
     // partition records
     char *tmp = nullptr;
     B.rec_words = nk + 1 + B.nused + 1;
@@ -751,7 +777,10 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
         B.S.mask = (uint64_t)a->cap - 1;
         B.S.gkeys = a->gkeys; B.S.gnull = a->gnull; B.S.sum_lo = a->sum_lo; B.S.sum_hi = a->sum_hi;
         B.S.cnt = a->cnt; B.S.first_row = a->first_row; B.S.gcap = a->gcap;
-        if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+        if (attempt == 0) {   // one clearing launch: the new table's slots and all four counter words
+            if ((rc = agg_clear(a, new_table, 0, 4, nullptr, 0)) != PH_OK) break;
+            a->fresh = false;
+        } else if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
         switch (nk) {
         case 1: rc = bulk_launch<1>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
         case 2: rc = bulk_launch<2>(a, B, nwg, lds, nc, total_dev, attempt > 0); break;
@@ -967,17 +996,23 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     PH_CHECK(a->ctx->pool_alloc((int64_t)grid * 4, (void **)&progress));
     P.progress = progress;
     int rc = PH_OK;
-    if (hipMemsetAsync(progress, 0, (size_t)grid * 4, a->ctx->stream) != hipSuccess ||
-        hipMemsetAsync(a->counters + 2, 0, 4, a->ctx->stream) != hipSuccess) rc = PH_EHIP;
+    bool new_table = false;
     // First sink into an empty table of up to 8 M rows: size the table so that growth is impossible
     // (capacity/2 > rows). The group count and the need-grow flag then never cross PCIe — two host
     // round trips (~50 us of idle GPU) against one larger memset of the slot array (32 MiB: 9 us).
     if (rc == PH_OK && a->rows_sunk == 0 && n <= (8ll << 20)) {
         int64_t want = a->cap ? a->cap : next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups));
         while (want / 2 <= n) want *= 2;
-        if (want != a->cap) rc = agg_resize(a, want, 0);
+        if (want != a->cap) { rc = agg_resize(a, want, 0, false); new_table = true; }
     }
-    if (rc == PH_OK) rc = agg_ensure(a);
+    if (rc == PH_OK && a->cap == 0) {
+        rc = agg_resize(a, next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups)), 0, false);
+        new_table = true;
+    }
+    // one clearing launch: a new table's slots, the counters (all four on first use, else the need-grow
+    // word), the progress words
+    if (rc == PH_OK) rc = agg_clear(a, new_table, a->fresh ? 0 : 2, a->fresh ? 4 : 1, progress, grid);
+    a->fresh = false;
     // the table cannot hold more groups than rows were sunk into it: while that bound plus this
     // call's rows fits, no growth is possible and neither the group count nor the need-grow flag
     // has to cross PCIe
