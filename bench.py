@@ -19,9 +19,10 @@ ONE JSON line on rank 0 (driver contract). Besides the contract's fields:
   cpu_baseline   the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
   N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu (every BASELINE.json
          config, each with its own roofline; Q3 with its own cpu_baseline)
-  N > 1: companion q3_partitioned — Q3 over an SF`--sf` database split N ways (strong scaling,
-         BASELINE.json config 4), join sides hash-partitioned by order key and exchanged with
-         ph_comm_exchange_columns; probe rows/s and exchange bytes against the xGMI peak
+  N > 1: companions q3_partitioned and q9_partitioned — Q3 / Q9 over an SF`--sf` database split N
+         ways (strong scaling, BASELINE.json configs 4 and 5), join sides hash-partitioned by order
+         key and exchanged with ph_comm_exchange_columns, small build sides broadcast; probe rows/s
+         and exchange bytes against the xGMI peak
 """
 import argparse
 import json
@@ -385,25 +386,31 @@ def bench_q3(h, sf, steps, warmup, scaling):
 
 # ---------------------------------------------------------------------------------- Q9
 
-def bench_q9(h, sf, steps, warmup):
+def bench_q9(h, sf, steps, warmup, scaling="weak"):
     """Q9: LIKE + four hash joins (one composite) + profit expression + 175-group aggregate
-    (plan_amd/pipelines.py Q9Pipeline). A step = one whole Q9. One GPU."""
+    (plan_amd/pipelines.py Q9Pipeline). A step = one whole Q9. N > 1: every table sharded by row ranges,
+    the small build sides broadcast, lineitem x orders hash-partitioned by order key (two all-to-alls)."""
     from plan_amd import pipelines, tpchgen
-    sf_total = (sf, 1)
-    L = tpchgen.lineitem(sf_total, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"])
-    Od = tpchgen.orders(sf_total, columns=["o_orderkey", "o_orderdate"])
-    P, PS, S = tpchgen.part(sf_total), tpchgen.partsupp(sf_total), tpchgen.supplier(sf_total)
+    sf_total, first, n_ord = shard_orders(h, sf, scaling)
+    L = tpchgen.lineitem(sf_total, first, n_ord, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"])
+    Od = tpchgen.orders(sf_total, first, n_ord, columns=["o_orderkey", "o_orderdate"])
+    tot_p = int(tpchgen.lib().tpchgen_part_count(tpchgen._i64(sf_total[0]), tpchgen._i64(sf_total[1])))
+    tot_s = int(tpchgen.lib().tpchgen_supplier_count(tpchgen._i64(sf_total[0]), tpchgen._i64(sf_total[1])))
+    p0, p1 = h.rank * tot_p // h.world, (h.rank + 1) * tot_p // h.world
+    s0, s1 = h.rank * tot_s // h.world, (h.rank + 1) * tot_s // h.world
+    P, PS, S = tpchgen.part(sf_total, p0, p1 - p0), tpchgen.partsupp(sf_total, p0, p1 - p0), tpchgen.supplier(sf_total, s0, s1 - s0)
     nrows = len(L["l_orderkey"])
     pipe = pipelines.Q9Pipeline(h.ctx, L, Od, P, PS, S)
     pipe.time_stages = False
     for _ in range(warmup):
         r = pipe.run()
-    h.torch.cuda.synchronize()
+    h.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         r = pipe.run()
-    h.torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    h.barrier()
+    elapsed = h.max_elapsed(time.perf_counter() - t0)
+    total_rows = h.allreduce([nrows], "sum")[0]
     pipe.time_stages = True
     agg_t, stage_steps = {}, min(steps, 10)
     for _ in range(stage_steps):
@@ -438,14 +445,19 @@ def bench_q9(h, sf, steps, warmup):
     h.ctx.free(ids)
     gm_bytes = n1 * (4 + 2 * (4 + 8 + 8 + 8 + 4))   # row id + the five values read and written once
     line = {
-        "metric": "rows/sec through 4 hash joins + hash-agg (Q9)", "value": nrows * steps / elapsed, "unit": "rows/s",
-        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-        "config": {"workload": f"TPC-H Q9 at SF{sf} ({nrows} lineitem rows), tables resident in HBM",
-                   "groups": r["ngroups"], "join_rows": r["join_rows"],
+        "metric": "rows/sec through 4 hash joins + hash-agg (Q9)", "value": total_rows * steps / elapsed, "unit": "rows/s",
+        "n_gpus": h.world, "steps": steps, "warmup": warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling,
+        "config": {"workload": f"TPC-H Q9, {nrows} lineitem rows on rank 0, {total_rows} in total "
+                               f"({'SF%d per GPU' % sf if scaling == 'weak' else 'SF%d split %d ways' % (sf, h.world)}), tables resident in HBM",
+                   "groups": r["ngroups"], "join_rows_rank0": r["join_rows"],
+                   "parallelism": ("pink part keys, their partsupp rows and supplier broadcast (ph_comm_allgather_rows); the intermediate and orders "
+                                   f"hash-partitioned by order key x{h.world} and exchanged with ph_comm_exchange_columns "
+                                   f"({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if h.world > 1 else "single GPU",
+                   "exchange_bytes_sent_rank0_per_step": (agg_t.get("exchange_bytes_sent", 0) / stage_steps) if h.world > 1 else 0,
                    "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk != "exchange_bytes_sent"},
                    "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage"},
         "roofline": roofline(gm_bytes / (gm_ms * 1e-3) / 1e9,
-                             traffic=pmc_traffic(("q9", "gather_multi_kernel")) if nrows == 59986052 else None,
+                             traffic=pmc_traffic(("q9", "gather_multi_kernel")) if (h.world == 1 and nrows == 59986052) else None,
                              kernel="gather_multi_kernel (largest kernel of the query: five lineitem columns at the ~5 % of rows that survive the part join)",
                              avg_launch_ms=gm_ms, algorithmic_bytes_per_launch=gm_bytes,
                              timing="HIP events on the launch stream around 20 launches over the query's own row ids",
@@ -537,7 +549,7 @@ def main():
     else:
         if world != 1:
             raise SystemExit("--query q9 is a one-GPU bench")
-        out, L, table = bench_q9(h, args.sf, args.steps, args.warmup), None, None
+        out, L, table = bench_q9(h, args.sf, args.steps, args.warmup, args.scaling), None, None
     out["roofline"]["peak_measured"] = h.peak_measured()
     out["roofline"]["frac_of_measured"] = out["roofline"]["achieved"] / out["roofline"]["peak_measured"]
     out["config"]["rccl_ranks"] = h.comm.n if h.comm is not None else (1 if world == 1 else f"gloo rehearsal x{world}")
@@ -588,6 +600,8 @@ def main():
         del L
         # BASELINE.json config 4: Q3 at SF`--sf`, hash-partitioned across the N GPUs (strong scaling)
         attempt("q3_partitioned", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "strong")))
+        # BASELINE.json config 5: Q9 at SF`--sf`, multi-stage partitioned build/probe across the N GPUs
+        attempt("q9_partitioned", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong")))
     elif rank0 and world == 1 and not args.no_cpu_baseline and L is not None:
         cb = cpu_baselines(L, args.cpu_rows)
         out["cpu_baseline"] = cb[args.query]
