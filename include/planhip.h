@@ -345,6 +345,22 @@ int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const ph_col *wher
                               const ph_const *where_k, const int32_t *sel, int64_t n,
                               int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap,
                               int64_t *n_out);
+/* ph_join_probe_inner[_where] with a RESIDUAL predicate on the build row: only pairs whose build row r
+ * has build_flags_dev[r] != 0 (a byte per row of the build-side table, e.g. from
+ * ph_join_probe_mark_where). This is the form a join takes whose build child is Filter / SemiJoin(T): T
+ * itself is built — whole, so a primary key in storage order builds in one pass and the filter's
+ * row count never reaches the host — and the filter becomes a flag per row of T that the probe tests
+ * on the row it found (Q3: lineitem JOIN (orders SEMI JOIN customer WHERE o_orderdate < ..)).
+ * where_col may be NULL (no probe-side filter). Direct tables built without a selection only;
+ * PH_EUNSUPPORTED otherwise. */
+int ph_join_probe_inner_residual(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
+                                 const ph_const *where_k, const uint8_t *build_flags_dev, const int32_t *sel, int64_t n,
+                                 int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out);
+/* Filter -> semi-join mark in one pass over rows 0..n: found_dev[i] = the comparison holds for row i
+ * AND its key is in the table (0 / 1). Direct tables, integer-range comparisons, 16-byte aligned
+ * columns without NULLs; PH_EUNSUPPORTED otherwise (ph_filter_select + ph_join_probe_mark). */
+int ph_join_probe_mark_where(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
+                             const ph_const *where_k, int64_t n, uint8_t *found_dev);
 /* Semi/anti/mark: found_dev[i] = 1 when probe row sel[i] (or i) has a match */
 int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                        uint8_t *found_dev);

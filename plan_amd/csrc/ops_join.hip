@@ -1730,6 +1730,7 @@ struct DirectCand {
     uint16_t *cand; int32_t *cmatch; uint16_t *ccnt; int32_t *ccount; int32_t *block_counts;
     int cshift;   // coarse bit = slot >> cshift
     const unsigned *dbits;   // one bit per slot (tables of <= 8 M slots: L2 resident) or NULL
+    const uint8_t *bflags;   // residual predicate on the BUILD row (a byte per build row, non-zero = keep) or NULL
 };
 
 template <int KW, int WK, bool SEL, bool COARSE>
@@ -1788,14 +1789,24 @@ __device__ __forceinline__ void direct_cand_block(const DirectCand &D, int64_t b
     }
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) d[rr] = D.direct[k[rr]];
+    if (D.bflags && !dups) {   // unique keys: the slot's row either passes the residual predicate or the probe row has no pair
+        uint8_t fl[JP_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) fl[rr] = D.bflags[ok[rr] && d[rr] >= 0 ? d[rr] : 0];
+#pragma unroll
+        for (int rr = 0; rr < JP_ROUNDS; rr++) if (!fl[rr]) d[rr] = -1;
+    }
     int total = 0;
     int c[JP_ROUNDS];
 #pragma unroll
     for (int rr = 0; rr < JP_ROUNDS; rr++) {
-        const bool take = ok[rr] && d[rr] >= 0;
+        bool take = ok[rr] && d[rr] >= 0;
         c[rr] = take ? 1 : 0;
-        if (dups && take)
-            for (int32_t x = D.next[d[rr]]; x >= 0; x = D.next[x]) c[rr]++;
+        if (dups && take) {
+            c[rr] = 0;
+            for (int32_t x = d[rr]; x >= 0; x = D.next[x]) c[rr] += !D.bflags || D.bflags[x];
+            take = c[rr] > 0;
+        }
         total += c[rr];
         bal[rr] = __ballot(take);
         if (lane == 0) wc[rr][wv] = __popcll(bal[rr]);
@@ -1886,6 +1897,13 @@ __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64
     }
 #pragma unroll
     for (int s = 0; s < 8; s++) d[s] = D.direct[k[s]];
+    if (D.bflags && !dups) {   // unique keys: the slot's row either passes the residual predicate or the probe row has no pair
+        uint8_t fl[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) fl[s] = D.bflags[ok[s] && d[s] >= 0 ? d[s] : 0];
+#pragma unroll
+        for (int s = 0; s < 8; s++) if (!fl[s]) d[s] = -1;
+    }
     int total = 0;
     int c[8];
     bool take[8];
@@ -1893,8 +1911,11 @@ __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64
     for (int s = 0; s < 8; s++) {
         take[s] = ok[s] && d[s] >= 0;
         c[s] = take[s] ? 1 : 0;
-        if (dups && take[s])
-            for (int32_t x = D.next[d[s]]; x >= 0; x = D.next[x]) c[s]++;
+        if (dups && take[s]) {
+            c[s] = 0;
+            for (int32_t x = d[s]; x >= 0; x = D.next[x]) c[s] += !D.bflags || D.bflags[x];
+            take[s] = c[s] > 0;
+        }
         total += c[s];
     }
     int first[G];
@@ -1959,11 +1980,12 @@ __global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restr
                                                           const int32_t *__restrict__ bsel, const uint16_t *__restrict__ cand,
                                                           const int32_t *__restrict__ cmatch, const uint16_t *__restrict__ ccnt,
                                                           const int32_t *__restrict__ ccount, const int32_t *__restrict__ block_off,
-                                                          const int *__restrict__ bcount,
+                                                          const int *__restrict__ bcount, const uint8_t *__restrict__ bflags,
                                                           int64_t nb, int64_t cap, int32_t *__restrict__ out_probe,
                                                           int32_t *__restrict__ out_build) {
     const int lane = threadIdx.x & 63;
     const bool dups = bcount[0] != bcount[1];
+    const bool walk1 = dups && bflags != nullptr;   // a single pair of a chain need not be the chain's head
     const int64_t nw = (int64_t)gridDim.x * 4;
     for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nb; blk += nw) {
         const int cnt = ccount[blk];
@@ -1978,24 +2000,74 @@ __global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restr
                 r = SELP ? (int64_t)psel[i] : i;
                 c = dups ? (int)ccnt[blk * JP_CHUNK + t] : 1;   // the candidate pass only writes counts when chains exist
                 first = cmatch[blk * JP_CHUNK + t];
-                if (c == 65535) { c = 0; for (int32_t x = first; x >= 0; x = next[x]) c++; }   // saturated: recount
+                if (c == 65535) { c = 0; for (int32_t x = first; x >= 0; x = next[x]) c += !bflags || bflags[x]; }   // saturated: recount
             }
             int incl = c;
             for (int o = 1; o < 64; o <<= 1) {
                 int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
-            if (c == 1) {
+            if (c == 1 && !walk1) {
                 const int64_t pos = running + incl - 1;
                 if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = SELB ? bsel[first] : first; }
-            } else if (c > 1) {
+            } else if (c >= 1) {
                 int64_t pos = running + incl - c;
                 for (int32_t x = first; x >= 0; x = next[x]) {
+                    if (bflags && !bflags[x]) continue;
                     if (pos < cap) { out_probe[pos] = (int32_t)r; out_build[pos] = SELB ? bsel[x] : x; }
                     pos++;
                 }
             }
             running += __shfl(incl, 63);
+        }
+    }
+}
+
+// mark probe with a pushed-down range filter on the probe side, vectorised shape only (identity selection,
+// no NULLs, 16-byte aligned columns): found[i] = filter(i) && key i is in the table. One pass, one byte
+// per row out, no counts — a semi-join flag array that a later probe takes as its residual predicate.
+template <int KW, int WK>
+__global__ __launch_bounds__(256) void direct_mark_where_kernel(const void *__restrict__ keycol, int64_t n, long long lo, unsigned long long range,
+                                                                const int32_t *__restrict__ direct, const unsigned *__restrict__ dbits,
+                                                                const void *__restrict__ wdata, long long wlo, long long whi,
+                                                                uint8_t *__restrict__ found) {
+    constexpr int R = 16 / KW, G = 8 / R;
+    const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool full = base + JP_CHUNK <= n;
+    long long k[8], k2[8];
+    bool ok[8];
+    dc_block_keys<KW, WK, 1>(keycol, nullptr, wdata, wlo, whi, base + wv * 512, lane, full, true, n, k, k2, ok);
+    int32_t d[8];
+    if (dbits) {   // membership is all a mark needs: the occupancy bitmap (L2 resident) instead of the 32x larger slot array
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const unsigned long long off = (unsigned long long)(k[s] - lo);
+            ok[s] = ok[s] && off < range;
+            const unsigned long long o = ok[s] ? off : 0;
+            d[s] = ((dbits[o >> 5] >> (o & 31)) & 1u) ? 0 : -1;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const unsigned long long off = (unsigned long long)(k[s] - lo);
+            ok[s] = ok[s] && off < range;
+            d[s] = direct[ok[s] ? off : 0];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int64_t row = base + wv * 512 + (int64_t)(g * 64 + lane) * R;
+        if (full) {
+            unsigned w = 0;
+#pragma unroll
+            for (int e = 0; e < R; e++) w |= (ok[g * R + e] && d[g * R + e] >= 0 ? 1u : 0u) << (8 * e);
+            if (R == 4) *reinterpret_cast<unsigned *>(found + row) = w;
+            else *reinterpret_cast<unsigned short *>(found + row) = (unsigned short)w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < R; e++)
+                if (row + e < n) found[row + e] = ok[g * R + e] && d[g * R + e] >= 0 ? 1 : 0;
         }
     }
 }
@@ -2209,10 +2281,10 @@ static void launch_direct_probe(ph_join *j, const ph::JoinSide &P, int64_t n, in
 }
 
 template <int KW, int WK>
-static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, uint16_t *cand, int32_t *cmatch,
-                               uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
+static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, const uint8_t *bflags, uint16_t *cand,
+                               int32_t *cmatch, uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
     ph::DirectCand D{P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev,
-                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift, j->dbits};
+                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift, j->dbits, bflags};
     hipStream_t st = j->ctx->stream;
     auto aligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = !P.sel && !P.key[0].validity && aligned(P.key[0].data) && (WK == 0 || aligned(w.data));
@@ -2243,8 +2315,8 @@ static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int
     else ph::direct_cand_kernel<KW, WK, false><<<nb, 256, 0, st>>>(D);
 }
 
-static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, const ph::RangePred &where, int32_t *out_probe_dev,
-                              int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, const ph::RangePred &where, const uint8_t *bflags,
+                              int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
     ph_ctx *ctx = j->ctx;
     const int64_t nb = (n + ph::JP_CHUNK - 1) / ph::JP_CHUNK;
     const int64_t o_ccount = ph::round_up(nb * 4, 8) + 64;
@@ -2258,10 +2330,10 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
 #define PH_DC_K(KWV)                                                                                                 \
     switch (where.kind) {                                                                                            \
-    case 0: launch_direct_cand<KWV, 0>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
-    case 1: launch_direct_cand<KWV, 1>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
-    case 2: launch_direct_cand<KWV, 2>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;          \
-    default: launch_direct_cand<KWV, 3>(j, P, n, (int)nb, where, cand, cmatch, ccnt, ccount, counts); break;         \
+    case 0: launch_direct_cand<KWV, 0>(j, P, n, (int)nb, where, bflags, cand, cmatch, ccnt, ccount, counts); break;          \
+    case 1: launch_direct_cand<KWV, 1>(j, P, n, (int)nb, where, bflags, cand, cmatch, ccnt, ccount, counts); break;          \
+    case 2: launch_direct_cand<KWV, 2>(j, P, n, (int)nb, where, bflags, cand, cmatch, ccnt, ccount, counts); break;          \
+    default: launch_direct_cand<KWV, 3>(j, P, n, (int)nb, where, bflags, cand, cmatch, ccnt, ccount, counts); break;         \
     }
     if (j->dkw == 4) { PH_DC_K(4) } else { PH_DC_K(8) }
 #undef PH_DC_K
@@ -2269,7 +2341,7 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
     const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
     const int32_t *bsel = j->build.sel;
-#define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, j->count_dev, nb, cap, out_probe_dev, out_build_dev
+#define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, j->count_dev, bflags, nb, cap, out_probe_dev, out_build_dev
     if (P.sel && bsel) ph::direct_emit_kernel<true, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
     else if (P.sel) ph::direct_emit_kernel<true, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
     else if (bsel) ph::direct_emit_kernel<false, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
@@ -2563,7 +2635,7 @@ static int check_probe(ph_join *j, const ph_col *keys, const int32_t *sel, int64
 }
 
 static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, const ph::RangePred &where,
-                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out);
+                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out, const uint8_t *bflags = nullptr);
 
 extern "C" int ph_join_probe_inner(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n,
                                    int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
@@ -2584,8 +2656,29 @@ extern "C" int ph_join_probe_inner_where(ph_join *j, const ph_col *keys, const p
     return probe_inner_impl(j, keys, sel, n, where, out_probe_dev, out_build_dev, cap, n_out);
 }
 
+// Inner probe with a RESIDUAL predicate on the build row: of the pairs ph_join_probe_inner[_where] would
+// emit, those whose build row r has build_flags_dev[r] != 0. What a join whose build child is
+// Filter / SemiJoin(build table) becomes when the filter's result is a flag per build-table row
+// instead of a selection: the build side stays the whole table (a primary-key column in storage order
+// builds in one pass, and the table can be shared by every plan that joins on that key), and neither
+// the filter's row count nor a filtered key list ever reaches the host. Direct tables built without a
+// selection only; PH_EUNSUPPORTED otherwise (the caller filters, builds and probes).
+extern "C" int ph_join_probe_inner_residual(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op,
+                                            const ph_const *where_k, const uint8_t *build_flags_dev, const int32_t *sel, int64_t n,
+                                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    PH_REQUIRE(j && build_flags_dev, "ph_join_probe_inner_residual: bad arguments");
+    ph::RangePred where{0, nullptr, nullptr, 0, 0};
+    const bool has_where = where_col != nullptr;
+    if (!j->direct || j->build.sel || (has_where && (!where_k || !ph::lower_range_pred(where_col, where_op, where_k, &where) || where.validity || where.kind < 0))) {
+        ph::set_error("ph_join_probe_inner_residual: only direct tables built without a selection, and integer-range probe filters over a "
+                      "column without NULLs");
+        return PH_EUNSUPPORTED;
+    }
+    return probe_inner_impl(j, keys, sel, n, where, out_probe_dev, out_build_dev, cap, n_out, build_flags_dev);
+}
+
 static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, const ph::RangePred &where,
-                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+                            int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out, const uint8_t *bflags) {
     ph::JoinSide P{};
     PH_CHECK(check_probe(j, keys, sel, n, &P));
     PH_REQUIRE(n_out && cap >= 0 && (cap == 0 || (out_probe_dev && out_build_dev)), "ph_join_probe_inner: bad output arguments");
@@ -2594,7 +2687,7 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     ph_ctx *ctx = j->ctx;
     if (j->direct) {
         if (!direct_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the direct table's"); return PH_EUNSUPPORTED; }
-        return direct_probe_inner(j, P, n, where, out_probe_dev, out_build_dev, cap, n_out);
+        return direct_probe_inner(j, P, n, where, bflags, out_probe_dev, out_build_dev, cap, n_out);
     }
     if (j->nodes) {
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
@@ -2627,6 +2720,33 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     }
     PH_CHECK(ctx->download(n_out, total, 8));
     if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
+    return PH_OK;
+}
+
+// Filter -> semi-join mark in one pass: found_dev[i] = (row i passes the comparison) && (its key is in the
+// table). Direct tables, identity selection, columns without NULLs and 16-byte aligned; PH_EUNSUPPORTED
+// otherwise (the caller runs ph_filter_select + ph_join_probe_mark).
+extern "C" int ph_join_probe_mark_where(ph_join *j, const ph_col *keys, const ph_col *where_col, int32_t where_op, const ph_const *where_k,
+                                        int64_t n, uint8_t *found_dev) {
+    PH_REQUIRE(j && keys && where_col && where_k && n >= 0 && (n == 0 || found_dev), "ph_join_probe_mark_where: bad arguments");
+    ph::JoinSide P{};
+    PH_CHECK(check_probe(j, keys, nullptr, n, &P));
+    ph::RangePred w{};
+    auto aligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!j->direct || !direct_probe_ok(j, P) || P.key[0].validity || !ph::lower_range_pred(where_col, where_op, where_k, &w) || w.validity ||
+        w.kind <= 0 || !aligned(P.key[0].data) || !aligned(w.data) || !aligned(found_dev)) {
+        ph::set_error("ph_join_probe_mark_where: only direct tables, an integer-range filter and aligned columns without NULLs");
+        return PH_EUNSUPPORTED;
+    }
+    if (n == 0) return PH_OK;
+    ph_ctx *ctx = j->ctx;
+    if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
+    const int nb = (int)((n + ph::JP_CHUNK - 1) / ph::JP_CHUNK);
+#define PH_MW(KWV, WKV) ph::direct_mark_where_kernel<KWV, WKV><<<nb, 256, 0, ctx->stream>>>(P.key[0].data, n, (long long)j->dlo, j->drange, j->direct, j->dbits, w.data, w.lo, w.hi, found_dev)
+    if (j->dkw == 4) { if (w.kind == 1) PH_MW(4, 1); else if (w.kind == 2) PH_MW(4, 2); else PH_MW(4, 3); }
+    else { if (w.kind == 1) PH_MW(8, 1); else if (w.kind == 2) PH_MW(8, 2); else PH_MW(8, 3); }
+#undef PH_MW
+    PH_HIP(hipGetLastError());
     return PH_OK;
 }
 

@@ -590,6 +590,35 @@ class Join:
         check(rc)
         return m.value, op, ob
 
+    def probe_inner_residual(self, keys, where_col, where_op, where_k, build_flags, sel, n, cap):
+        """ph_join_probe_inner_residual: pairs whose build row has build_flags[row] != 0; where_col may be
+        None. Returns None when the shape is not supported (direct tables only)."""
+        op = self.ctx.alloc(max(cap, 1) * 4)
+        ob = self.ctx.alloc(max(cap, 1) * 4)
+        m = i64()
+        w = None
+        if where_col is not None:
+            w = ctypes.byref(where_col.col() if isinstance(where_col, DevColumn) else where_col)
+        rc = lib().ph_join_probe_inner_residual(self.h, _cols(keys), w, i32(where_op), ctypes.byref(where_k) if where_k is not None else None,
+                                                build_flags, sel, i64(n), op, ob, i64(cap), ctypes.byref(m))
+        if rc == PH_EUNSUPPORTED:
+            self.ctx.free(op)
+            self.ctx.free(ob)
+            return None
+        check(rc)
+        return m.value, op, ob
+
+    def probe_mark_where(self, keys, where_col, where_op, where_k, n):
+        """ph_join_probe_mark_where: byte flags (filter && key present) or None when not supported"""
+        f = self.ctx.alloc(max(n, 1) + 16)
+        w = where_col.col() if isinstance(where_col, DevColumn) else where_col
+        rc = lib().ph_join_probe_mark_where(self.h, _cols(keys), ctypes.byref(w), i32(where_op), ctypes.byref(where_k), i64(n), f)
+        if rc == PH_EUNSUPPORTED:
+            self.ctx.free(f)
+            return None
+        check(rc)
+        return f
+
     def lookup(self, keys, sel, n, stats=None):
         """N:1 lookup probe: device int32[n] of matching build rows (-1 = none); stats: optional
         device int32[2] (misses, multi-matches), zeroed by the caller"""

@@ -38,6 +38,7 @@ class Q3Pipeline:
         self.c_key_range = (int(C["c_custkey"].min()), int(C["c_custkey"].max())) if self.nc else None
         self.c_seg = D(ctx, hip.PH_CODE8, C["c_mktsegment"])
         self.o_key = D(ctx, hip.PH_I64, O["o_orderkey"])
+        self.o_key_range = (int(O["o_orderkey"].min()), int(O["o_orderkey"].max())) if self.no else None
         self.o_cust = D(ctx, hip.PH_I32, O["o_custkey"])
         self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
         self.o_prio = D(ctx, hip.PH_I32, O["o_shippriority"])
@@ -119,22 +120,50 @@ class Q3Pipeline:
 
         # ---- orders filter + probe join 1
         t0 = tic()
-        # Filter(o_orderdate < date) under the probe child, fused into the probe when the shape
-        # allows (one pass over o_orderdate/o_custkey, no selection vector)
-        fused = j1.probe_inner_where([self.o_cust], self.o_date, hip.PH_LT, hip.const(hip.PH_DATE, i=date),
-                                     None, self.no, self.no)
-        if fused is not None:
+        # The build child of join 2 is  orders SEMI JOIN customer WHERE o_orderdate < date  (customer gives
+        # the output nothing but its key, which is unique). Residual form: ONE pass marks the orders rows
+        # that qualify (a byte per orders row: no pair list, no count read-back), join 2 is built over the
+        # WHOLE orders table (its primary key in storage order: one streaming fill of a direct table,
+        # independent of the mark), and the lineitem probe tests the flag of the orders row it finds.
+        residual = None
+        if N == 1 and self.o_key_range is not None and j1.kind == "direct" and not getattr(self, "no_residual", False):
+            flags = j1.probe_mark_where([self.o_cust], self.o_date, hip.PH_LT, hip.const(hip.PH_DATE, i=date), self.no)
+            if flags is not None:
+                frees.append(flags)
+                stage("orders_filter_probe", t0)
+                t0 = tic()
+                j2 = hip.Join(ctx, [self.o_key], None, self.no, key_range=self.o_key_range)
+                if j2.kind == "direct":
+                    residual = flags
+                    b_date, b_prio = self.o_date.col(), self.o_prio.col()   # addressed by orders row id
+                    m1 = 0
+                    if self.time_stages:   # reporting only: how many orders rows qualify
+                        qs, m1 = hip.filter_select(ctx, _raw(hip.PH_CODE8, flags), self.no, hip.PH_EQ, hip.const(hip.PH_I32, i=1))
+                        ctx.free(qs)
+                    stage("orders_partition_build", t0)
+                else:
+                    j2.free()
+        fused = None
+        if residual is None:
+            fused = j1.probe_inner_where([self.o_cust], self.o_date, hip.PH_LT, hip.const(hip.PH_DATE, i=date),
+                                         None, self.no, self.no)
+        if residual is not None:
+            pass
+        elif fused is not None:
             m1, orow, _c = fused
             frees += [orow, _c]
         else:
             os_, on = hip.filter_select(ctx, self.o_date, self.no, hip.PH_LT, hip.const(hip.PH_DATE, i=date))
             m1, orow, _c = j1.probe_inner([self.o_cust], os_, on, max(on, 1))
             frees += [os_, orow, _c]
-        stage("orders_filter_probe", t0)
+        if residual is None:
+            stage("orders_filter_probe", t0)
 
         # ---- build side of join 2 (partitioned by o_orderkey when N > 1)
         t0 = tic()
-        if N == 1:
+        if residual is not None:
+            pass
+        elif N == 1:
             j2 = hip.Join(ctx, [self.o_key], orow, m1)
             b_date, b_prio = self.o_date.col(), self.o_prio.col()   # addressed by orders row id
         else:
@@ -148,7 +177,8 @@ class Q3Pipeline:
             frees += [counts_dev, perm, rk, rd, rp] + [p for p, _ in send]
             j2 = hip.Join(ctx, [_raw(hip.PH_I64, rk)], None, nrecv)
             b_date, b_prio = _raw(hip.PH_DATE, rd), _raw(hip.PH_I32, rp)
-        stage("orders_partition_build", t0)
+        if residual is None:
+            stage("orders_partition_build", t0)
 
         # ---- lineitem filter (+ partition/exchange) + probe join 2
         t0 = tic()
@@ -157,8 +187,12 @@ class Q3Pipeline:
             p_key, p_ext, p_disc = self.l_key, self.l_ext, self.l_disc
             if self.probe_events:
                 self.probe_events[0].record()
-            fused2 = j2.probe_inner_where([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date),
-                                          None, self.nl, self.nl)
+            if residual is not None:
+                fused2 = j2.probe_inner_residual([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date), residual,
+                                                 None, self.nl, self.nl)
+            else:
+                fused2 = j2.probe_inner_where([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date),
+                                              None, self.nl, self.nl)
             if fused2 is not None:
                 if self.probe_events:
                     self.probe_events[1].record()

@@ -707,6 +707,61 @@ def test_join_build_where_equals_filter_then_build(ctx):
         c.free()
 
 
+def test_join_mark_where_and_residual_probe(ctx):
+    """ph_join_probe_mark_where (Filter -> semi-join mark in one pass) equals filter_select + probe_mark,
+    and ph_join_probe_inner_residual over a table built on ALL rows equals the inner probe of a table
+    built on the flagged rows only — unique build keys and duplicate ones (chains are walked with the
+    flag tested per row), with and without a probe-side filter, 4- and 8-byte keys."""
+    rng = np.random.default_rng(71)
+    nc, no, nl = 200_000, 700_000, 900_000
+    ckeys = (rng.permutation(400_000)[:nc] + 1).astype(np.int32)
+    dck = hip.DevColumn(ctx, hip.PH_I32, ckeys)
+    jc = hip.Join(ctx, [dck], None, nc, key_range=(1, 400_000))
+    assert jc.kind == "direct"
+    ocust = rng.integers(1, 400_001, no).astype(np.int32)
+    odate = rng.integers(9000, 9200, no).astype(np.int32)
+    docust, dodate = hip.DevColumn(ctx, hip.PH_I32, ocust), hip.DevColumn(ctx, hip.PH_DATE, odate)
+    cut = hip.const(hip.PH_DATE, i=9100)
+    f = jc.probe_mark_where([docust], dodate, hip.PH_LT, cut, no)
+    assert f is not None
+    flags = ctx.download(f, np.uint8, no)
+    want = (np.isin(ocust, ckeys) & (odate < 9100)).astype(np.uint8)
+    assert np.array_equal(flags, want)
+    for dt, ht, keys_of in ((np.int64, hip.PH_I64, "unique"), (np.int32, hip.PH_I32, "dups")):
+        if keys_of == "unique":
+            okey = (np.arange(no) * 3 + 10).astype(dt)               # sorted unique (sorted fill, range 2.1 M: bitmap)
+        else:
+            okey = np.sort(rng.integers(0, 250_000, no)).astype(dt)  # ~3 rows per key
+        lkey = rng.integers(0, int(okey.max()) + 50, nl).astype(dt)
+        lship = rng.integers(9000, 9200, nl).astype(np.int32)
+        dok, dlk, dls = hip.DevColumn(ctx, ht, okey), hip.DevColumn(ctx, ht, lkey), hip.DevColumn(ctx, hip.PH_DATE, lship)
+        rngk = (int(okey.min()), int(okey.max()))
+        jall = hip.Join(ctx, [dok], None, no, key_range=rngk)
+        assert jall.kind == "direct"
+        sel = np.flatnonzero(flags).astype(np.int32)
+        jsel = hip.Join(ctx, [dok], ctx.upload(sel), len(sel), key_range=rngk)
+        for with_where in (False, True):
+            if with_where:
+                got = jall.probe_inner_residual([dlk], dls, hip.PH_GT, cut, f, None, nl, 4 * nl)
+                ref = jsel.probe_inner_where([dlk], dls, hip.PH_GT, cut, None, nl, 4 * nl)
+            else:
+                got = jall.probe_inner_residual([dlk], None, 0, None, f, None, nl, 4 * nl)
+                ref = jsel.probe_inner([dlk], None, nl, 4 * nl)
+            assert got is not None and ref is not None and got[0] == ref[0] > 0
+            a = np.stack([ctx.download(got[1], np.int32, got[0]), ctx.download(got[2], np.int32, got[0])], 1)
+            b = np.stack([ctx.download(ref[1], np.int32, ref[0]), ctx.download(ref[2], np.int32, ref[0])], 1)
+            assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b[np.lexsort((b[:, 1], b[:, 0]))])
+            assert np.all(flags[a[:, 1]] == 1) and np.array_equal(okey[a[:, 1]], lkey[a[:, 0]])
+        jall.free(); jsel.free()
+        for c in (dok, dlk, dls):
+            c.free()
+    hj = hip.Join(ctx, [dck], None, nc)                               # a hash table: not fused
+    assert hj.probe_mark_where([docust], dodate, hip.PH_LT, cut, no) is None
+    hj.free(); jc.free()
+    for c in (dck, docust, dodate):
+        c.free()
+
+
 def test_join_fk_probe_hint_takes_node_table(ctx):
     """ph_join_build_ex with PH_JOIN_FK_PROBES: build sides of >= 32 K rows take the node table (no
     Bloom bitmap); lookups, pairs and marks equal the default table's (composite 4-byte keys and one
