@@ -63,6 +63,16 @@ int ph_ctx_sync(ph_ctx *ctx);
  * is what a query does with PH_EOVERFLOW anyway (it falls back as a whole). Off by default: every
  * call then reports its own errors, like the reference's operators do per chunk. */
 int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on);
+/* Asynchronous counts. With `on` != 0 the calls that hand a row count back to the host
+ * (ph_filter_select's *n_out, ph_join_probe_inner*'s *n_out) return as soon as their kernels and an
+ * 8-byte copy are queued, with *n_out = -1; ph_ctx_wait_counts fills every pending count in (waiting
+ * for the last of those copies, not for the stream) and reports PH_ECAPACITY for a pair list that
+ * overflowed. The count variables must stay alive until then. Independent work queued in between —
+ * another join's build, a probe that needs the table but not the count — keeps the GPU busy while
+ * the host wakes up and prepares the launches that depend on the count (~25 us per round trip).
+ * Switching it off waits first. */
+int ph_ctx_set_async_counts(ph_ctx *ctx, int32_t on);
+int ph_ctx_wait_counts(ph_ctx *ctx);
 /* synchronise and report a pending deferred error (PH_OK when none is pending) */
 int ph_ctx_check_deferred(ph_ctx *ctx);
 void ph_ctx_destroy(ph_ctx *ctx);

@@ -87,6 +87,18 @@ struct ph_ctx {
     // match counts) OR / add into; the next download() of this ctx fetches them in the same stream
     // synchronisation and fails with the deferred error. [0] overflow, [1] lookup misses, [2] lookup
     // multi-matches.
+    // Asynchronous counts (ph_ctx_set_async_counts): a call that returns a row count to the host
+    // (ph_filter_select, ph_join_probe_inner*) enqueues the 8-byte copy into a pinned slot of its own and
+    // returns at once with *n_out = -1; ph_ctx_wait_counts waits for the LAST such copy only (an event,
+    // not the stream) and fills the counts in. Work queued between the call and the wait runs while the
+    // host wakes up and prepares the launches that depend on the count.
+    struct PendingCount { int64_t *host; int64_t cap; const char *what; };
+    std::vector<PendingCount> pending_counts;
+    int64_t *count_slots = nullptr;   // pinned, PH_MAX_PENDING_COUNTS entries
+    void *count_event = nullptr;      // hipEvent_t
+    bool async_counts = false;
+    int download_count(int64_t *host, const void *dev, int64_t cap, const char *what);
+    int wait_counts();
     int *deferred_dev = nullptr;
     bool defer_errors = false, deferred_pending = false;
     int deferred_words(int **out);   // allocates (zeroed) on first use

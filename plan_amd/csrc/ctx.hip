@@ -114,6 +114,52 @@ int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
     return rc;
 }
 
+constexpr int PH_MAX_PENDING_COUNTS = 64;
+
+int ph_ctx::download_count(int64_t *host, const void *dev, int64_t cap, const char *what) {
+    if (!async_counts || pending_counts.size() >= (size_t)PH_MAX_PENDING_COUNTS) {
+        PH_CHECK(download(host, dev, 8));
+        if (cap >= 0 && *host > cap) { ph::set_error("%s: %lld rows, output capacity %lld", what, (long long)*host, (long long)cap); return PH_ECAPACITY; }
+        return PH_OK;
+    }
+    if (!count_slots) PH_HIP(hipHostMalloc((void **)&count_slots, PH_MAX_PENDING_COUNTS * 8, hipHostMallocDefault));
+    if (!count_event) { hipEvent_t e; PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); count_event = e; }
+    const size_t slot = pending_counts.size();
+    PH_HIP(hipMemcpyAsync(count_slots + slot, dev, 8, hipMemcpyDeviceToHost, stream));
+    PH_HIP(hipEventRecord((hipEvent_t)count_event, stream));
+    pending_counts.push_back({host, cap, what});
+    *host = -1;
+    return PH_OK;
+}
+
+int ph_ctx::wait_counts() {
+    if (pending_counts.empty()) return PH_OK;
+    PH_HIP(hipEventSynchronize((hipEvent_t)count_event));
+    int rc = PH_OK;
+    for (size_t i = 0; i < pending_counts.size(); i++) {
+        const PendingCount &p = pending_counts[i];
+        *p.host = count_slots[i];
+        if (rc == PH_OK && p.cap >= 0 && *p.host > p.cap) {
+            ph::set_error("%s: %lld rows, output capacity %lld", p.what, (long long)*p.host, (long long)p.cap);
+            rc = PH_ECAPACITY;
+        }
+    }
+    pending_counts.clear();
+    return rc;
+}
+
+extern "C" int ph_ctx_set_async_counts(ph_ctx *ctx, int32_t on) {
+    PH_REQUIRE(ctx, "ph_ctx_set_async_counts: ctx is NULL");
+    if (!on) PH_CHECK(ctx->wait_counts());
+    ctx->async_counts = on != 0;
+    return PH_OK;
+}
+
+extern "C" int ph_ctx_wait_counts(ph_ctx *ctx) {
+    PH_REQUIRE(ctx, "ph_ctx_wait_counts: ctx is NULL");
+    return ctx->wait_counts();
+}
+
 extern "C" int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on) {
     PH_REQUIRE(ctx, "ph_ctx_set_deferred_errors: ctx is NULL");
     ctx->defer_errors = on != 0;
@@ -214,6 +260,8 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->deferred_dev) (void)hipFree(ctx->deferred_dev);
+    if (ctx->count_slots) (void)hipHostFree(ctx->count_slots);
+    if (ctx->count_event) (void)hipEventDestroy((hipEvent_t)ctx->count_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

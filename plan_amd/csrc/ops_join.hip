@@ -2348,9 +2348,7 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     else ph::direct_emit_kernel<false, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
 #undef PH_DE_ARGS
     PH_HIP(hipGetLastError());
-    PH_CHECK(ctx->download(n_out, total, 8));
-    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
-    return PH_OK;
+    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
 }
 
 // probe-side shape check of a node table: same packing as the build side, no other key shape
@@ -2394,9 +2392,7 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
     else { if (P.sel) ph::big_emit_kernel<8, 1, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); else ph::big_emit_kernel<8, 1, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); }
 #undef PH_BE_ARGS
     PH_HIP(hipGetLastError());
-    PH_CHECK(ctx->download(n_out, total, 8));
-    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
-    return PH_OK;
+    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
 }
 
 static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, bool have_range,
@@ -2718,9 +2714,7 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
                                                                  out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     }
-    PH_CHECK(ctx->download(n_out, total, 8));
-    if (*n_out > cap) { ph::set_error("ph_join_probe_inner: %lld matches, output capacity %lld", (long long)*n_out, (long long)cap); return PH_ECAPACITY; }
-    return PH_OK;
+    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
 }
 
 // Filter -> semi-join mark in one pass: found_dev[i] = (row i passes the comparison) && (its key is in the

@@ -774,8 +774,7 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
                  : P.kind == ph::SK_RANGE_I64 ? ph::run_vsel<int64_t>(ctx, P, n_in, sel_out, counts, nb, total)
                                               : ph::run_vsel<uint8_t>(ctx, P, n_in, sel_out, counts, nb, total);
         PH_CHECK(rc);
-        PH_CHECK(ctx->download(n_out, total, 8));
-        return PH_OK;
+        return ctx->download_count(n_out, total, -1, "ph_filter_select");
     }
     static const bool no_direct_like = getenv("PH_LIKE_STAGED") != nullptr;   // the staged form, for the parity test
     if (P.kind == ph::SK_STR && P.contains && sel_in == nullptr && P.plen >= 3 && !no_direct_like &&
@@ -787,8 +786,7 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
     PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
     ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, flags);
     PH_HIP(hipGetLastError());
-    PH_CHECK(ctx->download(n_out, total, 8));
-    return PH_OK;
+    return ctx->download_count(n_out, total, -1, "ph_filter_select");
 }
 
 // ------------------------------------------------------------------ union (OR / IN lists)

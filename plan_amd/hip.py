@@ -177,6 +177,13 @@ class Ctx:
     def check_deferred(self):
         check(lib().ph_ctx_check_deferred(self.h))
 
+    def set_async_counts(self, on=True):
+        """row counts of filter_select / probe_inner* are filled in by wait_counts() (ph_ctx_set_async_counts)"""
+        check(lib().ph_ctx_set_async_counts(self.h, i32(1 if on else 0)))
+
+    def wait_counts(self):
+        check(lib().ph_ctx_wait_counts(self.h))
+
     def close(self):
         if self.h:
             lib().ph_ctx_destroy(self.h)
@@ -366,8 +373,9 @@ def _cols(cols):
     return (Col * max(len(cols), 1))(*[c.col() if isinstance(c, DevColumn) else c for c in cols])
 
 
-def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None):
-    """Returns (sel_out_dev, count). sel_in: device pointer or None."""
+def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None, defer=False):
+    """Returns (sel_out_dev, count). sel_in: device pointer or None. defer (with Ctx.set_async_counts):
+    the count comes back as the ctypes int64 itself, valid after Ctx.wait_counts()."""
     if n_in is None:
         n_in = n
     out = ctx.alloc(max(n_in, 1) * 4)
@@ -375,7 +383,7 @@ def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None):
     c = col.col() if isinstance(col, DevColumn) else col
     check(lib().ph_filter_select(ctx.h, ctypes.byref(c), i64(n), i32(op), ctypes.byref(k),
                                  sel_in, i64(n_in), out, ctypes.byref(cnt)))
-    return out, cnt.value
+    return (out, cnt) if defer else (out, cnt.value)
 
 
 def sel_union(ctx, sels, counts, n_rows):
@@ -567,12 +575,14 @@ class Join:
     def count(self):
         return int(lib().ph_join_count(self.h))
 
-    def probe_inner(self, keys, sel, n, cap):
+    def probe_inner(self, keys, sel, n, cap, defer=False):
+        """defer (with Ctx.set_async_counts): the pair count comes back as the ctypes int64 itself, valid
+        after Ctx.wait_counts()"""
         op = self.ctx.alloc(max(cap, 1) * 4)
         ob = self.ctx.alloc(max(cap, 1) * 4)
         m = i64()
         check(lib().ph_join_probe_inner(self.h, _cols(keys), sel, i64(n), op, ob, i64(cap), ctypes.byref(m)))
-        return m.value, op, ob
+        return (m if defer else m.value), op, ob
 
     def probe_inner_where(self, keys, where_col, where_op, where_k, sel, n, cap):
         """Filter -> probe in one pass; returns None when the shape is not fused (caller runs

@@ -707,6 +707,39 @@ def test_join_build_where_equals_filter_then_build(ctx):
         c.free()
 
 
+def test_async_counts(ctx):
+    """ph_ctx_set_async_counts: filter_select / probe_inner return at once with the count pending (-1)
+    and ph_ctx_wait_counts fills all of them in; an overflowing pair list is reported by the wait;
+    switching the mode off waits too."""
+    rng = np.random.default_rng(81)
+    n = 300_000
+    v = rng.integers(0, 100, n).astype(np.int32)
+    dv = hip.DevColumn(ctx, hip.PH_I32, v)
+    bk = np.arange(1000, dtype=np.int32)
+    dbk = hip.DevColumn(ctx, hip.PH_I32, bk)
+    j = hip.Join(ctx, [dbk], None, len(bk))
+    ctx.set_async_counts(True)
+    try:
+        s1, c1 = hip.filter_select(ctx, dv, n, hip.PH_LT, hip.const(hip.PH_I32, i=10), defer=True)
+        s2, c2 = hip.filter_select(ctx, dv, n, hip.PH_GE, hip.const(hip.PH_I32, i=90), defer=True)
+        m, op, ob = j.probe_inner([dv], None, n, n, defer=True)
+        assert c1.value == c2.value == m.value == -1
+        ctx.wait_counts()
+        assert c1.value == int((v < 10).sum()) and c2.value == int((v >= 90).sum()) and m.value == n
+        assert np.array_equal(ctx.download(s1, np.int32, c1.value), np.flatnonzero(v < 10))
+        m2, op2, ob2 = j.probe_inner([dv], None, n, 1000, defer=True)      # capacity too small: reported by the wait
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.wait_counts()
+        assert e.value.code == hip.PH_ECAPACITY and m2.value == n
+        s3, c3 = hip.filter_select(ctx, dv, n, hip.PH_EQ, hip.const(hip.PH_I32, i=5), defer=True)
+    finally:
+        ctx.set_async_counts(False)                                        # waits for c3
+    assert c3.value == int((v == 5).sum())
+    s4, c4 = hip.filter_select(ctx, dv, n, hip.PH_EQ, hip.const(hip.PH_I32, i=5))
+    assert c4 == c3.value
+    j.free(); dv.free(); dbk.free()
+
+
 def test_join_mark_where_and_residual_probe(ctx):
     """ph_join_probe_mark_where (Filter -> semi-join mark in one pass) equals filter_select + probe_mark,
     and ph_join_probe_inner_residual over a table built on ALL rows equals the inner probe of a table
