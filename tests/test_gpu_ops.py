@@ -707,6 +707,42 @@ def test_join_build_where_equals_filter_then_build(ctx):
         c.free()
 
 
+def test_direct_table_edge_cases(ctx):
+    """Empty and tiny inputs through the direct-table entry points: zero build rows, zero probe rows, one
+    row, a range of one value, probe keys all outside the range, ph_join_build_where over zero rows,
+    residual flags that reject everything."""
+    one = hip.DevColumn(ctx, hip.PH_I64, np.array([42], np.int64))
+    some = hip.DevColumn(ctx, hip.PH_I64, np.array([40, 41, 42, 43, 42, 1000], np.int64))
+    j0 = hip.Join(ctx, [one], None, 0, key_range=(42, 42))                 # no build rows: whatever table, no matches
+    assert j0.count() == 0
+    m, a, b = j0.probe_inner([some], None, 6, 16)
+    assert m == 0 and ctx.download(j0.probe_mark([some], None, 6), np.uint8, 6).sum() == 0
+    j0.free()
+    j1 = hip.Join(ctx, [one], None, 1, key_range=(42, 42))                 # a range of one value
+    assert j1.kind == "direct" and j1.count() == 1
+    m, a, b = j1.probe_inner([some], None, 6, 16)
+    assert m == 2 and ctx.download(a, np.int32, 2).tolist() == [2, 4] and ctx.download(b, np.int32, 2).tolist() == [0, 0]
+    assert ctx.download(j1.lookup([some], None, 6), np.int32, 6).tolist() == [-1, -1, 0, -1, 0, -1]
+    m, a, b = j1.probe_inner([some], None, 0, 16)                         # zero probe rows
+    assert m == 0
+    far = hip.DevColumn(ctx, hip.PH_I64, np.array([-5, 10**12, 41, 43], np.int64))
+    assert ctx.download(j1.probe_mark([far], None, 4), np.uint8, 4).tolist() == [0, 0, 0, 0]
+    flags0 = ctx.upload(np.zeros(1, np.uint8))
+    r = j1.probe_inner_residual([some], None, 0, None, flags0, None, 6, 16)
+    assert r is not None and r[0] == 0
+    flags1 = ctx.upload(np.ones(1, np.uint8))
+    r = j1.probe_inner_residual([some], None, 0, None, flags1, None, 6, 16)
+    assert r is not None and r[0] == 2
+    j1.free()
+    seg = hip.DevColumn(ctx, hip.PH_CODE8, np.array([1], np.uint8))
+    jw = hip.Join.build_where(ctx, [one], seg, hip.PH_EQ, hip.const(hip.PH_I32, i=1), None, 0, (42, 42))
+    assert jw is None or jw.count() == 0                                   # zero rows: no direct table is fine, so is an empty one
+    if jw is not None:
+        jw.free()
+    for c in (one, some, far, seg):
+        c.free()
+
+
 def test_async_counts(ctx):
     """ph_ctx_set_async_counts: filter_select / probe_inner return at once with the count pending (-1)
     and ph_ctx_wait_counts fills all of them in; an overflowing pair list is reported by the wait;
