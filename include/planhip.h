@@ -117,6 +117,8 @@ void ph_table_free(ph_table *t);
 /* plain device buffers for callers without their own allocator */
 int ph_dev_alloc(ph_ctx *ctx, int64_t bytes, void **dev);
 int ph_dev_free(ph_ctx *ctx, void *dev);
+/* n buffers in one call (the end of a query plan frees dozens of intermediates: one FFI crossing) */
+int ph_dev_free_many(ph_ctx *ctx, void *const *devs, int64_t n);
 int ph_dev_upload(ph_ctx *ctx, void *dev, const void *host, int64_t bytes);
 int ph_dev_download(ph_ctx *ctx, void *host, const void *dev, int64_t bytes);
 int ph_dev_memset(ph_ctx *ctx, void *dev, int value, int64_t bytes);

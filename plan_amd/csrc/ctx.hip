@@ -274,6 +274,12 @@ extern "C" int ph_dev_alloc(ph_ctx *ctx, int64_t bytes, void **dev) {
     return ctx->pool_alloc(bytes, dev);
 }
 
+extern "C" int ph_dev_free_many(ph_ctx *ctx, void *const *devs, int64_t n) {
+    PH_REQUIRE(ctx != nullptr && n >= 0 && (n == 0 || devs), "ph_dev_free_many: bad arguments");
+    for (int64_t i = 0; i < n; i++) ctx->pool_release(devs[i]);   // stream-ordered reuse; no synchronisation needed
+    return PH_OK;
+}
+
 extern "C" int ph_dev_free(ph_ctx *ctx, void *dev) {
     PH_REQUIRE(ctx != nullptr, "ph_dev_free: ctx is NULL");
     ctx->pool_release(dev);  // stream-ordered reuse; no synchronisation needed

@@ -198,6 +198,12 @@ class Ctx:
     def free(self, p):
         check(lib().ph_dev_free(self.h, p))
 
+    def free_many(self, ptrs):
+        ptrs = [p for p in ptrs if p]
+        if ptrs:
+            arr = (vp * len(ptrs))(*[vp(p.value) if isinstance(p, vp) else vp(p) for p in ptrs])
+            check(lib().ph_dev_free_many(self.h, arr, i64(len(ptrs))))
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         p = self.alloc(arr.nbytes)

@@ -270,8 +270,7 @@ class Q3Pipeline:
         agg.free()
         j1.free()
         j2.free()
-        for p in frees:
-            ctx.free(p)
+        ctx.free_many(frees)
         return dict(ngroups=ngroups_total, groups=groups, top=top, join_rows=m2, build_rows=cn + m1, timings=t)
 
 
@@ -561,8 +560,7 @@ class Q9Pipeline:
         r = agg.finalize()
         agg.free()
         stage("expr_aggregate", t0)
-        for p in frees:
-            ctx.free(p)
+        ctx.free_many(frees)
         mine = {(int(r["keys"][g][0]), int(r["keys"][g][1])): ([r["sum"][g][0]], [int(r["count"][g][0])])
                 for g in range(r["ngroups"])}
         merged = dist.merge_group_partials(mine, ctx=ctx)
