@@ -343,6 +343,7 @@ class Q9Pipeline:
             except hip.PlanHipError as e:
                 if e.code != hip.PH_ECONSTRAINT:
                     raise
+                self.ctx.set_async_counts(False)   # counts of the abandoned attempt land in variables that are still alive
             return self._run(strict=False)
         finally:
             self.ctx.set_async_counts(False)   # waits for counts still in flight (their variables live in self._counts)
