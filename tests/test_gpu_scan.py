@@ -237,6 +237,32 @@ def test_q9_pipeline_sf1_matches_reference_golden(ctx, sf1):
     assert {(a, b): c for a, b, c in r["rows"]} == want
 
 
+def test_q9_pipeline_with_dangling_foreign_keys_falls_back_to_counted_lookups(ctx, sf001):
+    """Q9's strict lookups assume every lineitem row finds its supplier / partsupp / order. With
+    lineitem rows whose l_suppkey or l_orderkey point nowhere, the deferred PH_ECONSTRAINT arrives with the
+    final download, the pipeline runs again with counted lookups that drop those rows (inner-join
+    semantics), and the groups equal the oracle's on the same damaged tables — in the stage-timed
+    form and in the pipelined one."""
+    from plan_amd import pipelines
+    t = dict(sf001)
+    L = {k: v.copy() for k, v in sf001["lineitem"].items()}
+    bad_s = (np.arange(len(L["l_orderkey"])) % 37) == 0
+    L["l_suppkey"][bad_s] = 10**6                                 # no such supplier (and no such partsupp row)
+    bad_o = (np.arange(len(L["l_orderkey"])) % 41) == 0
+    L["l_orderkey"][bad_o] = L["l_orderkey"][bad_o] + 9           # keys 9, 10, .. of a group of 32 are never used
+    t["lineitem"] = L
+    n, rows = O.q9(t, "%pink%")
+    want = {(rows[i].nationkey, rows[i].o_year): rows[i].sum_profit.unscaled(4) for i in range(n)}
+    assert 0 < len(want) <= 175
+    for timed in (True, False):
+        p = pipelines.Q9Pipeline(ctx, t["lineitem"], t["orders"], t["part"], t["partsupp"], t["supplier"])
+        p.time_stages = timed
+        r = p.run()
+        r2 = p.run()
+        p.free()
+        assert {(a, b): c for a, b, c in r["rows"]} == want == {(a, b): c for a, b, c in r2["rows"]}
+
+
 def test_generic_scan_plan_runs_unfused_shapes(ctx, sf001):
     """Descriptors outside the two fused shapes run as the operator chain on the device
     (ph_scan_plan_kind == "generic") and must agree with the oracle's group-by."""
