@@ -543,7 +543,7 @@ def main():
 
     h = Harness(args)
     rank0 = h.rank == 0
-    comp_steps, comp_warm = min(args.steps, 30), min(args.warmup, 3)
+    comp_steps, comp_warm = min(args.steps, 30), min(args.warmup, 5)
     if args.query in ("q1", "q6"):
         out, L, table = bench_scan(h, args.query, args.sf, args.steps, args.warmup, args.scaling)
     elif args.query == "q3":
