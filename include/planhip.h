@@ -326,6 +326,14 @@ int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const in
  * Every probe call works on every table form; the flags only pick the faster one. */
 #define PH_JOIN_KEY_RANGE 1
 #define PH_JOIN_FK_PROBES 2
+/*   PH_JOIN_KEYS_SORTED_UNIQUE  column statistics say the build keys are strictly ascending (a primary key in
+ *                      storage order). With PH_JOIN_KEY_RANGE and a dense range the direct table is then ONE
+ *                      kernel: the sorted fill, which still verifies the claim, but reports a violation as a
+ *                      DEFERRED PH_ECONSTRAINT of the ctx (see ph_ctx_set_deferred_errors: the next call that
+ *                      reads back fails, whether or not that option is on) instead of launching the general
+ *                      passes behind itself. The caller then builds again without the flag. Ignored where the
+ *                      sorted fill does not apply (selections, NULL-able keys, small or sparse tables). */
+#define PH_JOIN_KEYS_SORTED_UNIQUE 4
 int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int32_t flags,
                      int64_t key_lo, int64_t key_hi, ph_join **out);
 /* Filter -> HashJoin build in one pass (filterExecutor under joinExecutor's build child): the rows

@@ -66,10 +66,14 @@ int ph_ctx::deferred_words(int **out) {
 int ph_ctx::finish_deferred() {
     deferred_pending = false;
     const int *d = reinterpret_cast<const int *>((const char *)mailbox + PH_MAILBOX);
-    if (!d[0] && !d[1] && !d[2]) return PH_OK;
-    const int ovf = d[0], miss = d[1], multi = d[2];
+    if (!d[0] && !d[1] && !d[2] && !d[3]) return PH_OK;
+    const int ovf = d[0], miss = d[1], multi = d[2], unsorted = d[3];
     PH_HIP(hipMemsetAsync(deferred_dev, 0, 64, stream));
     if (ovf) { ph::set_error("deferred from ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
+    if (unsorted) {
+        ph::set_error("deferred from ph_join_build_ex: build keys declared PH_JOIN_KEYS_SORTED_UNIQUE are not sorted and unique");
+        return PH_ECONSTRAINT;
+    }
     ph::set_error("deferred from ph_join_lookup_strict: %d probe rows without a match, %d with more than one", miss, multi);
     return PH_ECONSTRAINT;
 }

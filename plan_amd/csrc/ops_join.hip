@@ -1462,7 +1462,11 @@ constexpr int SF_TILE = 4096;    // slots composed in LDS at a time
 template <int KW>
 __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__restrict__ kcol, int64_t n, long long lo,
                                                                 unsigned long long range, int64_t cap4, int32_t *__restrict__ direct,
-                                                                int *__restrict__ count, int *__restrict__ partials) {
+                                                                int *__restrict__ count, int *__restrict__ partials,
+                                                                int *__restrict__ declared) {
+    // declared != NULL: the caller stated (column statistics) that the keys are sorted and unique. The
+    // kernel still verifies both, but a violation becomes a deferred error of the ctx (*declared) instead of
+    // a fallback: none of the general passes is launched behind this kernel.
     __shared__ int tile[SF_TILE];
     __shared__ long long kk[SF_ROWS + 2];   // key[r0 - 1] (the run test of the first row), the chunk's keys, key[r1]
     long long *keys = kk + 1;
@@ -1501,7 +1505,10 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
         }
         if (bad) s_bad = 1;
         __syncthreads();
-        if (s_bad) { if (threadIdx.x == 0) atomicOr(count + 3, 1); continue; }   // nothing written for this chunk: the general passes rebuild everything
+        if (s_bad) {   // nothing written for this chunk: the general passes rebuild everything (or the deferred error says so)
+            if (threadIdx.x == 0) { atomicOr(count + 3, 1); if (declared) atomicOr(declared, 1); }
+            continue;
+        }
         const int64_t s0 = c == 0 ? 0 : keys[0] - lo;
         const int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
         for (int64_t t = s0; t < s1; t += SF_TILE) {
@@ -1532,8 +1539,9 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = stored; part[1][threadIdx.x >> 6] = runs; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
-        partials[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        const int st = part[0][0] + part[0][1] + part[0][2] + part[0][3], rn = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (partials) { partials[2 * blockIdx.x] = st; partials[2 * blockIdx.x + 1] = rn; }
+        if (declared && st != rn) atomicOr(declared, 1);   // two adjacent rows share a key
     }
 }
 
@@ -1657,7 +1665,7 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
                                                            const int32_t *__restrict__ psel, int64_t n, long long lo,
                                                            unsigned long long range, const int32_t *__restrict__ direct,
                                                            const int32_t *__restrict__ next, const int32_t *__restrict__ bsel,
-                                                           const int *__restrict__ bcount, int32_t *__restrict__ out,
+                                                           const int *__restrict__ bcount, int32_t nbuild, int32_t *__restrict__ out,
                                                            uint8_t *__restrict__ found, int *__restrict__ stats) {
     const bool dups = bcount[0] != bcount[1];   // rows stored vs slots occupied
     int misses = 0, multi = 0;
@@ -1687,7 +1695,7 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
             const unsigned long long off = (unsigned long long)(k[u] - lo);
             ok[u] = ok[u] && off < range;
             const int32_t d = direct[ok[u] ? off : 0];
-            b[u] = ok[u] ? d : -1;
+            b[u] = ok[u] && (unsigned)d < (unsigned)nbuild ? d : -1;   // anything but a build row reads as empty
             c[u] = b[u] >= 0 ? 1 : 0;
         }
         if (dups) {   // duplicate build keys: a chain holds every row of the key; report the last, count all
@@ -1731,6 +1739,8 @@ struct DirectCand {
     int cshift;   // coarse bit = slot >> cshift
     const unsigned *dbits;   // one bit per slot (tables of <= 8 M slots: L2 resident) or NULL
     const uint8_t *bflags;   // residual predicate on the BUILD row (a byte per build row, non-zero = keep) or NULL
+    int32_t nbuild;          // build rows: a slot holding anything else reads as empty (a fill that gave up on keys
+                             // declared sorted leaves slots unwritten until the deferred error is seen)
 };
 
 template <int KW, int WK, bool SEL, bool COARSE>
@@ -1788,7 +1798,7 @@ __device__ __forceinline__ void direct_cand_block(const DirectCand &D, int64_t b
         for (int rr = 0; rr < JP_ROUNDS; rr++) { ok[rr] = ok[rr] && ((bw[rr] >> (k[rr] & 31)) & 1u); if (!ok[rr]) k[rr] = 0; }
     }
 #pragma unroll
-    for (int rr = 0; rr < JP_ROUNDS; rr++) d[rr] = D.direct[k[rr]];
+    for (int rr = 0; rr < JP_ROUNDS; rr++) { d[rr] = D.direct[k[rr]]; d[rr] = (unsigned)d[rr] < (unsigned)D.nbuild ? d[rr] : -1; }
     if (D.bflags && !dups) {   // unique keys: the slot's row either passes the residual predicate or the probe row has no pair
         uint8_t fl[JP_ROUNDS];
 #pragma unroll
@@ -1896,7 +1906,7 @@ __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64
         for (int s = 0; s < 8; s++) { ok[s] = ok[s] && ((bw[s] >> (k[s] & 31)) & 1u); if (!ok[s]) k[s] = 0; }
     }
 #pragma unroll
-    for (int s = 0; s < 8; s++) d[s] = D.direct[k[s]];
+    for (int s = 0; s < 8; s++) { d[s] = D.direct[k[s]]; d[s] = (unsigned)d[s] < (unsigned)D.nbuild ? d[s] : -1; }
     if (D.bflags && !dups) {   // unique keys: the slot's row either passes the residual predicate or the probe row has no pair
         uint8_t fl[8];
 #pragma unroll
@@ -2029,7 +2039,7 @@ __global__ __launch_bounds__(256) void direct_emit_kernel(const int32_t *__restr
 template <int KW, int WK>
 __global__ __launch_bounds__(256) void direct_mark_where_kernel(const void *__restrict__ keycol, int64_t n, long long lo, unsigned long long range,
                                                                 const int32_t *__restrict__ direct, const unsigned *__restrict__ dbits,
-                                                                const void *__restrict__ wdata, long long wlo, long long whi,
+                                                                int32_t nbuild, const void *__restrict__ wdata, long long wlo, long long whi,
                                                                 uint8_t *__restrict__ found) {
     constexpr int R = 16 / KW, G = 8 / R;
     const int64_t base = (int64_t)blockIdx.x * JP_CHUNK;
@@ -2053,6 +2063,7 @@ __global__ __launch_bounds__(256) void direct_mark_where_kernel(const void *__re
             const unsigned long long off = (unsigned long long)(k[s] - lo);
             ok[s] = ok[s] && off < range;
             d[s] = direct[ok[s] ? off : 0];
+            d[s] = (unsigned)d[s] < (unsigned)nbuild ? d[s] : -1;
         }
     }
 #pragma unroll
@@ -2183,7 +2194,7 @@ static int build_big(ph_join *j, int kw, int nparts) {
         else { if (B.sel) KERNEL<8, true><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); else KERNEL<8, false><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); }         \
     } while (0)
 
-static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where) {
+static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where, bool declared_sorted_unique) {
     ph_ctx *ctx = j->ctx;
     const int64_t n = j->build.n;
     const int64_t cap4 = ph::round_up(range, 4);
@@ -2233,11 +2244,25 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
         }
         const int *gate = nullptr;
         int *partials = nullptr;
+        if (try_sorted && declared_sorted_unique) {
+            // keys the caller's statistics declare sorted and unique: the fill alone (it verifies the claim; a
+            // violation is a deferred PH_ECONSTRAINT of the ctx and the caller builds again without the claim).
+            // The six launches of the general passes, ~4.6 us each although they would leave at once, are not made.
+            int *words = nullptr;
+            PH_CHECK(ctx->deferred_words(&words));
+            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * 8);
+            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3);
+            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3);
+            PH_HIP(hipGetLastError());
+            ctx->deferred_pending = true;
+            j->count = n;   // every row is stored when the claim holds (count[0] == count[1] == 0 on the device: no chains)
+            return PH_OK;
+        }
         if (try_sorted) {
             const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * 8);
             PH_CHECK(ctx->pool_alloc((int64_t)gridf * 8, (void **)&partials));
-            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials);
-            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials);
+            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr);
+            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr);
             ph::direct_recount_kernel<<<1, 256, 0, ctx->stream>>>(j->count_dev, partials, gridf);
             ph::direct_refill_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->count_dev);
             ctx->pool_release(partials);   // stream-ordered reuse
@@ -2267,7 +2292,7 @@ template <int MODE>
 static void launch_direct_probe(ph_join *j, const ph::JoinSide &P, int64_t n, int grid, int32_t *out, uint8_t *found, int *stats) {
     hipStream_t st = j->ctx->stream;
     const int32_t *bsel = j->build.sel;
-#define PH_DP_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, bsel, j->count_dev, out, found, stats
+#define PH_DP_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, bsel, j->count_dev, (int32_t)j->build.n, out, found, stats
 #define PH_DP_LAUNCH(KWV)                                                                                                      \
     do {                                                                                                                       \
         if (P.sel && bsel) ph::direct_probe_kernel<KWV, true, true, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                   \
@@ -2284,7 +2309,7 @@ template <int KW, int WK>
 static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int nb, const ph::RangePred &w, const uint8_t *bflags, uint16_t *cand,
                                int32_t *cmatch, uint16_t *ccnt, int32_t *ccount, int32_t *counts) {
     ph::DirectCand D{P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, j->count_dev,
-                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift, j->dbits, bflags};
+                     w.data, w.lo, w.hi, cand, cmatch, ccnt, ccount, counts, j->dcshift, j->dbits, bflags, (int32_t)j->build.n};
     hipStream_t st = j->ctx->stream;
     auto aligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec = !P.sel && !P.key[0].validity && aligned(P.key[0].data) && (WK == 0 || aligned(w.data));
@@ -2397,7 +2422,7 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
 
 static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, bool have_range,
                            int64_t key_lo, int64_t key_hi, bool fk_probes, ph_join **out,
-                           const ph::RangePred &where = ph::RangePred{0, nullptr, nullptr, 0, 0}) {
+                           const ph::RangePred &where = ph::RangePred{0, nullptr, nullptr, 0, 0}, bool sorted_unique = false) {
     PH_REQUIRE(ctx && keys && out && nkeys >= 1 && nkeys <= ph::JOIN_MAX_KEYS && n >= 0 && n < (1ll << 31),
                "ph_join_build: bad arguments (1..%d keys)", ph::JOIN_MAX_KEYS);
     ph_join *j = new ph_join();
@@ -2417,7 +2442,7 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
         const bool dense = (int64_t)span + 1 <= std::max<int64_t>(8 * n, 4096);
         const bool small_range = span < (4ull << 20) && n <= (256 << 10);
         if (!(dz && atoi(dz) == 0) && kw != 1 && span < (1ull << 30) && (dense || small_range)) {
-            int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1, where);
+            int rcd = build_direct(j, kw, key_lo, (int64_t)span + 1, where, sorted_unique);
             if (rcd != PH_OK) { ph_join_free(j); return rcd; }
             *out = j;
             return PH_OK;
@@ -2575,8 +2600,9 @@ extern "C" int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkey
 
 extern "C" int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int32_t flags,
                                 int64_t key_lo, int64_t key_hi, ph_join **out) {
-    PH_REQUIRE((flags & ~(PH_JOIN_KEY_RANGE | PH_JOIN_FK_PROBES)) == 0, "ph_join_build_ex: unknown flags %d", flags);
-    return join_build_impl(ctx, keys, nkeys, sel, n, (flags & PH_JOIN_KEY_RANGE) != 0, key_lo, key_hi, (flags & PH_JOIN_FK_PROBES) != 0, out);
+    PH_REQUIRE((flags & ~(PH_JOIN_KEY_RANGE | PH_JOIN_FK_PROBES | PH_JOIN_KEYS_SORTED_UNIQUE)) == 0, "ph_join_build_ex: unknown flags %d", flags);
+    return join_build_impl(ctx, keys, nkeys, sel, n, (flags & PH_JOIN_KEY_RANGE) != 0, key_lo, key_hi, (flags & PH_JOIN_FK_PROBES) != 0, out,
+                           ph::RangePred{0, nullptr, nullptr, 0, 0}, (flags & PH_JOIN_KEYS_SORTED_UNIQUE) != 0);
 }
 
 extern "C" int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
@@ -2736,7 +2762,7 @@ extern "C" int ph_join_probe_mark_where(ph_join *j, const ph_col *keys, const ph
     ph_ctx *ctx = j->ctx;
     if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
     const int nb = (int)((n + ph::JP_CHUNK - 1) / ph::JP_CHUNK);
-#define PH_MW(KWV, WKV) ph::direct_mark_where_kernel<KWV, WKV><<<nb, 256, 0, ctx->stream>>>(P.key[0].data, n, (long long)j->dlo, j->drange, j->direct, j->dbits, w.data, w.lo, w.hi, found_dev)
+#define PH_MW(KWV, WKV) ph::direct_mark_where_kernel<KWV, WKV><<<nb, 256, 0, ctx->stream>>>(P.key[0].data, n, (long long)j->dlo, j->drange, j->direct, j->dbits, (int32_t)j->build.n, w.data, w.lo, w.hi, found_dev)
     if (j->dkw == 4) { if (w.kind == 1) PH_MW(4, 1); else if (w.kind == 2) PH_MW(4, 2); else PH_MW(4, 3); }
     else { if (w.kind == 1) PH_MW(8, 1); else if (w.kind == 2) PH_MW(8, 2); else PH_MW(8, 3); }
 #undef PH_MW

@@ -673,6 +673,46 @@ def test_join_direct_table_sorted_fill(ctx):
     j.free(); d32.free()
 
 
+def test_join_keys_declared_sorted_unique(ctx):
+    """PH_JOIN_KEYS_SORTED_UNIQUE: with a true claim the direct table is built by the fill alone and
+    answers like the undeclared build; with a false claim (one descending pair; one duplicate) the
+    build call still returns, probes stay in bounds, and the next read-back fails with the deferred
+    PH_ECONSTRAINT — after which an undeclared build of the same keys is correct."""
+    rng = np.random.default_rng(91)
+    n = 1_200_000                                                   # 9 M slots: above the bitmap limit, within 8 slots per row
+    keys = np.sort(rng.choice(9_000_000, n, replace=False)).astype(np.int64) + 5
+    rngk = (5, 9_000_004)
+    p = rng.integers(0, 9_000_100, 500_000).astype(np.int64)
+    dk, dp = hip.DevColumn(ctx, hip.PH_I64, keys), hip.DevColumn(ctx, hip.PH_I64, p)
+    jd = hip.Join(ctx, [dk], None, n, key_range=rngk, sorted_unique=True)
+    ju = hip.Join(ctx, [dk], None, n, key_range=rngk)
+    assert jd.kind == ju.kind == "direct" and jd.count() == ju.count() == n
+    a = ctx.download(jd.lookup([dp], None, len(p)), np.int32, len(p))
+    b = ctx.download(ju.lookup([dp], None, len(p)), np.int32, len(p))
+    assert np.array_equal(a, b) and (a >= 0).sum() > 40_000
+    ctx.check_deferred()
+    jd.free(); ju.free()
+    for kind in ("descending", "duplicate"):
+        bad = keys.copy()
+        if kind == "descending":
+            bad[600_000], bad[600_001] = keys[600_001], keys[600_000]
+        else:
+            bad[700_001] = bad[700_000]   # (still non-decreasing: only the uniqueness half of the claim fails)
+        dbad = hip.DevColumn(ctx, hip.PH_I64, bad)
+        jb = hip.Join(ctx, [dbad], None, n, key_range=rngk, sorted_unique=True)
+        rows = jb.lookup([dp], None, len(p))                      # slots may be unwritten: anything but a build row reads as empty
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(rows, np.int32, len(p))
+        assert e.value.code == hip.PH_ECONSTRAINT and "SORTED_UNIQUE" in str(e.value)
+        jb.free()
+        jg = hip.Join(ctx, [dbad], None, n, key_range=rngk)     # the caller's second attempt, without the claim
+        got = ctx.download(jg.lookup([dp], None, len(p)), np.int32, len(p))
+        hit = got >= 0
+        assert np.array_equal(bad[got[hit]], p[hit]) and np.array_equal(hit, np.isin(p, bad))
+        jg.free(); dbad.free()
+    dk.free(); dp.free()
+
+
 def test_join_build_where_equals_filter_then_build(ctx):
     """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
     row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
