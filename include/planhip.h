@@ -266,6 +266,16 @@ int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *args, int32_
  * table with ph_agg_sink_masked. Returns the group count through *ngroups. */
 int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev, uint8_t *out_validity_dev,
                     int64_t capacity, int64_t *ngroups);
+/* Streaming aggregate (the planner's StreamAggregate): the FIRST sink into an empty table whose n rows
+ * (positions 0..n of keys and args: no selection) arrive ordered by the group-key tuple — e.g. the
+ * output of a join whose probe side is clustered by the key. Every group is then one run of adjacent
+ * rows: run heads are marked, counted and scanned, and each head's thread reduces its run and writes
+ * the group's record, in first-seen order by construction; no hash table, so no later ph_agg_sink into
+ * the same table (PH_EUNSUPPORTED). Results are those of ph_agg_sink (exact 128-bit sums, NULL inputs
+ * skipped). The order is verified on the device: a key tuple lexicographically below its predecessor's
+ * is a DEFERRED PH_ECONSTRAINT of the ctx, reported by the next call that reads back, and the caller
+ * aggregates again with ph_agg_sink. NULL-able keys: PH_EUNSUPPORTED. */
+int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs, int64_t n, int64_t row_base);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
 /* Build check without a device of the plan-specialised sink: ph_agg_sink calls of >= 2^20 rows run
  * the sink kernel compiled (hiprtc, cached per shape) with the key types / aggregate kinds /

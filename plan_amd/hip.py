@@ -465,6 +465,15 @@ class Agg:
         check(lib().ph_agg_create(ctx.h, i32(len(key_types)), kt, i32(len(aggs)), sp,
                                   i64(expected_groups), ctypes.byref(self.h)))
 
+    def sink_sorted(self, keys, args, n, row_base=0):
+        """ph_agg_sink_sorted: streaming aggregate over rows ordered by the group key (first sink only);
+        False when the shape is not supported (the caller sinks with sink())"""
+        rc = lib().ph_agg_sink_sorted(self.h, _cols(keys), _cols(args), i32(len(args)), i64(n), i64(row_base))
+        if rc == PH_EUNSUPPORTED:
+            return False
+        check(rc)
+        return True
+
     def sink(self, keys, args, sel, n, positional=False, row_base=0, mask=None):
         """mask: bit a set = aggregate a is updated (AddChunk's filter); None = all"""
         if mask is None:

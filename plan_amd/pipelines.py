@@ -45,6 +45,8 @@ class Q3Pipeline:
         self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
         self.o_prio = D(ctx, hip.PH_I32, O["o_shippriority"])
         self.l_key = D(ctx, hip.PH_I64, L["l_orderkey"])
+        # column statistics: lineitem clustered by order key -> the join output arrives ordered by the group key
+        self.l_key_sorted = bool(self.nl > 1 and np.all(np.diff(L["l_orderkey"]) >= 0))
         self.l_ext = D(ctx, hip.PH_DEC64, L["l_extendedprice"], 2)
         self.l_disc = D(ctx, hip.PH_DEC64, L["l_discount"], 2)
         self.l_ship = D(ctx, hip.PH_DATE, L["l_shipdate"])
@@ -77,9 +79,9 @@ class Q3Pipeline:
             try:
                 return self._run(limit, want_groups)
             except hip.PlanHipError as e:
-                if e.code != hip.PH_ECONSTRAINT or not self.o_key_sorted_unique:
+                if e.code != hip.PH_ECONSTRAINT or not (self.o_key_sorted_unique or self.l_key_sorted):
                     raise
-                self.o_key_sorted_unique = False
+                self.o_key_sorted_unique = self.l_key_sorted = False   # a statistic did not hold: the general forms
             return self._run(limit, want_groups)
         finally:
             self.ctx.set_deferred_errors(False)
@@ -248,8 +250,13 @@ class Q3Pipeline:
         gd, gp = hip.gather_multi(ctx, [b_date, b_prio], brow, m2)
         frees += [rev, gk, gd, gp]
         agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_DATE, hip.PH_I32], [(hip.PH_A_SUM, 0)], max(m2 // 2, 1024))
-        agg.sink([_raw(hip.PH_I64, gk), _raw(hip.PH_DATE, gd), _raw(hip.PH_I32, gp)],
-                 [_raw(hip.PH_DEC64, rev, 4)], None, m2, positional=True)
+        gkeys, gargs = [_raw(hip.PH_I64, gk), _raw(hip.PH_DATE, gd), _raw(hip.PH_I32, gp)], [_raw(hip.PH_DEC64, rev, 4)]
+        # the pairs come out in lineitem order; lineitem clustered by order key (a column statistic) makes
+        # every group one run of adjacent rows: the streaming aggregate instead of the hash table
+        streamed = N == 1 and fused2 is not None and self.l_key_sorted and not getattr(self, "no_stream_agg", False) and \
+            agg.sink_sorted(gkeys, gargs, m2)
+        if not streamed:
+            agg.sink(gkeys, gargs, None, m2, positional=True)
         stage("expr_aggregate", t0)
         t0 = tic()
         # the total group count is reporting only (one more host round trip): not in measured steps

@@ -1206,6 +1206,68 @@ def test_join_lookup_matches_inner_probe_on_unique_keys(ctx):
         c.free()
 
 
+def test_streaming_aggregate_over_sorted_input_equals_hash_aggregate(ctx):
+    """ph_agg_sink_sorted: rows ordered by the group-key tuple (runs of 1..40 rows, one run of 100 000
+    rows, a run across a 2048-row block boundary; two keys; SUM / AVG / COUNT / MIN / MAX / COUNT(*) with
+    a NULL-able argument) give the groups ph_agg_sink gives, record for record and in first-seen order;
+    a further sink is refused; rows that are NOT ordered are a deferred PH_ECONSTRAINT."""
+    rng = np.random.default_rng(101)
+    lens = rng.integers(1, 41, 60_000)
+    lens[1000] = 100_000
+    k0 = np.repeat(np.arange(len(lens), dtype=np.int64) * 3, lens)
+    k1 = np.repeat(rng.integers(0, 5, len(lens)).astype(np.int32), lens)
+    n = len(k0)
+    v0 = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    v1 = rng.integers(0, 1000, n).astype(np.int32)
+    valid = rng.random(n) > 0.1
+    d0, d1 = hip.DevColumn(ctx, hip.PH_I64, k0), hip.DevColumn(ctx, hip.PH_I32, k1)
+    a0 = hip.DevColumn(ctx, hip.PH_DEC64, v0, 2, validity=np.packbits(valid, bitorder="little"))
+    a1 = hip.DevColumn(ctx, hip.PH_I32, v1)
+    aggs = [(hip.PH_A_SUM, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 1), (hip.PH_A_AVG, 1), (hip.PH_A_COUNT_STAR, -1), (hip.PH_A_COUNT, 0)]
+    res = []
+    for sorted_form in (True, False):
+        agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_I32], aggs, 1024)
+        if sorted_form:
+            assert agg.sink_sorted([d0, d1], [a0, a1], n)
+            with pytest.raises(hip.PlanHipError):
+                agg.sink([d0, d1], [a0, a1], None, n)
+        else:
+            agg.sink([d0, d1], [a0, a1], None, n)
+        r = agg.finalize(python_ints=False, room=len(lens))
+        res.append({k: np.asarray(r[k]) for k in ("first_row", "keys", "key_null", "sum_lo", "sum_hi", "count")})
+        assert r["ngroups"] == len(lens)
+        agg.free()
+    ctx.check_deferred()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert np.array_equal(res[0]["first_row"], np.concatenate([[0], np.cumsum(lens)[:-1]]))
+    # top-k works on the streamed table too (groups whose every input is NULL sort first, in both forms)
+    tops = []
+    for sorted_form in (True, False):
+        agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_I32], [(hip.PH_A_SUM, 1)], 1024)
+        if sorted_form:
+            assert agg.sink_sorted([d0, d1], [a0, a1], n)
+        else:
+            agg.sink([d0, d1], [a0, a1], None, n)
+        top = agg.topk(0, 5)
+        tops.append(sorted(zip(top["keys"][:, 0].tolist(), top["sum_lo"][:, 0].tolist())))
+        agg.free()
+    sums = np.add.reduceat(v1.astype(np.int64), np.concatenate([[0], np.cumsum(lens)[:-1]]))
+    assert tops[0] == tops[1] and {k for k, _ in tops[0]} >= set((np.argsort(-sums, kind="stable")[:1] * 3).tolist())
+    # not ordered by the key: the claim is verified on the device
+    kb = k0.copy()
+    kb[500_000:500_010] = 1
+    db = hip.DevColumn(ctx, hip.PH_I64, kb)
+    agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_I32], aggs, 1024)
+    assert agg.sink_sorted([db, d1], [a0, a1], n)
+    with pytest.raises(hip.PlanHipError) as e:
+        agg.group_count()
+    assert e.value.code == hip.PH_ECONSTRAINT
+    agg.free()
+    for c in (d0, d1, a0, a1, db):
+        c.free()
+
+
 def test_specialised_sink_equals_generic_sink_and_numpy(ctx):
     """ph_agg_sink calls of >= 2^20 rows run the hiprtc-specialised form of the sink kernel (same
     source, the shape as constants): for several shapes — NULL-able keys and arguments, selections,
