@@ -746,7 +746,10 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     if (T * per_entry > 120 * 1024) return PH_EUNSUPPORTED;
     B.lds_entries = T;
     int64_t want_parts = (a->expected_groups + T / 4 - 1) / (T / 4);
-    int nparts = 8;
+    // one 1024-thread workgroup builds one partition: big inputs get at least two partitions per CU
+    // (65 k groups from 32 M rows used 64 partitions = a quarter of the CUs: build 1.09 -> 0.51 ms)
+    int nparts = n >= (4ll << 20) ? 512 : 8;
+    if (const char *pe = getenv("PH_AGG_BULK_PARTS")) nparts = std::max(8, std::min(atoi(pe), 4096));
     while (nparts < want_parts && nparts < 4096) nparts *= 2;
     B.nparts = nparts;
     B.rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
@@ -813,13 +816,24 @@ namespace {
 
 // ---- plan-specialised sink: the same device source (agg_sink.inc), compiled through hiprtc with
 // the sink's shape as compile-time constants. Key = everything the SK_* macros fold.
-std::string agg_spec_defines(const ph::AggSinkParams &P, int threads, std::string *key) {
+// does any aggregate of the call count its own non-NULL inputs (an argument column with a validity mask)?
+// Otherwise every count is the LDS entry's row count and the per-aggregate counters are not allocated.
+bool agg_spec_need_cnt(const ph::AggSinkParams &P) {
+    for (int a = 0; a < P.naggs; a++)
+        if (((P.agg_mask >> a) & 1) && P.agg_kind[a] != PH_A_COUNT_STAR && P.arg[P.agg_arg[a]].validity) return true;
+    return false;
+}
+int agg_spec_entry_bytes(const ph::AggSinkParams &P) { return 12 + 8 * P.nkeys + 8 * P.naggs + (agg_spec_need_cnt(P) ? 4 * P.naggs : 0); }
+
+std::string agg_spec_defines(const ph::AggSinkParams &P, int threads, int slots, size_t lds, std::string *key) {
     std::ostringstream d, k;
     auto list = [&](const char *name, int n, auto f) {   // #define name(i) ((i)==0?v0:(i)==1?v1:...:0)
         d << "#define " << name << "(i) (";
         for (int i = 0; i < n; i++) d << "(i)==" << i << "?" << f(i) << ":";
         d << "0)\n";
     };
+    if (getenv("PH_AGG_HASH2")) d << "#define PH_LDS_HASH_2MUL 1\n";
+    d << "#define SPEC_SLOTS " << slots << "\n#define SPEC_LDS_BYTES " << lds << "\n#define SPEC_NEED_CNT " << (agg_spec_need_cnt(P) ? 1 : 0) << "\n";
     d << "#define PH_SPEC 1\n#define SPEC_T " << threads << "\n#define SPEC_NK " << P.nkeys << "\n#define SPEC_NA " << P.naggs << "\n"
       << "#define SPEC_HAS_SEL " << (P.sel ? 1 : 0) << "\n#define SPEC_POSITIONAL " << (P.positional ? 1 : 0) << "\n"
       << "#define SPEC_AGG_MASK " << (P.agg_mask & ((1u << P.naggs) - 1u)) << "u\n#define SPEC_ARG_USED " << P.arg_used << "u\n";
@@ -834,11 +848,11 @@ std::string agg_spec_defines(const ph::AggSinkParams &P, int threads, std::strin
 }
 
 // the specialised kernel of this sink shape, or PH_EUNSUPPORTED (no hiprtc, PH_AGG_JIT=0, compile trouble)
-int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, int threads, ph::JitKernel *out) {
+int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, int threads, int slots, size_t lds, ph::JitKernel *out) {
     const char *e = getenv("PH_AGG_JIT");   // read per call: tests compare both kernels in one process
     if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
     std::string key;
-    std::string defs = agg_spec_defines(P, threads, &key);
+    std::string defs = agg_spec_defines(P, threads, slots, lds, &key);
     if (ph::jit_cached(ctx, key, out)) return PH_OK;   // no 20 KB source concatenation on a hit
     int rc = ph::jit_module(ctx, key, defs + AGG_SINK_SRC, "agg_sink_spec", out);
     return rc == PH_OK ? PH_OK : PH_EUNSUPPORTED;
@@ -870,7 +884,9 @@ extern "C" int ph_agg_jit_selfcheck(int32_t which) {
         return PH_EINVAL;
     }
     std::string key, log;
-    std::string src = agg_spec_defines(P, which == 0 ? 1024 : 256, &key) + AGG_SINK_SRC;
+    const int per_entry = agg_spec_entry_bytes(P);
+    const int slots = which == 0 ? 2048 : 512;
+    std::string src = agg_spec_defines(P, which == 0 ? 1024 : 256, slots, (size_t)slots * per_entry, &key) + AGG_SINK_SRC;
     return ph::jit_compile_only(src, "gfx950", &log);
 }
 
@@ -1108,7 +1124,18 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     P.n = n;
     P.row_base = row_base;
     static const bool no_bulk = getenv("PH_AGG_NO_BULK") != nullptr;
-    if (!no_bulk && a->rows_sunk == 0 && a->expected_groups >= 32768 && n >= 65536) {
+    // ... and big first sinks whose expected groups overflow the largest LDS table the incremental
+    // kernel can have (144 KiB at 70 %): their rows would update the global table one by one with
+    // device-scope atomics (3000 groups / 32 M rows: 4.9 ms against 1.5 ms for the bulk build)
+    int64_t bulk_min = 32768;
+    if (n >= (4ll << 20)) {
+        const int sper = agg_spec_entry_bytes(P);
+        int t = 64;
+        while ((size_t)t * 2 * sper <= 144 * 1024 && t < 8192) t *= 2;
+        bulk_min = std::min<int64_t>(bulk_min, (int64_t)t * 7 / 10 + 1);
+    }
+    if (const char *be = getenv("PH_AGG_BULK_MIN")) bulk_min = atoll(be);
+    if (!no_bulk && a->rows_sunk == 0 && a->expected_groups >= bulk_min && n >= 65536) {
         int brc = bulk_sink(a, P, used, n);
         if (brc != PH_EUNSUPPORTED) {
             if (brc == PH_OK) a->rows_sunk += n;
@@ -1148,10 +1175,25 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
         const char *te = getenv("PH_AGG_T");
         spec_threads = te ? atoi(te) : 512;
         if (spec_threads != 256 && spec_threads != 512 && spec_threads != 1024) spec_threads = 256;
-        have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, Q, spec_threads, &spec) == PH_OK;
+        // The specialised kernel's table is static, so it may pass 64 KiB: when the creator expects more
+        // groups than half of the 32 KiB table holds, the table grows (up to 128 KiB: one 1024-thread
+        // workgroup per CU) — rows whose group finds no room in LDS go to the global table one by
+        // one (1000 groups in a 256-entry table: 4.3 ms per 32 M rows).
+        int sslots = slots;
+        const int sper = agg_spec_entry_bytes(Q);
+        size_t budget = 32 * 1024;
+        if (const char *le = getenv("PH_AGG_LDS_KB")) budget = (size_t)std::max(8, std::min(atoi(le), 144)) * 1024;
+        auto fit = [&](size_t b) { int t = 64; while ((size_t)t * 2 * sper <= b && t < 8192) t *= 2; return t; };
+        sslots = fit(budget);
+        if (!getenv("PH_AGG_LDS_KB"))   // the smallest table the expected groups fill to 70 % at most
+            for (size_t b = budget; b <= 144 * 1024; b = b < 128 * 1024 ? b * 2 : b + 16 * 1024)
+                if ((int64_t)fit(b) * 7 / 10 >= a->expected_groups) { budget = b; sslots = fit(b); break; }
+        if (budget > 64 * 1024 && !te) spec_threads = 1024;
+        have_spec = n >= (1 << 20) && agg_spec_kernel(a->ctx, Q, spec_threads, sslots, (size_t)sslots * sper, &spec) == PH_OK;
+        if (have_spec) { slots = sslots; P.lds_slots = slots; lds = (size_t)slots * sper; }
     }
     const int threads = have_spec ? spec_threads : 256;
-    if (have_spec) PH_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spec.fn, threads, lds));
+    if (have_spec) PH_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spec.fn, threads, 0));
     else PH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds));
     const int occ_raw = occ;
     occ = std::max(1, std::min(occ, 4));
@@ -1160,14 +1202,16 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     // every thread one row before giving any thread a second one
     const int64_t resident = (int64_t)a->ctx->cu_count * occ;
     int chunk = threads;
-    while (chunk < ph::AGG_CHUNK && (n + chunk - 1) / chunk > resident) chunk *= 2;
+    int max_chunk = have_spec ? 4 * ph::AGG_CHUNK : ph::AGG_CHUNK;   // fewer growth checks (two barriers + one device-scope read each)
+    if (const char *ce = getenv("PH_AGG_CHUNK")) max_chunk = std::max(256, std::min(atoi(ce), 1 << 16));
+    while (chunk < max_chunk && (n + chunk - 1) / chunk > resident) chunk *= 2;
     P.chunk = chunk;
     const int64_t nchunks = (n + chunk - 1) / chunk;
     // staged partials are int64 sums of |v| < 2^40 and u32 counts: at most 2^22 rows per workgroup
     const int64_t min_grid = (n + (1ll << 22) - 1) >> 22;
     const int grid = (int)std::max<int64_t>(std::min<int64_t>(nchunks, resident), min_grid);
     // this call creates at most n groups in total, so a slack of n is always enough
-    P.slack = std::min<long long>((long long)grid * (chunk + slots / 2), n);
+    P.slack = std::min<long long>((long long)grid * (chunk + slots), n);
     int *progress = nullptr;
     PH_CHECK(a->ctx->pool_alloc((int64_t)grid * 4, (void **)&progress));
     P.progress = progress;
@@ -1219,7 +1263,7 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
             ph::AggSinkParams copy = P;
             size_t size = sizeof copy;
             void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-            if (hipModuleLaunchKernel(spec.fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, a->ctx->stream, nullptr, config) != hipSuccess) { rc = PH_EHIP; break; }
+            if (hipModuleLaunchKernel(spec.fn, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, 0, a->ctx->stream, nullptr, config) != hipSuccess) { rc = PH_EHIP; break; }
         } else {
             kernel<<<grid, 256, lds, a->ctx->stream>>>(P);
             if (hipGetLastError() != hipSuccess) { rc = PH_EHIP; break; }
