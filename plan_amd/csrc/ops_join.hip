@@ -1878,15 +1878,33 @@ __global__ __launch_bounds__(1024) void direct_cand_coarse_kernel(DirectCand D, 
 // ballots. The round-per-row form above spends ~75 VALU instructions per row (64-bit index
 // arithmetic, a scalar load and a ballot round per row) and was VALU bound: 60 M 4-byte keys took
 // 174 us where the key column streams in 40.
+template <int KW, bool COARSE, bool WAVE>
+__device__ __forceinline__ void direct_cand_block_keys(const DirectCand &D, int64_t blk, bool have, int tid, int *wcv, int *wtot,
+                                                       const unsigned *co_lds, bool dups, long long (&k)[8], bool (&ok)[8],
+                                                       int sub, int &run_cands, int &run_total);
+
 template <int KW, int WK, bool COARSE>
 __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64_t blk, bool have, int tid, int *wcv, int *wtot,
                                                       const unsigned *co_lds, bool dups) {
-    constexpr int R = 16 / KW, G = 8 / R;
     const int64_t base = blk * JP_CHUNK;
     const int lane = tid & 63, wv = tid >> 6;
     long long k[8], k2[8];
     bool ok[8];
     dc_block_keys<KW, WK, 1>(D.keycol, nullptr, D.wdata, D.wlo, D.whi, base + wv * 512, lane, have && base + JP_CHUNK <= D.n, have, D.n, k, k2, ok);
+    int rc = 0, rt = 0;
+    direct_cand_block_keys<KW, COARSE, false>(D, blk, have, tid, wcv, wtot, co_lds, dups, k, ok, 0, rc, rt);
+}
+
+// the same with the keys (and filter results) already in registers. WAVE: one wave works through the
+// block alone, step `sub` of four (the persistent coarse kernel): the offsets inside the block run in
+// run_cands / run_total instead of LDS counts, and there is no barrier
+template <int KW, bool COARSE, bool WAVE>
+__device__ __forceinline__ void direct_cand_block_keys(const DirectCand &D, int64_t blk, bool have, int tid, int *wcv, int *wtot,
+                                                       const unsigned *co_lds, bool dups, long long (&k)[8], bool (&ok)[8],
+                                                       int sub, int &run_cands, int &run_total) {
+    constexpr int R = 16 / KW, G = 8 / R;
+    const int64_t base = blk * JP_CHUNK;
+    const int lane = tid & 63, wv = WAVE ? sub : tid >> 6;
     int32_t d[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
@@ -1931,11 +1949,13 @@ __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64
     int first[G];
     const int wave_cands = dc_wave_ranks<R>(take, first);
     if (dups) { for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o); } else total = wave_cands;
-    if (lane == 0) { wcv[wv] = wave_cands; wtot[wv] = total; }
-    __syncthreads();
+    if (!WAVE) {
+        if (lane == 0) { wcv[wv] = wave_cands; wtot[wv] = total; }
+        __syncthreads();
+    }
     if (have) {
-        int off = 0;
-        for (int q = 0; q < wv; q++) off += wcv[q];
+        int off = run_cands;
+        if (!WAVE) for (int q = 0; q < wv; q++) off += wcv[q];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             int64_t slot = base + off + first[g];
@@ -1950,11 +1970,12 @@ __device__ __forceinline__ void direct_cand_block_vec(const DirectCand &D, int64
                 }
             }
         }
-        if (tid == 0) {
+        if (!WAVE && tid == 0) {
             D.ccount[blk] = wcv[0] + wcv[1] + wcv[2] + wcv[3];
             D.block_counts[blk] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
         }
     }
+    if (WAVE) { run_cands += wave_cands; run_total += total; }
 }
 
 template <int KW, int WK>
@@ -1966,8 +1987,6 @@ __global__ __launch_bounds__(256) void direct_cand_vec_kernel(DirectCand D) {
 template <int KW, int WK>
 __global__ __launch_bounds__(1024) void direct_cand_coarse_vec_kernel(DirectCand D, const unsigned *__restrict__ coarse, int64_t nb) {
     extern __shared__ unsigned dcv_lds[];          // CO_WORDS words, then the per-group wave counts
-    int (*wcv)[4] = reinterpret_cast<int (*)[4]>(dcv_lds + CO_WORDS);
-    int (*wtot)[4] = reinterpret_cast<int (*)[4]>(dcv_lds + CO_WORDS + 16);
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(coarse);
         uint4 *dst = reinterpret_cast<uint4 *>(dcv_lds);
@@ -1975,11 +1994,28 @@ __global__ __launch_bounds__(1024) void direct_cand_coarse_vec_kernel(DirectCand
     }
     __syncthreads();
     const bool dups = D.bcount[0] != D.bcount[1];
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    for (int64_t it = 0; (it * gridDim.x + blockIdx.x) * 4 < nb; it++) {
-        const int64_t blk = (it * gridDim.x + blockIdx.x) * 4 + grp;
-        direct_cand_block_vec<KW, WK, true>(D, blk, blk < nb, tid, wcv[grp], wtot[grp], dcv_lds, dups);
-        __syncthreads();   // the counts are rewritten in the next step
+    // One workgroup per CU (the bitmap takes the LDS), and every WAVE works alone: it takes a whole 2048-row
+    // block in four 512-row steps, ranks its survivors with ballots and keeps the block's running offset in
+    // a register — no LDS counts, no barrier. (With four waves per block and a barrier per step the 16
+    // waves of the CU moved in lockstep through key read -> bitmap test -> table read -> barrier: 240 MB of
+    // l_partkey took 127 us.) The keys of the next step are requested before the current step's table reads.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t blk = (int64_t)blockIdx.x * 16 + wave; blk < nb; blk += (int64_t)gridDim.x * 16) {
+        const bool full = (blk + 1) * JP_CHUNK <= D.n;
+        int run_cands = 0, run_total = 0;
+        long long k[8], k2[8], kn[8];
+        bool ok[8], okn[8];
+        dc_block_keys<KW, WK, 1>(D.keycol, nullptr, D.wdata, D.wlo, D.whi, blk * JP_CHUNK, lane, full, true, D.n, k, k2, ok);
+#pragma unroll 1
+        for (int sub = 0; sub < 4; sub++) {   // not unrolled: four copies of the body overflow the instruction cache
+            if (sub < 3) dc_block_keys<KW, WK, 1>(D.keycol, nullptr, D.wdata, D.wlo, D.whi, blk * JP_CHUNK + (sub + 1) * 512, lane, full, true, D.n, kn, k2, okn);
+            direct_cand_block_keys<KW, true, true>(D, blk, true, lane, nullptr, nullptr, dcv_lds, dups, k, ok, sub, run_cands, run_total);
+            if (sub < 3) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) { k[s] = kn[s]; ok[s] = okn[s]; }
+            }
+        }
+        if (lane == 0) { D.ccount[blk] = run_cands; D.block_counts[blk] = run_total; }
     }
 }
 
@@ -2317,8 +2353,8 @@ static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int
     // dependent L2 read per survivor) made the kernel slower (Q9: 119 -> 151 us)
     if (j->bloom.coarse && nb >= 64) D.dbits = nullptr;
     if (vec && j->bloom.coarse && nb >= 64) {
-        const size_t lds = (size_t)ph::CO_WORDS * 4 + 2 * 16 * sizeof(int);
-        const int grid = std::min((nb + 3) / 4, j->ctx->cu_count);
+        const size_t lds = (size_t)ph::CO_WORDS * 4;
+        const int grid = std::min((nb + 15) / 16, j->ctx->cu_count);   // one block per wave and step
         (void)hipFuncSetAttribute((const void *)ph::direct_cand_coarse_vec_kernel<KW, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         ph::direct_cand_coarse_vec_kernel<KW, WK><<<grid, 1024, lds, st>>>(D, j->bloom.coarse, (int64_t)nb);
         return;
