@@ -320,27 +320,48 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
         unsigned long long k[BU][AGG_MAX_KEYS];
         unsigned nm[BU];
         bulk_keys_batch<NK, PLAINK>(B.S, base, i1, ii, rr, k, nm);
+        // the carried argument values of all BU rows first (independent loads in flight together; read row
+        // by row behind each cursor add they were BU x nused dependent HBM latencies per thread and step)
+        long long av[BU][BK_MAX_ARGS];
+        unsigned vb[BU];
+#pragma unroll
+        for (int u = 0; u < BU; u++) vb[u] = 0;
+#pragma unroll
+        for (int j = 0; j < BK_MAX_ARGS; j++) {
+            if (j >= B.nused) break;   // wave-uniform
+            const AggCol &c = B.S.arg[B.used_col[j]];
+            const bool w32 = c.type == PH_I32;
+#pragma unroll
+            for (int u = 0; u < BU; u++) {
+                const int64_t ic = ii[u] < i1 ? ii[u] : i1 - 1;
+                const int64_t ar = B.S.positional ? ic : rr[u];
+                av[u][j] = w32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+                if (bit_valid(c.validity, ar)) vb[u] |= 1u << j; else av[u][j] = 0;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < BU; u++) {
             if (ii[u] >= i1) continue;
             const int64_t i = ii[u], r = rr[u];
             const int pos = atomicAdd(&cursor[(keys_hash(k[u], nm[u], NK) >> 40) & (B.nparts - 1)], 1);
             unsigned long long *rec = B.rec + (int64_t)pos * B.rec_words;
+            const unsigned long long rowid = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
+            const unsigned long long tail = (unsigned long long)nm[u] | ((unsigned long long)vb[u] << 8);
+            if (NK == 1 && B.nused == 1) {   // the common record {key, row, value, masks}: two 16-byte stores
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 a, b;
+                a.x = k[u][0]; a.y = rowid; b.x = (unsigned long long)av[u][0]; b.y = tail;
+                reinterpret_cast<u64x2 *>(rec)[0] = a;
+                reinterpret_cast<u64x2 *>(rec)[1] = b;
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < NK; c++) rec[c] = k[u][c];
-            rec[NK] = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
-            unsigned vbits = 0;
-            const int64_t ar = B.S.positional ? i : r;
-            for (int j = 0; j < B.nused; j++) {
-                const AggCol &c = B.S.arg[B.used_col[j]];
-                long long v = 0;
-                if (bit_valid(c.validity, ar)) {
-                    vbits |= 1u << j;
-                    v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
-                }
-                rec[NK + 1 + j] = (unsigned long long)v;
-            }
-            rec[NK + 1 + B.nused] = (unsigned long long)nm[u] | ((unsigned long long)vbits << 8);
+            rec[NK] = rowid;
+#pragma unroll
+            for (int j = 0; j < BK_MAX_ARGS; j++)
+                if (j < B.nused) rec[NK + 1 + j] = (unsigned long long)av[u][j];
+            rec[NK + 1 + B.nused] = tail;
         }
     }
 }
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
 template <int NK>
 __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
-    __shared__ int s_nent, s_base, s_wsum[16];
+    __shared__ int s_nent, s_base, s_wsum[16], s_flagged;
     const AggSinkParams &S = B.S;
     const int T = B.lds_entries, na = S.naggs;
     const int64_t n = S.n;
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             l_cnt[e * na + a] = 0;
         }
     }
-    if (threadIdx.x == 0) s_nent = 0;
+    if (threadIdx.x == 0) { s_nent = 0; s_flagged = 0; }
     __syncthreads();
     const int p = blockIdx.x, nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
     const int64_t start = B.counts[(int64_t)p * nwg];
@@ -380,18 +401,28 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
     // key got in after all, else takes the global path. Deciding "not in LDS" while other lanes
     // may still be inserting that very key would create the group twice (once by find_or_create,
     // once by the write-out below, which claims slots without comparing keys).
+    const bool rec4 = NK == 1 && B.nused == 1;   // the common record {key, row, value, masks}: two 16-byte reads
     for (int phase = 0; phase < 2; phase++) {
+    // nearly always no row was flagged (the partitions are sized for a quarter-full table): phase 1
+    // would re-read every line of the partition just to look at the flag words
+    if (phase == 1 && !s_flagged) break;
     for (int64_t t = start + threadIdx.x; t < end; t += 1024) {
         unsigned long long *rec = B.rec + t * B.rec_words;
-        const unsigned long long flags = rec[NK + 1 + B.nused];
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 ra = {0, 0}, rb = {0, 0};
+        if (rec4) { ra = reinterpret_cast<const u64x2 *>(rec)[0]; rb = reinterpret_cast<const u64x2 *>(rec)[1]; }
+        const unsigned long long flags = rec4 ? rb.y : rec[NK + 1 + B.nused];
         const bool no_room = flags >> 63;
         if (phase == 1 && !no_room) continue;
         unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+        if (rec4) k[0] = ra.x;
+        else {
 #pragma unroll
-        for (int c = 0; c < NK; c++) k[c] = rec[c];
+            for (int c = 0; c < NK; c++) k[c] = rec[c];
+        }
         const unsigned nullmask = (unsigned)(flags & 0xFF);
         const unsigned vbits = (unsigned)((flags >> 8) & 0xFF);
-        const long long frow = (long long)rec[NK];
+        const long long frow = (long long)(rec4 ? ra.y : rec[NK]);
         int ent = -1;
         int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
         for (int probes = 0, spins = 0; probes < 32 && spins < (1 << 16);) {
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
         }
         int gid = -1;
         if (ent < 0) {
-            if (phase == 0) { rec[NK + 1 + B.nused] = flags | (1ull << 63); continue; }   // decided in phase 1
+            if (phase == 0) { rec[NK + 1 + B.nused] = flags | (1ull << 63); s_flagged = 1; continue; }   // decided in phase 1
             // no room in LDS: the ordinary global path for this row. Once the table has run out of
             // ids this attempt is void (the host grows the table and runs the build again).
             if (__hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
@@ -436,6 +467,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
             // through phase 1 a second time
             if (phase == 0 && no_room) rec[NK + 1 + B.nused] = flags & ~(1ull << 63);
         }
+        const long long v0 = (long long)(rec4 ? rb.x : 0ull);
         for (int a = 0; a < na; a++) {
             if (!((S.agg_mask >> a) & 1)) continue;
             const int kind = S.agg_kind[a];
@@ -445,7 +477,7 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
                 int j = 0;
                 for (; j < B.nused; j++) if (B.used_col[j] == S.agg_arg[a]) break;
                 valid = (vbits >> j) & 1;
-                v = (long long)rec[NK + 1 + j];
+                v = rec4 ? v0 : (long long)rec[NK + 1 + j];
             }
             if (!valid) continue;
             if (ent >= 0) {
