@@ -356,6 +356,14 @@ int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32
 int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
                         const ph_const *where_k, const int32_t *sel, int64_t n, int64_t key_lo, int64_t key_hi,
                         ph_join **out);
+/* ... with the planner hints of ph_join_build_ex (PH_JOIN_KEY_RANGE is implied). With
+ * PH_JOIN_KEYS_SORTED_UNIQUE the Filter rides along in the verified one-pass sorted fill, which also
+ * writes the table's occupancy bitmap (ranges up to 128 M slots): the candidate pass of a later inner probe
+ * tests the bitmap and reads the slot array only for keys that are present — Q3's orders build after the
+ * customer semi-join flags (the planner's Filter over executor_join.go:54-264's build child). */
+int ph_join_build_where_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
+                           const ph_const *where_k, const int32_t *sel, int64_t n, int32_t flags, int64_t key_lo,
+                           int64_t key_hi, ph_join **out);
 /* the table form a build chose: "direct", "nodes", "chained+bloom" or "chained" */
 const char *ph_join_kind(const ph_join *j);
 int64_t ph_join_count(const ph_join *j);

@@ -11,6 +11,7 @@
 // pass, a scan over workgroup totals and a write pass place them (no atomics on the output).
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "device_util.h"
@@ -1459,17 +1460,35 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(DirectSrc S, int64_t
 constexpr int SF_ROWS = 512;     // rows per step of a 256-thread workgroup (eight workgroups per CU overlap each other's latencies)
 constexpr int SF_TILE = 4096;    // slots composed in LDS at a time
 
-template <int KW>
+// GATED (declared sorted-unique keys only): the build child's Filter rides along — rows whose wdata value is
+// outside [wlo, whi] keep their slot empty — and the fill also writes the occupancy bitmap the candidate pass
+// of inner probes tests first (words wholly inside a tile with plain stores, the two edge words of a tile
+// with atomic ORs into the pre-cleared bitmap). The rows stored are the bitmap's set bits (ph_join_count).
+template <int KW, int WK>   // WK: 0 plain, else the gate column's kind (1 int32, 2 int64, 3 uint8) — a template parameter
+                            // because a run-time switch between three load widths put waits into the key prefetch
 __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__restrict__ kcol, int64_t n, long long lo,
                                                                 unsigned long long range, int64_t cap4, int32_t *__restrict__ direct,
                                                                 int *__restrict__ count, int *__restrict__ partials,
-                                                                int *__restrict__ declared) {
+                                                                int *__restrict__ declared, const void *__restrict__ wdata,
+                                                                long long wlo, long long whi, unsigned *__restrict__ dbits) {
+    constexpr bool GATED = WK != 0;
     // declared != NULL: the caller stated (column statistics) that the keys are sorted and unique. The
     // kernel still verifies both, but a violation becomes a deferred error of the ctx (*declared) instead of
     // a fallback: none of the general passes is launched behind this kernel.
     __shared__ int tile[SF_TILE];
     __shared__ long long kk[SF_ROWS + 2];   // key[r0 - 1] (the run test of the first row), the chunk's keys, key[r1]
     long long *keys = kk + 1;
+    // the gate column's values of the chunk's rows, RAW as loaded (bytes travel four to a dword): any
+    // arithmetic on a prefetched value — a compare, even the widening of a byte — is scheduled next to its
+    // load and waits there for the whole prefetch (the kernel took 150 us instead of 70)
+    using GT = typename std::conditional<WK == 2, long long, int>::type;
+    constexpr int GN = WK == 3 ? 1 : SF_ROWS / 256;
+    __shared__ GT graw[WK == 0 ? 1 : WK == 3 ? SF_ROWS / 4 : SF_ROWS];
+    auto gate_pass = [&](int e) {
+        const long long v = WK == 3 ? (long long)reinterpret_cast<const unsigned char *>(graw)[e] : (long long)graw[WK == 3 ? 0 : e];
+        return v >= wlo && v <= whi;
+    };
+    __shared__ unsigned lbits[GATED ? SF_TILE / 32 + 1 : 1];   // occupancy words of the tile being composed
     __shared__ int s_bad;
     int stored = 0, runs = 0;
     const int64_t nchunks = (n + SF_ROWS - 1) / SF_ROWS;
@@ -1477,12 +1496,23 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
     // software pipeline: the keys of the NEXT chunk are in flight while this one is composed
     constexpr int KR = (SF_ROWS + 2 + 255) / 256;
     long long kreg[KR];
+    GT greg[GN];
     auto fetch = [&](int64_t c) {
         const int64_t r0 = c * SF_ROWS;
 #pragma unroll
         for (int q = 0; q < KR; q++) {
             const int64_t i = r0 - 1 + q * 256 + threadIdx.x;
             kreg[q] = (c < nchunks && i >= 0 && i < n && q * 256 + (int)threadIdx.x < SF_ROWS + 2) ? (long long)load_kw<KW>(kcol, i) : beyond;
+        }
+        if (WK == 3) {   // 512 flag bytes = 128 aligned dwords (the host checked the column's alignment)
+            const int64_t d = r0 / 4 + threadIdx.x;
+            greg[0] = (c < nchunks && threadIdx.x < SF_ROWS / 4 && d * 4 < n) ? ((const int *)wdata)[d] : 0;
+        } else if (GATED) {
+#pragma unroll
+            for (int q = 0; q < GN; q++) {
+                const int64_t i = r0 + q * 256 + threadIdx.x;
+                greg[q] = (c < nchunks && i < n) ? ((const GT *)wdata)[i] : (GT)0;
+            }
         }
     };
     fetch(blockIdx.x);
@@ -1494,6 +1524,11 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
 #pragma unroll
         for (int q = 0; q < KR; q++)
             if (q * 256 + (int)threadIdx.x < SF_ROWS + 2) kk[q * 256 + threadIdx.x] = kreg[q];
+        if (WK == 3) { if (threadIdx.x < SF_ROWS / 4) graw[threadIdx.x] = greg[0]; }
+        else if (GATED) {
+#pragma unroll
+            for (int q = 0; q < GN; q++) graw[q * 256 + threadIdx.x] = greg[q];
+        }
         fetch(c + gridDim.x);
         __syncthreads();
         bool bad = false;
@@ -1515,12 +1550,27 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
             const int w = (int)(s1 - t < SF_TILE ? s1 - t : SF_TILE);
             __syncthreads();
             for (int e = threadIdx.x; e < w; e += 256) tile[e] = -1;
+            if (GATED && threadIdx.x <= SF_TILE / 32) lbits[threadIdx.x] = 0;
             __syncthreads();
             for (int e = threadIdx.x; e < m; e += 256) {
                 const int64_t off = keys[e] - lo - t;
-                if (off >= 0 && off < w) tile[off] = (int32_t)(r0 + e);   // equal keys: any of them; the chains are linked afterwards
+                if (off >= 0 && off < w && (!GATED || gate_pass(e))) {
+                    tile[off] = (int32_t)(r0 + e);   // equal keys: any of them; the chains are linked afterwards
+                    if (GATED) { const int b = (int)(t & 31) + (int)off; atomicOr(&lbits[b >> 5], 1u << (b & 31)); }
+                }
             }
             __syncthreads();
+            if (GATED && dbits) {
+                // the tile's occupancy words were composed beside the slots (one LDS OR per stored row — a
+                // ballot pass over the 4096 slots was more instructions than the rest of the tile's work)
+                const int sh = (int)(t & 31), nwords = (sh + w + 31) >> 5;
+                for (int jw = threadIdx.x; jw < nwords; jw += 256) {
+                    const unsigned bits = lbits[jw];
+                    const bool whole = jw * 32 >= sh && (jw + 1) * 32 <= sh + w;
+                    if (whole) dbits[(t >> 5) + jw] = bits;
+                    else if (bits) atomicOr(&dbits[(t >> 5) + jw], bits);
+                }
+            }
             // 16-byte stores over the part of [t, t + w) that is 16-byte aligned in the table, 4-byte stores at the ends
             const int head = (int)((4 - (t & 3)) & 3) < w ? (int)((4 - (t & 3)) & 3) : w;
             const int nq = (w - head) / 4;
@@ -1543,6 +1593,17 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
         if (partials) { partials[2 * blockIdx.x] = st; partials[2 * blockIdx.x + 1] = rn; }
         if (declared && st != rn) atomicOr(declared, 1);   // two adjacent rows share a key
     }
+}
+
+// rows stored by a gated fill = bits set in its occupancy bitmap (only ph_join_count asks)
+__global__ __launch_bounds__(256) void direct_popcount_kernel(const unsigned *__restrict__ dbits, int64_t words, int *__restrict__ count) {
+    __shared__ int part[4];
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) c += __popc(dbits[i]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(count, part[0] + part[1] + part[2] + part[3]);
 }
 
 // the general passes' initialisation when the sorted fill gave up
@@ -2137,6 +2198,7 @@ struct ph_join {
     unsigned long long drange = 0;
     int dkw = 0;
     int dcshift = 0;                // sparse direct tables: bloom.coarse bit = slot >> dcshift (occupied slot groups)
+    int64_t count_from_bits = 0;    // gated sorted fill: words of dbits whose set bits are the rows stored
     unsigned *dbits = nullptr;      // direct tables of <= 8 M slots: one occupancy bit per slot
 };
 
@@ -2230,6 +2292,17 @@ static int build_big(ph_join *j, int kw, int nparts) {
         else { if (B.sel) KERNEL<8, true><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); else KERNEL<8, false><<<GRID, THREADS, 0, ctx->stream>>>(__VA_ARGS__); }         \
     } while (0)
 
+// workgroups of the sorted fill resident per CU: its chunks are assigned statically (chunk c, c + grid, ...),
+// so a workgroup that had to wait for a free CU would start its share when the others are done — 8 per CU
+// were launched where the static LDS (20.5 KB) lets 7 in, and the kernel took twice its time
+static int sorted_fill_occupancy(int kw, bool gated) {
+    int occ = 0;
+    const void *f = kw == 4 ? (gated ? (const void *)ph::direct_sorted_fill_kernel<4, 3> : (const void *)ph::direct_sorted_fill_kernel<4, 0>)
+                            : (gated ? (const void *)ph::direct_sorted_fill_kernel<8, 3> : (const void *)ph::direct_sorted_fill_kernel<8, 0>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, f, 256, 0) != hipSuccess || occ < 1) occ = 4;
+    return std::min(occ, 8);
+}
+
 static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where, bool declared_sorted_unique) {
     ph_ctx *ctx = j->ctx;
     const int64_t n = j->build.n;
@@ -2254,7 +2327,12 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
     // occupancy bitmap for the candidate pass of inner probes: 1 MiB at most, so that it stays in L2 while
     // the slot array (32 x larger) is only read for rows that match
     int64_t dwords = 0;
-    if (range <= (8ll << 20)) {
+    const char *sfe0 = getenv("PH_JOIN_SORTED_FILL");
+    // a filtered build over keys declared sorted and unique: the gated sorted fill writes the bitmap in its one
+    // pass, so the bitmap may be larger (clustered probes stream it; 128 M slots = 16 MiB)
+    const bool gated_fill = declared_sorted_unique && where.kind != 0 && (where.kind != 3 || (reinterpret_cast<uintptr_t>(where.data) & 3) == 0) && !(sfe0 && atoi(sfe0) == 0) && n > (256 << 10) && !j->build.sel &&
+                            !j->build.key[0].validity && range <= (128ll << 20) && lo <= INT64_MAX - range - 1;
+    if (range <= (8ll << 20) || gated_fill) {
         dwords = ph::round_up(cap4, 128) / 32;   // the occupied kernel writes whole words up to cap4
         PH_CHECK(ctx->pool_alloc(dwords * 4, (void **)&j->dbits));
     }
@@ -2262,10 +2340,10 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
     // Plain shapes only (no selection, NULLs or pushed-down filter; no occupancy bitmap to derive).
     const char *sfe = getenv("PH_JOIN_SORTED_FILL");   // read per call: the test builds both ways in one process
     const bool no_sorted = sfe && atoi(sfe) == 0;
-    const bool try_sorted = !no_sorted && n > (256 << 10) && !B.sel && !B.key[0].validity && where.kind == 0 && !j->dbits &&
-                            lo <= INT64_MAX - range - 1;   // the kernel uses lo + range as the "key after the last"
+    const bool try_sorted = gated_fill || (!no_sorted && n > (256 << 10) && !B.sel && !B.key[0].validity && where.kind == 0 && !j->dbits &&
+                            lo <= INT64_MAX - range - 1);   // the kernel uses lo + range as the "key after the last"
     // (the sorted fill writes every slot itself: only the counters are cleared here)
-    ph::join_init_kernel<<<try_sorted ? 1 : ctx->cu_count * 4, 256, 0, ctx->stream>>>(try_sorted ? nullptr : j->direct, cap4, j->dbits, dwords,
+    ph::join_init_kernel<<<try_sorted && !j->dbits ? 1 : ctx->cu_count * 4, 256, 0, ctx->stream>>>(try_sorted ? nullptr : j->direct, cap4, j->dbits, dwords,
                                                                                      j->bloom.coarse, j->count_dev);
     if (n > 0) {
         const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 8);
@@ -2286,19 +2364,31 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
             // The six launches of the general passes, ~4.6 us each although they would leave at once, are not made.
             int *words = nullptr;
             PH_CHECK(ctx->deferred_words(&words));
-            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * 8);
-            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3);
-            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3);
+            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * sorted_fill_occupancy(kw, where.kind != 0));
+            if (where.kind != 0) {   // the build child's Filter rides along; the fill also writes the occupancy bitmap
+                unsigned *fill_bits = getenv("PH_GATED_NO_BITS") ? nullptr : j->dbits;
+#define PH_SF_GATED(KWV, WKV) ph::direct_sorted_fill_kernel<KWV, WKV><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3, where.data, where.lo, where.hi, fill_bits)
+                if (kw == 4) { if (where.kind == 1) PH_SF_GATED(4, 1); else if (where.kind == 2) PH_SF_GATED(4, 2); else PH_SF_GATED(4, 3); }
+                else { if (where.kind == 1) PH_SF_GATED(8, 1); else if (where.kind == 2) PH_SF_GATED(8, 2); else PH_SF_GATED(8, 3); }
+#undef PH_SF_GATED
+                PH_HIP(hipGetLastError());
+                ctx->deferred_pending = true;
+                j->count = -1;   // the rows that pass = the bitmap's set bits, counted when ph_join_count asks
+                j->count_from_bits = dwords;
+                return PH_OK;
+            }
+            if (kw == 4) ph::direct_sorted_fill_kernel<4, 0><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3, nullptr, 0, 0, nullptr);
+            else ph::direct_sorted_fill_kernel<8, 0><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3, nullptr, 0, 0, nullptr);
             PH_HIP(hipGetLastError());
             ctx->deferred_pending = true;
             j->count = n;   // every row is stored when the claim holds (count[0] == count[1] == 0 on the device: no chains)
             return PH_OK;
         }
         if (try_sorted) {
-            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * 8);
+            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * sorted_fill_occupancy(kw, false));
             PH_CHECK(ctx->pool_alloc((int64_t)gridf * 8, (void **)&partials));
-            if (kw == 4) ph::direct_sorted_fill_kernel<4><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr);
-            else ph::direct_sorted_fill_kernel<8><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr);
+            if (kw == 4) ph::direct_sorted_fill_kernel<4, 0><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr, nullptr, 0, 0, nullptr);
+            else ph::direct_sorted_fill_kernel<8, 0><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, partials, nullptr, nullptr, 0, 0, nullptr);
             ph::direct_recount_kernel<<<1, 256, 0, ctx->stream>>>(j->count_dev, partials, gridf);
             ph::direct_refill_kernel<<<ctx->cu_count * 4, 256, 0, ctx->stream>>>(j->direct, cap4, j->count_dev);
             ctx->pool_release(partials);   // stream-ordered reuse
@@ -2644,6 +2734,12 @@ extern "C" int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, 
 extern "C" int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
                                    const ph_const *where_k, const int32_t *sel, int64_t n, int64_t key_lo, int64_t key_hi,
                                    ph_join **out) {
+    return ph_join_build_where_ex(ctx, keys, nkeys, where_col, where_op, where_k, sel, n, 0, key_lo, key_hi, out);
+}
+
+extern "C" int ph_join_build_where_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
+                                      const ph_const *where_k, const int32_t *sel, int64_t n, int32_t flags, int64_t key_lo,
+                                      int64_t key_hi, ph_join **out) {
     PH_REQUIRE(where_col && where_k, "ph_join_build_where: bad arguments");
     ph::RangePred where{};
     if (!ph::lower_range_pred(where_col, where_op, where_k, &where) || where.validity) {
@@ -2651,7 +2747,8 @@ extern "C" int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkey
         return PH_EUNSUPPORTED;
     }
     if (where.kind < 0) { where.kind = 1; where.data = keys[0].data; where.lo = 1; where.hi = 0; }   // never true: an empty range over any column
-    return join_build_impl(ctx, keys, nkeys, sel, n, true, key_lo, key_hi, false, out, where);
+    return join_build_impl(ctx, keys, nkeys, sel, n, true, key_lo, key_hi, (flags & PH_JOIN_FK_PROBES) != 0, out, where,
+                           (flags & PH_JOIN_KEYS_SORTED_UNIQUE) != 0);
 }
 
 extern "C" const char *ph_join_kind(const ph_join *j) {
@@ -2661,6 +2758,16 @@ extern "C" const char *ph_join_kind(const ph_join *j) {
 extern "C" int64_t ph_join_count(const ph_join *cj) {
     ph_join *j = const_cast<ph_join *>(cj);
     if (!j) return -1;
+    if (j->count < 0 && j->direct && j->count_from_bits > 0) {
+        int *tmp = nullptr, c = 0;
+        if (j->ctx->pool_alloc(16, (void **)&tmp) != PH_OK) return -1;
+        if (hipMemsetAsync(tmp, 0, 4, j->ctx->stream) != hipSuccess) return -1;
+        ph::direct_popcount_kernel<<<j->ctx->cu_count, 256, 0, j->ctx->stream>>>(j->dbits, j->count_from_bits, tmp);
+        const int rc = j->ctx->download(&c, tmp, 4);
+        j->ctx->pool_release(tmp);
+        if (rc != PH_OK) return -1;
+        j->count = c;
+    }
     if (j->count < 0 && j->direct) {
         int c[4] = {0, 0, 0, 0};
         if (j->ctx->download(c, j->count_dev, 16) != PH_OK) return -1;

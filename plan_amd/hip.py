@@ -572,13 +572,15 @@ class Join:
                                          ctypes.byref(self.h)))
 
     @classmethod
-    def build_where(cls, ctx, keys, where_col, where_op, where_k, sel, n, key_range):
-        """ph_join_build_where (Filter -> build fused, direct tables only); None when the shape is not fused"""
+    def build_where(cls, ctx, keys, where_col, where_op, where_k, sel, n, key_range, sorted_unique=False):
+        """ph_join_build_where_ex (Filter -> build fused, direct tables only); None when the shape is not fused.
+        sorted_unique: PH_JOIN_KEYS_SORTED_UNIQUE (the gated sorted fill + occupancy bitmap)"""
         self = cls.__new__(cls)
         self.ctx, self.h = ctx, vp()
         w = where_col.col() if isinstance(where_col, DevColumn) else where_col
-        rc = lib().ph_join_build_where(ctx.h, _cols(keys), i32(len(keys)), ctypes.byref(w), i32(where_op), ctypes.byref(where_k),
-                                       sel, i64(n), i64(key_range[0]), i64(key_range[1]), ctypes.byref(self.h))
+        rc = lib().ph_join_build_where_ex(ctx.h, _cols(keys), i32(len(keys)), ctypes.byref(w), i32(where_op), ctypes.byref(where_k),
+                                          sel, i64(n), i32(PH_JOIN_KEYS_SORTED_UNIQUE if sorted_unique else 0),
+                                          i64(key_range[0]), i64(key_range[1]), ctypes.byref(self.h))
         if rc == PH_EUNSUPPORTED:
             return None
         check(rc)

@@ -138,13 +138,25 @@ class Q3Pipeline:
         # WHOLE orders table (its primary key in storage order: one streaming fill of a direct table,
         # independent of the mark), and the lineitem probe tests the flag of the orders row it finds.
         residual = None
+        gated = False   # the flags were consumed by join 2's build (no residual test in the probe)
         if N == 1 and self.o_key_range is not None and j1.kind == "direct" and not getattr(self, "no_residual", False):
             flags = j1.probe_mark_where([self.o_cust], self.o_date, hip.PH_LT, hip.const(hip.PH_DATE, i=date), self.no)
             if flags is not None:
                 frees.append(flags)
                 stage("orders_filter_probe", t0)
                 t0 = tic()
-                j2 = hip.Join(ctx, [self.o_key], None, self.no, key_range=self.o_key_range, sorted_unique=self.o_key_sorted_unique)
+                j2 = None
+                if self.o_key_sorted_unique and not getattr(self, "no_gated_fill", False):
+                    # the flags ride along in the verified sorted fill: only qualifying orders get a slot, and the
+                    # fill writes the occupancy bitmap the lineitem probe tests before it touches the slot array
+                    j2 = hip.Join.build_where(ctx, [self.o_key], _raw(hip.PH_CODE8, flags), hip.PH_EQ, hip.const(hip.PH_I32, i=1),
+                                              None, self.no, self.o_key_range, sorted_unique=True)
+                    gated = j2 is not None and j2.kind == "direct"
+                    if j2 is not None and not gated:
+                        j2.free()
+                        j2 = None
+                if j2 is None:
+                    j2 = hip.Join(ctx, [self.o_key], None, self.no, key_range=self.o_key_range, sorted_unique=self.o_key_sorted_unique)
                 if j2.kind == "direct":
                     residual = flags
                     b_date, b_prio = self.o_date.col(), self.o_prio.col()   # addressed by orders row id
@@ -199,7 +211,7 @@ class Q3Pipeline:
             p_key, p_ext, p_disc = self.l_key, self.l_ext, self.l_disc
             if self.probe_events:
                 self.probe_events[0].record()
-            if residual is not None:
+            if residual is not None and not gated:
                 fused2 = j2.probe_inner_residual([p_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date), residual,
                                                  None, self.nl, self.nl)
             else:

@@ -713,6 +713,59 @@ def test_join_keys_declared_sorted_unique(ctx):
     dk.free(); dp.free()
 
 
+def test_join_build_where_sorted_unique_gated_fill(ctx):
+    """ph_join_build_where_ex with PH_JOIN_KEYS_SORTED_UNIQUE: the Filter rides along in the sorted fill,
+    which also writes the occupancy bitmap (here 9 M slots: above the general passes' bitmap limit). Pairs,
+    lookups and the row count equal ph_filter_select + ph_join_build_range; int32 and int64 keys; a gate
+    nothing passes; a false claim is the deferred PH_ECONSTRAINT."""
+    rng = np.random.default_rng(93)
+    n = 1_300_000
+    for dt, typ in ((np.int64, hip.PH_I64), (np.int32, hip.PH_I32)):
+        keys = (np.sort(rng.choice(9_000_000, n, replace=False)) + 7).astype(dt)
+        rngk = (7, 9_000_006)
+        flag = (rng.random(n) < 0.1).astype(np.uint8)
+        flag[:3] = 1; flag[-3:] = 1                                    # first and last tile edges
+        p = np.concatenate([rng.integers(0, 9_000_100, 700_000), keys[rng.integers(0, n, 100_000)]]).astype(dt)
+        p.sort()                                                        # clustered probes, like lineitem by order key
+        ship = rng.integers(0, 100, len(p)).astype(np.int32)
+        dk, dfl, dp, dsh = (hip.DevColumn(ctx, typ, keys), hip.DevColumn(ctx, hip.PH_CODE8, flag), hip.DevColumn(ctx, typ, p),
+                            hip.DevColumn(ctx, hip.PH_I32, ship))
+        for code in (1, 5):                                             # 5: nothing passes
+            jw = hip.Join.build_where(ctx, [dk], dfl, hip.PH_EQ, hip.const(hip.PH_I32, i=code), None, n, rngk, sorted_unique=True)
+            assert jw is not None and jw.kind == "direct"
+            fs, fn = hip.filter_select(ctx, dfl, n, hip.PH_EQ, hip.const(hip.PH_I32, i=code))
+            jf = hip.Join(ctx, [dk], fs, fn, key_range=rngk)
+            assert jw.count() == jf.count() == int((flag == code).sum())
+            mw, pw, bw = jw.probe_inner([dp], None, len(p), len(p))
+            mf, pf, bf = jf.probe_inner([dp], None, len(p), len(p))
+            assert mw == mf == int(np.isin(p, keys[flag == code]).sum())
+            assert np.array_equal(ctx.download(pw, np.int32, mw), ctx.download(pf, np.int32, mf))
+            assert np.array_equal(ctx.download(bw, np.int32, mw), ctx.download(bf, np.int32, mf))
+            fw = jw.probe_inner_where([dp], dsh, hip.PH_GT, hip.const(hip.PH_I32, i=40), None, len(p), len(p))
+            assert fw is not None
+            want = np.isin(p, keys[flag == code]) & (ship > 40)
+            assert fw[0] == int(want.sum()) and np.array_equal(ctx.download(fw[1], np.int32, fw[0]), np.nonzero(want)[0])
+            assert np.array_equal(keys[ctx.download(fw[2], np.int32, fw[0])], p[want])
+            lw = ctx.download(jw.lookup([dp], None, len(p)), np.int32, len(p))
+            lf = ctx.download(jf.lookup([dp], None, len(p)), np.int32, len(p))
+            assert np.array_equal(lw, lf)
+            ctx.check_deferred()
+            for b in (pw, bw, pf, bf, fs, fw[1], fw[2]):
+                ctx.free(b)
+            jw.free(); jf.free()
+        bad = keys.copy()
+        bad[650_000], bad[650_001] = keys[650_001], keys[650_000]
+        dbad = hip.DevColumn(ctx, typ, bad)
+        jb = hip.Join.build_where(ctx, [dbad], dfl, hip.PH_EQ, hip.const(hip.PH_I32, i=1), None, n, rngk, sorted_unique=True)
+        rows = jb.lookup([dp], None, len(p))
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(rows, np.int32, len(p))
+        assert e.value.code == hip.PH_ECONSTRAINT
+        jb.free()
+        for c in (dk, dfl, dp, dsh, dbad):
+            c.free()
+
+
 def test_join_build_where_equals_filter_then_build(ctx):
     """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
     row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
