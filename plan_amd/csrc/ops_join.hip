@@ -1459,6 +1459,7 @@ __global__ __launch_bounds__(DT) void direct_scatter_kernel(DirectSrc S, int64_t
 // which otherwise leave at once, run instead.
 constexpr int SF_ROWS = 512;     // rows per step of a 256-thread workgroup (eight workgroups per CU overlap each other's latencies)
 constexpr int SF_TILE = 4096;    // slots composed in LDS at a time
+constexpr int SF_GATED_ROWS = 2048;   // rows per step of the gated form
 
 // GATED (declared sorted-unique keys only): the build child's Filter rides along — rows whose wdata value is
 // outside [wlo, whi] keep their slot empty — and the fill also writes the occupancy bitmap the candidate pass
@@ -1472,41 +1473,49 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
                                                                 int *__restrict__ declared, const void *__restrict__ wdata,
                                                                 long long wlo, long long whi, unsigned *__restrict__ dbits) {
     constexpr bool GATED = WK != 0;
+    // the gated form has no slot image in LDS: bigger chunks (more key bytes in flight per workgroup; with 512 rows
+    // it moved 135 MB in 62 us) and a bitmap tile that spans a chunk of 4-slots-per-row keys
+    constexpr int ROWS = GATED ? SF_GATED_ROWS : SF_ROWS, TILE = GATED ? 16384 : SF_TILE;
     // declared != NULL: the caller stated (column statistics) that the keys are sorted and unique. The
     // kernel still verifies both, but a violation becomes a deferred error of the ctx (*declared) instead of
     // a fallback: none of the general passes is launched behind this kernel.
-    __shared__ int tile[SF_TILE];
-    __shared__ long long kk[SF_ROWS + 2];   // key[r0 - 1] (the run test of the first row), the chunk's keys, key[r1]
+    // GATED: only the occupied slots are written (straight to the table) — the bitmap is authoritative and no
+    // probe reads a slot whose bit is clear, so the 4 x range bytes of "-1" are never written
+    __shared__ int tile[WK != 0 ? 1 : SF_TILE];
+    __shared__ long long kk[ROWS + 2];   // key[r0 - 1] (the run test of the first row), the chunk's keys, key[r1]
     long long *keys = kk + 1;
     // the gate column's values of the chunk's rows, RAW as loaded (bytes travel four to a dword): any
     // arithmetic on a prefetched value — a compare, even the widening of a byte — is scheduled next to its
     // load and waits there for the whole prefetch (the kernel took 150 us instead of 70)
     using GT = typename std::conditional<WK == 2, long long, int>::type;
-    constexpr int GN = WK == 3 ? 1 : SF_ROWS / 256;
-    __shared__ GT graw[WK == 0 ? 1 : WK == 3 ? SF_ROWS / 4 : SF_ROWS];
+    constexpr int GN = WK == 3 ? (ROWS / 4 + 255) / 256 : ROWS / 256;
+    __shared__ GT graw[WK == 0 ? 1 : WK == 3 ? ROWS / 4 : ROWS];
     auto gate_pass = [&](int e) {
         const long long v = WK == 3 ? (long long)reinterpret_cast<const unsigned char *>(graw)[e] : (long long)graw[WK == 3 ? 0 : e];
         return v >= wlo && v <= whi;
     };
-    __shared__ unsigned lbits[GATED ? SF_TILE / 32 + 1 : 1];   // occupancy words of the tile being composed
+    __shared__ unsigned lbits[GATED ? TILE / 32 + 1 : 1];   // occupancy words of the tile being composed
     __shared__ int s_bad;
     int stored = 0, runs = 0;
-    const int64_t nchunks = (n + SF_ROWS - 1) / SF_ROWS;
+    const int64_t nchunks = (n + ROWS - 1) / ROWS;
     const long long beyond = (long long)(lo + (long long)range);   // above every valid key: the "next key" of the last row
     // software pipeline: the keys of the NEXT chunk are in flight while this one is composed
-    constexpr int KR = (SF_ROWS + 2 + 255) / 256;
+    constexpr int KR = (ROWS + 2 + 255) / 256;
     long long kreg[KR];
     GT greg[GN];
     auto fetch = [&](int64_t c) {
-        const int64_t r0 = c * SF_ROWS;
+        const int64_t r0 = c * ROWS;
 #pragma unroll
         for (int q = 0; q < KR; q++) {
             const int64_t i = r0 - 1 + q * 256 + threadIdx.x;
-            kreg[q] = (c < nchunks && i >= 0 && i < n && q * 256 + (int)threadIdx.x < SF_ROWS + 2) ? (long long)load_kw<KW>(kcol, i) : beyond;
+            kreg[q] = (c < nchunks && i >= 0 && i < n && q * 256 + (int)threadIdx.x < ROWS + 2) ? (long long)load_kw<KW>(kcol, i) : beyond;
         }
         if (WK == 3) {   // 512 flag bytes = 128 aligned dwords (the host checked the column's alignment)
-            const int64_t d = r0 / 4 + threadIdx.x;
-            greg[0] = (c < nchunks && threadIdx.x < SF_ROWS / 4 && d * 4 < n) ? ((const int *)wdata)[d] : 0;
+#pragma unroll
+            for (int q = 0; q < GN; q++) {
+                const int64_t d = r0 / 4 + q * 256 + threadIdx.x;
+                greg[q] = (c < nchunks && q * 256 + (int)threadIdx.x < ROWS / 4 && d * 4 < n) ? ((const int *)wdata)[d] : 0;
+            }
         } else if (GATED) {
 #pragma unroll
             for (int q = 0; q < GN; q++) {
@@ -1517,20 +1526,65 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
     };
     fetch(blockIdx.x);
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int64_t r0 = c * SF_ROWS, r1 = r0 + SF_ROWS < n ? r0 + SF_ROWS : n;
+        const int64_t r0 = c * ROWS, r1 = r0 + ROWS < n ? r0 + ROWS : n;
         const int m = (int)(r1 - r0);
         __syncthreads();   // the previous chunk's readers are done
         if (threadIdx.x == 0) s_bad = 0;
 #pragma unroll
         for (int q = 0; q < KR; q++)
-            if (q * 256 + (int)threadIdx.x < SF_ROWS + 2) kk[q * 256 + threadIdx.x] = kreg[q];
-        if (WK == 3) { if (threadIdx.x < SF_ROWS / 4) graw[threadIdx.x] = greg[0]; }
+            if (q * 256 + (int)threadIdx.x < ROWS + 2) kk[q * 256 + threadIdx.x] = kreg[q];
+        if (WK == 3) {
+#pragma unroll
+            for (int q = 0; q < GN; q++) if (q * 256 + (int)threadIdx.x < ROWS / 4) graw[q * 256 + threadIdx.x] = greg[q];
+        }
         else if (GATED) {
 #pragma unroll
             for (int q = 0; q < GN; q++) graw[q * 256 + threadIdx.x] = greg[q];
         }
+        if (GATED) for (int e = threadIdx.x; e <= TILE / 32; e += 256) lbits[e] = 0;
         fetch(c + gridDim.x);
         __syncthreads();
+        if (GATED) {
+            // Gated form: three barriers per chunk instead of seven. Rows are verified while they are stored
+            // (a chunk that breaks the claim raises the deferred error; what it wrote stays inside the table
+            // and the table is void anyway), only occupied slots are written, straight to the table, and the
+            // occupancy words are composed in LDS beside them.
+            const int64_t s0 = c == 0 ? 0 : keys[0] - lo;
+            const int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+            bool bad = false;
+            for (int64_t t = s0; t < s1 || t == s0; t += TILE) {
+                const int w = (int)(s1 - t < TILE ? s1 - t : TILE);
+                if (t != s0) {
+                    __syncthreads();   // the previous tile's words have been read
+                    for (int e = threadIdx.x; e <= TILE / 32; e += 256) lbits[e] = 0;
+                    __syncthreads();
+                }
+                for (int e = threadIdx.x; e < m; e += 256) {
+                    const long long k = keys[e];
+                    if (t == s0) {
+                        bad = bad || (unsigned long long)(k - lo) >= range || k > keys[e + 1];
+                        runs += (r0 + e == 0) || keys[e - 1] != k;
+                        stored++;
+                    }
+                    const int64_t off = k - lo - t;
+                    if (off >= 0 && off < w && gate_pass(e)) {
+                        direct[t + off] = (int32_t)(r0 + e);
+                        const int b = (int)(t & 31) + (int)off;
+                        atomicOr(&lbits[b >> 5], 1u << (b & 31));
+                    }
+                }
+                __syncthreads();
+                const int sh = (int)(t & 31), nwords = w > 0 ? (sh + w + 31) >> 5 : 0;
+                for (int jw = threadIdx.x; jw < nwords; jw += 256) {
+                    const unsigned bits = lbits[jw];
+                    const bool whole = jw * 32 >= sh && (jw + 1) * 32 <= sh + w;
+                    if (whole) dbits[(t >> 5) + jw] = bits;
+                    else if (bits) atomicOr(&dbits[(t >> 5) + jw], bits);
+                }
+            }
+            if (bad) { atomicOr(count + 3, 1); if (declared) atomicOr(declared, 1); }
+            continue;
+        }
         bool bad = false;
         for (int e = threadIdx.x; e < m; e += 256) {
             const unsigned long long off = (unsigned long long)(keys[e] - lo);
@@ -1550,27 +1604,12 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
             const int w = (int)(s1 - t < SF_TILE ? s1 - t : SF_TILE);
             __syncthreads();
             for (int e = threadIdx.x; e < w; e += 256) tile[e] = -1;
-            if (GATED && threadIdx.x <= SF_TILE / 32) lbits[threadIdx.x] = 0;
             __syncthreads();
             for (int e = threadIdx.x; e < m; e += 256) {
                 const int64_t off = keys[e] - lo - t;
-                if (off >= 0 && off < w && (!GATED || gate_pass(e))) {
-                    tile[off] = (int32_t)(r0 + e);   // equal keys: any of them; the chains are linked afterwards
-                    if (GATED) { const int b = (int)(t & 31) + (int)off; atomicOr(&lbits[b >> 5], 1u << (b & 31)); }
-                }
+                if (off >= 0 && off < w) tile[off] = (int32_t)(r0 + e);   // equal keys: any of them; the chains are linked afterwards
             }
             __syncthreads();
-            if (GATED && dbits) {
-                // the tile's occupancy words were composed beside the slots (one LDS OR per stored row — a
-                // ballot pass over the 4096 slots was more instructions than the rest of the tile's work)
-                const int sh = (int)(t & 31), nwords = (sh + w + 31) >> 5;
-                for (int jw = threadIdx.x; jw < nwords; jw += 256) {
-                    const unsigned bits = lbits[jw];
-                    const bool whole = jw * 32 >= sh && (jw + 1) * 32 <= sh + w;
-                    if (whole) dbits[(t >> 5) + jw] = bits;
-                    else if (bits) atomicOr(&dbits[(t >> 5) + jw], bits);
-                }
-            }
             // 16-byte stores over the part of [t, t + w) that is 16-byte aligned in the table, 4-byte stores at the ends
             const int head = (int)((4 - (t & 3)) & 3) < w ? (int)((4 - (t & 3)) & 3) : w;
             const int nq = (w - head) / 4;
@@ -1727,7 +1766,10 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
                                                            unsigned long long range, const int32_t *__restrict__ direct,
                                                            const int32_t *__restrict__ next, const int32_t *__restrict__ bsel,
                                                            const int *__restrict__ bcount, int32_t nbuild, int32_t *__restrict__ out,
-                                                           uint8_t *__restrict__ found, int *__restrict__ stats) {
+                                                           uint8_t *__restrict__ found, int *__restrict__ stats,
+                                                           const unsigned *__restrict__ abits) {
+    // abits: the table's occupancy bitmap is AUTHORITATIVE (gated sorted fill: only occupied slots were ever
+    // written, the rest of the slot array is uninitialised memory) — a slot is read only when its bit is set
     const bool dups = bcount[0] != bcount[1];   // rows stored vs slots occupied
     int misses = 0, multi = 0;
     for (int64_t base = (int64_t)blockIdx.x * 256 * DU; base < n; base += (int64_t)gridDim.x * 256 * DU) {
@@ -1755,6 +1797,7 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
         for (int u = 0; u < DU; u++) {
             const unsigned long long off = (unsigned long long)(k[u] - lo);
             ok[u] = ok[u] && off < range;
+            if (abits) ok[u] = ok[u] && ((abits[(ok[u] ? off : 0) >> 5] >> (off & 31)) & 1u);
             const int32_t d = direct[ok[u] ? off : 0];
             b[u] = ok[u] && (unsigned)d < (unsigned)nbuild ? d : -1;   // anything but a build row reads as empty
             c[u] = b[u] >= 0 ? 1 : 0;
@@ -2199,6 +2242,7 @@ struct ph_join {
     int dkw = 0;
     int dcshift = 0;                // sparse direct tables: bloom.coarse bit = slot >> dcshift (occupied slot groups)
     int64_t count_from_bits = 0;    // gated sorted fill: words of dbits whose set bits are the rows stored
+    bool bits_authoritative = false;   // ... and only the occupied slots of `direct` were ever written: every probe tests dbits first
     unsigned *dbits = nullptr;      // direct tables of <= 8 M slots: one occupancy bit per slot
 };
 
@@ -2364,9 +2408,11 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
             // The six launches of the general passes, ~4.6 us each although they would leave at once, are not made.
             int *words = nullptr;
             PH_CHECK(ctx->deferred_words(&words));
-            const int gridf = (int)std::min<int64_t>((n + ph::SF_ROWS - 1) / ph::SF_ROWS, (int64_t)ctx->cu_count * sorted_fill_occupancy(kw, where.kind != 0));
+            const int frows = where.kind != 0 ? ph::SF_GATED_ROWS : ph::SF_ROWS;
+            const int gridf = (int)std::min<int64_t>((n + frows - 1) / frows, (int64_t)ctx->cu_count * sorted_fill_occupancy(kw, where.kind != 0));
             if (where.kind != 0) {   // the build child's Filter rides along; the fill also writes the occupancy bitmap
-                unsigned *fill_bits = getenv("PH_GATED_NO_BITS") ? nullptr : j->dbits;
+                unsigned *fill_bits = j->dbits;
+                j->bits_authoritative = true;
 #define PH_SF_GATED(KWV, WKV) ph::direct_sorted_fill_kernel<KWV, WKV><<<gridf, 256, 0, ctx->stream>>>(B.key[0].data, n, (long long)lo, j->drange, cap4, j->direct, j->count_dev, nullptr, words + 3, where.data, where.lo, where.hi, fill_bits)
                 if (kw == 4) { if (where.kind == 1) PH_SF_GATED(4, 1); else if (where.kind == 2) PH_SF_GATED(4, 2); else PH_SF_GATED(4, 3); }
                 else { if (where.kind == 1) PH_SF_GATED(8, 1); else if (where.kind == 2) PH_SF_GATED(8, 2); else PH_SF_GATED(8, 3); }
@@ -2418,7 +2464,7 @@ template <int MODE>
 static void launch_direct_probe(ph_join *j, const ph::JoinSide &P, int64_t n, int grid, int32_t *out, uint8_t *found, int *stats) {
     hipStream_t st = j->ctx->stream;
     const int32_t *bsel = j->build.sel;
-#define PH_DP_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, bsel, j->count_dev, (int32_t)j->build.n, out, found, stats
+#define PH_DP_ARGS P.key[0].data, P.key[0].validity, P.sel, n, (long long)j->dlo, j->drange, j->direct, j->next, bsel, j->count_dev, (int32_t)j->build.n, out, found, stats, j->bits_authoritative ? j->dbits : nullptr
 #define PH_DP_LAUNCH(KWV)                                                                                                      \
     do {                                                                                                                       \
         if (P.sel && bsel) ph::direct_probe_kernel<KWV, true, true, MODE><<<grid, 256, 0, st>>>(PH_DP_ARGS);                   \
@@ -2441,8 +2487,8 @@ static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int
     const bool vec = !P.sel && !P.key[0].validity && aligned(P.key[0].data) && (WK == 0 || aligned(w.data));
     // the LDS bitmap of occupied slot groups already rejects most probes: a second filter stage (one more
     // dependent L2 read per survivor) made the kernel slower (Q9: 119 -> 151 us)
-    if (j->bloom.coarse && nb >= 64) D.dbits = nullptr;
-    if (vec && j->bloom.coarse && nb >= 64) {
+    if (j->bloom.coarse && nb >= 64 && !j->bits_authoritative) D.dbits = nullptr;
+    if (vec && j->bloom.coarse && nb >= 64 && !j->bits_authoritative) {
         const size_t lds = (size_t)ph::CO_WORDS * 4;
         const int grid = std::min((nb + 15) / 16, j->ctx->cu_count);   // one block per wave and step
         (void)hipFuncSetAttribute((const void *)ph::direct_cand_coarse_vec_kernel<KW, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2450,7 +2496,7 @@ static void launch_direct_cand(ph_join *j, const ph::JoinSide &P, int64_t n, int
         return;
     }
     if (vec) { ph::direct_cand_vec_kernel<KW, WK><<<nb, 256, 0, st>>>(D); return; }
-    if (j->bloom.coarse && nb >= 64) {   // sparse table: occupied-group bitmap in LDS, one 1024-thread workgroup per CU
+    if (j->bloom.coarse && nb >= 64 && !j->bits_authoritative) {   // sparse table: occupied-group bitmap in LDS, one 1024-thread workgroup per CU
         const size_t lds = (size_t)ph::CO_WORDS * 4 + 4 * ph::JP_ROUNDS * 4 * sizeof(int) + 4 * 4 * sizeof(int);
         const int grid = std::min((nb + 3) / 4, j->ctx->cu_count);
         if (P.sel) {
