@@ -41,6 +41,7 @@ class Q3Pipeline:
         self.o_key_range = (int(O["o_orderkey"].min()), int(O["o_orderkey"].max())) if self.no else None
         # column statistics, computed once at load like the range: a primary key in storage order
         self.o_key_sorted_unique = bool(self.no > 1 and np.all(np.diff(O["o_orderkey"]) > 0))
+        self.c_key_sorted_unique = bool(self.nc > 1 and np.all(np.diff(C["c_custkey"]) > 0))
         self.o_cust = D(ctx, hip.PH_I32, O["o_custkey"])
         self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
         self.o_prio = D(ctx, hip.PH_I32, O["o_shippriority"])
@@ -79,9 +80,9 @@ class Q3Pipeline:
             try:
                 return self._run(limit, want_groups)
             except hip.PlanHipError as e:
-                if e.code != hip.PH_ECONSTRAINT or not (self.o_key_sorted_unique or self.l_key_sorted):
+                if e.code != hip.PH_ECONSTRAINT or not (self.o_key_sorted_unique or self.l_key_sorted or self.c_key_sorted_unique):
                     raise
-                self.o_key_sorted_unique = self.l_key_sorted = False   # a statistic did not hold: the general forms
+                self.o_key_sorted_unique = self.l_key_sorted = self.c_key_sorted_unique = False   # a statistic did not hold: the general forms
             return self._run(limit, want_groups)
         finally:
             self.ctx.set_deferred_errors(False)
@@ -106,7 +107,8 @@ class Q3Pipeline:
             # primary key, so the table is a direct table sized by the key range and the number of
             # customers that pass never has to reach the host (no selection vector, no read-back)
             j1 = hip.Join.build_where(ctx, [self.c_key], self.c_seg, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code),
-                                      None, self.nc, self.c_key_range)
+                                      None, self.nc, self.c_key_range,
+                                      sorted_unique=self.c_key_sorted_unique and not getattr(self, "no_gated_fill", False))
             if j1 is not None:
                 cn = j1.count() if self.time_stages else 0   # reporting only
         if j1 is not None:
