@@ -366,11 +366,11 @@ def bench_q3(h, sf, steps, warmup, scaling):
         "roofline": roofline(probe_bytes / (probe_ms * 1e-3) / 1e9,
                              traffic=pmc_traffic_any("q3", ("direct_cand_vec_kernel<8", "join_cand_vec_kernel<8", "join_cand_fast_kernel<8")) if (h.world == 1 and nrows == 59986052) else None,
                              traffic_note="PMC traffic of the lineitem candidate kernel (direct_cand_vec_kernel<8,1>: l_shipdate + l_orderkey streamed, "
-                                          "the orders direct table read in key order, the residual flag of the row found; ~186 of ~205 us); "
+                                          "the occupancy bitmap of the gated orders table, its slots only for matching rows; ~138 of ~155 us); "
                                           "traffic_stage_kernels has the stage's other kernel",
                              traffic_stage_kernels=({k: pmc_traffic(("q3", k)) for k in ("direct_emit_kernel",)}
                                                     if (h.world == 1 and nrows == 59986052) else None),
-                             kernel="direct_cand_vec_kernel+scan+direct_emit_kernel (lineitem Filter+probe stage, residual flag on the orders row)"
+                             kernel="direct_cand_vec_kernel+scan+direct_emit_kernel (lineitem Filter+probe stage against the gated orders table)"
                                     if h.world == 1 else "join_cand_vec_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
                              avg_launch_ms=probe_ms, algorithmic_bytes_per_launch=probe_bytes,
                              timing="HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
