@@ -288,7 +288,7 @@ def bench_scan(h, query, sf, steps, warmup, scaling, L=None, table=None, with_ex
 
 # ---------------------------------------------------------------------------------- Q3
 
-def bench_q3(h, sf, steps, warmup, scaling):
+def bench_q3(h, sf, steps, warmup, scaling, partitionwise=False):
     """Q3: customer |x| orders |x| lineitem hash joins + 3-column group-by from the operator-granular
     kernels; N > 1: join sides hash-partitioned by order key and exchanged (plan_amd/pipelines.py).
     A step = one whole Q3, tables resident, top-10 rows on the host at the end."""
@@ -303,6 +303,10 @@ def bench_q3(h, sf, steps, warmup, scaling):
     C = tpchgen.customer(sf_total, c0, c1 - c0)
     nrows, n_o, n_c = len(L["l_orderkey"]), len(Od["o_orderkey"]), len(C["c_custkey"])
     pipe = pipelines.Q3Pipeline(h.ctx, L, Od, C)
+    # N > 1: the hash-partitioned exchange plan (BASELINE.json config 4) unless the caller asks for the
+    # partition-wise join that the shards' co-partitioning by order key allows (reported beside it)
+    pipe.allow_partitionwise = partitionwise
+    pw = h.world > 1 and partitionwise and pipe.copartitioned
     pipe.time_stages = False   # the measured steps run without a host sync per stage
     for _ in range(warmup):
         r = pipe.run()
@@ -355,7 +359,10 @@ def bench_q3(h, sf, steps, warmup, scaling):
             "workload": f"TPC-H Q3 over customer/orders/lineitem, {nrows} lineitem rows on rank 0, {total_rows} in total "
                         f"({'SF%d per GPU' % sf if scaling == 'weak' else 'SF%d split %d ways' % (sf, h.world)}), tables resident in HBM",
             "groups_rank0": r["ngroups"], "join_rows_rank0": pairs,
-            "parallelism": (f"customer keys broadcast (ph_comm_allgather_rows), orders and lineitem rows hash-partitioned by order key "
+            "parallelism": ("partition-wise join: the ranks' order-key ranges are disjoint and hold their own lineitem rows (statistic "
+                            "all-gathered at load), so only the customer keys are broadcast (ph_comm_allgather_rows) and the top-10 "
+                            f"candidates merged; x{h.world} ({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if pw else
+                           (f"customer keys broadcast (ph_comm_allgather_rows), orders and lineitem rows hash-partitioned by order key "
                             f"x{h.world} (ph_partition_dev) and exchanged with ph_comm_exchange_columns "
                             f"({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if h.world > 1 else "single GPU",
             "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk not in ("probe_rows", "exchange_bytes_sent")},
@@ -371,7 +378,7 @@ def bench_q3(h, sf, steps, warmup, scaling):
                              traffic_stage_kernels=({k: pmc_traffic(("q3", k)) for k in ("direct_emit_kernel",)}
                                                     if (h.world == 1 and nrows == 59986052) else None),
                              kernel="direct_cand_vec_kernel+scan+direct_emit_kernel (lineitem Filter+probe stage against the gated orders table)"
-                                    if h.world == 1 else "join_cand_vec_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
+                                    if (h.world == 1 or pw) else "join_cand_vec_kernel+join_chain_fast_kernel+scan+join_emit_kernel (lineitem Filter+probe stage)",
                              avg_launch_ms=probe_ms, algorithmic_bytes_per_launch=probe_bytes,
                              timing="HIP events on the launch stream around the stage" if fused and probe_dev_ms > 0 else "host clock around the stage",
                              host_timed_stage_ms=host_probe_ms,
@@ -602,6 +609,8 @@ def main():
         del L
         # BASELINE.json config 4: Q3 at SF`--sf`, hash-partitioned across the N GPUs (strong scaling)
         attempt("q3_partitioned", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "strong")))
+        # the same database and query as a partition-wise join (the shards are co-partitioned by order key)
+        attempt("q3_partitionwise", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "strong", partitionwise=True)))
         # BASELINE.json config 5: Q9 at SF`--sf`, multi-stage partitioned build/probe across the N GPUs
         attempt("q9_partitioned", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong")))
     elif rank0 and world == 1 and not args.no_cpu_baseline and L is not None:

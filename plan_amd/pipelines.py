@@ -54,6 +54,22 @@ class Q3Pipeline:
         self.cols = [self.c_key, self.c_seg, self.o_key, self.o_cust, self.o_date, self.o_prio,
                      self.l_key, self.l_ext, self.l_disc, self.l_ship]
         self.revenue_prog = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]
+        # Table statistic of a sharded database (one all-gather of four numbers per rank at load): orders and
+        # lineitem are CO-PARTITIONED by order key when the ranks' o_orderkey ranges are pairwise disjoint and
+        # every rank's l_orderkey values lie inside its own range (TPC-H tables split by row ranges are).
+        # Then lineitem JOIN orders and the group-by on l_orderkey are rank-local — a partition-wise join:
+        # only the customer keys (the small build side) cross the links, and the top-k candidates at the end.
+        self.copartitioned = False
+        self.allow_partitionwise = True   # False: always the hash-partitioned exchange plan
+        if dist.world() > 1:
+            l_lo = int(L["l_orderkey"].min()) if self.nl else 0
+            l_hi = int(L["l_orderkey"].max()) if self.nl else -1
+            o_lo, o_hi = self.o_key_range if self.o_key_range is not None else (0, -1)
+            rec = dist.allgather_records(ctx, np.array([[o_lo, o_hi, l_lo, l_hi]], dtype=np.int64))
+            ranges = sorted((int(a), int(b)) for a, b, _, _ in rec if b >= a)
+            disjoint = all(ranges[i][1] < ranges[i + 1][0] for i in range(len(ranges) - 1))
+            inside = all(int(d) < int(c) or (int(a) <= int(c) and int(d) <= int(b)) for a, b, c, d in rec)
+            self.copartitioned = bool(disjoint and inside)
 
     def free(self):
         for c in self.cols:
@@ -90,6 +106,9 @@ class Q3Pipeline:
     def _run(self, limit, want_groups):
         ctx, date = self.ctx, self.date
         N = dist.world()
+        W = N   # ranks the customer keys are gathered over
+        if N > 1 and self.copartitioned and self.allow_partitionwise:
+            N = 1   # partition-wise join: everything behind the customer build is this rank's own (see __init__)
         t = {}
         frees = []
         tic = time.perf_counter
@@ -102,7 +121,7 @@ class Q3Pipeline:
         # ---- customer filter, build side of join 1
         t0 = tic()
         j1 = None
-        if N == 1 and self.c_key_range is not None:
+        if W == 1 and self.c_key_range is not None:
             # Filter(c_mktsegment = ..) under the build child, fused into the build: c_custkey is a dense
             # primary key, so the table is a direct table sized by the key range and the number of
             # customers that pass never has to reach the host (no selection vector, no read-back)
@@ -113,7 +132,7 @@ class Q3Pipeline:
                 cn = j1.count() if self.time_stages else 0   # reporting only
         if j1 is not None:
             pass
-        elif N == 1:
+        elif W == 1:
             cs, cn = hip.filter_select(ctx, self.c_seg, self.nc, hip.PH_EQ, hip.const(hip.PH_I32, i=self.seg_code))
             frees.append(cs)
             # build on the gathered keys (no selection inside the table: one dependent read less per

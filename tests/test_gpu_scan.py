@@ -184,7 +184,7 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
         return ({k: v[l0:l1] for k, v in L.items()}, {k: v[o0:o1] for k, v in Od.items()},
                 {k: v[c0:c1] for k, v in C.items()})
     grp = pd.ThreadGroup(N)
-    results, errors = [None] * N, []
+    results, local, errors = [None] * N, [None] * N, []
 
     def run(r):
         try:
@@ -193,7 +193,11 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
             c = hip.Ctx(0)
             Ls, Os, Cs = shard(r)
             p = pipelines.Q3Pipeline(c, Ls, Os, Cs)
+            assert p.copartitioned                      # the statistic the partition-wise plan rests on
+            p.allow_partitionwise = False               # the hash-partitioned exchange plan
             results[r] = p.run(want_groups=True)
+            p.allow_partitionwise = True                # the partition-wise join over the same shards
+            local[r] = p.run(want_groups=True)
             p.free()
             c.close()
         except Exception as e:   # noqa: BLE001 - surface any rank's failure in the main thread
@@ -214,6 +218,11 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
     golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
     assert pipelines.q3_text(results[0]["top"]) == golden == pipelines.q3_text(results[1]["top"])
     assert results[0]["timings"]["exchange_bytes_sent"] > 0
+    # partition-wise: the same groups in all (each rank keeps the orders of its own key range), the same
+    # top 10 on every rank, and no row exchange
+    assert set(local[0]["groups"]) | set(local[1]["groups"]) == want and not (set(local[0]["groups"]) & set(local[1]["groups"]))
+    assert pipelines.q3_text(local[0]["top"]) == golden == pipelines.q3_text(local[1]["top"])
+    assert "exchange_bytes_sent" not in local[0]["timings"]
 
 
 def test_q9_pipeline_sf1_matches_reference_golden(ctx, sf1):
