@@ -76,6 +76,14 @@ struct ph_ctx {
     // caller memory makes the runtime pin/unpin those pages on every call (milliseconds when the
     // caller's buffers come and go, as numpy / Go-heap buffers do).
     void *mailbox = nullptr;  // 64 KiB pinned, for counts / flags / small results
+    // Small results reach the host WITHOUT a copy command and a stream synchronisation: the mailbox is mapped
+    // into the device's address space (coherent host memory), a one-workgroup kernel stores the bytes there and
+    // then a sequence number, and the host polls that word (publish(); ctx.hip).
+    void *mailbox_dev = nullptr;          // device address of the mailbox
+    unsigned long long publish_seq = 0;   // last sequence number handed to a publish kernel
+    int64_t *count_slots_dev = nullptr;   // device address of count_slots
+    unsigned long long count_seq_issued = 0;
+    int publish(const void *dev, int64_t bytes, bool with_deferred);   // bytes <= 64 KiB -> mailbox; waits for it
     // single-pass scan (ops_select.hip): tile states + ticket counter, reused across calls by epoch
     void *scan_state = nullptr;
     int64_t scan_tiles = 0;

@@ -79,11 +79,73 @@ int ph_ctx::finish_deferred() {
     return PH_ECONSTRAINT;
 }
 
+// ---- mailbox publish: a kernel stores a small result into mapped host memory, the host polls a sequence word
+namespace ph {
+__global__ __launch_bounds__(256) void publish_kernel(const unsigned char *__restrict__ src, int64_t bytes, const int *__restrict__ deferred,
+                                                      unsigned char *__restrict__ mbox, int *__restrict__ mbox_deferred,
+                                                      unsigned long long *__restrict__ flag, unsigned long long seq) {
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mbox)) & 15) == 0) {
+        const int64_t nv = bytes >> 4;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(mbox);
+        for (int64_t i = threadIdx.x; i < nv; i += 256) d4[i] = s4[i];
+        for (int64_t i = (nv << 4) + threadIdx.x; i < bytes; i += 256) mbox[i] = src[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < bytes; i += 256) mbox[i] = src[i];
+    }
+    if (deferred && threadIdx.x < 4) mbox_deferred[threadIdx.x] = deferred[threadIdx.x];
+    __threadfence_system();   // this thread's stores are visible to the host ...
+    __syncthreads();          // ... for every thread of the (single) workgroup ...
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the number is
+}
+}  // namespace ph
+
+// wait until *flag == seq (written by a publish kernel on `stream`). The poll is bounded: every few thousand
+// reads it asks the stream — idle without the number means the kernel never ran (an earlier fault)
+static int poll_flag(const unsigned long long *flag, unsigned long long seq, hipStream_t stream) {
+    for (unsigned long long spins = 1;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return PH_OK;
+        if ((spins & 8191) == 0) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return PH_OK;
+                ph::set_error("device-to-host mailbox: the stream went idle without publishing (%s)", hipGetErrorString(hipGetLastError()));
+                return PH_EHIP;
+            }
+            if (q != hipErrorNotReady) { ph::set_error("device-to-host mailbox: %s", hipGetErrorString(q)); return PH_EHIP; }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+int ph_ctx::publish(const void *dev, int64_t bytes, bool with_deferred) {
+    const int64_t MB = PH_MAILBOX;
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>((char *)mailbox + MB + 64);
+    unsigned long long *flag_dev = reinterpret_cast<unsigned long long *>((char *)mailbox_dev + MB + 64);
+    const unsigned long long seq = ++publish_seq;
+    ph::publish_kernel<<<1, 256, 0, stream>>>((const unsigned char *)dev, bytes, with_deferred ? deferred_dev : nullptr,
+                                              (unsigned char *)mailbox_dev, (int *)((char *)mailbox_dev + MB), flag_dev, seq);
+    PH_HIP(hipGetLastError());
+    return poll_flag(flag, seq, stream);
+}
+
 int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
     if (bytes <= 0) return PH_OK;
     const int64_t MB = PH_MAILBOX;
-    if (!mailbox) PH_HIP(hipHostMalloc(&mailbox, (size_t)MB + 64, hipHostMallocDefault));
+    if (!mailbox) {
+        PH_HIP(hipHostMalloc(&mailbox, (size_t)MB + 128, hipHostMallocMapped | hipHostMallocCoherent));
+        memset((char *)mailbox + MB, 0, 128);
+        PH_HIP(hipHostGetDevicePointer(&mailbox_dev, mailbox, 0));
+    }
     const bool chk = deferred_pending && deferred_dev;
+    static const bool no_publish = getenv("PH_NO_PUBLISH") != nullptr;   // A/B switch: copy command + stream synchronisation
+    if (bytes <= MB && !no_publish) {
+        PH_CHECK(publish(dev, bytes, chk));
+        memcpy(host, mailbox, (size_t)bytes);
+        return chk ? finish_deferred() : PH_OK;
+    }
     if (chk) PH_HIP(hipMemcpyAsync((char *)mailbox + MB, deferred_dev, 16, hipMemcpyDeviceToHost, stream));
     if (bytes <= MB) {
         PH_HIP(hipMemcpyAsync(mailbox, dev, (size_t)bytes, hipMemcpyDeviceToHost, stream));
@@ -127,11 +189,15 @@ int ph_ctx::download_count(int64_t *host, const void *dev, int64_t cap, const ch
         if (cap >= 0 && *host > cap) { ph::set_error("%s: %lld rows, output capacity %lld", what, (long long)*host, (long long)cap); return PH_ECAPACITY; }
         return PH_OK;
     }
-    if (!count_slots) PH_HIP(hipHostMalloc((void **)&count_slots, PH_MAX_PENDING_COUNTS * 8, hipHostMallocDefault));
-    if (!count_event) { hipEvent_t e; PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); count_event = e; }
+    if (!count_slots) {   // + one word behind the slots: the sequence number of the last count published
+        PH_HIP(hipHostMalloc((void **)&count_slots, (PH_MAX_PENDING_COUNTS + 2) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(count_slots, 0, (PH_MAX_PENDING_COUNTS + 2) * 8);
+        PH_HIP(hipHostGetDevicePointer((void **)&count_slots_dev, count_slots, 0));
+    }
     const size_t slot = pending_counts.size();
-    PH_HIP(hipMemcpyAsync(count_slots + slot, dev, 8, hipMemcpyDeviceToHost, stream));
-    PH_HIP(hipEventRecord((hipEvent_t)count_event, stream));
+    ph::publish_kernel<<<1, 256, 0, stream>>>((const unsigned char *)dev, 8, nullptr, (unsigned char *)(count_slots_dev + slot), nullptr,
+                                              (unsigned long long *)(count_slots_dev + PH_MAX_PENDING_COUNTS), ++count_seq_issued);
+    PH_HIP(hipGetLastError());
     pending_counts.push_back({host, cap, what});
     *host = -1;
     return PH_OK;
@@ -139,7 +205,8 @@ int ph_ctx::download_count(int64_t *host, const void *dev, int64_t cap, const ch
 
 int ph_ctx::wait_counts() {
     if (pending_counts.empty()) return PH_OK;
-    PH_HIP(hipEventSynchronize((hipEvent_t)count_event));
+    // the counts were published in stream order: the last one's number means all of them have arrived
+    PH_CHECK(poll_flag((const unsigned long long *)(count_slots + PH_MAX_PENDING_COUNTS), count_seq_issued, stream));
     int rc = PH_OK;
     for (size_t i = 0; i < pending_counts.size(); i++) {
         const PendingCount &p = pending_counts[i];

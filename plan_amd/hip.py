@@ -525,9 +525,10 @@ class Agg:
                    key_null=knull.reshape(m, self.nkeys)[:ng],
                    sum_lo=lo.reshape(m, na)[:ng, :self.naggs], sum_hi=hi.reshape(m, na)[:ng, :self.naggs],
                    count=cnt.reshape(m, na)[:ng, :self.naggs].astype(np.int64))
-        if python_ints:  # exact 128-bit python ints (slow for many groups)
-            out["sum"] = [[(int(hi[g * na + a]) << 64) + int(lo[g * na + a]) for a in range(self.naggs)]
-                          for g in range(ng)]
+        if python_ints:  # exact 128-bit python ints (one C-level tolist per word array, then plain int arithmetic)
+            hl, ll = hi[:ng * na].tolist(), lo[:ng * na].tolist()
+            nag = self.naggs
+            out["sum"] = [[(hl[g * na + a] << 64) + ll[g * na + a] for a in range(nag)] for g in range(ng)]
         return out
 
     def topk(self, agg_index, k, descending=True, cap=4096):

@@ -613,8 +613,8 @@ class Q9Pipeline:
         agg.free()
         stage("expr_aggregate", t0)
         ctx.free_many(frees)
-        mine = {(int(r["keys"][g][0]), int(r["keys"][g][1])): ([r["sum"][g][0]], [int(r["count"][g][0])])
-                for g in range(r["ngroups"])}
+        kl, cl, sl = r["keys"].tolist(), r["count"].tolist(), r["sum"]
+        mine = {(kl[g][0], kl[g][1]): ([sl[g][0]], [cl[g][0]]) for g in range(r["ngroups"])}
         merged = dist.merge_group_partials(mine, ctx=ctx)
         rows = [(k[0], k[1], v[0][0]) for k, v in merged.items()]
         return dict(ngroups=len(rows), rows=rows, join_rows=n4, timings=t)
