@@ -294,6 +294,10 @@ class Q3Pipeline:
         t0 = tic()
         # the total group count is reporting only (one more host round trip): not in measured steps
         ngroups_total = agg.group_count() if (self.time_stages or want_groups) else None
+        # the intermediates go back to the (stream-ordered) pool BEFORE the host blocks in the fetch: the
+        # bookkeeping runs while the GPU is still busy instead of between two queries
+        ctx.free_many(frees)
+        frees = []
         if want_groups:
             r = agg.finalize(python_ints=False)
         else:   # ORDER BY revenue DESC ... LIMIT: only the groups at least as good as the k-th
@@ -303,9 +307,21 @@ class Q3Pipeline:
         # ORDER BY revenue DESC, o_orderdate LIMIT k over this rank's groups (vectorised; the
         # revenue of one order fits int64, which the high word confirms)
         rev_lo = r["sum_lo"][:, 0].view(np.int64)
-        assert np.array_equal(r["sum_hi"][:, 0], rev_lo >> 63), "Q3 revenue left the int64 range"
         keys = r["keys"]
         ng = r["ngroups"]
+        if ng <= 64 and not want_groups:
+            # the usual case after the device top-k (k rows + ties): plain Python over a handful of rows — a dozen
+            # numpy calls on 10-element arrays cost more host time between two queries than the sort itself
+            rl, hl, kl = rev_lo.tolist(), r["sum_hi"][:, 0].tolist(), keys.tolist()
+            assert all(h == (v >> 63) for h, v in zip(hl, rl)), "Q3 revenue left the int64 range"
+            cand = sorted(((kl[g][0], rl[g], kl[g][1], kl[g][2]) for g in range(ng)), key=lambda x: (-x[1], x[2]))[:limit]
+            top = dist.merge_topk(cand, limit, key=lambda x: (-x[1], x[2]), ctx=ctx)   # revenue desc, o_orderdate
+            agg.free()
+            j1.free()
+            j2.free()
+            ctx.free_many(frees)
+            return dict(ngroups=ngroups_total, groups=None, top=top, join_rows=m2, build_rows=cn + m1, timings=t)
+        assert np.array_equal(r["sum_hi"][:, 0], rev_lo >> 63), "Q3 revenue left the int64 range"
         if ng > limit:   # O(n) selection of everything >= the k-th largest revenue, then a tiny sort
             kth = np.partition(rev_lo, ng - limit)[ng - limit]
             pick = np.nonzero(rev_lo >= kth)[0]
@@ -609,12 +625,19 @@ class Q9Pipeline:
         agg = hip.Agg(ctx, [hip.PH_I32, hip.PH_I32], [(hip.PH_A_SUM, 0)], 1024)
         agg.sink([_raw(hip.PH_I32, nat), _raw(hip.PH_I32, year)], [_raw(hip.PH_DEC64, amount, 4)], None, n4,
                  positional=True)
+        # the intermediates go back to the (stream-ordered) pool BEFORE the host blocks in the fetch: the
+        # bookkeeping runs while the GPU is still busy instead of between two queries
+        ctx.free_many(frees)
         r = agg.finalize()
         agg.free()
         stage("expr_aggregate", t0)
-        ctx.free_many(frees)
-        kl, cl, sl = r["keys"].tolist(), r["count"].tolist(), r["sum"]
-        mine = {(kl[g][0], kl[g][1]): ([sl[g][0]], [cl[g][0]]) for g in range(r["ngroups"])}
+        ng, sl = r["ngroups"], r["sum"]
+        if dist.world() == 1:   # the groups are final: no merge, no per-group dictionary (30 us of host time between two queries)
+            keys = r["keys"]
+            rows = list(zip(keys[:ng, 0].tolist(), keys[:ng, 1].tolist(), [x[0] for x in sl]))
+            return dict(ngroups=ng, rows=rows, join_rows=n4, timings=t)
+        kl, cl = r["keys"].tolist(), r["count"].tolist()
+        mine = {(kl[g][0], kl[g][1]): ([sl[g][0]], [cl[g][0]]) for g in range(ng)}
         merged = dist.merge_group_partials(mine, ctx=ctx)
         rows = [(k[0], k[1], v[0][0]) for k, v in merged.items()]
         return dict(ngroups=len(rows), rows=rows, join_rows=n4, timings=t)

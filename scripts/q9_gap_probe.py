@@ -24,6 +24,10 @@ def wrap(obj, name, tag):
 wrap(hip.Agg, "finalize", "finalize")
 wrap(hip, "filter_like", "like") if hasattr(hip, "filter_like") else None
 wrap(hip.Ctx, "wait_counts", "wait_counts")
+from plan_amd import dist
+for obj, name in ((hip.Agg, "free"), (hip.Ctx, "free_many"), (hip.Ctx, "set_async_counts"), (hip.Ctx, "set_deferred_errors"),
+                  (dist, "merge_group_partials"), (hip, "filter_select"), (hip.Agg, "__init__"), (hip.Agg, "sink")):
+    wrap(obj, name, "x:" + name)
 for _ in range(5):
     pipe.run()
 marks.clear()
@@ -39,3 +43,7 @@ for i in range(3, 8):
     w = [m for m in marks if m[0] == "wait_counts" and t0 <= m[1] <= t1]
     print(f"run {i}: total {1e6*(t1-t0):.0f} us | until finalize call {1e6*(f[1]-t0):.0f} | in finalize {1e6*(f[2]-f[1]):.0f} | after finalize {1e6*(t1-f[2]):.0f} | "
           + " ".join(f"wait@{1e6*(m[1]-t0):.0f}+{1e6*(m[2]-m[1]):.0f}" for m in w))
+    if i == 5:
+        for m in marks:
+            if m[0].startswith("x:") and f[1] - 60e-6 <= m[1] <= t1 + 60e-6:
+                print(f"     {m[0][2:]:24s} @{1e6*(m[1]-f[2]):8.1f} us after finalize, took {1e6*(m[2]-m[1]):6.1f}")
