@@ -422,6 +422,18 @@ int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n
 int ph_join_lookup_strict(ph_join *j, const ph_col *keys, const int32_t *sel, int64_t n, int32_t *out_build_dev);
 void ph_join_free(ph_join *j);
 
+/* Merge-style N:1 lookup, no table: build_key is a unique key column in ascending order (a primary key stored in
+ * key order), the probe rows sel[0..n) / 0..n arrive ordered by the key too (a clustered table behind
+ * order-preserving operators). out[i] = build row whose key equals probe row i's, or -1. A block of probe rows
+ * finds the slice of build keys it spans with two searches, streams it through LDS once and searches there:
+ * the build column is read once and nothing is written — where the reference builds one hash table whatever
+ * its children's order (executor_join.go:54-264). Both orders are checked on the device as the rows stream by
+ * (blocks of very sparse probes search the column directly and check the probe order only); a violation is the
+ * ctx's deferred PH_ECONSTRAINT and the caller joins again with ph_join_build + ph_join_lookup. strict != 0:
+ * a probe row without a match is a deferred PH_ECONSTRAINT as in ph_join_lookup_strict. */
+int ph_merge_lookup(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const ph_col *probe_key, const int32_t *sel,
+                    int64_t n, int32_t strict, int32_t *out_build_dev);
+
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:
  * for every right row, all left rows in order — the order the reference emits (one output chunk
  * per (left chunk, right row)) — so that both sides materialise with ph_gather like a join's

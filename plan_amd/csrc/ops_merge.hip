@@ -1,0 +1,154 @@
+// Merge-style N:1 lookup: both sides ordered by the join key.
+//
+// The reference joins with one hash table whatever the children's order (pkg/compute/executor_join.go:54-264,
+// join_table.go:197-288). When the build key is a primary key stored in key order AND the probe rows arrive
+// ordered by the key (a clustered table behind order-preserving filters and joins: Q9's surviving lineitem rows
+// against orders), no table is needed at all: a block of probe rows spans one contiguous slice of the build
+// keys, found with two searches; the slice streams through LDS once and every probe row finds its key there
+// with a binary search in LDS. The build column is read once (coalesced), nothing is written but the answers —
+// against a direct table that costs a fill of 4 B x key range plus a random slot read per probe.
+// Both orders are VERIFIED on the device (a violation raises the ctx's deferred PH_ECONSTRAINT word, the caller
+// falls back to ph_join_build + ph_join_lookup); a probe key that is absent answers -1 and counts as a miss.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "device_util.h"
+#include "ops.h"
+
+namespace ph {
+
+constexpr int ML_ROWS = 2048;    // probe rows per 256-thread workgroup
+constexpr int ML_CHUNK = 4096;   // build keys staged in LDS at a time (32 KiB)
+constexpr int ML_MAX_CHUNKS = 64;   // a block whose slice is longer searches the column itself (sparse probes)
+
+template <int KW>
+__device__ __forceinline__ long long ml_key(const void *col, int64_t i) {
+    return KW == 4 ? (long long)((const int32_t *)col)[i] : ((const long long *)col)[i];
+}
+
+// first index in [lo, hi) whose key is >= k (hi if none): 64-ary search, the wave reads 64 pivots per step
+template <int KW>
+__device__ __forceinline__ int64_t wave_lower_bound(const void *a, int64_t lo, int64_t hi, long long k, int lane) {
+    while (hi > lo) {
+        const int64_t step = (hi - lo + 63) / 64;
+        const int64_t idx = lo + (int64_t)lane * step;
+        const bool less = idx < hi && ml_key<KW>(a, idx) < k;
+        const int c = __popcll(__ballot(less));   // sorted: the lanes that see a smaller key are a prefix
+        if (c == 0) return lo;
+        const int64_t nlo = lo + (int64_t)(c - 1) * step + 1;
+        hi = lo + (int64_t)c * step < hi ? lo + (int64_t)c * step : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
+template <int KW, bool SEL>
+__global__ __launch_bounds__(256) void merge_lookup_kernel(const void *__restrict__ bkeys, int64_t nb, const void *__restrict__ pkeys,
+                                                           const int32_t *__restrict__ psel, int64_t n, int32_t *__restrict__ out,
+                                                           int *__restrict__ stats, int *__restrict__ unsorted) {
+    __shared__ long long bk[ML_CHUNK + 1];   // the chunk and the key behind it (order check across the chunk's end)
+    __shared__ long long s_b[2];
+    constexpr int PT = ML_ROWS / 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = (int64_t)blockIdx.x * ML_ROWS, p1 = p0 + ML_ROWS < n ? p0 + ML_ROWS : n;
+    long long k[PT];
+    int32_t res[PT];
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < PT; q++) {
+        const int64_t i = p0 + q * 256 + threadIdx.x;
+        res[q] = -1;
+        k[q] = 0;
+        if (i < p1) {
+            k[q] = ml_key<KW>(pkeys, SEL ? (int64_t)psel[i] : i);
+            if (i + 1 < n) bad = bad || k[q] > ml_key<KW>(pkeys, SEL ? (int64_t)psel[i + 1] : i + 1);   // the probe order
+        }
+    }
+    if (threadIdx.x < 64) {   // wave 0: the slice of the build keys this block's probe keys span
+        const long long klo = ml_key<KW>(pkeys, SEL ? (int64_t)psel[p0] : p0);
+        const long long khi = ml_key<KW>(pkeys, SEL ? (int64_t)psel[p1 - 1] : p1 - 1);
+        const int64_t b0 = wave_lower_bound<KW>(bkeys, 0, nb, klo, lane);
+        // unique ascending integers: the keys in [klo, khi] are at most khi - klo + 1 rows
+        const unsigned long long span = (unsigned long long)khi - (unsigned long long)klo;
+        const int64_t cap1 = span < (unsigned long long)(nb - b0) ? b0 + (int64_t)span + 1 : nb;
+        const int64_t b1 = khi == INT64_MAX ? nb : wave_lower_bound<KW>(bkeys, b0, cap1 < nb ? cap1 : nb, khi + 1, lane);
+        if (lane == 0) { s_b[0] = b0; s_b[1] = b1; }
+    }
+    __syncthreads();
+    const int64_t b0 = s_b[0], b1 = s_b[1];
+    if (b1 - b0 > (int64_t)ML_MAX_CHUNKS * ML_CHUNK) {
+        // sparse probes: the slice is too long to stream for 1024 rows — every row searches the column
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            const int64_t i = p0 + q * 256 + threadIdx.x;
+            if (i >= p1) continue;
+            int64_t lo = b0, hi = b1;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ml_key<KW>(bkeys, mid) < k[q]) lo = mid + 1; else hi = mid; }
+            if (lo < b1 && ml_key<KW>(bkeys, lo) == k[q]) res[q] = (int32_t)lo;
+        }
+    } else {
+        for (int64_t c = b0; c < b1; c += ML_CHUNK) {
+            const int m = (int)(b1 - c < ML_CHUNK ? b1 - c : ML_CHUNK);
+            __syncthreads();   // the previous chunk's searches are done
+            {   // all 16 reads of a thread in flight before the first store (a load -> store loop waits per element)
+                long long v[ML_CHUNK / 256];
+#pragma unroll
+                for (int q = 0; q < ML_CHUNK / 256; q++) {
+                    const int e = q * 256 + threadIdx.x;
+                    v[q] = e <= m && c + e < nb ? ml_key<KW>(bkeys, c + e) : INT64_MAX;
+                }
+#pragma unroll
+                for (int q = 0; q < ML_CHUNK / 256; q++) bk[q * 256 + threadIdx.x] = v[q];
+                if (threadIdx.x == 0) bk[ML_CHUNK] = m == ML_CHUNK && c + m < nb ? ml_key<KW>(bkeys, c + m) : INT64_MAX;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < m; e += 256) bad = bad || (c + e + 1 < nb && bk[e] >= bk[e + 1]);   // the build order (strict)
+            const long long first = bk[0], last = bk[m - 1];
+#pragma unroll
+            for (int q = 0; q < PT; q++) {
+                if (res[q] >= 0 || k[q] < first || k[q] > last || p0 + q * 256 + (int64_t)threadIdx.x >= p1) continue;
+                int lo = 0, hi = m;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (bk[mid] < k[q]) lo = mid + 1; else hi = mid; }
+                if (lo < m && bk[lo] == k[q]) res[q] = (int32_t)(c + lo);
+            }
+        }
+    }
+    int misses = 0;
+#pragma unroll
+    for (int q = 0; q < PT; q++) {
+        const int64_t i = p0 + q * 256 + threadIdx.x;
+        if (i < p1) { out[i] = res[q]; misses += res[q] < 0; }
+    }
+    for (int o = 32; o > 0; o >>= 1) misses += __shfl_xor(misses, o);
+    if (lane == 0 && misses && stats) atomicAdd(stats, misses);
+    if (bad) atomicOr(unsorted, 1);
+}
+
+}  // namespace ph
+
+extern "C" int ph_merge_lookup(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const ph_col *probe_key, const int32_t *sel,
+                               int64_t n, int32_t strict, int32_t *out_build_dev) {
+    PH_REQUIRE(ctx && build_key && probe_key && n_build >= 0 && n >= 0 && n_build < (1ll << 31) && (n == 0 || out_build_dev),
+               "ph_merge_lookup: bad arguments");
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : (t == PH_I64 || t == PH_DEC64) ? 8 : 0; };
+    const int kw = width(build_key->type);
+    if (kw == 0 || width(probe_key->type) != kw || build_key->validity || probe_key->validity) {
+        ph::set_error("ph_merge_lookup: one 4- or 8-byte integer key column of the same width on both sides, no NULLs");
+        return PH_EUNSUPPORTED;
+    }
+    if (n == 0) return PH_OK;
+    if (n_build == 0) { PH_HIP(hipMemsetAsync(out_build_dev, 0xff, (size_t)n * 4, ctx->stream)); return PH_OK; }
+    int *words = nullptr;
+    PH_CHECK(ctx->deferred_words(&words));
+    const int grid = (int)((n + ph::ML_ROWS - 1) / ph::ML_ROWS);
+    int *stats = strict ? words + 1 : nullptr;   // a miss of a strict lookup is the deferred word of ph_join_lookup_strict
+#define PH_ML(KWV, SELV) ph::merge_lookup_kernel<KWV, SELV><<<grid, 256, 0, ctx->stream>>>(build_key->data, n_build, probe_key->data, sel, n, out_build_dev, stats, words + 3)
+    if (kw == 4) { if (sel) PH_ML(4, true); else PH_ML(4, false); }
+    else { if (sel) PH_ML(8, true); else PH_ML(8, false); }
+#undef PH_ML
+    PH_HIP(hipGetLastError());
+    ctx->deferred_pending = true;
+    return PH_OK;
+}

@@ -672,6 +672,16 @@ class Join:
             self.h = None
 
 
+def merge_lookup(ctx, build_key, n_build, probe_key, sel, n, strict=False):
+    """ph_merge_lookup: N:1 lookup of probe keys that arrive in key order into a unique, ascending key column;
+    device int32[n] of build rows (-1 = none)"""
+    out = ctx.alloc(max(n, 1) * 4)
+    b = build_key.col() if isinstance(build_key, DevColumn) else build_key
+    p = probe_key.col() if isinstance(probe_key, DevColumn) else probe_key
+    check(lib().ph_merge_lookup(ctx.h, ctypes.byref(b), i64(n_build), ctypes.byref(p), sel, i64(n), i32(1 if strict else 0), out))
+    return out
+
+
 def gather(ctx, col, idx_dev, n):
     c = col.col() if isinstance(col, DevColumn) else col
     w = {PH_CODE8: 1, PH_I32: 4, PH_DATE: 4, PH_F32: 4}.get(c.type, 8)

@@ -385,6 +385,8 @@ class Q9Pipeline:
         self.o_key = D(ctx, hip.PH_I64, O["o_orderkey"])
         self.o_date = D(ctx, hip.PH_DATE, O["o_orderdate"])
         self.l_key = D(ctx, hip.PH_I64, L["l_orderkey"])
+        # column statistic: lineitem clustered by order key -> the surviving rows reach the orders join in key order
+        self.l_key_sorted = bool(self.n["l"] > 1 and np.all(np.diff(L["l_orderkey"]) >= 0))
         self.l_part = D(ctx, hip.PH_I32, L["l_partkey"])
         self.l_supp = D(ctx, hip.PH_I32, L["l_suppkey"])
         self.l_qty = D(ctx, hip.PH_I32, L["l_quantity"])
@@ -452,13 +454,18 @@ class Q9Pipeline:
         # supplier and orders builds while the LIKE count travels, and the partsupp semi-join while the
         # pair count of the part join does.
         pipelined = N == 1 and not self.time_stages
+        # orders: both sides of the last join are ordered by the key (o_orderkey a primary key in storage order,
+        # the intermediate in lineitem order, lineitem clustered by l_orderkey): a merge lookup, no table
+        merge_orders = (strict and N == 1 and self.o_key_sorted_unique and self.l_key_sorted
+                        and not getattr(self, "no_merge_lookup", False))
         js = jo = None
         if pipelined:
             ctx.set_async_counts(True)
             psel, np_c = hip.filter_select(ctx, self.p_name, self.n["p"], hip.PH_LIKE, hip.const(hip.PH_STR, s=self.pattern), defer=True)
             self._counts = [np_c]
             js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range)
-            jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range, sorted_unique=strict and self.o_key_sorted_unique)
+            if not merge_orders:
+                jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range, sorted_unique=strict and self.o_key_sorted_unique)
             ctx.wait_counts()
             np_ = np_c.value
         else:
@@ -601,12 +608,15 @@ class Q9Pipeline:
         # no gathers of the amount / nation columns. Building 15 M order keys costs 0.37 ms with the
         # node table (was 0.65 ms with one atomic per row, which is why round 1 built the 3.3 M-row
         # intermediate instead and probed it with all 15 M orders: 0.83 ms for the stage).
-        if jo is None:
-            jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range, sorted_unique=strict and self.o_key_sorted_unique)
-        if not strict:
-            hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
-        orow = lookup(jo, [_raw(hip.PH_I64, c_okey)], m)
-        jo.free()
+        if merge_orders:
+            orow = hip.merge_lookup(ctx, self.o_key, self.n["o"], _raw(hip.PH_I64, c_okey), None, m, strict=True)
+        else:
+            if jo is None:
+                jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range, sorted_unique=strict and self.o_key_sorted_unique)
+            if not strict:
+                hip.check(hip.lib().ph_dev_memset(ctx.h, stats, 0, hip.i64(8)))
+            orow = lookup(jo, [_raw(hip.PH_I64, c_okey)], m)
+            jo.free()
         frees.append(orow)
         misses, multi = (0, 0) if strict else ctx.download(stats, np.int32, 2).tolist()
         if multi:

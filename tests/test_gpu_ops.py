@@ -766,6 +766,61 @@ def test_join_build_where_sorted_unique_gated_fill(ctx):
             c.free()
 
 
+def test_merge_lookup_equals_table_lookup(ctx):
+    """ph_merge_lookup (both sides ordered by the key, no table) answers like ph_join_build + ph_join_lookup:
+    dense clustered probes (blocks stream their slice of the build keys through LDS), very sparse probes (blocks
+    search the column), a probe selection, int32 keys, absent keys, keys below / above every build key, empty
+    sides; strict misses and either broken order are the deferred PH_ECONSTRAINT."""
+    rng = np.random.default_rng(101)
+    nb = 2_000_000
+    i = np.arange(nb, dtype=np.int64)
+    bk = (i // 8) * 32 + i % 8 + 1                                     # the o_orderkey pattern
+    for dt, typ in ((np.int64, hip.PH_I64), (np.int32, hip.PH_I32)):
+        b = bk.astype(dt)
+        db = hip.DevColumn(ctx, typ, b)
+        jt = hip.Join(ctx, [db], None, nb, key_range=(int(b[0]), int(b[-1])))
+        dense = np.sort(np.concatenate([b[rng.integers(0, nb, 900_000)], rng.integers(-5, int(b[-1]) + 50, 100_000).astype(dt)]))
+        sparse = np.sort(np.concatenate([b[rng.integers(0, nb, 1500)], np.array([-7, int(b[-1]) + 3], dtype=dt)]))
+        for p in (dense, sparse):
+            dp = hip.DevColumn(ctx, typ, p)
+            got = ctx.download(hip.merge_lookup(ctx, db, nb, dp, None, len(p)), np.int32, len(p))
+            want = ctx.download(jt.lookup([dp], None, len(p)), np.int32, len(p))
+            assert np.array_equal(got, want) and (got >= 0).sum() > 1000 and (got < 0).sum() >= 2
+            ctx.check_deferred()
+            dp.free()
+        # a selection that keeps the order; strict lookups of present keys only
+        dp = hip.DevColumn(ctx, typ, dense)
+        sel = np.nonzero(np.isin(dense, b))[0].astype(np.int32)[::3]
+        ds = ctx.upload(sel)
+        got = ctx.download(hip.merge_lookup(ctx, db, nb, dp, ds, len(sel), strict=True), np.int32, len(sel))
+        assert np.array_equal(b[got], dense[sel])
+        ctx.check_deferred()
+        # strict with a miss, probes out of order, build out of order: deferred errors
+        miss = hip.merge_lookup(ctx, db, nb, dp, None, len(dense), strict=True)
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(miss, np.int32, 4)
+        assert e.value.code == hip.PH_ECONSTRAINT
+        bad = dense.copy(); bad[500_000], bad[500_001] = dense[-1], dense[0]
+        dbad = hip.DevColumn(ctx, typ, bad)
+        r = hip.merge_lookup(ctx, db, nb, dbad, None, len(bad))
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(r, np.int32, 4)
+        assert e.value.code == hip.PH_ECONSTRAINT
+        b2 = b.copy(); b2[1_000_000], b2[1_000_001] = b[1_000_001], b[1_000_000]
+        db2 = hip.DevColumn(ctx, typ, b2)
+        r = hip.merge_lookup(ctx, db2, nb, dp, None, len(dense))
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(r, np.int32, 4)
+        assert e.value.code == hip.PH_ECONSTRAINT
+        # empty sides
+        assert (ctx.download(hip.merge_lookup(ctx, db, 0, dp, None, 1000), np.int32, 1000) == -1).all()
+        hip.merge_lookup(ctx, db, nb, dp, None, 0)
+        ctx.check_deferred()
+        jt.free(); ctx.free(ds)
+        for c in (db, dp, dbad, db2):
+            c.free()
+
+
 def test_join_build_where_equals_filter_then_build(ctx):
     """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
     row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
