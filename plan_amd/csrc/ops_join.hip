@@ -1381,6 +1381,21 @@ __global__ __launch_bounds__(256) void join_mark_set_kernel(const uint16_t *__re
 // build-side rows: key column, validity, selection and an optional pushed-down range filter (Filter ->
 // build in one pass: a direct table is sized by the key RANGE, so the number of rows that pass need
 // not be known on the host — no selection vector, no count read-back before the build)
+// slot of a key: key - lo, in range iff < range. 4-byte keys compute it in 32 bits (build_direct clamps the range
+// of a 4-byte table to the int32 domain, so the wrapped difference of two int32 values below `range` is exact:
+// a false hit would need key + 2^32 < lo + range <= 2^31) — the 64-bit form is two VALU instructions per
+// subtract / compare / shift where the candidate kernels spend ~39 per key.
+template <int KW>
+__device__ __forceinline__ bool direct_slot(long long k, long long lo, unsigned long long range, unsigned long long *off) {
+    if (KW == 4) {
+        const unsigned o = (unsigned)((int)k - (int)lo);
+        *off = o;
+        return o < (unsigned)range;
+    }
+    *off = (unsigned long long)(k - lo);
+    return *off < range;
+}
+
 struct DirectSrc {
     const void *kcol; const uint8_t *valid; const int32_t *sel;
     int wkind;   // 0 none, 1 int32, 2 int64, 3 uint8 column wdata, rows with wlo <= value <= whi are built
@@ -1795,8 +1810,8 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const void *__restric
         }
 #pragma unroll
         for (int u = 0; u < DU; u++) {
-            const unsigned long long off = (unsigned long long)(k[u] - lo);
-            ok[u] = ok[u] && off < range;
+            unsigned long long off;
+            ok[u] = direct_slot<KW>(k[u], lo, range, &off) && ok[u];
             if (abits) ok[u] = ok[u] && ((abits[(ok[u] ? off : 0) >> 5] >> (off & 31)) & 1u);
             const int32_t d = direct[ok[u] ? off : 0];
             b[u] = ok[u] && (unsigned)d < (unsigned)nbuild ? d : -1;   // anything but a build row reads as empty
@@ -2012,8 +2027,8 @@ __device__ __forceinline__ void direct_cand_block_keys(const DirectCand &D, int6
     int32_t d[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-        const unsigned long long off = (unsigned long long)(k[s] - D.lo);
-        ok[s] = ok[s] && off < D.range;
+        unsigned long long off;
+        ok[s] = direct_slot<KW>(k[s], D.lo, D.range, &off) && ok[s];
         if (COARSE) {
             const unsigned cb = (unsigned)((ok[s] ? off : 0) >> D.cshift);
             ok[s] = ok[s] && ((co_lds[cb >> 5] >> (cb & 31)) & 1u);
@@ -2192,16 +2207,16 @@ __global__ __launch_bounds__(256) void direct_mark_where_kernel(const void *__re
     if (dbits) {   // membership is all a mark needs: the occupancy bitmap (L2 resident) instead of the 32x larger slot array
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            const unsigned long long off = (unsigned long long)(k[s] - lo);
-            ok[s] = ok[s] && off < range;
+            unsigned long long off;
+            ok[s] = direct_slot<KW>(k[s], lo, range, &off) && ok[s];
             const unsigned long long o = ok[s] ? off : 0;
             d[s] = ((dbits[o >> 5] >> (o & 31)) & 1u) ? 0 : -1;
         }
     } else {
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            const unsigned long long off = (unsigned long long)(k[s] - lo);
-            ok[s] = ok[s] && off < range;
+            unsigned long long off;
+            ok[s] = direct_slot<KW>(k[s], lo, range, &off) && ok[s];
             d[s] = direct[ok[s] ? off : 0];
             d[s] = (unsigned)d[s] < (unsigned)nbuild ? d[s] : -1;
         }
@@ -2350,6 +2365,11 @@ static int sorted_fill_occupancy(int kw, bool gated) {
 static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where, bool declared_sorted_unique) {
     ph_ctx *ctx = j->ctx;
     const int64_t n = j->build.n;
+    if (kw == 4) {   // a 4-byte key cannot lie outside the int32 domain: the slot arithmetic of 4-byte tables is 32-bit (direct_slot)
+        const int64_t hi = std::min<int64_t>(lo + range - 1, INT32_MAX);
+        lo = std::min<int64_t>(std::max<int64_t>(lo, INT32_MIN), INT32_MAX);
+        range = hi >= lo ? hi - lo + 1 : 1;   // (an empty intersection: one slot no stated-range key can claim)
+    }
     const int64_t cap4 = ph::round_up(range, 4);
     j->dkw = kw;
     j->dlo = lo;
