@@ -753,6 +753,22 @@ def test_join_build_where_sorted_unique_gated_fill(ctx):
             for b in (pw, bw, pf, bf, fs, fw[1], fw[2]):
                 ctx.free(b)
             jw.free(); jf.free()
+        # gates over 4- and 8-byte columns (a date range, a decimal threshold) through the same fill
+        gd = rng.integers(8000, 10000, n).astype(np.int32)
+        gv = rng.integers(0, 10**9, n).astype(np.int64)
+        dgd, dgv = hip.DevColumn(ctx, hip.PH_DATE, gd), hip.DevColumn(ctx, hip.PH_DEC64, gv, 2)   # (BIGINT has no comparison in the reference)
+        for wcol, op, kc, keep in ((dgd, hip.PH_LT, hip.const(hip.PH_DATE, i=8200), gd < 8200),
+                                   (dgv, hip.PH_GT, hip.const(hip.PH_DEC64, i=900_000_000, scale=2), gv > 900_000_000)):
+            jw = hip.Join.build_where(ctx, [dk], wcol, op, kc, None, n, rngk, sorted_unique=True)
+            assert jw is not None and jw.kind == "direct" and jw.count() == int(keep.sum())
+            lw = ctx.download(jw.lookup([dp], None, len(p)), np.int32, len(p))
+            pos = np.searchsorted(keys, p)
+            hit = (pos < n) & (keys[np.minimum(pos, n - 1)] == p)
+            hit &= keep[np.minimum(pos, n - 1)]
+            assert np.array_equal(lw >= 0, hit) and np.array_equal(lw[hit], pos[hit])
+            ctx.check_deferred()
+            jw.free()
+        dgd.free(); dgv.free()
         bad = keys.copy()
         bad[650_000], bad[650_001] = keys[650_001], keys[650_000]
         dbad = hip.DevColumn(ctx, typ, bad)
