@@ -61,6 +61,7 @@ class Q3Pipeline:
         # only the customer keys (the small build side) cross the links, and the top-k candidates at the end.
         self.copartitioned = False
         self.allow_partitionwise = True   # False: always the hash-partitioned exchange plan
+        self.semijoin_reduce = True       # the exchange plan filters lineitem by the all-gathered qualifying order keys first
         if dist.world() > 1:
             l_lo = int(L["l_orderkey"].min()) if self.nl else 0
             l_hi = int(L["l_orderkey"].max()) if self.nl else -1
@@ -243,7 +244,27 @@ class Q3Pipeline:
                     self.probe_events[1].record()
                 stage("lineitem_filter_probe", t0)
                 t["probe_rows"] = self.nl   # rows streamed by the fused filter+probe
-        if fused2 is None:
+        if fused2 is None and N > 1 and self.semijoin_reduce:
+            # SEMI-JOIN REDUCTION in front of the exchange: every rank learns the order keys that qualify anywhere
+            # (8 B per qualifying order, all-gathered: 12 MB per rank at SF10) and sends only the lineitem rows
+            # whose order qualifies — 0.5 % of the rows the date filter keeps, so the all-to-all moves ~24 B x 0.3 M
+            # rows per rank instead of 24 B x 32 M, and the partition + gathers in front of it shrink likewise
+            qk = hip.gather(ctx, self.o_key, orow, m1)
+            allq, nq = dist.allgather_rows(ctx, qk, m1, np.int64)
+            frees += [qk, allq]
+            jq = hip.Join(ctx, [_raw(hip.PH_I64, allq)], None, nq)
+            red = jq.probe_inner_where([self.l_key], self.l_ship, hip.PH_GT, hip.const(hip.PH_DATE, i=date), None, self.nl, self.nl)
+            if red is not None:
+                ln, lsel, _b = red
+                frees += [lsel, _b]
+            else:
+                ls0, l0 = hip.filter_select(ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=date))
+                ln, lsel, _b = jq.probe_inner([self.l_key], ls0, l0, max(l0, 1))
+                frees += [ls0, lsel, _b]
+            jq.free()
+            t["semijoin_keys_gathered"] = nq
+            stage("lineitem_filter", t0)
+        elif fused2 is None:
             lsel, ln = hip.filter_select(ctx, self.l_ship, self.nl, hip.PH_GT, hip.const(hip.PH_DATE, i=date))
             frees.append(lsel)
             stage("lineitem_filter", t0)

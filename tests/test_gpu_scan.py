@@ -184,7 +184,7 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
         return ({k: v[l0:l1] for k, v in L.items()}, {k: v[o0:o1] for k, v in Od.items()},
                 {k: v[c0:c1] for k, v in C.items()})
     grp = pd.ThreadGroup(N)
-    results, local, errors = [None] * N, [None] * N, []
+    results, local, plain, errors = [None] * N, [None] * N, [None] * N, []
 
     def run(r):
         try:
@@ -194,7 +194,10 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
             Ls, Os, Cs = shard(r)
             p = pipelines.Q3Pipeline(c, Ls, Os, Cs)
             assert p.copartitioned                      # the statistic the partition-wise plan rests on
-            p.allow_partitionwise = False               # the hash-partitioned exchange plan
+            p.allow_partitionwise = False               # the hash-partitioned exchange plan ...
+            p.semijoin_reduce = False                   # ... sending every lineitem row the date filter keeps
+            plain[r] = p.run(want_groups=True)
+            p.semijoin_reduce = True                    # ... and with the semi-join reduction in front of the exchange
             results[r] = p.run(want_groups=True)
             p.allow_partitionwise = True                # the partition-wise join over the same shards
             local[r] = p.run(want_groups=True)
@@ -218,6 +221,10 @@ def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
     golden = open(os.path.join(os.path.dirname(__file__), "golden", "plan_q3.txt")).read()
     assert pipelines.q3_text(results[0]["top"]) == golden == pipelines.q3_text(results[1]["top"])
     assert results[0]["timings"]["exchange_bytes_sent"] > 0
+    # the semi-join reduction changes what travels, not the result: far fewer lineitem rows are exchanged
+    assert [set(x["groups"]) for x in plain] == [set(x["groups"]) for x in results]
+    assert pipelines.q3_text(plain[0]["top"]) == golden
+    assert results[0]["timings"]["exchange_bytes_sent"] * 20 < plain[0]["timings"]["exchange_bytes_sent"]
     # partition-wise: the same groups in all (each rank keeps the orders of its own key range), the same
     # top 10 on every rank, and no row exchange
     assert set(local[0]["groups"]) | set(local[1]["groups"]) == want and not (set(local[0]["groups"]) & set(local[1]["groups"]))
