@@ -19,7 +19,7 @@ ONE JSON line on rank 0 (driver contract). Besides the contract's fields:
   cpu_baseline   the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
   N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu (every BASELINE.json
          config, each with its own roofline; Q3 with its own cpu_baseline)
-  N > 1: companions q3_partitioned and q9_partitioned — Q3 / Q9 over an SF`--sf` database split N
+  N > 1: companions q3_partitioned, q3_partitionwise, q9_partitioned, q9_partitionwise — Q3 / Q9 over an SF`--sf` database split N
          ways (strong scaling, BASELINE.json configs 4 and 5), join sides hash-partitioned by order
          key and exchanged with ph_comm_exchange_columns, small build sides broadcast; probe rows/s
          and exchange bytes against the xGMI peak
@@ -395,7 +395,7 @@ def bench_q3(h, sf, steps, warmup, scaling, partitionwise=False):
 
 # ---------------------------------------------------------------------------------- Q9
 
-def bench_q9(h, sf, steps, warmup, scaling="weak"):
+def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
     """Q9: LIKE + four hash joins (one composite) + profit expression + 175-group aggregate
     (plan_amd/pipelines.py Q9Pipeline). A step = one whole Q9. N > 1: every table sharded by row ranges,
     the small build sides broadcast, lineitem x orders hash-partitioned by order key (two all-to-alls)."""
@@ -410,6 +410,8 @@ def bench_q9(h, sf, steps, warmup, scaling="weak"):
     P, PS, S = tpchgen.part(sf_total, p0, p1 - p0), tpchgen.partsupp(sf_total, p0, p1 - p0), tpchgen.supplier(sf_total, s0, s1 - s0)
     nrows = len(L["l_orderkey"])
     pipe = pipelines.Q9Pipeline(h.ctx, L, Od, P, PS, S)
+    pipe.allow_partitionwise = partitionwise   # N > 1: the order-key stage exchanged (BASELINE.json config 5) or rank-local
+    pw = h.world > 1 and partitionwise and pipe.copartitioned
     pipe.time_stages = False
     for _ in range(warmup):
         r = pipe.run()
@@ -459,7 +461,10 @@ def bench_q9(h, sf, steps, warmup, scaling="weak"):
         "config": {"workload": f"TPC-H Q9, {nrows} lineitem rows on rank 0, {total_rows} in total "
                                f"({'SF%d per GPU' % sf if scaling == 'weak' else 'SF%d split %d ways' % (sf, h.world)}), tables resident in HBM",
                    "groups": r["ngroups"], "join_rows_rank0": r["join_rows"],
-                   "parallelism": ("pink part keys, their partsupp rows and supplier broadcast (ph_comm_allgather_rows); the intermediate and orders "
+                   "parallelism": ("pink part keys, their partsupp rows and supplier broadcast (ph_comm_allgather_rows); lineitem x orders "
+                                   "partition-wise (the shards are co-partitioned by order key: statistic all-gathered at load), the 175 partial "
+                                   f"groups merged; x{h.world} ({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if pw else
+                                  ("pink part keys, their partsupp rows and supplier broadcast (ph_comm_allgather_rows); the intermediate and orders "
                                    f"hash-partitioned by order key x{h.world} and exchanged with ph_comm_exchange_columns "
                                    f"({'RCCL' if h.comm is not None else 'gloo rehearsal'})") if h.world > 1 else "single GPU",
                    "exchange_bytes_sent_rank0_per_step": (agg_t.get("exchange_bytes_sent", 0) / stage_steps) if h.world > 1 else 0,
@@ -613,6 +618,7 @@ def main():
         attempt("q3_partitionwise", lambda: brief(bench_q3(h, args.sf, comp_steps, comp_warm, "strong", partitionwise=True)))
         # BASELINE.json config 5: Q9 at SF`--sf`, multi-stage partitioned build/probe across the N GPUs
         attempt("q9_partitioned", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong")))
+        attempt("q9_partitionwise", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong", partitionwise=True)))
     elif rank0 and world == 1 and not args.no_cpu_baseline and L is not None:
         cb = cpu_baselines(L, args.cpu_rows)
         out["cpu_baseline"] = cb[args.query]

@@ -14,6 +14,23 @@ def _raw(typ, ptr, scale=0):
     return hip.Col(typ, scale, ptr, None, None, 0)
 
 
+def copartitioned_by_order_key(ctx, o_key_range, l_orderkey):
+    """Table statistic of a sharded database (one all-gather of four numbers per rank at load): orders and
+    lineitem are CO-PARTITIONED by order key when the ranks' o_orderkey ranges are pairwise disjoint and every
+    rank's l_orderkey values lie inside its own range (TPC-H tables split by row ranges are). Then
+    lineitem JOIN orders is rank-local — a partition-wise join."""
+    if dist.world() == 1:
+        return False
+    l_lo = int(l_orderkey.min()) if len(l_orderkey) else 0
+    l_hi = int(l_orderkey.max()) if len(l_orderkey) else -1
+    o_lo, o_hi = o_key_range if o_key_range is not None else (0, -1)
+    rec = dist.allgather_records(ctx, np.array([[o_lo, o_hi, l_lo, l_hi]], dtype=np.int64))
+    ranges = sorted((int(a), int(b)) for a, b, _, _ in rec if b >= a)
+    disjoint = all(ranges[i][1] < ranges[i + 1][0] for i in range(len(ranges) - 1))
+    inside = all(int(d) < int(c) or (int(a) <= int(c) and int(d) <= int(b)) for a, b, c, d in rec)
+    return bool(disjoint and inside)
+
+
 class Q3Pipeline:
     """TPC-H Q3 on device-resident customer / orders / lineitem shards.
 
@@ -54,23 +71,12 @@ class Q3Pipeline:
         self.cols = [self.c_key, self.c_seg, self.o_key, self.o_cust, self.o_date, self.o_prio,
                      self.l_key, self.l_ext, self.l_disc, self.l_ship]
         self.revenue_prog = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]
-        # Table statistic of a sharded database (one all-gather of four numbers per rank at load): orders and
-        # lineitem are CO-PARTITIONED by order key when the ranks' o_orderkey ranges are pairwise disjoint and
-        # every rank's l_orderkey values lie inside its own range (TPC-H tables split by row ranges are).
-        # Then lineitem JOIN orders and the group-by on l_orderkey are rank-local — a partition-wise join:
-        # only the customer keys (the small build side) cross the links, and the top-k candidates at the end.
-        self.copartitioned = False
+        # orders and lineitem co-partitioned by order key (see copartitioned_by_order_key): lineitem JOIN orders
+        # and the group-by on l_orderkey are rank-local; only the customer keys (the small build side) cross
+        # the links, and the top-k candidates at the end
         self.allow_partitionwise = True   # False: always the hash-partitioned exchange plan
         self.semijoin_reduce = True       # the exchange plan filters lineitem by the all-gathered qualifying order keys first
-        if dist.world() > 1:
-            l_lo = int(L["l_orderkey"].min()) if self.nl else 0
-            l_hi = int(L["l_orderkey"].max()) if self.nl else -1
-            o_lo, o_hi = self.o_key_range if self.o_key_range is not None else (0, -1)
-            rec = dist.allgather_records(ctx, np.array([[o_lo, o_hi, l_lo, l_hi]], dtype=np.int64))
-            ranges = sorted((int(a), int(b)) for a, b, _, _ in rec if b >= a)
-            disjoint = all(ranges[i][1] < ranges[i + 1][0] for i in range(len(ranges) - 1))
-            inside = all(int(d) < int(c) or (int(a) <= int(c) and int(d) <= int(b)) for a, b, c, d in rec)
-            self.copartitioned = bool(disjoint and inside)
+        self.copartitioned = copartitioned_by_order_key(ctx, self.o_key_range, L["l_orderkey"])
 
     def free(self):
         for c in self.cols:
@@ -408,6 +414,9 @@ class Q9Pipeline:
         self.l_key = D(ctx, hip.PH_I64, L["l_orderkey"])
         # column statistic: lineitem clustered by order key -> the surviving rows reach the orders join in key order
         self.l_key_sorted = bool(self.n["l"] > 1 and np.all(np.diff(L["l_orderkey"]) >= 0))
+        # shards co-partitioned by order key: the one large join, lineitem x orders, needs no exchange
+        self.allow_partitionwise = True
+        self.copartitioned = copartitioned_by_order_key(ctx, self.o_key_range, L["l_orderkey"])
         self.l_part = D(ctx, hip.PH_I32, L["l_partkey"])
         self.l_supp = D(ctx, hip.PH_I32, L["l_suppkey"])
         self.l_qty = D(ctx, hip.PH_I32, L["l_quantity"])
@@ -477,7 +486,8 @@ class Q9Pipeline:
         pipelined = N == 1 and not self.time_stages
         # orders: both sides of the last join are ordered by the key (o_orderkey a primary key in storage order,
         # the intermediate in lineitem order, lineitem clustered by l_orderkey): a merge lookup, no table
-        merge_orders = (strict and N == 1 and self.o_key_sorted_unique and self.l_key_sorted
+        local_orders = N == 1 or (self.copartitioned and self.allow_partitionwise)   # partition-wise join on the order key
+        merge_orders = (strict and local_orders and self.o_key_sorted_unique and self.l_key_sorted
                         and not getattr(self, "no_merge_lookup", False))
         js = jo = None
         if pipelined:
@@ -605,7 +615,7 @@ class Q9Pipeline:
                                       [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL,
                                        hip.X_COL(2), hip.X_COL(3), hip.X_MUL, hip.X_SUB], None, n3)
         frees.append(c_amount)
-        if N == 1:
+        if local_orders:
             # jo: built below on this rank's orders unless the pipelined form already queued it
             o_date = self.o_date.col()
             m = n3

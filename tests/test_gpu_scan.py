@@ -354,7 +354,7 @@ def test_q9_partitioned_two_ranks_on_one_gpu(sf1):
         return ({k: v[l0:l1] for k, v in L.items()}, {k: v[o0:o1] for k, v in Od.items()}, Pr,
                 {k: v[4 * p0:4 * p1] for k, v in PS.items()}, {k: v[s0:s1] for k, v in S.items()})
     grp = pd.ThreadGroup(N)
-    results, errors = [None] * N, []
+    results, local, errors = [None] * N, [None] * N, []
 
     def run(r):
         try:
@@ -362,7 +362,11 @@ def test_q9_partitioned_two_ranks_on_one_gpu(sf1):
             torch.cuda.set_device(0)
             c = hip.Ctx(0)
             p = pipelines.Q9Pipeline(c, *shard(r))
+            assert p.copartitioned
+            p.allow_partitionwise = False      # the order-key stage hash-partitioned and exchanged
             results[r] = p.run()
+            p.allow_partitionwise = True       # ... or rank-local (the shards are co-partitioned by order key)
+            local[r] = p.run()
             p.free()
             c.close()
         except Exception as e:   # noqa: BLE001
@@ -380,6 +384,9 @@ def test_q9_partitioned_two_ranks_on_one_gpu(sf1):
         assert pipelines.q9_text(results[r]["rows"], tpchgen.nation_names()) == golden
     assert results[0]["timings"]["exchange_bytes_sent"] > 0
     assert results[0]["join_rows"] + results[1]["join_rows"] > 300000   # both ranks did real work
+    for r in range(N):   # the partition-wise plan: the same 175 rows, nothing exchanged for the orders join
+        assert pipelines.q9_text(local[r]["rows"], tpchgen.nation_names()) == golden
+        assert "exchange_bytes_sent" not in local[r]["timings"]
 
 
 def test_fused_plan_partials_merge_across_shards(ctx, sf001):
