@@ -2475,6 +2475,99 @@ static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph:
 }
 #undef PH_DIRECT_KS
 
+namespace ph {
+// The mark probe with the table's occupancy bitmap STAGED IN LDS. Every probe row that passes the filter reads
+// one bitmap word at a random position; from L2 that is one request per row, and the L1 -> L2 request path
+// (~140 k requests / us on the whole device, PMC: TCP pending stalls half of the kernel) bounds the plain kernel
+// at 48 us for Q3's 15 M orders rows where the columns stream in 20. One 1024-thread workgroup per CU keeps a
+// 1 Mbit image of the bitmap in LDS: the bitmap itself when it has at most 2^20 bits, else its words FOLDED
+// (image word w = OR of bitmap words w, w + 32768, ...): a clear image bit answers "absent", a set one is
+// confirmed in the real bitmap (L2) only when the image is folded. Waves work alone on 512-row sub-blocks.
+template <int KW, int WK>
+__global__ __launch_bounds__(1024) void direct_mark_where_lds_kernel(const void *__restrict__ keycol, int64_t n, long long lo, unsigned long long range,
+                                                                     const unsigned *__restrict__ dbits, int64_t dwords,
+                                                                     const void *__restrict__ wdata, long long wlo, long long whi,
+                                                                     uint8_t *__restrict__ found) {
+    extern __shared__ unsigned mw_img[];   // CO_WORDS words
+    constexpr int R = 16 / KW, G = 8 / R;
+    const bool folded = dwords > CO_WORDS;
+    {   // 32 image words per thread, their reads issued together (a word-by-word loop is 64 dependent L2 latencies: 45 us)
+        unsigned v[CO_WORDS / 1024];
+#pragma unroll
+        for (int q = 0; q < CO_WORDS / 1024; q++) v[q] = 0;
+        for (int64_t fold = 0; fold < dwords; fold += CO_WORDS) {
+#pragma unroll
+            for (int q = 0; q < CO_WORDS / 1024; q++) {
+                const int64_t x = fold + q * 1024 + threadIdx.x;
+                v[q] |= x < dwords ? dbits[x] : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CO_WORDS / 1024; q++) mw_img[q * 1024 + threadIdx.x] = v[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nsub = (n + 511) / 512;
+    // two sub-blocks of a wave in flight: their key / filter reads are issued together, then their bitmap tests,
+    // then their confirmations (one wave per SIMD x 4 has little else to hide a memory round trip behind)
+    constexpr int NB = 2;   // (four: no faster, 40 vs 39 us)
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    for (int64_t sb0 = (int64_t)blockIdx.x * 16 + wave; sb0 < nsub; sb0 += stride * NB) {
+        long long k[NB][8], k2[8];
+        bool ok[NB][8];
+        unsigned long long off[NB][8];
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int64_t sb = sb0 + u * stride;
+            const bool have = sb < nsub;
+            const int64_t row0 = have ? sb * 512 : 0;
+            dc_block_keys<KW, WK, 1>(keycol, nullptr, wdata, wlo, whi, row0, lane, have && row0 + 512 <= n, have, n, k[u], k2, ok[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                ok[u][s] = direct_slot<KW>(k[u][s], lo, range, &off[u][s]) && ok[u][s];
+                const unsigned b = ok[u][s] ? (unsigned)off[u][s] & (CO_WORDS * 32 - 1) : 0u;
+                ok[u][s] = ok[u][s] && ((mw_img[b >> 5] >> (b & 31)) & 1u);
+            }
+        if (folded) {   // confirm the survivors in the real bitmap
+            unsigned wd[NB][8];
+#pragma unroll
+            for (int u = 0; u < NB; u++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) wd[u][s] = dbits[ok[u][s] ? off[u][s] >> 5 : 0];
+#pragma unroll
+            for (int u = 0; u < NB; u++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) ok[u][s] = ok[u][s] && ((wd[u][s] >> (off[u][s] & 31)) & 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int64_t sb = sb0 + u * stride;
+            if (sb >= nsub) break;   // wave-uniform
+            const int64_t row0 = sb * 512;
+            const bool full = row0 + 512 <= n;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int64_t row = row0 + (int64_t)(g * 64 + lane) * R;
+                if (full) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int e = 0; e < R; e++) w |= (ok[u][g * R + e] ? 1u : 0u) << (8 * e);
+                    if (R == 4) *reinterpret_cast<unsigned *>(found + row) = w;
+                    else *reinterpret_cast<unsigned short *>(found + row) = (unsigned short)w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < R; e++)
+                        if (row + e < n) found[row + e] = ok[u][g * R + e] ? 1 : 0;
+                }
+            }
+        }
+    }
+}
+}  // namespace ph
+
 static bool direct_probe_ok(const ph_join *j, const ph::JoinSide &P) {
     auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
     return P.nkeys == 1 && width(P.key[0].type) == j->dkw;
@@ -2971,6 +3064,24 @@ extern "C" int ph_join_probe_mark_where(ph_join *j, const ph_col *keys, const ph
     ph_ctx *ctx = j->ctx;
     if (j->build.n == 0) { PH_HIP(hipMemsetAsync(found_dev, 0, (size_t)n, ctx->stream)); return PH_OK; }
     const int nb = (int)((n + ph::JP_CHUNK - 1) / ph::JP_CHUNK);
+    const char *mle = getenv("PH_JOIN_MARK_LDS");   // read per call: the test marks both ways in one process
+    if (j->dbits && !(mle && atoi(mle) == 0) && n >= (1 << 20) && j->drange <= (8ull << 20)) {
+        // big probe side, bitmap of at most 8 Mbit: the LDS-staged (folded) image, one workgroup per CU
+        const int64_t dwords = (int64_t)((j->drange + 31) / 32);
+        const size_t lds = (size_t)ph::CO_WORDS * 4;
+        const int grid = ctx->cu_count;
+#define PH_MWL(KWV, WKV)                                                                                                                   \
+    do {                                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)ph::direct_mark_where_lds_kernel<KWV, WKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        ph::direct_mark_where_lds_kernel<KWV, WKV><<<grid, 1024, lds, ctx->stream>>>(P.key[0].data, n, (long long)j->dlo, j->drange, j->dbits, dwords, \
+                                                                                      w.data, w.lo, w.hi, found_dev);                      \
+    } while (0)
+        if (j->dkw == 4) { if (w.kind == 1) PH_MWL(4, 1); else if (w.kind == 2) PH_MWL(4, 2); else PH_MWL(4, 3); }
+        else { if (w.kind == 1) PH_MWL(8, 1); else if (w.kind == 2) PH_MWL(8, 2); else PH_MWL(8, 3); }
+#undef PH_MWL
+        PH_HIP(hipGetLastError());
+        return PH_OK;
+    }
 #define PH_MW(KWV, WKV) ph::direct_mark_where_kernel<KWV, WKV><<<nb, 256, 0, ctx->stream>>>(P.key[0].data, n, (long long)j->dlo, j->drange, j->direct, j->dbits, (int32_t)j->build.n, w.data, w.lo, w.hi, found_dev)
     if (j->dkw == 4) { if (w.kind == 1) PH_MW(4, 1); else if (w.kind == 2) PH_MW(4, 2); else PH_MW(4, 3); }
     else { if (w.kind == 1) PH_MW(8, 1); else if (w.kind == 2) PH_MW(8, 2); else PH_MW(8, 3); }

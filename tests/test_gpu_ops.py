@@ -940,6 +940,37 @@ def test_async_counts(ctx):
     j.free(); dv.free(); dbk.free()
 
 
+def test_join_mark_where_lds_staged_bitmap(ctx, monkeypatch):
+    """Big probe sides run ph_join_probe_mark_where with the occupancy bitmap staged in LDS: the bitmap itself
+    (range <= 2^20 slots) or its folded image confirmed in L2 (here 1.5 M and 5 M slots); the flags equal the plain
+    kernel's (PH_JOIN_MARK_LDS=0) and numpy, 4- and 8-byte keys, a ragged tail, keys outside the range."""
+    rng = np.random.default_rng(103)
+    no = 1_500_037
+    odate = rng.integers(9000, 9200, no).astype(np.int32)
+    dodate = hip.DevColumn(ctx, hip.PH_DATE, odate)
+    cut = hip.const(hip.PH_DATE, i=9100)
+    for dt, ht, span in ((np.int32, hip.PH_I32, 900_000), (np.int32, hip.PH_I32, 1_500_000), (np.int64, hip.PH_I64, 5_000_000)):
+        nc = span // 5
+        ckeys = np.sort(rng.choice(span, nc, replace=False) + 1).astype(dt)
+        dck = hip.DevColumn(ctx, ht, ckeys)
+        jc = hip.Join(ctx, [dck], None, nc, key_range=(1, span))
+        assert jc.kind == "direct"
+        ocust = rng.integers(-3, span + 40, no).astype(dt)
+        docust = hip.DevColumn(ctx, ht, ocust)
+        f = jc.probe_mark_where([docust], dodate, hip.PH_LT, cut, no)
+        assert f is not None
+        got = ctx.download(f, np.uint8, no)
+        monkeypatch.setenv("PH_JOIN_MARK_LDS", "0")
+        f0 = jc.probe_mark_where([docust], dodate, hip.PH_LT, cut, no)
+        monkeypatch.delenv("PH_JOIN_MARK_LDS")
+        plain = ctx.download(f0, np.uint8, no)
+        want = (np.isin(ocust, ckeys) & (odate < 9100)).astype(np.uint8)
+        assert np.array_equal(got, want) and np.array_equal(plain, want) and 50_000 < want.sum() < no // 4
+        ctx.free(f); ctx.free(f0)
+        jc.free(); dck.free(); docust.free()
+    dodate.free()
+
+
 def test_join_mark_where_and_residual_probe(ctx):
     """ph_join_probe_mark_where (Filter -> semi-join mark in one pass) equals filter_select + probe_mark,
     and ph_join_probe_inner_residual over a table built on ALL rows equals the inner probe of a table
