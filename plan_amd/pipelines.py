@@ -406,6 +406,7 @@ class Q9Pipeline:
         self.s_key = D(ctx, hip.PH_I32, S["s_suppkey"])
         # column statistics: dense primary keys (supplier, orders) build direct tables
         self.s_key_range = (int(S["s_suppkey"].min()), int(S["s_suppkey"].max())) if self.n["s"] else None
+        self.s_key_sorted_unique = bool(self.n["s"] > 1 and np.all(np.diff(S["s_suppkey"]) > 0))
         self.o_key_range = (int(O["o_orderkey"].min()), int(O["o_orderkey"].max())) if self.n["o"] else None
         self.o_key_sorted_unique = bool(self.n["o"] > 1 and np.all(np.diff(O["o_orderkey"]) > 0))
         self.s_nat = D(ctx, hip.PH_I32, S["s_nationkey"])
@@ -494,7 +495,7 @@ class Q9Pipeline:
             ctx.set_async_counts(True)
             psel, np_c = hip.filter_select(ctx, self.p_name, self.n["p"], hip.PH_LIKE, hip.const(hip.PH_STR, s=self.pattern), defer=True)
             self._counts = [np_c]
-            js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range)
+            js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range, sorted_unique=strict and self.s_key_sorted_unique)
             if not merge_orders:
                 jo = hip.Join(ctx, [self.o_key], None, self.n["o"], key_range=self.o_key_range, sorted_unique=strict and self.o_key_sorted_unique)
             ctx.wait_counts()
@@ -578,7 +579,7 @@ class Q9Pipeline:
         t0 = tic()
         if N == 1:
             if js is None:
-                js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range)
+                js = hip.Join(ctx, [self.s_key], None, self.n["s"], key_range=self.s_key_range, sorted_unique=strict and self.s_key_sorted_unique)
             s_nat = self.s_nat
         else:
             ident = ctx.upload(np.arange(self.n["s"], dtype=np.int32))

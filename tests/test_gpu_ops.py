@@ -837,6 +837,42 @@ def test_merge_lookup_equals_table_lookup(ctx):
             c.free()
 
 
+def test_join_small_dense_table_declared_sorted_unique(ctx):
+    """A small dense table (a dimension's primary key: 100 k rows) over keys declared sorted and unique is built by
+    the gated sorted fill with an always-true gate (no atomics): lookups, marks, pairs and the count equal the
+    undeclared build (direct_small_kernel); 4- and 8-byte keys; a false claim is the deferred PH_ECONSTRAINT."""
+    rng = np.random.default_rng(109)
+    n = 100_000
+    for dt, typ in ((np.int32, hip.PH_I32), (np.int64, hip.PH_I64)):
+        keys = (np.sort(rng.choice(3 * n, n, replace=False)) + 11).astype(dt)   # 3 slots per row
+        rngk = (11, 3 * n + 10)
+        p = rng.integers(0, 3 * n + 40, 700_000).astype(dt)
+        dk, dp = hip.DevColumn(ctx, typ, keys), hip.DevColumn(ctx, typ, p)
+        jd = hip.Join(ctx, [dk], None, n, key_range=rngk, sorted_unique=True)
+        ju = hip.Join(ctx, [dk], None, n, key_range=rngk)
+        assert jd.kind == ju.kind == "direct" and jd.count() == ju.count() == n
+        a = ctx.download(jd.lookup([dp], None, len(p)), np.int32, len(p))
+        b = ctx.download(ju.lookup([dp], None, len(p)), np.int32, len(p))
+        assert np.array_equal(a, b) and 200_000 < (a >= 0).sum() < 260_000
+        assert np.array_equal(ctx.download(jd.probe_mark([dp], None, len(p)), np.uint8, len(p)) != 0, a >= 0)
+        md, pd_, bd = jd.probe_inner([dp], None, len(p), len(p))
+        assert md == int((a >= 0).sum()) and np.array_equal(ctx.download(bd, np.int32, md), a[a >= 0])
+        ctx.check_deferred()
+        jd.free(); ju.free()
+        bad = keys.copy(); bad[40_000], bad[40_001] = keys[40_001], keys[40_000]
+        dbad = hip.DevColumn(ctx, typ, bad)
+        jb = hip.Join(ctx, [dbad], None, n, key_range=rngk, sorted_unique=True)
+        r = jb.lookup([dp], None, len(p))
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.download(r, np.int32, 4)
+        assert e.value.code == hip.PH_ECONSTRAINT
+        jb.free()
+        for x in (pd_, bd):
+            ctx.free(x)
+        for c in (dk, dp, dbad):
+            c.free()
+
+
 def test_join_build_where_equals_filter_then_build(ctx):
     """ph_join_build_where (Filter -> build fused into a direct table): pairs, marks, lookups and the
     row count equal ph_filter_select + ph_join_build_range over the same rows (build row ids are rows
