@@ -2,6 +2,8 @@
 types, NULLs, selections, aggregate mixes, cardinalities and sizes on both sides of the thresholds
 that switch kernels (LDS pre-aggregation / bulk build at 64 K rows with a high hint; atomic /
 partitioned join build at 128 K rows; Bloom bitmap up to 4 M keys; one- and two-key fast kernels)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from plan_amd import hip
 from test_gpu_ops import agg_compare, join_compare, rnd_validity
 
 pytestmark = pytest.mark.gpu
+SEED_BASE = int(os.environ.get("PH_TEST_SEED_BASE", "0"))   # soak runs: other seeds through the same shapes
 
 
 @pytest.fixture(scope="module")
@@ -24,7 +27,7 @@ KEY_TYPES = [(hip.PH_I32, O.OT_INT32, np.int32), (hip.PH_I64, O.OT_INT64, np.int
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_aggregates(ctx, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + SEED_BASE + seed)
     n = int(rng.choice([300, 5_000, 70_000, 150_000, 400_000]))
     nk = int(rng.integers(1, 4))
     card = int(rng.choice([1, 3, 40, 2_000, 60_000]))
@@ -50,7 +53,7 @@ def test_random_aggregates(ctx, seed):
 
 @pytest.mark.parametrize("seed", range(10))
 def test_random_joins(ctx, seed):
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + SEED_BASE + seed)
     nb = int(rng.choice([50, 20_000, 140_000, 300_000]))
     np_ = int(rng.choice([1_000, 90_000, 500_000]))
     nk = int(rng.integers(1, 3))
