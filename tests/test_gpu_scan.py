@@ -161,6 +161,34 @@ def test_q3_pipeline_sf1_matches_reference_golden(ctx, sf1):
     assert pipelines.q3_text(r["top"]) == golden
 
 
+@pytest.mark.parametrize("segment,ymd", [("AUTOMOBILE", (1994, 1, 1)), ("FURNITURE", (1992, 2, 1)), ("HOUSEHOLD", (1998, 12, 1)),
+                                         ("NOSUCHSEGMENT", (1995, 3, 15))])
+def test_q3_pipeline_other_parameters_match_oracle(ctx, sf1, segment, ymd):
+    """Q3 with other segments and cut-off dates than the golden's (other selectivities of both build-side gates,
+    an empty result, a segment that is not in the dictionary): the top 10 equal the oracle's text."""
+    from plan_amd import pipelines
+    date = tpchgen.days(*ymd)
+    p = pipelines.Q3Pipeline(ctx, sf1["lineitem"], sf1["orders"], sf1["customer"], segment=segment, date=date)
+    p.time_stages = False
+    r = p.run()
+    p.free()
+    n, rows = O.q3(sf1, segment, date)
+    assert pipelines.q3_text(r["top"]) == O.q3_text(rows, n)
+
+
+@pytest.mark.parametrize("pattern", ["%green%", "%zzzz%", "%a%"])
+def test_q9_pipeline_other_patterns_match_oracle(ctx, sf1, pattern):
+    """Q9 with other LIKE patterns: a different 5 % of the parts, no part at all, and 95 % of them (the part side
+    then takes other table forms and probe kernels than the golden run's)."""
+    from plan_amd import pipelines
+    p = pipelines.Q9Pipeline(ctx, sf1["lineitem"], sf1["orders"], sf1["part"], sf1["partsupp"], sf1["supplier"], pattern=pattern)
+    p.time_stages = False
+    r = p.run()
+    p.free()
+    n, rows = O.q9(sf1, pattern)
+    assert pipelines.q9_text(r["rows"], tpchgen.nation_names()) == O.q9_text(rows, n, tpchgen.nation_names())
+
+
 def test_q3_partitioned_two_ranks_on_one_gpu(sf1):
     """The N>1 form of Q3 (broadcast customer keys, hash-partition orders' and lineitem rows by
     order key, exchange, local build/probe/aggregate, top-10 merge) with 2 ranks run as 2 threads
