@@ -480,7 +480,7 @@ def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
                                   "all run within 8 % of each other",
                              whole_query={"algorithmic_bytes": inputs, "achieved": inputs / (ms_step * 1e-3) / 1e9,
                                           "frac": inputs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "timing": "host clock around the timed steps (one query = ~45 launches)"}),
+                                          "timing": "host clock around the timed steps (one query = ~38 launches)"}),
     }
     pipe.free()
     return line
