@@ -61,7 +61,12 @@ int ph_ctx_sync(ph_ctx *ctx);
  * returns the deferred error (PH_EOVERFLOW / PH_ECONSTRAINT, ph_last_error names the origin)
  * instead of its own success: everything computed since the failing call must be discarded, which
  * is what a query does with PH_EOVERFLOW anyway (it falls back as a whole). Off by default: every
- * call then reports its own errors, like the reference's operators do per chunk. */
+ * call then reports its own errors, like the reference's operators do per chunk.
+ * `on` == 2 HOLDS deferred errors: no ordinary read-back reports them, only ph_ctx_check_deferred does.
+ * That is the mode of a query that runs over several ranks: a rank must not leave the sequence of
+ * collectives in the middle because of an error only it has seen (its peers would block in the next
+ * collective) — it runs to the end, checks, and the ranks agree on the outcome (one small all-reduce)
+ * before any of them reruns the query. The ph_comm_* calls never report a deferred error. */
 int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on);
 /* Asynchronous counts. With `on` != 0 the calls that hand a row count back to the host
  * (ph_filter_select's *n_out, ph_join_probe_inner*'s *n_out) return as soon as their kernels and an
@@ -574,6 +579,12 @@ int ph_comm_exchange_columns(ph_comm *c, int32_t ncols, const void *const *send_
  * counts_host is valid then) */
 int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
                            int64_t recv_capacity, int64_t *counts_host);
+/* The capacity test above is collective: the ranks exchange (count, capacity) pairs and either ALL return
+ * PH_ECAPACITY (the total exceeds the smallest capacity) or all exchange — no rank leaves alone. This form needs
+ * no capacity at all: the library allocates exactly the total (*recv_dev_out, from ph_dev_alloc's pool; free it
+ * with ph_dev_free). */
+int ph_comm_allgather_rows_alloc(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void **recv_dev_out,
+                                 int64_t *counts_host);
 
 /* ------------------------------------------------------------------ measurement
  * streaming-read ceiling: a read-only reduce over `bytes` of device memory with the fused scan

@@ -68,7 +68,7 @@ extern "C" int ph_comm_init(ph_ctx *ctx, int32_t nranks, int32_t rank, const voi
         hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->done[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->done[3], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->dev_words, ((size_t)nranks * nranks + 64) * 8) != hipSuccess) {
+        hipMalloc((void **)&c->dev_words, ((size_t)nranks * nranks + 2 * (size_t)nranks + 64) * 8) != hipSuccess) {
         ph::set_error("ph_comm_init: stream/event/scratch creation failed");
         ph_comm_destroy(c);
         return PH_EHIP;
@@ -133,7 +133,7 @@ extern "C" int ph_comm_allreduce_i64(ph_comm *c, int64_t *host_vals, int32_t n, 
     PH_HIP(hipMemcpyAsync(d, host_vals, (size_t)n * 8, hipMemcpyHostToDevice, st));
     ncclRedOp_t rop = op == PH_RED_SUM ? ncclSum : op == PH_RED_MAX ? ncclMax : ncclMin;
     PH_NCCL(ncclAllReduce(d, d, (size_t)n, ncclInt64, rop, c->comm, st));
-    return c->ctx->download(host_vals, d, (int64_t)n * 8);
+    return c->ctx->download_plain(host_vals, d, (int64_t)n * 8);
 }
 
 extern "C" int ph_comm_barrier(ph_comm *c) {
@@ -145,7 +145,7 @@ extern "C" int ph_comm_exchange_counts(ph_comm *c, const int64_t *send_counts_de
     PH_REQUIRE(c && send_counts_dev && matrix_host, "ph_comm_exchange_counts: bad arguments");
     PH_CHECK(ph_comm_wait(c));
     PH_NCCL(ncclAllGather(send_counts_dev, c->dev_words, (size_t)c->nranks, ncclInt64, c->comm, c->ctx->stream));
-    return c->ctx->download(matrix_host, c->dev_words, (int64_t)c->nranks * c->nranks * 8);   // the stage's one round trip
+    return c->ctx->download_plain(matrix_host, c->dev_words, (int64_t)c->nranks * c->nranks * 8);   // the stage's one round trip
 }
 
 extern "C" int ph_exchange_layout(const int64_t *matrix, int32_t nranks, int32_t rank, int64_t *send_off, int64_t *recv_off) {
@@ -160,27 +160,33 @@ extern "C" int ph_exchange_layout(const int64_t *matrix, int32_t nranks, int32_t
     return PH_OK;
 }
 
+// Inside ncclGroupStart/End every rank must make the same calls: a rank that returned early would leave its peers
+// blocked in the group. So everything that can fail by ARGUMENT (pointers, widths, the matrix) is validated first —
+// from values that are identical on all ranks or local — the group holds nothing but the sends and receives, and
+// the own-rows device copy comes after it.
 extern "C" int ph_comm_exchange_columns(ph_comm *c, int32_t ncols, const void *const *send_dev, void *const *recv_dev,
                                         const int32_t *elem_bytes, const int64_t *matrix_host) {
     PH_REQUIRE(c && ncols >= 0 && (ncols == 0 || (send_dev && recv_dev && elem_bytes)) && matrix_host,
                "ph_comm_exchange_columns: bad arguments");
-    PH_CHECK(ph_comm_wait(c));
     std::vector<int64_t> so((size_t)c->nranks + 1), ro((size_t)c->nranks + 1);
     PH_CHECK(ph_exchange_layout(matrix_host, c->nranks, c->rank, so.data(), ro.data()));
+    for (int32_t k = 0; k < ncols; k++) {
+        PH_REQUIRE(elem_bytes[k] > 0, "ph_comm_exchange_columns: column %d has element width %d", k, elem_bytes[k]);
+        PH_REQUIRE(so[(size_t)c->nranks] == 0 || send_dev[k], "ph_comm_exchange_columns: send buffer %d is NULL", k);
+        PH_REQUIRE(ro[(size_t)c->nranks] == 0 || recv_dev[k], "ph_comm_exchange_columns: receive buffer %d is NULL", k);
+    }
+    PH_CHECK(ph_comm_wait(c));
     hipStream_t st = c->ctx->stream;
     PH_NCCL(ncclGroupStart());
     ncclResult_t bad = ncclSuccess;
-    for (int32_t k = 0; k < ncols && bad == ncclSuccess; k++) {
+    for (int32_t k = 0; k < ncols; k++) {
         const int64_t w = elem_bytes[k];
-        for (int r = 0; r < c->nranks && bad == ncclSuccess; r++) {
+        for (int r = 0; r < c->nranks; r++) {
+            if (r == c->rank) continue;
             const int64_t ns = so[(size_t)r + 1] - so[(size_t)r], nr = ro[(size_t)r + 1] - ro[(size_t)r];
-            if (r == c->rank) {   // own rows: a device copy, no link involved
-                if (ns > 0 && hipMemcpyAsync((char *)recv_dev[k] + ro[(size_t)r] * w, (const char *)send_dev[k] + so[(size_t)r] * w,
-                                             (size_t)(ns * w), hipMemcpyDeviceToDevice, st) != hipSuccess) bad = ncclUnhandledCudaError;
-                continue;
-            }
-            if (ns > 0) bad = ncclSend((const char *)send_dev[k] + so[(size_t)r] * w, (size_t)(ns * w), ncclChar, r, c->comm, st);
-            if (nr > 0 && bad == ncclSuccess) bad = ncclRecv((char *)recv_dev[k] + ro[(size_t)r] * w, (size_t)(nr * w), ncclChar, r, c->comm, st);
+            // a failing call is remembered, the remaining calls are still made: the group stays symmetric
+            if (ns > 0) { ncclResult_t e = ncclSend((const char *)send_dev[k] + so[(size_t)r] * w, (size_t)(ns * w), ncclChar, r, c->comm, st); if (bad == ncclSuccess) bad = e; }
+            if (nr > 0) { ncclResult_t e = ncclRecv((char *)recv_dev[k] + ro[(size_t)r] * w, (size_t)(nr * w), ncclChar, r, c->comm, st); if (bad == ncclSuccess) bad = e; }
         }
     }
     ncclResult_t endr = ncclGroupEnd();
@@ -188,35 +194,29 @@ extern "C" int ph_comm_exchange_columns(ph_comm *c, int32_t ncols, const void *c
         ph::set_error("ph_comm_exchange_columns: %s", ncclGetErrorString(bad != ncclSuccess ? bad : endr));
         return PH_EHIP;
     }
+    const int me = c->rank;   // own rows: a device copy, no link involved
+    const int64_t ns = so[(size_t)me + 1] - so[(size_t)me];
+    for (int32_t k = 0; k < ncols && ns > 0; k++) {
+        const int64_t w = elem_bytes[k];
+        PH_HIP(hipMemcpyAsync((char *)recv_dev[k] + ro[(size_t)me] * w, (const char *)send_dev[k] + so[(size_t)me] * w, (size_t)(ns * w),
+                              hipMemcpyDeviceToDevice, st));
+    }
     return PH_OK;
 }
 
-extern "C" int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
-                                      int64_t recv_capacity, int64_t *counts_host) {
-    PH_REQUIRE(c && count >= 0 && elem_bytes > 0 && counts_host && (count == 0 || send_dev), "ph_comm_allgather_rows: bad arguments");
-    PH_CHECK(ph_comm_wait(c));
+// The rows of every rank behind the counts: one group of send/recv pairs (counts identical on all ranks)
+static int allgather_rows_group(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
+                                const int64_t *counts) {
     hipStream_t st = c->ctx->stream;
-    int64_t *d = c->dev_words;
-    PH_HIP(hipMemcpyAsync(d + c->nranks, &count, 8, hipMemcpyHostToDevice, st));
-    PH_NCCL(ncclAllGather(d + c->nranks, d, 1, ncclInt64, c->comm, st));
-    PH_CHECK(c->ctx->download(counts_host, d, (int64_t)c->nranks * 8));
-    int64_t total = 0;
-    for (int r = 0; r < c->nranks; r++) total += counts_host[r];
-    if (total > recv_capacity) { ph::set_error("ph_comm_allgather_rows: %lld rows, room for %lld", (long long)total, (long long)recv_capacity); return PH_ECAPACITY; }
-    if (total == 0) return PH_OK;
-    PH_REQUIRE(recv_dev != nullptr, "ph_comm_allgather_rows: recv_dev is NULL");
-    // every rank sends its rows to every other rank; one group, all peer pairs concurrently
     PH_NCCL(ncclGroupStart());
     ncclResult_t bad = ncclSuccess;
-    int64_t off = 0;
-    for (int r = 0; r < c->nranks && bad == ncclSuccess; r++) {
-        const int64_t nr = counts_host[r];
-        if (r == c->rank) {
-            if (nr > 0 && hipMemcpyAsync((char *)recv_dev + off * elem_bytes, send_dev, (size_t)(nr * elem_bytes),
-                                         hipMemcpyDeviceToDevice, st) != hipSuccess) bad = ncclUnhandledCudaError;
-        } else {
-            if (count > 0) bad = ncclSend(send_dev, (size_t)(count * elem_bytes), ncclChar, r, c->comm, st);
-            if (nr > 0 && bad == ncclSuccess) bad = ncclRecv((char *)recv_dev + off * elem_bytes, (size_t)(nr * elem_bytes), ncclChar, r, c->comm, st);
+    int64_t off = 0, own_off = 0;
+    for (int r = 0; r < c->nranks; r++) {
+        const int64_t nr = counts[r];
+        if (r == c->rank) own_off = off;
+        else {
+            if (count > 0) { ncclResult_t e = ncclSend(send_dev, (size_t)(count * elem_bytes), ncclChar, r, c->comm, st); if (bad == ncclSuccess) bad = e; }
+            if (nr > 0) { ncclResult_t e = ncclRecv((char *)recv_dev + off * elem_bytes, (size_t)(nr * elem_bytes), ncclChar, r, c->comm, st); if (bad == ncclSuccess) bad = e; }
         }
         off += nr;
     }
@@ -225,5 +225,54 @@ extern "C" int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t 
         ph::set_error("ph_comm_allgather_rows: %s", ncclGetErrorString(bad != ncclSuccess ? bad : endr));
         return PH_EHIP;
     }
+    if (count > 0)
+        PH_HIP(hipMemcpyAsync((char *)recv_dev + own_off * elem_bytes, send_dev, (size_t)(count * elem_bytes), hipMemcpyDeviceToDevice, st));
     return PH_OK;
+}
+
+// The capacity decision is COLLECTIVE: every rank contributes (count, capacity), and the rows are exchanged only
+// when the total fits the SMALLEST capacity — otherwise every rank returns PH_ECAPACITY, together, with the
+// counts filled in, and nobody has entered the send/recv group. (Round 2 decided per rank: a rank with a small
+// local count sized its buffer too small, left with PH_ECAPACITY, and its peers blocked in the group.)
+extern "C" int ph_comm_allgather_rows(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void *recv_dev,
+                                      int64_t recv_capacity, int64_t *counts_host) {
+    PH_REQUIRE(c && count >= 0 && elem_bytes > 0 && counts_host && (count == 0 || send_dev) && recv_capacity >= 0 &&
+               (recv_capacity == 0 || recv_dev), "ph_comm_allgather_rows: bad arguments");
+    PH_CHECK(ph_comm_wait(c));
+    hipStream_t st = c->ctx->stream;
+    int64_t *d = c->dev_words;   // [0, 2 n): every rank's (count, capacity); [2 n, 2 n + 2): this rank's pair
+    const int64_t mine[2] = {count, recv_capacity};
+    PH_HIP(hipMemcpyAsync(d + 2 * c->nranks, mine, 16, hipMemcpyHostToDevice, st));
+    PH_NCCL(ncclAllGather(d + 2 * c->nranks, d, 2, ncclInt64, c->comm, st));
+    std::vector<int64_t> pairs((size_t)c->nranks * 2);
+    PH_CHECK(c->ctx->download_plain(pairs.data(), d, (int64_t)c->nranks * 16));
+    int64_t total = 0, mincap = INT64_MAX;
+    for (int r = 0; r < c->nranks; r++) { counts_host[r] = pairs[(size_t)r * 2]; total += counts_host[r]; mincap = std::min(mincap, pairs[(size_t)r * 2 + 1]); }
+    if (total > mincap) {
+        ph::set_error("ph_comm_allgather_rows: %lld rows in total, the smallest receive capacity over the ranks is %lld",
+                      (long long)total, (long long)mincap);
+        return PH_ECAPACITY;
+    }
+    if (total == 0) return PH_OK;
+    return allgather_rows_group(c, send_dev, count, elem_bytes, recv_dev, counts_host);
+}
+
+// ... and the form that cannot run out of room: the library allocates exactly the total (ph_dev_alloc's pool; the
+// caller frees with ph_dev_free). *recv_dev_out is a valid (possibly 1-row) allocation even when the total is 0.
+extern "C" int ph_comm_allgather_rows_alloc(ph_comm *c, const void *send_dev, int64_t count, int32_t elem_bytes, void **recv_dev_out,
+                                            int64_t *counts_host) {
+    PH_REQUIRE(c && count >= 0 && elem_bytes > 0 && counts_host && recv_dev_out && (count == 0 || send_dev),
+               "ph_comm_allgather_rows_alloc: bad arguments");
+    PH_CHECK(ph_comm_wait(c));
+    hipStream_t st = c->ctx->stream;
+    int64_t *d = c->dev_words;
+    PH_HIP(hipMemcpyAsync(d + c->nranks, &count, 8, hipMemcpyHostToDevice, st));
+    PH_NCCL(ncclAllGather(d + c->nranks, d, 1, ncclInt64, c->comm, st));
+    PH_CHECK(c->ctx->download_plain(counts_host, d, (int64_t)c->nranks * 8));
+    int64_t total = 0;
+    for (int r = 0; r < c->nranks; r++) total += counts_host[r];
+    // an allocation failure here is local, but it is a failure of the process (out of device memory), not a retry path
+    PH_CHECK(ph_dev_alloc(c->ctx, std::max<int64_t>(total, 1) * elem_bytes, recv_dev_out));
+    if (total == 0) return PH_OK;
+    return allgather_rows_group(c, send_dev, count, elem_bytes, *recv_dev_out, counts_host);
 }

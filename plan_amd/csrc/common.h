@@ -89,7 +89,12 @@ struct ph_ctx {
     int64_t scan_tiles = 0;
     unsigned scan_ticket_base = 0;
     unsigned long long scan_epoch = 0;
-    int download(void *host, const void *dev, int64_t bytes);
+    // with_deferred: also fetch (and report) a pending deferred error in the same synchronisation — unless the ctx
+    // HOLDS deferred errors (ph_ctx_set_deferred_errors(ctx, 2)): then only ph_ctx_check_deferred reports them
+    int download(void *host, const void *dev, int64_t bytes, bool with_deferred = true);
+    // a read-back that never reports a deferred error (the multi-GPU collectives' count downloads: a rank that left a
+    // collective sequence early with ITS deferred error would leave its peers blocked in the next collective)
+    int download_plain(void *host, const void *dev, int64_t bytes) { return download(host, dev, bytes, false); }
     // Deferred errors (ph_ctx_set_deferred_errors): device words that kernels of calls which would
     // otherwise read a flag back (ph_expr_eval's overflow flag, ph_join_lookup_strict's miss / multi-
     // match counts) OR / add into; the next download() of this ctx fetches them in the same stream
@@ -108,7 +113,7 @@ struct ph_ctx {
     int download_count(int64_t *host, const void *dev, int64_t cap, const char *what);
     int wait_counts();
     int *deferred_dev = nullptr;
-    bool defer_errors = false, deferred_pending = false;
+    bool defer_errors = false, deferred_pending = false, defer_hold = false;
     int deferred_words(int **out);   // allocates (zeroed) on first use
     int finish_deferred();           // after a sync that also copied the words into the mailbox tail
     // Stream-ordered device memory pool: freed blocks are reused by later allocations of the

@@ -131,7 +131,7 @@ int ph_ctx::publish(const void *dev, int64_t bytes, bool with_deferred) {
     return poll_flag(flag, seq, stream);
 }
 
-int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
+int ph_ctx::download(void *host, const void *dev, int64_t bytes, bool with_deferred) {
     if (bytes <= 0) return PH_OK;
     const int64_t MB = PH_MAILBOX;
     if (!mailbox) {
@@ -139,7 +139,7 @@ int ph_ctx::download(void *host, const void *dev, int64_t bytes) {
         memset((char *)mailbox + MB, 0, 128);
         PH_HIP(hipHostGetDevicePointer(&mailbox_dev, mailbox, 0));
     }
-    const bool chk = deferred_pending && deferred_dev;
+    const bool chk = with_deferred && !defer_hold && deferred_pending && deferred_dev;
     static const bool no_publish = getenv("PH_NO_PUBLISH") != nullptr;   // A/B switch: copy command + stream synchronisation
     if (bytes <= MB && !no_publish) {
         PH_CHECK(publish(dev, bytes, chk));
@@ -235,6 +235,7 @@ extern "C" int ph_ctx_wait_counts(ph_ctx *ctx) {
 extern "C" int ph_ctx_set_deferred_errors(ph_ctx *ctx, int32_t on) {
     PH_REQUIRE(ctx, "ph_ctx_set_deferred_errors: ctx is NULL");
     ctx->defer_errors = on != 0;
+    ctx->defer_hold = on == 2;
     return PH_OK;
 }
 
@@ -242,7 +243,11 @@ extern "C" int ph_ctx_check_deferred(ph_ctx *ctx) {
     PH_REQUIRE(ctx, "ph_ctx_check_deferred: ctx is NULL");
     if (!ctx->deferred_pending || !ctx->deferred_dev) return PH_OK;
     int d[4];
-    return ctx->download(d, ctx->deferred_dev, 16);
+    const bool hold = ctx->defer_hold;
+    ctx->defer_hold = false;   // this IS the call that reports a held error
+    const int rc = ctx->download(d, ctx->deferred_dev, 16);
+    ctx->defer_hold = hold;
+    return rc;
 }
 
 int ph_ctx::pool_alloc(int64_t bytes, void **out) {

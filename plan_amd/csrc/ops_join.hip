@@ -1564,8 +1564,12 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
             // (a chunk that breaks the claim raises the deferred error; what it wrote stays inside the table
             // and the table is void anyway), only occupied slots are written, straight to the table, and the
             // occupancy words are composed in LDS beside them.
-            const int64_t s0 = c == 0 ? 0 : keys[0] - lo;
-            const int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+            // the span is clamped to the table: a key outside [lo, lo + range) is reported (deferred error) but must
+            // not move the span — and with it the stores below — outside the allocation
+            int64_t s0 = c == 0 ? 0 : keys[0] - lo;
+            int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+            s0 = s0 < 0 ? 0 : s0 > cap4 ? cap4 : s0;
+            s1 = s1 > cap4 ? cap4 : s1 < s0 ? s0 : s1;
             bool bad = false;
             for (int64_t t = s0; t < s1 || t == s0; t += TILE) {
                 const int w = (int)(s1 - t < TILE ? s1 - t : TILE);
@@ -1582,13 +1586,13 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
                         stored++;
                     }
                     const int64_t off = k - lo - t;
-                    if (off >= 0 && off < w && gate_pass(e)) {
+                    if (off >= 0 && off < w && (unsigned long long)(k - lo) < range && gate_pass(e)) {
                         direct[t + off] = (int32_t)(r0 + e);
                         const int b = (int)(t & 31) + (int)off;
                         atomicOr(&lbits[b >> 5], 1u << (b & 31));
                     }
                 }
-                __syncthreads();
+                const int anybad = __syncthreads_or(bad);   // a chunk that breaks the claim stops after this tile: the table is void
                 const int sh = (int)(t & 31), nwords = w > 0 ? (sh + w + 31) >> 5 : 0;
                 for (int jw = threadIdx.x; jw < nwords; jw += 256) {
                     const unsigned bits = lbits[jw];
@@ -1596,6 +1600,7 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
                     if (whole) dbits[(t >> 5) + jw] = bits;
                     else if (bits) atomicOr(&dbits[(t >> 5) + jw], bits);
                 }
+                if (anybad) break;
             }
             if (bad) { atomicOr(count + 3, 1); if (declared) atomicOr(declared, 1); }
             continue;
@@ -1604,6 +1609,8 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
         for (int e = threadIdx.x; e < m; e += 256) {
             const unsigned long long off = (unsigned long long)(keys[e] - lo);
             bad = bad || off >= range || keys[e] > keys[e + 1];
+            // the next chunk's first key bounds this chunk's slot span: outside the range it voids the table too
+            if (e == m - 1 && r1 < n) bad = bad || (unsigned long long)(keys[m] - lo) >= range;
             runs += (r0 + e == 0) || keys[e - 1] != keys[e];
             stored++;
         }
@@ -1613,8 +1620,11 @@ __global__ __launch_bounds__(256) void direct_sorted_fill_kernel(const void *__r
             if (threadIdx.x == 0) { atomicOr(count + 3, 1); if (declared) atomicOr(declared, 1); }
             continue;
         }
-        const int64_t s0 = c == 0 ? 0 : keys[0] - lo;
-        const int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+        // keys[m] is the NEXT chunk's first key and has not been checked by this chunk: clamp the span to the table
+        int64_t s0 = c == 0 ? 0 : keys[0] - lo;
+        int64_t s1 = r1 == n ? cap4 : keys[m] - lo;
+        s0 = s0 < 0 ? 0 : s0 > cap4 ? cap4 : s0;
+        s1 = s1 > cap4 ? cap4 : s1 < s0 ? s0 : s1;
         for (int64_t t = s0; t < s1; t += SF_TILE) {
             const int w = (int)(s1 - t < SF_TILE ? s1 - t : SF_TILE);
             __syncthreads();

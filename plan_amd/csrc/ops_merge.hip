@@ -8,7 +8,9 @@
 // with a binary search in LDS. The build column is read once (coalesced), nothing is written but the answers —
 // against a direct table that costs a fill of 4 B x key range plus a random slot read per probe.
 // Both orders are VERIFIED on the device (a violation raises the ctx's deferred PH_ECONSTRAINT word, the caller
-// falls back to ph_join_build + ph_join_lookup); a probe key that is absent answers -1 and counts as a miss.
+// falls back to ph_join_build + ph_join_lookup): the probe order for every row; the build order for every pair a
+// block stages through LDS, and — in blocks of very sparse probes, which search the column instead — for the pairs
+// around every position a search ends at. A probe key that is absent answers -1 and counts as a miss.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -87,6 +89,12 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(const void *__restric
             int64_t lo = b0, hi = b1;
             while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ml_key<KW>(bkeys, mid) < k[q]) lo = mid + 1; else hi = mid; }
             if (lo < b1 && ml_key<KW>(bkeys, lo) == k[q]) res[q] = (int32_t)lo;
+            // the build order (strict) around the position the search ended at: a duplicated or descending pair there
+            // is what could have misled it (the streaming branch below checks every pair it stages)
+            if (lo < nb) {
+                const long long at = ml_key<KW>(bkeys, lo);
+                bad = bad || (lo > 0 && ml_key<KW>(bkeys, lo - 1) >= at) || (lo + 1 < nb && at >= ml_key<KW>(bkeys, lo + 1));
+            }
         }
     } else {
         for (int64_t c = b0; c < b1; c += ML_CHUNK) {

@@ -84,11 +84,14 @@ class RcclGroup:
         m = np.ascontiguousarray(matrix, dtype=np.int64)
         hip.check(hip.lib().ph_comm_exchange_columns(self.h, hip.i32(k), sp, rp, wd, hip.vp(m.ctypes.data)))
 
-    def allgather_rows(self, send_ptr, count, width, recv_ptr, cap):
+    def allgather_rows(self, send_ptr, count, width):
+        """ph_comm_allgather_rows_alloc: the library sizes the output from the all-gathered counts (no rank can
+        leave between the count exchange and the send/recv group). Returns (device pointer, counts)."""
         counts = (hip.i64 * self.n)()
-        rc = hip.lib().ph_comm_allgather_rows(self.h, hip.vp(_addr(send_ptr)), hip.i64(count), hip.i32(width),
-                                              hip.vp(_addr(recv_ptr)), hip.i64(cap), counts)
-        return rc, [counts[r] for r in range(self.n)]
+        out = hip.vp()
+        hip.check(hip.lib().ph_comm_allgather_rows_alloc(self.h, hip.vp(_addr(send_ptr)), hip.i64(count), hip.i32(width),
+                                                         ctypes.byref(out), counts))
+        return out, [counts[r] for r in range(self.n)]
 
 
 class ThreadGroup:
@@ -261,17 +264,8 @@ def allgather_rows(ctx, ptr, count, dtype):
     w = np.dtype(dtype).itemsize
     g = _rccl()
     if g is not None and _tg() is None:
-        cap = max(count * n * 2, 1024)
-        for _ in range(2):
-            out = ctx.alloc(cap * w)
-            rc, counts = g.allgather_rows(ptr, count, w, out, cap)
-            if rc == hip.PH_ECAPACITY:
-                ctx.free(out)
-                cap = sum(counts)
-                continue
-            hip.check(rc)
-            return out, sum(counts)
-        raise RuntimeError("allgather_rows: capacity retry failed")
+        out, counts = g.allgather_rows(ptr, count, w)
+        return out, sum(counts)
     mine = ctx.download(ptr, dtype, count) if count else np.empty(0, dtype)
     allv = np.concatenate(_gather_objects(mine))
     return (ctx.upload(allv) if len(allv) else ctx.alloc(8)), len(allv)
@@ -301,6 +295,16 @@ def allgather_records(ctx, records):
         ctx.free(out)
         return res
     return np.concatenate(_gather_objects(records)).reshape(-1, width)
+
+
+def agree_max(ctx, value):
+    """max over all ranks of a small integer (an error flag): every rank calls it at the same point"""
+    if world() == 1:
+        return int(value)
+    g = _rccl()
+    if g is not None and _tg() is None:
+        return int(g.allreduce([int(value)], "max")[0])
+    return int(max(_gather_objects(int(value))))
 
 
 def global_range(ctx, lo_hi):

@@ -172,7 +172,7 @@ class Ctx:
     def set_deferred_errors(self, on=True):
         """flags that would cost a host round trip each (expression overflow) are reported by the next
         call that reads anything back (ph_ctx_set_deferred_errors)"""
-        check(lib().ph_ctx_set_deferred_errors(self.h, i32(1 if on else 0)))
+        check(lib().ph_ctx_set_deferred_errors(self.h, i32(2 if on == 2 else 1 if on else 0)))   # 2: held until check_deferred()
 
     def check_deferred(self):
         check(lib().ph_ctx_check_deferred(self.h))

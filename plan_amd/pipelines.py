@@ -31,6 +31,39 @@ def copartitioned_by_order_key(ctx, o_key_range, l_orderkey):
     return bool(disjoint and inside)
 
 
+def _run_with_fallback(ctx, attempt, relax, can_relax):
+    """One query attempt with the optimistic forms (statistics trusted, strict lookups, deferred errors), and — only
+    when a deferred PH_ECONSTRAINT says a claim did not hold — a second one after relax().
+    One rank: the error surfaces at the next read-back and aborts the attempt there.
+    Several ranks: the decision is COLLECTIVE. The ctx HOLDS deferred errors (no read-back in the middle of the
+    pipeline reports them, so no rank leaves the sequence of collectives alone — its peers would block in the next
+    exchange; the kernels stay in bounds after a broken claim by construction), every rank checks at the end of its
+    attempt, and one all-reduce(max) of the flag decides for all of them whether the query runs again."""
+    multi = dist.world() > 1
+    ctx.set_deferred_errors(2 if multi else True)
+    try:
+        failed, err, res = 0, None, None
+        try:
+            res = attempt()
+            if multi:
+                ctx.check_deferred()
+        except hip.PlanHipError as e:
+            if e.code != hip.PH_ECONSTRAINT or not can_relax():
+                raise
+            failed, err = 1, e
+        if multi:
+            failed = dist.agree_max(ctx, failed)
+        if not failed:
+            return res
+        relax()
+        res = attempt()
+        if multi:
+            ctx.check_deferred()
+        return res
+    finally:
+        ctx.set_deferred_errors(False)
+
+
 class Q3Pipeline:
     """TPC-H Q3 on device-resident customer / orders / lineitem shards.
 
@@ -98,17 +131,11 @@ class Q3Pipeline:
         """the revenue expression's overflow flag is a deferred error (seen at the result download); so is
         a violation of the sorted-and-unique statistic the orders build relies on, after which the query
         runs again without it"""
-        self.ctx.set_deferred_errors(True)
-        try:
-            try:
-                return self._run(limit, want_groups)
-            except hip.PlanHipError as e:
-                if e.code != hip.PH_ECONSTRAINT or not (self.o_key_sorted_unique or self.l_key_sorted or self.c_key_sorted_unique):
-                    raise
-                self.o_key_sorted_unique = self.l_key_sorted = self.c_key_sorted_unique = False   # a statistic did not hold: the general forms
-            return self._run(limit, want_groups)
-        finally:
-            self.ctx.set_deferred_errors(False)
+        return _run_with_fallback(self.ctx, lambda: self._run(limit, want_groups), self._drop_statistics,
+                                  lambda: self.o_key_sorted_unique or self.l_key_sorted or self.c_key_sorted_unique)
+
+    def _drop_statistics(self):
+        self.o_key_sorted_unique = self.l_key_sorted = self.c_key_sorted_unique = False   # a statistic did not hold: the general forms
 
     def _run(self, limit, want_groups):
         ctx, date = self.ctx, self.date
@@ -436,19 +463,16 @@ class Q9Pipeline:
         statistics read-back; a violation is a deferred PH_ECONSTRAINT, seen at the final download)
         with the expression's overflow flag deferred the same way — then, only if that error came,
         again with the counted lookups, which drop unmatched rows as an inner join must."""
-        self.ctx.set_deferred_errors(True)
+        st = {"strict": True}
+
+        def relax():
+            self.ctx.set_async_counts(False)   # counts of the abandoned attempt land in variables that are still alive
+            st["strict"] = False
         try:
-            try:
-                return self._run(strict=True)
-            except hip.PlanHipError as e:
-                if e.code != hip.PH_ECONSTRAINT:
-                    raise
-                self.ctx.set_async_counts(False)   # counts of the abandoned attempt land in variables that are still alive
-            return self._run(strict=False)
+            return _run_with_fallback(self.ctx, lambda: self._run(strict=st["strict"]), relax, lambda: st["strict"])
         finally:
             self.ctx.set_async_counts(False)   # waits for counts still in flight (their variables live in self._counts)
             self._counts = []
-            self.ctx.set_deferred_errors(False)
 
     def _run(self, strict):
         """N == 1: everything local. N > 1 (one process per GPU, tables sharded by row ranges):

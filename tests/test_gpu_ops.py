@@ -713,6 +713,55 @@ def test_join_keys_declared_sorted_unique(ctx):
     dk.free(); dp.free()
 
 
+def test_join_sorted_fill_understated_range_stays_in_bounds(ctx):
+    """sorted build keys whose tail lies ABOVE the stated key_hi (an understated statistic), longer
+    than one 2048-row chunk and ending in a far sentinel, and keys below key_lo in later chunks. The fill derives
+    a chunk's slot span from raw keys, so it must clamp the span to the table: the build reports the error
+    (ph_join_count = -1 for the undeclared build, the deferred PH_ECONSTRAINT for PH_JOIN_KEYS_SORTED_UNIQUE,
+    plain and gated) and guard buffers allocated around the table keep their pattern."""
+    rng = np.random.default_rng(97)
+    n = 1_200_000
+    inside = np.sort(rng.choice(9_000_000, n - 6000, replace=False)).astype(np.int64) + 100
+    tail = np.arange(6000, dtype=np.int64) * 3 + 9_500_000             # 6000 rows (three chunks) above key_hi
+    tail[-1] = 2**40                                                   # a far sentinel as the last key
+    hi_keys = np.concatenate([inside, tail])
+    low_keys = np.concatenate([np.arange(5000, dtype=np.int64) - 6000, inside[: n - 5000] + 20_000])   # chunks 0..2 below key_lo
+    rngk = (100, 9_000_099)
+    flag = np.ones(n, np.uint8)
+    dfl = hip.DevColumn(ctx, hip.PH_CODE8, flag)
+    p = rng.integers(0, 9_000_200, 300_000).astype(np.int64)
+    dp = hip.DevColumn(ctx, hip.PH_I64, p)
+    pattern = np.full(1 << 20, 0x5A, np.uint8)
+    for keys in (hi_keys, low_keys):
+        assert np.all(np.diff(keys) > 0)
+        dk = hip.DevColumn(ctx, hip.PH_I64, keys)
+        for form in ("range", "declared", "gated"):
+            g0 = ctx.upload(pattern)
+            if form == "range":
+                j = hip.Join(ctx, [dk], None, n, key_range=rngk)
+            elif form == "declared":
+                j = hip.Join(ctx, [dk], None, n, key_range=rngk, sorted_unique=True)
+            else:
+                j = hip.Join.build_where(ctx, [dk], dfl, hip.PH_EQ, hip.const(hip.PH_I32, i=1), None, n, rngk, sorted_unique=True)
+            g1 = ctx.upload(pattern)
+            assert j is not None and j.kind == "direct"
+            rows = j.lookup([dp], None, len(p))                        # probes stay in bounds whatever the fill wrote
+            if form == "range":
+                ctx.download(rows, np.int32, len(p))
+                assert j.count() == -1 and "outside the stated range" in hip.last_error()
+            else:
+                with pytest.raises(hip.PlanHipError) as e:
+                    ctx.download(rows, np.int32, len(p))
+                assert e.value.code == hip.PH_ECONSTRAINT
+            ctx.sync()
+            assert np.array_equal(ctx.download(g0, np.uint8, len(pattern)), pattern)
+            assert np.array_equal(ctx.download(g1, np.uint8, len(pattern)), pattern)
+            j.free()
+            ctx.free(g0); ctx.free(g1); ctx.free(rows)
+        dk.free()
+    dfl.free(); dp.free()
+
+
 def test_join_build_where_sorted_unique_gated_fill(ctx):
     """ph_join_build_where_ex with PH_JOIN_KEYS_SORTED_UNIQUE: the Filter rides along in the sorted fill,
     which also writes the occupancy bitmap (here 9 M slots: above the general passes' bitmap limit). Pairs,
@@ -828,6 +877,23 @@ def test_merge_lookup_equals_table_lookup(ctx):
         with pytest.raises(hip.PlanHipError) as e:
             ctx.download(r, np.int32, 4)
         assert e.value.code == hip.PH_ECONSTRAINT
+        # sparse probes (the block searches the column itself) against a build column with a duplicated pair / a
+        # descending pair exactly where a search ends: the local order check raises the deferred error
+        dsp = hip.DevColumn(ctx, typ, sparse)
+        hitpos = int(np.searchsorted(b, sparse[len(sparse) // 2]))
+        for kind in ("dup", "desc"):
+            b3 = b.copy()
+            if kind == "dup":
+                b3[hitpos + 1] = b3[hitpos]
+            else:
+                b3[hitpos], b3[hitpos + 1] = b[hitpos + 1], b[hitpos]
+            db3 = hip.DevColumn(ctx, typ, b3)
+            r = hip.merge_lookup(ctx, db3, nb, dsp, None, len(sparse))
+            with pytest.raises(hip.PlanHipError) as e:
+                ctx.download(r, np.int32, 4)
+            assert e.value.code == hip.PH_ECONSTRAINT
+            db3.free()
+        dsp.free()
         # empty sides
         assert (ctx.download(hip.merge_lookup(ctx, db, 0, dp, None, 1000), np.int32, 1000) == -1).all()
         hip.merge_lookup(ctx, db, nb, dp, None, 0)
@@ -1334,10 +1400,26 @@ def test_rccl_communicator_single_rank_roundtrip(ctx):
         g.exchange_columns([sk, sv], [rk, rv], [8, 4], matrix)
         assert np.array_equal(ctx.download(rk, np.int64, n), keys) and np.array_equal(ctx.download(rv, np.int32, n), vals)
         out = ctx.alloc(n * 8)
-        rc, counts = g.allgather_rows(dk.data, n, 8, out, n)
-        assert rc == 0 and counts == [n] and np.array_equal(ctx.download(out, np.int64, n), keys)
-        rc, counts = g.allgather_rows(dk.data, n, 8, out, n - 1)
-        assert rc == hip.PH_ECAPACITY and counts == [n]
+        import ctypes
+        cnt = (hip.i64 * 1)()
+        rc = hip.lib().ph_comm_allgather_rows(g.h, dk.data, hip.i64(n), hip.i32(8), out, hip.i64(n), cnt)
+        assert rc == 0 and cnt[0] == n and np.array_equal(ctx.download(out, np.int64, n), keys)
+        rc = hip.lib().ph_comm_allgather_rows(g.h, dk.data, hip.i64(n), hip.i32(8), out, hip.i64(n - 1), cnt)
+        assert rc == hip.PH_ECAPACITY and cnt[0] == n      # the capacity decision is collective (min over the ranks)
+        got, counts = g.allgather_rows(dk.data, n, 8)       # the allocating form: sized from the counts
+        assert counts == [n] and np.array_equal(ctx.download(got, np.int64, n), keys)
+        ctx.free(got)
+        # a held deferred error is not reported by the collectives' read-backs, only by check_deferred
+        ctx.set_deferred_errors(2)
+        bad = hip.merge_lookup(ctx, dk, n, dk, None, n)     # unsorted keys on both sides: the deferred PH_ECONSTRAINT
+        assert g.allreduce([3], "max") == [3]
+        assert g.exchange_counts(cdev).tolist() == [[n]]
+        ctx.download(bad, np.int32, 4)                      # an ordinary read-back stays silent while the error is held
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.check_deferred()
+        assert e.value.code == hip.PH_ECONSTRAINT
+        ctx.set_deferred_errors(False)
+        ctx.free(bad)
         assert g.allreduce([5, -7], "sum") == [5, -7] and g.allreduce([5], "max") == [5]
         g.barrier()
         for i in range(6):        # more asynchronous collectives than the event ring holds
