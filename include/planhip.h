@@ -117,6 +117,19 @@ int32_t ph_table_ncols(const ph_table *t);
 int ph_table_col(const ph_table *t, int32_t c, ph_col *out);
 /* per-column min/max gathered at load (int64 domain; used for overflow proofs) */
 int ph_table_col_range(const ph_table *t, int32_t c, int64_t *min, int64_t *max);
+/* Order statistics gathered at load like min / max (one pass per integer column without NULLs), and what the
+ * catalog declares. They are what a planner's choice of table form rests on (ph_plan below; ph_join_build_ex's
+ * hints): PH_STAT_ASCENDING = values non-decreasing in storage order (a clustering column: lineitem by
+ * l_orderkey), PH_STAT_STRICT = strictly ascending (a primary key stored in key order),
+ * PH_STAT_DECLARED_UNIQUE = ph_table_declare_unique named this single column. */
+#define PH_STAT_ASCENDING 1
+#define PH_STAT_STRICT 2
+#define PH_STAT_DECLARED_UNIQUE 4
+int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags);
+/* the catalog's PRIMARY KEY / UNIQUE constraint over 1..4 columns of the table (cases/tpch/query/ddl.sql: every
+ * TPC-H table declares one). A join whose build key covers a declared-unique set is N:1. Trusted, like the
+ * reference trusts its catalog; a lookup that meets two build rows for one key reports it (PH_ECONSTRAINT). */
+int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols);
 void ph_table_free(ph_table *t);
 
 /* plain device buffers for callers without their own allocator */
@@ -517,6 +530,110 @@ int ph_scan_jit_selfcheck(int32_t which, char *src_out, int64_t cap);
 const char *ph_scan_plan_kind(const ph_scan_plan *p);
 void ph_scan_plan_free(ph_scan_plan *p);
 void ph_agg_result_free(ph_agg_result *r);
+
+/* ------------------------------------------------------------------ resident plans
+ * The join analogue of ph_scan_plan: a whole operator SUBTREE over resident tables,
+ *     Agg <- [Project] <- [Filter] <- HashJoin* <- Scan(filter)
+ * exactly as buildOperatorExec (pkg/compute/executor.go:305-350) receives it from the planner, handed to the
+ * library as a flat array of node descriptors and run there without a chunk crossing the boundary:
+ * joinExecutor.Execute's build + probe (executor_join.go:54-264), filterExecutor (executor_filter.go:27-114),
+ * projectExecutor (executor_project.go:39-78) and aggExecutor's sink + finalize (executor_aggr.go:106-265).
+ * The shim's gpuResidentPlanExecutor translates a PhysicalOperator subtree whose leaves are
+ * resident tables into this descriptor, else the tree falls through to the per-operator executors.
+ *
+ * The library is the physical planner below the operator interface. Per join it picks, from the tables'
+ * STATISTICS (ph_table_col_range, ph_table_col_stats, ph_table_declare_unique) — never from hints of the caller:
+ *   - the table form: direct table over a dense integer key range, the one-pass sorted fill for a key in
+ *     storage order, the gated fill when a filter or a semi-join's marks sit under the build child, node table
+ *     for composite foreign keys, chained + Bloom otherwise (ph_join_build_ex / ph_join_build_where_ex);
+ *   - the probe form: N:1 lookup when the build key is unique (no pair list; the intermediate stays aligned
+ *     with the probe side), a merge lookup without any table when both sides are ordered by the key, marks
+ *     instead of pairs for a join that only tests existence (SEMI, or INNER with a unique build key none of
+ *     whose columns is used above) and feeds another build, the fused Filter -> probe otherwise;
+ *   - sideways information passing: a big build side whose key the probe side has already joined against a
+ *     small table is first reduced to the rows that can match (a mark probe against that table);
+ *   - late materialisation: intermediates are row-id vectors per base table; columns are gathered once, when an
+ *     expression, a key or the aggregate needs them;
+ *   - the aggregate form: the fused scan kernels for Agg <- Scan, the streaming aggregate when the rows reach
+ *     the aggregate ordered by the first group key, the LDS hash aggregate otherwise, a top-k preselection
+ *     when the caller announces ORDER BY <aggregate> LIMIT k (ph_plan_set_topk).
+ * Claims derived from statistics (sorted, unique, every foreign key has its row) are verified on the device
+ * while the data streams by; a broken claim is the deferred PH_ECONSTRAINT, and ph_plan_fetch then runs the
+ * plan again in its conservative forms (general builds, counted lookups, hash aggregate) — results never
+ * depend on a statistic being right. ph_plan_explain names the forms the last run chose. */
+typedef enum { PH_PN_SCAN = 1, PH_PN_FILTER, PH_PN_JOIN, PH_PN_PROJECT, PH_PN_AGG } ph_plan_kind;
+typedef enum { PH_JT_INNER = 1, PH_JT_SEMI, PH_JT_ANTI } ph_plan_join_type;   /* LOT_JoinType* of join_scan.go:47-165 */
+typedef enum {
+    PH_PE_COL = 1,    /* column reference (executeColumnRef: zero copy) */
+    PH_PE_DECIMAL,    /* decimal / integer arithmetic, RPN over the child's output columns (executeFunc) */
+    PH_PE_YEAR        /* extract(year from <DATE column>)  (ExtractFunc, function_scalar.go:1509-1563) */
+} ph_plan_expr_kind;
+
+typedef struct {
+    int32_t kind;     /* ph_plan_expr_kind */
+    int32_t col;      /* PH_PE_COL / PH_PE_YEAR: child output column */
+    int32_t nprog;
+    ph_rpn prog[12];  /* PH_PE_DECIMAL: ph_rpn.col indexes the child's output columns */
+} ph_plan_expr;
+
+typedef struct {
+    int32_t kind;     /* ph_aggkind */
+    ph_plan_expr arg; /* over the child's output columns; ignored for PH_A_COUNT_STAR */
+} ph_plan_agg;
+
+typedef struct {
+    int32_t kind;                /* ph_plan_kind */
+    int32_t child[2];            /* node indexes (children precede their parent), -1 = none.
+                                    PH_PN_JOIN: child[0] probes, child[1] is built (executor_join.go:237-264) */
+    /* PH_PN_SCAN: the pruned columns of a resident table + the conjuncts pushed into the scan
+       (scanExecutor.runFilterExec, executor_scan.go:225). ph_pred.col is a TABLE column. */
+    const ph_table *table;
+    int32_t ncols;
+    const int32_t *cols;         /* table columns the scan emits, in output order */
+    /* PH_PN_SCAN / PH_PN_FILTER: conjuncts, AND-ed in order (PH_PN_FILTER: ph_pred.col = child output column) */
+    int32_t npreds;
+    const ph_pred *preds;
+    /* PH_PN_JOIN: equi-join on nkeys column pairs; the output picks from [probe child's columns | build
+       child's columns] (SEMI / ANTI: probe columns only) */
+    int32_t join_type;           /* ph_plan_join_type */
+    int32_t nkeys;
+    const int32_t *probe_keys;   /* probe child's output columns */
+    const int32_t *build_keys;   /* build child's output columns */
+    int32_t nout;
+    const int32_t *out;          /* indexes into the concatenation [probe columns | build columns] */
+    /* PH_PN_PROJECT */
+    int32_t nexprs;
+    const ph_plan_expr *exprs;
+    /* PH_PN_AGG (the root): group-by expressions and aggregates over the child's output columns; no group
+       expression = one global group (executor_aggr.go:37-48) */
+    int32_t ngroups;
+    const ph_plan_expr *groups;
+    int32_t naggs;
+    const ph_plan_agg *aggs;
+} ph_plan_node;
+
+typedef struct ph_plan ph_plan;
+/* nodes[nnodes-1] is the root and must be a PH_PN_AGG. The descriptor (and the strings of its predicates) is
+ * copied; the tables must outlive the plan. PH_EUNSUPPORTED for a shape outside the device path (the caller
+ * keeps its per-operator executors). */
+int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_plan **out);
+/* ORDER BY <aggregate agg_index> [DESC] ... LIMIT k sits above the aggregate: only the groups at least as good
+ * as the k-th come back (>= k with ties), as ph_agg_topk; the caller applies the full ORDER BY and the LIMIT. */
+int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k);
+/* enqueue one execution of the whole subtree (host round trips only where a row count sizes the next step) */
+int ph_plan_run(ph_plan *p);
+/* the group rows of the last run, in first-seen order (ph_agg_result_free releases them). If the run's
+ * optimistic forms met a broken statistic (deferred PH_ECONSTRAINT), the plan is run again conservatively
+ * first; later runs of this plan then start conservatively. */
+int ph_plan_fetch(ph_plan *p, ph_agg_result **out);
+/* group key k of the result: device type and scale, and — when it is a table column carried through unchanged
+ * (dictionary codes need their dictionary) — the table and column it comes from (else *table = NULL) */
+int ph_plan_key_info(const ph_plan *p, int32_t k, int32_t *type, int32_t *scale, const ph_table **table, int32_t *col);
+/* type (PH_I32 / PH_I64 / PH_DEC64 ...) of aggregate a's argument; its scale is ph_agg_result.scale[a] */
+int ph_plan_agg_arg_type(const ph_plan *p, int32_t a, int32_t *type);
+/* one line per operator of the last run: the forms chosen and the row counts seen */
+const char *ph_plan_explain(const ph_plan *p);
+void ph_plan_free(ph_plan *p);
 
 /* ------------------------------------------------------------------ multi-GPU partitioning
  * No reference counterpart (the reference is single-threaded): hash-partition

@@ -138,8 +138,13 @@ struct ph_table {
         std::vector<std::string> dict; // PH_CODE8 dictionary (host), from aux at load
         int64_t min = 0, max = 0;
         bool has_range = false;
+        // order statistics of integer columns, one pass at load (like min / max): the values are non-decreasing in
+        // storage order (a clustering column: lineitem by l_orderkey) / strictly ascending (a primary key in key order)
+        bool ascending = false, strict = false;
     };
     std::vector<column> cols;
+    // column sets the catalog declares unique (PRIMARY KEY): ph_table_declare_unique
+    std::vector<std::vector<int32_t>> unique_keys;
 };
 
 // rows a column allocation is padded to, so vector loads never leave the allocation

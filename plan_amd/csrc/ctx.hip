@@ -465,6 +465,35 @@ static int column_range(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, i
     return PH_OK;
 }
 
+// order statistics: out[0] |= 1 when a row is below its predecessor, |= 2 when it is not above it
+template <typename T>
+__global__ __launch_bounds__(256) void order_stat_kernel(const T *__restrict__ v, int64_t n, int *__restrict__ out) {
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T a = v[i], b = v[i + 1];
+        f |= (b < a ? 1 : 0) | (b <= a ? 2 : 0);
+    }
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(out, f);
+}
+
+static int column_order(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, bool *ascending, bool *strict) {
+    PH_CHECK(ctx->ensure_scratch(64));
+    PH_HIP(hipMemsetAsync(ctx->scratch, 0, 8, ctx->stream));
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    if (grid < 1) grid = 1;
+    int *out = (int *)ctx->scratch;
+    if (type == PH_I32 || type == PH_DATE) order_stat_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t *)dev, n, out);
+    else if (type == PH_I64 || type == PH_DEC64) order_stat_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t *)dev, n, out);
+    else return PH_EUNSUPPORTED;
+    PH_HIP(hipGetLastError());
+    int f = 0;
+    PH_CHECK(ctx->download(&f, out, 4));
+    *ascending = (f & 1) == 0;
+    *strict = (f & 2) == 0;
+    return PH_OK;
+}
+
 // ---------------------------------------------------------------- tables
 
 extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_cols, int64_t nrows,
@@ -513,6 +542,7 @@ extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_co
                               h.type == PH_DEC64 || h.type == PH_CODE8)) {
                 rc = column_range(ctx, h.type, d.data, nrows, &d.min, &d.max);
                 d.has_range = rc == PH_OK;
+                if (rc == PH_OK && h.type != PH_CODE8 && !h.validity) rc = column_order(ctx, h.type, d.data, nrows, &d.ascending, &d.strict);
             }
         }
         if (rc == PH_OK && h.validity) {
@@ -552,6 +582,23 @@ extern "C" int ph_table_col_range(const ph_table *t, int32_t c, int64_t *mn, int
     if (!d.has_range) { ph::set_error("column %d has no range statistics", c); return PH_EUNSUPPORTED; }
     if (mn) *mn = d.min;
     if (mx) *mx = d.max;
+    return PH_OK;
+}
+
+extern "C" int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags) {
+    PH_REQUIRE(t && flags && c >= 0 && c < (int32_t)t->cols.size(), "ph_table_col_stats: bad column %d", c);
+    const ph_table::column &d = t->cols[(size_t)c];
+    *flags = (d.ascending ? PH_STAT_ASCENDING : 0) | (d.strict ? PH_STAT_STRICT : 0);
+    for (auto &u : t->unique_keys) if (u.size() == 1 && u[0] == c) *flags |= PH_STAT_DECLARED_UNIQUE;
+    return PH_OK;
+}
+
+extern "C" int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols) {
+    PH_REQUIRE(t && cols && ncols >= 1 && ncols <= 4, "ph_table_declare_unique: 1..4 columns");
+    std::vector<int32_t> u(cols, cols + ncols);
+    for (int32_t c : u) PH_REQUIRE(c >= 0 && c < (int32_t)t->cols.size(), "ph_table_declare_unique: bad column %d", c);
+    std::sort(u.begin(), u.end());
+    t->unique_keys.push_back(u);
     return PH_OK;
 }
 

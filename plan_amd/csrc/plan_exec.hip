@@ -1,0 +1,1177 @@
+// Resident plans (ph_plan_*): an operator subtree Agg <- [Project] <- [Filter] <- HashJoin* <- Scan(filter) over
+// resident tables, lowered here to the operator-granular entry points of this library. This is the physical
+// planner below the reference's operator interface: what buildOperatorExec (pkg/compute/executor.go:305-350)
+// instantiates as a tree of joinExecutor / filterExecutor / projectExecutor / aggExecutor objects pulling
+// 2048-row chunks through each other (executor_join.go:54-264, executor_filter.go:27-114,
+// executor_project.go:39-78, executor_aggr.go:106-265) runs as ONE descriptor in the library, and every choice the
+// hand-assembled Q3 / Q9 pipelines of round 2 made by hand (plan_amd/pipelines.py) is made here from the tables'
+// statistics. Host code only: the kernels are the ones behind ph_join_*, ph_filter_select, ph_gather*, ph_expr_eval,
+// ph_agg_*, ph_merge_lookup and ph_scan_plan_*.
+//
+// An intermediate result ("relation") is a set of LANES — one row-id vector per base table taking part, all of
+// the relation's length and aligned by position — plus output columns that are either references into a lane's
+// table (late materialisation: gathered when something needs the values) or positional device columns.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct PCol {                       // an output column of a relation
+    int32_t type = 0, scale = 0;
+    int lane = -1, tcol = -1;       // lane >= 0: column tcol of lanes[lane].t, addressed through lanes[lane].rows
+    const void *data = nullptr;     // lane < 0: positional values, one per row of the relation
+    const uint8_t *validity = nullptr;
+    const ph_table *src = nullptr;  // provenance: the table column these values are unchanged copies of
+    int src_col = -1;
+    bool ordered = false;           // values are non-decreasing in the relation's row order
+    int domain = -1;                // index into ph_plan::domains: the values are a subset of that join table's keys
+};
+
+struct Lane {
+    const ph_table *t = nullptr;
+    const int32_t *rows = nullptr;  // nullptr = identity (row i of the relation is row i of the table)
+    bool asc = true;                // the row ids are ascending (table order preserved)
+    bool dup_free = true;           // no table row occurs twice
+};
+
+struct Rel {
+    int64_t n = 0;                  // rows; an upper bound (the table's rows) while `pending` / `flags` are not applied
+    std::vector<Lane> lanes;
+    std::vector<PCol> cols;
+    // single identity lane only: what still filters the table's rows
+    std::vector<ph_pred> pending;   // conjuncts over TABLE columns, not applied yet (fused into the next build / probe when possible)
+    const uint8_t *flags = nullptr; // a byte per table row, 0 = filtered out (the marks of a semi-join)
+    bool covers = true;             // every table row is (still) there, up to a reduction by the probing side's own key domain
+    bool lazy() const { return !pending.empty() || flags != nullptr; }
+    bool single_identity() const { return lanes.size() == 1 && lanes[0].rows == nullptr; }
+};
+
+struct Node {
+    int32_t kind = 0, child[2] = {-1, -1};
+    const ph_table *table = nullptr;
+    std::vector<int32_t> cols;
+    std::vector<ph_pred> preds;
+    std::vector<std::string> pred_strs;
+    int32_t join_type = 0;
+    std::vector<int32_t> pkeys, bkeys, out;
+    std::vector<ph_plan_expr> exprs, groups;
+    std::vector<ph_plan_agg> aggs;
+};
+
+struct Domain { ph_join *j; int64_t nkeys; };
+
+struct KeyInfo { int32_t type = 0, scale = 0; const ph_table *table = nullptr; int32_t col = -1; };
+
+}  // namespace
+
+struct ph_plan {
+    ph_ctx *ctx = nullptr;
+    std::vector<Node> nodes;
+    int32_t topk_agg = -1, topk_desc = 0;
+    int64_t topk_k = 0;
+    bool conservative = false;          // statistics are not trusted (after a broken claim)
+    // state of the last run
+    bool ran = false;
+    std::vector<void *> temps;
+    std::vector<ph_join *> joins;
+    std::vector<Domain> domains;
+    ph_agg *agg = nullptr;
+    ph_scan_plan *scan = nullptr;       // Agg <- Scan: the fused scan plan
+    std::vector<KeyInfo> keys;
+    std::vector<int32_t> agg_scale, agg_arg_type;
+    std::string explain;
+    int64_t expected_groups = 1024;
+};
+
+namespace {
+
+using ph::set_error;
+
+#define PL_CHECK(expr) do { int rc__ = (expr); if (rc__ != PH_OK) return rc__; } while (0)
+
+int width_of(int32_t t) { return t == PH_STR ? 0 : ph::type_width(t); }
+
+void note(ph_plan *p, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    p->explain += buf;
+    p->explain += '\n';
+}
+
+int palloc(ph_plan *p, int64_t bytes, void **out) {
+    PL_CHECK(p->ctx->pool_alloc(bytes > 0 ? bytes : 8, out));
+    p->temps.push_back(*out);
+    return PH_OK;
+}
+
+void release_run(ph_plan *p, bool keep_agg) {
+    for (ph_join *j : p->joins) ph_join_free(j);
+    p->joins.clear();
+    p->domains.clear();
+    for (void *q : p->temps) p->ctx->pool_release(q);
+    p->temps.clear();
+    if (!keep_agg) {
+        if (p->agg) { ph_agg_free(p->agg); p->agg = nullptr; }
+    }
+}
+
+ph_col table_view(const ph_table *t, int c) {
+    ph_col v{};
+    const auto &d = t->cols[(size_t)c];
+    v.type = d.type; v.scale = d.scale; v.data = d.data; v.validity = d.validity; v.aux = d.aux; v.aux_bytes = d.aux_bytes;
+    return v;
+}
+
+// device view of a column and the selection that addresses it (nullptr = positions 0..n)
+ph_col col_view(const Rel &r, const PCol &c, const int32_t **sel) {
+    if (c.lane >= 0) {
+        *sel = r.lanes[(size_t)c.lane].rows;
+        return table_view(r.lanes[(size_t)c.lane].t, c.tcol);
+    }
+    ph_col v{};
+    v.type = c.type; v.scale = c.scale; v.data = c.data; v.validity = c.validity;
+    *sel = nullptr;
+    return v;
+}
+
+// a string literal against a dictionary-code column: the code of the literal (999 = not in the dictionary)
+void fix_dict_const(const ph_table *t, int tcol, ph_const *k) {
+    if (!t || tcol < 0) return;
+    const auto &d = t->cols[(size_t)tcol];
+    if (d.type == PH_CODE8 && k->type == PH_STR) {
+        int code = 999;
+        for (size_t i = 0; i < d.dict.size(); i++) if (k->s && d.dict[i] == k->s) code = (int)i;
+        k->type = PH_I32;
+        k->i = code;
+        k->s = nullptr;
+    }
+}
+
+// ---- apply what still filters a lazy single-lane relation: conjunct by conjunct (execSelectAnd), then the marks
+int apply_pending(ph_plan *p, Rel *r) {
+    if (!r->lazy()) return PH_OK;
+    ph_ctx *ctx = p->ctx;
+    const ph_table *t = r->lanes[0].t;
+    const int64_t N = t->nrows;
+    const int32_t *sel = nullptr;
+    int64_t cnt = N;
+    for (size_t i = 0; i < r->pending.size() && cnt > 0; i++) {
+        ph_pred pr = r->pending[i];
+        fix_dict_const(t, pr.col, &pr.k);
+        ph_col v = table_view(t, pr.col);
+        void *out = nullptr;
+        PL_CHECK(palloc(p, cnt * 4, &out));
+        int64_t m = 0;
+        PL_CHECK(ph_filter_select(ctx, &v, N, pr.op, &pr.k, sel, cnt, (int32_t *)out, &m));
+        sel = (const int32_t *)out;
+        cnt = m;
+    }
+    if (r->flags && cnt > 0) {
+        ph_col f{};
+        f.type = PH_CODE8; f.data = r->flags;
+        ph_const one{};
+        one.type = PH_I32; one.i = 1;   // marks are 0 / 1
+        void *out = nullptr;
+        PL_CHECK(palloc(p, cnt * 4, &out));
+        int64_t m = 0;
+        PL_CHECK(ph_filter_select(ctx, &f, N, PH_EQ, &one, sel, cnt, (int32_t *)out, &m));
+        sel = (const int32_t *)out;
+        cnt = m;
+    }
+    if (!sel) { void *out = nullptr; PL_CHECK(palloc(p, 8, &out)); sel = (const int32_t *)out; }
+    note(p, "  select %lld of %lld rows (%zu conjuncts%s)", (long long)cnt, (long long)N, r->pending.size(), r->flags ? " + marks" : "");
+    r->lanes[0].rows = sel;
+    r->n = cnt;
+    r->pending.clear();
+    r->flags = nullptr;
+    return PH_OK;
+}
+
+// ---- make the listed columns positional (late materialisation: one gather pass per lane, up to 8 columns each)
+int positional(ph_plan *p, Rel *r, const std::vector<int> &want) {
+    PL_CHECK(apply_pending(p, r));
+    for (size_t L = 0; L < r->lanes.size(); L++) {
+        std::vector<int> cs;
+        for (int c : want)
+            if (r->cols[(size_t)c].lane == (int)L && std::find(cs.begin(), cs.end(), c) == cs.end()) cs.push_back(c);
+        // several output columns may reference the same table column: gather it once
+        for (size_t base = 0; base < cs.size();) {
+            std::vector<int> batch;       // distinct table columns of this pass
+            std::vector<int> members;     // output columns served by it
+            size_t k = base;
+            for (; k < cs.size(); k++) {
+                const int tc = r->cols[(size_t)cs[k]].tcol;
+                if (std::find(batch.begin(), batch.end(), tc) == batch.end()) {
+                    if (batch.size() == 8) break;
+                    batch.push_back(tc);
+                }
+                members.push_back(cs[k]);
+            }
+            base = k;
+            const Lane &ln = r->lanes[L];
+            std::vector<const void *> outp(batch.size());
+            if (!ln.rows) {   // identity over the whole table: the table column IS the positional column
+                for (size_t b = 0; b < batch.size(); b++) outp[b] = ln.t->cols[(size_t)batch[b]].data;
+            } else {
+                std::vector<ph_col> views;
+                std::vector<void *> outs(batch.size());
+                for (size_t b = 0; b < batch.size(); b++) {
+                    ph_col v = table_view(ln.t, batch[b]);
+                    const int w = width_of(v.type);
+                    if (w == 0 || v.validity) { set_error("ph_plan: column %d of a joined table cannot be materialised (VARCHAR bytes / NULL-able)", batch[b]); return PH_EUNSUPPORTED; }
+                    views.push_back(v);
+                    PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * w, &outs[b]));
+                    outp[b] = outs[b];
+                }
+                if (r->n > 0) {
+                    if (views.size() == 1) PL_CHECK(ph_gather(p->ctx, &views[0], ln.rows, r->n, outs[0]));
+                    else PL_CHECK(ph_gather_multi(p->ctx, (int32_t)views.size(), views.data(), ln.rows, r->n, outs.data()));
+                }
+            }
+            for (int c : members) {
+                PCol &pc = r->cols[(size_t)c];
+                const size_t b = (size_t)(std::find(batch.begin(), batch.end(), pc.tcol) - batch.begin());
+                pc.data = outp[b];
+                pc.validity = ln.rows ? nullptr : ln.t->cols[(size_t)pc.tcol].validity;
+                pc.lane = -1;
+                pc.tcol = -1;
+            }
+        }
+    }
+    return PH_OK;
+}
+
+// lanes no column references any more are dropped (their row ids would only be dragged through later compactions)
+void drop_unused_lanes(Rel *r) {
+    std::vector<int> remap(r->lanes.size(), -1);
+    std::vector<Lane> keep;
+    for (size_t L = 0; L < r->lanes.size(); L++) {
+        bool used = false;
+        for (auto &c : r->cols) used |= c.lane == (int)L;
+        if (used) { remap[L] = (int)keep.size(); keep.push_back(r->lanes[L]); }
+    }
+    if (keep.empty() && !r->lanes.empty()) return;   // keep at least the shape of a lazy scan
+    for (auto &c : r->cols) if (c.lane >= 0) c.lane = remap[(size_t)c.lane];
+    r->lanes = keep;
+}
+
+// ---- keep rows idx[0..m) (positions) of a relation: every lane's row ids and every positional column
+int compact(ph_plan *p, Rel *r, const int32_t *idx, int64_t m) {
+    for (auto &ln : r->lanes) {
+        if (!ln.rows) { ln.rows = idx; continue; }   // identity: position = row id
+        ph_col v{};
+        v.type = PH_I32; v.data = ln.rows;
+        void *out = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(m, 1) * 4, &out));
+        if (m > 0) PL_CHECK(ph_gather(p->ctx, &v, idx, m, out));
+        ln.rows = (const int32_t *)out;
+    }
+    std::vector<ph_col> views;
+    std::vector<void *> outs;
+    std::vector<PCol *> cols;
+    auto flush = [&]() -> int {
+        if (views.empty()) return PH_OK;
+        if (m > 0) {
+            if (views.size() == 1) PL_CHECK(ph_gather(p->ctx, &views[0], idx, m, outs[0]));
+            else PL_CHECK(ph_gather_multi(p->ctx, (int32_t)views.size(), views.data(), idx, m, outs.data()));
+        }
+        for (size_t i = 0; i < cols.size(); i++) cols[i]->data = outs[i];
+        views.clear(); outs.clear(); cols.clear();
+        return PH_OK;
+    };
+    for (auto &c : r->cols) {
+        if (c.lane >= 0) continue;
+        if (c.validity) { set_error("ph_plan: NULL-able intermediate column in a compaction"); return PH_EUNSUPPORTED; }
+        ph_col v{};
+        v.type = c.type; v.scale = c.scale; v.data = c.data;
+        void *out = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(m, 1) * width_of(c.type), &out));
+        views.push_back(v); outs.push_back(out); cols.push_back(&c);
+        if (views.size() == 8) PL_CHECK(flush());
+    }
+    PL_CHECK(flush());
+    r->n = m;
+    return PH_OK;
+}
+
+// ---- expression over a relation's columns -> a positional decimal column
+int eval_rpn(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, PCol *out) {
+    PL_CHECK(apply_pending(p, r));
+    std::vector<int> operands;
+    for (int i = 0; i < nprog; i++)
+        if (prog[i].op == PH_X_COL && std::find(operands.begin(), operands.end(), prog[i].col) == operands.end()) operands.push_back(prog[i].col);
+    for (int c : operands) if (c < 0 || c >= (int)r->cols.size()) { set_error("ph_plan: expression column %d out of range", c); return PH_EINVAL; }
+    // all operands in one lane: evaluate straight over the table's columns through the lane's row ids (a fused gather)
+    int lane = operands.empty() ? -1 : r->cols[(size_t)operands[0]].lane;
+    for (int c : operands) if (r->cols[(size_t)c].lane != lane) lane = -2;
+    if (lane < 0 && !operands.empty()) PL_CHECK(positional(p, r, operands));
+    std::vector<ph_col> views;
+    const int32_t *sel = nullptr;
+    bool any_validity = false;
+    for (int c : operands) {
+        const int32_t *s = nullptr;
+        views.push_back(col_view(*r, r->cols[(size_t)c], &s));
+        sel = s;
+        any_validity |= views.back().validity != nullptr;
+    }
+    std::vector<ph_rpn> pr(prog, prog + nprog);
+    for (auto &o : pr) if (o.op == PH_X_COL) o.col = (int32_t)(std::find(operands.begin(), operands.end(), o.col) - operands.begin());
+    int32_t scale = 0;
+    PL_CHECK(ph_expr_scale(views.data(), pr.data(), nprog, &scale));
+    void *o = nullptr, *val = nullptr;
+    PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 8, &o));
+    if (any_validity) PL_CHECK(palloc(p, (r->n + 7) / 8 + 64, &val));
+    if (r->n > 0) PL_CHECK(ph_expr_eval(p->ctx, views.data(), (int32_t)views.size(), pr.data(), nprog, sel, r->n, (int64_t *)o, (uint8_t *)val));
+    *out = PCol{};
+    out->type = PH_DEC64; out->scale = scale; out->data = o; out->validity = (const uint8_t *)val;
+    return PH_OK;
+}
+
+int eval_expr(ph_plan *p, Rel *r, const ph_plan_expr &e, PCol *out) {
+    switch (e.kind) {
+    case PH_PE_COL:
+        if (e.col < 0 || e.col >= (int)r->cols.size()) { set_error("ph_plan: column %d out of range", e.col); return PH_EINVAL; }
+        *out = r->cols[(size_t)e.col];
+        return PH_OK;
+    case PH_PE_DECIMAL:
+        return eval_rpn(p, r, e.prog, e.nprog, out);
+    case PH_PE_YEAR: {
+        if (e.col < 0 || e.col >= (int)r->cols.size() || r->cols[(size_t)e.col].type != PH_DATE) { set_error("ph_plan: extract(year) needs a DATE column"); return PH_EINVAL; }
+        PL_CHECK(apply_pending(p, r));
+        const int32_t *sel = nullptr;
+        ph_col v = col_view(*r, r->cols[(size_t)e.col], &sel);
+        if (v.validity) { set_error("ph_plan: extract over a NULL-able column"); return PH_EUNSUPPORTED; }
+        void *o = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &o));
+        if (r->n > 0) PL_CHECK(ph_date_extract(p->ctx, PH_PART_YEAR, &v, sel, r->n, (int32_t *)o));
+        *out = PCol{};
+        out->type = PH_I32; out->data = o;
+        out->ordered = r->cols[(size_t)e.col].ordered;   // the year of a non-decreasing date is non-decreasing
+        return PH_OK;
+    }
+    default:
+        set_error("ph_plan: unknown expression kind %d", e.kind);
+        return PH_EINVAL;
+    }
+}
+
+// ---- is the (multi-column) key of this relation unique? only base-table keys the statistics or the catalog vouch for
+bool key_unique(const Rel &r, const std::vector<int32_t> &keys) {
+    int lane = -1;
+    std::vector<int32_t> tcols;
+    const ph_table *t = nullptr;
+    for (int32_t k : keys) {
+        const PCol &c = r.cols[(size_t)k];
+        if (c.lane < 0) {
+            // a positional copy of a table column keeps the table's uniqueness only in a relation of that one table
+            if (!c.src || r.lanes.size() != 1 || r.lanes[0].t != c.src || !r.lanes[0].dup_free) return false;
+            if (lane >= 0 && lane != 0) return false;
+            lane = 0; t = c.src; tcols.push_back(c.src_col);
+            continue;
+        }
+        if (lane >= 0 && c.lane != lane) return false;
+        lane = c.lane;
+        t = r.lanes[(size_t)lane].t;
+        tcols.push_back(c.tcol);
+    }
+    if (lane < 0 || !r.lanes[(size_t)lane].dup_free) return false;
+    std::sort(tcols.begin(), tcols.end());
+    if (tcols.size() == 1 && t->cols[(size_t)tcols[0]].strict) return true;
+    for (auto &u : t->unique_keys)
+        if (std::includes(tcols.begin(), tcols.end(), u.begin(), u.end())) return true;
+    return false;
+}
+
+int lower(ph_plan *p, int idx, bool as_build, Rel *out);
+
+struct KeySide {            // the key columns of one join side as the kernels want them
+    std::vector<ph_col> views;
+    const int32_t *sel = nullptr;
+    int64_t n = 0;
+    bool rowids = false;    // the kernels report base row ids of lane 0 (table columns through the lane's row ids)
+};
+
+// key columns of a relation: table columns addressed through the one lane's row ids when the relation is a
+// (filtered) base table, positional columns otherwise
+int key_side(ph_plan *p, Rel *r, const std::vector<int32_t> &keys, KeySide *ks) {
+    bool all_lane0 = r->lanes.size() == 1;
+    for (int32_t k : keys) all_lane0 = all_lane0 && r->cols[(size_t)k].lane == 0;
+    bool any_positional = false;
+    for (auto &c : r->cols) any_positional |= c.lane < 0;
+    if (all_lane0 && !any_positional) {
+        for (int32_t k : keys) ks->views.push_back(table_view(r->lanes[0].t, r->cols[(size_t)k].tcol));
+        ks->sel = r->lanes[0].rows;
+        ks->n = r->lanes[0].rows ? r->n : r->lanes[0].t->nrows;
+        ks->rowids = true;
+        return PH_OK;
+    }
+    std::vector<int> want(keys.begin(), keys.end());
+    PL_CHECK(positional(p, r, want));
+    for (int32_t k : keys) { const int32_t *s = nullptr; ks->views.push_back(col_view(*r, r->cols[(size_t)k], &s)); }
+    ks->sel = nullptr;
+    ks->n = r->n;
+    ks->rowids = false;
+    return PH_OK;
+}
+
+// pairs (probe position / row id, build row id) of an inner probe; retried once with the exact size when a
+// non-unique build side produced more pairs than probe rows
+int pair_probe(ph_plan *p, ph_join *j, const KeySide &pk, const ph_pred *where, const ph_table *where_t, const uint8_t *residual,
+               int64_t *m_out, int32_t **prow, int32_t **brow, const char **form) {
+    int64_t cap = std::max<int64_t>(pk.n, 1), m = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        void *op = nullptr, *ob = nullptr;
+        PL_CHECK(palloc(p, cap * 4, &op));
+        PL_CHECK(palloc(p, cap * 4, &ob));
+        int rc = PH_EUNSUPPORTED;
+        if (where || residual) {
+            ph_pred w{};
+            ph_col wv{};
+            if (where) { w = *where; fix_dict_const(where_t, w.col, &w.k); wv = table_view(where_t, w.col); }
+            if (residual) { rc = ph_join_probe_inner_residual(j, pk.views.data(), where ? &wv : nullptr, w.op, where ? &w.k : nullptr, residual, pk.sel, pk.n, (int32_t *)op, (int32_t *)ob, cap, &m); *form = "fused filter+probe with residual marks"; }
+            else { rc = ph_join_probe_inner_where(j, pk.views.data(), &wv, w.op, &w.k, pk.sel, pk.n, (int32_t *)op, (int32_t *)ob, cap, &m); *form = "fused filter+probe"; }
+            if (rc == PH_EUNSUPPORTED) return rc;   // the caller applies the filter first
+        } else {
+            rc = ph_join_probe_inner(j, pk.views.data(), pk.sel, pk.n, (int32_t *)op, (int32_t *)ob, cap, &m);
+            *form = "probe";
+        }
+        if (rc == PH_ECAPACITY && attempt == 0 && m > cap) { cap = m; continue; }
+        PL_CHECK(rc);
+        *m_out = m; *prow = (int32_t *)op; *brow = (int32_t *)ob;
+        return PH_OK;
+    }
+    return PH_ECAPACITY;
+}
+
+// ---- HashJoin
+int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
+    const Node &nd = p->nodes[(size_t)idx];
+    ph_ctx *ctx = p->ctx;
+    Rel P, B;
+    PL_CHECK(lower(p, nd.child[0], false, &P));
+    PL_CHECK(lower(p, nd.child[1], true, &B));
+    const size_t nP = P.cols.size(), nB = B.cols.size();
+    const size_t nk = nd.pkeys.size();
+    for (size_t k = 0; k < nk; k++) {
+        if (nd.pkeys[k] < 0 || (size_t)nd.pkeys[k] >= nP || nd.bkeys[k] < 0 || (size_t)nd.bkeys[k] >= nB) { set_error("ph_plan: join key out of range"); return PH_EINVAL; }
+        const int a = P.cols[(size_t)nd.pkeys[k]].type, b = B.cols[(size_t)nd.bkeys[k]].type;
+        if (width_of(a) == 0 || width_of(a) != width_of(b)) { set_error("ph_plan: join key %zu types differ or are VARCHAR (%d / %d)", k, a, b); return PH_EUNSUPPORTED; }
+    }
+    bool need_build_cols = false;
+    for (int32_t o : nd.out) {
+        if (o < 0 || (size_t)o >= nP + nB) { set_error("ph_plan: join output column out of range"); return PH_EINVAL; }
+        need_build_cols |= (size_t)o >= nP;
+    }
+    if (nd.join_type != PH_JT_INNER && need_build_cols) { set_error("ph_plan: a SEMI / ANTI join emits probe columns only"); return PH_EINVAL; }
+    const bool optimistic = !p->conservative;
+    const bool unique = key_unique(B, nd.bkeys);
+    const bool exists_only = nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI || (nd.join_type == PH_JT_INNER && !need_build_cols && unique);
+    std::string how;
+
+    // ---- sideways information passing: a big, unfiltered build table whose key the probe side has already joined
+    // against a small table is reduced to the rows that can match (marks from a probe of that small table)
+    if (B.single_identity() && !B.lazy() && B.n >= (1 << 18)) {
+        for (size_t k = 0; k < nk; k++) {
+            const int d = P.cols[(size_t)nd.pkeys[k]].domain;
+            const PCol &bc = B.cols[(size_t)nd.bkeys[k]];
+            if (d < 0 || bc.lane != 0 || p->domains[(size_t)d].nkeys * 8 >= B.n) continue;
+            ph_col bv = table_view(B.lanes[0].t, bc.tcol);
+            void *f = nullptr;
+            PL_CHECK(palloc(p, B.n + 64, &f));
+            int rc = ph_join_probe_mark(p->domains[(size_t)d].j, &bv, nullptr, B.n, (uint8_t *)f);
+            if (rc == PH_EUNSUPPORTED) break;
+            PL_CHECK(rc);
+            B.flags = (const uint8_t *)f;   // B.covers stays: only rows the probe side cannot reference are gone
+            how += " build side reduced by the probe key's domain;";
+            break;
+        }
+    }
+
+    // ---- merge lookup: both sides ordered by the key, no table at all
+    const bool n_to_1 = nd.join_type == PH_JT_INNER && unique && !exists_only;
+    if (n_to_1 && optimistic && nk == 1 && B.covers && B.single_identity() && !B.lazy() && !getenv("PH_PLAN_NO_MERGE")) {
+        const PCol &bc = B.cols[(size_t)nd.bkeys[0]];
+        const PCol &pc = P.cols[(size_t)nd.pkeys[0]];
+        if (bc.lane == 0 && B.lanes[0].t->cols[(size_t)bc.tcol].strict && pc.ordered) {
+            PL_CHECK(apply_pending(p, &P));
+            const int32_t *psel = nullptr;
+            ph_col pv = col_view(P, pc, &psel), bv = table_view(B.lanes[0].t, bc.tcol);
+            void *o = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &o));
+            int rc = ph_merge_lookup(ctx, &bv, B.n, &pv, psel, P.n, 1, (int32_t *)o);
+            if (rc == PH_OK) {
+                *out = P;
+                Lane bl; bl.t = B.lanes[0].t; bl.rows = (const int32_t *)o; bl.asc = true; bl.dup_free = false;
+                out->lanes.push_back(bl);
+                std::vector<PCol> all = P.cols;
+                for (auto c : B.cols) { c.lane = (int)P.lanes.size(); c.ordered = false; c.domain = -1; all.push_back(c); }
+                out->cols.clear();
+                for (int32_t oi : nd.out) out->cols.push_back(all[(size_t)oi]);
+                out->covers = false;
+                note(p, "join#%d: merge lookup (both sides ordered by the key, no table), %lld probe rows", idx, (long long)P.n);
+                return PH_OK;
+            }
+            if (rc != PH_EUNSUPPORTED) return rc;
+        }
+    }
+
+    // ---- build
+    ph_join *j = nullptr;
+    const uint8_t *residual = nullptr;   // marks of the build table's rows tested by the probe instead of the build
+    bool brow_is_rowid = false;          // build row ids reported by probes are row ids of B's lane 0 (else positions in B)
+    {
+        bool all_lane0 = B.lanes.size() == 1;
+        for (int32_t k : nd.bkeys) all_lane0 = all_lane0 && B.cols[(size_t)k].lane == 0;
+        bool any_positional = false;
+        for (auto &c : B.cols) any_positional |= c.lane < 0;
+        int32_t flags = 0;
+        int64_t lo = 0, hi = 0;
+        if (all_lane0 && !any_positional) {
+            const ph_table *t = B.lanes[0].t;
+            std::vector<ph_col> kv;
+            for (int32_t k : nd.bkeys) kv.push_back(table_view(t, B.cols[(size_t)k].tcol));
+            const auto &kc = t->cols[(size_t)B.cols[(size_t)nd.bkeys[0]].tcol];
+            if (nk == 1 && kc.has_range && (kc.type == PH_I32 || kc.type == PH_I64)) { flags |= PH_JOIN_KEY_RANGE; lo = kc.min; hi = kc.max; }
+            const bool su = optimistic && nk == 1 && kc.strict && B.single_identity();
+            // every probe row is expected to find its row (a foreign key into a table nothing but the probe side's own
+            // key domain has reduced): no Bloom bitmap, node table for composite keys
+            if (B.covers && unique && nk >= 1 && !(flags & PH_JOIN_KEY_RANGE)) flags |= PH_JOIN_FK_PROBES;
+            int rc = PH_EUNSUPPORTED;
+            if (B.single_identity() && (flags & PH_JOIN_KEY_RANGE) && B.pending.size() + (B.flags ? 1 : 0) == 1) {
+                // Filter (or a semi-join's marks) under the build child rides along in the build
+                ph_pred w{};
+                ph_col wv{};
+                if (B.flags) { wv.type = PH_CODE8; wv.data = B.flags; w.op = PH_EQ; w.k.type = PH_I32; w.k.i = 1; }   // marks are 0 / 1
+                else { w = B.pending[0]; fix_dict_const(t, w.col, &w.k); wv = table_view(t, w.col); }
+                rc = ph_join_build_where_ex(ctx, kv.data(), 1, &wv, w.op, &w.k, nullptr, t->nrows, su ? PH_JOIN_KEYS_SORTED_UNIQUE : 0, lo, hi, &j);
+                if (rc == PH_OK) { how += su ? " build: gated sorted fill (filter rides along);" : " build: filter fused into the direct build;"; brow_is_rowid = true; }
+                else if (rc != PH_EUNSUPPORTED) return rc;
+            }
+            if (rc == PH_EUNSUPPORTED) {
+                PL_CHECK(apply_pending(p, &B));
+                const bool ident = B.lanes[0].rows == nullptr;
+                const int32_t f2 = flags | (su && ident ? PH_JOIN_KEYS_SORTED_UNIQUE : 0);
+                PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, B.lanes[0].rows, ident ? t->nrows : B.n, f2, lo, hi, &j));
+                how += (f2 & PH_JOIN_KEYS_SORTED_UNIQUE) ? " build: sorted fill;" : ident ? " build: whole table;" : " build: selected rows;";
+                brow_is_rowid = true;
+            }
+        } else {
+            std::vector<int> want(nd.bkeys.begin(), nd.bkeys.end());
+            PL_CHECK(positional(p, &B, want));
+            std::vector<ph_col> kv;
+            for (int32_t k : nd.bkeys) { const int32_t *s = nullptr; kv.push_back(col_view(B, B.cols[(size_t)k], &s)); }
+            const PCol &k0 = B.cols[(size_t)nd.bkeys[0]];
+            if (nk == 1 && k0.src && k0.src->cols[(size_t)k0.src_col].has_range && (k0.type == PH_I32 || k0.type == PH_I64)) {
+                flags |= PH_JOIN_KEY_RANGE; lo = k0.src->cols[(size_t)k0.src_col].min; hi = k0.src->cols[(size_t)k0.src_col].max;
+            }
+            PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, nullptr, B.n, flags, lo, hi, &j));
+            how += " build: intermediate rows;";
+        }
+        p->joins.push_back(j);
+        how += std::string(" table=") + ph_join_kind(j) + ";";
+    }
+    (void)residual;
+
+    // what the probe side's key columns are known to be afterwards: a subset of this table's keys
+    int dom = -1;
+    if (nd.join_type != PH_JT_ANTI && !B.covers) {
+        p->domains.push_back(Domain{j, B.lazy() || B.single_identity() ? B.n : B.n});
+        dom = (int)p->domains.size() - 1;
+    }
+
+    // ---- probe
+    auto build_cols = [&](const int32_t *brow, std::vector<PCol> *cols, Rel *res) -> int {
+        // the build side's columns in the result, addressed through the build row ids of the matches
+        if (brow_is_rowid) {
+            Lane bl; bl.t = B.lanes[0].t; bl.rows = brow; bl.asc = false; bl.dup_free = false;
+            res->lanes.push_back(bl);
+            for (auto c : B.cols) { c.lane = (int)res->lanes.size() - 1; c.ordered = false; c.domain = -1; cols->push_back(c); }
+            return PH_OK;
+        }
+        // positions in B: B's lanes and positional columns gathered by them
+        Rel Bc = B;
+        PL_CHECK(compact(p, &Bc, brow, res->n));
+        const int base = (int)res->lanes.size();
+        for (auto &ln : Bc.lanes) { Lane l2 = ln; l2.asc = false; l2.dup_free = false; res->lanes.push_back(l2); }
+        for (auto c : Bc.cols) { if (c.lane >= 0) c.lane += base; c.ordered = false; c.domain = -1; cols->push_back(c); }
+        return PH_OK;
+    };
+    auto finish = [&](Rel *res, std::vector<PCol> &all) {
+        res->cols.clear();
+        for (int32_t oi : nd.out) res->cols.push_back(all[(size_t)oi]);
+        res->covers = false;
+        drop_unused_lanes(res);
+    };
+    auto tag_domain = [&](std::vector<PCol> &cols) {
+        if (dom < 0) return;
+        for (size_t k = 0; k < nk; k++) if (nk == 1) cols[(size_t)nd.pkeys[k]].domain = dom;
+    };
+
+    // (1) existence only and the result feeds another build: marks, no pair list, no count
+    if (exists_only && nd.join_type != PH_JT_ANTI && as_build && P.single_identity() && P.pending.size() <= 1 && !P.flags) {
+        bool lane_keys = true;
+        for (int32_t k : nd.pkeys) lane_keys = lane_keys && P.cols[(size_t)k].lane == 0;
+        if (lane_keys) {
+            const ph_table *t = P.lanes[0].t;
+            std::vector<ph_col> kv;
+            for (int32_t k : nd.pkeys) kv.push_back(table_view(t, P.cols[(size_t)k].tcol));
+            void *f = nullptr;
+            PL_CHECK(palloc(p, t->nrows + 64, &f));
+            int rc = PH_EUNSUPPORTED;
+            if (P.pending.size() == 1) {
+                ph_pred w = P.pending[0];
+                fix_dict_const(t, w.col, &w.k);
+                ph_col wv = table_view(t, w.col);
+                rc = ph_join_probe_mark_where(j, kv.data(), &wv, w.op, &w.k, t->nrows, (uint8_t *)f);
+            } else rc = ph_join_probe_mark(j, kv.data(), nullptr, t->nrows, (uint8_t *)f);
+            if (rc == PH_OK) {
+                *out = P;
+                out->pending.clear();
+                out->flags = (const uint8_t *)f;
+                std::vector<PCol> all = P.cols;
+                tag_domain(all);
+                out->cols.clear();
+                for (int32_t oi : nd.out) out->cols.push_back(all[(size_t)oi]);
+                out->covers = false;
+                note(p, "join#%d:%s probe: filter + semi-join marks in one pass over %lld rows (no pairs, no count)", idx, how.c_str(), (long long)t->nrows);
+                return PH_OK;
+            }
+            if (rc != PH_EUNSUPPORTED) return rc;
+        }
+    }
+
+    // (2) ANTI: marks, then the rows without one
+    if (nd.join_type == PH_JT_ANTI) {
+        PL_CHECK(apply_pending(p, &P));
+        KeySide pk;
+        PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
+        void *f = nullptr, *sel = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) + 64, &f));
+        PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &sel));
+        int64_t m = 0;
+        if (P.n > 0) {
+            PL_CHECK(ph_join_probe_mark(j, pk.views.data(), pk.sel, P.n, (uint8_t *)f));
+            ph_col fc{};
+            fc.type = PH_CODE8; fc.data = f;
+            ph_const zero{};
+            zero.type = PH_I32; zero.i = 0;
+            PL_CHECK(ph_filter_select(ctx, &fc, P.n, PH_EQ, &zero, nullptr, P.n, (int32_t *)sel, &m));
+        }
+        *out = P;
+        PL_CHECK(compact(p, out, (const int32_t *)sel, m));
+        std::vector<PCol> all = out->cols;
+        finish(out, all);
+        note(p, "join#%d:%s probe: anti (marks + selection), %lld of %lld rows", idx, how.c_str(), (long long)m, (long long)P.n);
+        return PH_OK;
+    }
+
+    // (3) N:1 where every probe row is expected to find its row: a lookup, the intermediate keeps its rows
+    if (n_to_1 && B.covers) {
+        PL_CHECK(apply_pending(p, &P));
+        KeySide pk;
+        PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
+        void *o = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &o));
+        bool compacted = false;
+        if (optimistic) {
+            if (P.n > 0) PL_CHECK(ph_join_lookup_strict(j, pk.views.data(), pk.sel, P.n, (int32_t *)o));
+            how += " probe: strict N:1 lookup";
+        } else {
+            void *st = nullptr;
+            PL_CHECK(palloc(p, 8, &st));
+            PL_CHECK(ph_dev_memset(ctx, st, 0, 8));
+            if (P.n > 0) PL_CHECK(ph_join_lookup(j, pk.views.data(), pk.sel, P.n, (int32_t *)o, (int32_t *)st));
+            int32_t stats[2] = {0, 0};
+            PL_CHECK(ph_dev_download(ctx, stats, st, 8));
+            if (stats[1]) { set_error("ph_plan: join#%d build key declared unique has duplicates (%d probe rows met several build rows)", idx, stats[1]); return PH_ECONSTRAINT; }
+            how += " probe: counted N:1 lookup";
+            if (stats[0]) {   // inner-join semantics: probe rows without a build row leave the result
+                ph_col rc{};
+                rc.type = PH_I32; rc.data = o;
+                ph_const zero{};
+                zero.type = PH_I32; zero.i = 0;
+                void *keep = nullptr;
+                PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &keep));
+                int64_t m = 0;
+                PL_CHECK(ph_filter_select(ctx, &rc, P.n, PH_GE, &zero, nullptr, P.n, (int32_t *)keep, &m));
+                // the lookup result joins the relation as a positional column so that the compaction carries it along
+                Rel Pc = P;
+                PCol tmp; tmp.type = PH_I32; tmp.data = o;
+                Pc.cols.push_back(tmp);
+                if (pk.rowids && Pc.lanes[0].rows == nullptr) { /* identity lane: positions are row ids */ }
+                PL_CHECK(compact(p, &Pc, (const int32_t *)keep, m));
+                o = const_cast<void *>(Pc.cols.back().data);
+                Pc.cols.pop_back();
+                P = Pc;
+                compacted = true;
+                how += " (+ compaction of the misses)";
+            }
+        }
+        (void)compacted;
+        *out = P;
+        std::vector<PCol> all = P.cols;
+        tag_domain(all);
+        out->cols = all;   // build_cols appends lanes to *out
+        std::vector<PCol> bcols;
+        PL_CHECK(build_cols((const int32_t *)o, &bcols, out));
+        for (auto &c : bcols) all.push_back(c);
+        finish(out, all);
+        note(p, "join#%d:%s, %lld rows", idx, how.c_str(), (long long)out->n);
+        return PH_OK;
+    }
+
+    // (4) pairs: the general inner probe (also existence-only joins whose result is probed or aggregated next, and N:1
+    // joins against a filtered build side, where misses are the rule)
+    {
+        int64_t m = 0;
+        int32_t *prow = nullptr, *brow = nullptr;
+        const char *form = "";
+        int rc = PH_EUNSUPPORTED;
+        KeySide pk;
+        bool lane_keys = P.lanes.size() == 1;
+        for (int32_t k : nd.pkeys) lane_keys = lane_keys && P.cols[(size_t)k].lane == 0;
+        for (auto &c : P.cols) lane_keys = lane_keys && c.lane == 0;
+        if (lane_keys && P.single_identity() && P.pending.size() == 1 && !P.flags) {   // Filter -> probe in one pass
+            const ph_table *t = P.lanes[0].t;
+            for (int32_t k : nd.pkeys) pk.views.push_back(table_view(t, P.cols[(size_t)k].tcol));
+            pk.sel = nullptr; pk.n = t->nrows; pk.rowids = true;
+            rc = pair_probe(p, j, pk, &P.pending[0], t, nullptr, &m, &prow, &brow, &form);
+            if (rc == PH_OK) P.pending.clear();
+            else if (rc != PH_EUNSUPPORTED) return rc;
+        }
+        if (rc == PH_EUNSUPPORTED) {
+            PL_CHECK(apply_pending(p, &P));
+            pk = KeySide{};
+            PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
+            PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form));
+        }
+        *out = P;
+        if (pk.rowids) {   // prow = row ids of the one lane, ascending: the lane IS the pair list's probe side
+            out->lanes[0].rows = prow;
+            out->lanes[0].dup_free = out->lanes[0].dup_free && unique;
+            out->n = m;
+        } else {
+            PL_CHECK(compact(p, out, prow, m));
+            for (auto &ln : out->lanes) ln.dup_free = ln.dup_free && unique;
+        }
+        std::vector<PCol> all = out->cols;
+        if (!unique) for (auto &c : all) c.ordered = c.ordered;   // duplicates of a probe row stay adjacent: the order survives
+        tag_domain(all);
+        out->cols = all;
+        if (nd.join_type == PH_JT_INNER) {
+            std::vector<PCol> bcols;
+            PL_CHECK(build_cols(brow, &bcols, out));
+            for (auto &c : bcols) all.push_back(c);
+        }
+        finish(out, all);
+        // late materialisation, ONCE: a sparse row-id vector into a big table — every column the operators above
+        // need from it is fetched in one pass (all reads of a row in flight together, the ids read once)
+        for (size_t L = 0; L < out->lanes.size(); L++) {
+            std::vector<int> cs;
+            for (size_t c = 0; c < out->cols.size(); c++) if (out->cols[c].lane == (int)L) cs.push_back((int)c);
+            if (cs.size() >= 2 && out->lanes[L].rows && out->lanes[L].t->nrows >= 8 * std::max<int64_t>(m, 1) && out->lanes[L].t->nrows >= (1 << 20))
+                PL_CHECK(positional(p, out, cs));
+        }
+        drop_unused_lanes(out);
+        note(p, "join#%d:%s probe: %s, %lld pairs from %lld probe rows", idx, how.c_str(), form, (long long)m, (long long)pk.n);
+        return PH_OK;
+    }
+}
+
+int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
+    if (idx < 0 || idx >= (int)p->nodes.size()) { set_error("ph_plan: child index %d out of range", idx); return PH_EINVAL; }
+    const Node &nd = p->nodes[(size_t)idx];
+    switch (nd.kind) {
+    case PH_PN_SCAN: {
+        const ph_table *t = nd.table;
+        *out = Rel{};
+        out->n = t->nrows;
+        Lane ln; ln.t = t;
+        out->lanes.push_back(ln);
+        for (int32_t c : nd.cols) {
+            if (c < 0 || c >= (int32_t)t->cols.size()) { set_error("ph_plan: scan column %d out of range", c); return PH_EINVAL; }
+            PCol pc;
+            pc.type = t->cols[(size_t)c].type; pc.scale = t->cols[(size_t)c].scale; pc.lane = 0; pc.tcol = c; pc.src = t; pc.src_col = c;
+            pc.ordered = !p->conservative && t->cols[(size_t)c].ascending;
+            out->cols.push_back(pc);
+        }
+        for (size_t i = 0; i < nd.preds.size(); i++) {
+            ph_pred pr = nd.preds[i];
+            if (pr.col < 0 || pr.col >= (int32_t)t->cols.size()) { set_error("ph_plan: scan predicate column %d out of range", pr.col); return PH_EINVAL; }
+            pr.k.s = nd.pred_strs[i].empty() ? nullptr : nd.pred_strs[i].c_str();
+            out->pending.push_back(pr);
+        }
+        out->covers = nd.preds.empty();
+        note(p, "scan#%d: %lld rows, %zu pushed conjuncts", idx, (long long)t->nrows, nd.preds.size());
+        return PH_OK;
+    }
+    case PH_PN_FILTER: {
+        PL_CHECK(lower(p, nd.child[0], as_build, out));
+        bool pushed = true;
+        // conjuncts over the columns of a lazy single-table relation join its pending list (and may still fuse)
+        for (size_t i = 0; i < nd.preds.size(); i++) {
+            const ph_pred &pr = nd.preds[i];
+            if (pr.col < 0 || pr.col >= (int32_t)out->cols.size()) { set_error("ph_plan: filter column %d out of range", pr.col); return PH_EINVAL; }
+            pushed = pushed && out->single_identity() && !out->flags && out->cols[(size_t)pr.col].lane == 0;
+        }
+        if (pushed) {
+            for (size_t i = 0; i < nd.preds.size(); i++) {
+                ph_pred pr = nd.preds[i];
+                pr.col = out->cols[(size_t)pr.col].tcol;
+                pr.k.s = nd.pred_strs[i].empty() ? nullptr : nd.pred_strs[i].c_str();
+                out->pending.push_back(pr);
+            }
+            out->covers = out->covers && nd.preds.empty();
+            return PH_OK;
+        }
+        PL_CHECK(apply_pending(p, out));
+        const int32_t *sel = nullptr;
+        int64_t cnt = out->n;
+        for (size_t i = 0; i < nd.preds.size() && cnt > 0; i++) {
+            ph_pred pr = nd.preds[i];
+            pr.k.s = nd.pred_strs[i].empty() ? nullptr : nd.pred_strs[i].c_str();
+            PL_CHECK(positional(p, out, {pr.col}));
+            const PCol &pc = out->cols[(size_t)pr.col];
+            fix_dict_const(pc.src, pc.src_col, &pr.k);
+            const int32_t *s = nullptr;
+            ph_col v = col_view(*out, pc, &s);
+            void *o = nullptr;
+            PL_CHECK(palloc(p, cnt * 4, &o));
+            int64_t m = 0;
+            PL_CHECK(ph_filter_select(p->ctx, &v, out->n, pr.op, &pr.k, sel, cnt, (int32_t *)o, &m));
+            sel = (const int32_t *)o;
+            cnt = m;
+        }
+        if (sel) PL_CHECK(compact(p, out, sel, cnt));
+        out->covers = false;
+        note(p, "filter#%d: %lld rows kept", idx, (long long)out->n);
+        return PH_OK;
+    }
+    case PH_PN_JOIN:
+        return lower_join(p, idx, as_build, out);
+    case PH_PN_PROJECT: {
+        Rel child;
+        PL_CHECK(lower(p, nd.child[0], as_build, &child));
+        std::vector<PCol> cols;
+        for (auto &e : nd.exprs) {
+            PCol c;
+            PL_CHECK(eval_expr(p, &child, e, &c));
+            cols.push_back(c);
+        }
+        *out = child;
+        out->cols = cols;
+        drop_unused_lanes(out);
+        note(p, "project#%d: %zu expressions", idx, nd.exprs.size());
+        return PH_OK;
+    }
+    default:
+        set_error("ph_plan: node %d has kind %d, which cannot be a child", idx, nd.kind);
+        return PH_EINVAL;
+    }
+}
+
+// ---- the root: HashAggregate
+int lower_agg(ph_plan *p) {
+    const int idx = (int)p->nodes.size() - 1;
+    const Node &nd = p->nodes[(size_t)idx];
+    ph_ctx *ctx = p->ctx;
+    p->keys.clear(); p->agg_scale.clear(); p->agg_arg_type.clear();
+    Rel R;
+    PL_CHECK(lower(p, nd.child[0], false, &R));
+
+    // Agg <- Scan(filter): the fused scan kernels (ph_scan_plan) — the Q1 / Q6 shapes and everything scan_jit generates
+    const Node &ch = p->nodes[(size_t)nd.child[0]];
+    if (ch.kind == PH_PN_SCAN && R.single_identity() && !R.flags) {
+        bool ok = true;
+        std::vector<int32_t> gcols;
+        for (auto &g : nd.groups) { ok = ok && g.kind == PH_PE_COL; if (ok) gcols.push_back(R.cols[(size_t)g.col].tcol); }
+        std::vector<ph_aggexpr> ax(nd.aggs.size());
+        for (size_t a = 0; a < nd.aggs.size() && ok; a++) {
+            ax[a].kind = nd.aggs[a].kind;
+            const ph_plan_expr &e = nd.aggs[a].arg;
+            if (nd.aggs[a].kind == PH_A_COUNT_STAR) { ax[a].nprog = 0; continue; }
+            if (e.kind == PH_PE_COL) { ax[a].nprog = 1; ax[a].prog[0] = ph_rpn{PH_X_COL, R.cols[(size_t)e.col].tcol, 0, 0}; }
+            else if (e.kind == PH_PE_DECIMAL) {
+                ax[a].nprog = e.nprog;
+                for (int i = 0; i < e.nprog; i++) { ax[a].prog[i] = e.prog[i]; if (e.prog[i].op == PH_X_COL) ax[a].prog[i].col = R.cols[(size_t)e.prog[i].col].tcol; }
+            } else ok = false;
+        }
+        if (ok) {
+            std::vector<ph_pred> preds = R.pending;
+            if (p->scan) { ph_scan_plan_free(p->scan); p->scan = nullptr; }
+            int rc = ph_scan_plan_create(ctx, ch.table, preds.data(), (int32_t)preds.size(), gcols.data(), (int32_t)gcols.size(), ax.data(), (int32_t)ax.size(), &p->scan);
+            if (rc == PH_OK) {
+                PL_CHECK(ph_scan_plan_run(p->scan, 0, ch.table->nrows));
+                for (auto &g : nd.groups) { const PCol &c = R.cols[(size_t)g.col]; p->keys.push_back(KeyInfo{c.type, c.scale, c.src, c.src_col}); }
+                for (size_t a = 0; a < nd.aggs.size(); a++) {
+                    int32_t t = PH_I32;
+                    const ph_plan_expr &e = nd.aggs[a].arg;
+                    if (nd.aggs[a].kind != PH_A_COUNT_STAR) t = e.kind == PH_PE_COL ? R.cols[(size_t)e.col].type : PH_DEC64;
+                    p->agg_arg_type.push_back(t);
+                }
+                note(p, "agg#%d: fused scan plan (%s)", idx, ph_scan_plan_kind(p->scan));
+                return PH_OK;
+            }
+            if (rc != PH_EUNSUPPORTED) return rc;
+        }
+    }
+
+    PL_CHECK(apply_pending(p, &R));
+    // group keys and aggregate arguments as columns of the relation
+    std::vector<PCol> kc(nd.groups.size()), ac(nd.aggs.size());
+    for (size_t g = 0; g < nd.groups.size(); g++) PL_CHECK(eval_expr(p, &R, nd.groups[g], &kc[g]));
+    for (size_t a = 0; a < nd.aggs.size(); a++) {
+        if (nd.aggs[a].kind == PH_A_COUNT_STAR) continue;
+        PL_CHECK(eval_expr(p, &R, nd.aggs[a].arg, &ac[a]));
+    }
+    // everything positional: the sink reads position i of every key and argument
+    Rel S = R;
+    S.cols.clear();
+    for (auto &c : kc) S.cols.push_back(c);
+    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind != PH_A_COUNT_STAR) S.cols.push_back(ac[a]);
+    std::vector<int> all;
+    for (size_t c = 0; c < S.cols.size(); c++) if (S.cols[c].lane >= 0) all.push_back((int)c);
+    PL_CHECK(positional(p, &S, all));
+    std::vector<ph_col> keys, args(nd.aggs.size());
+    std::vector<int32_t> key_types;
+    size_t ci = 0;
+    for (size_t g = 0; g < nd.groups.size(); g++, ci++) {
+        const PCol &c = S.cols[ci];
+        if (width_of(c.type) == 0) { set_error("ph_plan: VARCHAR group key that is not a dictionary-code column"); return PH_EUNSUPPORTED; }
+        const int32_t *s = nullptr;
+        keys.push_back(col_view(S, c, &s));
+        key_types.push_back(c.type);
+        p->keys.push_back(KeyInfo{c.type, c.scale, c.src, c.src_col});
+    }
+    std::vector<ph_aggspec> specs;
+    for (size_t a = 0; a < nd.aggs.size(); a++) {
+        specs.push_back(ph_aggspec{nd.aggs[a].kind, (int32_t)a});
+        if (nd.aggs[a].kind == PH_A_COUNT_STAR) { p->agg_scale.push_back(0); p->agg_arg_type.push_back(PH_I32); continue; }
+        const PCol &c = S.cols[ci++];
+        const int32_t *s = nullptr;
+        args[a] = col_view(S, c, &s);
+        p->agg_scale.push_back(c.scale);
+        p->agg_arg_type.push_back(c.type);
+    }
+    if (keys.empty()) {   // one global group: a constant key (executor_aggr.go:37-48)
+        void *zero = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(S.n, 1) * 4, &zero));
+        PL_CHECK(ph_dev_memset(ctx, zero, 0, std::max<int64_t>(S.n, 1) * 4));
+        ph_col c{};
+        c.type = PH_I32; c.data = zero;
+        keys.push_back(c);
+        key_types.push_back(PH_I32);
+    }
+    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind == PH_A_COUNT_STAR) args[a] = keys[0];
+    // expected groups: a key that is (a copy of) a wide integer table column is taken to be high-cardinality
+    int64_t expected = 1024;
+    if (!nd.groups.empty() && (S.cols[0].type == PH_I64 || S.cols[0].type == PH_I32) && S.cols[0].src) {
+        const auto &sc = S.cols[0].src->cols[(size_t)S.cols[0].src_col];
+        if (sc.has_range && sc.max - sc.min > 65536) expected = std::max<int64_t>(S.n / 2, 1024);
+    }
+    if (p->agg) { ph_agg_free(p->agg); p->agg = nullptr; }
+    PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &p->agg));
+    bool streamed = false;
+    if (!p->conservative && !nd.groups.empty() && S.cols[0].ordered && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
+        int rc = ph_agg_sink_sorted(p->agg, keys.data(), args.data(), (int32_t)args.size(), S.n, 0);
+        if (rc == PH_OK) streamed = true;
+        else if (rc != PH_EUNSUPPORTED) return rc;
+    }
+    if (!streamed && S.n > 0) PL_CHECK(ph_agg_sink(p->agg, keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0));
+    note(p, "agg#%d: %s over %lld rows, %zu keys, %zu aggregates", idx, streamed ? "streaming aggregate (rows ordered by the first key)" : "hash aggregate",
+         (long long)S.n, nd.groups.size(), nd.aggs.size());
+    return PH_OK;
+}
+
+int run_once(ph_plan *p) {
+    release_run(p, false);
+    if (p->scan) { ph_scan_plan_free(p->scan); p->scan = nullptr; }
+    p->explain.clear();
+    note(p, "plan run (%s forms)", p->conservative ? "conservative" : "optimistic");
+    PL_CHECK(ph_ctx_set_deferred_errors(p->ctx, 1));
+    int rc = lower_agg(p);
+    if (rc != PH_OK) { release_run(p, false); (void)ph_ctx_set_deferred_errors(p->ctx, 0); return rc; }
+    p->ran = true;
+    return PH_OK;
+}
+
+ph_agg_result *new_result(int64_t ng, int nkeys, int naggs) {
+    const size_t g = (size_t)std::max<int64_t>(ng, 1), nk = (size_t)std::max(nkeys, 1), na = (size_t)std::max(naggs, 1);
+    ph_agg_result *r = (ph_agg_result *)calloc(1, sizeof *r);
+    r->ngroups = ng; r->nkeys = nkeys; r->naggs = naggs;
+    r->first_row = (int64_t *)calloc(g, 8);
+    r->keys = (int64_t *)calloc(g * nk, 8);
+    r->sum_lo = (uint64_t *)calloc(g * na, 8);
+    r->sum_hi = (int64_t *)calloc(g * na, 8);
+    r->count = (uint64_t *)calloc(g * na, 8);
+    r->scale = (int32_t *)calloc(na, 4);
+    return r;
+}
+
+int fetch_once(ph_plan *p, ph_agg_result **out) {
+    const Node &nd = p->nodes.back();
+    if (p->scan) return ph_scan_plan_fetch(p->scan, out);
+    const int nkeys = (int)nd.groups.size(), naggs = (int)nd.aggs.size();
+    const int nk = std::max(nkeys, 1);
+    int64_t room = p->topk_agg >= 0 ? 4096 : 1024, ng = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        std::vector<int64_t> first((size_t)room), keys((size_t)room * nk), hi((size_t)room * std::max(naggs, 1));
+        std::vector<uint8_t> knull((size_t)room * nk);
+        std::vector<uint64_t> lo((size_t)room * std::max(naggs, 1)), cnt((size_t)room * std::max(naggs, 1));
+        int rc;
+        if (p->topk_agg >= 0) rc = ph_agg_topk(p->agg, p->topk_agg, p->topk_desc, p->topk_k, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
+        else rc = ph_agg_fetch(p->agg, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
+        if (rc == PH_ECAPACITY && ng > room) { room = ng; continue; }
+        PL_CHECK(rc);
+        ph_agg_result *r = new_result(ng, nkeys, naggs);
+        for (int64_t g = 0; g < ng; g++) {
+            r->first_row[g] = first[(size_t)g];
+            for (int k = 0; k < nkeys; k++) r->keys[g * nk + k] = keys[(size_t)(g * nk + k)];
+            for (int a = 0; a < naggs; a++) {
+                r->sum_lo[g * naggs + a] = lo[(size_t)(g * naggs + a)];
+                r->sum_hi[g * naggs + a] = hi[(size_t)(g * naggs + a)];
+                r->count[g * naggs + a] = cnt[(size_t)(g * naggs + a)];
+            }
+        }
+        for (int a = 0; a < naggs; a++) r->scale[a] = p->agg_scale[(size_t)a];
+        *out = r;
+        return PH_OK;
+    }
+    set_error("ph_plan_fetch: group count kept growing");
+    return PH_ECAPACITY;
+}
+
+}  // namespace
+
+extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_plan **out) {
+    PH_REQUIRE(ctx && nodes && out && nnodes >= 2 && nnodes <= 64, "ph_plan_create: bad arguments (2..64 nodes)");
+    PH_REQUIRE(nodes[nnodes - 1].kind == PH_PN_AGG, "ph_plan_create: the last node is the root and must be a PH_PN_AGG");
+    ph_plan *p = new ph_plan();
+    p->ctx = ctx;
+    auto fail = [&](int rc) { delete p; return rc; };
+    for (int32_t i = 0; i < nnodes; i++) {
+        const ph_plan_node &s = nodes[i];
+        Node n;
+        n.kind = s.kind;
+        n.child[0] = s.child[0]; n.child[1] = s.child[1];
+        for (int c = 0; c < 2; c++)
+            if (n.child[c] >= i) { set_error("ph_plan_create: node %d: children must precede their parent", i); return fail(PH_EINVAL); }
+        switch (s.kind) {
+        case PH_PN_SCAN:
+            if (!s.table || s.ncols < 0 || (s.ncols && !s.cols) || s.npreds < 0 || (s.npreds && !s.preds)) { set_error("ph_plan_create: node %d: bad scan", i); return fail(PH_EINVAL); }
+            n.table = s.table;
+            n.cols.assign(s.cols, s.cols + s.ncols);
+            break;
+        case PH_PN_FILTER:
+            if (s.child[0] < 0 || s.npreds < 0 || (s.npreds && !s.preds)) { set_error("ph_plan_create: node %d: bad filter", i); return fail(PH_EINVAL); }
+            break;
+        case PH_PN_JOIN:
+            if (s.child[0] < 0 || s.child[1] < 0 || s.nkeys < 1 || s.nkeys > 4 || !s.probe_keys || !s.build_keys || s.nout < 0 || (s.nout && !s.out) ||
+                s.join_type < PH_JT_INNER || s.join_type > PH_JT_ANTI) { set_error("ph_plan_create: node %d: bad join", i); return fail(PH_EINVAL); }
+            n.join_type = s.join_type;
+            n.pkeys.assign(s.probe_keys, s.probe_keys + s.nkeys);
+            n.bkeys.assign(s.build_keys, s.build_keys + s.nkeys);
+            n.out.assign(s.out, s.out + s.nout);
+            break;
+        case PH_PN_PROJECT:
+            if (s.child[0] < 0 || s.nexprs < 1 || !s.exprs) { set_error("ph_plan_create: node %d: bad project", i); return fail(PH_EINVAL); }
+            n.exprs.assign(s.exprs, s.exprs + s.nexprs);
+            break;
+        case PH_PN_AGG:
+            if (i != nnodes - 1 || s.child[0] < 0 || s.naggs < 1 || !s.aggs || s.ngroups < 0 || s.ngroups > 4 || (s.ngroups && !s.groups) || s.naggs > 16) {
+                set_error("ph_plan_create: node %d: bad aggregate (root only, <= 4 group expressions, 1..16 aggregates)", i);
+                return fail(PH_EINVAL);
+            }
+            n.groups.assign(s.groups, s.groups + s.ngroups);
+            n.aggs.assign(s.aggs, s.aggs + s.naggs);
+            break;
+        default:
+            set_error("ph_plan_create: node %d: unknown kind %d", i, s.kind);
+            return fail(PH_EINVAL);
+        }
+        if (s.kind == PH_PN_SCAN || s.kind == PH_PN_FILTER) {
+            n.pred_strs.resize((size_t)s.npreds);
+            for (int32_t k = 0; k < s.npreds; k++) {
+                n.preds.push_back(s.preds[k]);
+                if (s.preds[k].k.s) n.pred_strs[(size_t)k] = s.preds[k].k.s;
+                n.preds.back().k.s = nullptr;
+            }
+        }
+        for (auto &e : n.exprs) if (e.nprog < 0 || e.nprog > 12) { set_error("ph_plan_create: node %d: expression program too long", i); return fail(PH_EINVAL); }
+        p->nodes.push_back(std::move(n));
+    }
+    *out = p;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k) {
+    PH_REQUIRE(p && k > 0 && agg_index >= 0 && agg_index < (int32_t)p->nodes.back().aggs.size(), "ph_plan_set_topk: bad arguments");
+    p->topk_agg = agg_index;
+    p->topk_desc = descending ? 1 : 0;
+    p->topk_k = k;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_run(ph_plan *p) {
+    PH_REQUIRE(p != nullptr, "ph_plan_run: plan is NULL");
+    PH_HIP(hipSetDevice(p->ctx->device));
+    int rc = run_once(p);
+    if (rc == PH_ECONSTRAINT && !p->conservative) {   // a broken claim surfaced at a count read-back in the middle of the run
+        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): conservative forms from here on\n";
+        const std::string first = p->explain;
+        p->conservative = true;
+        rc = run_once(p);
+        p->explain = first + p->explain;
+    }
+    return rc;
+}
+
+extern "C" int ph_plan_fetch(ph_plan *p, ph_agg_result **out) {
+    PH_REQUIRE(p && out, "ph_plan_fetch: bad arguments");
+    PH_REQUIRE(p->ran, "ph_plan_fetch: ph_plan_run first");
+    // the intermediates go back to the pool BEFORE the host blocks in the download (bookkeeping while the GPU is busy)
+    release_run(p, true);
+    int rc = fetch_once(p, out);
+    if (rc == PH_ECONSTRAINT && !p->conservative) {
+        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): the plan runs again in its conservative forms\n";
+        const std::string first = p->explain;
+        p->conservative = true;
+        rc = run_once(p);
+        p->explain = first + p->explain;
+        if (rc == PH_OK) { release_run(p, true); rc = fetch_once(p, out); }
+    }
+    (void)ph_ctx_set_deferred_errors(p->ctx, 0);
+    p->ran = false;
+    return rc;
+}
+
+extern "C" int ph_plan_key_info(const ph_plan *p, int32_t k, int32_t *type, int32_t *scale, const ph_table **table, int32_t *col) {
+    PH_REQUIRE(p && k >= 0 && k < (int32_t)p->keys.size(), "ph_plan_key_info: key %d of %zu (after ph_plan_run)", k, p ? p->keys.size() : (size_t)0);
+    const KeyInfo &ki = p->keys[(size_t)k];
+    if (type) *type = ki.type;
+    if (scale) *scale = ki.scale;
+    if (table) *table = ki.table;
+    if (col) *col = ki.col;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_agg_arg_type(const ph_plan *p, int32_t a, int32_t *type) {
+    PH_REQUIRE(p && type && a >= 0 && a < (int32_t)p->agg_arg_type.size(), "ph_plan_agg_arg_type: aggregate %d (after ph_plan_run)", a);
+    *type = p->agg_arg_type[(size_t)a];
+    return PH_OK;
+}
+
+extern "C" const char *ph_plan_explain(const ph_plan *p) { return p ? p->explain.c_str() : ""; }
+
+extern "C" void ph_plan_free(ph_plan *p) {
+    if (!p) return;
+    release_run(p, false);
+    if (p->scan) ph_scan_plan_free(p->scan);
+    delete p;
+}

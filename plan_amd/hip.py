@@ -748,3 +748,148 @@ def cross_pairs(ctx, n_left, n_right):
     ol, orr = ctx.alloc(tot * 4), ctx.alloc(tot * 4)
     check(lib().ph_cross_pairs(ctx.h, i64(n_left), i64(n_right), ol, orr))
     return ol, orr
+
+
+# ---------------------------------------------------------------- resident plans (ph_plan_*)
+
+PH_PN_SCAN, PH_PN_FILTER, PH_PN_JOIN, PH_PN_PROJECT, PH_PN_AGG = range(1, 6)
+PH_JT_INNER, PH_JT_SEMI, PH_JT_ANTI = 1, 2, 3
+PH_PE_COL, PH_PE_DECIMAL, PH_PE_YEAR = 1, 2, 3
+PH_STAT_ASCENDING, PH_STAT_STRICT, PH_STAT_DECLARED_UNIQUE = 1, 2, 4
+
+
+class PlanExpr(ctypes.Structure):
+    _fields_ = [("kind", i32), ("col", i32), ("nprog", i32), ("prog", Rpn * 12)]
+
+
+class PlanAgg(ctypes.Structure):
+    _fields_ = [("kind", i32), ("arg", PlanExpr)]
+
+
+class PlanNode(ctypes.Structure):
+    _fields_ = [("kind", i32), ("child", i32 * 2), ("table", vp), ("ncols", i32), ("cols", ctypes.POINTER(i32)),
+                ("npreds", i32), ("preds", ctypes.POINTER(Pred)), ("join_type", i32), ("nkeys", i32),
+                ("probe_keys", ctypes.POINTER(i32)), ("build_keys", ctypes.POINTER(i32)), ("nout", i32), ("out", ctypes.POINTER(i32)),
+                ("nexprs", i32), ("exprs", ctypes.POINTER(PlanExpr)), ("ngroups", i32), ("groups", ctypes.POINTER(PlanExpr)),
+                ("naggs", i32), ("aggs", ctypes.POINTER(PlanAgg))]
+
+
+def pe_col(c):
+    e = PlanExpr()
+    e.kind, e.col = PH_PE_COL, c
+    return e
+
+
+def pe_year(c):
+    e = PlanExpr()
+    e.kind, e.col = PH_PE_YEAR, c
+    return e
+
+
+def pe_dec(prog):
+    e = PlanExpr()
+    e.kind, e.col, e.nprog = PH_PE_DECIMAL, -1, len(prog)
+    for j, x in enumerate(prog):
+        e.prog[j] = Rpn(*x)
+    return e
+
+
+def _i32arr(v):
+    return (i32 * max(len(v), 1))(*v)
+
+
+class Plan:
+    """ph_plan: an operator subtree Agg <- [Project] <- Join* <- Scan over resident tables, described node by node
+    (children first, the aggregate last) and lowered inside the library from the tables' statistics."""
+
+    def __init__(self, ctx):
+        self.ctx, self.nodes, self._keep, self.h = ctx, [], [], None
+
+    def _add(self, n):
+        self.nodes.append(n)
+        return len(self.nodes) - 1
+
+    def scan(self, table, cols, preds=()):
+        n = PlanNode()
+        n.kind, n.child[0], n.child[1] = PH_PN_SCAN, -1, -1
+        n.table = table.h
+        ca, pa = _i32arr(cols), (Pred * max(len(preds), 1))(*preds)
+        self._keep += [ca, pa, table]
+        n.ncols, n.cols = len(cols), ca
+        n.npreds, n.preds = len(preds), pa
+        return self._add(n)
+
+    def filter(self, child, preds):
+        n = PlanNode()
+        n.kind, n.child[0], n.child[1] = PH_PN_FILTER, child, -1
+        pa = (Pred * max(len(preds), 1))(*preds)
+        self._keep.append(pa)
+        n.npreds, n.preds = len(preds), pa
+        return self._add(n)
+
+    def join(self, probe, build, probe_keys, build_keys, out, join_type=PH_JT_INNER):
+        n = PlanNode()
+        n.kind, n.child[0], n.child[1] = PH_PN_JOIN, probe, build
+        pk, bk, oa = _i32arr(probe_keys), _i32arr(build_keys), _i32arr(out)
+        self._keep += [pk, bk, oa]
+        n.join_type, n.nkeys, n.probe_keys, n.build_keys = join_type, len(probe_keys), pk, bk
+        n.nout, n.out = len(out), oa
+        return self._add(n)
+
+    def project(self, child, exprs):
+        n = PlanNode()
+        n.kind, n.child[0], n.child[1] = PH_PN_PROJECT, child, -1
+        ea = (PlanExpr * len(exprs))(*exprs)
+        self._keep.append(ea)
+        n.nexprs, n.exprs = len(exprs), ea
+        return self._add(n)
+
+    def agg(self, child, groups, aggs):
+        """aggs: list of (ph_aggkind, PlanExpr or None)"""
+        n = PlanNode()
+        n.kind, n.child[0], n.child[1] = PH_PN_AGG, child, -1
+        ga = (PlanExpr * max(len(groups), 1))(*groups)
+        aa = (PlanAgg * len(aggs))()
+        for j, (kind, arg) in enumerate(aggs):
+            aa[j].kind = kind
+            if arg is not None:
+                aa[j].arg = arg
+        self._keep += [ga, aa]
+        n.ngroups, n.groups, n.naggs, n.aggs = len(groups), ga, len(aggs), aa
+        return self._add(n)
+
+    def create(self):
+        arr = (PlanNode * len(self.nodes))(*self.nodes)
+        self.h = vp()
+        check(lib().ph_plan_create(self.ctx.h, arr, i32(len(self.nodes)), ctypes.byref(self.h)))
+        return self
+
+    def set_topk(self, agg_index, k, descending=True):
+        check(lib().ph_plan_set_topk(self.h, i32(agg_index), i32(1 if descending else 0), i64(k)))
+
+    def run(self):
+        check(lib().ph_plan_run(self.h))
+
+    def fetch(self):
+        rp = ctypes.POINTER(AggResult)()
+        check(lib().ph_plan_fetch(self.h, ctypes.byref(rp)))
+        return _result(rp)
+
+    def explain(self):
+        lib().ph_plan_explain.restype = ctypes.c_char_p
+        return lib().ph_plan_explain(self.h).decode()
+
+    def free(self):
+        if self.h:
+            lib().ph_plan_free(self.h)
+            self.h = None
+
+
+def table_col_stats(table, c):
+    f = i32()
+    check(lib().ph_table_col_stats(table.h, i32(c), ctypes.byref(f)))
+    return f.value
+
+
+def table_declare_unique(table, cols):
+    check(lib().ph_table_declare_unique(table.h, i32(len(cols)), _i32arr(cols)))
