@@ -18,7 +18,8 @@ ONE JSON line on rank 0 (driver contract). Besides the contract's fields:
                  this run (ph_dev_read_reduce); traffic = HBM bytes of the committed PMC passes
   cpu_baseline   the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
   N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu (every BASELINE.json
-         config, each with its own roofline; Q3 with its own cpu_baseline)
+         config, each with its own roofline; Q3 / Q9 with their own cpu_baseline), and q3_operator_interface /
+         q9_operator_interface: the same two queries through the C++ OperatorExec layer as one resident-plan executor
   N > 1: companions q3_partitioned, q3_partitionwise, q9_partitioned, q9_partitionwise — Q3 / Q9 over an SF`--sf` database split N
          ways (strong scaling, BASELINE.json configs 4 and 5), join sides hash-partitioned by order
          key and exchanged with ph_comm_exchange_columns, small build sides broadcast; probe rows/s
@@ -486,6 +487,48 @@ def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
     return line
 
 
+# ---------------------------------------------------------------------------------- operator interface
+
+def bench_operator_interface(h, sf, steps, warmup):
+    """Q3 and Q9 behind the reference's OperatorExec interface: the C++ host layer (plan_amd/csrc/host, what the Go
+    shim is written after) builds, for every step, the executor tree limitExecutor <- gpuOrderExecutor <-
+    gpuResidentPlanExecutor over the resident database, pulls it like execOps (executor.go:151-188) and closes it.
+    The whole Agg <- Join* <- Scan subtree is ONE executor whose plan (ph_plan) the library lowers from the tables'
+    statistics. A step = one whole query, result text included; timed by the host layer like Run's
+    "Query N took" (executor_bench.go:126-137)."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "plan_amd", "libplantpch.so"))
+    lib.planhost_last_error.restype = ctypes.c_char_p
+    lib.planhost_tpch_rows.restype = ctypes.c_int64
+    db = ctypes.c_void_p()
+    t0 = time.time()
+    if lib.planhost_tpch_load(h.ctx.h, ctypes.c_int64(sf), ctypes.c_int64(1), ctypes.byref(db)) != 0:
+        raise RuntimeError(lib.planhost_last_error().decode())
+    load_s = time.time() - t0
+    out = {}
+    try:
+        nl = int(lib.planhost_tpch_rows(db, b"lineitem"))
+        for q in (3, 9):
+            avg, mn = ctypes.c_double(), ctypes.c_double()
+            text, explain = ctypes.create_string_buffer(1 << 16), ctypes.create_string_buffer(1 << 14)
+            if lib.planhost_tpch_run(db, ctypes.c_int32(q), ctypes.c_int32(steps), ctypes.c_int32(warmup), ctypes.byref(avg), ctypes.byref(mn),
+                                     text, ctypes.c_int64(len(text)), explain, ctypes.c_int64(len(explain))) != 0:
+                out[f"q{q}_operator_interface"] = {"error": lib.planhost_last_error().decode()}
+                continue
+            rows = text.value.decode().split("\n")
+            out[f"q{q}_operator_interface"] = {
+                "metric": f"rows/sec through Q{q} behind the OperatorExec interface (C++ host layer, one resident-plan executor)",
+                "value": nl / (avg.value * 1e-3), "unit": "rows/s", "n_gpus": 1, "ms_per_step": avg.value, "min_ms": mn.value, "steps": steps, "warmup": warmup,
+                "config": {"workload": f"TPC-H Q{q} at SF{sf}: limitExecutor <- gpuOrderExecutor <- gpuResidentPlanExecutor(ph_plan) built, pulled and closed per step; "
+                                       f"{nl} lineitem rows, all eight tables resident (generated + loaded by the host layer in {load_s:.1f} s)",
+                           "result_rows": len([r for r in rows[1:] if r]), "first_row": rows[1] if len(rows) > 1 else None,
+                           "forms_chosen_by_the_library": [l.strip() for l in explain.value.decode().split("\n") if l.startswith(("join", "agg"))]},
+            }
+    finally:
+        lib.planhost_tpch_free(db)
+    return out
+
+
 # ---------------------------------------------------------------------------------- CPU baselines
 
 def cpu_baselines(L, max_rows):
@@ -611,6 +654,10 @@ def main():
         # like their stand-alone runs
         attempt("q3_single_gpu", lambda: brief(bench_q3(h, args.sf, max(comp_steps, 50), max(comp_warm, 8), "weak")))
         attempt("q9_single_gpu", lambda: brief(bench_q9(h, args.sf, max(comp_steps, 50), max(comp_warm, 8))))
+        try:   # the same two queries behind the operator interface (C++ host layer -> ph_plan)
+            out.update(bench_operator_interface(h, args.sf, max(comp_steps, 50), max(comp_warm, 8)))
+        except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
+            out["q3_operator_interface"] = out["q9_operator_interface"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             if "error" not in out["q6_single_gpu"]:
                 out["q6_single_gpu"]["cpu_baseline"] = cb["q6"]

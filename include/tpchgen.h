@@ -46,7 +46,18 @@ extern const char *const TPCHGEN_RETURNFLAG_DICT[3];  /* "A","N","R" */
 extern const char *const TPCHGEN_LINESTATUS_DICT[2];  /* "F","O" */
 extern const char *const TPCHGEN_MKTSEGMENT_DICT[5];  /* AUTOMOBILE,BUILDING,FURNITURE,HOUSEHOLD,MACHINERY */
 extern const char *const TPCHGEN_NATION_NAMES[25];
+extern const int32_t TPCHGEN_NATION_REGION[25];        /* n_regionkey of nation n */
+extern const char *const TPCHGEN_REGION_NAMES[5];      /* AFRICA, AMERICA, ASIA, EUROPE, MIDDLE EAST */
 extern const char *const TPCHGEN_COLORS[92];
+/* dictionaries of the VARCHAR columns generated as codes (all in ascending byte order, so code order = string order) */
+extern const char *const TPCHGEN_SHIPMODE_DICT[7];     /* AIR, FOB, MAIL, RAIL, REG AIR, SHIP, TRUCK */
+extern const char *const TPCHGEN_SHIPINSTRUCT_DICT[4]; /* COLLECT COD, DELIVER IN PERSON, NONE, TAKE BACK RETURN */
+extern const char *const TPCHGEN_ORDERPRIORITY_DICT[5];/* 1-URGENT .. 5-LOW */
+/* p_type (150 strings "<size> <finish> <metal>"), p_container (40 "<size> <kind>"), p_brand (25 "Brand#MN"):
+ * code -> string through these; the strings are built once by tpchgen_part_dicts */
+const char *const *tpchgen_part_type_dict(void);      /* 150 */
+const char *const *tpchgen_part_container_dict(void); /* 40 */
+const char *const *tpchgen_part_brand_dict(void);     /* 25 */
 
 typedef struct {
     int64_t *l_orderkey;      /* BIGINT */
@@ -62,6 +73,8 @@ typedef struct {
     int32_t *l_shipdate;      /* days since epoch */
     int32_t *l_commitdate;
     int32_t *l_receiptdate;
+    uint8_t *l_shipinstruct;  /* code into TPCHGEN_SHIPINSTRUCT_DICT */
+    uint8_t *l_shipmode;      /* code into TPCHGEN_SHIPMODE_DICT */
 } tpchgen_lineitem_cols; /* any pointer may be NULL = column not wanted */
 
 /* Generates the lineitem rows of orders [first_order, first_order+n_orders).
@@ -76,6 +89,7 @@ typedef struct {
     int32_t *o_shippriority;
     int64_t *o_totalprice; /* DECIMAL(15,2) unscaled */
     uint8_t *o_orderstatus; /* 'F','O','P' raw byte */
+    uint8_t *o_orderpriority; /* code into TPCHGEN_ORDERPRIORITY_DICT */
 } tpchgen_orders_cols;
 
 int64_t tpchgen_orders(int64_t sf_num, int64_t sf_den, int64_t first_order,
@@ -94,6 +108,10 @@ typedef struct {
     int32_t *p_partkey;
     uint8_t *p_name_colors; /* 5 bytes per part: indices into TPCHGEN_COLORS; p_name is the
                                5 words joined by single blanks */
+    uint8_t *p_brand;       /* code into tpchgen_part_brand_dict() */
+    uint8_t *p_type;        /* code into tpchgen_part_type_dict() */
+    int32_t *p_size;        /* INTEGER 1..50 */
+    uint8_t *p_container;   /* code into tpchgen_part_container_dict() */
 } tpchgen_part_cols;
 
 int64_t tpchgen_part(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,

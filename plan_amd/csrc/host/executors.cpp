@@ -1190,3 +1190,255 @@ OperatorResult crossProductExecutor::Execute(Chunk *, Chunk *output, std::string
 }
 
 }  // namespace plan
+
+namespace plan {
+
+// ------------------------------------------------------------------ resident plans
+
+static std::string exprType(const ProjExpr &e, const std::vector<LType> &childTypes, const std::vector<const ResidentColumn *> &childSrc,
+                            LType *t, const ResidentColumn **src) {
+    std::vector<LType> one;
+    std::string err = gpuProjectExecutor::Types({e}, childTypes, &one);
+    if (!err.empty()) return err;
+    if (e.kind == ProjExpr::Substring) return "substring is not part of a resident plan";
+    *t = one[0];
+    *src = e.kind == ProjExpr::ColRef ? childSrc[(size_t)e.col] : nullptr;
+    return "";
+}
+
+int ResidentPlan::Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts) {
+    Node n;
+    n.kind = PH_PN_SCAN;
+    n.table = t;
+    for (int c : cols) {
+        if (c < 0 || c >= (int)t->cols.size()) { if (error.empty()) error = "scan column out of range"; c = 0; }
+        n.types.push_back(t->cols[(size_t)c].type);
+        n.source.push_back(&t->cols[(size_t)c]);
+    }
+    for (auto &c : conjuncts) if ((c.col < 0 || c.col >= (int)t->cols.size()) && error.empty()) error = "scan conjunct column out of range";
+    n.cols = std::move(cols);
+    n.conjuncts = std::move(conjuncts);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+int ResidentPlan::Filter(int child, std::vector<Compare> conjuncts) {
+    Node n;
+    n.kind = PH_PN_FILTER;
+    n.child[0] = child;
+    n.types = nodes[(size_t)child].types;
+    n.source = nodes[(size_t)child].source;
+    n.conjuncts = std::move(conjuncts);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+int ResidentPlan::Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type) {
+    Node n;
+    n.kind = PH_PN_JOIN;
+    n.child[0] = probe; n.child[1] = build;
+    n.joinType = type;
+    std::vector<LType> all = nodes[(size_t)probe].types;
+    std::vector<const ResidentColumn *> src = nodes[(size_t)probe].source;
+    for (auto &t : nodes[(size_t)build].types) all.push_back(t);
+    for (auto s : nodes[(size_t)build].source) src.push_back(s);
+    for (int o : out) {
+        if (o < 0 || o >= (int)all.size()) { if (error.empty()) error = "join output column out of range"; o = 0; }
+        n.types.push_back(all[(size_t)o]);
+        n.source.push_back(src[(size_t)o]);
+    }
+    if (type == JoinLeft && error.empty()) error = "LEFT joins stay with gpuJoinExecutor";
+    n.probeKeys = std::move(probeKeys); n.buildKeys = std::move(buildKeys); n.out = std::move(out);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+int ResidentPlan::Project(int child, std::vector<ProjExpr> exprs) {
+    Node n;
+    n.kind = PH_PN_PROJECT;
+    n.child[0] = child;
+    for (auto &e : exprs) {
+        LType t;
+        const ResidentColumn *s = nullptr;
+        std::string err = exprType(e, nodes[(size_t)child].types, nodes[(size_t)child].source, &t, &s);
+        if (!err.empty() && error.empty()) error = err;
+        n.types.push_back(t);
+        n.source.push_back(s);
+    }
+    n.exprs = std::move(exprs);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+int ResidentPlan::Agg(int child, std::vector<ProjExpr> groups, std::vector<AggExpr> aggs) {
+    Node n;
+    n.kind = PH_PN_AGG;
+    n.child[0] = child;
+    for (auto &e : groups) {
+        LType t;
+        const ResidentColumn *s = nullptr;
+        std::string err = exprType(e, nodes[(size_t)child].types, nodes[(size_t)child].source, &t, &s);
+        if (!err.empty() && error.empty()) error = err;
+        n.types.push_back(t);
+        n.source.push_back(s);
+    }
+    n.exprs = std::move(groups);
+    n.aggs = std::move(aggs);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+static ph_pred lowerCompare(const Compare &c) {
+    ph_pred p{};
+    p.col = c.col;
+    p.op = c.op;
+    switch (c.k.kind) {
+    case Literal::Int: p.k.type = PH_I32; p.k.i = c.k.i; break;
+    case Literal::Float: p.k.type = PH_F32; p.k.f = c.k.f; break;
+    case Literal::DateDays: p.k.type = PH_DATE; p.k.i = c.k.i; break;
+    case Literal::Dec: p.k.type = PH_DEC64; p.k.i = c.k.i; p.k.scale = c.k.scale; break;
+    case Literal::Str: p.k.type = PH_STR; p.k.s = c.k.s.c_str(); break;   // the plan outlives the call that copies it
+    }
+    return p;
+}
+
+static ph_plan_expr lowerExpr(const ProjExpr &e) {
+    ph_plan_expr x{};
+    switch (e.kind) {
+    case ProjExpr::ColRef: x.kind = PH_PE_COL; x.col = e.col; break;
+    case ProjExpr::ExtractYear: x.kind = PH_PE_YEAR; x.col = e.col; break;
+    default:
+        x.kind = PH_PE_DECIMAL; x.col = -1; x.nprog = (int32_t)std::min<size_t>(e.prog.size(), 12);
+        for (int i = 0; i < x.nprog; i++) x.prog[i] = e.prog[(size_t)i];
+    }
+    return x;
+}
+
+std::string gpuResidentPlanExecutor::Init() {
+    if (!rp_.error.empty()) return rp_.error;
+    if (rp_.nodes.empty() || rp_.nodes.back().kind != PH_PN_AGG) return "a resident plan ends in its aggregate";
+    // the descriptor arrays live until ph_plan_create has copied them
+    size_t nn = rp_.nodes.size();
+    std::vector<ph_plan_node> desc(nn);
+    std::vector<std::vector<int32_t>> i32s;
+    std::vector<std::vector<ph_pred>> preds(nn);
+    std::vector<std::vector<ph_plan_expr>> exprs(nn);
+    std::vector<std::vector<ph_plan_agg>> aggs(nn);
+    i32s.reserve(nn * 4);
+    auto keep = [&](const std::vector<int> &v) { i32s.emplace_back(v.begin(), v.end()); if (i32s.back().empty()) i32s.back().push_back(0); return i32s.back().data(); };
+    const ResidentPlan::Node &root = rp_.nodes.back();
+    for (size_t i = 0; i < nn; i++) {
+        const ResidentPlan::Node &n = rp_.nodes[i];
+        ph_plan_node &d = desc[i];
+        d = ph_plan_node{};
+        d.kind = n.kind;
+        d.child[0] = n.child[0]; d.child[1] = n.child[1];
+        for (auto &c : n.conjuncts) preds[i].push_back(lowerCompare(c));
+        d.npreds = (int32_t)preds[i].size();
+        d.preds = preds[i].data();
+        switch (n.kind) {
+        case PH_PN_SCAN:
+            d.table = n.table->table;
+            d.ncols = (int32_t)n.cols.size();
+            d.cols = keep(n.cols);
+            break;
+        case PH_PN_JOIN:
+            if (n.probeKeys.size() != n.buildKeys.size() || n.probeKeys.empty()) return "join needs matching key lists";
+            d.join_type = n.joinType == JoinSemi ? PH_JT_SEMI : n.joinType == JoinAnti ? PH_JT_ANTI : PH_JT_INNER;
+            d.nkeys = (int32_t)n.probeKeys.size();
+            d.probe_keys = keep(n.probeKeys);
+            d.build_keys = keep(n.buildKeys);
+            d.nout = (int32_t)n.out.size();
+            d.out = keep(n.out);
+            break;
+        case PH_PN_PROJECT:
+            for (auto &e : n.exprs) { if (e.prog.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e)); }
+            d.nexprs = (int32_t)exprs[i].size();
+            d.exprs = exprs[i].data();
+            break;
+        case PH_PN_AGG:
+            for (auto &e : n.exprs) { if (e.prog.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e)); }
+            for (auto &a : n.aggs) {
+                ph_plan_agg pa{};
+                pa.kind = a.kind;
+                if (a.kind != PH_A_COUNT_STAR) {
+                    if (a.prog.empty()) return "aggregate without an argument";
+                    if (a.prog.size() > 12) return "aggregate argument program too long";
+                    ProjExpr e = a.prog.size() == 1 && a.prog[0].op == PH_X_COL ? ProjExpr::Col(a.prog[0].col) : ProjExpr::Dec(a.prog);
+                    pa.arg = lowerExpr(e);
+                }
+                aggs[i].push_back(pa);
+            }
+            d.ngroups = (int32_t)exprs[i].size();
+            d.groups = exprs[i].data();
+            d.naggs = (int32_t)aggs[i].size();
+            d.aggs = aggs[i].data();
+            break;
+        default: break;
+        }
+    }
+    // output typing of the aggregate (FinalizeStates, as gpuAggExecutor)
+    const std::vector<LType> &childTypes = rp_.nodes[(size_t)root.child[0]].types;
+    std::vector<ph_col> protos;
+    for (auto &t : childTypes) { ph_col pc{}; pc.type = staged_phtype(t); pc.scale = t.Scale; protos.push_back(pc); }
+    outTypes_ = root.types;
+    argType_.clear();
+    for (auto &a : root.aggs) {
+        LType at = IntegerType();
+        int32_t scale = 0;
+        if (a.kind != PH_A_COUNT_STAR) {
+            if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { at = childTypes[(size_t)a.prog[0].col]; scale = at.Scale; }
+            else {
+                if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
+                at = DecimalType(38, scale);
+            }
+        }
+        argType_.push_back(at);
+        bool dec = at.Id == LTID_DECIMAL;
+        switch (a.kind) {
+        case PH_A_SUM: outTypes_.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;
+        case PH_A_AVG: outTypes_.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;
+        case PH_A_COUNT: case PH_A_COUNT_STAR: outTypes_.push_back(HugeintType()); break;
+        case PH_A_MIN: case PH_A_MAX: outTypes_.push_back(dec ? DecimalType(at.Width, scale) : at); break;
+        default: return "unknown aggregate kind";
+        }
+    }
+    if (ph_plan_create(ctx_, desc.data(), (int32_t)nn, &plan_) != PH_OK) return herr("ph_plan_create");
+    if (topkAgg_ >= 0 && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
+    for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
+    if (!outputs_.empty()) { std::string e = gpuProjectExecutor::Types(outputs_, outTypes_, &finalTypes_); if (!e.empty()) return e; }
+    return "";
+}
+
+std::string gpuResidentPlanExecutor::Close() {
+    if (plan_) { ph_plan_free(plan_); plan_ = nullptr; }
+    results_.clear();
+    return "";
+}
+
+OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!built_) {
+        ph_agg_result *r = nullptr;
+        if (ph_plan_run(plan_) != PH_OK || ph_plan_fetch(plan_, &r) != PH_OK) {
+            *err = herr("ph_plan_run/fetch");
+            return InvalidOpResult;
+        }
+        const ResidentPlan::Node &root = rp_.nodes.back();
+        std::vector<LType> keyTypes = root.types;
+        std::vector<const std::vector<std::string> *> dicts;
+        for (size_t k = 0; k < keyTypes.size(); k++) dicts.push_back(root.source[k] ? &root.source[k]->dict : nullptr);
+        std::vector<int> kinds, scales;
+        for (size_t i = 0; i < root.aggs.size(); i++) { kinds.push_back(root.aggs[i].kind); scales.push_back(r->scale[i]); }
+        std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo, r->sum_hi,
+                                       r->count, &results_);
+        ph_agg_result_free(r);
+        if (e.empty()) e = ApplyAggOutputPhase(ctx_, having_, outputs_, outTypes_, finalTypes_, &results_);
+        if (!e.empty()) { *err = e; return InvalidOpResult; }
+        built_ = true;
+    }
+    if (next_ >= results_.size()) return Done;
+    *output = *results_[next_++];
+    return haveMoreOutput;
+}
+
+}  // namespace plan

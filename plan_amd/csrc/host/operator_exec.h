@@ -356,6 +356,72 @@ private:
     bool built_ = false;
 };
 
+// ---- resident plans: a whole operator SUBTREE over resident tables behind ONE OperatorExec
+//
+// The join analogue of gpuScanAggExecutor. buildOperatorExec (executor.go:305-350) builds its executors bottom-up;
+// when the subtree under an Agg consists of Join / Filter / Project nodes whose leaves are scans of RESIDENT tables,
+// the shim does not instantiate joinExecutor / filterExecutor / projectExecutor / aggExecutor objects at all: it
+// writes the subtree down as a ResidentPlan (the PhysicalOperator fields each node carries: Filters, JoinOpInfo's
+// OnConds as key column pairs, Outputs, AggOpInfo's GroupBys / Aggs) and gpuResidentPlanExecutor hands it to the
+// library as a ph_plan (include/planhip.h). Every physical choice — table forms, lookups vs pairs, fused filters,
+// merge / streaming forms — is the library's, from the tables' statistics; nothing here or in the planner hints it.
+struct ResidentTable {
+    const ph_table *table = nullptr;
+    std::vector<ResidentColumn> cols;   // SQL type (and dictionary) of every column of the resident table
+};
+
+class ResidentPlan {
+public:
+    // every method returns the new node's index; children must exist already (bottom-up, like buildOperatorExec)
+    int Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts = {});
+    int Filter(int child, std::vector<Compare> conjuncts);
+    // output = the listed columns of [probe child's columns | build child's columns] (SEMI / ANTI: probe columns)
+    int Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type = JoinInner);
+    int Project(int child, std::vector<ProjExpr> exprs);
+    int Agg(int child, std::vector<ProjExpr> groups, std::vector<AggExpr> aggs);   // the root
+    struct Node {
+        int kind = 0, child[2] = {-1, -1};
+        const ResidentTable *table = nullptr;
+        std::vector<int> cols, probeKeys, buildKeys, out;
+        std::vector<Compare> conjuncts;
+        JoinType joinType = JoinInner;
+        std::vector<ProjExpr> exprs;    // Project; Agg: the group-by expressions
+        std::vector<AggExpr> aggs;
+        std::vector<LType> types;       // output types of the node (Agg: the group columns)
+        std::vector<const ResidentColumn *> source;   // per output column: the resident column it is an unchanged copy of (or null)
+    };
+    std::vector<Node> nodes;
+    std::string error;                  // first construction error ("" = none); checked by the executor's Init
+};
+
+class gpuResidentPlanExecutor : public OperatorExec {
+public:
+    gpuResidentPlanExecutor(ph_ctx *ctx, ResidentPlan plan) : ctx_(ctx), rp_(std::move(plan)) {}
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override;
+    std::vector<LType> OutputTypes() const override { return finalTypes_.empty() ? outTypes_ : finalTypes_; }
+    void SetHaving(std::vector<Compare> conjuncts) { having_ = std::move(conjuncts); }
+    void SetOutputs(std::vector<ProjExpr> outputs) { outputs_ = std::move(outputs); }
+    // Order <- Limit above the aggregate with an aggregate as the first ORDER BY key (what the shim sees when it
+    // walks up from the Agg): only the groups that can reach the first k rows come back from the device
+    void SetTopK(int aggIndex, bool descending, int64_t k) { topkAgg_ = aggIndex; topkDesc_ = descending; topkK_ = k; }
+    std::string Explain() const { return plan_ ? ph_plan_explain(plan_) : ""; }
+private:
+    ph_ctx *ctx_;
+    ResidentPlan rp_;
+    std::vector<Compare> having_;
+    std::vector<ProjExpr> outputs_;
+    std::vector<LType> outTypes_, finalTypes_, argType_;
+    int topkAgg_ = -1;
+    bool topkDesc_ = false;
+    int64_t topkK_ = 0;
+    ph_plan *plan_ = nullptr;
+    std::vector<std::shared_ptr<Chunk>> results_;
+    size_t next_ = 0;
+    bool built_ = false;
+};
+
 // builds the output chunks of an aggregate from the device result arrays (FinalizeStates typing)
 std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector<LType> &keyTypes,
                            const std::vector<const std::vector<std::string> *> &keyDicts,

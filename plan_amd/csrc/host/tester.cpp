@@ -6,9 +6,13 @@
 //   host_tester semi|anti|left|order|having|cross <sf_num> <sf_den>
 //   host_tester substr <sf_num> <sf_den> <offset> <length>
 //   host_tester q1|q6|q3|q9 <sf_num> <sf_den> [stub|resident]
+//   host_tester q3|q9 <sf_num> <sf_den> resident [repeat]     the whole subtree as ONE gpuResidentPlanExecutor (ph_plan)
+//   host_tester tpch <query_id> <sf_num> <sf_den> [repeat]    any query tpch_plans.cpp has a resident plan for
+// The resident-plan forms print "Query N took <dur> success" per repeat on stderr, like Run (executor_bench.go:126-137).
 // q1 / q3 / q9 run the whole plan tail on the library: gpuOrderExecutor (ORDER BY) and limitExecutor
 // (LIMIT), so their output is the reference's result file byte for byte with no sorting here.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +20,7 @@
 #include <memory>
 
 #include "operator_exec.h"
+#include "tpch_plans.h"
 #include "tpchgen.h"
 
 using namespace plan;
@@ -231,6 +236,40 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "formats")) return formats();
     if (argc < 4) die("usage: host_tester roundtrip | q1|q6|q3 <sf_num> <sf_den> [stub]");
     std::string q = argv[1];
+    {   // resident plans: the whole operator subtree behind one OperatorExec
+        int id = 0, a = 2;
+        if (q == "tpch" && argc >= 5) { id = atoi(argv[2]); a = 3; }
+        else if ((q == "q3" || q == "q9") && argc > 4 && !strcmp(argv[4], "resident")) id = atoi(q.c_str() + 1);
+        if (id > 0) {
+            int64_t num = atoll(argv[a]), den = atoll(argv[a + 1]);
+            int repeat = argc > a + (q == "tpch" ? 2 : 3) ? atoi(argv[a + (q == "tpch" ? 2 : 3)]) : 1;
+            ph_ctx *ctx = nullptr;
+            if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
+            {
+                TpchDatabase db;
+                std::string e = db.Load(ctx, num, den);
+                if (!e.empty()) die(e);
+                fprintf(stderr, "loaded SF%g: generate %.2f s, load %.2f s (%.2f GB, %.1f GB/s)\n", (double)num / (double)den, db.generate_s, db.load_s,
+                        (double)db.loaded_bytes / 1e9, (double)db.loaded_bytes / 1e9 / std::max(db.load_s, 1e-9));
+                TpchQuery tq;
+                e = BuildTpchQuery(db, id, &tq);
+                if (!e.empty()) die(e);
+                std::vector<std::string> lines;
+                std::string explain;
+                for (int r = 0; r < std::max(repeat, 1); r++) {
+                    auto t0 = std::chrono::steady_clock::now();
+                    e = RunTpchQuery(ctx, tq, &lines, &explain);
+                    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    if (!e.empty()) die(e);
+                    fprintf(stderr, "Query %d took %.3fms success\n", id, ms);
+                }
+                fprintf(stderr, "%s", explain.c_str());
+                print(tq.ncols, lines);
+            }
+            ph_ctx_destroy(ctx);
+            return 0;
+        }
+    }
     int64_t num = atoll(argv[2]), den = atoll(argv[3]);
     bool stub = argc > 4 && !strcmp(argv[4], "stub");
     ph_ctx *ctx = nullptr;

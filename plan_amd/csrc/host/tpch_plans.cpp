@@ -1,0 +1,342 @@
+// See tpch_plans.h.
+#include "tpch_plans.h"
+
+#include <chrono>
+#include <cstring>
+
+#include "tpchgen.h"
+
+namespace plan {
+
+static std::string herr(const char *what) { return std::string(what) + ": " + ph_last_error(); }
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+namespace {
+
+struct HostCol {
+    LType type;
+    int32_t ph = 0, scale = 0;
+    const void *data = nullptr;
+    std::vector<std::string> dict;           // PH_CODE8
+    const void *aux = nullptr;               // PH_STR bytes
+    int64_t aux_bytes = 0;
+};
+
+std::vector<std::string> dictOf(const char *const *d, int n) { return std::vector<std::string>(d, d + n); }
+
+std::string loadTable(ph_ctx *ctx, const std::vector<HostCol> &cols, int64_t n, const std::vector<int> &primaryKey, ResidentTable *out, int64_t *bytes) {
+    std::vector<ph_col> hc(cols.size());
+    std::vector<std::string> blobs(cols.size());
+    for (size_t c = 0; c < cols.size(); c++) {
+        hc[c] = ph_col{};
+        hc[c].type = cols[c].ph; hc[c].scale = cols[c].scale; hc[c].data = cols[c].data;
+        if (cols[c].ph == PH_CODE8) {
+            for (auto &s : cols[c].dict) { blobs[c] += s; blobs[c].push_back('\0'); }
+            hc[c].aux = blobs[c].data(); hc[c].aux_bytes = (int64_t)blobs[c].size();
+        } else if (cols[c].ph == PH_STR) { hc[c].aux = cols[c].aux; hc[c].aux_bytes = cols[c].aux_bytes; *bytes += cols[c].aux_bytes; }
+        *bytes += n * (cols[c].ph == PH_CODE8 ? 1 : (cols[c].ph == PH_I64 || cols[c].ph == PH_DEC64) ? 8 : 4);
+        out->cols.push_back(ResidentColumn{cols[c].type, cols[c].dict});
+    }
+    ph_table *t = nullptr;
+    if (ph_table_create(ctx, (int32_t)hc.size(), hc.data(), n, &t) != PH_OK) return herr("ph_table_create");
+    out->table = t;
+    if (!primaryKey.empty()) {
+        std::vector<int32_t> pk(primaryKey.begin(), primaryKey.end());
+        if (ph_table_declare_unique(t, (int32_t)pk.size(), pk.data()) != PH_OK) return herr("ph_table_declare_unique");
+    }
+    return "";
+}
+
+HostCol I32(const void *d) { return HostCol{IntegerType(), PH_I32, 0, d, {}, nullptr, 0}; }
+HostCol I64(const void *d) { return HostCol{BigintType(), PH_I64, 0, d, {}, nullptr, 0}; }
+HostCol DEC(const void *d) { return HostCol{DecimalType(15, 2), PH_DEC64, 2, d, {}, nullptr, 0}; }
+HostCol DATE(const void *d) { return HostCol{DateType(), PH_DATE, 0, d, {}, nullptr, 0}; }
+HostCol CODE(const void *d, std::vector<std::string> dict) { return HostCol{VarcharType(), PH_CODE8, 0, d, std::move(dict), nullptr, 0}; }
+
+}  // namespace
+
+TpchDatabase::~TpchDatabase() {
+    for (ResidentTable *t : {&lineitem, &orders, &customer, &part, &partsupp, &supplier, &nation, &region})
+        if (t->table) ph_table_free(const_cast<ph_table *>(t->table));
+}
+
+std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
+    ctx = c; num = sf_num; den = sf_den;
+    const int64_t no = tpchgen_orders_count(num, den), nc = tpchgen_customer_count(num, den), np = tpchgen_part_count(num, den),
+                  ns = tpchgen_supplier_count(num, den), nl = tpchgen_lineitem_count(num, den, 0, no);
+    std::string e;
+    double t0 = now_s();
+    {   // lineitem
+        std::vector<int64_t> okey((size_t)nl), ext((size_t)nl), disc((size_t)nl), tax((size_t)nl);
+        std::vector<int32_t> pk((size_t)nl), sk((size_t)nl), qty((size_t)nl), ship((size_t)nl), commit((size_t)nl), receipt((size_t)nl);
+        std::vector<uint8_t> rf((size_t)nl), ls((size_t)nl), mode((size_t)nl), instr((size_t)nl);
+        tpchgen_lineitem_cols lc{};
+        lc.l_orderkey = okey.data(); lc.l_partkey = pk.data(); lc.l_suppkey = sk.data(); lc.l_quantity = qty.data(); lc.l_extendedprice = ext.data();
+        lc.l_discount = disc.data(); lc.l_tax = tax.data(); lc.l_returnflag = rf.data(); lc.l_linestatus = ls.data(); lc.l_shipdate = ship.data();
+        lc.l_commitdate = commit.data(); lc.l_receiptdate = receipt.data(); lc.l_shipmode = mode.data(); lc.l_shipinstruct = instr.data();
+        tpchgen_lineitem(num, den, 0, no, &lc);
+        generate_s += now_s() - t0; t0 = now_s();
+        e = loadTable(ctx, {I64(okey.data()), I32(pk.data()), I32(sk.data()), I32(qty.data()), DEC(ext.data()), DEC(disc.data()), DEC(tax.data()),
+                            CODE(rf.data(), dictOf(TPCHGEN_RETURNFLAG_DICT, 3)), CODE(ls.data(), dictOf(TPCHGEN_LINESTATUS_DICT, 2)), DATE(ship.data()),
+                            DATE(commit.data()), DATE(receipt.data()), CODE(mode.data(), dictOf(TPCHGEN_SHIPMODE_DICT, 7)),
+                            CODE(instr.data(), dictOf(TPCHGEN_SHIPINSTRUCT_DICT, 4))}, nl, {}, &lineitem, &loaded_bytes);
+        if (!e.empty()) return e;
+        load_s += now_s() - t0; t0 = now_s();
+    }
+    {   // orders
+        std::vector<int64_t> okey((size_t)no);
+        std::vector<int32_t> cust((size_t)no), date((size_t)no), sprio((size_t)no);
+        std::vector<uint8_t> oprio((size_t)no);
+        tpchgen_orders_cols oc{};
+        oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data();
+        tpchgen_orders(num, den, 0, no, &oc);
+        generate_s += now_s() - t0; t0 = now_s();
+        e = loadTable(ctx, {I64(okey.data()), I32(cust.data()), DATE(date.data()), I32(sprio.data()), CODE(oprio.data(), dictOf(TPCHGEN_ORDERPRIORITY_DICT, 5))},
+                      no, {O_ORDERKEY}, &orders, &loaded_bytes);
+        if (!e.empty()) return e;
+        load_s += now_s() - t0; t0 = now_s();
+    }
+    {   // customer
+        std::vector<int32_t> key((size_t)nc), nat((size_t)nc);
+        std::vector<uint8_t> seg((size_t)nc);
+        tpchgen_customer_cols cc{};
+        cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data();
+        tpchgen_customer(num, den, 0, nc, &cc);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5))}, nc, {C_CUSTKEY}, &customer, &loaded_bytes);
+        if (!e.empty()) return e;
+    }
+    {   // part: p_name as offsets + bytes (LIKE operand), the other VARCHAR columns as dictionary codes
+        std::vector<int32_t> key((size_t)np), size((size_t)np), off((size_t)np + 1);
+        std::vector<uint8_t> colors((size_t)np * 5), brand((size_t)np), type((size_t)np), cntr((size_t)np);
+        tpchgen_part_cols pc{};
+        pc.p_partkey = key.data(); pc.p_name_colors = colors.data(); pc.p_brand = brand.data(); pc.p_type = type.data(); pc.p_size = size.data(); pc.p_container = cntr.data();
+        tpchgen_part(num, den, 0, np, &pc);
+        std::string bytes;
+        for (int64_t r = 0; r < np; r++) {
+            off[(size_t)r] = (int32_t)bytes.size();
+            for (int k = 0; k < 5; k++) { if (k) bytes.push_back(' '); bytes += TPCHGEN_COLORS[colors[(size_t)r * 5 + (size_t)k]]; }
+        }
+        off[(size_t)np] = (int32_t)bytes.size();
+        HostCol name{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()};
+        e = loadTable(ctx, {I32(key.data()), name, CODE(brand.data(), dictOf(tpchgen_part_brand_dict(), 25)), CODE(type.data(), dictOf(tpchgen_part_type_dict(), 150)),
+                            I32(size.data()), CODE(cntr.data(), dictOf(tpchgen_part_container_dict(), 40))}, np, {P_PARTKEY}, &part, &loaded_bytes);
+        if (!e.empty()) return e;
+    }
+    {   // partsupp
+        std::vector<int32_t> pk((size_t)np * 4), sk((size_t)np * 4);
+        std::vector<int64_t> cost((size_t)np * 4);
+        tpchgen_partsupp_cols pc{};
+        pc.ps_partkey = pk.data(); pc.ps_suppkey = sk.data(); pc.ps_supplycost = cost.data();
+        tpchgen_partsupp(num, den, 0, np, &pc);
+        e = loadTable(ctx, {I32(pk.data()), I32(sk.data()), DEC(cost.data())}, np * 4, {PS_PARTKEY, PS_SUPPKEY}, &partsupp, &loaded_bytes);
+        if (!e.empty()) return e;
+    }
+    {   // supplier
+        std::vector<int32_t> key((size_t)ns), nat((size_t)ns);
+        tpchgen_supplier_cols sc{};
+        sc.s_suppkey = key.data(); sc.s_nationkey = nat.data();
+        tpchgen_supplier(num, den, 0, ns, &sc);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data())}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
+        if (!e.empty()) return e;
+    }
+    {   // nation, region: the specification's fixed tables
+        std::vector<int32_t> nk(25), nr(25), rk(5);
+        std::vector<uint8_t> nn(25), rn(5);
+        for (int i = 0; i < 25; i++) { nk[(size_t)i] = i; nn[(size_t)i] = (uint8_t)i; nr[(size_t)i] = TPCHGEN_NATION_REGION[i]; }
+        for (int i = 0; i < 5; i++) { rk[(size_t)i] = i; rn[(size_t)i] = (uint8_t)i; }
+        e = loadTable(ctx, {I32(nk.data()), CODE(nn.data(), dictOf(TPCHGEN_NATION_NAMES, 25)), I32(nr.data())}, 25, {N_NATIONKEY}, &nation, &loaded_bytes);
+        if (!e.empty()) return e;
+        e = loadTable(ctx, {I32(rk.data()), CODE(rn.data(), dictOf(TPCHGEN_REGION_NAMES, 5))}, 5, {R_REGIONKEY}, &region, &loaded_bytes);
+        if (!e.empty()) return e;
+    }
+    load_s += now_s() - t0;
+    return "";
+}
+
+// ---- literals and expression shorthands
+static Literal LDate(int y, int m, int d) { Literal k; k.kind = Literal::DateDays; k.i = tpchgen_days_from_civil(y, m, d); return k; }
+static Literal LDays(int32_t days) { Literal k; k.kind = Literal::DateDays; k.i = days; return k; }
+static Literal LStr(const char *s) { Literal k; k.kind = Literal::Str; k.s = s; return k; }
+static Literal LInt(int64_t v) { Literal k; k.kind = Literal::Int; k.i = v; return k; }
+static Literal LFloat(float f) { Literal k; k.kind = Literal::Float; k.f = (double)f; return k; }
+static ph_rpn XC(int c) { return ph_rpn{PH_X_COL, c, 0, 0}; }
+static ph_rpn XK(int64_t v, int s = 0) { return ph_rpn{PH_X_CONST, -1, v, s}; }
+static ph_rpn XO(int op) { return ph_rpn{op, -1, 0, 0}; }
+// e * (1 - d)
+static std::vector<ph_rpn> DiscPrice(int e, int d) { return {XC(e), XK(1), XC(d), XO(PH_X_SUB), XO(PH_X_MUL)}; }
+
+std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
+    *q = TpchQuery{};
+    q->id = id;
+    ResidentPlan &p = q->plan;
+    switch (id) {
+    case 1: {   // Order <- Agg <- Scan(lineitem, l_shipdate <= date '1998-12-01' - interval '112 day')
+        int s = p.Scan(&db.lineitem, {L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS},
+                       {{L_SHIPDATE, PH_LE, LDays(tpchgen_days_from_civil(1998, 12, 1) - 112)}});
+        std::vector<ph_rpn> dp = DiscPrice(1, 2), ch = dp;
+        ch.push_back(XK(1)); ch.push_back(XC(3)); ch.push_back(XO(PH_X_ADD)); ch.push_back(XO(PH_X_MUL));
+        p.Agg(s, {ProjExpr::Col(4), ProjExpr::Col(5)},
+              {{PH_A_SUM, {XC(0)}}, {PH_A_SUM, {XC(1)}}, {PH_A_SUM, dp}, {PH_A_SUM, ch}, {PH_A_AVG, {XC(0)}}, {PH_A_AVG, {XC(1)}}, {PH_A_AVG, {XC(2)}},
+               {PH_A_COUNT_STAR, {}}});
+        q->order = {{0, false}, {1, false}};
+        q->ncols = 10;
+        break;
+    }
+    case 6: {   // Agg <- Scan(lineitem, shipdate range, discount between 0.03 -/+ 0.01 (float32 literals), quantity < 24)
+        int s = p.Scan(&db.lineitem, {L_EXTENDEDPRICE, L_DISCOUNT},
+                       {{L_SHIPDATE, PH_GE, LDate(1994, 1, 1)}, {L_SHIPDATE, PH_LT, LDate(1995, 1, 1)}, {L_DISCOUNT, PH_GE, LFloat(0.03f - 0.01f)},
+                        {L_DISCOUNT, PH_LE, LFloat(0.03f + 0.01f)}, {L_QUANTITY, PH_LT, LInt(24)}});
+        p.Agg(s, {}, {{PH_A_SUM, {XC(0), XC(1), XO(PH_X_MUL)}}});
+        q->ncols = 1;
+        break;
+    }
+    case 3: {
+        // Limit <- Order <- Agg(l_orderkey, o_orderdate, o_shippriority; sum(l_extendedprice * (1 - l_discount)))
+        //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, l_shipdate > d)
+        //        build <- Join(o_custkey = c_custkey) probe Scan(orders, o_orderdate < d), build Scan(customer, c_mktsegment = 'HOUSEHOLD')
+        Literal d = LDate(1995, 3, 29);
+        int cust = p.Scan(&db.customer, {C_CUSTKEY}, {{C_MKTSEGMENT, PH_EQ, LStr("HOUSEHOLD")}});
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY}, {{O_ORDERDATE, PH_LT, d}});
+        int j1 = p.Join(ord, cust, {1}, {0}, {0, 2, 3});
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_SHIPDATE, PH_GT, d}});
+        int j2 = p.Join(line, j1, {0}, {0}, {0, 1, 2, 4, 5});
+        p.Agg(j2, {ProjExpr::Col(0), ProjExpr::Col(3), ProjExpr::Col(4)}, {{PH_A_SUM, DiscPrice(1, 2)}});
+        // select list: l_orderkey, revenue, o_orderdate, o_shippriority; ORDER BY revenue DESC, o_orderdate LIMIT 10
+        q->outputs = {ProjExpr::Col(0), ProjExpr::Col(3), ProjExpr::Col(1), ProjExpr::Col(2)};
+        q->order = {{1, true}, {2, false}};
+        q->limit = 10;
+        q->topkAgg = 0; q->topkDesc = true;
+        q->ncols = 4;
+        break;
+    }
+    case 9: {
+        // Order <- Agg(nation, o_year; sum(amount)) <- Project(n_name, extract(year from o_orderdate),
+        //   l_extendedprice * (1 - l_discount) - ps_supplycost * l_quantity)
+        //   <- Join(s_nationkey = n_nationkey) <- Join(l_orderkey = o_orderkey) <- Join(l_suppkey = s_suppkey)
+        //   <- Join((l_partkey, l_suppkey) = (ps_partkey, ps_suppkey)) <- Join(l_partkey = p_partkey) <- Scan(lineitem); part filtered by LIKE
+        int part = p.Scan(&db.part, {P_PARTKEY}, {{P_NAME, PH_LIKE, LStr("%pink%")}});
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT});
+        int j1 = p.Join(line, part, {1}, {0}, {0, 1, 2, 3, 4, 5});
+        int ps = p.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST});
+        int j2 = p.Join(j1, ps, {1, 2}, {0, 1}, {0, 2, 3, 4, 5, 8});     // l_orderkey, l_suppkey, qty, ext, disc, ps_supplycost
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY});
+        int j3 = p.Join(j2, supp, {1}, {0}, {0, 2, 3, 4, 5, 7});           // l_orderkey, qty, ext, disc, cost, s_nationkey
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_ORDERDATE});
+        int j4 = p.Join(j3, ord, {0}, {0}, {1, 2, 3, 4, 5, 7});            // qty, ext, disc, cost, s_nationkey, o_orderdate
+        int nat = p.Scan(&db.nation, {N_NATIONKEY, N_NAME});
+        int j5 = p.Join(j4, nat, {4}, {0}, {0, 1, 2, 3, 5, 7});            // qty, ext, disc, cost, o_orderdate, n_name
+        std::vector<ph_rpn> amount = DiscPrice(1, 2);
+        amount.push_back(XC(3)); amount.push_back(XC(0)); amount.push_back(XO(PH_X_MUL)); amount.push_back(XO(PH_X_SUB));
+        int proj = p.Project(j5, {ProjExpr::Col(5), ProjExpr::Year(4), ProjExpr::Dec(amount)});
+        p.Agg(proj, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_SUM, {XC(2)}}});
+        q->order = {{0, false}, {1, true}};
+        q->ncols = 3;
+        break;
+    }
+    default:
+        return "no resident plan for TPC-H query " + std::to_string(id);
+    }
+    return p.error;
+}
+
+std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
+    gpuResidentPlanExecutor agg(ctx, q.plan);
+    if (!q.having.empty()) agg.SetHaving(q.having);
+    if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
+    if (q.topkAgg >= 0 && q.limit > 0) agg.SetTopK(q.topkAgg, q.topkDesc, q.limit);
+    std::string e = agg.Init();
+    if (!e.empty()) return "Init: " + e;
+    std::unique_ptr<gpuOrderExecutor> ord;
+    std::unique_ptr<limitExecutor> lim;
+    OperatorExec *root = &agg;
+    if (!q.order.empty()) {
+        ord.reset(new gpuOrderExecutor(ctx, q.order, root));
+        e = ord->Init();
+        if (!e.empty()) return "Init: " + e;
+        root = ord.get();
+    }
+    if (q.limit >= 0) {
+        lim.reset(new limitExecutor((uint64_t)q.limit, 0, root));
+        lim->Init();
+        root = lim.get();
+    }
+    lines->clear();
+    for (;;) {   // the pull loop of execOps (executor.go:151-188)
+        Chunk out;
+        std::string err;
+        OperatorResult r = root->Execute(nullptr, &out, &err);
+        if (r == InvalidOpResult) return "Execute: " + err;
+        if (r == Done) break;
+        std::string text;
+        out.AppendText(&text);
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t nl = text.find('\n', pos);
+            lines->push_back(text.substr(pos, nl - pos));
+            pos = nl + 1;
+        }
+    }
+    if (explain) *explain = agg.Explain();
+    if (lim) lim->Close();
+    if (ord) ord->Close();
+    agg.Close();
+    return "";
+}
+
+}  // namespace plan
+
+// ---------------------------------------------------------------- C entry points
+
+static thread_local std::string g_host_err;
+
+extern "C" const char *planhost_last_error(void) { return g_host_err.c_str(); }
+
+extern "C" int planhost_tpch_load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, void **db_out) {
+    if (!ctx || !db_out || sf_num <= 0 || sf_den <= 0) { g_host_err = "planhost_tpch_load: bad arguments"; return PH_EINVAL; }
+    auto *db = new plan::TpchDatabase();
+    std::string e = db->Load(ctx, sf_num, sf_den);
+    if (!e.empty()) { g_host_err = e; delete db; return PH_EHIP; }
+    *db_out = db;
+    return PH_OK;
+}
+
+extern "C" int64_t planhost_tpch_rows(void *dbp, const char *table) {
+    auto *db = (plan::TpchDatabase *)dbp;
+    if (!db || !table) return -1;
+    const std::string t = table;
+    const plan::ResidentTable *rt = t == "lineitem" ? &db->lineitem : t == "orders" ? &db->orders : t == "customer" ? &db->customer : t == "part" ? &db->part :
+                                    t == "partsupp" ? &db->partsupp : t == "supplier" ? &db->supplier : t == "nation" ? &db->nation : t == "region" ? &db->region : nullptr;
+    return rt && rt->table ? ph_table_rows(rt->table) : -1;
+}
+
+extern "C" int planhost_tpch_run(void *dbp, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
+                                 char *explain_out, int64_t explain_cap) {
+    auto *db = (plan::TpchDatabase *)dbp;
+    if (!db || repeat < 1 || warmup < 0) { g_host_err = "planhost_tpch_run: bad arguments"; return PH_EINVAL; }
+    plan::TpchQuery q;
+    std::string e = plan::BuildTpchQuery(*db, query, &q);
+    if (!e.empty()) { g_host_err = e; return PH_EUNSUPPORTED; }
+    std::vector<std::string> lines;
+    std::string explain;
+    double total = 0, best = 1e300;
+    for (int i = 0; i < warmup + repeat; i++) {
+        const double t0 = plan::now_s();
+        e = plan::RunTpchQuery(db->ctx, q, &lines, &explain);   // builds the executors, pulls every chunk, closes them: one whole query
+        const double dt = plan::now_s() - t0;
+        if (!e.empty()) { g_host_err = e; return PH_EHIP; }
+        if (i >= warmup) { total += dt; best = std::min(best, dt); }
+    }
+    if (ms_avg) *ms_avg = total / repeat * 1e3;
+    if (ms_min) *ms_min = best * 1e3;
+    if (text_out && text_cap > 0) {
+        std::string text = "#";
+        for (int i = 1; i < q.ncols; i++) text += "\t";
+        text += "\n";
+        for (auto &l : lines) { text += l; text += "\n"; }
+        snprintf(text_out, (size_t)text_cap, "%s", text.c_str());
+    }
+    if (explain_out && explain_cap > 0) snprintf(explain_out, (size_t)explain_cap, "%s", explain.c_str());
+    return PH_OK;
+}
+
+extern "C" void planhost_tpch_free(void *db) { delete (plan::TpchDatabase *)db; }

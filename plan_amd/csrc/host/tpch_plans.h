@@ -1,0 +1,70 @@
+// TPC-H as resident tables + the operator subtrees of its queries as ResidentPlans — the stand-in for what the
+// reference's planner (pkg/compute builder_*.go / optimizer_*.go, out of scope: SURVEY.md §2 rows 12-13) hands
+// buildOperatorExec for `tester tpch1g --query_id N` (cmd/tester/main.go:65-73). The join ORDER of each query is
+// fixed here as a planner would fix it; every physical choice below that is the library's (ph_plan, planhip.h).
+// Used by host_tester (`q3|q9 <sf> resident`), by tests/test_host_layer.py and — through the C entry points at the
+// bottom — by bench.py's q3_operator_interface / q9_operator_interface companions.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "operator_exec.h"
+
+namespace plan {
+
+// column positions in the resident tables (cases/tpch/query/ddl.sql names; the pruned columns the queries read)
+enum { L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE,
+       L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE, L_SHIPINSTRUCT };
+enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY };
+enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT };
+enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
+enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST };
+enum { S_SUPPKEY, S_NATIONKEY };
+enum { N_NATIONKEY, N_NAME, N_REGIONKEY };
+enum { R_REGIONKEY, R_NAME };
+
+struct TpchDatabase {
+    ph_ctx *ctx = nullptr;
+    int64_t num = 1, den = 1;
+    ResidentTable lineitem, orders, customer, part, partsupp, supplier, nation, region;
+    double generate_s = 0, load_s = 0;
+    int64_t loaded_bytes = 0;
+    // generates (clean-room dbgen equivalent, include/tpchgen.h) and loads every table; declares the primary keys
+    std::string Load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den);
+    ~TpchDatabase();
+};
+
+struct TpchQuery {
+    int id = 0;
+    ResidentPlan plan;
+    std::vector<Compare> having;          // aggExecutor's output phase (executor_aggr.go:143-263)
+    std::vector<ProjExpr> outputs;        //   ... its output expressions, in select-list order
+    std::vector<OrderKey> order;          // orderExecutor above the aggregate
+    int64_t limit = -1;                   // limitExecutor above that (-1 = none)
+    int topkAgg = -1;                     // ORDER BY's first key is aggregate topkAgg (index into the plan's aggregates)
+    bool topkDesc = false;
+    int ncols = 0;                        // result columns (the headline's tab count)
+};
+
+// the operator subtree of cases/tpch/query/q<id>.sql over the resident database
+std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *out);
+
+// one execution through the operator interface, exactly as execOps pulls it (executor.go:151-188):
+// limitExecutor <- gpuOrderExecutor <- gpuResidentPlanExecutor; result rows as text lines (Chunk.SaveToFile format)
+std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain);
+
+}  // namespace plan
+
+// ---- C entry points (libplantpch.so) for harnesses without C++ (bench.py): load once, run a query `repeat` times
+// behind `warmup` untimed runs, report the per-query wall time the way Run prints it (executor_bench.go:126-137)
+extern "C" {
+int planhost_tpch_load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, void **db_out);
+int64_t planhost_tpch_rows(void *db, const char *table);
+// text_out: headline + rows of the LAST run; explain_out: the library's account of the forms it chose
+int planhost_tpch_run(void *db, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
+                      char *explain_out, int64_t explain_cap);
+const char *planhost_last_error(void);
+void planhost_tpch_free(void *db);
+}

@@ -40,6 +40,17 @@
 #define SD_L_CDTE 904914315LL
 #define SD_L_RDTE 373135028LL
 #define SD_L_RFLG 1430063908LL
+/* round 3: the columns Q4 / Q5 / Q12 / Q14 / Q19 read. Seeds as I know them from the public generator's seed
+ * table; validated by the publicly known first rows of part.tbl / orders.tbl / lineitem.tbl (tests/test_tpchgen.py)
+ * and, finally, by the reference's goldens for those queries (tests/test_golden_tpch.py). */
+#define SD_L_SHIP 1371272478LL      /* l_shipinstruct, 7 per order */
+#define SD_L_SMODE 675466456LL      /* l_shipmode, 7 per order */
+#define SD_O_PRIO 591449447LL       /* 1 per order */
+#define SD_P_MFG 1LL                /* 1 per part */
+#define SD_P_BRND 46831694LL
+#define SD_P_TYPE 1841581359LL
+#define SD_P_SIZE 1193163244LL
+#define SD_P_CNTR 727633698LL
 
 #define O_LCNT_MAX 7
 #define SUPP_PER_PART 4
@@ -67,6 +78,56 @@ const char *const TPCHGEN_NATION_NAMES[25] = {
     "IRAN",    "IRAQ",      "JAPAN",   "JORDAN",         "KENYA",
     "MOROCCO", "MOZAMBIQUE", "PERU",   "CHINA",          "ROMANIA",
     "SAUDI ARABIA", "VIETNAM", "RUSSIA", "UNITED KINGDOM", "UNITED STATES"};
+
+/* nation -> region of the specification's fixed NATION table; regions in key order */
+const int32_t TPCHGEN_NATION_REGION[25] = {0, 1, 1, 1, 4, 0, 3, 3, 2, 2, 4, 4, 2, 4, 0, 0, 0, 1, 2, 3, 4, 2, 3, 3, 1};
+const char *const TPCHGEN_REGION_NAMES[5] = {"AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"};
+
+const char *const TPCHGEN_SHIPMODE_DICT[7] = {"AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"};
+const char *const TPCHGEN_SHIPINSTRUCT_DICT[4] = {"COLLECT COD", "DELIVER IN PERSON", "NONE", "TAKE BACK RETURN"};
+const char *const TPCHGEN_ORDERPRIORITY_DICT[5] = {"1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"};
+/* generation order of the distributions (the order their values are listed in, each with weight 1) -> dictionary code */
+static const uint8_t SMODE_GEN_TO_CODE[7] = {4 /*REG AIR*/, 0 /*AIR*/, 3 /*RAIL*/, 6 /*TRUCK*/, 2 /*MAIL*/, 1 /*FOB*/, 5 /*SHIP*/};
+static const uint8_t INSTRUCT_GEN_TO_CODE[4] = {1 /*DELIVER IN PERSON*/, 0 /*COLLECT COD*/, 3 /*TAKE BACK RETURN*/, 2 /*NONE*/};
+
+/* p_type = one of 6 x 5 x 5 syllable combinations, p_container = one of 5 x 8, listed syllable-major */
+static const char *const TYPE_S1[6] = {"STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO"};
+static const char *const TYPE_S2[5] = {"ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED"};
+static const char *const TYPE_S3[5] = {"TIN", "NICKEL", "BRASS", "STEEL", "COPPER"};
+static const char *const CNTR_S1[5] = {"SM", "LG", "MED", "JUMBO", "WRAP"};
+static const char *const CNTR_S2[8] = {"CASE", "BOX", "BAG", "JAR", "PACK", "PKG", "CAN", "DRUM"};
+static char type_store[150][32], cntr_store[40][16], brand_store[25][12];
+static const char *type_dict[150], *cntr_dict[40], *brand_dict[25];
+static int part_dicts_ready = 0;
+static void part_dicts(void) {
+    if (part_dicts_ready) return;
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 5; b++) for (int c = 0; c < 5; c++) {
+        int i = (a * 5 + b) * 5 + c;
+        size_t n = 0;
+        const char *parts[3] = {TYPE_S1[a], TYPE_S2[b], TYPE_S3[c]};
+        for (int k = 0; k < 3; k++) { if (k) type_store[i][n++] = ' '; size_t l = strlen(parts[k]); memcpy(type_store[i] + n, parts[k], l); n += l; }
+        type_store[i][n] = 0;
+        type_dict[i] = type_store[i];
+    }
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 8; b++) {
+        int i = a * 8 + b;
+        size_t n = strlen(CNTR_S1[a]);
+        memcpy(cntr_store[i], CNTR_S1[a], n);
+        cntr_store[i][n++] = ' ';
+        strcpy(cntr_store[i] + n, CNTR_S2[b]);
+        cntr_dict[i] = cntr_store[i];
+    }
+    for (int m = 1; m <= 5; m++) for (int b = 1; b <= 5; b++) {
+        int i = (m - 1) * 5 + (b - 1);
+        memcpy(brand_store[i], "Brand#", 6);
+        brand_store[i][6] = (char)('0' + m); brand_store[i][7] = (char)('0' + b); brand_store[i][8] = 0;
+        brand_dict[i] = brand_store[i];
+    }
+    part_dicts_ready = 1;
+}
+const char *const *tpchgen_part_type_dict(void) { part_dicts(); return type_dict; }
+const char *const *tpchgen_part_container_dict(void) { part_dicts(); return cntr_dict; }
+const char *const *tpchgen_part_brand_dict(void) { part_dicts(); return brand_dict; }
 
 const char *const TPCHGEN_COLORS[92] = {
     "almond",    "antique",   "aquamarine", "azure",     "beige",     "bisque",
@@ -188,7 +249,7 @@ static int64_t part_supplier(int64_t partkey, int64_t supp_no, int64_t supplier_
 /* ---- lineitem / orders share the order-level streams ---- */
 typedef struct {
     stream_t odate, lcnt, ckey;
-    stream_t qty, dcnt, tax, pkey, skey, sdte, cdte, rdte, rflg;
+    stream_t qty, dcnt, tax, pkey, skey, sdte, cdte, rdte, rflg, ship, smode, prio;
     int64_t part_count, supplier_count, customer_count;
 } order_streams;
 
@@ -205,6 +266,9 @@ static void order_streams_init(order_streams *s, int64_t num, int64_t den, int64
     stream_init(&s->cdte, SD_L_CDTE, O_LCNT_MAX, first);
     stream_init(&s->rdte, SD_L_RDTE, O_LCNT_MAX, first);
     stream_init(&s->rflg, SD_L_RFLG, O_LCNT_MAX, first);
+    stream_init(&s->ship, SD_L_SHIP, O_LCNT_MAX, first);
+    stream_init(&s->smode, SD_L_SMODE, O_LCNT_MAX, first);
+    stream_init(&s->prio, SD_O_PRIO, 1, first);
     s->part_count = tpchgen_part_count(num, den);
     s->supplier_count = tpchgen_supplier_count(num, den);
     s->customer_count = tpchgen_customer_count(num, den);
@@ -223,6 +287,9 @@ static void order_streams_row_done(order_streams *s) {
     stream_row_done(&s->cdte);
     stream_row_done(&s->rdte);
     stream_row_done(&s->rflg);
+    stream_row_done(&s->ship);
+    stream_row_done(&s->smode);
+    stream_row_done(&s->prio);
 }
 
 int64_t tpchgen_lineitem_count(int64_t num, int64_t den, int64_t first, int64_t n) {
@@ -254,6 +321,7 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
             delta = -delta;
         }
         int lines = (int)stream_int(&s.lcnt, 1, O_LCNT_MAX);
+        uint8_t prio = (uint8_t)(stream_int(&s.prio, 1, 5) - 1);   /* pick from 5 equally weighted values, already in byte order */
         int64_t total = 0;
         int shipped = 0;
         for (int ln = 0; ln < lines; ln++) {
@@ -272,6 +340,8 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
                 rflag = RFLAG_GEN_TO_CODE[stream_int(&s.rflg, 0, 1)];
             else
                 rflag = 1; /* N */
+            uint8_t instruct = INSTRUCT_GEN_TO_CODE[stream_int(&s.ship, 1, 4) - 1];
+            uint8_t smode = SMODE_GEN_TO_CODE[stream_int(&s.smode, 1, 7) - 1];
             uint8_t lstat = (sdate <= CURRENT_DATE_EPOCH) ? 0 /*F*/ : 1 /*O*/;
             if (lstat == 0) shipped++;
             /* o_totalprice = sum(ext * (1+tax) * (1-disc)) truncated per line */
@@ -290,6 +360,8 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
                 if (L->l_shipdate) L->l_shipdate[row] = sdate;
                 if (L->l_commitdate) L->l_commitdate[row] = cdate;
                 if (L->l_receiptdate) L->l_receiptdate[row] = rdate;
+                if (L->l_shipinstruct) L->l_shipinstruct[row] = instruct;
+                if (L->l_shipmode) L->l_shipmode[row] = smode;
             }
             row++;
         }
@@ -301,6 +373,7 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
             if (O->o_totalprice) O->o_totalprice[i] = total;
             if (O->o_orderstatus)
                 O->o_orderstatus[i] = shipped == lines ? 'F' : (shipped == 0 ? 'O' : 'P');
+            if (O->o_orderpriority) O->o_orderpriority[i] = prio;
         }
         order_streams_row_done(&s);
     }
@@ -338,10 +411,22 @@ int64_t tpchgen_customer(int64_t num, int64_t den, int64_t first, int64_t n,
 int64_t tpchgen_part(int64_t num, int64_t den, int64_t first, int64_t n,
                      const tpchgen_part_cols *out) {
     (void)num; (void)den;
-    stream_t name;
+    stream_t name, mfg, brnd, type, size, cntr;
     stream_init(&name, SD_P_NAME, 92, first);
+    stream_init(&mfg, SD_P_MFG, 1, first);
+    stream_init(&brnd, SD_P_BRND, 1, first);
+    stream_init(&type, SD_P_TYPE, 1, first);
+    stream_init(&size, SD_P_SIZE, 1, first);
+    stream_init(&cntr, SD_P_CNTR, 1, first);
     uint8_t perm[92];
     for (int64_t i = 0; i < n; i++) {
+        int64_t m = stream_int(&mfg, 1, 5), b = stream_int(&brnd, 1, 5);
+        int64_t ty = stream_int(&type, 1, 150) - 1, sz = stream_int(&size, 1, 50), cn = stream_int(&cntr, 1, 40) - 1;
+        if (out->p_brand) out->p_brand[i] = (uint8_t)((m - 1) * 5 + (b - 1));   /* Brand#MN: M = manufacturer, N = 1..5 */
+        if (out->p_type) out->p_type[i] = (uint8_t)ty;
+        if (out->p_size) out->p_size[i] = (int32_t)sz;
+        if (out->p_container) out->p_container[i] = (uint8_t)cn;
+        stream_row_done(&mfg); stream_row_done(&brnd); stream_row_done(&type); stream_row_done(&size); stream_row_done(&cntr);
         for (int k = 0; k < 92; k++) perm[k] = (uint8_t)k;
         for (int k = 0; k < 5; k++) {
             int64_t src = stream_int(&name, k, 91);

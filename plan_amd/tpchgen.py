@@ -45,6 +45,38 @@ def nation_names():
     return _dict("TPCHGEN_NATION_NAMES", 25)
 
 
+def region_names():
+    return _dict("TPCHGEN_REGION_NAMES", 5)
+
+
+def nation_regions():
+    return list((ctypes.c_int32 * 25).in_dll(lib(), "TPCHGEN_NATION_REGION"))
+
+
+SHIPMODE_DICT = ["AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"]
+SHIPINSTRUCT_DICT = ["COLLECT COD", "DELIVER IN PERSON", "NONE", "TAKE BACK RETURN"]
+ORDERPRIORITY_DICT = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
+
+
+def _fn_dict(fn, n):
+    f = getattr(lib(), fn)
+    f.restype = ctypes.POINTER(ctypes.c_char_p)
+    arr = f()
+    return [arr[i].decode() for i in range(n)]
+
+
+def part_type_dict():
+    return _fn_dict("tpchgen_part_type_dict", 150)
+
+
+def part_container_dict():
+    return _fn_dict("tpchgen_part_container_dict", 40)
+
+
+def part_brand_dict():
+    return _fn_dict("tpchgen_part_brand_dict", 25)
+
+
 def colors():
     return _dict("TPCHGEN_COLORS", 92)
 
@@ -59,11 +91,12 @@ _LINEITEM = [("l_orderkey", np.int64), ("l_partkey", np.int32), ("l_suppkey", np
              ("l_linenumber", np.int32), ("l_quantity", np.int32),
              ("l_extendedprice", np.int64), ("l_discount", np.int64), ("l_tax", np.int64),
              ("l_returnflag", np.uint8), ("l_linestatus", np.uint8), ("l_shipdate", np.int32),
-             ("l_commitdate", np.int32), ("l_receiptdate", np.int32)]
+             ("l_commitdate", np.int32), ("l_receiptdate", np.int32), ("l_shipinstruct", np.uint8), ("l_shipmode", np.uint8)]
 _ORDERS = [("o_orderkey", np.int64), ("o_custkey", np.int32), ("o_orderdate", np.int32),
-           ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8)]
+           ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8), ("o_orderpriority", np.uint8)]
 _CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8)]
-_PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8)]
+_PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8), ("p_brand", np.uint8), ("p_type", np.uint8), ("p_size", np.int32),
+         ("p_container", np.uint8)]
 _PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64)]
 _SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32)]
 

@@ -108,3 +108,28 @@ def test_generated_expression_kernels_compile_for_gfx950():
     for which in range(3):
         assert lib.ph_expr_jit_selfcheck(which) == hip.PH_OK, lib.ph_last_error().decode()
     assert lib.ph_expr_jit_selfcheck(5) == hip.PH_EINVAL
+
+
+def test_planhost_libraries_load_and_export_their_entry_points():
+    """libplanhost.so (the C++ operator layer) and libplantpch.so (TPC-H resident plans + the C entry points bench.py
+    uses) load next to libplanhip.so; no compute call without a GPU."""
+    hip.lib()
+    host = ctypes.CDLL(os.path.join(ROOT, "plan_amd", "libplanhost.so"))
+    tpch = ctypes.CDLL(os.path.join(ROOT, "plan_amd", "libplantpch.so"))
+    assert host is not None
+    for n in ("planhost_tpch_load", "planhost_tpch_run", "planhost_tpch_rows", "planhost_tpch_free", "planhost_last_error"):
+        assert hasattr(tpch, n), n
+    tpch.planhost_last_error.restype = ctypes.c_char_p
+    assert tpch.planhost_tpch_load(None, ctypes.c_int64(1), ctypes.c_int64(1), None) == hip.PH_EINVAL
+    assert b"bad arguments" in tpch.planhost_last_error()
+
+
+def test_plan_descriptor_validation_without_a_device():
+    """ph_plan_create checks the descriptor on the host: the root must be the aggregate, children precede parents"""
+    lib = hip.lib()
+    n = (hip.PlanNode * 2)()
+    n[0].kind, n[1].kind = hip.PH_PN_SCAN, hip.PH_PN_JOIN
+    out = hip.vp()
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
+    assert b"root" in lib.ph_last_error()
+    assert lib.ph_plan_create(None, n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL

@@ -181,3 +181,32 @@ def test_order_executor(sf001):
                   key=lambda r: ([-b for b in r[0].encode()] + [1], r[1], -r[2]))
     got = [tuple(l.split("\t")) for l in run("order", "1", "100").split("\n")[1:] if l]
     assert got == [(s, str(a), str(b)) for s, a, b in rows]
+
+
+def run_err(*args):
+    r = subprocess.run([TESTER, *args], check=True, capture_output=True, text=True, timeout=900)
+    return r.stdout, r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", ["q3", "q9"])
+def test_join_queries_as_one_resident_plan_executor_match_reference_goldens(q):
+    """`host_tester q3|q9 <sf> resident` — the whole Agg <- Join* <- Scan subtree behind ONE
+    OperatorExec (gpuResidentPlanExecutor -> ph_plan), ORDER BY / LIMIT through gpuOrderExecutor / limitExecutor
+    above it: the reference's result files byte for byte, the table forms chosen by the library from statistics."""
+    out, err = run_err(q, "1", "1", "resident", "3")
+    assert out == open(os.path.join(G, f"plan_{q}.txt")).read()
+    assert err.count(f"Query {q[1]} took") == 3 and "success" in err
+    assert "conservative" not in err
+    want = ["gated sorted fill", "semi-join marks", "streaming aggregate"] if q == "q3" else ["merge lookup", "strict N:1 lookup", "reduced by the probe key's domain"]
+    for phrase in want:
+        assert phrase in err, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qid,golden", [("1", "plan_q1.txt"), ("6", "plan_q6.txt")])
+def test_scan_queries_as_resident_plans(qid, golden):
+    """Agg <- Scan through the same executor: ph_plan hands it to the fused scan kernels"""
+    out, err = run_err("tpch", qid, "1", "1")
+    assert out == open(os.path.join(G, golden)).read()
+    assert "fused scan plan" in err
