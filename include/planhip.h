@@ -91,7 +91,8 @@ typedef enum {
     PH_CODE8 = 5, /* uint8 dictionary code */
     PH_F32 = 6,
     PH_F64 = 7,
-    PH_STR = 8    /* int32 offsets[n+1] in `data`, bytes in `aux` */
+    PH_STR = 8,   /* int32 offsets[n+1] in `data`, bytes in `aux` */
+    PH_COLREF = 9 /* ph_const only (resident plans): the right operand is another column, ph_const.i = its index */
 } ph_type;
 
 typedef struct {
@@ -149,6 +150,9 @@ int ph_dev_memset(ph_ctx *ctx, void *dev, int value, int64_t bytes);
  * The (type, op) pairs the reference does not implement select nothing, as there. */
 typedef enum { PH_EQ = 1, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE } ph_cmp;
 
+/* A dictionary-code column (PH_CODE8) takes the CODE of a string literal as a PH_I32 constant ('=' / '!='), or — type
+ * PH_CODE8, op PH_EQ — a RUN of codes i .. scale: what `LIKE 'prefix%'` or a sorted IN list is over a dictionary in
+ * byte order. */
 typedef struct {
     int32_t type;  /* PH_I32, PH_DATE, PH_F32 (decimal column vs float literal), PH_DEC64, PH_STR */
     int32_t scale;
@@ -161,6 +165,12 @@ typedef struct {
  * sel_out: dev buffer of >= n_in int32. *n_out (host) receives the count (synchronises). */
 int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op, const ph_const *k,
                      const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
+
+/* column OP column over the same rows (selectBinary with two FLAT vectors, function_operator_boolean.go:506-521),
+ * e.g. Q4 / Q12's l_commitdate < l_receiptdate. The (type, op) pairs are selectOperation's: INTEGER all six, DATE
+ * the four orderings, DECIMAL (one scale) '>' only; the pairs the reference does not implement select nothing. */
+int ph_filter_select_cols(ph_ctx *ctx, const ph_col *a, const ph_col *b, int64_t n, int32_t op, const int32_t *sel_in,
+                          int64_t n_in, int32_t *sel_out, int64_t *n_out);
 
 /* OR of predicates = union of their selections: execSelectOr (expr_exec.go:488-530), which is
  * also how `a IN (x, y, ...)` runs (in(a,x) OR in(a,y) ..., `in` selecting like `=`,
@@ -566,14 +576,38 @@ typedef enum { PH_JT_INNER = 1, PH_JT_SEMI, PH_JT_ANTI } ph_plan_join_type;   /*
 typedef enum {
     PH_PE_COL = 1,    /* column reference (executeColumnRef: zero copy) */
     PH_PE_DECIMAL,    /* decimal / integer arithmetic, RPN over the child's output columns (executeFunc) */
-    PH_PE_YEAR        /* extract(year from <DATE column>)  (ExtractFunc, function_scalar.go:1509-1563) */
+    PH_PE_YEAR,       /* extract(year from <DATE column>)  (ExtractFunc, function_scalar.go:1509-1563) */
+    PH_PE_CASE        /* CASE WHEN <when> THEN <prog> ELSE <else_prog> END (executeCase, expr_exec.go:144-246):
+                         the WHEN is a select, THEN is evaluated on its true rows and ELSE on the others
+                         (FillSwitch, :559-606). Both branches are DECIMAL programs of ONE result scale (an integer
+                         constant in a branch — `ELSE 0` — is cast to it), or — result_int != 0 — both INTEGER
+                         constants. */
 } ph_plan_expr_kind;
+
+/* A boolean expression over a node's input columns as a flat tree (node 0 = the root): what ExprExec.executeSelect
+ * walks (execSelectExpr / And / Or / Compare, expr_exec.go:342-530). AND narrows the selection child by child, OR
+ * evaluates every child on the parent's rows and unites the true rows (`a IN (x, y)` is in(a,x) OR in(a,y)).
+ * A comparison's right operand is a constant or — k.type = PH_COLREF — the column k.i. */
+typedef enum { PH_B_CMP = 1, PH_B_AND, PH_B_OR } ph_bool_kind;
+typedef struct {
+    int32_t kind;          /* ph_bool_kind */
+    int32_t col, op;       /* PH_B_CMP: column OP k  (ph_cmp; PH_LIKE / PH_NOTLIKE also over dictionary-code columns) */
+    ph_const k;
+    int32_t first_child;   /* PH_B_AND / PH_B_OR: children are nodes first_child .. first_child + nchildren - 1 */
+    int32_t nchildren;
+} ph_bool;
 
 typedef struct {
     int32_t kind;     /* ph_plan_expr_kind */
     int32_t col;      /* PH_PE_COL / PH_PE_YEAR: child output column */
     int32_t nprog;
-    ph_rpn prog[12];  /* PH_PE_DECIMAL: ph_rpn.col indexes the child's output columns */
+    ph_rpn prog[12];  /* PH_PE_DECIMAL: ph_rpn.col indexes the child's output columns. PH_PE_CASE: the THEN branch */
+    /* PH_PE_CASE */
+    int32_t nwhen;
+    const ph_bool *when;   /* the WHEN condition over the child's output columns */
+    int32_t nelse;
+    ph_rpn else_prog[12];
+    int32_t result_int;    /* != 0: THEN / ELSE are single PH_X_CONST programs of scale 0 and the result is INTEGER */
 } ph_plan_expr;
 
 typedef struct {
@@ -593,6 +627,10 @@ typedef struct {
     /* PH_PN_SCAN / PH_PN_FILTER: conjuncts, AND-ed in order (PH_PN_FILTER: ph_pred.col = child output column) */
     int32_t npreds;
     const ph_pred *preds;
+    /* ... and one more conjunct of any shape (OR / IN lists, column-vs-column comparisons), AND-ed behind them.
+       Simple `column OP constant` conjuncts belong in preds: those are the ones a build or a probe can absorb. */
+    int32_t nbools;
+    const ph_bool *bools;
     /* PH_PN_JOIN: equi-join on nkeys column pairs; the output picks from [probe child's columns | build
        child's columns] (SEMI / ANTI: probe columns only) */
     int32_t join_type;           /* ph_plan_join_type */

@@ -1,0 +1,486 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY. See oracle.h.
+ * Query drivers, round 3: TPC-H Q4, Q5, Q12, Q14, Q19 as physical pipelines over the operator restatements of
+ * oracle.c — filter (execSelectAnd / execSelectOr, expr_exec.go:444-530; column-vs-column selectBinary), hash join
+ * build / probe incl. the SEMI variant (join_scan.go:90-120, 166-180), CASE (executeCase, expr_exec.go:144-246), hash
+ * aggregate, and the FLOAT arithmetic Q14's select list binds to (function_scalar.go:476-512, 960-1010;
+ * function_cast.go:349-354). The join ORDER is a planner's choice (the result does not depend on it); the value
+ * semantics are the reference's. Pinned by cases/tpch/1g/plan/q{4,5,12,14,19}.txt through tests/test_golden_tpch.py. */
+#include "oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VS ORACLE_VECTOR_SIZE
+
+static ocol mkcol(int32_t type, int32_t scale, const void *data) {
+    ocol c;
+    memset(&c, 0, sizeof c);
+    c.type = type;
+    c.scale = scale;
+    c.data = data;
+    return c;
+}
+static ocol mkcode(const uint8_t *data, const char *const *dict) {
+    ocol c = mkcol(OT_CODE8, 0, data);
+    c.dict = dict;
+    return c;
+}
+static oconst kdate(int32_t d) { oconst k; memset(&k, 0, sizeof k); k.type = OT_DATE; k.i = d; return k; }
+static oconst kint(int64_t v) { oconst k; memset(&k, 0, sizeof k); k.type = OT_INT32; k.i = v; return k; }
+static oconst kstr(const char *s) { oconst k; memset(&k, 0, sizeof k); k.type = OT_VARCHAR; k.s = s; return k; }
+static int64_t *i64buf(int64_t n) { return (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1)); }
+
+/* e * (1 - d) */
+static const orpn DISC_PRICE[5] = {{OX_COL, 0, 0, 0}, {OX_CONST_INT, 0, 1, 0}, {OX_COL, 1, 0, 0}, {OX_SUB, 0, 0, 0}, {OX_MUL, 0, 0, 0}};
+
+/* ------------------------------------------------------------------ Q4
+ * Agg(o_orderpriority; count(*)) <- SemiJoin(o_orderkey = l_orderkey) probe Scan(orders, date range)
+ *                                       build Scan(lineitem, l_commitdate < l_receiptdate)        (EXISTS subquery) */
+int64_t oracle_q4(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracle_q4_row *out, int64_t max) {
+    int64_t *lsel = i64buf(T->n_lineitem);
+    ocol lc = mkcol(OT_DATE, 0, T->l_commitdate), lr = mkcol(OT_DATE, 0, T->l_receiptdate);
+    int64_t nl = oracle_select_cols(&lc, OP_LT, &lr, NULL, T->n_lineitem, lsel);
+    ocol lkey = mkcol(OT_INT64, 0, T->l_orderkey);
+    ojoin *j = oracle_join_build(&lkey, 1, lsel, nl);
+    int64_t *o1 = i64buf(T->n_orders), *o2 = i64buf(T->n_orders);
+    ocol od = mkcol(OT_DATE, 0, T->o_orderdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    int64_t n1 = oracle_select(&od, OP_GE, &k1, NULL, T->n_orders, o1);
+    int64_t n2 = oracle_select(&od, OP_LT, &k2, o1, n1, o2);
+    uint8_t *found = (uint8_t *)malloc((size_t)(n2 > 0 ? n2 : 1));
+    ocol okey = mkcol(OT_INT64, 0, T->o_orderkey);
+    oracle_join_probe_mark(j, &okey, 1, o2, n2, found);      /* NextSemiOrAntiJoin: the probe rows with a match */
+    oracle_join_free(j);
+    ocol kproto[1] = {mkcode(NULL, T->orderpriority_dict)};
+    oaggspec aggs[1] = {{OA_COUNT, -1}};
+    oagg *t = oracle_agg_create(kproto, 1, NULL, aggs, 1);
+    uint8_t pr[VS];
+    int rc = 0;
+    int64_t m = 0;
+    for (int64_t i = 0; i <= n2 && rc == 0; i++) {
+        if (i < n2 && found[i]) pr[m++] = T->o_orderpriority[o2[i]];
+        if (m == VS || (i == n2 && m > 0)) {
+            ocol keys[1] = {mkcode(pr, T->orderpriority_dict)};
+            rc = oracle_agg_sink(t, keys, NULL, NULL, m);
+            m = 0;
+        }
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[1];
+        oaggval v;
+        oracle_agg_group(t, g, NULL, kv, NULL, &v);
+        out[g].code = (int32_t)kv[0];
+        out[g].count = v.h;
+    }
+    oracle_agg_free(t);
+    free(lsel); free(o1); free(o2); free(found);
+    return ng;
+}
+
+/* ------------------------------------------------------------------ Q5
+ * Agg(n_name; sum(e*(1-d))) <- Join((l_suppkey, c_nationkey) = (s_suppkey, s_nationkey)) <- Join(l_orderkey = o_orderkey)
+ *   probe lineitem, build <- Join(o_custkey = c_custkey) probe orders[date range], build <- Join(c_nationkey = n_nationkey)
+ *   probe customer, build <- Join(n_regionkey = r_regionkey) probe nation, build region[r_name = ..] */
+int64_t oracle_q5(const oracle_tpch *T, const char *region, int32_t date_ge, int32_t date_lt, oracle_q5_row *out, int64_t max) {
+    int64_t rsel[5], np[25], nb[25];
+    ocol rn = mkcode(T->r_name, T->region_dict);
+    oconst kr = kstr(region);
+    int64_t nr = oracle_select(&rn, OP_EQ, &kr, NULL, 5, rsel);
+    ocol rk = mkcol(OT_INT32, 0, T->r_regionkey);
+    ojoin *jr = oracle_join_build(&rk, 1, rsel, nr);
+    ocol nrk = mkcol(OT_INT32, 0, T->n_regionkey);
+    int64_t nn = oracle_join_probe_inner(jr, &nrk, 1, NULL, 25, np, nb, 25);     /* nations of the region */
+    oracle_join_free(jr);
+    ocol nk = mkcol(OT_INT32, 0, T->n_nationkey);
+    ojoin *jn = oracle_join_build(&nk, 1, np, nn);
+    /* customer x nation */
+    int64_t *c_row = i64buf(T->n_customer), *c_nat = i64buf(T->n_customer);
+    ocol cn = mkcol(OT_INT32, 0, T->c_nationkey);
+    int64_t nc = oracle_join_probe_inner(jn, &cn, 1, NULL, T->n_customer, c_row, c_nat, T->n_customer);
+    oracle_join_free(jn);
+    ocol ck = mkcol(OT_INT32, 0, T->c_custkey);
+    ojoin *jc = oracle_join_build(&ck, 1, c_row, nc);          /* build row ids = customer rows */
+    /* orders[date range] x customer' */
+    int64_t *o1 = i64buf(T->n_orders), *o2 = i64buf(T->n_orders);
+    ocol od = mkcol(OT_DATE, 0, T->o_orderdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    int64_t n1 = oracle_select(&od, OP_GE, &k1, NULL, T->n_orders, o1);
+    int64_t n2 = oracle_select(&od, OP_LT, &k2, o1, n1, o2);
+    int64_t *o_row = i64buf(n2), *o_cust = i64buf(n2);
+    ocol oc = mkcol(OT_INT32, 0, T->o_custkey);
+    int64_t no = oracle_join_probe_inner(jc, &oc, 1, o2, n2, o_row, o_cust, n2);
+    oracle_join_free(jc);
+    /* lineitem x orders' (the build side is the join output: positional keys) */
+    int64_t *bk = i64buf(no);
+    for (int64_t i = 0; i < no; i++) bk[i] = T->o_orderkey[o_row[i]];
+    ocol bkc = mkcol(OT_INT64, 0, bk);
+    ojoin *jo = oracle_join_build(&bkc, 1, NULL, no);
+    int64_t cap = T->n_lineitem;
+    int64_t *l_row = i64buf(cap), *l_ord = i64buf(cap);
+    ocol lk = mkcol(OT_INT64, 0, T->l_orderkey);
+    int64_t nl = oracle_join_probe_inner(jo, &lk, 1, NULL, T->n_lineitem, l_row, l_ord, cap);
+    oracle_join_free(jo);
+    /* ... x supplier on (l_suppkey, c_nationkey) = (s_suppkey, s_nationkey) */
+    ocol sk[2] = {mkcol(OT_INT32, 0, T->s_suppkey), mkcol(OT_INT32, 0, T->s_nationkey)};
+    ojoin *js = oracle_join_build(sk, 2, NULL, T->n_supplier);
+    int32_t *p_supp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1)), *p_nat = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
+    for (int64_t i = 0; i < nl; i++) {
+        p_supp[i] = T->l_suppkey[l_row[i]];
+        p_nat[i] = T->c_nationkey[o_cust[l_ord[i]]];
+    }
+    ocol pk[2] = {mkcol(OT_INT32, 0, p_supp), mkcol(OT_INT32, 0, p_nat)};
+    int64_t *f_pos = i64buf(nl), *f_sup = i64buf(nl);
+    int64_t nf = oracle_join_probe_inner(js, pk, 2, NULL, nl, f_pos, f_sup, nl);
+    oracle_join_free(js);
+    /* aggregate by n_name */
+    ocol kproto[1] = {mkcode(NULL, T->nation_dict)};
+    ocol aproto[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 1);
+    static odec v[VS];
+    int64_t ext[VS], disc[VS];
+    uint8_t name[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < nf && rc == 0; base += VS) {
+        int64_t cnt = nf - base < VS ? nf - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            int64_t pos = f_pos[base + j], l = l_row[pos];
+            ext[j] = T->l_extendedprice[l];
+            disc[j] = T->l_discount[l];
+            name[j] = T->n_name[T->c_nationkey[o_cust[l_ord[pos]]]];   /* n_nationkey = its row (the fixed NATION table) */
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        rc = oracle_eval_decimal(cols, DISC_PRICE, 5, NULL, cnt, v);
+        ocol keys[1] = {mkcode(name, T->nation_dict)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        if (rc == 0) rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[1];
+        oaggval val;
+        oracle_agg_group(t, g, NULL, kv, NULL, &val);
+        out[g].nation = (int32_t)kv[0];
+        out[g].revenue = val.d;
+    }
+    oracle_agg_free(t);
+    free(c_row); free(c_nat); free(o1); free(o2); free(o_row); free(o_cust); free(bk); free(l_row); free(l_ord);
+    free(p_supp); free(p_nat); free(f_pos); free(f_sup);
+    (void)nb;
+    return ng;
+}
+
+/* ------------------------------------------------------------------ Q12
+ * Agg(l_shipmode; sum(case when prio = '1-URGENT' or prio = '2-HIGH' then 1 else 0 end), sum(case when prio <> .. and prio <> ..
+ * then 1 else 0 end)) <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, shipmode IN (..), commit < receipt, ship < commit,
+ * receipt range), build Scan(orders) */
+int64_t oracle_q12(const oracle_tpch *T, const char *mode1, const char *mode2, int32_t date_ge, int32_t date_lt, oracle_q12_row *out, int64_t max) {
+    int64_t n = T->n_lineitem;
+    int64_t *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol sm = mkcode(T->l_shipmode, T->shipmode_dict);
+    ocol orc[2] = {sm, sm};
+    int32_t ops[2] = {OP_EQ, OP_EQ};
+    oconst ks[2] = {kstr(mode1), kstr(mode2)};
+    int64_t c = oracle_select_or(orc, ops, ks, 2, NULL, n, s1);                 /* l_shipmode in (m1, m2) */
+    ocol lc = mkcol(OT_DATE, 0, T->l_commitdate), lr = mkcol(OT_DATE, 0, T->l_receiptdate), ls = mkcol(OT_DATE, 0, T->l_shipdate);
+    c = oracle_select_cols(&lc, OP_LT, &lr, s1, c, s2);                         /* l_commitdate < l_receiptdate */
+    c = oracle_select_cols(&ls, OP_LT, &lc, s2, c, s1);                         /* l_shipdate < l_commitdate */
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    c = oracle_select(&lr, OP_GE, &k1, s1, c, s2);
+    c = oracle_select(&lr, OP_LT, &k2, s2, c, s1);
+    ocol ok = mkcol(OT_INT64, 0, T->o_orderkey);
+    ojoin *jo = oracle_join_build(&ok, 1, NULL, T->n_orders);
+    int64_t *l_row = i64buf(c), *o_row = i64buf(c);
+    ocol lk = mkcol(OT_INT64, 0, T->l_orderkey);
+    int64_t nj = oracle_join_probe_inner(jo, &lk, 1, s1, c, l_row, o_row, c);
+    oracle_join_free(jo);
+    ocol kproto[1] = {mkcode(NULL, T->shipmode_dict)};
+    ocol aproto[2] = {mkcol(OT_INT32, 0, NULL), mkcol(OT_INT32, 0, NULL)};
+    oaggspec aggs[2] = {{OA_SUM, 0}, {OA_SUM, 1}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 2);
+    uint8_t mode[VS], prio[VS];
+    int32_t hi[VS], lo[VS];
+    int64_t ts[VS], ts2[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < nj && rc == 0; base += VS) {
+        int64_t cnt = nj - base < VS ? nj - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            mode[j] = T->l_shipmode[l_row[base + j]];
+            prio[j] = T->o_orderpriority[o_row[base + j]];
+            hi[j] = lo[j] = 0;                                   /* ELSE 0 */
+        }
+        ocol pc = mkcode(prio, T->orderpriority_dict);
+        ocol pcs[2] = {pc, pc};
+        oconst ku[2] = {kstr("1-URGENT"), kstr("2-HIGH")};
+        int32_t eq[2] = {OP_EQ, OP_EQ};
+        int64_t th = oracle_select_or(pcs, eq, ku, 2, NULL, cnt, ts);          /* WHEN a OR b: THEN 1 at the true rows */
+        for (int64_t i = 0; i < th; i++) hi[ts[i]] = 1;
+        int64_t tl = oracle_select(&pc, OP_NE, &ku[0], NULL, cnt, ts);         /* WHEN a AND b */
+        tl = oracle_select(&pc, OP_NE, &ku[1], ts, tl, ts2);
+        for (int64_t i = 0; i < tl; i++) lo[ts2[i]] = 1;
+        ocol keys[1] = {mkcode(mode, T->shipmode_dict)};
+        ocol args[2] = {mkcol(OT_INT32, 0, hi), mkcol(OT_INT32, 0, lo)};
+        rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[1];
+        oaggval v[2];
+        oracle_agg_group(t, g, NULL, kv, NULL, v);
+        out[g].mode = (int32_t)kv[0];
+        out[g].high = v[0].h;
+        out[g].low = v[1].h;
+    }
+    oracle_agg_free(t);
+    free(s1); free(s2); free(l_row); free(o_row);
+    return ng;
+}
+
+/* ------------------------------------------------------------------ Q14
+ * Agg(; sum(case when p_type like 'PROMO%' then e*(1-d) else 0 end), sum(e*(1-d))) <- Join(l_partkey = p_partkey)
+ * probe Scan(lineitem, shipdate range), build Scan(part); the select list's 100.00 * a / b is FLOAT arithmetic */
+int32_t oracle_q14(const oracle_tpch *T, const char *like_pattern, int32_t date_ge, int32_t date_lt, float *promo_revenue, odec *promo, odec *total) {
+    int64_t n = T->n_lineitem;
+    int64_t *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol ls = mkcol(OT_DATE, 0, T->l_shipdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    int64_t c = oracle_select(&ls, OP_GE, &k1, NULL, n, s1);
+    c = oracle_select(&ls, OP_LT, &k2, s1, c, s2);
+    ocol pk = mkcol(OT_INT32, 0, T->p_partkey);
+    ojoin *jp = oracle_join_build(&pk, 1, NULL, T->n_part);
+    int64_t *l_row = i64buf(c), *p_row = i64buf(c);
+    ocol lp = mkcol(OT_INT32, 0, T->l_partkey);
+    int64_t nj = oracle_join_probe_inner(jp, &lp, 1, s2, c, l_row, p_row, c);
+    oracle_join_free(jp);
+    static const int32_t one = 1;
+    ocol kproto[1] = {mkcol(OT_CONST32, 0, &one)};
+    ocol aproto[2] = {mkcol(OT_ODEC, 0, NULL), mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[2] = {{OA_SUM, 0}, {OA_SUM, 1}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 2);
+    static odec vc[VS], va[VS];
+    static uint8_t vnull[VS];
+    int64_t ext[VS], disc[VS];
+    uint8_t ty[VS];
+    const orpn zero[1] = {{OX_CONST_INT, 0, 0, 0}};
+    oconst kp = kstr(like_pattern);
+    int rc = 0;
+    for (int64_t base = 0; base < nj && rc == 0; base += VS) {
+        int64_t cnt = nj - base < VS ? nj - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            ext[j] = T->l_extendedprice[l_row[base + j]];
+            disc[j] = T->l_discount[l_row[base + j]];
+            ty[j] = T->p_type[p_row[base + j]];
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        ocol wc = mkcode(ty, T->type_dict);
+        rc = oracle_case_decimal(cols, &wc, OP_LIKE, &kp, DISC_PRICE, 5, zero, 1, cnt, vc, vnull);
+        if (rc == 0) rc = oracle_eval_decimal(cols, DISC_PRICE, 5, NULL, cnt, va);
+        ocol keys[1] = {mkcol(OT_CONST32, 0, &one)};
+        ocol args[2] = {mkcol(OT_ODEC, 0, vc), mkcol(OT_ODEC, 0, va)};
+        if (rc == 0) rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+    }
+    int32_t res = rc ? -1 : 1;
+    if (rc == 0 && oracle_agg_count(t) == 1) {
+        int64_t kv[1];
+        oaggval v[2];
+        oracle_agg_group(t, 0, NULL, kv, NULL, v);
+        if (v[0].kind == OV_DECIMAL && v[1].kind == OV_DECIMAL) {
+            *promo = v[0].d;
+            *total = v[1].d;
+            /* 100.00 is a FLOAT literal; `*` and `/` resolve to their FLOAT overloads with both decimals cast
+             * decimal -> float64 -> float32 (tryCastDecimalToFloat32); each operation rounds to float32 */
+            volatile float a = (float)odec_float64(v[0].d), b = (float)odec_float64(v[1].d);
+            volatile float m = 100.00f * a;
+            *promo_revenue = m / b;
+            res = 0;
+        }
+    }
+    oracle_agg_free(t);
+    free(s1); free(s2); free(l_row); free(p_row);
+    return res;
+}
+
+/* ------------------------------------------------------------------ Q19
+ * Agg(; sum(e*(1-d))) <- Filter(OR of three conjunctions over both sides) <- Join(l_partkey = p_partkey) probe lineitem, build part.
+ * (p_partkey = l_partkey is common to the three OR branches: the join condition.) execSelectOr evaluates a branch on the
+ * rows no earlier branch accepted; every branch is an execSelectAnd chain; IN lists are ORs of '='. */
+typedef struct { const char *brand; const char *cntr[4]; int32_t qlo, qhi, smax; } q19_branch;
+
+static int64_t and_step(const ocol *col, int32_t op, const oconst *k, int64_t *cur, int64_t n, int64_t *tmp) {
+    int64_t m = oracle_select(col, op, k, cur, n, tmp);
+    memcpy(cur, tmp, sizeof(int64_t) * (size_t)m);
+    return m;
+}
+static int64_t or_step(const ocol *col, const char *const *vals, int nv, int64_t *cur, int64_t n, int64_t *tmp) {
+    ocol cs[4];
+    int32_t ops[4];
+    oconst ks[4];
+    for (int i = 0; i < nv; i++) { cs[i] = *col; ops[i] = OP_EQ; ks[i] = kstr(vals[i]); }
+    int64_t m = oracle_select_or(cs, ops, ks, nv, cur, n, tmp);
+    memcpy(cur, tmp, sizeof(int64_t) * (size_t)m);
+    return m;
+}
+
+int32_t oracle_q19(const oracle_tpch *T, odec *revenue) {
+    static const q19_branch BR[3] = {{"Brand#23", {"SM CASE", "SM BOX", "SM PACK", "SM PKG"}, 5, 15, 5},
+                                     {"Brand#15", {"MED BAG", "MED BOX", "MED PKG", "MED PACK"}, 14, 24, 10},
+                                     {"Brand#44", {"LG CASE", "LG BOX", "LG PACK", "LG PKG"}, 28, 38, 15}};
+    static const char *const MODES[2] = {"AIR", "AIR REG"};
+    ocol pk = mkcol(OT_INT32, 0, T->p_partkey);
+    ojoin *jp = oracle_join_build(&pk, 1, NULL, T->n_part);
+    int64_t n = T->n_lineitem;
+    int64_t *l_row = i64buf(n), *p_row = i64buf(n);
+    ocol lp = mkcol(OT_INT32, 0, T->l_partkey);
+    int64_t nj = oracle_join_probe_inner(jp, &lp, 1, NULL, n, l_row, p_row, n);
+    oracle_join_free(jp);
+    static const int32_t one = 1;
+    ocol kproto[1] = {mkcol(OT_CONST32, 0, &one)};
+    ocol aproto[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 1);
+    static odec v[VS];
+    int64_t ext[VS], disc[VS], cur[VS], acc[VS], rest[VS], tmp[VS];
+    int32_t qty[VS], size[VS];
+    uint8_t brand[VS], cntr[VS], mode[VS], instr[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < nj && rc == 0; base += VS) {
+        int64_t cnt = nj - base < VS ? nj - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            int64_t l = l_row[base + j], p = p_row[base + j];
+            ext[j] = T->l_extendedprice[l]; disc[j] = T->l_discount[l]; qty[j] = T->l_quantity[l];
+            mode[j] = T->l_shipmode[l]; instr[j] = T->l_shipinstruct[l];
+            brand[j] = T->p_brand[p]; cntr[j] = T->p_container[p]; size[j] = T->p_size[p];
+        }
+        ocol cb = mkcode(brand, T->brand_dict), cc = mkcode(cntr, T->container_dict), cm = mkcode(mode, T->shipmode_dict),
+             ci = mkcode(instr, T->shipinstruct_dict), cq = mkcol(OT_INT32, 0, qty), cz = mkcol(OT_INT32, 0, size);
+        int64_t nrest = cnt, nacc = 0;
+        for (int64_t j = 0; j < cnt; j++) rest[j] = j;
+        for (int b = 0; b < 3 && nrest > 0; b++) {     /* execSelectOr: branch b on the rows not accepted yet */
+            int64_t m = nrest;
+            memcpy(cur, rest, sizeof(int64_t) * (size_t)nrest);
+            oconst kb = kstr(BR[b].brand), kq1 = kint(BR[b].qlo), kq2 = kint(BR[b].qhi), kz1 = kint(1), kz2 = kint(BR[b].smax), kin = kstr("DELIVER IN PERSON");
+            m = and_step(&cb, OP_EQ, &kb, cur, m, tmp);
+            m = or_step(&cc, BR[b].cntr, 4, cur, m, tmp);
+            m = and_step(&cq, OP_GE, &kq1, cur, m, tmp);
+            m = and_step(&cq, OP_LE, &kq2, cur, m, tmp);
+            m = and_step(&cz, OP_GE, &kz1, cur, m, tmp);
+            m = and_step(&cz, OP_LE, &kz2, cur, m, tmp);
+            m = or_step(&cm, MODES, 2, cur, m, tmp);
+            m = and_step(&ci, OP_EQ, &kin, cur, m, tmp);
+            /* accepted rows leave `rest` (or_step may have reordered cur: membership test) */
+            uint8_t hit[VS];
+            memset(hit, 0, (size_t)cnt);
+            for (int64_t i = 0; i < m; i++) { hit[cur[i]] = 1; acc[nacc++] = cur[i]; }
+            int64_t w = 0;
+            for (int64_t i = 0; i < nrest; i++) if (!hit[rest[i]]) rest[w++] = rest[i];
+            nrest = w;
+        }
+        if (nacc == 0) continue;
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        rc = oracle_eval_decimal(cols, DISC_PRICE, 5, acc, nacc, v);
+        ocol keys[1] = {mkcol(OT_CONST32, 0, &one)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        if (rc == 0) rc = oracle_agg_sink(t, keys, args, NULL, nacc);
+    }
+    int32_t res = rc ? -1 : 1;
+    if (rc == 0 && oracle_agg_count(t) == 1) {
+        int64_t kv[1];
+        oaggval val;
+        oracle_agg_group(t, 0, NULL, kv, NULL, &val);
+        if (val.kind == OV_DECIMAL) { *revenue = val.d; res = 0; }
+    }
+    oracle_agg_free(t);
+    free(l_row); free(p_row);
+    return res;
+}
+
+/* ------------------------------------------------------------------ text */
+typedef struct { char *buf; int64_t cap, len; } sbuf2;
+static void put(sbuf2 *s, const char *t) {
+    int64_t n = (int64_t)strlen(t);
+    if (s->len + n < s->cap) memcpy(s->buf + s->len, t, (size_t)n);
+    s->len += n;
+}
+static int64_t done(sbuf2 *s) { if (s->len < s->cap) s->buf[s->len] = 0; else if (s->cap > 0) s->buf[s->cap - 1] = 0; return s->len; }
+
+/* ORDER BY through the reference's key encoding (oracle_sort_rows: LocalSort's byte-comparable keys) */
+static void order_by_code(const int32_t *codes, int64_t n, int64_t *order) {
+    uint8_t *c8 = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) c8[i] = (uint8_t)codes[i];
+    ocol k = mkcol(OT_CODE8, 0, c8);
+    int32_t desc = 0;
+    oracle_sort_rows(&k, &desc, 1, NULL, n, order, NULL, NULL);
+    free(c8);
+}
+
+int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    int32_t *codes = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) codes[i] = rows[i].code;
+    order_by_code(codes, n, ord);
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        put(&s, dict[rows[ord[i]].code]); put(&s, "\t");
+        oracle_format_hugeint(rows[ord[i]].count, t); put(&s, t); put(&s, "\n");
+    }
+    free(codes); free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    int64_t *un = i64buf(n), *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) { __int128 u = 0; odec_to_unscaled(rows[i].revenue, 4, &u); un[i] = (int64_t)u; }
+    ocol k = mkcol(OT_DECIMAL, 4, un);
+    int32_t desc = 1;
+    oracle_sort_rows(&k, &desc, 1, NULL, n, ord, NULL, NULL);      /* ORDER BY revenue DESC */
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        put(&s, dict[rows[ord[i]].nation]); put(&s, "\t");
+        oracle_format_decimal(rows[ord[i]].revenue, 4, t); put(&s, t); put(&s, "\n");
+    }
+    free(un); free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\t\n");
+    int32_t *codes = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) codes[i] = rows[i].mode;
+    order_by_code(codes, n, ord);
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        put(&s, dict[rows[ord[i]].mode]); put(&s, "\t");
+        oracle_format_hugeint(rows[ord[i]].high, t); put(&s, t); put(&s, "\t");
+        oracle_format_hugeint(rows[ord[i]].low, t); put(&s, t); put(&s, "\n");
+    }
+    free(codes); free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q14_text(float promo_revenue, int is_null, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\n");
+    char t[64];
+    if (is_null) put(&s, "NULL");
+    else { oracle_format_double((double)promo_revenue, t); put(&s, t); }   /* Value.String FLOAT: %v of float64(float32) */
+    put(&s, "\n");
+    return done(&s);
+}
+
+int64_t oracle_q19_text(const odec *revenue, int is_null, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\n");
+    char t[64];
+    if (is_null) put(&s, "NULL");
+    else { oracle_format_decimal(*revenue, 4, t); put(&s, t); }
+    put(&s, "\n");
+    return done(&s);
+}

@@ -729,6 +729,41 @@ int oracle_case_decimal(const ocol *cols, const ocol *when_col, int32_t when_op,
     return rc;
 }
 
+/* ------------------------------------------------------------------ column OP column */
+
+/* selectBinary over two FLAT vectors (function_operator_boolean.go:506-521 -> selectFlat :672-778 ->
+ * selectFlatLoop :780-868): the same (type, op) table as against a constant; a NULL on either side never selects. */
+int64_t oracle_select_cols(const ocol *a, int32_t op, const ocol *b, const int64_t *sel_in, int64_t n_in,
+                           int64_t *sel_out) {
+    enum { P_INT32, P_DATE, P_FLOAT, P_DOUBLE, P_DECIMAL, P_VARCHAR, P_INT64 };
+    int phys;
+    if (a->type == OT_INT32 && b->type == OT_INT32) phys = P_INT32;
+    else if (a->type == OT_DATE && b->type == OT_DATE) phys = P_DATE;
+    else if (a->type == OT_DECIMAL && b->type == OT_DECIMAL) phys = P_DECIMAL;
+    else if (a->type == OT_INT64 && b->type == OT_INT64) phys = P_INT64;
+    else return 0;
+    if (!select_supported(phys, op)) return 0;
+    int64_t out = 0;
+    for (int64_t base = 0; base < n_in; base += VS) {
+        int64_t cnt = n_in - base < VS ? n_in - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            int64_t r = sel_in ? sel_in[base + j] : base + j;
+            if (!row_valid(a->validity, r) || !row_valid(b->validity, r)) continue;
+            int c;
+            if (phys == P_INT32) {
+                int32_t x = ((const int32_t *)a->data)[r], y = ((const int32_t *)b->data)[r];
+                c = x < y ? -1 : x > y;
+            } else if (phys == P_DATE) {
+                c = date_cmp(date_from_days(((const int32_t *)a->data)[r]), date_from_days(((const int32_t *)b->data)[r]));
+            } else {
+                c = odec_cmp(dec_from_unscaled(((const int64_t *)a->data)[r], a->scale), dec_from_unscaled(((const int64_t *)b->data)[r], b->scale));
+            }
+            if (cmp_result(c, op)) sel_out[out++] = r;
+        }
+    }
+    return out;
+}
+
 /* ------------------------------------------------------------------ OR of comparisons */
 
 int64_t oracle_select_or(const ocol *cols, const int32_t *ops, const oconst *ks, int32_t k,

@@ -77,6 +77,12 @@ typedef struct {
 int64_t oracle_select(const ocol *col, int32_t op, const oconst *k, const int64_t *sel_in,
                       int64_t n_in, int64_t *sel_out);
 
+/* column OP column over the same rows (selectBinary with two FLAT vectors, function_operator_boolean.go:506-521):
+ * INTEGER all six operators, DATE the four orderings, DECIMAL '>' — the pairs selectOperation has; others select
+ * nothing. Q4 / Q12: l_commitdate < l_receiptdate. */
+int64_t oracle_select_cols(const ocol *a, int32_t op, const ocol *b, const int64_t *sel_in, int64_t n_in,
+                           int64_t *sel_out);
+
 /* OR of k comparisons (`a IN (x, y)` binds to in(a,x) OR in(a,y); `in` selects like `=` for
  * INTEGER and VARCHAR and nothing for other types, function_operator_boolean.go:419-429).
  * execSelectOr (expr_exec.go:488-530): child i is evaluated on the rows every earlier child
@@ -294,6 +300,53 @@ typedef struct {
 int64_t oracle_q9(const oracle_lineitem *L, const oracle_orders *O, const oracle_part *P,
                   const oracle_partsupp *PS, const oracle_supplier *S, const char *like_pattern,
                   oracle_q9_row *out, int64_t max);
+
+/* ---- round 3: Q4, Q5, Q12, Q14, Q19 (cases/tpch/query/q{4,5,12,14,19}.sql) — SEMI join, the six-table join chain,
+ * IN / OR lists, CASE (integer and decimal branches, LIKE in a WHEN), column-vs-column comparisons and FLOAT
+ * arithmetic over aggregate results. Pinned by cases/tpch/1g/plan/q{4,5,12,14,19}.txt (tests/golden/). */
+typedef struct {
+    /* lineitem */
+    int64_t n_lineitem;
+    const int64_t *l_orderkey, *l_extendedprice, *l_discount;
+    const int32_t *l_partkey, *l_suppkey, *l_quantity, *l_shipdate, *l_commitdate, *l_receiptdate;
+    const uint8_t *l_shipmode, *l_shipinstruct;
+    /* orders */
+    int64_t n_orders;
+    const int64_t *o_orderkey;
+    const int32_t *o_custkey, *o_orderdate;
+    const uint8_t *o_orderpriority;
+    /* customer, supplier, part */
+    int64_t n_customer;
+    const int32_t *c_custkey, *c_nationkey;
+    int64_t n_supplier;
+    const int32_t *s_suppkey, *s_nationkey;
+    int64_t n_part;
+    const int32_t *p_partkey, *p_size;
+    const uint8_t *p_brand, *p_type, *p_container;
+    /* nation (25), region (5) */
+    const int32_t *n_nationkey, *n_regionkey, *r_regionkey;
+    const uint8_t *n_name, *r_name;
+    /* dictionaries (code -> string) */
+    const char *const *shipmode_dict, *const *shipinstruct_dict, *const *orderpriority_dict, *const *brand_dict, *const *type_dict,
+        *const *container_dict, *const *nation_dict, *const *region_dict;
+} oracle_tpch;
+
+typedef struct { int32_t code; ohuge count; } oracle_q4_row;          /* o_orderpriority code, count(*) */
+typedef struct { int32_t nation; odec revenue; } oracle_q5_row;       /* n_name code, sum */
+typedef struct { int32_t mode; ohuge high, low; } oracle_q12_row;     /* l_shipmode code, the two sums */
+/* each returns the number of groups (first-seen order), -1 on a decimal error */
+int64_t oracle_q4(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracle_q4_row *out, int64_t max);
+int64_t oracle_q5(const oracle_tpch *T, const char *region, int32_t date_ge, int32_t date_lt, oracle_q5_row *out, int64_t max);
+int64_t oracle_q12(const oracle_tpch *T, const char *mode1, const char *mode2, int32_t date_ge, int32_t date_lt, oracle_q12_row *out, int64_t max);
+/* promo_revenue = 100.00 * sum(case when p_type like pattern then e*(1-d) else 0 end) / sum(e*(1-d)), in float32 as the
+ * binder types it (the literal is FLOAT; MaxLType(FLOAT, DECIMAL) = FLOAT): returns 0 ok, 1 NULL sums, -1 decimal error */
+int32_t oracle_q14(const oracle_tpch *T, const char *like_pattern, int32_t date_ge, int32_t date_lt, float *promo_revenue, odec *promo, odec *total);
+int32_t oracle_q19(const oracle_tpch *T, odec *revenue);   /* the query's own constants; 0 ok, 1 NULL, -1 error */
+int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY o_orderpriority */
+int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY revenue DESC */
+int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);  /* ORDER BY l_shipmode */
+int64_t oracle_q14_text(float promo_revenue, int is_null, char *buf, int64_t cap);
+int64_t oracle_q19_text(const odec *revenue, int is_null, char *buf, int64_t cap);
 
 /* ---- result text: Chunk.SaveToFile (pkg/chunk/chunk.go:196-220), Vector.GetValue
  * (vector.go:76-186), Value.String (value.go:26-70), headline "#\t..." of execQuery

@@ -27,7 +27,9 @@ enum SelKind {
     SK_F32_DEC,     // float32(decimal) OP float32 literal
     SK_F32,         // float32 column
     SK_F64,         // float64 column ('<' only)
-    SK_STR          // PH_STR: =, !=, LIKE, NOT LIKE on offsets+bytes
+    SK_STR,         // PH_STR: =, !=, LIKE, NOT LIKE on offsets+bytes
+    SK_CMP2_I32,    // column OP column, 4-byte integers (INTEGER, DATE): ph_filter_select_cols
+    SK_CMP2_I64     // column OP column, 8-byte integers (DECIMAL of one scale)
 };
 
 struct SelParams {
@@ -43,7 +45,21 @@ struct SelParams {
     int plen;
     int contains;  // LIKE / NOT LIKE pattern is %literal% (no _ and no inner %): substring search
     char pat[96];
+    const void *data2;          // SK_CMP2_*: the right-hand column
+    const uint8_t *validity2;
 };
+
+__device__ __forceinline__ bool icmp(int op, long long a, long long b) {
+    switch (op) {
+    case PH_EQ: return a == b;
+    case PH_NE: return a != b;
+    case PH_LT: return a < b;
+    case PH_LE: return a <= b;
+    case PH_GT: return a > b;
+    case PH_GE: return a >= b;
+    default: return false;
+    }
+}
 
 __device__ __forceinline__ bool fcmp(int op, double v, double k) {
     switch (op) {
@@ -81,6 +97,8 @@ __device__ __forceinline__ bool sel_pred(const SelParams &P, int64_t r) {
     }
     case SK_F32: return fcmp(P.op, (double)((const float *)P.data)[r], (double)P.kf);
     case SK_F64: return fcmp(P.op, ((const double *)P.data)[r], P.kd);
+    case SK_CMP2_I32: return bit_valid(P.validity2, r) && icmp(P.op, ((const int32_t *)P.data)[r], ((const int32_t *)P.data2)[r]);
+    case SK_CMP2_I64: return bit_valid(P.validity2, r) && icmp(P.op, ((const int64_t *)P.data)[r], ((const int64_t *)P.data2)[r]);
     case SK_STR: {
         const int32_t *off = (const int32_t *)P.data;
         const char *s = P.bytes + off[r];
@@ -529,6 +547,12 @@ static bool lower_select(const ph_col *col, int32_t op, const ph_const *k, SelPa
     case PH_CODE8:
         // VARCHAR '=' / '!=' on a dictionary column: the caller resolves the literal to its
         // code (PH_I32 constant; a code outside 0..255 = literal not in the dictionary)
+        // ... or to a RUN of codes (k.type = PH_CODE8, codes k.i .. k.scale): `LIKE 'prefix%'` or a sorted IN list over a
+        // dictionary in byte order is a run of codes; '=' selects the codes inside it
+        if (k->type == PH_CODE8) {
+            if (op == PH_EQ && k->i <= k->scale && k->scale >= 0 && k->i <= 255) { P->lo = k->i < 0 ? 0 : k->i; P->hi = k->scale > 255 ? 255 : k->scale; P->kind = SK_RANGE_U8; }
+            return op == PH_EQ;
+        }
         if (k->type != PH_I32) return false;
         if (op == PH_EQ) { if (k->i >= 0 && k->i <= 255) { P->lo = P->hi = k->i; P->kind = SK_RANGE_U8; } return true; }
         if (op == PH_NE) { if (k->i >= 0 && k->i <= 255) { P->lo = k->i; P->kind = SK_NE_U8; } else { P->lo = 0; P->hi = 255; P->kind = SK_RANGE_U8; } return true; }
@@ -787,6 +811,42 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
     ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, flags);
     PH_HIP(hipGetLastError());
     return ctx->download_count(n_out, total, -1, "ph_filter_select");
+}
+
+// column OP column (selectBinary with two FLAT vectors, function_operator_boolean.go:506-521): the (type, op) pairs
+// are selectOperation's — INTEGER has all six, DATE the four orderings, DECIMAL only '>'; anything else selects nothing
+extern "C" int ph_filter_select_cols(ph_ctx *ctx, const ph_col *a, const ph_col *b, int64_t n, int32_t op, const int32_t *sel_in,
+                                     int64_t n_in, int32_t *sel_out, int64_t *n_out) {
+    PH_REQUIRE(ctx && a && b && n_out && n >= 0 && n_in >= 0, "ph_filter_select_cols: bad arguments");
+    PH_REQUIRE(sel_in || n_in == n, "ph_filter_select_cols: without sel_in, n_in must equal n");
+    PH_REQUIRE(n_in == 0 || sel_out, "ph_filter_select_cols: sel_out is NULL");
+    *n_out = 0;
+    if (n_in == 0) return PH_OK;
+    ph::SelParams P;
+    memset(&P, 0, sizeof P);
+    P.kind = ph::SK_NEVER;
+    P.op = op;
+    P.data = a->data; P.validity = a->validity; P.data2 = b->data; P.validity2 = b->validity;
+    const bool ordering = op == PH_LT || op == PH_LE || op == PH_GT || op == PH_GE;
+    if (a->type == PH_I32 && b->type == PH_I32) { if (op >= PH_EQ && op <= PH_GE) P.kind = ph::SK_CMP2_I32; }
+    else if (a->type == PH_DATE && b->type == PH_DATE) { if (ordering) P.kind = ph::SK_CMP2_I32; }
+    else if (a->type == PH_DEC64 && b->type == PH_DEC64 && a->scale == b->scale) { if (op == PH_GT) P.kind = ph::SK_CMP2_I64; }
+    else if ((a->type == PH_I64 && b->type == PH_I64) || (a->type == PH_CODE8 && b->type == PH_CODE8)) { /* no BIGINT comparison exists; dictionary codes of two columns are not comparable */ }
+    else {
+        ph::set_error("ph_filter_select_cols: column types %d and %d are outside the device path", a->type, b->type);
+        return PH_EUNSUPPORTED;
+    }
+    if (P.kind == ph::SK_NEVER) return PH_OK;
+    const int64_t nb = (n_in + ph::SEL_CHUNK - 1) / ph::SEL_CHUNK;
+    PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
+    int32_t *counts = (int32_t *)ctx->scratch;
+    int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, nullptr);
+    PH_HIP(hipGetLastError());
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, nullptr);
+    PH_HIP(hipGetLastError());
+    return ctx->download_count(n_out, total, -1, "ph_filter_select_cols");
 }
 
 // ------------------------------------------------------------------ union (OR / IN lists)

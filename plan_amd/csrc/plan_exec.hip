@@ -19,6 +19,23 @@
 
 namespace {
 
+struct BoolTree {                   // a deep copy of a ph_bool array (node 0 = root); string constants owned
+    std::vector<ph_bool> nodes;
+    std::vector<std::string> strs;
+    void fix() { for (size_t i = 0; i < nodes.size(); i++) nodes[i].k.s = strs[i].empty() ? nullptr : strs[i].c_str(); }
+    bool empty() const { return nodes.empty(); }
+};
+
+BoolTree copy_bools(const ph_bool *b, int32_t n) {
+    BoolTree t;
+    for (int32_t i = 0; i < n; i++) {
+        t.nodes.push_back(b[i]);
+        t.strs.push_back(b[i].k.s ? std::string(b[i].k.s) : std::string());
+        t.nodes.back().k.s = nullptr;
+    }
+    return t;
+}
+
 struct PCol {                       // an output column of a relation
     int32_t type = 0, scale = 0;
     int lane = -1, tcol = -1;       // lane >= 0: column tcol of lanes[lane].t, addressed through lanes[lane].rows
@@ -43,11 +60,19 @@ struct Rel {
     std::vector<PCol> cols;
     // single identity lane only: what still filters the table's rows
     std::vector<ph_pred> pending;   // conjuncts over TABLE columns, not applied yet (fused into the next build / probe when possible)
+    std::vector<BoolTree> complex;  // conjuncts of any shape over TABLE columns (OR lists, column-vs-column), applied behind them
     const uint8_t *flags = nullptr; // a byte per table row, 0 = filtered out (the marks of a semi-join)
     bool covers = true;             // every table row is (still) there, up to a reduction by the probing side's own key domain
-    bool lazy() const { return !pending.empty() || flags != nullptr; }
+    bool lazy() const { return !pending.empty() || !complex.empty() || flags != nullptr; }
     bool single_identity() const { return lanes.size() == 1 && lanes[0].rows == nullptr; }
 };
+
+struct Expr {                       // ph_plan_expr + the WHEN tree it points to, owned
+    ph_plan_expr e;
+    BoolTree when;
+};
+
+struct AggDesc { int32_t kind; Expr arg; };
 
 struct Node {
     int32_t kind = 0, child[2] = {-1, -1};
@@ -55,10 +80,11 @@ struct Node {
     std::vector<int32_t> cols;
     std::vector<ph_pred> preds;
     std::vector<std::string> pred_strs;
+    BoolTree bools;
     int32_t join_type = 0;
     std::vector<int32_t> pkeys, bkeys, out;
-    std::vector<ph_plan_expr> exprs, groups;
-    std::vector<ph_plan_agg> aggs;
+    std::vector<Expr> exprs, groups;
+    std::vector<AggDesc> aggs;
 };
 
 struct Domain { ph_join *j; int64_t nkeys; };
@@ -153,6 +179,131 @@ void fix_dict_const(const ph_table *t, int tcol, ph_const *k) {
     }
 }
 
+int positional(ph_plan *p, Rel *r, const std::vector<int> &want);
+
+// the reference's LIKE (likeOp: % = any run, _ = any one byte), for patterns applied to a DICTIONARY on the host
+bool host_like(const char *s, size_t sl, const char *pat, size_t pl) {
+    size_t si = 0, pi = 0, star = (size_t)-1, mark = 0;
+    while (si < sl) {
+        if (pi < pl && (pat[pi] == '_' || pat[pi] == s[si])) { si++; pi++; }
+        else if (pi < pl && pat[pi] == '%') { star = pi++; mark = si; }
+        else if (star != (size_t)-1) { pi = star + 1; si = ++mark; }
+        else return false;
+    }
+    while (pi < pl && pat[pi] == '%') pi++;
+    return pi == pl;
+}
+
+// ---- a boolean tree over a relation -> the selection of its true rows (ExprExec.executeSelect).
+// table mode (a lazy single-lane relation): ph_bool.col is a TABLE column, selections hold row ids of the table;
+// positional mode: ph_bool.col is an output column of the relation, selections hold positions.
+// sel_in == nullptr: all N rows. The result is ascending (AND narrows, OR unites in row order).
+int eval_bool(ph_plan *p, Rel *r, bool table_mode, const BoolTree &bt, int idx, const int32_t *sel_in, int64_t n_in,
+              const int32_t **sel_out, int64_t *n_out) {
+    ph_ctx *ctx = p->ctx;
+    const int64_t N = table_mode ? r->lanes[0].t->nrows : r->n;
+    if (idx < 0 || idx >= (int)bt.nodes.size()) { set_error("ph_plan: boolean node %d out of range", idx); return PH_EINVAL; }
+    const ph_bool &b = bt.nodes[(size_t)idx];
+    if (n_in == 0) { *sel_out = sel_in; *n_out = 0; return PH_OK; }
+    auto view_of = [&](int col, ph_col *v, const ph_table **dt, int *dc) -> int {
+        if (table_mode) {
+            if (col < 0 || col >= (int)r->lanes[0].t->cols.size()) { set_error("ph_plan: predicate column %d out of range", col); return PH_EINVAL; }
+            *v = table_view(r->lanes[0].t, col); *dt = r->lanes[0].t; *dc = col;
+            return PH_OK;
+        }
+        if (col < 0 || col >= (int)r->cols.size()) { set_error("ph_plan: predicate column %d out of range", col); return PH_EINVAL; }
+        PL_CHECK(positional(p, r, {col}));
+        const int32_t *s = nullptr;
+        *v = col_view(*r, r->cols[(size_t)col], &s);
+        *dt = r->cols[(size_t)col].src; *dc = r->cols[(size_t)col].src_col;
+        return PH_OK;
+    };
+    switch (b.kind) {
+    case PH_B_CMP: {
+        ph_col v{};
+        const ph_table *dt = nullptr;
+        int dc = -1;
+        PL_CHECK(view_of(b.col, &v, &dt, &dc));
+        ph_const k = b.k;
+        void *out = nullptr;
+        PL_CHECK(palloc(p, n_in * 4, &out));
+        int64_t m = 0;
+        if (k.type == PH_COLREF) {
+            ph_col v2{};
+            const ph_table *dt2 = nullptr;
+            int dc2 = -1;
+            PL_CHECK(view_of((int)k.i, &v2, &dt2, &dc2));
+            PL_CHECK(ph_filter_select_cols(ctx, &v, &v2, N, b.op, sel_in, n_in, (int32_t *)out, &m));
+        } else if (v.type == PH_CODE8 && (b.op == PH_LIKE || b.op == PH_NOTLIKE) && k.type == PH_STR) {
+            // LIKE over a dictionary column: the pattern is matched against the dictionary on the host; the codes that
+            // match form runs (a prefix pattern over a dictionary in byte order: one run), each a range predicate
+            if (!dt || dc < 0 || !k.s) { set_error("ph_plan: LIKE over a dictionary column needs the table's dictionary"); return PH_EUNSUPPORTED; }
+            const auto &dict = dt->cols[(size_t)dc].dict;
+            std::vector<std::pair<int, int>> runs;
+            for (int c = 0; c < (int)dict.size(); c++) {
+                const bool hit = host_like(dict[(size_t)c].data(), dict[(size_t)c].size(), k.s, strlen(k.s)) == (b.op == PH_LIKE);
+                if (!hit) continue;
+                if (!runs.empty() && runs.back().second == c - 1) runs.back().second = c; else runs.push_back({c, c});
+            }
+            std::vector<const int32_t *> sels;
+            std::vector<int64_t> counts;
+            for (auto &rn : runs) {
+                ph_const kr{};
+                kr.type = PH_CODE8; kr.i = rn.first; kr.scale = rn.second;
+                void *o2 = nullptr;
+                PL_CHECK(palloc(p, n_in * 4, &o2));
+                int64_t m2 = 0;
+                PL_CHECK(ph_filter_select(ctx, &v, N, PH_EQ, &kr, sel_in, n_in, (int32_t *)o2, &m2));
+                sels.push_back((const int32_t *)o2); counts.push_back(m2);
+            }
+            if (sels.size() == 1) { out = const_cast<int32_t *>(sels[0]); m = counts[0]; }
+            else if (!sels.empty()) PL_CHECK(ph_sel_union(ctx, sels.data(), counts.data(), (int32_t)sels.size(), N, (int32_t *)out, &m));
+        } else {
+            fix_dict_const(dt, dc, &k);
+            PL_CHECK(ph_filter_select(ctx, &v, N, b.op, &k, sel_in, n_in, (int32_t *)out, &m));
+        }
+        *sel_out = (const int32_t *)out;
+        *n_out = m;
+        return PH_OK;
+    }
+    case PH_B_AND: {
+        const int32_t *cur = sel_in;
+        int64_t cnt = n_in;
+        for (int c = 0; c < b.nchildren && cnt > 0; c++) {
+            const int32_t *o = nullptr;
+            int64_t m = 0;
+            PL_CHECK(eval_bool(p, r, table_mode, bt, b.first_child + c, cur, cnt, &o, &m));
+            cur = o; cnt = m;
+        }
+        if (!cur) { void *o = nullptr; PL_CHECK(palloc(p, 8, &o)); cur = (const int32_t *)o; }   // (an AND without children keeps everything: not produced by a binder)
+        *sel_out = cur;
+        *n_out = cnt;
+        return PH_OK;
+    }
+    case PH_B_OR: {
+        std::vector<const int32_t *> sels;
+        std::vector<int64_t> counts;
+        for (int c = 0; c < b.nchildren; c++) {
+            const int32_t *o = nullptr;
+            int64_t m = 0;
+            PL_CHECK(eval_bool(p, r, table_mode, bt, b.first_child + c, sel_in, n_in, &o, &m));
+            if (m > 0) { sels.push_back(o); counts.push_back(m); }
+        }
+        void *out = nullptr;
+        PL_CHECK(palloc(p, n_in * 4, &out));
+        int64_t m = 0;
+        if (sels.size() == 1) { out = const_cast<int32_t *>(sels[0]); m = counts[0]; }
+        else if (!sels.empty()) PL_CHECK(ph_sel_union(ctx, sels.data(), counts.data(), (int32_t)sels.size(), N, (int32_t *)out, &m));
+        *sel_out = (const int32_t *)out;
+        *n_out = m;
+        return PH_OK;
+    }
+    default:
+        set_error("ph_plan: boolean node %d has unknown kind %d", idx, b.kind);
+        return PH_EINVAL;
+    }
+}
+
 // ---- apply what still filters a lazy single-lane relation: conjunct by conjunct (execSelectAnd), then the marks
 int apply_pending(ph_plan *p, Rel *r) {
     if (!r->lazy()) return PH_OK;
@@ -172,6 +323,15 @@ int apply_pending(ph_plan *p, Rel *r) {
         sel = (const int32_t *)out;
         cnt = m;
     }
+    for (size_t i = 0; i < r->complex.size() && cnt > 0; i++) {
+        const int32_t *o = nullptr;
+        int64_t m = 0;
+        if (sel == nullptr) {   // eval_bool's "all rows" is sel_in == nullptr with n_in == N
+            PL_CHECK(eval_bool(p, r, true, r->complex[i], 0, nullptr, N, &o, &m));
+        } else PL_CHECK(eval_bool(p, r, true, r->complex[i], 0, sel, cnt, &o, &m));
+        sel = o;
+        cnt = m;
+    }
     if (r->flags && cnt > 0) {
         ph_col f{};
         f.type = PH_CODE8; f.data = r->flags;
@@ -185,10 +345,11 @@ int apply_pending(ph_plan *p, Rel *r) {
         cnt = m;
     }
     if (!sel) { void *out = nullptr; PL_CHECK(palloc(p, 8, &out)); sel = (const int32_t *)out; }
-    note(p, "  select %lld of %lld rows (%zu conjuncts%s)", (long long)cnt, (long long)N, r->pending.size(), r->flags ? " + marks" : "");
+    note(p, "  select %lld of %lld rows (%zu conjuncts%s)", (long long)cnt, (long long)N, r->pending.size() + r->complex.size(), r->flags ? " + marks" : "");
     r->lanes[0].rows = sel;
     r->n = cnt;
     r->pending.clear();
+    r->complex.clear();
     r->flags = nullptr;
     return PH_OK;
 }
@@ -333,8 +494,77 @@ int eval_rpn(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, PCol *out) {
     return PH_OK;
 }
 
-int eval_expr(ph_plan *p, Rel *r, const ph_plan_expr &e, PCol *out) {
+// expression program over the rows sel[0..m) (positions) of a relation -> m positional decimal values
+int eval_rpn_at(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, const int32_t *sel, int64_t m, void **out, int32_t *scale) {
+    std::vector<int> operands;
+    for (int i = 0; i < nprog; i++)
+        if (prog[i].op == PH_X_COL && std::find(operands.begin(), operands.end(), prog[i].col) == operands.end()) operands.push_back(prog[i].col);
+    for (int c : operands) if (c < 0 || c >= (int)r->cols.size()) { set_error("ph_plan: expression column %d out of range", c); return PH_EINVAL; }
+    if (!operands.empty()) PL_CHECK(positional(p, r, operands));
+    std::vector<ph_col> views;
+    for (int c : operands) {
+        const int32_t *s = nullptr;
+        views.push_back(col_view(*r, r->cols[(size_t)c], &s));
+        if (views.back().validity) { set_error("ph_plan: NULL-able operand in a CASE branch"); return PH_EUNSUPPORTED; }
+    }
+    std::vector<ph_rpn> pr(prog, prog + nprog);
+    for (auto &o : pr) if (o.op == PH_X_COL) o.col = (int32_t)(std::find(operands.begin(), operands.end(), o.col) - operands.begin());
+    PL_CHECK(ph_expr_scale(views.data(), pr.data(), nprog, scale));
+    PL_CHECK(palloc(p, std::max<int64_t>(m, 1) * 8, out));
+    ph_col dummy{};
+    dummy.type = PH_I32;
+    if (m > 0) PL_CHECK(ph_expr_eval(p->ctx, views.empty() ? &dummy : views.data(), (int32_t)views.size(), pr.data(), nprog, sel, m, (int64_t *)*out, nullptr));
+    return PH_OK;
+}
+
+bool is_int_const(const ph_rpn *prog, int n) { return n == 1 && prog[0].op == PH_X_CONST && prog[0].scale == 0; }
+
+int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
+    const ph_plan_expr &e = ex.e;
     switch (e.kind) {
+    case PH_PE_CASE: {
+        // executeCase (expr_exec.go:144-246): the WHEN is a select over the rows, THEN is evaluated on its true rows and
+        // filled in at those rows (FillSwitch), ELSE on the remaining rows
+        PL_CHECK(apply_pending(p, r));
+        const int64_t n = r->n;
+        const int32_t *st = nullptr;
+        int64_t nt = 0;
+        if (n > 0) PL_CHECK(eval_bool(p, r, false, ex.when, 0, nullptr, n, &st, &nt));
+        int32_t ts = 0, es = 0;
+        void *tv = nullptr, *outv = nullptr;
+        PL_CHECK(eval_rpn_at(p, r, e.prog, e.nprog, st, nt, &tv, &ts));
+        PL_CHECK(palloc(p, std::max<int64_t>(n, 1) * 8, &outv));
+        if (is_int_const(e.else_prog, e.nelse)) {
+            // `ELSE <integer literal>`: cast to the THEN branch's type — the unscaled value at the result scale
+            long long v = e.else_prog[0].ival;
+            for (int i = 0; i < ts; i++) if (__builtin_mul_overflow(v, 10ll, &v)) { set_error("ph_plan: CASE ELSE constant overflows"); return PH_EOVERFLOW; }
+            if (v == 0) PL_CHECK(ph_dev_memset(p->ctx, outv, 0, std::max<int64_t>(n, 1) * 8));
+            else {
+                ph_rpn k{PH_X_CONST, -1, v, ts};
+                void *cv = nullptr;
+                int32_t cs = 0;
+                PL_CHECK(eval_rpn_at(p, r, &k, 1, nullptr, n, &cv, &cs));
+                outv = cv;
+            }
+        } else {
+            void *sf = nullptr, *ev = nullptr;
+            int64_t nf = 0;
+            PL_CHECK(palloc(p, std::max<int64_t>(n, 1) * 4, &sf));
+            if (n > 0) PL_CHECK(ph_sel_difference(p->ctx, nullptr, n, st, nt, n, (int32_t *)sf, &nf));
+            PL_CHECK(eval_rpn_at(p, r, e.else_prog, e.nelse, (const int32_t *)sf, nf, &ev, &es));
+            if (es != ts) { set_error("ph_plan: CASE branches of different scales (%d / %d)", ts, es); return PH_EUNSUPPORTED; }
+            ph_col vals{};
+            vals.type = PH_DEC64; vals.scale = es; vals.data = ev;
+            if (nf > 0) PL_CHECK(ph_scatter(p->ctx, &vals, (const int32_t *)sf, nf, outv, nullptr));
+        }
+        ph_col tvals{};
+        tvals.type = PH_DEC64; tvals.scale = ts; tvals.data = tv;
+        if (nt > 0) PL_CHECK(ph_scatter(p->ctx, &tvals, st, nt, outv, nullptr));
+        *out = PCol{};
+        out->type = PH_DEC64; out->scale = ts; out->data = outv;
+        if (e.result_int) out->scale = 0;   // INTEGER result carried as a scale-0 decimal column (the sums are the same numbers)
+        return PH_OK;
+    }
     case PH_PE_COL:
         if (e.col < 0 || e.col >= (int)r->cols.size()) { set_error("ph_plan: column %d out of range", e.col); return PH_EINVAL; }
         *out = r->cols[(size_t)e.col];
@@ -362,7 +592,9 @@ int eval_expr(ph_plan *p, Rel *r, const ph_plan_expr &e, PCol *out) {
 }
 
 // ---- is the (multi-column) key of this relation unique? only base-table keys the statistics or the catalog vouch for
-bool key_unique(const Rel &r, const std::vector<int32_t> &keys) {
+// 0 = no; 2 = the key IS a unique column set (a foreign key into it finds exactly one row); 1 = it CONTAINS one (still at
+// most one match, but the extra columns act as a filter: misses are expected)
+int key_unique(const Rel &r, const std::vector<int32_t> &keys) {
     int lane = -1;
     std::vector<int32_t> tcols;
     const ph_table *t = nullptr;
@@ -370,22 +602,23 @@ bool key_unique(const Rel &r, const std::vector<int32_t> &keys) {
         const PCol &c = r.cols[(size_t)k];
         if (c.lane < 0) {
             // a positional copy of a table column keeps the table's uniqueness only in a relation of that one table
-            if (!c.src || r.lanes.size() != 1 || r.lanes[0].t != c.src || !r.lanes[0].dup_free) return false;
-            if (lane >= 0 && lane != 0) return false;
+            if (!c.src || r.lanes.size() != 1 || r.lanes[0].t != c.src || !r.lanes[0].dup_free) return 0;
+            if (lane >= 0 && lane != 0) return 0;
             lane = 0; t = c.src; tcols.push_back(c.src_col);
             continue;
         }
-        if (lane >= 0 && c.lane != lane) return false;
-        lane = c.lane;
-        t = r.lanes[(size_t)lane].t;
+        if (lane >= 0 && c.lane != lane) continue;   // a key column of another table: an extra filter, at best
+        if (lane < 0) { lane = c.lane; t = r.lanes[(size_t)lane].t; }
         tcols.push_back(c.tcol);
     }
-    if (lane < 0 || !r.lanes[(size_t)lane].dup_free) return false;
+    if (lane < 0 || !r.lanes[(size_t)lane].dup_free) return 0;
     std::sort(tcols.begin(), tcols.end());
-    if (tcols.size() == 1 && t->cols[(size_t)tcols[0]].strict) return true;
+    tcols.erase(std::unique(tcols.begin(), tcols.end()), tcols.end());
+    int best = 0;
+    for (int32_t c : tcols) if (t->cols[(size_t)c].strict) best = std::max(best, tcols.size() == 1 && keys.size() == 1 ? 2 : 1);
     for (auto &u : t->unique_keys)
-        if (std::includes(tcols.begin(), tcols.end(), u.begin(), u.end())) return true;
-    return false;
+        if (std::includes(tcols.begin(), tcols.end(), u.begin(), u.end())) best = std::max(best, u.size() == tcols.size() && keys.size() == tcols.size() ? 2 : 1);
+    return best;
 }
 
 int lower(ph_plan *p, int idx, bool as_build, Rel *out);
@@ -470,7 +703,8 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
     }
     if (nd.join_type != PH_JT_INNER && need_build_cols) { set_error("ph_plan: a SEMI / ANTI join emits probe columns only"); return PH_EINVAL; }
     const bool optimistic = !p->conservative;
-    const bool unique = key_unique(B, nd.bkeys);
+    const int uniq = key_unique(B, nd.bkeys);
+    const bool unique = uniq > 0;
     const bool exists_only = nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI || (nd.join_type == PH_JT_INNER && !need_build_cols && unique);
     std::string how;
 
@@ -495,7 +729,7 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
 
     // ---- merge lookup: both sides ordered by the key, no table at all
     const bool n_to_1 = nd.join_type == PH_JT_INNER && unique && !exists_only;
-    if (n_to_1 && optimistic && nk == 1 && B.covers && B.single_identity() && !B.lazy() && !getenv("PH_PLAN_NO_MERGE")) {
+    if (n_to_1 && uniq == 2 && optimistic && nk == 1 && B.covers && B.single_identity() && !B.lazy() && !getenv("PH_PLAN_NO_MERGE")) {
         const PCol &bc = B.cols[(size_t)nd.bkeys[0]];
         const PCol &pc = P.cols[(size_t)nd.pkeys[0]];
         if (bc.lane == 0 && B.lanes[0].t->cols[(size_t)bc.tcol].strict && pc.ordered) {
@@ -541,9 +775,9 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
             const bool su = optimistic && nk == 1 && kc.strict && B.single_identity();
             // every probe row is expected to find its row (a foreign key into a table nothing but the probe side's own
             // key domain has reduced): no Bloom bitmap, node table for composite keys
-            if (B.covers && unique && nk >= 1 && !(flags & PH_JOIN_KEY_RANGE)) flags |= PH_JOIN_FK_PROBES;
+            if (B.covers && uniq == 2 && !(flags & PH_JOIN_KEY_RANGE)) flags |= PH_JOIN_FK_PROBES;
             int rc = PH_EUNSUPPORTED;
-            if (B.single_identity() && (flags & PH_JOIN_KEY_RANGE) && B.pending.size() + (B.flags ? 1 : 0) == 1) {
+            if (B.single_identity() && (flags & PH_JOIN_KEY_RANGE) && B.complex.empty() && B.pending.size() + (B.flags ? 1 : 0) == 1) {
                 // Filter (or a semi-join's marks) under the build child rides along in the build
                 ph_pred w{};
                 ph_col wv{};
@@ -614,7 +848,7 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
     };
 
     // (1) existence only and the result feeds another build: marks, no pair list, no count
-    if (exists_only && nd.join_type != PH_JT_ANTI && as_build && P.single_identity() && P.pending.size() <= 1 && !P.flags) {
+    if (exists_only && nd.join_type != PH_JT_ANTI && as_build && P.single_identity() && P.pending.size() <= 1 && P.complex.empty() && !P.flags) {
         bool lane_keys = true;
         for (int32_t k : nd.pkeys) lane_keys = lane_keys && P.cols[(size_t)k].lane == 0;
         if (lane_keys) {
@@ -646,8 +880,10 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
         }
     }
 
-    // (2) ANTI: marks, then the rows without one
-    if (nd.join_type == PH_JT_ANTI) {
+    // (2) ANTI: marks, then the rows without one; SEMI against a build key with duplicates: marks, then the rows with one
+    // (a pair list would repeat the probe row once per duplicate)
+    if (nd.join_type == PH_JT_ANTI || (exists_only && !unique)) {
+        const bool anti = nd.join_type == PH_JT_ANTI;
         PL_CHECK(apply_pending(p, &P));
         KeySide pk;
         PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
@@ -659,20 +895,21 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
             PL_CHECK(ph_join_probe_mark(j, pk.views.data(), pk.sel, P.n, (uint8_t *)f));
             ph_col fc{};
             fc.type = PH_CODE8; fc.data = f;
-            ph_const zero{};
-            zero.type = PH_I32; zero.i = 0;
-            PL_CHECK(ph_filter_select(ctx, &fc, P.n, PH_EQ, &zero, nullptr, P.n, (int32_t *)sel, &m));
+            ph_const want{};
+            want.type = PH_I32; want.i = anti ? 0 : 1;
+            PL_CHECK(ph_filter_select(ctx, &fc, P.n, PH_EQ, &want, nullptr, P.n, (int32_t *)sel, &m));
         }
         *out = P;
         PL_CHECK(compact(p, out, (const int32_t *)sel, m));
         std::vector<PCol> all = out->cols;
+        if (!anti) tag_domain(all);
         finish(out, all);
-        note(p, "join#%d:%s probe: anti (marks + selection), %lld of %lld rows", idx, how.c_str(), (long long)m, (long long)P.n);
+        note(p, "join#%d:%s probe: %s (marks + selection), %lld of %lld rows", idx, how.c_str(), anti ? "anti" : "semi", (long long)m, (long long)P.n);
         return PH_OK;
     }
 
     // (3) N:1 where every probe row is expected to find its row: a lookup, the intermediate keeps its rows
-    if (n_to_1 && B.covers) {
+    if (n_to_1 && B.covers && uniq == 2) {
         PL_CHECK(apply_pending(p, &P));
         KeySide pk;
         PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
@@ -737,7 +974,7 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
         bool lane_keys = P.lanes.size() == 1;
         for (int32_t k : nd.pkeys) lane_keys = lane_keys && P.cols[(size_t)k].lane == 0;
         for (auto &c : P.cols) lane_keys = lane_keys && c.lane == 0;
-        if (lane_keys && P.single_identity() && P.pending.size() == 1 && !P.flags) {   // Filter -> probe in one pass
+        if (lane_keys && P.single_identity() && P.pending.size() == 1 && P.complex.empty() && !P.flags) {   // Filter -> probe in one pass
             const ph_table *t = P.lanes[0].t;
             for (int32_t k : nd.pkeys) pk.views.push_back(table_view(t, P.cols[(size_t)k].tcol));
             pk.sel = nullptr; pk.n = t->nrows; pk.rowids = true;
@@ -807,8 +1044,9 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
             pr.k.s = nd.pred_strs[i].empty() ? nullptr : nd.pred_strs[i].c_str();
             out->pending.push_back(pr);
         }
-        out->covers = nd.preds.empty();
-        note(p, "scan#%d: %lld rows, %zu pushed conjuncts", idx, (long long)t->nrows, nd.preds.size());
+        if (!nd.bools.empty()) { out->complex.push_back(nd.bools); out->complex.back().fix(); }
+        out->covers = nd.preds.empty() && nd.bools.empty();
+        note(p, "scan#%d: %lld rows, %zu pushed conjuncts", idx, (long long)t->nrows, nd.preds.size() + (nd.bools.empty() ? 0 : 1));
         return PH_OK;
     }
     case PH_PN_FILTER: {
@@ -820,6 +1058,9 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
             if (pr.col < 0 || pr.col >= (int32_t)out->cols.size()) { set_error("ph_plan: filter column %d out of range", pr.col); return PH_EINVAL; }
             pushed = pushed && out->single_identity() && !out->flags && out->cols[(size_t)pr.col].lane == 0;
         }
+        for (auto &b : nd.bools.nodes)
+            if (b.kind == PH_B_CMP) pushed = pushed && out->single_identity() && !out->flags && b.col >= 0 && b.col < (int)out->cols.size() && out->cols[(size_t)b.col].lane == 0 &&
+                                             (b.k.type != PH_COLREF || (b.k.i >= 0 && b.k.i < (int64_t)out->cols.size() && out->cols[(size_t)b.k.i].lane == 0));
         if (pushed) {
             for (size_t i = 0; i < nd.preds.size(); i++) {
                 ph_pred pr = nd.preds[i];
@@ -827,7 +1068,13 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
                 pr.k.s = nd.pred_strs[i].empty() ? nullptr : nd.pred_strs[i].c_str();
                 out->pending.push_back(pr);
             }
-            out->covers = out->covers && nd.preds.empty();
+            if (!nd.bools.empty()) {   // the tree's columns become table columns
+                BoolTree bt = nd.bools;
+                for (auto &b : bt.nodes) if (b.kind == PH_B_CMP) { b.col = out->cols[(size_t)b.col].tcol; if (b.k.type == PH_COLREF) b.k.i = out->cols[(size_t)b.k.i].tcol; }
+                out->complex.push_back(bt);
+                out->complex.back().fix();
+            }
+            out->covers = false;
             return PH_OK;
         }
         PL_CHECK(apply_pending(p, out));
@@ -846,6 +1093,15 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
             int64_t m = 0;
             PL_CHECK(ph_filter_select(p->ctx, &v, out->n, pr.op, &pr.k, sel, cnt, (int32_t *)o, &m));
             sel = (const int32_t *)o;
+            cnt = m;
+        }
+        if (!nd.bools.empty() && cnt > 0) {
+            BoolTree bt = nd.bools;
+            bt.fix();
+            const int32_t *o = nullptr;
+            int64_t m = 0;
+            PL_CHECK(eval_bool(p, out, false, bt, 0, sel, sel ? cnt : out->n, &o, &m));
+            sel = o;
             cnt = m;
         }
         if (sel) PL_CHECK(compact(p, out, sel, cnt));
@@ -890,11 +1146,12 @@ int lower_agg(ph_plan *p) {
     if (ch.kind == PH_PN_SCAN && R.single_identity() && !R.flags) {
         bool ok = true;
         std::vector<int32_t> gcols;
-        for (auto &g : nd.groups) { ok = ok && g.kind == PH_PE_COL; if (ok) gcols.push_back(R.cols[(size_t)g.col].tcol); }
+        ok = ok && R.complex.empty();
+        for (auto &g : nd.groups) { ok = ok && g.e.kind == PH_PE_COL; if (ok) gcols.push_back(R.cols[(size_t)g.e.col].tcol); }
         std::vector<ph_aggexpr> ax(nd.aggs.size());
         for (size_t a = 0; a < nd.aggs.size() && ok; a++) {
             ax[a].kind = nd.aggs[a].kind;
-            const ph_plan_expr &e = nd.aggs[a].arg;
+            const ph_plan_expr &e = nd.aggs[a].arg.e;
             if (nd.aggs[a].kind == PH_A_COUNT_STAR) { ax[a].nprog = 0; continue; }
             if (e.kind == PH_PE_COL) { ax[a].nprog = 1; ax[a].prog[0] = ph_rpn{PH_X_COL, R.cols[(size_t)e.col].tcol, 0, 0}; }
             else if (e.kind == PH_PE_DECIMAL) {
@@ -908,10 +1165,10 @@ int lower_agg(ph_plan *p) {
             int rc = ph_scan_plan_create(ctx, ch.table, preds.data(), (int32_t)preds.size(), gcols.data(), (int32_t)gcols.size(), ax.data(), (int32_t)ax.size(), &p->scan);
             if (rc == PH_OK) {
                 PL_CHECK(ph_scan_plan_run(p->scan, 0, ch.table->nrows));
-                for (auto &g : nd.groups) { const PCol &c = R.cols[(size_t)g.col]; p->keys.push_back(KeyInfo{c.type, c.scale, c.src, c.src_col}); }
+                for (auto &g : nd.groups) { const PCol &c = R.cols[(size_t)g.e.col]; p->keys.push_back(KeyInfo{c.type, c.scale, c.src, c.src_col}); }
                 for (size_t a = 0; a < nd.aggs.size(); a++) {
                     int32_t t = PH_I32;
-                    const ph_plan_expr &e = nd.aggs[a].arg;
+                    const ph_plan_expr &e = nd.aggs[a].arg.e;
                     if (nd.aggs[a].kind != PH_A_COUNT_STAR) t = e.kind == PH_PE_COL ? R.cols[(size_t)e.col].type : PH_DEC64;
                     p->agg_arg_type.push_back(t);
                 }
@@ -957,7 +1214,7 @@ int lower_agg(ph_plan *p) {
         const int32_t *s = nullptr;
         args[a] = col_view(S, c, &s);
         p->agg_scale.push_back(c.scale);
-        p->agg_arg_type.push_back(c.type);
+        p->agg_arg_type.push_back(nd.aggs[a].arg.e.kind == PH_PE_CASE && nd.aggs[a].arg.e.result_int ? PH_I32 : c.type);
     }
     if (keys.empty()) {   // one global group: a constant key (executor_aggr.go:37-48)
         void *zero = nullptr;
@@ -1081,15 +1338,16 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
             break;
         case PH_PN_PROJECT:
             if (s.child[0] < 0 || s.nexprs < 1 || !s.exprs) { set_error("ph_plan_create: node %d: bad project", i); return fail(PH_EINVAL); }
-            n.exprs.assign(s.exprs, s.exprs + s.nexprs);
+            for (int32_t k = 0; k < s.nexprs; k++) n.exprs.push_back(Expr{s.exprs[k], copy_bools(s.exprs[k].when, s.exprs[k].kind == PH_PE_CASE ? s.exprs[k].nwhen : 0)});
             break;
         case PH_PN_AGG:
             if (i != nnodes - 1 || s.child[0] < 0 || s.naggs < 1 || !s.aggs || s.ngroups < 0 || s.ngroups > 4 || (s.ngroups && !s.groups) || s.naggs > 16) {
                 set_error("ph_plan_create: node %d: bad aggregate (root only, <= 4 group expressions, 1..16 aggregates)", i);
                 return fail(PH_EINVAL);
             }
-            n.groups.assign(s.groups, s.groups + s.ngroups);
-            n.aggs.assign(s.aggs, s.aggs + s.naggs);
+            for (int32_t k = 0; k < s.ngroups; k++) n.groups.push_back(Expr{s.groups[k], copy_bools(s.groups[k].when, s.groups[k].kind == PH_PE_CASE ? s.groups[k].nwhen : 0)});
+            for (int32_t k = 0; k < s.naggs; k++)
+                n.aggs.push_back(AggDesc{s.aggs[k].kind, Expr{s.aggs[k].arg, copy_bools(s.aggs[k].arg.when, s.aggs[k].kind != PH_A_COUNT_STAR && s.aggs[k].arg.kind == PH_PE_CASE ? s.aggs[k].arg.nwhen : 0)}});
             break;
         default:
             set_error("ph_plan_create: node %d: unknown kind %d", i, s.kind);
@@ -1103,7 +1361,28 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
                 n.preds.back().k.s = nullptr;
             }
         }
-        for (auto &e : n.exprs) if (e.nprog < 0 || e.nprog > 12) { set_error("ph_plan_create: node %d: expression program too long", i); return fail(PH_EINVAL); }
+        if (s.kind == PH_PN_SCAN || s.kind == PH_PN_FILTER) {
+            if (s.nbools < 0 || (s.nbools && !s.bools)) { set_error("ph_plan_create: node %d: bad boolean tree", i); return fail(PH_EINVAL); }
+            n.bools = copy_bools(s.bools, s.nbools);
+            for (auto &b : n.bools.nodes)
+                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= 0 || b.nchildren < 1 || b.first_child + b.nchildren > s.nbools)) {
+                    set_error("ph_plan_create: node %d: boolean tree children out of range", i);
+                    return fail(PH_EINVAL);
+                }
+        }
+        auto check_expr = [&](Expr &x) {
+            x.when.fix();
+            x.e.when = nullptr;
+            if (x.e.nprog < 0 || x.e.nprog > 12 || (x.e.kind == PH_PE_CASE && (x.e.nelse < 1 || x.e.nelse > 12 || x.when.empty()))) return false;
+            for (auto &b : x.when.nodes)
+                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= 0 || b.nchildren < 1 || b.first_child + b.nchildren > (int)x.when.nodes.size())) return false;
+            return true;
+        };
+        bool okx = true;
+        for (auto &e : n.exprs) okx = okx && check_expr(e);
+        for (auto &e : n.groups) okx = okx && check_expr(e);
+        for (auto &a : n.aggs) if (a.kind != PH_A_COUNT_STAR) okx = okx && check_expr(a.arg);
+        if (!okx) { set_error("ph_plan_create: node %d: malformed expression (program length, CASE without WHEN / ELSE, boolean tree children)", i); return fail(PH_EINVAL); }
         p->nodes.push_back(std::move(n));
     }
     *out = p;

@@ -758,8 +758,52 @@ PH_PE_COL, PH_PE_DECIMAL, PH_PE_YEAR = 1, 2, 3
 PH_STAT_ASCENDING, PH_STAT_STRICT, PH_STAT_DECLARED_UNIQUE = 1, 2, 4
 
 
+PH_PE_CASE = 4
+PH_B_CMP, PH_B_AND, PH_B_OR = 1, 2, 3
+PH_COLREF = 9
+
+
+class Bool(ctypes.Structure):
+    _fields_ = [("kind", i32), ("col", i32), ("op", i32), ("k", Const), ("first_child", i32), ("nchildren", i32)]
+
+
 class PlanExpr(ctypes.Structure):
-    _fields_ = [("kind", i32), ("col", i32), ("nprog", i32), ("prog", Rpn * 12)]
+    _fields_ = [("kind", i32), ("col", i32), ("nprog", i32), ("prog", Rpn * 12), ("nwhen", i32), ("when", ctypes.POINTER(Bool)),
+                ("nelse", i32), ("else_prog", Rpn * 12), ("result_int", i32)]
+
+
+def bool_tree(expr):
+    """Nested tuples -> a flat ph_bool array (node 0 = root, children of a node contiguous):
+         ("cmp", col, op, Const) | ("colcmp", col, op, other_col) | ("and", child, ...) | ("or", child, ...)
+         ("in", col, [Const, ...])  =  OR of '=' comparisons, as the reference binds IN lists"""
+    nodes = []
+
+    def norm(e):
+        if e[0] == "in":
+            return ("or",) + tuple(("cmp", e[1], PH_EQ, k) for k in e[2])
+        return e
+
+    def emit(e, at):
+        e = norm(e)
+        b = Bool()
+        if e[0] == "cmp":
+            b.kind, b.col, b.op, b.k = PH_B_CMP, e[1], e[2], e[3]
+        elif e[0] == "colcmp":
+            b.kind, b.col, b.op = PH_B_CMP, e[1], e[2]
+            b.k = const(PH_COLREF, i=e[3])
+        else:
+            kids = e[1:]
+            b.kind = PH_B_AND if e[0] == "and" else PH_B_OR
+            b.first_child, b.nchildren = len(nodes), len(kids)
+            base = len(nodes)
+            nodes.extend([None] * len(kids))
+            for j, kid in enumerate(kids):
+                emit(kid, base + j)
+        nodes[at] = b
+
+    nodes.append(None)
+    emit(expr, 0)
+    return (Bool * len(nodes))(*nodes)
 
 
 class PlanAgg(ctypes.Structure):
@@ -768,7 +812,8 @@ class PlanAgg(ctypes.Structure):
 
 class PlanNode(ctypes.Structure):
     _fields_ = [("kind", i32), ("child", i32 * 2), ("table", vp), ("ncols", i32), ("cols", ctypes.POINTER(i32)),
-                ("npreds", i32), ("preds", ctypes.POINTER(Pred)), ("join_type", i32), ("nkeys", i32),
+                ("npreds", i32), ("preds", ctypes.POINTER(Pred)), ("nbools", i32), ("bools", ctypes.POINTER(Bool)),
+                ("join_type", i32), ("nkeys", i32),
                 ("probe_keys", ctypes.POINTER(i32)), ("build_keys", ctypes.POINTER(i32)), ("nout", i32), ("out", ctypes.POINTER(i32)),
                 ("nexprs", i32), ("exprs", ctypes.POINTER(PlanExpr)), ("ngroups", i32), ("groups", ctypes.POINTER(PlanExpr)),
                 ("naggs", i32), ("aggs", ctypes.POINTER(PlanAgg))]
@@ -794,6 +839,21 @@ def pe_dec(prog):
     return e
 
 
+def pe_case(when, then_prog, else_prog, result_int=False, keep=None):
+    """CASE WHEN <when: bool_tree()> THEN <then_prog> ELSE <else_prog> END; keep: a list the WHEN array is appended to
+    (it must outlive Plan.create)"""
+    e = PlanExpr()
+    e.kind, e.col, e.nprog, e.nelse, e.result_int = PH_PE_CASE, -1, len(then_prog), len(else_prog), 1 if result_int else 0
+    for j, x in enumerate(then_prog):
+        e.prog[j] = Rpn(*x)
+    for j, x in enumerate(else_prog):
+        e.else_prog[j] = Rpn(*x)
+    e.nwhen, e.when = len(when), when
+    if keep is not None:
+        keep.append(when)
+    return e
+
+
 def _i32arr(v):
     return (i32 * max(len(v), 1))(*v)
 
@@ -809,22 +869,27 @@ class Plan:
         self.nodes.append(n)
         return len(self.nodes) - 1
 
-    def scan(self, table, cols, preds=()):
+    def scan(self, table, cols, preds=(), bools=None):
+        """preds: simple conjuncts over TABLE columns; bools: one more conjunct of any shape (bool_tree())"""
         n = PlanNode()
         n.kind, n.child[0], n.child[1] = PH_PN_SCAN, -1, -1
         n.table = table.h
         ca, pa = _i32arr(cols), (Pred * max(len(preds), 1))(*preds)
-        self._keep += [ca, pa, table]
+        self._keep += [ca, pa, table, bools]
         n.ncols, n.cols = len(cols), ca
         n.npreds, n.preds = len(preds), pa
+        if bools is not None:
+            n.nbools, n.bools = len(bools), bools
         return self._add(n)
 
-    def filter(self, child, preds):
+    def filter(self, child, preds=(), bools=None):
         n = PlanNode()
         n.kind, n.child[0], n.child[1] = PH_PN_FILTER, child, -1
         pa = (Pred * max(len(preds), 1))(*preds)
-        self._keep.append(pa)
+        self._keep += [pa, bools]
         n.npreds, n.preds = len(preds), pa
+        if bools is not None:
+            n.nbools, n.bools = len(bools), bools
         return self._add(n)
 
     def join(self, probe, build, probe_keys, build_keys, out, join_type=PH_JT_INNER):

@@ -460,3 +460,131 @@ def cross_pairs(n_left, n_right, chunk=2048):
     orr = np.empty(max(n_left * n_right, 1), np.int64)
     lib().oracle_cross_pairs(i64(n_left), i64(n_right), i64(chunk), ptr(ol), ptr(orr))
     return ol[:n_left * n_right], orr[:n_left * n_right]
+
+
+# ---------------------------------------------------------------- round 3: Q4, Q5, Q12, Q14, Q19
+
+_VP, _DP = ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p)
+
+
+class Tpch(ctypes.Structure):
+    _fields_ = ([("n_lineitem", i64)] + [(c, _VP) for c in ("l_orderkey", "l_extendedprice", "l_discount", "l_partkey", "l_suppkey", "l_quantity",
+                                                           "l_shipdate", "l_commitdate", "l_receiptdate", "l_shipmode", "l_shipinstruct")] +
+                [("n_orders", i64)] + [(c, _VP) for c in ("o_orderkey", "o_custkey", "o_orderdate", "o_orderpriority")] +
+                [("n_customer", i64), ("c_custkey", _VP), ("c_nationkey", _VP), ("n_supplier", i64), ("s_suppkey", _VP), ("s_nationkey", _VP),
+                 ("n_part", i64), ("p_partkey", _VP), ("p_size", _VP), ("p_brand", _VP), ("p_type", _VP), ("p_container", _VP),
+                 ("n_nationkey", _VP), ("n_regionkey", _VP), ("r_regionkey", _VP), ("n_name", _VP), ("r_name", _VP)] +
+                [(c, _DP) for c in ("shipmode_dict", "shipinstruct_dict", "orderpriority_dict", "brand_dict", "type_dict", "container_dict",
+                                    "nation_dict", "region_dict")])
+
+
+class Q4Row(ctypes.Structure):
+    _fields_ = [("code", i32), ("count", OHuge)]
+
+
+class Q5Row(ctypes.Structure):
+    _fields_ = [("nation", i32), ("revenue", ODec)]
+
+
+class Q12Row(ctypes.Structure):
+    _fields_ = [("mode", i32), ("high", OHuge), ("low", OHuge)]
+
+
+def tpch_struct(t):
+    """oracle_tpch over the numpy tables of tpch_data.load (+ the fixed nation / region tables); returns (struct, keepalive)"""
+    from plan_amd import tpchgen
+    T, keep = Tpch(), []
+
+    def put(name, arr):
+        arr = np.ascontiguousarray(arr)
+        keep.append(arr)
+        setattr(T, name, arr.ctypes.data)
+
+    L, Od, C = t["lineitem"], t["orders"], t["customer"]
+    T.n_lineitem, T.n_orders, T.n_customer = len(L["l_orderkey"]), len(Od["o_orderkey"]), len(C["c_custkey"])
+    for c in ("l_orderkey", "l_extendedprice", "l_discount", "l_partkey", "l_suppkey", "l_quantity", "l_shipdate", "l_commitdate",
+              "l_receiptdate", "l_shipmode", "l_shipinstruct"):
+        put(c, L[c])
+    for c in ("o_orderkey", "o_custkey", "o_orderdate", "o_orderpriority"):
+        put(c, Od[c])
+    put("c_custkey", C["c_custkey"]); put("c_nationkey", C["c_nationkey"])
+    if "supplier" in t:
+        T.n_supplier = len(t["supplier"]["s_suppkey"])
+        put("s_suppkey", t["supplier"]["s_suppkey"]); put("s_nationkey", t["supplier"]["s_nationkey"])
+    if "part" in t:
+        P = t["part"]
+        T.n_part = len(P["p_partkey"])
+        for c in ("p_partkey", "p_size", "p_brand", "p_type", "p_container"):
+            put(c, P[c])
+    put("n_nationkey", np.arange(25, dtype=np.int32)); put("n_regionkey", np.array(tpchgen.nation_regions(), dtype=np.int32))
+    put("r_regionkey", np.arange(5, dtype=np.int32)); put("n_name", np.arange(25, dtype=np.uint8)); put("r_name", np.arange(5, dtype=np.uint8))
+    for field, strings in (("shipmode_dict", tpchgen.SHIPMODE_DICT), ("shipinstruct_dict", tpchgen.SHIPINSTRUCT_DICT),
+                           ("orderpriority_dict", tpchgen.ORDERPRIORITY_DICT), ("brand_dict", tpchgen.part_brand_dict()),
+                           ("type_dict", tpchgen.part_type_dict()), ("container_dict", tpchgen.part_container_dict()),
+                           ("nation_dict", tpchgen.nation_names()), ("region_dict", tpchgen.region_names())):
+        d = cdict(strings)
+        keep.append(d)
+        setattr(T, field, ctypes.cast(d, ctypes.POINTER(ctypes.c_char_p)))
+    return T, keep
+
+
+def _text(fn, *args, cap=1 << 16):
+    buf = ctypes.create_string_buffer(cap)
+    getattr(lib(), fn)(*args, buf, i64(cap))
+    return buf.value.decode()
+
+
+def q4_text(t, date_ge, date_lt):
+    from plan_amd import tpchgen
+    T, keep = tpch_struct(t)
+    rows = (Q4Row * 16)()
+    n = lib().oracle_q4(ctypes.byref(T), i32(date_ge), i32(date_lt), rows, i64(16))
+    assert n >= 0
+    return _text("oracle_q4_text", rows, i64(n), cdict(tpchgen.ORDERPRIORITY_DICT))
+
+
+def q5_text(t, region, date_ge, date_lt):
+    from plan_amd import tpchgen
+    T, keep = tpch_struct(t)
+    rows = (Q5Row * 32)()
+    n = lib().oracle_q5(ctypes.byref(T), region.encode(), i32(date_ge), i32(date_lt), rows, i64(32))
+    assert n >= 0
+    return _text("oracle_q5_text", rows, i64(n), cdict(tpchgen.nation_names()))
+
+
+def q12_text(t, mode1, mode2, date_ge, date_lt):
+    from plan_amd import tpchgen
+    T, keep = tpch_struct(t)
+    rows = (Q12Row * 16)()
+    n = lib().oracle_q12(ctypes.byref(T), mode1.encode(), mode2.encode(), i32(date_ge), i32(date_lt), rows, i64(16))
+    assert n >= 0
+    return _text("oracle_q12_text", rows, i64(n), cdict(tpchgen.SHIPMODE_DICT))
+
+
+def q14(t, pattern, date_ge, date_lt):
+    """(rc, float32 promo_revenue, promo sum, total sum)"""
+    T, keep = tpch_struct(t)
+    f, a, b = ctypes.c_float(), ODec(), ODec()
+    lib().oracle_q14.restype = i32
+    rc = lib().oracle_q14(ctypes.byref(T), pattern.encode(), i32(date_ge), i32(date_lt), ctypes.byref(f), ctypes.byref(a), ctypes.byref(b))
+    return rc, f.value, a, b
+
+
+def q14_text(t, pattern, date_ge, date_lt):
+    rc, f, _a, _b = q14(t, pattern, date_ge, date_lt)
+    assert rc >= 0
+    return _text("oracle_q14_text", ctypes.c_float(f), i32(rc))
+
+
+def q19(t):
+    T, keep = tpch_struct(t)
+    d = ODec()
+    lib().oracle_q19.restype = i32
+    rc = lib().oracle_q19(ctypes.byref(T), ctypes.byref(d))
+    return rc, d
+
+
+def q19_text(t):
+    rc, d = q19(t)
+    assert rc >= 0
+    return _text("oracle_q19_text", ctypes.byref(d), i32(rc))
