@@ -509,11 +509,17 @@ int eval_rpn_at(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, const int32_t
     }
     std::vector<ph_rpn> pr(prog, prog + nprog);
     for (auto &o : pr) if (o.op == PH_X_COL) o.col = (int32_t)(std::find(operands.begin(), operands.end(), o.col) - operands.begin());
+    if (views.empty()) {   // a program of constants only (`THEN 1`) names no column: the evaluator still wants one to address
+        void *z = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &z));
+        PL_CHECK(ph_dev_memset(p->ctx, z, 0, std::max<int64_t>(r->n, 1) * 4));
+        ph_col dummy{};
+        dummy.type = PH_I32; dummy.data = z;
+        views.push_back(dummy);
+    }
     PL_CHECK(ph_expr_scale(views.data(), pr.data(), nprog, scale));
     PL_CHECK(palloc(p, std::max<int64_t>(m, 1) * 8, out));
-    ph_col dummy{};
-    dummy.type = PH_I32;
-    if (m > 0) PL_CHECK(ph_expr_eval(p->ctx, views.empty() ? &dummy : views.data(), (int32_t)views.size(), pr.data(), nprog, sel, m, (int64_t *)*out, nullptr));
+    if (m > 0) PL_CHECK(ph_expr_eval(p->ctx, views.data(), (int32_t)views.size(), pr.data(), nprog, sel, m, (int64_t *)*out, nullptr));
     return PH_OK;
 }
 

@@ -17,23 +17,33 @@ SCHEMA = {
     "lineitem": [("l_orderkey", hip.PH_I64, 0, None), ("l_partkey", hip.PH_I32, 0, None), ("l_suppkey", hip.PH_I32, 0, None),
                  ("l_quantity", hip.PH_I32, 0, None), ("l_extendedprice", hip.PH_DEC64, 2, None), ("l_discount", hip.PH_DEC64, 2, None),
                  ("l_tax", hip.PH_DEC64, 2, None), ("l_returnflag", hip.PH_CODE8, 0, tpchgen.RETURNFLAG_DICT),
-                 ("l_linestatus", hip.PH_CODE8, 0, tpchgen.LINESTATUS_DICT), ("l_shipdate", hip.PH_DATE, 0, None)],
+                 ("l_linestatus", hip.PH_CODE8, 0, tpchgen.LINESTATUS_DICT), ("l_shipdate", hip.PH_DATE, 0, None),
+                 ("l_commitdate", hip.PH_DATE, 0, None), ("l_receiptdate", hip.PH_DATE, 0, None),
+                 ("l_shipmode", hip.PH_CODE8, 0, tpchgen.SHIPMODE_DICT), ("l_shipinstruct", hip.PH_CODE8, 0, tpchgen.SHIPINSTRUCT_DICT)],
     "orders": [("o_orderkey", hip.PH_I64, 0, None), ("o_custkey", hip.PH_I32, 0, None), ("o_orderdate", hip.PH_DATE, 0, None),
-               ("o_shippriority", hip.PH_I32, 0, None)],
+               ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT)],
     "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT)],
-    "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None)],
+    "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
+             ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
     "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None)],
     "supplier": [("s_suppkey", hip.PH_I32, 0, None), ("s_nationkey", hip.PH_I32, 0, None)],
-    "nation": [("n_nationkey", hip.PH_I32, 0, None), ("n_name", hip.PH_CODE8, 0, "nation_names")],
+    "nation": [("n_nationkey", hip.PH_I32, 0, None), ("n_name", hip.PH_CODE8, 0, "nation_names"), ("n_regionkey", hip.PH_I32, 0, None)],
+    "region": [("r_regionkey", hip.PH_I32, 0, None), ("r_name", hip.PH_CODE8, 0, "region_names")],
 }
+_NAMED_DICTS = {"nation_names": tpchgen.nation_names, "region_names": tpchgen.region_names, "part_brand": tpchgen.part_brand_dict,
+                "part_type": tpchgen.part_type_dict, "part_container": tpchgen.part_container_dict}
 # cases/tpch/query/ddl.sql: PRIMARY KEY of every table (lineitem's (l_orderkey, l_linenumber) is not loaded)
 PRIMARY_KEY = {"orders": ["o_orderkey"], "customer": ["c_custkey"], "part": ["p_partkey"], "partsupp": ["ps_partkey", "ps_suppkey"],
-               "supplier": ["s_suppkey"], "nation": ["n_nationkey"]}
+               "supplier": ["s_suppkey"], "nation": ["n_nationkey"], "region": ["r_regionkey"]}
 
 
 def nation_columns():
-    names = tpchgen.nation_names()
-    return {"n_nationkey": np.arange(25, dtype=np.int32), "n_name": np.arange(25, dtype=np.uint8)}, names
+    return {"n_nationkey": np.arange(25, dtype=np.int32), "n_name": np.arange(25, dtype=np.uint8),
+            "n_regionkey": np.array(tpchgen.nation_regions(), dtype=np.int32)}
+
+
+def region_columns():
+    return {"r_regionkey": np.arange(5, dtype=np.int32), "r_name": np.arange(5, dtype=np.uint8)}
 
 
 class Database:
@@ -45,7 +55,9 @@ class Database:
         for name, cols in SCHEMA.items():
             src = data.get(name)
             if name == "nation" and src is None:
-                src, _ = nation_columns()
+                src = nation_columns()
+            if name == "region" and src is None:
+                src = region_columns()
             if src is None:
                 continue
             specs, idx = [], {}
@@ -58,7 +70,7 @@ class Database:
                 else:
                     if cname not in src:
                         continue
-                    d = tpchgen.nation_names() if dic == "nation_names" else dic
+                    d = _NAMED_DICTS[dic]() if isinstance(dic, str) else dic
                     specs.append(dict(typ=typ, arr=src[cname], scale=scale, dictionary=d))
                     n = len(src[cname])
                 idx[cname] = len(specs) - 1
@@ -160,3 +172,128 @@ def q3_top(r, limit=10):
 def q9_rows(r):
     """(nation code, year, sum_profit unscaled at scale 4) per group"""
     return [(int(r["keys"][g][0]), int(r["keys"][g][1]), r["sum"][g][0]) for g in range(r["ngroups"])]
+
+
+# ---------------------------------------------------------------- round 3: Q4, Q5, Q12, Q14, Q19
+
+def _k(typ, **kw):
+    return hip.const(typ, **kw)
+
+
+def _s(x):
+    return hip.const(hip.PH_STR, s=x)
+
+
+def q4_plan(db, d1=None, d2=None):
+    """cases/tpch/query/q4.sql: Agg(o_orderpriority; count(*)) <- SemiJoin(o_orderkey = l_orderkey)
+       probe orders[date range], build lineitem[l_commitdate < l_receiptdate] (the EXISTS subquery)"""
+    d1 = tpchgen.days(1997, 7, 1) if d1 is None else d1
+    d2 = tpchgen.days(1997, 10, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    lc, lr = db.c("lineitem", "l_commitdate", "l_receiptdate")
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey"), bools=hip.bool_tree(("colcmp", lc, hip.PH_LT, lr)))
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_orderpriority"),
+                    [_pred(db, "orders", "o_orderdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "orders", "o_orderdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    j = p.join(orders, line, [0], [0], [1], join_type=hip.PH_JT_SEMI)
+    p.agg(j, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None)])
+    return p.create()
+
+
+def q5_plan(db, region="AMERICA", d1=None, d2=None):
+    """cases/tpch/query/q5.sql: the six-table chain; the last join carries the two-column condition
+       (l_suppkey, c_nationkey) = (s_suppkey, s_nationkey)"""
+    d1 = tpchgen.days(1994, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1995, 1, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    reg = p.scan(db.t("region"), db.c("region", "r_regionkey"), [_pred(db, "region", "r_name", hip.PH_EQ, _s(region))])
+    nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name", "n_regionkey"))
+    jn = p.join(nat, reg, [2], [0], [0, 1])                               # n_nationkey, n_name
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_nationkey"))
+    jc = p.join(cust, jn, [1], [0], [0, 1, 3])                            # c_custkey, c_nationkey, n_name
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_custkey"),
+                    [_pred(db, "orders", "o_orderdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "orders", "o_orderdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    jo = p.join(orders, jc, [1], [0], [0, 3, 4])                          # o_orderkey, c_nationkey, n_name
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"))
+    jl = p.join(line, jo, [0], [0], [1, 2, 3, 5, 6])                      # l_suppkey, ext, disc, c_nationkey, n_name
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey"))
+    js = p.join(jl, supp, [0, 3], [0, 1], [1, 2, 4])                      # ext, disc, n_name
+    p.agg(js, [hip.pe_col(2)], [(hip.PH_A_SUM, hip.pe_dec([hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]))])
+    return p.create()
+
+
+def q12_plan(db, modes=("FOB", "TRUCK"), d1=None, d2=None):
+    """cases/tpch/query/q12.sql: integer CASE sums over lineitem[shipmode IN, two column-vs-column date comparisons, receipt range]
+       joined with orders"""
+    d1 = tpchgen.days(1996, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1997, 1, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    sm, lc, lr, ls = db.c("lineitem", "l_shipmode", "l_commitdate", "l_receiptdate", "l_shipdate")
+    where = hip.bool_tree(("and", ("in", sm, [_s(m) for m in modes]), ("colcmp", lc, hip.PH_LT, lr), ("colcmp", ls, hip.PH_LT, lc)))
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_shipmode"),
+                  [_pred(db, "lineitem", "l_receiptdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_receiptdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))],
+                  bools=where)
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_orderpriority"))
+    j = p.join(line, orders, [0], [0], [1, 3])                            # l_shipmode, o_orderpriority
+    one, zero = [hip.X_CONST(1)], [hip.X_CONST(0)]
+    high = hip.pe_case(hip.bool_tree(("or", ("cmp", 1, hip.PH_EQ, _s("1-URGENT")), ("cmp", 1, hip.PH_EQ, _s("2-HIGH")))), one, zero, result_int=True, keep=p._keep)
+    low = hip.pe_case(hip.bool_tree(("and", ("cmp", 1, hip.PH_NE, _s("1-URGENT")), ("cmp", 1, hip.PH_NE, _s("2-HIGH")))), one, zero, result_int=True, keep=p._keep)
+    p.agg(j, [hip.pe_col(0)], [(hip.PH_A_SUM, high), (hip.PH_A_SUM, low)])
+    return p.create()
+
+
+def q14_plan(db, pattern="PROMO%", d1=None, d2=None):
+    """cases/tpch/query/q14.sql: sum(case when p_type like 'PROMO%' then e*(1-d) else 0 end), sum(e*(1-d)); the select list's
+       100.00 * a / b is FLOAT arithmetic over the one result row (q14_promo_revenue)"""
+    d1 = tpchgen.days(1996, 4, 1) if d1 is None else d1
+    d2 = tpchgen.days(1996, 5, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_extendedprice", "l_discount"),
+                  [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    part = p.scan(db.t("part"), db.c("part", "p_partkey", "p_type"))
+    j = p.join(line, part, [0], [0], [1, 2, 4])                           # ext, disc, p_type
+    dp = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]
+    promo = hip.pe_case(hip.bool_tree(("cmp", 2, hip.PH_LIKE, _s(pattern))), dp, [hip.X_CONST(0)], keep=p._keep)
+    p.agg(j, [], [(hip.PH_A_SUM, promo), (hip.PH_A_SUM, hip.pe_dec(dp))])
+    return p.create()
+
+
+def q14_promo_revenue(r):
+    """100.00 * a / b as the binder types it: the literal is FLOAT, so both sums are cast decimal -> float64 -> float32
+    (tryCastDecimalToFloat32) and `*`, `/` are the FLOAT overloads (function_scalar.go:476-512, 960-1010)"""
+    if r["ngroups"] == 0:
+        return None
+    from decimal import Decimal
+    a = np.float32(float(Decimal(r["sum"][0][0]).scaleb(-r["scale"][0])))
+    b = np.float32(float(Decimal(r["sum"][0][1]).scaleb(-r["scale"][1])))
+    return np.float32(np.float32(100.0) * a) / b
+
+
+Q19_BRANCHES = (("Brand#23", ("SM CASE", "SM BOX", "SM PACK", "SM PKG"), 5, 15, 5),
+                ("Brand#15", ("MED BAG", "MED BOX", "MED PKG", "MED PACK"), 14, 24, 10),
+                ("Brand#44", ("LG CASE", "LG BOX", "LG PACK", "LG PKG"), 28, 38, 15))
+
+
+def q19_plan(db):
+    """cases/tpch/query/q19.sql: the conjuncts common to the three OR branches (the join condition, l_shipmode IN (..),
+       l_shipinstruct = ..) are what DistributivityRule + filter push-down take out of the OR; the rest is a Filter over the join"""
+    p = hip.Plan(db.ctx)
+    sm = db.c("lineitem", "l_shipmode")[0]
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_quantity", "l_extendedprice", "l_discount"),
+                  [_pred(db, "lineitem", "l_shipinstruct", hip.PH_EQ, _s("DELIVER IN PERSON"))],
+                  bools=hip.bool_tree(("in", sm, [_s("AIR"), _s("AIR REG")])))
+    part = p.scan(db.t("part"), db.c("part", "p_partkey", "p_brand", "p_size", "p_container"))
+    j = p.join(line, part, [0], [0], [1, 2, 3, 5, 6, 7])                  # qty, ext, disc, p_brand, p_size, p_container
+    I = lambda v: _k(hip.PH_I32, i=v)
+    branches = tuple(("and", ("cmp", 3, hip.PH_EQ, _s(b)), ("in", 5, [_s(c) for c in cn]), ("cmp", 0, hip.PH_GE, I(q1)), ("cmp", 0, hip.PH_LE, I(q2)),
+                      ("cmp", 4, hip.PH_GE, I(1)), ("cmp", 4, hip.PH_LE, I(sz))) for b, cn, q1, q2, sz in Q19_BRANCHES)
+    f = p.filter(j, bools=hip.bool_tree(("or",) + branches))
+    p.agg(f, [], [(hip.PH_A_SUM, hip.pe_dec([hip.X_COL(1), hip.X_CONST(1), hip.X_COL(2), hip.X_SUB, hip.X_MUL]))])
+    return p.create()
+
+
+def dec_text(unscaled, scale):
+    """Value.String of a DECIMAL cell at `scale` (trailing zeros of the fraction trimmed, as NewFromInt64 does)"""
+    neg = "-" if unscaled < 0 else ""
+    w, f = divmod(abs(int(unscaled)), 10 ** scale)
+    frac = (("%0" + str(scale) + "d") % f).rstrip("0") if scale else ""
+    return f"{neg}{w}" + (f".{frac}" if frac else "")

@@ -173,3 +173,77 @@ def test_q9_plan_with_dangling_foreign_keys_reruns_conservatively(ctx, sf001):
         p.free()
     finally:
         d.free()
+
+
+# ---------------------------------------------------------------- round 3: five more reference goldens through ph_plan
+
+def _by_name(rows, dic):
+    return sorted(rows, key=lambda r: dic[r[0]])
+
+
+def q4_text(r):
+    dic = tpchgen.ORDERPRIORITY_DICT
+    rows = [(int(r["keys"][g][0]), r["count"][g][0]) for g in range(r["ngroups"])]
+    return "#\t\n" + "".join(f"{dic[c]}\t{n}\n" for c, n in _by_name(rows, dic))
+
+
+def q5_text(r):
+    dic = tpchgen.nation_names()
+    rows = sorted(((int(r["keys"][g][0]), r["sum"][g][0]) for g in range(r["ngroups"])), key=lambda x: -x[1])
+    return "#\t\n" + "".join(f"{dic[c]}\t{tpch.dec_text(s, 4)}\n" for c, s in rows)
+
+
+def q12_text(r):
+    dic = tpchgen.SHIPMODE_DICT
+    rows = [(int(r["keys"][g][0]), r["sum"][g][0], r["sum"][g][1]) for g in range(r["ngroups"])]
+    return "#\t\t\n" + "".join(f"{dic[c]}\t{h}\t{l}\n" for c, h, l in _by_name(rows, dic))
+
+
+def test_q4_semi_join_plan_matches_golden(ctx, db):
+    """SEMI join against a build side with duplicate keys (lineitem rows per order) behind a column-vs-column filter"""
+    p = tpch.q4_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert q4_text(r) == golden("plan_q4.txt"), ex
+    assert "semi (marks + selection)" in ex
+
+
+def test_q5_six_table_chain_matches_golden(ctx, db):
+    p = tpch.q5_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert q5_text(r) == golden("plan_q5.txt"), ex
+
+
+def test_q12_case_and_in_list_matches_golden(ctx, db):
+    p = tpch.q12_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert q12_text(r) == golden("plan_q12.txt"), ex
+
+
+def test_q14_case_like_and_float_result_matches_golden(ctx, db, sf1):
+    p = tpch.q14_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    rc, f, a, b = O.q14(sf1, "PROMO%", tpchgen.days(1996, 4, 1), tpchgen.days(1996, 5, 1))
+    assert r["ngroups"] == 1 and r["sum"][0] == [a.unscaled(4), b.unscaled(4)], ex     # both decimal sums bit-exact
+    assert f"#\n{float(tpch.q14_promo_revenue(r))!r}\n" == golden("plan_q14.txt")
+
+
+def test_q19_or_of_conjunctions_matches_golden(ctx, db):
+    p = tpch.q19_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert r["ngroups"] == 1, ex
+    assert f"#\n{tpch.dec_text(r['sum'][0][0], 4)}\n" == golden("plan_q19.txt"), ex
