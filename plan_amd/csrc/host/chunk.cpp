@@ -398,6 +398,8 @@ static std::string go_float(double v) {
     return o;
 }
 
+double DecimalToDouble(const Decimal &d) { return strtod(DecimalString(d).c_str(), nullptr); }   // correctly rounded, like the Go parse
+
 std::string ValueString(const Vector &v, int row) {
     Vector::Unified u;
     v.ToUnifiedFormat(row + 1, &u);
@@ -411,6 +413,7 @@ std::string ValueString(const Vector &v, int row) {
     case LTID_DECIMAL: return DecimalValueString(reinterpret_cast<const Decimal *>(u.data)[idx], v._Typ.Scale);
     case LTID_DATE: { const Date &d = reinterpret_cast<const Date *>(u.data)[idx]; snprintf(buf, sizeof buf, "%04d-%02d-%02d", d.Year, d.Month, d.Day); return buf; }
     case LTID_DOUBLE: return go_float(reinterpret_cast<const double *>(u.data)[idx]);
+    case LTID_FLOAT: return go_float((double)reinterpret_cast<const float *>(u.data)[idx]);   // Value.F64 = float64(float32), printed %v
     case LTID_HUGEINT: {
         const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx];
         __int128 x = ((__int128)h.Upper << 64) + (__int128)(u128)h.Lower;

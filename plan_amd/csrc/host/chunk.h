@@ -48,6 +48,7 @@ inline LType DateType() { return {LTID_DATE, 0, 0}; }
 inline LType DecimalType(int w, int s) { return {LTID_DECIMAL, w, s}; }
 inline LType VarcharType() { return {LTID_VARCHAR, 0, 0}; }
 inline LType DoubleType() { return {LTID_DOUBLE, 0, 0}; }
+inline LType FloatType() { return {LTID_FLOAT, 0, 0}; }
 inline LType HugeintType() { return {LTID_HUGEINT, 0, 0}; }
 
 struct Bitmap {
@@ -119,6 +120,8 @@ bool DecimalFromInt128(__int128 v, int scale, Decimal *out);
 // sum.Quo(count): 19 significant digits, half-even, trailing zeros trimmed (AvgOp.Finalize)
 bool DecimalQuoCount(__int128 sum, int scale, uint64_t count, Decimal *out);
 std::string DecimalString(const Decimal &d);
+// Float64(): the nearest double of the decimal's text (what tryCastDecimalToFloat32 / ToFloat64 start from)
+double DecimalToDouble(const Decimal &d);
 // Int64(scale) rounding + NewFromInt64 + String: the text the reference prints for a DECIMAL cell
 std::string DecimalValueString(const Decimal &d, int typeScale);
 // unscaled int64 of a Decimal at `scale` (exact) — what the staging code uploads

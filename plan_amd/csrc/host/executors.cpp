@@ -973,6 +973,18 @@ std::string gpuProjectExecutor::Types(const std::vector<ProjExpr> &exprs, const 
             if (e.col < 0 || e.col >= (int)childTypes.size() || childTypes[(size_t)e.col].GetInternalType() != PT_VARCHAR) return "substring needs a VARCHAR column";
             out->push_back(VarcharType());
             break;
+        case ProjExpr::Case: {
+            if (e.resultInt) { out->push_back(IntegerType()); break; }
+            int32_t scale = 0;
+            if (ph_expr_scale(protos.data(), e.prog.data(), (int32_t)e.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
+            out->push_back(DecimalType(38, scale));
+            break;
+        }
+        case ProjExpr::Float32:
+            for (auto &o : e.fprog)
+                if (o.op == FloatOp::Col && (o.col < 0 || o.col >= (int)childTypes.size())) return "float expression column out of range";
+            out->push_back(FloatType());
+            break;
         }
     }
     return "";
@@ -1064,6 +1076,41 @@ std::string gpuProjectExecutor::Evaluate(ph_ctx *ctx, const std::vector<ProjExpr
             const ProjExpr &ex = exprs[i];
             Vector &v = *oc->Data[i];
             if (ex.kind == ProjExpr::ColRef) { oc->Data[i] = c->Data[(size_t)ex.col]; continue; }   // Reference: no copy
+            if (ex.kind == ProjExpr::Case) return "CASE expressions run inside resident plans only";
+            if (ex.kind == ProjExpr::Float32) {
+                // FLOAT arithmetic, operand casts as the binder inserts them: DECIMAL -> float64 -> float32
+                // (tryCastDecimalToFloat32), INTEGER -> float32, HUGEINT sums -> float32; every operation rounds to float32
+                for (int r = 0; r < card; r++) {
+                    std::vector<float> st;
+                    bool null = false;
+                    for (auto &o : ex.fprog) {
+                        if (o.op == FloatOp::Const) { st.push_back(o.k); continue; }
+                        if (o.op == FloatOp::Col) {
+                            const Vector &src = *c->Data[(size_t)o.col];
+                            Vector::Unified u;
+                            src.ToUnifiedFormat(card, &u);
+                            int64_t idx = u.sel->GetIndex(r);
+                            if (!u.mask->RowIsValid((uint64_t)idx)) { null = true; st.push_back(0); continue; }
+                            switch (src._Typ.GetInternalType()) {
+                            case PT_DECIMAL: st.push_back((float)DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx])); break;
+                            case PT_INT32: st.push_back((float)reinterpret_cast<const int32_t *>(u.data)[idx]); break;
+                            case PT_FLOAT: st.push_back(reinterpret_cast<const float *>(u.data)[idx]); break;
+                            case PT_DOUBLE: st.push_back((float)reinterpret_cast<const double *>(u.data)[idx]); break;
+                            default: return "float expression over an unsupported column type";
+                            }
+                            continue;
+                        }
+                        if (st.size() < 2) return "malformed float expression";
+                        volatile float b = st.back(); st.pop_back();
+                        volatile float a = st.back(); st.pop_back();
+                        volatile float res = o.op == FloatOp::Add ? a + b : o.op == FloatOp::Sub ? a - b : o.op == FloatOp::Mul ? a * b : a / b;
+                        st.push_back((float)res);
+                    }
+                    if (st.size() != 1) return "malformed float expression";
+                    if (null) v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); else v.Slice<float>()[r] = st[0];
+                }
+                continue;
+            }
             for (int r = 0; r < card; r++) {
                 size_t g = (size_t)(base + r);
                 if (ex.kind == ProjExpr::Decimal) {
@@ -1200,13 +1247,13 @@ static std::string exprType(const ProjExpr &e, const std::vector<LType> &childTy
     std::vector<LType> one;
     std::string err = gpuProjectExecutor::Types({e}, childTypes, &one);
     if (!err.empty()) return err;
-    if (e.kind == ProjExpr::Substring) return "substring is not part of a resident plan";
+    if (e.kind == ProjExpr::Substring || e.kind == ProjExpr::Float32) return "substring / FLOAT expressions are not part of a resident plan";
     *t = one[0];
     *src = e.kind == ProjExpr::ColRef ? childSrc[(size_t)e.col] : nullptr;
     return "";
 }
 
-int ResidentPlan::Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts) {
+int ResidentPlan::Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts, BoolExpr where) {
     Node n;
     n.kind = PH_PN_SCAN;
     n.table = t;
@@ -1218,17 +1265,19 @@ int ResidentPlan::Scan(const ResidentTable *t, std::vector<int> cols, std::vecto
     for (auto &c : conjuncts) if ((c.col < 0 || c.col >= (int)t->cols.size()) && error.empty()) error = "scan conjunct column out of range";
     n.cols = std::move(cols);
     n.conjuncts = std::move(conjuncts);
+    n.where = std::move(where);
     nodes.push_back(std::move(n));
     return (int)nodes.size() - 1;
 }
 
-int ResidentPlan::Filter(int child, std::vector<Compare> conjuncts) {
+int ResidentPlan::Filter(int child, std::vector<Compare> conjuncts, BoolExpr where) {
     Node n;
     n.kind = PH_PN_FILTER;
     n.child[0] = child;
     n.types = nodes[(size_t)child].types;
     n.source = nodes[(size_t)child].source;
     n.conjuncts = std::move(conjuncts);
+    n.where = std::move(where);
     nodes.push_back(std::move(n));
     return (int)nodes.size() - 1;
 }
@@ -1302,9 +1351,58 @@ static ph_pred lowerCompare(const Compare &c) {
     return p;
 }
 
-static ph_plan_expr lowerExpr(const ProjExpr &e) {
+static ph_const lowerLiteral(const Literal &k) {
+    ph_const c{};
+    switch (k.kind) {
+    case Literal::Int: c.type = PH_I32; c.i = k.i; break;
+    case Literal::Float: c.type = PH_F32; c.f = k.f; break;
+    case Literal::DateDays: c.type = PH_DATE; c.i = k.i; break;
+    case Literal::Dec: c.type = PH_DEC64; c.i = k.i; c.scale = k.scale; break;
+    case Literal::Str: c.type = PH_STR; c.s = k.s.c_str(); break;
+    }
+    return c;
+}
+
+// BoolExpr tree -> the flat ph_bool array (node 0 = root, the children of a node contiguous)
+static void flattenBool(const BoolExpr &b, size_t at, std::vector<ph_bool> *out) {
+    ph_bool n{};
+    if (b.kind == BoolExpr::Cmp) {
+        n.kind = PH_B_CMP; n.col = b.col; n.op = b.op;
+        if (b.col2 >= 0) { n.k.type = PH_COLREF; n.k.i = b.col2; } else n.k = lowerLiteral(b.k);
+        (*out)[at] = n;
+        return;
+    }
+    n.kind = b.kind == BoolExpr::And ? PH_B_AND : PH_B_OR;
+    n.first_child = (int32_t)out->size();
+    n.nchildren = (int32_t)b.children.size();
+    (*out)[at] = n;
+    const size_t base = out->size();
+    out->resize(base + b.children.size());
+    for (size_t c = 0; c < b.children.size(); c++) flattenBool(b.children[c], base + c, out);
+}
+
+static std::vector<ph_bool> lowerBool(const BoolExpr &b) {
+    std::vector<ph_bool> out;
+    if (b.empty()) return out;
+    out.resize(1);
+    flattenBool(b, 0, &out);
+    return out;
+}
+
+static ph_plan_expr lowerExpr(const ProjExpr &e, std::vector<std::vector<ph_bool>> *whens) {
     ph_plan_expr x{};
     switch (e.kind) {
+    case ProjExpr::Case:
+        x.kind = PH_PE_CASE; x.col = -1;
+        x.nprog = (int32_t)std::min<size_t>(e.prog.size(), 12);
+        for (int i = 0; i < x.nprog; i++) x.prog[i] = e.prog[(size_t)i];
+        x.nelse = (int32_t)std::min<size_t>(e.elseProg.size(), 12);
+        for (int i = 0; i < x.nelse; i++) x.else_prog[i] = e.elseProg[(size_t)i];
+        x.result_int = e.resultInt ? 1 : 0;
+        whens->push_back(lowerBool(*e.when));
+        x.nwhen = (int32_t)whens->back().size();
+        x.when = whens->back().data();
+        break;
     case ProjExpr::ColRef: x.kind = PH_PE_COL; x.col = e.col; break;
     case ProjExpr::ExtractYear: x.kind = PH_PE_YEAR; x.col = e.col; break;
     default:
@@ -1324,6 +1422,8 @@ std::string gpuResidentPlanExecutor::Init() {
     std::vector<std::vector<ph_pred>> preds(nn);
     std::vector<std::vector<ph_plan_expr>> exprs(nn);
     std::vector<std::vector<ph_plan_agg>> aggs(nn);
+    std::vector<std::vector<ph_bool>> bools(nn), whens;
+    whens.reserve(256);   // the WHEN arrays must not move while the descriptor points at them
     i32s.reserve(nn * 4);
     auto keep = [&](const std::vector<int> &v) { i32s.emplace_back(v.begin(), v.end()); if (i32s.back().empty()) i32s.back().push_back(0); return i32s.back().data(); };
     const ResidentPlan::Node &root = rp_.nodes.back();
@@ -1336,6 +1436,9 @@ std::string gpuResidentPlanExecutor::Init() {
         for (auto &c : n.conjuncts) preds[i].push_back(lowerCompare(c));
         d.npreds = (int32_t)preds[i].size();
         d.preds = preds[i].data();
+        bools[i] = lowerBool(n.where);
+        d.nbools = (int32_t)bools[i].size();
+        d.bools = bools[i].data();
         switch (n.kind) {
         case PH_PN_SCAN:
             d.table = n.table->table;
@@ -1352,20 +1455,25 @@ std::string gpuResidentPlanExecutor::Init() {
             d.out = keep(n.out);
             break;
         case PH_PN_PROJECT:
-            for (auto &e : n.exprs) { if (e.prog.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e)); }
+            for (auto &e : n.exprs) { if (e.prog.size() > 12 || e.elseProg.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e, &whens)); }
             d.nexprs = (int32_t)exprs[i].size();
             d.exprs = exprs[i].data();
             break;
         case PH_PN_AGG:
-            for (auto &e : n.exprs) { if (e.prog.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e)); }
+            for (auto &e : n.exprs) { if (e.prog.size() > 12 || e.elseProg.size() > 12) return "expression program too long"; exprs[i].push_back(lowerExpr(e, &whens)); }
             for (auto &a : n.aggs) {
                 ph_plan_agg pa{};
                 pa.kind = a.kind;
                 if (a.kind != PH_A_COUNT_STAR) {
-                    if (a.prog.empty()) return "aggregate without an argument";
-                    if (a.prog.size() > 12) return "aggregate argument program too long";
-                    ProjExpr e = a.prog.size() == 1 && a.prog[0].op == PH_X_COL ? ProjExpr::Col(a.prog[0].col) : ProjExpr::Dec(a.prog);
-                    pa.arg = lowerExpr(e);
+                    if (a.expr) {
+                        if (a.expr->prog.size() > 12 || a.expr->elseProg.size() > 12) return "aggregate argument program too long";
+                        pa.arg = lowerExpr(*a.expr, &whens);
+                    } else {
+                        if (a.prog.empty()) return "aggregate without an argument";
+                        if (a.prog.size() > 12) return "aggregate argument program too long";
+                        ProjExpr e = a.prog.size() == 1 && a.prog[0].op == PH_X_COL ? ProjExpr::Col(a.prog[0].col) : ProjExpr::Dec(a.prog);
+                        pa.arg = lowerExpr(e, &whens);
+                    }
                 }
                 aggs[i].push_back(pa);
             }
@@ -1387,7 +1495,12 @@ std::string gpuResidentPlanExecutor::Init() {
         LType at = IntegerType();
         int32_t scale = 0;
         if (a.kind != PH_A_COUNT_STAR) {
-            if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { at = childTypes[(size_t)a.prog[0].col]; scale = at.Scale; }
+            if (a.expr) {
+                std::vector<LType> one;
+                std::string e = gpuProjectExecutor::Types({*a.expr}, childTypes, &one);
+                if (!e.empty()) return e;
+                at = one[0]; scale = at.Scale;
+            } else if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { at = childTypes[(size_t)a.prog[0].col]; scale = at.Scale; }
             else {
                 if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
                 at = DecimalType(38, scale);

@@ -55,23 +55,63 @@ struct Compare {  // one conjunct: child column OP literal
     int op;  // ph_cmp
     Literal k;
 };
-struct AggExpr {
-    int kind;                  // ph_aggkind
-    std::vector<ph_rpn> prog;  // argument over child columns (empty for count(*))
+// a boolean expression over a node's columns — the tree ExprExec.executeSelect walks (expr_exec.go:342-530):
+// comparisons of a column with a literal or with another column, AND (narrows child by child), OR (unites the
+// children's true rows; `a IN (x, y)` binds to in(a,x) OR in(a,y))
+struct BoolExpr {
+    enum Kind { Cmp, And, Or } kind = Cmp;
+    int col = -1, op = 0;        // Cmp: col OP k, or — col2 >= 0 — col OP column col2
+    Literal k;
+    int col2 = -1;
+    std::vector<BoolExpr> children;
+    static BoolExpr C(int col, int op, Literal k) { BoolExpr b; b.col = col; b.op = op; b.k = std::move(k); return b; }
+    static BoolExpr CC(int col, int op, int col2) { BoolExpr b; b.col = col; b.op = op; b.col2 = col2; return b; }
+    static BoolExpr AndOf(std::vector<BoolExpr> c) { BoolExpr b; b.kind = And; b.children = std::move(c); return b; }
+    static BoolExpr OrOf(std::vector<BoolExpr> c) { BoolExpr b; b.kind = Or; b.children = std::move(c); return b; }
+    static BoolExpr In(int col, const std::vector<Literal> &vals) { BoolExpr b; b.kind = Or; for (auto &v : vals) b.children.push_back(C(col, PH_EQ, v)); return b; }
+    bool empty() const { return kind == Cmp && col < 0; }
 };
+
+// FLOAT (float32) arithmetic over finalised aggregate rows — Q14's `100.00 * a / b`: the literal is FLOAT, both operators
+// bind to their FLOAT overloads, DECIMAL operands are cast decimal -> float64 -> float32 (function_scalar.go:476-512,
+// 960-1010; function_cast.go:349-354). RPN; evaluated on the host (the rows are group rows).
+struct FloatOp {
+    enum Op { Col, Const, Add, Sub, Mul, Div } op = Const;
+    int col = -1;
+    float k = 0;
+};
+
+struct AggExpr;
 
 // one output expression of a Project / of the aggregate's output phase: a column reference (zero
 // copy, like executeColumnRef), a decimal expression (RPN over child columns, evaluated on the
 // device: executeFunc over the binary decimal operators), extract(year ...) or substring
 struct ProjExpr {
-    enum Kind { ColRef, Decimal, ExtractYear, Substring } kind = ColRef;
+    enum Kind { ColRef, Decimal, ExtractYear, Substring, Case, Float32 } kind = ColRef;
     int col = -1;                 // ColRef / ExtractYear / Substring: child column
-    std::vector<ph_rpn> prog;     // Decimal: RPN over child columns
+    std::vector<ph_rpn> prog;     // Decimal: RPN over child columns; Case: the THEN branch
     int64_t offset = 1, length = 0;   // Substring(col FROM offset FOR length)
+    // Case (resident plans only): CASE WHEN when THEN prog ELSE elseProg END (executeCase, expr_exec.go:144-246)
+    std::shared_ptr<BoolExpr> when;
+    std::vector<ph_rpn> elseProg;
+    bool resultInt = false;       // both branches are INTEGER literals: the result is INTEGER
+    std::vector<FloatOp> fprog;   // Float32
+    static ProjExpr CaseOf(BoolExpr w, std::vector<ph_rpn> thenProg, std::vector<ph_rpn> elseProg, bool resultInt = false) {
+        ProjExpr e; e.kind = Case; e.when = std::make_shared<BoolExpr>(std::move(w)); e.prog = std::move(thenProg); e.elseProg = std::move(elseProg); e.resultInt = resultInt; return e;
+    }
+    static ProjExpr Float(std::vector<FloatOp> p) { ProjExpr e; e.kind = Float32; e.fprog = std::move(p); return e; }
     static ProjExpr Col(int c) { ProjExpr e; e.kind = ColRef; e.col = c; return e; }
     static ProjExpr Dec(std::vector<ph_rpn> p) { ProjExpr e; e.kind = Decimal; e.prog = std::move(p); return e; }
     static ProjExpr Year(int c) { ProjExpr e; e.kind = ExtractYear; e.col = c; return e; }
     static ProjExpr Substr(int c, int64_t off, int64_t len) { ProjExpr e; e.kind = Substring; e.col = c; e.offset = off; e.length = len; return e; }
+};
+
+struct AggExpr {
+    int kind;                  // ph_aggkind
+    std::vector<ph_rpn> prog;  // argument over child columns (empty for count(*))
+    std::shared_ptr<ProjExpr> expr;   // ... or any expression (a CASE: resident plans only); prog is ignored then
+    AggExpr(int k = 0, std::vector<ph_rpn> p = {}) : kind(k), prog(std::move(p)) {}
+    static AggExpr Of(int k, ProjExpr e) { AggExpr a(k); a.expr = std::make_shared<ProjExpr>(std::move(e)); return a; }
 };
 
 // replays serialized chunks (the reference's fixture mechanism)
@@ -373,8 +413,9 @@ struct ResidentTable {
 class ResidentPlan {
 public:
     // every method returns the new node's index; children must exist already (bottom-up, like buildOperatorExec)
-    int Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts = {});
-    int Filter(int child, std::vector<Compare> conjuncts);
+    // conjuncts: simple `column OP literal` ones (a build or a probe can absorb those); where: one more conjunct of any shape
+    int Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts = {}, BoolExpr where = BoolExpr());
+    int Filter(int child, std::vector<Compare> conjuncts, BoolExpr where = BoolExpr());
     // output = the listed columns of [probe child's columns | build child's columns] (SEMI / ANTI: probe columns)
     int Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type = JoinInner);
     int Project(int child, std::vector<ProjExpr> exprs);
@@ -384,6 +425,7 @@ public:
         const ResidentTable *table = nullptr;
         std::vector<int> cols, probeKeys, buildKeys, out;
         std::vector<Compare> conjuncts;
+        BoolExpr where;
         JoinType joinType = JoinInner;
         std::vector<ProjExpr> exprs;    // Project; Agg: the group-by expressions
         std::vector<AggExpr> aggs;

@@ -233,6 +233,92 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 3;
         break;
     }
+    case 4: {
+        // Order <- Agg(o_orderpriority; count(*)) <- SemiJoin(o_orderkey = l_orderkey) probe Scan(orders, date range)
+        //   build Scan(lineitem, l_commitdate < l_receiptdate): the decorrelated EXISTS
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY}, {}, BoolExpr::CC(L_COMMITDATE, PH_LT, L_RECEIPTDATE));
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_ORDERPRIORITY}, {{O_ORDERDATE, PH_GE, LDate(1997, 7, 1)}, {O_ORDERDATE, PH_LT, LDate(1997, 10, 1)}});
+        int j = p.Join(ord, line, {0}, {0}, {1}, JoinSemi);
+        p.Agg(j, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}});
+        q->order = {{0, false}};
+        q->ncols = 2;
+        break;
+    }
+    case 5: {
+        // Order <- Agg(n_name; sum(e * (1 - d))) over the six-table chain; the last join carries the two-column condition
+        // (l_suppkey, c_nationkey) = (s_suppkey, s_nationkey)
+        int reg = p.Scan(&db.region, {R_REGIONKEY}, {{R_NAME, PH_EQ, LStr("AMERICA")}});
+        int nat = p.Scan(&db.nation, {N_NATIONKEY, N_NAME, N_REGIONKEY});
+        int jn = p.Join(nat, reg, {2}, {0}, {0, 1});                       // n_nationkey, n_name
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_NATIONKEY});
+        int jc = p.Join(cust, jn, {1}, {0}, {0, 1, 3});                    // c_custkey, c_nationkey, n_name
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY}, {{O_ORDERDATE, PH_GE, LDate(1994, 1, 1)}, {O_ORDERDATE, PH_LT, LDate(1995, 1, 1)}});
+        int jo = p.Join(ord, jc, {1}, {0}, {0, 3, 4});                     // o_orderkey, c_nationkey, n_name
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY, L_EXTENDEDPRICE, L_DISCOUNT});
+        int jl = p.Join(line, jo, {0}, {0}, {1, 2, 3, 5, 6});              // l_suppkey, ext, disc, c_nationkey, n_name
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY});
+        int js = p.Join(jl, supp, {0, 3}, {0, 1}, {1, 2, 4});              // ext, disc, n_name
+        p.Agg(js, {ProjExpr::Col(2)}, {{PH_A_SUM, DiscPrice(0, 1)}});
+        q->order = {{1, true}};                                            // ORDER BY revenue DESC
+        q->ncols = 2;
+        break;
+    }
+    case 12: {
+        // Order <- Agg(l_shipmode; sum(case when prio = '1-URGENT' or prio = '2-HIGH' then 1 else 0 end), sum(case when prio <> .. and prio <> ..))
+        //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, shipmode IN ('FOB','TRUCK'), commit < receipt, ship < commit, receipt range)
+        BoolExpr where = BoolExpr::AndOf({BoolExpr::In(L_SHIPMODE, {LStr("FOB"), LStr("TRUCK")}), BoolExpr::CC(L_COMMITDATE, PH_LT, L_RECEIPTDATE),
+                                          BoolExpr::CC(L_SHIPDATE, PH_LT, L_COMMITDATE)});
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_SHIPMODE}, {{L_RECEIPTDATE, PH_GE, LDate(1996, 1, 1)}, {L_RECEIPTDATE, PH_LT, LDate(1997, 1, 1)}}, where);
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_ORDERPRIORITY});
+        int j = p.Join(line, ord, {0}, {0}, {1, 3});                       // l_shipmode, o_orderpriority
+        ProjExpr high = ProjExpr::CaseOf(BoolExpr::OrOf({BoolExpr::C(1, PH_EQ, LStr("1-URGENT")), BoolExpr::C(1, PH_EQ, LStr("2-HIGH"))}), {XK(1)}, {XK(0)}, true);
+        ProjExpr low = ProjExpr::CaseOf(BoolExpr::AndOf({BoolExpr::C(1, PH_NE, LStr("1-URGENT")), BoolExpr::C(1, PH_NE, LStr("2-HIGH"))}), {XK(1)}, {XK(0)}, true);
+        p.Agg(j, {ProjExpr::Col(0)}, {AggExpr::Of(PH_A_SUM, high), AggExpr::Of(PH_A_SUM, low)});
+        q->order = {{0, false}};
+        q->ncols = 3;
+        break;
+    }
+    case 14: {
+        // Agg(; sum(case when p_type like 'PROMO%' then e * (1 - d) else 0 end), sum(e * (1 - d))) <- Join(l_partkey = p_partkey)
+        //   probe Scan(lineitem, shipdate in April 1996), build Scan(part); select list: 100.00 * a / b — FLOAT arithmetic
+        int line = p.Scan(&db.lineitem, {L_PARTKEY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_SHIPDATE, PH_GE, LDate(1996, 4, 1)}, {L_SHIPDATE, PH_LT, LDate(1996, 5, 1)}});
+        int part = p.Scan(&db.part, {P_PARTKEY, P_TYPE});
+        int j = p.Join(line, part, {0}, {0}, {1, 2, 4});                   // ext, disc, p_type
+        ProjExpr promo = ProjExpr::CaseOf(BoolExpr::C(2, PH_LIKE, LStr("PROMO%")), DiscPrice(0, 1), {XK(0)});
+        p.Agg(j, {}, {AggExpr::Of(PH_A_SUM, promo), {PH_A_SUM, DiscPrice(0, 1)}});
+        FloatOp hundred; hundred.op = FloatOp::Const; hundred.k = 100.00f;
+        FloatOp a; a.op = FloatOp::Col; a.col = 0;
+        FloatOp b; b.op = FloatOp::Col; b.col = 1;
+        FloatOp mul; mul.op = FloatOp::Mul;
+        FloatOp div; div.op = FloatOp::Div;
+        q->outputs = {ProjExpr::Float({hundred, a, mul, b, div})};
+        q->ncols = 1;
+        break;
+    }
+    case 19: {
+        // Agg(; sum(e * (1 - d))) <- Filter(OR of the three conjunctions) <- Join(l_partkey = p_partkey); the conjuncts common to all
+        // three branches (join condition, l_shipmode IN ('AIR','AIR REG'), l_shipinstruct = 'DELIVER IN PERSON') are what
+        // DistributivityRule (rule_distributivity.go) + filter push-down lift out of the OR and into the lineitem scan
+        int line = p.Scan(&db.lineitem, {L_PARTKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_SHIPINSTRUCT, PH_EQ, LStr("DELIVER IN PERSON")}},
+                          BoolExpr::In(L_SHIPMODE, {LStr("AIR"), LStr("AIR REG")}));
+        int part = p.Scan(&db.part, {P_PARTKEY, P_BRAND, P_SIZE, P_CONTAINER});
+        int j = p.Join(line, part, {0}, {0}, {1, 2, 3, 5, 6, 7});          // qty, ext, disc, p_brand, p_size, p_container
+        struct Br { const char *brand; std::vector<const char *> cntr; int q1, q2, sz; };
+        const std::vector<Br> brs = {{"Brand#23", {"SM CASE", "SM BOX", "SM PACK", "SM PKG"}, 5, 15, 5},
+                                     {"Brand#15", {"MED BAG", "MED BOX", "MED PKG", "MED PACK"}, 14, 24, 10},
+                                     {"Brand#44", {"LG CASE", "LG BOX", "LG PACK", "LG PKG"}, 28, 38, 15}};
+        std::vector<BoolExpr> ors;
+        for (auto &b : brs) {
+            std::vector<Literal> cn;
+            for (auto c : b.cntr) cn.push_back(LStr(c));
+            ors.push_back(BoolExpr::AndOf({BoolExpr::C(3, PH_EQ, LStr(b.brand)), BoolExpr::In(5, cn), BoolExpr::C(0, PH_GE, LInt(b.q1)), BoolExpr::C(0, PH_LE, LInt(b.q2)),
+                                           BoolExpr::C(4, PH_GE, LInt(1)), BoolExpr::C(4, PH_LE, LInt(b.sz))}));
+        }
+        int f = p.Filter(j, {}, BoolExpr::OrOf(ors));
+        p.Agg(f, {}, {{PH_A_SUM, DiscPrice(1, 2)}});
+        q->ncols = 1;
+        break;
+    }
     default:
         return "no resident plan for TPC-H query " + std::to_string(id);
     }
