@@ -669,6 +669,29 @@ func residentTableFor(scanOp *PhysicalOperator, cfg *util.Config, txn *storage.T
 	if err = fallbackIf(C.ph_table_create(residentCtx, C.int32_t(len(host)), &host[0], C.int64_t(batch.rows), &rt.h)); err != nil {
 		return nil, err
 	}
+	// The catalog's PRIMARY KEY / UNIQUE constraints become declared-unique column sets of the resident table: what
+	// lets a resident plan (executor_gpu_plan.go) run a join against this table as an N:1 lookup. Constraint fields are
+	// unexported in pkg/storage; INTEGRATION.md §2 adds the 10-line accessor CatalogEntry.UniqueKeys() [][]string.
+	// Order statistics (ascending / strictly ascending per column) the library gathers itself at ph_table_create.
+	if si, ok := scanOp.Info.(*ScanOpInfo); ok && si.TableEnt != nil {
+		pos := map[string]int{}
+		for i, name := range scanOp.getScanColumns() {
+			pos[name] = i
+		}
+		for _, uk := range si.TableEnt.UniqueKeys() {
+			cols := make([]C.int32_t, 0, len(uk))
+			for _, name := range uk {
+				if p, ok := pos[name]; ok {
+					cols = append(cols, C.int32_t(p))
+				}
+			}
+			if len(cols) == len(uk) && len(cols) > 0 { // only when every key column was loaded
+				if err = phErr(C.ph_table_declare_unique(rt.h, C.int32_t(len(cols)), &cols[0])); err != nil {
+					return nil, err
+				}
+			}
+		}
+	}
 	residentTables[key] = rt
 	return rt, nil
 }
