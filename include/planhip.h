@@ -118,6 +118,52 @@ int32_t ph_table_ncols(const ph_table *t);
 int ph_table_col(const ph_table *t, int32_t c, ph_col *out);
 /* per-column min/max gathered at load (int64 domain; used for overflow proofs) */
 int ph_table_col_range(const ph_table *t, int32_t c, int64_t *min, int64_t *max);
+/* ---- Arrow C data interface (the stable ABI of https://arrow.apache.org/docs/format/CDataInterface.html; the two
+ * structs are declared here exactly as the specification prints them, under its own include guard) */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format;
+    const char *name;
+    const char *metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema **children;
+    struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *);
+    void *private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void **buffers;
+    struct ArrowArray **children;
+    struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *);
+    void *private_data;
+};
+#endif
+/* The column load path through the C-ABI: a record batch — a struct array ("+s") whose children
+ * are the columns, as parquet readers, Arrow Flight and Go's arrow/cdata hand it over — becomes a resident table in the
+ * device encodings, whole columns at a time. Replaces COPY FROM parquet + the scan's materialisation
+ * (pkg/compute/executor_scan.go:272-309 readers, :410-466 parquetColToValue + Vector.SetValue: one VALUE at a time into
+ * 24-byte Decimal / 12-byte Date / malloc'd String cells). Arrow's buffers already hold the narrow encodings:
+ *   int32 "i" -> PH_I32, int64 "l" -> PH_I64, date32 "tdD" -> PH_DATE (days since 1970-01-01, the same number),
+ *   decimal128 "d:p,s" -> PH_DEC64 (the low word; PH_EOVERFLOW when a value needs more than 64 bits),
+ *   utf8 "u" / large_utf8 "U" -> PH_CODE8 + dictionary in byte order when the column has <= 256 distinct strings
+ *   (also dictionary-encoded arrays of such strings), else PH_STR offsets + bytes;
+ * validity bitmaps have pkg/util/bitmap.go's convention (1 bit per row, LSB first, 1 = valid) and pass through (re-packed
+ * when the array's offset is not a multiple of 8). The buffers are read during the call only; the caller keeps
+ * ownership and releases the batch as usual. `cols` (optional, ncols entries) selects and orders the children, else all. */
+int ph_table_create_arrow(ph_ctx *ctx, const struct ArrowSchema *schema, const struct ArrowArray *batch, const int32_t *cols,
+                          int32_t ncols, ph_table **out);
+/* dictionary of a PH_CODE8 column (code -> string), for callers that did not build it themselves */
+int32_t ph_table_dict_size(const ph_table *t, int32_t c);
+const char *ph_table_dict_entry(const ph_table *t, int32_t c, int32_t code);
+
 /* Order statistics gathered at load like min / max (one pass per integer column without NULLs), and what the
  * catalog declares. They are what a planner's choice of table form rests on (ph_plan below; ph_join_build_ex's
  * hints): PH_STAT_ASCENDING = values non-decreasing in storage order (a clustering column: lineitem by

@@ -861,6 +861,10 @@ std::string gpuOrderExecutor::Init() {
 
 std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return ""; }
 
+// inputs up to this many rows are ordered on the host (PH_ORDER_HOST_ROWS moves it; 0 = always the device sort, which the
+// parity tests use to run both forms over the same rows)
+static const int64_t kHostSortRows = getenv("PH_ORDER_HOST_ROWS") ? atoll(getenv("PH_ORDER_HOST_ROWS")) : 2048;
+
 std::string gpuOrderExecutor::sortAll() {
     std::vector<int> cols;
     for (auto &k : keys_) cols.push_back(k.col);
@@ -873,13 +877,70 @@ std::string gpuOrderExecutor::sortAll() {
         if (r == InvalidOpResult) return err.empty() ? "child failed" : err;
         if (r == Done) break;
         if (c->Card() == 0) continue;
-        std::string e = batch.Append(*c);
-        if (!e.empty()) return e;
         start_.push_back(total);
         chunks_.push_back(c);
         total += c->Card();
     }
     if (total == 0) return "";
+    if (total <= kHostSortRows) {
+        // A handful of rows (the groups of an aggregate, a top-k preselection): LocalSort's order on the host — the same
+        // keys ph_sort_rows sorts by (NULLs first whatever the direction, sort_layout.go:46; INTEGER / DATE by value,
+        // DECIMAL by dec.Int64(2) = the value rounded half-even to cents, sort_encoder.go:65-70; VARCHAR bytewise; DESC
+        // inverts the value order), ties in input order. Uploading ten rows, five launches and three read-backs cost
+        // ~0.1 ms of an ORDER BY ... LIMIT 10 tail; the device sort is for inputs that are worth a launch.
+        struct HK { bool null; int64_t v; std::string s; };
+        std::vector<std::vector<HK>> hk(keys_.size(), std::vector<HK>((size_t)total));
+        auto types = child_->OutputTypes();
+        for (size_t k = 0; k < keys_.size(); k++) {
+            const LType &t = types[(size_t)keys_[k].col];
+            int64_t row = 0;
+            for (auto &c : chunks_) {
+                const Vector &v = *c->Data[(size_t)keys_[k].col];
+                Vector::Unified u;
+                v.ToUnifiedFormat(c->Card(), &u);
+                for (int i = 0; i < c->Card(); i++, row++) {
+                    HK &h = hk[k][(size_t)row];
+                    int64_t idx = u.sel->GetIndex(i);
+                    h.null = !u.mask->RowIsValid((uint64_t)idx);
+                    h.v = 0;
+                    if (h.null) continue;
+                    switch (t.GetInternalType()) {
+                    case PT_INT32: h.v = reinterpret_cast<const int32_t *>(u.data)[idx]; break;
+                    case PT_DATE: h.v = DaysFromDate(reinterpret_cast<const Date *>(u.data)[idx]); break;
+                    case PT_DECIMAL: {
+                        int64_t x;
+                        if (!DecimalToUnscaled(reinterpret_cast<const Decimal *>(u.data)[idx], t.Scale, &x)) return "decimal ORDER BY key does not fit 18 digits";
+                        if (t.Scale > 2) {   // round half-even to cents
+                            int64_t p = 1;
+                            for (int sc = 2; sc < t.Scale; sc++) p *= 10;
+                            int64_t q = x / p, r = x % p, ar = r < 0 ? -r : r;
+                            if (2 * ar > p || (2 * ar == p && (q & 1))) q += x < 0 ? -1 : 1;
+                            x = q;
+                        } else for (int sc = t.Scale; sc < 2; sc++) x *= 10;
+                        h.v = x;
+                        break;
+                    }
+                    case PT_VARCHAR: { const String &sv = reinterpret_cast<const String *>(u.data)[idx]; h.s.assign(sv.Data, (size_t)sv.Len); break; }
+                    default: break;
+                    }
+                }
+            }
+        }
+        order_.resize((size_t)total);
+        for (int64_t i = 0; i < total; i++) order_[(size_t)i] = (int32_t)i;
+        std::stable_sort(order_.begin(), order_.end(), [&](int32_t a, int32_t b) {
+            for (size_t k = 0; k < keys_.size(); k++) {
+                const HK &x = hk[k][(size_t)a], &y = hk[k][(size_t)b];
+                if (x.null != y.null) return x.null;            // NULLs first
+                if (x.null) continue;
+                int c = x.s.empty() && y.s.empty() ? (x.v < y.v ? -1 : x.v > y.v) : x.s.compare(y.s) < 0 ? -1 : x.s.compare(y.s) > 0;
+                if (c != 0) return keys_[k].descending ? c > 0 : c < 0;
+            }
+            return false;
+        });
+        return "";
+    }
+    for (auto &c : chunks_) { std::string e = batch.Append(*c); if (!e.empty()) return e; }
     std::string e = batch.Upload();
     if (!e.empty()) return e;
     // VARCHAR keys arrive as codes in first-seen order: re-code by the dictionary's byte order so

@@ -55,7 +55,8 @@ __device__ __forceinline__ unsigned long long order_key(long long v, int descend
 
 // Workgroup-wide radix select over n keys held in LDS (8 passes, most significant byte first):
 // returns the k-th smallest key, or ~0 with *all = true when there are fewer than k keys.
-constexpr int TOPK_CHUNK = 4096;   // keys one workgroup selects from (32 KiB of LDS)
+constexpr int TOPK_CHUNK = 1024;   // keys one workgroup selects from: small chunks = many workgroups selecting in parallel, each over 4 keys per thread
+constexpr int TOPK_FINAL = 4096;   // candidates the last workgroup selects from in LDS (32 KiB); more: from memory
 
 __device__ unsigned long long wg_radix_select(const unsigned long long *keys, int n, long long k, unsigned *lh,
                                               unsigned long long *s_state, bool *all) {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
                                                           int *__restrict__ cand_ids, unsigned long long *__restrict__ cand_keys,
                                                           int *__restrict__ cand_count, int *__restrict__ done,
                                                           int *__restrict__ out_ids, int *__restrict__ meta, int cap) {
-    __shared__ unsigned long long skeys[TOPK_CHUNK];
+    __shared__ unsigned long long skeys[TOPK_FINAL];
     __shared__ unsigned lh[256];
     __shared__ unsigned long long s_state[8];
     __shared__ int s_last;
@@ -147,23 +148,24 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
         for (int i = threadIdx.x; i < n; i += 256)
             if (all || skeys[i] <= kth) {
                 const int pos = atomicAdd(cand_count, 1);
-                cand_ids[pos] = base + i;          // the lists hold one entry per group at most
-                cand_keys[pos] = skeys[i];
+                // agent-scope stores: written through to the device's coherence point, where the last workgroup reads them.
+                // (Ordinary stores + __threadfence() made every workgroup write back its whole L2 — including the group
+                // states the previous kernel had just written: 39 us for a kernel whose own work is ~10.)
+                __hip_atomic_store(&cand_ids[pos], base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one entry per group at most
+                __hip_atomic_store(&cand_keys[pos], skeys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's candidate stores are performed
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();   // acquire: the other workgroups' candidate stores are visible from here on
     // final selection over the candidates (read at the coherence point: other workgroups wrote them)
     const int m = __hip_atomic_load(cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long kth = ~0ull;
     bool all = k >= m;
     if (!all) {
-        if (m <= TOPK_CHUNK) {
+        if (m <= TOPK_FINAL) {
             for (int i = threadIdx.x; i < m; i += 256)
                 skeys[i] = __hip_atomic_load(&cand_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();

@@ -1011,6 +1011,20 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
             std::vector<PCol> bcols;
             PL_CHECK(build_cols(brow, &bcols, out));
             for (auto &c : bcols) all.push_back(c);
+            // The probe key of a matched row EQUALS the build key it matched: when the build side is a small table and the
+            // probe side a big one, later readers of the probe key are served from the build key through the pair's build
+            // row (a cache-resident table) instead of one more 128-byte line per surviving row of the big table.
+            if (nk == 1 && brow_is_rowid) {
+                PCol &pkc = all[(size_t)nd.pkeys[0]];
+                const PCol &bkc = all[nP + (size_t)nd.bkeys[0]];
+                if (pkc.lane >= 0 && bkc.lane >= 0 && pkc.type == bkc.type && out->lanes[(size_t)pkc.lane].t->nrows >= 8 * out->lanes[(size_t)bkc.lane].t->nrows) {
+                    const bool ordered = pkc.ordered;
+                    const int domain = pkc.domain;
+                    pkc = bkc;
+                    pkc.ordered = ordered;
+                    pkc.domain = domain;
+                }
+            }
         }
         finish(out, all);
         // late materialisation, ONCE: a sparse row-id vector into a big table — every column the operators above

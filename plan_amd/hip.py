@@ -958,3 +958,9 @@ def table_col_stats(table, c):
 
 def table_declare_unique(table, cols):
     check(lib().ph_table_declare_unique(table.h, i32(len(cols)), _i32arr(cols)))
+
+
+def table_col_range_of(table, c):
+    mn, mx = i64(), i64()
+    check(lib().ph_table_col_range(table.h, i32(c), ctypes.byref(mn), ctypes.byref(mx)))
+    return mn.value, mx.value

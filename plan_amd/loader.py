@@ -87,3 +87,54 @@ def table_from_parquet(ctx, path, columns=None):
     executor_scan.go:61-143) and loads them resident."""
     import pyarrow.parquet as pq
     return table_from_arrow(ctx, pq.read_table(path, columns=columns), columns)
+
+
+# ---------------------------------------------------------------- through the C-ABI (Arrow C data interface)
+
+class _ArrowSchema(__import__("ctypes").Structure):
+    pass
+
+
+class _ArrowArray(__import__("ctypes").Structure):
+    pass
+
+
+def _declare_arrow_structs():
+    import ctypes
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    _ArrowSchema._fields_ = [("format", ctypes.c_char_p), ("name", ctypes.c_char_p), ("metadata", vp), ("flags", i64), ("n_children", i64),
+                             ("children", vp), ("dictionary", vp), ("release", ctypes.CFUNCTYPE(None, ctypes.POINTER(_ArrowSchema))), ("private_data", vp)]
+    _ArrowArray._fields_ = [("length", i64), ("null_count", i64), ("offset", i64), ("n_buffers", i64), ("n_children", i64), ("buffers", vp),
+                            ("children", vp), ("dictionary", vp), ("release", ctypes.CFUNCTYPE(None, ctypes.POINTER(_ArrowArray))), ("private_data", vp)]
+
+
+_declare_arrow_structs()
+
+
+def table_from_arrow_c(ctx, tbl, columns=None):
+    """pyarrow.Table / RecordBatch -> resident table through ph_table_create_arrow: the batch is exported with the Arrow C data
+    interface (what Go's arrow/cdata or any parquet reader hands a C library) and the LIBRARY maps the buffers to the device
+    encodings — the load path a host without Python uses. Returns a hip.Table (column_names, dictionaries attached)."""
+    import ctypes
+    import pyarrow as pa
+    if isinstance(tbl, pa.Table):
+        names = list(columns) if columns is not None else tbl.column_names
+        tbl = tbl.select(names).combine_chunks()
+        batch = tbl.to_batches()[0] if tbl.num_rows else pa.RecordBatch.from_pylist([], schema=tbl.schema)
+    else:
+        batch = tbl
+    sch, arr = _ArrowSchema(), _ArrowArray()
+    batch._export_to_c(ctypes.addressof(arr), ctypes.addressof(sch))
+    t = hip.Table.__new__(hip.Table)
+    t.ctx, t.h = ctx, hip.vp()
+    try:
+        hip.check(hip.lib().ph_table_create_arrow(ctx.h, ctypes.byref(sch), ctypes.byref(arr), None, hip.i32(0), ctypes.byref(t.h)))
+    finally:
+        arr.release(ctypes.byref(arr))      # the consumer releases what it was given (C data interface protocol)
+        sch.release(ctypes.byref(sch))
+    t.nrows, t.ncols, t.column_names = batch.num_rows, batch.num_columns, batch.schema.names
+    lib = hip.lib()
+    lib.ph_table_dict_entry.restype = ctypes.c_char_p
+    t.dicts = [[lib.ph_table_dict_entry(t.h, hip.i32(c), hip.i32(k)).decode() for k in range(max(lib.ph_table_dict_size(t.h, hip.i32(c)), 0))]
+               for c in range(t.ncols)]
+    return t

@@ -15,8 +15,9 @@ TESTER = os.path.join(ROOT, "plan_amd", "host_tester")
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def run(*args):
-    return subprocess.run([TESTER, *args], check=True, capture_output=True, text=True, timeout=600).stdout
+def run(*args, env=None):
+    e = dict(os.environ, **env) if env else None
+    return subprocess.run([TESTER, *args], check=True, capture_output=True, text=True, timeout=600, env=e).stdout
 
 
 def test_chunk_serialize_roundtrip_and_value_text():
@@ -172,15 +173,25 @@ def test_left_join_executor(sf001):
 
 
 @pytest.mark.gpu
-def test_order_executor(sf001):
+@pytest.mark.parametrize("host_rows", ["0", "2048"])
+def test_order_executor(sf001, host_rows):
     """gpuOrderExecutor (orderExecutor, executor_order.go:56-138): customer ordered by
-    c_mktsegment DESC (VARCHAR key), c_custkey % 97, c_custkey DESC."""
+    c_mktsegment DESC (VARCHAR key), c_custkey % 97, c_custkey DESC — 1500 rows through the device sort
+    (PH_ORDER_HOST_ROWS=0) and through the host form small inputs take: the same order."""
     C = sf001["customer"]
     segs = [tpchgen.MKTSEGMENT_DICT[c] for c in C["c_mktsegment"]]
     rows = sorted(zip(segs, (C["c_custkey"] % 97).tolist(), C["c_custkey"].tolist()),
                   key=lambda r: ([-b for b in r[0].encode()] + [1], r[1], -r[2]))
-    got = [tuple(l.split("\t")) for l in run("order", "1", "100").split("\n")[1:] if l]
+    got = [tuple(l.split("\t")) for l in run("order", "1", "100", env={"PH_ORDER_HOST_ROWS": host_rows}).split("\n")[1:] if l]
     assert got == [(s, str(a), str(b)) for s, a, b in rows]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", ["q3", "q9", "q1"])
+def test_order_by_tail_through_the_device_sort_matches_goldens(q):
+    """the ORDER BY tails of the goldens ((DECIMAL desc, DATE) + LIMIT; (VARCHAR, INTEGER desc); (VARCHAR, VARCHAR)) with the
+    host form switched off: ph_sort_rows orders the group rows"""
+    assert run(q, "1", "1", env={"PH_ORDER_HOST_ROWS": "0"}) == open(os.path.join(G, f"plan_{q}.txt")).read()
 
 
 def run_err(*args):
