@@ -298,6 +298,26 @@ int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, const int32_t 
 int ph_substring(ph_ctx *ctx, const ph_col *col, int64_t offset, int64_t length, const int32_t *sel, int64_t n,
                  int32_t *out_offsets_dev, uint8_t *out_bytes_dev, int64_t out_bytes_capacity, int64_t *out_bytes);
 
+/* ------------------------------------------------------------------ string keys
+ * VARCHAR group-by / join keys that are not <= 256-value dictionaries (PH_STR columns). The reference hashes them with
+ * util.HashBytes (pkg/chunk/hash.go:182-207, pkg/util/hash.go:13-65) and compares candidates byte by byte (Match,
+ * pkg/compute/util_match.go:25-301) inside its group table and its join table. On the device both steps are ONE
+ * primitive, string interning: every row's string is looked up in an open-addressing table keyed by the same hash and
+ * verified by the same byte compare; the first row to claim a slot becomes the string's representative, and every row
+ * gets the representative's ROW ID as its int32 code. Equal strings have equal codes, different strings different
+ * codes (colliding hashes included: the compare decides), so ph_agg_* and ph_join_* run unchanged on the codes
+ * (PH_I32 columns carrying the string column's validity), and a code leads back to the bytes (ph_table_strings).
+ * ph_strdict_build: codes of rows sel[0..n) / 0..n of `col` (which must outlive the dictionary); NULL rows get -1.
+ * ph_strdict_lookup: codes of another column's rows in that dictionary; absent strings and NULL rows get -2. */
+typedef struct ph_strdict ph_strdict;
+int ph_strdict_build(ph_ctx *ctx, const ph_col *col, const int32_t *sel, int64_t n, int32_t *codes_out_dev, ph_strdict **out);
+int ph_strdict_lookup(ph_strdict *d, const ph_col *col, const int32_t *sel, int64_t n, int32_t *codes_out_dev);
+void ph_strdict_free(ph_strdict *d);
+/* strings of rows rows_host[0..n) of PH_STR column c of a resident table (group keys that came back as codes):
+ * out_offsets n+1 int32 into out_bytes */
+int ph_table_strings(ph_ctx *ctx, const ph_table *t, int32_t c, const int64_t *rows_host, int64_t n, int32_t *out_offsets, char *out_bytes,
+                     int64_t out_capacity);
+
 /* ------------------------------------------------------------------ hash aggregate
  * GroupedAggrHashTable.AddChunk/FindOrCreateGroups + UpdateStates + FinalizeStates
  * (pkg/compute/aggregate_hash.go:136-391, aggregate_exec.go:456-475,
@@ -340,6 +360,12 @@ int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *args, int32_
  * table with ph_agg_sink_masked. Returns the group count through *ngroups. */
 int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev, uint8_t *out_validity_dev,
                     int64_t capacity, int64_t *ngroups);
+/* Aggregate `agg_index` of all current groups, in group-id order, as a dense DEVICE column of int64 (SUM: the sum, PH_EOVERFLOW
+ * when one exceeds int64; COUNT / COUNT_STAR: the count; MIN / MAX: the value) plus a validity bitmap (a group no input
+ * reached is NULL, as SumOp / CountOp / MinMaxOp.Finalize make it, function_aggr.go:813-823, 950-962). Together with
+ * ph_agg_keys_dev this turns an aggregate into a device-resident relation: an aggregate BELOW other operators (a
+ * subquery's GROUP BY .. HAVING under a join) never travels through the host. AVG: PH_EUNSUPPORTED. */
+int ph_agg_values_dev(ph_agg *a, int32_t agg_index, int64_t *out_dev, uint8_t *out_validity_dev, int64_t capacity, int64_t *ngroups);
 /* Streaming aggregate (the planner's StreamAggregate): the FIRST sink into an empty table whose n rows
  * (positions 0..n of keys and args: no selection) arrive ordered by the group-key tuple — e.g. the
  * output of a join whose probe side is clustered by the key. Every group is then one run of adjacent

@@ -396,6 +396,103 @@ int32_t oracle_q19(const oracle_tpch *T, odec *revenue) {
     return res;
 }
 
+/* ------------------------------------------------------------------ Q18
+ * Limit <- Order <- Agg(c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice; sum(l_quantity))
+ *   <- Join(l_orderkey = o_orderkey) probe lineitem, build <- Join(o_custkey = c_custkey) probe <- SemiJoin(o_orderkey = l_orderkey)
+ *      probe orders, build Filter(sum > k) <- Agg(l_orderkey; sum(l_quantity)) <- lineitem;   build customer */
+int64_t oracle_q18(const oracle_tpch *T, const int64_t *o_totalprice, int64_t qty_gt, oracle_q18_row *out, int64_t max) {
+    /* the subquery: group lineitem by l_orderkey, HAVING sum(l_quantity) > k (sum(INTEGER) is a HUGEINT; '>' exists for it) */
+    ocol kproto[1] = {mkcol(OT_INT64, 0, NULL)};
+    ocol aproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *sub = oracle_agg_create(kproto, 1, aproto, aggs, 1);
+    int rc = 0;
+    for (int64_t base = 0; base < T->n_lineitem && rc == 0; base += VS) {
+        int64_t cnt = T->n_lineitem - base < VS ? T->n_lineitem - base : VS;
+        ocol keys[1] = {mkcol(OT_INT64, 0, T->l_orderkey + base)};
+        ocol args[1] = {mkcol(OT_INT32, 0, T->l_quantity + base)};
+        rc = oracle_agg_sink(sub, keys, args, NULL, cnt);
+    }
+    if (rc) { oracle_agg_free(sub); return -1; }
+    int64_t ngs = oracle_agg_count(sub), nbig = 0;
+    int64_t *big = i64buf(ngs);
+    for (int64_t g = 0; g < ngs; g++) {
+        int64_t kv[1];
+        oaggval v;
+        oracle_agg_group(sub, g, NULL, kv, NULL, &v);
+        if (v.kind == OV_HUGEINT && (v.h.upper > 0 || (v.h.upper == 0 && v.h.lower > (uint64_t)qty_gt))) big[nbig++] = kv[0];
+    }
+    oracle_agg_free(sub);
+    ocol bk = mkcol(OT_INT64, 0, big);
+    ojoin *js = oracle_join_build(&bk, 1, NULL, nbig);
+    uint8_t *found = (uint8_t *)malloc((size_t)(T->n_orders > 0 ? T->n_orders : 1));
+    ocol ok = mkcol(OT_INT64, 0, T->o_orderkey);
+    oracle_join_probe_mark(js, &ok, 1, NULL, T->n_orders, found);            /* SEMI: the orders with a qualifying key */
+    oracle_join_free(js);
+    int64_t *osel = i64buf(T->n_orders), no = 0;
+    for (int64_t i = 0; i < T->n_orders; i++) if (found[i]) osel[no++] = i;
+    /* x customer */
+    ocol ck = mkcol(OT_INT32, 0, T->c_custkey);
+    ojoin *jc = oracle_join_build(&ck, 1, NULL, T->n_customer);
+    int64_t *o_row = i64buf(no), *c_row = i64buf(no);
+    ocol oc = mkcol(OT_INT32, 0, T->o_custkey);
+    int64_t n1 = oracle_join_probe_inner(jc, &oc, 1, osel, no, o_row, c_row, no);
+    oracle_join_free(jc);
+    /* lineitem x that */
+    int64_t *bkey = i64buf(n1);
+    for (int64_t i = 0; i < n1; i++) bkey[i] = T->o_orderkey[o_row[i]];
+    ocol bkc = mkcol(OT_INT64, 0, bkey);
+    ojoin *jo = oracle_join_build(&bkc, 1, NULL, n1);
+    int64_t cap = T->n_lineitem;
+    int64_t *l_row = i64buf(cap), *b_pos = i64buf(cap);
+    ocol lk = mkcol(OT_INT64, 0, T->l_orderkey);
+    int64_t n2 = oracle_join_probe_inner(jo, &lk, 1, NULL, T->n_lineitem, l_row, b_pos, cap);
+    oracle_join_free(jo);
+    /* final aggregate. c_name = 'Customer#' + nine digits of the key: a VARCHAR group key — hashed and compared as bytes through a
+     * dictionary built over the (few) names that reach the aggregate */
+    char (*names)[20] = (char (*)[20])malloc(sizeof(char[20]) * (size_t)(n1 > 0 ? n1 : 1));
+    const char **dict = (const char **)malloc(sizeof(char *) * (size_t)(n1 > 0 ? n1 : 1));
+    if (n1 > 255) { n2 = 0; rc = 1; }   /* the dictionary stand-in covers the handful of orders this query keeps */
+    for (int64_t i = 0; i < n1 && i < 256; i++) { snprintf(names[i], 20, "Customer#%09d", T->c_custkey[c_row[i]]); dict[i] = names[i]; }
+    ocol kp[5] = {mkcode(NULL, dict), mkcol(OT_INT32, 0, NULL), mkcol(OT_INT64, 0, NULL), mkcol(OT_DATE, 0, NULL), mkcol(OT_DECIMAL, 2, NULL)};
+    ocol ap[1] = {mkcol(OT_INT32, 0, NULL)};
+    oagg *t = oracle_agg_create(kp, 5, ap, aggs, 1);
+    uint8_t nm[VS];
+    int32_t ckv[VS], odv[VS], qty[VS];
+    int64_t okv[VS], tpv[VS];
+    for (int64_t base = 0; base < n2 && rc == 0; base += VS) {
+        int64_t cnt = n2 - base < VS ? n2 - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            int64_t b = b_pos[base + j], o = o_row[b];
+            nm[j] = (uint8_t)b;                                   /* code of the order's customer name (one dictionary entry per kept order) */
+            ckv[j] = T->c_custkey[c_row[b]];
+            okv[j] = T->o_orderkey[o];
+            odv[j] = T->o_orderdate[o];
+            tpv[j] = o_totalprice[o];
+            qty[j] = T->l_quantity[l_row[base + j]];
+        }
+        ocol keys[5] = {mkcode(nm, dict), mkcol(OT_INT32, 0, ckv), mkcol(OT_INT64, 0, okv), mkcol(OT_DATE, 0, odv), mkcol(OT_DECIMAL, 2, tpv)};
+        ocol args[1] = {mkcol(OT_INT32, 0, qty)};
+        rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[5];
+        oaggval v;
+        oracle_agg_group(t, g, NULL, kv, NULL, &v);
+        out[g].c_custkey = (int32_t)kv[1];
+        out[g].o_orderkey = kv[2];
+        out[g].o_orderdate = (int32_t)kv[3];
+        out[g].o_totalprice = kv[4];
+        out[g].sum_qty = v.h;
+    }
+    oracle_agg_free(t);
+    free(big); free(found); free(osel); free(o_row); free(c_row); free(bkey); free(l_row); free(b_pos); free(names); free(dict);
+    return ng;
+}
+
+int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);
+
 /* ------------------------------------------------------------------ text */
 typedef struct { char *buf; int64_t cap, len; } sbuf2;
 static void put(sbuf2 *s, const char *t) {
@@ -482,5 +579,28 @@ int64_t oracle_q19_text(const odec *revenue, int is_null, char *buf, int64_t cap
     if (is_null) put(&s, "NULL");
     else { oracle_format_decimal(*revenue, 4, t); put(&s, t); }
     put(&s, "\n");
+    return done(&s);
+}
+
+int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\t\t\t\t\n");
+    int64_t *tp = i64buf(n), *ord = i64buf(n);
+    int32_t *od = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) { tp[i] = rows[i].o_totalprice; od[i] = rows[i].o_orderdate; }
+    ocol k[2] = {mkcol(OT_DECIMAL, 2, tp), mkcol(OT_DATE, 0, od)};
+    int32_t desc[2] = {1, 0};
+    oracle_sort_rows(k, desc, 2, NULL, n, ord, NULL, NULL);          /* ORDER BY o_totalprice DESC, o_orderdate */
+    char t[64];
+    for (int64_t i = 0; i < n && i < limit; i++) {
+        const oracle_q18_row *r = &rows[ord[i]];
+        snprintf(t, sizeof t, "Customer#%09d\t%d\t%lld\t", r->c_custkey, r->c_custkey, (long long)r->o_orderkey); put(&s, t);
+        oracle_format_date(r->o_orderdate, t); put(&s, t); put(&s, "\t");
+        odec d;
+        odec_new(r->o_totalprice, 2, &d);
+        oracle_format_decimal(d, 2, t); put(&s, t); put(&s, "\t");
+        oracle_format_hugeint(r->sum_qty, t); put(&s, t); put(&s, "\n");
+    }
+    free(tp); free(ord); free(od);
     return done(&s);
 }

@@ -339,7 +339,7 @@ typedef struct { /* State[T] (function_aggr.go:420-425) */
     double f;
 } agg_state;
 
-#define AGG_MAX_KEYS 4
+#define AGG_MAX_KEYS 8
 #define AGG_MAX_AGGS 16
 
 struct oagg {

@@ -342,6 +342,13 @@ int64_t oracle_q12(const oracle_tpch *T, const char *mode1, const char *mode2, i
  * binder types it (the literal is FLOAT; MaxLType(FLOAT, DECIMAL) = FLOAT): returns 0 ok, 1 NULL sums, -1 decimal error */
 int32_t oracle_q14(const oracle_tpch *T, const char *like_pattern, int32_t date_ge, int32_t date_lt, float *promo_revenue, odec *promo, odec *total);
 int32_t oracle_q19(const oracle_tpch *T, odec *revenue);   /* the query's own constants; 0 ok, 1 NULL, -1 error */
+/* Q18 (cases/tpch/query/q18.sql): the IN (select l_orderkey .. group by l_orderkey having sum(l_quantity) > k) subquery as a
+ * SEMI join against an aggregate with HAVING (HUGEINT '>': greatHugeintOp), then customer x orders x lineitem grouped by the five
+ * select-list columns — c_name a VARCHAR key (hash = util.HashBytes, compare bytes). o_totalprice unscaled at scale 2. */
+typedef struct { int32_t c_custkey; int64_t o_orderkey; int32_t o_orderdate; int64_t o_totalprice; ohuge sum_qty; } oracle_q18_row;
+typedef struct { const int64_t *o_totalprice; } oracle_tpch_q18_extra;
+int64_t oracle_q18(const oracle_tpch *T, const int64_t *o_totalprice, int64_t qty_gt, oracle_q18_row *out, int64_t max);
+int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);   /* ORDER BY o_totalprice DESC, o_orderdate LIMIT */
 int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY o_orderpriority */
 int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY revenue DESC */
 int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);  /* ORDER BY l_shipmode */

@@ -578,6 +578,28 @@ __global__ __launch_bounds__(256) void agg_keys_kernel(const unsigned long long 
     if (valid) valid[g0 >> 3] = (uint8_t)bits;
 }
 
+// aggregate a of all groups -> dense int64 column + validity bits (a group no input reached is NULL); a thread converts 8 groups.
+// flag |= 1 when a SUM does not fit int64
+__global__ __launch_bounds__(256) void agg_values_kernel(const unsigned long long *__restrict__ sum_lo, const long long *__restrict__ sum_hi,
+                                                         const unsigned long long *__restrict__ cnt, int naggs, int a, int kind, int ng,
+                                                         long long *__restrict__ out, uint8_t *__restrict__ valid, int *__restrict__ flag) {
+    const int g0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (g0 >= ng) return;
+    unsigned bits = 0;
+    bool wide = false;
+    for (int j = 0; j < 8 && g0 + j < ng; j++) {
+        const int64_t st = (int64_t)(g0 + j) * naggs + a;
+        const unsigned long long c = cnt[st];
+        const bool counting = kind == PH_A_COUNT || kind == PH_A_COUNT_STAR;
+        if (c != 0) bits |= 1u << j;          // SumOp / CountOp / MinMaxOp.Finalize: NULL when never set (COUNT: when 0)
+        const long long lo = (long long)sum_lo[st];
+        if (kind == PH_A_SUM && c != 0 && sum_hi[st] != (lo >> 63)) wide = true;
+        out[g0 + j] = counting ? (long long)c : lo;
+    }
+    if (valid) valid[g0 >> 3] = (uint8_t)bits;
+    if (wide) atomicOr(flag, 1);
+}
+
 }  // namespace ph
 
 struct ph_agg {
@@ -1116,6 +1138,29 @@ extern "C" int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev,
                                                                               a->key_types[key_index], (int)ng, out_data_dev,
                                                                               out_validity_dev);
     PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+extern "C" int ph_agg_values_dev(ph_agg *a, int32_t agg_index, int64_t *out_dev, uint8_t *out_validity_dev, int64_t capacity, int64_t *ngroups) {
+    PH_REQUIRE(a && ngroups && agg_index >= 0 && agg_index < a->naggs && capacity >= 0, "ph_agg_values_dev: bad arguments");
+    const int kind = a->aggs[agg_index].kind;
+    if (kind == PH_A_AVG) { ph::set_error("ph_agg_values_dev: AVG is a quotient the caller owns (sum and count are separate aggregates)"); return PH_EUNSUPPORTED; }
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(a, &ng));
+    *ngroups = ng;
+    if (ng > capacity) { ph::set_error("ph_agg_values_dev: %lld groups, room for %lld", (long long)ng, (long long)capacity); return PH_ECAPACITY; }
+    if (ng == 0) return PH_OK;
+    PH_REQUIRE(out_dev, "ph_agg_values_dev: out_dev is NULL");
+    int *flag = nullptr;
+    PH_CHECK(a->ctx->pool_alloc(16, (void **)&flag));
+    PH_HIP(hipMemsetAsync(flag, 0, 4, a->ctx->stream));
+    ph::agg_values_kernel<<<(int)((ng + 2047) / 2048), 256, 0, a->ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, kind, (int)ng,
+                                                                                (long long *)out_dev, out_validity_dev, flag);
+    int wide = 0;
+    int rc = hipGetLastError() == hipSuccess ? a->ctx->download(&wide, flag, 4) : PH_EHIP;
+    a->ctx->pool_release(flag);
+    PH_CHECK(rc);
+    if (wide) { ph::set_error("ph_agg_values_dev: a sum does not fit int64"); return PH_EOVERFLOW; }
     return PH_OK;
 }
 

@@ -90,6 +90,8 @@ struct Node {
 struct Domain { ph_join *j; int64_t nkeys; };
 
 struct KeyInfo { int32_t type = 0, scale = 0; const ph_table *table = nullptr; int32_t col = -1; };
+// where original group key k lives in the aggregate's key words: part 0 = a whole word, 1 = the high half, 2 = the low half (biased by 2^31)
+struct KeyPack { int word; int part; };
 
 }  // namespace
 
@@ -103,10 +105,13 @@ struct ph_plan {
     bool ran = false;
     std::vector<void *> temps;
     std::vector<ph_join *> joins;
+    std::vector<ph_strdict *> strdicts;
+    std::vector<ph_agg *> inner_aggs;   // aggregates below other operators
     std::vector<Domain> domains;
     ph_agg *agg = nullptr;
     ph_scan_plan *scan = nullptr;       // Agg <- Scan: the fused scan plan
     std::vector<KeyInfo> keys;
+    std::vector<KeyPack> key_packs;     // how the result's key words unpack into the original group keys
     std::vector<int32_t> agg_scale, agg_arg_type;
     std::string explain;
     int64_t expected_groups = 1024;
@@ -139,6 +144,10 @@ int palloc(ph_plan *p, int64_t bytes, void **out) {
 void release_run(ph_plan *p, bool keep_agg) {
     for (ph_join *j : p->joins) ph_join_free(j);
     p->joins.clear();
+    for (ph_strdict *d : p->strdicts) ph_strdict_free(d);
+    p->strdicts.clear();
+    for (ph_agg *a : p->inner_aggs) ph_agg_free(a);
+    p->inner_aggs.clear();
     p->domains.clear();
     for (void *q : p->temps) p->ctx->pool_release(q);
     p->temps.clear();
@@ -164,6 +173,12 @@ ph_col col_view(const Rel &r, const PCol &c, const int32_t **sel) {
     v.type = c.type; v.scale = c.scale; v.data = c.data; v.validity = c.validity;
     *sel = nullptr;
     return v;
+}
+
+// an INTEGER literal against a DECIMAL column (or a HUGEINT aggregate carried as a scale-0 decimal) is cast to the column's
+// type by the binder (DecimalSizeCheck + tryCastInt32ToDecimal, ltype.go:601-624, function_cast.go:337-347)
+void fix_num_const(const ph_col &v, ph_const *k) {
+    if (v.type == PH_DEC64 && k->type == PH_I32) { k->type = PH_DEC64; k->scale = 0; }
 }
 
 // a string literal against a dictionary-code column: the code of the literal (999 = not in the dictionary)
@@ -260,6 +275,7 @@ int eval_bool(ph_plan *p, Rel *r, bool table_mode, const BoolTree &bt, int idx, 
             else if (!sels.empty()) PL_CHECK(ph_sel_union(ctx, sels.data(), counts.data(), (int32_t)sels.size(), N, (int32_t *)out, &m));
         } else {
             fix_dict_const(dt, dc, &k);
+            fix_num_const(v, &k);
             PL_CHECK(ph_filter_select(ctx, &v, N, b.op, &k, sel_in, n_in, (int32_t *)out, &m));
         }
         *sel_out = (const int32_t *)out;
@@ -316,6 +332,7 @@ int apply_pending(ph_plan *p, Rel *r) {
         ph_pred pr = r->pending[i];
         fix_dict_const(t, pr.col, &pr.k);
         ph_col v = table_view(t, pr.col);
+        fix_num_const(v, &pr.k);
         void *out = nullptr;
         PL_CHECK(palloc(p, cnt * 4, &out));
         int64_t m = 0;
@@ -597,6 +614,30 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
     }
 }
 
+// ---- VARCHAR keys: a PH_STR column of the relation becomes a positional int32 column of string codes (ph_strdict_*):
+// equal strings, equal codes. dict == nullptr: intern the column's own rows (a group key, a join's build key; *dict_out
+// receives the dictionary); else look the rows up in that dictionary (a join's probe key).
+int string_codes(ph_plan *p, Rel *r, int c, ph_strdict *dict, ph_strdict **dict_out, PCol *out) {
+    PL_CHECK(apply_pending(p, r));
+    const PCol &pc = r->cols[(size_t)c];
+    if (pc.lane < 0) { set_error("ph_plan: a VARCHAR key must be a table column (offsets + bytes cannot be gathered)"); return PH_EUNSUPPORTED; }
+    const Lane &ln = r->lanes[(size_t)pc.lane];
+    ph_col v = table_view(ln.t, pc.tcol);
+    void *codes = nullptr;
+    PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &codes));
+    if (dict) PL_CHECK(ph_strdict_lookup(dict, &v, ln.rows, r->n, (int32_t *)codes));
+    else {
+        ph_strdict *d = nullptr;
+        PL_CHECK(ph_strdict_build(p->ctx, &v, ln.rows, r->n, (int32_t *)codes, &d));
+        p->strdicts.push_back(d);
+        if (dict_out) *dict_out = d;
+    }
+    *out = PCol{};
+    out->type = PH_I32; out->data = codes;
+    out->src = ln.t; out->src_col = pc.tcol;   // a code is a row of this column: where the host finds the string
+    return PH_OK;
+}
+
 // ---- is the (multi-column) key of this relation unique? only base-table keys the statistics or the catalog vouch for
 // 0 = no; 2 = the key IS a unique column set (a foreign key into it finds exactly one row); 1 = it CONTAINS one (still at
 // most one match, but the extra columns act as a filter: misses are expected)
@@ -628,6 +669,8 @@ int key_unique(const Rel &r, const std::vector<int32_t> &keys) {
 }
 
 int lower(ph_plan *p, int idx, bool as_build, Rel *out);
+int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, std::vector<KeyInfo> *kinfo, std::vector<int32_t> *ascale,
+                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs);
 
 struct KeySide {            // the key columns of one join side as the kernels want them
     std::vector<ph_col> views;
@@ -688,17 +731,45 @@ int pair_probe(ph_plan *p, ph_join *j, const KeySide &pk, const ph_pred *where, 
     return PH_ECAPACITY;
 }
 
+int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out);
+
 // ---- HashJoin
 int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
-    const Node &nd = p->nodes[(size_t)idx];
-    ph_ctx *ctx = p->ctx;
     Rel P, B;
-    PL_CHECK(lower(p, nd.child[0], false, &P));
-    PL_CHECK(lower(p, nd.child[1], true, &B));
+    PL_CHECK(lower(p, p->nodes[(size_t)idx].child[0], false, &P));
+    PL_CHECK(lower(p, p->nodes[(size_t)idx].child[1], true, &B));
+    return join_rels(p, idx, p->nodes[(size_t)idx], P, B, as_build, out);
+}
+
+int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out) {
+    ph_ctx *ctx = p->ctx;
     const size_t nP = P.cols.size(), nB = B.cols.size();
     const size_t nk = nd.pkeys.size();
+    // VARCHAR key pairs: the build side's strings are interned, the probe side's looked up in that dictionary; the join
+    // then runs on the int32 codes. The code columns REPLACE the string columns in the working copies of the key lists
+    // (the relations' own columns, which the output picks from, stay as they are).
+    Node ndx = nd;
+    bool has_str = false;
     for (size_t k = 0; k < nk; k++) {
         if (nd.pkeys[k] < 0 || (size_t)nd.pkeys[k] >= nP || nd.bkeys[k] < 0 || (size_t)nd.bkeys[k] >= nB) { set_error("ph_plan: join key out of range"); return PH_EINVAL; }
+        if (P.cols[(size_t)nd.pkeys[k]].type == PH_STR && B.cols[(size_t)nd.bkeys[k]].type == PH_STR) has_str = true;
+    }
+    if (has_str) {
+        for (size_t k = 0; k < nk; k++) {
+            if (P.cols[(size_t)nd.pkeys[k]].type != PH_STR) continue;
+            ph_strdict *d = nullptr;
+            PCol bc, pc;
+            PL_CHECK(string_codes(p, &B, nd.bkeys[k], nullptr, &d, &bc));
+            PL_CHECK(string_codes(p, &P, nd.pkeys[k], d, nullptr, &pc));
+            bc.src = nullptr; pc.src = nullptr;   // codes of two different columns: no shared provenance, no statistics
+            B.cols.push_back(bc); ndx.bkeys[k] = (int32_t)B.cols.size() - 1;
+            P.cols.push_back(pc); ndx.pkeys[k] = (int32_t)P.cols.size() - 1;
+        }
+        // the output indexes address [P's original columns | B's original columns]: re-base the build half behind P's new width
+        for (auto &o : ndx.out) if ((size_t)o >= nP) o = (int32_t)((size_t)o - nP + P.cols.size());
+        return join_rels(p, idx, ndx, P, B, as_build, out);
+    }
+    for (size_t k = 0; k < nk; k++) {
         const int a = P.cols[(size_t)nd.pkeys[k]].type, b = B.cols[(size_t)nd.bkeys[k]].type;
         if (width_of(a) == 0 || width_of(a) != width_of(b)) { set_error("ph_plan: join key %zu types differ or are VARCHAR (%d / %d)", k, a, b); return PH_EUNSUPPORTED; }
     }
@@ -1108,6 +1179,7 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
             fix_dict_const(pc.src, pc.src_col, &pr.k);
             const int32_t *s = nullptr;
             ph_col v = col_view(*out, pc, &s);
+            fix_num_const(v, &pr.k);
             void *o = nullptr;
             PL_CHECK(palloc(p, cnt * 4, &o));
             int64_t m = 0;
@@ -1146,11 +1218,185 @@ int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
         note(p, "project#%d: %zu expressions", idx, nd.exprs.size());
         return PH_OK;
     }
+    case PH_PN_AGG: {
+        // an aggregate BELOW other operators (a subquery's GROUP BY [.. HAVING = the Filter above it] under a join): its groups
+        // become a device-resident relation — key columns and aggregate values as positional columns — and never visit the host
+        Rel R;
+        PL_CHECK(lower(p, nd.child[0], false, &R));
+        ph_agg *agg = nullptr;
+        std::vector<KeyInfo> kinfo;
+        std::vector<int32_t> ascale, atype;
+        std::vector<KeyPack> packs;
+        int rc = sink_into_agg(p, idx, R, false, &agg, &kinfo, &ascale, &atype, &packs);
+        if (agg) p->inner_aggs.push_back(agg);
+        PL_CHECK(rc);
+        int64_t ng = 0;
+        PL_CHECK(ph_agg_group_count(agg, &ng));
+        *out = Rel{};
+        out->n = ng;
+        out->covers = false;
+        for (size_t k = 0; k < nd.groups.size(); k++) {
+            PCol c;
+            c.type = kinfo[k].type; c.scale = kinfo[k].scale; c.src = kinfo[k].table; c.src_col = kinfo[k].col;
+            if (c.type == PH_STR) { set_error("ph_plan: VARCHAR keys of an aggregate below other operators"); return PH_EUNSUPPORTED; }
+            void *d = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(ng, 1) * 8, &d));
+            int64_t n2 = 0;
+            PL_CHECK(ph_agg_keys_dev(agg, (int32_t)k, d, nullptr, ng, &n2));
+            c.data = d;
+            out->cols.push_back(c);
+        }
+        for (size_t a = 0; a < nd.aggs.size(); a++) {
+            PCol c;
+            // SUM / COUNT results are HUGEINT (integer input) or DECIMAL: both travel as int64 at the argument's scale — a scale-0
+            // decimal stands in for the HUGEINT, whose one comparison ('>') DECIMAL has too (function_operator_boolean.go:431-442)
+            const bool minmax = nd.aggs[a].kind == PH_A_MIN || nd.aggs[a].kind == PH_A_MAX;
+            c.type = minmax && (atype[a] == PH_I32 || atype[a] == PH_DATE) ? PH_I64 : PH_DEC64;
+            c.scale = nd.aggs[a].kind == PH_A_COUNT || nd.aggs[a].kind == PH_A_COUNT_STAR ? 0 : ascale[a];
+            void *d = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(ng, 1) * 8, &d));
+            int64_t n2 = 0;
+            PL_CHECK(ph_agg_values_dev(agg, (int32_t)a, (int64_t *)d, nullptr, ng, &n2));
+            c.data = d;
+            out->cols.push_back(c);
+        }
+        note(p, "agg#%d: %lld groups stay on the device as a relation (%zu keys, %zu aggregates)", idx, (long long)ng, nd.groups.size(), nd.aggs.size());
+        return PH_OK;
+    }
     default:
         set_error("ph_plan: node %d has kind %d, which cannot be a child", idx, nd.kind);
         return PH_EINVAL;
     }
 }
+
+// ---- one relation into one aggregate table (aggExecutor's build phase: executeExprs for the group keys and the aggregate
+// arguments, then Sink; executor_aggr.go:110-142). Used by the root and by aggregates below other operators.
+int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, std::vector<KeyInfo> *kinfo, std::vector<int32_t> *ascale,
+                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs) {
+    const Node &nd = p->nodes[(size_t)idx];
+    ph_ctx *ctx = p->ctx;
+    PL_CHECK(apply_pending(p, &R));
+    // group keys and aggregate arguments as columns of the relation
+    std::vector<PCol> kc(nd.groups.size()), ac(nd.aggs.size());
+    std::vector<bool> str_key(nd.groups.size(), false);
+    for (size_t g = 0; g < nd.groups.size(); g++) {
+        PL_CHECK(eval_expr(p, &R, nd.groups[g], &kc[g]));
+        if (kc[g].type == PH_STR) {   // a VARCHAR key: group by the string's code (its representative row in the column)
+            if (nd.groups[g].e.kind != PH_PE_COL) { set_error("ph_plan: VARCHAR group key must be a column"); return PH_EUNSUPPORTED; }
+            PL_CHECK(string_codes(p, &R, nd.groups[g].e.col, nullptr, nullptr, &kc[g]));
+            str_key[g] = true;
+        }
+    }
+    for (size_t a = 0; a < nd.aggs.size(); a++) {
+        if (nd.aggs[a].kind == PH_A_COUNT_STAR) continue;
+        PL_CHECK(eval_expr(p, &R, nd.aggs[a].arg, &ac[a]));
+    }
+    // everything positional: the sink reads position i of every key and argument
+    Rel S = R;
+    S.cols.clear();
+    for (auto &c : kc) S.cols.push_back(c);
+    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind != PH_A_COUNT_STAR) S.cols.push_back(ac[a]);
+    std::vector<int> all;
+    for (size_t c = 0; c < S.cols.size(); c++) if (S.cols[c].lane >= 0) all.push_back((int)c);
+    PL_CHECK(positional(p, &S, all));
+    std::vector<ph_col> keys, args(nd.aggs.size());
+    std::vector<int32_t> key_types;
+    size_t ci = nd.groups.size();
+    packs->clear();
+    {
+        // The aggregate table holds up to four 8-byte key words. More group keys than that (Q18 groups by five columns) are
+        // PACKED: two 4-byte keys without NULLs share one word, high * 2^32 + (low + 2^31) — exact in int64, and unpacked
+        // again when the result is fetched.
+        std::vector<int> word_of(nd.groups.size(), -1);
+        std::vector<std::pair<int, int>> words;   // (key, partner or -1)
+        size_t nwords = nd.groups.size();
+        auto narrow = [&](size_t g) { const PCol &c = S.cols[g]; return (c.type == PH_I32 || c.type == PH_DATE) && !c.validity; };
+        std::vector<bool> used(nd.groups.size(), false);
+        if (allow_pack)
+            for (size_t g = 0; g < nd.groups.size() && nwords > 4; g++) {
+                if (used[g] || !narrow(g)) continue;
+                for (size_t h = g + 1; h < nd.groups.size(); h++)
+                    if (!used[h] && narrow(h)) { used[g] = used[h] = true; words.push_back({(int)g, (int)h}); nwords--; break; }
+            }
+        if (nwords > 4) { set_error("ph_plan: %zu group keys do not fit the aggregate table's four key words", nd.groups.size()); return PH_EUNSUPPORTED; }
+        // word order: the packed pairs and the single keys, in the order of their first key
+        std::vector<std::pair<int, int>> order;
+        for (size_t g = 0; g < nd.groups.size(); g++) {
+            if (!used[g]) order.push_back({(int)g, -1});
+            else for (auto &w : words) if (w.first == (int)g) order.push_back(w);
+        }
+        packs->assign(nd.groups.size(), KeyPack{0, 0});
+        for (size_t w = 0; w < order.size(); w++) {
+            const int g = order[w].first, h = order[w].second;
+            if (h < 0) {
+                const PCol &c = S.cols[(size_t)g];
+                if (width_of(c.type) == 0) { set_error("ph_plan: VARCHAR group key that is not a dictionary-code column"); return PH_EUNSUPPORTED; }
+                const int32_t *sx = nullptr;
+                keys.push_back(col_view(S, c, &sx));
+                key_types.push_back(c.type);
+                (*packs)[(size_t)g] = KeyPack{(int)w, 0};
+                continue;
+            }
+            ph_col two[2];
+            for (int t = 0; t < 2; t++) { const int32_t *sx = nullptr; two[t] = col_view(S, S.cols[(size_t)(t ? h : g)], &sx); two[t].type = PH_I32; }   // DATE days as the integers they are
+            const ph_rpn prog[7] = {{PH_X_COL, 0, 0, 0}, {PH_X_CONST, -1, 1ll << 32, 0}, {PH_X_MUL, -1, 0, 0}, {PH_X_COL, 1, 0, 0}, {PH_X_ADD, -1, 0, 0},
+                                    {PH_X_CONST, -1, 1ll << 31, 0}, {PH_X_ADD, -1, 0, 0}};
+            void *wv = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(S.n, 1) * 8, &wv));
+            if (S.n > 0) PL_CHECK(ph_expr_eval(ctx, two, 2, prog, 7, nullptr, S.n, (int64_t *)wv, nullptr));
+            ph_col wc{};
+            wc.type = PH_I64; wc.data = wv;
+            keys.push_back(wc);
+            key_types.push_back(PH_I64);
+            (*packs)[(size_t)g] = KeyPack{(int)w, 1};
+            (*packs)[(size_t)h] = KeyPack{(int)w, 2};
+        }
+        for (size_t g = 0; g < nd.groups.size(); g++) {
+            const PCol &c = S.cols[g];
+            // a VARCHAR key reports PH_STR: its int64 key values are ROW IDS of (table, col) whose strings are the keys (-1 = NULL)
+            kinfo->push_back(KeyInfo{str_key[g] ? (int32_t)PH_STR : c.type, c.scale, c.src, c.src_col});
+        }
+    }
+    std::vector<ph_aggspec> specs;
+    for (size_t a = 0; a < nd.aggs.size(); a++) {
+        specs.push_back(ph_aggspec{nd.aggs[a].kind, (int32_t)a});
+        if (nd.aggs[a].kind == PH_A_COUNT_STAR) { ascale->push_back(0); atype->push_back(PH_I32); continue; }
+        const PCol &c = S.cols[ci++];
+        const int32_t *s = nullptr;
+        args[a] = col_view(S, c, &s);
+        ascale->push_back(c.scale);
+        atype->push_back(nd.aggs[a].arg.e.kind == PH_PE_CASE && nd.aggs[a].arg.e.result_int ? PH_I32 : c.type);
+    }
+    if (keys.empty()) {   // one global group: a constant key (executor_aggr.go:37-48)
+        void *zero = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(S.n, 1) * 4, &zero));
+        PL_CHECK(ph_dev_memset(ctx, zero, 0, std::max<int64_t>(S.n, 1) * 4));
+        ph_col c{};
+        c.type = PH_I32; c.data = zero;
+        keys.push_back(c);
+        key_types.push_back(PH_I32);
+    }
+    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind == PH_A_COUNT_STAR) args[a] = keys[0];
+    // expected groups: a key that is (a copy of) a wide integer table column is taken to be high-cardinality
+    int64_t expected = 1024;
+    if (!nd.groups.empty() && (S.cols[0].type == PH_I64 || S.cols[0].type == PH_I32) && S.cols[0].src) {
+        const auto &sc = S.cols[0].src->cols[(size_t)S.cols[0].src_col];
+        if (sc.has_range && sc.max - sc.min > 65536) expected = std::max<int64_t>(S.n / 2, 1024);
+    }
+    if ((*aggp)) { ph_agg_free((*aggp)); (*aggp) = nullptr; }
+    PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &(*aggp)));
+    bool streamed = false;
+    if (!p->conservative && !nd.groups.empty() && S.cols[0].ordered && (*packs)[0].word == 0 && (*packs)[0].part == 0 && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
+        int rc = ph_agg_sink_sorted((*aggp), keys.data(), args.data(), (int32_t)args.size(), S.n, 0);
+        if (rc == PH_OK) streamed = true;
+        else if (rc != PH_EUNSUPPORTED) return rc;
+    }
+    if (!streamed && S.n > 0) PL_CHECK(ph_agg_sink((*aggp), keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0));
+    note(p, "agg#%d: %s over %lld rows, %zu keys, %zu aggregates", idx, streamed ? "streaming aggregate (rows ordered by the first key)" : "hash aggregate",
+         (long long)S.n, nd.groups.size(), nd.aggs.size());
+    return PH_OK;
+}
+
 
 // ---- the root: HashAggregate
 int lower_agg(ph_plan *p) {
@@ -1199,71 +1445,7 @@ int lower_agg(ph_plan *p) {
         }
     }
 
-    PL_CHECK(apply_pending(p, &R));
-    // group keys and aggregate arguments as columns of the relation
-    std::vector<PCol> kc(nd.groups.size()), ac(nd.aggs.size());
-    for (size_t g = 0; g < nd.groups.size(); g++) PL_CHECK(eval_expr(p, &R, nd.groups[g], &kc[g]));
-    for (size_t a = 0; a < nd.aggs.size(); a++) {
-        if (nd.aggs[a].kind == PH_A_COUNT_STAR) continue;
-        PL_CHECK(eval_expr(p, &R, nd.aggs[a].arg, &ac[a]));
-    }
-    // everything positional: the sink reads position i of every key and argument
-    Rel S = R;
-    S.cols.clear();
-    for (auto &c : kc) S.cols.push_back(c);
-    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind != PH_A_COUNT_STAR) S.cols.push_back(ac[a]);
-    std::vector<int> all;
-    for (size_t c = 0; c < S.cols.size(); c++) if (S.cols[c].lane >= 0) all.push_back((int)c);
-    PL_CHECK(positional(p, &S, all));
-    std::vector<ph_col> keys, args(nd.aggs.size());
-    std::vector<int32_t> key_types;
-    size_t ci = 0;
-    for (size_t g = 0; g < nd.groups.size(); g++, ci++) {
-        const PCol &c = S.cols[ci];
-        if (width_of(c.type) == 0) { set_error("ph_plan: VARCHAR group key that is not a dictionary-code column"); return PH_EUNSUPPORTED; }
-        const int32_t *s = nullptr;
-        keys.push_back(col_view(S, c, &s));
-        key_types.push_back(c.type);
-        p->keys.push_back(KeyInfo{c.type, c.scale, c.src, c.src_col});
-    }
-    std::vector<ph_aggspec> specs;
-    for (size_t a = 0; a < nd.aggs.size(); a++) {
-        specs.push_back(ph_aggspec{nd.aggs[a].kind, (int32_t)a});
-        if (nd.aggs[a].kind == PH_A_COUNT_STAR) { p->agg_scale.push_back(0); p->agg_arg_type.push_back(PH_I32); continue; }
-        const PCol &c = S.cols[ci++];
-        const int32_t *s = nullptr;
-        args[a] = col_view(S, c, &s);
-        p->agg_scale.push_back(c.scale);
-        p->agg_arg_type.push_back(nd.aggs[a].arg.e.kind == PH_PE_CASE && nd.aggs[a].arg.e.result_int ? PH_I32 : c.type);
-    }
-    if (keys.empty()) {   // one global group: a constant key (executor_aggr.go:37-48)
-        void *zero = nullptr;
-        PL_CHECK(palloc(p, std::max<int64_t>(S.n, 1) * 4, &zero));
-        PL_CHECK(ph_dev_memset(ctx, zero, 0, std::max<int64_t>(S.n, 1) * 4));
-        ph_col c{};
-        c.type = PH_I32; c.data = zero;
-        keys.push_back(c);
-        key_types.push_back(PH_I32);
-    }
-    for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind == PH_A_COUNT_STAR) args[a] = keys[0];
-    // expected groups: a key that is (a copy of) a wide integer table column is taken to be high-cardinality
-    int64_t expected = 1024;
-    if (!nd.groups.empty() && (S.cols[0].type == PH_I64 || S.cols[0].type == PH_I32) && S.cols[0].src) {
-        const auto &sc = S.cols[0].src->cols[(size_t)S.cols[0].src_col];
-        if (sc.has_range && sc.max - sc.min > 65536) expected = std::max<int64_t>(S.n / 2, 1024);
-    }
-    if (p->agg) { ph_agg_free(p->agg); p->agg = nullptr; }
-    PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &p->agg));
-    bool streamed = false;
-    if (!p->conservative && !nd.groups.empty() && S.cols[0].ordered && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
-        int rc = ph_agg_sink_sorted(p->agg, keys.data(), args.data(), (int32_t)args.size(), S.n, 0);
-        if (rc == PH_OK) streamed = true;
-        else if (rc != PH_EUNSUPPORTED) return rc;
-    }
-    if (!streamed && S.n > 0) PL_CHECK(ph_agg_sink(p->agg, keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0));
-    note(p, "agg#%d: %s over %lld rows, %zu keys, %zu aggregates", idx, streamed ? "streaming aggregate (rows ordered by the first key)" : "hash aggregate",
-         (long long)S.n, nd.groups.size(), nd.aggs.size());
-    return PH_OK;
+    return sink_into_agg(p, idx, R, true, &p->agg, &p->keys, &p->agg_scale, &p->agg_arg_type, &p->key_packs);
 }
 
 int run_once(ph_plan *p) {
@@ -1296,10 +1478,12 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
     if (p->scan) return ph_scan_plan_fetch(p->scan, out);
     const int nkeys = (int)nd.groups.size(), naggs = (int)nd.aggs.size();
     const int nk = std::max(nkeys, 1);
+    int nw = 1;   // key words of the aggregate table (packed keys share one)
+    for (auto &kp : p->key_packs) nw = std::max(nw, kp.word + 1);
     int64_t room = p->topk_agg >= 0 ? 4096 : 1024, ng = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
-        std::vector<int64_t> first((size_t)room), keys((size_t)room * nk), hi((size_t)room * std::max(naggs, 1));
-        std::vector<uint8_t> knull((size_t)room * nk);
+        std::vector<int64_t> first((size_t)room), keys((size_t)room * nw), hi((size_t)room * std::max(naggs, 1));
+        std::vector<uint8_t> knull((size_t)room * nw);
         std::vector<uint64_t> lo((size_t)room * std::max(naggs, 1)), cnt((size_t)room * std::max(naggs, 1));
         int rc;
         if (p->topk_agg >= 0) rc = ph_agg_topk(p->agg, p->topk_agg, p->topk_desc, p->topk_k, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
@@ -1309,7 +1493,11 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
         ph_agg_result *r = new_result(ng, nkeys, naggs);
         for (int64_t g = 0; g < ng; g++) {
             r->first_row[g] = first[(size_t)g];
-            for (int k = 0; k < nkeys; k++) r->keys[g * nk + k] = keys[(size_t)(g * nk + k)];
+            for (int k = 0; k < nkeys; k++) {
+                const KeyPack kp = p->key_packs[(size_t)k];
+                const int64_t w = keys[(size_t)(g * nw + kp.word)];
+                r->keys[g * nk + k] = kp.part == 0 ? w : kp.part == 1 ? (w >> 32) : (int64_t)(uint32_t)w - (1ll << 31);
+            }
             for (int a = 0; a < naggs; a++) {
                 r->sum_lo[g * naggs + a] = lo[(size_t)(g * naggs + a)];
                 r->sum_hi[g * naggs + a] = hi[(size_t)(g * naggs + a)];
@@ -1361,8 +1549,8 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
             for (int32_t k = 0; k < s.nexprs; k++) n.exprs.push_back(Expr{s.exprs[k], copy_bools(s.exprs[k].when, s.exprs[k].kind == PH_PE_CASE ? s.exprs[k].nwhen : 0)});
             break;
         case PH_PN_AGG:
-            if (i != nnodes - 1 || s.child[0] < 0 || s.naggs < 1 || !s.aggs || s.ngroups < 0 || s.ngroups > 4 || (s.ngroups && !s.groups) || s.naggs > 16) {
-                set_error("ph_plan_create: node %d: bad aggregate (root only, <= 4 group expressions, 1..16 aggregates)", i);
+            if (s.child[0] < 0 || s.naggs < 1 || !s.aggs || s.ngroups < 0 || s.ngroups > 8 || (s.ngroups && !s.groups) || s.naggs > 16) {
+                set_error("ph_plan_create: node %d: bad aggregate (<= 8 group expressions, 1..16 aggregates)", i);
                 return fail(PH_EINVAL);
             }
             for (int32_t k = 0; k < s.ngroups; k++) n.groups.push_back(Expr{s.groups[k], copy_bools(s.groups[k].when, s.groups[k].kind == PH_PE_CASE ? s.groups[k].nwhen : 0)});

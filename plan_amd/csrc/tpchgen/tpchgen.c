@@ -344,8 +344,9 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
             uint8_t smode = SMODE_GEN_TO_CODE[stream_int(&s.smode, 1, 7) - 1];
             uint8_t lstat = (sdate <= CURRENT_DATE_EPOCH) ? 0 /*F*/ : 1 /*O*/;
             if (lstat == 0) shipped++;
-            /* o_totalprice = sum(ext * (1+tax) * (1-disc)) truncated per line */
-            total += ((ext * (100 + tax)) / 100) * (100 - disc) / 100;
+            /* o_totalprice = sum over the lines of ext * (1 - disc) * (1 + tax) in integer cents, the discount applied (and
+             * truncated) first, then the tax — the order matters in the last cent (orders.tbl: order 1 = 173665.47) */
+            total += ((ext * (100 - disc)) / 100) * (100 + tax) / 100;
             if (L) {
                 if (L->l_orderkey) L->l_orderkey[row] = okey;
                 if (L->l_partkey) L->l_partkey[row] = (int32_t)pkey;

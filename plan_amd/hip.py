@@ -964,3 +964,44 @@ def table_col_range_of(table, c):
     mn, mx = i64(), i64()
     check(lib().ph_table_col_range(table.h, i32(c), ctypes.byref(mn), ctypes.byref(mx)))
     return mn.value, mx.value
+
+
+class StrDict:
+    """ph_strdict: VARCHAR keys as int32 codes (the representative row of each distinct string)"""
+
+    def __init__(self, ctx, col, sel, n):
+        self.ctx, self.h = ctx, vp()
+        c = col.col() if isinstance(col, DevColumn) else col
+        self.codes = ctx.alloc(max(n, 1) * 4)
+        check(lib().ph_strdict_build(ctx.h, ctypes.byref(c), sel, i64(n), self.codes, ctypes.byref(self.h)))
+        self._keep = col
+
+    def lookup(self, col, sel, n):
+        c = col.col() if isinstance(col, DevColumn) else col
+        out = self.ctx.alloc(max(n, 1) * 4)
+        check(lib().ph_strdict_lookup(self.h, ctypes.byref(c), sel, i64(n), out))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().ph_strdict_free(self.h)
+            self.h = None
+            self.ctx.free(self.codes)
+
+
+def plan_key_info(plan, k):
+    """(type, scale, table handle or None, column) of group key k of a ph_plan's last run"""
+    t, s, tab, c = i32(), i32(), vp(), i32()
+    check(lib().ph_plan_key_info(plan.h, i32(k), ctypes.byref(t), ctypes.byref(s), ctypes.byref(tab), ctypes.byref(c)))
+    return t.value, s.value, tab.value, c.value
+
+
+def table_strings(ctx, table, c, rows):
+    """strings of the given rows of PH_STR column c (ph_table_strings)"""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    n = len(rows)
+    off = np.zeros(n + 1, np.int32)
+    cap = 1 << 20
+    buf = ctypes.create_string_buffer(cap)
+    check(lib().ph_table_strings(ctx.h, table.h, i32(c), vp(rows.ctypes.data), i64(n), vp(off.ctypes.data), buf, i64(cap)))
+    return [buf.raw[off[i]:off[i + 1]].decode() for i in range(n)]

@@ -21,8 +21,10 @@ SCHEMA = {
                  ("l_commitdate", hip.PH_DATE, 0, None), ("l_receiptdate", hip.PH_DATE, 0, None),
                  ("l_shipmode", hip.PH_CODE8, 0, tpchgen.SHIPMODE_DICT), ("l_shipinstruct", hip.PH_CODE8, 0, tpchgen.SHIPINSTRUCT_DICT)],
     "orders": [("o_orderkey", hip.PH_I64, 0, None), ("o_custkey", hip.PH_I32, 0, None), ("o_orderdate", hip.PH_DATE, 0, None),
-               ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT)],
-    "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT)],
+               ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT),
+               ("o_totalprice", hip.PH_DEC64, 2, None)],
+    "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT),
+                 ("c_name", hip.PH_STR, 0, None)],
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
              ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
     "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None)],
@@ -297,3 +299,36 @@ def dec_text(unscaled, scale):
     w, f = divmod(abs(int(unscaled)), 10 ** scale)
     frac = (("%0" + str(scale) + "d") % f).rstrip("0") if scale else ""
     return f"{neg}{w}" + (f".{frac}" if frac else "")
+
+
+def q18_plan(db, qty_gt=314, topk=0):
+    """cases/tpch/query/q18.sql: the IN (select l_orderkey from lineitem group by l_orderkey having sum(l_quantity) > k) subquery is an
+       aggregate BELOW a SEMI join (its groups stay on the device), HAVING is the Filter above it; five group keys, c_name a VARCHAR that is
+       no small dictionary (1.5 M distinct names at SF10): interned on the device (ph_strdict), two narrow keys packed into one key word"""
+    p = hip.Plan(db.ctx)
+    sub_scan = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_quantity"))
+    sub = p.agg(sub_scan, [hip.pe_col(0)], [(hip.PH_A_SUM, hip.pe_col(1))])                 # l_orderkey, sum(l_quantity)
+    having = p.filter(sub, [hip.pred(1, hip.PH_GT, _k(hip.PH_I32, i=qty_gt))])
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"))
+    j1 = p.join(orders, having, [0], [0], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_name"))
+    j2 = p.join(j1, cust, [1], [0], [0, 2, 3, 4, 5])                                        # o_orderkey, o_orderdate, o_totalprice, c_custkey, c_name
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_quantity"))
+    j3 = p.join(line, j2, [0], [0], [1, 6, 5, 2, 3, 4])                                     # l_quantity, c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice
+    p.agg(j3, [hip.pe_col(1), hip.pe_col(2), hip.pe_col(3), hip.pe_col(4), hip.pe_col(5)], [(hip.PH_A_SUM, hip.pe_col(0))])
+    return p.create()
+
+
+def q18_text(db, p, r, limit=100):
+    """ORDER BY o_totalprice DESC, o_orderdate LIMIT 100 + the reference's text; c_name comes back as a row of customer.c_name"""
+    import datetime
+    typ, _s, _t, col = hip.plan_key_info(p, 0)
+    assert typ == hip.PH_STR
+    rows = [[int(x) for x in r["keys"][g]] + [r["sum"][g][0]] for g in range(r["ngroups"])]
+    names = hip.table_strings(db.ctx, db.t("customer"), col, [row[0] for row in rows])
+    rows = sorted(zip(names, rows), key=lambda nr: (-nr[1][4], nr[1][3]))[:limit]
+    out = ["#\t\t\t\t\t"]
+    for name, (_c, ck, ok, od, tp, q) in rows:
+        d = datetime.date(1970, 1, 1) + datetime.timedelta(days=od)
+        out.append(f"{name}\t{ck}\t{ok}\t{d.isoformat()}\t{dec_text(tp, 2)}\t{q}")
+    return "\n".join(out) + "\n"

@@ -144,9 +144,19 @@ def orders(sf, first=0, n=None, columns=None):
 
 
 def customer(sf, first=0, n=None, columns=None):
+    """c_name is 'Customer#' + the key as nine digits (TPC-H 4.2.3): derived here as offsets + bytes (c_name_off / c_name_bytes)"""
     if n is None:
         n = int(lib().tpchgen_customer_count(_i64(sf[0]), _i64(sf[1]))) - first
-    return _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns)
+    cols = _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns)
+    if columns is None or "c_name" in columns:
+        keys = np.arange(first + 1, first + n + 1, dtype=np.int64)
+        buf = np.empty((n, 18), dtype=np.uint8)
+        buf[:, :9] = np.frombuffer(b"Customer#", dtype=np.uint8)
+        for d in range(9):
+            buf[:, 17 - d] = ord("0") + (keys // 10 ** d) % 10
+        cols["c_name_off"] = np.arange(0, 18 * (n + 1), 18, dtype=np.int32)
+        cols["c_name_bytes"] = buf.reshape(-1)
+    return cols
 
 
 def part(sf, first=0, n=None):

@@ -588,3 +588,22 @@ def q19_text(t):
     rc, d = q19(t)
     assert rc >= 0
     return _text("oracle_q19_text", ctypes.byref(d), i32(rc))
+
+
+class Q18Row(ctypes.Structure):
+    _fields_ = [("c_custkey", i32), ("o_orderkey", i64), ("o_orderdate", i32), ("o_totalprice", i64), ("sum_qty", OHuge)]
+
+
+def q18(t, qty_gt=314):
+    T, keep = tpch_struct(t)
+    tp = np.ascontiguousarray(t["orders"]["o_totalprice"])
+    rows = (Q18Row * 4096)()
+    lib().oracle_q18.restype = i64
+    n = lib().oracle_q18(ctypes.byref(T), ctypes.c_void_p(tp.ctypes.data), i64(qty_gt), rows, i64(4096))
+    assert n >= 0
+    return n, rows
+
+
+def q18_text(t, qty_gt=314, limit=100):
+    n, rows = q18(t, qty_gt)
+    return _text("oracle_q18_text", rows, i64(n), i32(limit))

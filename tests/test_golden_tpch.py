@@ -82,3 +82,9 @@ def test_q14_matches_reference_golden(sf1):
 
 def test_q19_matches_reference_golden(sf1):
     assert O.q19_text(sf1) == golden("plan_q19.txt")
+
+
+def test_q18_matches_reference_golden(sf1):
+    # an aggregate with HAVING (HUGEINT '>') under a SEMI join, five group keys (c_name a VARCHAR), ORDER BY DECIMAL DESC, DATE LIMIT 100;
+    # also pins the generator's o_totalprice (discount applied before tax, truncated to cents each time)
+    assert O.q18_text(sf1) == golden("plan_q18.txt")

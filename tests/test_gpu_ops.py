@@ -1728,3 +1728,84 @@ def test_single_pass_scan_through_large_selections(ctx):
             assert cnt == len(want) and np.array_equal(got, want.astype(np.int32))
             ctx.free(sel)
         d.free()
+
+
+def _str_col(ctx, strings, nulls=None):
+    """list of str -> (DevColumn PH_STR, offsets, bytes)"""
+    enc = [s.encode() for s in strings]
+    off = np.zeros(len(enc) + 1, np.int32)
+    np.cumsum([len(b) for b in enc], out=off[1:])
+    byts = np.frombuffer(b"".join(enc), dtype=np.uint8) if off[-1] else np.zeros(1, np.uint8)
+    val = None
+    if nulls is not None:
+        val = np.packbits(~np.asarray(nulls, bool), bitorder="little")
+    return hip.DevColumn(ctx, hip.PH_STR, off, validity=val, aux=byts)
+
+
+def test_string_keys_interning_groups_and_joins(ctx):
+    """VERDICT r2 item 6 — VARCHAR keys that are not small dictionaries. ph_strdict_build interns a PH_STR column (hash =
+    util.HashBytes, candidates verified byte by byte): equal strings get equal codes, different strings different codes, a code is a
+    row holding the string, NULLs get -1. 200 k rows over 30 k distinct strings (so every table slot sees collisions that only the
+    byte compare resolves), strings that share long prefixes and differ in the last byte, the empty string, a selection.
+    The group-by over the codes equals numpy's over the strings; ph_strdict_lookup resolves a second column against the dictionary
+    (absent strings and NULLs: -2), and the integer join over the codes gives the pairs of the string join."""
+    rng = np.random.default_rng(2026)
+    base = [f"Customer#{i:09d}" for i in range(30_000)] + ["", "a", "aa", "aaa" * 40 + "x", "aaa" * 40 + "y"]
+    pick = rng.integers(0, len(base), 200_000)
+    strings = [base[i] for i in pick]
+    nulls = rng.random(len(strings)) < 0.01
+    col = _str_col(ctx, strings, nulls)
+    n = len(strings)
+    d = hip.StrDict(ctx, col, None, n)
+    codes = ctx.download(d.codes, np.int32, n)
+    assert np.all(codes[nulls] == -1) and np.all(codes[~nulls] >= 0)
+    live = np.nonzero(~nulls)[0]
+    assert all(strings[codes[i]] == strings[i] and not nulls[codes[i]] for i in live[:5000])          # a code is a row holding the string
+    ids = {}
+    for i in live:                                                                                       # equal <-> equal, over all rows
+        assert ids.setdefault(strings[i], codes[i]) == codes[i]
+    assert len(set(ids.values())) == len(ids)
+    # group by the codes: count(*) and sum(v) per string == numpy over the strings
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    dv = hip.DevColumn(ctx, hip.PH_I64, v)
+    key = hip.Col(); key.type, key.data, key.validity = hip.PH_I32, d.codes, col.validity
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, 0)], 40_000)
+    agg.sink([key], [dv, dv], None, n)
+    r = agg.finalize(room=40_000)
+    want = {}
+    for i in range(n):
+        k = None if nulls[i] else strings[i]
+        s, c = want.get(k, (0, 0))
+        want[k] = (s + int(v[i]), c + 1)
+    got = {}
+    for g in range(r["ngroups"]):
+        k = None if r["key_null"][g][0] else strings[int(r["keys"][g][0])]
+        got[k] = (r["sum"][g][0], int(r["count"][g][1]))
+    assert got == want
+    # a selection interns only its rows
+    sel = np.sort(rng.choice(n, 5000, replace=False)).astype(np.int32)
+    ds = ctx.upload(sel)
+    d2 = hip.StrDict(ctx, col, ds, len(sel))
+    c2 = ctx.download(d2.codes, np.int32, len(sel))
+    assert all((c2[j] == -1) if nulls[sel[j]] else strings[c2[j]] == strings[sel[j]] for j in range(len(sel)))
+    # lookup of another column: present strings resolve to the same code, absent ones and NULLs to -2
+    probe = [base[i] for i in rng.integers(0, len(base), 50_000)] + ["Customer#999999999", "aaa" * 40 + "z", "b"]
+    pn = np.zeros(len(probe), bool); pn[7] = True
+    pc = _str_col(ctx, probe, pn)
+    lk = ctx.download(d.lookup(pc, None, len(probe)), np.int32, len(probe))
+    for j, s in enumerate(probe):
+        assert lk[j] == (-2 if pn[j] or s not in ids else ids[s]), (j, s)
+    # the integer join over the codes = the string join
+    bcol = hip.Col(); bcol.type, bcol.data, bcol.validity = hip.PH_I32, d.codes, col.validity
+    j = hip.Join(ctx, [bcol], None, n)
+    pk = hip.Col(); pk.type, pk.data = hip.PH_I32, d.lookup(pc, None, len(probe))
+    m, pp, bb = j.probe_inner([pk], None, len(probe), 4 * n)
+    pp, bb = ctx.download(pp, np.int32, m), ctx.download(bb, np.int32, m)
+    counts = {}
+    for i in live:
+        counts[strings[i]] = counts.get(strings[i], 0) + 1
+    assert m == sum(counts.get(s, 0) for jx, s in enumerate(probe) if not pn[jx])
+    assert all(strings[b] == probe[a] for a, b in zip(pp[:20000], bb[:20000]))
+    j.free(); agg.free(); d.free(); d2.free()
+    for c in (col, dv, pc):
+        c.free()

@@ -11,7 +11,7 @@ def load(num, den, q9=True):
             "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate",
             "l_commitdate", "l_receiptdate", "l_shipinstruct", "l_shipmode"]),
         "orders": tpchgen.orders(sf, columns=[
-            "o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority"]),
+            "o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice"]),
         "customer": tpchgen.customer(sf),
     }
     if q9:
