@@ -1392,6 +1392,39 @@ int ResidentPlan::Agg(int child, std::vector<ProjExpr> groups, std::vector<AggEx
         n.types.push_back(t);
         n.source.push_back(s);
     }
+    n.ngroups = (int)groups.size();
+    // aggregate results, typed as FinalizeStates types them (function_aggr.go:1330-1365)
+    const std::vector<LType> &childTypes = nodes[(size_t)child].types;
+    std::vector<ph_col> protos;
+    for (auto &t : childTypes) { ph_col pc{}; pc.type = staged_phtype(t); pc.scale = t.Scale; protos.push_back(pc); }
+    for (auto &a : aggs) {
+        LType at = IntegerType();
+        int32_t scale = 0;
+        if (a.kind != PH_A_COUNT_STAR) {
+            if (a.expr) {
+                std::vector<LType> one;
+                std::string e = gpuProjectExecutor::Types({*a.expr}, childTypes, &one);
+                if (!e.empty()) { if (error.empty()) error = e; one = {IntegerType()}; }
+                at = one[0]; scale = at.Scale;
+            } else if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL && a.prog[0].col >= 0 && a.prog[0].col < (int)childTypes.size()) {
+                at = childTypes[(size_t)a.prog[0].col]; scale = at.Scale;
+            } else if (a.prog.empty()) { if (error.empty()) error = "aggregate without an argument"; }
+            else {
+                if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK && error.empty()) error = herr("ph_expr_scale");
+                at = DecimalType(38, scale);
+            }
+        }
+        n.argTypes.push_back(at);
+        const bool dec = at.Id == LTID_DECIMAL;
+        switch (a.kind) {
+        case PH_A_SUM: n.types.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;      // BindDecimalSum / GetSumAggr
+        case PH_A_AVG: n.types.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;       // BindDecimalAvg / GetAvgAggr
+        case PH_A_COUNT: case PH_A_COUNT_STAR: n.types.push_back(HugeintType()); break;
+        case PH_A_MIN: case PH_A_MAX: n.types.push_back(dec ? DecimalType(at.Width, scale) : at); break;
+        default: if (error.empty()) error = "unknown aggregate kind"; n.types.push_back(at);
+        }
+        n.source.push_back(nullptr);
+    }
     n.exprs = std::move(groups);
     n.aggs = std::move(aggs);
     nodes.push_back(std::move(n));
@@ -1546,37 +1579,8 @@ std::string gpuResidentPlanExecutor::Init() {
         default: break;
         }
     }
-    // output typing of the aggregate (FinalizeStates, as gpuAggExecutor)
-    const std::vector<LType> &childTypes = rp_.nodes[(size_t)root.child[0]].types;
-    std::vector<ph_col> protos;
-    for (auto &t : childTypes) { ph_col pc{}; pc.type = staged_phtype(t); pc.scale = t.Scale; protos.push_back(pc); }
-    outTypes_ = root.types;
-    argType_.clear();
-    for (auto &a : root.aggs) {
-        LType at = IntegerType();
-        int32_t scale = 0;
-        if (a.kind != PH_A_COUNT_STAR) {
-            if (a.expr) {
-                std::vector<LType> one;
-                std::string e = gpuProjectExecutor::Types({*a.expr}, childTypes, &one);
-                if (!e.empty()) return e;
-                at = one[0]; scale = at.Scale;
-            } else if (a.prog.size() == 1 && a.prog[0].op == PH_X_COL) { at = childTypes[(size_t)a.prog[0].col]; scale = at.Scale; }
-            else {
-                if (ph_expr_scale(protos.data(), a.prog.data(), (int32_t)a.prog.size(), &scale) != PH_OK) return herr("ph_expr_scale");
-                at = DecimalType(38, scale);
-            }
-        }
-        argType_.push_back(at);
-        bool dec = at.Id == LTID_DECIMAL;
-        switch (a.kind) {
-        case PH_A_SUM: outTypes_.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;
-        case PH_A_AVG: outTypes_.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;
-        case PH_A_COUNT: case PH_A_COUNT_STAR: outTypes_.push_back(HugeintType()); break;
-        case PH_A_MIN: case PH_A_MAX: outTypes_.push_back(dec ? DecimalType(at.Width, scale) : at); break;
-        default: return "unknown aggregate kind";
-        }
-    }
+    outTypes_ = root.types;       // [group columns | aggregate results], typed by ResidentPlan::Agg
+    argType_ = root.argTypes;
     if (ph_plan_create(ctx_, desc.data(), (int32_t)nn, &plan_) != PH_OK) return herr("ph_plan_create");
     if (topkAgg_ >= 0 && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
     for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
@@ -1598,9 +1602,33 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
             return InvalidOpResult;
         }
         const ResidentPlan::Node &root = rp_.nodes.back();
-        std::vector<LType> keyTypes = root.types;
+        std::vector<LType> keyTypes(root.types.begin(), root.types.begin() + root.ngroups);
         std::vector<const std::vector<std::string> *> dicts;
-        for (size_t k = 0; k < keyTypes.size(); k++) dicts.push_back(root.source[k] ? &root.source[k]->dict : nullptr);
+        std::vector<std::vector<std::string>> fetched(keyTypes.size());
+        const int nkw = std::max<int>((int)keyTypes.size(), 1);
+        for (size_t k = 0; k < keyTypes.size(); k++) {
+            dicts.push_back(root.source[k] ? &root.source[k]->dict : nullptr);
+            int32_t kt = 0, ks = 0, kc = -1;
+            const ph_table *tab = nullptr;
+            if (ph_plan_key_info(plan_, (int32_t)k, &kt, &ks, &tab, &kc) != PH_OK) { ph_agg_result_free(r); *err = herr("ph_plan_key_info"); return InvalidOpResult; }
+            if (kt != PH_STR) continue;
+            // a VARCHAR key that is no small dictionary came back as ROWS of its column: fetch those strings, one per group, and let
+            // the group's key value index them
+            std::vector<int64_t> rows((size_t)r->ngroups);
+            for (int64_t g = 0; g < r->ngroups; g++) rows[(size_t)g] = r->keys[g * nkw + (int64_t)k];
+            std::vector<int32_t> off((size_t)r->ngroups + 1);
+            std::vector<char> bytes((size_t)1 << 20);
+            if (ph_table_strings(ctx_, tab, kc, rows.data(), r->ngroups, off.data(), bytes.data(), (int64_t)bytes.size()) != PH_OK) {
+                ph_agg_result_free(r);
+                *err = herr("ph_table_strings");
+                return InvalidOpResult;
+            }
+            for (int64_t g = 0; g < r->ngroups; g++) {
+                fetched[k].emplace_back(bytes.data() + off[(size_t)g], (size_t)(off[(size_t)g + 1] - off[(size_t)g]));
+                r->keys[g * nkw + (int64_t)k] = g;
+            }
+            dicts[k] = &fetched[k];
+        }
         std::vector<int> kinds, scales;
         for (size_t i = 0; i < root.aggs.size(); i++) { kinds.push_back(root.aggs[i].kind); scales.push_back(r->scale[i]); }
         std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo, r->sum_hi,

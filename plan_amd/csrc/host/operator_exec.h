@@ -419,7 +419,9 @@ public:
     // output = the listed columns of [probe child's columns | build child's columns] (SEMI / ANTI: probe columns)
     int Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type = JoinInner);
     int Project(int child, std::vector<ProjExpr> exprs);
-    int Agg(int child, std::vector<ProjExpr> groups, std::vector<AggExpr> aggs);   // the root
+    // the root — or an aggregate BELOW other operators (a subquery's GROUP BY; its HAVING is a Filter above it): its output
+    // columns are [group columns | aggregate results] with FinalizeStates' types (SUM(INTEGER) / COUNT are HUGEINT)
+    int Agg(int child, std::vector<ProjExpr> groups, std::vector<AggExpr> aggs);
     struct Node {
         int kind = 0, child[2] = {-1, -1};
         const ResidentTable *table = nullptr;
@@ -429,7 +431,9 @@ public:
         JoinType joinType = JoinInner;
         std::vector<ProjExpr> exprs;    // Project; Agg: the group-by expressions
         std::vector<AggExpr> aggs;
-        std::vector<LType> types;       // output types of the node (Agg: the group columns)
+        int ngroups = 0;                // Agg: group-by expressions; its output = [group columns | aggregate results]
+        std::vector<LType> argTypes;    // Agg: type of every aggregate's argument
+        std::vector<LType> types;       // output types of the node
         std::vector<const ResidentColumn *> source;   // per output column: the resident column it is an unchanged copy of (or null)
     };
     std::vector<Node> nodes;

@@ -84,15 +84,15 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         load_s += now_s() - t0; t0 = now_s();
     }
     {   // orders
-        std::vector<int64_t> okey((size_t)no);
+        std::vector<int64_t> okey((size_t)no), total((size_t)no);
         std::vector<int32_t> cust((size_t)no), date((size_t)no), sprio((size_t)no);
         std::vector<uint8_t> oprio((size_t)no);
         tpchgen_orders_cols oc{};
-        oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data();
+        oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data(); oc.o_totalprice = total.data();
         tpchgen_orders(num, den, 0, no, &oc);
         generate_s += now_s() - t0; t0 = now_s();
-        e = loadTable(ctx, {I64(okey.data()), I32(cust.data()), DATE(date.data()), I32(sprio.data()), CODE(oprio.data(), dictOf(TPCHGEN_ORDERPRIORITY_DICT, 5))},
-                      no, {O_ORDERKEY}, &orders, &loaded_bytes);
+        e = loadTable(ctx, {I64(okey.data()), I32(cust.data()), DATE(date.data()), I32(sprio.data()), CODE(oprio.data(), dictOf(TPCHGEN_ORDERPRIORITY_DICT, 5)),
+                            DEC(total.data())}, no, {O_ORDERKEY}, &orders, &loaded_bytes);
         if (!e.empty()) return e;
         load_s += now_s() - t0; t0 = now_s();
     }
@@ -102,7 +102,19 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_customer_cols cc{};
         cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data();
         tpchgen_customer(num, den, 0, nc, &cc);
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5))}, nc, {C_CUSTKEY}, &customer, &loaded_bytes);
+        // c_name = 'Customer#' + the key as nine digits (TPC-H 4.2.3): 1.5 M distinct strings at SF10, so offsets + bytes, no dictionary
+        std::vector<int32_t> off((size_t)nc + 1);
+        std::string bytes((size_t)nc * 18, '0');
+        for (int64_t r = 0; r < nc; r++) {
+            off[(size_t)r] = (int32_t)(r * 18);
+            char *b = &bytes[(size_t)r * 18];
+            memcpy(b, "Customer#", 9);
+            int32_t k = key[(size_t)r];
+            for (int d = 17; d >= 9; d--) { b[d] = (char)('0' + k % 10); k /= 10; }
+        }
+        off[(size_t)nc] = (int32_t)(nc * 18);
+        HostCol name{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()};
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5)), name}, nc, {C_CUSTKEY}, &customer, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // part: p_name as offsets + bytes (LIKE operand), the other VARCHAR columns as dictionary codes
@@ -317,6 +329,27 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         int f = p.Filter(j, {}, BoolExpr::OrOf(ors));
         p.Agg(f, {}, {{PH_A_SUM, DiscPrice(1, 2)}});
         q->ncols = 1;
+        break;
+    }
+    case 18: {
+        // Limit <- Order <- Agg(c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice; sum(l_quantity))
+        //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem)
+        //        build <- Join(o_custkey = c_custkey) probe <- SEMI Join(o_orderkey = l_orderkey) probe Scan(orders)
+        //                                                        build Filter(sum > 314) <- Agg(l_orderkey; sum(l_quantity)) <- Scan(lineitem)
+        // (the IN subquery: an aggregate below the join, its HAVING the Filter above it)
+        int subScan = p.Scan(&db.lineitem, {L_ORDERKEY, L_QUANTITY});
+        int sub = p.Agg(subScan, {ProjExpr::Col(0)}, {{PH_A_SUM, {XC(1)}}});
+        int having = p.Filter(sub, {{1, PH_GT, LInt(314)}});
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_TOTALPRICE});
+        int j1 = p.Join(ord, having, {0}, {0}, {0, 1, 2, 3}, JoinSemi);
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_NAME});
+        int j2 = p.Join(j1, cust, {1}, {0}, {0, 2, 3, 4, 5});                 // o_orderkey, o_orderdate, o_totalprice, c_custkey, c_name
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_QUANTITY});
+        int j3 = p.Join(line, j2, {0}, {0}, {1, 6, 5, 2, 3, 4});              // l_quantity, c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice
+        p.Agg(j3, {ProjExpr::Col(1), ProjExpr::Col(2), ProjExpr::Col(3), ProjExpr::Col(4), ProjExpr::Col(5)}, {{PH_A_SUM, {XC(0)}}});
+        q->order = {{4, true}, {3, false}};
+        q->limit = 100;
+        q->ncols = 6;
         break;
     }
     default:

@@ -17,8 +17,8 @@ namespace plan {
 // column positions in the resident tables (cases/tpch/query/ddl.sql names; the pruned columns the queries read)
 enum { L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE,
        L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE, L_SHIPINSTRUCT };
-enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY };
-enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT };
+enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TOTALPRICE };
+enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME };
 enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
 enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST };
 enum { S_SUPPKEY, S_NATIONKEY };
