@@ -242,6 +242,7 @@ int main(int argc, char **argv) {
         else if ((q == "q3" || q == "q9") && argc > 4 && !strcmp(argv[4], "resident")) id = atoi(q.c_str() + 1);
         if (id > 0) {
             int64_t num = atoll(argv[a]), den = atoll(argv[a + 1]);
+            if (num <= 0 || den <= 0) { fprintf(stderr, "scale factor: <num> <den> must both be positive integers\n"); return 2; }
             int repeat = argc > a + (q == "tpch" ? 2 : 3) ? atoi(argv[a + (q == "tpch" ? 2 : 3)]) : 1;
             ph_ctx *ctx = nullptr;
             if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
@@ -271,6 +272,7 @@ int main(int argc, char **argv) {
         }
     }
     int64_t num = atoll(argv[2]), den = atoll(argv[3]);
+    if (num <= 0 || den <= 0) { fprintf(stderr, "scale factor: <num> <den> must both be positive integers\n"); return 2; }
     bool stub = argc > 4 && !strcmp(argv[4], "stub");
     ph_ctx *ctx = nullptr;
     if (ph_ctx_create(0, &ctx) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());

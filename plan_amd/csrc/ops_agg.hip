@@ -224,25 +224,6 @@ __global__ __launch_bounds__(256) void agg_pack_kernel(const int *__restrict__ i
 // finished group once: group ids reserved with one counter add per workgroup, state arrays with
 // plain stores, the slot claimed with one CAS (all keys are distinct, so no key is compared).
 // Rows that find no room in LDS go through find_or_create as in the ordinary sink.
-constexpr int BK_MAX_ARGS = 4;   // argument columns carried in the partition records
-
-struct BulkParams {
-    AggSinkParams S;             // keys, args, selection, table pointers (as in the ordinary sink)
-    int nparts, nused;           // partitions; argument columns carried (S.arg_used bits, in order)
-    int used_col[BK_MAX_ARGS];   // argument column of carried value j
-    int64_t rows_per_wg;
-    int32_t *counts;             // [nparts][nwg] -> offsets after the scan
-    const int64_t *total;        // rows after the scan
-    // partition records, one per row, rec_words 8-byte words each (one contiguous store per row:
-    // separate column arrays cost five scattered 1-8 byte stores per row and made the scatter the
-    // slowest kernel of the build): [keys nkeys][first-row id][values nused][flags]
-    // flags = key NULL mask | argument validity bits << 8 | bit 63: "found no room" (phase 0 -> 1)
-    unsigned long long *rec;
-    int rec_words;
-    int lds_entries;             // T (power of two)
-    int *overflow;               // set when the reserved ids run past gcap (host grows and reruns the build)
-};
-
 template <int NK>
 __device__ __forceinline__ void bulk_row_keys(const AggSinkParams &S, int64_t r, unsigned long long *k, unsigned *nullmask) {
     *nullmask = 0;
@@ -364,6 +345,72 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
             for (int j = 0; j < BK_MAX_ARGS; j++)
                 if (j < B.nused) rec[NK + 1 + j] = (unsigned long long)av[u][j];
             rec[NK + 1 + B.nused] = tail;
+        }
+    }
+}
+
+// The finished groups of one workgroup's LDS table -> the global table (1024-thread workgroups): rank the ready entries,
+// reserve their ids with ONE add, plain stores of the state, one CAS per group for its slot.
+template <int NK>
+__device__ __forceinline__ void bulk_write_groups(const BulkParams &B, int T, const long long *l_first, const unsigned long long *l_key,
+                                                  const unsigned long long *l_lo, const long long *l_hi, const int *l_state,
+                                                  const unsigned *l_cnt, int *s_wsum, int *s_base_p) {
+    const AggSinkParams &S = B.S;
+    const int na = S.naggs;
+    int &s_base = *s_base_p;
+    const int per = T / 1024 > 0 ? T / 1024 : 1;
+    int mine = 0;
+    for (int q = 0; q < per; q++) {
+        const int e = threadIdx.x * per + q;
+        if (e < T && l_state[e] >= 0) mine++;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int rank = incl - mine, total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wv) rank += s_wsum[w];
+        total += s_wsum[w];
+    }
+    if (threadIdx.x == 0) {
+        s_base = total ? atomicAdd(S.ngroups, total) : 0;
+        if (total && (long long)s_base + total > S.gcap) { atomicOr(B.overflow, 1); s_base = -1; }
+    }
+    __syncthreads();
+    if (s_base < 0) return;   // the table is too small: the host grows it and runs this kernel again
+    for (int q = 0; q < per; q++) {
+        const int e = threadIdx.x * per + q;
+        if (e >= T || l_state[e] < 0) continue;
+        const int gid = s_base + rank++;
+        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+        const unsigned nullmask = (unsigned)l_state[e];
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            k[c] = l_key[c * T + e];
+            __hip_atomic_store(&S.gkeys[(int64_t)gid * NK + c], k[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&S.gnull[gid], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arrays are not pre-initialised
+        S.first_row[gid] = l_first[e];
+        for (int a = 0; a < na; a++) {
+            const int kind = S.agg_kind[a];
+            const unsigned long long lo = l_lo[e * na + a];
+            S.cnt[(int64_t)gid * na + a] = l_cnt[e * na + a];
+            S.sum_lo[(int64_t)gid * na + a] = lo;
+            S.sum_hi[(int64_t)gid * na + a] = (kind == PH_A_SUM || kind == PH_A_AVG) ? l_hi[e * na + a] : 0;
+        }
+        // keys visible before the id (same publication rule as find_or_create); every key of this
+        // build is distinct, so the first free slot of the probe sequence is claimed without a compare
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t slot = keys_hash(k, nullmask, NK) & S.mask;
+        for (int guard = 0; guard < (1 << 24); guard++) {
+            if (atomicCAS(&S.slots[slot], SLOT_EMPTY, gid) == SLOT_EMPTY) break;
+            if ((guard & 255) == 255 && __hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            slot = (slot + 1) & S.mask;
         }
     }
 }
@@ -502,62 +549,267 @@ __global__ __launch_bounds__(1024) void bulk_build_kernel(BulkParams B) {
     }
     __syncthreads();   // phase 0 done: the table takes no more keys
     }
-    // ---- write the finished groups: rank the ready entries, reserve their ids with ONE add
-    const int per = T / 1024 > 0 ? T / 1024 : 1;
-    int mine = 0;
-    for (int q = 0; q < per; q++) {
-        const int e = threadIdx.x * per + q;
-        if (e < T && l_state[e] >= 0) mine++;
-    }
+    bulk_write_groups<NK>(B, T, l_first, l_key, l_lo, l_hi, l_state, l_cnt, s_wsum, &s_base);
+}
+
+// ------------------------------------------------------------------ bulk build, second form (big first sinks)
+// The form above scatters one 32-byte record per row straight to its partition: with 512 partitions x 512
+// workgroups the L2 holds a small part of the open lines, so HBM sees 32-byte partial writes (65 k groups, 32 M rows:
+// scatter 1.0 ms, build 0.53 ms). This form
+//   * keeps the partition count at (expected groups) / (groups one LDS table takes) — 128 for 65 k groups — and
+//     gets its parallelism from SLICES: `slices` workgroups aggregate disjoint row ranges of one partition in LDS
+//     tables of their own, write their groups as partial states, and one workgroup per partition merges them;
+//   * stages every 256 x BU-row chunk in LDS ordered by partition, so a chunk leaves as runs of consecutive rows
+//     per partition (16 rows at 128 partitions), into column arrays (key words, argument words, 4-byte row ids, and
+//     flag words only when some key or argument has NULLs): 20 bytes per row for one key and one argument.
+// A table that runs out of room in LDS voids the attempt (bit 1 of *overflow): the host runs the first form.
+template <int NK, bool PLAIN, int BUV, int TPB>
+__global__ __launch_bounds__(TPB) void bulk2_scatter_kernel(Bulk2Params Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sc_lds[];
+    const BulkParams &B = Q.B;
+    const AggSinkParams &S = B.S;
+    constexpr int CH = TPB * BUV;
+    const int P = B.nparts, W = Q.W;
+    int *hist = reinterpret_cast<int *>(sc_lds);
+    int *off = hist + P;
+    int *cursor = off + P;
+    unsigned long long *s_w = reinterpret_cast<unsigned long long *>(cursor + P + (P & 1));
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_w + (size_t)W * CH);
+    int *s_dst = reinterpret_cast<int *>(s_row + CH);
+    uint32_t *s_flags = reinterpret_cast<uint32_t *>(s_dst + CH);
+    __shared__ int s_wsum[TPB / 64];
+    for (int e = threadIdx.x; e < P; e += TPB) { hist[e] = 0; cursor[e] = B.counts[(int64_t)e * gridDim.x + blockIdx.x]; }
+    __syncthreads();
+    const int64_t n = S.n;
+    const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < n ? i0 + B.rows_per_wg : n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-    }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int rank = incl - mine, total = 0;
-    for (int w = 0; w < 16; w++) {
-        if (w < wv) rank += s_wsum[w];
-        total += s_wsum[w];
-    }
-    if (threadIdx.x == 0) {
-        s_base = total ? atomicAdd(S.ngroups, total) : 0;
-        if (total && (long long)s_base + total > S.gcap) { atomicOr(B.overflow, 1); s_base = -1; }
-    }
-    __syncthreads();
-    if (s_base < 0) return;   // the table is too small: the host grows it and runs this kernel again
-    for (int q = 0; q < per; q++) {
-        const int e = threadIdx.x * per + q;
-        if (e >= T || l_state[e] < 0) continue;
-        const int gid = s_base + rank++;
-        unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
-        const unsigned nullmask = (unsigned)l_state[e];
+    int64_t ii[BUV], rr[BUV];
+    unsigned long long k[BUV][NK];
+    unsigned nm[BUV], vb[BUV];
+    long long av[BUV][BK_MAX_ARGS];
+    // the reads of one chunk (keys, argument values): issued for chunk c + 1 as soon as chunk c sits in LDS, so they are in
+    // flight while c is written out (two 256-thread workgroups per CU hide little latency by themselves)
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int u = 0; u < BUV; u++) {
+            ii[u] = base + u * TPB + threadIdx.x;
+            const int64_t ic = ii[u] < i1 ? ii[u] : i1 - 1;
+            rr[u] = S.sel ? (int64_t)S.sel[ic] : ic;
+            nm[u] = 0;
+            vb[u] = 0xFu;
+        }
 #pragma unroll
         for (int c = 0; c < NK; c++) {
-            k[c] = l_key[c * T + e];
-            __hip_atomic_store(&S.gkeys[(int64_t)gid * NK + c], k[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int t = S.key[c].type;   // wave-uniform
+            if (t == PH_I32 || t == PH_DATE) {
+#pragma unroll
+                for (int u = 0; u < BUV; u++) k[u][c] = (unsigned long long)(long long)((const int32_t *)S.key[c].data)[rr[u]];
+            } else if (t == PH_CODE8) {
+#pragma unroll
+                for (int u = 0; u < BUV; u++) k[u][c] = ((const uint8_t *)S.key[c].data)[rr[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < BUV; u++) k[u][c] = ((const unsigned long long *)S.key[c].data)[rr[u]];
+            }
+            if (!PLAIN && S.key[c].validity) {
+#pragma unroll
+                for (int u = 0; u < BUV; u++)
+                    if (!bit_valid(S.key[c].validity, rr[u])) { k[u][c] = 0; nm[u] |= 1u << c; }
+            }
         }
-        __hip_atomic_store(&S.gnull[gid], nullmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // arrays are not pre-initialised
-        S.first_row[gid] = l_first[e];
+#pragma unroll
+        for (int j = 0; j < BK_MAX_ARGS; j++) {
+            if (j >= B.nused) break;   // wave-uniform
+            const AggCol &c = S.arg[B.used_col[j]];
+            const bool w32 = c.type == PH_I32;
+#pragma unroll
+            for (int u = 0; u < BUV; u++) {
+                const int64_t ic = ii[u] < i1 ? ii[u] : i1 - 1;
+                const int64_t ar = S.positional ? ic : rr[u];
+                av[u][j] = w32 ? (long long)((const int32_t *)c.data)[ar] : ((const int64_t *)c.data)[ar];
+                if (!PLAIN && !bit_valid(c.validity, ar)) { vb[u] &= ~(1u << j); av[u][j] = 0; }
+            }
+        }
+    };
+    if (i0 < i1) fetch(i0);
+    for (int64_t base = i0; base < i1; base += CH) {
+        int part[BUV], rank[BUV];
+        uint32_t rowv[BUV];
+        bool live[BUV];
+#pragma unroll
+        for (int u = 0; u < BUV; u++) { live[u] = ii[u] < i1; rowv[u] = (uint32_t)(S.sel ? rr[u] : ii[u]); }
+        // rank of every row inside its partition's run of this chunk
+#pragma unroll
+        for (int u = 0; u < BUV; u++) {
+            unsigned long long kk[AGG_MAX_KEYS] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NK; c++) kk[c] = k[u][c];
+            part[u] = (int)((keys_hash(kk, nm[u], NK) >> 40) & (uint64_t)(P - 1));
+            rank[u] = live[u] ? atomicAdd(&hist[part[u]], 1) : 0;
+        }
+        __syncthreads();
+        {   // exclusive scan of the chunk's histogram: `per` consecutive partitions per thread
+            const int per = (P + TPB - 1) / TPB;
+            int sum = 0;
+            for (int q = 0; q < per; q++) { const int e = threadIdx.x * per + q; if (e < P) sum += hist[e]; }
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wv; w++) run += s_wsum[w];
+            for (int q = 0; q < per; q++) { const int e = threadIdx.x * per + q; if (e < P) { off[e] = run; run += hist[e]; } }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BUV; u++) {
+            if (!live[u]) continue;
+            const int j = off[part[u]] + rank[u];
+#pragma unroll
+            for (int c = 0; c < NK; c++) s_w[(size_t)j * W + c] = k[u][c];
+#pragma unroll
+            for (int a = 0; a < BK_MAX_ARGS; a++)
+                if (a < B.nused) s_w[(size_t)j * W + NK + a] = (unsigned long long)av[u][a];
+            s_row[j] = rowv[u];
+            s_dst[j] = cursor[part[u]] + rank[u];
+            if (!PLAIN) s_flags[j] = nm[u] | (vb[u] << 8);
+        }
+        if (base + CH < i1) fetch(base + CH);
+        __syncthreads();
+        const int m = (int)(i1 - base < CH ? i1 - base : CH);
+        for (int j = threadIdx.x; j < m; j += TPB) {
+            const int64_t d = s_dst[j];
+            if (W == 2) {   // the common record {key, argument}: one 16-byte store
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                reinterpret_cast<u64x2 *>(Q.w64)[d] = reinterpret_cast<const u64x2 *>(s_w)[j];
+            } else {
+                for (int c = 0; c < W; c++) Q.w64[d * W + c] = s_w[(size_t)j * W + c];
+            }
+            Q.rowid[d] = s_row[j];
+            if (!PLAIN) Q.flags[d] = s_flags[j];
+        }
+        for (int e = threadIdx.x; e < P; e += TPB) { cursor[e] += hist[e]; hist[e] = 0; }
+        __syncthreads();
+    }
+}
+
+// the LDS table of the build workgroups: [first T x i64][key NK*T x u64][lo T*na x u64][hi T*na x i64][state T x i32][cnt T*na x u32]
+struct BulkLds {
+    long long *first;
+    unsigned long long *key, *lo;
+    long long *hi;
+    int *state;
+    unsigned *cnt;
+};
+template <int NK>
+__device__ __forceinline__ BulkLds bulk_lds_init(unsigned char *lds, int T, const AggSinkParams &S) {
+    BulkLds L;
+    const int na = S.naggs;
+    L.first = reinterpret_cast<long long *>(lds);
+    L.key = reinterpret_cast<unsigned long long *>(L.first + T);
+    L.lo = L.key + (size_t)NK * T;
+    L.hi = reinterpret_cast<long long *>(L.lo + (size_t)T * na);
+    L.state = reinterpret_cast<int *>(L.hi + (size_t)T * na);
+    L.cnt = reinterpret_cast<unsigned *>(L.state + T);
+    for (int e = threadIdx.x; e < T; e += blockDim.x) {
+        L.state[e] = L_EMPTY;
+        L.first[e] = INT64_MAX;
         for (int a = 0; a < na; a++) {
             const int kind = S.agg_kind[a];
-            const unsigned long long lo = l_lo[e * na + a];
-            S.cnt[(int64_t)gid * na + a] = l_cnt[e * na + a];
-            S.sum_lo[(int64_t)gid * na + a] = lo;
-            S.sum_hi[(int64_t)gid * na + a] = (kind == PH_A_SUM || kind == PH_A_AVG) ? l_hi[e * na + a] : 0;
-        }
-        // keys visible before the id (same publication rule as find_or_create); every key of this
-        // build is distinct, so the first free slot of the probe sequence is claimed without a compare
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint64_t slot = keys_hash(k, nullmask, NK) & S.mask;
-        for (int guard = 0; guard < (1 << 24); guard++) {
-            if (atomicCAS(&S.slots[slot], SLOT_EMPTY, gid) == SLOT_EMPTY) break;
-            if ((guard & 255) == 255 && __hip_atomic_load(S.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            slot = (slot + 1) & S.mask;
+            L.lo[e * na + a] = kind == PH_A_MIN ? (unsigned long long)INT64_MAX : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+            L.hi[e * na + a] = 0;
+            L.cnt[e * na + a] = 0;
         }
     }
+    return L;
+}
+
+// find the key's entry or insert it; -1 when the table takes no more keys (three quarters full) or the probe window ends
+template <int NK>
+__device__ __forceinline__ int bulk_lds_find_insert(const BulkLds &L, int T, const unsigned long long *k, unsigned nullmask, int *s_nent) {
+    int idx = (int)lds_hash<NK>(k, nullmask) & (T - 1);
+    for (int probes = 0, spins = 0; probes < 32 && spins < (1 << 16);) {
+        const int st = __hip_atomic_load(&L.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (st == L_EMPTY) {
+            if (__hip_atomic_load(s_nent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= T - T / 4) return -1;
+            const int old = atomicCAS(&L.state[idx], L_EMPTY, L_LOCKED);
+            if (old == L_EMPTY) {
+                atomicAdd(s_nent, 1);
+#pragma unroll
+                for (int c = 0; c < NK; c++) L.key[c * T + idx] = k[c];
+                __hip_atomic_store(&L.state[idx], (int)nullmask, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return idx;
+            }
+            spins++;
+        } else if (st == L_LOCKED) {
+            spins++;
+        } else {
+            bool eq = st == (int)nullmask;
+#pragma unroll
+            for (int c = 0; c < NK; c++) eq = eq && L.key[c * T + idx] == k[c];
+            if (eq) return idx;
+            idx = (idx + 1) & (T - 1);
+            probes++;
+        }
+    }
+    return -1;
+}
+
+// slice `s` of partition `p`: its rows aggregated in LDS, its groups written as partial states (bulk2_partial_body, agg_sink.inc;
+// the plan-specialised form of the same body is compiled at run time: agg_bulk2_partial_spec)
+template <int NK, bool PLAIN>
+__global__ __launch_bounds__(1024) void bulk2_partial_kernel(Bulk2Params Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
+    __shared__ int s_nent, s_wsum[16], s_void;
+    bulk2_partial_body<NK, PLAIN>(Q, bk_lds, s_nent, s_wsum, s_void);
+}
+
+// partition p: the partial states of its slices merged in LDS, the finished groups written to the table
+template <int NK>
+__global__ __launch_bounds__(1024) void bulk2_merge_kernel(Bulk2Params Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
+    __shared__ int s_nent, s_base, s_wsum[16], s_void;
+    const BulkParams &B = Q.B;
+    const AggSinkParams &S = B.S;
+    const int T = B.lds_entries, na = S.naggs;
+    if (__hip_atomic_load(B.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) return;   // a slice ran out of room (the previous launch)
+    const BulkLds L = bulk_lds_init<NK>(bk_lds, T, S);
+    if (threadIdx.x == 0) { s_nent = 0; s_void = 0; }
+    __syncthreads();
+    const int p = blockIdx.x;
+    for (int sl = 0; sl < Q.slices; sl++) {
+        const int wg = p * Q.slices + sl, cnt = Q.partial_n[wg];
+        const unsigned long long *in = Q.partials + (int64_t)wg * Q.pcap * Q.pwords;
+        for (int t = threadIdx.x; t < cnt; t += 1024) {
+            const unsigned long long *o = in + (int64_t)t * Q.pwords;
+            unsigned long long k[AGG_MAX_KEYS] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NK; c++) k[c] = o[c];
+            const long long frow = (long long)o[NK];
+            const unsigned nullmask = (unsigned)o[NK + 1];
+            const int ent = bulk_lds_find_insert<NK>(L, T, k, nullmask, &s_nent);
+            if (ent < 0) { s_void = 1; continue; }
+            if (frow < L.first[ent]) atomicMin(&L.first[ent], frow);
+            for (int a = 0; a < na; a++) {
+                const int kind = S.agg_kind[a];
+                const unsigned long long lo = o[NK + 2 + 3 * a];
+                const long long hi = (long long)o[NK + 3 + 3 * a];
+                const unsigned c = (unsigned)o[NK + 4 + 3 * a];
+                if (c == 0) continue;   // this slice saw no input of the aggregate
+                const int ls = ent * na + a;
+                atomicAdd(&L.cnt[ls], c);
+                if (kind == PH_A_SUM || kind == PH_A_AVG) {   // 128-bit add: low words with carry into the high ones
+                    const unsigned long long old = atomicAdd(&L.lo[ls], lo);
+                    const long long delta = hi + (old + lo < old ? 1 : 0);
+                    if (delta) atomicAdd((unsigned long long *)&L.hi[ls], (unsigned long long)delta);
+                } else if (kind == PH_A_MIN) atomicMin((long long *)&L.lo[ls], (long long)lo);
+                else if (kind == PH_A_MAX) atomicMax((long long *)&L.lo[ls], (long long)lo);
+            }
+        }
+    }
+    __syncthreads();
+    if (s_void) { if (threadIdx.x == 0) atomicOr(B.overflow, 2); return; }
+    bulk_write_groups<NK>(B, T, L.first, L.key, L.lo, L.hi, L.state, L.cnt, s_wsum, &s_base);
 }
 
 // key column c of all groups -> dense column + validity bits; a thread converts 8 groups
@@ -784,9 +1036,171 @@ int bulk_launch(ph_agg *a, ph::BulkParams &B, int nwg, size_t lds, int64_t nc, i
     return PH_OK;
 }
 
+int bulk2_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, bool plain, int slots, size_t lds, ph::JitKernel *out);
+
+// Second form of the bulk build (see bulk2_scatter_kernel): PH_EUNSUPPORTED = not this shape, or the attempt was void
+// (nothing sunk, table and counters clean) — the caller runs the first form.
+template <int NK>
+int bulk2_launch(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_build, size_t lds_scatter, int bu, int tpb, bool plain, int64_t nc,
+                 int64_t *total_dev, bool merge_only) {
+    hipStream_t st = a->ctx->stream;
+    if (!merge_only) {
+        if (plain) ph::bulk_count_kernel<NK, true><<<nwg, 256, (size_t)Q.B.nparts * 4, st>>>(Q.B);
+        else ph::bulk_count_kernel<NK, false><<<nwg, 256, (size_t)Q.B.nparts * 4, st>>>(Q.B);
+        PH_CHECK(ph::exclusive_scan_i32(a->ctx, Q.B.counts, nc, total_dev));
+#define PH_B2S(PL, BU, TP)                                                                                                                \
+    do {                                                                                                                                  \
+        PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_scatter_kernel<NK, PL, BU, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+        ph::bulk2_scatter_kernel<NK, PL, BU, TP><<<nwg, TP, lds_scatter, st>>>(Q);                                                       \
+    } while (0)
+        // the chunk is bu x 256 rows whatever the shape of the workgroup: 1024 threads x bu / 4 rows (more waves per CU to
+        // hide the reads and the write-out behind) or 256 threads x bu rows
+        if (tpb == 1024) {
+            if (plain) { if (bu == 16) PH_B2S(true, 4, 1024); else if (bu == 8) PH_B2S(true, 2, 1024); else PH_B2S(true, 1, 1024); }
+            else { if (bu == 16) PH_B2S(false, 4, 1024); else if (bu == 8) PH_B2S(false, 2, 1024); else PH_B2S(false, 1, 1024); }
+        } else if (tpb == 512) {
+            if (plain) { if (bu == 8) PH_B2S(true, 4, 512); else if (bu == 4) PH_B2S(true, 2, 512); else PH_B2S(true, 1, 512); }
+            else { if (bu == 8) PH_B2S(false, 4, 512); else if (bu == 4) PH_B2S(false, 2, 512); else PH_B2S(false, 1, 512); }
+        } else {
+            if (plain) { if (bu == 8) PH_B2S(true, 8, 256); else if (bu == 4) PH_B2S(true, 4, 256); else PH_B2S(true, 2, 256); }
+            else { if (bu == 8) PH_B2S(false, 8, 256); else if (bu == 4) PH_B2S(false, 4, 256); else PH_B2S(false, 2, 256); }
+        }
+#undef PH_B2S
+        ph::JitKernel spec{};
+        if (bulk2_spec_kernel(a->ctx, Q.B.S, plain, Q.B.lds_entries, lds_build, &spec) == PH_OK) {
+            // the body specialised for this shape through hiprtc (the generic one spends ~370 instructions per 64 rows on
+            // aggregate-kind and argument-slot interpretation: 320 us per 32 M rows)
+            ph::Bulk2Params copy = Q;
+            size_t size = sizeof copy;
+            void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+            PH_HIP(hipModuleLaunchKernel(spec.fn, (unsigned)(Q.B.nparts * Q.slices), 1, 1, 1024, 1, 1, 0, st, nullptr, config));
+        } else if (plain) {
+            PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_partial_kernel<NK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            ph::bulk2_partial_kernel<NK, true><<<Q.B.nparts * Q.slices, 1024, lds_build, st>>>(Q);
+        } else {
+            PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_partial_kernel<NK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            ph::bulk2_partial_kernel<NK, false><<<Q.B.nparts * Q.slices, 1024, lds_build, st>>>(Q);
+        }
+    }
+    PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_merge_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    ph::bulk2_merge_kernel<NK><<<Q.B.nparts, 1024, lds_build, st>>>(Q);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n) {
+    static const bool off = getenv("PH_AGG_BULK_V1") != nullptr;
+    if (off || n < (4ll << 20) || n >= (1ll << 31)) return PH_EUNSUPPORTED;
+    ph_ctx *ctx = a->ctx;
+    ph::Bulk2Params Q{};
+    ph::BulkParams &B = Q.B;
+    B.S = P;
+    bool plain = true;
+    for (int c = 0; c < P.nargs; c++) {
+        if (!used[c]) continue;
+        if (B.nused == ph::BK_MAX_ARGS) return PH_EUNSUPPORTED;
+        B.used_col[B.nused++] = c;
+        plain = plain && !P.arg[c].validity;
+    }
+    for (int c = 0; c < P.nargs; c++) if (used[c]) B.S.arg_used |= 1u << c;   // (the specialised partial build derives the argument slots from it)
+    const int nk = a->nkeys, na = a->naggs;
+    for (int c = 0; c < nk; c++) plain = plain && !P.key[c].validity;
+    const int per_entry = 4 + 8 * nk + 8 + 20 * na;
+    int T = 256;
+    while (T * 2 * per_entry <= 120 * 1024 && T < 4096) T *= 2;
+    if (T * per_entry > 120 * 1024) return PH_EUNSUPPORTED;
+    if (const char *te = getenv("PH_AGG_BULK_T")) { const int v = atoi(te); if (v >= 256 && v <= T && (v & (v - 1)) == 0) T = v; }
+    B.lds_entries = T;
+    // partitions: a quarter-full LDS table per partition (every slice of a partition sees all of its groups)
+    const int64_t want_parts = (a->expected_groups + T / 4 - 1) / (T / 4);
+    int nparts = 16;
+    while (nparts < want_parts) nparts *= 2;
+    if (nparts > 512) return PH_EUNSUPPORTED;   // runs of a row or two per partition and chunk: the first form
+    B.nparts = nparts;
+    int slices = 1;
+    while (nparts * slices < 512 && slices < 64) slices *= 2;   // two workgroups per CU in all: every slice pays a table initialisation and a write-out
+    if (const char *se = getenv("PH_AGG_BULK_SLICES")) slices = std::max(1, std::min(atoi(se), 64));
+    Q.slices = slices;
+    Q.W = nk + B.nused;
+    // chunk of the scatter: what fits 64 KiB of LDS beside the three partition tables (two workgroups per CU)
+    const int row_bytes = 8 * Q.W + 8 + (plain ? 0 : 4);
+    const size_t tables = (size_t)(3 * nparts + (nparts & 1)) * 4;
+    int bu = 8;
+    while (bu > 2 && tables + (size_t)256 * bu * row_bytes > 64 * 1024) bu /= 2;
+    if (const char *be = getenv("PH_AGG_BULK_BU")) { const int v = atoi(be); if (v == 2 || v == 4 || v == 8) bu = v; }
+    int tpb = 1024;
+    if (const char *te = getenv("PH_AGG_BULK_TPB")) { const int v = atoi(te); if (v == 256 || v == 512 || v == 1024) tpb = v; }
+    if (tpb == 1024 && bu < 4) bu = 4;   // at least a row per thread
+    // one 1024-thread workgroup per CU can stage 4096 rows: runs twice as long per partition (fewer partial lines written)
+    if (tpb == 1024 && bu == 8 && !getenv("PH_AGG_BULK_BU") && tables + (size_t)256 * 16 * row_bytes <= 120 * 1024) bu = 16;
+    if (const char *be = getenv("PH_AGG_BULK_BU")) { if (atoi(be) == 16 && tpb == 1024 && tables + (size_t)256 * 16 * row_bytes <= 120 * 1024) bu = 16; }
+    const size_t lds_scatter = tables + (size_t)256 * bu * row_bytes;
+    if (lds_scatter > 124 * 1024) return PH_EUNSUPPORTED;
+    const int ch = 256 * bu;
+    B.rows_per_wg = std::max<int64_t>(ch, ph::round_up((n + 511) / 512, ch));
+    const int nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
+    const int64_t nc = (int64_t)nparts * nwg;
+    int64_t cap = a->cap ? a->cap : next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups));
+    cap = std::max(cap, next_pow2(4 * a->expected_groups));
+    bool new_table = false;
+    if (cap != a->cap) { PH_CHECK(agg_resize(a, cap, 0, false)); new_table = true; }
+    Q.pcap = T;
+    Q.pwords = nk + 2 + 3 * na;
+    char *tmp = nullptr;
+    const int64_t o_w64 = ph::round_up(nc * 4, 16), o_row = o_w64 + (int64_t)Q.W * n * 8, o_flags = o_row + ph::round_up(n * 4, 16),
+                  o_part = o_flags + (plain ? 0 : ph::round_up(n * 4, 16)), o_pn = o_part + (int64_t)nparts * slices * Q.pcap * Q.pwords * 8,
+                  o_total = o_pn + ph::round_up((int64_t)nparts * slices * 4, 16);
+    PH_CHECK(ctx->pool_alloc(o_total + 16, (void **)&tmp));
+    B.counts = (int32_t *)tmp;
+    Q.w64 = (unsigned long long *)(tmp + o_w64);
+    Q.rowid = (uint32_t *)(tmp + o_row);
+    Q.flags = plain ? nullptr : (uint32_t *)(tmp + o_flags);
+    Q.partials = (unsigned long long *)(tmp + o_part);
+    Q.partial_n = (int *)(tmp + o_pn);
+    int64_t *total_dev = (int64_t *)(tmp + o_total);
+    B.total = total_dev;
+    B.overflow = a->counters + 2;
+    const size_t lds_build = (size_t)T * per_entry;
+    int rc = PH_OK;
+    bool settled = false, voided = false;
+    for (int attempt = 0; attempt < 6 && rc == PH_OK; attempt++) {
+        B.S.slots = a->slots;
+        B.S.mask = (uint64_t)a->cap - 1;
+        B.S.gkeys = a->gkeys; B.S.gnull = a->gnull; B.S.sum_lo = a->sum_lo; B.S.sum_hi = a->sum_hi;
+        B.S.cnt = a->cnt; B.S.first_row = a->first_row; B.S.gcap = a->gcap;
+        if (attempt == 0) {
+            if ((rc = agg_clear(a, new_table, 0, 4, nullptr, 0)) != PH_OK) break;
+            a->fresh = false;
+        } else if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+        switch (nk) {
+        case 1: rc = bulk2_launch<1>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
+        case 2: rc = bulk2_launch<2>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
+        case 3: rc = bulk2_launch<3>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
+        default: rc = bulk2_launch<4>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
+        }
+        if (rc != PH_OK) break;
+        int c[3] = {0, 0, 0};
+        if ((rc = ctx->download(c, a->counters, 12)) != PH_OK) break;
+        if (c[2] & 2) { voided = true; break; }          // an LDS table ran out of room: more groups than the hint said
+        if (!c[1] && !c[2]) { settled = true; break; }
+        rc = agg_resize(a, next_pow2(4 * std::max<int64_t>(c[0], a->gcap)), 0);   // ids ran out: a larger table, the merge again
+    }
+    ctx->pool_release(tmp);
+    if (rc != PH_OK) return rc;
+    if (settled) return PH_OK;
+    // void: leave an empty table and clean counters behind
+    (void)voided;
+    PH_CHECK(agg_clear(a, true, 0, 4, nullptr, 0));
+    return PH_EUNSUPPORTED;
+}
+
 // First sink into an empty table with a high expected cardinality: see bulk_build_kernel.
 // Returns PH_EUNSUPPORTED when the shape is not handled (the caller runs the ordinary sink).
 int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n) {
+    {   // big inputs, up to ~260 k expected groups: the staged, sliced form
+        const int rc2 = bulk_sink_v2(a, P, used, n);
+        if (rc2 != PH_EUNSUPPORTED) return rc2;
+    }
     ph_ctx *ctx = a->ctx;
     ph::BulkParams B{};
     B.S = P;
@@ -916,6 +1330,20 @@ int agg_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, int threads, int sl
 
 }  // namespace
 
+namespace {
+// the partial build of the bulk form (agg_bulk2_partial_spec) for this shape, or PH_EUNSUPPORTED
+int bulk2_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, bool plain, int slots, size_t lds, ph::JitKernel *out) {
+    const char *e = getenv("PH_AGG_JIT");
+    if (e && atoi(e) == 0) return PH_EUNSUPPORTED;
+    std::string key;
+    std::string defs = agg_spec_defines(P, 1024, slots, lds, &key) + "#define PH_SPEC_BULK2 1\n#define SPEC_BULK_PLAIN " + (plain ? "1" : "0") + "\n";
+    key = "aggbulk2:" + key + (plain ? "p" : "n");
+    if (ph::jit_cached(ctx, key, out)) return PH_OK;
+    int rc = ph::jit_module(ctx, key, defs + AGG_SINK_SRC, "agg_bulk2_partial_spec", out);
+    return rc == PH_OK ? PH_OK : PH_EUNSUPPORTED;
+}
+}  // namespace
+
 // Build check without a device: the sink source specialised for a Q9-like shape (two INTEGER keys,
 // SUM of a decimal, positional arguments) and a nullable two-aggregate shape compile for gfx950.
 extern "C" int ph_agg_jit_selfcheck(int32_t which) {
@@ -935,8 +1363,30 @@ extern "C" int ph_agg_jit_selfcheck(int32_t which) {
         P.agg_arg[0] = 0; P.agg_arg[1] = 1; P.agg_arg[2] = -1; P.agg_arg[3] = 1;
         P.sel = reinterpret_cast<const int32_t *>(&dummy);
         P.agg_mask = 0xb; P.arg_used = 3;
+    } else if (which == 2 || which == 3) {
+        // the partial build of the bulk form: one BIGINT key, SUM + COUNT(*) without NULLs / two keys, NULL-able argument, MIN + AVG + COUNT
+        static const uint8_t dummy = 0;
+        std::string key, log;
+        if (which == 2) {
+            P.nkeys = 1; P.naggs = 2; P.nargs = 1;
+            P.key[0].type = PH_I64; P.arg[0].type = PH_I64;
+            P.agg_kind[0] = PH_A_SUM; P.agg_arg[0] = 0; P.agg_kind[1] = PH_A_COUNT_STAR; P.agg_arg[1] = -1;
+            P.agg_mask = ~0u; P.arg_used = 1;
+        } else {
+            P.nkeys = 2; P.naggs = 3; P.nargs = 3;
+            P.key[0].type = PH_I64; P.key[1].type = PH_I32; P.key[0].validity = &dummy;
+            P.arg[0].type = PH_DEC64; P.arg[2].type = PH_I32; P.arg[2].validity = &dummy;
+            P.agg_kind[0] = PH_A_MIN; P.agg_arg[0] = 2; P.agg_kind[1] = PH_A_AVG; P.agg_arg[1] = 0; P.agg_kind[2] = PH_A_COUNT; P.agg_arg[2] = 2;
+            P.agg_mask = ~0u; P.arg_used = 5;
+        }
+        const int slots = which == 2 ? 2048 : 1024;
+        std::string src = agg_spec_defines(P, 1024, slots, (size_t)slots * (4 + 8 * P.nkeys + 8 + 20 * P.naggs), &key) +
+                          "#define PH_SPEC_BULK2 1\n#define SPEC_BULK_PLAIN " + (which == 2 ? "1" : "0") + "\n" + AGG_SINK_SRC;
+        int rc = ph::jit_compile_only(src, "gfx950", &log);
+        if (rc != PH_OK) ph::set_error("ph_agg_jit_selfcheck(%d): %s", which, log.c_str());
+        return rc;
     } else {
-        ph::set_error("ph_agg_jit_selfcheck: shapes 0..1");
+        ph::set_error("ph_agg_jit_selfcheck: shapes 0..3");
         return PH_EINVAL;
     }
     std::string key, log;

@@ -96,9 +96,10 @@ def test_plan_specialised_kernels_generate_and_compile_for_gfx950():
 
 def test_specialised_aggregate_sink_source_compiles_for_gfx950():
     """agg_sink.inc through hiprtc with a sink shape as compile-time constants (what ph_agg_sink
-    does for calls of >= 2^20 rows): both canned shapes compile for gfx950 without a device."""
+    does for calls of >= 2^20 rows): both canned sink shapes, and two shapes of the bulk build's partial
+    kernel (agg_bulk2_partial_spec), compile for gfx950 without a device."""
     lib = hip.lib()
-    for which in (0, 1):
+    for which in (0, 1, 2, 3):
         assert lib.ph_agg_jit_selfcheck(which) == hip.PH_OK, lib.ph_last_error().decode()
     assert lib.ph_agg_jit_selfcheck(7) == hip.PH_EINVAL
 

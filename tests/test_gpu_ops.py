@@ -451,6 +451,60 @@ def test_agg_bulk_build_outgrows_its_hint(ctx):
     agg.free(); dk.free(); dv.free()
 
 
+def test_agg_bulk_build_second_form(ctx):
+    """More than 4 M rows and up to ~260 k expected groups: the bulk build's second form — chunks staged in LDS by
+    partition, `slices` workgroups per partition aggregating in LDS tables of their own, one merge workgroup per
+    partition. Against the oracle: two keys (one with NULLs), NULL arguments, every aggregate kind, a selection.
+    Against numpy: 65 536 groups of 5 M plain rows (keys, first rows, sums, counts), and sums whose 128-bit carries
+    and borrows cross the slices of a partition."""
+    rng = np.random.default_rng(41)
+    n = 4_400_000
+    k0 = rng.integers(0, 11_000, n).astype(np.int64)
+    k1 = rng.integers(0, 4, n).astype(np.int32)
+    vk, _ = rnd_validity(rng, n, 0.01)
+    va, _ = rnd_validity(rng, n, 0.2)
+    v = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    q = rng.integers(1, 51, n).astype(np.int32)
+    sel = np.sort(rng.choice(n, 4_250_000, replace=False))
+    keys = [(hip.PH_I64, O.OT_INT64, k0, 0, vk), (hip.PH_I32, O.OT_INT32, k1, 0, None)]
+    args = [(hip.PH_DEC64, O.OT_DECIMAL, v, 2, va), (hip.PH_I32, O.OT_INT32, q, 0, None)]
+    aggs = [(hip.PH_A_SUM, 0), (hip.PH_A_AVG, 1), (hip.PH_A_COUNT, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 0), (hip.PH_A_COUNT_STAR, -1)]
+    r = agg_compare(ctx, keys, args, aggs, n, sel=sel, expected=50_000)
+    assert r["ngroups"] == 4 * 11_001
+    # plain rows, 65 536 groups
+    n = 5_000_000
+    k = rng.integers(0, 65_536, n).astype(np.int64)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], 65_536)
+    dk, dv = hip.DevColumn(ctx, hip.PH_I64, k), hip.DevColumn(ctx, hip.PH_I64, v)
+    agg.sink([dk], [dv], None, n, row_base=1000)
+    r = agg.finalize(python_ints=False)
+    uk, first, inv = np.unique(k, return_index=True, return_inverse=True)
+    order = np.argsort(first)
+    assert r["ngroups"] == len(uk)
+    assert np.array_equal(r["keys"][:, 0], uk[order]) and np.array_equal(r["first_row"], first[order] + 1000)
+    sums = np.zeros(len(uk), np.int64); np.add.at(sums, inv, v)
+    assert np.array_equal(r["sum_lo"][:, 0].astype(np.int64), sums[order])
+    assert np.array_equal(r["sum_hi"][:, 0], np.where(sums[order] < 0, -1, 0))
+    assert np.array_equal(r["count"][:, 1], np.bincount(inv)[order])
+    agg.free(); dk.free(); dv.free()
+    # 128-bit sums: +-2^62 per row, 3000 groups
+    n = 4_300_000
+    k = rng.integers(0, 3000, n).astype(np.int32)
+    sign = rng.integers(0, 2, n).astype(np.int64) * 2 - 1
+    v = sign * (2**62)
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_SUM, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 0)], 3000)
+    dk, dv = hip.DevColumn(ctx, hip.PH_I32, k), hip.DevColumn(ctx, hip.PH_I64, v)
+    agg.sink([dk], [dv], None, n)
+    r = agg.finalize()
+    net = np.zeros(3000, np.int64); np.add.at(net, k, sign)
+    assert r["ngroups"] == 3000
+    for g in range(3000):
+        key = int(r["keys"][g][0])
+        assert r["sum"][g][0] == int(net[key]) * 2**62 and r["sum"][g][1] == -(2**62) and r["sum"][g][2] == 2**62
+    agg.free(); dk.free(); dv.free()
+
+
 def test_agg_single_hot_group_and_empty(ctx):
     n = 300_000
     k = np.zeros(n, np.int32)
