@@ -2372,6 +2372,49 @@ static int sorted_fill_occupancy(int kw, bool gated) {
     return std::min(occ, 8);
 }
 
+namespace ph {
+// min / max of the build keys (NULL keys and rows outside the selection skipped): out = {min, max}, preset to {INT64_MAX, INT64_MIN}
+__global__ void join_key_range_init_kernel(long long *out) { out[0] = INT64_MAX; out[1] = INT64_MIN; }
+
+template <int KW>
+__global__ __launch_bounds__(256) void join_key_range_kernel(const void *__restrict__ kcol, const uint8_t *__restrict__ valid,
+                                                             const int32_t *__restrict__ sel, int64_t n, long long *__restrict__ out) {
+    long long lo = INT64_MAX, hi = INT64_MIN;
+    constexpr int U = 8;   // keys of a thread in flight together (two workgroups per CU: little else hides the latency)
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U; base < n; base += (int64_t)gridDim.x * 256 * U) {
+        long long x[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            ok[u] = i < n;
+            const int64_t r = ok[u] ? (sel ? (int64_t)sel[i] : i) : 0;
+            ok[u] = ok[u] && (!valid || bit_valid(valid, r));
+            x[u] = KW == 4 ? (long long)((const int32_t *)kcol)[r] : ((const long long *)kcol)[r];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            lo = ok[u] && x[u] < lo ? x[u] : lo;
+            hi = ok[u] && x[u] > hi ? x[u] : hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    // ONE pair of atomics per workgroup: atomics on one address execute one after the other at the memory side
+    // (~12 ns each; a pair per wave of a 2048-workgroup grid was 0.2 ms for a 25 us pass)
+    __shared__ long long s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+        if (lo <= hi) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
+    }
+}
+}  // namespace ph
+
 static int build_direct(ph_join *j, int kw, int64_t lo, int64_t range, const ph::RangePred &where_in, bool declared_sorted_unique) {
     ph_ctx *ctx = j->ctx;
     const int64_t n = j->build.n;
@@ -2736,6 +2779,33 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
     j->ctx = ctx;
     int rc = fill_side(&j->build, keys, nkeys, sel, n);
     if (rc != PH_OK) { delete j; return rc; }
+    if (!have_range && nkeys == 1 && where.kind == 0 && n >= (1ll << 20)) {
+        // No range from the caller and a build side big enough for the node table (whose probes cost a 128-byte line per row,
+        // hashing away whatever order the probe keys have: 15 M keys + 60 M probes 1.53 ms): read the key range off the column
+        // first — one streaming pass and one host round trip (~40 us for 15 M keys) — and let the density test below decide.
+        // Keys that are dense in their range (any surrogate key, also one that arrives here as an intermediate result without
+        // statistics) get the direct table: build + probe 0.11 + 0.45 ms for the same sizes.
+        const char *ar = getenv("PH_JOIN_AUTO_RANGE");   // read per call: the tests build both forms over the same keys
+        const int t = keys[0].type;
+        const int kw = (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8;
+        if (!(ar && atoi(ar) == 0) && kw != 1) {
+            long long *mm = nullptr;
+            if (ctx->pool_alloc(16, (void **)&mm) != PH_OK) { ph_join_free(j); ph::set_error("ph_join_build: allocation failed"); return PH_EHIP; }
+            long long res[2] = {0, -1};
+            const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 2);
+            bool ok = true;   // (a copy of the two initial words from pageable host memory costs ~0.2 ms: a one-thread kernel instead)
+            ph::join_key_range_init_kernel<<<1, 1, 0, ctx->stream>>>(mm);
+            {
+                const ph::JoinSide &Bs = j->build;
+                if (kw == 4) ph::join_key_range_kernel<4><<<grid, 256, 0, ctx->stream>>>(Bs.key[0].data, Bs.key[0].validity, Bs.sel, n, mm);
+                else ph::join_key_range_kernel<8><<<grid, 256, 0, ctx->stream>>>(Bs.key[0].data, Bs.key[0].validity, Bs.sel, n, mm);
+                ok = hipGetLastError() == hipSuccess && ctx->download_plain(res, mm, sizeof res) == PH_OK;
+            }
+            ctx->pool_release(mm);
+            if (!ok) { ph_join_free(j); ph::set_error("ph_join_build: key range pass failed"); return PH_EHIP; }
+            if (res[0] <= res[1]) { have_range = true; key_lo = res[0]; key_hi = res[1]; }
+        }
+    }
     if (have_range && nkeys == 1 && n > 0 && key_hi >= key_lo) {
         // dense keys: a direct table when the range is at most 8 slots per build row (a primary-key
         // column, possibly filtered) and at most 2^30 slots; sparse build sides keep the hash tables,

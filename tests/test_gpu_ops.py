@@ -692,6 +692,43 @@ def test_join_direct_table_dense_keys(ctx):
         c.free()
 
 
+def test_join_unhinted_big_build_reads_its_key_range(ctx):
+    """ph_join_build without a range and a build side of a million keys or more: the library reads min / max off
+    the key column (NULL keys and unselected rows skipped) and builds the direct table when the keys are dense in
+    their range — sorted keys (the verified one-pass fill), shuffled keys with NULLs behind a selection (general
+    passes), duplicates — and keeps the hash tables when they are not (random 62-bit keys) or when
+    PH_JOIN_AUTO_RANGE=0. All against the oracle's pairs."""
+    import os
+    rng = np.random.default_rng(77)
+    nb, np_ = 1_200_000, 1_500_000
+    dense = np.sort(rng.choice(5_000_000, nb, replace=False)).astype(np.int64) + 10**12     # 24 % dense, far from zero
+    p = rng.integers(10**12 - 1000, 10**12 + 5_001_000, np_).astype(np.int64)
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, dense, None)], [(hip.PH_I64, O.OT_INT64, p, None)], kind="direct")
+    shuf = rng.permutation(dense)
+    shuf[::1000] = shuf[1::1000]                                                             # duplicate keys
+    vb, _ = rnd_validity(rng, nb, 0.01)
+    bsel = np.sort(rng.choice(nb, 1_100_000, replace=False))
+    psel = np.sort(rng.choice(np_, 700_000, replace=False))
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, shuf, vb)], [(hip.PH_I64, O.OT_INT64, p, None)], bsel, psel, kind="direct")
+    k32 = rng.permutation(np.arange(-600_000, 600_000, dtype=np.int32))
+    p32 = rng.integers(-700_000, 700_000, np_).astype(np.int32)
+    join_compare(ctx, [(hip.PH_I32, O.OT_INT32, k32, None)], [(hip.PH_I32, O.OT_INT32, p32, None)], kind="direct")
+    sparse = rng.integers(0, 2**62, nb).astype(np.int64)
+    ps = np.concatenate([sparse[:400_000], rng.integers(0, 2**62, 300_000).astype(np.int64)])
+    j = hip.Join(ctx, [hip.DevColumn(ctx, hip.PH_I64, sparse)], None, nb)
+    assert j.kind != "direct"
+    j.free()
+    join_compare(ctx, [(hip.PH_I64, O.OT_INT64, sparse, None)], [(hip.PH_I64, O.OT_INT64, ps, None)])
+    os.environ["PH_JOIN_AUTO_RANGE"] = "0"
+    try:
+        d = hip.DevColumn(ctx, hip.PH_I64, dense)
+        j = hip.Join(ctx, [d], None, nb)
+        assert j.kind != "direct" and j.count() == nb
+        j.free(); d.free()
+    finally:
+        os.environ.pop("PH_JOIN_AUTO_RANGE")
+
+
 def test_join_direct_table_sorted_fill(ctx):
     """Build keys in storage order (sorted) and a range above 8 M slots take the one-pass sorted fill of
     the direct table; the kernel verifies the order, so unsorted keys of the same shape fall back to
