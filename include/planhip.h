@@ -464,8 +464,16 @@ int ph_join_build_where(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph
 int ph_join_build_where_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const ph_col *where_col, int32_t where_op,
                            const ph_const *where_k, const int32_t *sel, int64_t n, int32_t flags, int64_t key_lo,
                            int64_t key_hi, ph_join **out);
-/* the table form a build chose: "direct", "nodes", "chained+bloom" or "chained" */
+/* the table form a build chose: "direct", "radix", "nodes", "chained+bloom" or "chained".
+ * ph_join_build WITHOUT a range, over a million build rows or more, reads the key range off the column and takes the
+ * direct table when the keys are dense in it; build sides above 4 M rows whose keys are not (and at most 29 M rows)
+ * take the "radix" form: both sides partitioned by key hash, open-addressing tables built in LDS and kept as images
+ * that the probes of one partition find on chip (joinExecutor's chained table, join_table.go:85-288, for build sides
+ * that no cache holds). It answers inner probes itself; lookups and marks build the node table on first use. */
 const char *ph_join_kind(const ph_join *j);
+/* 1 when ph_join_probe_inner* emit their pairs in probe-row order (every form except "radix", whose pairs come out
+ * partition by partition — the same SET of pairs; a caller that relies on the order asks here) */
+int ph_join_pairs_ordered(const ph_join *j);
 int64_t ph_join_count(const ph_join *j);
 /* Inner probe: writes (probe row id, build row id) pairs to dev buffers of `cap` entries.
  * *n_out (host) = number of matches (may exceed cap -> PH_ECAPACITY, nothing lost but the tail). */

@@ -2248,6 +2248,373 @@ __global__ __launch_bounds__(256) void direct_mark_where_kernel(const void *__re
     }
 }
 
+// ---------------------------------------------------------------- radix-partitioned hash join
+// Big build sides whose keys are NOT dense in a range (the direct table does not apply). The node table
+// above answers a probe with two dependent random reads in HBM — a 128-byte line each for 4 + 16 bytes,
+// whatever order the probe keys arrive in: 60 M probes of 15 M random 62-bit keys 3.1 ms, 7.7 GB moved. Here both
+// sides are partitioned by key hash first, so that a probe only ever touches a table that is resident on chip:
+//   build  rows -> P x SUB bins (count, scan, LDS-staged scatter of {key, row}); ONE workgroup per bin builds the
+//          bin's open-addressing table (S slots of {key, row}, linear probing, duplicates in slots of their own)
+//          IN LDS and writes its image out whole — no global atomic, no random write;
+//   probe  rows -> P partitions (count, scan, LDS-staged scatter of {key, row}: 12 bytes per row in runs), then
+//          partition p's rows probe the SUB images of partition p (2 MiB: resident in the L2 of the XCD that the
+//          workgroups of p are dealt to — consecutive workgroup ids of one residue mod 8, see rj_map) and emit pairs
+//          through one reserving atomic per wave and probe step.
+// h = big_hash(key): bits [36, 36 + logSUB) pick the table inside a partition, the bits above them the partition,
+// the low bits the slot.
+constexpr int RJ_T = 1024;
+constexpr int RJ_U = 4;                      // rows per thread and chunk
+constexpr int RJ_CH = RJ_T * RJ_U;           // rows staged per chunk
+constexpr int RJ_SLOTS = 8192;               // slots of one table image: 128 KiB of LDS while it is built
+constexpr int RJ_SHIFT = 36;
+
+struct RjSide {
+    const void *k0, *k1;
+    const uint8_t *v0, *v1;
+    const int32_t *sel;
+    int64_t n;
+};
+
+struct RjPart {
+    int bins, shift;                         // bin = (h >> shift) & (bins - 1)
+    int64_t rows_per_wg;
+    int32_t *counts;                         // [bins][nwg] -> offsets after the scan
+    ulonglong2 *rec;                         // records {key, row} in bin order (16 bytes: one store, runs of 256 bytes and more per bin)
+};
+
+template <int KW, int NK, bool SEL>
+__device__ __forceinline__ void rj_keys(const RjSide &S, int64_t base, int64_t i1, unsigned long long (&key)[RJ_U], int32_t (&row)[RJ_U], bool (&ok)[RJ_U]) {
+    int64_t r[RJ_U];
+#pragma unroll
+    for (int u = 0; u < RJ_U; u++) {
+        const int64_t i = base + u * RJ_T + threadIdx.x;
+        ok[u] = i < i1;
+        const int64_t ic = ok[u] ? i : i1 - 1;
+        r[u] = SEL ? (int64_t)S.sel[ic] : ic;
+        row[u] = (int32_t)r[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RJ_U; u++) {
+        const unsigned long long a = load_kw<KW>(S.k0, r[u]);
+        const unsigned long long b = NK == 2 ? load_kw<KW>(S.k1, r[u]) : 0ull;
+        key[u] = big_pack<KW, NK>(a, b);
+        if (S.v0) ok[u] = ok[u] && bit_valid(S.v0, r[u]);          // NULL keys neither enter a table nor match
+        if (NK == 2 && S.v1) ok[u] = ok[u] && bit_valid(S.v1, r[u]);
+    }
+}
+
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(RJ_T) void rj_count_kernel(RjSide S, RjPart Q) {
+    extern __shared__ int rj_hist[];
+    for (int e = threadIdx.x; e < Q.bins; e += RJ_T) rj_hist[e] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * Q.rows_per_wg, i1 = i0 + Q.rows_per_wg < S.n ? i0 + Q.rows_per_wg : S.n;
+    for (int64_t base = i0; base < i1; base += RJ_CH) {
+        unsigned long long key[RJ_U];
+        int32_t row[RJ_U];
+        bool ok[RJ_U];
+        rj_keys<KW, NK, SEL>(S, base, i1, key, row, ok);
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++)
+            if (ok[u]) atomicAdd(&rj_hist[(int)((big_hash(key[u]) >> Q.shift) & (uint64_t)(Q.bins - 1))], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Q.bins; e += RJ_T) Q.counts[(int64_t)e * gridDim.x + blockIdx.x] = rj_hist[e];
+}
+
+// every chunk of RJ_CH rows is ordered by bin in LDS first and leaves as runs of consecutive records per bin.
+// Two words of LDS per bin (8192 bins + the staged chunk = 128 KiB): `hist` holds the chunk's counts, then — scanned in
+// place — the chunk offsets; `cursor` the bin's next position in the output.
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(RJ_T) void rj_scatter_kernel(RjSide S, RjPart Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rj_lds[];
+    const int B = Q.bins;
+    int *hist = reinterpret_cast<int *>(rj_lds);
+    int *cursor = hist + B;
+    ulonglong2 *s_rec = reinterpret_cast<ulonglong2 *>(cursor + B);   // (B is even: 16-byte aligned)
+    int *s_dst = reinterpret_cast<int *>(s_rec + RJ_CH);
+    __shared__ int s_wsum[RJ_T / 64], s_m;
+    for (int e = threadIdx.x; e < B; e += RJ_T) { hist[e] = 0; cursor[e] = Q.counts[(int64_t)e * gridDim.x + blockIdx.x]; }
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * Q.rows_per_wg, i1 = i0 + Q.rows_per_wg < S.n ? i0 + Q.rows_per_wg : S.n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int MAXPER = 8;                // bins per thread of the scan: up to 8192 bins
+    const int per = (B + RJ_T - 1) / RJ_T;
+    for (int64_t base = i0; base < i1; base += RJ_CH) {
+        unsigned long long key[RJ_U];
+        int32_t row[RJ_U];
+        bool ok[RJ_U];
+        int bin[RJ_U], rank[RJ_U];
+        rj_keys<KW, NK, SEL>(S, base, i1, key, row, ok);
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            bin[u] = (int)((big_hash(key[u]) >> Q.shift) & (uint64_t)(B - 1));
+            rank[u] = ok[u] ? atomicAdd(&hist[bin[u]], 1) : 0;
+        }
+        __syncthreads();
+        int cnt[MAXPER];
+        {   // exclusive scan of the chunk's histogram, in place: `per` consecutive bins per thread
+            int sum = 0;
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) { const int e = threadIdx.x * per + q; cnt[q] = (q < per && e < B) ? hist[e] : 0; sum += cnt[q]; }
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wv; w++) run += s_wsum[w];
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) { const int e = threadIdx.x * per + q; if (q < per && e < B) { hist[e] = run; run += cnt[q]; } }
+            if (threadIdx.x == RJ_T - 1) s_m = run;   // rows of the chunk that have a key
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            if (!ok[u]) continue;
+            const int j = hist[bin[u]] + rank[u];
+            s_rec[j] = make_ulonglong2(key[u], (unsigned long long)(unsigned)row[u]);
+            s_dst[j] = cursor[bin[u]] + rank[u];
+        }
+        __syncthreads();
+        const int m = s_m;
+        for (int j = threadIdx.x; j < m; j += RJ_T) {
+            Q.rec[s_dst[j]] = s_rec[j];
+        }
+#pragma unroll
+        for (int q = 0; q < MAXPER; q++) { const int e = threadIdx.x * per + q; if (q < per && e < B) { cursor[e] += cnt[q]; hist[e] = 0; } }
+        __syncthreads();
+    }
+}
+
+// workgroup id -> (partition, slice) such that all slices of a partition have ids of ONE residue mod 8 (workgroups are
+// dealt round-robin over the 8 XCDs: they share an L2) and follow each other in that XCD's stream. Needs parts % 8 == 0.
+__device__ __forceinline__ void rj_map(int b, int slices, int *p, int *s) {
+    const int q = b >> 3, x = b & 7;
+    *p = (q / slices) * 8 + x;
+    *s = q % slices;
+}
+
+// ONE workgroup per bin: its keys into a bucketed open-addressing table in LDS — RJ_BUCKETS buckets of 16 slots {key, row}, a
+// 16-byte tag word per bucket (one byte per slot: 0 = empty, else 0x80 | 7 hash bits) — and the image written out whole.
+// A probe reads its bucket's tag word (ONE 16-byte read), then only the slots whose tag matches (one, rarely two), and moves
+// to the next bucket only when this one is full (16 keys where 9 are expected: ~2 % of the buckets). Tried and measured
+// (15 M keys, 60 M probes, probe kernel alone): linear probing over single slots 4.7 ms — a wave takes as many steps as its
+// unluckiest lane, 24 at 45 % load; eight lanes reading one 8-slot bucket per probe row (one L2 request per row) 2.1 ms —
+// eight times the instructions; this form 1.15 ms, close to what the request path between the CUs and the L2 passes
+// (~140 requests/ns on the whole chip, two requests per probe).
+// flag |= 1 when a bin holds more keys than 7/8 of the slots (the host keeps the hash tables then)
+constexpr int RJ_BUCKETS = RJ_SLOTS / 16;
+__device__ __forceinline__ unsigned rj_tag(uint64_t h) { return 0x80u | (unsigned)((h >> 24) & 0x7f); }
+__device__ __forceinline__ int rj_bucket(uint64_t h) { return (int)(h & (uint64_t)(RJ_BUCKETS - 1)); }
+
+__global__ __launch_bounds__(RJ_T) void rj_tables_kernel(RjPart Q, int nwg, const int64_t *__restrict__ total, ulonglong2 *__restrict__ slots,
+                                                         uint4 *__restrict__ tags, int *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rj_lds[];
+    ulonglong2 *l_slot = reinterpret_cast<ulonglong2 *>(rj_lds);
+    unsigned char *l_tag = reinterpret_cast<unsigned char *>(l_slot + RJ_SLOTS);
+    int *l_cnt = reinterpret_cast<int *>(l_tag + RJ_SLOTS);
+    const int bin = blockIdx.x;
+    for (int e = threadIdx.x; e < RJ_SLOTS; e += RJ_T) l_slot[e] = make_ulonglong2(0ull, 0ull);
+    for (int e = threadIdx.x; e < RJ_SLOTS / 4; e += RJ_T) reinterpret_cast<unsigned *>(l_tag)[e] = 0u;
+    for (int e = threadIdx.x; e < RJ_BUCKETS; e += RJ_T) l_cnt[e] = 0;
+    __syncthreads();
+    const int64_t start = Q.counts[(int64_t)bin * nwg];
+    const int64_t end = bin + 1 < Q.bins ? (int64_t)Q.counts[(int64_t)(bin + 1) * nwg] : *total;
+    if (end - start > RJ_SLOTS - RJ_SLOTS / 8) {   // uniform: the table would have no room to spare
+        if (threadIdx.x == 0) atomicOr(flag, 1);
+        return;
+    }
+    for (int64_t t = start + threadIdx.x; t < end; t += RJ_T) {
+        const ulonglong2 r = Q.rec[t];
+        const uint64_t h = big_hash(r.x);
+        int b = rj_bucket(h);
+        for (int tries = 0; tries < RJ_BUCKETS; tries++) {
+            const int pos = atomicAdd(&l_cnt[b], 1);
+            if (pos < 16) {
+                l_slot[b * 16 + pos] = r;
+                l_tag[b * 16 + pos] = (unsigned char)rj_tag(h);
+                break;
+            }
+            b = (b + 1) & (RJ_BUCKETS - 1);
+        }
+    }
+    __syncthreads();
+    ulonglong2 *out = slots + (int64_t)bin * RJ_SLOTS;
+    for (int e = threadIdx.x; e < RJ_SLOTS; e += RJ_T) out[e] = l_slot[e];
+    uint4 *tout = tags + (int64_t)bin * RJ_BUCKETS;
+    for (int e = threadIdx.x; e < RJ_BUCKETS; e += RJ_T) tout[e] = reinterpret_cast<const uint4 *>(l_tag)[e];
+}
+
+struct RjProbe {
+    int parts, log_sub, slices;
+    const int32_t *counts;                   // probe-side offsets [parts][nwg]
+    int nwg;
+    const int64_t *total;                    // probe rows that have a key
+    const ulonglong2 *rec;                   // probe records {key, row} in partition order
+    const ulonglong2 *tables;                // slot images [bins][RJ_SLOTS]
+    const uint4 *tags;                       // tag words [bins][RJ_BUCKETS]
+    int32_t *out_probe, *out_build;
+    int64_t cap;
+    unsigned long long *n_out;               // pairs (also beyond cap: the caller learns how many there are)
+};
+
+// Pairs of one chunk are staged in LDS (one LDS add per wave and probe step reserves their places) and leave with ONE
+// reserving add on the global pair counter per workgroup and chunk: adds on one address execute one after the other at
+// the memory side (~12 ns each) — a reserving add per wave and step made 60 M probes take 35 ms.
+constexpr int RJ_STAGE = 8192;               // pairs staged per chunk (RJ_CH probe rows); beyond it a pair reserves its place by itself
+
+struct RjStage {
+    int32_t *p, *b;                          // [RJ_STAGE] each, LDS
+    int *cnt;                                // LDS word: pairs staged so far
+};
+
+__device__ __forceinline__ void rj_emit(bool match, int prow, int brow, const RjProbe &R, const RjStage &G) {
+    const unsigned long long m = __ballot(match);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(G.cnt, __popcll(m));
+    base = __shfl(base, leader);
+    if (match) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < RJ_STAGE) { G.p[pos] = prow; G.b[pos] = brow; }
+        else {   // (a chunk with more than two matches per probe row on average)
+            const int64_t g = (int64_t)atomicAdd(R.n_out, 1ull);
+            if (g < R.cap) { R.out_probe[g] = prow; R.out_build[g] = brow; }
+        }
+    }
+}
+
+// all rows of the chunk probed: the staged pairs to the output
+__device__ __forceinline__ void rj_flush(const RjProbe &R, const RjStage &G) {
+    __syncthreads();
+    const int cnt = *G.cnt < RJ_STAGE ? *G.cnt : RJ_STAGE;
+    __shared__ unsigned long long s_gbase;
+    if (threadIdx.x == 0) s_gbase = cnt ? atomicAdd(R.n_out, (unsigned long long)cnt) : 0ull;
+    __syncthreads();
+    const int64_t gb = (int64_t)s_gbase;
+    for (int i = threadIdx.x; i < cnt; i += RJ_T) {
+        const int64_t pos = gb + i;
+        if (pos < R.cap) { R.out_probe[pos] = G.p[i]; R.out_build[pos] = G.b[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *G.cnt = 0;
+    __syncthreads();
+}
+
+// RJ_U rows per lane against the table images of their bins. Wave-uniform rounds: every seeking row reads its bucket's tag
+// word; rows with candidate slots read them one at a time (reads of a lane's RJ_U rows are issued together); a row whose
+// bucket is full goes on to the next bucket.
+__device__ __forceinline__ void rj_probe_rows(const unsigned long long (&key)[RJ_U], const int (&prow)[RJ_U], bool (&seek)[RJ_U],
+                                              const int (&bin)[RJ_U], const uint64_t (&hh)[RJ_U], const RjProbe &R, const RjStage &G) {
+    int b[RJ_U];
+    unsigned long long T[RJ_U];
+#pragma unroll
+    for (int u = 0; u < RJ_U; u++) { b[u] = rj_bucket(hh[u]); T[u] = (unsigned long long)rj_tag(hh[u]) * 0x0101010101010101ull; }
+    for (int round = 0; round < RJ_BUCKETS; round++) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) any = any || seek[u];
+        if (__ballot(any) == 0ull) break;
+        uint4 tg[RJ_U];
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) tg[u] = seek[u] ? R.tags[(int64_t)bin[u] * RJ_BUCKETS + b[u]] : make_uint4(0, 0, 0, 0);
+        unsigned long long zlo[RJ_U], zhi[RJ_U];   // 0x80 in every byte whose tag equals the row's
+        bool full[RJ_U];
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            const unsigned long long lo = (unsigned long long)tg[u].x | ((unsigned long long)tg[u].y << 32);
+            const unsigned long long hi = (unsigned long long)tg[u].z | ((unsigned long long)tg[u].w << 32);
+            const unsigned long long xl = lo ^ T[u], xh = hi ^ T[u];
+            const unsigned long long k7 = 0x7f7f7f7f7f7f7f7full;
+            zlo[u] = seek[u] ? ~(((xl & k7) + k7) | xl | k7) : 0ull;
+            zhi[u] = seek[u] ? ~(((xh & k7) + k7) | xh | k7) : 0ull;
+            full[u] = (lo & hi & 0x8080808080808080ull) == 0x8080808080808080ull;
+        }
+        for (int cand = 0; cand < 16; cand++) {
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < RJ_U; u++) more = more || (zlo[u] | zhi[u]) != 0ull;
+            if (__ballot(more) == 0ull) break;
+            ulonglong2 e[RJ_U];
+            bool have[RJ_U];
+#pragma unroll
+            for (int u = 0; u < RJ_U; u++) {
+                have[u] = (zlo[u] | zhi[u]) != 0ull;
+                int pos = 0;
+                if (zlo[u]) { pos = __ffsll((long long)zlo[u]) - 1; zlo[u] &= zlo[u] - 1; pos >>= 3; }
+                else if (zhi[u]) { pos = __ffsll((long long)zhi[u]) - 1; zhi[u] &= zhi[u] - 1; pos = 8 + (pos >> 3); }
+                e[u] = have[u] ? R.tables[(int64_t)bin[u] * RJ_SLOTS + b[u] * 16 + pos] : make_ulonglong2(0ull, 0ull);
+            }
+#pragma unroll
+            for (int u = 0; u < RJ_U; u++) rj_emit(have[u] && e[u].x == key[u], prow[u], (int)(unsigned)e[u].y, R, G);
+        }
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) { seek[u] = seek[u] && full[u]; b[u] = (b[u] + 1) & (RJ_BUCKETS - 1); }
+    }
+}
+
+#define RJ_STAGE_DECL                                                                     \
+    __shared__ int32_t rj_sp[RJ_STAGE], rj_sb[RJ_STAGE];                                  \
+    __shared__ int rj_scnt;                                                               \
+    const RjStage G{rj_sp, rj_sb, &rj_scnt};                                              \
+    if (threadIdx.x == 0) rj_scnt = 0;                                                    \
+    __syncthreads()
+
+__global__ __launch_bounds__(RJ_T) void rj_probe_kernel(RjProbe R) {
+    RJ_STAGE_DECL;
+    int p, sl;
+    rj_map((int)blockIdx.x, R.slices, &p, &sl);
+    const int64_t start = R.counts[(int64_t)p * R.nwg];
+    const int64_t end = p + 1 < R.parts ? (int64_t)R.counts[(int64_t)(p + 1) * R.nwg] : *R.total;
+    const int64_t len = end - start, t0 = start + len * sl / R.slices, t1 = start + len * (sl + 1) / R.slices;
+    const int subs_mask = (1 << R.log_sub) - 1;
+    for (int64_t tb = t0; tb < t1; tb += RJ_CH) {
+        unsigned long long key[RJ_U];
+        int prow[RJ_U], bin[RJ_U];
+        uint64_t hh[RJ_U];
+        bool seek[RJ_U];
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            const int64_t t = tb + u * RJ_T + threadIdx.x;
+            seek[u] = t < t1;
+            const ulonglong2 r = R.rec[seek[u] ? t : t1 - 1];
+            key[u] = r.x;
+            prow[u] = (int)(unsigned)r.y;
+        }
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            hh[u] = big_hash(key[u]);
+            bin[u] = (p << R.log_sub) | (int)((hh[u] >> RJ_SHIFT) & (uint64_t)subs_mask);
+        }
+        rj_probe_rows(key, prow, seek, bin, hh, R, G);
+        rj_flush(R, G);
+    }
+}
+
+// small probe sides: straight from the probe columns, no partitioning (the images are the same tables)
+template <int KW, int NK, bool SEL>
+__global__ __launch_bounds__(RJ_T) void rj_probe_direct_kernel(RjSide S, RjProbe R, int log_parts) {
+    RJ_STAGE_DECL;
+    for (int64_t base = (int64_t)blockIdx.x * RJ_CH; base < S.n; base += (int64_t)gridDim.x * RJ_CH) {
+        unsigned long long key[RJ_U];
+        int32_t prow[RJ_U];
+        bool seek[RJ_U];
+        int bin[RJ_U];
+        uint64_t hh[RJ_U];
+        rj_keys<KW, NK, SEL>(S, base, S.n, key, prow, seek);
+#pragma unroll
+        for (int u = 0; u < RJ_U; u++) {
+            hh[u] = big_hash(key[u]);
+            bin[u] = (int)((hh[u] >> RJ_SHIFT) & (uint64_t)((1 << (log_parts + R.log_sub)) - 1));
+        }
+        rj_probe_rows(key, prow, seek, bin, hh, R, G);
+        rj_flush(R, G);
+    }
+}
+#undef RJ_STAGE_DECL
+
 }  // namespace ph
 
 struct ph_join {
@@ -2269,6 +2636,9 @@ struct ph_join {
     int64_t count_from_bits = 0;    // gated sorted fill: words of dbits whose set bits are the rows stored
     bool bits_authoritative = false;   // ... and only the occupied slots of `direct` were ever written: every probe tests dbits first
     unsigned *dbits = nullptr;      // direct tables of <= 8 M slots: one occupancy bit per slot
+    ulonglong2 *rj_tables = nullptr;   // radix-partitioned form: 2^(rj_log_parts + rj_log_sub) table images of RJ_SLOTS {key, row} slots
+    uint4 *rj_tags = nullptr;          // ... and their tag words (one per bucket of 16 slots)
+    int rj_log_parts = 0, rj_log_sub = 0;
 };
 
 extern "C" void ph_join_free(ph_join *j) {
@@ -2282,6 +2652,8 @@ extern "C" void ph_join_free(ph_join *j) {
     if (j->nodes) j->ctx->pool_release(j->nodes);
     if (j->direct) j->ctx->pool_release(j->direct);
     if (j->dbits) j->ctx->pool_release(j->dbits);
+    if (j->rj_tables) j->ctx->pool_release(j->rj_tables);
+    if (j->rj_tags) j->ctx->pool_release(j->rj_tags);
     delete j;
 }
 
@@ -2353,6 +2725,149 @@ static int build_big(ph_join *j, int kw, int nparts) {
     return rc;
 }
 
+
+// ---- radix-partitioned join: host side
+static void radix_free(ph_join *j) {
+    if (j->rj_tables) j->ctx->pool_release(j->rj_tables);
+    if (j->rj_tags) j->ctx->pool_release(j->rj_tags);
+    j->rj_tables = nullptr;
+    j->rj_tags = nullptr;
+}
+
+static int rj_raise_lds(const void *f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? PH_OK : PH_EHIP; }
+
+// count -> scan -> staged scatter of one side into `bins` bins; records in Q->pkey / Q->prow (allocated here, n entries),
+// offsets in Q->counts ([bins][nwg]), rows with a key in *total_dev
+static int rj_partition(ph_ctx *ctx, const ph::JoinSide &B, int kw, int bins, int shift, ph::RjPart *Q, int *nwg_out, int64_t *total_dev) {
+    const int64_t n = B.n;
+    ph::RjSide S{B.key[0].data, B.key[1].data, B.key[0].validity, B.key[1].validity, B.sel, n};
+    const int64_t target = std::max<int64_t>(1, std::min<int64_t>(bins > 1024 ? ctx->cu_count : (int64_t)ctx->cu_count * 2, n / ph::RJ_CH));
+    Q->bins = bins;
+    Q->shift = shift;
+    Q->rows_per_wg = ph::round_up((n + target - 1) / target, ph::RJ_CH);
+    const int nwg = (int)((n + Q->rows_per_wg - 1) / Q->rows_per_wg);
+    *nwg_out = nwg;
+    const int64_t nc = (int64_t)bins * nwg;
+    PH_CHECK(ctx->pool_alloc(nc * 4, (void **)&Q->counts));
+    PH_CHECK(ctx->pool_alloc(n * 16, (void **)&Q->rec));
+    const size_t hl = (size_t)bins * 4;
+    const size_t sl = (size_t)bins * 8 + (size_t)ph::RJ_CH * 20;
+    if (bins > 8192) { ph::set_error("radix join: more than 8192 bins"); return PH_EUNSUPPORTED; }
+    int rc = PH_OK;
+#define PH_RJ_PART(KWV, NKV, SELV)                                                                                              \
+    do {                                                                                                                        \
+        rc = rj_raise_lds((const void *)ph::rj_scatter_kernel<KWV, NKV, SELV>, 144 * 1024);                                     \
+        if (rc != PH_OK) break;                                                                                                 \
+        ph::rj_count_kernel<KWV, NKV, SELV><<<nwg, ph::RJ_T, hl, ctx->stream>>>(S, *Q);                                         \
+        rc = ph::exclusive_scan_i32(ctx, Q->counts, nc, total_dev);                                                             \
+        if (rc != PH_OK) break;                                                                                                 \
+        ph::rj_scatter_kernel<KWV, NKV, SELV><<<nwg, ph::RJ_T, sl, ctx->stream>>>(S, *Q);                                       \
+    } while (0)
+    if (B.nkeys == 2) { if (B.sel) PH_RJ_PART(4, 2, true); else PH_RJ_PART(4, 2, false); }
+    else if (kw == 4) { if (B.sel) PH_RJ_PART(4, 1, true); else PH_RJ_PART(4, 1, false); }
+    else { if (B.sel) PH_RJ_PART(8, 1, true); else PH_RJ_PART(8, 1, false); }
+#undef PH_RJ_PART
+    if (rc == PH_OK && hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    return rc;
+}
+
+static void rj_part_free(ph_ctx *ctx, ph::RjPart *Q) {
+    if (Q->counts) ctx->pool_release(Q->counts);
+    if (Q->rec) ctx->pool_release(Q->rec);
+    Q->counts = nullptr; Q->rec = nullptr;
+}
+
+// PH_OK with j->rj_tables set, or PH_EUNSUPPORTED (a bin overflows its table: heavy duplicates / skew — the caller builds the node table)
+static int build_radix(ph_join *j, int kw) {
+    ph_ctx *ctx = j->ctx;
+    const ph::JoinSide &B = j->build;
+    const int64_t n = B.n;
+    // bins of at most ~4.6 k keys (56 % of a table image) on average; a partition = the SUB images one XCD's L2 keeps while its rows probe (2 MiB)
+    int log_bins = 6;
+    while (((int64_t)1 << log_bins) * (ph::RJ_SLOTS * 9 / 16) < n && log_bins < 13) log_bins++;
+    if (((int64_t)1 << log_bins) * (ph::RJ_SLOTS * 9 / 16) < n) return PH_EUNSUPPORTED;   // beyond 37 M build rows: the node table
+    const int log_sub = std::min(4, log_bins - 3);
+    j->rj_log_sub = log_sub;
+    j->rj_log_parts = log_bins - log_sub;
+    j->big_kw = kw;
+    j->big_nk = B.nkeys;
+    ph::RjPart Q{};
+    int nwg = 0;
+    int64_t *total_dev = nullptr;
+    int *flag = nullptr;
+    PH_CHECK(ctx->pool_alloc(16, (void **)&j->count_dev));
+    PH_CHECK(ctx->pool_alloc(16, (void **)&flag));
+    total_dev = (int64_t *)j->count_dev;   // (the low word is the row count ph_join_count reads)
+    int rc = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess ? PH_OK : PH_EHIP;
+    if (rc == PH_OK) rc = rj_partition(ctx, B, kw, 1 << log_bins, ph::RJ_SHIFT, &Q, &nwg, total_dev);
+    const int64_t tbytes = ((int64_t)ph::RJ_SLOTS << log_bins) * 16;
+    if (rc == PH_OK) rc = ctx->pool_alloc(tbytes, (void **)&j->rj_tables);
+    if (rc == PH_OK) rc = ctx->pool_alloc(tbytes / 16, (void **)&j->rj_tags);
+    if (rc == PH_OK) rc = rj_raise_lds((const void *)ph::rj_tables_kernel, 144 * 1024);
+    int f = 0;
+    if (rc == PH_OK) {
+        ph::rj_tables_kernel<<<1 << log_bins, ph::RJ_T, (size_t)ph::RJ_SLOTS * 17 + (size_t)ph::RJ_BUCKETS * 4, ctx->stream>>>(Q, nwg, total_dev, j->rj_tables, j->rj_tags, flag);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    if (rc == PH_OK) rc = ctx->download_plain(&f, flag, 4);
+    rj_part_free(ctx, &Q);
+    ctx->pool_release(flag);
+    if (rc == PH_OK && f) {
+        radix_free(j);
+        ctx->pool_release(j->count_dev);
+        j->count_dev = nullptr;
+        return PH_EUNSUPPORTED;
+    }
+    if (rc != PH_OK) ph::set_error("ph_join_build: radix build failed");
+    return rc;
+}
+
+static int radix_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out) {
+    ph_ctx *ctx = j->ctx;
+    unsigned long long *cnt = nullptr;
+    PH_CHECK(ctx->pool_alloc(16, (void **)&cnt));
+    PH_HIP(hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    ph::RjProbe R{};
+    R.parts = 1 << j->rj_log_parts;
+    R.log_sub = j->rj_log_sub;
+    R.tables = j->rj_tables;
+    R.tags = j->rj_tags;
+    R.out_probe = out_probe_dev; R.out_build = out_build_dev; R.cap = cap; R.n_out = cnt;
+    int rc = PH_OK;
+    const char *pm = getenv("PH_JOIN_RADIX_PART_MIN");   // read per call: the tests probe both ways
+    const int64_t part_min = pm ? atoll(pm) : (1ll << 20);
+    if (n < part_min) {
+        // small probe sides: straight from the probe columns
+        ph::RjSide S{P.key[0].data, P.key[1].data, P.key[0].validity, P.key[1].validity, P.sel, n};
+        const int grid = (int)std::min<int64_t>((n + ph::RJ_CH - 1) / ph::RJ_CH, (int64_t)ctx->cu_count * 2);
+#define PH_RJ_PD(KWV, NKV, SELV) ph::rj_probe_direct_kernel<KWV, NKV, SELV><<<grid, ph::RJ_T, 0, ctx->stream>>>(S, R, j->rj_log_parts)
+        if (j->big_nk == 2) { if (P.sel) PH_RJ_PD(4, 2, true); else PH_RJ_PD(4, 2, false); }
+        else if (j->big_kw == 4) { if (P.sel) PH_RJ_PD(4, 1, true); else PH_RJ_PD(4, 1, false); }
+        else { if (P.sel) PH_RJ_PD(8, 1, true); else PH_RJ_PD(8, 1, false); }
+#undef PH_RJ_PD
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    } else {
+        ph::RjPart Q{};
+        int nwg = 0;
+        int64_t *total_dev = nullptr;
+        rc = ctx->pool_alloc(16, (void **)&total_dev);
+        if (rc == PH_OK) rc = rj_partition(ctx, P, j->big_kw, R.parts, ph::RJ_SHIFT + j->rj_log_sub, &Q, &nwg, total_dev);
+        if (rc == PH_OK) {
+            R.counts = Q.counts; R.nwg = nwg; R.total = total_dev; R.rec = Q.rec;
+            // as many slices as keep ONE partition's workgroups on an XCD at a time (two 1024-thread workgroups per CU x 32 CUs)
+            int slices = 64;
+            while (slices > 1 && n / ((int64_t)R.parts * slices) < 1024) slices /= 2;
+            R.slices = slices;
+            ph::rj_probe_kernel<<<R.parts * slices, ph::RJ_T, 0, ctx->stream>>>(R);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+        }
+        rj_part_free(ctx, &Q);
+        if (total_dev) ctx->pool_release(total_dev);
+    }
+    if (rc == PH_OK) rc = ctx->download_count(n_out, cnt, cap, "ph_join_probe_inner");
+    ctx->pool_release(cnt);
+    return rc;
+}
 
 // ---- direct table (dense integer keys): host side
 #define PH_DIRECT_KS(KERNEL, GRID, THREADS, ...)                                                            \
@@ -2770,6 +3285,17 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
     return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
 }
 
+// the radix form answers inner probes; marks and lookups go through the node table, built here on first use
+static int ensure_nodes(ph_join *j) {
+    if (j->nodes || !j->rj_tables) return PH_OK;
+    ph_ctx *ctx = j->ctx;
+    const int bparts = (int)(j->cap >> ph::BG_SLICE_LOG);
+    if (bparts < 2 || bparts > ph::BG_MAX_PARTS) { ph::set_error("ph_join: this probe kind needs the node table, which does not take %lld build rows", (long long)j->build.n); return PH_EUNSUPPORTED; }
+    PH_CHECK(ctx->pool_alloc(j->cap * 4, (void **)&j->head));
+    if (j->count_dev) { ctx->pool_release(j->count_dev); j->count_dev = nullptr; }   // (build_big allocates its own; the count is the same)
+    return build_big(j, j->big_kw, bparts);
+}
+
 static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, bool have_range,
                            int64_t key_lo, int64_t key_hi, bool fk_probes, ph_join **out,
                            const ph::RangePred &where = ph::RangePred{0, nullptr, nullptr, 0, 0}, bool sorted_unique = false) {
@@ -2836,6 +3362,24 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
     while (cap < 2 * n) cap <<= 1;
     j->cap = cap;
     auto fail = [&](const char *what) { ph::set_error("ph_join_build: %s failed", what); ph_join_free(j); return PH_EHIP; };
+    {   // large build sides whose keys are not dense in a range: both sides partitioned by key hash, tables built in LDS (see rj_*)
+        const char *re = getenv("PH_JOIN_RADIX"), *rm = getenv("PH_JOIN_RADIX_MIN");   // read per call: the tests build every form over the same keys
+        const int64_t radix_min = rm ? atoll(rm) : (4ll << 20) + 1;
+        auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : t == PH_CODE8 ? 1 : 8; };
+        const ph::JoinSide &Bs = j->build;
+        const int kw = width(Bs.key[0].type);
+        const bool packable = (Bs.nkeys == 1 && kw != 1) || (Bs.nkeys == 2 && kw == 4 && width(Bs.key[1].type) == 4);
+        if (!(re && atoi(re) == 0) && !fk_probes && packable && n >= radix_min) {
+            if (sel) {   // own copy: a probe kind the radix form does not answer builds the node table later, from the same rows
+                if (ctx->pool_alloc(n * 4, (void **)&j->sel_copy) != PH_OK) return fail("alloc(sel)");
+                if (hipMemcpyAsync(j->sel_copy, sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy sel");
+                j->build.sel = j->sel_copy;
+            }
+            const int rcr = build_radix(j, kw);
+            if (rcr == PH_OK) { j->count = -1; *out = j; return PH_OK; }
+            if (rcr != PH_EUNSUPPORTED) { ph_join_free(j); return rcr; }
+        }
+    }
     if (ctx->pool_alloc(cap * 4, (void **)&j->head) != PH_OK) return fail("alloc(head)");
     {   // large build sides with a packable key: the node table (see BigNode)
         const char *bm = getenv("PH_JOIN_BIG_MIN");   // read per call: the tests lower it to cover this path at small sizes
@@ -2857,7 +3401,7 @@ static int join_build_impl(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const
         }
     }
     if (ctx->pool_alloc(std::max<int64_t>(n, 1) * 4, (void **)&j->next) != PH_OK) return fail("alloc(next)");
-    if (sel && n > 0) {  // keep our own copy: the table outlives the caller's selection buffer
+    if (sel && n > 0 && !j->sel_copy) {  // keep our own copy: the table outlives the caller's selection buffer
         if (ctx->pool_alloc(n * 4, (void **)&j->sel_copy) != PH_OK) return fail("alloc(sel)");
         if (hipMemcpyAsync(j->sel_copy, sel, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return fail("copy sel");
         j->build.sel = j->sel_copy;
@@ -3003,8 +3547,10 @@ extern "C" int ph_join_build_where_ex(ph_ctx *ctx, const ph_col *keys, int32_t n
 }
 
 extern "C" const char *ph_join_kind(const ph_join *j) {
-    return !j ? "" : j->direct ? "direct" : j->nodes ? "nodes" : j->bloom.bits ? "chained+bloom" : "chained";
+    return !j ? "" : j->direct ? "direct" : j->rj_tables ? "radix" : j->nodes ? "nodes" : j->bloom.bits ? "chained+bloom" : "chained";
 }
+
+extern "C" int ph_join_pairs_ordered(const ph_join *j) { return j && !j->rj_tables ? 1 : 0; }
 
 extern "C" int64_t ph_join_count(const ph_join *cj) {
     ph_join *j = const_cast<ph_join *>(cj);
@@ -3105,6 +3651,10 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
         if (!direct_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the direct table's"); return PH_EUNSUPPORTED; }
         return direct_probe_inner(j, P, n, where, bflags, out_probe_dev, out_build_dev, cap, n_out);
     }
+    if (j->rj_tables) {
+        if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the table's"); return PH_EUNSUPPORTED; }
+        return radix_probe_inner(j, P, n, out_probe_dev, out_build_dev, cap, n_out);
+    }
     if (j->nodes) {
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_inner: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
         return big_probe_inner(j, P, n, out_probe_dev, out_build_dev, cap, n_out);
@@ -3195,6 +3745,7 @@ extern "C" int ph_join_probe_mark(ph_join *j, const ph_col *keys, const int32_t 
         PH_HIP(hipGetLastError());
         return PH_OK;
     }
+    if (j->rj_tables && !j->nodes) PH_CHECK(ensure_nodes(j));
     if (j->nodes) {
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_probe_mark: probe key shape differs from the node table's"); return PH_EUNSUPPORTED; }
         launch_big_probe<2>(j, P, n, (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16), nullptr, nullptr, nullptr, found_dev, nullptr);
@@ -3282,6 +3833,7 @@ extern "C" int ph_join_lookup(ph_join *j, const ph_col *keys, const int32_t *sel
         if (scratch) ctx->pool_release(scratch);
         return rcb;
     }
+    if (j->rj_tables && !j->nodes) PH_CHECK(ensure_nodes(j));
     if (j->nodes) {
         int rcb = PH_OK;
         if (!big_probe_ok(j, P)) { ph::set_error("ph_join_lookup: probe key shape differs from the node table's"); rcb = PH_EUNSUPPORTED; }

@@ -1075,7 +1075,12 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
             for (auto &ln : out->lanes) ln.dup_free = ln.dup_free && unique;
         }
         std::vector<PCol> all = out->cols;
-        if (!unique) for (auto &c : all) c.ordered = c.ordered;   // duplicates of a probe row stay adjacent: the order survives
+        // duplicates of a probe row stay adjacent, so a column's order survives the pair list — unless the table form emits
+        // its pairs partition by partition (the radix form of big build sides without a dense key range)
+        if (!ph_join_pairs_ordered(j)) {
+            for (auto &c : all) c.ordered = false;
+            for (auto &ln : out->lanes) ln.asc = false;
+        }
         tag_domain(all);
         out->cols = all;
         if (nd.join_type == PH_JT_INNER) {

@@ -591,6 +591,10 @@ class Join:
     def kind(self):
         return lib().ph_join_kind(self.h).decode()
 
+    def pairs_ordered(self):
+        """ph_join_pairs_ordered: inner probes emit their pairs in probe-row order (every form except 'radix')"""
+        return bool(lib().ph_join_pairs_ordered(self.h))
+
     def count(self):
         return int(lib().ph_join_count(self.h))
 

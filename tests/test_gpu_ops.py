@@ -549,6 +549,7 @@ def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None, key_range=None, kind=N
     j = hip.Join(ctx, db, bs, mb, key_range=key_range)
     if kind is not None:
         assert j.kind == kind
+    assert j.pairs_ordered() == (j.kind != "radix")
     oj = O.Join(ob, None if bsel is None else bsel.astype(np.int64), mb)
     assert j.count() == oj.count()
     cap = 1 << 22
@@ -559,7 +560,7 @@ def join_compare(ctx, bkeys, pkeys, bsel=None, psel=None, key_range=None, kind=N
     want = np.stack([wp, wb], 1)
     # bit-exact row SET: same pairs; order differs (the reference emits per chain round)
     assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))])
-    assert np.all(np.diff(got[:, 0]) >= 0) if psel is None else True   # device order: by probe row
+    assert np.all(np.diff(got[:, 0]) >= 0) if psel is None and j.pairs_ordered() else True   # device order: by probe row
     f = j.probe_mark(dp, ps, mp)
     gf = dl(ctx, f, np.uint8, mp)
     wf = oj.probe_mark(op, None if psel is None else psel.astype(np.int64), mp)
@@ -727,6 +728,63 @@ def test_join_unhinted_big_build_reads_its_key_range(ctx):
         j.free(); d.free()
     finally:
         os.environ.pop("PH_JOIN_AUTO_RANGE")
+
+
+def test_join_radix_partitioned_form(ctx, monkeypatch):
+    """Big build sides whose keys are not dense in a range: both sides partitioned by key hash, the tables built in
+    LDS and written out as images, probes against the images of their partition (kind "radix"; PH_JOIN_RADIX_MIN
+    lowers the 4 M-row threshold here). Random 62-bit keys with duplicates on both sides, NULL keys and
+    selections on both sides, one INTEGER key, two INTEGER keys (packed), the unpartitioned probe of small probe
+    sides, a bin that overflows its table (one key repeated 9000 times: the hash tables instead), and the probe
+    kinds the radix form hands to the node table (lookup, mark) — all against the oracle / the node table."""
+    monkeypatch.setenv("PH_JOIN_RADIX_MIN", "100000")
+    monkeypatch.setenv("PH_JOIN_AUTO_RANGE", "0")
+    rng = np.random.default_rng(91)
+    nb, np_ = 600_000, 1_400_000
+    b = rng.integers(0, 2**62, nb).astype(np.int64)
+    b[::50] = b[1::50]                                           # duplicate build keys
+    p = np.concatenate([b[rng.integers(0, nb, 900_000)], rng.integers(0, 2**62, np_ - 900_000).astype(np.int64)])
+    rng.shuffle(p)
+    for part_min in ("1", str(1 << 40)):                         # partitioned probe / straight from the probe column
+        monkeypatch.setenv("PH_JOIN_RADIX_PART_MIN", part_min)
+        join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, None)], [(hip.PH_I64, O.OT_INT64, p, None)], kind="radix")
+        vb, _ = rnd_validity(rng, nb, 0.02)
+        vp, _ = rnd_validity(rng, np_, 0.02)
+        bsel = np.sort(rng.choice(nb, 500_000, replace=False))
+        psel = np.sort(rng.choice(np_, 1_200_000, replace=False))
+        join_compare(ctx, [(hip.PH_I64, O.OT_INT64, b, vb)], [(hip.PH_I64, O.OT_INT64, p, vp)], bsel, psel, kind="radix")
+        k32 = rng.integers(-2**31, 2**31 - 1, nb).astype(np.int32)
+        p32 = np.concatenate([k32[rng.integers(0, nb, 700_000)], rng.integers(-2**31, 2**31 - 1, 700_000).astype(np.int32)])
+        join_compare(ctx, [(hip.PH_I32, O.OT_INT32, k32, None)], [(hip.PH_I32, O.OT_INT32, p32, None)], kind="radix")
+        ka, kb = rng.integers(0, 200_000, nb).astype(np.int32), rng.integers(0, 4, nb).astype(np.int32)
+        pa, pb = rng.integers(0, 220_000, np_).astype(np.int32), rng.integers(0, 4, np_).astype(np.int32)
+        join_compare(ctx, [(hip.PH_I32, O.OT_INT32, ka, None), (hip.PH_I32, O.OT_INT32, kb, None)],
+                     [(hip.PH_I32, O.OT_INT32, pa, None), (hip.PH_I32, O.OT_INT32, pb, None)], kind="radix")
+    monkeypatch.delenv("PH_JOIN_RADIX_PART_MIN")
+    # a bin that cannot hold its keys: the node table takes the build
+    hot = b.copy()
+    hot[:9000] = 12345
+    d = hip.DevColumn(ctx, hip.PH_I64, hot)
+    j = hip.Join(ctx, [d], None, nb)
+    assert j.kind != "radix" and j.count() == nb
+    j.free(); d.free()
+    # lookups and marks of a radix join go through the node table, built on first use
+    ub = rng.permutation(np.unique(b))
+    db, dp = hip.DevColumn(ctx, hip.PH_I64, ub), hip.DevColumn(ctx, hip.PH_I64, p)
+    jr = hip.Join(ctx, [db], None, len(ub))
+    monkeypatch.setenv("PH_JOIN_RADIX", "0")
+    jn = hip.Join(ctx, [db], None, len(ub))
+    monkeypatch.delenv("PH_JOIN_RADIX")
+    assert jr.kind == "radix" and jn.kind != "radix" and jr.count() == jn.count() == len(ub)
+    got = ctx.download(jr.lookup([dp], None, np_), np.int32, np_)
+    want = ctx.download(jn.lookup([dp], None, np_), np.int32, np_)
+    assert np.array_equal(got, want) and (want >= 0).sum() > 800_000
+    mr, ar, br = jr.probe_inner([dp], None, np_, np_)
+    pairs = np.stack([ctx.download(ar, np.int32, mr), ctx.download(br, np.int32, mr)], 1)
+    pairs = pairs[np.argsort(pairs[:, 0], kind="stable")]
+    hit = np.nonzero(want >= 0)[0]
+    assert mr == len(hit) and np.array_equal(pairs[:, 0], hit) and np.array_equal(pairs[:, 1], want[hit])
+    jr.free(); jn.free(); db.free(); dp.free()
 
 
 def test_join_direct_table_sorted_fill(ctx):
