@@ -451,8 +451,115 @@ func (b *planBuilder) lower(op *PhysicalOperator) (int, bool) {
 		n.child[0], n.child[1] = C.int32_t(c), -1
 		n.nexprs, n.exprs = C.int32_t(len(op.Projects)), ex
 		return b.add(n, m), true
+
+	case POT_Agg:
+		// an aggregate BELOW other operators (Q18's IN-subquery: GROUP BY l_orderkey HAVING sum(l_quantity) > k). Its output
+		// columns are [group columns | aggregate results] with FinalizeStates' types (function_aggr.go:1330-1365); the groups
+		// stay on the device (ph_agg_keys_dev / ph_agg_values_dev inside the library). A HAVING of the inner aggregate is the
+		// Filter of THIS operator over those columns: its column references carry the aggregate's own binding tags, and
+		// mapping them to positions is left to the maintainer who compiles this file — with a HAVING the subtree falls back.
+		info, ok := op.Info.(*AggOpInfo)
+		if !ok || len(op.Filters) > 0 || len(op.Children) != 1 {
+			return 0, false
+		}
+		c, ok := b.lower(op.Children[0])
+		if !ok {
+			return 0, false
+		}
+		var m planNodeMeta
+		groups := make([]C.ph_plan_expr, 0, len(info.GroupBys))
+		for _, g := range info.GroupBys {
+			x, ok := b.lowerPlanExpr(g, 0)
+			if !ok {
+				return 0, false
+			}
+			groups = append(groups, x)
+			m.types = append(m.types, g.DataTyp)
+			if x.kind == C.PH_PE_COL {
+				m.dicts = append(m.dicts, b.meta[c].dicts[int(x.col)])
+			} else {
+				m.dicts = append(m.dicts, nil)
+			}
+		}
+		aggs := make([]C.ph_plan_agg, 0, len(info.Aggs))
+		for _, a := range info.Aggs {
+			if a == nil || a.Typ != ET_Func || a.GetFuncInfo().FunImpl == nil || a.GetFuncInfo().FunImpl.IsDistinct() {
+				return 0, false
+			}
+			kind, ok := aggKinds[strings.ToLower(a.FuncName())]
+			if !ok {
+				return 0, false
+			}
+			var pa C.ph_plan_agg
+			if kind == C.PH_A_COUNT && (len(a.Children) == 0 || stripCast(a.Children[0]).Typ == ET_Const) {
+				pa.kind = C.PH_A_COUNT_STAR
+			} else {
+				if len(a.Children) != 1 {
+					return 0, false
+				}
+				x, ok := b.lowerPlanExpr(a.Children[0], 0)
+				if !ok {
+					return 0, false
+				}
+				pa.kind, pa.arg = kind, x
+			}
+			aggs = append(aggs, pa)
+			m.types = append(m.types, a.DataTyp) // the binder already typed the result as FinalizeStates produces it
+			m.dicts = append(m.dicts, nil)
+		}
+		var n C.ph_plan_node
+		n.kind = C.PH_PN_AGG
+		n.child[0], n.child[1] = C.int32_t(c), -1
+		if len(groups) > 0 {
+			gp := (*C.ph_plan_expr)(b.arena.alloc(uintptr(len(groups)) * unsafe.Sizeof(groups[0])))
+			copy(unsafe.Slice(gp, len(groups)), groups)
+			n.ngroups, n.groups = C.int32_t(len(groups)), gp
+		}
+		if len(aggs) > 0 {
+			ap := (*C.ph_plan_agg)(b.arena.alloc(uintptr(len(aggs)) * unsafe.Sizeof(aggs[0])))
+			copy(unsafe.Slice(ap, len(aggs)), aggs)
+			n.naggs, n.aggs = C.int32_t(len(aggs)), ap
+		}
+		return b.add(n, m), true
 	}
 	return 0, false
+}
+
+// VARCHAR group keys that are no small dictionary (Q18's c_name) come back as ROWS of their column
+// (ph_plan_key_info: type PH_STR, the table and column): fetch those strings, one per group, and let the group's
+// key value index them — the same decoding as gpuResidentPlanExecutor::Execute in plan_amd/csrc/host/executors.cpp.
+func (e *gpuResidentPlanExecutor) decodeStringKeys(r *C.ph_agg_result) error {
+	ng, nk := int(r.ngroups), maxInt(int(r.nkeys), 1)
+	if ng == 0 {
+		return nil
+	}
+	keys := unsafe.Slice((*int64)(unsafe.Pointer(r.keys)), ng*nk)
+	for k := 0; k < e.nGroups; k++ {
+		var kt, ks, kc C.int32_t
+		var tab *C.ph_table
+		if err := phErr(C.ph_plan_key_info(e.plan, C.int32_t(k), &kt, &ks, &tab, &kc)); err != nil {
+			return err
+		}
+		if kt != C.PH_STR {
+			continue
+		}
+		rows := make([]C.int64_t, ng)
+		for g := 0; g < ng; g++ {
+			rows[g] = C.int64_t(keys[g*nk+k])
+		}
+		off := make([]C.int32_t, ng+1)
+		buf := make([]byte, 1<<20)
+		if err := phErr(C.ph_table_strings(e.ctx, tab, kc, &rows[0], C.int64_t(ng), &off[0], (*C.char)(unsafe.Pointer(&buf[0])), C.int64_t(len(buf)))); err != nil {
+			return err
+		}
+		dict := make([]string, ng)
+		for g := 0; g < ng; g++ {
+			dict[g] = string(buf[off[g]:off[g+1]])
+			keys[g*nk+k] = int64(g)
+		}
+		e.keyDicts[k] = dict
+	}
+	return nil
 }
 
 func (b *planBuilder) setPreds(n *C.ph_plan_node, preds []C.ph_pred, bools []C.ph_bool) {
@@ -626,6 +733,9 @@ func (e *gpuResidentPlanExecutor) Execute(input, output *chunk.Chunk) (OperatorR
 			return InvalidOpResult, err
 		}
 		if err := phErr(C.ph_plan_fetch(e.plan, &e.result)); err != nil {
+			return InvalidOpResult, err
+		}
+		if err := e.decodeStringKeys(e.result); err != nil {
 			return InvalidOpResult, err
 		}
 	}

@@ -145,15 +145,31 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
     if (n > 0) {
         bool all;
         const unsigned long long kth = wg_radix_select(skeys, n, k, lh, s_state, &all);
-        for (int i = threadIdx.x; i < n; i += 256)
-            if (all || skeys[i] <= kth) {
-                const int pos = atomicAdd(cand_count, 1);
-                // agent-scope stores: written through to the device's coherence point, where the last workgroup reads them.
-                // (Ordinary stores + __threadfence() made every workgroup write back its whole L2 — including the group
-                // states the previous kernel had just written: 39 us for a kernel whose own work is ~10.)
-                __hip_atomic_store(&cand_ids[pos], base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one entry per group at most
-                __hip_atomic_store(&cand_keys[pos], skeys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        // ONE reserving add on the global candidate counter per workgroup (its candidates are counted in LDS first): adds on one
+        // address execute one after the other at the memory side (~12 ns each), and 111 workgroups x ~11 candidates were 14 of
+        // this kernel's 33 us
+        __shared__ int s_ncand, s_cbase;
+        if (threadIdx.x == 0) s_ncand = 0;
+        __syncthreads();
+        int mypos[TOPK_CHUNK / 256];
+#pragma unroll
+        for (int q = 0; q < TOPK_CHUNK / 256; q++) {
+            const int i = q * 256 + threadIdx.x;
+            mypos[q] = (i < n && (all || skeys[i] <= kth)) ? atomicAdd(&s_ncand, 1) : -1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cbase = s_ncand ? atomicAdd(cand_count, s_ncand) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TOPK_CHUNK / 256; q++) {
+            if (mypos[q] < 0) continue;
+            const int i = q * 256 + threadIdx.x, pos = s_cbase + mypos[q];
+            // agent-scope stores: written through to the device's coherence point, where the last workgroup reads them.
+            // (Ordinary stores + __threadfence() made every workgroup write back its whole L2 — including the group
+            // states the previous kernel had just written: 39 us for a kernel whose own work is ~10.)
+            __hip_atomic_store(&cand_ids[pos], base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one entry per group at most
+            __hip_atomic_store(&cand_keys[pos], skeys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's candidate stores are performed
     __syncthreads();
