@@ -443,6 +443,7 @@ def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
     pipe.keep_gather_ids = False
     ids, n1 = pipe.kept_gather_ids
     gcols = [pipe.l_supp, pipe.l_key, pipe.l_ext, pipe.l_disc, pipe.l_qty]
+    colocated = pipe.l_tab.colocated([0, 1, 2, 3, 4])
     T = h.torch
     ev = [T.cuda.Event(enable_timing=True) for _ in range(2)]
     reps = 20
@@ -472,13 +473,16 @@ def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
                    "stage_ms": {kk: round(v / stage_steps * 1e3, 3) for kk, v in agg_t.items() if kk != "exchange_bytes_sent"},
                    "stage_ms_note": f"{stage_steps} extra steps after the timed region, one host sync per stage"},
         "roofline": roofline(gm_bytes / (gm_ms * 1e-3) / 1e9,
-                             traffic=pmc_traffic(("q9", "gather_multi_kernel")) if (h.world == 1 and nrows == 59986052) else None,
-                             kernel="gather_multi_kernel (largest kernel of the query: five lineitem columns at the ~5 % of rows that survive the part join)",
+                             traffic=pmc_traffic(("q9", "gather_group_kernel" if colocated else "gather_multi_kernel")) if (h.world == 1 and nrows == 59986052) else None,
+                             kernel=("gather_group_kernel" if colocated else "gather_multi_kernel") +
+                                    " (the late materialisation: five lineitem columns at the ~5 % of rows that survive the part join" +
+                                    ("; read from their co-located copy, ph_table_colocate: 32 bytes per row side by side)" if colocated else ")"),
                              avg_launch_ms=gm_ms, algorithmic_bytes_per_launch=gm_bytes,
                              timing="HIP events on the launch stream around 20 launches over the query's own row ids",
-                             note="every gathered 4- or 8-byte value costs one 128-byte line: traffic = the distinct lines the row ids touch "
-                                  "(83 % of a 4-byte column's lines at 5.4 % row density); 1, 2, 4, 8 rows per thread and 4..64 workgroups per CU "
-                                  "all run within 8 % of each other",
+                             note=("one sector per surviving row id out of the co-located copy; out of the five column arrays every 4- or 8-byte value "
+                                   "cost a line of its own (rounds 1-2: 1.27 GB of traffic, 245 us)") if colocated else
+                                  ("every gathered 4- or 8-byte value costs one 128-byte line: traffic = the distinct lines the row ids touch "
+                                   "(83 % of a 4-byte column's lines at 5.4 % row density)"),
                              whole_query={"algorithmic_bytes": inputs, "achieved": inputs / (ms_step * 1e-3) / 1e9,
                                           "frac": inputs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "timing": "host clock around the timed steps (one query = ~38 launches)"}),

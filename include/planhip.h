@@ -177,6 +177,16 @@ int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags);
  * TPC-H table declares one). A join whose build key covers a declared-unique set is N:1. Trusted, like the
  * reference trusts its catalog; a lookup that meets two build rows for one key reports it (PH_ECONSTRAINT). */
 int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols);
+/* A co-located copy of 2..8 fixed-width columns without NULLs: row r of the copy holds the columns' values of row r side
+ * by side (widest first, the row padded to a power of two up to 64 bytes), beside the column arrays, which stay. It serves
+ * ph_gather_multi (and with it the late materialisation of ph_plan): the reference's row-format TupleDataCollection
+ * (join_collection.go:268-529) for exactly the columns that are fetched together by row id. A host that knows such a set
+ * (the planner: the probe-side columns that survive a selective join) calls this at load; without it the library builds
+ * the copy itself the SECOND time the same set of three or more columns of a table is gathered at no more than an eighth of
+ * its rows (PH_COLOCATE=0 switches both off). Costs stride x rows bytes of HBM and one pass. */
+int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols);
+/* 1 when a co-located copy covers the given columns */
+int32_t ph_table_colocated(const ph_table *t, int32_t ncols, const int32_t *cols);
 void ph_table_free(ph_table *t);
 
 /* plain device buffers for callers without their own allocator */
@@ -555,6 +565,9 @@ int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev, int64_t n,
 /* the same for up to 8 columns through one row-id array, in one pass: the late materialisation of a
  * join chain's probe side (all column reads of a row are in flight together, the index is read
  * once). out_dev[c]: n elements of column c's width. */
+/* When the views are columns of ONE resident table and the table holds a co-located copy of them (below), the gather
+ * reads it instead: one 64-byte sector per row id where the column arrays cost one per column (Q9's five lineitem
+ * columns at 5 % of the rows: 1.27 GB of traffic for 0.1 GB of values). */
 int ph_gather_multi(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n,
                     void *const *out_dev);
 

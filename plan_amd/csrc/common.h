@@ -121,6 +121,8 @@ struct ph_ctx {
     // every kernel and copy of a ctx runs on its one stream.
     std::multimap<int64_t, void *> pool_free_blocks;
     std::map<void *, int64_t> pool_sizes;
+    // device column base pointer -> (resident table, column): lets ph_gather_multi recognise a table's columns in the views it is given
+    std::map<const void *, std::pair<ph_table *, int>> table_cols;
     int pool_alloc(int64_t bytes, void **out);
     void pool_release(void *p);
     void pool_destroy();
@@ -145,6 +147,15 @@ struct ph_table {
     std::vector<column> cols;
     // column sets the catalog declares unique (PRIMARY KEY): ph_table_declare_unique
     std::vector<std::vector<int32_t>> unique_keys;
+    // co-located copies of column sets (ph_table_colocate): row r of the group = the set's values of row r side by side, so a
+    // sparse gather of several columns reads ONE sector per row id instead of one per column
+    struct colgroup {
+        std::vector<int> cols, off, width;   // table column, byte offset in the group's row, width
+        int stride = 0;                      // bytes per row (a power of two up to 64, else a multiple of 16)
+        void *data = nullptr;
+    };
+    std::vector<colgroup> groups;
+    std::map<std::vector<int>, int> sparse_gathers;   // column set -> sparse multi-column gathers seen (the second one builds the group)
 };
 
 // rows a column allocation is padded to, so vector loads never leave the allocation

@@ -557,6 +557,7 @@ extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_co
         ph_table_free(t);
         return rc;
     }
+    for (size_t c = 0; c < t->cols.size(); c++) if (t->cols[c].data) ctx->table_cols[t->cols[c].data] = {t, (int)c};
     *out = t;
     return PH_OK;
 }
@@ -593,6 +594,76 @@ extern "C" int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags) 
     return PH_OK;
 }
 
+// ---- co-located column groups
+struct ColocateParams {
+    const void *src[8];
+    int off[8], width[8];
+    int ncols, stride;
+};
+__global__ __launch_bounds__(256) void colocate_kernel(ColocateParams P, int64_t n, unsigned char *__restrict__ out) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        unsigned char *row = out + r * P.stride;
+        for (int c = 0; c < P.ncols; c++) {   // offsets are multiples of the width: aligned stores
+            if (P.width[c] == 8) *reinterpret_cast<unsigned long long *>(row + P.off[c]) = ((const unsigned long long *)P.src[c])[r];
+            else if (P.width[c] == 4) *reinterpret_cast<unsigned *>(row + P.off[c]) = ((const unsigned *)P.src[c])[r];
+            else row[P.off[c]] = ((const unsigned char *)P.src[c])[r];
+        }
+    }
+}
+
+extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols) {
+    PH_REQUIRE(t && t->ctx && cols && ncols >= 2 && ncols <= 8, "ph_table_colocate: 2..8 columns");
+    ph_ctx *ctx = t->ctx;
+    std::vector<int> set(cols, cols + ncols);
+    std::sort(set.begin(), set.end());
+    PH_REQUIRE(std::adjacent_find(set.begin(), set.end()) == set.end(), "ph_table_colocate: a column is named twice");
+    for (auto &g : t->groups) if (g.cols == set) return PH_OK;   // already there
+    ph_table::colgroup g;
+    g.cols = set;
+    int total = 0;
+    for (int c : set) {
+        PH_REQUIRE(c >= 0 && c < (int)t->cols.size(), "ph_table_colocate: bad column %d", c);
+        const int w = ph::type_width(t->cols[(size_t)c].type);
+        if (w == 0 || t->cols[(size_t)c].validity) { ph::set_error("ph_table_colocate: column %d is not a fixed-width column without NULLs", c); return PH_EUNSUPPORTED; }
+        g.width.push_back(w);
+        total += w;
+    }
+    // widest first, so that every value is aligned to its width; rows of a power-of-two stride never straddle a 64-byte sector
+    g.off.assign(set.size(), 0);
+    int at = 0;
+    for (int w : {8, 4, 1})
+        for (size_t i = 0; i < set.size(); i++)
+            if (g.width[i] == w) { g.off[i] = at; at += w; }
+    int stride = 8;
+    while (stride < total && stride < 64) stride *= 2;
+    if (stride < total) stride = (int)ph::round_up(total, 16);
+    g.stride = stride;
+    PH_HIP(hipSetDevice(ctx->device));
+    const int64_t padded = ph::round_up(t->nrows > 0 ? t->nrows : 1, PH_ROW_PAD);
+    PH_HIP(hipMalloc(&g.data, (size_t)padded * stride));
+    PH_HIP(hipMemsetAsync(g.data, 0, (size_t)padded * stride, ctx->stream));
+    if (t->nrows > 0) {
+        ColocateParams P{};
+        P.ncols = (int)set.size();
+        P.stride = stride;
+        for (size_t i = 0; i < set.size(); i++) { P.src[i] = t->cols[(size_t)set[i]].data; P.off[i] = g.off[i]; P.width[i] = g.width[i]; }
+        colocate_kernel<<<(int)std::min<int64_t>((t->nrows + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(P, t->nrows, (unsigned char *)g.data);
+        PH_HIP(hipGetLastError());
+    }
+    t->groups.push_back(g);
+    return PH_OK;
+}
+
+extern "C" int32_t ph_table_colocated(const ph_table *t, int32_t ncols, const int32_t *cols) {
+    if (!t || !cols || ncols < 1) return 0;
+    for (auto &g : t->groups) {
+        bool all = true;
+        for (int i = 0; i < ncols && all; i++) all = std::find(g.cols.begin(), g.cols.end(), (int)cols[i]) != g.cols.end();
+        if (all) return 1;
+    }
+    return 0;
+}
+
 extern "C" int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols) {
     PH_REQUIRE(t && cols && ncols >= 1 && ncols <= 4, "ph_table_declare_unique: 1..4 columns");
     std::vector<int32_t> u(cols, cols + ncols);
@@ -608,7 +679,9 @@ extern "C" void ph_table_free(ph_table *t) {
         (void)hipSetDevice(t->ctx->device);
         (void)hipStreamSynchronize(t->ctx->stream);
     }
+    for (auto &g : t->groups) if (g.data) (void)hipFree(g.data);
     for (auto &c : t->cols) {
+        if (c.data && t->ctx) t->ctx->table_cols.erase(c.data);
         if (c.data) (void)hipFree(c.data);
         if (c.validity) (void)hipFree(c.validity);
         if (c.aux) (void)hipFree(c.aux);

@@ -1056,11 +1056,158 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherMulti G, const 
 }
 }  // namespace ph
 
+namespace ph {
+// the same gather out of a co-located group: one row of `stride` bytes holds every requested value
+struct GatherGroup {
+    const unsigned char *rows;
+    int stride, ncols;
+    int off[GM_MAX], width[GM_MAX];
+    void *dst[GM_MAX];
+};
+template <int U>
+__global__ __launch_bounds__(256) void gather_group_kernel(GatherGroup G, const int32_t *__restrict__ idx, int64_t n) {
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U; base < n; base += (int64_t)gridDim.x * 256 * U) {
+        const unsigned char *row[U];
+        unsigned long long v[U][GM_MAX];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + u * 256 + threadIdx.x;
+            int ix = idx[i < n ? i : 0];
+            ix = ix < 0 ? 0 : ix;               // (as ph_gather_multi: a negative row id reads row 0)
+            row[u] = G.rows + (int64_t)ix * G.stride;
+        }
+        if (G.stride <= 32) {
+            // the whole row in two 16-byte reads (one when it is 16 bytes), the values picked out of the registers: two requests
+            // per row id where a read per column is one request each — the request path, not the bytes, bounds this kernel
+            unsigned d[U][8];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(row[u]);
+                uint4 hi = make_uint4(0, 0, 0, 0);
+                if (G.stride == 32) hi = *reinterpret_cast<const uint4 *>(row[u] + 16);
+                else if (G.stride == 8) { /* 8-byte rows: the upper half of `lo` belongs to the next row, unused */ }
+                d[u][0] = lo.x; d[u][1] = lo.y; d[u][2] = lo.z; d[u][3] = lo.w;
+                d[u][4] = hi.x; d[u][5] = hi.y; d[u][6] = hi.z; d[u][7] = hi.w;
+            }
+#pragma unroll
+            for (int c = 0; c < GM_MAX; c++) {
+                if (c >= G.ncols) break;   // wave-uniform
+                const int w0 = G.off[c] >> 2;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    unsigned a = 0, b = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { a = w0 == k ? d[u][k] : a; b = (w0 + 1 == k) ? d[u][k] : b; }
+                    v[u][c] = G.width[c] == 8 ? ((unsigned long long)b << 32) | a
+                              : G.width[c] == 4 ? (unsigned long long)a
+                                                : (unsigned long long)((a >> (8 * (G.off[c] & 3))) & 0xffu);
+                }
+            }
+        } else {
+#pragma unroll
+        for (int c = 0; c < GM_MAX; c++) {
+            if (c >= G.ncols) break;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                v[u][c] = G.width[c] == 8 ? *reinterpret_cast<const unsigned long long *>(row[u] + G.off[c])
+                          : G.width[c] == 4 ? (unsigned long long)*reinterpret_cast<const uint32_t *>(row[u] + G.off[c])
+                                            : (unsigned long long)row[u][G.off[c]];
+        }
+        }
+#pragma unroll
+        for (int c = 0; c < GM_MAX; c++) {
+            if (c >= G.ncols) break;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = base + u * 256 + threadIdx.x;
+                if (i >= n) continue;
+                if (G.width[c] == 8) ((unsigned long long *)G.dst[c])[i] = v[u][c];
+                else if (G.width[c] == 4) ((uint32_t *)G.dst[c])[i] = (uint32_t)v[u][c];
+                else ((uint8_t *)G.dst[c])[i] = (uint8_t)v[u][c];
+            }
+        }
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols);
+
+// The views name columns of ONE resident table (recognised by their base pointers): through a co-located group that covers
+// them when the table has one. A sparse gather (at most an eighth of the rows) of three or more columns that comes a SECOND
+// time builds the group itself — the layout follows the access pattern the plans show, as the statistics follow the data.
+// PH_OK = done, PH_EUNSUPPORTED = not this shape (the caller gathers column by column in one pass as before).
+static int gather_through_group(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n, void *const *out_dev) {
+    static const bool off = getenv("PH_COLOCATE") && atoi(getenv("PH_COLOCATE")) == 0;
+    if (off || ncols < 2) return PH_EUNSUPPORTED;
+    ph_table *t = nullptr;
+    std::vector<int> tc((size_t)ncols);
+    for (int c = 0; c < ncols; c++) {
+        auto it = ctx->table_cols.find(cols[c].data);
+        if (it == ctx->table_cols.end() || (t && it->second.first != t)) return PH_EUNSUPPORTED;
+        t = it->second.first;
+        tc[(size_t)c] = it->second.second;
+        if (ph::type_width(cols[c].type) != ph::type_width(t->cols[(size_t)tc[(size_t)c]].type)) return PH_EUNSUPPORTED;
+    }
+    auto find = [&]() -> const ph_table::colgroup * {
+        for (auto &g : t->groups) {
+            bool all = true;
+            for (int c : tc) all = all && std::find(g.cols.begin(), g.cols.end(), c) != g.cols.end();
+            if (all) return &g;
+        }
+        return nullptr;
+    };
+    const ph_table::colgroup *g = find();
+    if (!g) {
+        if (ncols < 3 || n * 8 > t->nrows) return PH_EUNSUPPORTED;
+        std::vector<int> set = tc;
+        std::sort(set.begin(), set.end());
+        if (std::adjacent_find(set.begin(), set.end()) != set.end()) return PH_EUNSUPPORTED;
+        for (int c : set) if (t->cols[(size_t)c].validity) return PH_EUNSUPPORTED;
+        if (++t->sparse_gathers[set] < 2) return PH_EUNSUPPORTED;
+        std::vector<int32_t> s32(set.begin(), set.end());
+        if (ph_table_colocate(t, (int32_t)s32.size(), s32.data()) != PH_OK) return PH_EUNSUPPORTED;
+        g = find();
+        if (!g) return PH_EUNSUPPORTED;
+    }
+    ph::GatherGroup G{};
+    G.rows = (const unsigned char *)g->data;
+    G.stride = g->stride;
+    G.ncols = ncols;
+    for (int c = 0; c < ncols; c++) {
+        const size_t k = (size_t)(std::find(g->cols.begin(), g->cols.end(), tc[(size_t)c]) - g->cols.begin());
+        G.off[c] = g->off[k];
+        G.width[c] = g->width[k];
+        G.dst[c] = out_dev[c];
+    }
+    // rows per thread in flight (every row is one sector read by up to ncols adjacent loads)
+    static const int gu = getenv("PH_GATHER_GROUP_U") ? atoi(getenv("PH_GATHER_GROUP_U")) : 1;   // measured on Q9 (3.27 M ascending ids into 60 M rows, a read per column): 1: 114 us, 2: 143, 4: 233, 8: 294
+    if (gu == 8 && ncols <= 5) {
+        const int grid = (int)std::min<int64_t>((n + 2047) / 2048, 256 * 16);
+        ph::gather_group_kernel<8><<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    } else if (gu >= 4) {
+        const int grid = (int)std::min<int64_t>((n + 1023) / 1024, 256 * 16);
+        ph::gather_group_kernel<4><<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    } else if (gu == 1) {
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 32);
+        ph::gather_group_kernel<1><<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    } else {
+        const int grid = (int)std::min<int64_t>((n + 511) / 512, 256 * 16);
+        ph::gather_group_kernel<2><<<grid, 256, 0, ctx->stream>>>(G, idx_dev, n);
+    }
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 extern "C" int ph_gather_multi(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n,
                                void *const *out_dev) {
     PH_REQUIRE(ctx && ncols >= 1 && ncols <= ph::GM_MAX && cols && out_dev && (n == 0 || idx_dev),
                "ph_gather_multi: bad arguments (1..%d columns)", ph::GM_MAX);
     if (n == 0) return PH_OK;
+    for (int c = 0; c < ncols; c++) PH_REQUIRE(cols[c].data && out_dev[c], "ph_gather_multi: column %d has a NULL pointer", c);
+    {
+        const int rcg = gather_through_group(ctx, ncols, cols, idx_dev, n, out_dev);
+        if (rcg != PH_EUNSUPPORTED) return rcg;
+    }
     ph::GatherMulti G{};
     G.ncols = ncols;
     for (int c = 0; c < ncols; c++) {

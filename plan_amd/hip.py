@@ -267,6 +267,14 @@ class Table:
         check(lib().ph_table_col_range(self.h, i32(c), ctypes.byref(mn), ctypes.byref(mx)))
         return mn.value, mx.value
 
+    def colocate(self, cols):
+        """ph_table_colocate: a co-located (row-major) copy of these columns beside the column arrays; ph_gather_multi over
+        views of them then reads one sector per row id"""
+        check(lib().ph_table_colocate(self.h, i32(len(cols)), (i32 * len(cols))(*cols)))
+
+    def colocated(self, cols):
+        return bool(lib().ph_table_colocated(self.h, i32(len(cols)), (i32 * len(cols))(*cols)))
+
     def free(self):
         if self.h:
             lib().ph_table_free(self.h)
@@ -373,6 +381,23 @@ class DevColumn:
         for p in self.ptrs:
             self.ctx.free(p)
         self.ptrs = []
+
+
+class TableColumn(DevColumn):
+    """Column c of a resident Table, usable wherever a DevColumn is (col(), data, type, scale, n); freed with its table."""
+
+    def __init__(self, table, c):
+        self.table, self.index = table, c
+        v = table.col(c)
+        self.ctx, self.type, self.scale, self.data, self.validity, self.n = table.ctx, v.type, v.scale, v.data, v.validity, table.nrows
+        self.aux, self.aux_bytes = v.aux, v.aux_bytes
+        self.ptrs = []
+
+    def col(self):
+        return self.table.col(self.index)
+
+    def free(self):
+        pass
 
 
 def _cols(cols):

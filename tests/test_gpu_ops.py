@@ -730,6 +730,44 @@ def test_join_unhinted_big_build_reads_its_key_range(ctx):
         os.environ.pop("PH_JOIN_AUTO_RANGE")
 
 
+def test_gather_multi_through_a_colocated_copy(ctx):
+    """ph_table_colocate: columns of widths 8 / 4 / 1 side by side per row; ph_gather_multi over views of them reads the
+    copy (any subset, any order of the columns, negative row ids read row 0 as before) and gives what the column arrays
+    give; a sparse gather of three columns that comes a second time builds the copy by itself."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    a = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    b = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    c = rng.integers(0, 200, n).astype(np.uint8)
+    d = rng.integers(0, 10**9, n).astype(np.int64)
+    e = rng.integers(0, 50, n).astype(np.int32)
+    t = hip.Table(ctx, [(hip.PH_I64, a), (hip.PH_I32, b), (hip.PH_CODE8, c, 0, None, [str(i) for i in range(200)]), (hip.PH_DEC64, d, 2), (hip.PH_I32, e)], n)
+    cols = [hip.TableColumn(t, i) for i in range(5)]
+    host = [a, b, c, d, e]
+    idx = rng.integers(0, n, 20_000).astype(np.int32)
+    idx[:5] = -1
+    di = ctx.upload(idx)
+    want_idx = np.where(idx < 0, 0, idx)
+    def check(which):
+        outs = hip.gather_multi(ctx, [cols[i] for i in which], di, len(idx))
+        for o, i in zip(outs, which):
+            got = ctx.download(o, host[i].dtype, len(idx))
+            assert np.array_equal(got, host[i][want_idx]), i
+            ctx.free(o)
+    assert not t.colocated([0, 1, 3])
+    check([3, 0, 1])                      # first sparse gather of this set: the column arrays
+    assert not t.colocated([0, 1, 3])
+    check([3, 0, 1])                      # the second builds the copy and reads it
+    assert t.colocated([0, 1, 3]) and not t.colocated([0, 1, 2, 3, 4])
+    check([1, 3]); check([0, 1, 3])
+    t.colocate([0, 1, 2, 3, 4])           # the planner's set, widths 8, 4, 1, 8, 4
+    assert t.colocated([4, 2])
+    for which in ([0, 1, 2, 3, 4], [4, 2, 0], [2, 1], [3, 4, 0, 2]):
+        check(which)
+    ctx.free(di)
+    t.free()
+
+
 def test_join_radix_partitioned_form(ctx, monkeypatch):
     """Big build sides whose keys are not dense in a range: both sides partitioned by key hash, the tables built in
     LDS and written out as images, probes against the images of their partition (kind "radix"; PH_JOIN_RADIX_MIN
