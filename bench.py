@@ -17,7 +17,7 @@ ONE JSON line on rank 0 (driver contract). Besides the contract's fields:
                  HIP events on the launch stream; peak_measured = streaming-read ceiling measured in
                  this run (ph_dev_read_reduce); traffic = HBM bytes of the committed PMC passes
   cpu_baseline   the oracle (CPU restatement of the reference path, 1 thread) on a bounded sample
-  N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu (every BASELINE.json
+  N = 1: companions q6_single_gpu, q1_sf1, q3_single_gpu, q9_single_gpu, general_forms (every BASELINE.json
          config, each with its own roofline; Q3 / Q9 with their own cpu_baseline), and q3_operator_interface /
          q9_operator_interface: the same two queries through the C++ OperatorExec layer as one resident-plan executor
   N > 1: companions q3_partitioned, q3_partitionwise, q9_partitioned, q9_partitionwise — Q3 / Q9 over an SF`--sf` database split N
@@ -491,6 +491,65 @@ def bench_q9(h, sf, steps, warmup, scaling="weak", partitionwise=False):
     return line
 
 
+# ---------------------------------------------------------------------------------- general operator forms
+
+def bench_general_forms(h, sf):
+    """The operator-granular forms a plan gets when NO statistic or hint applies ("far below roofline"): the hash
+    aggregate at 65 536 groups over 32 M rows, and ph_join_build WITHOUT a key range over 15 M build keys + a 60 M-row inner
+    probe — once with TPC-H order keys (dense in their range: the library reads the range off the column and takes the direct
+    table) and once with random 62-bit keys probed in random order (the radix-partitioned form). Wall time per call around a
+    stream synchronisation, best of 3 (scripts/bench_ops.py, scripts/join_auto_probe.py)."""
+    import numpy as np
+    from plan_amd import tpchgen
+    hip, ctx = h.hip, h.ctx
+    rng = np.random.default_rng(0)
+
+    def best(f, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); f(); ctx.sync(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    out = {}
+    n = 32_000_000
+    vals = hip.DevColumn(ctx, hip.PH_I64, rng.integers(0, 10**6, n).astype(np.int64))
+    keys = hip.DevColumn(ctx, hip.PH_I64, rng.integers(0, 65536, n).astype(np.int64))
+
+    def agg_run():
+        agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], 65536)
+        agg.sink([keys], [vals], None, n)
+        agg.group_count()
+        agg.free()
+    agg_run()
+    t = best(agg_run)
+    out["agg_sink_65k_groups"] = {"rows": n, "groups": 65536, "ms": t * 1e3, "rows_per_s": n / t,
+                                  "algorithmic_GBps": n * 16 / t / 1e9, "frac_of_hbm_peak": n * 16 / t / 1e9 / HBM_PEAK_GBS,
+                                  "form": "bulk build, second form: count + LDS-staged scatter + sliced LDS tables + merge (4 passes over the rows' 16 B)"}
+    vals.free(); keys.free()
+    L = tpchgen.lineitem((sf, 1), columns=["l_orderkey"])
+    O = tpchgen.orders((sf, 1), columns=["o_orderkey"])
+    nl, no = len(L["l_orderkey"]), len(O["o_orderkey"])
+    sparse = rng.integers(0, 2**62, no).astype(np.int64)
+    cases = (("order_keys", O["o_orderkey"], L["l_orderkey"]), ("random_62bit_keys", sparse, sparse[rng.integers(0, no, nl)]))
+    del L, O
+    for name, bk, pk in cases:
+        b, p = hip.DevColumn(ctx, hip.PH_I64, bk), hip.DevColumn(ctx, hip.PH_I64, pk)
+        hip.Join(ctx, [b], None, no).free()
+        tb = best(lambda: hip.Join(ctx, [b], None, no).free())
+        j = hip.Join(ctx, [b], None, no)
+
+        def probe():
+            m, x, y = j.probe_inner([p], None, nl, nl)
+            ctx.free(x); ctx.free(y)
+            return m
+        probe()
+        tp = best(probe)
+        out["join_unhinted_" + name] = {"build_rows": no, "probe_rows": nl, "table": j.kind, "build_ms": tb * 1e3, "probe_ms": tp * 1e3,
+                                        "total_ms": (tb + tp) * 1e3, "probe_rows_per_s": nl / tp,
+                                        "algorithmic_GBps": (no * 8 + nl * 8 + nl * 8) / (tb + tp) / 1e9}
+        j.free(); b.free(); p.free()
+    return out
+
+
 # ---------------------------------------------------------------------------------- operator interface
 
 def bench_operator_interface(h, sf, steps, warmup):
@@ -662,6 +721,7 @@ def main():
             out.update(bench_operator_interface(h, args.sf, max(comp_steps, 50), max(comp_warm, 8)))
         except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
             out["q3_operator_interface"] = out["q9_operator_interface"] = {"error": f"{type(e).__name__}: {e}"}
+        attempt("general_forms", lambda: bench_general_forms(h, args.sf))
         if not args.no_cpu_baseline:
             if "error" not in out["q6_single_gpu"]:
                 out["q6_single_gpu"]["cpu_baseline"] = cb["q6"]
