@@ -494,6 +494,228 @@ int64_t oracle_q18(const oracle_tpch *T, const int64_t *o_totalprice, int64_t qt
 int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);
 
 /* ------------------------------------------------------------------ text */
+/* extract(year from date): Date.Year (pkg/common/date.go) */
+static int32_t year_of_days2(int32_t z) {
+    z += 719468;
+    int32_t era = (z >= 0 ? z : z - 146096) / 146097;
+    uint32_t doe = (uint32_t)(z - era * 146097);
+    uint32_t yoe = (doe - doe / 1460u + doe / 36524u - doe / 146096u) / 365u;
+    int32_t y = (int32_t)yoe + era * 400;
+    uint32_t doy = doe - (365u * yoe + yoe / 4u - yoe / 100u);
+    uint32_t mp = (5u * doy + 2u) / 153u;
+    int32_t m = (int32_t)(mp < 10 ? mp + 3 : mp - 9);
+    return y + (m <= 2);
+}
+
+
+/* ------------------------------------------------------------------ Q7 (cases/tpch/query/q7.sql)
+ * Agg(supp_nation, cust_nation, l_year; sum(volume)) <- Filter((n1 = A and n2 = B) or (n1 = B and n2 = A))
+ *   <- Join(c_nationkey = n2.n_nationkey) <- Join(s_nationkey = n1.n_nationkey) <- Join(c_custkey = o_custkey)
+ *   <- Join(o_orderkey = l_orderkey) <- Join(s_suppkey = l_suppkey) probe Scan(lineitem, l_shipdate between), build Scan(supplier).
+ * Every join is N:1 from lineitem's side, so the result does not depend on the order the optimizer picks; the pair
+ * condition is evaluated by executeSelect's OR of two ANDs (expr_exec.go:342-530) on the joined chunk. */
+int64_t oracle_q7(const oracle_tpch *T, const char *nation_a, const char *nation_b, int32_t date_ge, int32_t date_le, oracle_q7_row *out, int64_t max) {
+    int64_t n = T->n_lineitem;
+    int64_t *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol ls = mkcol(OT_DATE, 0, T->l_shipdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_le);
+    int64_t c = oracle_select(&ls, OP_GE, &k1, NULL, n, s1);          /* BETWEEN = >= AND <= (bindBetweenExpr) */
+    c = oracle_select(&ls, OP_LE, &k2, s1, c, s2);
+    /* x supplier */
+    ocol sk = mkcol(OT_INT32, 0, T->s_suppkey);
+    ojoin *js = oracle_join_build(&sk, 1, NULL, T->n_supplier);
+    int64_t *l1 = i64buf(c), *sr = i64buf(c);
+    ocol lsup = mkcol(OT_INT32, 0, T->l_suppkey);
+    int64_t n1 = oracle_join_probe_inner(js, &lsup, 1, s2, c, l1, sr, c);
+    oracle_join_free(js);
+    /* x orders */
+    ocol ok = mkcol(OT_INT64, 0, T->o_orderkey);
+    ojoin *jo = oracle_join_build(&ok, 1, NULL, T->n_orders);
+    int64_t *kbuf = i64buf(n1);
+    for (int64_t i = 0; i < n1; i++) kbuf[i] = T->l_orderkey[l1[i]];
+    ocol pk = mkcol(OT_INT64, 0, kbuf);
+    int64_t *p2 = i64buf(n1), *orow = i64buf(n1);
+    int64_t n2 = oracle_join_probe_inner(jo, &pk, 1, NULL, n1, p2, orow, n1);
+    oracle_join_free(jo);
+    /* x customer */
+    ocol ck = mkcol(OT_INT32, 0, T->c_custkey);
+    ojoin *jc = oracle_join_build(&ck, 1, NULL, T->n_customer);
+    int32_t *cbuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    for (int64_t i = 0; i < n2; i++) cbuf[i] = T->o_custkey[orow[i]];
+    ocol pc = mkcol(OT_INT32, 0, cbuf);
+    int64_t *p3 = i64buf(n2), *crow = i64buf(n2);
+    int64_t n3 = oracle_join_probe_inner(jc, &pc, 1, NULL, n2, p3, crow, n2);
+    oracle_join_free(jc);
+    /* x nation n1 (supplier's), x nation n2 (customer's): n_nationkey = row of the fixed NATION table; the joins keep every row */
+    ocol kproto[3] = {mkcode(NULL, T->nation_dict), mkcode(NULL, T->nation_dict), mkcol(OT_INT32, 0, NULL)};
+    ocol aproto[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *t = oracle_agg_create(kproto, 3, aproto, aggs, 1);
+    static odec v[VS];
+    int64_t ext[VS], disc[VS], t1[VS], t2[VS], t3[VS], t4[VS], keep[VS];
+    uint8_t sn[VS], cn[VS];
+    int32_t yr[VS];
+    oconst ka = kstr(nation_a), kb = kstr(nation_b);
+    int rc = 0;
+    for (int64_t base = 0; base < n3 && rc == 0; base += VS) {
+        int64_t cnt = n3 - base < VS ? n3 - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            const int64_t q3 = p3[base + j], q2 = p2[q3], l = l1[q2];
+            ext[j] = T->l_extendedprice[l];
+            disc[j] = T->l_discount[l];
+            sn[j] = T->n_name[T->s_nationkey[sr[q2]]];
+            cn[j] = T->n_name[T->c_nationkey[crow[base + j]]];
+            yr[j] = year_of_days2(T->l_shipdate[l]);
+        }
+        ocol snc = mkcode(sn, T->nation_dict), cnc = mkcode(cn, T->nation_dict);
+        /* (n1 = A and n2 = B) or (n1 = B and n2 = A): execSelectOr unites the two branches' selections in row order */
+        int64_t a1 = oracle_select(&snc, OP_EQ, &ka, NULL, cnt, t1);
+        a1 = oracle_select(&cnc, OP_EQ, &kb, t1, a1, t2);
+        int64_t b1 = oracle_select(&snc, OP_EQ, &kb, NULL, cnt, t3);
+        b1 = oracle_select(&cnc, OP_EQ, &ka, t3, b1, t4);
+        int64_t m = 0, ia = 0, ib = 0;
+        while (ia < a1 || ib < b1) {
+            if (ib >= b1 || (ia < a1 && t2[ia] < t4[ib])) keep[m++] = t2[ia++];
+            else if (ia >= a1 || t4[ib] < t2[ia]) keep[m++] = t4[ib++];
+            else { keep[m++] = t2[ia++]; ib++; }
+        }
+        /* the filter's selection narrows the chunk (SliceIndice): the aggregate sees the surviving rows, positionally */
+        for (int64_t i = 0; i < m; i++) {
+            const int64_t j = keep[i];   /* keep[i] >= i: in place */
+            ext[i] = ext[j]; disc[i] = disc[j]; sn[i] = sn[j]; cn[i] = cn[j]; yr[i] = yr[j];
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        rc = oracle_eval_decimal(cols, DISC_PRICE, 5, NULL, m, v);
+        ocol keys[3] = {mkcode(sn, T->nation_dict), mkcode(cn, T->nation_dict), mkcol(OT_INT32, 0, yr)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        if (rc == 0 && m > 0) rc = oracle_agg_sink(t, keys, args, NULL, m);
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[3];
+        oaggval val;
+        oracle_agg_group(t, g, NULL, kv, NULL, &val);
+        out[g].supp_nation = (int32_t)kv[0];
+        out[g].cust_nation = (int32_t)kv[1];
+        out[g].l_year = (int32_t)kv[2];
+        out[g].revenue = val.d;
+    }
+    oracle_agg_free(t);
+    free(s1); free(s2); free(l1); free(sr); free(kbuf); free(p2); free(orow); free(cbuf); free(p3); free(crow);
+    return ng;
+}
+
+/* ------------------------------------------------------------------ Q8 (cases/tpch/query/q8.sql)
+ * Agg(o_year; sum(case when nation = X then volume else 0 end), sum(volume)) over part[p_type] x lineitem x supplier x orders[date range]
+ * x customer x nation n1 x region[r_name] and nation n2 (the supplier's); the select list divides the two sums: DECIMAL `/` =
+ * govalues Quo, typed as its first argument (BindDecimalDivide, function_scalar.go:507-514), printed at that scale. */
+int64_t oracle_q8(const oracle_tpch *T, const char *nation, const char *region, const char *ptype, int32_t date_ge, int32_t date_le,
+                  oracle_q8_row *out, int64_t max) {
+    /* part[p_type = ..] */
+    int64_t *psel = i64buf(T->n_part);
+    ocol pt = mkcode(T->p_type, T->type_dict);
+    oconst kt = kstr(ptype);
+    int64_t np = oracle_select(&pt, OP_EQ, &kt, NULL, T->n_part, psel);
+    ocol pk = mkcol(OT_INT32, 0, T->p_partkey);
+    ojoin *jp = oracle_join_build(&pk, 1, psel, np);
+    int64_t cap = T->n_lineitem;
+    int64_t *l1 = i64buf(cap), *pr = i64buf(cap);
+    ocol lp = mkcol(OT_INT32, 0, T->l_partkey);
+    int64_t n1 = oracle_join_probe_inner(jp, &lp, 1, NULL, T->n_lineitem, l1, pr, cap);
+    oracle_join_free(jp);
+    /* x orders[o_orderdate between] */
+    int64_t *o1 = i64buf(T->n_orders), *o2 = i64buf(T->n_orders);
+    ocol od = mkcol(OT_DATE, 0, T->o_orderdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_le);
+    int64_t no = oracle_select(&od, OP_GE, &k1, NULL, T->n_orders, o1);
+    no = oracle_select(&od, OP_LE, &k2, o1, no, o2);
+    ocol ok = mkcol(OT_INT64, 0, T->o_orderkey);
+    ojoin *jo = oracle_join_build(&ok, 1, o2, no);
+    int64_t *kbuf = i64buf(n1);
+    for (int64_t i = 0; i < n1; i++) kbuf[i] = T->l_orderkey[l1[i]];
+    ocol pko = mkcol(OT_INT64, 0, kbuf);
+    int64_t *p2 = i64buf(n1), *orow = i64buf(n1);
+    int64_t n2 = oracle_join_probe_inner(jo, &pko, 1, NULL, n1, p2, orow, n1);
+    oracle_join_free(jo);
+    /* nations of the region, customers of those nations */
+    int64_t rsel[5], nrow[25], nreg[25];
+    ocol rn = mkcode(T->r_name, T->region_dict);
+    oconst kr = kstr(region);
+    int64_t nr = oracle_select(&rn, OP_EQ, &kr, NULL, 5, rsel);
+    ocol rk = mkcol(OT_INT32, 0, T->r_regionkey);
+    ojoin *jr = oracle_join_build(&rk, 1, rsel, nr);
+    ocol nrk = mkcol(OT_INT32, 0, T->n_regionkey);
+    int64_t nn = oracle_join_probe_inner(jr, &nrk, 1, NULL, 25, nrow, nreg, 25);
+    oracle_join_free(jr);
+    ocol nk = mkcol(OT_INT32, 0, T->n_nationkey);
+    ojoin *jn = oracle_join_build(&nk, 1, nrow, nn);
+    int64_t *c_row = i64buf(T->n_customer), *c_nat = i64buf(T->n_customer);
+    ocol cn = mkcol(OT_INT32, 0, T->c_nationkey);
+    int64_t nc = oracle_join_probe_inner(jn, &cn, 1, NULL, T->n_customer, c_row, c_nat, T->n_customer);
+    oracle_join_free(jn);
+    ocol ck = mkcol(OT_INT32, 0, T->c_custkey);
+    ojoin *jc = oracle_join_build(&ck, 1, c_row, nc);
+    int32_t *cbuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    for (int64_t i = 0; i < n2; i++) cbuf[i] = T->o_custkey[orow[i]];
+    ocol pc = mkcol(OT_INT32, 0, cbuf);
+    int64_t *p3 = i64buf(n2), *crow = i64buf(n2);
+    int64_t n3 = oracle_join_probe_inner(jc, &pc, 1, NULL, n2, p3, crow, n2);
+    oracle_join_free(jc);
+    /* x supplier x nation n2: both keep every row (foreign keys into whole tables); s_suppkey = row + 1 is NOT assumed: a join */
+    ocol sk = mkcol(OT_INT32, 0, T->s_suppkey);
+    ojoin *js = oracle_join_build(&sk, 1, NULL, T->n_supplier);
+    int32_t *sbuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n3 > 0 ? n3 : 1));
+    for (int64_t i = 0; i < n3; i++) sbuf[i] = T->l_suppkey[l1[p2[p3[i]]]];
+    ocol ps = mkcol(OT_INT32, 0, sbuf);
+    int64_t *p4 = i64buf(n3), *srow = i64buf(n3);
+    int64_t n4 = oracle_join_probe_inner(js, &ps, 1, NULL, n3, p4, srow, n3);
+    oracle_join_free(js);
+    ocol kproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    ocol aproto[2] = {mkcol(OT_ODEC, 0, NULL), mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[2] = {{OA_SUM, 0}, {OA_SUM, 1}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 2);
+    static odec vc[VS], va[VS];
+    static uint8_t vnull[VS];
+    int64_t ext[VS], disc[VS];
+    uint8_t nat[VS];
+    int32_t yr[VS];
+    const orpn zero[1] = {{OX_CONST_INT, 0, 0, 0}};
+    oconst kn = kstr(nation);
+    int rc = 0;
+    for (int64_t base = 0; base < n4 && rc == 0; base += VS) {
+        int64_t cnt = n4 - base < VS ? n4 - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            const int64_t q4 = p4[base + j], q3 = p3[q4], q2 = p2[q3], l = l1[q2];
+            ext[j] = T->l_extendedprice[l];
+            disc[j] = T->l_discount[l];
+            nat[j] = T->n_name[T->s_nationkey[srow[base + j]]];
+            yr[j] = year_of_days2(T->o_orderdate[orow[q3]]);
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        ocol wc = mkcode(nat, T->nation_dict);
+        rc = oracle_case_decimal(cols, &wc, OP_EQ, &kn, DISC_PRICE, 5, zero, 1, cnt, vc, vnull);   /* case when nation = X then volume else 0 end */
+        if (rc == 0) rc = oracle_eval_decimal(cols, DISC_PRICE, 5, NULL, cnt, va);
+        ocol keys[1] = {mkcol(OT_INT32, 0, yr)};
+        ocol args[2] = {mkcol(OT_ODEC, 0, vc), mkcol(OT_ODEC, 0, va)};
+        if (rc == 0) rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+    }
+    int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[1];
+        oaggval v[2];
+        oracle_agg_group(t, g, NULL, kv, NULL, v);
+        out[g].o_year = (int32_t)kv[0];
+        out[g].nation_volume = v[0].d;
+        out[g].volume = v[1].d;
+        if (odec_quo(v[0].d, v[1].d, &out[g].mkt_share) != 0) ng = -1;
+    }
+    oracle_agg_free(t);
+    free(psel); free(l1); free(pr); free(o1); free(o2); free(kbuf); free(p2); free(orow); free(c_row); free(c_nat); free(cbuf);
+    free(p3); free(crow); free(sbuf); free(p4); free(srow);
+    (void)nreg;
+    return ng;
+}
+
 typedef struct { char *buf; int64_t cap, len; } sbuf2;
 static void put(sbuf2 *s, const char *t) {
     int64_t n = (int64_t)strlen(t);
@@ -602,5 +824,56 @@ int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *bu
         oracle_format_hugeint(r->sum_qty, t); put(&s, t); put(&s, "\n");
     }
     free(tp); free(ord); free(od);
+    return done(&s);
+}
+
+static int q7_cmp_dict(const char *const *dict, int32_t a, int32_t b) { return strcmp(dict[a], dict[b]); }
+
+int64_t oracle_q7_text(oracle_q7_row *rows, int64_t n, const char *const *nation_names, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\t\t\n");
+    /* ORDER BY supp_nation, cust_nation, l_year (VARCHAR keys in byte order): a handful of rows, insertion sort */
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t j = i;
+        while (j > 0) {
+            const oracle_q7_row *a = &rows[ord[j - 1]], *b = &rows[i];
+            int c = q7_cmp_dict(nation_names, a->supp_nation, b->supp_nation);
+            if (c == 0) c = q7_cmp_dict(nation_names, a->cust_nation, b->cust_nation);
+            if (c == 0) c = (a->l_year > b->l_year) - (a->l_year < b->l_year);
+            if (c <= 0) break;
+            ord[j] = ord[j - 1];
+            j--;
+        }
+        ord[j] = i;
+    }
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        const oracle_q7_row *r = &rows[ord[i]];
+        put(&s, nation_names[r->supp_nation]); put(&s, "\t");
+        put(&s, nation_names[r->cust_nation]); put(&s, "\t");
+        sprintf(t, "%d", r->l_year); put(&s, t); put(&s, "\t");
+        oracle_format_decimal(r->revenue, 4, t); put(&s, t); put(&s, "\n");
+    }
+    free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q8_text(oracle_q8_row *rows, int64_t n, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) {       /* ORDER BY o_year */
+        int64_t j = i;
+        while (j > 0 && rows[ord[j - 1]].o_year > rows[i].o_year) { ord[j] = ord[j - 1]; j--; }
+        ord[j] = i;
+    }
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        const oracle_q8_row *r = &rows[ord[i]];
+        sprintf(t, "%d", r->o_year); put(&s, t); put(&s, "\t");
+        oracle_format_decimal(r->mkt_share, 4, t); put(&s, t); put(&s, "\n");   /* the quotient's column type is its first argument's: DECIMAL(38,4) */
+    }
+    free(ord);
     return done(&s);
 }

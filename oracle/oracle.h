@@ -349,6 +349,15 @@ typedef struct { int32_t c_custkey; int64_t o_orderkey; int32_t o_orderdate; int
 typedef struct { const int64_t *o_totalprice; } oracle_tpch_q18_extra;
 int64_t oracle_q18(const oracle_tpch *T, const int64_t *o_totalprice, int64_t qty_gt, oracle_q18_row *out, int64_t max);
 int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);   /* ORDER BY o_totalprice DESC, o_orderdate LIMIT */
+/* Q7 / Q8 (cases/tpch/query/q7.sql, q8.sql): six- and eight-table join chains, OR of conjunctions over two nation joins, CASE,
+ * EXTRACT(year), and Q8's DECIMAL division in the select list (govalues Quo, typed as its first argument) */
+typedef struct { int32_t supp_nation, cust_nation, l_year; odec revenue; } oracle_q7_row;     /* nation = row of NATION */
+typedef struct { int32_t o_year; odec nation_volume, volume, mkt_share; } oracle_q8_row;
+int64_t oracle_q7(const oracle_tpch *T, const char *nation_a, const char *nation_b, int32_t date_ge, int32_t date_le, oracle_q7_row *out, int64_t max);
+int64_t oracle_q8(const oracle_tpch *T, const char *nation, const char *region, const char *ptype, int32_t date_ge, int32_t date_le,
+                  oracle_q8_row *out, int64_t max);
+int64_t oracle_q7_text(oracle_q7_row *rows, int64_t n, const char *const *nation_names, char *buf, int64_t cap);   /* ORDER BY the three keys */
+int64_t oracle_q8_text(oracle_q8_row *rows, int64_t n, char *buf, int64_t cap);                                     /* ORDER BY o_year */
 int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY o_orderpriority */
 int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY revenue DESC */
 int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);  /* ORDER BY l_shipmode */

@@ -299,6 +299,36 @@ bool DecimalQuoCount(__int128 sum, int scale, uint64_t count, Decimal *out) {
     return true;
 }
 
+bool DecimalQuo(const Decimal &a, const Decimal &b, Decimal *out) {
+    // binDecimalDivOp: left.Quo(right) (function_operator_binary.go:199-207) — the quotient to 19 significant digits, half-even,
+    // trailing zeros trimmed down to the preferred scale max(0, scale(a) - scale(b)); the same digit loop as DecimalQuoCount
+    if (b.coef == 0) return false;
+    int pref = std::max(0, (int)a.scale - (int)b.scale);
+    if (a.coef == 0) { *out = Decimal{false, 0, (int8_t)pref}; return true; }
+    u128 n = a.coef;
+    int s = (int)a.scale - (int)b.scale;
+    if (s < 0) { n *= p10(-s); s = 0; }
+    u128 d = b.coef, c = n / d, r = n % d;
+    while (r != 0 && ndig(c) <= 19 && s <= 19) {
+        r *= 10;
+        c = c * 10 + r / d;
+        r %= d;
+        s++;
+    }
+    bool sticky = r != 0;
+    for (;;) {
+        int drop = std::max(ndig(c) - 19, s - 19);
+        if (drop <= 0) break;
+        if (s - drop < 0) return false;
+        c = rsh_half_even(c, drop, sticky);
+        sticky = false;
+        s -= drop;
+    }
+    while (s > pref && c % 10 == 0) { c /= 10; s--; }
+    *out = Decimal{(a.neg != b.neg) && c != 0, (uint64_t)c, (int8_t)s};
+    return true;
+}
+
 std::string DecimalString(const Decimal &d) {
     char digs[32];
     int n = snprintf(digs, sizeof digs, "%llu", (unsigned long long)d.coef);

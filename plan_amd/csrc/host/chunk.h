@@ -119,6 +119,8 @@ Decimal DecimalFromUnscaled(int64_t unscaled, int scale);
 bool DecimalFromInt128(__int128 v, int scale, Decimal *out);
 // sum.Quo(count): 19 significant digits, half-even, trailing zeros trimmed (AvgOp.Finalize)
 bool DecimalQuoCount(__int128 sum, int scale, uint64_t count, Decimal *out);
+// a.Quo(b): DECIMAL `/` (binDecimalDivOp); false on division by zero / a quotient beyond 19 digits
+bool DecimalQuo(const Decimal &a, const Decimal &b, Decimal *out);
 std::string DecimalString(const Decimal &d);
 // Float64(): the nearest double of the decimal's text (what tryCastDecimalToFloat32 / ToFloat64 start from)
 double DecimalToDouble(const Decimal &d);

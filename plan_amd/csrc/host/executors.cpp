@@ -1046,6 +1046,12 @@ std::string gpuProjectExecutor::Types(const std::vector<ProjExpr> &exprs, const 
                 if (o.op == FloatOp::Col && (o.col < 0 || o.col >= (int)childTypes.size())) return "float expression column out of range";
             out->push_back(FloatType());
             break;
+        case ProjExpr::DecimalQuo:
+            if (e.col < 0 || e.col >= (int)childTypes.size() || e.col2 < 0 || e.col2 >= (int)childTypes.size() ||
+                childTypes[(size_t)e.col].GetInternalType() != PT_DECIMAL || childTypes[(size_t)e.col2].GetInternalType() != PT_DECIMAL)
+                return "decimal division needs two DECIMAL columns";
+            out->push_back(childTypes[(size_t)e.col]);
+            break;
         }
     }
     return "";
@@ -1138,6 +1144,19 @@ std::string gpuProjectExecutor::Evaluate(ph_ctx *ctx, const std::vector<ProjExpr
             Vector &v = *oc->Data[i];
             if (ex.kind == ProjExpr::ColRef) { oc->Data[i] = c->Data[(size_t)ex.col]; continue; }   // Reference: no copy
             if (ex.kind == ProjExpr::Case) return "CASE expressions run inside resident plans only";
+            if (ex.kind == ProjExpr::DecimalQuo) {
+                Vector::Unified ua, ub;
+                c->Data[(size_t)ex.col]->ToUnifiedFormat(card, &ua);
+                c->Data[(size_t)ex.col2]->ToUnifiedFormat(card, &ub);
+                for (int r = 0; r < card; r++) {
+                    const int64_t ia = ua.sel->GetIndex(r), ib = ub.sel->GetIndex(r);
+                    if (!ua.mask->RowIsValid((uint64_t)ia) || !ub.mask->RowIsValid((uint64_t)ib)) { v.Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+                    Decimal q;
+                    if (!DecimalQuo(reinterpret_cast<const Decimal *>(ua.data)[ia], reinterpret_cast<const Decimal *>(ub.data)[ib], &q)) return "decimal division failed (division by zero)";
+                    v.Slice<Decimal>()[r] = q;
+                }
+                continue;
+            }
             if (ex.kind == ProjExpr::Float32) {
                 // FLOAT arithmetic, operand casts as the binder inserts them: DECIMAL -> float64 -> float32
                 // (tryCastDecimalToFloat32), INTEGER -> float32, HUGEINT sums -> float32; every operation rounds to float32
@@ -1308,7 +1327,7 @@ static std::string exprType(const ProjExpr &e, const std::vector<LType> &childTy
     std::vector<LType> one;
     std::string err = gpuProjectExecutor::Types({e}, childTypes, &one);
     if (!err.empty()) return err;
-    if (e.kind == ProjExpr::Substring || e.kind == ProjExpr::Float32) return "substring / FLOAT expressions are not part of a resident plan";
+    if (e.kind == ProjExpr::Substring || e.kind == ProjExpr::Float32 || e.kind == ProjExpr::DecimalQuo) return "substring / FLOAT / DECIMAL-division expressions are not part of a resident plan";
     *t = one[0];
     *src = e.kind == ProjExpr::ColRef ? childSrc[(size_t)e.col] : nullptr;
     return "";

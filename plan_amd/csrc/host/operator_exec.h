@@ -87,8 +87,9 @@ struct AggExpr;
 // copy, like executeColumnRef), a decimal expression (RPN over child columns, evaluated on the
 // device: executeFunc over the binary decimal operators), extract(year ...) or substring
 struct ProjExpr {
-    enum Kind { ColRef, Decimal, ExtractYear, Substring, Case, Float32 } kind = ColRef;
-    int col = -1;                 // ColRef / ExtractYear / Substring: child column
+    enum Kind { ColRef, Decimal, ExtractYear, Substring, Case, Float32, DecimalQuo } kind = ColRef;
+    int col = -1;                 // ColRef / ExtractYear / Substring: child column; DecimalQuo: the dividend
+    int col2 = -1;                // DecimalQuo: the divisor
     std::vector<ph_rpn> prog;     // Decimal: RPN over child columns; Case: the THEN branch
     int64_t offset = 1, length = 0;   // Substring(col FROM offset FOR length)
     // Case (resident plans only): CASE WHEN when THEN prog ELSE elseProg END (executeCase, expr_exec.go:144-246)
@@ -100,6 +101,9 @@ struct ProjExpr {
         ProjExpr e; e.kind = Case; e.when = std::make_shared<BoolExpr>(std::move(w)); e.prog = std::move(thenProg); e.elseProg = std::move(elseProg); e.resultInt = resultInt; return e;
     }
     static ProjExpr Float(std::vector<FloatOp> p) { ProjExpr e; e.kind = Float32; e.fprog = std::move(p); return e; }
+    // DECIMAL `/` over two DECIMAL columns, typed as the dividend (BindDecimalDivide, function_scalar.go:507-514); evaluated on the
+    // host: in the queries that have it (Q8's market share) it runs over the aggregate's few result rows
+    static ProjExpr DecQuo(int a, int b) { ProjExpr e; e.kind = DecimalQuo; e.col = a; e.col2 = b; return e; }
     static ProjExpr Col(int c) { ProjExpr e; e.kind = ColRef; e.col = c; return e; }
     static ProjExpr Dec(std::vector<ph_rpn> p) { ProjExpr e; e.kind = Decimal; e.prog = std::move(p); return e; }
     static ProjExpr Year(int c) { ProjExpr e; e.kind = ExtractYear; e.col = c; return e; }

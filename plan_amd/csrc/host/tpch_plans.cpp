@@ -275,6 +275,58 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 2;
         break;
     }
+    case 7: {
+        // Order <- Agg(n1.n_name, n2.n_name, year(l_shipdate); sum(volume)) <- Project <- Filter((n1 = A and n2 = B) or (n1 = B and n2 = A))
+        //   <- Join(o_custkey = c_custkey) <- Join(l_orderkey = o_orderkey) <- Join(l_suppkey = s_suppkey) probe Scan(lineitem, l_shipdate between);
+        // the supplier and the customer side each arrive joined with their nation scan, which carries n_name IN (A, B) — implied by the
+        // pair condition (the planner's derivation)
+        const char *A = "FRANCE", *B = "ARGENTINA";
+        int n1 = p.Scan(&db.nation, {N_NATIONKEY, N_NAME}, {}, BoolExpr::In(N_NAME, {LStr(A), LStr(B)}));
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY});
+        int js = p.Join(supp, n1, {1}, {0}, {0, 3});                       // s_suppkey, n1.n_name
+        int n2 = p.Scan(&db.nation, {N_NATIONKEY, N_NAME}, {}, BoolExpr::In(N_NAME, {LStr(A), LStr(B)}));
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_NATIONKEY});
+        int jc = p.Join(cust, n2, {1}, {0}, {0, 3});                       // c_custkey, n2.n_name
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY, L_SHIPDATE, L_EXTENDEDPRICE, L_DISCOUNT},
+                          {{L_SHIPDATE, PH_GE, LDate(1995, 1, 1)}, {L_SHIPDATE, PH_LE, LDate(1996, 12, 31)}});
+        int j1 = p.Join(line, js, {1}, {0}, {0, 2, 3, 4, 6});              // l_orderkey, l_shipdate, ext, disc, n1
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY});
+        int j2 = p.Join(j1, ord, {0}, {0}, {1, 2, 3, 4, 6});               // l_shipdate, ext, disc, n1, o_custkey
+        int j3 = p.Join(j2, jc, {4}, {0}, {0, 1, 2, 3, 6});                // l_shipdate, ext, disc, n1, n2
+        int f = p.Filter(j3, {}, BoolExpr::OrOf({BoolExpr::AndOf({BoolExpr::C(3, PH_EQ, LStr(A)), BoolExpr::C(4, PH_EQ, LStr(B))}),
+                                                 BoolExpr::AndOf({BoolExpr::C(3, PH_EQ, LStr(B)), BoolExpr::C(4, PH_EQ, LStr(A))})}));
+        int proj = p.Project(f, {ProjExpr::Col(3), ProjExpr::Col(4), ProjExpr::Year(0), ProjExpr::Dec(DiscPrice(1, 2))});
+        p.Agg(proj, {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(2)}, {{PH_A_SUM, {XC(3)}}});
+        q->order = {{0, false}, {1, false}, {2, false}};
+        q->ncols = 4;
+        break;
+    }
+    case 8: {
+        // Order <- Agg(year(o_orderdate); sum(case when n2.n_name = 'ARGENTINA' then volume else 0 end), sum(volume)) over eight tables:
+        // part[p_type] x lineitem x orders[date range] x customer x nation n1 x region[r_name] and supplier x nation n2;
+        // select list: o_year, the quotient of the two sums (DECIMAL `/`, typed as the dividend)
+        int reg = p.Scan(&db.region, {R_REGIONKEY}, {{R_NAME, PH_EQ, LStr("AMERICA")}});
+        int n1 = p.Scan(&db.nation, {N_NATIONKEY, N_REGIONKEY});
+        int jn = p.Join(n1, reg, {1}, {0}, {0});                           // n_nationkey (of the region)
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_NATIONKEY});
+        int jc = p.Join(cust, jn, {1}, {0}, {0});                          // c_custkey
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}, {{O_ORDERDATE, PH_GE, LDate(1995, 1, 1)}, {O_ORDERDATE, PH_LE, LDate(1996, 12, 31)}});
+        int jo = p.Join(ord, jc, {1}, {0}, {0, 2});                        // o_orderkey, o_orderdate
+        int part = p.Scan(&db.part, {P_PARTKEY}, {{P_TYPE, PH_EQ, LStr("ECONOMY BURNISHED TIN")}});
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_EXTENDEDPRICE, L_DISCOUNT});
+        int j1 = p.Join(line, part, {1}, {0}, {0, 2, 3, 4});               // l_orderkey, l_suppkey, ext, disc
+        int j2 = p.Join(j1, jo, {0}, {0}, {1, 2, 3, 5});                   // l_suppkey, ext, disc, o_orderdate
+        int n2 = p.Scan(&db.nation, {N_NATIONKEY, N_NAME});
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY});
+        int js = p.Join(supp, n2, {1}, {0}, {0, 3});                       // s_suppkey, n2.n_name
+        int j3 = p.Join(j2, js, {0}, {0}, {1, 2, 3, 5});                   // ext, disc, o_orderdate, n2.n_name
+        ProjExpr mine = ProjExpr::CaseOf(BoolExpr::C(3, PH_EQ, LStr("ARGENTINA")), DiscPrice(0, 1), {XK(0)});
+        p.Agg(j3, {ProjExpr::Year(2)}, {AggExpr::Of(PH_A_SUM, mine), {PH_A_SUM, DiscPrice(0, 1)}});
+        q->outputs = {ProjExpr::Col(0), ProjExpr::DecQuo(1, 2)};
+        q->order = {{0, false}};
+        q->ncols = 2;
+        break;
+    }
     case 12: {
         // Order <- Agg(l_shipmode; sum(case when prio = '1-URGENT' or prio = '2-HIGH' then 1 else 0 end), sum(case when prio <> .. and prio <> ..))
         //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, shipmode IN ('FOB','TRUCK'), commit < receipt, ship < commit, receipt range)

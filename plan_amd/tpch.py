@@ -223,6 +223,65 @@ def q5_plan(db, region="AMERICA", d1=None, d2=None):
     return p.create()
 
 
+def q7_plan(db, a="FRANCE", b="ARGENTINA", d1=None, d2=None):
+    """cases/tpch/query/q7.sql: lineitem[l_shipdate between] x supplier x orders x customer with the two nation joins, the pair
+       condition (n1 = a and n2 = b) or (n1 = b and n2 = a) as a Filter over both nation names, group by (n1, n2, year(l_shipdate)).
+       The planner's part here: each nation scan carries n_name IN (a, b), which the pair condition implies, so the supplier and the
+       customer side are reduced before they meet lineitem."""
+    d1 = tpchgen.days(1995, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1996, 12, 31) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    nn = db.c("nation", "n_name")[0]
+    two = lambda: hip.bool_tree(("in", nn, [_s(a), _s(b)]))
+    n1 = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name"), bools=two())
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey"))
+    js = p.join(supp, n1, [1], [0], [0, 3])                                # s_suppkey, n1.n_name
+    n2 = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name"), bools=two())
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_nationkey"))
+    jc = p.join(cust, n2, [1], [0], [0, 3])                                # c_custkey, n2.n_name
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey", "l_shipdate", "l_extendedprice", "l_discount"),
+                  [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LE, _k(hip.PH_DATE, i=d2))])
+    j1 = p.join(line, js, [1], [0], [0, 2, 3, 4, 6])                       # l_orderkey, l_shipdate, ext, disc, n1
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_custkey"))
+    j2 = p.join(j1, orders, [0], [0], [1, 2, 3, 4, 6])                     # l_shipdate, ext, disc, n1, o_custkey
+    j3 = p.join(j2, jc, [4], [0], [0, 1, 2, 3, 6])                         # l_shipdate, ext, disc, n1, n2
+    pair = hip.bool_tree(("or", ("and", ("cmp", 3, hip.PH_EQ, _s(a)), ("cmp", 4, hip.PH_EQ, _s(b))),
+                                ("and", ("cmp", 3, hip.PH_EQ, _s(b)), ("cmp", 4, hip.PH_EQ, _s(a)))))
+    f = p.filter(j3, bools=pair)
+    proj = p.project(f, [hip.pe_col(3), hip.pe_col(4), hip.pe_year(0), hip.pe_dec([hip.X_COL(1), hip.X_CONST(1), hip.X_COL(2), hip.X_SUB, hip.X_MUL])])
+    p.agg(proj, [hip.pe_col(0), hip.pe_col(1), hip.pe_col(2)], [(hip.PH_A_SUM, hip.pe_col(3))])
+    return p.create()
+
+
+def q8_plan(db, nation="ARGENTINA", region="AMERICA", ptype="ECONOMY BURNISHED TIN", d1=None, d2=None):
+    """cases/tpch/query/q8.sql: eight tables — part[p_type] x lineitem x orders[date range] x customer x nation n1 x region[r_name] for the
+       customer side, supplier x nation n2 for the CASE: Agg(year(o_orderdate); sum(case when n2 = nation then volume else 0 end), sum(volume));
+       the select list divides the two sums on the host (DECIMAL `/`)"""
+    d1 = tpchgen.days(1995, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1996, 12, 31) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    reg = p.scan(db.t("region"), db.c("region", "r_regionkey"), [_pred(db, "region", "r_name", hip.PH_EQ, _s(region))])
+    n1 = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_regionkey"))
+    jn = p.join(n1, reg, [1], [0], [0])                                    # n_nationkey (of the region)
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_nationkey"))
+    jc = p.join(cust, jn, [1], [0], [0])                                   # c_custkey
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_custkey", "o_orderdate"),
+                    [_pred(db, "orders", "o_orderdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "orders", "o_orderdate", hip.PH_LE, _k(hip.PH_DATE, i=d2))])
+    jo = p.join(orders, jc, [1], [0], [0, 2])                              # o_orderkey, o_orderdate
+    part = p.scan(db.t("part"), db.c("part", "p_partkey"), [_pred(db, "part", "p_type", hip.PH_EQ, _s(ptype))])
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount"))
+    j1 = p.join(line, part, [1], [0], [0, 2, 3, 4])                        # l_orderkey, l_suppkey, ext, disc
+    j2 = p.join(j1, jo, [0], [0], [1, 2, 3, 5])                            # l_suppkey, ext, disc, o_orderdate
+    n2 = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name"))
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey"))
+    js = p.join(supp, n2, [1], [0], [0, 3])                                # s_suppkey, n2.n_name
+    j3 = p.join(j2, js, [0], [0], [1, 2, 3, 5])                            # ext, disc, o_orderdate, n2.n_name
+    dp = [hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL]
+    mine = hip.pe_case(hip.bool_tree(("cmp", 3, hip.PH_EQ, _s(nation))), dp, [hip.X_CONST(0)], keep=p._keep)
+    p.agg(j3, [hip.pe_year(2)], [(hip.PH_A_SUM, mine), (hip.PH_A_SUM, hip.pe_dec(dp))])
+    return p.create()
+
+
 def q12_plan(db, modes=("FOB", "TRUCK"), d1=None, d2=None):
     """cases/tpch/query/q12.sql: integer CASE sums over lineitem[shipmode IN, two column-vs-column date comparisons, receipt range]
        joined with orders"""

@@ -490,6 +490,14 @@ class Q12Row(ctypes.Structure):
     _fields_ = [("mode", i32), ("high", OHuge), ("low", OHuge)]
 
 
+class Q7Row(ctypes.Structure):
+    _fields_ = [("supp_nation", i32), ("cust_nation", i32), ("l_year", i32), ("revenue", ODec)]
+
+
+class Q8Row(ctypes.Structure):
+    _fields_ = [("o_year", i32), ("nation_volume", ODec), ("volume", ODec), ("mkt_share", ODec)]
+
+
 def tpch_struct(t):
     """oracle_tpch over the numpy tables of tpch_data.load (+ the fixed nation / region tables); returns (struct, keepalive)"""
     from plan_amd import tpchgen
@@ -550,6 +558,33 @@ def q5_text(t, region, date_ge, date_lt):
     n = lib().oracle_q5(ctypes.byref(T), region.encode(), i32(date_ge), i32(date_lt), rows, i64(32))
     assert n >= 0
     return _text("oracle_q5_text", rows, i64(n), cdict(tpchgen.nation_names()))
+
+
+def q7_rows(t, nation_a, nation_b, date_ge, date_le):
+    T, keep = tpch_struct(t)
+    rows = (Q7Row * 64)()
+    n = lib().oracle_q7(ctypes.byref(T), nation_a.encode(), nation_b.encode(), i32(date_ge), i32(date_le), rows, i64(64))
+    assert n >= 0
+    return rows, n
+
+
+def q7_text(t, nation_a, nation_b, date_ge, date_le):
+    from plan_amd import tpchgen
+    rows, n = q7_rows(t, nation_a, nation_b, date_ge, date_le)
+    return _text("oracle_q7_text", rows, i64(n), cdict(tpchgen.nation_names()))
+
+
+def q8_rows(t, nation, region, ptype, date_ge, date_le):
+    T, keep = tpch_struct(t)
+    rows = (Q8Row * 16)()
+    n = lib().oracle_q8(ctypes.byref(T), nation.encode(), region.encode(), ptype.encode(), i32(date_ge), i32(date_le), rows, i64(16))
+    assert n >= 0
+    return rows, n
+
+
+def q8_text(t, nation, region, ptype, date_ge, date_le):
+    rows, n = q8_rows(t, nation, region, ptype, date_ge, date_le)
+    return _text("oracle_q8_text", rows, i64(n))
 
 
 def q12_text(t, mode1, mode2, date_ge, date_lt):

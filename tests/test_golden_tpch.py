@@ -88,3 +88,15 @@ def test_q18_matches_reference_golden(sf1):
     # an aggregate with HAVING (HUGEINT '>') under a SEMI join, five group keys (c_name a VARCHAR), ORDER BY DECIMAL DESC, DATE LIMIT 100;
     # also pins the generator's o_totalprice (discount applied before tax, truncated to cents each time)
     assert O.q18_text(sf1) == golden("plan_q18.txt")
+
+
+def test_q7_matches_reference_golden(sf1):
+    # six tables, two nation joins, (n1 = 'FRANCE' and n2 = 'ARGENTINA') or (n1 = 'ARGENTINA' and n2 = 'FRANCE'), l_shipdate BETWEEN,
+    # EXTRACT(year) as a group key, ORDER BY two VARCHAR keys and an INTEGER
+    assert O.q7_text(sf1, "FRANCE", "ARGENTINA", tpchgen.days(1995, 1, 1), tpchgen.days(1996, 12, 31)) == golden("plan_q7.txt")
+
+
+def test_q8_matches_reference_golden(sf1):
+    # eight tables; sum(case when nation = 'ARGENTINA' then volume else 0 end) / sum(volume): DECIMAL division (govalues Quo) typed as
+    # its first argument, DECIMAL(38,4), printed at scale 4
+    assert O.q8_text(sf1, "ARGENTINA", "AMERICA", "ECONOMY BURNISHED TIN", tpchgen.days(1995, 1, 1), tpchgen.days(1996, 12, 31)) == golden("plan_q8.txt")

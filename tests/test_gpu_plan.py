@@ -250,6 +250,37 @@ def test_q19_or_of_conjunctions_matches_golden(ctx, db):
     assert f"#\n{tpch.dec_text(r['sum'][0][0], 4)}\n" == golden("plan_q19.txt"), ex
 
 
+def test_q7_two_nation_joins_and_pair_filter_match_golden(ctx, db, sf1):
+    """six tables, the nation table joined twice, an OR of conjunctions over both nation names as a Filter above the joins,
+    EXTRACT(year) as a group key: the four groups equal the oracle's and the text cases/tpch/1g/plan/q7.txt"""
+    p = tpch.q7_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    dic = tpchgen.nation_names()
+    rows, n = O.q7_rows(sf1, "FRANCE", "ARGENTINA", tpchgen.days(1995, 1, 1), tpchgen.days(1996, 12, 31))
+    want = {(rows[i].supp_nation, rows[i].cust_nation, rows[i].l_year): rows[i].revenue.unscaled(4) for i in range(n)}
+    got = {(int(r["keys"][g][0]), int(r["keys"][g][1]), int(r["keys"][g][2])): r["sum"][g][0] for g in range(r["ngroups"])}
+    assert got == want, ex
+    text = "#\t\t\t\n" + "".join(f"{dic[a]}\t{dic[b]}\t{y}\t{tpch.dec_text(v, 4)}\n" for (a, b, y), v in sorted(got.items(), key=lambda kv: (dic[kv[0][0]], dic[kv[0][1]], kv[0][2])))
+    assert text == golden("plan_q7.txt"), ex
+
+
+def test_q8_eight_tables_and_case_sums_match_oracle(ctx, db, sf1):
+    """eight tables; both sums per year equal the oracle's bit for bit (the oracle's quotient of them is what q8.txt pins:
+    tests/test_golden_tpch.py; the host layer's own DECIMAL division: tests/test_host_layer.py)"""
+    p = tpch.q8_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    rows, n = O.q8_rows(sf1, "ARGENTINA", "AMERICA", "ECONOMY BURNISHED TIN", tpchgen.days(1995, 1, 1), tpchgen.days(1996, 12, 31))
+    want = {rows[i].o_year: (rows[i].nation_volume.unscaled(4), rows[i].volume.unscaled(4)) for i in range(n)}
+    got = {int(r["keys"][g][0]): (r["sum"][g][0], r["sum"][g][1]) for g in range(r["ngroups"])}
+    assert got == want and sorted(got) == [1995, 1996], ex
+
+
 def test_q18_subquery_aggregate_varchar_key_matches_golden(ctx, db):
     """an aggregate below a SEMI join (its 1.5 M groups stay on the device, HAVING is a Filter over them), five group keys — c_name a
     VARCHAR interned on the device, two narrow keys packed into one key word: cases/tpch/1g/plan/q18.txt byte for byte"""
