@@ -1163,9 +1163,10 @@ static int gather_through_group(ph_ctx *ctx, int32_t ncols, const ph_col *cols, 
         std::sort(set.begin(), set.end());
         if (std::adjacent_find(set.begin(), set.end()) != set.end()) return PH_EUNSUPPORTED;
         for (int c : set) if (t->cols[(size_t)c].validity) return PH_EUNSUPPORTED;
-        if (++t->sparse_gathers[set] < 2) return PH_EUNSUPPORTED;
+        int &seen = t->sparse_gathers[set];
+        if (seen < 0 || ++seen < 2) return PH_EUNSUPPORTED;
         std::vector<int32_t> s32(set.begin(), set.end());
-        if (ph_table_colocate(t, (int32_t)s32.size(), s32.data()) != PH_OK) return PH_EUNSUPPORTED;
+        if (ph_table_colocate(t, (int32_t)s32.size(), s32.data()) != PH_OK) { seen = -1; return PH_EUNSUPPORTED; }   // (no memory for the copy: not tried again)
         g = find();
         if (!g) return PH_EUNSUPPORTED;
     }
