@@ -121,6 +121,7 @@ typedef struct {
     int32_t *ps_partkey;
     int32_t *ps_suppkey;
     int64_t *ps_supplycost; /* DECIMAL(15,2) unscaled */
+    int32_t *ps_availqty;  /* INTEGER 1..9999 (round 3; appended: older callers that zero-initialise the struct keep working) */
 } tpchgen_partsupp_cols;
 
 /* first/n count PARTS; 4 partsupp rows are produced per part. Returns rows written. */

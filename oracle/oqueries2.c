@@ -716,6 +716,77 @@ int64_t oracle_q8(const oracle_tpch *T, const char *nation, const char *region, 
     return ng;
 }
 
+/* ------------------------------------------------------------------ Q11 (cases/tpch/query/q11.sql)
+ * Agg(ps_partkey; sum(ps_supplycost * ps_availqty)) over partsupp x supplier x nation[n_name], HAVING sum > (the same sum over
+ * all those rows) * 0.0001000000. The literal is FLOAT (bindAConst, builder_binder.go:264-273), so the subquery's select list is
+ * FLOAT arithmetic — the DECIMAL sum cast decimal -> float64 -> float32, multiplied in float32 (as Q14's) — and the HAVING compares
+ * a DECIMAL column with a FLOAT one: both sides as float32 (MaxLType(DECIMAL, FLOAT) = FLOAT; greaterFloatOp). ps_availqty is
+ * INTEGER: cast to DECIMAL(.., 0) for the product (scale 2). Returns the groups that pass, in first-seen order. */
+int64_t oracle_q11(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int64_t *ps_supplycost,
+                   const int32_t *ps_availqty, const char *nation, float fraction, oracle_q11_row *out, int64_t max) {
+    int64_t nsel[25];
+    ocol nn = mkcode(T->n_name, T->nation_dict);
+    oconst kn = kstr(nation);
+    int64_t cn = oracle_select(&nn, OP_EQ, &kn, NULL, 25, nsel);
+    ocol nk = mkcol(OT_INT32, 0, T->n_nationkey);
+    ojoin *jn = oracle_join_build(&nk, 1, nsel, cn);
+    int64_t *s_row = i64buf(T->n_supplier), *s_nat = i64buf(T->n_supplier);
+    ocol sn = mkcol(OT_INT32, 0, T->s_nationkey);
+    int64_t ns = oracle_join_probe_inner(jn, &sn, 1, NULL, T->n_supplier, s_row, s_nat, T->n_supplier);
+    oracle_join_free(jn);
+    ocol sk = mkcol(OT_INT32, 0, T->s_suppkey);
+    ojoin *js = oracle_join_build(&sk, 1, s_row, ns);
+    int64_t *p_row = i64buf(n_ps), *p_sup = i64buf(n_ps);
+    ocol pk = mkcol(OT_INT32, 0, ps_suppkey);
+    int64_t np = oracle_join_probe_inner(js, &pk, 1, NULL, n_ps, p_row, p_sup, n_ps);
+    oracle_join_free(js);
+    static const int32_t one = 1;
+    ocol kproto[1] = {mkcol(OT_INT32, 0, NULL)}, kproto1[1] = {mkcol(OT_CONST32, 0, &one)};
+    ocol aproto[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *t = oracle_agg_create(kproto, 1, aproto, aggs, 1), *tt = oracle_agg_create(kproto1, 1, aproto, aggs, 1);
+    static odec v[VS];
+    int64_t cost[VS];
+    int32_t qty[VS], part[VS];
+    const orpn prod[3] = {{OX_COL, 0, 0, 0}, {OX_COL, 1, 0, 0}, {OX_MUL, 0, 0, 0}};
+    int rc = 0;
+    for (int64_t base = 0; base < np && rc == 0; base += VS) {
+        int64_t cnt = np - base < VS ? np - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            const int64_t r = p_row[base + j];
+            cost[j] = ps_supplycost[r];
+            qty[j] = ps_availqty[r];
+            part[j] = ps_partkey[r];
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, cost), mkcol(OT_INT32, 0, qty)};
+        rc = oracle_eval_decimal(cols, prod, 3, NULL, cnt, v);
+        ocol keys[1] = {mkcol(OT_INT32, 0, part)}, keys1[1] = {mkcol(OT_CONST32, 0, &one)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        if (rc == 0) rc = oracle_agg_sink(t, keys, args, NULL, cnt);
+        if (rc == 0) rc = oracle_agg_sink(tt, keys1, args, NULL, cnt);
+    }
+    int64_t nout = rc ? -1 : 0;
+    if (rc == 0 && oracle_agg_count(tt) == 1) {
+        int64_t kv[1];
+        oaggval total;
+        oracle_agg_group(tt, 0, NULL, kv, NULL, &total);
+        volatile float tf = (float)odec_float64(total.d);
+        volatile float threshold = tf * fraction;
+        int64_t ng = oracle_agg_count(t);
+        for (int64_t g = 0; g < ng; g++) {
+            oaggval val;
+            oracle_agg_group(t, g, NULL, kv, NULL, &val);
+            volatile float gv = (float)odec_float64(val.d);
+            if (!(gv > threshold)) continue;
+            if (nout < max) { out[nout].ps_partkey = (int32_t)kv[0]; out[nout].value = val.d; }
+            nout++;
+        }
+    }
+    oracle_agg_free(t); oracle_agg_free(tt);
+    free(s_row); free(s_nat); free(p_row); free(p_sup);
+    return nout;
+}
+
 typedef struct { char *buf; int64_t cap, len; } sbuf2;
 static void put(sbuf2 *s, const char *t) {
     int64_t n = (int64_t)strlen(t);
@@ -875,5 +946,22 @@ int64_t oracle_q8_text(oracle_q8_row *rows, int64_t n, char *buf, int64_t cap) {
         oracle_format_decimal(r->mkt_share, 4, t); put(&s, t); put(&s, "\n");   /* the quotient's column type is its first argument's: DECIMAL(38,4) */
     }
     free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    int64_t *un = i64buf(n), *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) { __int128 u = 0; odec_to_unscaled(rows[i].value, 2, &u); un[i] = (int64_t)u; }
+    ocol k = mkcol(OT_DECIMAL, 2, un);
+    int32_t desc = 1;
+    oracle_sort_rows(&k, &desc, 1, NULL, n, ord, NULL, NULL);      /* ORDER BY value DESC */
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        sprintf(t, "%d", rows[ord[i]].ps_partkey); put(&s, t); put(&s, "\t");
+        oracle_format_decimal(rows[ord[i]].value, 2, t); put(&s, t); put(&s, "\n");
+    }
+    free(un); free(ord);
     return done(&s);
 }

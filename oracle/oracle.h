@@ -358,6 +358,11 @@ int64_t oracle_q8(const oracle_tpch *T, const char *nation, const char *region, 
                   oracle_q8_row *out, int64_t max);
 int64_t oracle_q7_text(oracle_q7_row *rows, int64_t n, const char *const *nation_names, char *buf, int64_t cap);   /* ORDER BY the three keys */
 int64_t oracle_q8_text(oracle_q8_row *rows, int64_t n, char *buf, int64_t cap);                                     /* ORDER BY o_year */
+/* Q11 (cases/tpch/query/q11.sql): HAVING against an uncorrelated scalar subquery whose select list is FLOAT arithmetic */
+typedef struct { int32_t ps_partkey; odec value; } oracle_q11_row;
+int64_t oracle_q11(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int64_t *ps_supplycost,
+                   const int32_t *ps_availqty, const char *nation, float fraction, oracle_q11_row *out, int64_t max);
+int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap);   /* ORDER BY value DESC */
 int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY o_orderpriority */
 int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY revenue DESC */
 int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);  /* ORDER BY l_shipmode */

@@ -25,6 +25,7 @@
  * the reference's own SF1 goldens for Q1, Q3, Q6 and Q9 are reproduced to the last digit. */
 #define SD_P_NAME 709314158LL       /* 92 draws per part row */
 #define SD_PS_SCST 1051288424LL     /* 4 per part */
+#define SD_PS_QTY 1671059989LL      /* 4 per part: ps_availqty = random(1, 9999); pinned by the public first rows of partsupp.tbl (tests/test_tpchgen.py) and by q11.txt */
 #define SD_S_NTRG 110356601LL       /* 1 per supplier */
 #define SD_C_NTRG 1489529863LL      /* 1 per customer */
 #define SD_C_MSEG 1140279430LL      /* 1 per customer */
@@ -444,14 +445,17 @@ int64_t tpchgen_part(int64_t num, int64_t den, int64_t first, int64_t n,
 
 int64_t tpchgen_partsupp(int64_t num, int64_t den, int64_t first, int64_t n,
                          const tpchgen_partsupp_cols *out) {
-    stream_t scst;
+    stream_t scst, sqty;
     stream_init(&scst, SD_PS_SCST, SUPP_PER_PART, first);
+    stream_init(&sqty, SD_PS_QTY, SUPP_PER_PART, first);
     int64_t supplier_count = tpchgen_supplier_count(num, den);
     int64_t row = 0;
     for (int64_t i = 0; i < n; i++) {
         int64_t pkey = first + i + 1;
         for (int j = 0; j < SUPP_PER_PART; j++) {
+            int64_t qty = stream_int(&sqty, 1, 9999);
             int64_t cost = stream_int(&scst, 100, 100000);
+            if (out->ps_availqty) out->ps_availqty[row] = (int32_t)qty;
             if (out->ps_partkey) out->ps_partkey[row] = (int32_t)pkey;
             if (out->ps_suppkey)
                 out->ps_suppkey[row] = (int32_t)part_supplier(pkey, j, supplier_count);
@@ -459,6 +463,7 @@ int64_t tpchgen_partsupp(int64_t num, int64_t den, int64_t first, int64_t n,
             row++;
         }
         stream_row_done(&scst);
+        stream_row_done(&sqty);
     }
     return row;
 }

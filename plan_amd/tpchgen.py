@@ -97,7 +97,7 @@ _ORDERS = [("o_orderkey", np.int64), ("o_custkey", np.int32), ("o_orderdate", np
 _CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8)]
 _PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8), ("p_brand", np.uint8), ("p_type", np.uint8), ("p_size", np.int32),
          ("p_container", np.uint8)]
-_PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64)]
+_PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64), ("ps_availqty", np.int32)]
 _SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32)]
 
 

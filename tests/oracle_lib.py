@@ -587,6 +587,28 @@ def q8_text(t, nation, region, ptype, date_ge, date_le):
     return _text("oracle_q8_text", rows, i64(n))
 
 
+class Q11Row(ctypes.Structure):
+    _fields_ = [("ps_partkey", i32), ("value", ODec)]
+
+
+def q11_rows(t, nation="JAPAN", fraction=0.0001):
+    T, keep = tpch_struct(t)
+    PS = t["partsupp"]
+    arrs = [np.ascontiguousarray(PS[c]) for c in ("ps_partkey", "ps_suppkey", "ps_supplycost", "ps_availqty")]
+    n_ps = len(arrs[0])
+    rows = (Q11Row * (n_ps // 4 + 1))()
+    lib().oracle_q11.restype = i64
+    n = lib().oracle_q11(ctypes.byref(T), i64(n_ps), *[ctypes.c_void_p(a.ctypes.data) for a in arrs], nation.encode(), ctypes.c_float(fraction),
+                         rows, i64(len(rows)))
+    assert n >= 0
+    return rows, n
+
+
+def q11_text(t, nation="JAPAN", fraction=0.0001):
+    rows, n = q11_rows(t, nation, fraction)
+    return _text("oracle_q11_text", rows, i64(n), cap=1 << 20)
+
+
 def q12_text(t, mode1, mode2, date_ge, date_lt):
     from plan_amd import tpchgen
     T, keep = tpch_struct(t)

@@ -100,3 +100,9 @@ def test_q8_matches_reference_golden(sf1):
     # eight tables; sum(case when nation = 'ARGENTINA' then volume else 0 end) / sum(volume): DECIMAL division (govalues Quo) typed as
     # its first argument, DECIMAL(38,4), printed at scale 4
     assert O.q8_text(sf1, "ARGENTINA", "AMERICA", "ECONOMY BURNISHED TIN", tpchgen.days(1995, 1, 1), tpchgen.days(1996, 12, 31)) == golden("plan_q8.txt")
+
+
+def test_q11_matches_reference_golden(sf1):
+    # HAVING sum(ps_supplycost * ps_availqty) > (select sum(..) * 0.0001000000 ..): the literal is FLOAT, so the threshold and the
+    # comparison are float32; 1225 rows ordered by value DESC. Also pins the generator's ps_availqty stream.
+    assert O.q11_text(sf1) == golden("plan_q11.txt")

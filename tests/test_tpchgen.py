@@ -36,3 +36,13 @@ def test_nation_region_table():
     america = sorted(n for n, r in zip(names, regions) if rn[r] == "AMERICA")
     assert america == ["ARGENTINA", "BRAZIL", "CANADA", "PERU", "UNITED STATES"]     # the five rows of cases/tpch/1g/plan/q5.txt
     assert [regions.count(r) for r in range(5)] == [5, 5, 5, 5, 5]
+
+
+def test_partsupp_availqty_first_rows():
+    """the first rows of dbgen's partsupp.tbl at SF1 as publicly known: 1|2|3325|771.64|, 1|2502|8076|993.49|, 1|5002|3956|337.09|,
+    1|7502|4069|357.84|, 2|3|8895|378.49|, 2|2503|4969|915.27|, 2|5003|8539|438.37|, 2|7503|3025|306.39|, 3|4|4651|920.92|"""
+    ps = g.partsupp(SF1, 0, 3)
+    assert ps["ps_partkey"][:9].tolist() == [1, 1, 1, 1, 2, 2, 2, 2, 3]
+    assert ps["ps_suppkey"][:9].tolist() == [2, 2502, 5002, 7502, 3, 2503, 5003, 7503, 4]
+    assert ps["ps_availqty"][:9].tolist() == [3325, 8076, 3956, 4069, 8895, 4969, 8539, 3025, 4651]
+    assert ps["ps_supplycost"][:9].tolist() == [77164, 99349, 33709, 35784, 37849, 91527, 43837, 30639, 92092]
