@@ -135,12 +135,12 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         if (!e.empty()) return e;
     }
     {   // partsupp
-        std::vector<int32_t> pk((size_t)np * 4), sk((size_t)np * 4);
+        std::vector<int32_t> pk((size_t)np * 4), sk((size_t)np * 4), qty((size_t)np * 4);
         std::vector<int64_t> cost((size_t)np * 4);
         tpchgen_partsupp_cols pc{};
-        pc.ps_partkey = pk.data(); pc.ps_suppkey = sk.data(); pc.ps_supplycost = cost.data();
+        pc.ps_partkey = pk.data(); pc.ps_suppkey = sk.data(); pc.ps_supplycost = cost.data(); pc.ps_availqty = qty.data();
         tpchgen_partsupp(num, den, 0, np, &pc);
-        e = loadTable(ctx, {I32(pk.data()), I32(sk.data()), DEC(cost.data())}, np * 4, {PS_PARTKEY, PS_SUPPKEY}, &partsupp, &loaded_bytes);
+        e = loadTable(ctx, {I32(pk.data()), I32(sk.data()), DEC(cost.data()), I32(qty.data())}, np * 4, {PS_PARTKEY, PS_SUPPKEY}, &partsupp, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // supplier
@@ -327,6 +327,30 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 2;
         break;
     }
+    case 11: {
+        // Order <- Agg(ps_partkey; sum(ps_supplycost * ps_availqty)) [HAVING sum > scalar] <- Join(ps_suppkey = s_suppkey) probe Scan(partsupp),
+        //   build <- Join(s_nationkey = n_nationkey) probe Scan(supplier), build Scan(nation, n_name = 'JAPAN'); the scalar subquery is the same
+        //   join under an ungrouped aggregate
+        auto chain = [&](ResidentPlan &pl) {
+            int nat = pl.Scan(&db.nation, {N_NATIONKEY}, {{N_NAME, PH_EQ, LStr("JAPAN")}});
+            int supp = pl.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY});
+            int js = pl.Join(supp, nat, {1}, {0}, {0});                    // s_suppkey
+            int ps = pl.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST, PS_AVAILQTY});
+            return pl.Join(ps, js, {1}, {0}, {0, 2, 3});                   // ps_partkey, ps_supplycost, ps_availqty
+        };
+        const std::vector<ph_rpn> value = {XC(1), XC(2), XO(PH_X_MUL)};
+        p.Agg(chain(p), {ProjExpr::Col(0)}, {{PH_A_SUM, value}});
+        q->scalar = std::make_shared<TpchQuery>();
+        q->scalar->id = 11;
+        q->scalar->plan.Agg(chain(q->scalar->plan), {}, {{PH_A_SUM, value}});
+        q->scalar->ncols = 1;
+        if (!q->scalar->plan.error.empty()) return q->scalar->plan.error;
+        q->scalarFactor = 0.0001f;
+        q->havingCol = 1;
+        q->order = {{1, true}};                                            // ORDER BY value DESC
+        q->ncols = 2;
+        break;
+    }
     case 12: {
         // Order <- Agg(l_shipmode; sum(case when prio = '1-URGENT' or prio = '2-HIGH' then 1 else 0 end), sum(case when prio <> .. and prio <> ..))
         //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, shipmode IN ('FOB','TRUCK'), commit < receipt, ship < commit, receipt range)
@@ -411,8 +435,27 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
 }
 
 std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
+    std::vector<Compare> having = q.having;
+    if (q.scalar) {   // the uncorrelated scalar subquery first: one row, one DECIMAL value
+        gpuResidentPlanExecutor sub(ctx, q.scalar->plan);
+        std::string e = sub.Init();
+        if (!e.empty()) return "Init (scalar subquery): " + e;
+        Chunk out;
+        std::string err;
+        OperatorResult r = sub.Execute(nullptr, &out, &err);
+        if (r == InvalidOpResult) return "Execute (scalar subquery): " + err;
+        if (r == Done || out.Card() != 1 || out.Data[0]->_Typ.GetInternalType() != PT_DECIMAL) { sub.Close(); return "scalar subquery: expected one DECIMAL value"; }
+        Vector::Unified u;
+        out.Data[0]->ToUnifiedFormat(1, &u);
+        const int64_t idx = u.sel->GetIndex(0);
+        if (!u.mask->RowIsValid((uint64_t)idx)) { sub.Close(); lines->clear(); return ""; }   // NULL threshold: the comparison selects nothing
+        volatile float v = (float)DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx]);
+        volatile float t = v * q.scalarFactor;
+        sub.Close();
+        having.push_back(Compare{q.havingCol, PH_GT, LFloat((float)t)});
+    }
     gpuResidentPlanExecutor agg(ctx, q.plan);
-    if (!q.having.empty()) agg.SetHaving(q.having);
+    if (!having.empty()) agg.SetHaving(having);
     if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
     if (q.topkAgg >= 0 && q.limit > 0) agg.SetTopK(q.topkAgg, q.topkDesc, q.limit);
     std::string e = agg.Init();

@@ -20,7 +20,7 @@ enum { L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT
 enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TOTALPRICE };
 enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME };
 enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
-enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST };
+enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST, PS_AVAILQTY };
 enum { S_SUPPKEY, S_NATIONKEY };
 enum { N_NATIONKEY, N_NAME, N_REGIONKEY };
 enum { R_REGIONKEY, R_NAME };
@@ -46,6 +46,13 @@ struct TpchQuery {
     int topkAgg = -1;                     // ORDER BY's first key is aggregate topkAgg (index into the plan's aggregates)
     bool topkDesc = false;
     int ncols = 0;                        // result columns (the headline's tab count)
+    // an UNCORRELATED scalar subquery in HAVING (Q11: sum > (select sum(..) * 0.0001 ..)): the reference plans it as a cross product
+    // with a one-row relation and a Filter above; here its plan runs first and its one value, cast and multiplied as the binder types
+    // the select list (a FLOAT literal: decimal -> float64 -> float32, `*` in float32), becomes the literal of one more HAVING conjunct
+    // `result column havingCol > value` — a DECIMAL column against a FLOAT: compared as float32
+    std::shared_ptr<TpchQuery> scalar;
+    float scalarFactor = 0;
+    int havingCol = -1;
 };
 
 // the operator subtree of cases/tpch/query/q<id>.sql over the resident database

@@ -27,7 +27,7 @@ SCHEMA = {
                  ("c_name", hip.PH_STR, 0, None)],
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
              ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
-    "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None)],
+    "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None), ("ps_availqty", hip.PH_I32, 0, None)],
     "supplier": [("s_suppkey", hip.PH_I32, 0, None), ("s_nationkey", hip.PH_I32, 0, None)],
     "nation": [("n_nationkey", hip.PH_I32, 0, None), ("n_name", hip.PH_CODE8, 0, "nation_names"), ("n_regionkey", hip.PH_I32, 0, None)],
     "region": [("r_regionkey", hip.PH_I32, 0, None), ("r_name", hip.PH_CODE8, 0, "region_names")],
@@ -280,6 +280,33 @@ def q8_plan(db, nation="ARGENTINA", region="AMERICA", ptype="ECONOMY BURNISHED T
     mine = hip.pe_case(hip.bool_tree(("cmp", 3, hip.PH_EQ, _s(nation))), dp, [hip.X_CONST(0)], keep=p._keep)
     p.agg(j3, [hip.pe_year(2)], [(hip.PH_A_SUM, mine), (hip.PH_A_SUM, hip.pe_dec(dp))])
     return p.create()
+
+
+def q11_plans(db, nation="JAPAN"):
+    """cases/tpch/query/q11.sql: (grouped plan, scalar plan) — Agg(ps_partkey; sum(ps_supplycost * ps_availqty)) and the same sum ungrouped over
+       partsupp x supplier x nation[n_name]; HAVING sum > scalar * 0.0001 is applied by the caller in float32 (q11_rows)"""
+    def chain(p):
+        nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey"), [_pred(db, "nation", "n_name", hip.PH_EQ, _s(nation))])
+        supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey"))
+        js = p.join(supp, nat, [1], [0], [0])
+        ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_suppkey", "ps_supplycost", "ps_availqty"))
+        return p.join(ps, js, [1], [0], [0, 2, 3])                         # ps_partkey, ps_supplycost, ps_availqty
+    value = lambda: hip.pe_dec([hip.X_COL(1), hip.X_COL(2), hip.X_MUL])
+    g = hip.Plan(db.ctx)
+    g.agg(chain(g), [hip.pe_col(0)], [(hip.PH_A_SUM, value())])
+    t = hip.Plan(db.ctx)
+    t.agg(chain(t), [], [(hip.PH_A_SUM, value())])
+    return g.create(), t.create()
+
+
+def q11_rows(grouped, total, fraction=0.0001):
+    """the groups whose DECIMAL sum, as float32, exceeds float32(total) * float32(fraction): (ps_partkey, unscaled value at scale 2)"""
+    from decimal import Decimal
+    f32 = lambda unscaled, scale: np.float32(float(Decimal(unscaled).scaleb(-scale)))
+    if total["ngroups"] == 0:
+        return []
+    thr = np.float32(f32(total["sum"][0][0], total["scale"][0]) * np.float32(fraction))
+    return [(int(grouped["keys"][g][0]), grouped["sum"][g][0]) for g in range(grouped["ngroups"]) if f32(grouped["sum"][g][0], grouped["scale"][0]) > thr]
 
 
 def q12_plan(db, modes=("FOB", "TRUCK"), d1=None, d2=None):

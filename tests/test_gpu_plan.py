@@ -281,6 +281,21 @@ def test_q8_eight_tables_and_case_sums_match_oracle(ctx, db, sf1):
     assert got == want and sorted(got) == [1995, 1996], ex
 
 
+def test_q11_having_against_a_scalar_subquery_matches_golden(ctx, db, sf1):
+    """Q11: the grouped and the ungrouped sum(ps_supplycost * ps_availqty) over partsupp x supplier x nation[JAPAN] from two plans; the
+    float32 HAVING threshold applied over the fetched groups gives the oracle's 1225 rows and the golden's text"""
+    g, t = tpch.q11_plans(db)
+    g.run(); t.run()
+    rg, rt = g.fetch(), t.fetch()
+    ex = g.explain()
+    g.free(); t.free()
+    rows = tpch.q11_rows(rg, rt)
+    orows, n = O.q11_rows(sf1)
+    assert sorted(rows) == sorted((orows[i].ps_partkey, orows[i].value.unscaled(2)) for i in range(n)), ex
+    text = "#\t\n" + "".join(f"{k}\t{tpch.dec_text(v, 2)}\n" for k, v in sorted(rows, key=lambda kv: -kv[1]))
+    assert text == golden("plan_q11.txt"), ex
+
+
 def test_q18_subquery_aggregate_varchar_key_matches_golden(ctx, db):
     """an aggregate below a SEMI join (its 1.5 M groups stay on the device, HAVING is a Filter over them), five group keys — c_name a
     VARCHAR interned on the device, two narrow keys packed into one key word: cases/tpch/1g/plan/q18.txt byte for byte"""
