@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void bulk_count_kernel(BulkParams B) {
         bulk_keys_batch<NK, PLAINK>(B.S, base, i1, ii, rr, k, nm);
 #pragma unroll
         for (int u = 0; u < BU; u++)
-            if (ii[u] < i1) atomicAdd(&hist[(keys_hash(k[u], nm[u], NK) >> 40) & (B.nparts - 1)], 1);
+            if (ii[u] < i1) atomicAdd(&hist[(keys_hash(k[u], nm[u], NK) >> B.shift) & (B.nparts - 1)], 1);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < B.nparts; e += 256) B.counts[(int64_t)e * gridDim.x + blockIdx.x] = hist[e];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bulk_scatter_kernel(BulkParams B) {
         for (int u = 0; u < BU; u++) {
             if (ii[u] >= i1) continue;
             const int64_t i = ii[u], r = rr[u];
-            const int pos = atomicAdd(&cursor[(keys_hash(k[u], nm[u], NK) >> 40) & (B.nparts - 1)], 1);
+            const int pos = atomicAdd(&cursor[(keys_hash(k[u], nm[u], NK) >> B.shift) & (B.nparts - 1)], 1);
             unsigned long long *rec = B.rec + (int64_t)pos * B.rec_words;
             const unsigned long long rowid = (unsigned long long)(B.S.row_base + (B.S.sel ? r : i));
             const unsigned long long tail = (unsigned long long)nm[u] | ((unsigned long long)vb[u] << 8);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(TPB) void bulk2_scatter_kernel(Bulk2Params Q) {
             unsigned long long kk[AGG_MAX_KEYS] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < NK; c++) kk[c] = k[u][c];
-            part[u] = (int)((keys_hash(kk, nm[u], NK) >> 40) & (uint64_t)(P - 1));
+            part[u] = (int)((keys_hash(kk, nm[u], NK) >> B.shift) & (uint64_t)(P - 1));
             rank[u] = live[u] ? atomicAdd(&hist[part[u]], 1) : 0;
         }
         __syncthreads();
@@ -707,6 +707,149 @@ __global__ __launch_bounds__(TPB) void bulk2_scatter_kernel(Bulk2Params Q) {
         for (int e = threadIdx.x; e < P; e += TPB) { cursor[e] += hist[e]; hist[e] = 0; }
         __syncthreads();
     }
+}
+
+// ---- second partition level (more groups than 512 partitions of LDS tables hold: up to 8192 bins). The first level's records,
+// already ordered by their top partition bits, are partitioned again by ALL bin bits: a chunk of consecutive records lies in one
+// or two first-level partitions, so it touches ~bins / parts1 bins and leaves in runs again. Two words of LDS per bin (`hist`
+// holds the chunk's counts, then — scanned in place — its offsets; `cursor` the bin's next output position) + the staged chunk.
+constexpr int B2R_T = 1024, B2R_U = 2, B2R_CH = B2R_T * B2R_U;
+
+template <int NK>
+__global__ __launch_bounds__(B2R_T) void bulk2_count_rec_kernel(Bulk2Params Q, Bulk2Rec In, int64_t n) {
+    extern __shared__ int b2_hist[];
+    const BulkParams &B = Q.B;
+    for (int e = threadIdx.x; e < B.nparts; e += B2R_T) b2_hist[e] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < n ? i0 + B.rows_per_wg : n;
+    constexpr int CU4 = 4;   // records of a thread in flight
+    for (int64_t base = i0; base < i1; base += B2R_T * CU4) {
+        unsigned long long k[CU4][AGG_MAX_KEYS];
+        unsigned nm[CU4];
+        bool live[CU4];
+#pragma unroll
+        for (int u = 0; u < CU4; u++) {
+            const int64_t i = base + u * B2R_T + threadIdx.x;
+            live[u] = i < i1;
+            const int64_t ic = live[u] ? i : i1 - 1;
+#pragma unroll
+            for (int c = 0; c < AGG_MAX_KEYS; c++) k[u][c] = c < NK ? In.w64[ic * Q.W + c] : 0ull;
+            nm[u] = In.flags ? In.flags[ic] & 0xFF : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < CU4; u++)
+            if (live[u]) atomicAdd(&b2_hist[(int)((keys_hash(k[u], nm[u], NK) >> B.shift) & (uint64_t)(B.nparts - 1))], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B.nparts; e += B2R_T) B.counts[(int64_t)e * gridDim.x + blockIdx.x] = b2_hist[e];
+}
+
+template <int NK>
+__global__ __launch_bounds__(B2R_T) void bulk2_scatter_rec_kernel(Bulk2Params Q, Bulk2Rec In, int64_t n, int sub_bins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
+    const BulkParams &B = Q.B;
+    const int P = B.nparts, W = Q.W;
+    int *hist = reinterpret_cast<int *>(b2_lds);
+    int *cursor = hist + P;
+    unsigned long long *s_w = reinterpret_cast<unsigned long long *>(cursor + P);   // (P is even)
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_w + (size_t)W * B2R_CH);
+    int *s_dst = reinterpret_cast<int *>(s_row + B2R_CH);
+    uint32_t *s_flags = reinterpret_cast<uint32_t *>(s_dst + B2R_CH);
+    __shared__ int s_wsum[B2R_T / 64], s_lo, s_hi;
+    for (int e = threadIdx.x; e < P; e += B2R_T) { hist[e] = 0; cursor[e] = B.counts[(int64_t)e * gridDim.x + blockIdx.x]; }
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * B.rows_per_wg, i1 = i0 + B.rows_per_wg < n ? i0 + B.rows_per_wg : n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int MAXPER = 8;                // bins per thread of the scan: up to 8192 bins
+    for (int64_t base = i0; base < i1; base += B2R_CH) {
+        unsigned long long k[B2R_U][AGG_MAX_KEYS + BK_MAX_ARGS];
+        uint32_t row[B2R_U], fl[B2R_U];
+        int bin[B2R_U], rank[B2R_U];
+        bool live[B2R_U];
+#pragma unroll
+        for (int u = 0; u < B2R_U; u++) {
+            const int64_t i = base + u * B2R_T + threadIdx.x;
+            live[u] = i < i1;
+            const int64_t ic = live[u] ? i : i1 - 1;
+#pragma unroll
+            for (int c = 0; c < AGG_MAX_KEYS + BK_MAX_ARGS; c++) k[u][c] = c < W ? In.w64[ic * W + c] : 0ull;
+            row[u] = In.rowid[ic];
+            fl[u] = In.flags ? In.flags[ic] : 0xF00u;
+        }
+#pragma unroll
+        for (int u = 0; u < B2R_U; u++) {
+            unsigned long long kk[AGG_MAX_KEYS] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NK; c++) kk[c] = k[u][c];
+            bin[u] = (int)((keys_hash(kk, fl[u] & 0xFF, NK) >> B.shift) & (uint64_t)(P - 1));
+            rank[u] = live[u] ? atomicAdd(&hist[bin[u]], 1) : 0;
+        }
+        // the input is ordered by the first level's partition: the chunk's bins lie between those of its first and its last record
+        if (threadIdx.x == 0) s_lo = bin[0] & ~(sub_bins - 1);
+        {
+            const int64_t last = (i1 - base < B2R_CH ? i1 - base : B2R_CH) - 1;
+#pragma unroll
+            for (int u = 0; u < B2R_U; u++)
+                if ((int64_t)u * B2R_T + threadIdx.x == last) s_hi = bin[u] | (sub_bins - 1);
+        }
+        __syncthreads();
+        const int lo = s_lo, hi = s_hi, span = hi - lo + 1;   // (a chunk over several first-level partitions: a longer span, still right)
+        const int per = (span + B2R_T - 1) / B2R_T;
+        int cnt[MAXPER];
+        {
+            int sum = 0;
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) { const int e = lo + threadIdx.x * per + q; cnt[q] = (q < per && e <= hi) ? hist[e] : 0; sum += cnt[q]; }
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wv; w++) run += s_wsum[w];
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) { const int e = lo + threadIdx.x * per + q; if (q < per && e <= hi) { hist[e] = run; run += cnt[q]; } }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < B2R_U; u++) {
+            if (!live[u]) continue;
+            const int j = hist[bin[u]] + rank[u];
+#pragma unroll
+            for (int c = 0; c < AGG_MAX_KEYS + BK_MAX_ARGS; c++) if (c < W) s_w[(size_t)j * W + c] = k[u][c];
+            s_row[j] = row[u];
+            s_dst[j] = cursor[bin[u]] + rank[u];
+            if (Q.flags) s_flags[j] = fl[u];
+        }
+        __syncthreads();
+        const int m = (int)(i1 - base < B2R_CH ? i1 - base : B2R_CH);
+        for (int j = threadIdx.x; j < m; j += B2R_T) {
+            const int64_t d = s_dst[j];
+            if (W == 2) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                reinterpret_cast<u64x2 *>(Q.w64)[d] = reinterpret_cast<const u64x2 *>(s_w)[j];
+            } else {
+                for (int c = 0; c < W; c++) Q.w64[d * W + c] = s_w[(size_t)j * W + c];
+            }
+            Q.rowid[d] = s_row[j];
+            if (Q.flags) Q.flags[d] = s_flags[j];
+        }
+#pragma unroll
+        for (int q = 0; q < MAXPER; q++) { const int e = lo + threadIdx.x * per + q; if (q < per && e <= hi) { cursor[e] += cnt[q]; hist[e] = 0; } }
+        __syncthreads();
+    }
+}
+
+// one workgroup per bin: the partial body with its groups written straight into the table (no slices, no merge)
+// Two workgroups per CU: each runs three short, latency-bound phases (read, build, write out) with barriers between them, so
+// 64 VGPRs a lane (8 waves per SIMD) let the second one fill the first one's waits (4 M groups of 32 M rows: 793 -> 725 us).
+// With 8 waves per SIMD the lock wait of the insert path needs its s_sleep: without it older spinning waves starve the
+// holder of the issue slot (measured: the same kernel took 50 ms).
+template <int NK, bool PLAIN>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void bulk2_build_direct_kernel(Bulk2Params Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
+    __shared__ int s_nent, s_wsum[16], s_void;
+    if (__hip_atomic_load(Q.B.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) return;
+    bulk2_partial_body<NK, PLAIN, true>(Q, bk_lds, s_nent, s_wsum, s_void);
 }
 
 // the LDS table of the build workgroups: [first T x i64][key NK*T x u64][lo T*na x u64][hi T*na x i64][state T x i32][cnt T*na x u32]
@@ -1057,10 +1200,9 @@ int bulk2_spec_kernel(ph_ctx *ctx, const ph::AggSinkParams &P, bool plain, int s
 // Second form of the bulk build (see bulk2_scatter_kernel): PH_EUNSUPPORTED = not this shape, or the attempt was void
 // (nothing sunk, table and counters clean) — the caller runs the first form.
 template <int NK>
-int bulk2_launch(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_build, size_t lds_scatter, int bu, int tpb, bool plain, int64_t nc,
-                 int64_t *total_dev, bool merge_only) {
+int bulk2_launch_scatter(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_scatter, int bu, int tpb, bool plain, int64_t nc, int64_t *total_dev) {
     hipStream_t st = a->ctx->stream;
-    if (!merge_only) {
+    {
         if (plain) ph::bulk_count_kernel<NK, true><<<nwg, 256, (size_t)Q.B.nparts * 4, st>>>(Q.B);
         else ph::bulk_count_kernel<NK, false><<<nwg, 256, (size_t)Q.B.nparts * 4, st>>>(Q.B);
         PH_CHECK(ph::exclusive_scan_i32(a->ctx, Q.B.counts, nc, total_dev));
@@ -1082,6 +1224,17 @@ int bulk2_launch(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_build, size_
             else { if (bu == 8) PH_B2S(false, 8, 256); else if (bu == 4) PH_B2S(false, 4, 256); else PH_B2S(false, 2, 256); }
         }
 #undef PH_B2S
+    }
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+template <int NK>
+int bulk2_launch(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_build, size_t lds_scatter, int bu, int tpb, bool plain, int64_t nc,
+                 int64_t *total_dev, bool merge_only) {
+    hipStream_t st = a->ctx->stream;
+    if (!merge_only) {
+        PH_CHECK(bulk2_launch_scatter<NK>(a, Q, nwg, lds_scatter, bu, tpb, plain, nc, total_dev));
         ph::JitKernel spec{};
         if (bulk2_spec_kernel(a->ctx, Q.B.S, plain, Q.B.lds_entries, lds_build, &spec) == PH_OK) {
             // the body specialised for this shape through hiprtc (the generic one spends ~370 instructions per 64 rows on
@@ -1100,6 +1253,33 @@ int bulk2_launch(ph_agg *a, ph::Bulk2Params &Q, int nwg, size_t lds_build, size_
     }
     PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_merge_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ph::bulk2_merge_kernel<NK><<<Q.B.nparts, 1024, lds_build, st>>>(Q);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+// two partition levels + one build workgroup per bin (more than 512 bins: up to 8192, ~4 M groups)
+template <int NK>
+int bulk2_two_level_launch(ph_agg *a, ph::Bulk2Params &Q1, ph::Bulk2Params &Q2, int nwg1, int nwg2, size_t lds_build, size_t lds_scatter1, int bu, int tpb,
+                           bool plain, int64_t n, int64_t *total1, int64_t *total2, bool build_only) {
+    hipStream_t st = a->ctx->stream;
+    if (!build_only) {
+        // level 1: the ordinary count + staged scatter into 64 partitions by the top bin bits
+        PH_CHECK(bulk2_launch_scatter<NK>(a, Q1, nwg1, lds_scatter1, bu, tpb, plain, (int64_t)Q1.B.nparts * nwg1, total1));
+        // level 2: its records into all bins
+        const ph::Bulk2Rec In{Q1.w64, Q1.rowid, Q1.flags};
+        const size_t lds2 = (size_t)Q2.B.nparts * 8 + (size_t)ph::B2R_CH * (8 * Q2.W + 12);
+        PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_scatter_rec_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        ph::bulk2_count_rec_kernel<NK><<<nwg2, ph::B2R_T, (size_t)Q2.B.nparts * 4, st>>>(Q2, In, n);
+        PH_CHECK(ph::exclusive_scan_i32(a->ctx, Q2.B.counts, (int64_t)Q2.B.nparts * nwg2, total2));
+        ph::bulk2_scatter_rec_kernel<NK><<<nwg2, ph::B2R_T, lds2, st>>>(Q2, In, n, Q2.B.nparts / Q1.B.nparts);
+    }
+    if (plain) {
+        PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_build_direct_kernel<NK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ph::bulk2_build_direct_kernel<NK, true><<<Q2.B.nparts, 1024, lds_build, st>>>(Q2);
+    } else {
+        PH_HIP(hipFuncSetAttribute((const void *)ph::bulk2_build_direct_kernel<NK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ph::bulk2_build_direct_kernel<NK, false><<<Q2.B.nparts, 1024, lds_build, st>>>(Q2);
+    }
     PH_HIP(hipGetLastError());
     return PH_OK;
 }
@@ -1131,10 +1311,16 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
     const int64_t want_parts = (a->expected_groups + T / 4 - 1) / (T / 4);
     int nparts = 16;
     while (nparts < want_parts) nparts *= 2;
-    if (nparts > 512) return PH_EUNSUPPORTED;   // runs of a row or two per partition and chunk: the first form
+    const bool two_level = nparts > 512;   // more bins than one staged scatter serves in runs: a first level of 64 partitions, then all bins
+    if (nparts > 8192 || getenv("PH_AGG_BULK_ONE_LEVEL") != nullptr) { if (two_level) return PH_EUNSUPPORTED; }
+    const int bins = nparts;
+    int log_bins = 0;
+    while ((1 << log_bins) < bins) log_bins++;
+    if (two_level) nparts = 64;
     B.nparts = nparts;
+    B.shift = two_level ? 40 + (log_bins - 6) : 40;
     int slices = 1;
-    while (nparts * slices < 512 && slices < 64) slices *= 2;   // two workgroups per CU in all: every slice pays a table initialisation and a write-out
+    while (!two_level && nparts * slices < 512 && slices < 64) slices *= 2;   // two workgroups per CU in all: every slice pays a table initialisation and a write-out
     if (const char *se = getenv("PH_AGG_BULK_SLICES")) slices = std::max(1, std::min(atoi(se), 64));
     Q.slices = slices;
     Q.W = nk + B.nused;
@@ -1164,7 +1350,7 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
     Q.pwords = nk + 2 + 3 * na;
     char *tmp = nullptr;
     const int64_t o_w64 = ph::round_up(nc * 4, 16), o_row = o_w64 + (int64_t)Q.W * n * 8, o_flags = o_row + ph::round_up(n * 4, 16),
-                  o_part = o_flags + (plain ? 0 : ph::round_up(n * 4, 16)), o_pn = o_part + (int64_t)nparts * slices * Q.pcap * Q.pwords * 8,
+                  o_part = o_flags + (plain ? 0 : ph::round_up(n * 4, 16)), o_pn = o_part + (two_level ? 0 : (int64_t)nparts * slices * Q.pcap * Q.pwords * 8),
                   o_total = o_pn + ph::round_up((int64_t)nparts * slices * 4, 16);
     PH_CHECK(ctx->pool_alloc(o_total + 16, (void **)&tmp));
     B.counts = (int32_t *)tmp;
@@ -1177,6 +1363,31 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
     B.total = total_dev;
     B.overflow = a->counters + 2;
     const size_t lds_build = (size_t)T * per_entry;
+    // second level: records of the first, partitioned again by all bin bits
+    ph::Bulk2Params Q2{};
+    char *tmp2 = nullptr;
+    int nwg2 = 0;
+    int64_t *total2 = nullptr;
+    if (two_level) {
+        const int64_t rows2 = std::max<int64_t>(ph::B2R_CH, ph::round_up((n + 511) / 512, ph::B2R_CH));
+        nwg2 = (int)((n + rows2 - 1) / rows2);
+        const int64_t nc2 = (int64_t)bins * nwg2;
+        const int64_t p_w64 = ph::round_up(nc2 * 4, 16), p_row = p_w64 + (int64_t)Q.W * n * 8, p_flags = p_row + ph::round_up(n * 4, 16),
+                      p_total = p_flags + (plain ? 0 : ph::round_up(n * 4, 16));
+        if (ctx->pool_alloc(p_total + 16, (void **)&tmp2) != PH_OK) { ctx->pool_release(tmp); ph::set_error("ph_agg_sink: allocation failed"); return PH_EHIP; }
+        Q2 = Q;
+        Q2.B.nparts = bins;
+        Q2.B.shift = 40;
+        Q2.B.rows_per_wg = rows2;
+        Q2.B.counts = (int32_t *)tmp2;
+        Q2.w64 = (unsigned long long *)(tmp2 + p_w64);
+        Q2.rowid = (uint32_t *)(tmp2 + p_row);
+        Q2.flags = plain ? nullptr : (uint32_t *)(tmp2 + p_flags);
+        Q2.slices = 1;
+        Q2.B.lds_entries = T / 2;   // a bin holds T / 4 groups on average: half-full tables, TWO build workgroups per CU (they close at 3/4 = 1.5x the hint)
+        total2 = (int64_t *)(tmp2 + p_total);
+        Q2.B.total = total2;
+    }
     int rc = PH_OK;
     bool settled = false, voided = false;
     for (int attempt = 0; attempt < 6 && rc == PH_OK; attempt++) {
@@ -1188,6 +1399,15 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
             if ((rc = agg_clear(a, new_table, 0, 4, nullptr, 0)) != PH_OK) break;
             a->fresh = false;
         } else if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
+        if (two_level) {
+            Q2.B.S = B.S;   // (the table pointers of this attempt)
+            switch (nk) {
+            case 1: rc = bulk2_two_level_launch<1>(a, Q, Q2, nwg, nwg2, lds_build / 2, lds_scatter, bu, tpb, plain, n, total_dev, total2, attempt > 0); break;
+            case 2: rc = bulk2_two_level_launch<2>(a, Q, Q2, nwg, nwg2, lds_build / 2, lds_scatter, bu, tpb, plain, n, total_dev, total2, attempt > 0); break;
+            case 3: rc = bulk2_two_level_launch<3>(a, Q, Q2, nwg, nwg2, lds_build / 2, lds_scatter, bu, tpb, plain, n, total_dev, total2, attempt > 0); break;
+            default: rc = bulk2_two_level_launch<4>(a, Q, Q2, nwg, nwg2, lds_build / 2, lds_scatter, bu, tpb, plain, n, total_dev, total2, attempt > 0); break;
+            }
+        } else
         switch (nk) {
         case 1: rc = bulk2_launch<1>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
         case 2: rc = bulk2_launch<2>(a, Q, nwg, lds_build, lds_scatter, bu, tpb, plain, nc, total_dev, attempt > 0); break;
@@ -1202,6 +1422,7 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
         rc = agg_resize(a, next_pow2(4 * std::max<int64_t>(c[0], a->gcap)), 0);   // ids ran out: a larger table, the merge again
     }
     ctx->pool_release(tmp);
+    if (tmp2) ctx->pool_release(tmp2);
     if (rc != PH_OK) return rc;
     if (settled) return PH_OK;
     // void: leave an empty table and clean counters behind
@@ -1238,6 +1459,7 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
     if (const char *pe = getenv("PH_AGG_BULK_PARTS")) nparts = std::max(8, std::min(atoi(pe), 4096));
     while (nparts < want_parts && nparts < 4096) nparts *= 2;
     B.nparts = nparts;
+    B.shift = 40;
     B.rows_per_wg = std::max<int64_t>(1024, ph::round_up((n + 511) / 512, 256));
     const int nwg = (int)((n + B.rows_per_wg - 1) / B.rows_per_wg);
     const int64_t nc = (int64_t)nparts * nwg;

@@ -488,6 +488,27 @@ def test_agg_bulk_build_second_form(ctx):
     assert np.array_equal(r["sum_hi"][:, 0], np.where(sums[order] < 0, -1, 0))
     assert np.array_equal(r["count"][:, 1], np.bincount(inv)[order])
     agg.free(); dk.free(); dv.free()
+    # more groups than 512 partitions of LDS tables hold: two partition levels, one build workgroup per bin (1.5 M groups, NULL arguments)
+    n = 5_200_000
+    k = rng.integers(0, 1_500_000, n).astype(np.int64)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    bits = rng.random(n) < 0.9
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1), (hip.PH_A_MAX, 0)], 1_500_000)
+    dk, dv = hip.DevColumn(ctx, hip.PH_I64, k), hip.DevColumn(ctx, hip.PH_I64, v, validity=np.packbits(bits, bitorder="little"))
+    agg.sink([dk], [dv], None, n)
+    r = agg.finalize(python_ints=False)
+    uk, first, inv = np.unique(k, return_index=True, return_inverse=True)
+    order = np.argsort(first)
+    assert r["ngroups"] == len(uk)
+    assert np.array_equal(r["keys"][:, 0], uk[order]) and np.array_equal(r["first_row"], first[order])
+    sums = np.zeros(len(uk), np.int64); np.add.at(sums, inv[bits], v[bits])
+    mx = np.full(len(uk), np.iinfo(np.int64).min); np.maximum.at(mx, inv[bits], v[bits])
+    cnt = np.bincount(inv[bits], minlength=len(uk))
+    assert np.array_equal(r["sum_lo"][:, 0].astype(np.int64), sums[order]) and np.array_equal(r["count"][:, 0], cnt[order])
+    assert np.array_equal(r["count"][:, 1], np.bincount(inv)[order])
+    has = cnt[order] > 0
+    assert np.array_equal(r["sum_lo"][:, 2].astype(np.int64)[has], mx[order][has])
+    agg.free(); dk.free(); dv.free()
     # 128-bit sums: +-2^62 per row, 3000 groups
     n = 4_300_000
     k = rng.integers(0, 3000, n).astype(np.int32)
