@@ -493,6 +493,103 @@ int64_t oracle_q18(const oracle_tpch *T, const int64_t *o_totalprice, int64_t qt
 
 int64_t oracle_q18_text(oracle_q18_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);
 
+/* ------------------------------------------------------------------ Q17 (cases/tpch/query/q17.sql)
+ * Project(sum / 7.0) <- Agg(; sum(l_extendedprice)) <- Filter(l_quantity < 0.2 * avg) <- Join(l_partkey = sub.l_partkey)
+ *   [Join(l_partkey = p_partkey) probe Scan(lineitem), build Scan(part, p_brand = .. and p_container = ..)]
+ *   x [Agg(l_partkey; avg(l_quantity)) <- Scan(lineitem)]   (the correlated subquery, decorrelated into an aggregate by its correlation key)
+ * Typing (l_quantity is INTEGER in this schema): avg(INTEGER) accumulates and divides in float64 (AvgOp, aggregate_hash.go:733-738,
+ * :873-900) -> DOUBLE; 0.2 is a FLOAT literal (bindAConst builder_binder.go:264-273) and `*` has only (T, T) overloads
+ * (function_scalar.go:389-425), so it is cast float32 -> float64 (tryCastFloat32ToFloat64 function_cast.go:411-414) and multiplied in
+ * float64; `<` has a DOUBLE overload (function_scalar.go:1429-1435, lessFloat64Op function_operator_boolean.go:466) and l_quantity is cast
+ * int32 -> float64 (function_cast.go:332-335). sum(DECIMAL) / 7.0: `/` has FLOAT and DECIMAL overloads only (:478-500), the literal is
+ * FLOAT, so the sum is cast decimal -> float64 -> float32 and divided in float32.
+ * Returns 0 ok / 1 when the sum is NULL (no row passes) / -1 on error. */
+int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out) {
+    /* part[brand, container] */
+    int64_t *ps1 = i64buf(T->n_part), *ps2 = i64buf(T->n_part);
+    ocol pb = mkcode(T->p_brand, T->brand_dict), pc = mkcode(T->p_container, T->container_dict);
+    oconst kb = kstr(brand), kc = kstr(container);
+    int64_t np = oracle_select(&pb, OP_EQ, &kb, NULL, T->n_part, ps1);
+    np = oracle_select(&pc, OP_EQ, &kc, ps1, np, ps2);
+    ocol pk = mkcol(OT_INT32, 0, T->p_partkey);
+    ojoin *jp = oracle_join_build(&pk, 1, ps2, np);
+    int64_t cap = T->n_lineitem;
+    int64_t *l_row = i64buf(cap), *p_row = i64buf(cap);
+    ocol lp = mkcol(OT_INT32, 0, T->l_partkey);
+    int64_t nj = oracle_join_probe_inner(jp, &lp, 1, NULL, T->n_lineitem, l_row, p_row, cap);
+    oracle_join_free(jp);
+    /* the subquery: avg(l_quantity) per l_partkey over all of lineitem */
+    ocol kproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    ocol aproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    oaggspec aggs[1] = {{OA_AVG, 0}};
+    oagg *sub = oracle_agg_create(kproto, 1, aproto, aggs, 1);
+    int rc = 0;
+    for (int64_t base = 0; base < T->n_lineitem && rc == 0; base += VS) {
+        int64_t cnt = T->n_lineitem - base < VS ? T->n_lineitem - base : VS;
+        ocol keys[1] = {mkcol(OT_INT32, 0, T->l_partkey + base)};
+        ocol args[1] = {mkcol(OT_INT32, 0, T->l_quantity + base)};
+        rc = oracle_agg_sink(sub, keys, args, NULL, cnt);
+    }
+    int64_t ngs = rc ? 0 : oracle_agg_count(sub);
+    int32_t *gkey = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ngs > 0 ? ngs : 1));
+    double *gavg = (double *)malloc(sizeof(double) * (size_t)(ngs > 0 ? ngs : 1));
+    for (int64_t g = 0; g < ngs; g++) {
+        int64_t kv[1];
+        oaggval v;
+        oracle_agg_group(sub, g, NULL, kv, NULL, &v);
+        gkey[g] = (int32_t)kv[0];
+        gavg[g] = v.kind == OV_DOUBLE ? v.f : 0.0;
+    }
+    oracle_agg_free(sub);
+    /* joined rows x the subquery's groups, then the Filter */
+    ocol gk = mkcol(OT_INT32, 0, gkey);
+    ojoin *jg = oracle_join_build(&gk, 1, NULL, ngs);
+    int32_t *jkey = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nj > 0 ? nj : 1));
+    for (int64_t i = 0; i < nj; i++) jkey[i] = T->l_partkey[l_row[i]];
+    ocol jk = mkcol(OT_INT32, 0, jkey);
+    int64_t *j_row = i64buf(nj), *g_row = i64buf(nj);
+    int64_t n2 = oracle_join_probe_inner(jg, &jk, 1, NULL, nj, j_row, g_row, nj);
+    oracle_join_free(jg);
+    static const int32_t one = 1;
+    ocol k1[1] = {mkcol(OT_CONST32, 0, &one)};
+    ocol a1[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec sum1[1] = {{OA_SUM, 0}};
+    oagg *t = oracle_agg_create(k1, 1, a1, sum1, 1);
+    static odec ext[VS];
+    int64_t fill = 0;
+    const double frac64 = (double)fraction;
+    for (int64_t i = 0; i <= n2 && rc == 0; i++) {
+        if (i < n2) {
+            const int64_t l = l_row[j_row[i]];
+            volatile double thr = frac64 * gavg[g_row[i]];
+            if ((double)T->l_quantity[l] < thr) odec_new(T->l_extendedprice[l], 2, &ext[fill++]);
+        }
+        if (fill == VS || (i == n2 && fill > 0)) {
+            ocol keys[1] = {mkcol(OT_CONST32, 0, &one)};
+            ocol args[1] = {mkcol(OT_ODEC, 0, ext)};
+            rc = oracle_agg_sink(t, keys, args, NULL, fill);
+            fill = 0;
+        }
+    }
+    int32_t res = rc ? -1 : 1;
+    if (rc == 0 && oracle_agg_count(t) == 1) {
+        int64_t kv[1];
+        oaggval v;
+        oracle_agg_group(t, 0, NULL, kv, NULL, &v);
+        if (v.kind == OV_DECIMAL) {
+            *sum_out = v.d;
+            volatile float a = (float)odec_float64(v.d);
+            *avg_yearly = a / divisor;
+            res = 0;
+        }
+    }
+    oracle_agg_free(t);
+    free(ps1); free(ps2); free(l_row); free(p_row); free(gkey); free(gavg); free(jkey); free(j_row); free(g_row);
+    return res;
+}
+
+int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);
+
 /* ------------------------------------------------------------------ text */
 /* extract(year from date): Date.Year (pkg/common/date.go) */
 static int32_t year_of_days2(int32_t z) {
@@ -964,4 +1061,8 @@ int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap)
     }
     free(un); free(ord);
     return done(&s);
+}
+
+int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap) {
+    return oracle_q14_text(avg_yearly, is_null, buf, cap);   /* one FLOAT column: the same rendering */
 }

@@ -363,6 +363,9 @@ typedef struct { int32_t ps_partkey; odec value; } oracle_q11_row;
 int64_t oracle_q11(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int64_t *ps_supplycost,
                    const int32_t *ps_availqty, const char *nation, float fraction, oracle_q11_row *out, int64_t max);
 int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap);   /* ORDER BY value DESC */
+/* Q17 (cases/tpch/query/q17.sql): 0 ok / 1 the sum is NULL / -1 error; avg_yearly = float32(sum) / divisor, the threshold fraction * avg in float64 */
+int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out);
+int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);
 int64_t oracle_q4_text(oracle_q4_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY o_orderpriority */
 int64_t oracle_q5_text(oracle_q5_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);    /* ORDER BY revenue DESC */
 int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict, char *buf, int64_t cap);  /* ORDER BY l_shipmode */

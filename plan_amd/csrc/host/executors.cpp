@@ -317,6 +317,74 @@ OperatorResult gpuFilterExecutor::Execute(Chunk *, Chunk *output, std::string *e
     return haveMoreOutput;
 }
 
+// ------------------------------------------------------------------ filter with a DOUBLE predicate (host)
+
+std::string doubleFilterExecutor::Init() {
+    const size_t nc = child_->OutputTypes().size();
+    for (auto *prog : {&pred_.lhs, &pred_.rhs}) {
+        if (prog->empty()) return "empty DOUBLE expression";
+        for (auto &o : *prog)
+            if (o.op == FloatOp::Col && (o.col < 0 || (size_t)o.col >= nc)) return "DOUBLE expression column out of range";
+    }
+    return "";
+}
+
+// one side of the predicate for row r; false = NULL
+static bool eval_double(const std::vector<FloatOp> &prog, const Chunk &c, int card, int r, double *out, std::string *err) {
+    std::vector<double> st;
+    for (auto &o : prog) {
+        if (o.op == FloatOp::Const) { st.push_back((double)o.k); continue; }            // tryCastFloat32ToFloat64
+        if (o.op == FloatOp::Col) {
+            const Vector &src = *c.Data[(size_t)o.col];
+            Vector::Unified u;
+            src.ToUnifiedFormat(card, &u);
+            const int64_t idx = u.sel->GetIndex(r);
+            if (!u.mask->RowIsValid((uint64_t)idx)) return false;
+            switch (src._Typ.GetInternalType()) {
+            case PT_INT32: st.push_back((double)reinterpret_cast<const int32_t *>(u.data)[idx]); break;   // tryCastInt32ToFloat64
+            case PT_DECIMAL: st.push_back(DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx])); break;
+            case PT_INT128: { const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx]; st.push_back((double)h.Upper * 18446744073709551616.0 + (double)h.Lower); break; }
+            case PT_FLOAT: st.push_back((double)reinterpret_cast<const float *>(u.data)[idx]); break;
+            case PT_DOUBLE: st.push_back(reinterpret_cast<const double *>(u.data)[idx]); break;
+            default: *err = "DOUBLE expression over an unsupported column type"; return false;
+            }
+            continue;
+        }
+        if (st.size() < 2) { *err = "malformed DOUBLE expression"; return false; }
+        volatile double b = st.back(); st.pop_back();
+        volatile double a = st.back(); st.pop_back();
+        volatile double res = o.op == FloatOp::Add ? a + b : o.op == FloatOp::Sub ? a - b : o.op == FloatOp::Mul ? a * b : a / b;
+        st.push_back((double)res);
+    }
+    if (st.size() != 1) { *err = "malformed DOUBLE expression"; return false; }
+    *out = st[0];
+    return true;
+}
+
+OperatorResult doubleFilterExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    for (;;) {
+        auto c = std::make_shared<Chunk>();
+        OperatorResult r = child_->Execute(nullptr, c.get(), err);
+        if (r == InvalidOpResult || r == Done) return r;
+        const int card = c->Card();
+        auto sv = std::make_shared<SelectVector>();
+        sv->identity = false;
+        for (int i = 0; i < card; i++) {
+            double a = 0, b = 0;
+            std::string e;
+            const bool va = eval_double(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_double(pred_.rhs, *c, card, i, &b, &e);
+            if (!e.empty()) { *err = e; return InvalidOpResult; }
+            if (va && vb && a < b) sv->SelVec.push_back(i);                              // lessFloat64Op; a NULL side selects nothing
+        }
+        if (sv->SelVec.empty()) continue;
+        ensureOutputChunk(OutputTypes(), output);
+        std::vector<int> indice;
+        for (int i = 0; i < c->ColumnCount(); i++) indice.push_back(i);
+        output->SliceIndice(*c, sv, (int)sv->SelVec.size(), 0, indice);   // DICT views that share the child's vectors
+        return haveMoreOutput;
+    }
+}
+
 // ------------------------------------------------------------------ aggregate
 
 gpuAggExecutor::gpuAggExecutor(ph_ctx *ctx, std::vector<int> groupCols, std::vector<AggExpr> aggs, OperatorExec *child,
@@ -452,6 +520,7 @@ std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector
                 case PT_INT64: v.Slice<int64_t>()[r] = kv; break;
                 case PT_DATE: v.Slice<Date>()[r] = DateFromDays((int32_t)kv); break;
                 case PT_DECIMAL: v.Slice<Decimal>()[r] = DecimalFromUnscaled(kv, v._Typ.Scale); break;
+                case PT_INT128: v.Slice<Hugeint>()[r] = Hugeint{(uint64_t)kv, kv < 0 ? -1 : 0}; break;   // a SUM / COUNT of an aggregate below, grouped by above
                 case PT_VARCHAR: { const std::string &s = (*keyDicts[c])[(size_t)kv]; v.SetString(r, s.data(), (int64_t)s.size()); break; }
                 default: break;
                 }

@@ -206,6 +206,26 @@ private:
     bool childDone_ = false;
 };
 
+// Filter whose one conjunct is DOUBLE arithmetic on both sides (Q17's `l_quantity < 0.2 * avg(l_quantity)`: avg(INTEGER) is DOUBLE,
+// `*` has only (T, T) overloads so the FLOAT literal is cast float32 -> float64, `<` has a DOUBLE overload — lessFloat64Op,
+// function_operator_boolean.go:461-470 — and it is the only DOUBLE comparison the reference has). Both sides are RPN programs of
+// FloatOp evaluated in float64: a constant is the float32 literal widened, a column is cast the way the binder casts it (INTEGER,
+// DECIMAL, HUGEINT, FLOAT -> DOUBLE). Evaluated on the host: the rows it sees are a resident plan's result rows.
+struct DoubleLess {
+    std::vector<FloatOp> lhs, rhs;
+};
+class doubleFilterExecutor : public OperatorExec {
+public:
+    doubleFilterExecutor(DoubleLess pred, OperatorExec *child) : pred_(std::move(pred)), child_(child) {}
+    std::string Init() override;
+    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
+    std::string Close() override { return ""; }
+    std::vector<LType> OutputTypes() const override { return child_->OutputTypes(); }
+private:
+    DoubleLess pred_;
+    OperatorExec *child_;
+};
+
 class gpuAggExecutor : public OperatorExec {
 public:
     gpuAggExecutor(ph_ctx *ctx, std::vector<int> groupCols, std::vector<AggExpr> aggs, OperatorExec *child,

@@ -407,6 +407,31 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 1;
         break;
     }
+    case 17: {
+        // Project(sum / 7.0) <- Agg(; sum(l_extendedprice)) <- Filter(l_quantity < 0.2 * avg) <- Join(l_partkey = sub.l_partkey)
+        //   probe <- Join(l_partkey = p_partkey) probe Scan(lineitem), build Scan(part, p_brand = 'Brand#54', p_container = 'LG BAG')
+        //   build Agg(l_partkey; avg(l_quantity)) <- Scan(lineitem)      (the correlated subquery, by its correlation key)
+        // avg(INTEGER) is DOUBLE and the predicate is DOUBLE arithmetic, which a resident plan does not have: the plan carries the
+        // average as its SUM and COUNT and aggregates by (l_quantity, sum, count) — all the predicate reads — so the Filter sees one row per
+        // distinct triple with that triple's exact DECIMAL sum, and the aggregate above adds what passes: the same rows' sum.
+        int subScan = p.Scan(&db.lineitem, {L_PARTKEY, L_QUANTITY});
+        int sub = p.Agg(subScan, {ProjExpr::Col(0)}, {{PH_A_SUM, {XC(1)}}, {PH_A_COUNT, {XC(1)}}});   // l_partkey, sum, count
+        int part = p.Scan(&db.part, {P_PARTKEY}, {{P_BRAND, PH_EQ, LStr("Brand#54")}, {P_CONTAINER, PH_EQ, LStr("LG BAG")}});
+        int line = p.Scan(&db.lineitem, {L_PARTKEY, L_QUANTITY, L_EXTENDEDPRICE});
+        int j1 = p.Join(line, part, {0}, {0}, {0, 1, 2});
+        int j2 = p.Join(j1, sub, {0}, {0}, {1, 2, 4, 5});                      // l_quantity, l_extendedprice, sum(l_quantity), count(l_quantity)
+        p.Agg(j2, {ProjExpr::Col(0), ProjExpr::Col(2), ProjExpr::Col(3)}, {{PH_A_SUM, {XC(1)}}});
+        auto fcol = [](int c) { FloatOp o; o.op = FloatOp::Col; o.col = c; return o; };
+        auto fk = [](float k) { FloatOp o; o.op = FloatOp::Const; o.k = k; return o; };
+        auto fop = [](FloatOp::Op op) { FloatOp o; o.op = op; return o; };
+        q->upperFilter = std::make_shared<DoubleLess>();
+        q->upperFilter->lhs = {fcol(0)};                                                          // l_quantity
+        q->upperFilter->rhs = {fk(0.2f), fcol(1), fcol(2), fop(FloatOp::Div), fop(FloatOp::Mul)}; // 0.2 * (sum / count)
+        q->upperAggs = {{PH_A_SUM, {XC(3)}}};
+        q->upperOutputs = {ProjExpr::Float({fcol(0), fk(7.0f), fop(FloatOp::Div)})};
+        q->ncols = 1;
+        break;
+    }
     case 18: {
         // Limit <- Order <- Agg(c_name, c_custkey, o_orderkey, o_orderdate, o_totalprice; sum(l_quantity))
         //   <- Join(l_orderkey = o_orderkey) probe Scan(lineitem)
@@ -462,7 +487,19 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (!e.empty()) return "Init: " + e;
     std::unique_ptr<gpuOrderExecutor> ord;
     std::unique_ptr<limitExecutor> lim;
+    std::unique_ptr<doubleFilterExecutor> upperFilter;
+    std::unique_ptr<gpuAggExecutor> upperAgg;
     OperatorExec *root = &agg;
+    if (q.upperFilter) {
+        upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
+        e = upperFilter->Init();
+        if (!e.empty()) return "Init: " + e;
+        upperAgg.reset(new gpuAggExecutor(ctx, {}, q.upperAggs, upperFilter.get()));
+        if (!q.upperOutputs.empty()) upperAgg->SetOutputs(q.upperOutputs);
+        e = upperAgg->Init();
+        if (!e.empty()) return "Init: " + e;
+        root = upperAgg.get();
+    }
     if (!q.order.empty()) {
         ord.reset(new gpuOrderExecutor(ctx, q.order, root));
         e = ord->Init();
@@ -493,6 +530,8 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (explain) *explain = agg.Explain();
     if (lim) lim->Close();
     if (ord) ord->Close();
+    if (upperAgg) upperAgg->Close();
+    if (upperFilter) upperFilter->Close();
     agg.Close();
     return "";
 }

@@ -53,6 +53,12 @@ struct TpchQuery {
     std::shared_ptr<TpchQuery> scalar;
     float scalarFactor = 0;
     int havingCol = -1;
+    // operators ABOVE the resident plan whose expressions are DOUBLE / FLOAT arithmetic (Q17): a Filter with a DOUBLE predicate over
+    // the plan's result rows (doubleFilterExecutor), then an ungrouped aggregate over what passes (gpuAggExecutor) with its output
+    // expressions
+    std::shared_ptr<DoubleLess> upperFilter;
+    std::vector<AggExpr> upperAggs;
+    std::vector<ProjExpr> upperOutputs;
 };
 
 // the operator subtree of cases/tpch/query/q<id>.sql over the resident database

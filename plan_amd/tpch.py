@@ -356,6 +356,42 @@ def q14_promo_revenue(r):
     return np.float32(np.float32(100.0) * a) / b
 
 
+def q17_plan(db, brand="Brand#54", container="LG BAG"):
+    """cases/tpch/query/q17.sql: the correlated avg(l_quantity) subquery is an aggregate by its correlation key BELOW a join (its groups
+       stay on the device; SUM and COUNT, the float64 average is taken where the DOUBLE predicate is). The reference's
+       Agg(sum(l_extendedprice)) <- Filter(l_quantity < 0.2 * avg) runs as Agg(l_quantity, sum, count; sum(l_extendedprice)): the predicate
+       reads only those three columns, so filtering the groups and adding their exact DECIMAL sums (q17_avg_yearly) is the same result;
+       the plan has no DOUBLE arithmetic"""
+    p = hip.Plan(db.ctx)
+    sub_scan = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_quantity"))
+    sub = p.agg(sub_scan, [hip.pe_col(0)], [(hip.PH_A_SUM, hip.pe_col(1)), (hip.PH_A_COUNT, hip.pe_col(1))])   # l_partkey, sum, count
+    part = p.scan(db.t("part"), db.c("part", "p_partkey"),
+                  [_pred(db, "part", "p_brand", hip.PH_EQ, _s(brand)), _pred(db, "part", "p_container", hip.PH_EQ, _s(container))])
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_quantity", "l_extendedprice"))
+    j1 = p.join(line, part, [0], [0], [0, 1, 2])
+    j2 = p.join(j1, sub, [0], [0], [1, 2, 4, 5])                          # l_quantity, l_extendedprice, sum(l_quantity), count(l_quantity)
+    p.agg(j2, [hip.pe_col(0), hip.pe_col(2), hip.pe_col(3)], [(hip.PH_A_SUM, hip.pe_col(1))])
+    return p.create()
+
+
+def q17_avg_yearly(r, fraction=0.2, divisor=7.0):
+    """(float32 avg_yearly or None, exact DECIMAL sum unscaled): the groups (l_quantity, sum, count) that pass
+       float64(l_quantity) < float64(float32(fraction)) * (float64(sum) / float64(count)) — avg(INTEGER) is float64, the FLOAT literal is
+       cast to DOUBLE for `*`, `<` is the DOUBLE overload — their sums added exactly, then float32(sum) / float32(divisor)"""
+    from decimal import Decimal
+    f = float(np.float32(fraction))
+    total, any_row = 0, False
+    for g in range(r["ngroups"]):
+        q, s, c = (int(x) for x in r["keys"][g])
+        if float(q) < f * (float(s) / float(c)):
+            total += r["sum"][g][0]
+            any_row = True
+    if not any_row:
+        return None, 0
+    a = np.float32(float(Decimal(total).scaleb(-r["scale"][0])))
+    return np.float32(a / np.float32(divisor)), total
+
+
 Q19_BRANCHES = (("Brand#23", ("SM CASE", "SM BOX", "SM PACK", "SM PKG"), 5, 15, 5),
                 ("Brand#15", ("MED BAG", "MED BOX", "MED PKG", "MED PACK"), 14, 24, 10),
                 ("Brand#44", ("LG CASE", "LG BOX", "LG PACK", "LG PKG"), 28, 38, 15))

@@ -633,6 +633,21 @@ def q14_text(t, pattern, date_ge, date_lt):
     return _text("oracle_q14_text", ctypes.c_float(f), i32(rc))
 
 
+def q17(t, brand="Brand#54", container="LG BAG", fraction=0.2, divisor=7.0):
+    """(rc, float32 avg_yearly, decimal sum)"""
+    T, keep = tpch_struct(t)
+    f, s = ctypes.c_float(), ODec()
+    lib().oracle_q17.restype = i32
+    rc = lib().oracle_q17(ctypes.byref(T), brand.encode(), container.encode(), ctypes.c_float(fraction), ctypes.c_float(divisor), ctypes.byref(f), ctypes.byref(s))
+    return rc, f.value, s
+
+
+def q17_text(t, **kw):
+    rc, f, _s = q17(t, **kw)
+    assert rc >= 0
+    return _text("oracle_q17_text", ctypes.c_float(f), i32(rc))
+
+
 def q19(t):
     T, keep = tpch_struct(t)
     d = ODec()

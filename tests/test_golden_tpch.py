@@ -80,6 +80,12 @@ def test_q14_matches_reference_golden(sf1):
     assert O.q14_text(sf1, "PROMO%", tpchgen.days(1996, 4, 1), tpchgen.days(1996, 5, 1)) == golden("plan_q14.txt")
 
 
+def test_q17_matches_reference_golden(sf1):
+    # a correlated subquery decorrelated into an aggregate by its key (avg(INTEGER) = float64), joined back; FLOAT literal x DOUBLE =
+    # float64 arithmetic and the DOUBLE '<'; sum(DECIMAL) / 7.0 in float32
+    assert O.q17_text(sf1) == golden("plan_q17.txt")
+
+
 def test_q19_matches_reference_golden(sf1):
     assert O.q19_text(sf1) == golden("plan_q19.txt")
 

@@ -296,6 +296,22 @@ def test_q11_having_against_a_scalar_subquery_matches_golden(ctx, db, sf1):
     assert text == golden("plan_q11.txt"), ex
 
 
+def test_q17_decorrelated_average_joined_back_matches_golden(ctx, db, sf1):
+    """Q17: an aggregate by the correlation key below a join whose payload is its SUM and COUNT; the DOUBLE predicate and the float32
+    division over the fetched groups: the oracle's exact sum and cases/tpch/1g/plan/q17.txt"""
+    p = tpch.q17_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    f, total = tpch.q17_avg_yearly(r)
+    rc, of, osum = O.q17(sf1)
+    assert rc == 0 and total == osum.unscaled(2), ex
+    assert f"#\n{float(f)!r}\n" == golden("plan_q17.txt"), ex
+    assert float(f) == of
+    assert "groups stay on the device" in ex
+
+
 def test_q18_subquery_aggregate_varchar_key_matches_golden(ctx, db):
     """an aggregate below a SEMI join (its 1.5 M groups stay on the device, HAVING is a Filter over them), five group keys — c_name a
     VARCHAR interned on the device, two narrow keys packed into one key word: cases/tpch/1g/plan/q18.txt byte for byte"""
