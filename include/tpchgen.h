@@ -128,9 +128,15 @@ typedef struct {
 int64_t tpchgen_partsupp(int64_t sf_num, int64_t sf_den, int64_t first_part, int64_t n_parts,
                          const tpchgen_partsupp_cols *out);
 
+#define TPCHGEN_S_ADDRESS_STRIDE 40   /* s_address: 10..40 characters, zero padded to the stride */
+#define TPCHGEN_S_PHONE_LEN 15        /* s_phone: "CC-AAA-EEE-NNNN" */
 typedef struct {
     int32_t *s_suppkey;
     int32_t *s_nationkey;
+    /* round 3 (appended: callers that zero-initialise the struct keep working) */
+    char *s_address;          /* TPCHGEN_S_ADDRESS_STRIDE bytes per row */
+    uint8_t *s_address_len;   /* its length */
+    char *s_phone;            /* TPCHGEN_S_PHONE_LEN bytes per row, no terminator */
 } tpchgen_supplier_cols;
 
 int64_t tpchgen_supplier(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,

@@ -590,6 +590,80 @@ int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *containe
 
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);
 
+/* ------------------------------------------------------------------ Q15 (cases/tpch/query/q15.sql)
+ * Order(s_suppkey) <- Project <- Join(s_suppkey = supplier_no) probe Scan(supplier)
+ *   build <- Join(total_revenue = max) [the scalar subquery's one row; `=` on DECIMAL exists only as a join condition: the hash join
+ *            hashes and matches the decimals (chunk/hash.go, util_match.go), executeSelect has no DECIMAL case for FuncEqual
+ *            (function_operator_boolean.go:395-407)]
+ *        probe  q15_revenue0 = Agg(l_suppkey; sum(l_extendedprice * (1 - l_discount))) <- Scan(lineitem, l_shipdate in [d, d + 3 months))
+ *        build  Agg(; max(total_revenue)) <- q15_revenue0        (MinMaxOp on DECIMAL: function_aggr.go:968-1027)
+ * Returns the rows (s_suppkey, total_revenue) in supplier order, -1 on error. */
+int64_t oracle_q15(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracle_q15_row *out, int64_t max) {
+    int64_t n = T->n_lineitem;
+    int64_t *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol ls = mkcol(OT_DATE, 0, T->l_shipdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    int64_t c = oracle_select(&ls, OP_GE, &k1, NULL, n, s1);
+    c = oracle_select(&ls, OP_LT, &k2, s1, c, s2);
+    ocol kproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    ocol aproto[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *rev = oracle_agg_create(kproto, 1, aproto, aggs, 1);
+    static odec v[VS];
+    int64_t ext[VS], disc[VS];
+    int32_t supp[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < c && rc == 0; base += VS) {
+        int64_t cnt = c - base < VS ? c - base : VS;
+        for (int64_t j = 0; j < cnt; j++) {
+            const int64_t r = s2[base + j];
+            ext[j] = T->l_extendedprice[r]; disc[j] = T->l_discount[r]; supp[j] = T->l_suppkey[r];
+        }
+        ocol cols[2] = {mkcol(OT_DECIMAL, 2, ext), mkcol(OT_DECIMAL, 2, disc)};
+        rc = oracle_eval_decimal(cols, DISC_PRICE, 5, NULL, cnt, v);
+        ocol keys[1] = {mkcol(OT_INT32, 0, supp)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        if (rc == 0) rc = oracle_agg_sink(rev, keys, args, NULL, cnt);
+    }
+    int64_t ng = rc ? 0 : oracle_agg_count(rev);
+    int32_t *gkey = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ng > 0 ? ng : 1));
+    odec *gval = (odec *)malloc(sizeof(odec) * (size_t)(ng > 0 ? ng : 1));
+    /* the scalar subquery: max over the groups (an ungrouped aggregate over the CTE's rows) */
+    static const int32_t one = 1;
+    ocol k1p[1] = {mkcol(OT_CONST32, 0, &one)};
+    oaggspec mx[1] = {{OA_MAX, 0}};
+    oagg *tmax = oracle_agg_create(k1p, 1, aproto, mx, 1);
+    for (int64_t g = 0; g < ng; g++) {
+        int64_t kv[1];
+        oaggval val;
+        oracle_agg_group(rev, g, NULL, kv, NULL, &val);
+        gkey[g] = (int32_t)kv[0];
+        gval[g] = val.d;
+    }
+    for (int64_t base = 0; base < ng && rc == 0; base += VS) {
+        int64_t cnt = ng - base < VS ? ng - base : VS;
+        ocol keys[1] = {mkcol(OT_CONST32, 0, &one)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, gval + base)};
+        rc = oracle_agg_sink(tmax, keys, args, NULL, cnt);
+    }
+    int64_t nout = rc ? -1 : 0;
+    if (rc == 0 && oracle_agg_count(tmax) == 1) {
+        int64_t kv[1];
+        oaggval m;
+        oracle_agg_group(tmax, 0, NULL, kv, NULL, &m);
+        /* the groups whose revenue equals the maximum (Decimal.Equal), joined with supplier on the key, in supplier order */
+        for (int64_t s = 0; s < T->n_supplier && m.kind == OV_DECIMAL; s++)
+            for (int64_t g = 0; g < ng; g++)
+                if (gkey[g] == T->s_suppkey[s] && odec_cmp(gval[g], m.d) == 0) {
+                    if (nout < max) { out[nout].s_suppkey = gkey[g]; out[nout].total_revenue = gval[g]; }
+                    nout++;
+                }
+    }
+    oracle_agg_free(rev); oracle_agg_free(tmax);
+    free(s1); free(s2); free(gkey); free(gval);
+    return nout;
+}
+
 /* ------------------------------------------------------------------ text */
 /* extract(year from date): Date.Year (pkg/common/date.go) */
 static int32_t year_of_days2(int32_t z) {
@@ -1065,4 +1139,23 @@ int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap)
 
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap) {
     return oracle_q14_text(avg_yearly, is_null, buf, cap);   /* one FLOAT column: the same rendering */
+}
+
+/* s_name = 'Supplier#' + nine digits of the key (TPC-H 4.2.3); address and phone of supplier row i as the generator made them */
+int64_t oracle_q15_text(const oracle_q15_row *rows, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes,
+                        const char *phone_bytes, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\t\t\t\n");
+    char t[96];
+    for (int64_t i = 0; i < n; i++) {   /* (already in supplier order = ORDER BY s_suppkey: the keys ascend) */
+        int64_t r = -1;
+        for (int64_t j = 0; j < n_supplier; j++) if (s_suppkey[j] == rows[i].s_suppkey) { r = j; break; }
+        if (r < 0) continue;
+        sprintf(t, "%d\tSupplier#%09d\t", rows[i].s_suppkey, rows[i].s_suppkey); put(&s, t);
+        int32_t len = addr_off[r + 1] - addr_off[r];
+        memcpy(t, addr_bytes + addr_off[r], (size_t)len); t[len] = 0; put(&s, t); put(&s, "\t");
+        memcpy(t, phone_bytes + 15 * r, 15); t[15] = 0; put(&s, t); put(&s, "\t");
+        oracle_format_decimal(rows[i].total_revenue, 4, t); put(&s, t); put(&s, "\n");
+    }
+    return done(&s);
 }

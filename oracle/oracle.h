@@ -363,6 +363,11 @@ typedef struct { int32_t ps_partkey; odec value; } oracle_q11_row;
 int64_t oracle_q11(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int64_t *ps_supplycost,
                    const int32_t *ps_availqty, const char *nation, float fraction, oracle_q11_row *out, int64_t max);
 int64_t oracle_q11_text(oracle_q11_row *rows, int64_t n, char *buf, int64_t cap);   /* ORDER BY value DESC */
+/* Q15 (cases/tpch/query/q15.sql): the suppliers whose quarter revenue equals the maximum, in s_suppkey order */
+typedef struct { int32_t s_suppkey; odec total_revenue; } oracle_q15_row;
+int64_t oracle_q15(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracle_q15_row *out, int64_t max);
+int64_t oracle_q15_text(const oracle_q15_row *rows, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes,
+                        const char *phone_bytes, char *buf, int64_t cap);
 /* Q17 (cases/tpch/query/q17.sql): 0 ok / 1 the sum is NULL / -1 error; avg_yearly = float32(sum) / divisor, the threshold fraction * avg in float64 */
 int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out);
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);

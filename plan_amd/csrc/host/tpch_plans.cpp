@@ -180,6 +180,7 @@ static std::vector<ph_rpn> DiscPrice(int e, int d) { return {XC(e), XK(1), XC(d)
 std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     *q = TpchQuery{};
     q->id = id;
+    q->sfNum = db.num; q->sfDen = db.den;
     ResidentPlan &p = q->plan;
     switch (id) {
     case 1: {   // Order <- Agg <- Scan(lineitem, l_shipdate <= date '1998-12-01' - interval '112 day')
@@ -407,6 +408,16 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 1;
         break;
     }
+    case 15: {
+        // the CTE q15_revenue0 = Agg(l_suppkey; sum(l_extendedprice * (1 - l_discount))) <- Scan(lineitem, l_shipdate in [1995-12-01, + 3 months)) is the
+        // resident plan; it is referenced twice, and what stands above it — max() over its rows, the DECIMAL equality as a join condition,
+        // the join with supplier, ORDER BY — runs over its group rows through the chunk executors (RunTpchQuery)
+        int line = p.Scan(&db.lineitem, {L_SUPPKEY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_SHIPDATE, PH_GE, LDate(1995, 12, 1)}, {L_SHIPDATE, PH_LT, LDate(1996, 3, 1)}});
+        p.Agg(line, {ProjExpr::Col(0)}, {{PH_A_SUM, DiscPrice(1, 2)}});
+        q->order = {{0, false}};
+        q->ncols = 5;
+        break;
+    }
     case 17: {
         // Project(sum / 7.0) <- Agg(; sum(l_extendedprice)) <- Filter(l_quantity < 0.2 * avg) <- Join(l_partkey = sub.l_partkey)
         //   probe <- Join(l_partkey = p_partkey) probe Scan(lineitem), build Scan(part, p_brand = 'Brand#54', p_container = 'LG BAG')
@@ -459,6 +470,35 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     return p.error;
 }
 
+// Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
+static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) {
+    struct St { int64_t n = 0, pos = 0; std::vector<int32_t> key; std::vector<char> addr, phone; std::vector<uint8_t> alen; };
+    auto st = std::make_shared<St>();
+    st->n = tpchgen_supplier_count(num, den);
+    st->key.resize((size_t)st->n); st->addr.resize((size_t)st->n * TPCHGEN_S_ADDRESS_STRIDE); st->alen.resize((size_t)st->n); st->phone.resize((size_t)st->n * TPCHGEN_S_PHONE_LEN);
+    tpchgen_supplier_cols sc{};
+    sc.s_suppkey = st->key.data(); sc.s_address = st->addr.data(); sc.s_address_len = st->alen.data(); sc.s_phone = st->phone.data();
+    tpchgen_supplier(num, den, 0, st->n, &sc);
+    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType()};
+    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [st, types](Chunk *out) {
+        if (st->pos >= st->n) return false;
+        const int card = (int)std::min<int64_t>(DefaultVectorSize, st->n - st->pos);
+        out->Init(types, DefaultVectorSize);
+        for (int i = 0; i < card; i++) {
+            const size_t r = (size_t)(st->pos + i);
+            out->Data[0]->Slice<int32_t>()[i] = st->key[r];
+            char name[32];
+            snprintf(name, sizeof name, "Supplier#%09d", st->key[r]);
+            out->Data[1]->SetString(i, name, 18);
+            out->Data[2]->SetString(i, st->addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, st->alen[r]);
+            out->Data[3]->SetString(i, st->phone.data() + r * TPCHGEN_S_PHONE_LEN, TPCHGEN_S_PHONE_LEN);
+        }
+        out->SetCard(card);
+        st->pos += card;
+        return true;
+    }));
+}
+
 std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
     std::vector<Compare> having = q.having;
     if (q.scalar) {   // the uncorrelated scalar subquery first: one row, one DECIMAL value
@@ -489,7 +529,28 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     std::unique_ptr<limitExecutor> lim;
     std::unique_ptr<doubleFilterExecutor> upperFilter;
     std::unique_ptr<gpuAggExecutor> upperAgg;
+    std::unique_ptr<gpuResidentPlanExecutor> cte2;
+    std::unique_ptr<sourceExecutor> suppSrc;
+    std::unique_ptr<gpuJoinExecutor> j1, j2;
     OperatorExec *root = &agg;
+    if (q.id == 15) {
+        // Order(s_suppkey) <- Join(s_suppkey = supplier_no) probe Scan(supplier), build <- Join(total_revenue = max) probe CTE,
+        //   build Agg(; max(total_revenue)) <- CTE (second reference): the hash join on a DECIMAL key is how `=` on DECIMAL runs
+        cte2.reset(new gpuResidentPlanExecutor(ctx, q.plan));
+        e = cte2->Init();
+        if (!e.empty()) return "Init (CTE, second reference): " + e;
+        upperAgg.reset(new gpuAggExecutor(ctx, {}, {{PH_A_MAX, {XC(1)}}}, cte2.get()));
+        e = upperAgg->Init();
+        if (!e.empty()) return "Init (max): " + e;
+        j1.reset(new gpuJoinExecutor(ctx, root, upperAgg.get(), {1}, {0}, {}));
+        e = j1->Init();
+        if (!e.empty()) return "Init (join on the maximum): " + e;
+        suppSrc = SupplierSource(q.sfNum, q.sfDen);
+        j2.reset(new gpuJoinExecutor(ctx, suppSrc.get(), j1.get(), {0}, {0}, {1}));
+        e = j2->Init();
+        if (!e.empty()) return "Init (join with supplier): " + e;
+        root = j2.get();
+    }
     if (q.upperFilter) {
         upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
         e = upperFilter->Init();
@@ -530,8 +591,11 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (explain) *explain = agg.Explain();
     if (lim) lim->Close();
     if (ord) ord->Close();
+    if (j2) j2->Close();
+    if (j1) j1->Close();
     if (upperAgg) upperAgg->Close();
     if (upperFilter) upperFilter->Close();
+    if (cte2) cte2->Close();
     agg.Close();
     return "";
 }

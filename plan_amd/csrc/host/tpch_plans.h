@@ -56,6 +56,7 @@ struct TpchQuery {
     // operators ABOVE the resident plan whose expressions are DOUBLE / FLOAT arithmetic (Q17): a Filter with a DOUBLE predicate over
     // the plan's result rows (doubleFilterExecutor), then an ungrouped aggregate over what passes (gpuAggExecutor) with its output
     // expressions
+    int64_t sfNum = 1, sfDen = 1;         // the database's scale factor (Q15's Scan(supplier) is a chunk source over the generator)
     std::shared_ptr<DoubleLess> upperFilter;
     std::vector<AggExpr> upperAggs;
     std::vector<ProjExpr> upperOutputs;

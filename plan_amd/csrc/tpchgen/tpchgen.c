@@ -11,6 +11,7 @@
 #include "tpchgen.h"
 
 #include <stddef.h>
+#include <stdio.h>
 #include <string.h>
 
 #define MODULUS 2147483647LL
@@ -52,6 +53,11 @@
 #define SD_P_TYPE 1841581359LL
 #define SD_P_SIZE 1193163244LL
 #define SD_P_CNTR 727633698LL
+/* round 3, Q15's select list: s_address = a v-string of 10..40 characters (1 draw for the length + 1 per 5 characters: 9 per row),
+ * s_phone = country code 10 + nation, then three draws. Pinned by the publicly known first rows of supplier.tbl
+ * (tests/test_tpchgen.py) and by the row cases/tpch/1g/plan/q15.txt prints. */
+#define SD_S_ADDR 706178559LL
+#define SD_S_PHNE 884434366LL
 
 #define O_LCNT_MAX 7
 #define SUPP_PER_PART 4
@@ -468,16 +474,47 @@ int64_t tpchgen_partsupp(int64_t num, int64_t den, int64_t first, int64_t n,
     return row;
 }
 
+/* the generator's random string: a length in [lo, hi], then one draw per five characters, six bits each, low bits first */
+static int vstring(stream_t *s, int lo, int hi, char *dest) {
+    static const char alnum[65] = "0123456789abcdefghijklmnopqrstuvwxyz ABCDEFGHIJKLMNOPQRSTUVWXYZ,";
+    const int len = (int)stream_int(s, lo, hi);
+    int64_t bits = 0;
+    for (int i = 0; i < len; i++) {
+        /* the draw over [0, 2^31 - 1] comes out NEGATED in the public generator's output (its range, hi - lo + 1, wraps to -2^31 in
+         * 32-bit arithmetic): six bits at a time of the two's complement of the draw, arithmetic shifts */
+        if (i % 5 == 0) bits = -stream_int(s, 0, 2147483647LL);
+        dest[i] = alnum[(uint64_t)bits & 63];
+        bits = (int64_t)(bits < 0 ? ~(~(uint64_t)bits >> 6) : (uint64_t)bits >> 6);
+    }
+    return len;
+}
+
 int64_t tpchgen_supplier(int64_t num, int64_t den, int64_t first, int64_t n,
                          const tpchgen_supplier_cols *out) {
     (void)num; (void)den;
-    stream_t ntrg;
+    stream_t ntrg, addr, phne;
     stream_init(&ntrg, SD_S_NTRG, 1, first);
+    stream_init(&addr, SD_S_ADDR, 9, first);
+    stream_init(&phne, SD_S_PHNE, 3, first);
     for (int64_t i = 0; i < n; i++) {
         int64_t nation = stream_int(&ntrg, 0, 24);
         if (out->s_suppkey) out->s_suppkey[i] = (int32_t)(first + i + 1);
         if (out->s_nationkey) out->s_nationkey[i] = (int32_t)nation;
+        if (out->s_address) {
+            char *a = out->s_address + TPCHGEN_S_ADDRESS_STRIDE * i;
+            memset(a, 0, TPCHGEN_S_ADDRESS_STRIDE);
+            const int len = vstring(&addr, 10, 40, a);
+            if (out->s_address_len) out->s_address_len[i] = (uint8_t)len;
+        }
+        if (out->s_phone) {
+            const int ac = (int)stream_int(&phne, 100, 999), ex = (int)stream_int(&phne, 100, 999), nr = (int)stream_int(&phne, 1000, 9999);
+            char buf[24];
+            snprintf(buf, sizeof buf, "%02d-%03d-%03d-%04d", (int)(10 + nation), ac, ex, nr);
+            memcpy(out->s_phone + TPCHGEN_S_PHONE_LEN * i, buf, TPCHGEN_S_PHONE_LEN);
+        }
         stream_row_done(&ntrg);
+        stream_row_done(&addr);
+        stream_row_done(&phne);
     }
     return n;
 }

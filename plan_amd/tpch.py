@@ -28,7 +28,8 @@ SCHEMA = {
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
              ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
     "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None), ("ps_availqty", hip.PH_I32, 0, None)],
-    "supplier": [("s_suppkey", hip.PH_I32, 0, None), ("s_nationkey", hip.PH_I32, 0, None)],
+    "supplier": [("s_suppkey", hip.PH_I32, 0, None), ("s_nationkey", hip.PH_I32, 0, None), ("s_name", hip.PH_STR, 0, None),
+                 ("s_address", hip.PH_STR, 0, None), ("s_phone", hip.PH_STR, 0, None)],
     "nation": [("n_nationkey", hip.PH_I32, 0, None), ("n_name", hip.PH_CODE8, 0, "nation_names"), ("n_regionkey", hip.PH_I32, 0, None)],
     "region": [("r_regionkey", hip.PH_I32, 0, None), ("r_name", hip.PH_CODE8, 0, "region_names")],
 }
@@ -354,6 +355,36 @@ def q14_promo_revenue(r):
     a = np.float32(float(Decimal(r["sum"][0][0]).scaleb(-r["scale"][0])))
     b = np.float32(float(Decimal(r["sum"][0][1]).scaleb(-r["scale"][1])))
     return np.float32(np.float32(100.0) * a) / b
+
+
+def q15_plan(db, d1=None, d2=None):
+    """cases/tpch/query/q15.sql: the CTE q15_revenue0 = Agg(l_suppkey; sum(l_extendedprice * (1 - l_discount))) over one quarter of lineitem.
+       What stands above it reads only its group rows (10 k x SF): the maximum, the DECIMAL equality and the supplier's columns (q15_rows)"""
+    d1 = tpchgen.days(1995, 12, 1) if d1 is None else d1
+    d2 = tpchgen.days(1996, 3, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_suppkey", "l_extendedprice", "l_discount"),
+                  [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    p.agg(line, [hip.pe_col(0)], [(hip.PH_A_SUM, hip.pe_dec([hip.X_COL(1), hip.X_CONST(1), hip.X_COL(2), hip.X_SUB, hip.X_MUL]))])
+    return p.create()
+
+
+def q15_rows(r):
+    """[(s_suppkey, total_revenue unscaled)] of the groups whose exact DECIMAL sum equals the maximum, ORDER BY s_suppkey"""
+    if r["ngroups"] == 0:
+        return []
+    top = max(r["sum"][g][0] for g in range(r["ngroups"]))
+    return sorted((int(r["keys"][g][0]), r["sum"][g][0]) for g in range(r["ngroups"]) if r["sum"][g][0] == top)
+
+
+def q15_text(db, rows, supp_keys, scale=4):
+    """the reference's text: s_suppkey, s_name, s_address, s_phone (rows of the resident supplier table), total_revenue"""
+    pos = [int(np.nonzero(supp_keys == k)[0][0]) for k, _ in rows]
+    cols = [hip.table_strings(db.ctx, db.t("supplier"), db.c("supplier", c)[0], pos) for c in ("s_name", "s_address", "s_phone")]
+    out = ["#\t\t\t\t"]
+    for i, (k, v) in enumerate(rows):
+        out.append(f"{k}\t{cols[0][i]}\t{cols[1][i]}\t{cols[2][i]}\t{dec_text(v, scale)}")
+    return "\n".join(out) + "\n"
 
 
 def q17_plan(db, brand="Brand#54", container="LG BAG"):

@@ -98,7 +98,8 @@ _CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment"
 _PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8), ("p_brand", np.uint8), ("p_type", np.uint8), ("p_size", np.int32),
          ("p_container", np.uint8)]
 _PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64), ("ps_availqty", np.int32)]
-_SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32)]
+_SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32), ("s_address", np.uint8), ("s_address_len", np.uint8), ("s_phone", np.uint8)]
+S_ADDRESS_STRIDE, S_PHONE_LEN = 40, 15
 
 
 def _gen(fn, layout, nrows, sf, first, n, columns, width=None):
@@ -194,6 +195,32 @@ def partsupp(sf, first_part=0, n_parts=None, columns=None):
 
 
 def supplier(sf, first=0, n=None, columns=None):
+    """s_name is 'Supplier#' + the key as nine digits (TPC-H 4.2.3); s_name, s_address, s_phone come as offsets + bytes (<col>_off / <col>_bytes)"""
     if n is None:
         n = int(lib().tpchgen_supplier_count(_i64(sf[0]), _i64(sf[1]))) - first
-    return _gen(lib().tpchgen_supplier, _SUPPLIER, n, sf, first, n, columns)
+    want = None if columns is None else list(columns)
+    raw = None if want is None else [c for c in want if c in ("s_suppkey", "s_nationkey")]
+    if want is None or "s_address" in want:
+        raw = None if raw is None else raw + ["s_address", "s_address_len"]
+    if want is None or "s_phone" in want:
+        raw = None if raw is None else raw + ["s_phone"]
+    cols = _gen(lib().tpchgen_supplier, _SUPPLIER, n, sf, first, n, raw, width={"s_address": S_ADDRESS_STRIDE, "s_phone": S_PHONE_LEN})
+    if "s_address" in cols:
+        lens = cols.pop("s_address_len").astype(np.int64)
+        a = cols.pop("s_address").reshape(n, S_ADDRESS_STRIDE)
+        off = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(lens, out=off[1:])
+        cols["s_address_off"] = off
+        cols["s_address_bytes"] = a[np.arange(S_ADDRESS_STRIDE)[None, :] < lens[:, None]]
+    if "s_phone" in cols:
+        cols["s_phone_bytes"] = cols.pop("s_phone")
+        cols["s_phone_off"] = np.arange(0, S_PHONE_LEN * (n + 1), S_PHONE_LEN, dtype=np.int32)
+    if want is None or "s_name" in want:
+        keys = np.arange(first + 1, first + n + 1, dtype=np.int64)
+        buf = np.empty((n, 18), dtype=np.uint8)
+        buf[:, :9] = np.frombuffer(b"Supplier#", dtype=np.uint8)
+        for d in range(9):
+            buf[:, 17 - d] = ord("0") + (keys // 10 ** d) % 10
+        cols["s_name_off"] = np.arange(0, 18 * (n + 1), 18, dtype=np.int32)
+        cols["s_name_bytes"] = buf.reshape(-1)
+    return cols

@@ -633,6 +633,28 @@ def q14_text(t, pattern, date_ge, date_lt):
     return _text("oracle_q14_text", ctypes.c_float(f), i32(rc))
 
 
+class Q15Row(ctypes.Structure):
+    _fields_ = [("s_suppkey", i32), ("total_revenue", ODec)]
+
+
+def q15_rows(t, date_ge, date_lt):
+    T, keep = tpch_struct(t)
+    rows = (Q15Row * 64)()
+    lib().oracle_q15.restype = i64
+    n = lib().oracle_q15(ctypes.byref(T), i32(date_ge), i32(date_lt), rows, i64(64))
+    assert 0 <= n <= 64
+    return rows, n
+
+
+def q15_text(t, date_ge, date_lt):
+    rows, n = q15_rows(t, date_ge, date_lt)
+    S = t["supplier"]
+    key, off = np.ascontiguousarray(S["s_suppkey"]), np.ascontiguousarray(S["s_address_off"])
+    ab, pb = np.ascontiguousarray(S["s_address_bytes"]), np.ascontiguousarray(S["s_phone_bytes"])
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    return _text("oracle_q15_text", rows, i64(n), vp(key), i64(len(key)), vp(off), vp(ab), vp(pb))
+
+
 def q17(t, brand="Brand#54", container="LG BAG", fraction=0.2, divisor=7.0):
     """(rc, float32 avg_yearly, decimal sum)"""
     T, keep = tpch_struct(t)

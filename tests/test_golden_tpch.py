@@ -80,6 +80,12 @@ def test_q14_matches_reference_golden(sf1):
     assert O.q14_text(sf1, "PROMO%", tpchgen.days(1996, 4, 1), tpchgen.days(1996, 5, 1)) == golden("plan_q14.txt")
 
 
+def test_q15_matches_reference_golden(sf1):
+    # a CTE used twice: Agg(l_suppkey; sum) and max() over its groups, DECIMAL equality as a join condition, the supplier's generated
+    # s_address / s_phone in the select list (pins the generator's v-string and phone streams at supplier 7895)
+    assert O.q15_text(sf1, tpchgen.days(1995, 12, 1), tpchgen.days(1996, 3, 1)) == golden("plan_q15.txt")
+
+
 def test_q17_matches_reference_golden(sf1):
     # a correlated subquery decorrelated into an aggregate by its key (avg(INTEGER) = float64), joined back; FLOAT literal x DOUBLE =
     # float64 arithmetic and the DOUBLE '<'; sum(DECIMAL) / 7.0 in float32

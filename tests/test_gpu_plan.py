@@ -296,6 +296,20 @@ def test_q11_having_against_a_scalar_subquery_matches_golden(ctx, db, sf1):
     assert text == golden("plan_q11.txt"), ex
 
 
+def test_q15_cte_maximum_and_supplier_strings_match_golden(ctx, db, sf1):
+    """Q15: the CTE's aggregate as the plan, its maximum and the DECIMAL equality over the fetched groups, the supplier's generated VARCHAR
+    columns read back from the resident table: the oracle's rows and cases/tpch/1g/plan/q15.txt"""
+    p = tpch.q15_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    rows = tpch.q15_rows(r)
+    orows, n = O.q15_rows(sf1, tpchgen.days(1995, 12, 1), tpchgen.days(1996, 3, 1))
+    assert rows == [(orows[i].s_suppkey, orows[i].total_revenue.unscaled(4)) for i in range(n)], ex
+    assert tpch.q15_text(db, rows, sf1["supplier"]["s_suppkey"], r["scale"][0]) == golden("plan_q15.txt"), ex
+
+
 def test_q17_decorrelated_average_joined_back_matches_golden(ctx, db, sf1):
     """Q17: an aggregate by the correlation key below a join whose payload is its SUM and COUNT; the DOUBLE predicate and the float32
     division over the fetched groups: the oracle's exact sum and cases/tpch/1g/plan/q17.txt"""

@@ -46,3 +46,19 @@ def test_partsupp_availqty_first_rows():
     assert ps["ps_suppkey"][:9].tolist() == [2, 2502, 5002, 7502, 3, 2503, 5003, 7503, 4]
     assert ps["ps_availqty"][:9].tolist() == [3325, 8076, 3956, 4069, 8895, 4969, 8539, 3025, 4651]
     assert ps["ps_supplycost"][:9].tolist() == [77164, 99349, 33709, 35784, 37849, 91527, 43837, 30639, 92092]
+
+
+def test_supplier_address_and_phone_first_rows():
+    """the first rows of dbgen's supplier.tbl at SF1 as publicly known: 1|Supplier#000000001| N kD4on9OM Ipw3,gf0JBoQDd7tgrzrddZ|17|27-918-335-1736|,
+    2|Supplier#000000002|89eJ5ksX3ImxJQBvxObC,|5|15-679-861-2259|, 3|Supplier#000000003|q1,G3Pj6OjIuUYfUoH18BFTKP5aU9bEV3|1|11-383-516-1199|;
+    and the row cases/tpch/1g/plan/q15.txt prints for supplier 7895"""
+    def strs(S, c):
+        o, b = S[c + "_off"], S[c + "_bytes"].tobytes()
+        return [b[o[i]:o[i + 1]].decode() for i in range(len(o) - 1)]
+    S = g.supplier(SF1, 0, 3)
+    assert strs(S, "s_name") == ["Supplier#000000001", "Supplier#000000002", "Supplier#000000003"]
+    assert strs(S, "s_address") == [" N kD4on9OM Ipw3,gf0JBoQDd7tgrzrddZ", "89eJ5ksX3ImxJQBvxObC,", "q1,G3Pj6OjIuUYfUoH18BFTKP5aU9bEV3"]
+    assert strs(S, "s_phone") == ["27-918-335-1736", "15-679-861-2259", "11-383-516-1199"]
+    assert S["s_nationkey"].tolist() == [17, 5, 1]
+    S = g.supplier(SF1, 7894, 1)
+    assert (strs(S, "s_address"), strs(S, "s_phone")) == (["NYl,i8UhxTykLxGJ2voIRn20Ugk1KTzz"], ["14-559-808-3306"])
