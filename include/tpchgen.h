@@ -95,10 +95,14 @@ typedef struct {
 int64_t tpchgen_orders(int64_t sf_num, int64_t sf_den, int64_t first_order,
                        int64_t n_orders, const tpchgen_orders_cols *out);
 
+#define TPCHGEN_S_PHONE_LEN 15        /* s_phone / c_phone: "CC-AAA-EEE-NNNN" */
 typedef struct {
     int32_t *c_custkey;
     int32_t *c_nationkey;
     uint8_t *c_mktsegment; /* code into TPCHGEN_MKTSEGMENT_DICT */
+    /* round 3 (appended) */
+    char *c_phone;         /* 15 bytes per row: "CC-AAA-EEE-NNNN", CC = 10 + nation */
+    int64_t *c_acctbal;    /* DECIMAL(15,2) unscaled, -999.99 .. 9999.99 */
 } tpchgen_customer_cols;
 
 int64_t tpchgen_customer(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,
@@ -129,7 +133,6 @@ int64_t tpchgen_partsupp(int64_t sf_num, int64_t sf_den, int64_t first_part, int
                          const tpchgen_partsupp_cols *out);
 
 #define TPCHGEN_S_ADDRESS_STRIDE 40   /* s_address: 10..40 characters, zero padded to the stride */
-#define TPCHGEN_S_PHONE_LEN 15        /* s_phone: "CC-AAA-EEE-NNNN" */
 typedef struct {
     int32_t *s_suppkey;
     int32_t *s_nationkey;

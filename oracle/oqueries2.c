@@ -664,6 +664,113 @@ int64_t oracle_q15(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracl
     return nout;
 }
 
+/* ------------------------------------------------------------------ Q22 (cases/tpch/query/q22.sql)
+ * Order(cntrycode) <- Agg(cntrycode; count(*), sum(c_acctbal)) <- ANTI Join(c_custkey = o_custkey) probe
+ *   Filter(c_acctbal > scalar) <- Project(substring(c_phone from 1 for 2) as cntrycode, ..) <- Scan(customer, cntrycode IN (..)), build Scan(orders);
+ *   scalar = Agg(; avg(c_acctbal)) <- Scan(customer, c_acctbal > 0.00 and cntrycode IN (..)).
+ * substring: substringFunc (function_operator_binary.go:553-625); IN binds to an OR of `=` on VARCHAR (equalStrOp); `c_acctbal > 0.00` is DECIMAL
+ * against a FLOAT literal: float32 compare (greatFloat32Op); avg(DECIMAL) = govalues Quo(sum, count) (AvgOp.Finalize, function_aggr.go:873-900);
+ * `c_acctbal > (subquery)` is DECIMAL > DECIMAL: greatDecimalOp, an exact comparison (function_operator_boolean.go:431-442); NOT EXISTS is the
+ * ANTI join (join_scan.go:102-120). c_phone: 15 bytes per row. Returns the groups in first-seen order, -1 on error. */
+int64_t oracle_q22(const oracle_tpch *T, const char *c_phone, const int64_t *c_acctbal, const char *const *codes, int32_t ncodes,
+                   oracle_q22_row *out, int64_t max) {
+    const int64_t n = T->n_customer;
+    /* cntrycode as a dictionary column: the dictionary is the distinct substrings in first-seen order (at most 25 country codes) */
+    static char dict_store[256][4];
+    const char *dict[256];
+    int32_t ndict = 0;
+    uint8_t *code = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) {
+        char sub[16];
+        const int64_t len = oracle_substring(c_phone + 15 * i, 15, 1, 2, sub);
+        sub[len] = 0;
+        int32_t k = 0;
+        while (k < ndict && strcmp(dict[k], sub) != 0) k++;
+        if (k == ndict) {
+            if (ndict == 256 || len > 3) { free(code); return -1; }
+            memcpy(dict_store[ndict], sub, (size_t)len + 1);
+            dict[ndict] = dict_store[ndict];
+            ndict++;
+        }
+        code[i] = (uint8_t)k;
+    }
+    ocol cc = mkcode(code, dict);
+    cc.dict_size = ndict;
+    int64_t *in_sel = i64buf(n), *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol orc[16]; int32_t ops[16]; oconst ks[16];
+    if (ncodes > 16) { free(code); return -1; }
+    for (int32_t k = 0; k < ncodes; k++) { orc[k] = cc; ops[k] = OP_EQ; ks[k] = kstr(codes[k]); }
+    const int64_t nin = oracle_select_or(orc, ops, ks, ncodes, NULL, n, in_sel);
+    /* the scalar subquery */
+    ocol bal = mkcol(OT_DECIMAL, 2, c_acctbal);
+    oconst zero; memset(&zero, 0, sizeof zero); zero.type = OT_FLOAT; zero.f = 0.00;
+    const int64_t npos = oracle_select(&bal, OP_GT, &zero, in_sel, nin, s1);
+    static const int32_t one = 1;
+    ocol k1[1] = {mkcol(OT_CONST32, 0, &one)};
+    ocol a1[1] = {mkcol(OT_ODEC, 0, NULL)};
+    oaggspec av[1] = {{OA_AVG, 0}};
+    oagg *ta = oracle_agg_create(k1, 1, a1, av, 1);
+    static odec v[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < npos && rc == 0; base += VS) {
+        int64_t cnt = npos - base < VS ? npos - base : VS;
+        for (int64_t j = 0; j < cnt; j++) odec_new(c_acctbal[s1[base + j]], 2, &v[j]);
+        ocol keys[1] = {mkcol(OT_CONST32, 0, &one)};
+        ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+        rc = oracle_agg_sink(ta, keys, args, NULL, cnt);
+    }
+    int64_t nout = -1;
+    oaggval avg;
+    memset(&avg, 0, sizeof avg);
+    if (rc == 0 && oracle_agg_count(ta) == 1) { int64_t kv[1]; oracle_agg_group(ta, 0, NULL, kv, NULL, &avg); }
+    oracle_agg_free(ta);
+    if (rc == 0 && avg.kind == OV_DECIMAL) {
+        /* c_acctbal > avg (exact), then the ANTI join */
+        int64_t nf = 0;
+        for (int64_t j = 0; j < nin; j++) {
+            odec b;
+            odec_new(c_acctbal[in_sel[j]], 2, &b);
+            if (odec_cmp(b, avg.d) > 0) s2[nf++] = in_sel[j];
+        }
+        ocol ok = mkcol(OT_INT32, 0, T->o_custkey);
+        ojoin *jo = oracle_join_build(&ok, 1, NULL, T->n_orders);
+        uint8_t *found = (uint8_t *)malloc((size_t)(nf > 0 ? nf : 1));
+        ocol ck = mkcol(OT_INT32, 0, T->c_custkey);
+        oracle_join_probe_mark(jo, &ck, 1, s2, nf, found);
+        oracle_join_free(jo);
+        ocol kp[1] = {cc};
+        kp[0].data = NULL;
+        oaggspec ag[2] = {{OA_COUNT, -1}, {OA_SUM, 0}};
+        oagg *t = oracle_agg_create(kp, 1, a1, ag, 2);
+        uint8_t kc[VS];
+        int64_t fill = 0;
+        for (int64_t j = 0; j <= nf && rc == 0; j++) {
+            if (j < nf && !found[j]) { kc[fill] = code[s2[j]]; odec_new(c_acctbal[s2[j]], 2, &v[fill]); fill++; }
+            if (fill == VS || (j == nf && fill > 0)) {
+                ocol keys[1] = {cc};
+                keys[0].data = kc;
+                ocol args[1] = {mkcol(OT_ODEC, 0, v)};
+                rc = oracle_agg_sink(t, keys, args, NULL, fill);
+                fill = 0;
+            }
+        }
+        nout = rc ? -1 : oracle_agg_count(t);
+        for (int64_t g = 0; g < nout && g < max; g++) {
+            int64_t kv[1];
+            oaggval val[2];
+            oracle_agg_group(t, g, NULL, kv, NULL, val);
+            memset(out[g].cntrycode, 0, sizeof out[g].cntrycode);
+            strncpy(out[g].cntrycode, dict[kv[0]], 3);
+            out[g].numcust = val[0].h;
+            out[g].totacctbal = val[1].d;
+        }
+        oracle_agg_free(t);
+        free(found);
+    }
+    free(code); free(in_sel); free(s1); free(s2);
+    return nout;
+}
+
 /* ------------------------------------------------------------------ text */
 /* extract(year from date): Date.Year (pkg/common/date.go) */
 static int32_t year_of_days2(int32_t z) {
@@ -1157,5 +1264,25 @@ int64_t oracle_q15_text(const oracle_q15_row *rows, int64_t n, const int32_t *s_
         memcpy(t, phone_bytes + 15 * r, 15); t[15] = 0; put(&s, t); put(&s, "\t");
         oracle_format_decimal(rows[i].total_revenue, 4, t); put(&s, t); put(&s, "\n");
     }
+    return done(&s);
+}
+
+int64_t oracle_q22_text(oracle_q22_row *rows, int64_t n, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\t\n");
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) {   /* ORDER BY cntrycode: byte order of the strings */
+        int64_t j = i;
+        while (j > 0 && strcmp(rows[ord[j - 1]].cntrycode, rows[i].cntrycode) > 0) { ord[j] = ord[j - 1]; j--; }
+        ord[j] = i;
+    }
+    char t[64];
+    for (int64_t i = 0; i < n; i++) {
+        const oracle_q22_row *r = &rows[ord[i]];
+        put(&s, r->cntrycode); put(&s, "\t");
+        oracle_format_hugeint(r->numcust, t); put(&s, t); put(&s, "\t");
+        oracle_format_decimal(r->totacctbal, 2, t); put(&s, t); put(&s, "\n");
+    }
+    free(ord);
     return done(&s);
 }

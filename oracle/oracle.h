@@ -368,6 +368,11 @@ typedef struct { int32_t s_suppkey; odec total_revenue; } oracle_q15_row;
 int64_t oracle_q15(const oracle_tpch *T, int32_t date_ge, int32_t date_lt, oracle_q15_row *out, int64_t max);
 int64_t oracle_q15_text(const oracle_q15_row *rows, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes,
                         const char *phone_bytes, char *buf, int64_t cap);
+/* Q22 (cases/tpch/query/q22.sql): c_phone = 15 bytes per customer row, c_acctbal unscaled at scale 2, codes = the IN list */
+typedef struct { char cntrycode[4]; ohuge numcust; odec totacctbal; } oracle_q22_row;
+int64_t oracle_q22(const oracle_tpch *T, const char *c_phone, const int64_t *c_acctbal, const char *const *codes, int32_t ncodes,
+                   oracle_q22_row *out, int64_t max);
+int64_t oracle_q22_text(oracle_q22_row *rows, int64_t n, char *buf, int64_t cap);   /* ORDER BY cntrycode */
 /* Q17 (cases/tpch/query/q17.sql): 0 ok / 1 the sum is NULL / -1 error; avg_yearly = float32(sum) / divisor, the threshold fraction * avg in float64 */
 int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out);
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);

@@ -56,6 +56,8 @@
 /* round 3, Q15's select list: s_address = a v-string of 10..40 characters (1 draw for the length + 1 per 5 characters: 9 per row),
  * s_phone = country code 10 + nation, then three draws. Pinned by the publicly known first rows of supplier.tbl
  * (tests/test_tpchgen.py) and by the row cases/tpch/1g/plan/q15.txt prints. */
+#define SD_C_PHNE 1521138112LL      /* c_phone: 3 per customer; c_acctbal: 1 — Q22; pinned by the public first rows of customer.tbl and q22.txt */
+#define SD_C_ABAL 298370230LL
 #define SD_S_ADDR 706178559LL
 #define SD_S_PHNE 884434366LL
 
@@ -401,17 +403,28 @@ int64_t tpchgen_orders(int64_t num, int64_t den, int64_t first, int64_t n,
 int64_t tpchgen_customer(int64_t num, int64_t den, int64_t first, int64_t n,
                          const tpchgen_customer_cols *out) {
     (void)num; (void)den;
-    stream_t ntrg, mseg;
+    stream_t ntrg, mseg, phne, abal;
     stream_init(&ntrg, SD_C_NTRG, 1, first);
     stream_init(&mseg, SD_C_MSEG, 1, first);
+    stream_init(&phne, SD_C_PHNE, 3, first);
+    stream_init(&abal, SD_C_ABAL, 1, first);
     for (int64_t i = 0; i < n; i++) {
         int64_t nation = stream_int(&ntrg, 0, 24);
         int64_t seg = stream_int(&mseg, 0, 4);
         if (out->c_custkey) out->c_custkey[i] = (int32_t)(first + i + 1);
         if (out->c_nationkey) out->c_nationkey[i] = (int32_t)nation;
         if (out->c_mktsegment) out->c_mktsegment[i] = MSEG_GEN_TO_CODE[seg];
+        if (out->c_phone) {
+            const int ac = (int)stream_int(&phne, 100, 999), ex = (int)stream_int(&phne, 100, 999), nr = (int)stream_int(&phne, 1000, 9999);
+            char buf[24];
+            snprintf(buf, sizeof buf, "%02d-%03d-%03d-%04d", (int)(10 + nation), ac, ex, nr);
+            memcpy(out->c_phone + TPCHGEN_S_PHONE_LEN * i, buf, TPCHGEN_S_PHONE_LEN);
+        }
+        if (out->c_acctbal) out->c_acctbal[i] = stream_int(&abal, -99999, 999999);   /* cents */
         stream_row_done(&ntrg);
         stream_row_done(&mseg);
+        stream_row_done(&phne);
+        stream_row_done(&abal);
     }
     return n;
 }

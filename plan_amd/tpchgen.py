@@ -94,7 +94,7 @@ _LINEITEM = [("l_orderkey", np.int64), ("l_partkey", np.int32), ("l_suppkey", np
              ("l_commitdate", np.int32), ("l_receiptdate", np.int32), ("l_shipinstruct", np.uint8), ("l_shipmode", np.uint8)]
 _ORDERS = [("o_orderkey", np.int64), ("o_custkey", np.int32), ("o_orderdate", np.int32),
            ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8), ("o_orderpriority", np.uint8)]
-_CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8)]
+_CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8), ("c_phone", np.uint8), ("c_acctbal", np.int64)]
 _PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8), ("p_brand", np.uint8), ("p_type", np.uint8), ("p_size", np.int32),
          ("p_container", np.uint8)]
 _PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64), ("ps_availqty", np.int32)]
@@ -148,7 +148,10 @@ def customer(sf, first=0, n=None, columns=None):
     """c_name is 'Customer#' + the key as nine digits (TPC-H 4.2.3): derived here as offsets + bytes (c_name_off / c_name_bytes)"""
     if n is None:
         n = int(lib().tpchgen_customer_count(_i64(sf[0]), _i64(sf[1]))) - first
-    cols = _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns)
+    cols = _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns, width={"c_phone": 15})
+    if "c_phone" in cols:
+        cols["c_phone_bytes"] = cols.pop("c_phone")
+        cols["c_phone_off"] = np.arange(0, 15 * (n + 1), 15, dtype=np.int32)
     if columns is None or "c_name" in columns:
         keys = np.arange(first + 1, first + n + 1, dtype=np.int64)
         buf = np.empty((n, 18), dtype=np.uint8)

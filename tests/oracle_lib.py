@@ -633,6 +633,30 @@ def q14_text(t, pattern, date_ge, date_lt):
     return _text("oracle_q14_text", ctypes.c_float(f), i32(rc))
 
 
+Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
+
+
+class Q22Row(ctypes.Structure):
+    _fields_ = [("cntrycode", ctypes.c_char * 4), ("numcust", OHuge), ("totacctbal", ODec)]
+
+
+def q22_rows(t, codes=Q22_CODES):
+    T, keep = tpch_struct(t)
+    C = t["customer"]
+    ph, bal = np.ascontiguousarray(C["c_phone_bytes"]), np.ascontiguousarray(C["c_acctbal"])
+    arr = (ctypes.c_char_p * len(codes))(*[c.encode() for c in codes])
+    rows = (Q22Row * 32)()
+    lib().oracle_q22.restype = i64
+    n = lib().oracle_q22(ctypes.byref(T), ctypes.c_void_p(ph.ctypes.data), ctypes.c_void_p(bal.ctypes.data), arr, i32(len(codes)), rows, i64(32))
+    assert 0 <= n <= 32
+    return rows, n
+
+
+def q22_text(t, codes=Q22_CODES):
+    rows, n = q22_rows(t, codes)
+    return _text("oracle_q22_text", rows, i64(n))
+
+
 class Q15Row(ctypes.Structure):
     _fields_ = [("s_suppkey", i32), ("total_revenue", ODec)]
 

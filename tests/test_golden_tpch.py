@@ -86,6 +86,12 @@ def test_q15_matches_reference_golden(sf1):
     assert O.q15_text(sf1, tpchgen.days(1995, 12, 1), tpchgen.days(1996, 3, 1)) == golden("plan_q15.txt")
 
 
+def test_q22_matches_reference_golden(sf1):
+    # substring() as a filter operand and as the group key (pins oracle_substring with a reference fixture), IN over VARCHAR, avg(DECIMAL) as a
+    # scalar subquery compared DECIMAL > DECIMAL, DECIMAL > FLOAT literal, NOT EXISTS as an ANTI join; pins the generator's c_phone / c_acctbal
+    assert O.q22_text(sf1) == golden("plan_q22.txt")
+
+
 def test_q17_matches_reference_golden(sf1):
     # a correlated subquery decorrelated into an aggregate by its key (avg(INTEGER) = float64), joined back; FLOAT literal x DOUBLE =
     # float64 arithmetic and the DOUBLE '<'; sum(DECIMAL) / 7.0 in float32

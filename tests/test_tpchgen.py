@@ -62,3 +62,13 @@ def test_supplier_address_and_phone_first_rows():
     assert S["s_nationkey"].tolist() == [17, 5, 1]
     S = g.supplier(SF1, 7894, 1)
     assert (strs(S, "s_address"), strs(S, "s_phone")) == (["NYl,i8UhxTykLxGJ2voIRn20Ugk1KTzz"], ["14-559-808-3306"])
+
+
+def test_customer_phone_and_acctbal_first_rows():
+    """customer.tbl at SF1 as publicly known: 1|..|15|25-989-741-2988|711.56|BUILDING|, 2|..|13|23-768-687-3665|121.65|AUTOMOBILE|,
+    3|..|1|11-719-748-3364|7498.12|AUTOMOBILE|, 4|..|4|14-128-190-5944|2866.83|MACHINERY|, 5|..|3|13-750-942-6364|794.47|HOUSEHOLD|"""
+    C = g.customer(SF1, 0, 5)
+    b = C["c_phone_bytes"].tobytes()
+    assert [b[i * 15:(i + 1) * 15].decode() for i in range(5)] == ["25-989-741-2988", "23-768-687-3665", "11-719-748-3364", "14-128-190-5944", "13-750-942-6364"]
+    assert C["c_acctbal"].tolist() == [71156, 12165, 749812, 286683, 79447]
+    assert C["c_nationkey"].tolist() == [15, 13, 1, 4, 3]
