@@ -670,11 +670,17 @@ typedef enum {
     PH_PE_COL = 1,    /* column reference (executeColumnRef: zero copy) */
     PH_PE_DECIMAL,    /* decimal / integer arithmetic, RPN over the child's output columns (executeFunc) */
     PH_PE_YEAR,       /* extract(year from <DATE column>)  (ExtractFunc, function_scalar.go:1509-1563) */
-    PH_PE_CASE        /* CASE WHEN <when> THEN <prog> ELSE <else_prog> END (executeCase, expr_exec.go:144-246):
+    PH_PE_CASE,       /* CASE WHEN <when> THEN <prog> ELSE <else_prog> END (executeCase, expr_exec.go:144-246):
                          the WHEN is a select, THEN is evaluated on its true rows and ELSE on the others
                          (FillSwitch, :559-606). Both branches are DECIMAL programs of ONE result scale (an integer
                          constant in a branch — `ELSE 0` — is cast to it), or — result_int != 0 — both INTEGER
                          constants. */
+    PH_PE_SUBSTR      /* substring(<VARCHAR table column col> FROM sub_offset FOR sub_length) (substringFunc,
+                         function_operator_binary.go:553-625; ph_substring). The value is VARCHAR computed inside the plan:
+                         it may be compared with VARCHAR constants by = / <> in a PH_PN_FILTER above (an IN list is their OR),
+                         be a group key or pass through joins; as a group key it is reported as PH_STR by ph_plan_key_info,
+                         whose table is then a one-column relation the PLAN owns (valid until the plan runs again or is
+                         freed): the key values are its rows, ph_table_strings reads them. */
 } ph_plan_expr_kind;
 
 /* A boolean expression over a node's input columns as a flat tree (node 0 = the root): what ExprExec.executeSelect
@@ -701,6 +707,8 @@ typedef struct {
     int32_t nelse;
     ph_rpn else_prog[12];
     int32_t result_int;    /* != 0: THEN / ELSE are single PH_X_CONST programs of scale 0 and the result is INTEGER */
+    /* PH_PE_SUBSTR */
+    int64_t sub_offset, sub_length;   /* as ph_substring's; sub_length = INT64_MAX is the two-argument form */
 } ph_plan_expr;
 
 typedef struct {

@@ -255,6 +255,18 @@ func (b *planBuilder) lowerPlanExpr(e *Expr, nLeft int) (C.ph_plan_expr, bool) {
 		}
 		return x, false
 	}
+	if e.Typ == ET_Func && e.FuncName() == FuncSubstring && len(e.Children) == 3 {
+		// substring(<VARCHAR column> FROM <const> FOR <const>) (substringFunc, function_operator_binary.go:553-625): computed inside the plan
+		// as string codes (PH_PE_SUBSTR); a filter's = / <> / IN against VARCHAR constants and a group key read it
+		col, ok := childColumn(e.Children[0], nLeft)
+		from, length := stripCast(e.Children[1]), stripCast(e.Children[2])
+		if ok && from.Typ == ET_Const && length.Typ == ET_Const {
+			x.kind, x.col = C.PH_PE_SUBSTR, C.int32_t(col)
+			x.sub_offset, x.sub_length = C.int64_t(from.ConstValue.Integer), C.int64_t(length.ConstValue.Integer)
+			return x, true
+		}
+		return x, false
+	}
 	if e.Typ == ET_Func && e.FuncName() == FuncCase && len(e.Children) == 3 {
 		// Children[0] = ELSE, then (WHEN, THEN) pairs (executeCase, expr_exec.go:144-246); one WHEN here
 		var thenP, elseP []C.ph_rpn

@@ -362,6 +362,16 @@ bool DecimalToUnscaled(const Decimal &d, int scale, int64_t *out) {
     return true;
 }
 
+bool DecimalFloorUnscaled(const Decimal &d, int scale, int64_t *out) {
+    u128 c = d.coef;
+    bool inexact = false;
+    if (scale >= d.scale) c *= p10(scale - d.scale);
+    else { inexact = c % p10(d.scale - scale) != 0; c /= p10(d.scale - scale); }
+    if (c >= (u128)INT64_MAX) return false;
+    *out = d.neg ? -(int64_t)c - (inexact ? 1 : 0) : (int64_t)c;
+    return true;
+}
+
 // ------------------------------------------------------------------ dates
 
 int32_t DaysFromDate(const Date &dt) {

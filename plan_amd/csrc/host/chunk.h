@@ -128,6 +128,8 @@ double DecimalToDouble(const Decimal &d);
 std::string DecimalValueString(const Decimal &d, int typeScale);
 // unscaled int64 of a Decimal at `scale` (exact) — what the staging code uploads
 bool DecimalToUnscaled(const Decimal &d, int scale, int64_t *out);
+// floor of the decimal at `scale` as an unscaled int64: for an x with exactly `scale` digits, x > d  <=>  unscaled(x) > floor
+bool DecimalFloorUnscaled(const Decimal &d, int scale, int64_t *out);
 
 int32_t DaysFromDate(const Date &d);
 Date DateFromDays(int32_t days);

@@ -1396,7 +1396,7 @@ static std::string exprType(const ProjExpr &e, const std::vector<LType> &childTy
     std::vector<LType> one;
     std::string err = gpuProjectExecutor::Types({e}, childTypes, &one);
     if (!err.empty()) return err;
-    if (e.kind == ProjExpr::Substring || e.kind == ProjExpr::Float32 || e.kind == ProjExpr::DecimalQuo) return "substring / FLOAT / DECIMAL-division expressions are not part of a resident plan";
+    if (e.kind == ProjExpr::Float32 || e.kind == ProjExpr::DecimalQuo) return "FLOAT / DECIMAL-division expressions are not part of a resident plan";
     *t = one[0];
     *src = e.kind == ProjExpr::ColRef ? childSrc[(size_t)e.col] : nullptr;
     return "";
@@ -1587,6 +1587,7 @@ static ph_plan_expr lowerExpr(const ProjExpr &e, std::vector<std::vector<ph_bool
         break;
     case ProjExpr::ColRef: x.kind = PH_PE_COL; x.col = e.col; break;
     case ProjExpr::ExtractYear: x.kind = PH_PE_YEAR; x.col = e.col; break;
+    case ProjExpr::Substring: x.kind = PH_PE_SUBSTR; x.col = e.col; x.sub_offset = e.offset; x.sub_length = e.length; break;
     default:
         x.kind = PH_PE_DECIMAL; x.col = -1; x.nprog = (int32_t)std::min<size_t>(e.prog.size(), 12);
         for (int i = 0; i < x.nprog; i++) x.prog[i] = e.prog[(size_t)i];

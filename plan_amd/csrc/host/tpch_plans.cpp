@@ -99,9 +99,14 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
     {   // customer
         std::vector<int32_t> key((size_t)nc), nat((size_t)nc);
         std::vector<uint8_t> seg((size_t)nc);
+        std::vector<char> phone((size_t)nc * TPCHGEN_S_PHONE_LEN);
+        std::vector<int64_t> bal((size_t)nc);
+        std::vector<int32_t> poff((size_t)nc + 1);
         tpchgen_customer_cols cc{};
-        cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data();
+        cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data(); cc.c_phone = phone.data(); cc.c_acctbal = bal.data();
         tpchgen_customer(num, den, 0, nc, &cc);
+        for (int64_t r = 0; r <= nc; r++) poff[(size_t)r] = (int32_t)(r * TPCHGEN_S_PHONE_LEN);
+        HostCol phoneCol{VarcharType(), PH_STR, 0, poff.data(), {}, phone.data(), (int64_t)phone.size()};
         // c_name = 'Customer#' + the key as nine digits (TPC-H 4.2.3): 1.5 M distinct strings at SF10, so offsets + bytes, no dictionary
         std::vector<int32_t> off((size_t)nc + 1);
         std::string bytes((size_t)nc * 18, '0');
@@ -114,7 +119,8 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         }
         off[(size_t)nc] = (int32_t)(nc * 18);
         HostCol name{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()};
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5)), name}, nc, {C_CUSTKEY}, &customer, &loaded_bytes);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5)), name, phoneCol, DEC(bal.data())}, nc, {C_CUSTKEY}, &customer,
+                      &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // part: p_name as offsets + bytes (LIKE operand), the other VARCHAR columns as dictionary codes
@@ -171,6 +177,7 @@ static Literal LDays(int32_t days) { Literal k; k.kind = Literal::DateDays; k.i 
 static Literal LStr(const char *s) { Literal k; k.kind = Literal::Str; k.s = s; return k; }
 static Literal LInt(int64_t v) { Literal k; k.kind = Literal::Int; k.i = v; return k; }
 static Literal LFloat(float f) { Literal k; k.kind = Literal::Float; k.f = (double)f; return k; }
+static Literal LDec(int64_t unscaled, int scale) { Literal k; k.kind = Literal::Dec; k.i = unscaled; k.scale = scale; return k; }
 static ph_rpn XC(int c) { return ph_rpn{PH_X_COL, c, 0, 0}; }
 static ph_rpn XK(int64_t v, int s = 0) { return ph_rpn{PH_X_CONST, -1, v, s}; }
 static ph_rpn XO(int op) { return ph_rpn{op, -1, 0, 0}; }
@@ -464,6 +471,34 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 6;
         break;
     }
+    case 22: {
+        // Order(cntrycode) <- Agg(cntrycode; count(*), sum(c_acctbal)) <- ANTI Join(c_custkey = o_custkey) probe Filter(cntrycode IN (..)) <-
+        //   Project(substring(c_phone from 1 for 2) as cntrycode, ..) <- Scan(customer, c_acctbal > scalar), build Scan(orders);
+        //   scalar = Agg(; avg(c_acctbal)) <- Filter(cntrycode IN (..)) <- Project <- Scan(customer, c_acctbal > 0.00 [FLOAT literal: float32 compare])
+        std::vector<Literal> codes;
+        for (const char *c : {"10", "11", "26", "22", "19", "20", "27"}) codes.push_back(LStr(c));
+        q->scalar = std::make_shared<TpchQuery>();
+        q->scalar->id = 22;
+        {
+            ResidentPlan &s = q->scalar->plan;
+            int cust = s.Scan(&db.customer, {C_PHONE, C_ACCTBAL}, {{C_ACCTBAL, PH_GT, LFloat(0.00f)}});
+            int pr = s.Project(cust, {ProjExpr::Substr(0, 1, 2), ProjExpr::Col(1)});
+            int f = s.Filter(pr, {}, BoolExpr::In(0, codes));
+            s.Agg(f, {}, {{PH_A_AVG, {XC(1)}}});
+            q->scalar->ncols = 1;
+            if (!s.error.empty()) return s.error;
+        }
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_PHONE, C_ACCTBAL}, {{C_ACCTBAL, PH_GT, LDec(0, 2)}});   // (the literal: the scalar, at run time)
+        q->scalarScanNode = cust; q->scalarConjunct = 0;
+        int pr = p.Project(cust, {ProjExpr::Col(0), ProjExpr::Substr(1, 1, 2), ProjExpr::Col(2)});
+        int f = p.Filter(pr, {}, BoolExpr::In(1, codes));
+        int ord = p.Scan(&db.orders, {O_CUSTKEY});
+        int j = p.Join(f, ord, {0}, {0}, {1, 2}, JoinAnti);                    // cntrycode, c_acctbal
+        p.Agg(j, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}, {PH_A_SUM, {XC(1)}}});
+        q->order = {{0, false}};
+        q->ncols = 3;
+        break;
+    }
     default:
         return "no resident plan for TPC-H query " + std::to_string(id);
     }
@@ -501,6 +536,7 @@ static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) 
 
 std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
     std::vector<Compare> having = q.having;
+    ResidentPlan mainPlan = q.plan;   // (Q22 patches a scan literal with its scalar subquery's value)
     if (q.scalar) {   // the uncorrelated scalar subquery first: one row, one DECIMAL value
         gpuResidentPlanExecutor sub(ctx, q.scalar->plan);
         std::string e = sub.Init();
@@ -514,12 +550,20 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
         out.Data[0]->ToUnifiedFormat(1, &u);
         const int64_t idx = u.sel->GetIndex(0);
         if (!u.mask->RowIsValid((uint64_t)idx)) { sub.Close(); lines->clear(); return ""; }   // NULL threshold: the comparison selects nothing
-        volatile float v = (float)DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx]);
-        volatile float t = v * q.scalarFactor;
+        const Decimal sv = reinterpret_cast<const Decimal *>(u.data)[idx];
         sub.Close();
-        having.push_back(Compare{q.havingCol, PH_GT, LFloat((float)t)});
+        if (q.scalarScanNode >= 0) {
+            Compare &c = mainPlan.nodes[(size_t)q.scalarScanNode].conjuncts[(size_t)q.scalarConjunct];
+            int64_t fl = 0;
+            if (!DecimalFloorUnscaled(sv, c.k.scale, &fl)) return "scalar subquery: value out of range";
+            c.k.i = fl;
+        } else {
+            volatile float v = (float)DecimalToDouble(sv);
+            volatile float t = v * q.scalarFactor;
+            having.push_back(Compare{q.havingCol, PH_GT, LFloat((float)t)});
+        }
     }
-    gpuResidentPlanExecutor agg(ctx, q.plan);
+    gpuResidentPlanExecutor agg(ctx, mainPlan);
     if (!having.empty()) agg.SetHaving(having);
     if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
     if (q.topkAgg >= 0 && q.limit > 0) agg.SetTopK(q.topkAgg, q.topkDesc, q.limit);

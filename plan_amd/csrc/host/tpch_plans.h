@@ -18,7 +18,7 @@ namespace plan {
 enum { L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE,
        L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE, L_SHIPINSTRUCT };
 enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TOTALPRICE };
-enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME };
+enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME, C_PHONE, C_ACCTBAL };
 enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
 enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST, PS_AVAILQTY };
 enum { S_SUPPKEY, S_NATIONKEY };
@@ -53,6 +53,10 @@ struct TpchQuery {
     std::shared_ptr<TpchQuery> scalar;
     float scalarFactor = 0;
     int havingCol = -1;
+    // ... or the scalar is the right side of a DECIMAL > DECIMAL conjunct pushed into a scan of the main plan (Q22: c_acctbal > (select
+    // avg(c_acctbal) ..)): conjunct scalarConjunct of node scalarScanNode gets floor(value) at the column's scale as its literal
+    // (greatDecimalOp is exact: for a column with `scale` digits, x > v  <=>  unscaled(x) > floor(v * 10^scale))
+    int scalarScanNode = -1, scalarConjunct = -1;
     // operators ABOVE the resident plan whose expressions are DOUBLE / FLOAT arithmetic (Q17): a Filter with a DOUBLE predicate over
     // the plan's result rows (doubleFilterExecutor), then an ungrouped aggregate over what passes (gpuAggExecutor) with its output
     // expressions

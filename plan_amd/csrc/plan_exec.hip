@@ -45,6 +45,8 @@ struct PCol {                       // an output column of a relation
     int src_col = -1;
     bool ordered = false;           // values are non-decreasing in the relation's row order
     int domain = -1;                // index into ph_plan::domains: the values are a subset of that join table's keys
+    ph_strdict *sdict = nullptr;    // a VARCHAR value COMPUTED in the plan (substring): the values are int32 codes of this dictionary,
+                                    // a code = the row of `src` (a one-column relation the plan owns) that holds the string
 };
 
 struct Lane {
@@ -107,6 +109,8 @@ struct ph_plan {
     std::vector<ph_join *> joins;
     std::vector<ph_strdict *> strdicts;
     std::vector<ph_agg *> inner_aggs;   // aggregates below other operators
+    std::vector<ph_table *> computed;   // one-column relations of computed VARCHAR values: like the aggregate they outlive the fetch (the host
+    std::vector<void *> computed_bufs;  // reads a group key's strings from them) and go with the next run
     std::vector<Domain> domains;
     ph_agg *agg = nullptr;
     ph_scan_plan *scan = nullptr;       // Agg <- Scan: the fused scan plan
@@ -153,6 +157,10 @@ void release_run(ph_plan *p, bool keep_agg) {
     p->temps.clear();
     if (!keep_agg) {
         if (p->agg) { ph_agg_free(p->agg); p->agg = nullptr; }
+        for (ph_table *vt : p->computed) delete vt;
+        p->computed.clear();
+        for (void *q : p->computed_bufs) p->ctx->pool_release(q);
+        p->computed_bufs.clear();
     }
 }
 
@@ -195,6 +203,7 @@ void fix_dict_const(const ph_table *t, int tcol, ph_const *k) {
 }
 
 int positional(ph_plan *p, Rel *r, const std::vector<int> &want);
+int const_code(ph_plan *p, ph_strdict *d, const char *s, int32_t *code);
 
 // the reference's LIKE (likeOp: % = any run, _ = any one byte), for patterns applied to a DICTIONARY on the host
 bool host_like(const char *s, size_t sl, const char *pat, size_t pl) {
@@ -273,6 +282,14 @@ int eval_bool(ph_plan *p, Rel *r, bool table_mode, const BoolTree &bt, int idx, 
             }
             if (sels.size() == 1) { out = const_cast<int32_t *>(sels[0]); m = counts[0]; }
             else if (!sels.empty()) PL_CHECK(ph_sel_union(ctx, sels.data(), counts.data(), (int32_t)sels.size(), N, (int32_t *)out, &m));
+        } else if (!table_mode && r->cols[(size_t)b.col].sdict && k.type == PH_STR) {
+            // a computed VARCHAR column (codes) against a VARCHAR constant: `=` / `<>` on the constant's code (equalStrOp / notEqualStrOp)
+            if (b.op != PH_EQ && b.op != PH_NE) { set_error("ph_plan: only = / <> over a computed VARCHAR column"); return PH_EUNSUPPORTED; }
+            int32_t code = -2;
+            PL_CHECK(const_code(p, r->cols[(size_t)b.col].sdict, k.s, &code));
+            ph_const kc{};
+            kc.type = PH_I32; kc.i = code;
+            PL_CHECK(ph_filter_select(ctx, &v, N, b.op, &kc, sel_in, n_in, (int32_t *)out, &m));
         } else {
             fix_dict_const(dt, dc, &k);
             fix_num_const(v, &k);
@@ -608,10 +625,67 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
         out->ordered = r->cols[(size_t)e.col].ordered;   // the year of a non-decreasing date is non-decreasing
         return PH_OK;
     }
+    case PH_PE_SUBSTR: {
+        // substring(<VARCHAR table column> FROM offset FOR length): the result is interned at once — a positional int32 column of
+        // string codes (equal strings, equal codes: what a filter's `=`, a group key and a join key need) whose dictionary rows are the
+        // substrings themselves, kept as a one-column relation the plan owns so that a code leads back to its bytes (ph_table_strings)
+        if (e.col < 0 || e.col >= (int)r->cols.size()) { set_error("ph_plan: column %d out of range", e.col); return PH_EINVAL; }
+        PL_CHECK(apply_pending(p, r));
+        const PCol &pc = r->cols[(size_t)e.col];
+        if (pc.type != PH_STR || pc.lane < 0) { set_error("ph_plan: substring needs a VARCHAR table column"); return PH_EUNSUPPORTED; }
+        const Lane &ln = r->lanes[(size_t)pc.lane];
+        ph_col v = table_view(ln.t, pc.tcol);
+        const int64_t n = r->n;
+        int64_t cap = v.aux_bytes + 64;
+        if (e.sub_length >= 0 && e.sub_length <= 256) cap = std::min(cap, n * e.sub_length + 64);   // (row ids may repeat below a join: length bounds it)
+        else if (ln.rows && !ln.dup_free) { set_error("ph_plan: unbounded substring over repeated rows"); return PH_EUNSUPPORTED; }
+        void *off = nullptr, *bytes = nullptr, *codes = nullptr;
+        PL_CHECK(p->ctx->pool_alloc((n + 1) * 4, &off));
+        p->computed_bufs.push_back(off);
+        PL_CHECK(p->ctx->pool_alloc(cap, &bytes));
+        p->computed_bufs.push_back(bytes);
+        PL_CHECK(palloc(p, std::max<int64_t>(n, 1) * 4, &codes));
+        int64_t nbytes = 0;
+        PL_CHECK(ph_substring(p->ctx, &v, e.sub_offset, e.sub_length, ln.rows, n, (int32_t *)off, (uint8_t *)bytes, cap, &nbytes));
+        ph_table *vt = new ph_table();
+        vt->ctx = p->ctx;
+        vt->nrows = n;
+        vt->cols.resize(1);
+        vt->cols[0].type = PH_STR; vt->cols[0].data = off; vt->cols[0].aux = bytes; vt->cols[0].aux_bytes = nbytes;
+        vt->cols[0].validity = nullptr;
+        p->computed.push_back(vt);
+        if (v.validity) { set_error("ph_plan: substring over a NULL-able column"); return PH_EUNSUPPORTED; }
+        ph_col sv = table_view(vt, 0);
+        ph_strdict *d = nullptr;
+        PL_CHECK(ph_strdict_build(p->ctx, &sv, nullptr, n, (int32_t *)codes, &d));
+        p->strdicts.push_back(d);
+        *out = PCol{};
+        out->type = PH_I32; out->data = codes;
+        out->src = vt; out->src_col = 0;
+        out->sdict = d;
+        return PH_OK;
+    }
     default:
         set_error("ph_plan: unknown expression kind %d", e.kind);
         return PH_EINVAL;
     }
+}
+
+// a VARCHAR constant compared with a computed VARCHAR column: its code in the column's dictionary (-2 = no row holds that string:
+// `=` selects nothing, `<>` everything — codes are >= 0)
+int const_code(ph_plan *p, ph_strdict *d, const char *s, int32_t *code) {
+    const int64_t len = s ? (int64_t)strlen(s) : 0;
+    void *off = nullptr, *bytes = nullptr, *out = nullptr;
+    PL_CHECK(palloc(p, 8, &off));
+    PL_CHECK(palloc(p, len + 64, &bytes));
+    PL_CHECK(palloc(p, 8, &out));
+    const int32_t offs[2] = {0, (int32_t)len};
+    PL_CHECK(ph_dev_upload(p->ctx, off, offs, 8));
+    if (len > 0) PL_CHECK(ph_dev_upload(p->ctx, bytes, s, len));
+    ph_col c{};
+    c.type = PH_STR; c.data = off; c.aux = bytes; c.aux_bytes = len;
+    PL_CHECK(ph_strdict_lookup(d, &c, nullptr, 1, (int32_t *)out));
+    return p->ctx->download(code, out, 4);
 }
 
 // ---- VARCHAR keys: a PH_STR column of the relation becomes a positional int32 column of string codes (ph_strdict_*):
@@ -1290,7 +1364,7 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
             if (nd.groups[g].e.kind != PH_PE_COL) { set_error("ph_plan: VARCHAR group key must be a column"); return PH_EUNSUPPORTED; }
             PL_CHECK(string_codes(p, &R, nd.groups[g].e.col, nullptr, nullptr, &kc[g]));
             str_key[g] = true;
-        }
+        } else if (kc[g].sdict) str_key[g] = true;   // a computed VARCHAR (already codes): reported as PH_STR, its strings are rows of kc[g].src
     }
     for (size_t a = 0; a < nd.aggs.size(); a++) {
         if (nd.aggs[a].kind == PH_A_COUNT_STAR) continue;

@@ -788,6 +788,7 @@ PH_STAT_ASCENDING, PH_STAT_STRICT, PH_STAT_DECLARED_UNIQUE = 1, 2, 4
 
 
 PH_PE_CASE = 4
+PH_PE_SUBSTR = 5
 PH_B_CMP, PH_B_AND, PH_B_OR = 1, 2, 3
 PH_COLREF = 9
 
@@ -798,7 +799,7 @@ class Bool(ctypes.Structure):
 
 class PlanExpr(ctypes.Structure):
     _fields_ = [("kind", i32), ("col", i32), ("nprog", i32), ("prog", Rpn * 12), ("nwhen", i32), ("when", ctypes.POINTER(Bool)),
-                ("nelse", i32), ("else_prog", Rpn * 12), ("result_int", i32)]
+                ("nelse", i32), ("else_prog", Rpn * 12), ("result_int", i32), ("sub_offset", i64), ("sub_length", i64)]
 
 
 def bool_tree(expr):
@@ -857,6 +858,13 @@ def pe_col(c):
 def pe_year(c):
     e = PlanExpr()
     e.kind, e.col = PH_PE_YEAR, c
+    return e
+
+
+def pe_substr(c, offset, length):
+    """substring(<VARCHAR column c> FROM offset FOR length): a VARCHAR computed in the plan (filter by = / <> / IN, group key)"""
+    e = PlanExpr()
+    e.kind, e.col, e.sub_offset, e.sub_length = PH_PE_SUBSTR, c, offset, length
     return e
 
 
@@ -1026,11 +1034,11 @@ def plan_key_info(plan, k):
 
 
 def table_strings(ctx, table, c, rows):
-    """strings of the given rows of PH_STR column c (ph_table_strings)"""
+    """strings of the given rows of PH_STR column c (ph_table_strings); `table` is a Table or the raw handle plan_key_info returned"""
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     n = len(rows)
     off = np.zeros(n + 1, np.int32)
     cap = 1 << 20
     buf = ctypes.create_string_buffer(cap)
-    check(lib().ph_table_strings(ctx.h, table.h, i32(c), vp(rows.ctypes.data), i64(n), vp(off.ctypes.data), buf, i64(cap)))
+    check(lib().ph_table_strings(ctx.h, table.h if hasattr(table, "h") else vp(table), i32(c), vp(rows.ctypes.data), i64(n), vp(off.ctypes.data), buf, i64(cap)))
     return [buf.raw[off[i]:off[i + 1]].decode() for i in range(n)]

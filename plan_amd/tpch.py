@@ -24,7 +24,7 @@ SCHEMA = {
                ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT),
                ("o_totalprice", hip.PH_DEC64, 2, None)],
     "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT),
-                 ("c_name", hip.PH_STR, 0, None)],
+                 ("c_name", hip.PH_STR, 0, None), ("c_phone", hip.PH_STR, 0, None), ("c_acctbal", hip.PH_DEC64, 2, None)],
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
              ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
     "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None), ("ps_availqty", hip.PH_I32, 0, None)],
@@ -385,6 +385,55 @@ def q15_text(db, rows, supp_keys, scale=4):
     for i, (k, v) in enumerate(rows):
         out.append(f"{k}\t{cols[0][i]}\t{cols[1][i]}\t{cols[2][i]}\t{dec_text(v, scale)}")
     return "\n".join(out) + "\n"
+
+
+Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
+
+
+def _q22_in(col, codes):
+    return hip.bool_tree(("or",) + tuple(("cmp", col, hip.PH_EQ, _s(c)) for c in codes))
+
+
+def q22_scalar_plan(db, codes=Q22_CODES):
+    """cases/tpch/query/q22.sql, the scalar subquery: avg(c_acctbal) over customer[c_acctbal > 0.00 (a FLOAT literal: float32 compare),
+       substring(c_phone from 1 for 2) IN (..)] as its SUM and COUNT — avg(DECIMAL) is the quotient of the two (q22_threshold)"""
+    p = hip.Plan(db.ctx)
+    cust = p.scan(db.t("customer"), db.c("customer", "c_phone", "c_acctbal"), [_pred(db, "customer", "c_acctbal", hip.PH_GT, _k(hip.PH_F32, f=0.00))])
+    pr = p.project(cust, [hip.pe_substr(0, 1, 2), hip.pe_col(1)])
+    f = p.filter(pr, bools=_q22_in(0, codes))
+    p.agg(f, [], [(hip.PH_A_SUM, hip.pe_col(1)), (hip.PH_A_COUNT, hip.pe_col(1))])
+    return p.create()
+
+
+def q22_threshold(r):
+    """c_acctbal (scale 2) > avg  <=>  unscaled c_acctbal > floor(sum / count): the comparison is DECIMAL > DECIMAL, exact (greatDecimalOp), and the
+       19-digit quotient lies strictly between two cents unless it is a whole number of cents — either way the floor decides"""
+    if r["ngroups"] == 0 or r["count"][0][1] == 0:
+        return None
+    return r["sum"][0][0] // r["count"][0][1]
+
+
+def q22_plan(db, threshold, codes=Q22_CODES):
+    """Agg(cntrycode; count(*), sum(c_acctbal)) <- ANTI Join(c_custkey = o_custkey) probe Filter(cntrycode IN (..)) <- Project(substring) <-
+       Scan(customer, c_acctbal > avg), build Scan(orders)"""
+    p = hip.Plan(db.ctx)
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_phone", "c_acctbal"),
+                  [_pred(db, "customer", "c_acctbal", hip.PH_GT, _k(hip.PH_DEC64, i=threshold, scale=2))])
+    pr = p.project(cust, [hip.pe_col(0), hip.pe_substr(1, 1, 2), hip.pe_col(2)])
+    f = p.filter(pr, bools=_q22_in(1, codes))
+    orders = p.scan(db.t("orders"), db.c("orders", "o_custkey"))
+    j = p.join(f, orders, [0], [0], [1, 2], join_type=hip.PH_JT_ANTI)          # cntrycode, c_acctbal
+    p.agg(j, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None), (hip.PH_A_SUM, hip.pe_col(1))])
+    return p.create()
+
+
+def q22_text(db, p, r):
+    """ORDER BY cntrycode + the reference's text; the group key is a VARCHAR computed in the plan: its strings are rows of a relation the plan owns"""
+    typ, _sc, tab, col = hip.plan_key_info(p, 0)
+    assert typ == hip.PH_STR
+    names = hip.table_strings(db.ctx, tab, col, [int(r["keys"][g][0]) for g in range(r["ngroups"])])
+    rows = sorted((names[g], int(r["count"][g][0]), r["sum"][g][1]) for g in range(r["ngroups"]))
+    return "#\t\t\n" + "".join(f"{c}\t{n}\t{dec_text(v, 2)}\n" for c, n, v in rows)
 
 
 def q17_plan(db, brand="Brand#54", container="LG BAG"):

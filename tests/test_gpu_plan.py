@@ -310,6 +310,55 @@ def test_q15_cte_maximum_and_supplier_strings_match_golden(ctx, db, sf1):
     assert tpch.q15_text(db, rows, sf1["supplier"]["s_suppkey"], r["scale"][0]) == golden("plan_q15.txt"), ex
 
 
+def test_q22_substring_keys_anti_join_and_scalar_average_match_golden(ctx, db, sf1):
+    """Q22: substring() computed in the plan as a filter operand (IN = OR of =) and as the group key, a scalar avg(DECIMAL) subquery as its own
+    plan, DECIMAL > DECIMAL as an exact threshold, NOT EXISTS as an ANTI join: the oracle's groups and cases/tpch/1g/plan/q22.txt"""
+    s = tpch.q22_scalar_plan(db)
+    s.run()
+    thr = tpch.q22_threshold(s.fetch())
+    s.free()
+    p = tpch.q22_plan(db, thr)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    text = tpch.q22_text(db, p, r)
+    p.free()
+    orows, n = O.q22_rows(sf1)
+    assert r["ngroups"] == n, ex
+    assert text == golden("plan_q22.txt"), ex
+
+
+@pytest.mark.parametrize("offset,length,op", [(1, 3, hip.PH_NE), (-4, 3, hip.PH_EQ), (3, 5, hip.PH_NE)])
+def test_plan_substring_as_filter_operand_and_group_key_matches_oracle(ctx, db, sf1, offset, length, op):
+    """PH_PE_SUBSTR on its own: substring(p_name ..) with a positive and a negative offset, = and <> against a constant, as the group key of
+    count(*) / sum(p_size) — against oracle_substring over the same strings (the reference semantics: function_operator_binary.go:553-625)"""
+    P = sf1["part"]
+    off, by = P["p_name_off"], P["p_name_bytes"].tobytes()
+    subs = [O.substring(by[off[i]:off[i + 1]], offset, length) for i in range(20000)]
+    k = max(set(subs), key=subs.count)                       # the most frequent value as the constant
+    keep = [(s == k) == (op == hip.PH_EQ) for s in subs]
+    want = {}
+    for i, s in enumerate(subs):
+        if keep[i]:
+            c, v = want.get(s, (0, 0))
+            want[s] = (c + 1, v + int(P["p_size"][i]))
+    p = hip.Plan(ctx)
+    part = p.scan(db.t("part"), db.c("part", "p_name", "p_size", "p_partkey"), [hip.pred(db.c("part", "p_partkey")[0], hip.PH_LE, hip.const(hip.PH_I32, i=20000))])
+    pr = p.project(part, [hip.pe_substr(0, offset, length), hip.pe_col(1)])
+    f = p.filter(pr, bools=hip.bool_tree(("cmp", 0, op, hip.const(hip.PH_STR, s=k.decode()))))
+    p.agg(f, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None), (hip.PH_A_SUM, hip.pe_col(1))])
+    p.create()
+    p.run()
+    r = p.fetch()
+    typ, _sc, tab, col = hip.plan_key_info(p, 0)
+    assert typ == hip.PH_STR
+    names = hip.table_strings(ctx, tab, col, [int(r["keys"][g][0]) for g in range(r["ngroups"])])
+    got = {names[g].encode(): (int(r["count"][g][0]), r["sum"][g][1]) for g in range(r["ngroups"])}
+    ex = p.explain()
+    p.free()
+    assert got == want, ex
+
+
 def test_q17_decorrelated_average_joined_back_matches_golden(ctx, db, sf1):
     """Q17: an aggregate by the correlation key below a join whose payload is its SUM and COUNT; the DOUBLE predicate and the float32
     division over the fetched groups: the oracle's exact sum and cases/tpch/1g/plan/q17.txt"""
