@@ -771,6 +771,101 @@ int64_t oracle_q22(const oracle_tpch *T, const char *c_phone, const int64_t *c_a
     return nout;
 }
 
+/* ------------------------------------------------------------------ Q20 (cases/tpch/query/q20.sql)
+ * Order(s_name) <- Project(s_name, s_address) <- SEMI Join(s_suppkey = ps_suppkey) probe Join(s_nationkey = n_nationkey)[supplier, nation(n_name = ..)]
+ *   build Filter(ps_availqty > 0.5 * sum) <- Join((ps_partkey, ps_suppkey) = (l_partkey, l_suppkey))
+ *           probe SEMI Join(ps_partkey = p_partkey) probe Scan(partsupp), build Scan(part, p_name like 'lime%')
+ *           build Agg(l_partkey, l_suppkey; sum(l_quantity)) <- Scan(lineitem, l_shipdate in [d, d + 1 year))   (the correlated subquery by its keys)
+ * Typing: sum(INTEGER) is HUGEINT; 0.5 is a FLOAT literal, MaxLType(FLOAT, HUGEINT) = FLOAT: the sum is cast tryCastBigintToFloat32
+ * (function_cast.go:365-374) and multiplied in float32; ps_availqty (INTEGER) > FLOAT compares in float32 (tryCastInt32ToFloat32,
+ * greatFloat32Op). A partsupp row without lineitems in the year has a NULL subquery: the comparison is not true (the inner join drops it).
+ * Returns the qualifying suppliers' keys in s_suppkey order (= ORDER BY s_name: the name is the zero-padded key), -1 on error. */
+int64_t oracle_q20(const oracle_tpch *T, const int32_t *p_name_off, const char *p_name_bytes, int64_t n_ps, const int32_t *ps_partkey,
+                   const int32_t *ps_suppkey, const int32_t *ps_availqty, const char *like_pattern, const char *nation, int32_t date_ge, int32_t date_lt,
+                   float fraction, int32_t *out, int64_t max) {
+    /* part[p_name like ..] */
+    int64_t *psel = i64buf(T->n_part);
+    ocol pname = mkcol(OT_VARCHAR, 0, p_name_off);
+    pname.dict = (const char *const *)p_name_bytes;
+    oconst kl = kstr(like_pattern);
+    const int64_t np = oracle_select(&pname, OP_LIKE, &kl, NULL, T->n_part, psel);
+    ocol pk = mkcol(OT_INT32, 0, T->p_partkey);
+    ojoin *jp = oracle_join_build(&pk, 1, psel, np);
+    uint8_t *ps_hit = (uint8_t *)malloc((size_t)(n_ps > 0 ? n_ps : 1));
+    ocol psp = mkcol(OT_INT32, 0, ps_partkey);
+    oracle_join_probe_mark(jp, &psp, 1, NULL, n_ps, ps_hit);        /* SEMI: partsupp rows of those parts */
+    oracle_join_free(jp);
+    int64_t *ps_sel = i64buf(n_ps), nps = 0;
+    for (int64_t i = 0; i < n_ps; i++) if (ps_hit[i]) ps_sel[nps++] = i;
+    /* the subquery's aggregate */
+    const int64_t n = T->n_lineitem;
+    int64_t *s1 = i64buf(n), *s2 = i64buf(n);
+    ocol ls = mkcol(OT_DATE, 0, T->l_shipdate);
+    oconst k1 = kdate(date_ge), k2 = kdate(date_lt);
+    int64_t c = oracle_select(&ls, OP_GE, &k1, NULL, n, s1);
+    c = oracle_select(&ls, OP_LT, &k2, s1, c, s2);
+    ocol kproto[2] = {mkcol(OT_INT32, 0, NULL), mkcol(OT_INT32, 0, NULL)};
+    ocol aproto[1] = {mkcol(OT_INT32, 0, NULL)};
+    oaggspec aggs[1] = {{OA_SUM, 0}};
+    oagg *sub = oracle_agg_create(kproto, 2, aproto, aggs, 1);
+    int32_t kp[VS], ksu[VS], q[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < c && rc == 0; base += VS) {
+        int64_t cnt = c - base < VS ? c - base : VS;
+        for (int64_t j = 0; j < cnt; j++) { const int64_t r = s2[base + j]; kp[j] = T->l_partkey[r]; ksu[j] = T->l_suppkey[r]; q[j] = T->l_quantity[r]; }
+        ocol keys[2] = {mkcol(OT_INT32, 0, kp), mkcol(OT_INT32, 0, ksu)};
+        ocol args[1] = {mkcol(OT_INT32, 0, q)};
+        rc = oracle_agg_sink(sub, keys, args, NULL, cnt);
+    }
+    const int64_t ng = rc ? 0 : oracle_agg_count(sub);
+    int32_t *gp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ng > 0 ? ng : 1)), *gs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ng > 0 ? ng : 1));
+    float *gsum = (float *)malloc(sizeof(float) * (size_t)(ng > 0 ? ng : 1));
+    for (int64_t g = 0; g < ng; g++) {
+        int64_t kv[2];
+        oaggval v;
+        oracle_agg_group(sub, g, NULL, kv, NULL, &v);
+        gp[g] = (int32_t)kv[0]; gs[g] = (int32_t)kv[1];
+        gsum[g] = v.h.upper == -1 ? -(float)(UINT64_MAX - v.h.lower) - 1 : (float)v.h.lower + (float)v.h.upper * (float)UINT64_MAX;   /* tryCastBigintToFloat32 */
+    }
+    oracle_agg_free(sub);
+    /* partsupp x the groups on both keys, then the Filter */
+    ocol gk[2] = {mkcol(OT_INT32, 0, gp), mkcol(OT_INT32, 0, gs)};
+    ojoin *jg = oracle_join_build(gk, 2, NULL, ng);
+    ocol pkeys[2] = {mkcol(OT_INT32, 0, ps_partkey), mkcol(OT_INT32, 0, ps_suppkey)};
+    int64_t *j_ps = i64buf(nps), *j_g = i64buf(nps);
+    const int64_t nj = oracle_join_probe_inner(jg, pkeys, 2, ps_sel, nps, j_ps, j_g, nps);
+    oracle_join_free(jg);
+    int32_t *good = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nj > 0 ? nj : 1));
+    int64_t ngood = 0;
+    for (int64_t i = 0; i < nj; i++) {
+        volatile float thr = fraction * gsum[j_g[i]];
+        if ((float)ps_availqty[j_ps[i]] > thr) good[ngood++] = ps_suppkey[j_ps[i]];
+    }
+    /* supplier x nation[name], SEMI on the qualifying keys */
+    int64_t nsel[25];
+    ocol nn = mkcode(T->n_name, T->nation_dict);
+    oconst kn = kstr(nation);
+    const int64_t cn = oracle_select(&nn, OP_EQ, &kn, NULL, 25, nsel);
+    ocol nk = mkcol(OT_INT32, 0, T->n_nationkey);
+    ojoin *jn = oracle_join_build(&nk, 1, nsel, cn);
+    int64_t *s_row = i64buf(T->n_supplier), *s_nat = i64buf(T->n_supplier);
+    ocol sn = mkcol(OT_INT32, 0, T->s_nationkey);
+    const int64_t ns = oracle_join_probe_inner(jn, &sn, 1, NULL, T->n_supplier, s_row, s_nat, T->n_supplier);
+    oracle_join_free(jn);
+    ocol gd = mkcol(OT_INT32, 0, good);
+    ojoin *js = oracle_join_build(&gd, 1, NULL, ngood);
+    uint8_t *found = (uint8_t *)malloc((size_t)(ns > 0 ? ns : 1));
+    ocol sk = mkcol(OT_INT32, 0, T->s_suppkey);
+    oracle_join_probe_mark(js, &sk, 1, s_row, ns, found);
+    oracle_join_free(js);
+    int64_t nout = rc ? -1 : 0;
+    for (int64_t i = 0; i < ns && rc == 0; i++)
+        if (found[i]) { if (nout < max) out[nout] = T->s_suppkey[s_row[i]]; nout++; }
+    /* (s_row ascends: the probe keeps supplier order; the keys ascend with it) */
+    free(psel); free(ps_hit); free(ps_sel); free(s1); free(s2); free(gp); free(gs); free(gsum); free(j_ps); free(j_g); free(good); free(s_row); free(s_nat); free(found);
+    return nout;
+}
+
 /* ------------------------------------------------------------------ text */
 /* extract(year from date): Date.Year (pkg/common/date.go) */
 static int32_t year_of_days2(int32_t z) {
@@ -1284,5 +1379,21 @@ int64_t oracle_q22_text(oracle_q22_row *rows, int64_t n, char *buf, int64_t cap)
         oracle_format_decimal(r->totacctbal, 2, t); put(&s, t); put(&s, "\n");
     }
     free(ord);
+    return done(&s);
+}
+
+int64_t oracle_q20_text(const int32_t *keys, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes, char *buf,
+                        int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    char t[96];
+    for (int64_t i = 0; i < n; i++) {   /* ORDER BY s_name = key order (zero-padded), which is the order the keys come in */
+        int64_t r = -1;
+        for (int64_t j = 0; j < n_supplier; j++) if (s_suppkey[j] == keys[i]) { r = j; break; }
+        if (r < 0) continue;
+        sprintf(t, "Supplier#%09d\t", keys[i]); put(&s, t);
+        int32_t len = addr_off[r + 1] - addr_off[r];
+        memcpy(t, addr_bytes + addr_off[r], (size_t)len); t[len] = 0; put(&s, t); put(&s, "\n");
+    }
     return done(&s);
 }

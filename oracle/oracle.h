@@ -373,6 +373,12 @@ typedef struct { char cntrycode[4]; ohuge numcust; odec totacctbal; } oracle_q22
 int64_t oracle_q22(const oracle_tpch *T, const char *c_phone, const int64_t *c_acctbal, const char *const *codes, int32_t ncodes,
                    oracle_q22_row *out, int64_t max);
 int64_t oracle_q22_text(oracle_q22_row *rows, int64_t n, char *buf, int64_t cap);   /* ORDER BY cntrycode */
+/* Q20 (cases/tpch/query/q20.sql): the qualifying suppliers' keys in s_name order; p_name as offsets + bytes, partsupp's three columns */
+int64_t oracle_q20(const oracle_tpch *T, const int32_t *p_name_off, const char *p_name_bytes, int64_t n_ps, const int32_t *ps_partkey,
+                   const int32_t *ps_suppkey, const int32_t *ps_availqty, const char *like_pattern, const char *nation, int32_t date_ge, int32_t date_lt,
+                   float fraction, int32_t *out, int64_t max);
+int64_t oracle_q20_text(const int32_t *keys, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes, char *buf,
+                        int64_t cap);
 /* Q17 (cases/tpch/query/q17.sql): 0 ok / 1 the sum is NULL / -1 error; avg_yearly = float32(sum) / divisor, the threshold fraction * avg in float64 */
 int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out);
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);

@@ -633,6 +633,30 @@ def q14_text(t, pattern, date_ge, date_lt):
     return _text("oracle_q14_text", ctypes.c_float(f), i32(rc))
 
 
+def q20_keys(t, pattern="lime%", nation="VIETNAM", date_ge=None, date_lt=None, fraction=0.5):
+    from plan_amd import tpchgen
+    date_ge = tpchgen.days(1993, 1, 1) if date_ge is None else date_ge
+    date_lt = tpchgen.days(1994, 1, 1) if date_lt is None else date_lt
+    T, keep = tpch_struct(t)
+    P, PS = t["part"], t["partsupp"]
+    arrs = [np.ascontiguousarray(P["p_name_off"]), np.ascontiguousarray(P["p_name_bytes"])] + [np.ascontiguousarray(PS[c]) for c in ("ps_partkey", "ps_suppkey", "ps_availqty")]
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    out = np.zeros(len(t["supplier"]["s_suppkey"]), np.int32)
+    lib().oracle_q20.restype = i64
+    n = lib().oracle_q20(ctypes.byref(T), vp(arrs[0]), vp(arrs[1]), i64(len(arrs[2])), vp(arrs[2]), vp(arrs[3]), vp(arrs[4]), pattern.encode(), nation.encode(),
+                         i32(date_ge), i32(date_lt), ctypes.c_float(fraction), vp(out), i64(len(out)))
+    assert n >= 0
+    return out[:n]
+
+
+def q20_text(t, **kw):
+    keys = np.ascontiguousarray(q20_keys(t, **kw))
+    S = t["supplier"]
+    key, off, ab = np.ascontiguousarray(S["s_suppkey"]), np.ascontiguousarray(S["s_address_off"]), np.ascontiguousarray(S["s_address_bytes"])
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    return _text("oracle_q20_text", vp(keys), i64(len(keys)), vp(key), i64(len(key)), vp(off), vp(ab), cap=1 << 18)
+
+
 Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
 
 

@@ -86,6 +86,12 @@ def test_q15_matches_reference_golden(sf1):
     assert O.q15_text(sf1, tpchgen.days(1995, 12, 1), tpchgen.days(1996, 3, 1)) == golden("plan_q15.txt")
 
 
+def test_q20_matches_reference_golden(sf1):
+    # nested IN subqueries as SEMI joins, LIKE with a prefix pattern, a correlated sum by two keys joined back on both, INTEGER > FLOAT x HUGEINT in
+    # float32; 177 suppliers with their generated s_address
+    assert O.q20_text(sf1) == golden("plan_q20.txt")
+
+
 def test_q22_matches_reference_golden(sf1):
     # substring() as a filter operand and as the group key (pins oracle_substring with a reference fixture), IN over VARCHAR, avg(DECIMAL) as a
     # scalar subquery compared DECIMAL > DECIMAL, DECIMAL > FLOAT literal, NOT EXISTS as an ANTI join; pins the generator's c_phone / c_acctbal
