@@ -321,6 +321,7 @@ OperatorResult gpuFilterExecutor::Execute(Chunk *, Chunk *output, std::string *e
 
 std::string doubleFilterExecutor::Init() {
     const size_t nc = child_->OutputTypes().size();
+    if (pred_.float32 ? (pred_.op != PH_GT && pred_.op != PH_GE && pred_.op != PH_LE) : pred_.op != PH_LT) return "no such comparison for this type in selectOperation";
     for (auto *prog : {&pred_.lhs, &pred_.rhs}) {
         if (prog->empty()) return "empty DOUBLE expression";
         for (auto &o : *prog)
@@ -361,6 +362,41 @@ static bool eval_double(const std::vector<FloatOp> &prog, const Chunk &c, int ca
     return true;
 }
 
+// the FLOAT form: every value and every operation in float32
+static bool eval_float(const std::vector<FloatOp> &prog, const Chunk &c, int card, int r, float *out, std::string *err) {
+    std::vector<float> st;
+    for (auto &o : prog) {
+        if (o.op == FloatOp::Const) { st.push_back(o.k); continue; }
+        if (o.op == FloatOp::Col) {
+            const Vector &src = *c.Data[(size_t)o.col];
+            Vector::Unified u;
+            src.ToUnifiedFormat(card, &u);
+            const int64_t idx = u.sel->GetIndex(r);
+            if (!u.mask->RowIsValid((uint64_t)idx)) return false;
+            switch (src._Typ.GetInternalType()) {
+            case PT_INT32: st.push_back((float)reinterpret_cast<const int32_t *>(u.data)[idx]); break;
+            case PT_DECIMAL: st.push_back((float)DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx])); break;
+            case PT_INT128: {   // tryCastBigintToFloat32 (function_cast.go:365-374)
+                const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx];
+                st.push_back(h.Upper == -1 ? -(float)(UINT64_MAX - h.Lower) - 1 : (float)h.Lower + (float)h.Upper * (float)UINT64_MAX);
+                break;
+            }
+            case PT_FLOAT: st.push_back(reinterpret_cast<const float *>(u.data)[idx]); break;
+            default: *err = "FLOAT expression over an unsupported column type"; return false;
+            }
+            continue;
+        }
+        if (st.size() < 2) { *err = "malformed FLOAT expression"; return false; }
+        volatile float b = st.back(); st.pop_back();
+        volatile float a = st.back(); st.pop_back();
+        volatile float res = o.op == FloatOp::Add ? a + b : o.op == FloatOp::Sub ? a - b : o.op == FloatOp::Mul ? a * b : a / b;
+        st.push_back((float)res);
+    }
+    if (st.size() != 1) { *err = "malformed FLOAT expression"; return false; }
+    *out = st[0];
+    return true;
+}
+
 OperatorResult doubleFilterExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
     for (;;) {
         auto c = std::make_shared<Chunk>();
@@ -370,11 +406,19 @@ OperatorResult doubleFilterExecutor::Execute(Chunk *, Chunk *output, std::string
         auto sv = std::make_shared<SelectVector>();
         sv->identity = false;
         for (int i = 0; i < card; i++) {
-            double a = 0, b = 0;
             std::string e;
-            const bool va = eval_double(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_double(pred_.rhs, *c, card, i, &b, &e);
+            bool pass = false;
+            if (pred_.float32) {
+                float a = 0, b = 0;
+                const bool va = eval_float(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_float(pred_.rhs, *c, card, i, &b, &e);
+                pass = va && vb && (pred_.op == PH_GT ? a > b : pred_.op == PH_GE ? a >= b : a <= b);   // great / greatEqual / lessEqual Float32Op
+            } else {
+                double a = 0, b = 0;
+                const bool va = eval_double(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_double(pred_.rhs, *c, card, i, &b, &e);
+                pass = va && vb && a < b;                                                // lessFloat64Op; a NULL side selects nothing
+            }
             if (!e.empty()) { *err = e; return InvalidOpResult; }
-            if (va && vb && a < b) sv->SelVec.push_back(i);                              // lessFloat64Op; a NULL side selects nothing
+            if (pass) sv->SelVec.push_back(i);
         }
         if (sv->SelVec.empty()) continue;
         ensureOutputChunk(OutputTypes(), output);

@@ -213,6 +213,11 @@ private:
 // DECIMAL, HUGEINT, FLOAT -> DOUBLE). Evaluated on the host: the rows it sees are a resident plan's result rows.
 struct DoubleLess {
     std::vector<FloatOp> lhs, rhs;
+    // float32 = true: the FLOAT form instead — both sides in float32, every operation rounded to it, columns cast as the binder casts them
+    // to FLOAT (tryCastInt32ToFloat32, tryCastBigintToFloat32, tryCastDecimalToFloat32); op = PH_GT / PH_GE / PH_LE, the FLOAT comparisons
+    // selectOperation has (function_operator_boolean.go:431-490). Q20: ps_availqty > 0.5 * sum(l_quantity).
+    bool float32 = false;
+    int op = PH_LT;
 };
 class doubleFilterExecutor : public OperatorExec {
 public:

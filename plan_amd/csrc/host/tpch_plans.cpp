@@ -471,6 +471,28 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->ncols = 6;
         break;
     }
+    case 20: {
+        // the resident plan: partsupp SEMI part[p_name like 'lime%'] joined on BOTH keys with Agg(l_partkey, l_suppkey; sum(l_quantity)) over 1993's lineitem,
+        // grouped by (ps_suppkey, ps_availqty, sum) — the columns the FLOAT predicate reads; the rest of the tree runs over those rows (RunTpchQuery)
+        int subScan = p.Scan(&db.lineitem, {L_PARTKEY, L_SUPPKEY, L_QUANTITY}, {{L_SHIPDATE, PH_GE, LDate(1993, 1, 1)}, {L_SHIPDATE, PH_LT, LDate(1994, 1, 1)}});
+        int sub = p.Agg(subScan, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_SUM, {XC(2)}}});
+        int part = p.Scan(&db.part, {P_PARTKEY}, {{P_NAME, PH_LIKE, LStr("lime%")}});
+        int ps = p.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY, PS_AVAILQTY});
+        int j1 = p.Join(ps, part, {0}, {0}, {0, 1, 2}, JoinSemi);
+        int j2 = p.Join(j1, sub, {0, 1}, {0, 1}, {1, 2, 5});                   // ps_suppkey, ps_availqty, sum(l_quantity)
+        p.Agg(j2, {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(2)}, {{PH_A_COUNT_STAR, {}}});
+        auto fcol = [](int c) { FloatOp o; o.op = FloatOp::Col; o.col = c; return o; };
+        FloatOp half; half.op = FloatOp::Const; half.k = 0.5f;
+        FloatOp mul; mul.op = FloatOp::Mul;
+        q->upperFilter = std::make_shared<DoubleLess>();
+        q->upperFilter->float32 = true;
+        q->upperFilter->op = PH_GT;
+        q->upperFilter->lhs = {fcol(1)};                    // ps_availqty
+        q->upperFilter->rhs = {half, fcol(2), mul};         // 0.5 * sum(l_quantity)
+        q->order = {{0, false}};                            // ORDER BY s_name
+        q->ncols = 2;
+        break;
+    }
     case 22: {
         // Order(cntrycode) <- Agg(cntrycode; count(*), sum(c_acctbal)) <- ANTI Join(c_custkey = o_custkey) probe Filter(cntrycode IN (..)) <-
         //   Project(substring(c_phone from 1 for 2) as cntrycode, ..) <- Scan(customer, c_acctbal > scalar), build Scan(orders);
@@ -505,16 +527,16 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     return p.error;
 }
 
-// Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
+// Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone, s_nationkey] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
 static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) {
-    struct St { int64_t n = 0, pos = 0; std::vector<int32_t> key; std::vector<char> addr, phone; std::vector<uint8_t> alen; };
+    struct St { int64_t n = 0, pos = 0; std::vector<int32_t> key, nat; std::vector<char> addr, phone; std::vector<uint8_t> alen; };
     auto st = std::make_shared<St>();
     st->n = tpchgen_supplier_count(num, den);
-    st->key.resize((size_t)st->n); st->addr.resize((size_t)st->n * TPCHGEN_S_ADDRESS_STRIDE); st->alen.resize((size_t)st->n); st->phone.resize((size_t)st->n * TPCHGEN_S_PHONE_LEN);
+    st->key.resize((size_t)st->n); st->nat.resize((size_t)st->n); st->addr.resize((size_t)st->n * TPCHGEN_S_ADDRESS_STRIDE); st->alen.resize((size_t)st->n); st->phone.resize((size_t)st->n * TPCHGEN_S_PHONE_LEN);
     tpchgen_supplier_cols sc{};
-    sc.s_suppkey = st->key.data(); sc.s_address = st->addr.data(); sc.s_address_len = st->alen.data(); sc.s_phone = st->phone.data();
+    sc.s_suppkey = st->key.data(); sc.s_nationkey = st->nat.data(); sc.s_address = st->addr.data(); sc.s_address_len = st->alen.data(); sc.s_phone = st->phone.data();
     tpchgen_supplier(num, den, 0, st->n, &sc);
-    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType()};
+    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType(), IntegerType()};
     return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [st, types](Chunk *out) {
         if (st->pos >= st->n) return false;
         const int card = (int)std::min<int64_t>(DefaultVectorSize, st->n - st->pos);
@@ -527,9 +549,27 @@ static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) 
             out->Data[1]->SetString(i, name, 18);
             out->Data[2]->SetString(i, st->addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, st->alen[r]);
             out->Data[3]->SetString(i, st->phone.data() + r * TPCHGEN_S_PHONE_LEN, TPCHGEN_S_PHONE_LEN);
+            out->Data[4]->Slice<int32_t>()[i] = st->nat[r];
         }
         out->SetCard(card);
         st->pos += card;
+        return true;
+    }));
+}
+
+// Scan(nation) -> [n_nationkey, n_name]
+static std::unique_ptr<sourceExecutor> NationSource() {
+    auto done = std::make_shared<bool>(false);
+    const std::vector<LType> types = {IntegerType(), VarcharType()};
+    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [done, types](Chunk *out) {
+        if (*done) return false;
+        out->Init(types, DefaultVectorSize);
+        for (int i = 0; i < 25; i++) {
+            out->Data[0]->Slice<int32_t>()[i] = i;
+            out->Data[1]->SetString(i, TPCHGEN_NATION_NAMES[i], (int64_t)strlen(TPCHGEN_NATION_NAMES[i]));
+        }
+        out->SetCard(25);
+        *done = true;
         return true;
     }));
 }
@@ -576,6 +616,9 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     std::unique_ptr<gpuResidentPlanExecutor> cte2;
     std::unique_ptr<sourceExecutor> suppSrc;
     std::unique_ptr<gpuJoinExecutor> j1, j2;
+    std::unique_ptr<gpuProjectExecutor> proj;
+    std::unique_ptr<sourceExecutor> natSrc;
+    std::unique_ptr<gpuFilterExecutor> natFilter;
     OperatorExec *root = &agg;
     if (q.id == 15) {
         // Order(s_suppkey) <- Join(s_suppkey = supplier_no) probe Scan(supplier), build <- Join(total_revenue = max) probe CTE,
@@ -593,9 +636,34 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
         j2.reset(new gpuJoinExecutor(ctx, suppSrc.get(), j1.get(), {0}, {0}, {1}));
         e = j2->Init();
         if (!e.empty()) return "Init (join with supplier): " + e;
-        root = j2.get();
+        proj.reset(new gpuProjectExecutor(ctx, {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(2), ProjExpr::Col(3), ProjExpr::Col(5)}, j2.get()));
+        e = proj->Init();
+        if (!e.empty()) return "Init (project): " + e;
+        root = proj.get();
     }
-    if (q.upperFilter) {
+    if (q.id == 20) {
+        // Order(s_name) <- Project(s_name, s_address) <- SEMI Join(s_suppkey = ps_suppkey) probe Join(s_nationkey = n_nationkey)[Scan(supplier),
+        //   Filter(n_name = 'VIETNAM') <- Scan(nation)], build Filter(ps_availqty > 0.5 * sum [FLOAT]) <- the resident plan's group rows
+        upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
+        e = upperFilter->Init();
+        if (!e.empty()) return "Init (FLOAT filter): " + e;
+        natSrc = NationSource();
+        natFilter.reset(new gpuFilterExecutor(ctx, {{1, PH_EQ, LStr("VIETNAM")}}, natSrc.get()));
+        e = natFilter->Init();
+        if (!e.empty()) return "Init (nation filter): " + e;
+        suppSrc = SupplierSource(q.sfNum, q.sfDen);
+        j1.reset(new gpuJoinExecutor(ctx, suppSrc.get(), natFilter.get(), {4}, {0}, {}));
+        e = j1->Init();
+        if (!e.empty()) return "Init (supplier x nation): " + e;
+        j2.reset(new gpuJoinExecutor(ctx, j1.get(), upperFilter.get(), {0}, {0}, {}, 512, JoinSemi));
+        e = j2->Init();
+        if (!e.empty()) return "Init (SEMI join): " + e;
+        proj.reset(new gpuProjectExecutor(ctx, {ProjExpr::Col(1), ProjExpr::Col(2)}, j2.get()));
+        e = proj->Init();
+        if (!e.empty()) return "Init (project): " + e;
+        root = proj.get();
+    }
+    if (q.upperFilter && q.id != 20) {
         upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
         e = upperFilter->Init();
         if (!e.empty()) return "Init: " + e;
@@ -635,8 +703,10 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (explain) *explain = agg.Explain();
     if (lim) lim->Close();
     if (ord) ord->Close();
+    if (proj) proj->Close();
     if (j2) j2->Close();
     if (j1) j1->Close();
+    if (natFilter) natFilter->Close();
     if (upperAgg) upperAgg->Close();
     if (upperFilter) upperFilter->Close();
     if (cte2) cte2->Close();

@@ -387,6 +387,45 @@ def q15_text(db, rows, supp_keys, scale=4):
     return "\n".join(out) + "\n"
 
 
+def q20_plans(db, pattern="lime%", nation="VIETNAM", d1=None, d2=None):
+    """cases/tpch/query/q20.sql as two plans: (1) partsupp SEMI part[p_name like ..] joined on BOTH keys with the correlated subquery's aggregate
+       (Agg(l_partkey, l_suppkey; sum(l_quantity)) over one year of lineitem, its groups stay on the device), grouped by the three columns the
+       FLOAT predicate reads (ps_suppkey, ps_availqty, sum) — the plan has no FLOAT arithmetic, q20_keys applies it to the groups;
+       (2) the suppliers of the nation: supplier x nation[n_name = ..] by key"""
+    d1 = tpchgen.days(1993, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1994, 1, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    sub_scan = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_suppkey", "l_quantity"),
+                      [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    sub = p.agg(sub_scan, [hip.pe_col(0), hip.pe_col(1)], [(hip.PH_A_SUM, hip.pe_col(2))])          # l_partkey, l_suppkey, sum
+    part = p.scan(db.t("part"), db.c("part", "p_partkey"), [_pred(db, "part", "p_name", hip.PH_LIKE, _s(pattern))])
+    ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_suppkey", "ps_availqty"))
+    j1 = p.join(ps, part, [0], [0], [0, 1, 2], join_type=hip.PH_JT_SEMI)
+    j2 = p.join(j1, sub, [0, 1], [0, 1], [1, 2, 5])                                                # ps_suppkey, ps_availqty, sum
+    p.agg(j2, [hip.pe_col(0), hip.pe_col(1), hip.pe_col(2)], [(hip.PH_A_COUNT_STAR, None)])
+    s = hip.Plan(db.ctx)
+    nat = s.scan(db.t("nation"), db.c("nation", "n_nationkey"), [_pred(db, "nation", "n_name", hip.PH_EQ, _s(nation))])
+    supp = s.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey"))
+    js = s.join(supp, nat, [1], [0], [0])
+    s.agg(js, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None)])
+    return p.create(), s.create()
+
+
+def q20_keys(r, rs, fraction=0.5):
+    """s_suppkey of the result, ascending: the groups with float32(ps_availqty) > float32(fraction) * float32(sum) (sum(INTEGER) is HUGEINT, cast
+       tryCastBigintToFloat32; INTEGER > FLOAT compares in float32), SEMI-joined with the nation's suppliers"""
+    f = np.float32(fraction)
+    good = {int(r["keys"][g][0]) for g in range(r["ngroups"]) if np.float32(int(r["keys"][g][1])) > np.float32(f * np.float32(int(r["keys"][g][2])))}
+    return sorted(int(rs["keys"][g][0]) for g in range(rs["ngroups"]) if int(rs["keys"][g][0]) in good)
+
+
+def q20_text(db, keys, supp_keys):
+    """s_name, s_address ORDER BY s_name (the zero-padded key: key order)"""
+    pos = [int(np.nonzero(supp_keys == k)[0][0]) for k in keys]
+    cols = [hip.table_strings(db.ctx, db.t("supplier"), db.c("supplier", c)[0], pos) for c in ("s_name", "s_address")]
+    return "#\t\n" + "".join(f"{a}\t{b}\n" for a, b in zip(*cols))
+
+
 Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
 
 

@@ -310,6 +310,20 @@ def test_q15_cte_maximum_and_supplier_strings_match_golden(ctx, db, sf1):
     assert tpch.q15_text(db, rows, sf1["supplier"]["s_suppkey"], r["scale"][0]) == golden("plan_q15.txt"), ex
 
 
+def test_q20_two_key_join_with_the_subquery_aggregate_matches_golden(ctx, db, sf1):
+    """Q20: SEMI join on a LIKE-filtered part, a join on two keys whose build side is an aggregate by those keys, the float32 predicate over
+    the fetched groups, the nation's suppliers from a second plan: the oracle's keys and cases/tpch/1g/plan/q20.txt (177 generated addresses)"""
+    p, s = tpch.q20_plans(db)
+    p.run(); s.run()
+    r, rs = p.fetch(), s.fetch()
+    ex = p.explain()
+    p.free(); s.free()
+    keys = tpch.q20_keys(r, rs)
+    assert keys == O.q20_keys(sf1).tolist(), ex
+    assert tpch.q20_text(db, keys, sf1["supplier"]["s_suppkey"]) == golden("plan_q20.txt"), ex
+    assert "groups stay on the device" in ex
+
+
 def test_q22_substring_keys_anti_join_and_scalar_average_match_golden(ctx, db, sf1):
     """Q22: substring() computed in the plan as a filter operand (IN = OR of =) and as the group key, a scalar avg(DECIMAL) subquery as its own
     plan, DECIMAL > DECIMAL as an exact threshold, NOT EXISTS as an ANTI join: the oracle's groups and cases/tpch/1g/plan/q22.txt"""
