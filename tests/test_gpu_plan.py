@@ -117,11 +117,11 @@ def test_q1_plan_takes_the_fused_scan(ctx, db, sf1):
 
 
 def shuffled(table, rng):
-    table = {k: v for k, v in table.items() if not k.startswith("c_name_")}   # (Q3 / Q9 never read c_name)
+    if "p_name_off" in table:
+        return table   # (part stays in order: Q9 reads its VARCHAR column, offsets + bytes)
+    table = {k: v for k, v in table.items() if not (k.endswith("_off") or k.endswith("_bytes"))}   # (Q3 / Q9 read no other VARCHAR column)
     n = len(next(iter(table.values())))
     perm = rng.permutation(n)
-    if "p_name_off" in table:
-        return table   # (part stays in order: its VARCHAR column is offsets + bytes)
     return {k: np.ascontiguousarray(v[perm]) for k, v in table.items()}
 
 
