@@ -8,10 +8,10 @@ n = 32_000_000
 ctx = hip.Ctx(0)
 rng = np.random.default_rng(0)
 vals = hip.DevColumn(ctx, hip.PH_I64, rng.integers(0, 10**6, n).astype(np.int64))
-for card in (200_000, 500_000, 1_000_000, 2_000_000, 4_000_000):
+for card in ([int(x) for x in sys.argv[1:]] or (200_000, 500_000, 1_000_000, 2_000_000, 4_000_000)):
     keys = hip.DevColumn(ctx, hip.PH_I64, rng.integers(0, card, n).astype(np.int64))
     best = 1e9
-    for it in range(6):
+    for it in range(12):
         agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], card)
         ctx.sync()
         t0 = time.perf_counter()
