@@ -866,6 +866,98 @@ int64_t oracle_q20(const oracle_tpch *T, const int32_t *p_name_off, const char *
     return nout;
 }
 
+/* ------------------------------------------------------------------ Q21 (cases/tpch/query/q21.sql)
+ * Limit 100 <- Order(numwait desc, s_name) <- Agg(s_name; count(*))
+ *   <- ANTI Join(l3.l_orderkey = l1.l_orderkey AND l3.l_suppkey <> l1.l_suppkey) build Scan(lineitem l3, l_receiptdate > l_commitdate)
+ *   <- SEMI Join(l2.l_orderkey = l1.l_orderkey AND l2.l_suppkey <> l1.l_suppkey) build Scan(lineitem l2)
+ *   <- Join(o_orderkey = l_orderkey) build Scan(orders, o_orderstatus = 'F') <- Join(s_suppkey = l_suppkey) probe Scan(lineitem l1, receipt > commit)
+ *      build Join(s_nationkey = n_nationkey)[supplier, nation(n_name = ..)].
+ * A join's non-equi conjunct is evaluated over the key matches (the hash join's pairs, then the condition as a select over the joined
+ * columns: join_scan.go's Next* with the extra conditions), EXISTS / NOT EXISTS keep the probe rows with / without a surviving match.
+ * l2 / l3's key matches are the lines of l1's own order. Returns the groups (supplier key, count) in first-seen order, -1 on error. */
+int64_t oracle_q21(const oracle_tpch *T, const uint8_t *o_orderstatus, const char *nation, oracle_q21_row *out, int64_t max) {
+    /* supplier x nation[name] */
+    int64_t nsel[25];
+    ocol nn = mkcode(T->n_name, T->nation_dict);
+    oconst kn = kstr(nation);
+    const int64_t cn = oracle_select(&nn, OP_EQ, &kn, NULL, 25, nsel);
+    ocol nk = mkcol(OT_INT32, 0, T->n_nationkey);
+    ojoin *jn = oracle_join_build(&nk, 1, nsel, cn);
+    int64_t *s_row = i64buf(T->n_supplier), *s_nat = i64buf(T->n_supplier);
+    ocol sn = mkcol(OT_INT32, 0, T->s_nationkey);
+    const int64_t ns = oracle_join_probe_inner(jn, &sn, 1, NULL, T->n_supplier, s_row, s_nat, T->n_supplier);
+    oracle_join_free(jn);
+    /* l1 = lineitem[l_receiptdate > l_commitdate] x those suppliers */
+    const int64_t n = T->n_lineitem;
+    int64_t *late = i64buf(n);
+    ocol lr = mkcol(OT_DATE, 0, T->l_receiptdate), lc = mkcol(OT_DATE, 0, T->l_commitdate);
+    const int64_t nlate = oracle_select_cols(&lr, OP_GT, &lc, NULL, n, late);
+    ocol sk = mkcol(OT_INT32, 0, T->s_suppkey);
+    ojoin *js = oracle_join_build(&sk, 1, s_row, ns);
+    int64_t *l1 = i64buf(nlate), *l1s = i64buf(nlate);
+    ocol lsup = mkcol(OT_INT32, 0, T->l_suppkey);
+    const int64_t n1 = oracle_join_probe_inner(js, &lsup, 1, late, nlate, l1, l1s, nlate);
+    oracle_join_free(js);
+    /* x orders[o_orderstatus = 'F'] */
+    int64_t *osel = i64buf(T->n_orders), no = 0;
+    for (int64_t i = 0; i < T->n_orders; i++) if (o_orderstatus[i] == 'F') osel[no++] = i;      /* equalStrOp on the one-character status */
+    ocol ok = mkcol(OT_INT64, 0, T->o_orderkey);
+    ojoin *jo = oracle_join_build(&ok, 1, osel, no);
+    int64_t *kb = i64buf(n1);
+    for (int64_t i = 0; i < n1; i++) kb[i] = T->l_orderkey[l1[i]];
+    ocol kbc = mkcol(OT_INT64, 0, kb);
+    int64_t *p2 = i64buf(n1), *o2 = i64buf(n1);
+    const int64_t n2 = oracle_join_probe_inner(jo, &kbc, 1, NULL, n1, p2, o2, n1);
+    oracle_join_free(jo);
+    /* rows so far: lineitem row l1[p2[i]], supplier row l1s[p2[i]] */
+    int64_t *cur = i64buf(n2), *cur_s = i64buf(n2);
+    for (int64_t i = 0; i < n2; i++) { cur[i] = l1[p2[i]]; cur_s[i] = l1s[p2[i]]; }
+    /* EXISTS l2 / NOT EXISTS l3: the join on l_orderkey, then `<>` on the suppliers over the pairs */
+    ocol lk = mkcol(OT_INT64, 0, T->l_orderkey);
+    int64_t ncur = n2;
+    for (int pass = 0; pass < 2; pass++) {
+        ojoin *jl = pass == 0 ? oracle_join_build(&lk, 1, NULL, n) : oracle_join_build(&lk, 1, late, nlate);
+        int64_t *key = i64buf(ncur);
+        for (int64_t i = 0; i < ncur; i++) key[i] = T->l_orderkey[cur[i]];
+        ocol kc = mkcol(OT_INT64, 0, key);
+        const int64_t cap = 8 * ncur + 64;                     /* at most seven lines per order */
+        int64_t *pp = i64buf(cap), *bb = i64buf(cap);
+        const int64_t np = oracle_join_probe_inner(jl, &kc, 1, NULL, ncur, pp, bb, cap);
+        oracle_join_free(jl);
+        uint8_t *hit = (uint8_t *)calloc((size_t)(ncur > 0 ? ncur : 1), 1);
+        for (int64_t i = 0; i < np && np <= cap; i++)
+            if (T->l_suppkey[bb[i]] != T->l_suppkey[cur[pp[i]]]) hit[pp[i]] = 1;      /* notEqualOp[int32] over the joined pair */
+        int64_t m = 0;
+        for (int64_t i = 0; i < ncur; i++)
+            if ((pass == 0) == (hit[i] != 0)) { cur[m] = cur[i]; cur_s[m] = cur_s[i]; m++; }
+        ncur = np <= cap ? m : 0;
+        free(key); free(pp); free(bb); free(hit);
+    }
+    /* Agg(s_name; count(*)): s_name is the supplier's key in text, a VARCHAR key — grouped here by the key */
+    ocol kp[1] = {mkcol(OT_INT32, 0, NULL)};
+    oaggspec ag[1] = {{OA_COUNT, -1}};
+    oagg *t = oracle_agg_create(kp, 1, NULL, ag, 1);
+    int32_t kv32[VS];
+    int rc = 0;
+    for (int64_t base = 0; base < ncur && rc == 0; base += VS) {
+        int64_t cnt = ncur - base < VS ? ncur - base : VS;
+        for (int64_t j = 0; j < cnt; j++) kv32[j] = T->s_suppkey[cur_s[base + j]];   /* (a build over a selection reports its ROW ids) */
+        ocol keys[1] = {mkcol(OT_INT32, 0, kv32)};
+        rc = oracle_agg_sink(t, keys, NULL, NULL, cnt);
+    }
+    const int64_t ng = rc ? -1 : oracle_agg_count(t);
+    for (int64_t g = 0; g < ng && g < max; g++) {
+        int64_t kv[1];
+        oaggval v;
+        oracle_agg_group(t, g, NULL, kv, NULL, &v);
+        out[g].s_suppkey = (int32_t)kv[0];
+        out[g].numwait = v.h;
+    }
+    oracle_agg_free(t);
+    free(s_row); free(s_nat); free(late); free(l1); free(l1s); free(osel); free(kb); free(p2); free(o2); free(cur); free(cur_s);
+    return ng;
+}
+
 /* ------------------------------------------------------------------ text */
 /* extract(year from date): Date.Year (pkg/common/date.go) */
 static int32_t year_of_days2(int32_t z) {
@@ -1395,5 +1487,28 @@ int64_t oracle_q20_text(const int32_t *keys, int64_t n, const int32_t *s_suppkey
         int32_t len = addr_off[r + 1] - addr_off[r];
         memcpy(t, addr_bytes + addr_off[r], (size_t)len); t[len] = 0; put(&s, t); put(&s, "\n");
     }
+    return done(&s);
+}
+
+int64_t oracle_q21_text(oracle_q21_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap) {
+    sbuf2 s = {buf, cap, 0};
+    put(&s, "#\t\n");
+    int64_t *ord = i64buf(n);
+    for (int64_t i = 0; i < n; i++) {   /* ORDER BY numwait DESC, s_name (= the key: zero-padded) */
+        int64_t j = i;
+        while (j > 0) {
+            const oracle_q21_row *a = &rows[ord[j - 1]], *b = &rows[i];
+            const int after = a->numwait.lower < b->numwait.lower || (a->numwait.lower == b->numwait.lower && a->s_suppkey > b->s_suppkey);
+            if (!after) break;
+            ord[j] = ord[j - 1]; j--;
+        }
+        ord[j] = i;
+    }
+    char t[64];
+    for (int64_t i = 0; i < n && i < limit; i++) {
+        sprintf(t, "Supplier#%09d\t", rows[ord[i]].s_suppkey); put(&s, t);
+        oracle_format_hugeint(rows[ord[i]].numwait, t); put(&s, t); put(&s, "\n");
+    }
+    free(ord);
     return done(&s);
 }

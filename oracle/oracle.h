@@ -379,6 +379,10 @@ int64_t oracle_q20(const oracle_tpch *T, const int32_t *p_name_off, const char *
                    float fraction, int32_t *out, int64_t max);
 int64_t oracle_q20_text(const int32_t *keys, int64_t n, const int32_t *s_suppkey, int64_t n_supplier, const int32_t *addr_off, const char *addr_bytes, char *buf,
                         int64_t cap);
+/* Q21 (cases/tpch/query/q21.sql): groups (supplier, count of its waiting lines); o_orderstatus = one raw byte per order ('F' / 'O' / 'P') */
+typedef struct { int32_t s_suppkey; ohuge numwait; } oracle_q21_row;
+int64_t oracle_q21(const oracle_tpch *T, const uint8_t *o_orderstatus, const char *nation, oracle_q21_row *out, int64_t max);
+int64_t oracle_q21_text(oracle_q21_row *rows, int64_t n, int32_t limit, char *buf, int64_t cap);   /* ORDER BY numwait DESC, s_name LIMIT */
 /* Q17 (cases/tpch/query/q17.sql): 0 ok / 1 the sum is NULL / -1 error; avg_yearly = float32(sum) / divisor, the threshold fraction * avg in float64 */
 int32_t oracle_q17(const oracle_tpch *T, const char *brand, const char *container, float fraction, float divisor, float *avg_yearly, odec *sum_out);
 int64_t oracle_q17_text(float avg_yearly, int is_null, char *buf, int64_t cap);

@@ -19,10 +19,11 @@ SCHEMA = {
                  ("l_tax", hip.PH_DEC64, 2, None), ("l_returnflag", hip.PH_CODE8, 0, tpchgen.RETURNFLAG_DICT),
                  ("l_linestatus", hip.PH_CODE8, 0, tpchgen.LINESTATUS_DICT), ("l_shipdate", hip.PH_DATE, 0, None),
                  ("l_commitdate", hip.PH_DATE, 0, None), ("l_receiptdate", hip.PH_DATE, 0, None),
-                 ("l_shipmode", hip.PH_CODE8, 0, tpchgen.SHIPMODE_DICT), ("l_shipinstruct", hip.PH_CODE8, 0, tpchgen.SHIPINSTRUCT_DICT)],
+                 ("l_shipmode", hip.PH_CODE8, 0, tpchgen.SHIPMODE_DICT), ("l_shipinstruct", hip.PH_CODE8, 0, tpchgen.SHIPINSTRUCT_DICT),
+                 ("l_linenumber", hip.PH_I32, 0, None)],
     "orders": [("o_orderkey", hip.PH_I64, 0, None), ("o_custkey", hip.PH_I32, 0, None), ("o_orderdate", hip.PH_DATE, 0, None),
                ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT),
-               ("o_totalprice", hip.PH_DEC64, 2, None)],
+               ("o_totalprice", hip.PH_DEC64, 2, None), ("o_orderstatus", hip.PH_CODE8, 0, tpchgen.ORDERSTATUS_DICT)],
     "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT),
                  ("c_name", hip.PH_STR, 0, None), ("c_phone", hip.PH_STR, 0, None), ("c_acctbal", hip.PH_DEC64, 2, None)],
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),

@@ -138,10 +138,19 @@ def lineitem(sf, first_order=0, n_orders=None, columns=None):
     return _gen(lib().tpchgen_lineitem, _LINEITEM, nrows, sf, first_order, n_orders, columns)
 
 
+ORDERSTATUS_DICT = ["F", "O", "P"]
+
+
 def orders(sf, first=0, n=None, columns=None):
+    """o_orderstatus comes as a code into ORDERSTATUS_DICT (the generator writes the raw byte 'F' / 'O' / 'P')"""
     if n is None:
         n = orders_count(sf) - first
-    return _gen(lib().tpchgen_orders, _ORDERS, n, sf, first, n, columns)
+    cols = _gen(lib().tpchgen_orders, _ORDERS, n, sf, first, n, columns)
+    if "o_orderstatus" in cols:
+        lut = np.zeros(256, np.uint8)
+        lut[ord("O")], lut[ord("P")] = 1, 2
+        cols["o_orderstatus"] = lut[cols["o_orderstatus"]]
+    return cols
 
 
 def customer(sf, first=0, n=None, columns=None):

@@ -657,6 +657,26 @@ def q20_text(t, **kw):
     return _text("oracle_q20_text", vp(keys), i64(len(keys)), vp(key), i64(len(key)), vp(off), vp(ab), cap=1 << 18)
 
 
+class Q21Row(ctypes.Structure):
+    _fields_ = [("s_suppkey", i32), ("numwait", OHuge)]
+
+
+def q21_rows(t, nation="BRAZIL"):
+    T, keep = tpch_struct(t)
+    st = np.frombuffer(b"FOP", np.uint8)[np.ascontiguousarray(t["orders"]["o_orderstatus"])]   # codes -> the raw bytes the restatement compares
+    st = np.ascontiguousarray(st)
+    rows = (Q21Row * len(t["supplier"]["s_suppkey"]))()
+    lib().oracle_q21.restype = i64
+    n = lib().oracle_q21(ctypes.byref(T), ctypes.c_void_p(st.ctypes.data), nation.encode(), rows, i64(len(rows)))
+    assert n >= 0
+    return rows, n
+
+
+def q21_text(t, nation="BRAZIL", limit=100):
+    rows, n = q21_rows(t, nation)
+    return _text("oracle_q21_text", rows, i64(n), i32(limit), cap=1 << 18)
+
+
 Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
 
 

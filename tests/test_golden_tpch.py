@@ -92,6 +92,12 @@ def test_q20_matches_reference_golden(sf1):
     assert O.q20_text(sf1) == golden("plan_q20.txt")
 
 
+def test_q21_matches_reference_golden(sf1):
+    # EXISTS / NOT EXISTS whose join carries a non-equi condition (l2.l_suppkey <> l1.l_suppkey) beside the key, a column-vs-column filter,
+    # o_orderstatus (pins the generator's derivation of it from the lines' status), ORDER BY count DESC, VARCHAR LIMIT 100
+    assert O.q21_text(sf1) == golden("plan_q21.txt")
+
+
 def test_q22_matches_reference_golden(sf1):
     # substring() as a filter operand and as the group key (pins oracle_substring with a reference fixture), IN over VARCHAR, avg(DECIMAL) as a
     # scalar subquery compared DECIMAL > DECIMAL, DECIMAL > FLOAT literal, NOT EXISTS as an ANTI join; pins the generator's c_phone / c_acctbal

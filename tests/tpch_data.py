@@ -9,9 +9,9 @@ def load(num, den, q9=True):
         "lineitem": tpchgen.lineitem(sf, columns=[
             "l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice",
             "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate",
-            "l_commitdate", "l_receiptdate", "l_shipinstruct", "l_shipmode"]),
+            "l_commitdate", "l_receiptdate", "l_shipinstruct", "l_shipmode", "l_linenumber"]),
         "orders": tpchgen.orders(sf, columns=[
-            "o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice"]),
+            "o_orderkey", "o_custkey", "o_orderdate", "o_shippriority", "o_orderpriority", "o_totalprice", "o_orderstatus"]),
         "customer": tpchgen.customer(sf),
     }
     if q9:
