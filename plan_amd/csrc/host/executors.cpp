@@ -966,7 +966,7 @@ std::string gpuOrderExecutor::Init() {
     for (auto &k : keys_) {
         if (k.col < 0 || k.col >= (int)t.size()) return "order key column out of range";
         PhyType p = t[(size_t)k.col].GetInternalType();
-        if (p != PT_INT32 && p != PT_DATE && p != PT_DECIMAL && p != PT_VARCHAR)
+        if (p != PT_INT32 && p != PT_DATE && p != PT_DECIMAL && p != PT_VARCHAR && p != PT_INT128)
             return "ORDER BY key type stays on the CPU executor";   // no RadixScatter case (sort_radix.go:257-321)
     }
     return "";
@@ -1034,6 +1034,12 @@ std::string gpuOrderExecutor::sortAll() {
                         break;
                     }
                     case PT_VARCHAR: { const String &sv = reinterpret_cast<const String *>(u.data)[idx]; h.s.assign(sv.Data, (size_t)sv.Len); break; }
+                    case PT_INT128: {   // hugeEncoder (sort_encoder.go:87-92): Upper then Lower = the signed 128-bit order; COUNT / SUM(INTEGER) results fit 64 bits
+                        const Hugeint &hv = reinterpret_cast<const Hugeint *>(u.data)[idx];
+                        if (!((hv.Upper == 0 && (int64_t)hv.Lower >= 0) || (hv.Upper == -1 && (int64_t)hv.Lower < 0))) return "HUGEINT ORDER BY key beyond 64 bits";
+                        h.v = (int64_t)hv.Lower;
+                        break;
+                    }
                     default: break;
                     }
                 }
@@ -1078,6 +1084,7 @@ std::string gpuOrderExecutor::sortAll() {
             recoded.push_back(d);
             c.data = d;
         }
+        if (child_->OutputTypes()[(size_t)keys_[k].col].GetInternalType() == PT_INT128) c.type = PH_I64;   // staged as its low 64 bits (checked at staging): plain integer order
         kc.push_back(c);
         desc.push_back(keys_[k].descending ? 1 : 0);
     }

@@ -68,31 +68,34 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
     double t0 = now_s();
     {   // lineitem
         std::vector<int64_t> okey((size_t)nl), ext((size_t)nl), disc((size_t)nl), tax((size_t)nl);
-        std::vector<int32_t> pk((size_t)nl), sk((size_t)nl), qty((size_t)nl), ship((size_t)nl), commit((size_t)nl), receipt((size_t)nl);
+        std::vector<int32_t> pk((size_t)nl), sk((size_t)nl), qty((size_t)nl), ship((size_t)nl), commit((size_t)nl), receipt((size_t)nl), lno((size_t)nl);
         std::vector<uint8_t> rf((size_t)nl), ls((size_t)nl), mode((size_t)nl), instr((size_t)nl);
         tpchgen_lineitem_cols lc{};
         lc.l_orderkey = okey.data(); lc.l_partkey = pk.data(); lc.l_suppkey = sk.data(); lc.l_quantity = qty.data(); lc.l_extendedprice = ext.data();
         lc.l_discount = disc.data(); lc.l_tax = tax.data(); lc.l_returnflag = rf.data(); lc.l_linestatus = ls.data(); lc.l_shipdate = ship.data();
         lc.l_commitdate = commit.data(); lc.l_receiptdate = receipt.data(); lc.l_shipmode = mode.data(); lc.l_shipinstruct = instr.data();
+        lc.l_linenumber = lno.data();
         tpchgen_lineitem(num, den, 0, no, &lc);
         generate_s += now_s() - t0; t0 = now_s();
         e = loadTable(ctx, {I64(okey.data()), I32(pk.data()), I32(sk.data()), I32(qty.data()), DEC(ext.data()), DEC(disc.data()), DEC(tax.data()),
                             CODE(rf.data(), dictOf(TPCHGEN_RETURNFLAG_DICT, 3)), CODE(ls.data(), dictOf(TPCHGEN_LINESTATUS_DICT, 2)), DATE(ship.data()),
                             DATE(commit.data()), DATE(receipt.data()), CODE(mode.data(), dictOf(TPCHGEN_SHIPMODE_DICT, 7)),
-                            CODE(instr.data(), dictOf(TPCHGEN_SHIPINSTRUCT_DICT, 4))}, nl, {}, &lineitem, &loaded_bytes);
+                            CODE(instr.data(), dictOf(TPCHGEN_SHIPINSTRUCT_DICT, 4)), I32(lno.data())}, nl, {}, &lineitem, &loaded_bytes);
         if (!e.empty()) return e;
         load_s += now_s() - t0; t0 = now_s();
     }
     {   // orders
         std::vector<int64_t> okey((size_t)no), total((size_t)no);
         std::vector<int32_t> cust((size_t)no), date((size_t)no), sprio((size_t)no);
-        std::vector<uint8_t> oprio((size_t)no);
+        std::vector<uint8_t> oprio((size_t)no), ostat((size_t)no);
         tpchgen_orders_cols oc{};
         oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data(); oc.o_totalprice = total.data();
+        oc.o_orderstatus = ostat.data();
         tpchgen_orders(num, den, 0, no, &oc);
+        for (auto &b : ostat) b = b == 'F' ? 0 : b == 'O' ? 1 : 2;   // the generator writes the raw byte: codes into {"F", "O", "P"}
         generate_s += now_s() - t0; t0 = now_s();
         e = loadTable(ctx, {I64(okey.data()), I32(cust.data()), DATE(date.data()), I32(sprio.data()), CODE(oprio.data(), dictOf(TPCHGEN_ORDERPRIORITY_DICT, 5)),
-                            DEC(total.data())}, no, {O_ORDERKEY}, &orders, &loaded_bytes);
+                            DEC(total.data()), CODE(ostat.data(), {"F", "O", "P"})}, no, {O_ORDERKEY}, &orders, &loaded_bytes);
         if (!e.empty()) return e;
         load_s += now_s() - t0; t0 = now_s();
     }
@@ -154,7 +157,18 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_supplier_cols sc{};
         sc.s_suppkey = key.data(); sc.s_nationkey = nat.data();
         tpchgen_supplier(num, den, 0, ns, &sc);
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data())}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
+        std::vector<int32_t> noff((size_t)ns + 1);
+        std::string nbytes((size_t)ns * 18, '0');
+        for (int64_t r = 0; r < ns; r++) {   // s_name = 'Supplier#' + the key as nine digits (TPC-H 4.2.3)
+            noff[(size_t)r] = (int32_t)(r * 18);
+            char *b = &nbytes[(size_t)r * 18];
+            memcpy(b, "Supplier#", 9);
+            int32_t k = key[(size_t)r];
+            for (int d = 17; d >= 9; d--) { b[d] = (char)('0' + k % 10); k /= 10; }
+        }
+        noff[(size_t)ns] = (int32_t)(ns * 18);
+        HostCol sname{VarcharType(), PH_STR, 0, noff.data(), {}, nbytes.data(), (int64_t)nbytes.size()};
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), sname}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // nation, region: the specification's fixed tables
@@ -490,6 +504,38 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->upperFilter->lhs = {fcol(1)};                    // ps_availqty
         q->upperFilter->rhs = {half, fcol(2), mul};         // 0.5 * sum(l_quantity)
         q->order = {{0, false}};                            // ORDER BY s_name
+        q->ncols = 2;
+        break;
+    }
+    case 21: {
+        // Limit <- Order(numwait desc, s_name) <- Agg(s_name; count(*)) <- ANTI Join[l3] <- SEMI Join[l2] <- Join(orders[o_orderstatus = 'F'])
+        //   <- Join(supplier x nation[BRAZIL]) probe Scan(lineitem l1, l_receiptdate > l_commitdate).
+        // The EXISTS / NOT EXISTS joins carry l2.l_suppkey <> l1.l_suppkey beside the key: the INNER join on l_orderkey emits the key matches, a
+        // Filter compares the two supplier columns, and the l1 rows that keep a pair — by lineitem's primary key (l_orderkey, l_linenumber) — are
+        // an aggregate below the SEMI / ANTI join that closes the step (the l1 subtree is referenced twice per step, so it is built twice).
+        BoolExpr late = BoolExpr::CC(L_RECEIPTDATE, PH_GT, L_COMMITDATE);
+        auto l1Side = [&]() {
+            int nat = p.Scan(&db.nation, {N_NATIONKEY}, {{N_NAME, PH_EQ, LStr("BRAZIL")}});
+            int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY, S_NAME});
+            int js = p.Join(supp, nat, {1}, {0}, {0, 2});                       // s_suppkey, s_name
+            int l1 = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY, L_LINENUMBER}, {}, late);
+            int j1 = p.Join(l1, js, {1}, {0}, {0, 1, 2, 4});                    // l_orderkey, l_suppkey, l_linenumber, s_name
+            int ord = p.Scan(&db.orders, {O_ORDERKEY}, {{O_ORDERSTATUS, PH_EQ, LStr("F")}});
+            return p.Join(j1, ord, {0}, {0}, {0, 1, 2, 3});
+        };
+        auto withOtherSupplier = [&](int rows, bool onlyLate) {
+            int other = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY}, {}, onlyLate ? late : BoolExpr());
+            int pairs = p.Join(rows, other, {0}, {0}, {0, 2, 1, 5});            // l_orderkey, l_linenumber, l1.l_suppkey, other.l_suppkey
+            int differ = p.Filter(pairs, {}, BoolExpr::CC(2, PH_NE, 3));
+            return p.Agg(differ, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_COUNT_STAR, {}}});
+        };
+        int e2 = withOtherSupplier(l1Side(), false);
+        auto j3 = [&]() { return p.Join(l1Side(), e2, {0, 2}, {0, 1}, {0, 1, 2, 3}, JoinSemi); };
+        int n3 = withOtherSupplier(j3(), true);
+        int j4 = p.Join(j3(), n3, {0, 2}, {0, 1}, {3}, JoinAnti);             // s_name
+        p.Agg(j4, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}});
+        q->order = {{1, true}, {0, false}};
+        q->limit = 100;
         q->ncols = 2;
         break;
     }

@@ -427,6 +427,46 @@ def q20_text(db, keys, supp_keys):
     return "#\t\n" + "".join(f"{a}\t{b}\n" for a, b in zip(*cols))
 
 
+def q21_plan(db, nation="BRAZIL"):
+    """cases/tpch/query/q21.sql. A join's non-equi conjunct (l2.l_suppkey <> l1.l_suppkey) is evaluated over the key matches: the INNER join on
+       l_orderkey emits the pairs, a Filter compares the two supplier columns, and the l1 rows that keep a pair — identified by lineitem's primary
+       key (l_orderkey, l_linenumber) — are an aggregate below the SEMI (EXISTS) / ANTI (NOT EXISTS) join that closes the step. The l1 side is
+       referenced by both the pair join and the closing join: the subtree is lowered twice"""
+    p = hip.Plan(db.ctx)
+    late = hip.bool_tree(("colcmp", db.c("lineitem", "l_receiptdate")[0], hip.PH_GT, db.c("lineitem", "l_commitdate")[0]))
+
+    def l1_side():
+        nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey"), [_pred(db, "nation", "n_name", hip.PH_EQ, _s(nation))])
+        supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey", "s_name"))
+        js = p.join(supp, nat, [1], [0], [0, 2])                                                  # s_suppkey, s_name
+        l1 = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey", "l_linenumber"), bools=late)
+        j1 = p.join(l1, js, [1], [0], [0, 1, 2, 4])                                               # l_orderkey, l_suppkey, l_linenumber, s_name
+        orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey"), [_pred(db, "orders", "o_orderstatus", hip.PH_EQ, _s("F"))])
+        return p.join(j1, orders, [0], [0], [0, 1, 2, 3])
+
+    def with_other_supplier(rows, only_late):
+        other = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey"), bools=late if only_late else None)
+        pairs = p.join(rows, other, [0], [0], [0, 2, 1, 5])                                       # l_orderkey, l_linenumber, l1.l_suppkey, other.l_suppkey
+        differ = p.filter(pairs, bools=hip.bool_tree(("colcmp", 2, hip.PH_NE, 3)))
+        return p.agg(differ, [hip.pe_col(0), hip.pe_col(1)], [(hip.PH_A_COUNT_STAR, None)])       # the l1 rows with such a line
+
+    e = with_other_supplier(l1_side(), False)
+    j3 = lambda: p.join(l1_side(), e, [0, 2], [0, 1], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
+    n = with_other_supplier(j3(), True)
+    j4 = p.join(j3(), n, [0, 2], [0, 1], [3], join_type=hip.PH_JT_ANTI)                        # s_name
+    p.agg(j4, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None)])
+    return p.create()
+
+
+def q21_text(db, p, r, limit=100):
+    """ORDER BY numwait DESC, s_name LIMIT 100 + the reference's text; s_name comes back as a row of supplier.s_name"""
+    typ, _sc, _t, col = hip.plan_key_info(p, 0)
+    assert typ == hip.PH_STR
+    names = hip.table_strings(db.ctx, db.t("supplier"), col, [int(r["keys"][g][0]) for g in range(r["ngroups"])])
+    rows = sorted(((names[g], int(r["count"][g][0])) for g in range(r["ngroups"])), key=lambda x: (-x[1], x[0]))[:limit]
+    return "#\t\n" + "".join(f"{a}\t{c}\n" for a, c in rows)
+
+
 Q22_CODES = ("10", "11", "26", "22", "19", "20", "27")
 
 

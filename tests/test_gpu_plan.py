@@ -324,6 +324,20 @@ def test_q20_two_key_join_with_the_subquery_aggregate_matches_golden(ctx, db, sf
     assert "groups stay on the device" in ex
 
 
+def test_q21_exists_with_a_non_equi_condition_matches_golden(ctx, db, sf1):
+    """Q21: the pairs of an N:M join on l_orderkey filtered by a column-vs-column <>, the l1 rows that keep a pair as an aggregate by
+    lineitem's primary key below a two-key SEMI / ANTI join, a VARCHAR group key: the oracle's groups and cases/tpch/1g/plan/q21.txt"""
+    p = tpch.q21_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    text = tpch.q21_text(db, p, r)
+    p.free()
+    orows, n = O.q21_rows(sf1)
+    assert r["ngroups"] == n, ex
+    assert text == golden("plan_q21.txt"), ex
+
+
 def test_q22_substring_keys_anti_join_and_scalar_average_match_golden(ctx, db, sf1):
     """Q22: substring() computed in the plan as a filter operand (IN = OR of =) and as the group key, a scalar avg(DECIMAL) subquery as its own
     plan, DECIMAL > DECIMAL as an exact threshold, NOT EXISTS as an ANTI join: the oracle's groups and cases/tpch/1g/plan/q22.txt"""
