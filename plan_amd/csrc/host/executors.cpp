@@ -979,8 +979,14 @@ std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return 
 static const int64_t kHostSortRows = getenv("PH_ORDER_HOST_ROWS") ? atoll(getenv("PH_ORDER_HOST_ROWS")) : 2048;
 
 std::string gpuOrderExecutor::sortAll() {
-    std::vector<int> cols;
-    for (auto &k : keys_) cols.push_back(k.col);
+    // VARCHAR keys do not go through the batch (its VARCHAR staging is the <= 256-value dictionary of a group column): their rows
+    // are ranked on the host (rank = position of the string among the distinct strings in byte order) and the ranks are the key
+    std::vector<int> cols, batchPos(keys_.size(), -1);
+    {
+        auto types = child_->OutputTypes();
+        for (size_t k = 0; k < keys_.size(); k++)
+            if (types[(size_t)keys_[k].col].GetInternalType() != PT_VARCHAR) { batchPos[k] = (int)cols.size(); cols.push_back(keys_[k].col); }
+    }
     DeviceBatch batch(ctx_, child_->OutputTypes(), cols);
     int64_t total = 0;
     for (;;) {   // SinkChunk for every child chunk (executor_order.go:75-99)
@@ -1062,29 +1068,47 @@ std::string gpuOrderExecutor::sortAll() {
     for (auto &c : chunks_) { std::string e = batch.Append(*c); if (!e.empty()) return e; }
     std::string e = batch.Upload();
     if (!e.empty()) return e;
-    // VARCHAR keys arrive as codes in first-seen order: re-code by the dictionary's byte order so
-    // that code order = string order (what the reference's prefix + full compare yields)
     std::vector<ph_col> kc;
     std::vector<int32_t> desc;
     std::vector<void *> recoded;
+    auto freeRecoded = [&]() { for (void *d : recoded) ph_dev_free(ctx_, d); };
     for (size_t k = 0; k < keys_.size(); k++) {
-        ph_col c = batch.col((int)k);
-        if (c.type == PH_CODE8) {
-            const auto &dict = batch.dict((int)k);
-            std::vector<int> idx(dict.size());
-            for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
-            std::sort(idx.begin(), idx.end(), [&](int a, int b) { return dict[(size_t)a] < dict[(size_t)b]; });
-            std::vector<uint8_t> rank(256, 0);
-            for (size_t i = 0; i < idx.size(); i++) rank[(size_t)idx[i]] = (uint8_t)i;
-            std::vector<uint8_t> codes((size_t)total);
-            if (ph_dev_download(ctx_, codes.data(), c.data, total) != PH_OK) return herr("ph_dev_download");
-            for (auto &x : codes) x = rank[x];
-            void *d = nullptr;
-            if (ph_dev_alloc(ctx_, total, &d) != PH_OK || ph_dev_upload(ctx_, d, codes.data(), total) != PH_OK) return herr("ph_dev_upload");
+        ph_col c{};
+        if (batchPos[k] >= 0) c = batch.col(batchPos[k]);
+        else {
+            std::vector<std::string> vals((size_t)total);
+            std::vector<uint8_t> valid((size_t)(total + 7) / 8 + 8, 0);
+            bool anyNull = false;
+            int64_t row = 0;
+            for (auto &ch : chunks_) {
+                const Vector &v = *ch->Data[(size_t)keys_[k].col];
+                Vector::Unified u;
+                v.ToUnifiedFormat(ch->Card(), &u);
+                for (int i = 0; i < ch->Card(); i++, row++) {
+                    const int64_t idx = u.sel->GetIndex(i);
+                    if (!u.mask->RowIsValid((uint64_t)idx)) { anyNull = true; continue; }
+                    valid[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
+                    const String &sv = reinterpret_cast<const String *>(u.data)[idx];
+                    vals[(size_t)row].assign(sv.Data, (size_t)sv.Len);
+                }
+            }
+            std::vector<std::string> uniq(vals);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            std::vector<int32_t> rank((size_t)total);
+            for (int64_t r = 0; r < total; r++) rank[(size_t)r] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[(size_t)r]) - uniq.begin());
+            void *d = nullptr, *vd = nullptr;
+            if (ph_dev_alloc(ctx_, total * 4, &d) != PH_OK) { freeRecoded(); return herr("ph_dev_alloc"); }
             recoded.push_back(d);
-            c.data = d;
+            if (ph_dev_upload(ctx_, d, rank.data(), total * 4) != PH_OK) { freeRecoded(); return herr("ph_dev_upload"); }
+            if (anyNull) {
+                if (ph_dev_alloc(ctx_, (int64_t)valid.size(), &vd) != PH_OK) { freeRecoded(); return herr("ph_dev_alloc"); }
+                recoded.push_back(vd);
+                if (ph_dev_upload(ctx_, vd, valid.data(), (int64_t)valid.size()) != PH_OK) { freeRecoded(); return herr("ph_dev_upload"); }
+            }
+            c.type = PH_I32; c.data = d; c.validity = (const uint8_t *)vd;
         }
-        if (child_->OutputTypes()[(size_t)keys_[k].col].GetInternalType() == PT_INT128) c.type = PH_I64;   // staged as its low 64 bits (checked at staging): plain integer order
+        // (a HUGEINT key is staged as a scale-0 decimal of its low 64 bits: ph_sort_rows orders decimals by value)
         kc.push_back(c);
         desc.push_back(keys_[k].descending ? 1 : 0);
     }

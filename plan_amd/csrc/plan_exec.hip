@@ -1181,7 +1181,12 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
         // need from it is fetched in one pass (all reads of a row in flight together, the ids read once)
         for (size_t L = 0; L < out->lanes.size(); L++) {
             std::vector<int> cs;
-            for (size_t c = 0; c < out->cols.size(); c++) if (out->cols[c].lane == (int)L) cs.push_back((int)c);
+            for (size_t c = 0; c < out->cols.size(); c++) {
+                if (out->cols[c].lane != (int)L) continue;
+                const auto &tc = out->lanes[L].t->cols[(size_t)out->cols[c].tcol];
+                if (width_of(tc.type) == 0 || tc.validity) continue;   // VARCHAR (offsets + bytes) and NULL-able columns stay behind the row ids
+                cs.push_back((int)c);
+            }
             if (cs.size() >= 2 && out->lanes[L].rows && out->lanes[L].t->nrows >= 8 * std::max<int64_t>(m, 1) && out->lanes[L].t->nrows >= (1 << 20))
                 PL_CHECK(positional(p, out, cs));
         }
