@@ -587,6 +587,19 @@ def bench_operator_interface(h, sf, steps, warmup):
                            "result_rows": len([r for r in rows[1:] if r]), "first_row": rows[1] if len(rows) > 1 else None,
                            "forms_chosen_by_the_library": [l.strip() for l in explain.value.decode().split("\n") if l.startswith(("join", "agg"))]},
             }
+        # every other query whose reference golden the host layer reproduces (tests/test_host_layer.py): whole-query wall time behind the
+        # operator interface at this scale factor, few steps (a record of where each plan stands, not a tuned number)
+        others = {}
+        for q in (1, 4, 5, 6, 7, 8, 11, 12, 14, 15, 17, 18, 19, 20, 21, 22):
+            avg, mn = ctypes.c_double(), ctypes.c_double()
+            text, explain = ctypes.create_string_buffer(1 << 20), ctypes.create_string_buffer(1 << 14)
+            if lib.planhost_tpch_run(db, ctypes.c_int32(q), ctypes.c_int32(3), ctypes.c_int32(2), ctypes.byref(avg), ctypes.byref(mn),
+                                     text, ctypes.c_int64(len(text)), explain, ctypes.c_int64(len(explain))) != 0:
+                others[f"q{q}"] = {"error": lib.planhost_last_error().decode()}
+                continue
+            others[f"q{q}"] = {"ms": round(avg.value, 3), "min_ms": round(mn.value, 3), "result_rows": len([r for r in text.value.decode().split("\n")[1:] if r])}
+        out["tpch_operator_interface"] = {"workload": f"TPC-H SF{sf}, the 16 other queries with a reference golden, through the C++ OperatorExec layer (3 steps behind 2 warm-up runs each)",
+                                          "queries": others}
     finally:
         lib.planhost_tpch_free(db)
     return out

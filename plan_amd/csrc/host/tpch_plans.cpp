@@ -512,7 +512,7 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         //   <- Join(supplier x nation[BRAZIL]) probe Scan(lineitem l1, l_receiptdate > l_commitdate).
         // The EXISTS / NOT EXISTS joins carry l2.l_suppkey <> l1.l_suppkey beside the key: the INNER join on l_orderkey emits the key matches, a
         // Filter compares the two supplier columns, and the l1 rows that keep a pair — by lineitem's primary key (l_orderkey, l_linenumber) — are
-        // an aggregate below the SEMI / ANTI join that closes the step (the l1 subtree is referenced twice per step, so it is built twice).
+        // an aggregate below the SEMI / ANTI join that closes the step (the l1 subtree has two parents per step).
         BoolExpr late = BoolExpr::CC(L_RECEIPTDATE, PH_GT, L_COMMITDATE);
         auto l1Side = [&]() {
             int nat = p.Scan(&db.nation, {N_NATIONKEY}, {{N_NAME, PH_EQ, LStr("BRAZIL")}});
@@ -529,10 +529,11 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
             int differ = p.Filter(pairs, {}, BoolExpr::CC(2, PH_NE, 3));
             return p.Agg(differ, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_COUNT_STAR, {}}});
         };
-        int e2 = withOtherSupplier(l1Side(), false);
-        auto j3 = [&]() { return p.Join(l1Side(), e2, {0, 2}, {0, 1}, {0, 1, 2, 3}, JoinSemi); };
-        int n3 = withOtherSupplier(j3(), true);
-        int j4 = p.Join(j3(), n3, {0, 2}, {0, 1}, {3}, JoinAnti);             // s_name
+        int l1 = l1Side();                                                    // two parents each: ph_plan lowers such a node once per run
+        int e2 = withOtherSupplier(l1, false);
+        int j3 = p.Join(l1, e2, {0, 2}, {0, 1}, {0, 1, 2, 3}, JoinSemi);
+        int n3 = withOtherSupplier(j3, true);
+        int j4 = p.Join(j3, n3, {0, 2}, {0, 1}, {3}, JoinAnti);               // s_name
         p.Agg(j4, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}});
         q->order = {{1, true}, {0, false}};
         q->limit = 100;
@@ -576,19 +577,31 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
 // Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone, s_nationkey] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
 static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) {
     struct St { int64_t n = 0, pos = 0; std::vector<int32_t> key, nat; std::vector<char> addr, phone; std::vector<uint8_t> alen; };
+    // (the generated columns are kept per scale factor: a Scan reads stored rows, it does not regenerate them per query)
+    static std::map<std::pair<int64_t, int64_t>, std::shared_ptr<const St>> cache;
+    std::shared_ptr<const St> data;
+    auto it = cache.find({num, den});
+    if (it != cache.end()) data = it->second;
+    else {
     auto st = std::make_shared<St>();
     st->n = tpchgen_supplier_count(num, den);
     st->key.resize((size_t)st->n); st->nat.resize((size_t)st->n); st->addr.resize((size_t)st->n * TPCHGEN_S_ADDRESS_STRIDE); st->alen.resize((size_t)st->n); st->phone.resize((size_t)st->n * TPCHGEN_S_PHONE_LEN);
     tpchgen_supplier_cols sc{};
     sc.s_suppkey = st->key.data(); sc.s_nationkey = st->nat.data(); sc.s_address = st->addr.data(); sc.s_address_len = st->alen.data(); sc.s_phone = st->phone.data();
     tpchgen_supplier(num, den, 0, st->n, &sc);
+    cache[{num, den}] = st;
+    data = st;
+    }
     const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType(), IntegerType()};
-    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [st, types](Chunk *out) {
-        if (st->pos >= st->n) return false;
-        const int card = (int)std::min<int64_t>(DefaultVectorSize, st->n - st->pos);
+    auto posp = std::make_shared<int64_t>(0);
+    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [data, posp, types](Chunk *out) {
+        const St *st = data.get();
+        int64_t &pos = *posp;
+        if (pos >= st->n) return false;
+        const int card = (int)std::min<int64_t>(DefaultVectorSize, st->n - pos);
         out->Init(types, DefaultVectorSize);
         for (int i = 0; i < card; i++) {
-            const size_t r = (size_t)(st->pos + i);
+            const size_t r = (size_t)(pos + i);
             out->Data[0]->Slice<int32_t>()[i] = st->key[r];
             char name[32];
             snprintf(name, sizeof name, "Supplier#%09d", st->key[r]);
@@ -598,7 +611,7 @@ static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) 
             out->Data[4]->Slice<int32_t>()[i] = st->nat[r];
         }
         out->SetCard(card);
-        st->pos += card;
+        pos += card;
         return true;
     }));
 }

@@ -12,7 +12,10 @@
 // the relation's length and aligned by position — plus output columns that are either references into a lane's
 // table (late materialisation: gathered when something needs the values) or positional device columns.
 #include <algorithm>
+#include <map>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -109,6 +112,8 @@ struct ph_plan {
     std::vector<ph_join *> joins;
     std::vector<ph_strdict *> strdicts;
     std::vector<ph_agg *> inner_aggs;   // aggregates below other operators
+    std::vector<int> parents;           // how many nodes reference node i as a child
+    std::map<std::pair<int, bool>, std::shared_ptr<Rel>> memo;   // relations of nodes with several parents, per run
     std::vector<ph_table *> computed;   // one-column relations of computed VARCHAR values: like the aggregate they outlive the fetch (the host
     std::vector<void *> computed_bufs;  // reads a group key's strings from them) and go with the next run
     std::vector<Domain> domains;
@@ -153,6 +158,7 @@ void release_run(ph_plan *p, bool keep_agg) {
     for (ph_agg *a : p->inner_aggs) ph_agg_free(a);
     p->inner_aggs.clear();
     p->domains.clear();
+    p->memo.clear();
     for (void *q : p->temps) p->ctx->pool_release(q);
     p->temps.clear();
     if (!keep_agg) {
@@ -1196,8 +1202,24 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
     }
 }
 
+int lower_node(ph_plan *p, int idx, bool as_build, Rel *out);
+
+// A node that several parents reference (a subtree used twice: Q21's l1 side feeds the pair join and the SEMI / ANTI join that closes
+// the step) is lowered once per run and role: the relation is a value — row-id vectors and positional columns in run temporaries that
+// nobody writes again — so every further parent starts from a copy of it.
 int lower(ph_plan *p, int idx, bool as_build, Rel *out) {
     if (idx < 0 || idx >= (int)p->nodes.size()) { set_error("ph_plan: child index %d out of range", idx); return PH_EINVAL; }
+    if (p->parents[(size_t)idx] < 2 || p->nodes[(size_t)idx].kind == PH_PN_SCAN) return lower_node(p, idx, as_build, out);
+    const auto key = std::make_pair(idx, as_build);
+    auto it = p->memo.find(key);
+    if (it != p->memo.end()) { *out = *it->second; note(p, "node#%d: lowered before in this run, reused", idx); return PH_OK; }
+    PL_CHECK(lower_node(p, idx, as_build, out));
+    PL_CHECK(apply_pending(p, out));   // (filters still pending would be applied once per parent)
+    p->memo[key] = std::make_shared<Rel>(*out);
+    return PH_OK;
+}
+
+int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
     const Node &nd = p->nodes[(size_t)idx];
     switch (nd.kind) {
     case PH_PN_SCAN: {
@@ -1677,6 +1699,9 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
         if (!okx) { set_error("ph_plan_create: node %d: malformed expression (program length, CASE without WHEN / ELSE, boolean tree children)", i); return fail(PH_EINVAL); }
         p->nodes.push_back(std::move(n));
     }
+    p->parents.assign(p->nodes.size(), 0);
+    for (auto &n : p->nodes)
+        for (int c = 0; c < 2; c++) if (n.child[c] >= 0) p->parents[(size_t)n.child[c]]++;
     *out = p;
     return PH_OK;
 }

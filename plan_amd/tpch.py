@@ -431,7 +431,7 @@ def q21_plan(db, nation="BRAZIL"):
     """cases/tpch/query/q21.sql. A join's non-equi conjunct (l2.l_suppkey <> l1.l_suppkey) is evaluated over the key matches: the INNER join on
        l_orderkey emits the pairs, a Filter compares the two supplier columns, and the l1 rows that keep a pair — identified by lineitem's primary
        key (l_orderkey, l_linenumber) — are an aggregate below the SEMI (EXISTS) / ANTI (NOT EXISTS) join that closes the step. The l1 side is
-       referenced by both the pair join and the closing join: the subtree is lowered twice"""
+       referenced by both the pair join and the closing join: a node with two parents, which the library lowers once per run"""
     p = hip.Plan(db.ctx)
     late = hip.bool_tree(("colcmp", db.c("lineitem", "l_receiptdate")[0], hip.PH_GT, db.c("lineitem", "l_commitdate")[0]))
 
@@ -450,10 +450,11 @@ def q21_plan(db, nation="BRAZIL"):
         differ = p.filter(pairs, bools=hip.bool_tree(("colcmp", 2, hip.PH_NE, 3)))
         return p.agg(differ, [hip.pe_col(0), hip.pe_col(1)], [(hip.PH_A_COUNT_STAR, None)])       # the l1 rows with such a line
 
-    e = with_other_supplier(l1_side(), False)
-    j3 = lambda: p.join(l1_side(), e, [0, 2], [0, 1], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
-    n = with_other_supplier(j3(), True)
-    j4 = p.join(j3(), n, [0, 2], [0, 1], [3], join_type=hip.PH_JT_ANTI)                        # s_name
+    l1 = l1_side()                                                                                # two parents each: lowered once per run
+    e = with_other_supplier(l1, False)
+    j3 = p.join(l1, e, [0, 2], [0, 1], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
+    n = with_other_supplier(j3, True)
+    j4 = p.join(j3, n, [0, 2], [0, 1], [3], join_type=hip.PH_JT_ANTI)                          # s_name
     p.agg(j4, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None)])
     return p.create()
 
