@@ -1488,6 +1488,9 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
     if (!nd.groups.empty() && (S.cols[0].type == PH_I64 || S.cols[0].type == PH_I32) && S.cols[0].src) {
         const auto &sc = S.cols[0].src->cols[(size_t)S.cols[0].src_col];
         if (sc.has_range && sc.max - sc.min > 65536) expected = std::max<int64_t>(S.n / 2, 1024);
+        // ... but a lone key has no more groups than its column has values (Q17's subquery: 60 M rows by l_partkey, 2 M values — the hint
+        // decides between the bulk build's forms)
+        if (sc.has_range && nd.groups.size() == 1) expected = std::min<int64_t>(expected, std::max<int64_t>(sc.max - sc.min + 1, 1024));
     }
     if ((*aggp)) { ph_agg_free((*aggp)); (*aggp) = nullptr; }
     PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &(*aggp)));
