@@ -524,6 +524,19 @@ def bench_general_forms(h, sf):
     out["agg_sink_65k_groups"] = {"rows": n, "groups": 65536, "ms": t * 1e3, "rows_per_s": n / t,
                                   "algorithmic_GBps": n * 16 / t / 1e9, "frac_of_hbm_peak": n * 16 / t / 1e9 / HBM_PEAK_GBS,
                                   "form": "bulk build, second form: count + LDS-staged scatter + sliced LDS tables + merge (4 passes over the rows' 16 B)"}
+    keys.free()
+    card4 = 4_000_000
+    keys = hip.DevColumn(ctx, hip.PH_I64, rng.integers(0, card4, n).astype(np.int64))
+
+    def agg_run4():
+        agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], card4)
+        agg.sink([keys], [vals], None, n)
+        agg.group_count()
+        agg.free()
+    agg_run4()
+    t = best(agg_run4)
+    out["agg_sink_4m_groups"] = {"rows": n, "groups": card4, "ms": t * 1e3, "rows_per_s": n / t, "algorithmic_GBps": n * 16 / t / 1e9,
+                                 "form": "bulk build, second form with two partition levels (64 x 128 bins), one workgroup per bin builds straight into the table"}
     vals.free(); keys.free()
     L = tpchgen.lineitem((sf, 1), columns=["l_orderkey"])
     O = tpchgen.orders((sf, 1), columns=["o_orderkey"])
