@@ -72,8 +72,8 @@ def test_q9_whole_plan_through_operator_interface_matches_reference_golden():
 def test_aggregate_having_and_output_expressions(sf001):
     """The aggregate's output phase (executor_aggr.go:143-263): HAVING conjuncts on a DECIMAL sum and
     on a HUGEINT count ('>' is the comparison both types have), then output expressions over the
-    surviving groups. Parity unpinned by reference fixtures (no golden exercises HAVING): checked
-    against numpy."""
+    surviving groups: checked against numpy here, at these thresholds. The reference fixtures that pin HAVING are Q11's (a DECIMAL sum against
+    a FLOAT threshold) and Q18's (a HUGEINT sum '>' an INTEGER, as the Filter above an aggregate) goldens, further down."""
     import numpy as np
     L = sf001["lineitem"]
     keys, inv = np.unique(L["l_suppkey"], return_inverse=True)

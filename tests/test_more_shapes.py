@@ -317,8 +317,8 @@ def test_device_sort_matches_oracle():
 @pytest.mark.gpu
 def test_device_substring_and_cross_pairs_match_oracle():
     """ph_substring over a PH_STR column (NULL rows, a selection, every branch of substringStartEnd)
-    and ph_cross_pairs against their oracle restatements. No reference fixture exercises either
-    (parity unpinned beyond the Go source the oracle restates)."""
+    and ph_cross_pairs against their oracle restatements. oracle_substring's positive-offset branch is pinned by Q22's golden
+    (tests/test_golden_tpch.py); the other branches and the cross product follow the Go source alone (parity unpinned)."""
     from plan_amd import hip
     ctx = hip.Ctx(0)
     rng = np.random.default_rng(17)
