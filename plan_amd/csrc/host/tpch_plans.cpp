@@ -576,42 +576,47 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
 
 // Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone, s_nationkey] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
 static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) {
-    struct St { int64_t n = 0, pos = 0; std::vector<int32_t> key, nat; std::vector<char> addr, phone; std::vector<uint8_t> alen; };
-    // (the generated columns are kept per scale factor: a Scan reads stored rows, it does not regenerate them per query)
-    static std::map<std::pair<int64_t, int64_t>, std::shared_ptr<const St>> cache;
-    std::shared_ptr<const St> data;
+    // the table's chunks are kept per scale factor — a Scan reads stored rows (the reference's column segments), it neither regenerates
+    // nor re-encodes them per query; every execution hands out shallow copies (the vectors are shared, like a Reference())
+    using Chunks = std::vector<std::shared_ptr<Chunk>>;
+    static std::map<std::pair<int64_t, int64_t>, std::shared_ptr<const Chunks>> cache;
+    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType(), IntegerType()};
+    std::shared_ptr<const Chunks> data;
     auto it = cache.find({num, den});
     if (it != cache.end()) data = it->second;
     else {
-    auto st = std::make_shared<St>();
-    st->n = tpchgen_supplier_count(num, den);
-    st->key.resize((size_t)st->n); st->nat.resize((size_t)st->n); st->addr.resize((size_t)st->n * TPCHGEN_S_ADDRESS_STRIDE); st->alen.resize((size_t)st->n); st->phone.resize((size_t)st->n * TPCHGEN_S_PHONE_LEN);
-    tpchgen_supplier_cols sc{};
-    sc.s_suppkey = st->key.data(); sc.s_nationkey = st->nat.data(); sc.s_address = st->addr.data(); sc.s_address_len = st->alen.data(); sc.s_phone = st->phone.data();
-    tpchgen_supplier(num, den, 0, st->n, &sc);
-    cache[{num, den}] = st;
-    data = st;
-    }
-    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType(), IntegerType()};
-    auto posp = std::make_shared<int64_t>(0);
-    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [data, posp, types](Chunk *out) {
-        const St *st = data.get();
-        int64_t &pos = *posp;
-        if (pos >= st->n) return false;
-        const int card = (int)std::min<int64_t>(DefaultVectorSize, st->n - pos);
-        out->Init(types, DefaultVectorSize);
-        for (int i = 0; i < card; i++) {
-            const size_t r = (size_t)(pos + i);
-            out->Data[0]->Slice<int32_t>()[i] = st->key[r];
-            char name[32];
-            snprintf(name, sizeof name, "Supplier#%09d", st->key[r]);
-            out->Data[1]->SetString(i, name, 18);
-            out->Data[2]->SetString(i, st->addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, st->alen[r]);
-            out->Data[3]->SetString(i, st->phone.data() + r * TPCHGEN_S_PHONE_LEN, TPCHGEN_S_PHONE_LEN);
-            out->Data[4]->Slice<int32_t>()[i] = st->nat[r];
+        const int64_t n = tpchgen_supplier_count(num, den);
+        std::vector<int32_t> key((size_t)n), nat((size_t)n);
+        std::vector<char> addr((size_t)n * TPCHGEN_S_ADDRESS_STRIDE), phone((size_t)n * TPCHGEN_S_PHONE_LEN);
+        std::vector<uint8_t> alen((size_t)n);
+        tpchgen_supplier_cols sc{};
+        sc.s_suppkey = key.data(); sc.s_nationkey = nat.data(); sc.s_address = addr.data(); sc.s_address_len = alen.data(); sc.s_phone = phone.data();
+        tpchgen_supplier(num, den, 0, n, &sc);
+        auto chunks = std::make_shared<Chunks>();
+        for (int64_t pos = 0; pos < n; pos += DefaultVectorSize) {
+            const int card = (int)std::min<int64_t>(DefaultVectorSize, n - pos);
+            auto c = std::make_shared<Chunk>();
+            c->Init(types, DefaultVectorSize);
+            for (int i = 0; i < card; i++) {
+                const size_t r = (size_t)(pos + i);
+                c->Data[0]->Slice<int32_t>()[i] = key[r];
+                char name[32];
+                snprintf(name, sizeof name, "Supplier#%09d", key[r]);
+                c->Data[1]->SetString(i, name, 18);
+                c->Data[2]->SetString(i, addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, alen[r]);
+                c->Data[3]->SetString(i, phone.data() + r * TPCHGEN_S_PHONE_LEN, TPCHGEN_S_PHONE_LEN);
+                c->Data[4]->Slice<int32_t>()[i] = nat[r];
+            }
+            c->SetCard(card);
+            chunks->push_back(c);
         }
-        out->SetCard(card);
-        pos += card;
+        cache[{num, den}] = chunks;
+        data = chunks;
+    }
+    auto next = std::make_shared<size_t>(0);
+    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [data, next](Chunk *out) {
+        if (*next >= data->size()) return false;
+        *out = *(*data)[(*next)++];
         return true;
     }));
 }
