@@ -404,6 +404,14 @@ int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *
  * even when it exceeds max_groups (PH_ECAPACITY: call again with room). */
 int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
                  uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);
+/* ph_agg_fetch restricted to the groups whose aggregates satisfy `value OP k` for every conjunct (the HAVING of aggExecutor's output phase,
+ * executor_aggr.go:143-263, evaluated on the device: the values as columns, ph_filter_select over the group ids, the survivors packed):
+ * agg_index[c] names the aggregate (SUM / MIN / MAX / COUNT: a value that fits int64; AVG is PH_EUNSUPPORTED), value_scale[c] the scale its
+ * values carry (ph_agg_result.scale), k[c] a PH_I32 / PH_DEC64 / PH_F32 constant — a DECIMAL value against a FLOAT literal compares in
+ * float32, as everywhere. NULL aggregates (no input reached them) fail every comparison. */
+int ph_agg_fetch_where(ph_agg *a, int32_t nconj, const int32_t *agg_index, const int32_t *op, const ph_const *k, const int32_t *value_scale,
+                       int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys, uint8_t *key_null, uint64_t *sum_lo,
+                       int64_t *sum_hi, uint64_t *count);
 /* Top-N pre-selection for an `ORDER BY <aggregate> [DESC] ... LIMIT k` tail (the reference's
  * orderExecutor + limit, executor_order.go:56-138, executor_limit.go:105-238, sort over all group
  * rows on the host). A one-workgroup radix select finds the k-th best value
@@ -759,6 +767,11 @@ int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_pl
 /* ORDER BY <aggregate agg_index> [DESC] ... LIMIT k sits above the aggregate: only the groups at least as good
  * as the k-th come back (>= k with ties), as ph_agg_topk; the caller applies the full ORDER BY and the LIMIT. */
 int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k);
+/* HAVING conjuncts `result column OP constant` over the root's AGGREGATE columns (ph_pred.col counts the result's columns: group keys first,
+ * then the aggregates), applied on the device when the groups are fetched (ph_agg_fetch_where): only the surviving groups come back.
+ * PH_EUNSUPPORTED — and the caller filters the fetched rows itself — for a conjunct over a key column or an AVG, for Agg <- Scan plans
+ * (a fused scan: few groups) and beside ph_plan_set_topk. */
+int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj);
 /* enqueue one execution of the whole subtree (host round trips only where a row count sizes the next step) */
 int ph_plan_run(ph_plan *p);
 /* the group rows of the last run, in first-seen order (ph_agg_result_free releases them). If the run's

@@ -1748,6 +1748,12 @@ std::string gpuResidentPlanExecutor::Init() {
     if (ph_plan_create(ctx_, desc.data(), (int32_t)nn, &plan_) != PH_OK) return herr("ph_plan_create");
     if (topkAgg_ >= 0 && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
     for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
+    if (!having_.empty() && topkAgg_ < 0) {   // numeric conjuncts over aggregate columns: filtered on the device, only the survivors are fetched
+        std::vector<ph_pred> hp;
+        bool numeric = true;
+        for (auto &h : having_) { numeric = numeric && h.k.kind != Literal::Str && h.k.kind != Literal::DateDays; hp.push_back(lowerCompare(h)); }
+        havingOnDevice_ = numeric && ph_plan_set_having(plan_, (int32_t)hp.size(), hp.data()) == PH_OK;
+    }
     if (!outputs_.empty()) { std::string e = gpuProjectExecutor::Types(outputs_, outTypes_, &finalTypes_); if (!e.empty()) return e; }
     return "";
 }
@@ -1798,7 +1804,7 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
         std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo, r->sum_hi,
                                        r->count, &results_);
         ph_agg_result_free(r);
-        if (e.empty()) e = ApplyAggOutputPhase(ctx_, having_, outputs_, outTypes_, finalTypes_, &results_);
+        if (e.empty()) e = ApplyAggOutputPhase(ctx_, havingOnDevice_ ? std::vector<Compare>{} : having_, outputs_, outTypes_, finalTypes_, &results_);
         if (!e.empty()) { *err = e; return InvalidOpResult; }
         built_ = true;
     }

@@ -486,6 +486,7 @@ private:
     ph_ctx *ctx_;
     ResidentPlan rp_;
     std::vector<Compare> having_;
+    bool havingOnDevice_ = false;       // the plan applies the conjuncts where the groups are (ph_plan_set_having)
     std::vector<ProjExpr> outputs_;
     std::vector<LType> outTypes_, finalTypes_, argType_;
     int topkAgg_ = -1;

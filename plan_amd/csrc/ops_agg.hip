@@ -2065,28 +2065,26 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
 // One host round trip: the records of up to max_groups groups are packed on the device (the kernel
 // reads the group count there) and header + records come back in one copy when they fit the mailbox
 // (64 KiB; otherwise the header first, then exactly the records that exist).
-extern "C" int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
-                            uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
-    PH_REQUIRE(a && ngroups && max_groups >= 0, "ph_agg_fetch: bad arguments");
-    *ngroups = 0;
-    if (a->cap == 0) return PH_OK;   // nothing sunk yet
+// the groups ids_dev[0 .. meta_dev[0]) (ids_dev == nullptr: all of them, meta_dev = the table's counters) to the host, first-seen order
+static int agg_fetch_impl(ph_agg *a, const int *ids_dev, const int *meta_dev, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
+                          uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
     ph_ctx *cx = a->ctx;
     const size_t rec = 2 + (size_t)a->nkeys + 3 * (size_t)a->naggs;
     const int64_t cap = std::min<int64_t>(max_groups, a->gcap);
     unsigned long long *pack = nullptr;
     PH_CHECK(cx->pool_alloc((int64_t)(2 + (size_t)cap * rec) * 8, (void **)&pack));
     ph::agg_pack_kernel<<<(int)std::max<int64_t>(1, std::min<int64_t>((cap + 255) / 256, 1024)), 256, 0, cx->stream>>>(
-        nullptr, a->counters, a->counters, (int)cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
+        ids_dev, meta_dev, a->counters, (int)cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
     std::vector<unsigned long long> host(2 + (size_t)cap * rec);
     int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
     const bool one_copy = (int64_t)host.size() * 8 <= (64 << 10);
     if (rc == PH_OK) rc = cx->download(host.data(), pack, one_copy ? (int64_t)host.size() * 8 : 16);
     int64_t ng = 0;
     if (rc == PH_OK) {
-        const int *h = reinterpret_cast<const int *>(host.data());   // {group count, error flag, group count, error flag}
+        const int *h = reinterpret_cast<const int *>(host.data());   // {groups to fetch, -, the table's group count, its error flag}
         ng = h[0];
         *ngroups = ng;
-        if (h[1]) { ph::set_error("ph_agg: device table error flag %d", h[1]); rc = PH_EHIP; }
+        if (h[3]) { ph::set_error("ph_agg: device table error flag %d", h[3]); rc = PH_EHIP; }
         else if (ng > max_groups) { ph::set_error("ph_agg_fetch: %lld groups, room for %lld", (long long)ng, (long long)max_groups); rc = PH_ECAPACITY; }
         else if (!one_copy && ng > 0) rc = cx->download(host.data() + 2, pack + 2, (int64_t)((size_t)ng * rec) * 8);
     }
@@ -2131,6 +2129,65 @@ extern "C" int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int
         }
     }
     return PH_OK;
+}
+
+extern "C" int ph_agg_fetch(ph_agg *a, int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys,
+                            uint8_t *key_null, uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && ngroups && max_groups >= 0, "ph_agg_fetch: bad arguments");
+    *ngroups = 0;
+    if (a->cap == 0) return PH_OK;   // nothing sunk yet
+    return agg_fetch_impl(a, nullptr, a->counters, max_groups, ngroups, first_row, keys, key_null, sum_lo, sum_hi, count);
+}
+
+// HAVING on the device: the aggregate values as columns (ph_agg_values_dev), the conjuncts as a chain of ph_filter_select over the group
+// ids, the surviving groups packed and fetched — instead of every group travelling to the host for the comparison
+extern "C" int ph_agg_fetch_where(ph_agg *a, int32_t nconj, const int32_t *agg_index, const int32_t *op, const ph_const *k, const int32_t *value_scale,
+                                  int64_t max_groups, int64_t *ngroups, int64_t *first_row, int64_t *keys, uint8_t *key_null, uint64_t *sum_lo,
+                                  int64_t *sum_hi, uint64_t *count) {
+    PH_REQUIRE(a && ngroups && max_groups >= 0 && nconj >= 1 && agg_index && op && k && value_scale, "ph_agg_fetch_where: bad arguments");
+    *ngroups = 0;
+    if (a->cap == 0) return PH_OK;
+    ph_ctx *cx = a->ctx;
+    int64_t ng = 0;
+    PH_CHECK(ph_agg_group_count(a, &ng));
+    if (ng == 0) return PH_OK;
+    std::vector<void *> tmp;
+    auto release = [&]() { for (void *q : tmp) cx->pool_release(q); };
+    auto alloc = [&](int64_t bytes, void **out) { int rc = cx->pool_alloc(bytes, out); if (rc == PH_OK) tmp.push_back(*out); return rc; };
+    const int32_t *sel = nullptr;
+    int64_t cnt = ng;
+    int rc = PH_OK;
+    for (int32_t c = 0; c < nconj && rc == PH_OK && cnt > 0; c++) {
+        if (agg_index[c] < 0 || agg_index[c] >= a->naggs) { ph::set_error("ph_agg_fetch_where: aggregate %d out of range", agg_index[c]); rc = PH_EINVAL; break; }
+        void *vals = nullptr, *valid = nullptr, *out = nullptr;
+        if ((rc = alloc(ng * 8, &vals)) != PH_OK || (rc = alloc((ng + 7) / 8 + 64, &valid)) != PH_OK || (rc = alloc(cnt * 4, &out)) != PH_OK) break;
+        int64_t n2 = 0;
+        if ((rc = ph_agg_values_dev(a, agg_index[c], (int64_t *)vals, (uint8_t *)valid, ng, &n2)) != PH_OK) break;
+        ph_col v{};
+        const int kind = a->aggs[agg_index[c]].kind;
+        v.type = (kind == PH_A_COUNT || kind == PH_A_COUNT_STAR) ? PH_DEC64 : PH_DEC64;   // values travel as int64 at the argument's scale
+        v.scale = value_scale[c];
+        v.data = vals; v.validity = (const uint8_t *)valid;
+        int64_t m = 0;
+        ph_const kc = k[c];
+        if (kc.type == PH_I32) {   // an INTEGER literal against a DECIMAL / HUGEINT value is cast to the value's type by the binder (DecimalSizeCheck + tryCastInt32ToDecimal)
+            kc.type = PH_DEC64; kc.scale = v.scale;
+            for (int s = 0; s < v.scale; s++) kc.i *= 10;
+        }
+        rc = ph_filter_select(cx, &v, ng, op[c], &kc, sel, cnt, (int32_t *)out, &m);
+        sel = (const int32_t *)out;
+        cnt = m;
+    }
+    if (rc != PH_OK) { release(); return rc; }
+    if (cnt == 0) { release(); return PH_OK; }
+    if (cnt > max_groups) { release(); *ngroups = cnt; ph::set_error("ph_agg_fetch_where: %lld groups, room for %lld", (long long)cnt, (long long)max_groups); return PH_ECAPACITY; }
+    int *meta = nullptr;
+    if ((rc = alloc(16, (void **)&meta)) != PH_OK) { release(); return rc; }
+    const int m2[2] = {(int)cnt, 0};
+    rc = ph_dev_upload(cx, meta, m2, 8);
+    if (rc == PH_OK) rc = agg_fetch_impl(a, sel, meta, max_groups, ngroups, first_row, keys, key_null, sum_lo, sum_hi, count);
+    release();
+    return rc;
 }
 
 extern "C" int ph_agg_finalize(ph_agg *a, int64_t max_groups, int64_t *first_row, int64_t *keys,

@@ -112,6 +112,7 @@ struct ph_plan {
     std::vector<ph_join *> joins;
     std::vector<ph_strdict *> strdicts;
     std::vector<ph_agg *> inner_aggs;   // aggregates below other operators
+    std::vector<ph_pred> having;        // conjuncts over the root's aggregate columns, applied where the groups are (ph_plan_set_having)
     std::vector<int> parents;           // how many nodes reference node i as a child
     std::map<std::pair<int, bool>, std::shared_ptr<Rel>> memo;   // relations of nodes with several parents, per run
     std::vector<ph_table *> computed;   // one-column relations of computed VARCHAR values: like the aggregate they outlive the fetch (the host
@@ -1596,7 +1597,18 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
         std::vector<uint64_t> lo((size_t)room * std::max(naggs, 1)), cnt((size_t)room * std::max(naggs, 1));
         int rc;
         if (p->topk_agg >= 0) rc = ph_agg_topk(p->agg, p->topk_agg, p->topk_desc, p->topk_k, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
-        else rc = ph_agg_fetch(p->agg, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
+        else if (!p->having.empty()) {
+            std::vector<int32_t> ai, op, sc;
+            std::vector<ph_const> ks;
+            for (auto &h : p->having) {
+                const int a = h.col - nkeys;
+                ai.push_back(a); op.push_back(h.op); ks.push_back(h.k);
+                const int kind = nd.aggs[(size_t)a].kind;
+                sc.push_back(kind == PH_A_COUNT || kind == PH_A_COUNT_STAR ? 0 : p->agg_scale[(size_t)a]);
+            }
+            rc = ph_agg_fetch_where(p->agg, (int32_t)ai.size(), ai.data(), op.data(), ks.data(), sc.data(), room, &ng, first.data(), keys.data(), knull.data(),
+                                    lo.data(), hi.data(), cnt.data());
+        } else rc = ph_agg_fetch(p->agg, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
         if (rc == PH_ECAPACITY && ng > room) { room = ng; continue; }
         PL_CHECK(rc);
         ph_agg_result *r = new_result(ng, nkeys, naggs);
@@ -1714,6 +1726,23 @@ extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descendin
     p->topk_agg = agg_index;
     p->topk_desc = descending ? 1 : 0;
     p->topk_k = k;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj) {
+    PH_REQUIRE(p && nconj >= 0 && (nconj == 0 || conj), "ph_plan_set_having: bad arguments");
+    const Node &root = p->nodes.back();
+    const int nkeys = (int)root.groups.size(), naggs = (int)root.aggs.size();
+    if (p->topk_agg >= 0) { set_error("ph_plan_set_having: the plan has a top-k preselection"); return PH_EUNSUPPORTED; }
+    if (root.child[0] >= 0 && p->nodes[(size_t)root.child[0]].kind == PH_PN_SCAN) { set_error("ph_plan_set_having: Agg <- Scan runs as a fused scan (few groups: the host filters them)"); return PH_EUNSUPPORTED; }
+    for (int32_t c = 0; c < nconj; c++) {
+        const int a = conj[c].col - nkeys;
+        if (a < 0 || a >= naggs) { set_error("ph_plan_set_having: conjunct %d is not over an aggregate column", c); return PH_EUNSUPPORTED; }
+        if (root.aggs[(size_t)a].kind == PH_A_AVG) { set_error("ph_plan_set_having: AVG is a quotient the host owns"); return PH_EUNSUPPORTED; }
+        const int kt = conj[c].k.type;
+        if (kt != PH_I32 && kt != PH_DEC64 && kt != PH_F32) { set_error("ph_plan_set_having: constant type %d", kt); return PH_EUNSUPPORTED; }
+    }
+    p->having.assign(conj, conj + nconj);
     return PH_OK;
 }
 

@@ -525,12 +525,18 @@ class Agg:
         check(lib().ph_agg_group_count(self.h, ctypes.byref(n)))
         return n.value
 
-    def finalize(self, python_ints=True, room=1024):
+    def finalize(self, python_ints=True, room=1024, where=None):
         """ph_agg_fetch with room for `room` groups first (one host round trip when they fit), again
-        with the reported count when there are more"""
+        with the reported count when there are more. where = [(agg_index, op, Const, value_scale), ...]: ph_agg_fetch_where — only the
+        groups whose aggregates satisfy every conjunct (HAVING on the device)"""
         na = max(self.naggs, 1)
         P = lambda a: vp(a.ctypes.data)
         m = max(room, 1)
+        if where:
+            wi = (i32 * len(where))(*[w[0] for w in where])
+            wo = (i32 * len(where))(*[w[1] for w in where])
+            wk = (Const * len(where))(*[w[2] for w in where])
+            ws = (i32 * len(where))(*[w[3] for w in where])
         while True:
             first = np.zeros(m, np.int64)
             keys = np.zeros(m * self.nkeys, np.int64)
@@ -539,7 +545,10 @@ class Agg:
             hi = np.zeros(m * na, np.int64)
             cnt = np.zeros(m * na, np.uint64)
             n = i64()
-            rc = lib().ph_agg_fetch(self.h, i64(m), ctypes.byref(n), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt))
+            if where:
+                rc = lib().ph_agg_fetch_where(self.h, i32(len(where)), wi, wo, wk, ws, i64(m), ctypes.byref(n), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt))
+            else:
+                rc = lib().ph_agg_fetch(self.h, i64(m), ctypes.byref(n), P(first), P(keys), P(knull), P(lo), P(hi), P(cnt))
             if rc == PH_ECAPACITY and n.value > m:
                 m = n.value
                 continue
@@ -965,6 +974,13 @@ class Plan:
         self.h = vp()
         check(lib().ph_plan_create(self.ctx.h, arr, i32(len(self.nodes)), ctypes.byref(self.h)))
         return self
+
+    def set_having(self, conjuncts):
+        """conjuncts: hip.pred(result column, op, const) over the root's aggregate columns; raises PlanHipError(PH_EUNSUPPORTED) when the
+        plan cannot apply them on the device (the caller filters the fetched groups)"""
+        arr = (Pred * max(len(conjuncts), 1))(*conjuncts)
+        self._keep.append(arr)
+        check(lib().ph_plan_set_having(self.h, i32(len(conjuncts)), arr))
 
     def set_topk(self, agg_index, k, descending=True):
         check(lib().ph_plan_set_topk(self.h, i32(agg_index), i32(1 if descending else 0), i64(k)))

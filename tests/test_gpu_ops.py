@@ -2017,3 +2017,34 @@ def test_string_keys_interning_groups_and_joins(ctx):
     j.free(); agg.free(); d.free(); d2.free()
     for c in (col, dv, pc):
         c.free()
+
+
+@pytest.mark.gpu
+def test_having_on_the_device_matches_the_oracle_filter(ctx):
+    """ph_agg_fetch_where: the groups whose SUM(DECIMAL) exceeds a DECIMAL / a FLOAT constant (float32 compare, as ph_filter_select) and whose
+    COUNT(*) exceeds k — against oracle_select over the same group values (executeSelect's rules: function_operator_boolean.go:393-521)"""
+    rng = np.random.default_rng(21)
+    n, card = 300_000, 5_000
+    keys = rng.integers(0, card, n).astype(np.int32)
+    vals = rng.integers(-50_000, 200_000, n).astype(np.int64)          # DECIMAL scale 2
+    agg = hip.Agg(ctx, [hip.PH_I32], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], card)
+    agg.sink([hip.DevColumn(ctx, hip.PH_I32, keys)], [hip.DevColumn(ctx, hip.PH_DEC64, vals, scale=2)], None, n)
+    full = agg.finalize()
+    sums = np.array([s[0] for s in full["sum"]], np.int64)
+    cnts = full["count"][:, 1]
+    for k_sum, k_cnt in ((hip.const(hip.PH_DEC64, i=4_500_000, scale=2), 55), (hip.const(hip.PH_F32, f=45000.37), 62), (hip.const(hip.PH_I32, i=47000), 1)):
+        # ('>' is the one comparison DECIMAL and HUGEINT both have in selectOperation: '>=' on them selects nothing there — and here)
+        got = agg.finalize(where=[(0, hip.PH_GT, k_sum, 2), (1, hip.PH_GT, hip.const(hip.PH_I32, i=k_cnt - 1), 0)])
+        assert agg.finalize(where=[(1, hip.PH_GE, hip.const(hip.PH_I32, i=1), 0)])["ngroups"] == 0
+        if k_sum.type == hip.PH_F32:
+            s1 = O.select(O.col(O.OT_DECIMAL, sums, scale=2), O.OP_GT, O.const(O.OT_FLOAT, f=k_sum.f), n=len(sums))
+        elif k_sum.type == hip.PH_DEC64:
+            s1 = np.nonzero(sums > k_sum.i)[0]
+        else:
+            s1 = np.nonzero(sums > k_sum.i * 100)[0]
+        keep = [g for g in s1 if cnts[g] >= k_cnt]
+        assert 0 < len(keep) < full["ngroups"]
+        assert got["ngroups"] == len(keep)
+        assert got["keys"][:, 0].tolist() == full["keys"][keep, 0].tolist()                   # first-seen order kept
+        assert [s[0] for s in got["sum"]] == [full["sum"][g][0] for g in keep]
+    agg.free()
