@@ -311,6 +311,17 @@ def q11_rows(grouped, total, fraction=0.0001):
     return [(int(grouped["keys"][g][0]), grouped["sum"][g][0]) for g in range(grouped["ngroups"]) if f32(grouped["sum"][g][0], grouped["scale"][0]) > thr]
 
 
+def q11_set_having(grouped_plan, total, fraction=0.0001):
+    """the same HAVING on the device: the threshold float32(total) * float32(fraction) becomes a FLOAT constant of ph_plan_set_having, the
+       DECIMAL sums compare with it in float32 where the groups are, and only the survivors are fetched. Returns False when the total is NULL"""
+    from decimal import Decimal
+    if total["ngroups"] == 0:
+        return False
+    thr = np.float32(np.float32(float(Decimal(total["sum"][0][0]).scaleb(-total["scale"][0]))) * np.float32(fraction))
+    grouped_plan.set_having([hip.pred(1, hip.PH_GT, hip.const(hip.PH_F32, f=float(thr)))])
+    return True
+
+
 def q12_plan(db, modes=("FOB", "TRUCK"), d1=None, d2=None):
     """cases/tpch/query/q12.sql: integer CASE sums over lineitem[shipmode IN, two column-vs-column date comparisons, receipt range]
        joined with orders"""

@@ -288,8 +288,15 @@ def test_q11_having_against_a_scalar_subquery_matches_golden(ctx, db, sf1):
     g.run(); t.run()
     rg, rt = g.fetch(), t.fetch()
     ex = g.explain()
-    g.free(); t.free()
+    t.free()
     rows = tpch.q11_rows(rg, rt)
+    # ... and with the HAVING applied on the device (ph_plan_set_having): the same groups, only they are fetched
+    assert tpch.q11_set_having(g, rt)
+    g.run()
+    rd = g.fetch()
+    assert rd["ngroups"] == len(rows) < rg["ngroups"]
+    assert sorted((int(rd["keys"][i][0]), rd["sum"][i][0]) for i in range(rd["ngroups"])) == sorted(rows)
+    g.free()
     orows, n = O.q11_rows(sf1)
     assert sorted(rows) == sorted((orows[i].ps_partkey, orows[i].value.unscaled(2)) for i in range(n)), ex
     text = "#\t\n" + "".join(f"{k}\t{tpch.dec_text(v, 2)}\n" for k, v in sorted(rows, key=lambda kv: -kv[1]))
