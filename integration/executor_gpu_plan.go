@@ -729,8 +729,39 @@ type planTopK struct {
 	k          int64
 }
 
+// HAVING conjuncts of the form `aggregate OP numeric literal` go down to the plan (ph_plan_set_having: evaluated on the device when the
+// groups are fetched, with selectOperation's own rules — '>' is the one comparison DECIMAL and HUGEINT have, a DECIMAL against a FLOAT
+// literal compares in float32); anything else — a conjunct over a group key, an OR, an AVG — keeps the reference's ExprExec below.
+// In the aggregate's output phase a column reference addresses [group columns (table -1) | - | aggregate results (table -3)]
+// (executor_aggr.go:143-263): the result column of ph_pred counts the group keys first.
+func (e *gpuResidentPlanExecutor) pushHaving() bool {
+	var ptrs []unsafe.Pointer
+	preds := make([]C.ph_pred, 0, len(e.op.Filters))
+	for _, f := range e.op.Filters {
+		if f == nil || f.Typ != ET_Func || len(f.Children) != 2 {
+			return false
+		}
+		op, isCmp := cmpOps[f.FuncName()]
+		tab, col, isCol := colRefOf(stripCast(f.Children[0]))
+		if !isCmp || !isCol || tab != -3 {
+			return false
+		}
+		k, ok := lowerConst(f.Children[1], &ptrs)
+		if !ok || len(ptrs) > 0 || k._type == C.PH_STR || k._type == C.PH_DATE {
+			for _, q := range ptrs {
+				C.free(q)
+			}
+			return false
+		}
+		var p C.ph_pred
+		p.col, p.op, p.k = C.int32_t(e.nGroups+col), op, k
+		preds = append(preds, p)
+	}
+	return len(preds) > 0 && C.ph_plan_set_having(e.plan, C.int32_t(len(preds)), &preds[0]) == C.PH_OK
+}
+
 func (e *gpuResidentPlanExecutor) Init() error {
-	if len(e.op.Filters) > 0 {
+	if len(e.op.Filters) > 0 && !e.pushHaving() {
 		e.havingEx = NewExprExec(e.op.Filters...)
 		e.sel = chunk.NewSelectVector(util.DefaultVectorSize)
 	}
