@@ -1028,7 +1028,9 @@ struct ph_agg {
     long long *sum_hi = nullptr;
     unsigned long long *cnt = nullptr;
     long long *first_row = nullptr;
-    int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] need-grow flag of the running sink
+    int *counters = nullptr;  // [0] ngroups, [1] error flag, [2] need-grow flag of the running sink; [4..7] ph_agg_topk's state words (zeroed with the
+                              // counters by the first sink's clearing launch: the first top-k of a table needs no memset launch of its own)
+    bool topk_state_used = false;
     int *kinds_dev = nullptr;
     int64_t rows_sunk = 0;
     int64_t expected_groups = 0;   // ph_agg_create's hint: selects the bulk build of the first sink
@@ -1118,7 +1120,7 @@ int agg_resize(ph_agg *a, int64_t cap, int ng, bool clear_slots = true) {
 int agg_ensure(ph_agg *a, int64_t min_cap = 0) {
     if (a->cap != 0) return PH_OK;
     PH_CHECK(agg_resize(a, std::max(min_cap, next_pow2(std::max<int64_t>(4096, 2 * a->expected_groups))), 0, false));
-    PH_CHECK(agg_clear(a, true, 0, a->fresh ? 4 : 0, nullptr, 0));
+    PH_CHECK(agg_clear(a, true, 0, a->fresh ? 8 : 0, nullptr, 0));
     a->fresh = false;
     return PH_OK;
 }
@@ -1153,7 +1155,7 @@ extern "C" int ph_agg_create(ph_ctx *ctx, int32_t nkeys, const int32_t *key_type
     for (int c = 0; c < nkeys; c++) a->key_types[c] = key_types[c];
     for (int i = 0; i < naggs; i++) { a->aggs[i] = aggs[i]; kinds[i] = aggs[i].kind; }
     int rc = PH_OK;
-    if (ctx->pool_alloc(16, (void **)&a->counters) != PH_OK) {   // cleared by the first sink's clearing launch (a->fresh)
+    if (ctx->pool_alloc(32, (void **)&a->counters) != PH_OK) {   // cleared by the first sink's clearing launch (a->fresh)
         ph::set_error("ph_agg_create: device allocation failed");
         rc = PH_EHIP;
     }
@@ -1399,7 +1401,7 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
         B.S.gkeys = a->gkeys; B.S.gnull = a->gnull; B.S.sum_lo = a->sum_lo; B.S.sum_hi = a->sum_hi;
         B.S.cnt = a->cnt; B.S.first_row = a->first_row; B.S.gcap = a->gcap;
         if (attempt == 0) {
-            if ((rc = agg_clear(a, new_table, 0, 4, nullptr, 0)) != PH_OK) break;
+            if ((rc = agg_clear(a, new_table, 0, 8, nullptr, 0)) != PH_OK) break;
             a->fresh = false;
         } else if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
         if (two_level) {
@@ -1430,7 +1432,7 @@ int bulk_sink_v2(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_
     if (settled) return PH_OK;
     // void: leave an empty table and clean counters behind
     (void)voided;
-    PH_CHECK(agg_clear(a, true, 0, 4, nullptr, 0));
+    PH_CHECK(agg_clear(a, true, 0, 8, nullptr, 0));
     return PH_EUNSUPPORTED;
 }
 
@@ -1493,7 +1495,7 @@ int bulk_sink(ph_agg *a, const ph::AggSinkParams &P, const bool *used, int64_t n
         B.S.gkeys = a->gkeys; B.S.gnull = a->gnull; B.S.sum_lo = a->sum_lo; B.S.sum_hi = a->sum_hi;
         B.S.cnt = a->cnt; B.S.first_row = a->first_row; B.S.gcap = a->gcap;
         if (attempt == 0) {   // one clearing launch: the new table's slots and all four counter words
-            if ((rc = agg_clear(a, new_table, 0, 4, nullptr, 0)) != PH_OK) break;
+            if ((rc = agg_clear(a, new_table, 0, 8, nullptr, 0)) != PH_OK) break;
             a->fresh = false;
         } else if (hipMemsetAsync(a->counters, 0, 12, ctx->stream) != hipSuccess) { rc = PH_EHIP; break; }
         switch (nk) {
@@ -1803,7 +1805,7 @@ extern "C" int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *a
     PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
-    PH_CHECK(agg_clear(a, false, 0, 4, nullptr, 0));   // the four counter words
+    PH_CHECK(agg_clear(a, false, 0, 8, nullptr, 0));   // the four counter words + the top-k state words
     a->fresh = false;
     ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
     PH_HIP(hipGetLastError());
@@ -2001,7 +2003,7 @@ extern "C" int ph_agg_sink_masked(ph_agg *a, const ph_col *keys, const ph_col *a
     }
     // one clearing launch: a new table's slots, the counters (all four on first use, else the need-grow
     // word), the progress words
-    if (rc == PH_OK) rc = agg_clear(a, new_table, a->fresh ? 0 : 2, a->fresh ? 4 : 1, progress, grid);
+    if (rc == PH_OK) rc = agg_clear(a, new_table, a->fresh ? 0 : 2, a->fresh ? 8 : 1, progress, grid);
     a->fresh = false;
     // the table cannot hold more groups than rows were sunk into it: while that bound plus this
     // call's rows fits, no growth is possible and neither the group count nor the need-grow flag
@@ -2223,9 +2225,15 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     PH_CHECK(ctx->pool_alloc((int64_t)std::max(cap, 1) * 4, (void **)&ids));
     PH_CHECK(ctx->pool_alloc(a->gcap * 4, (void **)&cand_ids));
     PH_CHECK(ctx->pool_alloc(a->gcap * 8, (void **)&cand_keys));
-    PH_CHECK(ctx->pool_alloc(64, (void **)&state));
+    const bool own_state = a->topk_state_used;   // the words beside the counters are clean once: zeroed by the table's first clearing launch
+    if (own_state) {
+        PH_CHECK(ctx->pool_alloc(64, (void **)&state));
+        PH_HIP(hipMemsetAsync(state, 0, 64, ctx->stream));
+    } else {
+        state = a->counters + 4;
+        a->topk_state_used = true;
+    }
     PH_CHECK(ctx->pool_alloc((int64_t)(2 + (size_t)cap * rec) * 8, (void **)&pack));
-    PH_HIP(hipMemsetAsync(state, 0, 64, ctx->stream));
     int *meta = state + 2;
     const int tg = (int)((a->gcap + ph::TOPK_CHUNK - 1) / ph::TOPK_CHUNK);   // grid from the capacity: the count stays on the device
     ph::topk_select_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, a->counters, descending,
@@ -2247,7 +2255,7 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
         host.resize(2 + n * rec);
         rc = ctx->download(host.data() + 2 + first_recs * rec, pack + 2 + first_recs * rec, (int64_t)((n - first_recs) * rec) * 8);
     }
-    ctx->pool_release(state);
+    if (own_state) ctx->pool_release(state);
     ctx->pool_release(ids);
     ctx->pool_release(cand_ids);
     ctx->pool_release(cand_keys);
