@@ -760,7 +760,8 @@ typedef struct {
 } ph_plan_node;
 
 typedef struct ph_plan ph_plan;
-/* nodes[nnodes-1] is the root and must be a PH_PN_AGG. The descriptor (and the strings of its predicates) is
+/* nodes[nnodes-1] is the root: a PH_PN_AGG (the groups come back through ph_plan_fetch) or a join / filter / project (its rows through
+ * ph_plan_fetch_rows). The descriptor (and the strings of its predicates) is
  * copied; the tables must outlive the plan. PH_EUNSUPPORTED for a shape outside the device path (the caller
  * keeps its per-operator executors). */
 int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_plan **out);
@@ -778,6 +779,21 @@ int ph_plan_run(ph_plan *p);
  * optimistic forms met a broken statistic (deferred PH_ECONSTRAINT), the plan is run again conservatively
  * first; later runs of this plan then start conservatively. */
 int ph_plan_fetch(ph_plan *p, ph_agg_result **out);
+/* A plan whose root is NOT an aggregate — a join, filter or project (Q15's final Join(supplier, revenue = max)) — returns the root
+ * relation's rows: every fixed-width column as nrows values widened to 64 bits (type[c] / scale[c] say what they are; NULL-able
+ * columns are PH_EUNSUPPORTED), every VARCHAR column — a table column behind row ids, or a value computed in the plan — as
+ * offsets[c] (nrows + 1) and bytes[c], gathered on the device. Row order is the root relation's (probe order for joins the
+ * library ran in probe order; apply the query's ORDER BY above). */
+typedef struct {
+    int64_t nrows;
+    int32_t ncols;
+    int32_t *type, *scale;
+    int64_t **values;    /* [ncols]: NULL for VARCHAR columns */
+    int32_t **offsets;   /* [ncols]: NULL for fixed-width columns */
+    char **bytes;
+} ph_rows_result;
+int ph_plan_fetch_rows(ph_plan *p, ph_rows_result **out);
+void ph_rows_result_free(ph_rows_result *r);
 /* group key k of the result: device type and scale, and — when it is a table column carried through unchanged
  * (dictionary codes need their dictionary) — the table and column it comes from (else *table = NULL) */
 int ph_plan_key_info(const ph_plan *p, int32_t k, int32_t *type, int32_t *scale, const ph_table **table, int32_t *col);

@@ -1672,7 +1672,9 @@ static ph_plan_expr lowerExpr(const ProjExpr &e, std::vector<std::vector<ph_bool
 
 std::string gpuResidentPlanExecutor::Init() {
     if (!rp_.error.empty()) return rp_.error;
-    if (rp_.nodes.empty() || rp_.nodes.back().kind != PH_PN_AGG) return "a resident plan ends in its aggregate";
+    if (rp_.nodes.empty()) return "empty resident plan";
+    rowsRoot_ = rp_.nodes.back().kind != PH_PN_AGG;   // a join / filter / project root: the plan returns its rows
+    if (rowsRoot_ && (!having_.empty() || !outputs_.empty() || topkAgg_ >= 0)) return "HAVING / output expressions / top-k belong to an aggregate root";
     // the descriptor arrays live until ph_plan_create has copied them
     size_t nn = rp_.nodes.size();
     std::vector<ph_plan_node> desc(nn);
@@ -1765,6 +1767,43 @@ std::string gpuResidentPlanExecutor::Close() {
 }
 
 OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
+    if (!built_ && rowsRoot_) {
+        ph_rows_result *r = nullptr;
+        if (ph_plan_run(plan_) != PH_OK || ph_plan_fetch_rows(plan_, &r) != PH_OK) { *err = herr("ph_plan_run/fetch_rows"); return InvalidOpResult; }
+        const ResidentPlan::Node &root = rp_.nodes.back();
+        if (r->ncols != (int32_t)outTypes_.size()) { ph_rows_result_free(r); *err = "row plan: column count differs from the plan's typing"; return InvalidOpResult; }
+        for (int64_t base = 0; base < r->nrows; base += DefaultVectorSize) {
+            const int card = (int)std::min<int64_t>(DefaultVectorSize, r->nrows - base);
+            auto c = std::make_shared<Chunk>();
+            c->Init(outTypes_, DefaultVectorSize);
+            for (int col = 0; col < r->ncols; col++) {
+                Vector &v = *c->Data[(size_t)col];
+                for (int i = 0; i < card; i++) {
+                    const int64_t row = base + i;
+                    if (r->type[col] == PH_STR) { v.SetString(i, r->bytes[col] + r->offsets[col][row], r->offsets[col][row + 1] - r->offsets[col][row]); continue; }
+                    const int64_t x = r->values[col][row];
+                    switch (v._Typ.GetInternalType()) {
+                    case PT_INT32: v.Slice<int32_t>()[i] = (int32_t)x; break;
+                    case PT_INT64: v.Slice<int64_t>()[i] = x; break;
+                    case PT_DATE: v.Slice<Date>()[i] = DateFromDays((int32_t)x); break;
+                    case PT_DECIMAL: v.Slice<Decimal>()[i] = DecimalFromUnscaled(x, r->scale[col]); break;
+                    case PT_INT128: v.Slice<Hugeint>()[i] = Hugeint{(uint64_t)x, x < 0 ? -1 : 0}; break;
+                    case PT_VARCHAR: {   // a dictionary-code column of a table: the code's string
+                        const ResidentColumn *src = root.source[(size_t)col];
+                        if (!src || x < 0 || (size_t)x >= src->dict.size()) { ph_rows_result_free(r); *err = "row plan: dictionary code without its dictionary"; return InvalidOpResult; }
+                        v.SetString(i, src->dict[(size_t)x].data(), (int64_t)src->dict[(size_t)x].size());
+                        break;
+                    }
+                    default: ph_rows_result_free(r); *err = "row plan: unsupported column type"; return InvalidOpResult;
+                    }
+                }
+            }
+            c->SetCard(card);
+            results_.push_back(c);
+        }
+        ph_rows_result_free(r);
+        built_ = true;
+    }
     if (!built_) {
         ph_agg_result *r = nullptr;
         if (ph_plan_run(plan_) != PH_OK || ph_plan_fetch(plan_, &r) != PH_OK) {

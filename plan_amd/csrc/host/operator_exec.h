@@ -487,6 +487,7 @@ private:
     ResidentPlan rp_;
     std::vector<Compare> having_;
     bool havingOnDevice_ = false;       // the plan applies the conjuncts where the groups are (ph_plan_set_having)
+    bool rowsRoot_ = false;             // the plan's root is a join / filter / project: its ROWS are the output (ph_plan_fetch_rows)
     std::vector<ProjExpr> outputs_;
     std::vector<LType> outTypes_, finalTypes_, argType_;
     int topkAgg_ = -1;

@@ -154,9 +154,21 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
     }
     {   // supplier
         std::vector<int32_t> key((size_t)ns), nat((size_t)ns);
+        std::vector<char> addr((size_t)ns * TPCHGEN_S_ADDRESS_STRIDE), phone((size_t)ns * TPCHGEN_S_PHONE_LEN);
+        std::vector<uint8_t> alen((size_t)ns);
         tpchgen_supplier_cols sc{};
-        sc.s_suppkey = key.data(); sc.s_nationkey = nat.data();
+        sc.s_suppkey = key.data(); sc.s_nationkey = nat.data(); sc.s_address = addr.data(); sc.s_address_len = alen.data(); sc.s_phone = phone.data();
         tpchgen_supplier(num, den, 0, ns, &sc);
+        std::vector<int32_t> aoff((size_t)ns + 1, 0), poff((size_t)ns + 1);
+        std::string abytes;
+        for (int64_t r = 0; r < ns; r++) {
+            abytes.append(addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, alen[(size_t)r]);
+            aoff[(size_t)r + 1] = (int32_t)abytes.size();
+            poff[(size_t)r] = (int32_t)(r * TPCHGEN_S_PHONE_LEN);
+        }
+        poff[(size_t)ns] = (int32_t)(ns * TPCHGEN_S_PHONE_LEN);
+        HostCol saddr{VarcharType(), PH_STR, 0, aoff.data(), {}, abytes.data(), (int64_t)abytes.size()};
+        HostCol sphone{VarcharType(), PH_STR, 0, poff.data(), {}, phone.data(), (int64_t)phone.size()};
         std::vector<int32_t> noff((size_t)ns + 1);
         std::string nbytes((size_t)ns * 18, '0');
         for (int64_t r = 0; r < ns; r++) {   // s_name = 'Supplier#' + the key as nine digits (TPC-H 4.2.3)
@@ -168,7 +180,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         }
         noff[(size_t)ns] = (int32_t)(ns * 18);
         HostCol sname{VarcharType(), PH_STR, 0, noff.data(), {}, nbytes.data(), (int64_t)nbytes.size()};
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), sname}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), sname, saddr, sphone}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // nation, region: the specification's fixed tables
@@ -430,11 +442,17 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         break;
     }
     case 15: {
-        // the CTE q15_revenue0 = Agg(l_suppkey; sum(l_extendedprice * (1 - l_discount))) <- Scan(lineitem, l_shipdate in [1995-12-01, + 3 months)) is the
-        // resident plan; it is referenced twice, and what stands above it — max() over its rows, the DECIMAL equality as a join condition,
-        // the join with supplier, ORDER BY — runs over its group rows through the chunk executors (RunTpchQuery)
+        // Order(s_suppkey) <- Join(s_suppkey = supplier_no) probe Scan(supplier), build Join(total_revenue = max) probe CTE,
+        //   build Agg(; max(total_revenue)) <- CTE;  CTE q15_revenue0 = Agg(l_suppkey; sum(l_extendedprice * (1 - l_discount))) <- Scan(lineitem,
+        //   l_shipdate in [1995-12-01, + 3 months)). ONE resident plan whose ROOT is the final join (its rows come back: ph_plan_fetch_rows); the CTE
+        //   node has two parents (lowered once per run); `=` on DECIMAL is the hash join the reference runs it as (executeSelect has no DECIMAL
+        //   case for FuncEqual).
         int line = p.Scan(&db.lineitem, {L_SUPPKEY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_SHIPDATE, PH_GE, LDate(1995, 12, 1)}, {L_SHIPDATE, PH_LT, LDate(1996, 3, 1)}});
-        p.Agg(line, {ProjExpr::Col(0)}, {{PH_A_SUM, DiscPrice(1, 2)}});
+        int cte = p.Agg(line, {ProjExpr::Col(0)}, {{PH_A_SUM, DiscPrice(1, 2)}});
+        int top = p.Agg(cte, {}, {{PH_A_MAX, {XC(1)}}});
+        int j1 = p.Join(cte, top, {1}, {0}, {0, 1});
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NAME, S_ADDRESS, S_PHONE});
+        p.Join(supp, j1, {0}, {0}, {0, 1, 2, 3, 5});
         q->order = {{0, false}};
         q->ncols = 5;
         break;
@@ -677,34 +695,12 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     std::unique_ptr<limitExecutor> lim;
     std::unique_ptr<doubleFilterExecutor> upperFilter;
     std::unique_ptr<gpuAggExecutor> upperAgg;
-    std::unique_ptr<gpuResidentPlanExecutor> cte2;
     std::unique_ptr<sourceExecutor> suppSrc;
     std::unique_ptr<gpuJoinExecutor> j1, j2;
     std::unique_ptr<gpuProjectExecutor> proj;
     std::unique_ptr<sourceExecutor> natSrc;
     std::unique_ptr<gpuFilterExecutor> natFilter;
     OperatorExec *root = &agg;
-    if (q.id == 15) {
-        // Order(s_suppkey) <- Join(s_suppkey = supplier_no) probe Scan(supplier), build <- Join(total_revenue = max) probe CTE,
-        //   build Agg(; max(total_revenue)) <- CTE (second reference): the hash join on a DECIMAL key is how `=` on DECIMAL runs
-        cte2.reset(new gpuResidentPlanExecutor(ctx, q.plan));
-        e = cte2->Init();
-        if (!e.empty()) return "Init (CTE, second reference): " + e;
-        upperAgg.reset(new gpuAggExecutor(ctx, {}, {{PH_A_MAX, {XC(1)}}}, cte2.get()));
-        e = upperAgg->Init();
-        if (!e.empty()) return "Init (max): " + e;
-        j1.reset(new gpuJoinExecutor(ctx, root, upperAgg.get(), {1}, {0}, {}));
-        e = j1->Init();
-        if (!e.empty()) return "Init (join on the maximum): " + e;
-        suppSrc = SupplierSource(q.sfNum, q.sfDen);
-        j2.reset(new gpuJoinExecutor(ctx, suppSrc.get(), j1.get(), {0}, {0}, {1}));
-        e = j2->Init();
-        if (!e.empty()) return "Init (join with supplier): " + e;
-        proj.reset(new gpuProjectExecutor(ctx, {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(2), ProjExpr::Col(3), ProjExpr::Col(5)}, j2.get()));
-        e = proj->Init();
-        if (!e.empty()) return "Init (project): " + e;
-        root = proj.get();
-    }
     if (q.id == 20) {
         // Order(s_name) <- Project(s_name, s_address) <- SEMI Join(s_suppkey = ps_suppkey) probe Join(s_nationkey = n_nationkey)[Scan(supplier),
         //   Filter(n_name = 'VIETNAM') <- Scan(nation)], build Filter(ps_availqty > 0.5 * sum [FLOAT]) <- the resident plan's group rows
@@ -773,7 +769,6 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (natFilter) natFilter->Close();
     if (upperAgg) upperAgg->Close();
     if (upperFilter) upperFilter->Close();
-    if (cte2) cte2->Close();
     agg.Close();
     return "";
 }

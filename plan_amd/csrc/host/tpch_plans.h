@@ -21,7 +21,7 @@ enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TO
 enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME, C_PHONE, C_ACCTBAL };
 enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
 enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST, PS_AVAILQTY };
-enum { S_SUPPKEY, S_NATIONKEY, S_NAME };
+enum { S_SUPPKEY, S_NATIONKEY, S_NAME, S_ADDRESS, S_PHONE };
 enum { N_NATIONKEY, N_NAME, N_REGIONKEY };
 enum { R_REGIONKEY, R_NAME };
 

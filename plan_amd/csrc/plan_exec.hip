@@ -112,6 +112,8 @@ struct ph_plan {
     std::vector<ph_join *> joins;
     std::vector<ph_strdict *> strdicts;
     std::vector<ph_agg *> inner_aggs;   // aggregates below other operators
+    bool rows_root = false;             // the root is no aggregate: the plan returns the root relation's rows (ph_plan_fetch_rows)
+    std::shared_ptr<Rel> rows_rel;      // ... of the last run (its buffers are run temporaries: fetched before they are released)
     std::vector<ph_pred> having;        // conjuncts over the root's aggregate columns, applied where the groups are (ph_plan_set_having)
     std::vector<int> parents;           // how many nodes reference node i as a child
     std::map<std::pair<int, bool>, std::shared_ptr<Rel>> memo;   // relations of nodes with several parents, per run
@@ -160,6 +162,7 @@ void release_run(ph_plan *p, bool keep_agg) {
     p->inner_aggs.clear();
     p->domains.clear();
     p->memo.clear();
+    p->rows_rel.reset();
     for (void *q : p->temps) p->ctx->pool_release(q);
     p->temps.clear();
     if (!keep_agg) {
@@ -1564,9 +1567,81 @@ int run_once(ph_plan *p) {
     p->explain.clear();
     note(p, "plan run (%s forms)", p->conservative ? "conservative" : "optimistic");
     PL_CHECK(ph_ctx_set_deferred_errors(p->ctx, 1));
-    int rc = lower_agg(p);
+    int rc = PH_OK;
+    if (p->rows_root) {
+        Rel R;
+        rc = lower(p, (int)p->nodes.size() - 1, false, &R);
+        if (rc == PH_OK) rc = apply_pending(p, &R);
+        if (rc == PH_OK) p->rows_rel = std::make_shared<Rel>(R);
+    } else rc = lower_agg(p);
     if (rc != PH_OK) { release_run(p, false); (void)ph_ctx_set_deferred_errors(p->ctx, 0); return rc; }
     p->ran = true;
+    return PH_OK;
+}
+
+// the root relation's rows to the host: fixed-width columns positional and widened to 64 bits, VARCHAR columns (table columns behind
+// row ids, or values computed in the plan behind their codes) gathered on the device into offsets + bytes
+int fetch_rows_once(ph_plan *p, ph_rows_result **out) {
+    Rel &R = *p->rows_rel;
+    ph_ctx *ctx = p->ctx;
+    const int64_t n = R.n;
+    const int nc = (int)R.cols.size();
+    std::vector<int> fixed;
+    for (int c = 0; c < nc; c++) if (R.cols[(size_t)c].type != PH_STR) fixed.push_back(c);
+    PL_CHECK(positional(p, &R, fixed));
+    ph_rows_result *r = (ph_rows_result *)calloc(1, sizeof *r);
+    r->nrows = n; r->ncols = nc;
+    r->type = (int32_t *)calloc((size_t)std::max(nc, 1), 4);
+    r->scale = (int32_t *)calloc((size_t)std::max(nc, 1), 4);
+    r->values = (int64_t **)calloc((size_t)std::max(nc, 1), sizeof(int64_t *));
+    r->offsets = (int32_t **)calloc((size_t)std::max(nc, 1), sizeof(int32_t *));
+    r->bytes = (char **)calloc((size_t)std::max(nc, 1), sizeof(char *));
+    auto fail = [&](int rc) { ph_rows_result_free(r); return rc; };
+    for (int c = 0; c < nc; c++) {
+        const PCol &pc = R.cols[(size_t)c];
+        r->type[c] = pc.sdict ? (int32_t)PH_STR : pc.type;
+        r->scale[c] = pc.scale;
+        if (pc.type == PH_STR || pc.sdict) {
+            // strings: ph_substring(1, whole) over the column with the row ids (or the codes of a computed value) as its selection
+            ph_col v{};
+            const int32_t *sel = nullptr;
+            if (pc.sdict) { v = table_view(pc.src, pc.src_col); sel = (const int32_t *)pc.data; }
+            else {
+                if (pc.lane < 0) { set_error("ph_plan_fetch_rows: VARCHAR column %d is not a table column", c); return fail(PH_EUNSUPPORTED); }
+                v = table_view(R.lanes[(size_t)pc.lane].t, pc.tcol);
+                sel = R.lanes[(size_t)pc.lane].rows;
+            }
+            r->offsets[c] = (int32_t *)calloc((size_t)n + 1, 4);
+            if (n == 0) { r->bytes[c] = (char *)calloc(1, 1); continue; }
+            int64_t cap = v.aux_bytes + 64, nbytes = 0;
+            void *off = nullptr, *bytes = nullptr;
+            int rc = PH_OK;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if ((rc = palloc(p, (n + 1) * 4, &off)) != PH_OK || (rc = palloc(p, cap + 64, &bytes)) != PH_OK) return fail(rc);
+                rc = ph_substring(ctx, &v, 1, INT64_MAX, sel, n, (int32_t *)off, (uint8_t *)bytes, cap, &nbytes);
+                if (rc == PH_ECAPACITY && attempt == 0 && nbytes > cap) { cap = nbytes; continue; }   // (repeated rows below a join)
+                break;
+            }
+            if (rc != PH_OK) return fail(rc);
+            r->bytes[c] = (char *)calloc((size_t)std::max<int64_t>(nbytes, 1), 1);
+            if ((rc = ctx->download(r->offsets[c], off, (n + 1) * 4)) != PH_OK) return fail(rc);
+            if (nbytes > 0 && (rc = ctx->download(r->bytes[c], bytes, nbytes)) != PH_OK) return fail(rc);
+            continue;
+        }
+        if (pc.validity) { set_error("ph_plan_fetch_rows: NULL-able column %d", c); return fail(PH_EUNSUPPORTED); }
+        r->values[c] = (int64_t *)calloc((size_t)std::max<int64_t>(n, 1), 8);
+        if (n == 0) continue;
+        const int w = width_of(pc.type);
+        std::vector<unsigned char> raw((size_t)n * (size_t)w);
+        int rc = ctx->download(raw.data(), pc.data, n * w);
+        if (rc != PH_OK) return fail(rc);
+        for (int64_t i = 0; i < n; i++) {
+            if (w == 8) r->values[c][i] = reinterpret_cast<const int64_t *>(raw.data())[i];
+            else if (w == 4) r->values[c][i] = reinterpret_cast<const int32_t *>(raw.data())[i];
+            else r->values[c][i] = raw[(size_t)i];
+        }
+    }
+    *out = r;
     return PH_OK;
 }
 
@@ -1637,9 +1712,12 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
 
 extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_plan **out) {
     PH_REQUIRE(ctx && nodes && out && nnodes >= 2 && nnodes <= 64, "ph_plan_create: bad arguments (2..64 nodes)");
-    PH_REQUIRE(nodes[nnodes - 1].kind == PH_PN_AGG, "ph_plan_create: the last node is the root and must be a PH_PN_AGG");
+    const int32_t rk = nodes[nnodes - 1].kind;
+    PH_REQUIRE(rk == PH_PN_AGG || rk == PH_PN_JOIN || rk == PH_PN_FILTER || rk == PH_PN_PROJECT,
+               "ph_plan_create: the last node is the root: a PH_PN_AGG (ph_plan_fetch), or a join / filter / project whose rows ph_plan_fetch_rows returns");
     ph_plan *p = new ph_plan();
     p->ctx = ctx;
+    p->rows_root = rk != PH_PN_AGG;
     auto fail = [&](int rc) { delete p; return rc; };
     for (int32_t i = 0; i < nnodes; i++) {
         const ph_plan_node &s = nodes[i];
@@ -1722,7 +1800,7 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
 }
 
 extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k) {
-    PH_REQUIRE(p && k > 0 && agg_index >= 0 && agg_index < (int32_t)p->nodes.back().aggs.size(), "ph_plan_set_topk: bad arguments");
+    PH_REQUIRE(p && !p->rows_root && k > 0 && agg_index >= 0 && agg_index < (int32_t)p->nodes.back().aggs.size(), "ph_plan_set_topk: bad arguments");
     p->topk_agg = agg_index;
     p->topk_desc = descending ? 1 : 0;
     p->topk_k = k;
@@ -1730,7 +1808,7 @@ extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descendin
 }
 
 extern "C" int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj) {
-    PH_REQUIRE(p && nconj >= 0 && (nconj == 0 || conj), "ph_plan_set_having: bad arguments");
+    PH_REQUIRE(p && !p->rows_root && nconj >= 0 && (nconj == 0 || conj), "ph_plan_set_having: bad arguments");
     const Node &root = p->nodes.back();
     const int nkeys = (int)root.groups.size(), naggs = (int)root.aggs.size();
     if (p->topk_agg >= 0) { set_error("ph_plan_set_having: the plan has a top-k preselection"); return PH_EUNSUPPORTED; }
@@ -1760,8 +1838,39 @@ extern "C" int ph_plan_run(ph_plan *p) {
     return rc;
 }
 
+extern "C" void ph_rows_result_free(ph_rows_result *r) {
+    if (!r) return;
+    for (int c = 0; c < r->ncols; c++) {
+        if (r->values) free(r->values[c]);
+        if (r->offsets) free(r->offsets[c]);
+        if (r->bytes) free(r->bytes[c]);
+    }
+    free(r->type); free(r->scale); free(r->values); free(r->offsets); free(r->bytes);
+    free(r);
+}
+
+extern "C" int ph_plan_fetch_rows(ph_plan *p, ph_rows_result **out) {
+    PH_REQUIRE(p && out, "ph_plan_fetch_rows: bad arguments");
+    PH_REQUIRE(p->rows_root, "ph_plan_fetch_rows: the plan's root is an aggregate (ph_plan_fetch)");
+    PH_REQUIRE(p->ran && p->rows_rel, "ph_plan_fetch_rows: ph_plan_run first");
+    int rc = fetch_rows_once(p, out);
+    if (rc == PH_ECONSTRAINT && !p->conservative) {
+        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): the plan runs again in its conservative forms\n";
+        const std::string first = p->explain;
+        p->conservative = true;
+        rc = run_once(p);
+        p->explain = first + p->explain;
+        if (rc == PH_OK) rc = fetch_rows_once(p, out);
+    }
+    release_run(p, true);
+    (void)ph_ctx_set_deferred_errors(p->ctx, 0);
+    p->ran = false;
+    return rc;
+}
+
 extern "C" int ph_plan_fetch(ph_plan *p, ph_agg_result **out) {
     PH_REQUIRE(p && out, "ph_plan_fetch: bad arguments");
+    PH_REQUIRE(!p->rows_root, "ph_plan_fetch: the plan's root is no aggregate (ph_plan_fetch_rows)");
     PH_REQUIRE(p->ran, "ph_plan_fetch: ph_plan_run first");
     // the intermediates go back to the pool BEFORE the host blocks in the download (bookkeeping while the GPU is busy)
     release_run(p, true);

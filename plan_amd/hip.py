@@ -63,6 +63,12 @@ class AggResult(ctypes.Structure):
                 ("nkeys", i32), ("naggs", i32)]
 
 
+class RowsResult(ctypes.Structure):
+    _fields_ = [("nrows", i64), ("ncols", i32), ("type", ctypes.POINTER(i32)), ("scale", ctypes.POINTER(i32)),
+                ("values", ctypes.POINTER(ctypes.POINTER(i64))), ("offsets", ctypes.POINTER(ctypes.POINTER(i32))),
+                ("bytes", ctypes.POINTER(ctypes.c_void_p))]
+
+
 def _preload_torch_hip_runtime():
     """One HIP runtime per process. PyTorch-ROCm bundles its own libamdhip64.so / libhiprtc.so /
     librccl.so (SONAMEs libamdhip64.so.7, libhiprtc.so.7, librccl.so.1 — the ones libplanhip.so
@@ -992,6 +998,24 @@ class Plan:
         rp = ctypes.POINTER(AggResult)()
         check(lib().ph_plan_fetch(self.h, ctypes.byref(rp)))
         return _result(rp)
+
+    def fetch_rows(self):
+        """rows of a plan whose root is a join / filter / project (ph_plan_fetch_rows): {"nrows", "types", "scales", "columns"} — a fixed-width
+        column is an int64 numpy array, a VARCHAR column a list of str"""
+        rp = ctypes.POINTER(RowsResult)()
+        check(lib().ph_plan_fetch_rows(self.h, ctypes.byref(rp)))
+        r = rp.contents
+        n, cols = r.nrows, []
+        for c in range(r.ncols):
+            if r.values[c]:
+                cols.append(np.ctypeslib.as_array(r.values[c], shape=(max(n, 1),))[:n].copy())
+            else:
+                off = np.ctypeslib.as_array(r.offsets[c], shape=(n + 1,))
+                raw = ctypes.string_at(r.bytes[c], int(off[n])) if n else b""
+                cols.append([raw[off[i]:off[i + 1]].decode() for i in range(n)])
+        out = dict(nrows=n, types=[r.type[c] for c in range(r.ncols)], scales=[r.scale[c] for c in range(r.ncols)], columns=cols)
+        lib().ph_rows_result_free(rp)
+        return out
 
     def explain(self):
         lib().ph_plan_explain.restype = ctypes.c_char_p

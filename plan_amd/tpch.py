@@ -381,6 +381,30 @@ def q15_plan(db, d1=None, d2=None):
     return p.create()
 
 
+def q15_rows_plan(db, d1=None, d2=None):
+    """Q15 whole, as the reference's tree, in ONE plan whose root is the final join (ph_plan_fetch_rows): Join(s_suppkey = supplier_no) probe
+       Scan(supplier), build Join(total_revenue = max) probe CTE, build Agg(; max(total_revenue)) <- CTE. The CTE node has two parents (lowered
+       once per run); `=` on DECIMAL runs as the hash join the reference runs it as. Rows: s_suppkey, s_name, s_address, s_phone, total_revenue"""
+    d1 = tpchgen.days(1995, 12, 1) if d1 is None else d1
+    d2 = tpchgen.days(1996, 3, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_suppkey", "l_extendedprice", "l_discount"),
+                  [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    cte = p.agg(line, [hip.pe_col(0)], [(hip.PH_A_SUM, hip.pe_dec([hip.X_COL(1), hip.X_CONST(1), hip.X_COL(2), hip.X_SUB, hip.X_MUL]))])
+    top = p.agg(cte, [], [(hip.PH_A_MAX, hip.pe_col(1))])
+    j1 = p.join(cte, top, [1], [0], [0, 1])
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_name", "s_address", "s_phone"))
+    p.join(supp, j1, [0], [0], [0, 1, 2, 3, 5])
+    return p.create()
+
+
+def q15_rows_text(r):
+    """ORDER BY s_suppkey + the reference's text over ph_plan_fetch_rows' columns"""
+    key, name, addr, phone, rev = r["columns"]
+    order = np.argsort(key, kind="stable")
+    return "#\t\t\t\t\n" + "".join(f"{int(key[i])}\t{name[i]}\t{addr[i]}\t{phone[i]}\t{dec_text(int(rev[i]), r['scales'][4])}\n" for i in order)
+
+
 def q15_rows(r):
     """[(s_suppkey, total_revenue unscaled)] of the groups whose exact DECIMAL sum equals the maximum, ORDER BY s_suppkey"""
     if r["ngroups"] == 0:

@@ -394,6 +394,19 @@ def test_plan_substring_as_filter_operand_and_group_key_matches_oracle(ctx, db, 
     assert got == want, ex
 
 
+def test_q15_as_one_plan_with_a_join_root_matches_golden(ctx, db, sf1):
+    """a plan whose ROOT is a join (ph_plan_fetch_rows): the CTE with two parents, max() over it as an ungrouped aggregate below a join on a
+    DECIMAL key, the supplier's three VARCHAR columns gathered on the device: cases/tpch/1g/plan/q15.txt"""
+    p = tpch.q15_rows_plan(db)
+    p.run()
+    r = p.fetch_rows()
+    ex = p.explain()
+    p.free()
+    assert r["nrows"] == 1 and r["types"][1] == hip.PH_STR, ex
+    assert tpch.q15_rows_text(r) == golden("plan_q15.txt"), ex
+    assert "lowered before in this run, reused" in ex
+
+
 def test_q17_decorrelated_average_joined_back_matches_golden(ctx, db, sf1):
     """Q17: an aggregate by the correlation key below a join whose payload is its SUM and COUNT; the DOUBLE predicate and the float32
     division over the fetched groups: the oracle's exact sum and cases/tpch/1g/plan/q17.txt"""

@@ -228,8 +228,8 @@ def test_scan_queries_as_resident_plans(qid, golden):
 def test_more_reference_goldens_through_the_operator_interface(qid):
     """Q4 (SEMI join), Q5 (six-table chain), Q12 (IN list, integer CASE, column-vs-column filters), Q14
     (CASE with LIKE, FLOAT select list), Q7 (nation joined twice, OR of conjunctions as a Filter above the joins), Q8 (eight tables, DECIMAL
-    division in the select list), Q11 (HAVING against an uncorrelated scalar subquery with a FLOAT factor: float32 comparison, 1225 rows), Q15 (a CTE referenced twice as two resident-plan executors, max() over its rows and both joins — one on a DECIMAL key, one with a Scan(supplier)
-    chunk source carrying three VARCHAR columns — through the chunk executors gpuAggExecutor / gpuJoinExecutor), Q17 (an aggregate by the correlation key joined back, a Filter with a DOUBLE predicate and an ungrouped aggregate above the plan), Q18
+    division in the select list), Q11 (HAVING against an uncorrelated scalar subquery with a FLOAT factor: float32 comparison, 1225 rows), Q15 (ONE resident plan whose root is the final join — its rows come back through ph_plan_fetch_rows: the CTE with two parents, max() over it as an
+    ungrouped aggregate below a join on a DECIMAL key, three VARCHAR columns of supplier gathered on the device), Q17 (an aggregate by the correlation key joined back, a Filter with a DOUBLE predicate and an ungrouped aggregate above the plan), Q18
     (aggregate below a SEMI join, VARCHAR group key), Q19 (OR of conjunctions over both join sides), Q20 (a join on two keys whose build side is an aggregate by those keys, a FLOAT predicate over the plan's rows, then supplier x nation and a SEMI join
     through the chunk executors, ORDER BY a VARCHAR), Q21 (EXISTS / NOT EXISTS with a non-equi condition: pair join + column-vs-column Filter + an aggregate by lineitem's primary key below two-key SEMI /
     ANTI joins, ORDER BY a HUGEINT DESC and a VARCHAR, LIMIT), Q22 (substring() computed in the plan as an IN operand and as the VARCHAR group key, an ANTI join, a scalar
