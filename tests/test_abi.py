@@ -126,11 +126,16 @@ def test_planhost_libraries_load_and_export_their_entry_points():
 
 
 def test_plan_descriptor_validation_without_a_device():
-    """ph_plan_create checks the descriptor on the host: the root must be the aggregate, children precede parents"""
+    """ph_plan_create checks the descriptor on the host: the root is an aggregate, or a join / filter / project whose rows come back —
+    never a scan; children precede parents"""
     lib = hip.lib()
     n = (hip.PlanNode * 2)()
-    n[0].kind, n[1].kind = hip.PH_PN_SCAN, hip.PH_PN_JOIN
+    n[0].kind, n[1].kind = hip.PH_PN_SCAN, hip.PH_PN_SCAN
     out = hip.vp()
     assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
     assert b"root" in lib.ph_last_error()
+    n[1].kind = hip.PH_PN_JOIN          # an acceptable root, but its children (0, 0 by default) do not both precede it as distinct inputs
+    n[1].child[0], n[1].child[1] = 1, 0
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
+    assert b"precede" in lib.ph_last_error()
     assert lib.ph_plan_create(None, n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
