@@ -265,7 +265,8 @@ uint64_t ph_hash_bytes(const void *p, uint64_t len);
  * function_operator_binary.go:134-207). Values are exact unscaled int64 at a scale fixed by the
  * binder's typing rules (Mul: sum of scales, Add/Sub: max; function_scalar.go:37-84, 429-475).
  * Program = RPN over columns and literals. */
-typedef enum { PH_X_COL = 1, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL } ph_xop;
+typedef enum { PH_X_COL = 1, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL,
+               PH_X_DIV, PH_X_LT, PH_X_LE, PH_X_GT, PH_X_GE /* ph_float_eval only */ } ph_xop;
 
 typedef struct {
     int32_t op;
@@ -274,6 +275,13 @@ typedef struct {
     int32_t scale; /* PH_X_CONST: its scale */
 } ph_rpn;
 
+/* FLOAT / DOUBLE arithmetic and comparisons (the FLOAT and DOUBLE overloads of + - * / and of the comparison operators: function_scalar.go:476-512,
+ * 960-1025, 1335-1470): the program per row in float32 — every operation rounded to it — or, wide != 0, in float64. PH_X_COL casts the column as the
+ * binder does (INTEGER -> float, DECIMAL -> float64 -> float32; a HUGEINT travels as a scale-0 decimal), PH_X_CONST is a FLOAT literal (its float32
+ * bits in ival; widened for DOUBLE arithmetic). Comparisons give 1 / 0 and follow selectOperation: FLOAT has > >= <=, DOUBLE has < — the others are
+ * never true. out_type PH_I32: the truth value of a program that ends in a comparison (a NULL operand: 0); PH_F32: the value (float32 only). */
+int ph_float_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *prog, int32_t nprog, int32_t wide, const int32_t *sel, int64_t n,
+                  int32_t out_type, void *out_dev, uint8_t *out_validity_dev);
 /* result scale of a program (host side, no device work); PH_EUNSUPPORTED if malformed */
 int ph_expr_scale(const ph_col *cols, const ph_rpn *prog, int32_t nprog, int32_t *scale);
 /* out_dev[i] = value of row sel[i] (or i), unscaled at ph_expr_scale's scale. Every add/sub/mul
@@ -683,12 +691,16 @@ typedef enum {
                          (FillSwitch, :559-606). Both branches are DECIMAL programs of ONE result scale (an integer
                          constant in a branch — `ELSE 0` — is cast to it), or — result_int != 0 — both INTEGER
                          constants. */
-    PH_PE_SUBSTR      /* substring(<VARCHAR table column col> FROM sub_offset FOR sub_length) (substringFunc,
+    PH_PE_SUBSTR,     /* substring(<VARCHAR table column col> FROM sub_offset FOR sub_length) (substringFunc,
                          function_operator_binary.go:553-625; ph_substring). The value is VARCHAR computed inside the plan:
                          it may be compared with VARCHAR constants by = / <> in a PH_PN_FILTER above (an IN list is their OR),
                          be a group key or pass through joins; as a group key it is reported as PH_STR by ph_plan_key_info,
                          whose table is then a one-column relation the PLAN owns (valid until the plan runs again or is
                          freed): the key values are its rows, ph_table_strings reads them. */
+    PH_PE_FLOAT       /* FLOAT (float_wide = 0) or DOUBLE (float_wide != 0) arithmetic over the child's columns, as ph_float_eval: `prog` with
+                         PH_X_DIV and the comparison steps allowed. result_int != 0: the program ends in a comparison and the value is its truth
+                         (an INTEGER 1 / 0 column: a PH_PN_FILTER above keeps `column = 1` — Q17's `l_quantity < 0.2 * avg`, Q20's
+                         `ps_availqty > 0.5 * sum`); else FLOAT values (float32 only). */
 } ph_plan_expr_kind;
 
 /* A boolean expression over a node's input columns as a flat tree (node 0 = the root): what ExprExec.executeSelect
@@ -717,6 +729,8 @@ typedef struct {
     int32_t result_int;    /* != 0: THEN / ELSE are single PH_X_CONST programs of scale 0 and the result is INTEGER */
     /* PH_PE_SUBSTR */
     int64_t sub_offset, sub_length;   /* as ph_substring's; sub_length = INT64_MAX is the two-argument form */
+    /* PH_PE_FLOAT */
+    int32_t float_wide;               /* != 0: DOUBLE arithmetic */
 } ph_plan_expr;
 
 typedef struct {

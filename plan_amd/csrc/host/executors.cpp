@@ -317,118 +317,6 @@ OperatorResult gpuFilterExecutor::Execute(Chunk *, Chunk *output, std::string *e
     return haveMoreOutput;
 }
 
-// ------------------------------------------------------------------ filter with a DOUBLE predicate (host)
-
-std::string doubleFilterExecutor::Init() {
-    const size_t nc = child_->OutputTypes().size();
-    if (pred_.float32 ? (pred_.op != PH_GT && pred_.op != PH_GE && pred_.op != PH_LE) : pred_.op != PH_LT) return "no such comparison for this type in selectOperation";
-    for (auto *prog : {&pred_.lhs, &pred_.rhs}) {
-        if (prog->empty()) return "empty DOUBLE expression";
-        for (auto &o : *prog)
-            if (o.op == FloatOp::Col && (o.col < 0 || (size_t)o.col >= nc)) return "DOUBLE expression column out of range";
-    }
-    return "";
-}
-
-// one side of the predicate for row r; false = NULL
-static bool eval_double(const std::vector<FloatOp> &prog, const Chunk &c, int card, int r, double *out, std::string *err) {
-    std::vector<double> st;
-    for (auto &o : prog) {
-        if (o.op == FloatOp::Const) { st.push_back((double)o.k); continue; }            // tryCastFloat32ToFloat64
-        if (o.op == FloatOp::Col) {
-            const Vector &src = *c.Data[(size_t)o.col];
-            Vector::Unified u;
-            src.ToUnifiedFormat(card, &u);
-            const int64_t idx = u.sel->GetIndex(r);
-            if (!u.mask->RowIsValid((uint64_t)idx)) return false;
-            switch (src._Typ.GetInternalType()) {
-            case PT_INT32: st.push_back((double)reinterpret_cast<const int32_t *>(u.data)[idx]); break;   // tryCastInt32ToFloat64
-            case PT_DECIMAL: st.push_back(DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx])); break;
-            case PT_INT128: { const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx]; st.push_back((double)h.Upper * 18446744073709551616.0 + (double)h.Lower); break; }
-            case PT_FLOAT: st.push_back((double)reinterpret_cast<const float *>(u.data)[idx]); break;
-            case PT_DOUBLE: st.push_back(reinterpret_cast<const double *>(u.data)[idx]); break;
-            default: *err = "DOUBLE expression over an unsupported column type"; return false;
-            }
-            continue;
-        }
-        if (st.size() < 2) { *err = "malformed DOUBLE expression"; return false; }
-        volatile double b = st.back(); st.pop_back();
-        volatile double a = st.back(); st.pop_back();
-        volatile double res = o.op == FloatOp::Add ? a + b : o.op == FloatOp::Sub ? a - b : o.op == FloatOp::Mul ? a * b : a / b;
-        st.push_back((double)res);
-    }
-    if (st.size() != 1) { *err = "malformed DOUBLE expression"; return false; }
-    *out = st[0];
-    return true;
-}
-
-// the FLOAT form: every value and every operation in float32
-static bool eval_float(const std::vector<FloatOp> &prog, const Chunk &c, int card, int r, float *out, std::string *err) {
-    std::vector<float> st;
-    for (auto &o : prog) {
-        if (o.op == FloatOp::Const) { st.push_back(o.k); continue; }
-        if (o.op == FloatOp::Col) {
-            const Vector &src = *c.Data[(size_t)o.col];
-            Vector::Unified u;
-            src.ToUnifiedFormat(card, &u);
-            const int64_t idx = u.sel->GetIndex(r);
-            if (!u.mask->RowIsValid((uint64_t)idx)) return false;
-            switch (src._Typ.GetInternalType()) {
-            case PT_INT32: st.push_back((float)reinterpret_cast<const int32_t *>(u.data)[idx]); break;
-            case PT_DECIMAL: st.push_back((float)DecimalToDouble(reinterpret_cast<const Decimal *>(u.data)[idx])); break;
-            case PT_INT128: {   // tryCastBigintToFloat32 (function_cast.go:365-374)
-                const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx];
-                st.push_back(h.Upper == -1 ? -(float)(UINT64_MAX - h.Lower) - 1 : (float)h.Lower + (float)h.Upper * (float)UINT64_MAX);
-                break;
-            }
-            case PT_FLOAT: st.push_back(reinterpret_cast<const float *>(u.data)[idx]); break;
-            default: *err = "FLOAT expression over an unsupported column type"; return false;
-            }
-            continue;
-        }
-        if (st.size() < 2) { *err = "malformed FLOAT expression"; return false; }
-        volatile float b = st.back(); st.pop_back();
-        volatile float a = st.back(); st.pop_back();
-        volatile float res = o.op == FloatOp::Add ? a + b : o.op == FloatOp::Sub ? a - b : o.op == FloatOp::Mul ? a * b : a / b;
-        st.push_back((float)res);
-    }
-    if (st.size() != 1) { *err = "malformed FLOAT expression"; return false; }
-    *out = st[0];
-    return true;
-}
-
-OperatorResult doubleFilterExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
-    for (;;) {
-        auto c = std::make_shared<Chunk>();
-        OperatorResult r = child_->Execute(nullptr, c.get(), err);
-        if (r == InvalidOpResult || r == Done) return r;
-        const int card = c->Card();
-        auto sv = std::make_shared<SelectVector>();
-        sv->identity = false;
-        for (int i = 0; i < card; i++) {
-            std::string e;
-            bool pass = false;
-            if (pred_.float32) {
-                float a = 0, b = 0;
-                const bool va = eval_float(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_float(pred_.rhs, *c, card, i, &b, &e);
-                pass = va && vb && (pred_.op == PH_GT ? a > b : pred_.op == PH_GE ? a >= b : a <= b);   // great / greatEqual / lessEqual Float32Op
-            } else {
-                double a = 0, b = 0;
-                const bool va = eval_double(pred_.lhs, *c, card, i, &a, &e), vb = va && eval_double(pred_.rhs, *c, card, i, &b, &e);
-                pass = va && vb && a < b;                                                // lessFloat64Op; a NULL side selects nothing
-            }
-            if (!e.empty()) { *err = e; return InvalidOpResult; }
-            if (pass) sv->SelVec.push_back(i);
-        }
-        if (sv->SelVec.empty()) continue;
-        ensureOutputChunk(OutputTypes(), output);
-        std::vector<int> indice;
-        for (int i = 0; i < c->ColumnCount(); i++) indice.push_back(i);
-        output->SliceIndice(*c, sv, (int)sv->SelVec.size(), 0, indice);   // DICT views that share the child's vectors
-        return haveMoreOutput;
-    }
-}
-
 // ------------------------------------------------------------------ aggregate
 
 gpuAggExecutor::gpuAggExecutor(ph_ctx *ctx, std::vector<int> groupCols, std::vector<AggExpr> aggs, OperatorExec *child,
@@ -1471,8 +1359,9 @@ static std::string exprType(const ProjExpr &e, const std::vector<LType> &childTy
     std::vector<LType> one;
     std::string err = gpuProjectExecutor::Types({e}, childTypes, &one);
     if (!err.empty()) return err;
-    if (e.kind == ProjExpr::Float32 || e.kind == ProjExpr::DecimalQuo) return "FLOAT / DECIMAL-division expressions are not part of a resident plan";
-    *t = one[0];
+    if (e.kind == ProjExpr::DecimalQuo) return "DECIMAL-division expressions are not part of a resident plan";
+    if (e.kind == ProjExpr::Float32 && e.fprog.size() > 12) return "FLOAT expression program too long";
+    *t = e.kind == ProjExpr::Float32 && e.floatTruth ? IntegerType() : one[0];
     *src = e.kind == ProjExpr::ColRef ? childSrc[(size_t)e.col] : nullptr;
     return "";
 }
@@ -1663,6 +1552,28 @@ static ph_plan_expr lowerExpr(const ProjExpr &e, std::vector<std::vector<ph_bool
     case ProjExpr::ColRef: x.kind = PH_PE_COL; x.col = e.col; break;
     case ProjExpr::ExtractYear: x.kind = PH_PE_YEAR; x.col = e.col; break;
     case ProjExpr::Substring: x.kind = PH_PE_SUBSTR; x.col = e.col; x.sub_offset = e.offset; x.sub_length = e.length; break;
+    case ProjExpr::Float32: {
+        x.kind = PH_PE_FLOAT; x.col = -1; x.result_int = e.floatTruth ? 1 : 0; x.float_wide = e.floatWide ? 1 : 0;
+        x.nprog = (int32_t)std::min<size_t>(e.fprog.size(), 12);
+        for (int i = 0; i < x.nprog; i++) {
+            const FloatOp &o = e.fprog[(size_t)i];
+            ph_rpn r{};
+            switch (o.op) {
+            case FloatOp::Col: r.op = PH_X_COL; r.col = o.col; break;
+            case FloatOp::Const: { r.op = PH_X_CONST; uint32_t bits; memcpy(&bits, &o.k, 4); r.ival = bits; break; }
+            case FloatOp::Add: r.op = PH_X_ADD; break;
+            case FloatOp::Sub: r.op = PH_X_SUB; break;
+            case FloatOp::Mul: r.op = PH_X_MUL; break;
+            case FloatOp::Div: r.op = PH_X_DIV; break;
+            case FloatOp::Lt: r.op = PH_X_LT; break;
+            case FloatOp::Le: r.op = PH_X_LE; break;
+            case FloatOp::Gt: r.op = PH_X_GT; break;
+            case FloatOp::Ge: r.op = PH_X_GE; break;
+            }
+            x.prog[i] = r;
+        }
+        break;
+    }
     default:
         x.kind = PH_PE_DECIMAL; x.col = -1; x.nprog = (int32_t)std::min<size_t>(e.prog.size(), 12);
         for (int i = 0; i < x.nprog; i++) x.prog[i] = e.prog[(size_t)i];

@@ -76,7 +76,7 @@ struct BoolExpr {
 // bind to their FLOAT overloads, DECIMAL operands are cast decimal -> float64 -> float32 (function_scalar.go:476-512,
 // 960-1010; function_cast.go:349-354). RPN; evaluated on the host (the rows are group rows).
 struct FloatOp {
-    enum Op { Col, Const, Add, Sub, Mul, Div } op = Const;
+    enum Op { Col, Const, Add, Sub, Mul, Div, Lt, Le, Gt, Ge } op = Const;   // (the comparisons: resident plans only — PH_PE_FLOAT)
     int col = -1;
     float k = 0;
 };
@@ -97,6 +97,11 @@ struct ProjExpr {
     std::vector<ph_rpn> elseProg;
     bool resultInt = false;       // both branches are INTEGER literals: the result is INTEGER
     std::vector<FloatOp> fprog;   // Float32
+    // Float32 inside a resident plan (PH_PE_FLOAT, evaluated on the device): floatWide = DOUBLE arithmetic (a FLOAT literal beside a DOUBLE
+    // operand is widened: Q17's 0.2 * avg(INTEGER)); floatTruth = the program ends in a comparison and the value is its INTEGER truth, which a
+    // Filter above tests with `= 1`
+    bool floatWide = false, floatTruth = false;
+    static ProjExpr FloatTruth(std::vector<FloatOp> p, bool wide) { ProjExpr e; e.kind = Float32; e.fprog = std::move(p); e.floatTruth = true; e.floatWide = wide; return e; }
     static ProjExpr CaseOf(BoolExpr w, std::vector<ph_rpn> thenProg, std::vector<ph_rpn> elseProg, bool resultInt = false) {
         ProjExpr e; e.kind = Case; e.when = std::make_shared<BoolExpr>(std::move(w)); e.prog = std::move(thenProg); e.elseProg = std::move(elseProg); e.resultInt = resultInt; return e;
     }
@@ -204,31 +209,6 @@ private:
     std::unique_ptr<DeviceBatch> batch_;
     std::deque<std::pair<std::shared_ptr<Chunk>, std::shared_ptr<SelectVector>>> ready_;
     bool childDone_ = false;
-};
-
-// Filter whose one conjunct is DOUBLE arithmetic on both sides (Q17's `l_quantity < 0.2 * avg(l_quantity)`: avg(INTEGER) is DOUBLE,
-// `*` has only (T, T) overloads so the FLOAT literal is cast float32 -> float64, `<` has a DOUBLE overload — lessFloat64Op,
-// function_operator_boolean.go:461-470 — and it is the only DOUBLE comparison the reference has). Both sides are RPN programs of
-// FloatOp evaluated in float64: a constant is the float32 literal widened, a column is cast the way the binder casts it (INTEGER,
-// DECIMAL, HUGEINT, FLOAT -> DOUBLE). Evaluated on the host: the rows it sees are a resident plan's result rows.
-struct DoubleLess {
-    std::vector<FloatOp> lhs, rhs;
-    // float32 = true: the FLOAT form instead — both sides in float32, every operation rounded to it, columns cast as the binder casts them
-    // to FLOAT (tryCastInt32ToFloat32, tryCastBigintToFloat32, tryCastDecimalToFloat32); op = PH_GT / PH_GE / PH_LE, the FLOAT comparisons
-    // selectOperation has (function_operator_boolean.go:431-490). Q20: ps_availqty > 0.5 * sum(l_quantity).
-    bool float32 = false;
-    int op = PH_LT;
-};
-class doubleFilterExecutor : public OperatorExec {
-public:
-    doubleFilterExecutor(DoubleLess pred, OperatorExec *child) : pred_(std::move(pred)), child_(child) {}
-    std::string Init() override;
-    OperatorResult Execute(Chunk *input, Chunk *output, std::string *err) override;
-    std::string Close() override { return ""; }
-    std::vector<LType> OutputTypes() const override { return child_->OutputTypes(); }
-private:
-    DoubleLess pred_;
-    OperatorExec *child_;
 };
 
 class gpuAggExecutor : public OperatorExec {

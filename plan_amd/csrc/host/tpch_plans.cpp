@@ -213,7 +213,6 @@ static std::vector<ph_rpn> DiscPrice(int e, int d) { return {XC(e), XK(1), XC(d)
 std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     *q = TpchQuery{};
     q->id = id;
-    q->sfNum = db.num; q->sfDen = db.den;
     ResidentPlan &p = q->plan;
     switch (id) {
     case 1: {   // Order <- Agg <- Scan(lineitem, l_shipdate <= date '1998-12-01' - interval '112 day')
@@ -461,24 +460,22 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         // Project(sum / 7.0) <- Agg(; sum(l_extendedprice)) <- Filter(l_quantity < 0.2 * avg) <- Join(l_partkey = sub.l_partkey)
         //   probe <- Join(l_partkey = p_partkey) probe Scan(lineitem), build Scan(part, p_brand = 'Brand#54', p_container = 'LG BAG')
         //   build Agg(l_partkey; avg(l_quantity)) <- Scan(lineitem)      (the correlated subquery, by its correlation key)
-        // avg(INTEGER) is DOUBLE and the predicate is DOUBLE arithmetic, which a resident plan does not have: the plan carries the
-        // average as its SUM and COUNT and aggregates by (l_quantity, sum, count) — all the predicate reads — so the Filter sees one row per
-        // distinct triple with that triple's exact DECIMAL sum, and the aggregate above adds what passes: the same rows' sum.
+        // avg(INTEGER) is DOUBLE and `*` has only (T, T) overloads: the FLOAT literal is widened and the predicate is DOUBLE arithmetic — a
+        // PH_PE_FLOAT flag column (float64(l_quantity) < float64(0.2f) * (float64(sum) / float64(count)): the average travels as its SUM and
+        // COUNT) under the Filter. The select list's `/ 7.0` is FLOAT arithmetic over the one result row (the aggregate's output phase).
         int subScan = p.Scan(&db.lineitem, {L_PARTKEY, L_QUANTITY});
         int sub = p.Agg(subScan, {ProjExpr::Col(0)}, {{PH_A_SUM, {XC(1)}}, {PH_A_COUNT, {XC(1)}}});   // l_partkey, sum, count
         int part = p.Scan(&db.part, {P_PARTKEY}, {{P_BRAND, PH_EQ, LStr("Brand#54")}, {P_CONTAINER, PH_EQ, LStr("LG BAG")}});
         int line = p.Scan(&db.lineitem, {L_PARTKEY, L_QUANTITY, L_EXTENDEDPRICE});
         int j1 = p.Join(line, part, {0}, {0}, {0, 1, 2});
         int j2 = p.Join(j1, sub, {0}, {0}, {1, 2, 4, 5});                      // l_quantity, l_extendedprice, sum(l_quantity), count(l_quantity)
-        p.Agg(j2, {ProjExpr::Col(0), ProjExpr::Col(2), ProjExpr::Col(3)}, {{PH_A_SUM, {XC(1)}}});
         auto fcol = [](int c) { FloatOp o; o.op = FloatOp::Col; o.col = c; return o; };
         auto fk = [](float k) { FloatOp o; o.op = FloatOp::Const; o.k = k; return o; };
         auto fop = [](FloatOp::Op op) { FloatOp o; o.op = op; return o; };
-        q->upperFilter = std::make_shared<DoubleLess>();
-        q->upperFilter->lhs = {fcol(0)};                                                          // l_quantity
-        q->upperFilter->rhs = {fk(0.2f), fcol(1), fcol(2), fop(FloatOp::Div), fop(FloatOp::Mul)}; // 0.2 * (sum / count)
-        q->upperAggs = {{PH_A_SUM, {XC(3)}}};
-        q->upperOutputs = {ProjExpr::Float({fcol(0), fk(7.0f), fop(FloatOp::Div)})};
+        int pr = p.Project(j2, {ProjExpr::FloatTruth({fcol(0), fk(0.2f), fcol(2), fcol(3), fop(FloatOp::Div), fop(FloatOp::Mul), fop(FloatOp::Lt)}, true), ProjExpr::Col(1)});
+        int f = p.Filter(pr, {{0, PH_EQ, LInt(1)}});
+        p.Agg(f, {}, {{PH_A_SUM, {XC(1)}}});
+        q->outputs = {ProjExpr::Float({fcol(0), fk(7.0f), fop(FloatOp::Div)})};
         q->ncols = 1;
         break;
     }
@@ -504,23 +501,27 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         break;
     }
     case 20: {
-        // the resident plan: partsupp SEMI part[p_name like 'lime%'] joined on BOTH keys with Agg(l_partkey, l_suppkey; sum(l_quantity)) over 1993's lineitem,
-        // grouped by (ps_suppkey, ps_availqty, sum) — the columns the FLOAT predicate reads; the rest of the tree runs over those rows (RunTpchQuery)
+        // Order(s_name) <- Project(s_name, s_address) <- SEMI Join(s_suppkey = ps_suppkey) probe Join(s_nationkey = n_nationkey)[Scan(supplier),
+        //   Scan(nation, n_name = 'VIETNAM')], build Filter(ps_availqty > 0.5 * sum [FLOAT]) <- Join((ps_partkey, ps_suppkey) = (l_partkey, l_suppkey))
+        //   probe SEMI Join(ps_partkey = p_partkey)[Scan(partsupp), Scan(part, p_name like 'lime%')], build Agg(l_partkey, l_suppkey; sum(l_quantity))
+        //   <- Scan(lineitem, 1993). ONE resident plan whose ROOT is the SEMI join (rows: s_name, s_address); the FLOAT predicate is a PH_PE_FLOAT flag
+        //   column (float32(ps_availqty) > 0.5f * float32(sum)) under the Filter.
         int subScan = p.Scan(&db.lineitem, {L_PARTKEY, L_SUPPKEY, L_QUANTITY}, {{L_SHIPDATE, PH_GE, LDate(1993, 1, 1)}, {L_SHIPDATE, PH_LT, LDate(1994, 1, 1)}});
         int sub = p.Agg(subScan, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_SUM, {XC(2)}}});
         int part = p.Scan(&db.part, {P_PARTKEY}, {{P_NAME, PH_LIKE, LStr("lime%")}});
         int ps = p.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY, PS_AVAILQTY});
         int j1 = p.Join(ps, part, {0}, {0}, {0, 1, 2}, JoinSemi);
         int j2 = p.Join(j1, sub, {0, 1}, {0, 1}, {1, 2, 5});                   // ps_suppkey, ps_availqty, sum(l_quantity)
-        p.Agg(j2, {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(2)}, {{PH_A_COUNT_STAR, {}}});
         auto fcol = [](int c) { FloatOp o; o.op = FloatOp::Col; o.col = c; return o; };
         FloatOp half; half.op = FloatOp::Const; half.k = 0.5f;
         FloatOp mul; mul.op = FloatOp::Mul;
-        q->upperFilter = std::make_shared<DoubleLess>();
-        q->upperFilter->float32 = true;
-        q->upperFilter->op = PH_GT;
-        q->upperFilter->lhs = {fcol(1)};                    // ps_availqty
-        q->upperFilter->rhs = {half, fcol(2), mul};         // 0.5 * sum(l_quantity)
+        FloatOp gt; gt.op = FloatOp::Gt;
+        int pr = p.Project(j2, {ProjExpr::Col(0), ProjExpr::FloatTruth({fcol(1), half, fcol(2), mul, gt}, false)});
+        int good = p.Filter(pr, {{1, PH_EQ, LInt(1)}});
+        int nat = p.Scan(&db.nation, {N_NATIONKEY}, {{N_NAME, PH_EQ, LStr("VIETNAM")}});
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY, S_NAME, S_ADDRESS});
+        int js = p.Join(supp, nat, {1}, {0}, {0, 2, 3});                       // s_suppkey, s_name, s_address
+        p.Join(js, good, {0}, {0}, {1, 2}, JoinSemi);
         q->order = {{0, false}};                            // ORDER BY s_name
         q->ncols = 2;
         break;
@@ -592,70 +593,6 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     return p.error;
 }
 
-// Scan(supplier) -> [s_suppkey, s_name, s_address, s_phone, s_nationkey] as a chunk source over the generator (TPC-H 4.2.3: s_name = 'Supplier#' + nine digits)
-static std::unique_ptr<sourceExecutor> SupplierSource(int64_t num, int64_t den) {
-    // the table's chunks are kept per scale factor — a Scan reads stored rows (the reference's column segments), it neither regenerates
-    // nor re-encodes them per query; every execution hands out shallow copies (the vectors are shared, like a Reference())
-    using Chunks = std::vector<std::shared_ptr<Chunk>>;
-    static std::map<std::pair<int64_t, int64_t>, std::shared_ptr<const Chunks>> cache;
-    const std::vector<LType> types = {IntegerType(), VarcharType(), VarcharType(), VarcharType(), IntegerType()};
-    std::shared_ptr<const Chunks> data;
-    auto it = cache.find({num, den});
-    if (it != cache.end()) data = it->second;
-    else {
-        const int64_t n = tpchgen_supplier_count(num, den);
-        std::vector<int32_t> key((size_t)n), nat((size_t)n);
-        std::vector<char> addr((size_t)n * TPCHGEN_S_ADDRESS_STRIDE), phone((size_t)n * TPCHGEN_S_PHONE_LEN);
-        std::vector<uint8_t> alen((size_t)n);
-        tpchgen_supplier_cols sc{};
-        sc.s_suppkey = key.data(); sc.s_nationkey = nat.data(); sc.s_address = addr.data(); sc.s_address_len = alen.data(); sc.s_phone = phone.data();
-        tpchgen_supplier(num, den, 0, n, &sc);
-        auto chunks = std::make_shared<Chunks>();
-        for (int64_t pos = 0; pos < n; pos += DefaultVectorSize) {
-            const int card = (int)std::min<int64_t>(DefaultVectorSize, n - pos);
-            auto c = std::make_shared<Chunk>();
-            c->Init(types, DefaultVectorSize);
-            for (int i = 0; i < card; i++) {
-                const size_t r = (size_t)(pos + i);
-                c->Data[0]->Slice<int32_t>()[i] = key[r];
-                char name[32];
-                snprintf(name, sizeof name, "Supplier#%09d", key[r]);
-                c->Data[1]->SetString(i, name, 18);
-                c->Data[2]->SetString(i, addr.data() + r * TPCHGEN_S_ADDRESS_STRIDE, alen[r]);
-                c->Data[3]->SetString(i, phone.data() + r * TPCHGEN_S_PHONE_LEN, TPCHGEN_S_PHONE_LEN);
-                c->Data[4]->Slice<int32_t>()[i] = nat[r];
-            }
-            c->SetCard(card);
-            chunks->push_back(c);
-        }
-        cache[{num, den}] = chunks;
-        data = chunks;
-    }
-    auto next = std::make_shared<size_t>(0);
-    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [data, next](Chunk *out) {
-        if (*next >= data->size()) return false;
-        *out = *(*data)[(*next)++];
-        return true;
-    }));
-}
-
-// Scan(nation) -> [n_nationkey, n_name]
-static std::unique_ptr<sourceExecutor> NationSource() {
-    auto done = std::make_shared<bool>(false);
-    const std::vector<LType> types = {IntegerType(), VarcharType()};
-    return std::unique_ptr<sourceExecutor>(new sourceExecutor(types, [done, types](Chunk *out) {
-        if (*done) return false;
-        out->Init(types, DefaultVectorSize);
-        for (int i = 0; i < 25; i++) {
-            out->Data[0]->Slice<int32_t>()[i] = i;
-            out->Data[1]->SetString(i, TPCHGEN_NATION_NAMES[i], (int64_t)strlen(TPCHGEN_NATION_NAMES[i]));
-        }
-        out->SetCard(25);
-        *done = true;
-        return true;
-    }));
-}
-
 std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
     std::vector<Compare> having = q.having;
     ResidentPlan mainPlan = q.plan;   // (Q22 patches a scan literal with its scalar subquery's value)
@@ -693,46 +630,7 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (!e.empty()) return "Init: " + e;
     std::unique_ptr<gpuOrderExecutor> ord;
     std::unique_ptr<limitExecutor> lim;
-    std::unique_ptr<doubleFilterExecutor> upperFilter;
-    std::unique_ptr<gpuAggExecutor> upperAgg;
-    std::unique_ptr<sourceExecutor> suppSrc;
-    std::unique_ptr<gpuJoinExecutor> j1, j2;
-    std::unique_ptr<gpuProjectExecutor> proj;
-    std::unique_ptr<sourceExecutor> natSrc;
-    std::unique_ptr<gpuFilterExecutor> natFilter;
     OperatorExec *root = &agg;
-    if (q.id == 20) {
-        // Order(s_name) <- Project(s_name, s_address) <- SEMI Join(s_suppkey = ps_suppkey) probe Join(s_nationkey = n_nationkey)[Scan(supplier),
-        //   Filter(n_name = 'VIETNAM') <- Scan(nation)], build Filter(ps_availqty > 0.5 * sum [FLOAT]) <- the resident plan's group rows
-        upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
-        e = upperFilter->Init();
-        if (!e.empty()) return "Init (FLOAT filter): " + e;
-        natSrc = NationSource();
-        natFilter.reset(new gpuFilterExecutor(ctx, {{1, PH_EQ, LStr("VIETNAM")}}, natSrc.get()));
-        e = natFilter->Init();
-        if (!e.empty()) return "Init (nation filter): " + e;
-        suppSrc = SupplierSource(q.sfNum, q.sfDen);
-        j1.reset(new gpuJoinExecutor(ctx, suppSrc.get(), natFilter.get(), {4}, {0}, {}));
-        e = j1->Init();
-        if (!e.empty()) return "Init (supplier x nation): " + e;
-        j2.reset(new gpuJoinExecutor(ctx, j1.get(), upperFilter.get(), {0}, {0}, {}, 512, JoinSemi));
-        e = j2->Init();
-        if (!e.empty()) return "Init (SEMI join): " + e;
-        proj.reset(new gpuProjectExecutor(ctx, {ProjExpr::Col(1), ProjExpr::Col(2)}, j2.get()));
-        e = proj->Init();
-        if (!e.empty()) return "Init (project): " + e;
-        root = proj.get();
-    }
-    if (q.upperFilter && q.id != 20) {
-        upperFilter.reset(new doubleFilterExecutor(*q.upperFilter, root));
-        e = upperFilter->Init();
-        if (!e.empty()) return "Init: " + e;
-        upperAgg.reset(new gpuAggExecutor(ctx, {}, q.upperAggs, upperFilter.get()));
-        if (!q.upperOutputs.empty()) upperAgg->SetOutputs(q.upperOutputs);
-        e = upperAgg->Init();
-        if (!e.empty()) return "Init: " + e;
-        root = upperAgg.get();
-    }
     if (!q.order.empty()) {
         ord.reset(new gpuOrderExecutor(ctx, q.order, root));
         e = ord->Init();
@@ -763,12 +661,6 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (explain) *explain = agg.Explain();
     if (lim) lim->Close();
     if (ord) ord->Close();
-    if (proj) proj->Close();
-    if (j2) j2->Close();
-    if (j1) j1->Close();
-    if (natFilter) natFilter->Close();
-    if (upperAgg) upperAgg->Close();
-    if (upperFilter) upperFilter->Close();
     agg.Close();
     return "";
 }

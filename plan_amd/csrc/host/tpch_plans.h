@@ -57,13 +57,6 @@ struct TpchQuery {
     // avg(c_acctbal) ..)): conjunct scalarConjunct of node scalarScanNode gets floor(value) at the column's scale as its literal
     // (greatDecimalOp is exact: for a column with `scale` digits, x > v  <=>  unscaled(x) > floor(v * 10^scale))
     int scalarScanNode = -1, scalarConjunct = -1;
-    // operators ABOVE the resident plan whose expressions are DOUBLE / FLOAT arithmetic (Q17): a Filter with a DOUBLE predicate over
-    // the plan's result rows (doubleFilterExecutor), then an ungrouped aggregate over what passes (gpuAggExecutor) with its output
-    // expressions
-    int64_t sfNum = 1, sfDen = 1;         // the database's scale factor (Q15's Scan(supplier) is a chunk source over the generator)
-    std::shared_ptr<DoubleLess> upperFilter;
-    std::vector<AggExpr> upperAggs;
-    std::vector<ProjExpr> upperOutputs;
 };
 
 // the operator subtree of cases/tpch/query/q<id>.sql over the resident database

@@ -418,6 +418,107 @@ extern "C" int ph_expr_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, cons
     return PH_OK;
 }
 
+// ------------------------------------------------------------------ FLOAT / DOUBLE arithmetic and comparisons
+namespace ph {
+
+struct FParams {
+    struct { int32_t type, scale; const void *data; const uint8_t *validity; } c[8];
+    int32_t ncols, nprog, wide, truth;
+    struct { int32_t op, col; float k; } prog[12];
+};
+
+// One row: the program in float32 (every operation rounds to float32: mulFloat32 and friends, function_scalar.go:1010-1025) or float64.
+// Column operands are cast as the binder casts them: INTEGER -> float (tryCastInt32ToFloat32 / ..Float64), DECIMAL -> float64 ->
+// float32 (tryCastDecimalToFloat32: the nearest double of the decimal, then rounded), a HUGEINT carried as a scale-0 decimal likewise.
+// The comparisons are the ones selectOperation has for the type: FLOAT has > >= <=, DOUBLE has < (function_operator_boolean.go:431-490);
+// the others select nothing there, and give 0 here.
+__global__ __launch_bounds__(256) void float_eval_kernel(FParams F, const int32_t *__restrict__ sel, int64_t n, void *__restrict__ out,
+                                                         uint8_t *__restrict__ out_valid) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool valid = true;
+    double st[8];
+    int sp = 0;
+    if (i < n) {
+        const int64_t r = sel ? (int64_t)sel[i] : i;
+        for (int q = 0; q < F.nprog; q++) {
+            const int op = F.prog[q].op;
+            if (op == PH_X_COL) {
+                const auto &c = F.c[F.prog[q].col];
+                if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) valid = false;
+                double v;
+                if (c.type == PH_I32 || c.type == PH_DATE) v = (double)((const int32_t *)c.data)[r];
+                else {
+                    v = (double)((const long long *)c.data)[r];
+                    if (c.type == PH_DEC64 && c.scale > 0) { double p10 = 1.0; for (int s = 0; s < c.scale; s++) p10 *= 10.0; v = v / p10; }
+                }
+                st[sp++] = F.wide ? v : (double)(float)v;
+            } else if (op == PH_X_CONST) {
+                st[sp++] = (double)F.prog[q].k;      // a FLOAT literal (widened for DOUBLE arithmetic: tryCastFloat32ToFloat64)
+            } else {
+                const double b = st[--sp], a = st[--sp];
+                double x;
+                if (F.wide) {
+                    x = op == PH_X_ADD ? a + b : op == PH_X_SUB ? a - b : op == PH_X_MUL ? a * b : op == PH_X_DIV ? a / b
+                        : op == PH_X_LT ? (a < b ? 1.0 : 0.0) : 0.0;
+                } else {
+                    const float fa = (float)a, fb = (float)b;
+                    float fx;
+                    if (op == PH_X_ADD) fx = __fadd_rn(fa, fb);
+                    else if (op == PH_X_SUB) fx = __fsub_rn(fa, fb);
+                    else if (op == PH_X_MUL) fx = __fmul_rn(fa, fb);
+                    else if (op == PH_X_DIV) fx = __fdiv_rn(fa, fb);
+                    else fx = (op == PH_X_GT ? fa > fb : op == PH_X_GE ? fa >= fb : op == PH_X_LE ? fa <= fb : false) ? 1.0f : 0.0f;
+                    x = (double)fx;
+                }
+                st[sp++] = x;
+            }
+        }
+        if (F.truth) ((int32_t *)out)[i] = valid && st[0] != 0.0 ? 1 : 0;     // a NULL operand: the comparison is not true
+        else ((float *)out)[i] = (float)st[0];
+    }
+    if (out_valid && !F.truth) {
+        const unsigned long long m = __ballot(i < n && valid);
+        if ((threadIdx.x & 63) == 0 && i < n) reinterpret_cast<unsigned long long *>(out_valid)[i >> 6] = m;
+    }
+}
+
+}  // namespace ph
+
+extern "C" int ph_float_eval(ph_ctx *ctx, const ph_col *cols, int32_t ncols, const ph_rpn *prog, int32_t nprog, int32_t wide, const int32_t *sel,
+                             int64_t n, int32_t out_type, void *out_dev, uint8_t *out_validity_dev) {
+    PH_REQUIRE(ctx && cols && prog && ncols >= 1 && ncols <= 8 && nprog >= 1 && nprog <= 12 && n >= 0 && (out_type == PH_I32 || out_type == PH_F32),
+               "ph_float_eval: bad arguments (1..8 columns, 1..12 program steps, out_type PH_I32 or PH_F32)");
+    if (out_type == PH_F32 && wide) { ph::set_error("ph_float_eval: DOUBLE values have no column type here: only the truth value of a DOUBLE comparison"); return PH_EUNSUPPORTED; }
+    ph::FParams F{};
+    F.ncols = ncols; F.nprog = nprog; F.wide = wide ? 1 : 0; F.truth = out_type == PH_I32 ? 1 : 0;
+    bool any_validity = false;
+    for (int c = 0; c < ncols; c++) {
+        const int t = cols[c].type;
+        if (t != PH_I32 && t != PH_I64 && t != PH_DEC64 && t != PH_DATE) { ph::set_error("ph_float_eval: column %d has type %d", c, t); return PH_EUNSUPPORTED; }
+        F.c[c].type = t; F.c[c].scale = cols[c].scale; F.c[c].data = cols[c].data; F.c[c].validity = cols[c].validity;
+        any_validity |= cols[c].validity != nullptr;
+    }
+    int depth = 0;
+    for (int q = 0; q < nprog; q++) {
+        const int op = prog[q].op;
+        F.prog[q].op = op; F.prog[q].col = prog[q].col;
+        if (op == PH_X_COL) { if (prog[q].col < 0 || prog[q].col >= ncols) { ph::set_error("ph_float_eval: column %d out of range", prog[q].col); return PH_EINVAL; } depth++; }
+        else if (op == PH_X_CONST) { uint32_t bits = (uint32_t)prog[q].ival; memcpy(&F.prog[q].k, &bits, 4); depth++; }
+        else if (op == PH_X_ADD || op == PH_X_SUB || op == PH_X_MUL || op == PH_X_DIV || op == PH_X_LT || op == PH_X_LE || op == PH_X_GT || op == PH_X_GE) {
+            if (depth < 2) { ph::set_error("ph_float_eval: malformed program"); return PH_EINVAL; }
+            depth--;
+        } else { ph::set_error("ph_float_eval: operation %d", op); return PH_EINVAL; }
+        if (depth > 8) { ph::set_error("ph_float_eval: program too deep"); return PH_EUNSUPPORTED; }
+    }
+    if (depth != 1) { ph::set_error("ph_float_eval: malformed program"); return PH_EINVAL; }
+    if (any_validity && !F.truth && !out_validity_dev) { ph::set_error("ph_float_eval: inputs carry validity but out_validity_dev is NULL"); return PH_EINVAL; }
+    if (n == 0) return PH_OK;
+    PH_REQUIRE(out_dev, "ph_float_eval: out_dev is NULL");
+    ph::float_eval_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(F, sel, n, out_dev, any_validity ? out_validity_dev : nullptr);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 // ------------------------------------------------------------------ extract(part from date)
 namespace ph {
 __global__ __launch_bounds__(256) void date_extract_kernel(int part, const int32_t *__restrict__ days,

@@ -538,6 +538,38 @@ int eval_rpn(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, PCol *out) {
     return PH_OK;
 }
 
+// ---- FLOAT / DOUBLE program over a relation's columns -> a positional column: the int32 truth value of a comparison, or float32 values
+int eval_float(ph_plan *p, Rel *r, const ph_plan_expr &e, PCol *out) {
+    PL_CHECK(apply_pending(p, r));
+    std::vector<int> operands;
+    for (int i = 0; i < e.nprog; i++)
+        if (e.prog[i].op == PH_X_COL && std::find(operands.begin(), operands.end(), e.prog[i].col) == operands.end()) operands.push_back(e.prog[i].col);
+    if (operands.empty()) { set_error("ph_plan: a FLOAT expression without a column"); return PH_EUNSUPPORTED; }
+    for (int c : operands) if (c < 0 || c >= (int)r->cols.size()) { set_error("ph_plan: expression column %d out of range", c); return PH_EINVAL; }
+    int lane = r->cols[(size_t)operands[0]].lane;
+    for (int c : operands) if (r->cols[(size_t)c].lane != lane) lane = -2;
+    if (lane < 0) PL_CHECK(positional(p, r, operands));
+    std::vector<ph_col> views;
+    const int32_t *sel = nullptr;
+    bool any_validity = false;
+    for (int c : operands) {
+        const int32_t *s = nullptr;
+        views.push_back(col_view(*r, r->cols[(size_t)c], &s));
+        sel = s;
+        any_validity |= views.back().validity != nullptr;
+    }
+    std::vector<ph_rpn> pr(e.prog, e.prog + e.nprog);
+    for (auto &o : pr) if (o.op == PH_X_COL) o.col = (int32_t)(std::find(operands.begin(), operands.end(), o.col) - operands.begin());
+    const int32_t out_type = e.result_int ? PH_I32 : PH_F32;
+    void *o = nullptr, *val = nullptr;
+    PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &o));
+    if (any_validity && !e.result_int) PL_CHECK(palloc(p, (r->n + 7) / 8 + 64, &val));
+    if (r->n > 0) PL_CHECK(ph_float_eval(p->ctx, views.data(), (int32_t)views.size(), pr.data(), e.nprog, e.float_wide, sel, r->n, out_type, o, (uint8_t *)val));
+    *out = PCol{};
+    out->type = out_type; out->data = o; out->validity = (const uint8_t *)val;
+    return PH_OK;
+}
+
 // expression program over the rows sel[0..m) (positions) of a relation -> m positional decimal values
 int eval_rpn_at(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, const int32_t *sel, int64_t m, void **out, int32_t *scale) {
     std::vector<int> operands;
@@ -635,6 +667,8 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
         out->ordered = r->cols[(size_t)e.col].ordered;   // the year of a non-decreasing date is non-decreasing
         return PH_OK;
     }
+    case PH_PE_FLOAT:
+        return eval_float(p, r, e, out);
     case PH_PE_SUBSTR: {
         // substring(<VARCHAR table column> FROM offset FOR length): the result is interned at once — a positional int32 column of
         // string codes (equal strings, equal codes: what a filter's `=`, a group key and a join key need) whose dictionary rows are the

@@ -486,6 +486,15 @@ def expr_eval(ctx, cols, prog, sel, n, want_validity=False):
     return out, val
 
 
+def float_eval(ctx, cols, prog, sel, n, truth=True, wide=False):
+    """ph_float_eval: FLOAT / DOUBLE program over device columns -> device pointer of int32 truth values (truth=True) or float32 values"""
+    arr = (Col * len(cols))(*_cols(cols))
+    pr = (Rpn * len(prog))(*[Rpn(*x) for x in prog])
+    out = ctx.alloc(max(n, 1) * 4)
+    check(lib().ph_float_eval(ctx.h, arr, i32(len(cols)), pr, i32(len(prog)), i32(1 if wide else 0), sel, i64(n), i32(PH_I32 if truth else PH_F32), out, None))
+    return out
+
+
 class Agg:
     def __init__(self, ctx, key_types, aggs, expected_groups=1024):
         self.ctx = ctx
@@ -804,6 +813,8 @@ PH_STAT_ASCENDING, PH_STAT_STRICT, PH_STAT_DECLARED_UNIQUE = 1, 2, 4
 
 PH_PE_CASE = 4
 PH_PE_SUBSTR = 5
+PH_PE_FLOAT = 6
+PH_X_DIV, PH_X_LT, PH_X_LE, PH_X_GT, PH_X_GE = 6, 7, 8, 9, 10
 PH_B_CMP, PH_B_AND, PH_B_OR = 1, 2, 3
 PH_COLREF = 9
 
@@ -814,7 +825,7 @@ class Bool(ctypes.Structure):
 
 class PlanExpr(ctypes.Structure):
     _fields_ = [("kind", i32), ("col", i32), ("nprog", i32), ("prog", Rpn * 12), ("nwhen", i32), ("when", ctypes.POINTER(Bool)),
-                ("nelse", i32), ("else_prog", Rpn * 12), ("result_int", i32), ("sub_offset", i64), ("sub_length", i64)]
+                ("nelse", i32), ("else_prog", Rpn * 12), ("result_int", i32), ("sub_offset", i64), ("sub_length", i64), ("float_wide", i32)]
 
 
 def bool_tree(expr):
@@ -873,6 +884,24 @@ def pe_col(c):
 def pe_year(c):
     e = PlanExpr()
     e.kind, e.col = PH_PE_YEAR, c
+    return e
+
+
+def X_F32(v):
+    """a FLOAT literal of a PH_PE_FLOAT program (its float32 bits)"""
+    return (PH_X_CONST, -1, int(np.float32(v).view(np.uint32)), 0)
+
+
+def X_OP(op):
+    return (op, -1, 0, 0)
+
+
+def pe_float(prog, truth=True, wide=False):
+    """FLOAT (wide=False) / DOUBLE arithmetic ending — truth=True — in a comparison whose 1 / 0 a Filter above tests (ph_float_eval)"""
+    e = PlanExpr()
+    e.kind, e.col, e.nprog, e.result_int, e.float_wide = PH_PE_FLOAT, -1, len(prog), 1 if truth else 0, 1 if wide else 0
+    for i, r in enumerate(prog):
+        e.prog[i] = Rpn(*r)
     return e
 
 

@@ -570,6 +570,58 @@ def q17_plan(db, brand="Brand#54", container="LG BAG"):
     return p.create()
 
 
+def q17_whole_plan(db, brand="Brand#54", container="LG BAG", fraction=0.2):
+    """Q17 with its DOUBLE predicate in the plan (PH_PE_FLOAT): Agg(; sum(l_extendedprice)) <- Filter(flag = 1) <- Project(flag =
+       float64(l_quantity) < float64(0.2f) * (float64(sum) / float64(count)), l_extendedprice) <- the two joins. One group comes back; the select
+       list's float32 division stays with the caller (q17_avg_of_sum)"""
+    p = hip.Plan(db.ctx)
+    sub_scan = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_quantity"))
+    sub = p.agg(sub_scan, [hip.pe_col(0)], [(hip.PH_A_SUM, hip.pe_col(1)), (hip.PH_A_COUNT, hip.pe_col(1))])
+    part = p.scan(db.t("part"), db.c("part", "p_partkey"),
+                  [_pred(db, "part", "p_brand", hip.PH_EQ, _s(brand)), _pred(db, "part", "p_container", hip.PH_EQ, _s(container))])
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_quantity", "l_extendedprice"))
+    j1 = p.join(line, part, [0], [0], [0, 1, 2])
+    j2 = p.join(j1, sub, [0], [0], [1, 2, 4, 5])                          # l_quantity, l_extendedprice, sum, count
+    flag = hip.pe_float([hip.X_COL(0), hip.X_F32(fraction), hip.X_COL(2), hip.X_COL(3), hip.X_OP(hip.PH_X_DIV), hip.X_MUL, hip.X_OP(hip.PH_X_LT)], wide=True)
+    pr = p.project(j2, [flag, hip.pe_col(1)])
+    f = p.filter(pr, [hip.pred(0, hip.PH_EQ, hip.const(hip.PH_I32, i=1))])
+    p.agg(f, [], [(hip.PH_A_SUM, hip.pe_col(1))])
+    return p.create()
+
+
+def q17_avg_of_sum(r, divisor=7.0):
+    """float32(sum) / float32(divisor) over the one group of q17_whole_plan; (None, 0) when no row passed"""
+    from decimal import Decimal
+    if r["ngroups"] == 0 or r["count"][0][0] == 0:
+        return None, 0
+    total = r["sum"][0][0]
+    return np.float32(np.float32(float(Decimal(total).scaleb(-r["scale"][0]))) / np.float32(divisor)), total
+
+
+def q20_whole_plan(db, pattern="lime%", nation="VIETNAM", d1=None, d2=None, fraction=0.5):
+    """Q20 as ONE plan whose root is the SEMI join (ph_plan_fetch_rows: s_name, s_address): the FLOAT predicate ps_availqty > 0.5 * sum is a
+       PH_PE_FLOAT flag under a Filter, the qualifying partsupp rows are the build side of SEMI Join(s_suppkey = ps_suppkey) whose probe side is
+       supplier x nation[n_name]"""
+    d1 = tpchgen.days(1993, 1, 1) if d1 is None else d1
+    d2 = tpchgen.days(1994, 1, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    sub_scan = p.scan(db.t("lineitem"), db.c("lineitem", "l_partkey", "l_suppkey", "l_quantity"),
+                      [_pred(db, "lineitem", "l_shipdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "lineitem", "l_shipdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    sub = p.agg(sub_scan, [hip.pe_col(0), hip.pe_col(1)], [(hip.PH_A_SUM, hip.pe_col(2))])
+    part = p.scan(db.t("part"), db.c("part", "p_partkey"), [_pred(db, "part", "p_name", hip.PH_LIKE, _s(pattern))])
+    ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_suppkey", "ps_availqty"))
+    j1 = p.join(ps, part, [0], [0], [0, 1, 2], join_type=hip.PH_JT_SEMI)
+    j2 = p.join(j1, sub, [0, 1], [0, 1], [1, 2, 5])                                                # ps_suppkey, ps_availqty, sum
+    flag = hip.pe_float([hip.X_COL(1), hip.X_F32(fraction), hip.X_COL(2), hip.X_MUL, hip.X_OP(hip.PH_X_GT)])
+    pr = p.project(j2, [hip.pe_col(0), flag])
+    good = p.filter(pr, [hip.pred(1, hip.PH_EQ, hip.const(hip.PH_I32, i=1))])
+    nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey"), [_pred(db, "nation", "n_name", hip.PH_EQ, _s(nation))])
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey", "s_name", "s_address"))
+    js = p.join(supp, nat, [1], [0], [0, 2, 3])                                                    # s_suppkey, s_name, s_address
+    p.join(js, good, [0], [0], [1, 2], join_type=hip.PH_JT_SEMI)
+    return p.create()
+
+
 def q17_avg_yearly(r, fraction=0.2, divisor=7.0):
     """(float32 avg_yearly or None, exact DECIMAL sum unscaled): the groups (l_quantity, sum, count) that pass
        float64(l_quantity) < float64(float32(fraction)) * (float64(sum) / float64(count)) — avg(INTEGER) is float64, the FLOAT literal is

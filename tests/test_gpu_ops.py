@@ -2048,3 +2048,35 @@ def test_having_on_the_device_matches_the_oracle_filter(ctx):
         assert got["keys"][:, 0].tolist() == full["keys"][keep, 0].tolist()                   # first-seen order kept
         assert [s[0] for s in got["sum"]] == [full["sum"][g][0] for g in keep]
     agg.free()
+
+
+@pytest.mark.gpu
+def test_float_eval_follows_the_float_and_double_overloads(ctx):
+    """ph_float_eval against numpy's IEEE float32 / float64 arithmetic, operation by operation as mulFloat32 / mulFloat64 and the casts
+    tryCastInt32ToFloat32 / tryCastDecimalToFloat32 (decimal -> float64 -> float32) do it; comparisons that selectOperation lacks for the type
+    ('<' on FLOAT, '>' on DOUBLE) are never true. Parity unpinned beyond Q17 / Q20, whose goldens run through these two programs."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    q = rng.integers(1, 51, n).astype(np.int32)
+    s = rng.integers(1, 4000, n).astype(np.int64)                     # a HUGEINT sum, carried as a scale-0 decimal
+    c = rng.integers(1, 80, n).astype(np.int64)
+    d = rng.integers(-10**9, 10**9, n).astype(np.int64)               # DECIMAL scale 2
+    Q, S, C, D = (hip.DevColumn(ctx, hip.PH_I32, q), hip.DevColumn(ctx, hip.PH_DEC64, s, scale=0), hip.DevColumn(ctx, hip.PH_DEC64, c, scale=0),
+                  hip.DevColumn(ctx, hip.PH_DEC64, d, scale=2))
+    f32 = np.float32
+    # Q17's: float64(q) < float64(0.2f) * (float64(s) / float64(c))
+    got = ctx.download(hip.float_eval(ctx, [Q, S, C], [hip.X_COL(0), hip.X_F32(0.2), hip.X_COL(1), hip.X_COL(2), hip.X_OP(hip.PH_X_DIV), hip.X_MUL,
+                                                      hip.X_OP(hip.PH_X_LT)], None, n, wide=True), np.int32, n)
+    want = (q.astype(np.float64) < np.float64(f32(0.2)) * (s.astype(np.float64) / c.astype(np.float64)))
+    assert np.array_equal(got.astype(bool), want) and 0 < want.sum() < n
+    # Q20's: float32(q) > 0.5f * float32(s), and '>=' / '<=' beside it; '<' on FLOAT is never true
+    for op, fn in ((hip.PH_X_GT, np.greater), (hip.PH_X_GE, np.greater_equal), (hip.PH_X_LE, np.less_equal), (hip.PH_X_LT, lambda a, b: np.zeros(n, bool))):
+        got = ctx.download(hip.float_eval(ctx, [Q, S], [hip.X_COL(0), hip.X_F32(0.5), hip.X_COL(1), hip.X_MUL, hip.X_OP(op)], None, n), np.int32, n)
+        assert np.array_equal(got.astype(bool), fn(q.astype(f32), f32(0.5) * s.astype(f32)))
+    # values: 100.00f * float32(decimal) / float32(decimal') — Q14's select list — every operation rounded to float32
+    got = ctx.download(hip.float_eval(ctx, [D, S], [hip.X_F32(100.0), hip.X_COL(0), hip.X_MUL, hip.X_COL(1), hip.X_OP(hip.PH_X_DIV)], None, n, truth=False), np.float32, n)
+    want = (f32(100.0) * (d.astype(np.float64) / 100.0).astype(f32)) / s.astype(f32)
+    assert np.array_equal(got, want.astype(f32))
+    # '>' on DOUBLE does not exist: never true
+    got = ctx.download(hip.float_eval(ctx, [Q, S], [hip.X_COL(0), hip.X_COL(1), hip.X_OP(hip.PH_X_GT)], None, n, wide=True), np.int32, n)
+    assert not got.any()

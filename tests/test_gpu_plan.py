@@ -407,6 +407,28 @@ def test_q15_as_one_plan_with_a_join_root_matches_golden(ctx, db, sf1):
     assert "lowered before in this run, reused" in ex
 
 
+def test_q17_and_q20_with_their_float_predicates_inside_the_plan_match_the_goldens(ctx, db, sf1):
+    """PH_PE_FLOAT: Q17's DOUBLE predicate (l_quantity < 0.2 * avg, float64 with the FLOAT literal widened) and Q20's FLOAT one (ps_availqty >
+    0.5 * sum, float32) as flag columns under a Filter; Q20 whole as a plan whose root is the SEMI join (rows: s_name, s_address)"""
+    p = tpch.q17_whole_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    f, total = tpch.q17_avg_of_sum(r)
+    rc, of, osum = O.q17(sf1)
+    assert rc == 0 and total == osum.unscaled(2), ex
+    assert f"#\n{float(f)!r}\n" == golden("plan_q17.txt"), ex
+    p = tpch.q20_whole_plan(db)
+    p.run()
+    rows = p.fetch_rows()
+    ex = p.explain()
+    p.free()
+    names, addrs = rows["columns"]
+    text = "#\t\n" + "".join(f"{a}\t{b}\n" for a, b in sorted(zip(names, addrs)))
+    assert text == golden("plan_q20.txt"), ex
+
+
 def test_q17_decorrelated_average_joined_back_matches_golden(ctx, db, sf1):
     """Q17: an aggregate by the correlation key below a join whose payload is its SUM and COUNT; the DOUBLE predicate and the float32
     division over the fetched groups: the oracle's exact sum and cases/tpch/1g/plan/q17.txt"""
