@@ -31,6 +31,7 @@ package compute
 import "C"
 
 import (
+	"math"
 	"strings"
 	"unsafe"
 
@@ -332,6 +333,59 @@ func (b *planBuilder) lowerRPNChild(e *Expr, nLeft int, out *[]C.ph_rpn) bool {
 		return true
 	}
 	return false
+}
+
+// A FLOAT / DOUBLE expression (the binder typed it so: a FLOAT literal beside a DECIMAL or INTEGER operand, avg(INTEGER) beside anything)
+// as a PH_PE_FLOAT program: column references keep the cast the binder put on them out of the program (ph_float_eval casts by column type, as
+// tryCast*ToFloat32 / ..Float64 do), FLOAT literals carry their float32 bits, the arithmetic and — as the last step — one comparison follow.
+// wide: the expression's type is DOUBLE. A Filter `l_quantity < 0.2 * avg` lowers to Project(flag) + Filter(flag = 1): see lower(POT_Filter).
+func (b *planBuilder) lowerFloatRPN(e *Expr, nLeft int, out *[]C.ph_rpn) bool {
+	e = stripCast(e)
+	if e == nil {
+		return false
+	}
+	if col, ok := childColumn(e, nLeft); ok {
+		*out = append(*out, C.ph_rpn{op: C.PH_X_COL, col: C.int32_t(col)})
+		return true
+	}
+	switch e.Typ {
+	case ET_Const:
+		if e.ConstValue.Type != ConstTypeFloat {
+			return false
+		}
+		bits := math.Float32bits(float32(e.ConstValue.Float))
+		*out = append(*out, C.ph_rpn{op: C.PH_X_CONST, col: -1, ival: C.int64_t(bits)})
+		return true
+	case ET_Func:
+		ops := map[string]C.int32_t{FuncAdd: C.PH_X_ADD, FuncSubtract: C.PH_X_SUB, FuncMultiply: C.PH_X_MUL, FuncDivide: C.PH_X_DIV,
+			FuncLess: C.PH_X_LT, FuncLessEqual: C.PH_X_LE, FuncGreater: C.PH_X_GT, FuncGreaterEqual: C.PH_X_GE}
+		op, ok := ops[e.FuncName()]
+		if !ok || len(e.Children) != 2 || !b.lowerFloatRPN(e.Children[0], nLeft, out) || !b.lowerFloatRPN(e.Children[1], nLeft, out) {
+			return false
+		}
+		*out = append(*out, C.ph_rpn{op: op, col: -1})
+		return true
+	}
+	return false
+}
+
+func (b *planBuilder) lowerFloatExpr(e *Expr, nLeft int, truth bool) (C.ph_plan_expr, bool) {
+	var x C.ph_plan_expr
+	var prog []C.ph_rpn
+	if !b.lowerFloatRPN(e, nLeft, &prog) || len(prog) > 12 {
+		return x, false
+	}
+	x.kind, x.col, x.nprog = C.PH_PE_FLOAT, -1, C.int32_t(len(prog))
+	for i := range prog {
+		x.prog[i] = prog[i]
+	}
+	if truth {
+		x.result_int = 1
+	}
+	if stripCast(e.Children[0]).DataTyp.Id == common.LTID_DOUBLE || stripCast(e.Children[1]).DataTyp.Id == common.LTID_DOUBLE {
+		x.float_wide = 1
+	}
+	return x, true
 }
 
 // ---- the subtree, bottom-up
