@@ -456,3 +456,43 @@ def test_q18_subquery_aggregate_varchar_key_matches_golden(ctx, db):
     p.free()
     assert text == golden("plan_q18.txt"), ex
     assert "groups stay on the device" in ex
+
+
+@pytest.mark.parametrize("jt", ["inner", "semi", "anti"])
+def test_join_rooted_plan_rows_match_the_oracle_join(ctx, jt):
+    """a plan whose root is a join over two ad-hoc tables with duplicate keys on both sides and a Filter under the build side: the rows
+    ph_plan_fetch_rows returns are the oracle's pair set (INNER: probe key, probe payload, build payload) / its marked probe rows (SEMI, ANTI)"""
+    rng = np.random.default_rng({"inner": 1, "semi": 2, "anti": 3}[jt])
+    nb, npr = 30_000, 90_000
+    bk = rng.integers(0, 20_000, nb).astype(np.int32)
+    bv = rng.integers(0, 1000, nb).astype(np.int64)
+    pk = rng.integers(0, 25_000, npr).astype(np.int32)
+    pv = np.arange(npr, dtype=np.int64) * 7
+    B = hip.Table(ctx, [dict(typ=hip.PH_I32, arr=bk), dict(typ=hip.PH_DEC64, arr=bv, scale=2)], nb)
+    P = hip.Table(ctx, [dict(typ=hip.PH_I32, arr=pk), dict(typ=hip.PH_I64, arr=pv)], npr)
+    p = hip.Plan(ctx)
+    build = p.scan(B, [0, 1], [hip.pred(1, hip.PH_GT, hip.const(hip.PH_DEC64, i=30000, scale=2))])     # bv > 300.00
+    probe = p.scan(P, [0, 1])
+    if jt == "inner":
+        p.join(probe, build, [0], [0], [0, 1, 3])
+    else:
+        p.join(probe, build, [0], [0], [0, 1], join_type=hip.PH_JT_SEMI if jt == "semi" else hip.PH_JT_ANTI)
+    p.create()
+    p.run()
+    r = p.fetch_rows()
+    ex = p.explain()
+    p.free()
+    bsel = np.nonzero(bv > 30000)[0].astype(np.int64)
+    oj = O.Join([O.col(O.OT_INT32, bk)], bsel, len(bsel))
+    if jt == "inner":
+        m, wp, wb = oj.probe_inner([O.col(O.OT_INT32, pk)], None, npr, 1 << 22)
+        want = sorted(zip(pk[wp].tolist(), pv[wp].tolist(), bv[wb].tolist()))
+        got = sorted(zip(r["columns"][0].tolist(), r["columns"][1].tolist(), r["columns"][2].tolist()))
+        assert r["nrows"] == m and r["scales"][2] == 2, ex
+    else:
+        f = oj.probe_mark([O.col(O.OT_INT32, pk)], None, npr).astype(bool)
+        keep = f if jt == "semi" else ~f
+        want = sorted(zip(pk[keep].tolist(), pv[keep].tolist()))
+        got = sorted(zip(r["columns"][0].tolist(), r["columns"][1].tolist()))
+    assert got == want, ex
+    B.free(); P.free()
