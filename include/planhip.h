@@ -470,6 +470,11 @@ int ph_join_build_range(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const in
  *                      passes behind itself. The caller then builds again without the flag. Ignored where the
  *                      sorted fill does not apply (selections, NULL-able keys, small or sparse tables). */
 #define PH_JOIN_KEYS_SORTED_UNIQUE 4
+/*   PH_JOIN_EXISTS_ONLY  the table will only be asked WHETHER a key has a build row (ph_join_probe_mark / _mark_where: SEMI, ANTI and mark
+ *                      joins). With a key range of at most 64 M values and a big build side it is then a flag table — one byte per key value,
+ *                      one pass of plain byte stores, duplicates and row ids never materialised (ph_join_kind "bitmap"); every other probe is
+ *                      PH_EUNSUPPORTED on it. Ignored where it does not apply. */
+#define PH_JOIN_EXISTS_ONLY 8
 int ph_join_build_ex(ph_ctx *ctx, const ph_col *keys, int32_t nkeys, const int32_t *sel, int64_t n, int32_t flags,
                      int64_t key_lo, int64_t key_hi, ph_join **out);
 /* Filter -> HashJoin build in one pass (filterExecutor under joinExecutor's build child): the rows

@@ -901,6 +901,7 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
     const int uniq = key_unique(B, nd.bkeys);
     const bool unique = uniq > 0;
     const bool exists_only = nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI || (nd.join_type == PH_JT_INNER && !need_build_cols && unique);
+    const bool marks_only = nd.join_type == PH_JT_ANTI || (exists_only && !unique);   // probe form (2) below: ph_join_probe_mark and nothing else
     std::string how;
 
     // ---- sideways information passing: a big, unfiltered build table whose key the probe side has already joined
@@ -985,7 +986,8 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
             if (rc == PH_EUNSUPPORTED) {
                 PL_CHECK(apply_pending(p, &B));
                 const bool ident = B.lanes[0].rows == nullptr;
-                const int32_t f2 = flags | (su && ident ? PH_JOIN_KEYS_SORTED_UNIQUE : 0);
+                // SEMI against a key with duplicates / ANTI: the probe below only marks — a bitmap of the key values is the whole table
+                const int32_t f2 = flags | (su && ident ? PH_JOIN_KEYS_SORTED_UNIQUE : 0) | (marks_only ? PH_JOIN_EXISTS_ONLY : 0);
                 PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, B.lanes[0].rows, ident ? t->nrows : B.n, f2, lo, hi, &j));
                 how += (f2 & PH_JOIN_KEYS_SORTED_UNIQUE) ? " build: sorted fill;" : ident ? " build: whole table;" : " build: selected rows;";
                 brow_is_rowid = true;
@@ -999,7 +1001,7 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
             if (nk == 1 && k0.src && k0.src->cols[(size_t)k0.src_col].has_range && (k0.type == PH_I32 || k0.type == PH_I64)) {
                 flags |= PH_JOIN_KEY_RANGE; lo = k0.src->cols[(size_t)k0.src_col].min; hi = k0.src->cols[(size_t)k0.src_col].max;
             }
-            PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, nullptr, B.n, flags, lo, hi, &j));
+            PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, nullptr, B.n, flags | (marks_only ? PH_JOIN_EXISTS_ONLY : 0), lo, hi, &j));
             how += " build: intermediate rows;";
         }
         p->joins.push_back(j);

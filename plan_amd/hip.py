@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-PH_JOIN_KEY_RANGE, PH_JOIN_FK_PROBES, PH_JOIN_KEYS_SORTED_UNIQUE = 1, 2, 4
+PH_JOIN_KEY_RANGE, PH_JOIN_FK_PROBES, PH_JOIN_KEYS_SORTED_UNIQUE, PH_JOIN_EXISTS_ONLY = 1, 2, 4, 8
 PH_OK, PH_EINVAL, PH_EHIP, PH_EUNSUPPORTED, PH_EOVERFLOW, PH_ECAPACITY, PH_ECONSTRAINT = 0, -1, -2, -3, -4, -5, -6
 PH_I32, PH_I64, PH_DATE, PH_DEC64, PH_CODE8, PH_F32, PH_F64, PH_STR = range(1, 9)
 PH_EQ, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE = range(1, 9)
@@ -606,17 +606,17 @@ class Agg:
 
 
 class Join:
-    def __init__(self, ctx, keys, sel, n, key_range=None, fk_probes=False, sorted_unique=False):
+    def __init__(self, ctx, keys, sel, n, key_range=None, fk_probes=False, sorted_unique=False, exists_only=False):
         """key_range = (lo, hi) of the single key column from column statistics (Table.col_range): a
         direct table for dense keys; fk_probes: the probe side is a foreign key into these keys (node
         table, no Bloom bitmap) — ph_join_build_ex"""
         self.ctx = ctx
         self.h = vp()
-        if key_range is None and not fk_probes and not sorted_unique:
+        if key_range is None and not fk_probes and not sorted_unique and not exists_only:
             check(lib().ph_join_build(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), ctypes.byref(self.h)))
         else:
             flags = ((PH_JOIN_KEY_RANGE if key_range is not None else 0) | (PH_JOIN_FK_PROBES if fk_probes else 0) |
-                     (PH_JOIN_KEYS_SORTED_UNIQUE if sorted_unique else 0))
+                     (PH_JOIN_KEYS_SORTED_UNIQUE if sorted_unique else 0) | (PH_JOIN_EXISTS_ONLY if exists_only else 0))
             lo, hi = key_range if key_range is not None else (0, 0)
             check(lib().ph_join_build_ex(ctx.h, _cols(keys), i32(len(keys)), sel, i64(n), i32(flags), i64(lo), i64(hi),
                                          ctypes.byref(self.h)))

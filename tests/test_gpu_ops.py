@@ -2080,3 +2080,33 @@ def test_float_eval_follows_the_float_and_double_overloads(ctx):
     # '>' on DOUBLE does not exist: never true
     got = ctx.download(hip.float_eval(ctx, [Q, S], [hip.X_COL(0), hip.X_COL(1), hip.X_OP(hip.PH_X_GT)], None, n, wide=True), np.int32, n)
     assert not got.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [4, 8])
+def test_existence_only_table_marks_like_the_oracle(ctx, kw):
+    """PH_JOIN_EXISTS_ONLY: a big build side with duplicates, a key range, NULL keys and a build selection as one flag byte per key value; its
+    marks equal oracle_join_probe_mark's (probe selection and NULL probe keys included); every other probe is refused"""
+    rng = np.random.default_rng(kw)
+    nb, npr = 700_000, 900_000
+    dt, ht, ot = (np.int32, hip.PH_I32, O.OT_INT32) if kw == 4 else (np.int64, hip.PH_I64, O.OT_INT64)
+    bk = rng.integers(1000, 3_000_000, nb).astype(dt)
+    bvalid = np.packbits(rng.random(nb) > 0.01, bitorder="little")
+    bsel = np.sort(rng.choice(nb, 400_000, replace=False))
+    pk = rng.integers(0, 3_100_000, npr).astype(dt)
+    pvalid = np.packbits(rng.random(npr) > 0.02, bitorder="little")
+    psel = np.sort(rng.choice(npr, 500_000, replace=False))
+    B = hip.DevColumn(ctx, ht, bk, validity=bvalid)
+    P = hip.DevColumn(ctx, ht, pk, validity=pvalid)
+    j = hip.Join(ctx, [B], ctx.upload(bsel.astype(np.int32)), len(bsel), key_range=(1000, 2_999_999), exists_only=True)
+    assert j.kind == "bitmap"
+    oj = O.Join([O.col(ot, bk, validity=bvalid)], bsel.astype(np.int64), len(bsel))
+    got = dl(ctx, j.probe_mark([P], ctx.upload(psel.astype(np.int32)), len(psel)), np.uint8, len(psel))
+    want = oj.probe_mark([O.col(ot, pk, validity=pvalid)], psel.astype(np.int64), len(psel))
+    assert np.array_equal(got, want) and 0 < want.sum() < len(psel)
+    got = dl(ctx, j.probe_mark([P], None, npr), np.uint8, npr)
+    assert np.array_equal(got, oj.probe_mark([O.col(ot, pk, validity=pvalid)], None, npr))
+    with pytest.raises(hip.PlanHipError):
+        j.probe_inner([P], None, npr, 1 << 20)
+    j.free()
+    B.free(); P.free()
