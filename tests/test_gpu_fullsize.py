@@ -143,3 +143,35 @@ def test_q9_sf10_join_rows_and_profit_match_numpy(ctx, sf10):
     got = {a * 4096 + b: c for a, b, c in r["rows"]}
     assert r["ngroups"] == len(uk) == 175
     assert got == {int(k): int(v) for k, v in zip(uk, want)}
+
+
+def test_whole_plans_agree_with_their_two_step_forms_at_sf10(ctx):
+    """Q15, Q17 and Q20 at SF10, each in two independently lowered formulations whose SF1 results both equal the reference's golden
+    (tests/test_gpu_plan.py): the whole tree as one plan (join-rooted rows / FLOAT predicate inside the plan) against the aggregate-rooted
+    plan whose upper operators run over the fetched groups. At full size the two must give the same rows — exact DECIMAL sums included."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from plan_amd import tpch
+    sf = (10, 1)
+    data = {"sf": sf,
+            "lineitem": tpchgen.lineitem(sf, columns=["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount", "l_shipdate"]),
+            "part": tpchgen.part(sf), "partsupp": tpchgen.partsupp(sf), "supplier": tpchgen.supplier(sf)}
+    db = tpch.Database(ctx, data)
+    try:
+        # Q15
+        p = tpch.q15_rows_plan(db); p.run(); whole = p.fetch_rows(); p.free()
+        p = tpch.q15_plan(db); p.run(); rows = tpch.q15_rows(p.fetch()); p.free()
+        assert whole["nrows"] == len(rows) >= 1
+        assert sorted(zip(whole["columns"][0].tolist(), whole["columns"][4].tolist())) == rows
+        assert all(n == f"Supplier#{int(k):09d}" for k, n in zip(whole["columns"][0], whole["columns"][1]))
+        # Q17
+        p = tpch.q17_whole_plan(db); p.run(); f1, s1 = tpch.q17_avg_of_sum(p.fetch()); p.free()
+        p = tpch.q17_plan(db); p.run(); f2, s2 = tpch.q17_avg_yearly(p.fetch()); p.free()
+        assert s1 == s2 and s1 > 0 and float(f1) == float(f2)
+        # Q20
+        p = tpch.q20_whole_plan(db); p.run(); w = p.fetch_rows(); p.free()
+        g, s = tpch.q20_plans(db); g.run(); s.run(); keys = tpch.q20_keys(g.fetch(), s.fetch()); g.free(); s.free()
+        assert w["nrows"] == len(keys) > 1000
+        assert sorted(w["columns"][0]) == [f"Supplier#{k:09d}" for k in keys]
+    finally:
+        db.free()
