@@ -72,7 +72,8 @@ int ph_ctx::finish_deferred() {
     if (ovf) { ph::set_error("deferred from ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
     if (unsorted) {
         ph::set_error("deferred: a sorted-input claim does not hold (ph_join_build_ex PH_JOIN_KEYS_SORTED_UNIQUE build keys are not "
-                      "strictly ascending, or ph_agg_sink_sorted rows are not ordered by the group key)");
+                      "strictly ascending, or ph_agg_sink_sorted rows are not ordered by the group key — or one group's run is longer than "
+                      "the streaming form walks: take ph_agg_sink)");
         return PH_ECONSTRAINT;
     }
     ph::set_error("deferred from ph_join_lookup_strict: %d probe rows without a match, %d with more than one", miss, multi);

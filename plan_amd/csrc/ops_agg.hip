@@ -1706,10 +1706,23 @@ __global__ __launch_bounds__(256) void sorted_heads_kernel(SortedAgg S, int32_t 
     __shared__ int ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = heads;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+    if (threadIdx.x == 0) {
+        const int h = ws[0] + ws[1] + ws[2] + ws[3];
+        counts[blockIdx.x] = h;
+        // A whole chunk inside one run: not the shape the streaming form is for — a head's thread walks its run with dependent loads, so a
+        // run of a million rows (a table clustered by a low-cardinality key) would be one thread's million loads. When such chunks hold more
+        // than an eighth of the rows the claim is withdrawn like a broken order: deferred PH_ECONSTRAINT, the caller takes the hash aggregate
+        // (a plan reruns conservatively).
+        if (h == 0 && base + SA_CHUNK <= S.n && base > 0) atomicAdd(&S.counters[3], 1);   // (chunks that lie inside one run)
+    }
 }
 
 __global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total) {
+    // more than an eighth of the rows in runs that span whole chunks: withdrawn (a stray long run among short ones is walked)
+    if ((int64_t)__hip_atomic_load(&S.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * SA_CHUNK * 8 > S.n) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.violation, 2);
+        return;
+    }
     const int64_t base = (int64_t)blockIdx.x * SA_CHUNK;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ int wc[SA_CHUNK / 256][4];

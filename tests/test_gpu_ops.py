@@ -2110,3 +2110,28 @@ def test_existence_only_table_marks_like_the_oracle(ctx, kw):
         j.probe_inner([P], None, npr, 1 << 20)
     j.free()
     B.free(); P.free()
+
+
+@pytest.mark.gpu
+def test_streaming_aggregate_withdraws_on_long_runs(ctx):
+    """rows ordered by a LOW-cardinality key: a run spans whole 256-row chunks, the streaming form withdraws with the deferred
+    PH_ECONSTRAINT (it would walk each run in one thread) and the hash aggregate gives the groups"""
+    n = 400_000
+    keys = np.repeat(np.arange(8, dtype=np.int64), n // 8)
+    vals = np.arange(n, dtype=np.int64) % 1000
+    K, V = hip.DevColumn(ctx, hip.PH_I64, keys), hip.DevColumn(ctx, hip.PH_I64, vals)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0)], 16)
+    ctx.set_deferred_errors(True)
+    try:
+        assert agg.sink_sorted([K], [V], n)
+        with pytest.raises(hip.PlanHipError) as e:
+            ctx.check_deferred()
+        assert e.value.code == hip.PH_ECONSTRAINT
+    finally:
+        ctx.set_deferred_errors(False)
+    agg.free()
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0)], 16)
+    agg.sink([K], [V], None, n)
+    r = agg.finalize()
+    assert r["ngroups"] == 8 and [s[0] for s in r["sum"]] == [int(vals[keys == g].sum()) for g in range(8)]
+    agg.free()
