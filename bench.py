@@ -582,6 +582,16 @@ def bench_operator_interface(h, sf, steps, warmup):
         raise RuntimeError(lib.planhost_last_error().decode())
     load_s = time.time() - t0
     out = {}
+
+    def parity(q, text):
+        """The result text of this run against the oracle's text for the same generator data: committed fixtures (tests/golden/sf10/oracle_q*.txt,
+        made by scripts/oracle_sf10_texts.py and re-derived live by tests/test_gpu_sf10_parity.py) at SF10, the reference's own result files
+        (tests/golden/plan_q*.txt = cases/tpch/1g/plan) at SF1. A timing without a checked result says "unchecked"."""
+        path = {10: os.path.join(ROOT, "tests", "golden", "sf10", f"oracle_q{q}.txt"), 1: os.path.join(ROOT, "tests", "golden", f"plan_q{q}.txt")}.get(sf)
+        if not path or not os.path.exists(path):
+            return "unchecked (no fixture at this scale factor)"
+        return "ok: byte-identical to " + os.path.relpath(path, ROOT) if open(path).read() == text else "MISMATCH against " + os.path.relpath(path, ROOT)
+
     try:
         nl = int(lib.planhost_tpch_rows(db, b"lineitem"))
         for q in (3, 9):
@@ -595,6 +605,7 @@ def bench_operator_interface(h, sf, steps, warmup):
             out[f"q{q}_operator_interface"] = {
                 "metric": f"rows/sec through Q{q} behind the OperatorExec interface (C++ host layer, one resident-plan executor)",
                 "value": nl / (avg.value * 1e-3), "unit": "rows/s", "n_gpus": 1, "ms_per_step": avg.value, "min_ms": mn.value, "steps": steps, "warmup": warmup,
+                "parity": parity(q, text.value.decode()),
                 "config": {"workload": f"TPC-H Q{q} at SF{sf}: limitExecutor <- gpuOrderExecutor <- gpuResidentPlanExecutor(ph_plan) built, pulled and closed per step; "
                                        f"{nl} lineitem rows, all eight tables resident (generated + loaded by the host layer in {load_s:.1f} s)",
                            "result_rows": len([r for r in rows[1:] if r]), "first_row": rows[1] if len(rows) > 1 else None,
@@ -610,7 +621,8 @@ def bench_operator_interface(h, sf, steps, warmup):
                                      text, ctypes.c_int64(len(text)), explain, ctypes.c_int64(len(explain))) != 0:
                 others[f"q{q}"] = {"error": lib.planhost_last_error().decode()}
                 continue
-            others[f"q{q}"] = {"ms": round(avg.value, 3), "min_ms": round(mn.value, 3), "result_rows": len([r for r in text.value.decode().split("\n")[1:] if r])}
+            others[f"q{q}"] = {"ms": round(avg.value, 3), "min_ms": round(mn.value, 3), "result_rows": len([r for r in text.value.decode().split("\n")[1:] if r]),
+                               "parity": parity(q, text.value.decode())}
         out["tpch_operator_interface"] = {"workload": f"TPC-H SF{sf}, the 16 other queries with a reference golden, through the C++ OperatorExec layer (3 steps behind 2 warm-up runs each)",
                                           "queries": others}
     finally:

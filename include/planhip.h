@@ -788,13 +788,19 @@ typedef struct ph_plan ph_plan;
  * keeps its per-operator executors). */
 int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_plan **out);
 /* ORDER BY <aggregate agg_index> [DESC] ... LIMIT k sits above the aggregate: only the groups at least as good
- * as the k-th come back (>= k with ties), as ph_agg_topk; the caller applies the full ORDER BY and the LIMIT. */
+ * as the k-th come back (>= k with ties), as ph_agg_topk; the caller applies the full ORDER BY and the LIMIT. PH_EUNSUPPORTED beside
+ * ph_plan_set_having: HAVING runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263) — the k best groups
+ * could fail it while later ones pass — so a plan carries one or the other, and with a HAVING the caller sorts the survivors. */
 int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k);
 /* HAVING conjuncts `result column OP constant` over the root's AGGREGATE columns (ph_pred.col counts the result's columns: group keys first,
  * then the aggregates), applied on the device when the groups are fetched (ph_agg_fetch_where): only the surviving groups come back.
  * PH_EUNSUPPORTED — and the caller filters the fetched rows itself — for a conjunct over a key column or an AVG, for Agg <- Scan plans
  * (a fused scan: few groups) and beside ph_plan_set_topk. */
 int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj);
+/* 1 when the last ph_plan_fetch applied the conjuncts of ph_plan_set_having. The device compares the aggregates as int64 values: when
+ * a sum of the run exceeds that range every group comes back with its exact 128-bit sums instead (0 here; likewise a top-k
+ * preselection is then skipped) and the caller applies its HAVING to the fetched rows, as without ph_plan_set_having. */
+int32_t ph_plan_having_applied(const ph_plan *p);
 /* enqueue one execution of the whole subtree (host round trips only where a row count sizes the next step) */
 int ph_plan_run(ph_plan *p);
 /* the group rows of the last run, in first-seen order (ph_agg_result_free releases them). If the run's

@@ -761,7 +761,9 @@ func tryNewGpuResidentPlanExecutor(op *PhysicalOperator, cfg *util.Config, txn *
 		C.ph_ctx_destroy(e.ctx)
 		return nil, err
 	}
-	if topK != nil && topK.aggIndex >= 0 {
+	// HAVING (op.Filters of the aggregate) runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263):
+	// with one, the top-k preselection is not announced — the k best groups could fail it while later ones pass.
+	if topK != nil && topK.aggIndex >= 0 && len(op.Filters) == 0 {
 		desc := C.int32_t(0)
 		if topK.descending {
 			desc = 1
@@ -831,6 +833,12 @@ func (e *gpuResidentPlanExecutor) Execute(input, output *chunk.Chunk) (OperatorR
 		}
 		if err := phErr(C.ph_plan_fetch(e.plan, &e.result)); err != nil {
 			return InvalidOpResult, err
+		}
+		// a sum beyond int64 makes the device hand every group back unfiltered (ph_plan_having_applied = 0): the HAVING then runs
+		// here through the reference's own ExprExec, like one that never went down
+		if e.havingEx == nil && len(e.op.Filters) > 0 && C.ph_plan_having_applied(e.plan) == 0 {
+			e.havingEx = NewExprExec(e.op.Filters...)
+			e.sel = chunk.NewSelectVector(util.DefaultVectorSize)
 		}
 		if err := e.decodeStringKeys(e.result); err != nil {
 			return InvalidOpResult, err

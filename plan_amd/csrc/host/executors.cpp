@@ -1659,9 +1659,11 @@ std::string gpuResidentPlanExecutor::Init() {
     outTypes_ = root.types;       // [group columns | aggregate results], typed by ResidentPlan::Agg
     argType_ = root.argTypes;
     if (ph_plan_create(ctx_, desc.data(), (int32_t)nn, &plan_) != PH_OK) return herr("ph_plan_create");
-    if (topkAgg_ >= 0 && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
+    // HAVING runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263): with a HAVING the top-k
+    // preselection is not announced — the k best groups could fail it while later ones pass — and the Order above sorts the survivors
+    if (topkAgg_ >= 0 && having_.empty() && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
     for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
-    if (!having_.empty() && topkAgg_ < 0) {   // numeric conjuncts over aggregate columns: filtered on the device, only the survivors are fetched
+    if (!having_.empty()) {   // numeric conjuncts over aggregate columns: filtered on the device, only the survivors are fetched
         std::vector<ph_pred> hp;
         bool numeric = true;
         for (auto &h : having_) { numeric = numeric && h.k.kind != Literal::Str && h.k.kind != Literal::DateDays; hp.push_back(lowerCompare(h)); }
@@ -1721,6 +1723,8 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
             *err = herr("ph_plan_run/fetch");
             return InvalidOpResult;
         }
+        // (a sum beyond int64 makes the device hand every group back unfiltered: the HAVING is then applied below, like any other)
+        const bool havingDone = havingOnDevice_ && ph_plan_having_applied(plan_) != 0;
         const ResidentPlan::Node &root = rp_.nodes.back();
         std::vector<LType> keyTypes(root.types.begin(), root.types.begin() + root.ngroups);
         std::vector<const std::vector<std::string> *> dicts;
@@ -1754,7 +1758,7 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
         std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo, r->sum_hi,
                                        r->count, &results_);
         ph_agg_result_free(r);
-        if (e.empty()) e = ApplyAggOutputPhase(ctx_, havingOnDevice_ ? std::vector<Compare>{} : having_, outputs_, outTypes_, finalTypes_, &results_);
+        if (e.empty()) e = ApplyAggOutputPhase(ctx_, havingDone ? std::vector<Compare>{} : having_, outputs_, outTypes_, finalTypes_, &results_);
         if (!e.empty()) { *err = e; return InvalidOpResult; }
         built_ = true;
     }

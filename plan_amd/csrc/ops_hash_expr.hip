@@ -574,14 +574,20 @@ __device__ __forceinline__ bool substr_range(long long slen, long long offset, l
 __global__ __launch_bounds__(256) void substr_len_kernel(const int32_t *__restrict__ off, const uint8_t *validity,
                                                          const int32_t *__restrict__ sel, int64_t n, long long offset,
                                                          long long length, int32_t *__restrict__ out_len,
-                                                         int32_t *__restrict__ out_start) {
+                                                         int32_t *__restrict__ out_start, unsigned long long *__restrict__ total64) {
+    // total64: the result bytes summed in 64 bits (one add per wave) — the int32 offsets of the result wrap from 2^31 bytes on (row ids
+    // that repeat below a join can ask for more than the column holds), and the host refuses such a result instead of returning it
+    unsigned long long mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = sel ? sel[i] : i;
         long long s = 0, e = 0;
         const bool ok = bit_valid(validity, r) && substr_range(off[r + 1] - off[r], offset, length, &s, &e);
         out_len[i] = ok ? (int32_t)(e - s) : 0;
         out_start[i] = off[r] + (int32_t)s;
+        mine += ok ? (unsigned long long)(e - s) : 0ull;
     }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total64, mine);
 }
 
 __global__ __launch_bounds__(256) void substr_copy_kernel(const uint8_t *__restrict__ bytes, const int32_t *__restrict__ start,
@@ -612,17 +618,27 @@ extern "C" int ph_substring(ph_ctx *ctx, const ph_col *col, int64_t offset, int6
     *out_bytes = 0;
     if (n == 0) return PH_OK;
     int32_t *start = nullptr;
-    int64_t *total = nullptr;
+    int64_t *total = nullptr;   // [0]: the scan's total, [1]: the 64-bit byte count
     PH_CHECK(ctx->pool_alloc(n * 4, (void **)&start));
-    PH_CHECK(ctx->pool_alloc(8, (void **)&total));
+    int rc = ctx->pool_alloc(16, (void **)&total);
+    if (rc != PH_OK) { ctx->pool_release(start); return rc; }
+    if (hipMemsetAsync(total, 0, 16, ctx->stream) != hipSuccess) { ctx->pool_release(start); ctx->pool_release(total); ph::set_error("ph_substring: memset failed"); return PH_EHIP; }
     int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
     ph::substr_len_kernel<<<grid, 256, 0, ctx->stream>>>((const int32_t *)col->data, col->validity, sel, n, (long long)offset,
-                                                         (long long)length, out_offsets_dev, start);
-    int rc = ph::exclusive_scan_i32(ctx, out_offsets_dev, n, total);
-    long long tot = 0;
+                                                         (long long)length, out_offsets_dev, start, (unsigned long long *)(total + 1));
+    rc = ph::exclusive_scan_i32(ctx, out_offsets_dev, n, total);
+    long long tots[2] = {0, 0};
     if (rc == PH_OK) {
         ph::substr_total_kernel<<<1, 1, 0, ctx->stream>>>(total, out_offsets_dev, n);
-        rc = ctx->download(&tot, total, 8);
+        rc = ctx->download(tots, total, 16);
+    }
+    long long tot = tots[1];
+    if (rc == PH_OK && tot >= (1ll << 31)) {
+        ph::set_error("ph_substring: %lld result bytes do not fit the int32 offsets of a PH_STR column", tot);
+        *out_bytes = tot;
+        ctx->pool_release(start);
+        ctx->pool_release(total);
+        return PH_EUNSUPPORTED;
     }
     if (rc == PH_OK && tot > out_bytes_capacity) {
         ph::set_error("ph_substring: %lld result bytes, room for %lld", tot, (long long)out_bytes_capacity);

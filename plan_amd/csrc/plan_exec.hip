@@ -115,6 +115,7 @@ struct ph_plan {
     bool rows_root = false;             // the root is no aggregate: the plan returns the root relation's rows (ph_plan_fetch_rows)
     std::shared_ptr<Rel> rows_rel;      // ... of the last run (its buffers are run temporaries: fetched before they are released)
     std::vector<ph_pred> having;        // conjuncts over the root's aggregate columns, applied where the groups are (ph_plan_set_having)
+    bool having_applied = false;        // ... and whether the last fetch did apply them (a sum beyond int64 hands every group back)
     std::vector<int> parents;           // how many nodes reference node i as a child
     std::map<std::pair<int, bool>, std::shared_ptr<Rel>> memo;   // relations of nodes with several parents, per run
     std::vector<ph_table *> computed;   // one-column relations of computed VARCHAR values: like the aggregate they outlive the fetch (the host
@@ -680,17 +681,26 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
         const Lane &ln = r->lanes[(size_t)pc.lane];
         ph_col v = table_view(ln.t, pc.tcol);
         const int64_t n = r->n;
+        // capacity: a relation whose row ids do not repeat cannot ask for more bytes than the column holds; row ids that repeat (a small
+        // VARCHAR table fanned out below a join) can — up to n * sub_length for a bounded length — so that case starts from the length
+        // bound when it is small and otherwise retries once with the exact size ph_substring reports (as fetch_rows_once does)
+        const bool repeats = ln.rows && !ln.dup_free;
         int64_t cap = v.aux_bytes + 64;
-        if (e.sub_length >= 0 && e.sub_length <= 256) cap = std::min(cap, n * e.sub_length + 64);   // (row ids may repeat below a join: length bounds it)
-        else if (ln.rows && !ln.dup_free) { set_error("ph_plan: unbounded substring over repeated rows"); return PH_EUNSUPPORTED; }
+        if (e.sub_length >= 0 && e.sub_length <= 256) cap = repeats ? n * e.sub_length + 64 : std::min(cap, n * e.sub_length + 64);
+        if (cap >= (1ll << 31)) cap = v.aux_bytes + 64;   // (the exact size decides)
         void *off = nullptr, *bytes = nullptr, *codes = nullptr;
         PL_CHECK(p->ctx->pool_alloc((n + 1) * 4, &off));
         p->computed_bufs.push_back(off);
-        PL_CHECK(p->ctx->pool_alloc(cap, &bytes));
-        p->computed_bufs.push_back(bytes);
         PL_CHECK(palloc(p, std::max<int64_t>(n, 1) * 4, &codes));
         int64_t nbytes = 0;
-        PL_CHECK(ph_substring(p->ctx, &v, e.sub_offset, e.sub_length, ln.rows, n, (int32_t *)off, (uint8_t *)bytes, cap, &nbytes));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            PL_CHECK(p->ctx->pool_alloc(cap, &bytes));
+            p->computed_bufs.push_back(bytes);
+            int rc = ph_substring(p->ctx, &v, e.sub_offset, e.sub_length, ln.rows, n, (int32_t *)off, (uint8_t *)bytes, cap, &nbytes);
+            if (rc == PH_ECAPACITY && attempt == 0 && nbytes > cap) { cap = nbytes + 64; continue; }
+            PL_CHECK(rc);
+            break;
+        }
         ph_table *vt = new ph_table();
         vt->ctx = p->ctx;
         vt->nrows = n;
@@ -788,7 +798,7 @@ int key_unique(const Rel &r, const std::vector<int32_t> &keys) {
 
 int lower(ph_plan *p, int idx, bool as_build, Rel *out);
 int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, std::vector<KeyInfo> *kinfo, std::vector<int32_t> *ascale,
-                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs);
+                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs, std::vector<bool> *nullable = nullptr);
 
 struct KeySide {            // the key columns of one join side as the kernels want them
     std::vector<ph_col> views;
@@ -1373,7 +1383,8 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
         std::vector<KeyInfo> kinfo;
         std::vector<int32_t> ascale, atype;
         std::vector<KeyPack> packs;
-        int rc = sink_into_agg(p, idx, R, false, &agg, &kinfo, &ascale, &atype, &packs);
+        std::vector<bool> nullable;
+        int rc = sink_into_agg(p, idx, R, false, &agg, &kinfo, &ascale, &atype, &packs, &nullable);
         if (agg) p->inner_aggs.push_back(agg);
         PL_CHECK(rc);
         int64_t ng = 0;
@@ -1385,11 +1396,13 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
             PCol c;
             c.type = kinfo[k].type; c.scale = kinfo[k].scale; c.src = kinfo[k].table; c.src_col = kinfo[k].col;
             if (c.type == PH_STR) { set_error("ph_plan: VARCHAR keys of an aggregate below other operators"); return PH_EUNSUPPORTED; }
-            void *d = nullptr;
+            void *d = nullptr, *val = nullptr;
             PL_CHECK(palloc(p, std::max<int64_t>(ng, 1) * 8, &d));
+            if (nullable[k]) PL_CHECK(palloc(p, (ng + 7) / 8 + 64, &val));   // the NULL key's group keeps its NULL (operators that cannot take NULLs refuse it)
             int64_t n2 = 0;
-            PL_CHECK(ph_agg_keys_dev(agg, (int32_t)k, d, nullptr, ng, &n2));
+            PL_CHECK(ph_agg_keys_dev(agg, (int32_t)k, d, (uint8_t *)val, ng, &n2));
             c.data = d;
+            c.validity = (const uint8_t *)val;
             out->cols.push_back(c);
         }
         for (size_t a = 0; a < nd.aggs.size(); a++) {
@@ -1399,11 +1412,14 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
             const bool minmax = nd.aggs[a].kind == PH_A_MIN || nd.aggs[a].kind == PH_A_MAX;
             c.type = minmax && (atype[a] == PH_I32 || atype[a] == PH_DATE) ? PH_I64 : PH_DEC64;
             c.scale = nd.aggs[a].kind == PH_A_COUNT || nd.aggs[a].kind == PH_A_COUNT_STAR ? 0 : ascale[a];
-            void *d = nullptr;
+            void *d = nullptr, *val = nullptr;
             PL_CHECK(palloc(p, std::max<int64_t>(ng, 1) * 8, &d));
+            // a group whose inputs were all NULL is NULL, not 0 / INT64_MAX: the value column carries the bitmap wherever that can happen
+            if (nullable[nd.groups.size() + a]) PL_CHECK(palloc(p, (ng + 7) / 8 + 64, &val));
             int64_t n2 = 0;
-            PL_CHECK(ph_agg_values_dev(agg, (int32_t)a, (int64_t *)d, nullptr, ng, &n2));
+            PL_CHECK(ph_agg_values_dev(agg, (int32_t)a, (int64_t *)d, (uint8_t *)val, ng, &n2));
             c.data = d;
+            c.validity = (const uint8_t *)val;
             out->cols.push_back(c);
         }
         note(p, "agg#%d: %lld groups stay on the device as a relation (%zu keys, %zu aggregates)", idx, (long long)ng, nd.groups.size(), nd.aggs.size());
@@ -1417,8 +1433,11 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
 
 // ---- one relation into one aggregate table (aggExecutor's build phase: executeExprs for the group keys and the aggregate
 // arguments, then Sink; executor_aggr.go:110-142). Used by the root and by aggregates below other operators.
+// nullable (optional): per group key, then per aggregate — can the RESULT column hold a NULL? A key can when its column carries a validity
+// bitmap; an aggregate only when its argument does (SUM / MIN / MAX / COUNT of a group whose inputs were all NULL finalise to NULL,
+// function_aggr.go:813-823, 950-962; a group exists because a row reached it, so without NULL inputs every state is set).
 int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, std::vector<KeyInfo> *kinfo, std::vector<int32_t> *ascale,
-                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs) {
+                  std::vector<int32_t> *atype, std::vector<KeyPack> *packs, std::vector<bool> *nullable) {
     const Node &nd = p->nodes[(size_t)idx];
     ph_ctx *ctx = p->ctx;
     PL_CHECK(apply_pending(p, &R));
@@ -1522,6 +1541,11 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
         keys.push_back(c);
         key_types.push_back(PH_I32);
     }
+    if (nullable) {
+        nullable->clear();
+        for (size_t g = 0; g < nd.groups.size(); g++) nullable->push_back(S.cols[g].validity != nullptr);
+        for (size_t a = 0; a < nd.aggs.size(); a++) nullable->push_back(nd.aggs[a].kind != PH_A_COUNT_STAR && args[a].validity != nullptr);
+    }
     for (size_t a = 0; a < nd.aggs.size(); a++) if (nd.aggs[a].kind == PH_A_COUNT_STAR) args[a] = keys[0];
     // expected groups: a key that is (a copy of) a wide integer table column is taken to be high-cardinality
     int64_t expected = 1024;
@@ -1562,6 +1586,16 @@ int lower_agg(ph_plan *p) {
         bool ok = true;
         std::vector<int32_t> gcols;
         ok = ok && R.complex.empty();
+        // (the descriptor's column indexes are checked HERE: this lowering reads R.cols before eval_expr, which checks them, ever runs)
+        auto in_range = [&](int32_t c) { return c >= 0 && (size_t)c < R.cols.size(); };
+        for (auto &g : nd.groups) if (g.e.kind == PH_PE_COL && !in_range(g.e.col)) { set_error("ph_plan: group column %d out of range", g.e.col); return PH_EINVAL; }
+        for (auto &a : nd.aggs) {
+            if (a.kind == PH_A_COUNT_STAR) continue;
+            if (a.arg.e.kind == PH_PE_COL && !in_range(a.arg.e.col)) { set_error("ph_plan: aggregate column %d out of range", a.arg.e.col); return PH_EINVAL; }
+            if (a.arg.e.kind == PH_PE_DECIMAL)
+                for (int i = 0; i < a.arg.e.nprog; i++)
+                    if (a.arg.e.prog[i].op == PH_X_COL && !in_range(a.arg.e.prog[i].col)) { set_error("ph_plan: expression column %d out of range", a.arg.e.prog[i].col); return PH_EINVAL; }
+        }
         for (auto &g : nd.groups) { ok = ok && g.e.kind == PH_PE_COL; if (ok) gcols.push_back(R.cols[(size_t)g.e.col].tcol); }
         std::vector<ph_aggexpr> ax(nd.aggs.size());
         for (size_t a = 0; a < nd.aggs.size() && ok; a++) {
@@ -1702,13 +1736,15 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
     int nw = 1;   // key words of the aggregate table (packed keys share one)
     for (auto &kp : p->key_packs) nw = std::max(nw, kp.word + 1);
     int64_t room = p->topk_agg >= 0 ? 4096 : 1024, ng = 0;
+    bool skip_device_forms = false;
     for (int attempt = 0; attempt < 3; attempt++) {
         std::vector<int64_t> first((size_t)room), keys((size_t)room * nw), hi((size_t)room * std::max(naggs, 1));
         std::vector<uint8_t> knull((size_t)room * nw);
         std::vector<uint64_t> lo((size_t)room * std::max(naggs, 1)), cnt((size_t)room * std::max(naggs, 1));
         int rc;
-        if (p->topk_agg >= 0) rc = ph_agg_topk(p->agg, p->topk_agg, p->topk_desc, p->topk_k, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
-        else if (!p->having.empty()) {
+        p->having_applied = false;
+        if (p->topk_agg >= 0 && !skip_device_forms) rc = ph_agg_topk(p->agg, p->topk_agg, p->topk_desc, p->topk_k, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
+        else if (!p->having.empty() && !skip_device_forms) {
             std::vector<int32_t> ai, op, sc;
             std::vector<ph_const> ks;
             for (auto &h : p->having) {
@@ -1719,7 +1755,11 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
             }
             rc = ph_agg_fetch_where(p->agg, (int32_t)ai.size(), ai.data(), op.data(), ks.data(), sc.data(), room, &ng, first.data(), keys.data(), knull.data(),
                                     lo.data(), hi.data(), cnt.data());
+            p->having_applied = rc == PH_OK;
         } else rc = ph_agg_fetch(p->agg, room, &ng, first.data(), keys.data(), knull.data(), lo.data(), hi.data(), cnt.data());
+        // the preselection and the device HAVING compare the sums as int64 values: a sum beyond that range is no error of the query —
+        // every group comes back with its 128-bit sums and the host filters / sorts (ph_plan_having_applied tells it so)
+        if (rc == PH_EOVERFLOW && !skip_device_forms) { skip_device_forms = true; note(p, "  fetch: a sum exceeds int64 — HAVING / top-k left to the host"); attempt--; continue; }
         if (rc == PH_ECAPACITY && ng > room) { room = ng; continue; }
         PL_CHECK(rc);
         ph_agg_result *r = new_result(ng, nkeys, naggs);
@@ -1807,18 +1847,23 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
         if (s.kind == PH_PN_SCAN || s.kind == PH_PN_FILTER) {
             if (s.nbools < 0 || (s.nbools && !s.bools)) { set_error("ph_plan_create: node %d: bad boolean tree", i); return fail(PH_EINVAL); }
             n.bools = copy_bools(s.bools, s.nbools);
-            for (auto &b : n.bools.nodes)
-                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= 0 || b.nchildren < 1 || b.first_child + b.nchildren > s.nbools)) {
-                    set_error("ph_plan_create: node %d: boolean tree children out of range", i);
+            // children FOLLOW their parent in the flat array: a node that named itself or an earlier node would make eval_bool recurse forever
+            for (size_t bi = 0; bi < n.bools.nodes.size(); bi++) {
+                const ph_bool &b = n.bools.nodes[bi];
+                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= (int32_t)bi || b.nchildren < 1 || b.first_child + b.nchildren > s.nbools)) {
+                    set_error("ph_plan_create: node %d: boolean tree children out of range (they must follow their parent)", i);
                     return fail(PH_EINVAL);
                 }
+            }
         }
         auto check_expr = [&](Expr &x) {
             x.when.fix();
             x.e.when = nullptr;
             if (x.e.nprog < 0 || x.e.nprog > 12 || (x.e.kind == PH_PE_CASE && (x.e.nelse < 1 || x.e.nelse > 12 || x.when.empty()))) return false;
-            for (auto &b : x.when.nodes)
-                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= 0 || b.nchildren < 1 || b.first_child + b.nchildren > (int)x.when.nodes.size())) return false;
+            for (size_t bi = 0; bi < x.when.nodes.size(); bi++) {
+                const ph_bool &b = x.when.nodes[bi];
+                if ((b.kind == PH_B_AND || b.kind == PH_B_OR) && (b.first_child <= (int32_t)bi || b.nchildren < 1 || b.first_child + b.nchildren > (int)x.when.nodes.size())) return false;
+            }
             return true;
         };
         bool okx = true;
@@ -1837,6 +1882,9 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
 
 extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k) {
     PH_REQUIRE(p && !p->rows_root && k > 0 && agg_index >= 0 && agg_index < (int32_t)p->nodes.back().aggs.size(), "ph_plan_set_topk: bad arguments");
+    // HAVING runs inside the aggregate's output phase, BEFORE Order and Limit (executor_aggr.go:143-263): a preselection of the best k
+    // groups taken first would drop groups the HAVING keeps out of reach. The two are exclusive in both directions.
+    if (!p->having.empty()) { set_error("ph_plan_set_topk: the plan has a HAVING (the host sorts the surviving groups)"); return PH_EUNSUPPORTED; }
     p->topk_agg = agg_index;
     p->topk_desc = descending ? 1 : 0;
     p->topk_k = k;
@@ -1859,6 +1907,8 @@ extern "C" int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj
     p->having.assign(conj, conj + nconj);
     return PH_OK;
 }
+
+extern "C" int32_t ph_plan_having_applied(const ph_plan *p) { return p && p->having_applied ? 1 : 0; }
 
 extern "C" int ph_plan_run(ph_plan *p) {
     PH_REQUIRE(p != nullptr, "ph_plan_run: plan is NULL");

@@ -139,3 +139,44 @@ def test_plan_descriptor_validation_without_a_device():
     assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
     assert b"precede" in lib.ph_last_error()
     assert lib.ph_plan_create(None, n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
+
+
+def test_plan_descriptor_rejects_boolean_trees_that_point_backwards():
+    """an AND / OR node's children must FOLLOW it in the flat array — a node naming itself (or an earlier node) as its child
+    would send eval_bool into unbounded recursion. Checked by ph_plan_create on the host, for a scan's / filter's tree and for a CASE's WHEN."""
+    lib = hip.lib()
+    out = hip.vp()
+    cols = (hip.i32 * 1)(0)
+    # Filter(Scan) with the tree [OR(first_child=1, n=2), AND(first_child=1, n=1)  <- names itself, CMP]
+    b = (hip.Bool * 3)()
+    b[0].kind, b[0].first_child, b[0].nchildren = hip.PH_B_OR, 1, 2
+    b[1].kind, b[1].first_child, b[1].nchildren = hip.PH_B_AND, 1, 1
+    b[2].kind, b[2].col, b[2].op, b[2].k = hip.PH_B_CMP, 0, hip.PH_EQ, hip.const(hip.PH_I32, i=1)
+    n = (hip.PlanNode * 2)()
+    n[0].kind, n[0].child[0], n[0].child[1] = hip.PH_PN_SCAN, -1, -1
+    n[0].table, n[0].ncols, n[0].cols = hip.vp(1), 1, cols
+    n[1].kind, n[1].child[0], n[1].child[1] = hip.PH_PN_FILTER, 0, -1
+    n[1].nbools, n[1].bools = 3, b
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
+    assert b"follow their parent" in lib.ph_last_error()
+    b[1].first_child = 2                     # now a proper tree: OR(AND(CMP), CMP)
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_OK
+    lib.ph_plan_free(out)
+    # the same inside a CASE's WHEN (an aggregate argument)
+    w = (hip.Bool * 2)()
+    w[0].kind, w[0].first_child, w[0].nchildren = hip.PH_B_AND, 0, 1      # names itself
+    w[1].kind, w[1].col, w[1].op, w[1].k = hip.PH_B_CMP, 0, hip.PH_EQ, hip.const(hip.PH_I32, i=1)
+    e = hip.PlanExpr()
+    e.kind, e.nprog, e.nelse, e.nwhen, e.when = hip.PH_PE_CASE, 1, 1, 2, w
+    e.prog[0] = hip.X_CONST(1)
+    e.else_prog[0] = hip.X_CONST(0)
+    aggs = (hip.PlanAgg * 1)()
+    aggs[0].kind, aggs[0].arg = hip.PH_A_SUM, e
+    n[1] = hip.PlanNode()
+    n[1].kind, n[1].child[0], n[1].child[1] = hip.PH_PN_AGG, 0, -1
+    n[1].naggs, n[1].aggs = 1, aggs
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_EINVAL
+    assert b"malformed expression" in lib.ph_last_error()
+    w[0].first_child = 1
+    assert lib.ph_plan_create(hip.vp(1), n, hip.i32(2), ctypes.byref(out)) == hip.PH_OK
+    lib.ph_plan_free(out)

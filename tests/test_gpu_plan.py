@@ -64,6 +64,34 @@ def test_q3_plan_matches_golden_and_oracle(ctx, db, sf1):
     assert r["ngroups"] == n == 11378 and got == want
 
 
+def test_having_and_topk_are_exclusive_so_no_group_is_lost(ctx, db, sf1):
+    """GROUP BY .. HAVING agg > c ORDER BY agg LIMIT k ('>' is the one comparison selectOperation has for DECIMAL): HAVING runs in the aggregate's output phase, before Order and Limit
+    (executor_aggr.go:143-263). A top-k preselection taken first would hand back the best k groups, the HAVING would reject some of
+    them and the groups that should have moved up would be gone. The library refuses the combination in both directions
+    (PH_EUNSUPPORTED); with the HAVING on the device and the sort above it, Q3's ten smallest revenues ABOVE a floor equal the oracle's."""
+    n, rows = O.q3(sf1, "HOUSEHOLD", tpchgen.days(1995, 3, 29))
+    rev = sorted(rows[i].revenue.unscaled(4) for i in range(n))
+    cap = rev[4]                                     # removes the five best groups of the unrestricted (ascending) top 10
+    having = [hip.pred(3, hip.PH_GT, hip.const(hip.PH_DEC64, i=cap, scale=4))]
+    p = tpch.q3_plan(db, topk=0)
+    p.set_having(having)
+    with pytest.raises(hip.PlanHipError) as e:
+        p.set_topk(0, 10, descending=False)
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    p.run()
+    r = p.fetch()
+    p.free()
+    want = sorted(((rows[i].revenue.unscaled(4), rows[i].o_orderdate, rows[i].l_orderkey) for i in range(n) if rows[i].revenue.unscaled(4) > cap))
+    got = sorted((r["sum"][g][0], int(r["keys"][g][1]), int(r["keys"][g][0])) for g in range(r["ngroups"]))
+    assert r["ngroups"] == len(want) and len(want) <= n - 5 and got[:10] == want[:10] and got == want
+    # the other direction: a plan that announced its top-k refuses a HAVING
+    p = tpch.q3_plan(db, topk=10)
+    with pytest.raises(hip.PlanHipError) as e:
+        p.set_having(having)
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    p.free()
+
+
 @pytest.mark.parametrize("segment,ymd", [("AUTOMOBILE", (1994, 1, 1)), ("HOUSEHOLD", (1998, 12, 1)), ("NOSUCHSEGMENT", (1995, 3, 15))])
 def test_q3_plan_other_parameters(ctx, db, sf1, segment, ymd):
     date = tpchgen.days(*ymd)
