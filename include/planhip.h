@@ -187,6 +187,17 @@ int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols);
 int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols);
 /* 1 when a co-located copy covers the given columns */
 int32_t ph_table_colocated(const ph_table *t, int32_t ncols, const int32_t *cols);
+/* What the library may spend ON ITS OWN on co-located copies of this table (the automatic build above): `bytes` of HBM in all, default
+ * 4 GiB; 0 = never (the host's veto; copies asked for by name with ph_table_colocate are the host's decision and not limited). A build
+ * that would exceed the budget is skipped and the gather reads the column arrays. ph_table_colocate_bytes: what the copies hold now. */
+int ph_table_set_colocate_budget(ph_table *t, int64_t bytes);
+int64_t ph_table_colocate_bytes(const ph_table *t);
+/* Sharing (SURVEY.md §8(b) "threading"; the psql server path, cmd/main/main.go:71-122: every connection plans and runs its own query
+ * over the same storage). A resident table may be read by plans and operator calls on ANY ctx of its device, from several threads at
+ * once: columns, statistics and declared keys are immutable once loading is done (ph_table_create* / ph_table_declare_unique /
+ * ph_table_colocate belong to the load phase, one thread); the only state a query may add — an automatic co-located copy — is guarded
+ * by a mutex inside the table, built on the calling ctx's stream and ordered against every other consumer's stream by an event. The
+ * ctx rule stands: ONE thread at a time per ctx; concurrent queries take a ctx each. ph_table_free: when no plan reads the table. */
 void ph_table_free(ph_table *t);
 
 /* plain device buffers for callers without their own allocator */

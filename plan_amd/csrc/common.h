@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,8 +123,6 @@ struct ph_ctx {
     // every kernel and copy of a ctx runs on its one stream.
     std::multimap<int64_t, void *> pool_free_blocks;
     std::map<void *, int64_t> pool_sizes;
-    // device column base pointer -> (resident table, column): lets ph_gather_multi recognise a table's columns in the views it is given
-    std::map<const void *, std::pair<ph_table *, int>> table_cols;
     int pool_alloc(int64_t bytes, void **out);
     void pool_release(void *p);
     void pool_destroy();
@@ -147,16 +147,40 @@ struct ph_table {
     std::vector<column> cols;
     // column sets the catalog declares unique (PRIMARY KEY): ph_table_declare_unique
     std::vector<std::vector<int32_t>> unique_keys;
+    // Resident tables are SHARED: created on one ctx, read by plans on any other ctx of the device, from other threads (the Go shim keeps
+    // the tables on a process-wide context and gives every executor its own; SURVEY.md §8(b) "threading": only the table cache is shared,
+    // mutex-guarded). Columns, statistics and declared keys are immutable after ph_table_create / ph_table_declare_unique (load time);
+    // what a QUERY may change — the co-located copies and the count of sparse gathers that triggers one — sits behind `mu`.
+    std::mutex mu;
     // co-located copies of column sets (ph_table_colocate): row r of the group = the set's values of row r side by side, so a
     // sparse gather of several columns reads ONE sector per row id instead of one per column
     struct colgroup {
         std::vector<int> cols, off, width;   // table column, byte offset in the group's row, width
         int stride = 0;                      // bytes per row (a power of two up to 64, else a multiple of 16)
         void *data = nullptr;
+        int64_t bytes = 0;
+        // ordering against consumers: the copy is filled by a kernel on `built_on`; `ready` (hipEvent_t) is recorded behind it. A
+        // consumer on another stream waits for the event on ITS stream (stream-side) until some consumer has seen it complete.
+        void *ready = nullptr;
+        hipStream_t built_on = nullptr;
+        bool complete = false;
     };
-    std::vector<colgroup> groups;
+    std::deque<colgroup> groups;                      // (a deque: elements stay where they are when one is added)
     std::map<std::vector<int>, int> sparse_gathers;   // column set -> sparse multi-column gathers seen (the second one builds the group)
+    int64_t colocate_budget = 4ll << 30;              // bytes the library may spend on copies it builds ON ITS OWN (ph_table_set_colocate_budget)
+    int64_t colocate_bytes = 0;                       // bytes held by all copies
 };
+
+namespace ph {
+// process-wide registry: device column base pointer -> (resident table, column). Lets ph_gather_multi recognise a table's columns in the
+// views it is given whatever ctx it is called on (the registry of the CALLING ctx, the first form, never saw tables of another ctx).
+void register_table(ph_table *t);
+void unregister_table(ph_table *t);
+bool lookup_table_col(const void *data, ph_table **t, int *col);
+// the co-located group covering `tc` (table columns) for a consumer on `ctx`: found, or built on ctx's stream when `may_build`; ordered
+// against ctx's stream before it returns. Returns a COPY of the group's layout (the table may grow another group meanwhile).
+int colocated_group_for(ph_ctx *ctx, ph_table *t, const std::vector<int> &tc, bool may_build, bool explicit_request, ph_table::colgroup *out);
+}  // namespace ph
 
 // rows a column allocation is padded to, so vector loads never leave the allocation
 constexpr int64_t PH_ROW_PAD = 8192;

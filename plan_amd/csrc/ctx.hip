@@ -558,10 +558,35 @@ extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_co
         ph_table_free(t);
         return rc;
     }
-    for (size_t c = 0; c < t->cols.size(); c++) if (t->cols[c].data) ctx->table_cols[t->cols[c].data] = {t, (int)c};
+    ph::register_table(t);
     *out = t;
     return PH_OK;
 }
+
+// ---- the process-wide table registry (column base pointer -> table, column)
+namespace ph {
+static std::mutex g_tables_mu;
+static std::map<const void *, std::pair<ph_table *, int>> g_table_cols;
+void register_table(ph_table *t) {
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    for (size_t c = 0; c < t->cols.size(); c++) if (t->cols[c].data) g_table_cols[t->cols[c].data] = {t, (int)c};
+}
+void unregister_table(ph_table *t) {
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    for (auto &c : t->cols) {
+        auto it = g_table_cols.find(c.data);
+        if (c.data && it != g_table_cols.end() && it->second.first == t) g_table_cols.erase(it);
+    }
+}
+bool lookup_table_col(const void *data, ph_table **t, int *col) {
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    auto it = g_table_cols.find(data);
+    if (it == g_table_cols.end()) return false;
+    *t = it->second.first;
+    *col = it->second.second;
+    return true;
+}
+}  // namespace ph
 
 extern "C" int64_t ph_table_rows(const ph_table *t) { return t ? t->nrows : -1; }
 extern "C" int32_t ph_table_ncols(const ph_table *t) { return t ? (int32_t)t->cols.size() : -1; }
@@ -612,13 +637,8 @@ __global__ __launch_bounds__(256) void colocate_kernel(ColocateParams P, int64_t
     }
 }
 
-extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols) {
-    PH_REQUIRE(t && t->ctx && cols && ncols >= 2 && ncols <= 8, "ph_table_colocate: 2..8 columns");
-    ph_ctx *ctx = t->ctx;
-    std::vector<int> set(cols, cols + ncols);
-    std::sort(set.begin(), set.end());
-    PH_REQUIRE(std::adjacent_find(set.begin(), set.end()) == set.end(), "ph_table_colocate: a column is named twice");
-    for (auto &g : t->groups) if (g.cols == set) return PH_OK;   // already there
+// build the co-located copy of column set `set` (sorted, distinct) on `ctx`'s stream; t->mu is held by the caller
+static int colocate_locked(ph_ctx *ctx, ph_table *t, const std::vector<int> &set, bool explicit_request) {
     ph_table::colgroup g;
     g.cols = set;
     int total = 0;
@@ -639,30 +659,109 @@ extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols
     while (stride < total && stride < 64) stride *= 2;
     if (stride < total) stride = (int)ph::round_up(total, 16);
     g.stride = stride;
-    PH_HIP(hipSetDevice(ctx->device));
     const int64_t padded = ph::round_up(t->nrows > 0 ? t->nrows : 1, PH_ROW_PAD);
-    PH_HIP(hipMalloc(&g.data, (size_t)padded * stride));
-    PH_HIP(hipMemsetAsync(g.data, 0, (size_t)padded * stride, ctx->stream));
+    g.bytes = padded * stride;
+    // a copy the library builds on its own (the second sparse gather of a column set) stays inside the table's budget; one the host asked
+    // for by name is the host's decision
+    if (!explicit_request && t->colocate_bytes + g.bytes > t->colocate_budget) {
+        ph::set_error("ph_table_colocate: %lld bytes beyond the table's co-location budget (%lld of %lld used)", (long long)g.bytes,
+                      (long long)t->colocate_bytes, (long long)t->colocate_budget);
+        return PH_ECAPACITY;
+    }
+    PH_HIP(hipSetDevice(ctx->device));
+    PH_HIP(hipMalloc(&g.data, (size_t)g.bytes));
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(g.data); ph::set_error("ph_table_colocate: hipEventCreate failed"); return PH_EHIP; }
+    auto fail = [&]() { (void)hipEventDestroy(ev); (void)hipFree(g.data); ph::set_error("ph_table_colocate: launch failed"); return PH_EHIP; };
+    if (hipMemsetAsync(g.data, 0, (size_t)g.bytes, ctx->stream) != hipSuccess) return fail();
     if (t->nrows > 0) {
         ColocateParams P{};
         P.ncols = (int)set.size();
         P.stride = stride;
         for (size_t i = 0; i < set.size(); i++) { P.src[i] = t->cols[(size_t)set[i]].data; P.off[i] = g.off[i]; P.width[i] = g.width[i]; }
         colocate_kernel<<<(int)std::min<int64_t>((t->nrows + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(P, t->nrows, (unsigned char *)g.data);
-        PH_HIP(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) return fail();
     }
+    if (hipEventRecord(ev, ctx->stream) != hipSuccess) return fail();
+    g.ready = ev;
+    g.built_on = ctx->stream;
+    t->colocate_bytes += g.bytes;
     t->groups.push_back(g);
     return PH_OK;
 }
 
+// Found (or built) and ORDERED: when this returns PH_OK every read of out->data queued on ctx's stream afterwards sees the finished copy —
+// the builder's stream by stream order, any other stream through the group's event (a stream-side wait; once a consumer has seen the event
+// complete nobody waits again). PH_EUNSUPPORTED: no such group and none built.
+int ph::colocated_group_for(ph_ctx *ctx, ph_table *t, const std::vector<int> &tc, bool may_build, bool explicit_request, ph_table::colgroup *out) {
+    std::lock_guard<std::mutex> lock(t->mu);
+    auto find = [&]() -> ph_table::colgroup * {
+        for (auto &g : t->groups) {
+            bool all = true;
+            for (int c : tc) all = all && std::find(g.cols.begin(), g.cols.end(), c) != g.cols.end();
+            if (all) return &g;
+        }
+        return nullptr;
+    };
+    ph_table::colgroup *g = find();
+    if (!g) {
+        if (!may_build) return PH_EUNSUPPORTED;
+        std::vector<int> set = tc;
+        std::sort(set.begin(), set.end());
+        if (std::adjacent_find(set.begin(), set.end()) != set.end()) return PH_EUNSUPPORTED;
+        for (int c : set) if (c < 0 || c >= (int)t->cols.size() || t->cols[(size_t)c].validity) return PH_EUNSUPPORTED;
+        if (!explicit_request) {
+            int &seen = t->sparse_gathers[set];
+            if (seen < 0 || ++seen < 2) return PH_EUNSUPPORTED;
+            if (colocate_locked(ctx, t, set, false) != PH_OK) { seen = -1; return PH_EUNSUPPORTED; }   // (no room / no memory for the copy: not tried again)
+        } else PH_CHECK(colocate_locked(ctx, t, set, true));
+        g = find();
+        if (!g) return PH_EUNSUPPORTED;
+    }
+    if (!g->complete && g->built_on != ctx->stream) {
+        const hipError_t q = hipEventQuery((hipEvent_t)g->ready);
+        if (q == hipSuccess) g->complete = true;
+        else if (q == hipErrorNotReady) PH_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)g->ready, 0));
+        else { ph::set_error("co-located group: %s", hipGetErrorString(q)); return PH_EHIP; }
+    }
+    *out = *g;
+    return PH_OK;
+}
+
+extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols) {
+    PH_REQUIRE(t && t->ctx && cols && ncols >= 2 && ncols <= 8, "ph_table_colocate: 2..8 columns");
+    std::vector<int> set(cols, cols + ncols);
+    std::sort(set.begin(), set.end());
+    PH_REQUIRE(std::adjacent_find(set.begin(), set.end()) == set.end(), "ph_table_colocate: a column is named twice");
+    for (int c : set) PH_REQUIRE(c >= 0 && c < (int)t->cols.size(), "ph_table_colocate: bad column %d", c);
+    for (int c : set)
+        if (ph::type_width(t->cols[(size_t)c].type) == 0 || t->cols[(size_t)c].validity) { ph::set_error("ph_table_colocate: column %d is not a fixed-width column without NULLs", c); return PH_EUNSUPPORTED; }
+    ph_table::colgroup g;
+    return ph::colocated_group_for(t->ctx, t, set, true, true, &g);   // on the table's own ctx (load time)
+}
+
 extern "C" int32_t ph_table_colocated(const ph_table *t, int32_t ncols, const int32_t *cols) {
     if (!t || !cols || ncols < 1) return 0;
+    std::lock_guard<std::mutex> lock(const_cast<ph_table *>(t)->mu);
     for (auto &g : t->groups) {
         bool all = true;
         for (int i = 0; i < ncols && all; i++) all = std::find(g.cols.begin(), g.cols.end(), (int)cols[i]) != g.cols.end();
         if (all) return 1;
     }
     return 0;
+}
+
+extern "C" int ph_table_set_colocate_budget(ph_table *t, int64_t bytes) {
+    PH_REQUIRE(t && bytes >= 0, "ph_table_set_colocate_budget: bad arguments");
+    std::lock_guard<std::mutex> lock(t->mu);
+    t->colocate_budget = bytes;
+    return PH_OK;
+}
+
+extern "C" int64_t ph_table_colocate_bytes(const ph_table *t) {
+    if (!t) return -1;
+    std::lock_guard<std::mutex> lock(const_cast<ph_table *>(t)->mu);
+    return t->colocate_bytes;
 }
 
 extern "C" int ph_table_declare_unique(ph_table *t, int32_t ncols, const int32_t *cols) {
@@ -680,9 +779,9 @@ extern "C" void ph_table_free(ph_table *t) {
         (void)hipSetDevice(t->ctx->device);
         (void)hipStreamSynchronize(t->ctx->stream);
     }
-    for (auto &g : t->groups) if (g.data) (void)hipFree(g.data);
+    ph::unregister_table(t);
+    for (auto &g : t->groups) { if (g.ready) (void)hipEventDestroy((hipEvent_t)g.ready); if (g.data) (void)hipFree(g.data); }
     for (auto &c : t->cols) {
-        if (c.data && t->ctx) t->ctx->table_cols.erase(c.data);
         if (c.data) (void)hipFree(c.data);
         if (c.validity) (void)hipFree(c.validity);
         if (c.aux) (void)hipFree(c.aux);

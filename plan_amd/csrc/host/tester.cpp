@@ -8,6 +8,7 @@
 //   host_tester q1|q6|q3|q9 <sf_num> <sf_den> [stub|resident]
 //   host_tester q3|q9 <sf_num> <sf_den> resident [repeat]     the whole subtree as ONE gpuResidentPlanExecutor (ph_plan)
 //   host_tester tpch <query_id> <sf_num> <sf_den> [repeat]    any query tpch_plans.cpp has a resident plan for
+//   host_tester concurrent <sf_num> <sf_den> [iterations]     the tables on ONE context, Q3 and Q9 from two threads on two others at once
 // The resident-plan forms print "Query N took <dur> success" per repeat on stderr, like Run (executor_bench.go:126-137).
 // q1 / q3 / q9 run the whole plan tail on the library: gpuOrderExecutor (ORDER BY) and limitExecutor
 // (LIMIT), so their output is the reference's result file byte for byte with no sorting here.
@@ -18,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <thread>
 
 #include "operator_exec.h"
 #include "tpch_plans.h"
@@ -236,6 +238,50 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "formats")) return formats();
     if (argc < 4) die("usage: host_tester roundtrip | q1|q6|q3 <sf_num> <sf_den> [stub]");
     std::string q = argv[1];
+    if (q == "concurrent") {
+        // Concurrent queries over SHARED resident tables (SURVEY.md §8(b) threading; the psql server path, cmd/main/main.go:71-122): the
+        // database is loaded on context A; two threads own a context each and run whole queries — executors built, pulled, closed — over
+        // A's tables at the same time: Q3 on B, Q9 on C (whose late materialisation makes the library build a co-located copy of lineitem
+        // columns while Q3 reads the same table). Prints Q3's text, "--", Q9's text; every iteration of a thread must give the same lines.
+        int64_t num = atoll(argv[2]), den = atoll(argv[3]);
+        if (num <= 0 || den <= 0) { fprintf(stderr, "scale factor: <num> <den> must both be positive integers\n"); return 2; }
+        const int iters = argc > 4 ? std::max(atoi(argv[4]), 1) : 4;
+        ph_ctx *a = nullptr, *bc[2] = {nullptr, nullptr};
+        if (ph_ctx_create(0, &a) != PH_OK || ph_ctx_create(0, &bc[0]) != PH_OK || ph_ctx_create(0, &bc[1]) != PH_OK) die(std::string("ph_ctx_create: ") + ph_last_error());
+        int rc = 0;
+        {
+            TpchDatabase db;
+            std::string e = db.Load(a, num, den);
+            if (!e.empty()) die(e);
+            const int ids[2] = {3, 9};
+            TpchQuery tq[2];
+            for (int k = 0; k < 2; k++) { e = BuildTpchQuery(db, ids[k], &tq[k]); if (!e.empty()) die(e); }
+            std::vector<std::string> result[2];
+            std::string fail[2];
+            auto work = [&](int k) {
+                for (int it = 0; it < iters && fail[k].empty(); it++) {
+                    std::vector<std::string> lines;
+                    std::string explain;
+                    auto t0 = std::chrono::steady_clock::now();
+                    std::string err = RunTpchQuery(bc[k], tq[k], &lines, &explain);
+                    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    if (!err.empty()) { fail[k] = err; break; }
+                    fprintf(stderr, "Query %d took %.3fms success\n", ids[k], ms);
+                    if (it == 0) result[k] = lines;
+                    else if (lines != result[k]) fail[k] = "iteration " + std::to_string(it) + " of Q" + std::to_string(ids[k]) + " differs from the first";
+                }
+            };
+            std::thread t0(work, 0), t1(work, 1);
+            t0.join(); t1.join();
+            for (int k = 0; k < 2; k++) if (!fail[k].empty()) { fprintf(stderr, "host_tester concurrent: Q%d: %s\n", ids[k], fail[k].c_str()); rc = 1; }
+            int32_t cols5[5] = {L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_ORDERKEY};
+            fprintf(stderr, "lineitem co-located copies: %lld bytes (the five Q9 columns covered: %d)\n", (long long)ph_table_colocate_bytes(db.lineitem.table),
+                    (int)ph_table_colocated(db.lineitem.table, 5, cols5));
+            if (rc == 0) { print(tq[0].ncols, result[0]); printf("--\n"); print(tq[1].ncols, result[1]); }
+        }
+        ph_ctx_destroy(bc[0]); ph_ctx_destroy(bc[1]); ph_ctx_destroy(a);
+        return rc;
+    }
     {   // resident plans: the whole operator subtree behind one OperatorExec
         int id = 0, a = 2;
         if (q == "tpch" && argc >= 5) { id = atoi(argv[2]); a = 3; }

@@ -1130,46 +1130,33 @@ __global__ __launch_bounds__(256) void gather_group_kernel(GatherGroup G, const 
 }
 }  // namespace ph
 
-extern "C" int ph_table_colocate(ph_table *t, int32_t ncols, const int32_t *cols);
-
-// The views name columns of ONE resident table (recognised by their base pointers): through a co-located group that covers
-// them when the table has one. A sparse gather (at most an eighth of the rows) of three or more columns that comes a SECOND
-// time builds the group itself — the layout follows the access pattern the plans show, as the statistics follow the data.
-// PH_OK = done, PH_EUNSUPPORTED = not this shape (the caller gathers column by column in one pass as before).
+// The views name columns of ONE resident table (recognised by their base pointers in the process-wide registry, whatever ctx created the
+// table): through a co-located group that covers them when the table has one. A sparse gather (at most an eighth of the rows) of three or
+// more columns that comes a SECOND time builds the group itself, inside the table's budget (ph_table_set_colocate_budget) — the layout
+// follows the access pattern the plans show, as the statistics follow the data. The copy is built on the CALLER's stream and ordered
+// against every other consumer's by an event (ph::colocated_group_for); the table's mutable state is behind its mutex, so two queries on two
+// contexts may meet here. PH_OK = done, PH_EUNSUPPORTED = not this shape (the caller gathers column by column in one pass as before).
 static int gather_through_group(ph_ctx *ctx, int32_t ncols, const ph_col *cols, const int32_t *idx_dev, int64_t n, void *const *out_dev) {
     static const bool off = getenv("PH_COLOCATE") && atoi(getenv("PH_COLOCATE")) == 0;
     if (off || ncols < 2) return PH_EUNSUPPORTED;
     ph_table *t = nullptr;
     std::vector<int> tc((size_t)ncols);
     for (int c = 0; c < ncols; c++) {
-        auto it = ctx->table_cols.find(cols[c].data);
-        if (it == ctx->table_cols.end() || (t && it->second.first != t)) return PH_EUNSUPPORTED;
-        t = it->second.first;
-        tc[(size_t)c] = it->second.second;
-        if (ph::type_width(cols[c].type) != ph::type_width(t->cols[(size_t)tc[(size_t)c]].type)) return PH_EUNSUPPORTED;
+        ph_table *tt = nullptr;
+        int col = -1;
+        if (!ph::lookup_table_col(cols[c].data, &tt, &col) || (t && tt != t)) return PH_EUNSUPPORTED;
+        t = tt;
+        tc[(size_t)c] = col;
+        if (ph::type_width(cols[c].type) != ph::type_width(t->cols[(size_t)col].type)) return PH_EUNSUPPORTED;
     }
-    auto find = [&]() -> const ph_table::colgroup * {
-        for (auto &g : t->groups) {
-            bool all = true;
-            for (int c : tc) all = all && std::find(g.cols.begin(), g.cols.end(), c) != g.cols.end();
-            if (all) return &g;
-        }
-        return nullptr;
-    };
-    const ph_table::colgroup *g = find();
-    if (!g) {
-        if (ncols < 3 || n * 8 > t->nrows) return PH_EUNSUPPORTED;
-        std::vector<int> set = tc;
-        std::sort(set.begin(), set.end());
-        if (std::adjacent_find(set.begin(), set.end()) != set.end()) return PH_EUNSUPPORTED;
-        for (int c : set) if (t->cols[(size_t)c].validity) return PH_EUNSUPPORTED;
-        int &seen = t->sparse_gathers[set];
-        if (seen < 0 || ++seen < 2) return PH_EUNSUPPORTED;
-        std::vector<int32_t> s32(set.begin(), set.end());
-        if (ph_table_colocate(t, (int32_t)s32.size(), s32.data()) != PH_OK) { seen = -1; return PH_EUNSUPPORTED; }   // (no memory for the copy: not tried again)
-        g = find();
-        if (!g) return PH_EUNSUPPORTED;
+    if (t->ctx && t->ctx->device != ctx->device) return PH_EUNSUPPORTED;
+    ph_table::colgroup grp;
+    const bool may_build = ncols >= 3 && n * 8 <= t->nrows;
+    {
+        const int rcg = ph::colocated_group_for(ctx, t, tc, may_build, false, &grp);
+        if (rcg != PH_OK) return rcg == PH_EUNSUPPORTED ? rcg : rcg;
     }
+    const ph_table::colgroup *g = &grp;
     ph::GatherGroup G{};
     G.rows = (const unsigned char *)g->data;
     G.stride = g->stride;

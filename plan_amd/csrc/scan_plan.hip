@@ -276,19 +276,23 @@ struct ph_scan_plan {
     ph_agg *g_agg = nullptr;
 };
 
+// The plan's two device buffers come from the ctx's stream-ordered pool: a plan that is created, run, fetched and freed per query — the
+// executor behind the operator interface is built and closed per query, like the reference's — then costs no hipMalloc / hipFree. Both
+// synchronise the device: rocprofv3 --hip-trace of Q1 at SF10 behind OperatorExec showed two hipFree calls of ~160 us each per query,
+// the whole of the 0.28 ms it stood above the fused kernel (profiles/r04_q1_opif_before_hip_api_stats.csv).
 static int plan_alloc(ph_scan_plan *p) {
-    PH_HIP(hipMalloc((void **)&p->partials, (size_t)std::max(p->max_grid, 8192) * p->nacc * sizeof(long long)));
+    PH_CHECK(p->ctx->pool_alloc((int64_t)std::max(p->max_grid, 8192) * p->nacc * (int64_t)sizeof(long long), (void **)&p->partials));
     // one allocation, lo[nacc] then hi[nacc]: the raw partial result other ranks all-gather
-    PH_HIP(hipMalloc((void **)&p->out_lo, (size_t)p->nacc * 2 * sizeof(unsigned long long)));
+    PH_CHECK(p->ctx->pool_alloc((int64_t)p->nacc * 2 * (int64_t)sizeof(unsigned long long), (void **)&p->out_lo));
     p->out_hi = (long long *)(p->out_lo + p->nacc);
     return PH_OK;
 }
 
 extern "C" void ph_scan_plan_free(ph_scan_plan *p) {
     if (!p) return;
-    if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->partials) (void)hipFree(p->partials);
-    if (p->out_lo) (void)hipFree(p->out_lo);
+    // stream-ordered reuse: whatever takes these blocks next is queued behind the plan's last kernel on the ctx's one stream
+    if (p->partials) p->ctx->pool_release(p->partials);
+    if (p->out_lo) p->ctx->pool_release(p->out_lo);
     if (p->g_agg) ph_agg_free(p->g_agg);
     delete p;
 }
@@ -926,10 +930,12 @@ extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
         PH_REQUIRE(p->g_agg != nullptr, "ph_scan_plan_fetch: run the plan first");
         return generic_fetch(p, out);
     }
-    std::vector<unsigned long long> lo((size_t)p->nacc);
+    // lo[nacc] and hi[nacc] are ONE allocation (plan_alloc): one host round trip for both (two cost ~45 us more per query)
+    std::vector<unsigned long long> words((size_t)p->nacc * 2);
+    PH_CHECK(p->ctx->download(words.data(), p->out_lo, (int64_t)words.size() * 8));
+    std::vector<unsigned long long> lo(words.begin(), words.begin() + p->nacc);
     std::vector<long long> hi((size_t)p->nacc);
-    PH_CHECK(p->ctx->download(lo.data(), p->out_lo, (int64_t)lo.size() * 8));
-    PH_CHECK(p->ctx->download(hi.data(), p->out_hi, (int64_t)hi.size() * 8));
+    memcpy(hi.data(), words.data() + p->nacc, (size_t)p->nacc * 8);
     return assemble(p, lo, hi, out);
 }
 

@@ -281,6 +281,14 @@ class Table:
     def colocated(self, cols):
         return bool(lib().ph_table_colocated(self.h, i32(len(cols)), (i32 * len(cols))(*cols)))
 
+    def set_colocate_budget(self, nbytes):
+        """bytes of HBM the library may spend on its own on co-located copies of this table (0 = never; default 4 GiB)"""
+        check(lib().ph_table_set_colocate_budget(self.h, i64(nbytes)))
+
+    def colocate_bytes(self):
+        lib().ph_table_colocate_bytes.restype = i64
+        return int(lib().ph_table_colocate_bytes(self.h))
+
     def free(self):
         if self.h:
             lib().ph_table_free(self.h)

@@ -84,6 +84,14 @@ class Database:
                 hip.table_declare_unique(t, [idx[c] for c in pk])
             self.tables[name], self.index[name] = t, idx
 
+    def on(self, ctx):
+        """the same resident tables seen from another ctx: plans built from the view are created and run on `ctx` (its own stream) while
+        the tables stay where they were loaded — the arrangement of a host that keeps one table cache for every query's context"""
+        import copy
+        v = copy.copy(self)
+        v.ctx = ctx
+        return v
+
     def t(self, name):
         return self.tables[name]
 
