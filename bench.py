@@ -623,6 +623,13 @@ def bench_operator_interface(h, sf, steps, warmup):
                 continue
             others[f"q{q}"] = {"ms": round(avg.value, 3), "min_ms": round(mn.value, 3), "result_rows": len([r for r in text.value.decode().split("\n")[1:] if r]),
                                "parity": parity(q, text.value.decode())}
+            if q in (1, 6):
+                # the fused scans behind the operator interface against the same roofline as the headline: SURVEY §8(d)'s algorithmic bytes per
+                # row (Q1 34 B, Q6 24 B) x the table's rows / the WHOLE query's wall time (executor built, pulled, text made, closed)
+                per_row = 34 if q == 1 else 24
+                gbps = per_row * nl / (avg.value * 1e-3) / 1e9
+                others[f"q{q}"]["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                                               "algorithmic_bytes_per_query": per_row * nl, "over": "whole-query wall time behind OperatorExec, host work included"}
         out["tpch_operator_interface"] = {"workload": f"TPC-H SF{sf}, the 16 other queries with a reference golden, through the C++ OperatorExec layer (3 steps behind 2 warm-up runs each)",
                                           "queries": others}
     finally:

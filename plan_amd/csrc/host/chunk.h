@@ -19,6 +19,10 @@
 namespace plan {
 
 constexpr int DefaultVectorSize = 2048;  // pkg/util/util.go:123-125
+// Buffer capacity of a chunk that is known to hold `card` rows and is never appended to (an aggregate's result rows, a sorted page): the
+// reference allocates every chunk at 2048 rows (ensureOutputChunk, executor.go:201-210) — ~400 KB of zeroed memory for Q1's four group
+// rows, per chunk and query: 10 us each beside a 320 us kernel. Same rows, same Card(); only the allocation is right-sized.
+inline int ChunkCapacityFor(int card) { int c = (card < 1 ? 1 : card); c = (c + 63) / 64 * 64; return c > DefaultVectorSize ? DefaultVectorSize : c; }
 
 enum LTypeId : int {  // pkg/common/type_id.go
     LTID_INVALID = 0, LTID_BOOLEAN = 10, LTID_INTEGER = 13, LTID_BIGINT = 14, LTID_DATE = 15,

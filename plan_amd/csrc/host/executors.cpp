@@ -440,7 +440,7 @@ std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector
     for (int64_t base = 0; base < ng; base += DefaultVectorSize) {
         int card = (int)std::min<int64_t>(DefaultVectorSize, ng - base);
         auto out = std::make_shared<Chunk>();
-        out->Init(outTypes, DefaultVectorSize);
+        out->Init(outTypes, ChunkCapacityFor(card));
         for (int r = 0; r < card; r++) {
             size_t gi = (size_t)(base + r);
             for (size_t c = 0; c < nkOut; c++) {
@@ -1019,8 +1019,8 @@ OperatorResult gpuOrderExecutor::Execute(Chunk *, Chunk *output, std::string *er
     }
     if (next_ >= order_.size()) return Done;
     // PayloadScanner (executor_order.go:101-138): the next <= 2048 rows in sorted order
-    output->Init(OutputTypes(), DefaultVectorSize);
     int card = (int)std::min<size_t>((size_t)DefaultVectorSize, order_.size() - next_);
+    output->Init(OutputTypes(), ChunkCapacityFor(card));
     int ncol = (int)OutputTypes().size();
     for (int r = 0; r < card; r++) {
         int64_t row = order_[next_ + (size_t)r];

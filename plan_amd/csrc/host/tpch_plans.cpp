@@ -622,6 +622,8 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
             having.push_back(Compare{q.havingCol, PH_GT, LFloat((float)t)});
         }
     }
+    static const bool timing = getenv("PH_HOST_TIMING") != nullptr;   // where a query's HOST time goes (stderr, one line per query)
+    const double tq0 = now_s();
     gpuResidentPlanExecutor agg(ctx, mainPlan);
     if (!having.empty()) agg.SetHaving(having);
     if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
@@ -643,10 +645,13 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
         root = lim.get();
     }
     lines->clear();
+    const double tq1 = now_s();
+    double tq2 = 0;
     for (;;) {   // the pull loop of execOps (executor.go:151-188)
         Chunk out;
         std::string err;
         OperatorResult r = root->Execute(nullptr, &out, &err);
+        if (tq2 == 0) tq2 = now_s();
         if (r == InvalidOpResult) return "Execute: " + err;
         if (r == Done) break;
         std::string text;
@@ -658,10 +663,13 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
             pos = nl + 1;
         }
     }
+    const double tq3 = now_s();
     if (explain) *explain = agg.Explain();
     if (lim) lim->Close();
     if (ord) ord->Close();
     agg.Close();
+    if (timing) fprintf(stderr, "host timing Q%d: init %.1f us, first Execute %.1f us, rest of the pull loop + text %.1f us, close %.1f us\n", q.id, (tq1 - tq0) * 1e6,
+                        (tq2 - tq1) * 1e6, (tq3 - tq2) * 1e6, (now_s() - tq3) * 1e6);
     return "";
 }
 
