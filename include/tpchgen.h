@@ -90,12 +90,24 @@ typedef struct {
     int64_t *o_totalprice; /* DECIMAL(15,2) unscaled */
     uint8_t *o_orderstatus; /* 'F','O','P' raw byte */
     uint8_t *o_orderpriority; /* code into TPCHGEN_ORDERPRIORITY_DICT */
+    /* round 4 (appended) */
+    char *o_comment;          /* TPCHGEN_O_COMMENT_STRIDE bytes per row, zero padded: 19..78 characters of the text pool */
+    uint8_t *o_comment_len;
 } tpchgen_orders_cols;
 
 int64_t tpchgen_orders(int64_t sf_num, int64_t sf_den, int64_t first_order,
                        int64_t n_orders, const tpchgen_orders_cols *out);
 
 #define TPCHGEN_S_PHONE_LEN 15        /* s_phone / c_phone: "CC-AAA-EEE-NNNN" */
+#define TPCHGEN_O_COMMENT_STRIDE 80   /* o_comment: 19..78 characters */
+#define TPCHGEN_C_COMMENT_STRIDE 120  /* c_comment: 29..116 */
+#define TPCHGEN_S_COMMENT_STRIDE 104  /* s_comment: 25..100 */
+/* The COMMENT columns are substrings of one pregenerated 300 MiB text (sentences of the specification's grammar, clause 4.2.2.14), built
+ * on first use (~3 s, kept for the process lifetime, thread-safe). Returns the pool and its size. */
+const char *tpchgen_text_pool(int64_t *size);
+/* n_comment / r_comment of one row of the fixed NATION / REGION tables (28..115 characters into dest, which needs 116 bytes); returns the length */
+int32_t tpchgen_nation_comment(int32_t nation, char *dest);
+int32_t tpchgen_region_comment(int32_t region, char *dest);
 typedef struct {
     int32_t *c_custkey;
     int32_t *c_nationkey;
@@ -103,6 +115,11 @@ typedef struct {
     /* round 3 (appended) */
     char *c_phone;         /* 15 bytes per row: "CC-AAA-EEE-NNNN", CC = 10 + nation */
     int64_t *c_acctbal;    /* DECIMAL(15,2) unscaled, -999.99 .. 9999.99 */
+    /* round 4 (appended) */
+    char *c_address;          /* TPCHGEN_S_ADDRESS_STRIDE bytes per row (10..40 characters), like s_address */
+    uint8_t *c_address_len;
+    char *c_comment;          /* TPCHGEN_C_COMMENT_STRIDE bytes per row */
+    uint8_t *c_comment_len;
 } tpchgen_customer_cols;
 
 int64_t tpchgen_customer(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,
@@ -116,6 +133,7 @@ typedef struct {
     uint8_t *p_type;        /* code into tpchgen_part_type_dict() */
     int32_t *p_size;        /* INTEGER 1..50 */
     uint8_t *p_container;   /* code into tpchgen_part_container_dict() */
+    uint8_t *p_mfgr;        /* round 4 (appended): 0..4 = "Manufacturer#1" .. "#5" */
 } tpchgen_part_cols;
 
 int64_t tpchgen_part(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,
@@ -140,6 +158,11 @@ typedef struct {
     char *s_address;          /* TPCHGEN_S_ADDRESS_STRIDE bytes per row */
     uint8_t *s_address_len;   /* its length */
     char *s_phone;            /* TPCHGEN_S_PHONE_LEN bytes per row, no terminator */
+    /* round 4 (appended) */
+    int64_t *s_acctbal;       /* DECIMAL(15,2) unscaled, -999.99 .. 9999.99 */
+    char *s_comment;          /* TPCHGEN_S_COMMENT_STRIDE bytes per row, "Customer ... Complaints / Recommends" injected for 10 in 10 000 */
+    uint8_t *s_comment_len;
+    uint8_t *s_complaint;     /* 1 = the injected text is "Customer ... Complaints" (what Q16's LIKE selects); needs no text pool */
 } tpchgen_supplier_cols;
 
 int64_t tpchgen_supplier(int64_t sf_num, int64_t sf_den, int64_t first, int64_t n,

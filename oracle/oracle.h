@@ -392,6 +392,28 @@ int64_t oracle_q12_text(oracle_q12_row *rows, int64_t n, const char *const *dict
 int64_t oracle_q14_text(float promo_revenue, int is_null, char *buf, int64_t cap);
 int64_t oracle_q19_text(const odec *revenue, int is_null, char *buf, int64_t cap);
 
+/* ---- round 4: Q2, Q10, Q13, Q16 (oqueries3.c) — the queries that read the generator's COMMENT text. VARCHAR columns come as offsets (int32[n+1]) +
+ * bytes; s_phone / c_phone are 15 bytes per row; acctbal / supplycost unscaled at scale 2. */
+typedef struct { int32_t brand, type, size; ohuge supplier_cnt; uint8_t cnt_null; } oracle_q16_row;     /* dictionary codes, p_size, count(distinct) */
+int64_t oracle_q16(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int32_t *s_comment_off,
+                   const char *s_comment_bytes, const char *brand_ne, const char *type_notlike, const int32_t *sizes, int32_t nsizes,
+                   const char *comment_like, oracle_q16_row *out, int64_t max);
+int64_t oracle_q16_text(oracle_q16_row *rows, int64_t n, const char *const *brand_dict, const char *const *type_dict, char *buf, int64_t cap);
+typedef struct { int64_t c_count; uint8_t c_count_null; ohuge custdist; } oracle_q13_row;
+int64_t oracle_q13(const oracle_tpch *T, const int32_t *o_comment_off, const char *o_comment_bytes, const char *notlike, oracle_q13_row *out, int64_t max);
+int64_t oracle_q13_text(oracle_q13_row *rows, int64_t n, char *buf, int64_t cap);
+typedef struct { int32_t s_row, nation, p_row; } oracle_q2_row;     /* rows of supplier / NATION / part */
+int64_t oracle_q2(const oracle_tpch *T, int64_t n_ps, const int32_t *ps_partkey, const int32_t *ps_suppkey, const int64_t *ps_supplycost, int32_t size,
+                  const char *type_like, const char *region, oracle_q2_row *out, int64_t max);
+int64_t oracle_q2_text(oracle_q2_row *rows, int64_t n, int32_t limit, const oracle_tpch *T, const int64_t *s_acctbal, const uint8_t *p_mfgr,
+                       const int32_t *addr_off, const char *addr_bytes, const char *phone_bytes, const int32_t *cmnt_off, const char *cmnt_bytes,
+                       char *buf, int64_t cap);
+typedef struct { int32_t c_custkey, nation_code; odec revenue; } oracle_q10_row;
+int64_t oracle_q10(const oracle_tpch *T, const uint8_t *l_returnflag, const char *const *returnflag_dict, const int64_t *c_acctbal, const char *flag,
+                   int32_t date_ge, int32_t date_lt, oracle_q10_row *out, int64_t max);
+int64_t oracle_q10_text(oracle_q10_row *rows, int64_t n, int32_t limit, const oracle_tpch *T, const int64_t *c_acctbal, const int32_t *addr_off,
+                        const char *addr_bytes, const char *phone_bytes, const int32_t *cmnt_off, const char *cmnt_bytes, char *buf, int64_t cap);
+
 /* ---- result text: Chunk.SaveToFile (pkg/chunk/chunk.go:196-220), Vector.GetValue
  * (vector.go:76-186), Value.String (value.go:26-70), headline "#\t..." of execQuery
  * (executor_bench.go:229-238). The ORDER BY / LIMIT tail of each query is applied here with a

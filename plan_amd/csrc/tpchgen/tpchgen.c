@@ -10,8 +10,10 @@
  */
 #include "tpchgen.h"
 
+#include <pthread.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define MODULUS 2147483647LL
@@ -60,6 +62,23 @@
 #define SD_C_ABAL 298370230LL
 #define SD_S_ADDR 706178559LL
 #define SD_S_PHNE 884434366LL
+
+/* round 4: the COMMENT columns and the last columns Q2 / Q10 / Q13 / Q16 read. Seeds as I know them from the public generator's seed table;
+ * every one is pinned below the text: the publicly known first rows of supplier.tbl / customer.tbl / orders.tbl / nation.tbl / region.tbl
+ * (tests/test_tpchgen.py), and the reference's goldens q2.txt (100 rows of s_acctbal, s_address, s_phone, s_comment), q10.txt (c_address,
+ * c_comment), q13.txt (o_comment through NOT LIKE) and q16.txt (the "Customer ... Complaints" injection) — tests/test_golden_tpch.py. */
+#define SD_TEXT_POOL 933588178LL    /* the sentence stream the text pool is pregenerated from */
+#define SD_O_CMNT 276090261LL       /* 2 per order: offset into the pool, length */
+#define SD_C_ADDR 881155353LL       /* 9 per customer (v-string, like s_address) */
+#define SD_C_CMNT 1335826707LL      /* 2 per customer */
+#define SD_S_ABAL 962338209LL       /* 1 per supplier */
+#define SD_S_CMNT 1341315363LL      /* 2 per supplier */
+#define SD_N_CMNT 606179079LL       /* 2 per nation */
+#define SD_R_CMNT 1500869201LL      /* 2 per region */
+#define SD_BBB_OFFSET 263032577LL   /* 1 per supplier each: the "Customer ... Complaints / Recommends" injection into s_comment */
+#define SD_BBB_TYPE 753643799LL
+#define SD_BBB_CMNT 202794285LL
+#define SD_BBB_JNK 715851524LL
 
 #define O_LCNT_MAX 7
 #define SUPP_PER_PART 4
@@ -202,6 +221,8 @@ static inline void stream_row_done(stream_t *s) {
     s->used = 0;
 }
 
+static int text_comment(stream_t *s, int avg, char *dest);   /* a COMMENT value: a substring of the text pool (below) */
+
 /* ---- scale ---- */
 static int64_t scaled(int64_t base, int64_t num, int64_t den) { return base * num / den; }
 
@@ -258,7 +279,7 @@ static int64_t part_supplier(int64_t partkey, int64_t supp_no, int64_t supplier_
 /* ---- lineitem / orders share the order-level streams ---- */
 typedef struct {
     stream_t odate, lcnt, ckey;
-    stream_t qty, dcnt, tax, pkey, skey, sdte, cdte, rdte, rflg, ship, smode, prio;
+    stream_t qty, dcnt, tax, pkey, skey, sdte, cdte, rdte, rflg, ship, smode, prio, ocmt;
     int64_t part_count, supplier_count, customer_count;
 } order_streams;
 
@@ -278,6 +299,7 @@ static void order_streams_init(order_streams *s, int64_t num, int64_t den, int64
     stream_init(&s->ship, SD_L_SHIP, O_LCNT_MAX, first);
     stream_init(&s->smode, SD_L_SMODE, O_LCNT_MAX, first);
     stream_init(&s->prio, SD_O_PRIO, 1, first);
+    stream_init(&s->ocmt, SD_O_CMNT, 2, first);
     s->part_count = tpchgen_part_count(num, den);
     s->supplier_count = tpchgen_supplier_count(num, den);
     s->customer_count = tpchgen_customer_count(num, den);
@@ -299,6 +321,7 @@ static void order_streams_row_done(order_streams *s) {
     stream_row_done(&s->ship);
     stream_row_done(&s->smode);
     stream_row_done(&s->prio);
+    stream_row_done(&s->ocmt);
 }
 
 int64_t tpchgen_lineitem_count(int64_t num, int64_t den, int64_t first, int64_t n) {
@@ -384,6 +407,12 @@ static int64_t gen_orders_lines(int64_t num, int64_t den, int64_t first, int64_t
             if (O->o_orderstatus)
                 O->o_orderstatus[i] = shipped == lines ? 'F' : (shipped == 0 ? 'O' : 'P');
             if (O->o_orderpriority) O->o_orderpriority[i] = prio;
+            if (O->o_comment) {
+                char *c = O->o_comment + TPCHGEN_O_COMMENT_STRIDE * i;
+                memset(c, 0, TPCHGEN_O_COMMENT_STRIDE);
+                const int len = text_comment(&s.ocmt, 49, c);
+                if (O->o_comment_len) O->o_comment_len[i] = (uint8_t)len;
+            }
         }
         order_streams_row_done(&s);
     }
@@ -400,14 +429,171 @@ int64_t tpchgen_orders(int64_t num, int64_t den, int64_t first, int64_t n,
     return gen_orders_lines(num, den, first, n, NULL, out);
 }
 
+/* ---- the text pool -------------------------------------------------------------------------------------------------
+ * The public generator fills every COMMENT column with a random substring of ONE pregenerated text: 300 MiB of sentences
+ * drawn from the specification's grammar (clause 4.2.2.14: sentence forms over noun / verb phrases, prepositions and
+ * terminators; noun phrases over nouns, adjectives, adverbs; verb phrases over verbs, auxiliaries, adverbs — each a weighted
+ * list, picked with one draw of the sentence stream per choice). A comment is two draws of the column's own stream: an offset
+ * into the pool and a length in [0.4, 1.6] x the column's average length. The word lists and weights below are the
+ * specification's (the preposition "whithout" is its spelling); nothing here comes from the reference repository. What pins
+ * them: the total weights of the lists are the sums the public generator's fast path is built on (nouns 340, adjectives 289,
+ * adverbs 262, verbs 174, auxiliaries 18, prepositions 456), the known first rows of supplier / customer / nation / region /
+ * orders.tbl come out to the byte (tests/test_tpchgen.py) — a 115-character comment cannot match by chance — and the 120
+ * comments the reference's goldens q2.txt / q10.txt print do too. */
+typedef struct { const char *text; int weight; } dist_entry;
+typedef struct { const dist_entry *e; int n; int cum[64]; int total; } dist_t;
+static const dist_entry D_GRAMMAR[] = {{"N V T", 3}, {"N V P T", 3}, {"N V N T", 3}, {"N P V N T", 1}, {"N P V P T", 1}};
+static const dist_entry D_NP[] = {{"N", 10}, {"J N", 20}, {"J, J N", 10}, {"D J N", 50}};
+static const dist_entry D_VP[] = {{"V", 30}, {"X V", 1}, {"V D", 40}, {"X V D", 1}};
+static const dist_entry D_NOUNS[] = {{"packages", 40}, {"requests", 40}, {"accounts", 40}, {"deposits", 40}, {"foxes", 20}, {"ideas", 20},
+    {"theodolites", 20}, {"pinto beans", 20}, {"instructions", 20}, {"dependencies", 10}, {"excuses", 10}, {"platelets", 10}, {"asymptotes", 10},
+    {"courts", 5}, {"dolphins", 5}, {"multipliers", 1}, {"sauternes", 1}, {"warthogs", 1}, {"frets", 1}, {"dinos", 1}, {"attainments", 1}, {"somas", 1},
+    {"Tiresias", 1}, {"patterns", 1}, {"forges", 1}, {"braids", 1}, {"frays", 1}, {"warhorses", 1}, {"dugouts", 1}, {"notornis", 1}, {"epitaphs", 1},
+    {"pearls", 1}, {"tithes", 1}, {"waters", 1}, {"orbits", 1}, {"gifts", 1}, {"sheaves", 1}, {"depths", 1}, {"sentiments", 1}, {"decoys", 1},
+    {"realms", 1}, {"pains", 1}, {"grouches", 1}, {"escapades", 1}, {"hockey players", 1}};
+static const dist_entry D_VERBS[] = {{"sleep", 20}, {"wake", 20}, {"are", 20}, {"cajole", 20}, {"haggle", 20}, {"nag", 10}, {"use", 10}, {"boost", 10},
+    {"affix", 5}, {"detect", 5}, {"integrate", 5}, {"maintain", 1}, {"nod", 1}, {"was", 1}, {"lose", 1}, {"sublate", 1}, {"solve", 1}, {"thrash", 1},
+    {"promise", 1}, {"engage", 1}, {"hinder", 1}, {"print", 1}, {"x-ray", 1}, {"breach", 1}, {"eat", 1}, {"grow", 1}, {"impress", 1}, {"mold", 1},
+    {"poach", 1}, {"serve", 1}, {"run", 1}, {"dazzle", 1}, {"snooze", 1}, {"doze", 1}, {"unwind", 1}, {"kindle", 1}, {"play", 1}, {"hang", 1},
+    {"believe", 1}, {"doubt", 1}};
+static const dist_entry D_ADJECTIVES[] = {{"special", 20}, {"pending", 20}, {"unusual", 20}, {"express", 20}, {"furious", 1}, {"sly", 1}, {"careful", 1},
+    {"blithe", 1}, {"quick", 1}, {"fluffy", 1}, {"slow", 1}, {"quiet", 1}, {"ruthless", 1}, {"thin", 1}, {"close", 1}, {"dogged", 1}, {"daring", 1},
+    {"brave", 1}, {"stealthy", 1}, {"permanent", 1}, {"enticing", 1}, {"idle", 1}, {"busy", 1}, {"regular", 50}, {"final", 40}, {"ironic", 40},
+    {"even", 30}, {"bold", 20}, {"silent", 10}};
+static const dist_entry D_ADVERBS[] = {{"sometimes", 1}, {"always", 1}, {"never", 1}, {"furiously", 50}, {"slyly", 50}, {"carefully", 50}, {"blithely", 40},
+    {"quickly", 30}, {"fluffily", 20}, {"slowly", 1}, {"quietly", 1}, {"ruthlessly", 1}, {"thinly", 1}, {"closely", 1}, {"doggedly", 1}, {"daringly", 1},
+    {"bravely", 1}, {"stealthily", 1}, {"permanently", 1}, {"enticingly", 1}, {"idly", 1}, {"busily", 1}, {"regularly", 1}, {"finally", 1},
+    {"ironically", 1}, {"evenly", 1}, {"boldly", 1}, {"silently", 1}};
+static const dist_entry D_PREPOSITIONS[] = {{"about", 50}, {"above", 50}, {"according to", 50}, {"across", 50}, {"after", 50}, {"against", 40},
+    {"along", 40}, {"alongside of", 30}, {"among", 30}, {"around", 20}, {"at", 10}, {"atop", 1}, {"before", 1}, {"behind", 1}, {"beneath", 1},
+    {"beside", 1}, {"besides", 1}, {"between", 1}, {"beyond", 1}, {"by", 1}, {"despite", 1}, {"during", 1}, {"except", 1}, {"for", 1}, {"from", 1},
+    {"in place of", 1}, {"inside", 1}, {"instead of", 1}, {"into", 1}, {"near", 1}, {"of", 1}, {"on", 1}, {"outside", 1}, {"over", 1}, {"past", 1},
+    {"since", 1}, {"through", 1}, {"throughout", 1}, {"to", 1}, {"toward", 1}, {"under", 1}, {"until", 1}, {"up", 1}, {"upon", 1}, {"whithout", 1},
+    {"with", 1}, {"within", 1}};
+static const dist_entry D_AUXILLARIES[] = {{"do", 1}, {"may", 1}, {"might", 1}, {"shall", 1}, {"will", 1}, {"would", 1}, {"can", 1}, {"could", 1},
+    {"should", 1}, {"ought to", 1}, {"must", 1}, {"will have to", 1}, {"shall have to", 1}, {"could have to", 1}, {"should have to", 1},
+    {"must have to", 1}, {"need to", 1}, {"try to", 1}};
+static const dist_entry D_TERMINATORS[] = {{".", 50}, {";", 1}, {":", 1}, {"?", 1}, {"!", 1}, {"--", 1}};
+#define DIST(name, arr) static dist_t name = {arr, (int)(sizeof(arr) / sizeof(arr[0])), {0}, 0}
+DIST(grammar, D_GRAMMAR); DIST(np, D_NP); DIST(vp, D_VP); DIST(nouns, D_NOUNS); DIST(verbs, D_VERBS); DIST(adjectives, D_ADJECTIVES);
+DIST(adverbs, D_ADVERBS); DIST(prepositions, D_PREPOSITIONS); DIST(auxillaries, D_AUXILLARIES); DIST(terminators, D_TERMINATORS);
+
+static int dist_pick(const dist_t *d, stream_t *s) {
+    const int64_t j = stream_int(s, 1, d->total);
+    int i = 0;
+    while (d->cum[i] < j) i++;
+    return i;
+}
+
+/* a noun or verb phrase: its form, then a word per token of the form; a token's second character (the comma of "J,") follows the
+ * word; every word is followed by a blank. Returns the characters written. */
+static int text_phrase(char *dest, const dist_t *forms, stream_t *s) {
+    const char *form = forms->e[dist_pick(forms, s)].text;
+    int res = 0;
+    for (const char *t = form; *t;) {
+        const dist_t *src = *t == 'J' ? &adjectives : *t == 'D' ? &adverbs : *t == 'N' ? &nouns : *t == 'V' ? &verbs : &auxillaries;
+        const char *w = src->e[dist_pick(src, s)].text;
+        const int l = (int)strlen(w);
+        memcpy(dest + res, w, (size_t)l);
+        res += l;
+        t++;
+        if (*t && *t != ' ') dest[res++] = *t++;
+        dest[res++] = ' ';
+        while (*t == ' ') t++;
+    }
+    return res;
+}
+
+/* one sentence (no trailing blank): the terminator abuts the last word */
+static int text_sentence(char *dest, stream_t *s) {
+    const char *form = grammar.e[dist_pick(&grammar, s)].text;
+    int n = 0;
+    for (const char *t = form; *t; t++) {
+        if (*t == ' ') continue;
+        if (*t == 'V') n += text_phrase(dest + n, &vp, s);
+        else if (*t == 'N') n += text_phrase(dest + n, &np, s);
+        else if (*t == 'P') {
+            const char *w = prepositions.e[dist_pick(&prepositions, s)].text;
+            const int l = (int)strlen(w);
+            memcpy(dest + n, w, (size_t)l);
+            memcpy(dest + n + l, " the ", 5);
+            n += l + 5;
+            n += text_phrase(dest + n, &np, s);
+        } else if (*t == 'T') {
+            const char *w = terminators.e[dist_pick(&terminators, s)].text;
+            const int l = (int)strlen(w);
+            n--;   /* over the blank behind the last word */
+            memcpy(dest + n, w, (size_t)l);
+            n += l;
+        }
+    }
+    return n;
+}
+
+#define TEXT_POOL_SIZE (300 * 1024 * 1024)
+static char *text_pool;
+static pthread_once_t text_pool_once = PTHREAD_ONCE_INIT;
+static void text_pool_build(void) {
+    dist_t *all[] = {&grammar, &np, &vp, &nouns, &verbs, &adjectives, &adverbs, &prepositions, &auxillaries, &terminators};
+    for (size_t k = 0; k < sizeof all / sizeof all[0]; k++) {
+        int c = 0;
+        for (int i = 0; i < all[k]->n; i++) { c += all[k]->e[i].weight; all[k]->cum[i] = c; }
+        all[k]->total = c;
+    }
+    char *pool = (char *)malloc((size_t)TEXT_POOL_SIZE + 256);
+    if (!pool) return;
+    stream_t s;
+    stream_init(&s, SD_TEXT_POOL, 1, 0);
+    char sentence[512];
+    int64_t w = 0;
+    while (w < TEXT_POOL_SIZE) {
+        const int len = text_sentence(sentence, &s);
+        const int64_t need = TEXT_POOL_SIZE - w;
+        if (need >= len + 1) { memcpy(pool + w, sentence, (size_t)len); w += len; pool[w++] = ' '; }
+        else { memcpy(pool + w, sentence, (size_t)need); w += need; }
+    }
+    pool[TEXT_POOL_SIZE] = 0;
+    text_pool = pool;
+}
+const char *tpchgen_text_pool(int64_t *size) {
+    pthread_once(&text_pool_once, text_pool_build);
+    if (size) *size = text_pool ? TEXT_POOL_SIZE : 0;
+    return text_pool;
+}
+
+/* a COMMENT value of average length `avg`: two draws of the column's stream; returns the length */
+static int text_comment(stream_t *s, int avg, char *dest) {
+    const int lo = (int)(avg * 0.4), hi = (int)(avg * 1.6);
+    const char *pool = tpchgen_text_pool(NULL);
+    const int64_t off = stream_int(s, 0, (int64_t)TEXT_POOL_SIZE - hi);
+    const int len = (int)stream_int(s, lo, hi);
+    if (pool) memcpy(dest, pool + off, (size_t)len);
+    return len;
+}
+
+int32_t tpchgen_nation_comment(int32_t nation, char *dest) {
+    stream_t s;
+    stream_init(&s, SD_N_CMNT, 2, nation);
+    return text_comment(&s, 72, dest);
+}
+int32_t tpchgen_region_comment(int32_t region, char *dest) {
+    stream_t s;
+    stream_init(&s, SD_R_CMNT, 2, region);
+    return text_comment(&s, 72, dest);
+}
+
+static int vstring(stream_t *s, int lo, int hi, char *dest);
+
 int64_t tpchgen_customer(int64_t num, int64_t den, int64_t first, int64_t n,
                          const tpchgen_customer_cols *out) {
     (void)num; (void)den;
-    stream_t ntrg, mseg, phne, abal;
+    stream_t ntrg, mseg, phne, abal, addr, cmnt;
     stream_init(&ntrg, SD_C_NTRG, 1, first);
     stream_init(&mseg, SD_C_MSEG, 1, first);
     stream_init(&phne, SD_C_PHNE, 3, first);
     stream_init(&abal, SD_C_ABAL, 1, first);
+    stream_init(&addr, SD_C_ADDR, 9, first);
+    stream_init(&cmnt, SD_C_CMNT, 2, first);
     for (int64_t i = 0; i < n; i++) {
         int64_t nation = stream_int(&ntrg, 0, 24);
         int64_t seg = stream_int(&mseg, 0, 4);
@@ -421,10 +607,24 @@ int64_t tpchgen_customer(int64_t num, int64_t den, int64_t first, int64_t n,
             memcpy(out->c_phone + TPCHGEN_S_PHONE_LEN * i, buf, TPCHGEN_S_PHONE_LEN);
         }
         if (out->c_acctbal) out->c_acctbal[i] = stream_int(&abal, -99999, 999999);   /* cents */
+        if (out->c_address) {
+            char *a = out->c_address + TPCHGEN_S_ADDRESS_STRIDE * i;
+            memset(a, 0, TPCHGEN_S_ADDRESS_STRIDE);
+            const int len = vstring(&addr, 10, 40, a);
+            if (out->c_address_len) out->c_address_len[i] = (uint8_t)len;
+        }
+        if (out->c_comment) {
+            char *c = out->c_comment + TPCHGEN_C_COMMENT_STRIDE * i;
+            memset(c, 0, TPCHGEN_C_COMMENT_STRIDE);
+            const int len = text_comment(&cmnt, 73, c);
+            if (out->c_comment_len) out->c_comment_len[i] = (uint8_t)len;
+        }
         stream_row_done(&ntrg);
         stream_row_done(&mseg);
         stream_row_done(&phne);
         stream_row_done(&abal);
+        stream_row_done(&addr);
+        stream_row_done(&cmnt);
     }
     return n;
 }
@@ -444,6 +644,7 @@ int64_t tpchgen_part(int64_t num, int64_t den, int64_t first, int64_t n,
         int64_t m = stream_int(&mfg, 1, 5), b = stream_int(&brnd, 1, 5);
         int64_t ty = stream_int(&type, 1, 150) - 1, sz = stream_int(&size, 1, 50), cn = stream_int(&cntr, 1, 40) - 1;
         if (out->p_brand) out->p_brand[i] = (uint8_t)((m - 1) * 5 + (b - 1));   /* Brand#MN: M = manufacturer, N = 1..5 */
+        if (out->p_mfgr) out->p_mfgr[i] = (uint8_t)(m - 1);                     /* "Manufacturer#M" */
         if (out->p_type) out->p_type[i] = (uint8_t)ty;
         if (out->p_size) out->p_size[i] = (int32_t)sz;
         if (out->p_container) out->p_container[i] = (uint8_t)cn;
@@ -505,10 +706,16 @@ static int vstring(stream_t *s, int lo, int hi, char *dest) {
 int64_t tpchgen_supplier(int64_t num, int64_t den, int64_t first, int64_t n,
                          const tpchgen_supplier_cols *out) {
     (void)num; (void)den;
-    stream_t ntrg, addr, phne;
+    stream_t ntrg, addr, phne, abal, cmnt, bcmt, btyp, bjnk, boff;
     stream_init(&ntrg, SD_S_NTRG, 1, first);
     stream_init(&addr, SD_S_ADDR, 9, first);
     stream_init(&phne, SD_S_PHNE, 3, first);
+    stream_init(&abal, SD_S_ABAL, 1, first);
+    stream_init(&cmnt, SD_S_CMNT, 2, first);
+    stream_init(&bcmt, SD_BBB_CMNT, 1, first);
+    stream_init(&btyp, SD_BBB_TYPE, 1, first);
+    stream_init(&bjnk, SD_BBB_JNK, 1, first);
+    stream_init(&boff, SD_BBB_OFFSET, 1, first);
     for (int64_t i = 0; i < n; i++) {
         int64_t nation = stream_int(&ntrg, 0, 24);
         if (out->s_suppkey) out->s_suppkey[i] = (int32_t)(first + i + 1);
@@ -525,9 +732,37 @@ int64_t tpchgen_supplier(int64_t num, int64_t den, int64_t first, int64_t n,
             snprintf(buf, sizeof buf, "%02d-%03d-%03d-%04d", (int)(10 + nation), ac, ex, nr);
             memcpy(out->s_phone + TPCHGEN_S_PHONE_LEN * i, buf, TPCHGEN_S_PHONE_LEN);
         }
+        if (out->s_acctbal) out->s_acctbal[i] = stream_int(&abal, -99999, 999999);   /* cents */
+        if (out->s_comment || out->s_complaint) {
+            /* the comment, then — for 10 suppliers in 10 000 — "Customer " written over it at a random offset and, `noise` characters
+             * further, "Complaints" (half of them) or "Recommends": what Q16's `s_comment like '%Customer%Complaints%'` finds. The four
+             * draws are made for every supplier, as the public generator makes them. */
+            char buf[TPCHGEN_S_COMMENT_STRIDE];
+            memset(buf, 0, sizeof buf);
+            const int len = text_comment(&cmnt, 63, buf);
+            const int64_t bad_press = stream_int(&bcmt, 1, 10000);
+            const int64_t type = stream_int(&btyp, 0, 100);
+            const int64_t noise = stream_int(&bjnk, 0, len - 19);
+            const int64_t offset = stream_int(&boff, 0, len - (19 + noise));
+            uint8_t complaint = 0;
+            if (bad_press <= 10) {
+                memcpy(buf + offset, "Customer ", 9);
+                if (type < 50) { memcpy(buf + 9 + offset + noise, "Complaints", 10); complaint = 1; }
+                else memcpy(buf + 9 + offset + noise, "Recommends", 10);
+            }
+            if (out->s_comment) memcpy(out->s_comment + TPCHGEN_S_COMMENT_STRIDE * i, buf, TPCHGEN_S_COMMENT_STRIDE);
+            if (out->s_comment_len) out->s_comment_len[i] = (uint8_t)len;
+            if (out->s_complaint) out->s_complaint[i] = complaint;
+        }
         stream_row_done(&ntrg);
         stream_row_done(&addr);
         stream_row_done(&phne);
+        stream_row_done(&abal);
+        stream_row_done(&cmnt);
+        stream_row_done(&bcmt);
+        stream_row_done(&btyp);
+        stream_row_done(&bjnk);
+        stream_row_done(&boff);
     }
     return n;
 }

@@ -93,13 +93,54 @@ _LINEITEM = [("l_orderkey", np.int64), ("l_partkey", np.int32), ("l_suppkey", np
              ("l_returnflag", np.uint8), ("l_linestatus", np.uint8), ("l_shipdate", np.int32),
              ("l_commitdate", np.int32), ("l_receiptdate", np.int32), ("l_shipinstruct", np.uint8), ("l_shipmode", np.uint8)]
 _ORDERS = [("o_orderkey", np.int64), ("o_custkey", np.int32), ("o_orderdate", np.int32),
-           ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8), ("o_orderpriority", np.uint8)]
-_CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8), ("c_phone", np.uint8), ("c_acctbal", np.int64)]
+           ("o_shippriority", np.int32), ("o_totalprice", np.int64), ("o_orderstatus", np.uint8), ("o_orderpriority", np.uint8),
+           ("o_comment", np.uint8), ("o_comment_len", np.uint8)]
+_CUSTOMER = [("c_custkey", np.int32), ("c_nationkey", np.int32), ("c_mktsegment", np.uint8), ("c_phone", np.uint8), ("c_acctbal", np.int64),
+             ("c_address", np.uint8), ("c_address_len", np.uint8), ("c_comment", np.uint8), ("c_comment_len", np.uint8)]
 _PART = [("p_partkey", np.int32), ("p_name_colors", np.uint8), ("p_brand", np.uint8), ("p_type", np.uint8), ("p_size", np.int32),
-         ("p_container", np.uint8)]
+         ("p_container", np.uint8), ("p_mfgr", np.uint8)]
 _PARTSUPP = [("ps_partkey", np.int32), ("ps_suppkey", np.int32), ("ps_supplycost", np.int64), ("ps_availqty", np.int32)]
-_SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32), ("s_address", np.uint8), ("s_address_len", np.uint8), ("s_phone", np.uint8)]
+_SUPPLIER = [("s_suppkey", np.int32), ("s_nationkey", np.int32), ("s_address", np.uint8), ("s_address_len", np.uint8), ("s_phone", np.uint8),
+             ("s_acctbal", np.int64), ("s_comment", np.uint8), ("s_comment_len", np.uint8), ("s_complaint", np.uint8)]
 S_ADDRESS_STRIDE, S_PHONE_LEN = 40, 15
+O_COMMENT_STRIDE, C_COMMENT_STRIDE, S_COMMENT_STRIDE = 80, 120, 104
+MFGR_DICT = [f"Manufacturer#{i}" for i in range(1, 6)]
+
+
+def _varlen(cols, name, stride, n):
+    """fixed-stride characters + lengths (as the generator writes them) -> <name>_off (int32[n+1]) and <name>_bytes"""
+    lens = cols.pop(name + "_len").astype(np.int64)
+    a = cols.pop(name).reshape(n, stride)
+    off = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=off[1:])
+    cols[name + "_off"] = off
+    cols[name + "_bytes"] = a[np.arange(stride)[None, :] < lens[:, None]]
+
+
+def text_pool():
+    """the 300 MiB text every COMMENT column is cut from (built on first use), as a numpy uint8 view"""
+    size = _i64()
+    f = lib().tpchgen_text_pool
+    f.restype = ctypes.c_void_p
+    p = f(ctypes.byref(size))
+    return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(size.value,))
+
+
+def _fixed_comments(fn, n):
+    out = []
+    for i in range(n):
+        buf = ctypes.create_string_buffer(128)
+        k = getattr(lib(), fn)(ctypes.c_int32(i), buf)
+        out.append(buf.raw[:k].decode())
+    return out
+
+
+def nation_comments():
+    return _fixed_comments("tpchgen_nation_comment", 25)
+
+
+def region_comments():
+    return _fixed_comments("tpchgen_region_comment", 5)
 
 
 def _gen(fn, layout, nrows, sf, first, n, columns, width=None):
@@ -145,7 +186,12 @@ def orders(sf, first=0, n=None, columns=None):
     """o_orderstatus comes as a code into ORDERSTATUS_DICT (the generator writes the raw byte 'F' / 'O' / 'P')"""
     if n is None:
         n = orders_count(sf) - first
-    cols = _gen(lib().tpchgen_orders, _ORDERS, n, sf, first, n, columns)
+    want = [c for c, _ in _ORDERS if not c.startswith("o_comment")] if columns is None else list(columns)
+    if "o_comment" in want:   # (asked for by name: 19..78 characters of the text pool per order, as o_comment_off / o_comment_bytes)
+        want.append("o_comment_len")
+    cols = _gen(lib().tpchgen_orders, _ORDERS, n, sf, first, n, want, width={"o_comment": O_COMMENT_STRIDE})
+    if "o_comment" in cols:
+        _varlen(cols, "o_comment", O_COMMENT_STRIDE, n)
     if "o_orderstatus" in cols:
         lut = np.zeros(256, np.uint8)
         lut[ord("O")], lut[ord("P")] = 1, 2
@@ -153,11 +199,23 @@ def orders(sf, first=0, n=None, columns=None):
     return cols
 
 
-def customer(sf, first=0, n=None, columns=None):
-    """c_name is 'Customer#' + the key as nine digits (TPC-H 4.2.3): derived here as offsets + bytes (c_name_off / c_name_bytes)"""
+def customer(sf, first=0, n=None, columns=None, text=False):
+    """c_name is 'Customer#' + the key as nine digits (TPC-H 4.2.3): derived here as offsets + bytes (c_name_off / c_name_bytes).
+    text=True (or naming them in `columns`) adds c_address and c_comment (Q10's select list), as offsets + bytes"""
     if n is None:
         n = int(lib().tpchgen_customer_count(_i64(sf[0]), _i64(sf[1]))) - first
-    cols = _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, columns, width={"c_phone": 15})
+    if columns is None:
+        want = [c for c, _ in _CUSTOMER if text or not (c.startswith("c_address") or c.startswith("c_comment"))]
+    else:
+        want = list(columns)
+        for c in ("c_address", "c_comment"):
+            if c in want:
+                want.append(c + "_len")
+    cols = _gen(lib().tpchgen_customer, _CUSTOMER, n, sf, first, n, want, width={"c_phone": 15, "c_address": S_ADDRESS_STRIDE, "c_comment": C_COMMENT_STRIDE})
+    if "c_address" in cols:
+        _varlen(cols, "c_address", S_ADDRESS_STRIDE, n)
+    if "c_comment" in cols:
+        _varlen(cols, "c_comment", C_COMMENT_STRIDE, n)
     if "c_phone" in cols:
         cols["c_phone_bytes"] = cols.pop("c_phone")
         cols["c_phone_off"] = np.arange(0, 15 * (n + 1), 15, dtype=np.int32)
@@ -206,24 +264,28 @@ def partsupp(sf, first_part=0, n_parts=None, columns=None):
     return _gen(lib().tpchgen_partsupp, _PARTSUPP, 4 * n_parts, sf, first_part, n_parts, columns)
 
 
-def supplier(sf, first=0, n=None, columns=None):
-    """s_name is 'Supplier#' + the key as nine digits (TPC-H 4.2.3); s_name, s_address, s_phone come as offsets + bytes (<col>_off / <col>_bytes)"""
+def supplier(sf, first=0, n=None, columns=None, text=False):
+    """s_name is 'Supplier#' + the key as nine digits (TPC-H 4.2.3); s_name, s_address, s_phone come as offsets + bytes (<col>_off / <col>_bytes).
+    text=True (or naming it) adds s_comment — with the "Customer ... Complaints / Recommends" injection — as offsets + bytes; s_acctbal and
+    s_complaint (1 = the injection Q16's LIKE selects) always come along by default (no text pool needed)."""
     if n is None:
         n = int(lib().tpchgen_supplier_count(_i64(sf[0]), _i64(sf[1]))) - first
     want = None if columns is None else list(columns)
-    raw = None if want is None else [c for c in want if c in ("s_suppkey", "s_nationkey")]
-    if want is None or "s_address" in want:
-        raw = None if raw is None else raw + ["s_address", "s_address_len"]
-    if want is None or "s_phone" in want:
-        raw = None if raw is None else raw + ["s_phone"]
-    cols = _gen(lib().tpchgen_supplier, _SUPPLIER, n, sf, first, n, raw, width={"s_address": S_ADDRESS_STRIDE, "s_phone": S_PHONE_LEN})
+    if want is None:
+        raw = ["s_suppkey", "s_nationkey", "s_address", "s_address_len", "s_phone", "s_acctbal", "s_complaint"] + (["s_comment", "s_comment_len"] if text else [])
+    else:
+        raw = [c for c in want if c in ("s_suppkey", "s_nationkey", "s_acctbal", "s_complaint")]
+        if "s_address" in want:
+            raw += ["s_address", "s_address_len"]
+        if "s_phone" in want:
+            raw.append("s_phone")
+        if "s_comment" in want:
+            raw += ["s_comment", "s_comment_len"]
+    cols = _gen(lib().tpchgen_supplier, _SUPPLIER, n, sf, first, n, raw, width={"s_address": S_ADDRESS_STRIDE, "s_phone": S_PHONE_LEN, "s_comment": S_COMMENT_STRIDE})
     if "s_address" in cols:
-        lens = cols.pop("s_address_len").astype(np.int64)
-        a = cols.pop("s_address").reshape(n, S_ADDRESS_STRIDE)
-        off = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum(lens, out=off[1:])
-        cols["s_address_off"] = off
-        cols["s_address_bytes"] = a[np.arange(S_ADDRESS_STRIDE)[None, :] < lens[:, None]]
+        _varlen(cols, "s_address", S_ADDRESS_STRIDE, n)
+    if "s_comment" in cols:
+        _varlen(cols, "s_comment", S_COMMENT_STRIDE, n)
     if "s_phone" in cols:
         cols["s_phone_bytes"] = cols.pop("s_phone")
         cols["s_phone_off"] = np.arange(0, S_PHONE_LEN * (n + 1), S_PHONE_LEN, dtype=np.int32)

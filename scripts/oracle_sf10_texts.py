@@ -34,7 +34,7 @@ def main():
     num, den = (int(args[1]), int(args[2])) if len(args) > 2 else (10, 1)
     os.makedirs(out, exist_ok=True)
     t0 = time.time()
-    T = tpch_data.load(num, den)
+    T = tpch_data.load(num, den, text=True)
     print(f"generated SF{num}/{den} in {time.time() - t0:.1f} s", flush=True)
     order = sorted(OQ.QUERIES, key=lambda q: q != 1)   # Q1 (a minute of chunked decimal arithmetic at SF10) first
     if jobs > 1:

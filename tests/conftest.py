@@ -18,7 +18,7 @@ def sf1():
     """Official-dbgen-equivalent SF1 tables (tests/golden pins them), generated once."""
     import tpch_data
 
-    return tpch_data.load(1, 1)
+    return tpch_data.load(1, 1, text=True)
 
 
 @pytest.fixture(scope="session")

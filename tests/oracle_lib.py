@@ -769,3 +769,98 @@ def q18(t, qty_gt=314):
 def q18_text(t, qty_gt=314, limit=100):
     n, rows = q18(t, qty_gt)
     return _text("oracle_q18_text", rows, i64(n), i32(limit))
+
+
+# ---------------------------------------------------------------- round 4: Q2, Q10, Q13, Q16 (oracle/oqueries3.c)
+
+class Q16Row(ctypes.Structure):
+    _fields_ = [("brand", i32), ("type", i32), ("size", i32), ("supplier_cnt", OHuge), ("cnt_null", ctypes.c_uint8)]
+
+
+class Q13Row(ctypes.Structure):
+    _fields_ = [("c_count", i64), ("c_count_null", ctypes.c_uint8), ("custdist", OHuge)]
+
+
+class Q2Row(ctypes.Structure):
+    _fields_ = [("s_row", i32), ("nation", i32), ("p_row", i32)]
+
+
+class Q10Row(ctypes.Structure):
+    _fields_ = [("c_custkey", i32), ("nation_code", i32), ("revenue", ODec)]
+
+
+def _vp(a):
+    return ctypes.c_void_p(np.ascontiguousarray(a).ctypes.data)
+
+
+def q16_rows(t, brand_ne="Brand#35", type_notlike="ECONOMY BURNISHED%", sizes=(14, 7, 21, 24, 35, 33, 2, 20), comment_like="%Customer%Complaints%"):
+    T, keep = tpch_struct(t)
+    PS, S = t["partsupp"], t["supplier"]
+    arrs = [np.ascontiguousarray(PS["ps_partkey"]), np.ascontiguousarray(PS["ps_suppkey"]), np.ascontiguousarray(S["s_comment_off"]),
+            np.ascontiguousarray(S["s_comment_bytes"])]
+    sz = np.array(sizes, np.int32)
+    n_groups_max = 150 * 25 * len(sizes) + 16
+    rows = (Q16Row * n_groups_max)()
+    lib().oracle_q16.restype = i64
+    n = lib().oracle_q16(ctypes.byref(T), i64(len(arrs[0])), _vp(arrs[0]), _vp(arrs[1]), _vp(arrs[2]), _vp(arrs[3]), brand_ne.encode(), type_notlike.encode(),
+                         _vp(sz), i32(len(sz)), comment_like.encode(), rows, i64(n_groups_max))
+    assert 0 <= n <= n_groups_max
+    return rows, n
+
+
+def q16_text(t, **kw):
+    from plan_amd import tpchgen
+    rows, n = q16_rows(t, **kw)
+    return _text("oracle_q16_text", rows, i64(n), cdict(tpchgen.part_brand_dict()), cdict(tpchgen.part_type_dict()), cap=1 << 21)
+
+
+def q13_rows(t, notlike="%pending%accounts%"):
+    T, keep = tpch_struct(t)
+    Od = t["orders"]
+    off, b = np.ascontiguousarray(Od["o_comment_off"]), np.ascontiguousarray(Od["o_comment_bytes"])
+    rows = (Q13Row * 256)()
+    lib().oracle_q13.restype = i64
+    n = lib().oracle_q13(ctypes.byref(T), _vp(off), _vp(b), notlike.encode(), rows, i64(256))
+    assert 0 <= n <= 256
+    return rows, n
+
+
+def q13_text(t, **kw):
+    rows, n = q13_rows(t, **kw)
+    return _text("oracle_q13_text", rows, i64(n))
+
+
+def q2_text(t, size=48, type_like="%TIN", region="MIDDLE EAST", limit=100):
+    T, keep = tpch_struct(t)
+    PS, S, P = t["partsupp"], t["supplier"], t["part"]
+    a = [np.ascontiguousarray(PS[c]) for c in ("ps_partkey", "ps_suppkey", "ps_supplycost")]
+    cap = len(a[0])
+    rows = (Q2Row * cap)()
+    lib().oracle_q2.restype = i64
+    n = lib().oracle_q2(ctypes.byref(T), i64(cap), _vp(a[0]), _vp(a[1]), _vp(a[2]), i32(size), type_like.encode(), region.encode(), rows, i64(cap))
+    assert 0 <= n <= cap
+    s = [np.ascontiguousarray(S[c]) for c in ("s_acctbal", "s_address_off", "s_address_bytes", "s_phone_bytes", "s_comment_off", "s_comment_bytes")]
+    mf = np.ascontiguousarray(P["p_mfgr"])
+    return _text("oracle_q2_text", rows, i64(n), i32(limit), ctypes.byref(T), _vp(s[0]), _vp(mf), _vp(s[1]), _vp(s[2]), _vp(s[3]), _vp(s[4]), _vp(s[5]), cap=1 << 18)
+
+
+def q10_rows(t, flag="R", date_ge=None, date_lt=None):
+    from plan_amd import tpchgen
+    date_ge = tpchgen.days(1993, 3, 1) if date_ge is None else date_ge
+    date_lt = tpchgen.days(1993, 6, 1) if date_lt is None else date_lt
+    T, keep = tpch_struct(t)
+    rf = np.ascontiguousarray(t["lineitem"]["l_returnflag"])
+    bal = np.ascontiguousarray(t["customer"]["c_acctbal"])
+    cap = len(bal)
+    rows = (Q10Row * cap)()
+    lib().oracle_q10.restype = i64
+    n = lib().oracle_q10(ctypes.byref(T), _vp(rf), cdict(tpchgen.RETURNFLAG_DICT), _vp(bal), flag.encode(), i32(date_ge), i32(date_lt), rows, i64(cap))
+    assert 0 <= n <= cap
+    return rows, n, T, keep
+
+
+def q10_text(t, limit=20, **kw):
+    rows, n, T, keep = q10_rows(t, **kw)
+    C = t["customer"]
+    c = [np.ascontiguousarray(C[k]) for k in ("c_acctbal", "c_address_off", "c_address_bytes", "c_phone_bytes", "c_comment_off", "c_comment_bytes")]
+    return _text("oracle_q10_text", rows, i64(n), i32(limit), ctypes.byref(T), _vp(c[0]), _vp(c[1]), _vp(c[2]), _vp(c[3]), _vp(c[4]), _vp(c[5]), cap=1 << 16)

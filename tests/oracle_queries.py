@@ -6,13 +6,21 @@ import oracle_lib as O
 from plan_amd import tpchgen
 
 D = tpchgen.days
-QUERIES = (1, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 15, 17, 18, 19, 20, 21, 22)
+QUERIES = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22)
 
 
 def text(q, t):
-    """result file text (headline + rows) of query q over the numpy tables t (tpch_data.load)"""
+    """result file text (headline + rows) of query q over the numpy tables t (tpch_data.load with text=True: Q2 / Q10 / Q13 / Q16 read COMMENT columns)"""
     if q == 1:
         return O.q1_text(O.q1(t["lineitem"], D(1998, 12, 1) - 112))
+    if q == 2:
+        return O.q2_text(t)
+    if q == 10:
+        return O.q10_text(t)
+    if q == 13:
+        return O.q13_text(t)
+    if q == 16:
+        return O.q16_text(t)
     if q == 3:
         n, rows = O.q3(t, "HOUSEHOLD", D(1995, 3, 29), cap=1 << 25)
         return O.q3_text(rows, n, 10)

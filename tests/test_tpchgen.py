@@ -72,3 +72,60 @@ def test_customer_phone_and_acctbal_first_rows():
     assert [b[i * 15:(i + 1) * 15].decode() for i in range(5)] == ["25-989-741-2988", "23-768-687-3665", "11-719-748-3364", "14-128-190-5944", "13-750-942-6364"]
     assert C["c_acctbal"].tolist() == [71156, 12165, 749812, 286683, 79447]
     assert C["c_nationkey"].tolist() == [15, 13, 1, 4, 3]
+
+
+def _strs(T, c, k=None):
+    o, b = T[c + "_off"], T[c + "_bytes"].tobytes()
+    return [b[o[i]:o[i + 1]].decode() for i in range(len(o) - 1 if k is None else k)]
+
+
+def test_comment_columns_first_rows():
+    """Round 4: the COMMENT columns — substrings of the pregenerated 300 MiB text (include/tpchgen.h). The first rows of dbgen's SF1 files as
+    publicly known:
+      supplier.tbl  1|..|5755.94|each slyly above the careful|   2|..|4032.68| slyly bold instructions. idle dependen|
+                    3|..|4192.40|blithely silent requests after the express dependencies are sl|   4|..|4641.08|riously even requests above the exp|
+                    5|..|-283.84|. slyly regular pinto bea|
+      customer.tbl  1|Customer#000000001|IVhzIApeRb ot,c,E|15|..|to the even, regular platelets. regular, ironic epitaphs nag e|
+                    2|Customer#000000002|XSTf4,NCwDVaWNe6tEgvwfmRchLXak|13|..|l accounts. blithely ironic theodolites integrate boldly: caref|
+      orders.tbl    1|36901|O|173665.47|1996-01-02|5-LOW|Clerk#000000951|0|nstructions sleep furiously among |
+                    2|78002|O|46929.18|1996-12-01|1-URGENT|Clerk#000000880|0| foxes. pending accounts at the pending, silent asymptot|
+      nation.tbl    0|ALGERIA|0| haggle. carefully final deposits detect slyly agai|
+                    1|ARGENTINA|1|al foxes promise slyly according to the regular accounts. bold requests alon|
+      region.tbl    0|AFRICA|lar deposits. blithely final packages cajole. regular waters are final requests. regular accounts are according to |
+                    1|AMERICA|hs use ironic, even requests. s|
+    A 115-character comment does not come out right by chance: the grammar, the word lists and weights, the sentence stream and the columns'
+    own streams are all pinned by these rows (and again by the 120 comments of the reference's q2.txt / q10.txt, tests/test_golden_tpch.py)."""
+    S = g.supplier(SF1, 0, 5, text=True)
+    assert _strs(S, "s_comment") == ["each slyly above the careful", " slyly bold instructions. idle dependen",
+                                     "blithely silent requests after the express dependencies are sl", "riously even requests above the exp",
+                                     ". slyly regular pinto bea"]
+    assert S["s_acctbal"].tolist() == [575594, 403268, 419240, 464108, -28384]
+    C = g.customer(SF1, 0, 2, text=True)
+    assert _strs(C, "c_comment") == ["to the even, regular platelets. regular, ironic epitaphs nag e", "l accounts. blithely ironic theodolites integrate boldly: caref"]
+    assert _strs(C, "c_address") == ["IVhzIApeRb ot,c,E", "XSTf4,NCwDVaWNe6tEgvwfmRchLXak"]
+    O = g.orders(SF1, 0, 2, columns=["o_orderkey", "o_comment"])
+    assert _strs(O, "o_comment") == ["nstructions sleep furiously among ", " foxes. pending accounts at the pending, silent asymptot"]
+    assert g.nation_comments()[:2] == [" haggle. carefully final deposits detect slyly agai", "al foxes promise slyly according to the regular accounts. bold requests alon"]
+    assert g.region_comments()[:2] == ["lar deposits. blithely final packages cajole. regular waters are final requests. regular accounts are according to ",
+                                       "hs use ironic, even requests. s"]
+
+
+def test_supplier_complaint_injection():
+    """10 suppliers in 10 000 carry "Customer ... Complaints" or "... Recommends" written over their comment (TPC-H 4.2.3): Q16's
+    `s_comment like '%Customer%Complaints%'` selects the first kind. s_complaint flags them without the text pool; with the text the two agree."""
+    S = g.supplier(SF1, text=True)
+    com = _strs(S, "s_comment")
+    flagged = [i for i, c in enumerate(com) if "Customer" in c]
+    assert 2 <= len(flagged) <= 30
+    complaints = [i for i in flagged if "Complaints" in com[i][com[i].index("Customer"):]]
+    assert complaints == [int(i) for i in S["s_complaint"].nonzero()[0]] and all("Customer " in com[i] for i in flagged)
+    assert all(("Complaints" in com[i]) != ("Recommends" in com[i]) for i in flagged)
+    # generated from any row on: shards equal the whole
+    T = g.supplier(SF1, 5000, 100, text=True)
+    assert _strs(T, "s_comment") == com[5000:5100]
+
+
+def test_part_manufacturer_follows_the_brand():
+    P = g.part(SF1, 0, 1000)
+    bd = g.part_brand_dict()
+    assert all(g.MFGR_DICT[m][-1] == bd[b][6] for m, b in zip(P["p_mfgr"], P["p_brand"]))
