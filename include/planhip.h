@@ -353,7 +353,11 @@ int ph_table_strings(ph_ctx *ctx, const ph_table *t, int32_t c, const int64_t *r
  * function_aggr.go:420-1365). Device form: open-addressing table in HBM keyed by the packed
  * group key, LDS-staged per workgroup, 128-bit integer sums, counts, min/max; first-seen row id
  * per group so that groups come back in the reference's insertion order. */
-typedef enum { PH_A_SUM = 1, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR } ph_aggkind;
+typedef enum { PH_A_SUM = 1, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR,
+               PH_A_COUNT_DISTINCT /* resident plans only (ph_plan_agg.kind): count(distinct x) — the distinct (group keys, x) rows of a side
+                                      table feed the aggregate, as SinkDistinctGrouping / DistinctGrouping do (aggregate_exec.go:76-105,
+                                      201-304); at the operator level the same is ph_agg_sink_masked + ph_agg_keys_dev */
+} ph_aggkind;
 
 typedef struct {
     int32_t kind;
@@ -597,6 +601,13 @@ int ph_cross_pairs(ph_ctx *ctx, int64_t n_left, int64_t n_right, int32_t *out_le
  * TupleDataTemplatedGather join_collection.go:501-529) */
 int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev, int64_t n, void *out_dev);
 
+/* Validity of a row-id vector: bit i of bitmap_dev (pkg/util/bitmap.go's layout, (n + 7) / 8 bytes) = ids_dev[i] >= 0. The build side of a
+ * LEFT OUTER join reports row id -1 for a probe row without a match (NextLeftJoin, join_scan.go:67-88: the build side's vectors are constant
+ * NULL for those rows); values gathered through such ids (ph_gather* read row 0 for a negative id) carry this bitmap as their validity. */
+int ph_rowid_validity(ph_ctx *ctx, const int32_t *ids_dev, int64_t n, uint8_t *bitmap_dev);
+/* dictionary codes (PH_CODE8) of rows sel[0..n) / 0..n as INTEGERs: out_dev[i] = code (a code column as a 4-byte group-key part) */
+int ph_widen_codes(ph_ctx *ctx, const ph_col *col, const int32_t *sel, int64_t n, int32_t *out_dev);
+
 /* the same for up to 8 columns through one row-id array, in one pass: the late materialisation of a
  * join chain's probe side (all column reads of a row are in flight together, the index is read
  * once). out_dev[c]: n elements of column c's width. */
@@ -631,6 +642,7 @@ typedef struct {
     uint64_t *count;
     int32_t *scale;     /* naggs: scale of each aggregate's argument */
     int32_t nkeys, naggs;
+    uint8_t *key_null;  /* ngroups * nkeys, 1 = the key is NULL (the NULL group; keys[] holds 0 there); NULL pointer = no NULL-able key */
 } ph_agg_result;
 
 /* group_cols: table columns to group by (0 columns = one global group, the reference's
@@ -700,7 +712,12 @@ void ph_agg_result_free(ph_agg_result *r);
  * plan again in its conservative forms (general builds, counted lookups, hash aggregate) — results never
  * depend on a statistic being right. ph_plan_explain names the forms the last run chose. */
 typedef enum { PH_PN_SCAN = 1, PH_PN_FILTER, PH_PN_JOIN, PH_PN_PROJECT, PH_PN_AGG } ph_plan_kind;
-typedef enum { PH_JT_INNER = 1, PH_JT_SEMI, PH_JT_ANTI } ph_plan_join_type;   /* LOT_JoinType* of join_scan.go:47-165 */
+typedef enum { PH_JT_INNER = 1, PH_JT_SEMI, PH_JT_ANTI,
+               PH_JT_LEFT   /* LEFT OUTER (NextLeftJoin, join_scan.go:67-88): the inner matches, then every probe row without one with the build
+                               side's columns NULL. Those columns carry a validity bitmap from then on: aggregates skip the NULLs (count(x) of a
+                               customer without orders is 0 and finalises to NULL, function_aggr.go:950-962), operators that cannot take a
+                               NULL-able column answer PH_EUNSUPPORTED. Rows come out matches first, then the unmatched probe rows. */
+} ph_plan_join_type;   /* LOT_JoinType* of join_scan.go:47-165 */
 typedef enum {
     PH_PE_COL = 1,    /* column reference (executeColumnRef: zero copy) */
     PH_PE_DECIMAL,    /* decimal / integer arithmetic, RPN over the child's output columns (executeFunc) */

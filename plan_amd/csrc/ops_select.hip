@@ -1007,6 +1007,48 @@ extern "C" int ph_gather(ph_ctx *ctx, const ph_col *col, const int32_t *idx_dev,
     return PH_OK;
 }
 
+// ---- validity of a row-id vector (the NULL-extended side of a LEFT OUTER join: row id -1 = no build row) and dictionary codes as INTEGERs
+namespace ph {
+__global__ __launch_bounds__(256) void rowid_validity_kernel(const int32_t *__restrict__ ids, int64_t n, uint8_t *__restrict__ bitmap) {
+    // a lane composes the byte of eight consecutive rows: plain byte stores, no atomics
+    const int64_t nbytes = (n + 7) / 8;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nbytes; b += (int64_t)gridDim.x * 256) {
+        unsigned v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t i = b * 8 + k;
+            if (i < n && ids[i] >= 0) v |= 1u << k;
+        }
+        bitmap[b] = (uint8_t)v;
+    }
+}
+__global__ __launch_bounds__(256) void widen_codes_kernel(const uint8_t *__restrict__ codes, const int32_t *__restrict__ sel, int64_t n, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = sel ? (sel[i] < 0 ? 0 : sel[i]) : i;
+        out[i] = (int32_t)codes[r];
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_rowid_validity(ph_ctx *ctx, const int32_t *ids_dev, int64_t n, uint8_t *bitmap_dev) {
+    PH_REQUIRE(ctx && n >= 0 && (n == 0 || (ids_dev && bitmap_dev)), "ph_rowid_validity: bad arguments");
+    if (n == 0) return PH_OK;
+    const int grid = (int)std::min<int64_t>(((n + 7) / 8 + 255) / 256, 256 * 8);
+    ph::rowid_validity_kernel<<<grid, 256, 0, ctx->stream>>>(ids_dev, n, bitmap_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+extern "C" int ph_widen_codes(ph_ctx *ctx, const ph_col *col, const int32_t *sel, int64_t n, int32_t *out_dev) {
+    PH_REQUIRE(ctx && col && n >= 0 && (n == 0 || out_dev), "ph_widen_codes: bad arguments");
+    PH_REQUIRE(col->type == PH_CODE8 && col->data, "ph_widen_codes: column type %d is not PH_CODE8", col->type);
+    if (n == 0) return PH_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    ph::widen_codes_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)col->data, sel, n, out_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 // Several columns through ONE row-id array in one pass (late materialisation of a join chain's probe
 // side: Q9 needs six lineitem columns at the rows that survived the first join). A gather is two
 // dependent memory latencies per element; one launch per column pays them once per column, here

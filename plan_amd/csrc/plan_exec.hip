@@ -57,6 +57,7 @@ struct Lane {
     const int32_t *rows = nullptr;  // nullptr = identity (row i of the relation is row i of the table)
     bool asc = true;                // the row ids are ascending (table order preserved)
     bool dup_free = true;           // no table row occurs twice
+    bool nullable = false;          // row id -1 = no row (the build side of a LEFT OUTER join): the lane's columns are NULL there
 };
 
 struct Rel {
@@ -440,11 +441,18 @@ int positional(ph_plan *p, Rel *r, const std::vector<int> &want) {
                     else PL_CHECK(ph_gather_multi(p->ctx, (int32_t)views.size(), views.data(), ln.rows, r->n, outs.data()));
                 }
             }
+            const uint8_t *lane_validity = nullptr;
+            if (ln.rows && ln.nullable) {   // (the gathers read row 0 for a negative id; the bitmap says which values are real)
+                void *vb = nullptr;
+                PL_CHECK(palloc(p, (std::max<int64_t>(r->n, 1) + 7) / 8 + 64, &vb));
+                if (r->n > 0) PL_CHECK(ph_rowid_validity(p->ctx, ln.rows, r->n, (uint8_t *)vb));
+                lane_validity = (const uint8_t *)vb;
+            }
             for (int c : members) {
                 PCol &pc = r->cols[(size_t)c];
                 const size_t b = (size_t)(std::find(batch.begin(), batch.end(), pc.tcol) - batch.begin());
                 pc.data = outp[b];
-                pc.validity = ln.rows ? nullptr : ln.t->cols[(size_t)pc.tcol].validity;
+                pc.validity = ln.rows ? lane_validity : ln.t->cols[(size_t)pc.tcol].validity;
                 pc.lane = -1;
                 pc.tcol = -1;
             }
@@ -516,6 +524,7 @@ int eval_rpn(ph_plan *p, Rel *r, const ph_rpn *prog, int nprog, PCol *out) {
     // all operands in one lane: evaluate straight over the table's columns through the lane's row ids (a fused gather)
     int lane = operands.empty() ? -1 : r->cols[(size_t)operands[0]].lane;
     for (int c : operands) if (r->cols[(size_t)c].lane != lane) lane = -2;
+    if (lane >= 0 && r->lanes[(size_t)lane].nullable) lane = -2;   // row ids of -1 (a LEFT join's build side): gathered with their validity first
     if (lane < 0 && !operands.empty()) PL_CHECK(positional(p, r, operands));
     std::vector<ph_col> views;
     const int32_t *sel = nullptr;
@@ -549,6 +558,7 @@ int eval_float(ph_plan *p, Rel *r, const ph_plan_expr &e, PCol *out) {
     for (int c : operands) if (c < 0 || c >= (int)r->cols.size()) { set_error("ph_plan: expression column %d out of range", c); return PH_EINVAL; }
     int lane = r->cols[(size_t)operands[0]].lane;
     for (int c : operands) if (r->cols[(size_t)c].lane != lane) lane = -2;
+    if (lane >= 0 && r->lanes[(size_t)lane].nullable) lane = -2;
     if (lane < 0) PL_CHECK(positional(p, r, operands));
     std::vector<ph_col> views;
     const int32_t *sel = nullptr;
@@ -657,6 +667,7 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
     case PH_PE_YEAR: {
         if (e.col < 0 || e.col >= (int)r->cols.size() || r->cols[(size_t)e.col].type != PH_DATE) { set_error("ph_plan: extract(year) needs a DATE column"); return PH_EINVAL; }
         PL_CHECK(apply_pending(p, r));
+        if (r->cols[(size_t)e.col].lane >= 0 && r->lanes[(size_t)r->cols[(size_t)e.col].lane].nullable) { set_error("ph_plan: extract over a NULL-able column"); return PH_EUNSUPPORTED; }
         const int32_t *sel = nullptr;
         ph_col v = col_view(*r, r->cols[(size_t)e.col], &sel);
         if (v.validity) { set_error("ph_plan: extract over a NULL-able column"); return PH_EUNSUPPORTED; }
@@ -679,6 +690,7 @@ int eval_expr(ph_plan *p, Rel *r, const Expr &ex, PCol *out) {
         const PCol &pc = r->cols[(size_t)e.col];
         if (pc.type != PH_STR || pc.lane < 0) { set_error("ph_plan: substring needs a VARCHAR table column"); return PH_EUNSUPPORTED; }
         const Lane &ln = r->lanes[(size_t)pc.lane];
+        if (ln.nullable) { set_error("ph_plan: substring over a NULL-able column"); return PH_EUNSUPPORTED; }
         ph_col v = table_view(ln.t, pc.tcol);
         const int64_t n = r->n;
         // capacity: a relation whose row ids do not repeat cannot ask for more bytes than the column holds; row ids that repeat (a small
@@ -750,6 +762,7 @@ int string_codes(ph_plan *p, Rel *r, int c, ph_strdict *dict, ph_strdict **dict_
     const PCol &pc = r->cols[(size_t)c];
     if (pc.lane < 0) { set_error("ph_plan: a VARCHAR key must be a table column (offsets + bytes cannot be gathered)"); return PH_EUNSUPPORTED; }
     const Lane &ln = r->lanes[(size_t)pc.lane];
+    if (ln.nullable) { set_error("ph_plan: a VARCHAR key from the NULL-able side of a LEFT join"); return PH_EUNSUPPORTED; }
     ph_col v = table_view(ln.t, pc.tcol);
     void *codes = nullptr;
     PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &codes));
@@ -810,7 +823,7 @@ struct KeySide {            // the key columns of one join side as the kernels w
 // key columns of a relation: table columns addressed through the one lane's row ids when the relation is a
 // (filtered) base table, positional columns otherwise
 int key_side(ph_plan *p, Rel *r, const std::vector<int32_t> &keys, KeySide *ks) {
-    bool all_lane0 = r->lanes.size() == 1;
+    bool all_lane0 = r->lanes.size() == 1 && !r->lanes[0].nullable;
     for (int32_t k : keys) all_lane0 = all_lane0 && r->cols[(size_t)k].lane == 0;
     bool any_positional = false;
     for (auto &c : r->cols) any_positional |= c.lane < 0;
@@ -860,6 +873,7 @@ int pair_probe(ph_plan *p, ph_join *j, const KeySide &pk, const ph_pred *where, 
 }
 
 int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out);
+int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out);
 
 // ---- HashJoin
 int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
@@ -906,7 +920,8 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
         if (o < 0 || (size_t)o >= nP + nB) { set_error("ph_plan: join output column out of range"); return PH_EINVAL; }
         need_build_cols |= (size_t)o >= nP;
     }
-    if (nd.join_type != PH_JT_INNER && need_build_cols) { set_error("ph_plan: a SEMI / ANTI join emits probe columns only"); return PH_EINVAL; }
+    if (nd.join_type != PH_JT_INNER && nd.join_type != PH_JT_LEFT && need_build_cols) { set_error("ph_plan: a SEMI / ANTI join emits probe columns only"); return PH_EINVAL; }
+    if (nd.join_type == PH_JT_LEFT) return left_join_rels(p, idx, nd, P, B, out);
     const bool optimistic = !p->conservative;
     const int uniq = key_unique(B, nd.bkeys);
     const bool unique = uniq > 0;
@@ -1252,6 +1267,101 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
     }
 }
 
+// ---- LEFT OUTER join (NextLeftJoin, join_scan.go:67-88): the inner matches, then the probe rows without one, their build side NULL.
+// Pairs come from the general inner probe; the unmatched probe rows from a mark probe of the same table (found == 0). The result's
+// probe lanes are [pair probe rows | unmatched rows], its build lane [pair build rows | -1 ...] and marked NULL-able: positional()
+// gives the columns read through it a validity bitmap (ph_rowid_validity). The reference emits the two kinds chunk by chunk; here all
+// matches come first — the same rows (an ORDER BY above decides the order, as it must for a hash join's output anyway).
+int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out) {
+    ph_ctx *ctx = p->ctx;
+    const size_t nP = P.cols.size();
+    PL_CHECK(apply_pending(p, &P));
+    PL_CHECK(apply_pending(p, &B));
+    // build: the build side's rows (a filtered base table: row ids of the table; else positions in B)
+    KeySide bk;
+    PL_CHECK(key_side(p, &B, nd.bkeys, &bk));
+    if (!bk.rowids) { set_error("ph_plan: the build side of a LEFT join must be a (filtered) base table"); return PH_EUNSUPPORTED; }
+    int32_t flags = 0;
+    int64_t lo = 0, hi = 0;
+    {
+        const auto &kc = B.lanes[0].t->cols[(size_t)B.cols[(size_t)nd.bkeys[0]].tcol];
+        if (nd.bkeys.size() == 1 && kc.has_range && (kc.type == PH_I32 || kc.type == PH_I64)) { flags |= PH_JOIN_KEY_RANGE; lo = kc.min; hi = kc.max; }
+    }
+    ph_join *j = nullptr;
+    PL_CHECK(ph_join_build_ex(ctx, bk.views.data(), (int32_t)nd.bkeys.size(), bk.sel, bk.sel ? B.n : B.lanes[0].t->nrows, flags, lo, hi, &j));
+    p->joins.push_back(j);
+    KeySide pk;
+    PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
+    // pairs
+    int64_t m = 0;
+    int32_t *prow = nullptr, *brow = nullptr;
+    const char *form = "";
+    PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form));
+    // the probe rows without a match
+    void *f = nullptr, *un = nullptr;
+    PL_CHECK(palloc(p, std::max<int64_t>(pk.n, 1) + 64, &f));
+    PL_CHECK(palloc(p, std::max<int64_t>(pk.n, 1) * 4, &un));
+    int64_t u = 0;
+    if (pk.n > 0) {
+        PL_CHECK(ph_join_probe_mark(j, pk.views.data(), pk.sel, pk.n, (uint8_t *)f));
+        ph_col fc{};
+        fc.type = PH_CODE8; fc.data = f;
+        ph_const zero{};
+        zero.type = PH_I32; zero.i = 0;
+        PL_CHECK(ph_filter_select(ctx, &fc, pk.n, PH_EQ, &zero, nullptr, pk.n, (int32_t *)un, &u));   // positions among the probe rows
+    }
+    const int64_t total = m + u;
+    // the unmatched rows in the pair list's terms: with row-id keys the probe rows are row ids of lane 0 (sel[position], or the position itself)
+    const int32_t *un_rows = (const int32_t *)un;
+    if (pk.rowids && pk.sel && u > 0) {
+        ph_col sv{};
+        sv.type = PH_I32; sv.data = pk.sel;
+        void *g = nullptr;
+        PL_CHECK(palloc(p, u * 4, &g));
+        PL_CHECK(ph_gather(ctx, &sv, (const int32_t *)un, u, g));
+        un_rows = (const int32_t *)g;
+    }
+    void *pall = nullptr, *ball = nullptr;
+    PL_CHECK(palloc(p, std::max<int64_t>(total, 1) * 4, &pall));
+    PL_CHECK(palloc(p, std::max<int64_t>(total, 1) * 4, &ball));
+    if (m > 0) {
+        PH_HIP(hipMemcpyAsync(pall, prow, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemcpyAsync(ball, brow, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (u > 0) {
+        PH_HIP(hipMemcpyAsync((int32_t *)pall + m, un_rows, (size_t)u * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        PH_HIP(hipMemsetAsync((int32_t *)ball + m, 0xFF, (size_t)u * 4, ctx->stream));   // row id -1
+    }
+    *out = P;
+    if (pk.rowids) {
+        out->lanes[0].rows = (const int32_t *)pall;
+        out->lanes[0].asc = false;
+        out->lanes[0].dup_free = false;
+        out->n = total;
+    } else {
+        PL_CHECK(compact(p, out, (const int32_t *)pall, total));
+        for (auto &ln : out->lanes) { ln.asc = false; ln.dup_free = false; }
+    }
+    std::vector<PCol> all = out->cols;
+    for (auto &c : all) { c.ordered = false; c.domain = -1; }
+    Lane bl;
+    bl.t = B.lanes[0].t; bl.rows = (const int32_t *)ball; bl.asc = false; bl.dup_free = false; bl.nullable = true;
+    out->lanes.push_back(bl);
+    for (auto c : B.cols) {
+        if (c.lane != 0) { set_error("ph_plan: the build side of a LEFT join must be a (filtered) base table"); return PH_EUNSUPPORTED; }
+        c.lane = (int)out->lanes.size() - 1; c.ordered = false; c.domain = -1;
+        all.push_back(c);
+    }
+    (void)nP;
+    out->cols.clear();
+    for (int32_t oi : nd.out) out->cols.push_back(all[(size_t)oi]);
+    out->covers = false;
+    out->pending.clear(); out->complex.clear(); out->flags = nullptr;
+    drop_unused_lanes(out);
+    note(p, "join#%d: LEFT OUTER: table=%s, %lld pairs + %lld probe rows without a match (their build side NULL)", idx, ph_join_kind(j), (long long)m, (long long)u);
+    return PH_OK;
+}
+
 int lower_node(ph_plan *p, int idx, bool as_build, Rel *out);
 
 // A node that several parents reference (a subtree used twice: Q21's l1 side feeds the pair join and the SEMI / ANTI join that closes
@@ -1475,7 +1585,8 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
         std::vector<int> word_of(nd.groups.size(), -1);
         std::vector<std::pair<int, int>> words;   // (key, partner or -1)
         size_t nwords = nd.groups.size();
-        auto narrow = [&](size_t g) { const PCol &c = S.cols[g]; return (c.type == PH_I32 || c.type == PH_DATE) && !c.validity; };
+        // (a dictionary code counts as narrow: widened to an INTEGER first, ph_widen_codes — Q10 groups by seven columns)
+        auto narrow = [&](size_t g) { const PCol &c = S.cols[g]; return (c.type == PH_I32 || c.type == PH_DATE || c.type == PH_CODE8) && !c.validity; };
         std::vector<bool> used(nd.groups.size(), false);
         if (allow_pack)
             for (size_t g = 0; g < nd.groups.size() && nwords > 4; g++) {
@@ -1503,7 +1614,17 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
                 continue;
             }
             ph_col two[2];
-            for (int t = 0; t < 2; t++) { const int32_t *sx = nullptr; two[t] = col_view(S, S.cols[(size_t)(t ? h : g)], &sx); two[t].type = PH_I32; }   // DATE days as the integers they are
+            for (int t = 0; t < 2; t++) {
+                const int32_t *sx = nullptr;
+                two[t] = col_view(S, S.cols[(size_t)(t ? h : g)], &sx);
+                if (two[t].type == PH_CODE8) {   // codes as INTEGERs
+                    void *w32 = nullptr;
+                    PL_CHECK(palloc(p, std::max<int64_t>(S.n, 1) * 4, &w32));
+                    if (S.n > 0) PL_CHECK(ph_widen_codes(ctx, &two[t], nullptr, S.n, (int32_t *)w32));
+                    two[t].data = w32;
+                }
+                two[t].type = PH_I32;   // DATE days as the integers they are
+            }
             const ph_rpn prog[7] = {{PH_X_COL, 0, 0, 0}, {PH_X_CONST, -1, 1ll << 32, 0}, {PH_X_MUL, -1, 0, 0}, {PH_X_COL, 1, 0, 0}, {PH_X_ADD, -1, 0, 0},
                                     {PH_X_CONST, -1, 1ll << 31, 0}, {PH_X_ADD, -1, 0, 0}};
             void *wv = nullptr;
@@ -1523,8 +1644,10 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
         }
     }
     std::vector<ph_aggspec> specs;
+    uint32_t distinct_mask = 0;   // count(distinct x): COUNT in the main table, fed from a distinct side table (below)
     for (size_t a = 0; a < nd.aggs.size(); a++) {
-        specs.push_back(ph_aggspec{nd.aggs[a].kind, (int32_t)a});
+        if (nd.aggs[a].kind == PH_A_COUNT_DISTINCT) distinct_mask |= 1u << a;
+        specs.push_back(ph_aggspec{nd.aggs[a].kind == PH_A_COUNT_DISTINCT ? (int32_t)PH_A_COUNT : nd.aggs[a].kind, (int32_t)a});
         if (nd.aggs[a].kind == PH_A_COUNT_STAR) { ascale->push_back(0); atype->push_back(PH_I32); continue; }
         const PCol &c = S.cols[ci++];
         const int32_t *s = nullptr;
@@ -1559,12 +1682,52 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
     if ((*aggp)) { ph_agg_free((*aggp)); (*aggp) = nullptr; }
     PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &(*aggp)));
     bool streamed = false;
-    if (!p->conservative && !nd.groups.empty() && S.cols[0].ordered && (*packs)[0].word == 0 && (*packs)[0].part == 0 && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
+    if (!distinct_mask && !p->conservative && !nd.groups.empty() && S.cols[0].ordered && (*packs)[0].word == 0 && (*packs)[0].part == 0 && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
         int rc = ph_agg_sink_sorted((*aggp), keys.data(), args.data(), (int32_t)args.size(), S.n, 0);
         if (rc == PH_OK) streamed = true;
         else if (rc != PH_EUNSUPPORTED) return rc;
     }
-    if (!streamed && S.n > 0) PL_CHECK(ph_agg_sink((*aggp), keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0));
+    if (distinct_mask) {
+        // DISTINCT aggregates (SinkDistinctGrouping / DistinctGrouping, aggregate_exec.go:76-105, 201-304): the raw rows create the groups
+        // and feed the other aggregates (AddChunk's filter); every distinct aggregate has a side table keyed by (group keys, its argument)
+        // whose rows — the distinct combinations — are then sunk into the main table with only that aggregate enabled.
+        const uint32_t all_mask = nd.aggs.size() >= 32 ? 0xFFFFFFFFu : ((1u << nd.aggs.size()) - 1u);
+        if (S.n > 0) PL_CHECK(ph_agg_sink_masked((*aggp), keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0, all_mask & ~distinct_mask));
+        const bool const_key = nd.groups.empty();
+        for (size_t a = 0; a < nd.aggs.size() && S.n > 0; a++) {
+            if (!((distinct_mask >> a) & 1)) continue;
+            if (keys.size() + 1 > 4) { set_error("ph_plan: count(distinct) needs a key word beside the %zu group key words", keys.size()); return PH_EUNSUPPORTED; }
+            std::vector<ph_col> dkeys = keys;
+            std::vector<int32_t> dtypes = key_types;
+            ph_col av = args[a];
+            if (width_of(av.type) == 0) { set_error("ph_plan: count(distinct) over a VARCHAR argument"); return PH_EUNSUPPORTED; }
+            dkeys.push_back(av);
+            dtypes.push_back(av.type);
+            const ph_aggspec star{PH_A_COUNT_STAR, 0};
+            ph_agg *d = nullptr;
+            PL_CHECK(ph_agg_create(ctx, (int32_t)dtypes.size(), dtypes.data(), 1, &star, std::max<int64_t>(S.n / 2, 1024), &d));
+            p->inner_aggs.push_back(d);
+            PL_CHECK(ph_agg_sink(d, dkeys.data(), dkeys.data(), 1, nullptr, S.n, 1, 0));
+            int64_t nd_rows = 0;
+            PL_CHECK(ph_agg_group_count(d, &nd_rows));
+            // the side table's rows as columns again (ph_agg_keys_dev: RadixPartitionedHashTable.GetData for the distinct tables)
+            std::vector<ph_col> rk(dkeys.size());
+            for (size_t k = 0; k < dkeys.size(); k++) {
+                void *kd = nullptr, *kv = nullptr;
+                PL_CHECK(palloc(p, std::max<int64_t>(nd_rows, 1) * 8, &kd));
+                if (dkeys[k].validity) PL_CHECK(palloc(p, (std::max<int64_t>(nd_rows, 1) + 7) / 8 + 64, &kv));
+                int64_t n2 = 0;
+                PL_CHECK(ph_agg_keys_dev(d, (int32_t)k, kd, (uint8_t *)kv, nd_rows, &n2));
+                rk[k] = ph_col{};
+                rk[k].type = dtypes[k]; rk[k].scale = dkeys[k].scale; rk[k].data = kd; rk[k].validity = (const uint8_t *)kv;
+            }
+            std::vector<ph_col> rargs(args.size(), rk.back());   // only aggregate a reads its argument: the distinct values
+            (void)const_key;
+            if (nd_rows > 0) PL_CHECK(ph_agg_sink_masked((*aggp), rk.data(), rargs.data(), (int32_t)rargs.size(), nullptr, nd_rows, 1, 0, 1u << a));
+            note(p, "agg#%d: count(distinct) #%zu through a side table of %lld distinct (keys, argument) rows", idx, a, (long long)nd_rows);
+        }
+        streamed = false;
+    } else if (!streamed && S.n > 0) PL_CHECK(ph_agg_sink((*aggp), keys.data(), args.data(), (int32_t)args.size(), nullptr, S.n, 1, 0));
     note(p, "agg#%d: %s over %lld rows, %zu keys, %zu aggregates", idx, streamed ? "streaming aggregate (rows ordered by the first key)" : "hash aggregate",
          (long long)S.n, nd.groups.size(), nd.aggs.size());
     return PH_OK;
@@ -1600,6 +1763,7 @@ int lower_agg(ph_plan *p) {
         std::vector<ph_aggexpr> ax(nd.aggs.size());
         for (size_t a = 0; a < nd.aggs.size() && ok; a++) {
             ax[a].kind = nd.aggs[a].kind;
+            if (nd.aggs[a].kind == PH_A_COUNT_DISTINCT) { ok = false; break; }
             const ph_plan_expr &e = nd.aggs[a].arg.e;
             if (nd.aggs[a].kind == PH_A_COUNT_STAR) { ax[a].nprog = 0; continue; }
             if (e.kind == PH_PE_COL) { ax[a].nprog = 1; ax[a].prog[0] = ph_rpn{PH_X_COL, R.cols[(size_t)e.col].tcol, 0, 0}; }
@@ -1678,6 +1842,7 @@ int fetch_rows_once(ph_plan *p, ph_rows_result **out) {
             if (pc.sdict) { v = table_view(pc.src, pc.src_col); sel = (const int32_t *)pc.data; }
             else {
                 if (pc.lane < 0) { set_error("ph_plan_fetch_rows: VARCHAR column %d is not a table column", c); return fail(PH_EUNSUPPORTED); }
+                if (R.lanes[(size_t)pc.lane].nullable) { set_error("ph_plan_fetch_rows: VARCHAR column %d of the NULL-able side of a LEFT join", c); return fail(PH_EUNSUPPORTED); }
                 v = table_view(R.lanes[(size_t)pc.lane].t, pc.tcol);
                 sel = R.lanes[(size_t)pc.lane].rows;
             }
@@ -1763,12 +1928,16 @@ int fetch_once(ph_plan *p, ph_agg_result **out) {
         if (rc == PH_ECAPACITY && ng > room) { room = ng; continue; }
         PL_CHECK(rc);
         ph_agg_result *r = new_result(ng, nkeys, naggs);
+        bool any_null = false;
+        for (size_t i = 0; i < (size_t)ng * (size_t)nw; i++) any_null |= knull[i] != 0;
+        if (any_null) r->key_null = (uint8_t *)calloc((size_t)std::max<int64_t>(ng, 1) * (size_t)nk, 1);
         for (int64_t g = 0; g < ng; g++) {
             r->first_row[g] = first[(size_t)g];
             for (int k = 0; k < nkeys; k++) {
                 const KeyPack kp = p->key_packs[(size_t)k];
                 const int64_t w = keys[(size_t)(g * nw + kp.word)];
                 r->keys[g * nk + k] = kp.part == 0 ? w : kp.part == 1 ? (w >> 32) : (int64_t)(uint32_t)w - (1ll << 31);
+                if (any_null && kp.part == 0 && knull[(size_t)(g * nw + kp.word)]) { r->key_null[g * nk + k] = 1; r->keys[g * nk + k] = 0; }
             }
             for (int a = 0; a < naggs; a++) {
                 r->sum_lo[g * naggs + a] = lo[(size_t)(g * naggs + a)];
@@ -1813,7 +1982,7 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
             break;
         case PH_PN_JOIN:
             if (s.child[0] < 0 || s.child[1] < 0 || s.nkeys < 1 || s.nkeys > 4 || !s.probe_keys || !s.build_keys || s.nout < 0 || (s.nout && !s.out) ||
-                s.join_type < PH_JT_INNER || s.join_type > PH_JT_ANTI) { set_error("ph_plan_create: node %d: bad join", i); return fail(PH_EINVAL); }
+                s.join_type < PH_JT_INNER || s.join_type > PH_JT_LEFT) { set_error("ph_plan_create: node %d: bad join", i); return fail(PH_EINVAL); }
             n.join_type = s.join_type;
             n.pkeys.assign(s.probe_keys, s.probe_keys + s.nkeys);
             n.bkeys.assign(s.build_keys, s.build_keys + s.nkeys);

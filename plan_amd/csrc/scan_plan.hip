@@ -875,7 +875,7 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
 
 extern "C" void ph_agg_result_free(ph_agg_result *r) {
     if (!r) return;
-    free(r->first_row); free(r->keys); free(r->sum_lo); free(r->sum_hi); free(r->count); free(r->scale);
+    free(r->first_row); free(r->keys); free(r->sum_lo); free(r->sum_hi); free(r->count); free(r->scale); free(r->key_null);
     free(r);
 }
 

@@ -14,7 +14,7 @@ PH_OK, PH_EINVAL, PH_EHIP, PH_EUNSUPPORTED, PH_EOVERFLOW, PH_ECAPACITY, PH_ECONS
 PH_I32, PH_I64, PH_DATE, PH_DEC64, PH_CODE8, PH_F32, PH_F64, PH_STR = range(1, 9)
 PH_EQ, PH_NE, PH_LT, PH_LE, PH_GT, PH_GE, PH_LIKE, PH_NOTLIKE = range(1, 9)
 PH_X_COL, PH_X_CONST, PH_X_ADD, PH_X_SUB, PH_X_MUL = range(1, 6)
-PH_A_SUM, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR = range(1, 7)
+PH_A_SUM, PH_A_AVG, PH_A_COUNT, PH_A_MIN, PH_A_MAX, PH_A_COUNT_STAR, PH_A_COUNT_DISTINCT = range(1, 8)
 PH_COMM_ID_BYTES = 128
 PH_RED_SUM, PH_RED_MAX, PH_RED_MIN = 1, 2, 3
 
@@ -60,7 +60,7 @@ class AggResult(ctypes.Structure):
     _fields_ = [("ngroups", i64), ("first_row", ctypes.POINTER(i64)), ("keys", ctypes.POINTER(i64)),
                 ("sum_lo", ctypes.POINTER(ctypes.c_uint64)), ("sum_hi", ctypes.POINTER(i64)),
                 ("count", ctypes.POINTER(ctypes.c_uint64)), ("scale", ctypes.POINTER(i32)),
-                ("nkeys", i32), ("naggs", i32)]
+                ("nkeys", i32), ("naggs", i32), ("key_null", ctypes.POINTER(ctypes.c_uint8))]
 
 
 class RowsResult(ctypes.Structure):
@@ -307,6 +307,8 @@ def _result(rp):
         "sum": [[(int(r.sum_hi[g * na + a]) << 64) + int(r.sum_lo[g * na + a]) for a in range(na)]
                 for g in range(ng)],
         "count": [[int(r.count[g * na + a]) for a in range(na)] for g in range(ng)],
+        # 1 = the group's key is NULL (None when the result has no NULL-able key)
+        "key_null": np.array([r.key_null[i] for i in range(ng * nk)], dtype=np.uint8).reshape(ng, nk) if r.key_null else None,
     }
     lib().ph_agg_result_free(rp)
     return out
@@ -814,7 +816,7 @@ def cross_pairs(ctx, n_left, n_right):
 # ---------------------------------------------------------------- resident plans (ph_plan_*)
 
 PH_PN_SCAN, PH_PN_FILTER, PH_PN_JOIN, PH_PN_PROJECT, PH_PN_AGG = range(1, 6)
-PH_JT_INNER, PH_JT_SEMI, PH_JT_ANTI = 1, 2, 3
+PH_JT_INNER, PH_JT_SEMI, PH_JT_ANTI, PH_JT_LEFT = 1, 2, 3, 4
 PH_PE_COL, PH_PE_DECIMAL, PH_PE_YEAR = 1, 2, 3
 PH_STAT_ASCENDING, PH_STAT_STRICT, PH_STAT_DECLARED_UNIQUE = 1, 2, 4
 

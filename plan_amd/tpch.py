@@ -23,14 +23,16 @@ SCHEMA = {
                  ("l_linenumber", hip.PH_I32, 0, None)],
     "orders": [("o_orderkey", hip.PH_I64, 0, None), ("o_custkey", hip.PH_I32, 0, None), ("o_orderdate", hip.PH_DATE, 0, None),
                ("o_shippriority", hip.PH_I32, 0, None), ("o_orderpriority", hip.PH_CODE8, 0, tpchgen.ORDERPRIORITY_DICT),
-               ("o_totalprice", hip.PH_DEC64, 2, None), ("o_orderstatus", hip.PH_CODE8, 0, tpchgen.ORDERSTATUS_DICT)],
+               ("o_totalprice", hip.PH_DEC64, 2, None), ("o_orderstatus", hip.PH_CODE8, 0, tpchgen.ORDERSTATUS_DICT), ("o_comment", hip.PH_STR, 0, None)],
     "customer": [("c_custkey", hip.PH_I32, 0, None), ("c_nationkey", hip.PH_I32, 0, None), ("c_mktsegment", hip.PH_CODE8, 0, tpchgen.MKTSEGMENT_DICT),
-                 ("c_name", hip.PH_STR, 0, None), ("c_phone", hip.PH_STR, 0, None), ("c_acctbal", hip.PH_DEC64, 2, None)],
+                 ("c_name", hip.PH_STR, 0, None), ("c_phone", hip.PH_STR, 0, None), ("c_acctbal", hip.PH_DEC64, 2, None),
+                 ("c_address", hip.PH_STR, 0, None), ("c_comment", hip.PH_STR, 0, None)],
     "part": [("p_partkey", hip.PH_I32, 0, None), ("p_name", hip.PH_STR, 0, None), ("p_brand", hip.PH_CODE8, 0, "part_brand"),
-             ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container")],
+             ("p_type", hip.PH_CODE8, 0, "part_type"), ("p_size", hip.PH_I32, 0, None), ("p_container", hip.PH_CODE8, 0, "part_container"),
+             ("p_mfgr", hip.PH_CODE8, 0, tpchgen.MFGR_DICT)],
     "partsupp": [("ps_partkey", hip.PH_I32, 0, None), ("ps_suppkey", hip.PH_I32, 0, None), ("ps_supplycost", hip.PH_DEC64, 2, None), ("ps_availqty", hip.PH_I32, 0, None)],
     "supplier": [("s_suppkey", hip.PH_I32, 0, None), ("s_nationkey", hip.PH_I32, 0, None), ("s_name", hip.PH_STR, 0, None),
-                 ("s_address", hip.PH_STR, 0, None), ("s_phone", hip.PH_STR, 0, None)],
+                 ("s_address", hip.PH_STR, 0, None), ("s_phone", hip.PH_STR, 0, None), ("s_acctbal", hip.PH_DEC64, 2, None), ("s_comment", hip.PH_STR, 0, None)],
     "nation": [("n_nationkey", hip.PH_I32, 0, None), ("n_name", hip.PH_CODE8, 0, "nation_names"), ("n_regionkey", hip.PH_I32, 0, None)],
     "region": [("r_regionkey", hip.PH_I32, 0, None), ("r_name", hip.PH_CODE8, 0, "region_names")],
 }
@@ -709,4 +711,125 @@ def q18_text(db, p, r, limit=100):
     for name, (_c, ck, ok, od, tp, q) in rows:
         d = datetime.date(1970, 1, 1) + datetime.timedelta(days=od)
         out.append(f"{name}\t{ck}\t{ok}\t{d.isoformat()}\t{dec_text(tp, 2)}\t{q}")
+    return "\n".join(out) + "\n"
+
+
+# ---------------------------------------------------------------- round 4: Q16, Q13, Q2, Q10 — the queries that read the generator's COMMENT text
+
+Q16_SIZES = (14, 7, 21, 24, 35, 33, 2, 20)
+
+
+def q16_plan(db, brand_ne="Brand#35", type_notlike="ECONOMY BURNISHED%", sizes=Q16_SIZES, comment_like="%Customer%Complaints%"):
+    """cases/tpch/query/q16.sql: Agg(p_brand, p_type, p_size; count(DISTINCT ps_suppkey)) <- ANTI Join(ps_suppkey = s_suppkey) [NOT IN]
+       probe Join(ps_partkey = p_partkey) probe partsupp, build part[p_brand <> .., p_type NOT LIKE .., p_size IN (..)];
+       build supplier[s_comment LIKE '%Customer%Complaints%'] — PH_A_COUNT_DISTINCT: the library keeps the distinct side table"""
+    p = hip.Plan(db.ctx)
+    ty, sz = db.c("part", "p_type", "p_size")
+    part = p.scan(db.t("part"), db.c("part", "p_partkey", "p_brand", "p_type", "p_size"), [_pred(db, "part", "p_brand", hip.PH_NE, _s(brand_ne))],
+                  bools=hip.bool_tree(("and", ("cmp", ty, hip.PH_NOTLIKE, _s(type_notlike)), ("in", sz, [_k(hip.PH_I32, i=v) for v in sizes]))))
+    ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_suppkey"))
+    j1 = p.join(ps, part, [0], [0], [1, 3, 4, 5])                                              # ps_suppkey, p_brand, p_type, p_size
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey"), [_pred(db, "supplier", "s_comment", hip.PH_LIKE, _s(comment_like))])
+    j2 = p.join(j1, supp, [0], [0], [0, 1, 2, 3], join_type=hip.PH_JT_ANTI)
+    p.agg(j2, [hip.pe_col(1), hip.pe_col(2), hip.pe_col(3)], [(hip.PH_A_COUNT_DISTINCT, hip.pe_col(0))])
+    return p.create()
+
+
+def q16_text(r):
+    """ORDER BY supplier_cnt DESC, p_brand, p_type, p_size + the reference's text"""
+    bd, td = tpchgen.part_brand_dict(), tpchgen.part_type_dict()
+    rows = sorted(((bd[int(r["keys"][g][0])], td[int(r["keys"][g][1])], int(r["keys"][g][2]), r["count"][g][0]) for g in range(r["ngroups"])),
+                  key=lambda x: (-x[3], x[0], x[1], x[2]))
+    return "#\t\t\t\n" + "".join(f"{b}\t{t}\t{s}\t{c}\n" for b, t, s, c in rows)
+
+
+def q13_plan(db, notlike="%pending%accounts%"):
+    """cases/tpch/query/q13.sql: Agg(c_count; count(*)) <- Agg(c_custkey; count(o_orderkey)) <- LEFT Join(c_custkey = o_custkey) probe customer,
+       build orders[o_comment NOT LIKE ..]. count() over the NULL-extended side is 0 for a customer without orders and finalises to NULL
+       (CountOp.Finalize): the NULL is the group key of the aggregate above (key_null in the result)"""
+    p = hip.Plan(db.ctx)
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey"))
+    orders = p.scan(db.t("orders"), db.c("orders", "o_custkey", "o_orderkey"), [_pred(db, "orders", "o_comment", hip.PH_NOTLIKE, _s(notlike))])
+    j = p.join(cust, orders, [0], [0], [0, 2], join_type=hip.PH_JT_LEFT)                       # c_custkey, o_orderkey (NULL without a match)
+    inner = p.agg(j, [hip.pe_col(0)], [(hip.PH_A_COUNT, hip.pe_col(1))])                       # c_custkey, c_count
+    p.agg(inner, [hip.pe_col(1)], [(hip.PH_A_COUNT_STAR, None)])
+    return p.create()
+
+
+def q13_text(r):
+    """ORDER BY custdist DESC, c_count DESC (NULLs first) + the reference's text"""
+    kn = r.get("key_null")
+    rows = [(None if kn is not None and kn[g][0] else int(r["keys"][g][0]), r["count"][g][0]) for g in range(r["ngroups"])]
+    rows.sort(key=lambda x: (-x[1], 0 if x[0] is None else 1, -(x[0] or 0)))
+    return "#\t\n" + "".join(f"{'NULL' if k is None else k}\t{c}\n" for k, c in rows)
+
+
+def q2_plan(db, size=48, type_like="%TIN", region="MIDDLE EAST"):
+    """cases/tpch/query/q2.sql as ONE plan whose root is the final join (ph_plan_fetch_rows). The correlated min(ps_supplycost) is an
+       aggregate by ps_partkey over partsupp x supplier x nation x region[r_name = ..] — the same subtree the outer branch joins with part, a
+       node with two parents — joined back on (ps_partkey, ps_supplycost = min): DECIMAL `=` runs as the hash join the reference runs it as.
+       Rows: s_acctbal, s_name, n_name, p_partkey, p_mfgr, s_address, s_phone, s_comment"""
+    p = hip.Plan(db.ctx)
+    reg = p.scan(db.t("region"), db.c("region", "r_regionkey"), [_pred(db, "region", "r_name", hip.PH_EQ, _s(region))])
+    nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name", "n_regionkey"))
+    jn = p.join(nat, reg, [2], [0], [0, 1])                                                    # n_nationkey, n_name
+    supp = p.scan(db.t("supplier"), db.c("supplier", "s_suppkey", "s_nationkey", "s_acctbal", "s_name", "s_address", "s_phone", "s_comment"))
+    js = p.join(supp, jn, [1], [0], [0, 2, 3, 4, 5, 6, 8])                                     # s_suppkey, s_acctbal, s_name, s_address, s_phone, s_comment, n_name
+    ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_suppkey", "ps_supplycost"))
+    jps = p.join(ps, js, [1], [0], [0, 2, 4, 5, 6, 7, 8, 9])                                   # ps_partkey, ps_supplycost, s_acctbal, s_name, s_address, s_phone, s_comment, n_name
+    sub = p.agg(jps, [hip.pe_col(0)], [(hip.PH_A_MIN, hip.pe_col(1))])                         # ps_partkey, min(ps_supplycost)
+    ty = db.c("part", "p_type")[0]
+    part = p.scan(db.t("part"), db.c("part", "p_partkey", "p_mfgr"), [_pred(db, "part", "p_size", hip.PH_EQ, _k(hip.PH_I32, i=size))],
+                  bools=hip.bool_tree(("cmp", ty, hip.PH_LIKE, _s(type_like))))
+    jp = p.join(jps, part, [0], [0], [0, 1, 2, 3, 4, 5, 6, 7, 9])                              # + p_mfgr
+    p.join(jp, sub, [0, 1], [0, 1], [2, 3, 7, 0, 8, 4, 5, 6])
+    return p.create()
+
+
+def q2_text(r, limit=100):
+    """ORDER BY s_acctbal DESC, n_name, s_name, p_partkey LIMIT 100 + the reference's text over ph_plan_fetch_rows' columns"""
+    bal, name, nat, pk, mf, addr, phone, cmnt = r["columns"]
+    nn = tpchgen.nation_names()
+    rows = sorted(range(r["nrows"]), key=lambda i: (-int(bal[i]), nn[int(nat[i])], name[i], int(pk[i])))[:limit]
+    return "#\t\t\t\t\t\t\t\n" + "".join(
+        f"{dec_text(int(bal[i]), 2)}\t{name[i]}\t{nn[int(nat[i])]}\t{int(pk[i])}\t{tpchgen.MFGR_DICT[int(mf[i])]}\t{addr[i]}\t{phone[i]}\t{cmnt[i]}\n" for i in rows)
+
+
+def q10_plan(db, flag="R", d1=None, d2=None, topk=20):
+    """cases/tpch/query/q10.sql: Agg(c_custkey, c_name, c_acctbal, c_phone, n_name, c_address, c_comment; sum(l_extendedprice * (1 - l_discount)))
+       over lineitem[l_returnflag = 'R'] x orders[one quarter] x customer x nation, ORDER BY revenue DESC LIMIT 20 announced as a top-k.
+       Seven group keys, four of them VARCHAR columns that are no small dictionaries: interned on the device, narrow keys (INTEGER, string
+       codes, dictionary codes) packed two per key word"""
+    d1 = tpchgen.days(1993, 3, 1) if d1 is None else d1
+    d2 = tpchgen.days(1993, 6, 1) if d2 is None else d2
+    p = hip.Plan(db.ctx)
+    orders = p.scan(db.t("orders"), db.c("orders", "o_orderkey", "o_custkey"),
+                    [_pred(db, "orders", "o_orderdate", hip.PH_GE, _k(hip.PH_DATE, i=d1)), _pred(db, "orders", "o_orderdate", hip.PH_LT, _k(hip.PH_DATE, i=d2))])
+    line = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_extendedprice", "l_discount"), [_pred(db, "lineitem", "l_returnflag", hip.PH_EQ, _s(flag))])
+    j1 = p.join(line, orders, [0], [0], [1, 2, 4])                                             # ext, disc, o_custkey
+    cust = p.scan(db.t("customer"), db.c("customer", "c_custkey", "c_name", "c_acctbal", "c_phone", "c_nationkey", "c_address", "c_comment"))
+    j2 = p.join(j1, cust, [2], [0], [0, 1, 3, 4, 5, 6, 7, 8, 9])                               # ext, disc, c_custkey, c_name, c_acctbal, c_phone, c_nationkey, c_address, c_comment
+    nat = p.scan(db.t("nation"), db.c("nation", "n_nationkey", "n_name"))
+    j3 = p.join(j2, nat, [6], [0], [0, 1, 2, 3, 4, 5, 10, 7, 8])                               # ext, disc, c_custkey, c_name, c_acctbal, c_phone, n_name, c_address, c_comment
+    revenue = hip.pe_dec([hip.X_COL(0), hip.X_CONST(1), hip.X_COL(1), hip.X_SUB, hip.X_MUL])
+    p.agg(j3, [hip.pe_col(c) for c in (2, 3, 4, 5, 6, 7, 8)], [(hip.PH_A_SUM, revenue)])
+    p.create()
+    if topk:
+        p.set_topk(0, topk, descending=True)
+    return p
+
+
+def q10_text(db, p, r, limit=20):
+    """ORDER BY revenue DESC LIMIT 20 + the reference's text; the VARCHAR keys come back as rows of customer's columns"""
+    order = sorted(range(r["ngroups"]), key=lambda g: (-r["sum"][g][0], int(r["keys"][g][0])))[:limit]
+    strs = {}
+    for k in (1, 3, 5, 6):
+        typ, _sc, _t, col = hip.plan_key_info(p, k)
+        assert typ == hip.PH_STR
+        strs[k] = hip.table_strings(db.ctx, db.t("customer"), col, [int(r["keys"][g][k]) for g in order])
+    nn = tpchgen.nation_names()
+    out = ["#\t\t\t\t\t\t\t"]
+    for i, g in enumerate(order):
+        k = r["keys"][g]
+        out.append(f"{int(k[0])}\t{strs[1][i]}\t{dec_text(r['sum'][g][0], 4)}\t{dec_text(int(k[2]), 2)}\t{nn[int(k[4])]}\t{strs[5][i]}\t{strs[3][i]}\t{strs[6][i]}")
     return "\n".join(out) + "\n"

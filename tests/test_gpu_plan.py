@@ -591,3 +591,62 @@ def test_colocate_budget_is_the_hosts_veto(sf1):
     assert 0 < l2.colocate_bytes() <= 1 << 30
     db.free(); db2.free()
     ctx.close()
+
+
+# ---- round 4: the last four reference goldens (the queries that read the generator's COMMENT text)
+
+def test_q16_count_distinct_and_not_in_match_golden(ctx, db, sf1):
+    """Q16: PH_A_COUNT_DISTINCT (a distinct side table inside the library, re-sunk into the aggregate: SinkDistinctGrouping /
+    DistinctGrouping), NOT IN as an ANTI join, `<>` / NOT LIKE / IN over dictionary columns, LIKE '%Customer%Complaints%' over the
+    suppliers' generated comments: 18 341 groups, cases/tpch/1g/plan/q16.txt byte for byte"""
+    p = tpch.q16_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert "count(distinct)" in ex, ex
+    assert tpch.q16_text(r) == golden("plan_q16.txt"), ex
+    rows, n = O.q16_rows(sf1)
+    assert r["ngroups"] == n == 18341
+
+
+def test_q13_left_join_and_null_count_key_match_golden(ctx, db, sf1):
+    """Q13: PH_JT_LEFT (NextLeftJoin), count(o_orderkey) over the NULL-extended side, the count's NULL-for-zero as the GROUP KEY of the
+    aggregate above (key_null in the result: the golden's first row is NULL\t50005), NOT LIKE with two '%' over 1.5 M order comments"""
+    p = tpch.q13_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    p.free()
+    assert "LEFT OUTER" in ex, ex
+    assert r["key_null"] is not None and int(r["key_null"].sum()) == 1
+    assert tpch.q13_text(r) == golden("plan_q13.txt"), ex
+    # ... and the specification's default pattern: the publicly known answer's first rows
+    p = tpch.q13_plan(db, notlike="%special%requests%")
+    p.run()
+    r = p.fetch()
+    p.free()
+    assert tpch.q13_text(r) == O.q13_text(sf1, notlike="%special%requests%")
+    assert tpch.q13_text(r).split("\n")[1:4] == ["NULL\t50005", "9\t6641", "10\t6532"]
+
+
+def test_q2_minimum_joined_back_with_text_columns_matches_golden(ctx, db):
+    """Q2 as ONE join-rooted plan: the correlated min() as an aggregate by its key over a subtree with two parents, joined back on (key,
+    DECIMAL value); four VARCHAR columns of supplier (s_comment from the text pool) gathered on the device for the 100 rows"""
+    p = tpch.q2_plan(db)
+    p.run()
+    r = p.fetch_rows()
+    ex = p.explain()
+    p.free()
+    assert tpch.q2_text(r) == golden("plan_q2.txt"), ex
+
+
+def test_q10_seven_group_keys_match_golden(ctx, db):
+    """Q10: seven group keys — four VARCHAR columns interned on the device, narrow keys packed two per key word (a dictionary code widened to
+    an INTEGER for it) — top-k preselection for ORDER BY revenue DESC LIMIT 20; c_address / c_comment come back as rows of their columns"""
+    p = tpch.q10_plan(db)
+    p.run()
+    r = p.fetch()
+    ex = p.explain()
+    assert tpch.q10_text(db, p, r) == golden("plan_q10.txt"), ex
+    p.free()
