@@ -475,7 +475,7 @@ std::string BuildAggOutput(const std::vector<LType> &outTypes, const std::vector
                     if (dec) { Decimal d; if (!DecimalQuoCount(sum, argScales[(size_t)a], n, &d)) return "decimal average failed"; v.Slice<Decimal>()[r] = d; }
                     else v.Slice<double>()[r] = (double)sum / (double)n;
                     break;
-                case PH_A_COUNT: case PH_A_COUNT_STAR:  // CountOp.Finalize: NULL when 0 (:950-962)
+                case PH_A_COUNT: case PH_A_COUNT_STAR: case PH_A_COUNT_DISTINCT:  // CountOp.Finalize: NULL when 0 (:950-962)
                     if (n == 0) { null(); break; }
                     v.Slice<Hugeint>()[r] = Hugeint{n, 0};
                     break;
@@ -1409,7 +1409,6 @@ int ResidentPlan::Join(int probe, int build, std::vector<int> probeKeys, std::ve
         n.types.push_back(all[(size_t)o]);
         n.source.push_back(src[(size_t)o]);
     }
-    if (type == JoinLeft && error.empty()) error = "LEFT joins stay with gpuJoinExecutor";
     n.probeKeys = std::move(probeKeys); n.buildKeys = std::move(buildKeys); n.out = std::move(out);
     nodes.push_back(std::move(n));
     return (int)nodes.size() - 1;
@@ -1471,7 +1470,7 @@ int ResidentPlan::Agg(int child, std::vector<ProjExpr> groups, std::vector<AggEx
         switch (a.kind) {
         case PH_A_SUM: n.types.push_back(dec ? DecimalType(38, scale) : HugeintType()); break;      // BindDecimalSum / GetSumAggr
         case PH_A_AVG: n.types.push_back(dec ? DecimalType(38, scale) : DoubleType()); break;       // BindDecimalAvg / GetAvgAggr
-        case PH_A_COUNT: case PH_A_COUNT_STAR: n.types.push_back(HugeintType()); break;
+        case PH_A_COUNT: case PH_A_COUNT_STAR: case PH_A_COUNT_DISTINCT: n.types.push_back(HugeintType()); break;
         case PH_A_MIN: case PH_A_MAX: n.types.push_back(dec ? DecimalType(at.Width, scale) : at); break;
         default: if (error.empty()) error = "unknown aggregate kind"; n.types.push_back(at);
         }
@@ -1618,7 +1617,7 @@ std::string gpuResidentPlanExecutor::Init() {
             break;
         case PH_PN_JOIN:
             if (n.probeKeys.size() != n.buildKeys.size() || n.probeKeys.empty()) return "join needs matching key lists";
-            d.join_type = n.joinType == JoinSemi ? PH_JT_SEMI : n.joinType == JoinAnti ? PH_JT_ANTI : PH_JT_INNER;
+            d.join_type = n.joinType == JoinSemi ? PH_JT_SEMI : n.joinType == JoinAnti ? PH_JT_ANTI : n.joinType == JoinLeft ? PH_JT_LEFT : PH_JT_INNER;
             d.nkeys = (int32_t)n.probeKeys.size();
             d.probe_keys = keep(n.probeKeys);
             d.build_keys = keep(n.buildKeys);
@@ -1755,7 +1754,7 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
         }
         std::vector<int> kinds, scales;
         for (size_t i = 0; i < root.aggs.size(); i++) { kinds.push_back(root.aggs[i].kind); scales.push_back(r->scale[i]); }
-        std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, nullptr, r->sum_lo, r->sum_hi,
+        std::string e = BuildAggOutput(outTypes_, keyTypes, dicts, kinds, argType_, scales, r->ngroups, r->keys, r->key_null, r->sum_lo, r->sum_hi,
                                        r->count, &results_);
         ph_agg_result_free(r);
         if (e.empty()) e = ApplyAggOutputPhase(ctx_, havingDone ? std::vector<Compare>{} : having_, outputs_, outTypes_, finalTypes_, &results_);

@@ -47,6 +47,21 @@ std::string loadTable(ph_ctx *ctx, const std::vector<HostCol> &cols, int64_t n, 
     return "";
 }
 
+// the generator's fixed-stride characters + lengths as offsets + bytes (a PH_STR column)
+void packStrings(const std::vector<char> &fixed, int stride, const std::vector<uint8_t> &len, std::vector<int32_t> *off, std::string *bytes) {
+    const size_t n = len.size();
+    off->assign(n + 1, 0);
+    size_t total = 0;
+    for (size_t r = 0; r < n; r++) total += len[r];
+    bytes->clear();
+    bytes->reserve(total);
+    for (size_t r = 0; r < n; r++) {
+        bytes->append(fixed.data() + r * (size_t)stride, len[r]);
+        (*off)[r + 1] = (int32_t)bytes->size();
+    }
+}
+HostCol STR(const std::vector<int32_t> &off, const std::string &bytes) { return HostCol{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()}; }
+
 HostCol I32(const void *d) { return HostCol{IntegerType(), PH_I32, 0, d, {}, nullptr, 0}; }
 HostCol I64(const void *d) { return HostCol{BigintType(), PH_I64, 0, d, {}, nullptr, 0}; }
 HostCol DEC(const void *d) { return HostCol{DecimalType(15, 2), PH_DEC64, 2, d, {}, nullptr, 0}; }
@@ -87,15 +102,20 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
     {   // orders
         std::vector<int64_t> okey((size_t)no), total((size_t)no);
         std::vector<int32_t> cust((size_t)no), date((size_t)no), sprio((size_t)no);
-        std::vector<uint8_t> oprio((size_t)no), ostat((size_t)no);
+        std::vector<uint8_t> oprio((size_t)no), ostat((size_t)no), clen((size_t)no);
+        std::vector<char> cmnt((size_t)no * TPCHGEN_O_COMMENT_STRIDE);
         tpchgen_orders_cols oc{};
         oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data(); oc.o_totalprice = total.data();
-        oc.o_orderstatus = ostat.data();
+        oc.o_orderstatus = ostat.data(); oc.o_comment = cmnt.data(); oc.o_comment_len = clen.data();
         tpchgen_orders(num, den, 0, no, &oc);
+        std::vector<int32_t> coff;
+        std::string cbytes;
+        packStrings(cmnt, TPCHGEN_O_COMMENT_STRIDE, clen, &coff, &cbytes);   // o_comment: 19..78 characters of the generator's text pool (Q13's NOT LIKE)
+        std::vector<char>().swap(cmnt);
         for (auto &b : ostat) b = b == 'F' ? 0 : b == 'O' ? 1 : 2;   // the generator writes the raw byte: codes into {"F", "O", "P"}
         generate_s += now_s() - t0; t0 = now_s();
         e = loadTable(ctx, {I64(okey.data()), I32(cust.data()), DATE(date.data()), I32(sprio.data()), CODE(oprio.data(), dictOf(TPCHGEN_ORDERPRIORITY_DICT, 5)),
-                            DEC(total.data()), CODE(ostat.data(), {"F", "O", "P"})}, no, {O_ORDERKEY}, &orders, &loaded_bytes);
+                            DEC(total.data()), CODE(ostat.data(), {"F", "O", "P"}), STR(coff, cbytes)}, no, {O_ORDERKEY}, &orders, &loaded_bytes);
         if (!e.empty()) return e;
         load_s += now_s() - t0; t0 = now_s();
     }
@@ -105,9 +125,16 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         std::vector<char> phone((size_t)nc * TPCHGEN_S_PHONE_LEN);
         std::vector<int64_t> bal((size_t)nc);
         std::vector<int32_t> poff((size_t)nc + 1);
+        std::vector<char> addr((size_t)nc * TPCHGEN_S_ADDRESS_STRIDE), cmnt((size_t)nc * TPCHGEN_C_COMMENT_STRIDE);
+        std::vector<uint8_t> alen((size_t)nc), clen((size_t)nc);
         tpchgen_customer_cols cc{};
         cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data(); cc.c_phone = phone.data(); cc.c_acctbal = bal.data();
+        cc.c_address = addr.data(); cc.c_address_len = alen.data(); cc.c_comment = cmnt.data(); cc.c_comment_len = clen.data();
         tpchgen_customer(num, den, 0, nc, &cc);
+        std::vector<int32_t> aoff, coff;
+        std::string abytes, cbytes;
+        packStrings(addr, TPCHGEN_S_ADDRESS_STRIDE, alen, &aoff, &abytes);     // c_address / c_comment: Q10's select list
+        packStrings(cmnt, TPCHGEN_C_COMMENT_STRIDE, clen, &coff, &cbytes);
         for (int64_t r = 0; r <= nc; r++) poff[(size_t)r] = (int32_t)(r * TPCHGEN_S_PHONE_LEN);
         HostCol phoneCol{VarcharType(), PH_STR, 0, poff.data(), {}, phone.data(), (int64_t)phone.size()};
         // c_name = 'Customer#' + the key as nine digits (TPC-H 4.2.3): 1.5 M distinct strings at SF10, so offsets + bytes, no dictionary
@@ -122,15 +149,16 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         }
         off[(size_t)nc] = (int32_t)(nc * 18);
         HostCol name{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()};
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5)), name, phoneCol, DEC(bal.data())}, nc, {C_CUSTKEY}, &customer,
-                      &loaded_bytes);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), CODE(seg.data(), dictOf(TPCHGEN_MKTSEGMENT_DICT, 5)), name, phoneCol, DEC(bal.data()), STR(aoff, abytes),
+                            STR(coff, cbytes)}, nc, {C_CUSTKEY}, &customer, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // part: p_name as offsets + bytes (LIKE operand), the other VARCHAR columns as dictionary codes
         std::vector<int32_t> key((size_t)np), size((size_t)np), off((size_t)np + 1);
-        std::vector<uint8_t> colors((size_t)np * 5), brand((size_t)np), type((size_t)np), cntr((size_t)np);
+        std::vector<uint8_t> colors((size_t)np * 5), brand((size_t)np), type((size_t)np), cntr((size_t)np), mfgr((size_t)np);
         tpchgen_part_cols pc{};
         pc.p_partkey = key.data(); pc.p_name_colors = colors.data(); pc.p_brand = brand.data(); pc.p_type = type.data(); pc.p_size = size.data(); pc.p_container = cntr.data();
+        pc.p_mfgr = mfgr.data();
         tpchgen_part(num, den, 0, np, &pc);
         std::string bytes;
         for (int64_t r = 0; r < np; r++) {
@@ -140,7 +168,8 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         off[(size_t)np] = (int32_t)bytes.size();
         HostCol name{VarcharType(), PH_STR, 0, off.data(), {}, bytes.data(), (int64_t)bytes.size()};
         e = loadTable(ctx, {I32(key.data()), name, CODE(brand.data(), dictOf(tpchgen_part_brand_dict(), 25)), CODE(type.data(), dictOf(tpchgen_part_type_dict(), 150)),
-                            I32(size.data()), CODE(cntr.data(), dictOf(tpchgen_part_container_dict(), 40))}, np, {P_PARTKEY}, &part, &loaded_bytes);
+                            I32(size.data()), CODE(cntr.data(), dictOf(tpchgen_part_container_dict(), 40)),
+                            CODE(mfgr.data(), {"Manufacturer#1", "Manufacturer#2", "Manufacturer#3", "Manufacturer#4", "Manufacturer#5"})}, np, {P_PARTKEY}, &part, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // partsupp
@@ -155,10 +184,16 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
     {   // supplier
         std::vector<int32_t> key((size_t)ns), nat((size_t)ns);
         std::vector<char> addr((size_t)ns * TPCHGEN_S_ADDRESS_STRIDE), phone((size_t)ns * TPCHGEN_S_PHONE_LEN);
-        std::vector<uint8_t> alen((size_t)ns);
+        std::vector<uint8_t> alen((size_t)ns), clen((size_t)ns);
+        std::vector<char> cmnt((size_t)ns * TPCHGEN_S_COMMENT_STRIDE);
+        std::vector<int64_t> bal((size_t)ns);
         tpchgen_supplier_cols sc{};
         sc.s_suppkey = key.data(); sc.s_nationkey = nat.data(); sc.s_address = addr.data(); sc.s_address_len = alen.data(); sc.s_phone = phone.data();
+        sc.s_acctbal = bal.data(); sc.s_comment = cmnt.data(); sc.s_comment_len = clen.data();
         tpchgen_supplier(num, den, 0, ns, &sc);
+        std::vector<int32_t> coff;
+        std::string cbytes;
+        packStrings(cmnt, TPCHGEN_S_COMMENT_STRIDE, clen, &coff, &cbytes);   // s_comment with the "Customer ... Complaints" injection (Q16, Q2)
         std::vector<int32_t> aoff((size_t)ns + 1, 0), poff((size_t)ns + 1);
         std::string abytes;
         for (int64_t r = 0; r < ns; r++) {
@@ -180,7 +215,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         }
         noff[(size_t)ns] = (int32_t)(ns * 18);
         HostCol sname{VarcharType(), PH_STR, 0, noff.data(), {}, nbytes.data(), (int64_t)nbytes.size()};
-        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), sname, saddr, sphone}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
+        e = loadTable(ctx, {I32(key.data()), I32(nat.data()), sname, saddr, sphone, DEC(bal.data()), STR(coff, cbytes)}, ns, {S_SUPPKEY}, &supplier, &loaded_bytes);
         if (!e.empty()) return e;
     }
     {   // nation, region: the specification's fixed tables
@@ -585,6 +620,78 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         p.Agg(j, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}, {PH_A_SUM, {XC(1)}}});
         q->order = {{0, false}};
         q->ncols = 3;
+        break;
+    }
+    case 16: {
+        // Order(supplier_cnt desc, p_brand, p_type, p_size) <- Agg(p_brand, p_type, p_size; count(DISTINCT ps_suppkey))
+        //   <- ANTI Join(ps_suppkey = s_suppkey) [NOT IN] probe Join(ps_partkey = p_partkey) probe Scan(partsupp),
+        //        build Scan(part, p_brand <> 'Brand#35' and p_type not like 'ECONOMY BURNISHED%' and p_size in (..));  build Scan(supplier, s_comment like ..)
+        std::vector<Literal> sizes;
+        for (int v : {14, 7, 21, 24, 35, 33, 2, 20}) sizes.push_back(LInt(v));
+        int part = p.Scan(&db.part, {P_PARTKEY, P_BRAND, P_TYPE, P_SIZE}, {{P_BRAND, PH_NE, LStr("Brand#35")}},
+                          BoolExpr::AndOf({BoolExpr::C(P_TYPE, PH_NOTLIKE, LStr("ECONOMY BURNISHED%")), BoolExpr::In(P_SIZE, sizes)}));
+        int ps = p.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY});
+        int j1 = p.Join(ps, part, {0}, {0}, {1, 3, 4, 5});                     // ps_suppkey, p_brand, p_type, p_size
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY}, {{S_COMMENT, PH_LIKE, LStr("%Customer%Complaints%")}});
+        int j2 = p.Join(j1, supp, {0}, {0}, {0, 1, 2, 3}, JoinAnti);
+        p.Agg(j2, {ProjExpr::Col(1), ProjExpr::Col(2), ProjExpr::Col(3)}, {{PH_A_COUNT_DISTINCT, {XC(0)}}});
+        q->order = {{3, true}, {0, false}, {1, false}, {2, false}};
+        q->ncols = 4;
+        break;
+    }
+    case 13: {
+        // Order(custdist desc, c_count desc) <- Agg(c_count; count(*)) <- Agg(c_custkey; count(o_orderkey))
+        //   <- LEFT Join(c_custkey = o_custkey) probe Scan(customer), build Scan(orders, o_comment not like '%pending%accounts%')
+        // count() over the NULL-extended side is 0 for a customer without orders and finalises to NULL: the NULL group of the aggregate above
+        int cust = p.Scan(&db.customer, {C_CUSTKEY});
+        int ord = p.Scan(&db.orders, {O_CUSTKEY, O_ORDERKEY}, {{O_COMMENT, PH_NOTLIKE, LStr("%pending%accounts%")}});
+        int j = p.Join(cust, ord, {0}, {0}, {0, 2}, JoinLeft);                 // c_custkey, o_orderkey
+        int inner = p.Agg(j, {ProjExpr::Col(0)}, {{PH_A_COUNT, {XC(1)}}});     // c_custkey, c_count
+        p.Agg(inner, {ProjExpr::Col(1)}, {{PH_A_COUNT_STAR, {}}});
+        q->order = {{1, true}, {0, true}};
+        q->ncols = 2;
+        break;
+    }
+    case 2: {
+        // Limit <- Order(s_acctbal desc, n_name, s_name, p_partkey) <- Join((ps_partkey, ps_supplycost) = (sub.ps_partkey, sub.min))
+        //   probe Join(ps_partkey = p_partkey) [RS = partsupp x supplier x nation x region[MIDDLE EAST]] x part[p_size = 48, p_type like '%TIN']
+        //   build Agg(ps_partkey; min(ps_supplycost)) <- RS      (the correlated subquery by its key; RS has two parents: lowered once per run)
+        // ONE plan whose root is the final join (ph_plan_fetch_rows): four VARCHAR columns of supplier come back gathered on the device
+        int reg = p.Scan(&db.region, {R_REGIONKEY}, {{R_NAME, PH_EQ, LStr("MIDDLE EAST")}});
+        int nat = p.Scan(&db.nation, {N_NATIONKEY, N_NAME, N_REGIONKEY});
+        int jn = p.Join(nat, reg, {2}, {0}, {0, 1});                           // n_nationkey, n_name
+        int supp = p.Scan(&db.supplier, {S_SUPPKEY, S_NATIONKEY, S_ACCTBAL, S_NAME, S_ADDRESS, S_PHONE, S_COMMENT});
+        int js = p.Join(supp, jn, {1}, {0}, {0, 2, 3, 4, 5, 6, 8});            // s_suppkey, s_acctbal, s_name, s_address, s_phone, s_comment, n_name
+        int ps = p.Scan(&db.partsupp, {PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST});
+        int rs = p.Join(ps, js, {1}, {0}, {0, 2, 4, 5, 6, 7, 8, 9});           // ps_partkey, ps_supplycost, s_acctbal, s_name, s_address, s_phone, s_comment, n_name
+        int sub = p.Agg(rs, {ProjExpr::Col(0)}, {{PH_A_MIN, {XC(1)}}});        // ps_partkey, min(ps_supplycost)
+        int part = p.Scan(&db.part, {P_PARTKEY, P_MFGR}, {{P_SIZE, PH_EQ, LInt(48)}}, BoolExpr::C(P_TYPE, PH_LIKE, LStr("%TIN")));
+        int jp = p.Join(rs, part, {0}, {0}, {0, 1, 2, 3, 4, 5, 6, 7, 9});      // + p_mfgr
+        p.Join(jp, sub, {0, 1}, {0, 1}, {2, 3, 7, 0, 8, 4, 5, 6});             // s_acctbal, s_name, n_name, p_partkey, p_mfgr, s_address, s_phone, s_comment
+        q->order = {{0, true}, {2, false}, {1, false}, {3, false}};
+        q->limit = 100;
+        q->ncols = 8;
+        break;
+    }
+    case 10: {
+        // Limit <- Order(revenue desc) <- Agg(c_custkey, c_name, c_acctbal, c_phone, n_name, c_address, c_comment; sum(e * (1 - d)))
+        //   <- Join(c_nationkey = n_nationkey) <- Join(o_custkey = c_custkey) <- Join(l_orderkey = o_orderkey) probe Scan(lineitem, l_returnflag = 'R'),
+        //        build Scan(orders, o_orderdate in [1993-03-01, + 3 months))
+        int ord = p.Scan(&db.orders, {O_ORDERKEY, O_CUSTKEY}, {{O_ORDERDATE, PH_GE, LDate(1993, 3, 1)}, {O_ORDERDATE, PH_LT, LDate(1993, 6, 1)}});
+        int line = p.Scan(&db.lineitem, {L_ORDERKEY, L_EXTENDEDPRICE, L_DISCOUNT}, {{L_RETURNFLAG, PH_EQ, LStr("R")}});
+        int j1 = p.Join(line, ord, {0}, {0}, {1, 2, 4});                       // ext, disc, o_custkey
+        int cust = p.Scan(&db.customer, {C_CUSTKEY, C_NAME, C_ACCTBAL, C_PHONE, C_NATIONKEY, C_ADDRESS, C_COMMENT});
+        int j2 = p.Join(j1, cust, {2}, {0}, {0, 1, 3, 4, 5, 6, 7, 8, 9});      // ext, disc, c_custkey, c_name, c_acctbal, c_phone, c_nationkey, c_address, c_comment
+        int nat = p.Scan(&db.nation, {N_NATIONKEY, N_NAME});
+        int j3 = p.Join(j2, nat, {6}, {0}, {0, 1, 2, 3, 4, 5, 10, 7, 8});      // ext, disc, c_custkey, c_name, c_acctbal, c_phone, n_name, c_address, c_comment
+        p.Agg(j3, {ProjExpr::Col(2), ProjExpr::Col(3), ProjExpr::Col(4), ProjExpr::Col(5), ProjExpr::Col(6), ProjExpr::Col(7), ProjExpr::Col(8)},
+              {{PH_A_SUM, DiscPrice(0, 1)}});
+        // select list: c_custkey, c_name, revenue, c_acctbal, n_name, c_address, c_phone, c_comment; ORDER BY revenue DESC LIMIT 20
+        q->outputs = {ProjExpr::Col(0), ProjExpr::Col(1), ProjExpr::Col(7), ProjExpr::Col(2), ProjExpr::Col(4), ProjExpr::Col(5), ProjExpr::Col(3), ProjExpr::Col(6)};
+        q->order = {{2, true}};
+        q->limit = 20;
+        q->topkAgg = 0; q->topkDesc = true;
+        q->ncols = 8;
         break;
     }
     default:

@@ -17,11 +17,11 @@ namespace plan {
 // column positions in the resident tables (cases/tpch/query/ddl.sql names; the pruned columns the queries read)
 enum { L_ORDERKEY, L_PARTKEY, L_SUPPKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE,
        L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE, L_SHIPINSTRUCT, L_LINENUMBER };
-enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TOTALPRICE, O_ORDERSTATUS };
-enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME, C_PHONE, C_ACCTBAL };
-enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER };
+enum { O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY, O_ORDERPRIORITY, O_TOTALPRICE, O_ORDERSTATUS, O_COMMENT };
+enum { C_CUSTKEY, C_NATIONKEY, C_MKTSEGMENT, C_NAME, C_PHONE, C_ACCTBAL, C_ADDRESS, C_COMMENT };
+enum { P_PARTKEY, P_NAME, P_BRAND, P_TYPE, P_SIZE, P_CONTAINER, P_MFGR };
 enum { PS_PARTKEY, PS_SUPPKEY, PS_SUPPLYCOST, PS_AVAILQTY };
-enum { S_SUPPKEY, S_NATIONKEY, S_NAME, S_ADDRESS, S_PHONE };
+enum { S_SUPPKEY, S_NATIONKEY, S_NAME, S_ADDRESS, S_PHONE, S_ACCTBAL, S_COMMENT };
 enum { N_NATIONKEY, N_NAME, N_REGIONKEY };
 enum { R_REGIONKEY, R_NAME };
 

@@ -224,7 +224,7 @@ def test_scan_queries_as_resident_plans(qid, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("qid", ["4", "5", "7", "8", "11", "12", "14", "15", "17", "18", "19", "20", "21", "22"])
+@pytest.mark.parametrize("qid", ["2", "4", "5", "7", "8", "10", "11", "12", "13", "14", "15", "16", "17", "18", "19", "20", "21", "22"])
 def test_more_reference_goldens_through_the_operator_interface(qid):
     """Q4 (SEMI join), Q5 (six-table chain), Q12 (IN list, integer CASE, column-vs-column filters), Q14
     (CASE with LIKE, FLOAT select list), Q7 (nation joined twice, OR of conjunctions as a Filter above the joins), Q8 (eight tables, DECIMAL
@@ -233,7 +233,10 @@ def test_more_reference_goldens_through_the_operator_interface(qid):
     (aggregate below a SEMI join, VARCHAR group key), Q19 (OR of conjunctions over both join sides), Q20 (a join on two keys whose build side is an aggregate by those keys, a FLOAT predicate over the plan's rows, then supplier x nation and a SEMI join
     through the chunk executors, ORDER BY a VARCHAR), Q21 (EXISTS / NOT EXISTS with a non-equi condition: pair join + column-vs-column Filter + an aggregate by lineitem's primary key below two-key SEMI /
     ANTI joins, ORDER BY a HUGEINT DESC and a VARCHAR, LIMIT), Q22 (substring() computed in the plan as an IN operand and as the VARCHAR group key, an ANTI join, a scalar
-    avg(DECIMAL) subquery whose value becomes a scan literal) as resident-plan executors behind
+    avg(DECIMAL) subquery whose value becomes a scan literal), and — round 4, the queries that read the generator's COMMENT text — Q16 (COUNT(DISTINCT) through the plan's distinct side
+    table, NOT IN as an ANTI join, 18 341 groups ordered by a HUGEINT and two dictionary VARCHARs), Q13 (LEFT OUTER join inside the plan, count() over the NULL-extended side, the NULL
+    count as the group key above: first row NULL\t50005), Q2 (a join-rooted plan with four VARCHAR supplier columns incl. s_comment, the correlated min() joined back on (key, DECIMAL)),
+    Q10 (seven group keys, four of them VARCHAR columns, top-k) as resident-plan executors behind
     OperatorExec, ORDER BY through gpuOrderExecutor: cases/tpch/1g/plan/q{4,5,7,8,11,12,14,15,17,18,19,20,21,22}.txt byte for byte"""
     out, err = run_err("tpch", qid, "1", "1")
     assert out == open(os.path.join(G, f"plan_q{qid}.txt")).read(), err
