@@ -787,7 +787,7 @@ func emitGroupRows(out *chunk.Chunk, keyTypes []common.LType, keyDicts [][]strin
 					sum, _ := f.Float64()
 					chunk.GetSliceInPhyFormatFlat[float64](v)[r] = sum / float64(cn)
 				}
-			case C.PH_A_COUNT, C.PH_A_COUNT_STAR:
+			case C.PH_A_COUNT, C.PH_A_COUNT_STAR, C.PH_A_COUNT_DISTINCT:
 				chunk.GetSliceInPhyFormatFlat[common.Hugeint](v)[r] = common.Hugeint{Lower: cn}
 			case C.PH_A_MIN, C.PH_A_MAX:
 				if dec {

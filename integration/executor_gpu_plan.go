@@ -441,8 +441,10 @@ func (b *planBuilder) lower(op *PhysicalOperator) (int, bool) {
 			jt = C.PH_JT_SEMI
 		case LOT_JoinTypeANTI:
 			jt = C.PH_JT_ANTI
+		case LOT_JoinTypeLeft:
+			jt = C.PH_JT_LEFT // NextLeftJoin inside the plan: the build side's columns carry a validity bitmap from here on
 		default:
-			return 0, false // LEFT / MARK / cross: the per-operator executors
+			return 0, false // MARK / cross: the per-operator executors
 		}
 		l, ok := b.lower(op.Children[0])
 		if !ok {
@@ -549,12 +551,18 @@ func (b *planBuilder) lower(op *PhysicalOperator) (int, bool) {
 		}
 		aggs := make([]C.ph_plan_agg, 0, len(info.Aggs))
 		for _, a := range info.Aggs {
-			if a == nil || a.Typ != ET_Func || a.GetFuncInfo().FunImpl == nil || a.GetFuncInfo().FunImpl.IsDistinct() {
+			if a == nil || a.Typ != ET_Func || a.GetFuncInfo().FunImpl == nil {
 				return 0, false
 			}
 			kind, ok := aggKinds[strings.ToLower(a.FuncName())]
 			if !ok {
 				return 0, false
+			}
+			if a.GetFuncInfo().FunImpl.IsDistinct() { // SinkDistinctGrouping's side table lives inside the library for count(distinct x)
+				if kind != C.PH_A_COUNT || len(a.Children) != 1 {
+					return 0, false
+				}
+				kind = C.PH_A_COUNT_DISTINCT
 			}
 			var pa C.ph_plan_agg
 			if kind == C.PH_A_COUNT && (len(a.Children) == 0 || stripCast(a.Children[0]).Typ == ET_Const) {
@@ -711,12 +719,18 @@ func tryNewGpuResidentPlanExecutor(op *PhysicalOperator, cfg *util.Config, txn *
 	e.nGroups = len(groups)
 	aggs := make([]C.ph_plan_agg, 0, len(info.Aggs))
 	for _, a := range info.Aggs {
-		if a == nil || a.Typ != ET_Func || a.GetFuncInfo().FunImpl == nil || a.GetFuncInfo().FunImpl.IsDistinct() {
+		if a == nil || a.Typ != ET_Func || a.GetFuncInfo().FunImpl == nil {
 			return nil, errFallback
 		}
 		kind, ok := aggKinds[strings.ToLower(a.FuncName())]
 		if !ok {
 			return nil, errFallback
+		}
+		if a.GetFuncInfo().FunImpl.IsDistinct() { // count(distinct x): PH_A_COUNT_DISTINCT (aggregate_exec.go:76-105, 201-304 inside the library)
+			if kind != C.PH_A_COUNT || len(a.Children) != 1 {
+				return nil, errFallback
+			}
+			kind = C.PH_A_COUNT_DISTINCT
 		}
 		var pa C.ph_plan_agg
 		at := common.IntegerType()
@@ -861,7 +875,11 @@ func (e *gpuResidentPlanExecutor) Execute(input, output *chunk.Chunk) (OperatorR
 		for a := 0; a < na; a++ {
 			scales[a] = int(*(*C.int32_t)(unsafe.Add(unsafe.Pointer(r.scale), 4*a)))
 		}
-		if err := emitGroupRows(rows, e.rowTypes[:e.nGroups], e.keyDicts, e.kinds, e.argTypes, scales, nk, na, keys, nil, lo, hi, cnt, e.next, n); err != nil {
+		var keyNull []uint8 // the NULL group of a NULL-able key (Q13's c_count: a count of 0 finalises to NULL)
+		if r.key_null != nil {
+			keyNull = unsafe.Slice((*uint8)(unsafe.Pointer(r.key_null)), ng*nk)
+		}
+		if err := emitGroupRows(rows, e.rowTypes[:e.nGroups], e.keyDicts, e.kinds, e.argTypes, scales, nk, na, keys, keyNull, lo, hi, cnt, e.next, n); err != nil {
 			return InvalidOpResult, err
 		}
 		e.next += n
