@@ -810,6 +810,7 @@ typedef struct {
 } ph_plan_node;
 
 typedef struct ph_plan ph_plan;
+typedef struct ph_comm ph_comm;   /* the multi-GPU communicator (declared with its entry points further down) */
 /* nodes[nnodes-1] is the root: a PH_PN_AGG (the groups come back through ph_plan_fetch) or a join / filter / project (its rows through
  * ph_plan_fetch_rows). The descriptor (and the strings of its predicates) is
  * copied; the tables must outlive the plan. PH_EUNSUPPORTED for a shape outside the device path (the caller
@@ -857,6 +858,22 @@ int ph_plan_key_info(const ph_plan *p, int32_t k, int32_t *type, int32_t *scale,
 int ph_plan_agg_arg_type(const ph_plan *p, int32_t a, int32_t *type);
 /* one line per operator of the last run: the forms chosen and the row counts seen */
 const char *ph_plan_explain(const ph_plan *p);
+/* Multi-rank execution (no reference counterpart: the reference runs one goroutine). Every rank creates the SAME plan over its shard
+ * of the sharded tables (row ranges: the default) and its copy of the replicated ones (ph_table_set_replicated: NATION, REGION, any small table),
+ * announces the communicator, and runs and fetches like a single rank; every rank receives the complete result. The library inserts the exchanges:
+ *   join: build side replicated -> local; both sides co-located by key RANGE (the ranks' column statistics: a database split by order ranges)
+ *         -> local; build side small (ph_plan_set_broadcast_rows, default 4 Mi rows in all) -> all-gathered (VARCHAR columns included) into a
+ *         replicated temporary table; otherwise both sides hash-partitioned by the first key (ph_partition_dev) and exchanged all-to-all;
+ *   aggregate below other operators: whole groups per rank — by disjoint key ranges, else its input hash-partitioned by a group key;
+ *   root aggregate: local, the ranks' partial states (128-bit sums, counts, min / max) merged at ph_plan_fetch; with a top-k, a HAVING or a
+ *         DISTINCT aggregate its input is hash-partitioned first and the ranks' whole groups are concatenated;
+ *   join-rooted plans: the root relation's rows all-gathered.
+ * Every decision is taken from all-reduced values, so all ranks walk the same sequence of collectives; a broken statistic on any rank is agreed on at
+ * the end of the run and all ranks rerun conservatively, together. Works over RCCL (ph_comm_init) and the in-process transport alike. */
+int ph_plan_set_comm(ph_plan *p, ph_comm *comm);
+int ph_plan_set_broadcast_rows(ph_plan *p, int64_t rows);
+/* this rank holds ALL rows of the table (every rank loaded the same rows) — the default is a shard (a row range) */
+int ph_table_set_replicated(ph_table *t, int32_t on);
 void ph_plan_free(ph_plan *p);
 
 /* ------------------------------------------------------------------ multi-GPU partitioning
@@ -886,6 +903,14 @@ typedef enum { PH_RED_SUM = 1, PH_RED_MAX = 2, PH_RED_MIN = 3 } ph_redop;
  * channel (the Go side: the coordinator's RPC; the tests: a file / torch.distributed store) */
 int ph_comm_unique_id(void *id_out);
 int ph_comm_init(ph_ctx *ctx, int32_t nranks, int32_t rank, const void *id, ph_comm **out);
+/* The in-process transport: the ranks are THREADS of one process, each with a ctx of its own — on different devices (a host that drives every
+ * GPU of a node from one process) or on one (the single-GPU test box: RCCL refuses two ranks on one device). ph_local_group_create makes the
+ * rendezvous object the threads share; every thread calls ph_comm_init_local with its rank. Every ph_comm_* call below then works as over
+ * RCCL (same arguments, same results); the copies are device-to-device on the calling ctx's stream between host barriers. */
+typedef struct ph_local_group ph_local_group;
+int ph_local_group_create(int32_t nranks, ph_local_group **out);
+void ph_local_group_free(ph_local_group *g);
+int ph_comm_init_local(ph_ctx *ctx, ph_local_group *g, int32_t rank, ph_comm **out);
 int32_t ph_comm_nranks(const ph_comm *c);
 int32_t ph_comm_rank(const ph_comm *c);
 void ph_comm_destroy(ph_comm *c);

@@ -167,6 +167,7 @@ struct ph_table {
     };
     std::deque<colgroup> groups;                      // (a deque: elements stay where they are when one is added)
     std::map<std::vector<int>, int> sparse_gathers;   // column set -> sparse multi-column gathers seen (the second one builds the group)
+    bool replicated = false;                          // multi-rank plans (ph_plan_set_comm): every rank holds ALL rows of this table (ph_table_set_replicated)
     int64_t colocate_budget = 4ll << 30;              // bytes the library may spend on copies it builds ON ITS OWN (ph_table_set_colocate_budget)
     int64_t colocate_bytes = 0;                       // bytes held by all copies
 };

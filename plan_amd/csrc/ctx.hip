@@ -751,6 +751,12 @@ extern "C" int32_t ph_table_colocated(const ph_table *t, int32_t ncols, const in
     return 0;
 }
 
+extern "C" int ph_table_set_replicated(ph_table *t, int32_t on) {
+    PH_REQUIRE(t != nullptr, "ph_table_set_replicated: table is NULL");
+    t->replicated = on != 0;
+    return PH_OK;
+}
+
 extern "C" int ph_table_set_colocate_budget(ph_table *t, int64_t bytes) {
     PH_REQUIRE(t && bytes >= 0, "ph_table_set_colocate_budget: bad arguments");
     std::lock_guard<std::mutex> lock(t->mu);

@@ -50,6 +50,8 @@ struct PCol {                       // an output column of a relation
     int domain = -1;                // index into ph_plan::domains: the values are a subset of that join table's keys
     ph_strdict *sdict = nullptr;    // a VARCHAR value COMPUTED in the plan (substring): the values are int32 codes of this dictionary,
                                     // a code = the row of `src` (a one-column relation the plan owns) that holds the string
+    bool grange = false;            // multi-rank plans: the values lie in [gmin, gmax] on EVERY rank (the ranks' column statistics reduced before an
+    int64_t gmin = 0, gmax = 0;     // exchange; `src` statistics are a rank's own and say nothing about rows that arrived from elsewhere)
 };
 
 struct Lane {
@@ -69,6 +71,7 @@ struct Rel {
     std::vector<BoolTree> complex;  // conjuncts of any shape over TABLE columns (OR lists, column-vs-column), applied behind them
     const uint8_t *flags = nullptr; // a byte per table row, 0 = filtered out (the marks of a semi-join)
     bool covers = true;             // every table row is (still) there, up to a reduction by the probing side's own key domain
+    bool replicated = false;        // multi-rank plans: every rank holds the same rows (else: the ranks' rows together are the relation)
     bool lazy() const { return !pending.empty() || !complex.empty() || flags != nullptr; }
     bool single_identity() const { return lanes.size() == 1 && lanes[0].rows == nullptr; }
 };
@@ -129,6 +132,11 @@ struct ph_plan {
     std::vector<int32_t> agg_scale, agg_arg_type;
     std::string explain;
     int64_t expected_groups = 1024;
+    // multi-rank execution (ph_plan_set_comm)
+    ph_comm *comm = nullptr;
+    int64_t bcast_rows = 4ll << 20;     // build sides up to this many rows IN ALL are replicated (all-gather) instead of hash-partitioned
+    bool root_disjoint = false;         // the root aggregate's groups of this rank are nobody else's (no merge of partial states at fetch)
+    bool root_replicated = false;       // every rank computed the whole result
 };
 
 namespace {
@@ -810,6 +818,8 @@ int key_unique(const Rel &r, const std::vector<int32_t> &keys) {
 }
 
 int lower(ph_plan *p, int idx, bool as_build, Rel *out);
+int whole_groups(ph_plan *p, int idx, Rel *R);
+int replicate_rel(ph_plan *p, Rel *r, const char *what);
 int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, std::vector<KeyInfo> *kinfo, std::vector<int32_t> *ascale,
                   std::vector<int32_t> *atype, std::vector<KeyPack> *packs, std::vector<bool> *nullable = nullptr);
 
@@ -872,6 +882,412 @@ int pair_probe(ph_plan *p, ph_join *j, const KeySide &pk, const ph_pred *where, 
     return PH_ECAPACITY;
 }
 
+
+// ================================================================== multi-rank execution (ph_plan_set_comm)
+// No reference counterpart (the reference runs one goroutine). Every rank runs the SAME descriptor over its shard of the
+// sharded tables (row ranges) and its copy of the replicated ones (ph_table_set_replicated), and the library inserts the exchanges:
+//   join     build side replicated                      -> local
+//            both sides co-located by key RANGE          -> local (the ranks' column statistics: build ranges pairwise disjoint, each rank's
+//                                                           probe range inside its own build range — a database split by order ranges)
+//            build side small (<= bcast_rows in all)     -> all-gathered into a replicated temporary table, then local
+//            otherwise                                   -> both sides hash-partitioned by the (first) key and exchanged all-to-all, then local
+//   aggregate below other operators: groups disjoint by the RANGE of a group key -> local; else its input is hash-partitioned by the first key
+//   root aggregate: local; ph_plan_fetch gathers every rank's groups and merges the partial states on the host (128-bit sums, counts,
+//            min / max) — or, with a top-k / HAVING announced (which need whole groups), the input is hash-partitioned first and the ranks'
+//            results are concatenated.
+// Every decision is taken from values all ranks hold alike (all-reduced counts and statistics), so all ranks walk the same sequence of
+// collectives; broken statistics are agreed on at the end of the run (deferred errors held, one all-reduce) and all ranks rerun together.
+bool multi(const ph_plan *p) { return p->comm != nullptr && ph_comm_nranks(p->comm) > 1; }
+
+int global_sum(ph_plan *p, int64_t v, int64_t *out) {
+    int64_t x = v;
+    PL_CHECK(ph_comm_allreduce_i64(p->comm, &x, 1, PH_RED_SUM));
+    *out = x;
+    return PH_OK;
+}
+
+// the rank's own statistics of a column's source: false = unknown
+bool local_range(const PCol &c, int64_t *lo, int64_t *hi, bool *empty) {
+    *empty = false;
+    if (!c.src || c.src_col < 0) return false;
+    const auto &sc = c.src->cols[(size_t)c.src_col];
+    if (c.src->nrows == 0) { *empty = true; return true; }
+    if (!sc.has_range) return false;
+    *lo = sc.min; *hi = sc.max;
+    return true;
+}
+
+// [gmin, gmax] over all ranks of a column's source statistics
+int global_range(ph_plan *p, const PCol &c, bool *ok, int64_t *gmin, int64_t *gmax) {
+    int64_t lo = 0, hi = 0;
+    bool empty = false;
+    const bool known = local_range(c, &lo, &hi, &empty);
+    int64_t v[3] = {known && !empty ? -lo : INT64_MIN + 1, known && !empty ? hi : INT64_MIN + 1, known ? 0 : 1};   // max(-lo) = -min(lo)
+    PL_CHECK(ph_comm_allreduce_i64(p->comm, v, 3, PH_RED_MAX));
+    *ok = v[2] == 0 && v[0] != INT64_MIN + 1;
+    *gmin = -v[0]; *gmax = v[1];
+    return PH_OK;
+}
+
+// per-rank (lo, hi, state) of up to two columns: state 0 = range known, 1 = no rows, 2 = unknown
+int gather_ranges(ph_plan *p, const PCol *a, const PCol *b, std::vector<int64_t> *out) {
+    const int n = ph_comm_nranks(p->comm), me = ph_comm_rank(p->comm), per = b ? 6 : 3;
+    if (per * n > 64) { out->clear(); return PH_OK; }   // (beyond ten ranks: no range reasoning)
+    std::vector<int64_t> v((size_t)per * n, 0);
+    const PCol *cs[2] = {a, b};
+    for (int k = 0; k < (b ? 2 : 1); k++) {
+        int64_t lo = 0, hi = 0;
+        bool empty = false;
+        const bool known = local_range(*cs[k], &lo, &hi, &empty);
+        v[(size_t)(me * per + k * 3 + 0)] = known && !empty ? lo : 0;
+        v[(size_t)(me * per + k * 3 + 1)] = known && !empty ? hi : 0;
+        v[(size_t)(me * per + k * 3 + 2)] = !known ? 2 : empty ? 1 : 0;
+    }
+    PL_CHECK(ph_comm_allreduce_i64(p->comm, v.data(), per * n, PH_RED_SUM));
+    *out = v;
+    return PH_OK;
+}
+
+// are the ranks' value ranges of this column pairwise disjoint? (then equal values never sit on two ranks)
+int ranks_disjoint(ph_plan *p, const PCol &c, bool *yes) {
+    *yes = false;
+    std::vector<int64_t> v;
+    PL_CHECK(gather_ranges(p, &c, nullptr, &v));
+    if (v.empty()) return PH_OK;
+    const int n = ph_comm_nranks(p->comm);
+    for (int r = 0; r < n; r++) if (v[(size_t)r * 3 + 2] == 2) return PH_OK;
+    for (int r = 0; r < n; r++)
+        for (int q = r + 1; q < n; q++) {
+            if (v[(size_t)r * 3 + 2] || v[(size_t)q * 3 + 2]) continue;
+            if (!(v[(size_t)r * 3 + 1] < v[(size_t)q * 3] || v[(size_t)q * 3 + 1] < v[(size_t)r * 3])) return PH_OK;
+        }
+    *yes = true;
+    return PH_OK;
+}
+
+// probe and build side co-located by key range: the build ranges are pairwise disjoint and every rank's probe range lies inside its own build range
+int colocated(ph_plan *p, const PCol &pc, const PCol &bc, bool *yes) {
+    *yes = false;
+    std::vector<int64_t> v;
+    PL_CHECK(gather_ranges(p, &pc, &bc, &v));
+    if (v.empty()) return PH_OK;
+    const int n = ph_comm_nranks(p->comm);
+    for (int r = 0; r < n; r++) {
+        const int64_t *x = &v[(size_t)r * 6];
+        if (x[2] == 2 || x[5] == 2) return PH_OK;
+        if (x[2] == 0 && (x[5] != 0 || x[0] < x[3] || x[1] > x[4])) return PH_OK;   // probe rows without a covering build range on this rank
+    }
+    for (int r = 0; r < n; r++)
+        for (int q = r + 1; q < n; q++) {
+            const int64_t *x = &v[(size_t)r * 6], *y = &v[(size_t)q * 6];
+            if (x[5] || y[5]) continue;
+            if (!(x[4] < y[3] || y[4] < x[3])) return PH_OK;
+        }
+    *yes = true;
+    return PH_OK;
+}
+
+// what travels for a relation's columns: the row ids of lanes over REPLICATED tables (they mean the same on every rank) and the values of
+// every other fixed-width column
+struct Travel {
+    std::vector<int> lane_of;            // per relation lane: index of its row-id travel column, or -1
+    std::vector<int> col_of;             // per output column: index of its value travel column, or -1 (it rides on its lane)
+    std::vector<const void *> data;      // travel columns (device, relation length)
+    std::vector<int32_t> width;
+};
+
+int prepare_travel(ph_plan *p, Rel *r, Travel *tv, bool strings_ok, std::vector<int> *string_cols) {
+    PL_CHECK(apply_pending(p, r));
+    tv->lane_of.assign(r->lanes.size(), -1);
+    tv->col_of.assign(r->cols.size(), -1);
+    std::vector<int> need;
+    for (size_t c = 0; c < r->cols.size(); c++) {
+        const PCol &pc = r->cols[c];
+        if (pc.sdict) { set_error("ph_plan: a computed VARCHAR column cannot cross ranks"); return PH_EUNSUPPORTED; }
+        if (pc.lane >= 0 && r->lanes[(size_t)pc.lane].t->replicated) continue;     // rides on its lane's row ids
+        if (pc.type == PH_STR) {
+            if (!strings_ok) { set_error("ph_plan: VARCHAR column %zu of a sharded table cannot be hash-partitioned across ranks", c); return PH_EUNSUPPORTED; }
+            string_cols->push_back((int)c);
+            continue;
+        }
+        need.push_back((int)c);
+    }
+    PL_CHECK(positional(p, r, need));
+    for (size_t L = 0; L < r->lanes.size(); L++) {
+        bool used = false;
+        for (auto &pc : r->cols) used |= pc.lane == (int)L;
+        if (!used) continue;
+        const Lane &ln = r->lanes[L];
+        if (ln.nullable) { set_error("ph_plan: the NULL-able side of a LEFT join cannot cross ranks"); return PH_EUNSUPPORTED; }
+        if (!ln.t->replicated) continue;   // (a sharded table's lane only carries VARCHAR columns now: replicate_rel packs their strings itself)
+        const void *ids = ln.rows;
+        if (!ids) {   // identity: materialise 0..n-1 (a sequence through the expression evaluator would do; a gather of nothing is simpler: ph_sel_difference)
+            void *seq = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &seq));
+            int64_t m = 0;
+            if (r->n > 0) PL_CHECK(ph_sel_difference(p->ctx, nullptr, r->n, nullptr, 0, r->n, (int32_t *)seq, &m));
+            ids = seq;
+        }
+        tv->lane_of[L] = (int)tv->data.size();
+        tv->data.push_back(ids);
+        tv->width.push_back(4);
+    }
+    for (int c : need) {
+        const PCol &pc = r->cols[(size_t)c];
+        if (pc.validity) { set_error("ph_plan: a NULL-able column cannot cross ranks"); return PH_EUNSUPPORTED; }
+        tv->col_of[(size_t)c] = (int)tv->data.size();
+        tv->data.push_back(pc.data);
+        tv->width.push_back(width_of(pc.type));
+    }
+    return PH_OK;
+}
+
+// the relation after its travel columns arrived as `recv` (n rows): lanes over the replicated tables, positional values otherwise
+void rebuild_after_travel(const Rel &src, const Travel &tv, const std::vector<void *> &recv, int64_t n, Rel *out) {
+    *out = Rel{};
+    out->n = n;
+    out->covers = false;
+    std::vector<int> lane_map(src.lanes.size(), -1);
+    for (size_t L = 0; L < src.lanes.size(); L++) {
+        if (tv.lane_of[L] < 0) continue;
+        Lane ln;
+        ln.t = src.lanes[L].t; ln.rows = (const int32_t *)recv[(size_t)tv.lane_of[L]]; ln.asc = false; ln.dup_free = false;
+        lane_map[L] = (int)out->lanes.size();
+        out->lanes.push_back(ln);
+    }
+    for (size_t c = 0; c < src.cols.size(); c++) {
+        PCol pc = src.cols[c];
+        pc.ordered = false; pc.domain = -1;
+        if (tv.col_of[c] >= 0) { pc.lane = -1; pc.tcol = -1; pc.data = recv[(size_t)tv.col_of[c]]; pc.validity = nullptr; pc.src = nullptr; pc.src_col = -1; }
+        else pc.lane = lane_map[(size_t)pc.lane];
+        out->cols.push_back(pc);
+    }
+}
+
+// ---- hash-partition a relation by column `keycol` and exchange it all-to-all: afterwards every row sits on rank mix64(key) mod N
+int repartition_rel(ph_plan *p, Rel *r, int keycol, const char *what) {
+    ph_ctx *ctx = p->ctx;
+    const int n = ph_comm_nranks(p->comm);
+    // the key column's range over all ranks, before its provenance goes
+    bool gok = false;
+    int64_t gmin = 0, gmax = 0;
+    PL_CHECK(global_range(p, r->cols[(size_t)keycol], &gok, &gmin, &gmax));
+    Travel tv;
+    std::vector<int> strs;
+    PL_CHECK(prepare_travel(p, r, &tv, false, &strs));
+    // the key's values: positional already (prepare_travel), or behind a replicated table's lane
+    const int32_t *ks = nullptr;
+    ph_col kv = col_view(*r, r->cols[(size_t)keycol], &ks);
+    if (ks || width_of(kv.type) < 4) {   // (a key behind a replicated lane's row ids, or a 1-byte key: gathered / widened first)
+        if (kv.type == PH_CODE8) {
+            void *w32 = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &w32));
+            if (r->n > 0) PL_CHECK(ph_widen_codes(ctx, &kv, ks, r->n, (int32_t *)w32));
+            kv = ph_col{}; kv.type = PH_I32; kv.data = w32;
+        } else {
+            void *g = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * width_of(kv.type), &g));
+            if (r->n > 0) PL_CHECK(ph_gather(ctx, &kv, ks, r->n, g));
+            kv.data = g;
+        }
+    }
+    if (kv.validity) { set_error("ph_plan: a NULL-able partition key"); return PH_EUNSUPPORTED; }
+    void *counts = nullptr, *perm = nullptr;
+    PL_CHECK(palloc(p, (int64_t)n * 8, &counts));
+    PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * 4, &perm));
+    PL_CHECK(ph_partition_dev(ctx, &kv, nullptr, r->n, n, (int64_t *)counts, (int32_t *)perm));
+    std::vector<int64_t> matrix((size_t)n * n), so((size_t)n + 1), ro((size_t)n + 1);
+    PL_CHECK(ph_comm_exchange_counts(p->comm, (const int64_t *)counts, matrix.data()));
+    PL_CHECK(ph_exchange_layout(matrix.data(), n, ph_comm_rank(p->comm), so.data(), ro.data()));
+    const int64_t nrecv = ro[(size_t)n];
+    std::vector<const void *> send(tv.data.size());
+    std::vector<void *> recv(tv.data.size());
+    for (size_t k = 0; k < tv.data.size(); k++) {
+        ph_col v{};
+        v.type = tv.width[k] == 8 ? PH_I64 : tv.width[k] == 4 ? PH_I32 : PH_CODE8; v.data = tv.data[k];
+        void *g = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(r->n, 1) * tv.width[k], &g));
+        if (r->n > 0) PL_CHECK(ph_gather(ctx, &v, (const int32_t *)perm, r->n, g));
+        send[k] = g;
+        PL_CHECK(palloc(p, std::max<int64_t>(nrecv, 1) * tv.width[k], &recv[k]));
+    }
+    PL_CHECK(ph_comm_exchange_columns(p->comm, (int32_t)tv.data.size(), send.data(), recv.data(), tv.width.data(), matrix.data()));
+    const int64_t sent = r->n;
+    Rel out;
+    rebuild_after_travel(*r, tv, recv, nrecv, &out);
+    if (gok && out.cols[(size_t)keycol].lane < 0) { out.cols[(size_t)keycol].grange = true; out.cols[(size_t)keycol].gmin = gmin; out.cols[(size_t)keycol].gmax = gmax; }
+    out.replicated = false;
+    *r = out;
+    note(p, "  exchange (%s): %lld rows hash-partitioned by column %d over %d ranks, %lld received, %zu columns travel", what, (long long)sent, keycol, n,
+         (long long)nrecv, tv.data.size());
+    return PH_OK;
+}
+
+// ---- make a relation the same on every rank: all-gather its columns into a temporary table the plan owns (VARCHAR columns included: lengths
+// and bytes travel, the offsets are rebuilt); the result is a plain single-table relation again, with the table forms its statistics allow
+int replicate_rel(ph_plan *p, Rel *r, const char *what) {
+    ph_ctx *ctx = p->ctx;
+    const int n = ph_comm_nranks(p->comm);
+    std::vector<bool> gok(r->cols.size(), false);
+    std::vector<int64_t> gmin(r->cols.size(), 0), gmax(r->cols.size(), 0);
+    for (size_t c = 0; c < r->cols.size(); c++) {
+        const PCol &pc = r->cols[c];
+        if (pc.type == PH_I32 || pc.type == PH_I64) { bool ok = false; PL_CHECK(global_range(p, pc, &ok, &gmin[c], &gmax[c])); gok[c] = ok; }
+    }
+    // declared-unique column sets of the one source table survive (a primary key is unique over all shards)
+    const ph_table *src_t = nullptr;
+    bool one_src = true;
+    for (auto &pc : r->cols) { if (!pc.src) { one_src = false; break; } if (!src_t) src_t = pc.src; else if (src_t != pc.src) { one_src = false; break; } }
+    one_src = one_src && r->lanes.size() == 1 && r->lanes[0].dup_free;
+    std::vector<int> src_cols;
+    for (auto &pc : r->cols) src_cols.push_back(pc.src_col);
+    Travel tv;
+    std::vector<int> strs;
+    PL_CHECK(prepare_travel(p, r, &tv, true, &strs));
+    std::vector<int64_t> counts((size_t)n);
+    ph_table *vt = new ph_table();
+    p->computed.push_back(vt);
+    vt->ctx = ctx;
+    vt->replicated = true;
+    vt->cols.resize(r->cols.size());
+    int64_t total = -1;
+    std::vector<void *> recv(tv.data.size(), nullptr);
+    for (size_t k = 0; k < tv.data.size(); k++) {
+        void *out = nullptr;
+        PL_CHECK(ph_comm_allgather_rows_alloc(p->comm, tv.data[k], r->n, tv.width[k], &out, counts.data()));
+        p->computed_bufs.push_back(out);
+        recv[k] = out;
+    }
+    {
+        int64_t t2 = 0;
+        PL_CHECK(global_sum(p, r->n, &t2));
+        total = t2;
+    }
+    // VARCHAR columns of sharded tables: the selected rows' strings packed on the device (ph_substring over the row ids), bytes and offsets gathered,
+    // the offsets re-based on the host (a broadcast side is small by definition)
+    std::vector<void *> str_off(r->cols.size(), nullptr), str_bytes(r->cols.size(), nullptr);
+    std::vector<int64_t> str_nbytes(r->cols.size(), 0);
+    for (int c : strs) {
+        const PCol &pc = r->cols[(size_t)c];
+        if (pc.lane < 0) { set_error("ph_plan: VARCHAR column %d is not a table column", c); return PH_EUNSUPPORTED; }
+        const Lane &ln = r->lanes[(size_t)pc.lane];
+        ph_col v = table_view(ln.t, pc.tcol);
+        if (v.validity) { set_error("ph_plan: a NULL-able VARCHAR column cannot cross ranks"); return PH_EUNSUPPORTED; }
+        void *off = nullptr, *bytes = nullptr;
+        int64_t cap = v.aux_bytes + 64, nb = 0;
+        PL_CHECK(palloc(p, (r->n + 1) * 4 + 64, &off));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            PL_CHECK(palloc(p, cap, &bytes));
+            int rc = r->n > 0 ? ph_substring(ctx, &v, 1, INT64_MAX, ln.rows, r->n, (int32_t *)off, (uint8_t *)bytes, cap, &nb) : PH_OK;
+            if (rc == PH_ECAPACITY && attempt == 0 && nb > cap) { cap = nb + 64; continue; }
+            PL_CHECK(rc);
+            break;
+        }
+        if (r->n == 0) PL_CHECK(ph_dev_memset(ctx, off, 0, 8));
+        void *all_off = nullptr, *all_bytes = nullptr;
+        std::vector<int64_t> oc((size_t)n), bc((size_t)n);
+        PL_CHECK(ph_comm_allgather_rows_alloc(p->comm, off, r->n + 1, 4, &all_off, oc.data()));       // every rank's n_r + 1 local offsets
+        PL_CHECK(ph_comm_allgather_rows_alloc(p->comm, bytes, nb, 1, &all_bytes, bc.data()));
+        p->computed_bufs.push_back(all_bytes);
+        int64_t tot_off = 0, tot_bytes = 0;
+        for (int q = 0; q < n; q++) { tot_off += oc[(size_t)q]; tot_bytes += bc[(size_t)q]; }
+        if (tot_bytes >= (1ll << 31)) { ph_dev_free(ctx, all_off); set_error("ph_plan: %lld bytes of strings in a broadcast side", (long long)tot_bytes); return PH_EUNSUPPORTED; }
+        std::vector<int32_t> lo((size_t)tot_off), fixed((size_t)total + 1);
+        int rc = tot_off > 0 ? ctx->download(lo.data(), all_off, tot_off * 4) : PH_OK;
+        ph_dev_free(ctx, all_off);
+        PL_CHECK(rc);
+        int64_t at = 0, pos = 0, base = 0;
+        for (int q = 0; q < n; q++) {
+            const int64_t rows = oc[(size_t)q] - 1;
+            for (int64_t i = 0; i < rows; i++) fixed[(size_t)at++] = (int32_t)(base + lo[(size_t)(pos + i)]);
+            pos += oc[(size_t)q];
+            base += bc[(size_t)q];
+        }
+        fixed[(size_t)at] = (int32_t)base;
+        void *fo = nullptr;
+        PL_CHECK(ctx->pool_alloc((total + 1) * 4 + 64, &fo));
+        p->computed_bufs.push_back(fo);
+        PL_CHECK(ph_dev_upload(ctx, fo, fixed.data(), (total + 1) * 4));
+        str_off[(size_t)c] = fo; str_bytes[(size_t)c] = all_bytes; str_nbytes[(size_t)c] = tot_bytes;
+    }
+    vt->nrows = total;
+    // columns of the temporary table: gathered values, gathered strings, or — for columns that rode on a replicated table's lane — nothing (they stay lane columns)
+    Rel out;
+    out.n = total;
+    out.covers = false;
+    out.replicated = true;
+    Lane tl;
+    tl.t = vt;
+    out.lanes.push_back(tl);
+    std::vector<int> lane_map(r->lanes.size(), -1);
+    for (size_t L = 0; L < r->lanes.size(); L++) {
+        if (tv.lane_of[L] < 0 || !r->lanes[L].t->replicated) continue;
+        Lane ln;
+        ln.t = r->lanes[L].t; ln.rows = (const int32_t *)recv[(size_t)tv.lane_of[L]]; ln.asc = false; ln.dup_free = false;
+        lane_map[L] = (int)out.lanes.size();
+        out.lanes.push_back(ln);
+    }
+    for (size_t c = 0; c < r->cols.size(); c++) {
+        PCol pc = r->cols[c];
+        pc.ordered = false; pc.domain = -1;
+        auto &tc = vt->cols[c];
+        tc.type = pc.type; tc.scale = pc.scale;
+        if (tv.col_of[c] >= 0) {
+            tc.data = recv[(size_t)tv.col_of[c]];
+            if (gok[c]) { tc.has_range = true; tc.min = gmin[c]; tc.max = gmax[c]; }
+            if (pc.src && pc.src_col >= 0 && pc.type == PH_CODE8) tc.dict = pc.src->cols[(size_t)pc.src_col].dict;
+            pc.lane = 0; pc.tcol = (int)c; pc.data = nullptr; pc.validity = nullptr; pc.src = vt; pc.src_col = (int)c;
+        } else if (str_off[c]) {
+            tc.data = str_off[c]; tc.aux = str_bytes[c]; tc.aux_bytes = str_nbytes[c];
+            pc.lane = 0; pc.tcol = (int)c; pc.data = nullptr; pc.validity = nullptr; pc.src = vt; pc.src_col = (int)c;
+        } else {
+            tc.type = 0;   // (unused slot: the column lives behind a replicated table's lane)
+            pc.lane = lane_map[(size_t)pc.lane];
+        }
+        out.cols.push_back(pc);
+    }
+    if (one_src && src_t)
+        for (auto &u : src_t->unique_keys) {
+            std::vector<int32_t> mapped;
+            for (int32_t sc : u) {
+                int at = -1;
+                for (size_t c = 0; c < src_cols.size(); c++) if (src_cols[c] == sc && tv.col_of[c] >= 0) { at = (int)c; break; }
+                if (at < 0) { mapped.clear(); break; }
+                mapped.push_back(at);
+            }
+            if (!mapped.empty()) { std::sort(mapped.begin(), mapped.end()); vt->unique_keys.push_back(mapped); }
+        }
+    note(p, "  broadcast (%s): %lld rows of this rank, %lld on every rank afterwards (a replicated temporary table, %zu gathered columns%s)", what,
+         (long long)r->n, (long long)total, tv.data.size(), strs.empty() ? "" : " + VARCHAR");
+    *r = out;
+    return PH_OK;
+}
+
+// ---- where a join's sides must meet: decided from all-reduced facts, identically on every rank
+int distribute_join(ph_plan *p, int idx, const Node &nd, Rel *P, Rel *B) {
+    if (B->replicated) return PH_OK;                                              // local; the result is as distributed as P
+    if (P->replicated && nd.join_type == PH_JT_INNER) { note(p, "join#%d: replicated probe side x sharded build side: local (every pair is found on the build row's rank)", idx); return PH_OK; }
+    if (!P->replicated) {
+        bool co = false;
+        PL_CHECK(colocated(p, P->cols[(size_t)nd.pkeys[0]], B->cols[(size_t)nd.bkeys[0]], &co));
+        if (co) { note(p, "join#%d: co-located by key range (the ranks' statistics): no exchange", idx); return PH_OK; }
+    }
+    PL_CHECK(apply_pending(p, B));
+    int64_t total = 0;
+    PL_CHECK(global_sum(p, B->n, &total));
+    if (total <= p->bcast_rows || P->replicated) {
+        char what[64];
+        snprintf(what, sizeof what, "build side of join#%d", idx);
+        return replicate_rel(p, B, what);
+    }
+    char wb[64], wp[64];
+    snprintf(wb, sizeof wb, "build side of join#%d", idx);
+    snprintf(wp, sizeof wp, "probe side of join#%d", idx);
+    PL_CHECK(repartition_rel(p, B, nd.bkeys[0], wb));
+    PL_CHECK(repartition_rel(p, P, nd.pkeys[0], wp));
+    return PH_OK;
+}
+
 int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out);
 int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out);
 
@@ -883,7 +1299,23 @@ int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
     return join_rels(p, idx, p->nodes[(size_t)idx], P, B, as_build, out);
 }
 
+int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out);
+
+// one join: across ranks first the question where its sides meet (distribute_join), then the single-rank lowering
 int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out) {
+    if (!multi(p)) return join_rels_local(p, idx, nd, P, B, as_build, out);
+    for (size_t k = 0; k < nd.pkeys.size(); k++)
+        if (nd.pkeys[k] < 0 || (size_t)nd.pkeys[k] >= P.cols.size() || nd.bkeys[k] < 0 || (size_t)nd.bkeys[k] >= B.cols.size()) { set_error("ph_plan: join key out of range"); return PH_EINVAL; }
+    PL_CHECK(distribute_join(p, idx, nd, &P, &B));
+    const bool result_replicated = P.replicated && B.replicated;
+    if (!B.replicated) B.covers = false;   // a rank's share of the build side: "every probe row finds its row" is not this rank's to claim
+    for (auto &c : P.cols) c.domain = -1;  // (sideways information passing reasons about ONE rank's rows: off across ranks)
+    PL_CHECK(join_rels_local(p, idx, nd, P, B, as_build, out));
+    out->replicated = result_replicated;
+    return PH_OK;
+}
+
+int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out) {
     ph_ctx *ctx = p->ctx;
     const size_t nP = P.cols.size(), nB = B.cols.size();
     const size_t nk = nd.pkeys.size();
@@ -909,7 +1341,7 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
         }
         // the output indexes address [P's original columns | B's original columns]: re-base the build half behind P's new width
         for (auto &o : ndx.out) if ((size_t)o >= nP) o = (int32_t)((size_t)o - nP + P.cols.size());
-        return join_rels(p, idx, ndx, P, B, as_build, out);
+        return join_rels_local(p, idx, ndx, P, B, as_build, out);
     }
     for (size_t k = 0; k < nk; k++) {
         const int a = P.cols[(size_t)nd.pkeys[k]].type, b = B.cols[(size_t)nd.bkeys[k]].type;
@@ -1025,6 +1457,8 @@ int join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, 
             const PCol &k0 = B.cols[(size_t)nd.bkeys[0]];
             if (nk == 1 && k0.src && k0.src->cols[(size_t)k0.src_col].has_range && (k0.type == PH_I32 || k0.type == PH_I64)) {
                 flags |= PH_JOIN_KEY_RANGE; lo = k0.src->cols[(size_t)k0.src_col].min; hi = k0.src->cols[(size_t)k0.src_col].max;
+            } else if (nk == 1 && k0.grange && (k0.type == PH_I32 || k0.type == PH_I64)) {   // rows that arrived over an exchange: the ranks' reduced range
+                flags |= PH_JOIN_KEY_RANGE; lo = k0.gmin; hi = k0.gmax;
             }
             PL_CHECK(ph_join_build_ex(ctx, kv.data(), (int32_t)nk, nullptr, B.n, flags | (marks_only ? PH_JOIN_EXISTS_ONLY : 0), lo, hi, &j));
             how += " build: intermediate rows;";
@@ -1362,6 +1796,32 @@ int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out) 
     return PH_OK;
 }
 
+// ---- multi-rank: bring every group's rows onto one rank before an aggregate that needs WHOLE groups (an aggregate below other operators; a root
+// with a top-k, a HAVING or a DISTINCT aggregate). Nothing moves when a group key's per-rank value ranges are disjoint (the ranks' statistics:
+// a database split by order ranges grouped by the order key); an ungrouped aggregate gets its (small) input replicated; otherwise the rows are
+// hash-partitioned by the first group key that is a plain column.
+int whole_groups(ph_plan *p, int idx, Rel *R) {
+    const Node &nd = p->nodes[(size_t)idx];
+    if (nd.groups.empty()) {
+        char what[64];
+        snprintf(what, sizeof what, "input of the ungrouped aggregate #%d", idx);
+        return replicate_rel(p, R, what);
+    }
+    int part_key = -1;
+    for (auto &g : nd.groups) {
+        if (g.e.kind != PH_PE_COL || g.e.col < 0 || g.e.col >= (int)R->cols.size()) continue;
+        const PCol &c = R->cols[(size_t)g.e.col];
+        bool dj = false;
+        PL_CHECK(ranks_disjoint(p, c, &dj));
+        if (dj) { note(p, "agg#%d: the ranks' ranges of group key column %d are disjoint: every group is whole on its rank", idx, g.e.col); return PH_OK; }
+        if (part_key < 0 && (c.type == PH_I32 || c.type == PH_I64 || c.type == PH_DATE || c.type == PH_DEC64 || c.type == PH_CODE8) && !c.validity) part_key = g.e.col;
+    }
+    if (part_key < 0) { set_error("ph_plan: aggregate #%d across ranks needs a group key that is a plain fixed-width column", idx); return PH_EUNSUPPORTED; }
+    char what[64];
+    snprintf(what, sizeof what, "input of aggregate #%d", idx);
+    return repartition_rel(p, R, part_key, what);
+}
+
 int lower_node(ph_plan *p, int idx, bool as_build, Rel *out);
 
 // A node that several parents reference (a subtree used twice: Q21's l1 side feeds the pair join and the SEMI / ANTI join that closes
@@ -1403,6 +1863,7 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
         }
         if (!nd.bools.empty()) { out->complex.push_back(nd.bools); out->complex.back().fix(); }
         out->covers = nd.preds.empty() && nd.bools.empty();
+        out->replicated = multi(p) && t->replicated;
         note(p, "scan#%d: %lld rows, %zu pushed conjuncts", idx, (long long)t->nrows, nd.preds.size() + (nd.bools.empty() ? 0 : 1));
         return PH_OK;
     }
@@ -1489,6 +1950,8 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
         // become a device-resident relation — key columns and aggregate values as positional columns — and never visit the host
         Rel R;
         PL_CHECK(lower(p, nd.child[0], false, &R));
+        if (multi(p) && !R.replicated) PL_CHECK(whole_groups(p, idx, &R));   // every group's rows on one rank before they are aggregated
+        const bool agg_replicated = R.replicated;
         ph_agg *agg = nullptr;
         std::vector<KeyInfo> kinfo;
         std::vector<int32_t> ascale, atype;
@@ -1502,6 +1965,7 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
         *out = Rel{};
         out->n = ng;
         out->covers = false;
+        out->replicated = agg_replicated;
         for (size_t k = 0; k < nd.groups.size(); k++) {
             PCol c;
             c.type = kinfo[k].type; c.scale = kinfo[k].scale; c.src = kinfo[k].table; c.src_col = kinfo[k].col;
@@ -1742,6 +2206,18 @@ int lower_agg(ph_plan *p) {
     p->keys.clear(); p->agg_scale.clear(); p->agg_arg_type.clear();
     Rel R;
     PL_CHECK(lower(p, nd.child[0], false, &R));
+    p->root_replicated = p->root_disjoint = false;
+    if (multi(p)) {
+        p->root_replicated = R.replicated;
+        bool distinct = false;
+        for (auto &a : nd.aggs) distinct |= a.kind == PH_A_COUNT_DISTINCT;
+        // a top-k preselection, a HAVING and a DISTINCT aggregate are properties of WHOLE groups; plain sums, counts, minima and maxima merge at fetch
+        if (!R.replicated && (p->topk_agg >= 0 || !p->having.empty() || distinct)) {
+            if (nd.groups.empty()) { set_error("ph_plan: an ungrouped root aggregate with HAVING / DISTINCT across ranks"); return PH_EUNSUPPORTED; }
+            PL_CHECK(whole_groups(p, idx, &R));
+            p->root_disjoint = true;
+        }
+    }
 
     // Agg <- Scan(filter): the fused scan kernels (ph_scan_plan) — the Q1 / Q6 shapes and everything scan_jit generates
     const Node &ch = p->nodes[(size_t)nd.child[0]];
@@ -1800,12 +2276,13 @@ int run_once(ph_plan *p) {
     if (p->scan) { ph_scan_plan_free(p->scan); p->scan = nullptr; }
     p->explain.clear();
     note(p, "plan run (%s forms)", p->conservative ? "conservative" : "optimistic");
-    PL_CHECK(ph_ctx_set_deferred_errors(p->ctx, 1));
+    PL_CHECK(ph_ctx_set_deferred_errors(p->ctx, multi(p) ? 2 : 1));   // across ranks deferred errors are HELD: the ranks agree on them at the end of the run
     int rc = PH_OK;
     if (p->rows_root) {
         Rel R;
         rc = lower(p, (int)p->nodes.size() - 1, false, &R);
         if (rc == PH_OK) rc = apply_pending(p, &R);
+        if (rc == PH_OK && multi(p) && !R.replicated) rc = replicate_rel(p, &R, "the root relation's rows");   // every rank returns all rows
         if (rc == PH_OK) p->rows_rel = std::make_shared<Rel>(R);
     } else rc = lower_agg(p);
     if (rc != PH_OK) { release_run(p, false); (void)ph_ctx_set_deferred_errors(p->ctx, 0); return rc; }
@@ -2079,9 +2556,50 @@ extern "C" int ph_plan_set_having(ph_plan *p, int32_t nconj, const ph_pred *conj
 
 extern "C" int32_t ph_plan_having_applied(const ph_plan *p) { return p && p->having_applied ? 1 : 0; }
 
+// multi-rank run: deferred errors were held; now the ranks agree — 0 all fine, 1 a statistic did not hold somewhere (every rank reruns in the
+// conservative forms, together), 2 a rank failed otherwise (every rank reports failure)
+static int run_agreed(ph_plan *p) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = run_once(p);
+        int64_t state = 0;
+        if (rc == PH_OK) {
+            const int d = ph_ctx_check_deferred(p->ctx);
+            state = d == PH_OK ? 0 : d == PH_ECONSTRAINT ? 1 : 2;
+        } else state = rc == PH_ECONSTRAINT ? 1 : 2;
+        const std::string local_err = state ? ph_last_error() : "";
+        int64_t agreed = state;
+        // (a rank whose lowering failed before the others' next collective leaves them waiting there: only data-independent failures, which every
+        // rank meets at the same node, and the deferred ones, which wait until here, are expected)
+        if (ph_comm_allreduce_i64(p->comm, &agreed, 1, PH_RED_MAX) != PH_OK) return PH_EHIP;
+        if (agreed == 0) return PH_OK;
+        if (agreed == 2 || p->conservative) {
+            release_run(p, false);
+            (void)ph_ctx_set_deferred_errors(p->ctx, 0);
+            set_error("ph_plan_run (rank %d of %d): %s", ph_comm_rank(p->comm), ph_comm_nranks(p->comm), local_err.empty() ? "another rank failed" : local_err.c_str());
+            return state == 1 ? PH_ECONSTRAINT : rc != PH_OK ? rc : PH_EHIP;
+        }
+        p->explain += "  -> a statistic did not hold on some rank: every rank runs the plan again in its conservative forms\n";
+        p->conservative = true;
+    }
+    return PH_ECONSTRAINT;
+}
+
+extern "C" int ph_plan_set_comm(ph_plan *p, ph_comm *comm) {
+    PH_REQUIRE(p != nullptr, "ph_plan_set_comm: plan is NULL");
+    p->comm = comm;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_set_broadcast_rows(ph_plan *p, int64_t rows) {
+    PH_REQUIRE(p != nullptr && rows >= 0, "ph_plan_set_broadcast_rows: bad arguments");
+    p->bcast_rows = rows;
+    return PH_OK;
+}
+
 extern "C" int ph_plan_run(ph_plan *p) {
     PH_REQUIRE(p != nullptr, "ph_plan_run: plan is NULL");
     PH_HIP(hipSetDevice(p->ctx->device));
+    if (multi(p)) return run_agreed(p);
     int rc = run_once(p);
     if (rc == PH_ECONSTRAINT && !p->conservative) {   // a broken claim surfaced at a count read-back in the middle of the run
         p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): conservative forms from here on\n";
@@ -2123,10 +2641,108 @@ extern "C" int ph_plan_fetch_rows(ph_plan *p, ph_rows_result **out) {
     return rc;
 }
 
+// ---- multi-rank fetch: every rank's groups to every rank (one all-gather of the serialised results), then — unless the ranks' groups are disjoint —
+// the partial states of equal keys merged: 128-bit sums and counts add, minima / maxima compare (a state no input reached does not take part).
+namespace {
+void put64(std::vector<unsigned char> *b, uint64_t v) { for (int i = 0; i < 8; i++) b->push_back((unsigned char)(v >> (8 * i))); }
+uint64_t get64(const unsigned char *&q) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)q[i] << (8 * i); q += 8; return v; }
+
+int merge_over_ranks(ph_plan *p, ph_agg_result *mine, ph_agg_result **out) {
+    const Node &nd = p->nodes.back();
+    const int nk = std::max(mine->nkeys, 1), na = mine->naggs, nkeys = mine->nkeys;
+    // VARCHAR keys are row ids of a column: the same on every rank only for a replicated (or broadcast) table
+    for (int k = 0; k < nkeys; k++)
+        if (p->keys[(size_t)k].type == PH_STR && !(p->keys[(size_t)k].table && p->keys[(size_t)k].table->replicated)) {
+            set_error("ph_plan_fetch: VARCHAR group key %d names rows of a sharded table: it cannot be merged across ranks", k);
+            return PH_EUNSUPPORTED;
+        }
+    std::vector<unsigned char> blob;
+    put64(&blob, (uint64_t)mine->ngroups);
+    for (int64_t g = 0; g < mine->ngroups; g++) {
+        for (int k = 0; k < nk; k++) { put64(&blob, (uint64_t)mine->keys[g * nk + k]); blob.push_back(mine->key_null ? mine->key_null[g * nk + k] : 0); }
+        for (int a = 0; a < na; a++) { put64(&blob, mine->sum_lo[g * na + a]); put64(&blob, (uint64_t)mine->sum_hi[g * na + a]); put64(&blob, mine->count[g * na + a]); }
+    }
+    ph_ctx *ctx = p->ctx;
+    const int n = ph_comm_nranks(p->comm);
+    void *send = nullptr, *recv = nullptr;
+    PL_CHECK(ctx->pool_alloc((int64_t)blob.size() + 64, &send));
+    int rc = ph_dev_upload(ctx, send, blob.data(), (int64_t)blob.size());
+    std::vector<int64_t> counts((size_t)n);
+    if (rc == PH_OK) rc = ph_comm_allgather_rows_alloc(p->comm, send, (int64_t)blob.size(), 1, &recv, counts.data());
+    int64_t total = 0;
+    for (int r = 0; r < n; r++) total += counts[(size_t)r];
+    std::vector<unsigned char> all((size_t)std::max<int64_t>(total, 1));
+    if (rc == PH_OK && total > 0) rc = ctx->download_plain(all.data(), recv, total);
+    ctx->pool_release(send);
+    if (recv) ph_dev_free(ctx, recv);
+    PL_CHECK(rc);
+    struct G { std::vector<int64_t> key; std::vector<uint8_t> kn; std::vector<uint64_t> lo, cnt; std::vector<int64_t> hi; };
+    std::vector<G> groups;
+    std::map<std::pair<std::vector<int64_t>, std::vector<uint8_t>>, size_t> index;
+    const unsigned char *q = all.data();
+    for (int r = 0; r < n; r++) {
+        const unsigned char *end = q + counts[(size_t)r];
+        const int64_t ng = (int64_t)get64(q);
+        for (int64_t g = 0; g < ng; g++) {
+            G x;
+            x.key.resize((size_t)nk); x.kn.resize((size_t)nk); x.lo.resize((size_t)na); x.hi.resize((size_t)na); x.cnt.resize((size_t)na);
+            for (int k = 0; k < nk; k++) { x.key[(size_t)k] = (int64_t)get64(q); x.kn[(size_t)k] = *q++; }
+            for (int a = 0; a < na; a++) { x.lo[(size_t)a] = get64(q); x.hi[(size_t)a] = (int64_t)get64(q); x.cnt[(size_t)a] = get64(q); }
+            if (p->root_disjoint) { groups.push_back(std::move(x)); continue; }
+            auto key = std::make_pair(x.key, x.kn);
+            auto it = index.find(key);
+            if (it == index.end()) { index[key] = groups.size(); groups.push_back(std::move(x)); continue; }
+            G &t = groups[it->second];
+            for (int a = 0; a < na; a++) {
+                const int kind = nd.aggs[(size_t)a].kind;
+                if (kind == PH_A_MIN || kind == PH_A_MAX) {
+                    if (x.cnt[(size_t)a] == 0) continue;
+                    const int64_t v = (int64_t)x.lo[(size_t)a], w = (int64_t)t.lo[(size_t)a];
+                    if (t.cnt[(size_t)a] == 0 || (kind == PH_A_MIN ? v < w : v > w)) { t.lo[(size_t)a] = x.lo[(size_t)a]; t.hi[(size_t)a] = x.hi[(size_t)a]; }
+                    t.cnt[(size_t)a] += x.cnt[(size_t)a];
+                } else {
+                    const unsigned __int128 s = (((unsigned __int128)(uint64_t)t.hi[(size_t)a]) << 64 | t.lo[(size_t)a]) + (((unsigned __int128)(uint64_t)x.hi[(size_t)a]) << 64 | x.lo[(size_t)a]);
+                    t.lo[(size_t)a] = (uint64_t)s; t.hi[(size_t)a] = (int64_t)(uint64_t)(s >> 64);
+                    t.cnt[(size_t)a] += x.cnt[(size_t)a];
+                }
+            }
+        }
+        q = end;
+    }
+    ph_agg_result *r = new_result((int64_t)groups.size(), nkeys, na);
+    bool any_null = false;
+    for (auto &g : groups) for (auto v : g.kn) any_null |= v != 0;
+    if (any_null) r->key_null = (uint8_t *)calloc(std::max<size_t>(groups.size(), 1) * (size_t)nk, 1);
+    for (size_t g = 0; g < groups.size(); g++) {
+        r->first_row[g] = (int64_t)g;
+        for (int k = 0; k < nkeys; k++) { r->keys[g * (size_t)nk + (size_t)k] = groups[g].key[(size_t)k]; if (any_null) r->key_null[g * (size_t)nk + (size_t)k] = groups[g].kn[(size_t)k]; }
+        for (int a = 0; a < na; a++) { r->sum_lo[g * (size_t)na + (size_t)a] = groups[g].lo[(size_t)a]; r->sum_hi[g * (size_t)na + (size_t)a] = groups[g].hi[(size_t)a]; r->count[g * (size_t)na + (size_t)a] = groups[g].cnt[(size_t)a]; }
+    }
+    for (int a = 0; a < na; a++) r->scale[a] = mine->scale[a];
+    *out = r;
+    return PH_OK;
+}
+}  // namespace
+
 extern "C" int ph_plan_fetch(ph_plan *p, ph_agg_result **out) {
     PH_REQUIRE(p && out, "ph_plan_fetch: bad arguments");
     PH_REQUIRE(!p->rows_root, "ph_plan_fetch: the plan's root is no aggregate (ph_plan_fetch_rows)");
     PH_REQUIRE(p->ran, "ph_plan_fetch: ph_plan_run first");
+    if (multi(p)) {   // (broken statistics were settled, by all ranks together, at the end of the run)
+        release_run(p, true);
+        ph_agg_result *mine = nullptr;
+        int rc = fetch_once(p, &mine);
+        if (rc == PH_OK && !p->root_replicated) {
+            ph_agg_result *merged = nullptr;
+            rc = merge_over_ranks(p, mine, &merged);
+            ph_agg_result_free(mine);
+            mine = merged;
+        }
+        (void)ph_ctx_set_deferred_errors(p->ctx, 0);
+        p->ran = false;
+        if (rc == PH_OK) *out = mine;
+        return rc;
+    }
     // the intermediates go back to the pool BEFORE the host blocks in the download (bookkeeping while the GPU is busy)
     release_run(p, true);
     int rc = fetch_once(p, out);

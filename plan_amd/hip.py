@@ -281,6 +281,10 @@ class Table:
     def colocated(self, cols):
         return bool(lib().ph_table_colocated(self.h, i32(len(cols)), (i32 * len(cols))(*cols)))
 
+    def set_replicated(self, on=True):
+        """multi-rank plans: this rank holds ALL rows of the table (default: a shard)"""
+        check(lib().ph_table_set_replicated(self.h, i32(1 if on else 0)))
+
     def set_colocate_budget(self, nbytes):
         """bytes of HBM the library may spend on its own on co-located copies of this table (0 = never; default 4 GiB)"""
         check(lib().ph_table_set_colocate_budget(self.h, i64(nbytes)))
@@ -1027,6 +1031,13 @@ class Plan:
         self._keep.append(arr)
         check(lib().ph_plan_set_having(self.h, i32(len(conjuncts)), arr))
 
+    def set_comm(self, comm, broadcast_rows=None):
+        """multi-rank execution (ph_plan_set_comm): comm = a Comm (RCCL or the in-process transport); every rank creates, runs and fetches the same
+        plan over its shard and receives the complete result"""
+        check(lib().ph_plan_set_comm(self.h, comm.h if comm is not None else None))
+        if broadcast_rows is not None:
+            check(lib().ph_plan_set_broadcast_rows(self.h, i64(broadcast_rows)))
+
     def set_topk(self, agg_index, k, descending=True):
         check(lib().ph_plan_set_topk(self.h, i32(agg_index), i32(1 if descending else 0), i64(k)))
 
@@ -1121,3 +1132,29 @@ def table_strings(ctx, table, c, rows):
     buf = ctypes.create_string_buffer(cap)
     check(lib().ph_table_strings(ctx.h, table.h if hasattr(table, "h") else vp(table), i32(c), vp(rows.ctypes.data), i64(n), vp(off.ctypes.data), buf, i64(cap)))
     return [buf.raw[off[i]:off[i + 1]].decode() for i in range(n)]
+
+
+class LocalGroup:
+    """the rendezvous object of the in-process transport (ph_local_group): the ranks are threads of this process"""
+
+    def __init__(self, nranks):
+        self.h, self.nranks = vp(), nranks
+        check(lib().ph_local_group_create(i32(nranks), ctypes.byref(self.h)))
+
+    def free(self):
+        if self.h:
+            lib().ph_local_group_free(self.h)
+            self.h = None
+
+
+class Comm:
+    """ph_comm over the in-process transport (group = LocalGroup) — the RCCL form lives in plan_amd.dist.RcclGroup"""
+
+    def __init__(self, ctx, group, rank):
+        self.h, self.ctx, self.rank, self.nranks = vp(), ctx, rank, group.nranks
+        check(lib().ph_comm_init_local(ctx.h, group.h, i32(rank), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ph_comm_destroy(self.h)
+            self.h = None
