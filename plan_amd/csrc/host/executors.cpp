@@ -1658,6 +1658,7 @@ std::string gpuResidentPlanExecutor::Init() {
     outTypes_ = root.types;       // [group columns | aggregate results], typed by ResidentPlan::Agg
     argType_ = root.argTypes;
     if (ph_plan_create(ctx_, desc.data(), (int32_t)nn, &plan_) != PH_OK) return herr("ph_plan_create");
+    if (comm_ && ph_plan_set_comm(plan_, comm_) != PH_OK) return herr("ph_plan_set_comm");
     // HAVING runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263): with a HAVING the top-k
     // preselection is not announced — the k best groups could fail it while later ones pass — and the Order above sorts the survivors
     if (topkAgg_ >= 0 && having_.empty() && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");

@@ -461,6 +461,9 @@ public:
     // Order <- Limit above the aggregate with an aggregate as the first ORDER BY key (what the shim sees when it
     // walks up from the Agg): only the groups that can reach the first k rows come back from the device
     void SetTopK(int aggIndex, bool descending, int64_t k) { topkAgg_ = aggIndex; topkDesc_ = descending; topkK_ = k; }
+    // multi-rank execution: every rank builds this executor over its shard of the resident tables and announces the ranks' communicator; the
+    // library inserts the exchanges (ph_plan_set_comm) and every rank's executor emits the complete result
+    void SetComm(ph_comm *comm) { comm_ = comm; }
     std::string Explain() const { return plan_ ? ph_plan_explain(plan_) : ""; }
 private:
     ph_ctx *ctx_;
@@ -474,6 +477,7 @@ private:
     bool topkDesc_ = false;
     int64_t topkK_ = 0;
     ph_plan *plan_ = nullptr;
+    ph_comm *comm_ = nullptr;
     std::vector<std::shared_ptr<Chunk>> results_;
     size_t next_ = 0;
     bool built_ = false;

@@ -9,6 +9,8 @@
 //   host_tester q3|q9 <sf_num> <sf_den> resident [repeat]     the whole subtree as ONE gpuResidentPlanExecutor (ph_plan)
 //   host_tester tpch <query_id> <sf_num> <sf_den> [repeat]    any query tpch_plans.cpp has a resident plan for
 //   host_tester concurrent <sf_num> <sf_den> [iterations]     the tables on ONE context, Q3 and Q9 from two threads on two others at once
+//   host_tester ranks <n> <query_id> <sf_num> <sf_den>         the database split over n ranks (threads of this process, the in-process transport);
+//                                                              every rank runs the query over its shard through ph_plan_set_comm; rank 0 prints
 // The resident-plan forms print "Query N took <dur> success" per repeat on stderr, like Run (executor_bench.go:126-137).
 // q1 / q3 / q9 run the whole plan tail on the library: gpuOrderExecutor (ORDER BY) and limitExecutor
 // (LIMIT), so their output is the reference's result file byte for byte with no sorting here.
@@ -238,6 +240,54 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "formats")) return formats();
     if (argc < 4) die("usage: host_tester roundtrip | q1|q6|q3 <sf_num> <sf_den> [stub]");
     std::string q = argv[1];
+    if (q == "ranks") {
+        // The N-rank split behind the operator interface: n threads = n ranks, each with its own ctx (device 0: one GPU here) and its SHARD of the
+        // database, joined by the in-process transport. Every rank builds the same executor tree, announces the communicator (SetComm ->
+        // ph_plan_set_comm) and pulls it; every rank must produce the same, complete result. Prints rank 0's text.
+        if (argc < 6) die("usage: host_tester ranks <n> <query_id> <sf_num> <sf_den>");
+        const int n = atoi(argv[2]), id = atoi(argv[3]);
+        const int64_t num = atoll(argv[4]), den = atoll(argv[5]);
+        if (n < 1 || n > 8 || num <= 0 || den <= 0) die("ranks: 1..8 ranks, positive scale factor");
+        ph_local_group *grp = nullptr;
+        if (ph_local_group_create(n, &grp) != PH_OK) die(std::string("ph_local_group_create: ") + ph_last_error());
+        std::vector<std::vector<std::string>> result((size_t)n);
+        std::vector<std::string> fail((size_t)n), explain((size_t)n);
+        std::vector<int> ncols((size_t)n, 0);
+        auto work = [&](int r) {
+            ph_ctx *ctx = nullptr;
+            ph_comm *comm = nullptr;
+            if (ph_ctx_create(0, &ctx) != PH_OK || ph_comm_init_local(ctx, grp, r, &comm) != PH_OK) { fail[(size_t)r] = std::string("ctx / comm: ") + ph_last_error(); return; }
+            {
+                TpchDatabase db;
+                std::string e = db.Load(ctx, num, den, r, n);
+                TpchQuery tq;
+                if (e.empty()) e = BuildTpchQuery(db, id, &tq);
+                // (a rank that failed BEFORE the first collective would leave the others waiting in it: every rank reaches the query or none does)
+                int64_t bad = e.empty() ? 0 : 1;
+                ph_comm_allreduce_i64(comm, &bad, 1, PH_RED_MAX);
+                if (bad) fail[(size_t)r] = e.empty() ? "another rank failed to load" : e;
+                else {
+                    auto t0 = std::chrono::steady_clock::now();
+                    e = RunTpchQuery(ctx, tq, &result[(size_t)r], &explain[(size_t)r], comm);
+                    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    if (!e.empty()) fail[(size_t)r] = e;
+                    else if (r == 0) fprintf(stderr, "Query %d took %.3fms success (%d ranks)\n", id, ms, n);
+                    ncols[(size_t)r] = tq.ncols;
+                }
+            }
+            ph_comm_destroy(comm);
+            ph_ctx_destroy(ctx);
+        };
+        std::vector<std::thread> ts;
+        for (int r = 0; r < n; r++) ts.emplace_back(work, r);
+        for (auto &t : ts) t.join();
+        ph_local_group_free(grp);
+        int rc = 0;
+        for (int r = 0; r < n; r++) if (!fail[(size_t)r].empty()) { fprintf(stderr, "host_tester ranks: rank %d: %s\n", r, fail[(size_t)r].c_str()); rc = 1; }
+        for (int r = 1; r < n && rc == 0; r++) if (result[(size_t)r] != result[0]) { fprintf(stderr, "host_tester ranks: rank %d's result differs from rank 0's\n", r); rc = 1; }
+        if (rc == 0) { fprintf(stderr, "%s", explain[0].c_str()); print(ncols[0], result[0]); }
+        return rc;
+    }
     if (q == "concurrent") {
         // Concurrent queries over SHARED resident tables (SURVEY.md §8(b) threading; the psql server path, cmd/main/main.go:71-122): the
         // database is loaded on context A; two threads own a context each and run whole queries — executors built, pulled, closed — over

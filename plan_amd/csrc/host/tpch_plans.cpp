@@ -75,10 +75,14 @@ TpchDatabase::~TpchDatabase() {
         if (t->table) ph_table_free(const_cast<ph_table *>(t->table));
 }
 
-std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
+std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den, int rank, int nranks) {
     ctx = c; num = sf_num; den = sf_den;
-    const int64_t no = tpchgen_orders_count(num, den), nc = tpchgen_customer_count(num, den), np = tpchgen_part_count(num, den),
-                  ns = tpchgen_supplier_count(num, den), nl = tpchgen_lineitem_count(num, den, 0, no);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return "TpchDatabase::Load: bad rank";
+    // this rank's row ranges [first, first + n) of every table (the generator starts at any row)
+    auto cut = [&](int64_t n, int64_t *first) { *first = n * rank / nranks; return n * (rank + 1) / nranks - *first; };
+    int64_t o0 = 0, c0 = 0, p0 = 0, s0 = 0;
+    const int64_t no = cut(tpchgen_orders_count(num, den), &o0), nc = cut(tpchgen_customer_count(num, den), &c0), np = cut(tpchgen_part_count(num, den), &p0),
+                  ns = cut(tpchgen_supplier_count(num, den), &s0), nl = tpchgen_lineitem_count(num, den, o0, no);
     std::string e;
     double t0 = now_s();
     {   // lineitem
@@ -90,7 +94,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         lc.l_discount = disc.data(); lc.l_tax = tax.data(); lc.l_returnflag = rf.data(); lc.l_linestatus = ls.data(); lc.l_shipdate = ship.data();
         lc.l_commitdate = commit.data(); lc.l_receiptdate = receipt.data(); lc.l_shipmode = mode.data(); lc.l_shipinstruct = instr.data();
         lc.l_linenumber = lno.data();
-        tpchgen_lineitem(num, den, 0, no, &lc);
+        tpchgen_lineitem(num, den, o0, no, &lc);
         generate_s += now_s() - t0; t0 = now_s();
         e = loadTable(ctx, {I64(okey.data()), I32(pk.data()), I32(sk.data()), I32(qty.data()), DEC(ext.data()), DEC(disc.data()), DEC(tax.data()),
                             CODE(rf.data(), dictOf(TPCHGEN_RETURNFLAG_DICT, 3)), CODE(ls.data(), dictOf(TPCHGEN_LINESTATUS_DICT, 2)), DATE(ship.data()),
@@ -107,7 +111,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_orders_cols oc{};
         oc.o_orderkey = okey.data(); oc.o_custkey = cust.data(); oc.o_orderdate = date.data(); oc.o_shippriority = sprio.data(); oc.o_orderpriority = oprio.data(); oc.o_totalprice = total.data();
         oc.o_orderstatus = ostat.data(); oc.o_comment = cmnt.data(); oc.o_comment_len = clen.data();
-        tpchgen_orders(num, den, 0, no, &oc);
+        tpchgen_orders(num, den, o0, no, &oc);
         std::vector<int32_t> coff;
         std::string cbytes;
         packStrings(cmnt, TPCHGEN_O_COMMENT_STRIDE, clen, &coff, &cbytes);   // o_comment: 19..78 characters of the generator's text pool (Q13's NOT LIKE)
@@ -130,7 +134,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_customer_cols cc{};
         cc.c_custkey = key.data(); cc.c_nationkey = nat.data(); cc.c_mktsegment = seg.data(); cc.c_phone = phone.data(); cc.c_acctbal = bal.data();
         cc.c_address = addr.data(); cc.c_address_len = alen.data(); cc.c_comment = cmnt.data(); cc.c_comment_len = clen.data();
-        tpchgen_customer(num, den, 0, nc, &cc);
+        tpchgen_customer(num, den, c0, nc, &cc);
         std::vector<int32_t> aoff, coff;
         std::string abytes, cbytes;
         packStrings(addr, TPCHGEN_S_ADDRESS_STRIDE, alen, &aoff, &abytes);     // c_address / c_comment: Q10's select list
@@ -159,7 +163,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_part_cols pc{};
         pc.p_partkey = key.data(); pc.p_name_colors = colors.data(); pc.p_brand = brand.data(); pc.p_type = type.data(); pc.p_size = size.data(); pc.p_container = cntr.data();
         pc.p_mfgr = mfgr.data();
-        tpchgen_part(num, den, 0, np, &pc);
+        tpchgen_part(num, den, p0, np, &pc);
         std::string bytes;
         for (int64_t r = 0; r < np; r++) {
             off[(size_t)r] = (int32_t)bytes.size();
@@ -177,7 +181,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         std::vector<int64_t> cost((size_t)np * 4);
         tpchgen_partsupp_cols pc{};
         pc.ps_partkey = pk.data(); pc.ps_suppkey = sk.data(); pc.ps_supplycost = cost.data(); pc.ps_availqty = qty.data();
-        tpchgen_partsupp(num, den, 0, np, &pc);
+        tpchgen_partsupp(num, den, p0, np, &pc);
         e = loadTable(ctx, {I32(pk.data()), I32(sk.data()), DEC(cost.data()), I32(qty.data())}, np * 4, {PS_PARTKEY, PS_SUPPKEY}, &partsupp, &loaded_bytes);
         if (!e.empty()) return e;
     }
@@ -190,7 +194,7 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         tpchgen_supplier_cols sc{};
         sc.s_suppkey = key.data(); sc.s_nationkey = nat.data(); sc.s_address = addr.data(); sc.s_address_len = alen.data(); sc.s_phone = phone.data();
         sc.s_acctbal = bal.data(); sc.s_comment = cmnt.data(); sc.s_comment_len = clen.data();
-        tpchgen_supplier(num, den, 0, ns, &sc);
+        tpchgen_supplier(num, den, s0, ns, &sc);
         std::vector<int32_t> coff;
         std::string cbytes;
         packStrings(cmnt, TPCHGEN_S_COMMENT_STRIDE, clen, &coff, &cbytes);   // s_comment with the "Customer ... Complaints" injection (Q16, Q2)
@@ -227,6 +231,10 @@ std::string TpchDatabase::Load(ph_ctx *c, int64_t sf_num, int64_t sf_den) {
         if (!e.empty()) return e;
         e = loadTable(ctx, {I32(rk.data()), CODE(rn.data(), dictOf(TPCHGEN_REGION_NAMES, 5))}, 5, {R_REGIONKEY}, &region, &loaded_bytes);
         if (!e.empty()) return e;
+        if (nranks > 1) {   // the specification's fixed tables are whole on every rank
+            ph_table_set_replicated(const_cast<ph_table *>(nation.table), 1);
+            ph_table_set_replicated(const_cast<ph_table *>(region.table), 1);
+        }
     }
     load_s += now_s() - t0;
     return "";
@@ -700,11 +708,12 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
     return p.error;
 }
 
-std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain) {
+std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain, ph_comm *comm) {
     std::vector<Compare> having = q.having;
     ResidentPlan mainPlan = q.plan;   // (Q22 patches a scan literal with its scalar subquery's value)
     if (q.scalar) {   // the uncorrelated scalar subquery first: one row, one DECIMAL value
         gpuResidentPlanExecutor sub(ctx, q.scalar->plan);
+        if (comm) sub.SetComm(comm);
         std::string e = sub.Init();
         if (!e.empty()) return "Init (scalar subquery): " + e;
         Chunk out;
@@ -732,6 +741,7 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     static const bool timing = getenv("PH_HOST_TIMING") != nullptr;   // where a query's HOST time goes (stderr, one line per query)
     const double tq0 = now_s();
     gpuResidentPlanExecutor agg(ctx, mainPlan);
+    if (comm) agg.SetComm(comm);
     if (!having.empty()) agg.SetHaving(having);
     if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
     if (q.topkAgg >= 0 && q.limit > 0) agg.SetTopK(q.topkAgg, q.topkDesc, q.limit);
@@ -806,8 +816,30 @@ extern "C" int64_t planhost_tpch_rows(void *dbp, const char *table) {
     return rt && rt->table ? ph_table_rows(rt->table) : -1;
 }
 
+extern "C" int planhost_tpch_load_shard(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, int32_t rank, int32_t nranks, void **db_out) {
+    if (!ctx || !db_out || sf_num <= 0 || sf_den <= 0 || nranks < 1 || rank < 0 || rank >= nranks) { g_host_err = "planhost_tpch_load_shard: bad arguments"; return PH_EINVAL; }
+    auto *db = new plan::TpchDatabase();
+    std::string e = db->Load(ctx, sf_num, sf_den, rank, nranks);
+    if (!e.empty()) { g_host_err = e; delete db; return PH_EHIP; }
+    *db_out = db;
+    return PH_OK;
+}
+
+static int tpch_run(void *dbp, ph_comm *comm, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
+                    char *explain_out, int64_t explain_cap);
+
 extern "C" int planhost_tpch_run(void *dbp, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
                                  char *explain_out, int64_t explain_cap) {
+    return tpch_run(dbp, nullptr, query, repeat, warmup, ms_avg, ms_min, text_out, text_cap, explain_out, explain_cap);
+}
+
+extern "C" int planhost_tpch_run_comm(void *dbp, ph_comm *comm, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out,
+                                      int64_t text_cap, char *explain_out, int64_t explain_cap) {
+    return tpch_run(dbp, comm, query, repeat, warmup, ms_avg, ms_min, text_out, text_cap, explain_out, explain_cap);
+}
+
+static int tpch_run(void *dbp, ph_comm *comm, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
+                    char *explain_out, int64_t explain_cap) {
     auto *db = (plan::TpchDatabase *)dbp;
     if (!db || repeat < 1 || warmup < 0) { g_host_err = "planhost_tpch_run: bad arguments"; return PH_EINVAL; }
     plan::TpchQuery q;
@@ -818,7 +850,7 @@ extern "C" int planhost_tpch_run(void *dbp, int32_t query, int32_t repeat, int32
     double total = 0, best = 1e300;
     for (int i = 0; i < warmup + repeat; i++) {
         const double t0 = plan::now_s();
-        e = plan::RunTpchQuery(db->ctx, q, &lines, &explain);   // builds the executors, pulls every chunk, closes them: one whole query
+        e = plan::RunTpchQuery(db->ctx, q, &lines, &explain, comm);   // builds the executors, pulls every chunk, closes them: one whole query
         const double dt = plan::now_s() - t0;
         if (!e.empty()) { g_host_err = e; return PH_EHIP; }
         if (i >= warmup) { total += dt; best = std::min(best, dt); }

@@ -31,8 +31,10 @@ struct TpchDatabase {
     ResidentTable lineitem, orders, customer, part, partsupp, supplier, nation, region;
     double generate_s = 0, load_s = 0;
     int64_t loaded_bytes = 0;
-    // generates (clean-room dbgen equivalent, include/tpchgen.h) and loads every table; declares the primary keys
-    std::string Load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den);
+    // generates (clean-room dbgen equivalent, include/tpchgen.h) and loads every table; declares the primary keys.
+    // rank / nranks: this rank's SHARD of a database split over nranks ranks — orders and lineitem by order ranges (a line lives with its order),
+    // customer / supplier / part (+ its partsupp rows) by row ranges, NATION and REGION whole on every rank (ph_table_set_replicated)
+    std::string Load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, int rank = 0, int nranks = 1);
     ~TpchDatabase();
 };
 
@@ -64,7 +66,8 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *out);
 
 // one execution through the operator interface, exactly as execOps pulls it (executor.go:151-188):
 // limitExecutor <- gpuOrderExecutor <- gpuResidentPlanExecutor; result rows as text lines (Chunk.SaveToFile format)
-std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain);
+// comm != nullptr: multi-rank execution — every rank calls this over its shard with its communicator and receives the complete result (ph_plan_set_comm)
+std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::string> *lines, std::string *explain, ph_comm *comm = nullptr);
 
 }  // namespace plan
 
@@ -72,6 +75,10 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
 // behind `warmup` untimed runs, report the per-query wall time the way Run prints it (executor_bench.go:126-137)
 extern "C" {
 int planhost_tpch_load(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, void **db_out);
+// this rank's shard of a database split over nranks ranks; planhost_tpch_run_comm runs a query over the shards with the ranks' communicator
+int planhost_tpch_load_shard(ph_ctx *ctx, int64_t sf_num, int64_t sf_den, int32_t rank, int32_t nranks, void **db_out);
+int planhost_tpch_run_comm(void *db, ph_comm *comm, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,
+                           char *explain_out, int64_t explain_cap);
 int64_t planhost_tpch_rows(void *db, const char *table);
 // text_out: headline + rows of the LAST run; explain_out: the library's account of the forms it chose
 int planhost_tpch_run(void *db, int32_t query, int32_t repeat, int32_t warmup, double *ms_avg, double *ms_min, char *text_out, int64_t text_cap,

@@ -2650,19 +2650,52 @@ uint64_t get64(const unsigned char *&q) { uint64_t v = 0; for (int i = 0; i < 8;
 int merge_over_ranks(ph_plan *p, ph_agg_result *mine, ph_agg_result **out) {
     const Node &nd = p->nodes.back();
     const int nk = std::max(mine->nkeys, 1), na = mine->naggs, nkeys = mine->nkeys;
-    // VARCHAR keys are row ids of a column: the same on every rank only for a replicated (or broadcast) table
-    for (int k = 0; k < nkeys; k++)
-        if (p->keys[(size_t)k].type == PH_STR && !(p->keys[(size_t)k].table && p->keys[(size_t)k].table->replicated)) {
-            set_error("ph_plan_fetch: VARCHAR group key %d names rows of a sharded table: it cannot be merged across ranks", k);
-            return PH_EUNSUPPORTED;
+    ph_ctx *ctx = p->ctx;
+    // A VARCHAR key is a row id of a column: the same on every rank only for a replicated (or broadcast) table. Keys that name rows of a rank's OWN
+    // table (a sharded table's column, a substring computed in the plan) travel as their STRINGS and are merged by them; the merged distinct
+    // strings then form a small table the plan owns, and the key values name ITS rows (ph_plan_key_info reports it).
+    std::vector<bool> by_string((size_t)nk, false);
+    std::vector<std::vector<std::string>> my_strings((size_t)nk);
+    for (int k = 0; k < nkeys; k++) {
+        const KeyInfo &ki = p->keys[(size_t)k];
+        if (ki.type != PH_STR || (ki.table && ki.table->replicated)) continue;
+        if (!ki.table) { set_error("ph_plan_fetch: VARCHAR group key %d has no table", k); return PH_EUNSUPPORTED; }
+        by_string[(size_t)k] = true;
+        std::vector<int64_t> rows;
+        for (int64_t g = 0; g < mine->ngroups; g++) if (!(mine->key_null && mine->key_null[g * nk + k])) rows.push_back(mine->keys[g * nk + k]);
+        std::vector<int32_t> off(rows.size() + 1, 0);
+        int64_t cap = 1 << 20;
+        std::vector<char> bytes;
+        int rc = PH_OK;
+        for (int attempt = 0; attempt < 8; attempt++) {
+            bytes.assign((size_t)cap, 0);
+            rc = rows.empty() ? PH_OK : ph_table_strings(ctx, ki.table, ki.col, rows.data(), (int64_t)rows.size(), off.data(), bytes.data(), cap);
+            if (rc != PH_ECAPACITY) break;
+            cap *= 8;
         }
+        PL_CHECK(rc);
+        size_t at = 0;
+        for (int64_t g = 0; g < mine->ngroups; g++) {
+            if (mine->key_null && mine->key_null[g * nk + k]) { my_strings[(size_t)k].push_back(std::string()); continue; }
+            my_strings[(size_t)k].emplace_back(bytes.data() + off[at], (size_t)(off[at + 1] - off[at]));
+            at++;
+        }
+    }
     std::vector<unsigned char> blob;
     put64(&blob, (uint64_t)mine->ngroups);
     for (int64_t g = 0; g < mine->ngroups; g++) {
-        for (int k = 0; k < nk; k++) { put64(&blob, (uint64_t)mine->keys[g * nk + k]); blob.push_back(mine->key_null ? mine->key_null[g * nk + k] : 0); }
+        for (int k = 0; k < nk; k++) {
+            if (by_string[(size_t)k]) {
+                const std::string &sv = my_strings[(size_t)k][(size_t)g];
+                put64(&blob, (uint64_t)sv.size());
+                blob.insert(blob.end(), sv.begin(), sv.end());
+            } else put64(&blob, (uint64_t)mine->keys[g * nk + k]);
+            blob.push_back(mine->key_null ? mine->key_null[g * nk + k] : 0);
+        }
         for (int a = 0; a < na; a++) { put64(&blob, mine->sum_lo[g * na + a]); put64(&blob, (uint64_t)mine->sum_hi[g * na + a]); put64(&blob, mine->count[g * na + a]); }
     }
-    ph_ctx *ctx = p->ctx;
+    std::vector<std::map<std::string, int64_t>> interned((size_t)nk);
+    std::vector<std::vector<std::string>> merged_strings((size_t)nk);
     const int n = ph_comm_nranks(p->comm);
     void *send = nullptr, *recv = nullptr;
     PL_CHECK(ctx->pool_alloc((int64_t)blob.size() + 64, &send));
@@ -2686,7 +2719,17 @@ int merge_over_ranks(ph_plan *p, ph_agg_result *mine, ph_agg_result **out) {
         for (int64_t g = 0; g < ng; g++) {
             G x;
             x.key.resize((size_t)nk); x.kn.resize((size_t)nk); x.lo.resize((size_t)na); x.hi.resize((size_t)na); x.cnt.resize((size_t)na);
-            for (int k = 0; k < nk; k++) { x.key[(size_t)k] = (int64_t)get64(q); x.kn[(size_t)k] = *q++; }
+            for (int k = 0; k < nk; k++) {
+                if (by_string[(size_t)k]) {
+                    const uint64_t len = get64(q);
+                    std::string sv((const char *)q, (size_t)len);
+                    q += len;
+                    auto it = interned[(size_t)k].find(sv);
+                    if (it == interned[(size_t)k].end()) { it = interned[(size_t)k].emplace(sv, (int64_t)merged_strings[(size_t)k].size()).first; merged_strings[(size_t)k].push_back(sv); }
+                    x.key[(size_t)k] = it->second;
+                } else x.key[(size_t)k] = (int64_t)get64(q);
+                x.kn[(size_t)k] = *q++;
+            }
             for (int a = 0; a < na; a++) { x.lo[(size_t)a] = get64(q); x.hi[(size_t)a] = (int64_t)get64(q); x.cnt[(size_t)a] = get64(q); }
             if (p->root_disjoint) { groups.push_back(std::move(x)); continue; }
             auto key = std::make_pair(x.key, x.kn);
@@ -2708,6 +2751,28 @@ int merge_over_ranks(ph_plan *p, ph_agg_result *mine, ph_agg_result **out) {
             }
         }
         q = end;
+    }
+    // the merged strings of every by-string key as a one-column table of the plan: the key values are its rows
+    for (int k = 0; k < nkeys; k++) {
+        if (!by_string[(size_t)k]) continue;
+        const auto &ms = merged_strings[(size_t)k];
+        std::vector<int32_t> off(ms.size() + 1, 0);
+        std::string bytes;
+        for (size_t i = 0; i < ms.size(); i++) { bytes += ms[i]; off[i + 1] = (int32_t)bytes.size(); }
+        void *od = nullptr, *bd = nullptr;
+        PL_CHECK(ctx->pool_alloc((int64_t)off.size() * 4 + 64, &od));
+        p->computed_bufs.push_back(od);
+        PL_CHECK(ctx->pool_alloc((int64_t)bytes.size() + 64, &bd));
+        p->computed_bufs.push_back(bd);
+        PL_CHECK(ph_dev_upload(ctx, od, off.data(), (int64_t)off.size() * 4));
+        if (!bytes.empty()) PL_CHECK(ph_dev_upload(ctx, bd, bytes.data(), (int64_t)bytes.size()));
+        ph_table *vt = new ph_table();
+        p->computed.push_back(vt);
+        vt->ctx = ctx; vt->nrows = (int64_t)ms.size(); vt->replicated = true;
+        vt->cols.resize(1);
+        vt->cols[0].type = PH_STR; vt->cols[0].data = od; vt->cols[0].aux = bd; vt->cols[0].aux_bytes = (int64_t)bytes.size();
+        p->keys[(size_t)k].table = vt;
+        p->keys[(size_t)k].col = 0;
     }
     ph_agg_result *r = new_result((int64_t)groups.size(), nkeys, na);
     bool any_null = false;

@@ -254,3 +254,18 @@ def test_concurrent_queries_over_shared_resident_tables_match_goldens():
     assert q9 == open(os.path.join(G, "plan_q9.txt")).read(), err
     assert err.count("Query 3 took") == 4 and err.count("Query 9 took") == 4
     assert "the five Q9 columns covered: 1" in err and "co-located copies: 0 bytes" not in err, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qid", ["3", "5", "9", "13", "16", "18", "21", "22"])
+def test_queries_over_two_ranks_behind_the_operator_interface_match_goldens(qid):
+    """the N-rank split INSIDE the boundary. `host_tester ranks 2 <q> 1 1`: two threads = two ranks, each with its own context
+    and its SHARD of the database (orders / lineitem by order ranges, the other tables by row ranges, NATION / REGION whole), the in-process
+    transport between them; every rank builds the same executor tree, announces the communicator (gpuResidentPlanExecutor::SetComm ->
+    ph_plan_set_comm) and pulls it. The library co-locates by key ranges, broadcasts small build sides (VARCHAR columns included), hash-partitions
+    and exchanges the big ones, makes groups whole where a top-k / HAVING / DISTINCT / an aggregate below other operators needs them and merges
+    partial states at fetch (Q22: a computed VARCHAR key merged by its strings). Both ranks must print the reference's golden (host_tester
+    compares the ranks' results itself)."""
+    out, err = run_err("ranks", "2", qid, "1", "1")
+    assert out == open(os.path.join(G, f"plan_q{qid}.txt")).read(), err
+    assert "(2 ranks)" in err
