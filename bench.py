@@ -637,6 +637,49 @@ def bench_operator_interface(h, sf, steps, warmup):
     return out
 
 
+def bench_operator_interface_ranks(h, sf, steps, warmup):
+    """Q3 and Q9 behind the OperatorExec interface over ALL ranks: every rank loads its SHARD of the SF`sf` database through
+    the C++ host layer (planhost_tpch_load_shard: orders / lineitem by order ranges, the other tables by row ranges, NATION / REGION whole), builds
+    the same executor tree per step and announces the ranks' communicator (gpuResidentPlanExecutor::SetComm -> ph_plan_set_comm); the library
+    inserts the exchanges (co-location by key ranges, broadcast of small build sides, hash-partitioned all-to-all over RCCL, merge of partial
+    states) and every rank's executor emits the complete result. Strong scaling: the SF`sf` database split N ways. RCCL only (the one-GPU
+    rehearsal's gloo transport lives above the ABI; the in-process transport of the 2-rank tests needs the ranks in one process)."""
+    import ctypes
+    if h.comm is None:
+        return {"skipped": "needs the RCCL communicator (PH_BENCH_BACKEND=gloo rehearsal: the in-library split is covered by tests/test_gpu_multirank_plan.py "
+                           "and host_tester ranks, over the in-process transport)"}
+    lib = ctypes.CDLL(os.path.join(ROOT, "plan_amd", "libplantpch.so"))
+    lib.planhost_last_error.restype = ctypes.c_char_p
+    lib.planhost_tpch_rows.restype = ctypes.c_int64
+    db = ctypes.c_void_p()
+    if lib.planhost_tpch_load_shard(h.ctx.h, ctypes.c_int64(sf), ctypes.c_int64(1), ctypes.c_int32(h.rank), ctypes.c_int32(h.world), ctypes.byref(db)) != 0:
+        raise RuntimeError(lib.planhost_last_error().decode())
+    out = {}
+    try:
+        nl = h.allreduce([int(lib.planhost_tpch_rows(db, b"lineitem"))], "sum")[0]
+        for q in (3, 9):
+            avg, mn = ctypes.c_double(), ctypes.c_double()
+            text, explain = ctypes.create_string_buffer(1 << 16), ctypes.create_string_buffer(1 << 14)
+            rc = lib.planhost_tpch_run_comm(db, h.comm.h, ctypes.c_int32(q), ctypes.c_int32(steps), ctypes.c_int32(warmup), ctypes.byref(avg), ctypes.byref(mn),
+                                            text, ctypes.c_int64(len(text)), explain, ctypes.c_int64(len(explain)))
+            bad = h.allreduce([1 if rc != 0 else 0], "max")[0]
+            if bad:
+                out[f"q{q}"] = {"error": lib.planhost_last_error().decode() if rc != 0 else "another rank failed"}
+                continue
+            ms = h.allreduce([int(avg.value * 1e6)], "max")[0] / 1e6     # the slowest rank's average: every step ends in collectives
+            rows = text.value.decode().split("\n")
+            path = os.path.join(ROOT, "tests", "golden", "sf10", f"oracle_q{q}.txt") if sf == 10 else os.path.join(ROOT, "tests", "golden", f"plan_q{q}.txt") if sf == 1 else None
+            parity = "unchecked (no fixture at this scale factor)" if not path or not os.path.exists(path) else \
+                ("ok: byte-identical to " + os.path.relpath(path, ROOT) if open(path).read() == text.value.decode() else "MISMATCH against " + os.path.relpath(path, ROOT))
+            out[f"q{q}"] = {"metric": f"rows/sec through Q{q} behind the OperatorExec interface over {h.world} ranks (ph_plan_set_comm)", "value": nl / (ms * 1e-3),
+                            "unit": "rows/s", "n_gpus": h.world, "ms_per_step": ms, "steps": steps, "warmup": warmup, "scaling": "strong", "parity": parity,
+                            "config": {"workload": f"TPC-H Q{q} at SF{sf} split over {h.world} ranks, {nl} lineitem rows in all", "result_rows": len([r for r in rows[1:] if r]),
+                                       "forms_chosen_by_the_library": [l.strip() for l in explain.value.decode().split("\n") if l.strip().startswith(("join", "agg", "exchange", "broadcast"))]}}
+    finally:
+        lib.planhost_tpch_free(db)
+    return out
+
+
 # ---------------------------------------------------------------------------------- CPU baselines
 
 def cpu_baselines(L, max_rows):
@@ -784,6 +827,8 @@ def main():
         # BASELINE.json config 5: Q9 at SF`--sf`, multi-stage partitioned build/probe across the N GPUs
         attempt("q9_partitioned", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong")))
         attempt("q9_partitionwise", lambda: brief(bench_q9(h, args.sf, comp_steps, comp_warm, "strong", partitionwise=True)))
+        # the same two queries with the split INSIDE the boundary: the C++ OperatorExec layer over every rank's shard, ph_plan_set_comm
+        attempt("operator_interface_over_ranks", lambda: bench_operator_interface_ranks(h, args.sf, min(comp_steps, 20), min(comp_warm, 3)))
     elif rank0 and world == 1 and not args.no_cpu_baseline and L is not None:
         cb = cpu_baselines(L, args.cpu_rows)
         out["cpu_baseline"] = cb[args.query]
