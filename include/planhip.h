@@ -407,10 +407,8 @@ int ph_agg_values_dev(ph_agg *a, int32_t agg_index, int64_t *out_dev, uint8_t *o
  * the same table (PH_EUNSUPPORTED). Results are those of ph_agg_sink (exact 128-bit sums, NULL inputs
  * skipped). The order is verified on the device: a key tuple lexicographically below its predecessor's
  * is a DEFERRED PH_ECONSTRAINT of the ctx, reported by the next call that reads back, and the caller
- * aggregates again with ph_agg_sink. The same deferred PH_ECONSTRAINT withdraws the form when more than an
- * eighth of the rows lie in runs that span whole 256-row chunks (a table clustered by a low-cardinality key:
- * the form is for short runs; a head's thread walks its run alone) — nothing is written then. NULL-able
- * keys: PH_EUNSUPPORTED. */
+ * aggregates again with ph_agg_sink. Runs may be of any length: a 1024-row tile is reduced as a segmented scan and the pieces of a run that
+ * crosses tiles are joined one step per TILE (a table clustered by a low-cardinality key included). NULL-able keys: PH_EUNSUPPORTED. */
 int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *args, int32_t nargs, int64_t n, int64_t row_base);
 int ph_agg_group_count(ph_agg *a, int64_t *ngroups);
 /* Build check without a device of the plan-specialised sink: ph_agg_sink calls of >= 2^20 rows run

@@ -71,9 +71,9 @@ int ph_ctx::finish_deferred() {
     PH_HIP(hipMemsetAsync(deferred_dev, 0, 64, stream));
     if (ovf) { ph::set_error("deferred from ph_expr_eval: a row left the exact int64 decimal domain"); return PH_EOVERFLOW; }
     if (unsorted) {
-        ph::set_error("deferred: a sorted-input claim does not hold (ph_join_build_ex PH_JOIN_KEYS_SORTED_UNIQUE build keys are not "
-                      "strictly ascending, or ph_agg_sink_sorted rows are not ordered by the group key — or one group's run is longer than "
-                      "the streaming form walks: take ph_agg_sink)");
+        // bit 0: a sorted fill's keys, bit 2: a streaming aggregate's rows (the messages are told apart by ph_plan: it retires only the form that broke)
+        if (unsorted & 4) ph::set_error("deferred: ph_agg_sink_sorted rows are not ordered by the group key tuple (take ph_agg_sink)");
+        else ph::set_error("deferred: a sorted-input claim does not hold (ph_join_build_ex PH_JOIN_KEYS_SORTED_UNIQUE build keys are not strictly ascending)");
         return PH_ECONSTRAINT;
     }
     ph::set_error("deferred from ph_join_lookup_strict: %d probe rows without a match, %d with more than one", miss, multi);

@@ -1672,10 +1672,57 @@ struct SortedAgg {
     int *violation;      // deferred-error word of the ctx
 };
 
-constexpr int SA_CHUNK = 256;   // one row per thread: a head's thread walks its run with dependent loads, so the launch
-                                // wants as many independent walks in flight as possible (2048-row blocks: 76 us
-                                // for Q3's 298 k rows, 8 rounds of walks one after the other)
+// Round 4: tiles instead of one-row-per-thread walks. A workgroup takes a tile of SA_TILE rows, a lane SA_V consecutive rows: the keys are read
+// once per pass with plain coalesced loads, run heads come from comparing neighbours, group ids from the tile's head count (scanned over the tiles)
+// plus a workgroup scan. Every aggregate is reduced as a SEGMENTED SCAN over the tile: a lane first folds its own rows (runs that begin and end
+// inside its rows are written at once), then lanes combine across the wave with shuffles and across the four waves through LDS; the lane that
+// holds a run's LAST row in the tile adds what the scan carried in and writes the group's record — once, with plain stores. A run that crosses
+// tiles leaves two partials per tile in a small side array (what precedes the tile's first head, what follows its last head) and a fix-up
+// launch, one lane per tile, adds them up — per TILE, so a run of a million rows (a table clustered by a low-cardinality key) costs a thousand
+// steps of one lane, not a million dependent loads (round 3 withdrew the form for such inputs; ADVICE r3: a single long run among short ones
+// was still walked row by row). 60 M rows x (8 B key + 4 B argument), 15 M groups (Q18's subquery): 1 325 us -> see profiles/README.md.
+constexpr int SA_V = 4;                    // rows per lane
+constexpr int SA_TILE = 256 * SA_V;        // rows per workgroup
 
+struct SaPart {                            // the partial state of one aggregate over some rows of one run
+    unsigned long long lo;                 // SUM / AVG: the 128-bit sum; MIN / MAX: the value
+    long long hi;
+    unsigned long long cnt;                // non-NULL inputs (COUNT_STAR: rows)
+};
+
+__device__ __forceinline__ SaPart sa_empty(int kind) {
+    SaPart p;
+    p.lo = kind == PH_A_MIN ? (unsigned long long)INT64_MAX : kind == PH_A_MAX ? (unsigned long long)INT64_MIN : 0ull;
+    p.hi = 0; p.cnt = 0;
+    return p;
+}
+__device__ __forceinline__ SaPart sa_combine(int kind, const SaPart &a, const SaPart &b) {   // a's rows precede b's
+    SaPart r;
+    r.cnt = a.cnt + b.cnt;
+    if (kind == PH_A_MIN) { r.lo = (long long)b.lo < (long long)a.lo ? b.lo : a.lo; r.hi = 0; }
+    else if (kind == PH_A_MAX) { r.lo = (long long)b.lo > (long long)a.lo ? b.lo : a.lo; r.hi = 0; }
+    else { r.lo = a.lo + b.lo; r.hi = a.hi + b.hi + (r.lo < a.lo ? 1 : 0); }
+    return r;
+}
+__device__ __forceinline__ SaPart sa_value(int kind, long long v) {
+    SaPart p;
+    p.lo = (unsigned long long)v; p.hi = (kind == PH_A_MIN || kind == PH_A_MAX) ? 0 : (v < 0 ? -1 : 0); p.cnt = 1;
+    return p;
+}
+__device__ __forceinline__ SaPart sa_shfl_up(const SaPart &p, int o) {
+    SaPart r;
+    r.lo = __shfl_up(p.lo, o); r.hi = __shfl_up(p.hi, o); r.cnt = __shfl_up(p.cnt, o);
+    return r;
+}
+__device__ __forceinline__ void sa_store(const SortedAgg &S, int64_t g, int a, int kind, const SaPart &p) {
+    const int64_t st = g * S.naggs + a;
+    S.cnt[st] = p.cnt;
+    if (kind == PH_A_COUNT || kind == PH_A_COUNT_STAR) { S.sum_lo[st] = 0; S.sum_hi[st] = 0; }
+    else if (kind == PH_A_MIN || kind == PH_A_MAX) { S.sum_lo[st] = p.lo; S.sum_hi[st] = 0; }   // (cnt == 0: the value is the identity; readers test cnt)
+    else { S.sum_lo[st] = p.lo; S.sum_hi[st] = p.hi; }
+}
+
+// is row i a run head: its key tuple differs from row i-1's? (*descending: it is lexicographically BELOW it — the order claim is broken)
 __device__ __forceinline__ bool sa_is_head(const SortedAgg &S, int64_t i, bool *descending) {
     if (i == 0) return true;
     bool differ = false, below = false;
@@ -1689,94 +1736,163 @@ __device__ __forceinline__ bool sa_is_head(const SortedAgg &S, int64_t i, bool *
     return differ;
 }
 
-__global__ __launch_bounds__(256) void sorted_heads_kernel(SortedAgg S, int32_t *__restrict__ counts) {
-    const int64_t base = (int64_t)blockIdx.x * SA_CHUNK;
-    int heads = 0;
-    bool bad = false;
-    for (int r = 0; r < SA_CHUNK / 256; r++) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        if (i < S.n) {
-            bool desc = false;
-            heads += sa_is_head(S, i, &desc) ? 1 : 0;
-            bad = bad || desc;
+// head flags of a lane's SA_V rows as a bit mask (rows >= n: no head)
+__device__ __forceinline__ unsigned sa_lane_heads(const SortedAgg &S, int64_t base, bool *bad) {
+    unsigned h = 0;
+    if (S.nkeys == 1) {   // one key: SA_V + 1 loads instead of 2 * SA_V
+        long long prev = base > 0 && base - 1 < S.n ? (long long)load_key(S.key[0], base - 1) : 0;
+#pragma unroll
+        for (int r = 0; r < SA_V; r++) {
+            const int64_t i = base + r;
+            if (i >= S.n) break;
+            const long long k = (long long)load_key(S.key[0], i);
+            if (i == 0 || k != prev) { h |= 1u << r; if (i > 0 && k < prev) *bad = true; }
+            prev = k;
         }
+        return h;
     }
-    if (bad) atomicOr(S.violation, 1);
+#pragma unroll
+    for (int r = 0; r < SA_V; r++) {
+        const int64_t i = base + r;
+        if (i >= S.n) break;
+        bool desc = false;
+        if (sa_is_head(S, i, &desc)) h |= 1u << r;
+        *bad = *bad || desc;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(256) void sorted_heads_kernel(SortedAgg S, int32_t *__restrict__ counts) {
+    const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)threadIdx.x * SA_V;
+    bool bad = false;
+    int heads = __popc(sa_lane_heads(S, base, &bad));
+    if (bad) atomicOr(S.violation, 4);
     for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o);
     __shared__ int ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = heads;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int h = ws[0] + ws[1] + ws[2] + ws[3];
-        counts[blockIdx.x] = h;
-        // A whole chunk inside one run: not the shape the streaming form is for — a head's thread walks its run with dependent loads, so a
-        // run of a million rows (a table clustered by a low-cardinality key) would be one thread's million loads. When such chunks hold more
-        // than an eighth of the rows the claim is withdrawn like a broken order: deferred PH_ECONSTRAINT, the caller takes the hash aggregate
-        // (a plan reruns conservatively).
-        if (h == 0 && base + SA_CHUNK <= S.n && base > 0) atomicAdd(&S.counters[3], 1);   // (chunks that lie inside one run)
-    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total) {
-    // more than an eighth of the rows in runs that span whole chunks: withdrawn (a stray long run among short ones is walked)
-    if ((int64_t)__hip_atomic_load(&S.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * SA_CHUNK * 8 > S.n) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(S.violation, 2);
-        return;
-    }
-    const int64_t base = (int64_t)blockIdx.x * SA_CHUNK;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int wc[SA_CHUNK / 256][4];
-    bool head[SA_CHUNK / 256];
-    unsigned long long bal[SA_CHUNK / 256];
-#pragma unroll
-    for (int r = 0; r < SA_CHUNK / 256; r++) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        bool desc = false;
-        head[r] = i < S.n && sa_is_head(S, i, &desc);
-        bal[r] = __ballot(head[r]);
-        if (lane == 0) wc[r][wv] = __popcll(bal[r]);
-    }
+// side[(tile * naggs + a) * 2 + 0] = the partial of the rows before the tile's first head (the whole tile when it has none),
+// side[.. + 1] = the partial from the tile's last head to its end (unused without a head)
+__global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
+                                                            SaPart *__restrict__ side) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)tid * SA_V;
+    bool bad = false;
+    const unsigned h = sa_lane_heads(S, base, &bad);
+    const int nh = __popc(h);
+    // exclusive scan of the head counts over the workgroup -> the lane's first group id
+    __shared__ int wc[4];
+    __shared__ SaPart wpart[4];
+    __shared__ int wflag[4];
+    int incl = nh;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+    if (lane == 63) wc[wv] = incl;
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) S.counters[0] = (int)*total;
-    int before = block_off[blockIdx.x];
+    int excl = incl - nh;
+    for (int q = 0; q < wv; q++) excl += wc[q];
+    const int tile_heads = wc[0] + wc[1] + wc[2] + wc[3];
+    const int64_t goff = (int64_t)block_off[blockIdx.x] + excl;     // group id of the lane's first head; goff - 1: the run its leading rows continue
+    if (blockIdx.x == 0 && tid == 0) S.counters[0] = (int)*total;
+    // the heads' keys and first rows
+    {
+        int k = 0;
 #pragma unroll
-    for (int r = 0; r < SA_CHUNK / 256; r++) {
-        int off = before;
-        for (int q = 0; q < wv; q++) off += wc[r][q];
-        if (head[r]) {
-            const int64_t i = base + r * 256 + threadIdx.x;
-            const int64_t g = off + __popcll(bal[r] & ((1ull << lane) - 1ull));
-            // the run: rows i .. j-1 share the key tuple
-            int64_t j = i + 1;
-            for (bool desc; j < S.n && !sa_is_head(S, j, &desc); j++) {}
+        for (int r = 0; r < SA_V; r++) {
+            if (!((h >> r) & 1)) continue;
+            const int64_t i = base + r, g = goff + k++;
             S.first_row[g] = S.row_base + i;
             S.gnull[g] = 0;
             for (int c = 0; c < S.nkeys; c++) S.gkeys[g * S.nkeys + c] = load_key(S.key[c], i);
-            // one aggregate at a time (runs are short; no per-thread arrays indexed by the aggregate)
-            for (int a = 0; a < S.naggs; a++) {
-                const int kind = S.agg_kind[a];
-                const int64_t st = g * S.naggs + a;
-                if (kind == PH_A_COUNT_STAR) { S.cnt[st] = (unsigned long long)(j - i); S.sum_lo[st] = 0; S.sum_hi[st] = 0; continue; }
-                const AggCol &c = S.arg[S.agg_arg[a]];
-                __int128 sum = 0;
-                long long mn = INT64_MAX, mx = INT64_MIN;
-                unsigned long long cn = 0;
-                for (int64_t q = i; q < j; q++) {
-                    if (c.validity && !bit_valid(c.validity, q)) continue;   // NULL inputs are skipped
-                    const long long v = c.type == PH_I32 ? (long long)((const int32_t *)c.data)[q] : ((const int64_t *)c.data)[q];
-                    cn++;
-                    sum += v;
-                    mn = v < mn ? v : mn;
-                    mx = v > mx ? v : mx;
-                }
-                S.cnt[st] = cn;
-                if (kind == PH_A_MIN) { S.sum_lo[st] = (unsigned long long)mn; S.sum_hi[st] = 0; }
-                else if (kind == PH_A_MAX) { S.sum_lo[st] = (unsigned long long)mx; S.sum_hi[st] = 0; }
-                else if (kind == PH_A_COUNT) { S.sum_lo[st] = 0; S.sum_hi[st] = 0; }
-                else { S.sum_lo[st] = (unsigned long long)sum; S.sum_hi[st] = (long long)(sum >> 64); }
+        }
+    }
+    int rows_here = 0;
+#pragma unroll
+    for (int r = 0; r < SA_V; r++) rows_here += base + r < S.n ? 1 : 0;
+    for (int a = 0; a < S.naggs; a++) {
+        const int kind = S.agg_kind[a];
+        // the lane's own rows: `pre` = before its first head (all rows without one), interior runs written at once, `suf` = from its last head on
+        SaPart pre = sa_empty(kind), cur = sa_empty(kind);
+        int k = 0;
+        bool seen_head = false;
+        const AggCol *col = kind == PH_A_COUNT_STAR ? nullptr : &S.arg[S.agg_arg[a]];
+#pragma unroll
+        for (int r = 0; r < SA_V; r++) {
+            const int64_t i = base + r;
+            if (i >= S.n) break;
+            if ((h >> r) & 1) {
+                if (seen_head) sa_store(S, goff + k - 1, a, kind, cur);   // a run that began and ended inside this lane's rows
+                else pre = cur;
+                cur = sa_empty(kind);
+                seen_head = true;
+                k++;
+            }
+            if (!col) cur.cnt++;
+            else if (!col->validity || bit_valid(col->validity, i)) {
+                const long long v = col->type == PH_I32 ? (long long)((const int32_t *)col->data)[i] : ((const int64_t *)col->data)[i];
+                cur = sa_combine(kind, cur, sa_value(kind, v));
             }
         }
-        before += wc[r][0] + wc[r][1] + wc[r][2] + wc[r][3];
+        if (!seen_head) { pre = cur; }
+        // segmented inclusive scan over the lanes: element = (has a head ? the part from its last head : all its rows)
+        SaPart x = cur;           // (== pre when the lane has no head)
+        int f = seen_head ? 1 : 0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const SaPart y = sa_shfl_up(x, o);
+            const int fy = __shfl_up(f, o);
+            if (lane >= o && !f) { x = sa_combine(kind, y, x); f = fy; }
+        }
+        // carry into this lane = the scanned value of the previous lane (and whether a head precedes inside the wave)
+        SaPart carry = sa_shfl_up(x, 1);
+        int cflag = __shfl_up(f, 1);
+        if (lane == 0) { carry = sa_empty(kind); cflag = 0; }
+        if (lane == 63) { wpart[wv] = x; wflag[wv] = f; }
+        __syncthreads();
+        // earlier waves: their tails extend into this wave as long as no head intervenes
+        SaPart wcarry = sa_empty(kind);
+        int wcf = 0;
+        for (int q = 0; q < wv; q++) {
+            if (wflag[q]) { wcarry = wpart[q]; wcf = 1; }
+            else wcarry = sa_combine(kind, wcarry, wpart[q]);
+        }
+        if (!cflag) { carry = sa_combine(kind, wcarry, carry); cflag = wcf; }
+        // the run that ENDS at this lane's first head (or continues through the lane): carried part + `pre`
+        if (seen_head && rows_here > 0) {
+            const SaPart done = sa_combine(kind, carry, pre);
+            if (cflag) sa_store(S, goff - 1, a, kind, done);                                   // its head lies in this tile: whole here? only if it began here
+            else side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 0] = done;                      // it began in an earlier tile: the tile's leading partial
+        }
+        // the tile's trailing partial: the last lane's inclusive value
+        if (tid == 255) {
+            const SaPart incl_all = f ? x : sa_combine(kind, wcarry, x);
+            const bool any = f || wcf;
+            // (x of the last lane already folds its wave's tail; wcarry folds the earlier waves' when no head sits in between)
+            if (tile_heads == 0) side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 0] = incl_all;  // the whole tile inside one run
+            else side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 1] = any ? incl_all : incl_all;
+        }
+        __syncthreads();
+    }
+}
+
+// one lane per tile with a head: its last run = its trailing partial + the following tiles without a head + the next tile's leading partial
+__global__ __launch_bounds__(256) void sorted_fixup_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
+                                                           const SaPart *__restrict__ side) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const int64_t off = block_off[t], next = t + 1 < ntiles ? block_off[t + 1] : *total;
+    if (next == off) return;                       // no head in this tile: some earlier tile's lane walks over it
+    const int64_t g = next - 1;                    // the tile's last head's group
+    for (int a = 0; a < S.naggs; a++) {
+        const int kind = S.agg_kind[a];
+        SaPart acc = side[(t * S.naggs + a) * 2 + 1];
+        for (int64_t u = t + 1; u < ntiles; u++) {
+            const int64_t uo = block_off[u], un = u + 1 < ntiles ? block_off[u + 1] : *total;
+            acc = sa_combine(kind, acc, side[(u * S.naggs + a) * 2 + 0]);
+            if (un != uo) break;                   // tile u has a head: its leading partial closed the run
+        }
+        sa_store(S, g, a, kind, acc);
     }
 }
 
@@ -1814,17 +1930,24 @@ extern "C" int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *a
     int *words = nullptr;
     PH_CHECK(ctx->deferred_words(&words));
     S.violation = words + 3;
-    const int64_t nb = (n + ph::SA_CHUNK - 1) / ph::SA_CHUNK;
+    const int64_t nb = (n + ph::SA_TILE - 1) / ph::SA_TILE;
     PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    ph::SaPart *side = nullptr;   // two partials per tile and aggregate (runs that cross tiles)
+    PH_CHECK(ctx->pool_alloc(nb * a->naggs * 2 * (int64_t)sizeof(ph::SaPart) + 64, (void **)&side));
     PH_CHECK(agg_clear(a, false, 0, 8, nullptr, 0));   // the four counter words + the top-k state words
     a->fresh = false;
     ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
-    PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
-    ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total);
-    PH_HIP(hipGetLastError());
+    int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
+    if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
+    if (rc == PH_OK) {
+        ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total, side);
+        ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(S, counts, total, nb, side);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    ctx->pool_release(side);   // (stream-ordered reuse)
+    if (rc != PH_OK) { ph::set_error("ph_agg_sink_sorted: launch failed"); return rc; }
     ctx->deferred_pending = true;
     a->rows_sunk += n;
     a->sorted_built = true;

@@ -110,6 +110,8 @@ struct ph_plan {
     int32_t topk_agg = -1, topk_desc = 0;
     int64_t topk_k = 0;
     bool conservative = false;          // statistics are not trusted (after a broken claim)
+    bool no_stream_agg = false;         // only the streaming aggregate's order claim broke (rows ordered by the first key, not by the key TUPLE): the
+                                        // hash aggregate from then on — the joins keep their optimistic forms
     // state of the last run
     bool ran = false;
     std::vector<void *> temps;
@@ -2146,7 +2148,7 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
     if ((*aggp)) { ph_agg_free((*aggp)); (*aggp) = nullptr; }
     PL_CHECK(ph_agg_create(ctx, (int32_t)key_types.size(), key_types.data(), (int32_t)specs.size(), specs.data(), expected, &(*aggp)));
     bool streamed = false;
-    if (!distinct_mask && !p->conservative && !nd.groups.empty() && S.cols[0].ordered && (*packs)[0].word == 0 && (*packs)[0].part == 0 && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
+    if (!distinct_mask && !p->conservative && !p->no_stream_agg && !nd.groups.empty() && S.cols[0].ordered && (*packs)[0].word == 0 && (*packs)[0].part == 0 && S.n > 0 && !getenv("PH_PLAN_NO_STREAM_AGG")) {
         int rc = ph_agg_sink_sorted((*aggp), keys.data(), args.data(), (int32_t)args.size(), S.n, 0);
         if (rc == PH_OK) streamed = true;
         else if (rc != PH_EUNSUPPORTED) return rc;
@@ -2269,6 +2271,19 @@ int lower_agg(ph_plan *p) {
     }
 
     return sink_into_agg(p, idx, R, true, &p->agg, &p->keys, &p->agg_scale, &p->agg_arg_type, &p->key_packs);
+}
+
+// a deferred PH_ECONSTRAINT surfaced: which claim broke? The streaming aggregate's message names it: only that form is retired (the plan's
+// joins keep theirs); anything else (a sorted fill, a strict lookup) makes the plan conservative as before.
+void retire_broken_claim(ph_plan *p) {
+    const char *msg = ph_last_error();
+    if (msg && strstr(msg, "ph_agg_sink_sorted") && !p->no_stream_agg) {
+        p->no_stream_agg = true;
+        p->explain += "  -> the rows were not ordered by the whole group-key tuple: hash aggregate from here on (the joins keep their forms)\n";
+    } else {
+        p->explain += "  -> a statistic did not hold (" + std::string(msg ? msg : "") + "): conservative forms from here on\n";
+        p->conservative = true;
+    }
 }
 
 int run_once(ph_plan *p) {
@@ -2601,10 +2616,9 @@ extern "C" int ph_plan_run(ph_plan *p) {
     PH_HIP(hipSetDevice(p->ctx->device));
     if (multi(p)) return run_agreed(p);
     int rc = run_once(p);
-    if (rc == PH_ECONSTRAINT && !p->conservative) {   // a broken claim surfaced at a count read-back in the middle of the run
-        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): conservative forms from here on\n";
+    for (int again = 0; again < 2 && rc == PH_ECONSTRAINT && !p->conservative; again++) {   // a broken claim surfaced at a count read-back in the middle of the run
+        retire_broken_claim(p);
         const std::string first = p->explain;
-        p->conservative = true;
         rc = run_once(p);
         p->explain = first + p->explain;
     }
@@ -2627,10 +2641,9 @@ extern "C" int ph_plan_fetch_rows(ph_plan *p, ph_rows_result **out) {
     PH_REQUIRE(p->rows_root, "ph_plan_fetch_rows: the plan's root is an aggregate (ph_plan_fetch)");
     PH_REQUIRE(p->ran && p->rows_rel, "ph_plan_fetch_rows: ph_plan_run first");
     int rc = fetch_rows_once(p, out);
-    if (rc == PH_ECONSTRAINT && !p->conservative) {
-        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): the plan runs again in its conservative forms\n";
+    for (int again = 0; again < 2 && rc == PH_ECONSTRAINT && !p->conservative; again++) {
+        retire_broken_claim(p);
         const std::string first = p->explain;
-        p->conservative = true;
         rc = run_once(p);
         p->explain = first + p->explain;
         if (rc == PH_OK) rc = fetch_rows_once(p, out);
@@ -2811,10 +2824,9 @@ extern "C" int ph_plan_fetch(ph_plan *p, ph_agg_result **out) {
     // the intermediates go back to the pool BEFORE the host blocks in the download (bookkeeping while the GPU is busy)
     release_run(p, true);
     int rc = fetch_once(p, out);
-    if (rc == PH_ECONSTRAINT && !p->conservative) {
-        p->explain += "  -> a statistic did not hold (" + std::string(ph_last_error()) + "): the plan runs again in its conservative forms\n";
+    for (int again = 0; again < 2 && rc == PH_ECONSTRAINT && !p->conservative; again++) {
+        retire_broken_claim(p);
         const std::string first = p->explain;
-        p->conservative = true;
         rc = run_once(p);
         p->explain = first + p->explain;
         if (rc == PH_OK) { release_run(p, true); rc = fetch_once(p, out); }

@@ -2113,25 +2113,56 @@ def test_existence_only_table_marks_like_the_oracle(ctx, kw):
 
 
 @pytest.mark.gpu
-def test_streaming_aggregate_withdraws_on_long_runs(ctx):
-    """rows ordered by a LOW-cardinality key: a run spans whole 256-row chunks, the streaming form withdraws with the deferred
-    PH_ECONSTRAINT (it would walk each run in one thread) and the hash aggregate gives the groups"""
-    n = 400_000
-    keys = np.repeat(np.arange(8, dtype=np.int64), n // 8)
-    vals = np.arange(n, dtype=np.int64) % 1000
-    K, V = hip.DevColumn(ctx, hip.PH_I64, keys), hip.DevColumn(ctx, hip.PH_I64, vals)
-    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0)], 16)
-    ctx.set_deferred_errors(True)
-    try:
-        assert agg.sink_sorted([K], [V], n)
-        with pytest.raises(hip.PlanHipError) as e:
-            ctx.check_deferred()
-        assert e.value.code == hip.PH_ECONSTRAINT
-    finally:
-        ctx.set_deferred_errors(False)
+def test_streaming_aggregate_long_runs_are_reduced_tile_by_tile(ctx):
+    """Round 4: the streaming aggregate reduces every 1024-row tile as a segmented scan and joins the pieces of a run that crosses
+    tiles in a fix-up pass, one step per TILE — so the shapes round 3 withdrew from (a table clustered by a low-cardinality key: 8 runs of
+    50 000 rows) and the one it still walked row by row (ONE long run among short ones) both give the hash aggregate's groups, record for
+    record: SUM, MIN, MAX, COUNT(*) and a NULL-able argument, runs that end exactly at a tile boundary, a last partial tile."""
+    rng = np.random.default_rng(9)
+    cases = {
+        "low cardinality": np.repeat(np.arange(8, dtype=np.int64), 50_000),
+        "one long run among short ones": np.concatenate([np.repeat(np.arange(3000, dtype=np.int64), rng.integers(1, 6, 3000)), np.full(300_000, 5000, np.int64),
+                                                        np.repeat(np.arange(6000, 9000, dtype=np.int64), rng.integers(1, 6, 3000))]),
+        "runs ending at tile boundaries": np.repeat(np.arange(40, dtype=np.int64), 1024),
+        "every row a group": np.arange(5000, dtype=np.int64),
+    }
+    aggs = [(hip.PH_A_SUM, 0), (hip.PH_A_MIN, 0), (hip.PH_A_MAX, 0), (hip.PH_A_COUNT_STAR, -1), (hip.PH_A_COUNT, 1)]
+    for name, keys in cases.items():
+        n = len(keys)
+        vals = rng.integers(-10**15, 10**15, n).astype(np.int64)
+        v2 = rng.integers(0, 100, n).astype(np.int32)
+        valid = rng.random(n) > 0.3
+        K, V = hip.DevColumn(ctx, hip.PH_I64, keys), hip.DevColumn(ctx, hip.PH_I64, vals)
+        W = hip.DevColumn(ctx, hip.PH_I32, v2, validity=np.packbits(valid, bitorder="little"))
+        res = []
+        for sorted_form in (True, False):
+            agg = hip.Agg(ctx, [hip.PH_I64], aggs, 1024)
+            if sorted_form:
+                assert agg.sink_sorted([K], [V, W], n), name
+            else:
+                agg.sink([K], [V, W], None, n)
+            r = agg.finalize(python_ints=False, room=len(np.unique(keys)))
+            res.append({k: np.asarray(r[k]) for k in ("first_row", "keys", "sum_lo", "sum_hi", "count")})
+            agg.free()
+        ctx.check_deferred()
+        for k in res[0]:
+            assert np.array_equal(res[0][k], res[1][k]), (name, k)
+        uk, first = np.unique(keys, return_index=True)
+        assert np.array_equal(res[0]["keys"][:, 0], uk) and np.array_equal(res[0]["first_row"], first), name
+        sums = np.add.reduceat(vals.astype(object), first)
+        got = [(int(h) << 64) + int(l) for l, h in zip(res[0]["sum_lo"][:, 0], res[0]["sum_hi"][:, 0])]
+        assert got == [int(x) for x in sums], name
+        for c in (K, V, W):
+            c.free()
+    # (ordered first key, UNordered second key): equal (k0, k1) tuples are no longer adjacent — the claim is verified on the device
+    k0 = np.repeat(np.arange(1000, dtype=np.int64), 4)
+    k1 = np.tile(np.array([2, 1, 2, 1], np.int32), 1000)
+    K0, K1, V = hip.DevColumn(ctx, hip.PH_I64, k0), hip.DevColumn(ctx, hip.PH_I32, k1), hip.DevColumn(ctx, hip.PH_I64, np.ones(4000, np.int64))
+    agg = hip.Agg(ctx, [hip.PH_I64, hip.PH_I32], [(hip.PH_A_SUM, 0)], 1024)
+    assert agg.sink_sorted([K0, K1], [V], 4000)
+    with pytest.raises(hip.PlanHipError) as e:
+        agg.group_count()
+    assert e.value.code == hip.PH_ECONSTRAINT and "ph_agg_sink_sorted" in str(e.value)
     agg.free()
-    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0)], 16)
-    agg.sink([K], [V], None, n)
-    r = agg.finalize()
-    assert r["ngroups"] == 8 and [s[0] for s in r["sum"]] == [int(vals[keys == g].sum()) for g in range(8)]
-    agg.free()
+    for c in (K0, K1, V):
+        c.free()
