@@ -589,6 +589,15 @@ void ph_join_free(ph_join *j);
 int ph_merge_lookup(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const ph_col *probe_key, const int32_t *sel,
                     int64_t n, int32_t strict, int32_t *out_build_dev);
 
+/* Inner pairs against a CLUSTERED build key column, no table: build_key is a key column in ascending order WITH duplicates (lineitem by
+ * l_orderkey; PH_STAT_ASCENDING), the probe rows sel[0..n) / 0..n come in any order. Every probe row finds the run of its key with a binary
+ * search over the column; the pairs are (probe row id, each row of the run), in probe order. For a probe side far smaller than the build
+ * side this replaces every pass a table build makes over ALL build rows (JoinHashTable.Build / Finalize, join_table.go:85-288) by
+ * ~log2(n_build) reads per probe row. Same outputs and capacity protocol as ph_join_probe_inner. The column's order is the caller's claim
+ * (ph_table_col_stats reports what the library measured at load). */
+int ph_join_sorted_pairs(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const ph_col *probe_key, const int32_t *sel, int64_t n,
+                         int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out);
+
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:
  * for every right row, all left rows in order — the order the reference emits (one output chunk
  * per (left chunk, right row)) — so that both sides materialise with ph_gather like a join's

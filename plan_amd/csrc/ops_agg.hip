@@ -974,43 +974,49 @@ __global__ __launch_bounds__(1024) void bulk2_merge_kernel(Bulk2Params Q) {
 }
 
 // key column c of all groups -> dense column + validity bits; a thread converts 8 groups
+// (one group per lane and step: a wave reads 64 consecutive records and composes the validity bytes with a ballot. The first form gave a lane
+// 8 consecutive groups — a 64-byte stride between the lanes of one load — and ran at 0.9 TB/s: 518 + 337 us of Q18's 3 ms at SF10.)
 __global__ __launch_bounds__(256) void agg_keys_kernel(const unsigned long long *__restrict__ gkeys,
                                                        const unsigned *__restrict__ gnull, int nkeys, int c, int type,
                                                        int ng, void *__restrict__ out, uint8_t *__restrict__ valid) {
-    const int g0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (g0 >= ng) return;
-    unsigned bits = 0;
-    for (int j = 0; j < 8 && g0 + j < ng; j++) {
-        const int g = g0 + j;
-        const unsigned long long k = gkeys[(int64_t)g * nkeys + c];
-        if (!((gnull[g] >> c) & 1)) bits |= 1u << j;
-        if (type == PH_I32 || type == PH_DATE) ((int32_t *)out)[g] = (int32_t)k;
-        else if (type == PH_CODE8) ((uint8_t *)out)[g] = (uint8_t)k;
-        else ((unsigned long long *)out)[g] = k;
+    const int lane = threadIdx.x & 63;
+    for (int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll; g0 < ng; g0 += (int64_t)gridDim.x * 256) {
+        const int64_t g = g0 + lane;
+        bool ok = false;
+        if (g < ng) {
+            const unsigned long long k = gkeys[g * nkeys + c];
+            ok = !((gnull[g] >> c) & 1);
+            if (type == PH_I32 || type == PH_DATE) ((int32_t *)out)[g] = (int32_t)k;
+            else if (type == PH_CODE8) ((uint8_t *)out)[g] = (uint8_t)k;
+            else ((unsigned long long *)out)[g] = k;
+        }
+        const unsigned long long bits = __ballot(ok);
+        if (valid && (lane & 7) == 0 && g0 + lane < ng) valid[(g0 + lane) >> 3] = (uint8_t)(bits >> lane);
     }
-    if (valid) valid[g0 >> 3] = (uint8_t)bits;
 }
 
-// aggregate a of all groups -> dense int64 column + validity bits (a group no input reached is NULL); a thread converts 8 groups.
-// flag |= 1 when a SUM does not fit int64
+// aggregate a of all groups -> dense int64 column + validity bits (a group no input reached is NULL). flag |= 1 when a SUM does not fit int64
 __global__ __launch_bounds__(256) void agg_values_kernel(const unsigned long long *__restrict__ sum_lo, const long long *__restrict__ sum_hi,
                                                          const unsigned long long *__restrict__ cnt, int naggs, int a, int kind, int ng,
                                                          long long *__restrict__ out, uint8_t *__restrict__ valid, int *__restrict__ flag) {
-    const int g0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (g0 >= ng) return;
-    unsigned bits = 0;
+    const int lane = threadIdx.x & 63;
+    const bool counting = kind == PH_A_COUNT || kind == PH_A_COUNT_STAR;
     bool wide = false;
-    for (int j = 0; j < 8 && g0 + j < ng; j++) {
-        const int64_t st = (int64_t)(g0 + j) * naggs + a;
-        const unsigned long long c = cnt[st];
-        const bool counting = kind == PH_A_COUNT || kind == PH_A_COUNT_STAR;
-        if (c != 0) bits |= 1u << j;          // SumOp / CountOp / MinMaxOp.Finalize: NULL when never set (COUNT: when 0)
-        const long long lo = (long long)sum_lo[st];
-        if (kind == PH_A_SUM && c != 0 && sum_hi[st] != (lo >> 63)) wide = true;
-        out[g0 + j] = counting ? (long long)c : lo;
+    for (int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll; g0 < ng; g0 += (int64_t)gridDim.x * 256) {
+        const int64_t g = g0 + lane;
+        bool ok = false;
+        if (g < ng) {
+            const int64_t st = g * naggs + a;
+            const unsigned long long c = cnt[st];
+            ok = c != 0;                         // SumOp / CountOp / MinMaxOp.Finalize: NULL when never set (COUNT: when 0)
+            const long long lo = (long long)sum_lo[st];
+            if (kind == PH_A_SUM && c != 0 && sum_hi[st] != (lo >> 63)) wide = true;
+            out[g] = counting ? (long long)c : lo;
+        }
+        const unsigned long long bits = __ballot(ok);
+        if (valid && (lane & 7) == 0 && g0 + lane < ng) valid[(g0 + lane) >> 3] = (uint8_t)(bits >> lane);
     }
-    if (valid) valid[g0 >> 3] = (uint8_t)bits;
-    if (wide) atomicOr(flag, 1);
+    if (__ballot(wide) && lane == 0) atomicOr(flag, 1);
 }
 
 }  // namespace ph
@@ -1714,6 +1720,9 @@ __device__ __forceinline__ SaPart sa_shfl_up(const SaPart &p, int o) {
     r.lo = __shfl_up(p.lo, o); r.hi = __shfl_up(p.hi, o); r.cnt = __shfl_up(p.cnt, o);
     return r;
 }
+// (The descriptor lives in DEVICE memory and the kernels take a pointer: indexed by the aggregate / key number it is a handful of scalar loads.
+// Passed by value, the same indexing made the compiler copy the whole struct into scratch — 712 bytes per lane — and the kernel ran at a third
+// of the row-per-thread form it replaces.)
 __device__ __forceinline__ void sa_store(const SortedAgg &S, int64_t g, int a, int kind, const SaPart &p) {
     const int64_t st = g * S.naggs + a;
     S.cnt[st] = p.cnt;
@@ -1736,18 +1745,41 @@ __device__ __forceinline__ bool sa_is_head(const SortedAgg &S, int64_t i, bool *
     return differ;
 }
 
-// head flags of a lane's SA_V rows as a bit mask (rows >= n: no head)
-__device__ __forceinline__ unsigned sa_lane_heads(const SortedAgg &S, int64_t base, bool *bad) {
+// a lane's SA_V consecutive values of a 4- or 8-byte column as 16-byte loads (the lane's first row is a multiple of SA_V: aligned whenever the column
+// is; the ragged last lanes and unaligned columns take the scalar loads)
+__device__ __forceinline__ void sa_load4(int type, const void *data, int64_t base, int64_t n, long long v[SA_V]) {
+    const bool w4 = type == PH_I32 || type == PH_DATE;
+    if (base + SA_V <= n && type != PH_CODE8 && ((reinterpret_cast<uintptr_t>(data) & 15) == 0)) {
+        if (w4) {
+            const int4 x = *reinterpret_cast<const int4 *>((const int32_t *)data + base);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+            const longlong2 a = *reinterpret_cast<const longlong2 *>((const int64_t *)data + base);
+            const longlong2 b = *reinterpret_cast<const longlong2 *>((const int64_t *)data + base + 2);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < SA_V; r++) {
+        const int64_t i = base + r;
+        v[r] = i < n ? (type == PH_CODE8 ? (long long)((const uint8_t *)data)[i] : w4 ? (long long)((const int32_t *)data)[i] : ((const int64_t *)data)[i]) : 0;
+    }
+}
+
+// head flags of a lane's SA_V rows as a bit mask (rows >= n: no head); k0[] receives the first key's values
+__device__ __forceinline__ unsigned sa_lane_heads(const SortedAgg &S, int64_t base, bool *bad, long long k0[SA_V]) {
     unsigned h = 0;
-    if (S.nkeys == 1) {   // one key: SA_V + 1 loads instead of 2 * SA_V
+    sa_load4(S.key[0].type, S.key[0].data, base, S.n, k0);
+    if (S.nkeys == 1) {   // one key: the lane's own keys in 16-byte loads + its predecessor's last
         long long prev = base > 0 && base - 1 < S.n ? (long long)load_key(S.key[0], base - 1) : 0;
 #pragma unroll
         for (int r = 0; r < SA_V; r++) {
             const int64_t i = base + r;
-            if (i >= S.n) break;
-            const long long k = (long long)load_key(S.key[0], i);
-            if (i == 0 || k != prev) { h |= 1u << r; if (i > 0 && k < prev) *bad = true; }
-            prev = k;
+            if (i < S.n) {
+                if (i == 0 || k0[r] != prev) { h |= 1u << r; if (i > 0 && k0[r] < prev) *bad = true; }
+                prev = k0[r];
+            }
         }
         return h;
     }
@@ -1762,10 +1794,12 @@ __device__ __forceinline__ unsigned sa_lane_heads(const SortedAgg &S, int64_t ba
     return h;
 }
 
-__global__ __launch_bounds__(256) void sorted_heads_kernel(SortedAgg S, int32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void sorted_heads_kernel(const SortedAgg *__restrict__ Sp, int32_t *__restrict__ counts) {
+    const SortedAgg &S = *Sp;
     const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)threadIdx.x * SA_V;
     bool bad = false;
-    int heads = __popc(sa_lane_heads(S, base, &bad));
+    long long k0[SA_V];
+    int heads = __popc(sa_lane_heads(S, base, &bad, k0));
     if (bad) atomicOr(S.violation, 4);
     for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o);
     __shared__ int ws[4];
@@ -1776,12 +1810,14 @@ __global__ __launch_bounds__(256) void sorted_heads_kernel(SortedAgg S, int32_t 
 
 // side[(tile * naggs + a) * 2 + 0] = the partial of the rows before the tile's first head (the whole tile when it has none),
 // side[.. + 1] = the partial from the tile's last head to its end (unused without a head)
-__global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
+__global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
                                                             SaPart *__restrict__ side) {
+    const SortedAgg &S = *Sp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)tid * SA_V;
     bool bad = false;
-    const unsigned h = sa_lane_heads(S, base, &bad);
+    long long k0[SA_V];
+    const unsigned h = sa_lane_heads(S, base, &bad, k0);
     const int nh = __popc(h);
     // exclusive scan of the head counts over the workgroup -> the lane's first group id
     __shared__ int wc[4];
@@ -1805,7 +1841,8 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const i
             const int64_t i = base + r, g = goff + k++;
             S.first_row[g] = S.row_base + i;
             S.gnull[g] = 0;
-            for (int c = 0; c < S.nkeys; c++) S.gkeys[g * S.nkeys + c] = load_key(S.key[c], i);
+            S.gkeys[g * S.nkeys] = (unsigned long long)k0[r];
+            for (int c = 1; c < S.nkeys; c++) S.gkeys[g * S.nkeys + c] = load_key(S.key[c], i);
         }
     }
     int rows_here = 0;
@@ -1818,6 +1855,8 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const i
         int k = 0;
         bool seen_head = false;
         const AggCol *col = kind == PH_A_COUNT_STAR ? nullptr : &S.arg[S.agg_arg[a]];
+        long long vv[SA_V] = {0, 0, 0, 0};
+        if (col) sa_load4(col->type, col->data, base, S.n, vv);
 #pragma unroll
         for (int r = 0; r < SA_V; r++) {
             const int64_t i = base + r;
@@ -1831,8 +1870,7 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const i
             }
             if (!col) cur.cnt++;
             else if (!col->validity || bit_valid(col->validity, i)) {
-                const long long v = col->type == PH_I32 ? (long long)((const int32_t *)col->data)[i] : ((const int64_t *)col->data)[i];
-                cur = sa_combine(kind, cur, sa_value(kind, v));
+                cur = sa_combine(kind, cur, sa_value(kind, vv[r]));
             }
         }
         if (!seen_head) { pre = cur; }
@@ -1877,8 +1915,9 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(SortedAgg S, const i
 }
 
 // one lane per tile with a head: its last run = its trailing partial + the following tiles without a head + the next tile's leading partial
-__global__ __launch_bounds__(256) void sorted_fixup_kernel(SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
+__global__ __launch_bounds__(256) void sorted_fixup_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
                                                            const SaPart *__restrict__ side) {
+    const SortedAgg &S = *Sp;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
     const int64_t off = block_off[t], next = t + 1 < ntiles ? block_off[t + 1] : *total;
@@ -1938,15 +1977,21 @@ extern "C" int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *a
     PH_CHECK(ctx->pool_alloc(nb * a->naggs * 2 * (int64_t)sizeof(ph::SaPart) + 64, (void **)&side));
     PH_CHECK(agg_clear(a, false, 0, 8, nullptr, 0));   // the four counter words + the top-k state words
     a->fresh = false;
-    ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
-    int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
+    ph::SortedAgg *Sd = nullptr;
+    int rc = ctx->pool_alloc((int64_t)sizeof(ph::SortedAgg), (void **)&Sd);
+    if (rc == PH_OK && hipMemcpyAsync(Sd, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PH_EHIP;   // (pageable source: staged before the call returns)
+    if (rc == PH_OK) {
+        ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
     if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
     if (rc == PH_OK) {
-        ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total, side);
-        ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(S, counts, total, nb, side);
+        ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts, total, side);
+        ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(Sd, counts, total, nb, side);
         if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
     }
     ctx->pool_release(side);   // (stream-ordered reuse)
+    if (Sd) ctx->pool_release(Sd);
     if (rc != PH_OK) { ph::set_error("ph_agg_sink_sorted: launch failed"); return rc; }
     ctx->deferred_pending = true;
     a->rows_sunk += n;
@@ -1963,7 +2008,7 @@ extern "C" int ph_agg_keys_dev(ph_agg *a, int32_t key_index, void *out_data_dev,
     if (ng > capacity) { ph::set_error("ph_agg_keys_dev: %lld groups, room for %lld", (long long)ng, (long long)capacity); return PH_ECAPACITY; }
     if (ng == 0) return PH_OK;
     PH_REQUIRE(out_data_dev, "ph_agg_keys_dev: out_data_dev is NULL");
-    ph::agg_keys_kernel<<<(int)((ng + 2047) / 2048), 256, 0, a->ctx->stream>>>(a->gkeys, a->gnull, a->nkeys, key_index,
+    ph::agg_keys_kernel<<<(int)std::min<int64_t>((ng + 255) / 256, 256 * 16), 256, 0, a->ctx->stream>>>(a->gkeys, a->gnull, a->nkeys, key_index,
                                                                               a->key_types[key_index], (int)ng, out_data_dev,
                                                                               out_validity_dev);
     PH_HIP(hipGetLastError());
@@ -1983,7 +2028,7 @@ extern "C" int ph_agg_values_dev(ph_agg *a, int32_t agg_index, int64_t *out_dev,
     int *flag = nullptr;
     PH_CHECK(a->ctx->pool_alloc(16, (void **)&flag));
     PH_HIP(hipMemsetAsync(flag, 0, 4, a->ctx->stream));
-    ph::agg_values_kernel<<<(int)((ng + 2047) / 2048), 256, 0, a->ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, kind, (int)ng,
+    ph::agg_values_kernel<<<(int)std::min<int64_t>((ng + 255) / 256, 256 * 16), 256, 0, a->ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, kind, (int)ng,
                                                                                 (long long *)out_dev, out_validity_dev, flag);
     int wide = 0;
     int rc = hipGetLastError() == hipSuccess ? a->ctx->download(&wide, flag, 4) : PH_EHIP;

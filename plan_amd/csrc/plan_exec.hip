@@ -1410,6 +1410,118 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
         }
     }
 
+    // ---- no table: the build side is a big base table CLUSTERED by the key and the probe side is a sliver of it — every probe row binary-searches
+    // the key column for its run (ph_join_sorted_pairs); what still filters the build table is applied to the PAIRS' build rows afterwards (a few
+    // million rows instead of the table's sixty). The order is the library's own load-time measurement (ph_table_col_stats), not a claim of the caller.
+    if (nd.join_type == PH_JT_INNER && nk == 1 && B.single_identity() && !B.flags && !getenv("PH_PLAN_NO_SORTED_PAIRS")) {
+        const PCol &bc = B.cols[(size_t)nd.bkeys[0]];
+        const ph_table *bt = B.lanes[0].t;
+        bool all_lane0 = bc.lane == 0;
+        for (auto &c : B.cols) all_lane0 = all_lane0 && c.lane == 0;
+        if (all_lane0 && bt->cols[(size_t)bc.tcol].ascending && !bt->cols[(size_t)bc.tcol].strict && bt->nrows >= (1 << 22)) {
+            PL_CHECK(apply_pending(p, &P));
+            if (P.n * 32 <= bt->nrows) {
+                KeySide pk;
+                PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
+                ph_col bv = table_view(bt, bc.tcol);
+                int64_t cap = std::max<int64_t>(pk.n * 4, 1024), m = 0;
+                void *op = nullptr, *ob = nullptr;
+                int rc = PH_OK;
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    PL_CHECK(palloc(p, cap * 4, &op));
+                    PL_CHECK(palloc(p, cap * 4, &ob));
+                    rc = ph_join_sorted_pairs(ctx, &bv, bt->nrows, &pk.views[0], pk.sel, pk.n, (int32_t *)op, (int32_t *)ob, cap, &m);
+                    if (rc == PH_ECAPACITY && attempt == 0 && m > cap) { cap = m; continue; }
+                    break;
+                }
+                if (rc == PH_OK) {
+                    const int64_t found = m;
+                    // the build table's own filters over the matched build rows: a relation of the pairs' build rows, filtered, gives the surviving pairs
+                    const int32_t *keep = nullptr;
+                    int64_t nkeep = m;
+                    if (B.lazy() && m > 0) {
+                        Rel Bm;
+                        Bm.n = m;
+                        Lane bl; bl.t = bt; bl.rows = (const int32_t *)ob; bl.asc = false; bl.dup_free = false;
+                        Bm.lanes.push_back(bl);
+                        const int32_t *selp = nullptr;   // positions among the pairs
+                        int64_t cnt = m;
+                        for (size_t i = 0; i < B.pending.size() && cnt > 0; i++) {
+                            ph_pred pr = B.pending[i];
+                            fix_dict_const(bt, pr.col, &pr.k);
+                            PCol tmp; tmp.type = bt->cols[(size_t)pr.col].type; tmp.scale = bt->cols[(size_t)pr.col].scale; tmp.lane = 0; tmp.tcol = pr.col; tmp.src = bt; tmp.src_col = pr.col;
+                            Bm.cols.push_back(tmp);
+                            const int ci = (int)Bm.cols.size() - 1;
+                            PL_CHECK(positional(p, &Bm, {ci}));
+                            const int32_t *s0 = nullptr;
+                            ph_col v = col_view(Bm, Bm.cols[(size_t)ci], &s0);
+                            fix_num_const(v, &pr.k);
+                            void *o = nullptr;
+                            PL_CHECK(palloc(p, cnt * 4, &o));
+                            int64_t m2 = 0;
+                            PL_CHECK(ph_filter_select(ctx, &v, m, pr.op, &pr.k, selp, selp ? cnt : m, (int32_t *)o, &m2));
+                            selp = (const int32_t *)o; cnt = m2;
+                        }
+                        for (size_t i = 0; i < B.complex.size() && cnt > 0; i++) {
+                            // the tree's columns are TABLE columns: as output columns of the pairs' relation
+                            BoolTree bt2 = B.complex[i];
+                            for (auto &b : bt2.nodes) {
+                                if (b.kind != PH_B_CMP) continue;
+                                auto as_col = [&](int tc) {
+                                    PCol tmp; tmp.type = bt->cols[(size_t)tc].type; tmp.scale = bt->cols[(size_t)tc].scale; tmp.lane = 0; tmp.tcol = tc; tmp.src = bt; tmp.src_col = tc;
+                                    Bm.cols.push_back(tmp);
+                                    return (int)Bm.cols.size() - 1;
+                                };
+                                b.col = as_col(b.col);
+                                if (b.k.type == PH_COLREF) b.k.i = as_col((int)b.k.i);
+                            }
+                            bt2.fix();
+                            const int32_t *o = nullptr;
+                            int64_t m2 = 0;
+                            PL_CHECK(eval_bool(p, &Bm, false, bt2, 0, selp, selp ? cnt : m, &o, &m2));
+                            selp = o; cnt = m2;
+                        }
+                        keep = selp; nkeep = cnt;
+                    }
+                    int32_t *prow = (int32_t *)op, *brow = (int32_t *)ob;
+                    if (keep) {
+                        ph_col pv{}; pv.type = PH_I32; pv.data = op;
+                        ph_col bvv{}; bvv.type = PH_I32; bvv.data = ob;
+                        void *p2 = nullptr, *b2 = nullptr;
+                        PL_CHECK(palloc(p, std::max<int64_t>(nkeep, 1) * 4, &p2));
+                        PL_CHECK(palloc(p, std::max<int64_t>(nkeep, 1) * 4, &b2));
+                        if (nkeep > 0) { PL_CHECK(ph_gather(ctx, &pv, keep, nkeep, p2)); PL_CHECK(ph_gather(ctx, &bvv, keep, nkeep, b2)); }
+                        prow = (int32_t *)p2; brow = (int32_t *)b2; m = nkeep;
+                    }
+                    // the result: as the general pair probe assembles it (probe rows are ROW IDS of lane 0 when the keys were table columns, positions otherwise)
+                    *out = P;
+                    if (pk.rowids) {
+                        out->lanes[0].rows = prow;
+                        out->lanes[0].dup_free = false;
+                        out->n = m;
+                    } else {
+                        // prow holds positions i of the probe relation (ph_join_sorted_pairs reports sel[i] or i: there was no selection)
+                        PL_CHECK(compact(p, out, prow, m));
+                        for (auto &ln : out->lanes) ln.dup_free = false;
+                    }
+                    std::vector<PCol> all = out->cols;
+                    Lane bl2; bl2.t = bt; bl2.rows = brow; bl2.asc = false; bl2.dup_free = false;
+                    out->lanes.push_back(bl2);
+                    for (auto c : B.cols) { c.lane = (int)out->lanes.size() - 1; c.ordered = false; c.domain = -1; all.push_back(c); }
+                    out->cols.clear();
+                    for (int32_t oi : nd.out) out->cols.push_back(all[(size_t)oi]);
+                    out->covers = false;
+                    out->pending.clear(); out->complex.clear(); out->flags = nullptr;
+                    drop_unused_lanes(out);
+                    note(p, "join#%d: no table — the build side is clustered by the key: %lld probe rows binary-search the column, %lld pairs%s, %lld kept", idx, (long long)pk.n,
+                         (long long)found, B.lazy() ? " (the build side's filters applied to the pairs)" : "", (long long)m);
+                    return PH_OK;
+                }
+                if (rc != PH_EUNSUPPORTED) return rc;
+            }
+        }
+    }
+
     // ---- build
     ph_join *j = nullptr;
     const uint8_t *residual = nullptr;   // marks of the build table's rows tested by the probe instead of the build

@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plan_amd import hip
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000_000
