@@ -1794,8 +1794,7 @@ __device__ __forceinline__ unsigned sa_lane_heads(const SortedAgg &S, int64_t ba
     return h;
 }
 
-__global__ __launch_bounds__(256) void sorted_heads_kernel(const SortedAgg *__restrict__ Sp, int32_t *__restrict__ counts) {
-    const SortedAgg &S = *Sp;
+__device__ __forceinline__ void sorted_heads_body(const SortedAgg &S, int32_t *__restrict__ counts) {
     const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)threadIdx.x * SA_V;
     bool bad = false;
     long long k0[SA_V];
@@ -1807,12 +1806,17 @@ __global__ __launch_bounds__(256) void sorted_heads_kernel(const SortedAgg *__re
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
+// two entries per kernel: the descriptor by pointer (any shape), and BY VALUE for tables with ONE aggregate — then every index into the
+// descriptor is a constant, it stays in the kernel-argument segment, and the call needs no descriptor upload (a pageable host-to-device copy
+// costs ~10 us of launch time: a third of the whole aggregate over Q3's 298 k rows)
+__global__ __launch_bounds__(256) void sorted_heads_kernel(const SortedAgg *__restrict__ Sp, int32_t *__restrict__ counts) { sorted_heads_body(*Sp, counts); }
+__global__ __launch_bounds__(256) void sorted_heads_kernel_v(const SortedAgg S, int32_t *__restrict__ counts) { sorted_heads_body(S, counts); }
 
 // side[(tile * naggs + a) * 2 + 0] = the partial of the rows before the tile's first head (the whole tile when it has none),
 // side[.. + 1] = the partial from the tile's last head to its end (unused without a head)
-__global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
-                                                            SaPart *__restrict__ side) {
-    const SortedAgg &S = *Sp;
+template <bool ONE>
+__device__ __forceinline__ void sorted_groups_body(const SortedAgg &S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
+                                                   SaPart *__restrict__ side) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)tid * SA_V;
     bool bad = false;
@@ -1842,19 +1846,21 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__r
             S.first_row[g] = S.row_base + i;
             S.gnull[g] = 0;
             S.gkeys[g * S.nkeys] = (unsigned long long)k0[r];
-            for (int c = 1; c < S.nkeys; c++) S.gkeys[g * S.nkeys + c] = load_key(S.key[c], i);
+#pragma unroll
+            for (int c = 1; c < AGG_MAX_KEYS; c++) if (c < S.nkeys) S.gkeys[g * S.nkeys + c] = load_key(S.key[c], i);
         }
     }
     int rows_here = 0;
 #pragma unroll
     for (int r = 0; r < SA_V; r++) rows_here += base + r < S.n ? 1 : 0;
-    for (int a = 0; a < S.naggs; a++) {
-        const int kind = S.agg_kind[a];
+    const int na = ONE ? 1 : S.naggs;
+    for (int a = 0; a < na; a++) {
+        const int kind = ONE ? S.agg_kind[0] : S.agg_kind[a];
         // the lane's own rows: `pre` = before its first head (all rows without one), interior runs written at once, `suf` = from its last head on
         SaPart pre = sa_empty(kind), cur = sa_empty(kind);
         int k = 0;
         bool seen_head = false;
-        const AggCol *col = kind == PH_A_COUNT_STAR ? nullptr : &S.arg[S.agg_arg[a]];
+        const AggCol *col = kind == PH_A_COUNT_STAR ? nullptr : (ONE ? &S.arg[0] : &S.arg[S.agg_arg[a]]);   // (ONE: the host put the argument first)
         long long vv[SA_V] = {0, 0, 0, 0};
         if (col) sa_load4(col->type, col->data, base, S.n, vv);
 #pragma unroll
@@ -1914,17 +1920,23 @@ __global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__r
     }
 }
 
+__global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
+                                                            SaPart *__restrict__ side) { sorted_groups_body<false>(*Sp, block_off, total, side); }
+__global__ __launch_bounds__(256) void sorted_groups_kernel_v(const SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
+                                                              SaPart *__restrict__ side) { sorted_groups_body<true>(S, block_off, total, side); }
+
 // one lane per tile with a head: its last run = its trailing partial + the following tiles without a head + the next tile's leading partial
-__global__ __launch_bounds__(256) void sorted_fixup_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
-                                                           const SaPart *__restrict__ side) {
-    const SortedAgg &S = *Sp;
+template <bool ONE>
+__device__ __forceinline__ void sorted_fixup_body(const SortedAgg &S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
+                                                  const SaPart *__restrict__ side) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
     const int64_t off = block_off[t], next = t + 1 < ntiles ? block_off[t + 1] : *total;
     if (next == off) return;                       // no head in this tile: some earlier tile's lane walks over it
     const int64_t g = next - 1;                    // the tile's last head's group
-    for (int a = 0; a < S.naggs; a++) {
-        const int kind = S.agg_kind[a];
+    const int na = ONE ? 1 : S.naggs;
+    for (int a = 0; a < na; a++) {
+        const int kind = ONE ? S.agg_kind[0] : S.agg_kind[a];
         SaPart acc = side[(t * S.naggs + a) * 2 + 1];
         for (int64_t u = t + 1; u < ntiles; u++) {
             const int64_t uo = block_off[u], un = u + 1 < ntiles ? block_off[u + 1] : *total;
@@ -1934,6 +1946,10 @@ __global__ __launch_bounds__(256) void sorted_fixup_kernel(const SortedAgg *__re
         sa_store(S, g, a, kind, acc);
     }
 }
+__global__ __launch_bounds__(256) void sorted_fixup_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
+                                                           const SaPart *__restrict__ side) { sorted_fixup_body<false>(*Sp, block_off, total, ntiles, side); }
+__global__ __launch_bounds__(256) void sorted_fixup_kernel_v(const SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total, int64_t ntiles,
+                                                             const SaPart *__restrict__ side) { sorted_fixup_body<true>(S, block_off, total, ntiles, side); }
 
 }  // namespace ph
 
@@ -1978,17 +1994,31 @@ extern "C" int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *a
     PH_CHECK(agg_clear(a, false, 0, 8, nullptr, 0));   // the four counter words + the top-k state words
     a->fresh = false;
     ph::SortedAgg *Sd = nullptr;
-    int rc = ctx->pool_alloc((int64_t)sizeof(ph::SortedAgg), (void **)&Sd);
-    if (rc == PH_OK && hipMemcpyAsync(Sd, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PH_EHIP;   // (pageable source: staged before the call returns)
-    if (rc == PH_OK) {
-        ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts);
+    int rc = PH_OK;
+    const bool one = a->naggs == 1;
+    if (one) {   // the by-value entries: the one aggregate's argument first, every descriptor index a constant
+        if (S.agg_kind[0] != PH_A_COUNT_STAR && S.agg_arg[0] != 0) { S.arg[0] = S.arg[S.agg_arg[0]]; S.agg_arg[0] = 0; }
+        ph::sorted_heads_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
         if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
-    }
-    if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
-    if (rc == PH_OK) {
-        ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts, total, side);
-        ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(Sd, counts, total, nb, side);
-        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+        if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
+        if (rc == PH_OK) {
+            ph::sorted_groups_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total, side);
+            ph::sorted_fixup_kernel_v<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(S, counts, total, nb, side);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+        }
+    } else {
+        rc = ctx->pool_alloc((int64_t)sizeof(ph::SortedAgg), (void **)&Sd);
+        if (rc == PH_OK && hipMemcpyAsync(Sd, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PH_EHIP;   // (pageable source: staged before the call returns)
+        if (rc == PH_OK) {
+            ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+        }
+        if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
+        if (rc == PH_OK) {
+            ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts, total, side);
+            ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(Sd, counts, total, nb, side);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+        }
     }
     ctx->pool_release(side);   // (stream-ordered reuse)
     if (Sd) ctx->pool_release(Sd);

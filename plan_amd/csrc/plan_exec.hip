@@ -1424,7 +1424,7 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
                 KeySide pk;
                 PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
                 ph_col bv = table_view(bt, bc.tcol);
-                int64_t cap = std::max<int64_t>(pk.n * 4, 1024), m = 0;
+                int64_t cap = std::max<int64_t>(pk.n * 8, 1024), m = 0;   // (a retry repeats the searches: room for eight rows per probe row up front)
                 void *op = nullptr, *ob = nullptr;
                 int rc = PH_OK;
                 for (int attempt = 0; attempt < 2; attempt++) {
