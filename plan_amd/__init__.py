@@ -9,6 +9,7 @@ Layout:
   plan_amd/pipelines.py Q3 / Q9 assembled from the operator-granular calls (single GPU and N ranks)
   plan_amd/dist.py      the exchange protocol over ph_comm_* (RCCL), with two host-memory test doubles
   plan_amd/queries.py   plan descriptors of the fused Q1 / Q6 scans
+  plan_amd/tpch.py      the 22 TPC-H queries as ph_plan operator trees (what the reference's planner would hand over) + result text
   plan_amd/loader.py    Arrow / parquet columns -> resident tables
   plan_amd/tpchgen.py   synthetic TPC-H data (libtpchgen.so)
 """
