@@ -86,6 +86,13 @@ struct ph_ctx {
     int64_t *count_slots_dev = nullptr;   // device address of count_slots
     unsigned long long count_seq_issued = 0;
     int publish(const void *dev, int64_t bytes, bool with_deferred);   // bytes <= 64 KiB -> mailbox; waits for it
+    // A kernel that publishes its own result (ScanTail): arm_publish hands out the mailbox, the sequence word and the next number BEFORE the launch;
+    // collect_armed waits for that number and copies the bytes out — unless another publish has used the mailbox since (returns 1: download as usual)
+    // or the arming was refused (seq 0: PH_NO_PUBLISH, deferred words pending).
+    int arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq);
+    int collect_armed(void *host, int64_t bytes, unsigned long long seq);
+    int ensure_mailbox();
+    unsigned *scan_done_dev = nullptr;    // the ticket counter of fused scans' last-workgroup tails (zero between launches)
     // single-pass scan (ops_select.hip): tile states + ticket counter, reused across calls by epoch
     void *scan_state = nullptr;
     int64_t scan_tiles = 0;

@@ -132,14 +132,39 @@ int ph_ctx::publish(const void *dev, int64_t bytes, bool with_deferred) {
     return poll_flag(flag, seq, stream);
 }
 
+int ph_ctx::ensure_mailbox() {
+    if (mailbox) return PH_OK;
+    const int64_t MB = PH_MAILBOX;
+    PH_HIP(hipHostMalloc(&mailbox, (size_t)MB + 128, hipHostMallocMapped | hipHostMallocCoherent));
+    memset((char *)mailbox + MB, 0, 128);
+    PH_HIP(hipHostGetDevicePointer(&mailbox_dev, mailbox, 0));
+    return PH_OK;
+}
+
+int ph_ctx::arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq) {
+    *seq = 0;
+    *mbox_dev = nullptr;
+    *flag_dev = nullptr;
+    static const bool no_publish = getenv("PH_NO_PUBLISH") != nullptr || getenv("PH_NO_SCAN_TAIL_PUBLISH") != nullptr;
+    if (no_publish || bytes > (int64_t)PH_MAILBOX || (deferred_pending && deferred_dev && !defer_hold)) return PH_OK;
+    PH_CHECK(ensure_mailbox());
+    *mbox_dev = reinterpret_cast<unsigned long long *>(mailbox_dev);
+    *flag_dev = reinterpret_cast<unsigned long long *>((char *)mailbox_dev + PH_MAILBOX + 64);
+    *seq = ++publish_seq;
+    return PH_OK;
+}
+
+int ph_ctx::collect_armed(void *host, int64_t bytes, unsigned long long seq) {
+    if (!seq || seq != publish_seq || (deferred_pending && deferred_dev && !defer_hold)) return 1;
+    PH_CHECK(poll_flag(reinterpret_cast<const unsigned long long *>((const char *)mailbox + PH_MAILBOX + 64), seq, stream));
+    memcpy(host, mailbox, (size_t)bytes);
+    return PH_OK;
+}
+
 int ph_ctx::download(void *host, const void *dev, int64_t bytes, bool with_deferred) {
     if (bytes <= 0) return PH_OK;
     const int64_t MB = PH_MAILBOX;
-    if (!mailbox) {
-        PH_HIP(hipHostMalloc(&mailbox, (size_t)MB + 128, hipHostMallocMapped | hipHostMallocCoherent));
-        memset((char *)mailbox + MB, 0, 128);
-        PH_HIP(hipHostGetDevicePointer(&mailbox_dev, mailbox, 0));
-    }
+    PH_CHECK(ensure_mailbox());
     const bool chk = with_deferred && !defer_hold && deferred_pending && deferred_dev;
     static const bool no_publish = getenv("PH_NO_PUBLISH") != nullptr;   // A/B switch: copy command + stream synchronisation
     if (bytes <= MB && !no_publish) {
@@ -338,6 +363,7 @@ extern "C" void ph_ctx_destroy(ph_ctx *ctx) {
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->deferred_dev) (void)hipFree(ctx->deferred_dev);
+    if (ctx->scan_done_dev) (void)hipFree(ctx->scan_done_dev);
     if (ctx->count_slots) (void)hipHostFree(ctx->count_slots);
     if (ctx->count_event) (void)hipEventDestroy((hipEvent_t)ctx->count_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

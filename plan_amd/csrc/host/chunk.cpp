@@ -407,11 +407,14 @@ static std::string go_float(double v) {
     if (v != v) return "NaN";
     if (v == 0) return "0";
     char tmp[64];
-    int prec;
-    for (prec = 1; prec <= 17; prec++) {
-        snprintf(tmp, sizeof tmp, "%.*e", prec - 1, v);
-        if (strtod(tmp, nullptr) == v) break;
+    // the shortest digit string that parses back to v: if p digits do, p + 1 do too, so the smallest such p is found by bisection (17 always does)
+    int lo = 1, hi = 17;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        snprintf(tmp, sizeof tmp, "%.*e", mid - 1, v);
+        if (strtod(tmp, nullptr) == v) hi = mid; else lo = mid + 1;
     }
+    snprintf(tmp, sizeof tmp, "%.*e", lo - 1, v);
     std::string digits;
     const char *p = tmp;
     bool neg = false;

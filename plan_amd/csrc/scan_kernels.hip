@@ -58,6 +58,76 @@ template <bool NT> __device__ __forceinline__ unsigned ld_u32(const uint8_t *p) 
     return *reinterpret_cast<const unsigned *>(p);
 }
 
+// ------------------------------------------------------------------ fused merge + publish (ScanTail)
+// one partial word of this workgroup, stored where the other XCDs can read it (a plain store would stay in this XCD's write-back L2 until a fence)
+__device__ __forceinline__ void scan_tail_put(long long *partials, int nacc, int j, long long v) {
+    __hip_atomic_store(partials + (int64_t)blockIdx.x * nacc + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL threads of every workgroup (256 threads) after its scan_tail_put calls; lds: 2 * SCAN_TAIL_MAX_ACC + 1 words nothing else uses any more.
+// A 64-bit partial is folded as two halves (a += low 32 bits, b += high 32 bits signed: no carries between LDS atomics), first-row minima as the
+// maximum of the complement (zero is every word's identity).
+__device__ __forceinline__ void scan_tail(const long long *partials, const ScanTail &T, unsigned long long *lds) {
+    // Everything the workgroups tell each other travels in device-scope stores / atomics (performed at the device's coherent level, not in an XCD's
+    // L2), so ordering is all that is needed: s_waitcnt returns when this wave's stores have been acknowledged, the barrier collects the waves, then
+    // the ticket. A device-scope fence here (__threadfence: an L2 write-back + invalidate per workgroup) cost 36-50 us per launch.
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    int *s_flag = reinterpret_cast<int *>(lds + 2 * SCAN_TAIL_MAX_ACC);
+    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(T.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    for (int j = threadIdx.x; j < 2 * SCAN_TAIL_MAX_ACC; j += 256) lds[j] = 0;
+    __syncthreads();
+    if (!*s_flag) return;
+    unsigned long long *la = lds, *lb = lds + SCAN_TAIL_MAX_ACC;
+    const int total = (int)gridDim.x * T.nacc;
+    for (int i0 = 0; i0 < total; i0 += 256 * 16) {
+        long long v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = i0 + k * 256 + (int)threadIdx.x;
+            v[k] = i < total ? __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = i0 + k * 256 + (int)threadIdx.x;
+            if (i >= total) break;
+            const int j = i % T.nacc;
+            if (T.min_stride > 0 && j % T.min_stride == T.min_stride - 1) atomicMax(la + j, ~(unsigned long long)v[k]);
+            else {
+                atomicAdd(la + j, (unsigned long long)v[k] & 0xffffffffull);
+                atomicAdd(lb + j, (unsigned long long)(v[k] >> 32));   // arithmetic shift: the signed high half
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < T.nacc; j += 256) {
+        const unsigned long long a = la[j];
+        const long long b = (long long)lb[j];
+        unsigned long long lo;
+        long long hi;
+        if (T.min_stride > 0 && j % T.min_stride == T.min_stride - 1) {
+            lo = ~a;
+            hi = 0;
+        } else {   // a + (b << 32) in 128 bits: a < 2^63 (2^31 workgroups x 2^32), b a signed sum of signed halves
+            lo = a + ((unsigned long long)b << 32);
+            hi = (b >> 32) + (lo < a ? 1 : 0);
+        }
+        T.out_lo[j] = lo;
+        T.out_hi[j] = hi;
+        if (T.mbox) {
+            T.mbox[j] = lo;
+            T.mbox[T.nacc + j] = (unsigned long long)hi;
+        }
+    }
+    if (T.mbox) __threadfence_system();   // the mailbox words are visible to the host ...
+    __syncthreads();                      // ... for every wave ...
+    if (threadIdx.x == 0) {
+        *T.done = 0;
+        if (T.mbox) __hip_atomic_store(T.flag, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the number is
+    }
+}
+
 // ------------------------------------------------------------------ filter_sumprod (Q6 shape)
 
 struct FsTile {
@@ -120,9 +190,17 @@ template <bool NT> __global__ __launch_bounds__(256) void filter_sumprod_kernel(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        P.partials[(int64_t)blockIdx.x * 2 + 0] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-        P.partials[(int64_t)blockIdx.x * 2 + 1] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+        const long long s = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3], c = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+        if (P.tail.done) {
+            scan_tail_put(P.partials, 2, 0, s);
+            scan_tail_put(P.partials, 2, 1, c);
+        } else {
+            P.partials[(int64_t)blockIdx.x * 2 + 0] = s;
+            P.partials[(int64_t)blockIdx.x * 2 + 1] = c;
+        }
     }
+    __shared__ unsigned long long tail_lds[2 * SCAN_TAIL_MAX_ACC + 1];
+    if (P.tail.done) scan_tail(P.partials, P.tail, tail_lds);
 }
 
 // ------------------------------------------------------------------ lowcard_chain (Q1 shape)
@@ -249,7 +327,46 @@ template <bool NT, int U> __global__ __launch_bounds__(256) void lowcard_chain_k
             for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
             v = (long long)m;
         }
-        if (lane == 0) P.partials[(int64_t)blockIdx.x * ns * per_slot + j] = v;
+        if (lane == 0) {
+            if (P.tail.done) scan_tail_put(P.partials, ns * per_slot, j, v);
+            else P.partials[(int64_t)blockIdx.x * ns * per_slot + j] = v;
+        }
+    }
+    if (P.tail.done) {
+        __syncthreads();   // the LDS accumulators have been read by every wave: their first 2 KiB serve the tail
+        scan_tail(P.partials, P.tail, lds_acc);
+    }
+}
+
+// The end of a merge wave (one wave per accumulator word j; lane 0 holds the merged word): store it, and — when the merge is to publish (T.done) — take
+// a ticket; the wave that finishes last copies all words into the mapped mailbox and stores the sequence number (what publish_kernel does as one more
+// launch). Every host-visible store comes from that one wave, in publish_kernel's order: words, system fence, number.
+__device__ __forceinline__ void merge_finish(const ScanTail &T, int j, unsigned long long lo, long long hi, unsigned long long *out_lo, long long *out_hi) {
+    const int lane = threadIdx.x;
+    if (!T.done) {
+        if (lane == 0) {
+            out_lo[j] = lo;
+            out_hi[j] = hi;
+        }
+        return;
+    }
+    unsigned ticket = 0;
+    if (lane == 0) {
+        __hip_atomic_store(out_lo + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // where the other XCDs can read them (not this XCD's write-back L2)
+        __hip_atomic_store(out_hi + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);   // acknowledged before the ticket
+        ticket = __hip_atomic_fetch_add(T.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = (unsigned)__shfl((int)ticket, 0);
+    if (ticket != gridDim.x - 1) return;
+    for (int k = lane; k < T.nacc; k += 64) {
+        T.mbox[k] = __hip_atomic_load(out_lo + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T.mbox[T.nacc + k] = (unsigned long long)__hip_atomic_load(out_hi + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence_system();
+    if (lane == 0) {
+        *T.done = 0;
+        __hip_atomic_store(T.flag, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -259,7 +376,7 @@ template <bool NT, int U> __global__ __launch_bounds__(256) void lowcard_chain_k
 __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__restrict__ partials,
                                                             int nblocks, int nacc, int min_stride,
                                                             unsigned long long *__restrict__ out_lo,
-                                                            long long *__restrict__ out_hi) {
+                                                            long long *__restrict__ out_hi, ScanTail T) {
     int j = blockIdx.x;
     int lane = threadIdx.x;
     if (min_stride > 0 && j % min_stride == min_stride - 1) {
@@ -272,10 +389,7 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__r
             long long v = __shfl_xor(m, o);
             m = v < m ? v : m;
         }
-        if (lane == 0) {
-            out_lo[j] = (unsigned long long)m;
-            out_hi[j] = 0;
-        }
+        merge_finish(T, j, (unsigned long long)m, 0, out_lo, out_hi);
         return;
     }
     // accumulate positives and negatives as unsigned magnitudes to keep carries simple
@@ -295,10 +409,7 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__r
         hi = hi + ohi + (nlo < lo ? 1 : 0);
         lo = nlo;
     }
-    if (lane == 0) {
-        out_lo[j] = lo;
-        out_hi[j] = hi;
-    }
+    merge_finish(T, j, lo, hi, out_lo, out_hi);
 }
 
 // out[j] over blocks with a per-word operation: op = (opmask >> 2*(j % stride)) & 3 — 0: 128-bit sum,
@@ -306,7 +417,7 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const long long *__r
 __global__ __launch_bounds__(64) void merge_partials_ops_kernel(const long long *__restrict__ partials,
                                                                 int nblocks, int nacc, int stride, unsigned long long opmask,
                                                                 unsigned long long *__restrict__ out_lo,
-                                                                long long *__restrict__ out_hi) {
+                                                                long long *__restrict__ out_hi, ScanTail T) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const int op = (int)((opmask >> (2 * (j % stride))) & 3);
     if (op != 0) {
@@ -319,10 +430,7 @@ __global__ __launch_bounds__(64) void merge_partials_ops_kernel(const long long 
             long long v = __shfl_xor(m, o);
             m = op == 1 ? (v < m ? v : m) : (v > m ? v : m);
         }
-        if (lane == 0) {
-            out_lo[j] = (unsigned long long)m;
-            out_hi[j] = m < 0 ? -1 : 0;
-        }
+        merge_finish(T, j, (unsigned long long)m, m < 0 ? -1 : 0, out_lo, out_hi);
         return;
     }
     unsigned long long lo = 0;
@@ -340,10 +448,7 @@ __global__ __launch_bounds__(64) void merge_partials_ops_kernel(const long long 
         hi = hi + ohi + (nlo < lo ? 1 : 0);
         lo = nlo;
     }
-    if (lane == 0) {
-        out_lo[j] = lo;
-        out_hi[j] = hi;
-    }
+    merge_finish(T, j, lo, hi, out_lo, out_hi);
 }
 
 static bool scan_nt() {
@@ -388,17 +493,21 @@ int launch_lowcard_chain(ph_ctx *ctx, const LowcardChainParams &P, int grid) {
 }
 
 int launch_merge_partials(ph_ctx *ctx, const long long *partials, int nblocks, int nacc,
-                          int min_stride, unsigned long long *out_lo, long long *out_hi) {
+                          int min_stride, unsigned long long *out_lo, long long *out_hi, const ScanTail *publish) {
+    ScanTail T = {};
+    if (publish && publish->mbox) T = *publish;
     merge_partials_kernel<<<nacc, 64, 0, ctx->stream>>>(partials, nblocks, nacc, min_stride, out_lo,
-                                                        out_hi);
+                                                        out_hi, T);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }
 
 
 int launch_merge_partials_ops(ph_ctx *ctx, const long long *partials, int nblocks, int nacc, int stride,
-                              unsigned long long opmask, unsigned long long *out_lo, long long *out_hi) {
-    merge_partials_ops_kernel<<<nacc, 64, 0, ctx->stream>>>(partials, nblocks, nacc, stride, opmask, out_lo, out_hi);
+                              unsigned long long opmask, unsigned long long *out_lo, long long *out_hi, const ScanTail *publish) {
+    ScanTail T = {};
+    if (publish && publish->mbox) T = *publish;
+    merge_partials_ops_kernel<<<nacc, 64, 0, ctx->stream>>>(partials, nblocks, nacc, stride, opmask, out_lo, out_hi, T);
     PH_HIP(hipGetLastError());
     return PH_OK;
 }

@@ -268,6 +268,7 @@ struct ph_scan_plan {
     long double row_bound = 0;  // largest |per-row accumulator value|
     int64_t last_rows = 0;
     int last_grid = 0;
+    unsigned long long armed_seq = 0;   // the last run's own publish (ScanTail), 0 = none: fetch downloads
     // PK_GENERIC: the descriptor itself, run through the operator-granular kernels
     std::vector<ph_pred> g_preds;
     std::vector<std::string> g_pred_strs;
@@ -846,13 +847,34 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
     }
     p->last_rows = rows;
     p->last_grid = grid;
+    p->armed_seq = 0;
+    // One host-visible result per run without a publish launch (PH_SCAN_TAIL=0: merge kernel, then publish_kernel at the fetch). The one-group
+    // sum kernel (Q6 shape: two words per workgroup) merges AND publishes in its last workgroup — one launch per run; for the others the merge
+    // kernel's last wave publishes — two launches (a single workgroup folding 42 words x 256 workgroups was slower than the 42-wave merge launch).
+    ph::ScanTail tail = {};
+    static const bool fused_tail = !(getenv("PH_SCAN_TAIL") && getenv("PH_SCAN_TAIL")[0] == '0');
+    if (fused_tail && p->nacc <= ph::SCAN_TAIL_MAX_ACC) {
+        ph_ctx *ctx = p->ctx;
+        if (!ctx->scan_done_dev) {   // the ticket: zero between launches
+            PH_HIP(hipMalloc((void **)&ctx->scan_done_dev, 64));
+            PH_HIP(hipMemsetAsync(ctx->scan_done_dev, 0, 64, ctx->stream));
+        }
+        tail.done = ctx->scan_done_dev;
+        tail.out_lo = p->out_lo;
+        tail.out_hi = p->out_hi;
+        tail.nacc = p->nacc;
+        PH_CHECK(ctx->arm_publish((int64_t)p->nacc * 16, &tail.mbox, &tail.flag, &tail.seq));
+        p->armed_seq = tail.seq;
+    }
     if (p->kind == PK_FILTER_SUMPROD) {
         ph::FilterSumProdParams P = p->fs;
         P.row_begin = row_begin;
         P.row_end = row_begin + rows;
         P.partials = p->partials;
+        P.tail = tail;
+        P.tail.min_stride = 0;
         PH_CHECK(ph::launch_filter_sumprod(p->ctx, P, grid));
-        PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, 2, 0, p->out_lo, p->out_hi));
+        if (!tail.done) PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, 2, 0, p->out_lo, p->out_hi));
     } else if (p->kind == PK_JIT) {
         ph::JitParams P = p->jparams;
         P.row_begin = row_begin;
@@ -861,14 +883,15 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
         PH_CHECK(ph::jit_launch(p->ctx, p->jkernel, P, grid));
         unsigned long long opmask = 0;
         for (int j = 0; j < p->stride; j++) opmask |= (unsigned long long)p->ops[(size_t)j] << (2 * j);
-        PH_CHECK(ph::launch_merge_partials_ops(p->ctx, p->partials, grid, p->nacc, p->stride, opmask, p->out_lo, p->out_hi));
+        PH_CHECK(ph::launch_merge_partials_ops(p->ctx, p->partials, grid, p->nacc, p->stride, opmask, p->out_lo, p->out_hi, &tail));
     } else {
         ph::LowcardChainParams P = p->lc;
         P.row_begin = row_begin;
         P.row_end = row_begin + rows;
         P.partials = p->partials;
+        P.tail = ph::ScanTail{};
         PH_CHECK(ph::launch_lowcard_chain(p->ctx, P, grid));
-        PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, p->nacc, ph::LC_NACC + 1, p->out_lo, p->out_hi));
+        PH_CHECK(ph::launch_merge_partials(p->ctx, p->partials, grid, p->nacc, ph::LC_NACC + 1, p->out_lo, p->out_hi, &tail));
     }
     return PH_OK;
 }
@@ -932,7 +955,10 @@ extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
     }
     // lo[nacc] and hi[nacc] are ONE allocation (plan_alloc): one host round trip for both (two cost ~45 us more per query)
     std::vector<unsigned long long> words((size_t)p->nacc * 2);
-    PH_CHECK(p->ctx->download(words.data(), p->out_lo, (int64_t)words.size() * 8));
+    const int armed = p->ctx->collect_armed(words.data(), (int64_t)words.size() * 8, p->armed_seq);   // 1: the mailbox has been used since
+    p->armed_seq = 0;
+    if (armed < 0) return armed;
+    if (armed == 1) PH_CHECK(p->ctx->download(words.data(), p->out_lo, (int64_t)words.size() * 8));
     std::vector<unsigned long long> lo(words.begin(), words.begin() + p->nacc);
     std::vector<long long> hi((size_t)p->nacc);
     memcpy(hi.data(), words.data() + p->nacc, (size_t)p->nacc * 8);
