@@ -442,7 +442,8 @@ int ph_agg_fetch_where(ph_agg *a, int32_t nconj, const int32_t *agg_index, const
  * of aggregate `agg_index` on the device and only the groups at least that good come back
  * (>= k of them when ties exist, fewer when there are fewer groups), in first-seen order, in the
  * same layout as ph_agg_finalize. The caller applies the full ORDER BY (tie-breaks) and LIMIT to
- * those few rows. Sums must fit int64 (PH_EOVERFLOW otherwise: use ph_agg_finalize). */
+ * those few rows. Sums must fit int64 (PH_EOVERFLOW otherwise: use ph_agg_finalize). SUM / MIN / MAX rank by their value, COUNT / COUNT(*)
+ * by their count; AVG and COUNT(DISTINCT) are refused (PH_EUNSUPPORTED). */
 int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int64_t k, int64_t max_groups,
                 int64_t *n_out, int64_t *first_row, int64_t *keys, uint8_t *key_null,
                 uint64_t *sum_lo, int64_t *sum_hi, uint64_t *count);

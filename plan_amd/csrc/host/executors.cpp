@@ -3,6 +3,9 @@
 #include "operator_exec.h"
 
 #include <algorithm>
+#include <chrono>
+#include <string_view>
+#include <unordered_map>
 #include <cstdio>
 
 namespace plan {
@@ -864,7 +867,7 @@ std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return 
 
 // inputs up to this many rows are ordered on the host (PH_ORDER_HOST_ROWS moves it; 0 = always the device sort, which the
 // parity tests use to run both forms over the same rows)
-static const int64_t kHostSortRows = getenv("PH_ORDER_HOST_ROWS") ? atoll(getenv("PH_ORDER_HOST_ROWS")) : 2048;
+static const int64_t kHostSortRows = getenv("PH_ORDER_HOST_ROWS") ? atoll(getenv("PH_ORDER_HOST_ROWS")) : (1 << 17);
 
 std::string gpuOrderExecutor::sortAll() {
     // VARCHAR keys do not go through the batch (its VARCHAR staging is the <= 256-value dictionary of a group column): their rows
@@ -889,31 +892,67 @@ std::string gpuOrderExecutor::sortAll() {
         total += c->Card();
     }
     if (total == 0) return "";
+    // ranks of a VARCHAR key's rows: position of the row's string among the key's DISTINCT strings in byte order (the distinct strings are
+    // found by hashing — a group column has few — and only they are sorted)
+    auto rankStrings = [&](size_t k, std::vector<int32_t> *rank, std::vector<uint8_t> *valid, bool *anyNull) {
+        rank->assign((size_t)total, 0);
+        valid->assign((size_t)(total + 7) / 8 + 8, 0);
+        *anyNull = false;
+        std::unordered_map<std::string_view, int32_t> ids;
+        std::vector<std::string_view> distinct;
+        std::vector<int32_t> idOf((size_t)total, -1);
+        int64_t row = 0;
+        for (auto &ch : chunks_) {
+            const Vector &v = *ch->Data[(size_t)keys_[k].col];
+            Vector::Unified u;
+            v.ToUnifiedFormat(ch->Card(), &u);
+            for (int i = 0; i < ch->Card(); i++, row++) {
+                const int64_t idx = u.sel->GetIndex(i);
+                if (!u.mask->RowIsValid((uint64_t)idx)) { *anyNull = true; continue; }
+                (*valid)[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
+                const String &sv = reinterpret_cast<const String *>(u.data)[idx];
+                auto it = ids.emplace(std::string_view(sv.Data, (size_t)sv.Len), (int32_t)distinct.size());
+                if (it.second) distinct.push_back(it.first->first);
+                idOf[(size_t)row] = it.first->second;
+            }
+        }
+        std::vector<int32_t> byOrder(distinct.size()), rankOfId(distinct.size());
+        for (size_t i = 0; i < byOrder.size(); i++) byOrder[i] = (int32_t)i;
+        std::sort(byOrder.begin(), byOrder.end(), [&](int32_t x, int32_t y) { return distinct[(size_t)x] < distinct[(size_t)y]; });
+        for (size_t i = 0; i < byOrder.size(); i++) rankOfId[(size_t)byOrder[i]] = (int32_t)i;
+        for (int64_t r = 0; r < total; r++) if (idOf[(size_t)r] >= 0) (*rank)[(size_t)r] = rankOfId[(size_t)idOf[(size_t)r]];
+    };
     if (total <= kHostSortRows) {
-        // A handful of rows (the groups of an aggregate, a top-k preselection): LocalSort's order on the host — the same
-        // keys ph_sort_rows sorts by (NULLs first whatever the direction, sort_layout.go:46; INTEGER / DATE by value,
-        // DECIMAL by dec.Int64(2) = the value rounded half-even to cents, sort_encoder.go:65-70; VARCHAR bytewise; DESC
-        // inverts the value order), ties in input order. Uploading ten rows, five launches and three read-backs cost
-        // ~0.1 ms of an ORDER BY ... LIMIT 10 tail; the device sort is for inputs that are worth a launch.
-        struct HK { bool null; int64_t v; std::string s; };
-        std::vector<std::vector<HK>> hk(keys_.size(), std::vector<HK>((size_t)total));
+        // The groups of an aggregate, a top-k preselection: LocalSort's order on the host — the same keys ph_sort_rows sorts by (NULLs first
+        // whatever the direction, sort_layout.go:46; INTEGER / DATE by value, DECIMAL by dec.Int64(2) = the value rounded half-even to cents,
+        // sort_encoder.go:65-70; VARCHAR bytewise, as ranks; DESC inverts the value order), ties in input order. Every key becomes an int64 per
+        // row; when the keys' value ranges fit 64 bits together the rows are sorted by ONE packed word (Q16's 28 k groups: four keys in 30 bits).
+        // Uploading rows, five launches and three read-backs cost ~0.1 ms for ten rows and 12 ms for 28 k (string ranks, allocations).
+        std::vector<std::vector<int64_t>> kv(keys_.size(), std::vector<int64_t>((size_t)total, 0));
+        std::vector<std::vector<uint8_t>> kn(keys_.size(), std::vector<uint8_t>((size_t)total, 0));
         auto types = child_->OutputTypes();
         for (size_t k = 0; k < keys_.size(); k++) {
             const LType &t = types[(size_t)keys_[k].col];
+            if (t.GetInternalType() == PT_VARCHAR) {
+                std::vector<int32_t> rank;
+                std::vector<uint8_t> valid;
+                bool anyNull = false;
+                rankStrings(k, &rank, &valid, &anyNull);
+                for (int64_t r = 0; r < total; r++) { kv[k][(size_t)r] = rank[(size_t)r]; kn[k][(size_t)r] = !((valid[(size_t)r >> 3] >> (r & 7)) & 1); }
+                continue;
+            }
             int64_t row = 0;
             for (auto &c : chunks_) {
                 const Vector &v = *c->Data[(size_t)keys_[k].col];
                 Vector::Unified u;
                 v.ToUnifiedFormat(c->Card(), &u);
                 for (int i = 0; i < c->Card(); i++, row++) {
-                    HK &h = hk[k][(size_t)row];
                     int64_t idx = u.sel->GetIndex(i);
-                    h.null = !u.mask->RowIsValid((uint64_t)idx);
-                    h.v = 0;
-                    if (h.null) continue;
+                    if (!u.mask->RowIsValid((uint64_t)idx)) { kn[k][(size_t)row] = 1; continue; }
+                    int64_t &hv = kv[k][(size_t)row];
                     switch (t.GetInternalType()) {
-                    case PT_INT32: h.v = reinterpret_cast<const int32_t *>(u.data)[idx]; break;
-                    case PT_DATE: h.v = DaysFromDate(reinterpret_cast<const Date *>(u.data)[idx]); break;
+                    case PT_INT32: hv = reinterpret_cast<const int32_t *>(u.data)[idx]; break;
+                    case PT_DATE: hv = DaysFromDate(reinterpret_cast<const Date *>(u.data)[idx]); break;
                     case PT_DECIMAL: {
                         int64_t x;
                         if (!DecimalToUnscaled(reinterpret_cast<const Decimal *>(u.data)[idx], t.Scale, &x)) return "decimal ORDER BY key does not fit 18 digits";
@@ -924,14 +963,13 @@ std::string gpuOrderExecutor::sortAll() {
                             if (2 * ar > p || (2 * ar == p && (q & 1))) q += x < 0 ? -1 : 1;
                             x = q;
                         } else for (int sc = t.Scale; sc < 2; sc++) x *= 10;
-                        h.v = x;
+                        hv = x;
                         break;
                     }
-                    case PT_VARCHAR: { const String &sv = reinterpret_cast<const String *>(u.data)[idx]; h.s.assign(sv.Data, (size_t)sv.Len); break; }
                     case PT_INT128: {   // hugeEncoder (sort_encoder.go:87-92): Upper then Lower = the signed 128-bit order; COUNT / SUM(INTEGER) results fit 64 bits
-                        const Hugeint &hv = reinterpret_cast<const Hugeint *>(u.data)[idx];
-                        if (!((hv.Upper == 0 && (int64_t)hv.Lower >= 0) || (hv.Upper == -1 && (int64_t)hv.Lower < 0))) return "HUGEINT ORDER BY key beyond 64 bits";
-                        h.v = (int64_t)hv.Lower;
+                        const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx];
+                        if (!((h.Upper == 0 && (int64_t)h.Lower >= 0) || (h.Upper == -1 && (int64_t)h.Lower < 0))) return "HUGEINT ORDER BY key beyond 64 bits";
+                        hv = (int64_t)h.Lower;
                         break;
                     }
                     default: break;
@@ -941,13 +979,49 @@ std::string gpuOrderExecutor::sortAll() {
         }
         order_.resize((size_t)total);
         for (int64_t i = 0; i < total; i++) order_[(size_t)i] = (int32_t)i;
+        // one packed word: per key (value - min) or (max - value) for DESC, + 1 (0 = NULL, first either way), most significant key first
+        std::vector<unsigned __int128> span(keys_.size());
+        std::vector<int64_t> lo(keys_.size(), 0), hi(keys_.size(), 0);
+        int bits = 0;
+        bool packs = true;
+        for (size_t k = 0; k < keys_.size() && packs; k++) {
+            bool any = false;
+            for (int64_t r = 0; r < total; r++) {
+                if (kn[k][(size_t)r]) continue;
+                const int64_t v = kv[k][(size_t)r];
+                if (!any) { lo[k] = hi[k] = v; any = true; } else { lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
+            }
+            span[k] = (unsigned __int128)((__int128)hi[k] - (__int128)lo[k]) + 2;   // values 1 .. span-1, 0 = NULL
+            int b = 0;
+            while (b < 64 && ((unsigned __int128)1 << b) < span[k]) b++;
+            if (((unsigned __int128)1 << b) < span[k]) packs = false;
+            bits += b;
+            if (bits > 64) packs = false;
+        }
+        if (packs) {
+            std::vector<std::pair<uint64_t, int32_t>> rows((size_t)total);
+            for (int64_t r = 0; r < total; r++) {
+                uint64_t w = 0;
+                for (size_t k = 0; k < keys_.size(); k++) {
+                    int b = 0;
+                    while (((unsigned __int128)1 << b) < span[k]) b++;
+                    uint64_t f = 0;
+                    if (!kn[k][(size_t)r]) f = (uint64_t)(keys_[k].descending ? (__int128)hi[k] - kv[k][(size_t)r] : (__int128)kv[k][(size_t)r] - lo[k]) + 1;
+                    w = b == 64 ? f : (w << b) | f;
+                }
+                rows[(size_t)r] = {w, (int32_t)r};
+            }
+            std::sort(rows.begin(), rows.end());   // (word, input position): ties in input order
+            for (int64_t r = 0; r < total; r++) order_[(size_t)r] = rows[(size_t)r].second;
+            return "";
+        }
         std::stable_sort(order_.begin(), order_.end(), [&](int32_t a, int32_t b) {
             for (size_t k = 0; k < keys_.size(); k++) {
-                const HK &x = hk[k][(size_t)a], &y = hk[k][(size_t)b];
-                if (x.null != y.null) return x.null;            // NULLs first
-                if (x.null) continue;
-                int c = x.s.empty() && y.s.empty() ? (x.v < y.v ? -1 : x.v > y.v) : x.s.compare(y.s) < 0 ? -1 : x.s.compare(y.s) > 0;
-                if (c != 0) return keys_[k].descending ? c > 0 : c < 0;
+                const bool xn = kn[k][(size_t)a], yn = kn[k][(size_t)b];
+                if (xn != yn) return xn;            // NULLs first
+                if (xn) continue;
+                const int64_t x = kv[k][(size_t)a], y = kv[k][(size_t)b];
+                if (x != y) return keys_[k].descending ? x > y : x < y;
             }
             return false;
         });
@@ -964,27 +1038,10 @@ std::string gpuOrderExecutor::sortAll() {
         ph_col c{};
         if (batchPos[k] >= 0) c = batch.col(batchPos[k]);
         else {
-            std::vector<std::string> vals((size_t)total);
-            std::vector<uint8_t> valid((size_t)(total + 7) / 8 + 8, 0);
+            std::vector<int32_t> rank;
+            std::vector<uint8_t> valid;
             bool anyNull = false;
-            int64_t row = 0;
-            for (auto &ch : chunks_) {
-                const Vector &v = *ch->Data[(size_t)keys_[k].col];
-                Vector::Unified u;
-                v.ToUnifiedFormat(ch->Card(), &u);
-                for (int i = 0; i < ch->Card(); i++, row++) {
-                    const int64_t idx = u.sel->GetIndex(i);
-                    if (!u.mask->RowIsValid((uint64_t)idx)) { anyNull = true; continue; }
-                    valid[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
-                    const String &sv = reinterpret_cast<const String *>(u.data)[idx];
-                    vals[(size_t)row].assign(sv.Data, (size_t)sv.Len);
-                }
-            }
-            std::vector<std::string> uniq(vals);
-            std::sort(uniq.begin(), uniq.end());
-            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-            std::vector<int32_t> rank((size_t)total);
-            for (int64_t r = 0; r < total; r++) rank[(size_t)r] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[(size_t)r]) - uniq.begin());
+            rankStrings(k, &rank, &valid, &anyNull);
             void *d = nullptr, *vd = nullptr;
             if (ph_dev_alloc(ctx_, total * 4, &d) != PH_OK) { freeRecoded(); return herr("ph_dev_alloc"); }
             recoded.push_back(d);
@@ -1719,10 +1776,18 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
     }
     if (!built_) {
         ph_agg_result *r = nullptr;
-        if (ph_plan_run(plan_) != PH_OK || ph_plan_fetch(plan_, &r) != PH_OK) {
+        static const bool timing = getenv("PH_HOST_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
+        int prc = ph_plan_run(plan_);
+        const double t1 = now();
+        if (prc == PH_OK) prc = ph_plan_fetch(plan_, &r);
+        if (timing) fprintf(stderr, "  resident plan: ph_plan_run %.1f us, ph_plan_fetch %.1f us\n", (t1 - t0) * 1e6, (now() - t1) * 1e6);
+        if (prc != PH_OK) {
             *err = herr("ph_plan_run/fetch");
             return InvalidOpResult;
         }
+        const double t2 = now();
         // (a sum beyond int64 makes the device hand every group back unfiltered: the HAVING is then applied below, like any other)
         const bool havingDone = havingOnDevice_ && ph_plan_having_applied(plan_) != 0;
         const ResidentPlan::Node &root = rp_.nodes.back();
@@ -1760,6 +1825,7 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
         ph_agg_result_free(r);
         if (e.empty()) e = ApplyAggOutputPhase(ctx_, havingDone ? std::vector<Compare>{} : having_, outputs_, outTypes_, finalTypes_, &results_);
         if (!e.empty()) { *err = e; return InvalidOpResult; }
+        if (timing) fprintf(stderr, "  resident plan: %lld groups into chunks %.1f us\n", (long long)results_.size(), (now() - t2) * 1e6);
         built_ = true;
     }
     if (next_ >= results_.size()) return Done;

@@ -600,6 +600,7 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->order = {{1, true}, {0, false}};
         q->limit = 100;
         q->ncols = 2;
+        q->topkAgg = 0; q->topkDesc = true;   // ORDER BY numwait DESC .. LIMIT 100: the groups that can be among the first hundred (ties kept)
         break;
     }
     case 22: {

@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
     bool wide = false;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int64_t st = (int64_t)(base + i) * naggs + a;
-        const long long lo = (long long)sum_lo[st];
         const bool live = cnt[st] != 0;
-        if (is_sum && live && sum_hi[st] != (lo >> 63)) wide = true;
+        const long long lo = is_sum == 2 ? (long long)cnt[st] : (long long)sum_lo[st];   // 2: COUNT / COUNT(*) rank by their count word
+        if (is_sum == 1 && live && sum_hi[st] != (lo >> 63)) wide = true;
         // an aggregate no input ever reached is NULL, and NULLs sort first whatever the direction
         // (sort_layout.go:46): the best possible key
         skeys[i] = live ? order_key(lo, descending) : 0ull;
@@ -2416,9 +2416,9 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     PH_REQUIRE(a && n_out && k >= 0 && max_groups >= 0 && agg_index >= 0 && agg_index < a->naggs,
                "ph_agg_topk: bad arguments");
     int kind = a->aggs[agg_index].kind;
-    if (kind != PH_A_SUM && kind != PH_A_MIN && kind != PH_A_MAX) {
-        // AVG orders by sum/count, COUNT by the count word: neither is the raw sum word ranked here
-        ph::set_error("ph_agg_topk: aggregate %d (kind %d) is not ordered by its sum/min/max word; use ph_agg_finalize", agg_index, kind);
+    if (kind != PH_A_SUM && kind != PH_A_MIN && kind != PH_A_MAX && kind != PH_A_COUNT && kind != PH_A_COUNT_STAR) {
+        // AVG orders by sum/count, COUNT(DISTINCT) by a side table: neither is a word of the group's state
+        ph::set_error("ph_agg_topk: aggregate %d (kind %d) is not ordered by its sum / min / max / count word; use ph_agg_finalize", agg_index, kind);
         return PH_EUNSUPPORTED;
     }
     *n_out = 0;
@@ -2448,7 +2448,7 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     int *meta = state + 2;
     const int tg = (int)((a->gcap + ph::TOPK_CHUNK - 1) / ph::TOPK_CHUNK);   // grid from the capacity: the count stays on the device
     ph::topk_select_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, a->counters, descending,
-                                                        kind == PH_A_SUM ? 1 : 0, (long long)k, cand_ids, cand_keys, state, state + 1,
+                                                        kind == PH_A_SUM ? 1 : (kind == PH_A_COUNT || kind == PH_A_COUNT_STAR) ? 2 : 0, (long long)k, cand_ids, cand_keys, state, state + 1,
                                                         ids, meta, cap);
     ph::agg_pack_kernel<<<std::max(1, std::min((cap + 255) / 256, 64)), 256, 0, ctx->stream>>>(
         ids, meta, a->counters, cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);

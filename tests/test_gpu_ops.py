@@ -1504,6 +1504,14 @@ def test_agg_topk_preselection(ctx):
         for key, s_ in zip(full["keys"][:, 0].tolist(), sums.tolist()):
             if key in got_sum:
                 assert got_sum[key] == s_
+    # ORDER BY count(*) [DESC] LIMIT k (Q21's numwait): COUNT aggregates rank by their count word
+    counts = full["count"][:, 1].astype(np.int64)
+    for kk, desc in [(10, True), (100, False), (1, True)]:
+        r = agg.topk(1, kk, descending=desc, cap=full["ngroups"])
+        order = np.sort(counts)[::-1] if desc else np.sort(counts)
+        kth = order[min(kk, len(order)) - 1]
+        want = set(full["keys"][:, 0][(counts >= kth) if desc else (counts <= kth)].tolist())
+        assert set(r["keys"][:, 0].tolist()) == want and r["ngroups"] == len(want)
     agg.free(); dk.free(); dv.free()
 
 
