@@ -173,6 +173,9 @@ const char *ph_table_dict_entry(const ph_table *t, int32_t c, int32_t code);
 #define PH_STAT_STRICT 2
 #define PH_STAT_DECLARED_UNIQUE 4
 int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags);
+/* > 0: the column is ascending in runs of this ONE length over consecutive values — row i holds min + i / run_len (PARTSUPP by ps_partkey: four
+ * suppliers per part) — so the rows of a key are found by arithmetic (ph_join_run_lookup). Measured at load like the order; 0 = not that shape. */
+int32_t ph_table_col_run_len(const ph_table *t, int32_t c);
 /* the catalog's PRIMARY KEY / UNIQUE constraint over 1..4 columns of the table (cases/tpch/query/ddl.sql: every
  * TPC-H table declares one). A join whose build key covers a declared-unique set is N:1. Trusted, like the
  * reference trusts its catalog; a lookup that meets two build rows for one key reports it (PH_ECONSTRAINT). */
@@ -598,6 +601,14 @@ int ph_merge_lookup(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const
  * (ph_table_col_stats reports what the library measured at load). */
 int ph_join_sorted_pairs(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, const ph_col *probe_key, const int32_t *sel, int64_t n,
                          int32_t *out_probe_dev, int32_t *out_build_dev, int64_t cap, int64_t *n_out);
+
+/* N:1 lookup on a two-column unique key into a table stored in runs of one length by the FIRST key column (ph_table_col_run_len > 0; key1_min =
+ * that column's minimum, ph_table_col_range), no table: the candidate rows of probe row i are (probe_keys[0][i] - key1_min) * run_len .. + run_len,
+ * the one whose build_key2 equals probe_keys[1][i] is the match (out_build_dev[i], -1 = none). Replaces JoinHashTable.Build + Probe
+ * (join_table.go:85-288, join_scan.go:67-165) for a composite foreign key into such a table (Q9's lineitem -> partsupp). strict != 0: a probe row
+ * without a match, or with several, is a deferred PH_ECONSTRAINT as in ph_join_lookup_strict. The run structure is the caller's claim. */
+int ph_join_run_lookup(ph_ctx *ctx, const ph_col *build_key2, int64_t n_build, int64_t key1_min, int32_t run_len, const ph_col *probe_keys,
+                       const int32_t *sel, int64_t n, int32_t strict, int32_t *out_build_dev);
 
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:
  * for every right row, all left rows in order — the order the reference emits (one output chunk

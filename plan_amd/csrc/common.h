@@ -150,6 +150,9 @@ struct ph_table {
         // order statistics of integer columns, one pass at load (like min / max): the values are non-decreasing in
         // storage order (a clustering column: lineitem by l_orderkey) / strictly ascending (a primary key in key order)
         bool ascending = false, strict = false;
+        // an ascending column made of runs of ONE length over consecutive values (row i holds min + i / run_len: partsupp by ps_partkey, four
+        // suppliers per part): the rows of a key are found by arithmetic. 0 = not that shape. Verified on the device at load, like the order.
+        int32_t run_len = 0;
     };
     std::vector<column> cols;
     // column sets the catalog declares unique (PRIMARY KEY): ph_table_declare_unique

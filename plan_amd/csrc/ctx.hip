@@ -521,6 +521,35 @@ static int column_order(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, b
     return PH_OK;
 }
 
+// run statistic: out[0] |= 1 when some row i does not hold mn + i / c
+template <typename T>
+__global__ __launch_bounds__(256) void run_stat_kernel(const T *__restrict__ v, int64_t n, long long mn, int c, int *__restrict__ out) {
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) f |= (long long)v[i] != mn + i / c ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(out, f);
+}
+
+static int column_runs(ph_ctx *ctx, int32_t type, const void *dev, int64_t n, int64_t mn, int64_t mx, int32_t *run_len) {
+    *run_len = 0;
+    const __int128 span = (__int128)mx - (__int128)mn + 1;
+    if (span <= 0 || span > n || n % (int64_t)span != 0) return PH_OK;
+    const int64_t c = n / (int64_t)span;
+    if (c < 2 || c > 64) return PH_OK;
+    PH_CHECK(ctx->ensure_scratch(64));
+    PH_HIP(hipMemsetAsync(ctx->scratch, 0, 8, ctx->stream));
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    int *out = (int *)ctx->scratch;
+    if (type == PH_I32 || type == PH_DATE) run_stat_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t *)dev, n, (long long)mn, (int)c, out);
+    else if (type == PH_I64 || type == PH_DEC64) run_stat_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t *)dev, n, (long long)mn, (int)c, out);
+    else return PH_OK;
+    PH_HIP(hipGetLastError());
+    int f = 0;
+    PH_CHECK(ctx->download(&f, out, 4));
+    if (!f) *run_len = (int32_t)c;
+    return PH_OK;
+}
+
 // ---------------------------------------------------------------- tables
 
 extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_cols, int64_t nrows,
@@ -570,6 +599,7 @@ extern "C" int ph_table_create(ph_ctx *ctx, int32_t ncols, const ph_col *host_co
                 rc = column_range(ctx, h.type, d.data, nrows, &d.min, &d.max);
                 d.has_range = rc == PH_OK;
                 if (rc == PH_OK && h.type != PH_CODE8 && !h.validity) rc = column_order(ctx, h.type, d.data, nrows, &d.ascending, &d.strict);
+                if (rc == PH_OK && d.ascending && !d.strict) rc = column_runs(ctx, h.type, d.data, nrows, d.min, d.max, &d.run_len);
             }
         }
         if (rc == PH_OK && h.validity) {
@@ -644,6 +674,11 @@ extern "C" int ph_table_col_stats(const ph_table *t, int32_t c, int32_t *flags) 
     *flags = (d.ascending ? PH_STAT_ASCENDING : 0) | (d.strict ? PH_STAT_STRICT : 0);
     for (auto &u : t->unique_keys) if (u.size() == 1 && u[0] == c) *flags |= PH_STAT_DECLARED_UNIQUE;
     return PH_OK;
+}
+
+extern "C" int32_t ph_table_col_run_len(const ph_table *t, int32_t c) {
+    if (!t || c < 0 || c >= (int32_t)t->cols.size()) return 0;
+    return t->cols[(size_t)c].run_len;
 }
 
 // ---- co-located column groups

@@ -255,3 +255,64 @@ extern "C" int ph_join_sorted_pairs(ph_ctx *ctx, const ph_col *build_key, int64_
     if (m > cap) { ph::set_error("ph_join_sorted_pairs: %lld pairs, room for %lld", (long long)m, (long long)cap); return PH_ECAPACITY; }
     return PH_OK;
 }
+
+// ------------------------------------------------------------------ N:1 lookup into a table stored in runs of one length, no table
+// The build table is clustered by its first key in runs of a constant length over consecutive values (ph_table_col_run_len: partsupp by
+// ps_partkey, four rows per part), the join key is (that column, a second column) and unique: the rows of a first key are at
+// (key - min) * run_len .. + run_len, the second key picks the row among them — one short read of the second key column per probe row, where
+// the node table took a build over the (reduced) build side and two dependent random reads per probe (Q9 at SF10: 211 us -> ~40 us).
+namespace ph {
+template <int KW, int KW2>
+__global__ __launch_bounds__(256) void run_lookup_kernel(const void *__restrict__ bkey2, int64_t nruns, long long kmin, int c, const void *__restrict__ pk1,
+                                                         const uint8_t *pv1, const void *__restrict__ pk2, const uint8_t *pv2, const int32_t *__restrict__ sel,
+                                                         int64_t n, int32_t *__restrict__ out, int *__restrict__ stats) {
+    int misses = 0, multi = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = sel ? sel[i] : i;
+        int32_t row = -1;
+        if ((!pv1 || bit_valid(pv1, r)) && (!pv2 || bit_valid(pv2, r))) {   // a NULL key matches nothing (prepareKeys, join_table.go:152)
+            const long long d = sp_key<KW>(pk1, r) - kmin;
+            if (d >= 0 && d < nruns) {
+                const long long k2 = sp_key<KW2>(pk2, r);
+                const int64_t base = d * c;
+                int found = 0;
+                for (int j = 0; j < c; j++)
+                    if (sp_key<KW2>(bkey2, base + j) == k2) { if (!found) row = (int32_t)(base + j); found++; }
+                multi += found > 1;
+            }
+        }
+        misses += row < 0;
+        out[i] = row;
+    }
+    for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (misses) atomicAdd(stats, misses);
+        if (multi) atomicAdd(stats + 1, multi);
+    }
+}
+}  // namespace ph
+
+extern "C" int ph_join_run_lookup(ph_ctx *ctx, const ph_col *build_key2, int64_t n_build, int64_t key1_min, int32_t run_len, const ph_col *probe_keys,
+                                  const int32_t *sel, int64_t n, int32_t strict, int32_t *out_build_dev) {
+    PH_REQUIRE(ctx && build_key2 && probe_keys && n_build >= 0 && n >= 0 && n_build < (1ll << 31) && run_len >= 1 && n_build % run_len == 0 && (n == 0 || out_build_dev),
+               "ph_join_run_lookup: bad arguments");
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : (t == PH_I64 || t == PH_DEC64) ? 8 : 0; };
+    const int kw = width(probe_keys[0].type), kw2 = width(build_key2->type);
+    if (kw == 0 || kw2 == 0 || width(probe_keys[1].type) != kw2 || build_key2->validity) {
+        ph::set_error("ph_join_run_lookup: 4- or 8-byte integer keys, the second of the same width on both sides, no NULLs on the build side");
+        return PH_EUNSUPPORTED;
+    }
+    if (n == 0) return PH_OK;
+    int *words = nullptr;
+    PH_CHECK(ctx->deferred_words(&words));
+    int *stats = strict ? words + 1 : nullptr;   // [1] misses, [2] several rows for one key: the deferred words of ph_join_lookup_strict
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 16);
+    const int64_t nruns = n_build / run_len;
+#define PH_RL(A, B) ph::run_lookup_kernel<A, B><<<grid, 256, 0, ctx->stream>>>(build_key2->data, nruns, (long long)key1_min, (int)run_len, probe_keys[0].data, probe_keys[0].validity, \
+                                                                             probe_keys[1].data, probe_keys[1].validity, sel, n, out_build_dev, stats)
+    if (kw == 4 && kw2 == 4) PH_RL(4, 4); else if (kw == 4) PH_RL(4, 8); else if (kw2 == 4) PH_RL(8, 4); else PH_RL(8, 8);
+#undef PH_RL
+    PH_HIP(hipGetLastError());
+    if (strict) ctx->deferred_pending = true;
+    return PH_OK;
+}

@@ -44,6 +44,7 @@ struct SelParams {
     double div;  // 10^scale
     int plen;
     int contains;  // LIKE / NOT LIKE pattern is %literal% (no _ and no inner %): substring search
+    int lit2_at, lit1_len, lit2_len;   // pattern %A%B% (no _): A = pat[1 .. 1+lit1_len), B = pat[lit2_at .. lit2_at+lit2_len); lit2_at == 0: not that shape
     char pat[96];
     const void *data2;          // SK_CMP2_*: the right-hand column
     const uint8_t *validity2;
@@ -291,6 +292,83 @@ __global__ __launch_bounds__(256) void like_contains_count_kernel(SelParams P, i
         const int64_t i = base + lr;
         bool pass = false;
         if (i < n_in && bit_valid(P.validity, i)) pass = (((rowhit[lr >> 5] >> (lr & 31)) & 1) != 0) == (P.op == PH_LIKE);
+        cnt += pass ? 1 : 0;
+        const unsigned long long m = __ballot(pass);
+        if ((threadIdx.x & 63) == 0) flags[((int64_t)blockIdx.x * SEL_ROUNDS + r) * 4 + (threadIdx.x >> 6)] = m;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __shared__ int ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// %A%B% over consecutive rows, like like_contains_count_kernel: the row matches when SOME occurrence of A ends at or before the start of SOME
+// occurrence of B, i.e. the earliest end of A <= the latest start of B — two words of LDS per row (atomicMin / atomicMax of the hits), no
+// per-row scan (Q13's o_comment NOT LIKE '%special%requests%': 15 M rows, 730 MB; the row-per-thread matcher ran 2.0 ms at SF10).
+__global__ __launch_bounds__(256) void like_contains2_count_kernel(SelParams P, int64_t n_in, int32_t *__restrict__ block_counts,
+                                                                   unsigned long long *__restrict__ flags) {
+    __shared__ int soff[SEL_CHUNK + 1];
+    __shared__ int endA[SEL_CHUNK], startB[SEL_CHUNK];
+    __shared__ char spat[96];
+    const int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
+    const int nrow = (int)(base + SEL_CHUNK < n_in ? SEL_CHUNK : n_in - base);
+    const int32_t *off = (const int32_t *)P.data;
+    for (int e = threadIdx.x; e <= nrow; e += 256) soff[e] = off[base + e];
+    for (int e = threadIdx.x; e < SEL_CHUNK; e += 256) { endA[e] = 0x7fffffff; startB[e] = -1; }
+    if (threadIdx.x < 96) spat[threadIdx.x] = P.pat[threadIdx.x];
+    __syncthreads();
+    const int LA = P.lit1_len, LB = P.lit2_len, atB = P.lit2_at;
+    const int64_t s0 = soff[0], s1 = soff[nrow];
+    unsigned litA = 0, litB = 0;
+    for (int c = 0; c < 4 && c < LA; c++) litA |= (unsigned)(unsigned char)spat[1 + c] << (8 * c);
+    for (int c = 0; c < 4 && c < LB; c++) litB |= (unsigned)(unsigned char)spat[atB + c] << (8 * c);
+    const unsigned mA = LA >= 4 ? 0xFFFFFFFFu : (1u << (8 * LA)) - 1u, mB = LB >= 4 ? 0xFFFFFFFFu : (1u << (8 * LB)) - 1u;
+    const int64_t a0 = s0 & ~15ll;
+    for (int64_t p = a0 + (int64_t)threadIdx.x * 16; p < s1; p += 256 * 16) {
+        unsigned w[5] = {0, 0, 0, 0, 0};
+        if (p + 20 <= s1) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(P.bytes + p);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            w[4] = *reinterpret_cast<const unsigned *>(P.bytes + p + 16);
+        } else {
+            for (int b = 0; b < 20 && p + b < s1; b++) w[b >> 2] |= (unsigned)(unsigned char)P.bytes[p + b] << (8 * (b & 3));
+        }
+        unsigned hits = 0;   // bit k: a prefix of A at position k, bit 16 + k: of B
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned long long two = (unsigned long long)w[k >> 2] | ((unsigned long long)w[(k >> 2) + 1] << 32);
+            const unsigned four = (unsigned)(two >> (8 * (k & 3)));
+            hits |= (((four ^ litA) & mA) == 0 ? 1u : 0u) << k;
+            hits |= (((four ^ litB) & mB) == 0 ? 1u : 0u) << (16 + k);
+        }
+        while (hits) {
+            const int h = __ffs(hits) - 1;
+            hits &= hits - 1;
+            const bool isB = h >= 16;
+            const int L = isB ? LB : LA, at = isB ? atB : 1;
+            const int64_t x = p + (h & 15);
+            if (x < s0 || x + L > s1) continue;
+            bool m = true;
+            for (int c = 4; m && c < L; c++) m = P.bytes[x + c] == spat[at + c];
+            if (!m) continue;
+            int lo = 0, hi = nrow;   // last row with offset <= position
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (soff[mid] <= x) lo = mid; else hi = mid;
+            }
+            if (x + L > soff[lo + 1]) continue;   // straddles two rows
+            const int rel = (int)(x - soff[lo]);
+            if (isB) atomicMax(&startB[lo], rel); else atomicMin(&endA[lo], rel + L);
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int r = 0; r < SEL_ROUNDS; r++) {
+        const int lr = r * 256 + threadIdx.x;
+        const int64_t i = base + lr;
+        bool pass = false;
+        if (i < n_in && bit_valid(P.validity, i)) pass = (endA[lr] <= startB[lr]) == (P.op == PH_LIKE);
         cnt += pass ? 1 : 0;
         const unsigned long long m = __ballot(pass);
         if ((threadIdx.x & 63) == 0) flags[((int64_t)blockIdx.x * SEL_ROUNDS + r) * 4 + (threadIdx.x >> 6)] = m;
@@ -593,8 +671,15 @@ static bool lower_select(const ph_col *col, int32_t op, const ph_const *k, SelPa
         memcpy(P->pat, k->s, (size_t)P->plen);
         if ((op == PH_LIKE || op == PH_NOTLIKE) && P->plen >= 3 && P->pat[0] == '%' && P->pat[P->plen - 1] == '%') {
             P->contains = 1;
-            for (int c = 1; c < P->plen - 1; c++)
+            int inner = 0, at = 0;
+            bool plain = true;
+            for (int c = 1; c < P->plen - 1; c++) {
                 if (P->pat[c] == '%' || P->pat[c] == '_') P->contains = 0;
+                if (P->pat[c] == '%') { inner++; at = c; }
+                if (P->pat[c] == '_' || P->pat[c] == '\\') plain = false;
+            }
+            // %A%B%: A somewhere, B somewhere behind it (wildcardMatch's % = any run of characters, function_operator_like.go)
+            if (plain && inner == 1 && at > 1 && at < P->plen - 2) { P->lit1_len = at - 1; P->lit2_at = at + 1; P->lit2_len = P->plen - 1 - (at + 1); }
         }
         P->bytes = (const char *)col->aux;
         P->kind = SK_STR;
@@ -804,6 +889,9 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
     if (P.kind == ph::SK_STR && P.contains && sel_in == nullptr && P.plen >= 3 && !no_direct_like &&
         (reinterpret_cast<uintptr_t>(P.bytes) & 15) == 0)
         ph::like_contains_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, n_in, counts, flags);
+    else if (P.kind == ph::SK_STR && P.lit2_at > 0 && (P.op == PH_LIKE || P.op == PH_NOTLIKE) && sel_in == nullptr && memo && !no_direct_like &&
+             (reinterpret_cast<uintptr_t>(P.bytes) & 15) == 0)
+        ph::like_contains2_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, n_in, counts, flags);
     else
         ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, flags);
     PH_HIP(hipGetLastError());

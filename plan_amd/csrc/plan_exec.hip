@@ -1432,6 +1432,45 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
     const bool marks_only = nd.join_type == PH_JT_ANTI || (exists_only && !unique);   // probe form (2) below: ph_join_probe_mark and nothing else
     std::string how;
 
+    // ---- run lookup: the build table is stored in runs of one length by the first key column and (first, second) is its unique key — the row is
+    // found by arithmetic and a look at the run's second keys (ph_join_run_lookup): no table, no reduction of the build side, one short read per
+    // probe row. The run structure is the library's own load-time measurement (ph_table_col_run_len).
+    if (nd.join_type == PH_JT_INNER && unique && !exists_only && uniq == 2 && optimistic && nk == 2 && B.covers && B.single_identity() && !B.lazy() &&
+        !getenv("PH_PLAN_NO_RUN_LOOKUP")) {
+        const ph_table *bt = B.lanes[0].t;
+        int first = -1;
+        for (int k = 0; k < 2; k++) {
+            const PCol &bc = B.cols[(size_t)nd.bkeys[(size_t)k]];
+            if (bc.lane == 0 && bc.tcol >= 0 && bt->cols[(size_t)bc.tcol].run_len > 1) first = k;
+        }
+        const PCol &b2 = B.cols[(size_t)nd.bkeys[(size_t)(first < 0 ? 0 : 1 - first)]];
+        if (first >= 0 && b2.lane == 0 && b2.tcol >= 0 && !bt->cols[(size_t)b2.tcol].validity) {
+            const PCol &b1 = B.cols[(size_t)nd.bkeys[(size_t)first]];
+            PL_CHECK(apply_pending(p, &P));
+            KeySide pk;
+            PL_CHECK(key_side(p, &P, {nd.pkeys[(size_t)first], nd.pkeys[(size_t)(1 - first)]}, &pk));
+            ph_col bv2 = table_view(bt, b2.tcol);
+            void *o = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &o));
+            int rc = ph_join_run_lookup(ctx, &bv2, bt->nrows, bt->cols[(size_t)b1.tcol].min, bt->cols[(size_t)b1.tcol].run_len, pk.views.data(), pk.sel, P.n, 1, (int32_t *)o);
+            if (rc == PH_OK) {
+                *out = P;
+                Lane bl; bl.t = bt; bl.rows = (const int32_t *)o; bl.asc = false; bl.dup_free = false;
+                out->lanes.push_back(bl);
+                std::vector<PCol> all = P.cols;
+                for (auto c : B.cols) { c.lane = (int)P.lanes.size(); c.ordered = false; c.domain = -1; all.push_back(c); }
+                out->cols.clear();
+                for (int32_t oi : nd.out) out->cols.push_back(all[(size_t)oi]);
+                out->covers = false;
+                drop_unused_lanes(out);
+                note(p, "join#%d: run lookup (the build table is stored in runs of %d by its first key: row = arithmetic + the run's second keys, no table), %lld probe rows", idx,
+                     (int)bt->cols[(size_t)b1.tcol].run_len, (long long)P.n);
+                return PH_OK;
+            }
+            if (rc != PH_EUNSUPPORTED) return rc;
+        }
+    }
+
     // ---- sideways information passing: a big, unfiltered build table whose key the probe side has already joined
     // against a small table is reduced to the rows that can match (marks from a probe of that small table)
     if (B.single_identity() && !B.lazy() && B.n >= (1 << 18)) {

@@ -268,6 +268,11 @@ class Table:
         check(lib().ph_table_col(self.h, i32(c), ctypes.byref(out)))
         return out
 
+    def col_run_len(self, c):
+        """ph_table_col_run_len: > 0 = the column is stored in runs of that one length over consecutive values"""
+        lib().ph_table_col_run_len.restype = ctypes.c_int32
+        return int(lib().ph_table_col_run_len(self.h, i32(c)))
+
     def col_range(self, c):
         mn, mx = i64(), i64()
         check(lib().ph_table_col_range(self.h, i32(c), ctypes.byref(mn), ctypes.byref(mx)))
@@ -746,6 +751,25 @@ def merge_lookup(ctx, build_key, n_build, probe_key, sel, n, strict=False):
     b = build_key.col() if isinstance(build_key, DevColumn) else build_key
     p = probe_key.col() if isinstance(probe_key, DevColumn) else probe_key
     check(lib().ph_merge_lookup(ctx.h, ctypes.byref(b), i64(n_build), ctypes.byref(p), sel, i64(n), i32(1 if strict else 0), out))
+    return out
+
+
+def join_sorted_pairs(ctx, build_key, n_build, probe_key, sel, n, cap):
+    """ph_join_sorted_pairs: inner pairs against a key column stored in ascending order with duplicates, no table; (probe rows, build rows, count)"""
+    op, ob = ctx.alloc(max(cap, 1) * 4), ctx.alloc(max(cap, 1) * 4)
+    b = build_key.col() if isinstance(build_key, DevColumn) else build_key
+    p = probe_key.col() if isinstance(probe_key, DevColumn) else probe_key
+    m = ctypes.c_int64(0)
+    check(lib().ph_join_sorted_pairs(ctx.h, ctypes.byref(b), i64(n_build), ctypes.byref(p), sel, i64(n), op, ob, i64(cap), ctypes.byref(m)))
+    return op, ob, m.value
+
+
+def join_run_lookup(ctx, build_key2, n_build, key1_min, run_len, probe_keys, sel, n, strict=False):
+    """ph_join_run_lookup: N:1 lookup on (first key, second key) into a table stored in runs of run_len by the first key; device int32[n] (-1 = none)"""
+    out = ctx.alloc(max(n, 1) * 4)
+    b = build_key2.col() if isinstance(build_key2, DevColumn) else build_key2
+    arr = (Col * 2)(*[k.col() if isinstance(k, DevColumn) else k for k in probe_keys])
+    check(lib().ph_join_run_lookup(ctx.h, ctypes.byref(b), i64(n_build), i64(key1_min), i32(run_len), arr, sel, i64(n), i32(1 if strict else 0), out))
     return out
 
 

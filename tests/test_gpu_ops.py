@@ -133,7 +133,12 @@ def test_filter_like_contains_edge_cases(ctx):
     col = hip.DevColumn(ctx, hip.PH_STR, off, aux=b, validity=vb)
     ocol = O.col(O.OT_VARCHAR, off, validity=vb, dictionary=b)
     for op, pat in [(hip.PH_LIKE, "%pink%"), (hip.PH_NOTLIKE, "%pink%"), (hip.PH_LIKE, "%k%"), (hip.PH_LIKE, "%pi nk%"),
-                    (hip.PH_LIKE, "%nkp%"), (hip.PH_LIKE, "%p_nk%"), (hip.PH_LIKE, "%pin%pink%")]:
+                    (hip.PH_LIKE, "%nkp%"), (hip.PH_LIKE, "%p_nk%"), (hip.PH_LIKE, "%pin%pink%"),
+                    # %A%B% (the two-literal kernel: earliest end of A <= latest start of B, inside ONE row): B may not overlap A, order
+                    # matters, one-byte literals, literals at the row's ends, rows longer than the LDS stage
+                    (hip.PH_NOTLIKE, "%pin%pink%"), (hip.PH_LIKE, "%pi%nk%"), (hip.PH_LIKE, "%nk%pi%"), (hip.PH_LIKE, "%p%p%"),
+                    (hip.PH_LIKE, "%pink%pink%"), (hip.PH_LIKE, "%ink%k%"), (hip.PH_NOTLIKE, "%k%p%"), (hip.PH_LIKE, "%aaaaa%pink%"),
+                    (hip.PH_LIKE, "%pink%ccccc%"), (hip.PH_LIKE, "%x %x%")]:
         s, c = hip.filter_select(ctx, col, len(words), op, hip.const(hip.PH_STR, s=pat))
         want = O.select(ocol, op, O.const(O.OT_VARCHAR, s=pat), n=len(words))
         assert c == len(want), (op, pat, c, len(want))
@@ -1037,6 +1042,71 @@ def test_join_build_where_sorted_unique_gated_fill(ctx):
         jb.free()
         for c in (dk, dfl, dp, dsh, dbad):
             c.free()
+
+
+def test_sorted_pairs_and_run_lookup_equal_table_joins(ctx):
+    """The two table-less joins against a table stored in key order answer like a built table:
+    ph_join_sorted_pairs (binary search of a clustered key column with duplicates: the lineitem-by-order shape) against ph_join_build +
+    ph_join_probe_inner, incl. absent keys, a probe selection, runs longer than the walk's 16 rows, the capacity protocol;
+    ph_join_run_lookup (runs of one length by the first key, the second key picks the row: the partsupp shape) against numpy, incl. misses,
+    NULL probe keys, keys outside the range, and the strict form's deferred error; ph_table_col_run_len finds the shape and refuses near misses."""
+    rng = np.random.default_rng(202)
+    # ---- sorted pairs
+    norders = 300_000
+    per = rng.integers(1, 8, norders)
+    per[1000] = 40                                                   # one long run
+    okeys = (np.arange(norders, dtype=np.int64) // 8) * 32 + np.arange(norders) % 8 + 1
+    bk = np.repeat(okeys, per)
+    nb = len(bk)
+    db = hip.DevColumn(ctx, hip.PH_I64, bk)
+    probe = np.concatenate([okeys[rng.integers(0, norders, 20_000)], np.array([okeys[1000], -3, int(okeys[-1]) + 9], dtype=np.int64),
+                            rng.integers(0, int(okeys[-1]), 2000)]).astype(np.int64)
+    rng.shuffle(probe)
+    dp = hip.DevColumn(ctx, hip.PH_I64, probe)
+    first = np.searchsorted(bk, probe, "left"); last = np.searchsorted(bk, probe, "right")
+    want = [(i, r) for i in range(len(probe)) for r in range(first[i], last[i])]
+    op, ob, m = hip.join_sorted_pairs(ctx, db, nb, dp, None, len(probe), len(want) + 10)
+    got = list(zip(ctx.download(op, np.int32, m).tolist(), ctx.download(ob, np.int32, m).tolist()))
+    assert m == len(want) and got == want
+    sel = np.sort(rng.choice(len(probe), 5000, replace=False)).astype(np.int32)
+    ds = ctx.upload(sel)
+    want_s = [(int(i), r) for i in sel for r in range(first[i], last[i])]
+    op2, ob2, m2 = hip.join_sorted_pairs(ctx, db, nb, dp, ds, len(sel), len(want_s))
+    assert m2 == len(want_s) and list(zip(ctx.download(op2, np.int32, m2).tolist(), ctx.download(ob2, np.int32, m2).tolist())) == want_s
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.join_sorted_pairs(ctx, db, nb, dp, None, len(probe), 100)
+    assert e.value.code == hip.PH_ECAPACITY
+    for q in (op, ob, op2, ob2, ds):
+        ctx.free(q)
+    db.free(); dp.free()
+    # ---- run lookup
+    nparts, c = 50_000, 4
+    pk = np.repeat(np.arange(7, 7 + nparts, dtype=np.int32), c)
+    sk = np.empty(nparts * c, np.int32)
+    for j in range(c):
+        sk[j::c] = (np.arange(nparts) * 3 + j * 1250) % 5000 + 1     # four distinct suppliers per part
+    t = hip.Table(ctx, [(hip.PH_I32, pk), (hip.PH_I32, sk)], nparts * c)
+    assert t.col_run_len(0) == c and t.col_run_len(1) == 0
+    rows = rng.integers(0, nparts * c, 100_000)
+    p1, p2 = pk[rows].copy(), sk[rows].copy()
+    p2[:500] = 6000                                                  # no such supplier
+    p1[500:600] = 3                                                  # below the range
+    p1[600:700] = 7 + nparts                                         # above it
+    valid = np.ones(len(rows), bool); valid[700:800] = False
+    d1 = hip.DevColumn(ctx, hip.PH_I32, p1, validity=np.packbits(valid, bitorder="little"))
+    d2 = hip.DevColumn(ctx, hip.PH_I32, p2)
+    got = ctx.download(hip.join_run_lookup(ctx, t.col(1), nparts * c, 7, c, [d1, d2], None, len(rows)), np.int32, len(rows))
+    want = rows.astype(np.int32).copy(); want[:800] = -1
+    assert np.array_equal(got, want)
+    ctx.check_deferred()
+    strict = hip.join_run_lookup(ctx, t.col(1), nparts * c, 7, c, [d1, d2], None, len(rows), strict=True)
+    with pytest.raises(hip.PlanHipError) as e:
+        ctx.download(strict, np.int32, 4)
+    assert e.value.code == hip.PH_ECONSTRAINT
+    pk2 = pk.copy(); pk2[1000] = pk2[999]                            # one run of five, one of three: not the shape
+    t2 = hip.Table(ctx, [(hip.PH_I32, np.sort(pk2))], nparts * c)
+    assert t2.col_run_len(0) == 0
+    t.free(); t2.free(); d1.free(); d2.free()
 
 
 def test_merge_lookup_equals_table_lookup(ctx):

@@ -103,19 +103,24 @@ def test_q3_plan_other_parameters(ctx, db, sf1, segment, ymd):
     assert pipelines.q3_text(tpch.q3_top(r)) == O.q3_text(rows, n)
 
 
-def test_q9_plan_matches_golden(ctx, db):
-    """Q9: LIKE, five joins (one composite), Project, 175 groups; the library reduces partsupp by the part keys'
-    domain, uses strict N:1 lookups and the merge lookup for orders"""
-    p = tpch.q9_plan(db)
-    for _ in range(2):   # a plan can be run again
-        p.run()
-        r = p.fetch()
-        assert pipelines.q9_text(tpch.q9_rows(r), tpchgen.nation_names()) == golden("plan_q9.txt")
-    ex = p.explain()
-    for phrase in ("reduced by the probe key's domain", "strict N:1 lookup", "merge lookup"):
-        assert phrase in ex, ex
-    assert "conservative" not in ex
-    p.free()
+def test_q9_plan_matches_golden(ctx, db, monkeypatch):
+    """Q9: LIKE, five joins (one composite), Project, 175 groups; the library finds partsupp's rows by arithmetic (stored in runs of four
+    by ps_partkey: the run lookup), uses strict N:1 lookups and the merge lookup for orders; with the run lookup switched off it reduces
+    partsupp by the part keys' domain and builds the node table — the same rows"""
+    for no_run, phrases in ((False, ("run lookup", "strict N:1 lookup", "merge lookup")),
+                            (True, ("reduced by the probe key's domain", "strict N:1 lookup", "merge lookup"))):
+        if no_run:
+            monkeypatch.setenv("PH_PLAN_NO_RUN_LOOKUP", "1")
+        p = tpch.q9_plan(db)
+        for _ in range(2):   # a plan can be run again
+            p.run()
+            r = p.fetch()
+            assert pipelines.q9_text(tpch.q9_rows(r), tpchgen.nation_names()) == golden("plan_q9.txt")
+        ex = p.explain()
+        for phrase in phrases:
+            assert phrase in ex, ex
+        assert "conservative" not in ex
+        p.free()
 
 
 @pytest.mark.parametrize("pattern", ["%green%", "%zzzz%", "%a%"])

@@ -209,7 +209,7 @@ def test_join_queries_as_one_resident_plan_executor_match_reference_goldens(q):
     assert out == open(os.path.join(G, f"plan_{q}.txt")).read()
     assert err.count(f"Query {q[1]} took") == 3 and "success" in err
     assert "conservative" not in err
-    want = ["gated sorted fill", "semi-join marks", "streaming aggregate"] if q == "q3" else ["merge lookup", "strict N:1 lookup", "reduced by the probe key's domain"]
+    want = ["gated sorted fill", "semi-join marks", "streaming aggregate"] if q == "q3" else ["merge lookup", "strict N:1 lookup", "run lookup"]
     for phrase in want:
         assert phrase in err, err
 
