@@ -236,6 +236,12 @@ typedef struct {
 int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op, const ph_const *k,
                      const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
 
+/* Two conjuncts `col OP1 k1 AND col OP2 k2` over ONE column in one pass (a date range: execSelectAnd, expr_exec.go:430-486, runs the second over
+ * the first's selection). Both must lower to value ranges of one kind (integer / date / decimal orderings, '=', a dictionary code);
+ * PH_EUNSUPPORTED otherwise — run them one after the other with ph_filter_select. Same outputs as ph_filter_select. */
+int ph_filter_select_and(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op1, const ph_const *k1, int32_t op2, const ph_const *k2,
+                         const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
+
 /* column OP column over the same rows (selectBinary with two FLAT vectors, function_operator_boolean.go:506-521),
  * e.g. Q4 / Q12's l_commitdate < l_receiptdate. The (type, op) pairs are selectOperation's: INTEGER all six, DATE
  * the four orderings, DECIMAL (one scale) '>' only; the pairs the reference does not implement select nothing. */

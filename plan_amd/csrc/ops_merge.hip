@@ -266,23 +266,52 @@ template <int KW, int KW2>
 __global__ __launch_bounds__(256) void run_lookup_kernel(const void *__restrict__ bkey2, int64_t nruns, long long kmin, int c, const void *__restrict__ pk1,
                                                          const uint8_t *pv1, const void *__restrict__ pk2, const uint8_t *pv2, const int32_t *__restrict__ sel,
                                                          int64_t n, int32_t *__restrict__ out, int *__restrict__ stats) {
+    // Four probe rows per thread and step, every stage's loads issued for all four before any is used: the row ids, the two keys (two scattered
+    // reads per row when the keys are table columns behind row ids), then the run's second keys (ONE 16-byte read for runs of four 4-byte keys)
+    constexpr int U = 4;
     int misses = 0, multi = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = sel ? sel[i] : i;
-        int32_t row = -1;
-        if ((!pv1 || bit_valid(pv1, r)) && (!pv2 || bit_valid(pv2, r))) {   // a NULL key matches nothing (prepareKeys, join_table.go:152)
-            const long long d = sp_key<KW>(pk1, r) - kmin;
-            if (d >= 0 && d < nruns) {
-                const long long k2 = sp_key<KW2>(pk2, r);
-                const int64_t base = d * c;
+    const bool quad = KW2 == 4 && c == 4 && (reinterpret_cast<uintptr_t>(bkey2) & 15) == 0;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * U; i0 < n; i0 += (int64_t)gridDim.x * 256 * U) {
+        int64_t r[U];
+        long long d[U], k2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = i0 + u < n ? (sel ? sel[i0 + u] : i0 + u) : -1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            live[u] = r[u] >= 0 && (!pv1 || bit_valid(pv1, r[u])) && (!pv2 || bit_valid(pv2, r[u]));   // a NULL key matches nothing (prepareKeys, join_table.go:152)
+            d[u] = live[u] ? sp_key<KW>(pk1, r[u]) - kmin : -1;
+            k2[u] = live[u] ? sp_key<KW2>(pk2, r[u]) : 0;
+            live[u] = live[u] && d[u] >= 0 && d[u] < nruns;
+        }
+        int32_t row[U];
+        if (quad) {
+            int4 run[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) run[u] = live[u] ? reinterpret_cast<const int4 *>(bkey2)[d[u]] : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = (int)k2[u];
+                const int f0 = run[u].x == k, f1 = run[u].y == k, f2 = run[u].z == k, f3 = run[u].w == k;
+                const int found = live[u] ? f0 + f1 + f2 + f3 : 0;
+                row[u] = found ? (int32_t)(d[u] * 4 + (f0 ? 0 : f1 ? 1 : f2 ? 2 : 3)) : -1;
+                multi += found > 1;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                row[u] = -1;
+                if (!live[u]) continue;
+                const int64_t base = d[u] * c;
                 int found = 0;
                 for (int j = 0; j < c; j++)
-                    if (sp_key<KW2>(bkey2, base + j) == k2) { if (!found) row = (int32_t)(base + j); found++; }
+                    if (sp_key<KW2>(bkey2, base + j) == k2[u]) { if (!found) row[u] = (int32_t)(base + j); found++; }
                 multi += found > 1;
             }
         }
-        misses += row < 0;
-        out[i] = row;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i0 + u < n) { out[i0 + u] = row[u]; misses += row[u] < 0; }
     }
     for (int o = 32; o > 0; o >>= 1) { misses += __shfl_xor(misses, o); multi += __shfl_xor(multi, o); }
     if ((threadIdx.x & 63) == 0 && stats) {
@@ -306,7 +335,7 @@ extern "C" int ph_join_run_lookup(ph_ctx *ctx, const ph_col *build_key2, int64_t
     int *words = nullptr;
     PH_CHECK(ctx->deferred_words(&words));
     int *stats = strict ? words + 1 : nullptr;   // [1] misses, [2] several rows for one key: the deferred words of ph_join_lookup_strict
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 16);
+    const int grid = (int)std::min<int64_t>((n + 1023) / 1024, (int64_t)ctx->cu_count * 16);
     const int64_t nruns = n_build / run_len;
 #define PH_RL(A, B) ph::run_lookup_kernel<A, B><<<grid, 256, 0, ctx->stream>>>(build_key2->data, nruns, (long long)key1_min, (int)run_len, probe_keys[0].data, probe_keys[0].validity, \
                                                                              probe_keys[1].data, probe_keys[1].validity, sel, n, out_build_dev, stats)

@@ -852,6 +852,8 @@ int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev)
 
 }  // namespace ph
 
+static int run_select(ph_ctx *ctx, ph::SelParams &P, const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
+
 extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op,
                                 const ph_const *k, const int32_t *sel_in, int64_t n_in,
                                 int32_t *sel_out, int64_t *n_out) {
@@ -865,6 +867,34 @@ extern "C" int ph_filter_select(ph_ctx *ctx, const ph_col *col, int64_t n, int32
         ph::set_error("ph_filter_select: column type %d with constant type %d is outside the device path", col->type, k->type);
         return PH_EUNSUPPORTED;
     }
+    return run_select(ctx, P, sel_in, n_in, sel_out, n_out);
+}
+
+// Two conjuncts over ONE column in one pass (l_shipdate >= a AND l_shipdate < b: execSelectAnd runs the second over the first's selection,
+// expr_exec.go:430-486 — two passes and a gather): both lower to a value range, the ranges intersect. PH_EUNSUPPORTED when either is no range
+// (a string, a float, '!='): the caller runs them one after the other.
+extern "C" int ph_filter_select_and(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op1, const ph_const *k1, int32_t op2, const ph_const *k2,
+                                    const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out) {
+    PH_REQUIRE(ctx && col && k1 && k2 && n_out && n >= 0 && n_in >= 0, "ph_filter_select_and: bad arguments");
+    PH_REQUIRE(sel_in || n_in == n, "ph_filter_select_and: without sel_in, n_in must equal n");
+    PH_REQUIRE(n_in == 0 || sel_out, "ph_filter_select_and: sel_out is NULL");
+    *n_out = 0;
+    if (n_in == 0) return PH_OK;
+    ph::SelParams P, Q;
+    if (!ph::lower_select(col, op1, k1, &P) || !ph::lower_select(col, op2, k2, &Q)) {
+        ph::set_error("ph_filter_select_and: column type %d with these constants is outside the device path", col->type);
+        return PH_EUNSUPPORTED;
+    }
+    if (P.kind == ph::SK_NEVER || Q.kind == ph::SK_NEVER) return PH_OK;   // a (type, op) pair the reference does not implement selects nothing
+    const bool range = P.kind == Q.kind && (P.kind == ph::SK_RANGE_I32 || P.kind == ph::SK_RANGE_I64 || P.kind == ph::SK_RANGE_U8);
+    if (!range) { ph::set_error("ph_filter_select_and: the two conjuncts are not value ranges of one kind"); return PH_EUNSUPPORTED; }
+    P.lo = std::max(P.lo, Q.lo);
+    P.hi = std::min(P.hi, Q.hi);
+    if (P.lo > P.hi) return PH_OK;
+    return run_select(ctx, P, sel_in, n_in, sel_out, n_out);
+}
+
+static int run_select(ph_ctx *ctx, ph::SelParams &P, const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out) {
     if (P.kind == ph::SK_NEVER) return PH_OK;
     // the 4-values-per-lane path needs 16-byte (uint8: 4-byte) aligned column data
     uintptr_t addr = (uintptr_t)P.data;

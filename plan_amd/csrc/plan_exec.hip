@@ -122,6 +122,10 @@ struct ph_plan {
     std::shared_ptr<Rel> rows_rel;      // ... of the last run (its buffers are run temporaries: fetched before they are released)
     std::vector<ph_pred> having;        // conjuncts over the root's aggregate columns, applied where the groups are (ph_plan_set_having)
     bool having_applied = false;        // ... and whether the last fetch did apply them (a sum beyond int64 hands every group back)
+    // A join whose build side is an aggregate grouped by the join key: the probe side's keys, lowered first, filter the aggregate's INPUT (groups no
+    // probe row asks for are never built). Set by lower_join around the build child's lowering, consumed by that aggregate node.
+    struct PushedKeys { std::shared_ptr<Rel> probe; int32_t pkey = -1, gcol = -1; int join = -1; };
+    std::map<int, PushedKeys> pushed;
     std::vector<int> parents;           // how many nodes reference node i as a child
     std::map<std::pair<int, bool>, std::shared_ptr<Rel>> memo;   // relations of nodes with several parents, per run
     std::vector<ph_table *> computed;   // one-column relations of computed VARCHAR values: like the aggregate they outlive the fetch (the host
@@ -368,7 +372,9 @@ int apply_pending(ph_plan *p, Rel *r) {
     const int64_t N = t->nrows;
     const int32_t *sel = nullptr;
     int64_t cnt = N;
+    std::vector<bool> done(r->pending.size(), false);
     for (size_t i = 0; i < r->pending.size() && cnt > 0; i++) {
+        if (done[i]) continue;
         ph_pred pr = r->pending[i];
         fix_dict_const(t, pr.col, &pr.k);
         ph_col v = table_view(t, pr.col);
@@ -376,7 +382,18 @@ int apply_pending(ph_plan *p, Rel *r) {
         void *out = nullptr;
         PL_CHECK(palloc(p, cnt * 4, &out));
         int64_t m = 0;
-        PL_CHECK(ph_filter_select(ctx, &v, N, pr.op, &pr.k, sel, cnt, (int32_t *)out, &m));
+        // a second conjunct over the same column (a date range) rides in the same pass when both are value ranges
+        int rc = PH_EUNSUPPORTED;
+        for (size_t j = i + 1; j < r->pending.size() && rc == PH_EUNSUPPORTED; j++) {
+            if (done[j] || r->pending[j].col != pr.col) continue;
+            ph_pred p2 = r->pending[j];
+            fix_dict_const(t, p2.col, &p2.k);
+            fix_num_const(v, &p2.k);
+            rc = ph_filter_select_and(ctx, &v, N, pr.op, &pr.k, p2.op, &p2.k, sel, cnt, (int32_t *)out, &m);
+            if (rc == PH_OK) done[j] = true;
+            else if (rc != PH_EUNSUPPORTED) return rc;
+        }
+        if (rc == PH_EUNSUPPORTED) PL_CHECK(ph_filter_select(ctx, &v, N, pr.op, &pr.k, sel, cnt, (int32_t *)out, &m));
         sel = (const int32_t *)out;
         cnt = m;
     }
@@ -1298,8 +1315,35 @@ int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out);
 int lower_join(ph_plan *p, int idx, bool as_build, Rel *out) {
     Rel P, B;
     PL_CHECK(lower(p, p->nodes[(size_t)idx].child[0], false, &P));
-    PL_CHECK(lower(p, p->nodes[(size_t)idx].child[1], true, &B));
-    return join_rels(p, idx, p->nodes[(size_t)idx], P, B, as_build, out);
+    // ---- the probe side's keys go DOWN into a build-side aggregate grouped by the join key (Q17: avg(l_quantity) by l_partkey over sixty million
+    // rows, asked for by the 2 000 parts of one brand; Q20, Q2 alike): a group no probe row matches never reaches the result of an INNER / SEMI
+    // join, so its input rows need not be aggregated — the aggregate's input is semi-joined with the probe keys first (lower_node, PH_PN_AGG).
+    // Through Filters over the groups (a HAVING), not through anything that has another parent.
+    const Node &nd = p->nodes[(size_t)idx];
+    int target = -1;
+    if ((nd.join_type == PH_JT_INNER || nd.join_type == PH_JT_SEMI) && !multi(p) && !getenv("PH_PLAN_NO_KEY_PUSHDOWN")) {
+        int c = nd.child[1];
+        while (c >= 0 && c < (int)p->nodes.size() && p->nodes[(size_t)c].kind == PH_PN_FILTER && p->parents[(size_t)c] < 2) c = p->nodes[(size_t)c].child[0];
+        if (c >= 0 && c < (int)p->nodes.size() && p->nodes[(size_t)c].kind == PH_PN_AGG && p->parents[(size_t)c] < 2) {
+            const Node &ag = p->nodes[(size_t)c];
+            for (size_t k = 0; k < nd.bkeys.size() && target < 0; k++) {
+                const int32_t b = nd.bkeys[k];
+                if (b < 0 || b >= (int32_t)ag.groups.size() || ag.groups[(size_t)b].e.kind != PH_PE_COL) continue;
+                if (nd.pkeys[k] < 0 || (size_t)nd.pkeys[k] >= P.cols.size() || P.cols[(size_t)nd.pkeys[k]].type == PH_STR) continue;
+                ph_plan::PushedKeys pk;
+                pk.probe = std::make_shared<Rel>(P);
+                pk.pkey = nd.pkeys[k];
+                pk.gcol = ag.groups[(size_t)b].e.col;
+                pk.join = idx;
+                p->pushed[c] = pk;
+                target = c;
+            }
+        }
+    }
+    const int rc = lower(p, nd.child[1], true, &B);
+    if (target >= 0) p->pushed.erase(target);
+    PL_CHECK(rc);
+    return join_rels(p, idx, nd, P, B, as_build, out);
 }
 
 int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_build, Rel *out);
@@ -2172,6 +2216,27 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
         // become a device-resident relation — key columns and aggregate values as positional columns — and never visit the host
         Rel R;
         PL_CHECK(lower(p, nd.child[0], false, &R));
+        {   // the keys of the join above (lower_join): only input rows some probe row can meet are aggregated
+            auto it = p->pushed.find(idx);
+            if (it != p->pushed.end() && it->second.gcol >= 0 && (size_t)it->second.gcol < R.cols.size()) {
+                Rel K = *it->second.probe;
+                if (R.n >= (1 << 20) && K.n * 4 <= R.n && width_of(R.cols[(size_t)it->second.gcol].type) == width_of(K.cols[(size_t)it->second.pkey].type) &&
+                    width_of(R.cols[(size_t)it->second.gcol].type) != 0) {
+                    Node sj;
+                    sj.kind = PH_PN_JOIN;
+                    sj.join_type = PH_JT_SEMI;
+                    sj.pkeys = {it->second.gcol};
+                    sj.bkeys = {it->second.pkey};
+                    for (size_t c = 0; c < R.cols.size(); c++) sj.out.push_back((int32_t)c);
+                    const int64_t before = R.n;
+                    Rel R2;
+                    PL_CHECK(join_rels_local(p, idx, sj, R, K, false, &R2));
+                    PL_CHECK(apply_pending(p, &R2));
+                    note(p, "agg#%d: input reduced to the rows the keys of join#%d ask for: %lld of at most %lld", idx, it->second.join, (long long)R2.n, (long long)before);
+                    R = R2;
+                }
+            }
+        }
         if (multi(p) && !R.replicated) PL_CHECK(whole_groups(p, idx, &R));   // every group's rows on one rank before they are aggregated
         const bool agg_replicated = R.replicated;
         ph_agg *agg = nullptr;

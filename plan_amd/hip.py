@@ -442,6 +442,21 @@ def filter_select(ctx, col, n, op, k, sel_in=None, n_in=None, defer=False):
     return (out, cnt) if defer else (out, cnt.value)
 
 
+def filter_select_and(ctx, col, n, op1, k1, op2, k2, sel_in=None, n_in=None):
+    """ph_filter_select_and: two conjuncts over one column in one pass; (sel_out_dev, count). PH_EUNSUPPORTED when they are not two value ranges."""
+    if n_in is None:
+        n_in = n
+    out = ctx.alloc(max(n_in, 1) * 4)
+    cnt = i64()
+    c = col.col() if isinstance(col, DevColumn) else col
+    try:
+        check(lib().ph_filter_select_and(ctx.h, ctypes.byref(c), i64(n), i32(op1), ctypes.byref(k1), i32(op2), ctypes.byref(k2), sel_in, i64(n_in), out, ctypes.byref(cnt)))
+    except PlanHipError:
+        ctx.free(out)
+        raise
+    return out, cnt.value
+
+
 def sel_union(ctx, sels, counts, n_rows):
     """OR of predicates: ascending union of the children's selections (device pointers).
     Returns (sel_out_dev, count)."""

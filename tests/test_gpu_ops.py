@@ -115,6 +115,34 @@ def test_filter_and_chain_and_strings(ctx, sf001):
         d.free()
 
 
+def test_two_conjuncts_over_one_column_in_one_pass(ctx):
+    """ph_filter_select_and = ph_filter_select twice (execSelectAnd): date and integer ranges, '=' inside a range, an empty intersection,
+    a (type, op) pair the reference lacks (DATE '=') selecting nothing, over all rows and over a selection; '!=' is refused."""
+    rng = np.random.default_rng(8)
+    n = 300_001
+    d = rng.integers(8000, 10500, n).astype(np.int32)
+    cases = [(hip.PH_DATE, hip.PH_GE, 9000, hip.PH_LT, 9365), (hip.PH_DATE, hip.PH_LT, 9365, hip.PH_GT, 8999), (hip.PH_I32, hip.PH_GE, 9000, hip.PH_EQ, 9100),
+             (hip.PH_I32, hip.PH_GT, 9500, hip.PH_LT, 9400), (hip.PH_DATE, hip.PH_EQ, 9100, hip.PH_LT, 9365), (hip.PH_I32, hip.PH_LE, 9000, hip.PH_LE, 8500)]
+    sel_in = np.sort(rng.choice(n, 100_000, replace=False)).astype(np.int32)
+    ds = ctx.upload(sel_in)
+    for typ, o1, a, o2, b in cases:
+        col = hip.DevColumn(ctx, typ, d)
+        k1, k2 = hip.const(typ, i=a), hip.const(typ, i=b)
+        for s_in, m_in in ((None, n), (ds, len(sel_in))):
+            s1, c1 = hip.filter_select(ctx, col, n, o1, k1, s_in, m_in)
+            s2, c2 = hip.filter_select(ctx, col, n, o2, k2, s1, c1)
+            sa, ca = hip.filter_select_and(ctx, col, n, o1, k1, o2, k2, s_in, m_in)
+            assert ca == c2 and np.array_equal(dl(ctx, sa, np.int32, ca), dl(ctx, s2, np.int32, c2)), (typ, o1, a, o2, b)
+            for q in (s1, s2, sa):
+                ctx.free(q)
+        col.free()
+    col = hip.DevColumn(ctx, hip.PH_I32, d)
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.filter_select_and(ctx, col, n, hip.PH_NE, hip.const(hip.PH_I32, i=9000), hip.PH_LT, hip.const(hip.PH_I32, i=9365))
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    col.free(); ctx.free(ds)
+
+
 def test_filter_like_contains_edge_cases(ctx):
     """%literal% takes the position-parallel substring path: literals that span two rows must not
     match, matches at the first/last byte of a row must, empty and shorter-than-literal rows never
