@@ -616,6 +616,14 @@ int ph_join_sorted_pairs(ph_ctx *ctx, const ph_col *build_key, int64_t n_build, 
 int ph_join_run_lookup(ph_ctx *ctx, const ph_col *build_key2, int64_t n_build, int64_t key1_min, int32_t run_len, const ph_col *probe_keys,
                        const int32_t *sel, int64_t n, int32_t strict, int32_t *out_build_dev);
 
+/* Children per parent: what Agg(parent key; count(child column)) <- LEFT JOIN(parent, child ON parent key = child key) computes when the parent
+ * key is unique (Q13: orders per customer) without the pair list (NextLeftJoin, join_scan.go) and the second fold (AddChunk, aggregate_hash.go):
+ * the child rows child_sel[0..n_child) / 0..n_child are counted by key into an array over [key_min, key_min + key_range), parent row i receives
+ * out_counts_dev[i] = the count of its key and bit i of out_valid_dev = count > 0 (a group without a non-NULL input finalises as NULL: CountOp,
+ * aggr_ops.go). out_valid_dev: (n_parent + 63) / 64 * 8 bytes. Child rows with a NULL key or a key outside the range match nothing. */
+int ph_count_by_key(ph_ctx *ctx, const ph_col *child_key, const int32_t *child_sel, int64_t n_child, int64_t key_min, int64_t key_range,
+                    const ph_col *parent_key, const int32_t *parent_sel, int64_t n_parent, int64_t *out_counts_dev, uint8_t *out_valid_dev);
+
 /* Cross product (CrossProduct / CrossProductExec, pkg/compute/join_cross.go:34-230) as row-id pairs:
  * for every right row, all left rows in order — the order the reference emits (one output chunk
  * per (left chunk, right row)) — so that both sides materialise with ph_gather like a join's

@@ -345,3 +345,68 @@ extern "C" int ph_join_run_lookup(ph_ctx *ctx, const ph_col *build_key2, int64_t
     if (strict) ctx->deferred_pending = true;
     return PH_OK;
 }
+
+// ------------------------------------------------------------------ children per parent: count(col) over a LEFT join grouped by the parent's key
+// Agg(parent key; count(child column)) <- LEFT JOIN(parent, child ON parent key = child key) with a unique parent key (Q13: orders per customer)
+// is, per parent row, the number of child rows with its key — NULL where there is none (CountOp finalises a group without non-NULL inputs as NULL,
+// aggr_ops.go). The reference emits the pairs (join_scan.go NextLeftJoin) and folds them again (GroupedAggrHashTable.AddChunk); here the child
+// keys are counted into an array over their value range (one atomic add per child row, the array in L2) and every parent row reads its count.
+namespace ph {
+template <int KW>
+__global__ __launch_bounds__(256) void count_by_key_kernel(const void *__restrict__ key, const uint8_t *__restrict__ valid, const int32_t *__restrict__ sel, int64_t n,
+                                                           long long kmin, unsigned long long range, int32_t *__restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = sel ? sel[i] : i;
+        if (valid && !bit_valid(valid, r)) continue;   // a NULL key matches nothing
+        const unsigned long long d = (unsigned long long)(sp_key<KW>(key, r) - kmin);
+        if (d < range) atomicAdd(&counts[d], 1);
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void counts_lookup_kernel(const int32_t *__restrict__ counts, long long kmin, unsigned long long range, const void *__restrict__ key,
+                                                            const uint8_t *__restrict__ valid, const int32_t *__restrict__ sel, int64_t n, int64_t *__restrict__ out,
+                                                            uint8_t *__restrict__ out_valid) {
+    // one thread per output row, a wave's 64 validity bits stored as one 8-byte word (n is padded to whole waves by the grid)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    long long c = 0;
+    if (i < n) {
+        const int64_t r = sel ? sel[i] : i;
+        if (!valid || bit_valid(valid, r)) {
+            const unsigned long long d = (unsigned long long)(sp_key<KW>(key, r) - kmin);
+            if (d < range) c = counts[d];
+        }
+        out[i] = c;
+    }
+    const unsigned long long m = __ballot(c > 0);
+    if ((threadIdx.x & 63) == 0 && (i & ~63ll) < n) reinterpret_cast<unsigned long long *>(out_valid)[i >> 6] = m;
+}
+}  // namespace ph
+
+extern "C" int ph_count_by_key(ph_ctx *ctx, const ph_col *child_key, const int32_t *child_sel, int64_t n_child, int64_t key_min, int64_t key_range,
+                               const ph_col *parent_key, const int32_t *parent_sel, int64_t n_parent, int64_t *out_counts_dev, uint8_t *out_valid_dev) {
+    PH_REQUIRE(ctx && child_key && parent_key && n_child >= 0 && n_parent >= 0 && key_range >= 1 && key_range <= (1ll << 28) && (n_parent == 0 || (out_counts_dev && out_valid_dev)),
+               "ph_count_by_key: bad arguments (the key range is limited to 2^28 values)");
+    auto width = [](int t) { return (t == PH_I32 || t == PH_DATE) ? 4 : (t == PH_I64 || t == PH_DEC64) ? 8 : 0; };
+    const int kw = width(child_key->type);
+    if (kw == 0 || width(parent_key->type) != kw) { ph::set_error("ph_count_by_key: 4- or 8-byte integer keys of one width"); return PH_EUNSUPPORTED; }
+    if (n_parent == 0) return PH_OK;
+    int32_t *counts = nullptr;
+    PH_CHECK(ctx->pool_alloc(key_range * 4, (void **)&counts));
+    int rc = hipMemsetAsync(counts, 0, (size_t)key_range * 4, ctx->stream) == hipSuccess ? PH_OK : PH_EHIP;
+    if (rc == PH_OK && n_child > 0) {
+        const int grid = (int)std::min<int64_t>((n_child + 255) / 256, (int64_t)ctx->cu_count * 16);
+        if (kw == 4) ph::count_by_key_kernel<4><<<grid, 256, 0, ctx->stream>>>(child_key->data, child_key->validity, child_sel, n_child, (long long)key_min, (unsigned long long)key_range, counts);
+        else ph::count_by_key_kernel<8><<<grid, 256, 0, ctx->stream>>>(child_key->data, child_key->validity, child_sel, n_child, (long long)key_min, (unsigned long long)key_range, counts);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    if (rc == PH_OK) {
+        const int grid = (int)((n_parent + 255) / 256);
+        if (kw == 4) ph::counts_lookup_kernel<4><<<grid, 256, 0, ctx->stream>>>(counts, (long long)key_min, (unsigned long long)key_range, parent_key->data, parent_key->validity, parent_sel, n_parent, out_counts_dev, out_valid_dev);
+        else ph::counts_lookup_kernel<8><<<grid, 256, 0, ctx->stream>>>(counts, (long long)key_min, (unsigned long long)key_range, parent_key->data, parent_key->validity, parent_sel, n_parent, out_counts_dev, out_valid_dev);
+        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+    }
+    ctx->pool_release(counts);
+    if (rc != PH_OK) ph::set_error("ph_count_by_key: launch failed");
+    return rc;
+}

@@ -875,9 +875,10 @@ int key_side(ph_plan *p, Rel *r, const std::vector<int32_t> &keys, KeySide *ks) 
 
 // pairs (probe position / row id, build row id) of an inner probe; retried once with the exact size when a
 // non-unique build side produced more pairs than probe rows
+// cap_hint: the pairs expected when the build key has duplicates (its rows: a foreign key's side) — a pair list that does not fit costs the whole probe again
 int pair_probe(ph_plan *p, ph_join *j, const KeySide &pk, const ph_pred *where, const ph_table *where_t, const uint8_t *residual,
-               int64_t *m_out, int32_t **prow, int32_t **brow, const char **form) {
-    int64_t cap = std::max<int64_t>(pk.n, 1), m = 0;
+               int64_t *m_out, int32_t **prow, int32_t **brow, const char **form, int64_t cap_hint = 0) {
+    int64_t cap = std::max<int64_t>(std::max<int64_t>(pk.n, 1), std::min<int64_t>(cap_hint, 64ll << 20)), m = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         void *op = nullptr, *ob = nullptr;
         PL_CHECK(palloc(p, cap * 4, &op));
@@ -1908,7 +1909,7 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
             PL_CHECK(apply_pending(p, &P));
             pk = KeySide{};
             PL_CHECK(key_side(p, &P, nd.pkeys, &pk));
-            PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form));
+            PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form, unique ? 0 : B.n));
         }
         *out = P;
         if (pk.rowids) {   // prow = row ids of the one lane, ascending: the lane IS the pair list's probe side
@@ -1996,7 +1997,7 @@ int left_join_rels(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, Rel *out) 
     int64_t m = 0;
     int32_t *prow = nullptr, *brow = nullptr;
     const char *form = "";
-    PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form));
+    PL_CHECK(pair_probe(p, j, pk, nullptr, nullptr, nullptr, &m, &prow, &brow, &form, B.n));
     // the probe rows without a match
     void *f = nullptr, *un = nullptr;
     PL_CHECK(palloc(p, std::max<int64_t>(pk.n, 1) + 64, &f));
@@ -2214,8 +2215,71 @@ int lower_node(ph_plan *p, int idx, bool as_build, Rel *out) {
     case PH_PN_AGG: {
         // an aggregate BELOW other operators (a subquery's GROUP BY [.. HAVING = the Filter above it] under a join): its groups
         // become a device-resident relation — key columns and aggregate values as positional columns — and never visit the host
+        // ---- children per parent: Agg(parent key; count(child column)...) <- LEFT JOIN(parent, child) on that key, the parent key unique (Q13's
+        // orders per customer): the child keys are counted into an array over their value range and every parent row reads its count
+        // (ph_count_by_key) — no pair list, no second fold. NULL where there is no child (CountOp over the NULL-extended row).
         Rel R;
-        PL_CHECK(lower(p, nd.child[0], false, &R));
+        bool have_R = false;
+        if (!multi(p) && nd.groups.size() == 1 && nd.groups[0].e.kind == PH_PE_COL && !nd.aggs.empty() && nd.child[0] >= 0 && p->parents[(size_t)nd.child[0]] < 2 &&
+            p->nodes[(size_t)nd.child[0]].kind == PH_PN_JOIN && p->nodes[(size_t)nd.child[0]].join_type == PH_JT_LEFT && p->nodes[(size_t)nd.child[0]].pkeys.size() == 1 &&
+            !getenv("PH_PLAN_NO_COUNT_PUSHDOWN")) {
+            const Node &jn = p->nodes[(size_t)nd.child[0]];
+            bool shape = true;
+            for (auto &a : nd.aggs) shape = shape && a.kind == PH_A_COUNT && a.arg.e.kind == PH_PE_COL && a.arg.e.col >= 0 && (size_t)a.arg.e.col < jn.out.size();
+            shape = shape && nd.groups[0].e.col >= 0 && (size_t)nd.groups[0].e.col < jn.out.size() && jn.out[(size_t)nd.groups[0].e.col] == jn.pkeys[0];
+            if (shape) {
+                Rel P, B;
+                PL_CHECK(lower(p, jn.child[0], false, &P));
+                PL_CHECK(lower(p, jn.child[1], true, &B));
+                const size_t nP = P.cols.size();
+                bool ok = jn.pkeys[0] >= 0 && (size_t)jn.pkeys[0] < nP && jn.bkeys[0] >= 0 && (size_t)jn.bkeys[0] < B.cols.size() && key_unique(P, {jn.pkeys[0]}) > 0 &&
+                          B.lanes.size() == 1 && !B.lanes[0].nullable;
+                if (ok) {
+                    const PCol &bk = B.cols[(size_t)jn.bkeys[0]];
+                    ok = bk.lane == 0 && bk.tcol >= 0 && B.lanes[0].t->cols[(size_t)bk.tcol].has_range && width_of(bk.type) != 0 &&
+                         width_of(bk.type) == width_of(P.cols[(size_t)jn.pkeys[0]].type);
+                    for (auto &a : nd.aggs) {   // count(child column): a column of the build side that cannot be NULL itself
+                        const int32_t oc = jn.out[(size_t)a.arg.e.col];
+                        ok = ok && oc >= (int32_t)nP && (size_t)oc - nP < B.cols.size();
+                        if (ok) { const PCol &c = B.cols[(size_t)oc - nP]; ok = c.lane == 0 && c.tcol >= 0 && !B.lanes[0].t->cols[(size_t)c.tcol].validity; }
+                    }
+                    if (ok) {
+                        const auto &kc = B.lanes[0].t->cols[(size_t)bk.tcol];
+                        const __int128 range = (__int128)kc.max - (__int128)kc.min + 1;
+                        ok = range >= 1 && range <= (1ll << 28);
+                        if (ok) {
+                            PL_CHECK(apply_pending(p, &P));
+                            PL_CHECK(apply_pending(p, &B));
+                            KeySide pk, ck;
+                            PL_CHECK(key_side(p, &P, {jn.pkeys[0]}, &pk));
+                            PL_CHECK(key_side(p, &B, {jn.bkeys[0]}, &ck));
+                            void *cnt = nullptr, *val = nullptr;
+                            PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 8, &cnt));
+                            PL_CHECK(palloc(p, (P.n + 63) / 64 * 8 + 64, &val));
+                            PL_CHECK(ph_count_by_key(p->ctx, &ck.views[0], ck.sel, ck.n, kc.min, (int64_t)range, &pk.views[0], pk.sel, pk.n, (int64_t *)cnt, (uint8_t *)val));
+                            *out = P;
+                            out->cols.clear();
+                            out->cols.push_back(P.cols[(size_t)jn.pkeys[0]]);
+                            for (size_t a = 0; a < nd.aggs.size(); a++) {
+                                PCol c;
+                                c.type = PH_DEC64; c.scale = 0; c.data = cnt; c.validity = (const uint8_t *)val;
+                                out->cols.push_back(c);
+                            }
+                            out->covers = false;
+                            out->pending.clear(); out->complex.clear(); out->flags = nullptr;
+                            drop_unused_lanes(out);
+                            note(p, "agg#%d over join#%d: children per parent — %lld child keys counted over a range of %lld, %lld parent rows read their count (no pairs, no second fold)", idx,
+                                 nd.child[0], (long long)ck.n, (long long)range, (long long)P.n);
+                            return PH_OK;
+                        }
+                    }
+                }
+                // not the shape after all: the join over the children lowered here (they ran once)
+                PL_CHECK(join_rels(p, nd.child[0], jn, P, B, false, &R));
+                have_R = true;
+            }
+        }
+        if (!have_R) PL_CHECK(lower(p, nd.child[0], false, &R));
         {   // the keys of the join above (lower_join): only input rows some probe row can meet are aggregated
             auto it = p->pushed.find(idx);
             if (it != p->pushed.end() && it->second.gcol >= 0 && (size_t)it->second.gcol < R.cols.size()) {

@@ -788,6 +788,15 @@ def join_run_lookup(ctx, build_key2, n_build, key1_min, run_len, probe_keys, sel
     return out
 
 
+def count_by_key(ctx, child_key, child_sel, n_child, key_min, key_range, parent_key, parent_sel, n_parent):
+    """ph_count_by_key: child rows counted by key, every parent row reads its count; (device int64[n_parent], device validity bits: count > 0)"""
+    out, val = ctx.alloc(max(n_parent, 1) * 8), ctx.alloc((n_parent + 63) // 64 * 8 + 64)
+    c = child_key.col() if isinstance(child_key, DevColumn) else child_key
+    p = parent_key.col() if isinstance(parent_key, DevColumn) else parent_key
+    check(lib().ph_count_by_key(ctx.h, ctypes.byref(c), child_sel, i64(n_child), i64(key_min), i64(key_range), ctypes.byref(p), parent_sel, i64(n_parent), out, val))
+    return out, val
+
+
 def gather(ctx, col, idx_dev, n):
     c = col.col() if isinstance(col, DevColumn) else col
     w = {PH_CODE8: 1, PH_I32: 4, PH_DATE: 4, PH_F32: 4}.get(c.type, 8)

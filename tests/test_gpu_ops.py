@@ -1137,6 +1137,38 @@ def test_sorted_pairs_and_run_lookup_equal_table_joins(ctx):
     t.free(); t2.free(); d1.free(); d2.free()
 
 
+def test_count_by_key_is_left_join_plus_count(ctx):
+    """ph_count_by_key against numpy: children per parent with child / parent selections, NULL child keys, keys outside the range, parents
+    without children (count 0, validity bit clear: the NULL of count() over the NULL-extended row), int32 and int64 keys"""
+    rng = np.random.default_rng(77)
+    for dt, typ in ((np.int32, hip.PH_I32), (np.int64, hip.PH_I64)):
+        nparent, nchild = 100_003, 1_000_000
+        pkeys = (np.arange(nparent) + 5).astype(dt)
+        ckeys = rng.integers(0, nparent + 20, nchild).astype(dt)          # some below 5 / above the parents' keys
+        ckeys[rng.integers(0, nchild, 50_000)] = 17                        # a hot key
+        cvalid = rng.random(nchild) > 0.01
+        dc = hip.DevColumn(ctx, typ, ckeys, validity=np.packbits(cvalid, bitorder="little"))
+        dp = hip.DevColumn(ctx, typ, pkeys)
+        csel = np.sort(rng.choice(nchild, 700_000, replace=False)).astype(np.int32)
+        psel = np.sort(rng.choice(nparent, 60_000, replace=False)).astype(np.int32)
+        for cs, ps in ((None, None), (csel, psel)):
+            crow = np.arange(nchild) if cs is None else cs
+            prow = np.arange(nparent) if ps is None else ps
+            live = ckeys[crow][cvalid[crow]]
+            hist = np.bincount(live[(live >= 5) & (live < 5 + nparent)].astype(np.int64) - 5, minlength=nparent)
+            want = hist[pkeys[prow].astype(np.int64) - 5]
+            dcs = ctx.upload(cs) if cs is not None else None
+            dps = ctx.upload(ps) if ps is not None else None
+            out, val = hip.count_by_key(ctx, dc, dcs, len(crow), 5, nparent, dp, dps, len(prow))
+            got = ctx.download(out, np.int64, len(prow))
+            bits = np.unpackbits(ctx.download(val, np.uint8, (len(prow) + 7) // 8), bitorder="little")[:len(prow)].astype(bool)
+            assert np.array_equal(got, want) and np.array_equal(bits, want > 0) and (want == 0).any()
+            for q in (out, val, dcs, dps):
+                if q is not None:
+                    ctx.free(q)
+        dc.free(); dp.free()
+
+
 def test_merge_lookup_equals_table_lookup(ctx):
     """ph_merge_lookup (both sides ordered by the key, no table) answers like ph_join_build + ph_join_lookup:
     dense clustered probes (blocks stream their slice of the build keys through LDS), very sparse probes (blocks
