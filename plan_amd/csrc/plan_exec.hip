@@ -2373,7 +2373,27 @@ int sink_into_agg(ph_plan *p, int idx, Rel &R, bool allow_pack, ph_agg **aggp, s
         PL_CHECK(eval_expr(p, &R, nd.groups[g], &kc[g]));
         if (kc[g].type == PH_STR) {   // a VARCHAR key: group by the string's code (its representative row in the column)
             if (nd.groups[g].e.kind != PH_PE_COL) { set_error("ph_plan: VARCHAR group key must be a column"); return PH_EUNSUPPORTED; }
-            PL_CHECK(string_codes(p, &R, nd.groups[g].e.col, nullptr, nullptr, &kc[g]));
+            // ... unless the table's unique key is a group key too (Q10 groups by c_custkey AND c_name, c_phone, c_address, c_comment): rows of one
+            // group are then ONE table row, and that row's id is as good a code as the first row holding the same string — no interning pass
+            // over the strings (four of them: 600 us of Q10 at SF10)
+            const PCol &sc = R.cols[(size_t)nd.groups[g].e.col];
+            bool by_row = false;
+            if (sc.lane >= 0 && sc.tcol >= 0 && !R.lanes[(size_t)sc.lane].nullable && R.lanes[(size_t)sc.lane].rows != nullptr && !getenv("PH_PLAN_NO_ROW_CODES")) {
+                const ph_table *t = R.lanes[(size_t)sc.lane].t;
+                for (size_t g2 = 0; g2 < nd.groups.size() && !by_row; g2++) {
+                    if (g2 == g || nd.groups[g2].e.kind != PH_PE_COL || nd.groups[g2].e.col < 0 || (size_t)nd.groups[g2].e.col >= R.cols.size()) continue;
+                    const PCol &c2 = R.cols[(size_t)nd.groups[g2].e.col];
+                    if (c2.lane != sc.lane || c2.tcol < 0 || t->cols[(size_t)c2.tcol].validity) continue;
+                    by_row = t->cols[(size_t)c2.tcol].strict;
+                    for (auto &u : t->unique_keys) by_row = by_row || (u.size() == 1 && u[0] == c2.tcol);
+                }
+                if (by_row) {
+                    kc[g] = PCol{};
+                    kc[g].type = PH_I32; kc[g].data = R.lanes[(size_t)sc.lane].rows;
+                    kc[g].src = t; kc[g].src_col = sc.tcol;
+                }
+            }
+            if (!by_row) PL_CHECK(string_codes(p, &R, nd.groups[g].e.col, nullptr, nullptr, &kc[g]));
             str_key[g] = true;
         } else if (kc[g].sdict) str_key[g] = true;   // a computed VARCHAR (already codes): reported as PH_STR, its strings are rows of kc[g].src
     }
