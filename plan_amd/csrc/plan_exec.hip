@@ -231,6 +231,7 @@ void fix_dict_const(const ph_table *t, int tcol, ph_const *k) {
 
 int positional(ph_plan *p, Rel *r, const std::vector<int> &want);
 int const_code(ph_plan *p, ph_strdict *d, const char *s, int32_t *code);
+int const_codes(ph_plan *p, ph_strdict *d, const std::vector<const char *> &strs, std::vector<int32_t> *codes);
 
 // the reference's LIKE (likeOp: % = any run, _ = any one byte), for patterns applied to a DICTIONARY on the host
 bool host_like(const char *s, size_t sl, const char *pat, size_t pl) {
@@ -341,6 +342,47 @@ int eval_bool(ph_plan *p, Rel *r, bool table_mode, const BoolTree &bt, int idx, 
         return PH_OK;
     }
     case PH_B_OR: {
+        // an IN list — every child `col = constant` over ONE integer / dictionary-code / computed-VARCHAR column: one pass (ph_filter_select_in), the
+        // string constants' codes looked up together
+        if (b.nchildren >= 2 && b.nchildren <= 16 && !getenv("PH_PLAN_NO_IN_LIST")) {
+            bool in_list = true;
+            const ph_bool &c0 = bt.nodes[(size_t)b.first_child];
+            for (int c = 0; c < b.nchildren && in_list; c++) {
+                const ph_bool &ch = bt.nodes[(size_t)(b.first_child + c)];
+                in_list = ch.kind == PH_B_CMP && ch.op == PH_EQ && ch.col == c0.col && ch.k.type != PH_COLREF;
+            }
+            if (in_list) {
+                ph_col v{};
+                const ph_table *dt = nullptr;
+                int dc = -1;
+                PL_CHECK(view_of(c0.col, &v, &dt, &dc));
+                const bool computed = !table_mode && r->cols[(size_t)c0.col].sdict != nullptr;
+                std::vector<int64_t> vals;
+                bool ok = v.type == PH_I32 || v.type == PH_CODE8;
+                if (ok && computed) {
+                    std::vector<const char *> strs;
+                    for (int c = 0; c < b.nchildren && ok; c++) { const ph_const &k = bt.nodes[(size_t)(b.first_child + c)].k; ok = k.type == PH_STR && k.s; strs.push_back(k.s); }
+                    std::vector<int32_t> codes;
+                    if (ok) { PL_CHECK(const_codes(p, r->cols[(size_t)c0.col].sdict, strs, &codes)); for (int32_t cd : codes) if (cd >= 0) vals.push_back(cd); }
+                } else if (ok) {
+                    for (int c = 0; c < b.nchildren && ok; c++) {
+                        ph_const k = bt.nodes[(size_t)(b.first_child + c)].k;
+                        fix_dict_const(dt, dc, &k);
+                        fix_num_const(v, &k);
+                        ok = k.type == PH_I32;   // an INTEGER constant, or the code of a dictionary string (a string not in the dictionary: a code no row holds)
+                        vals.push_back(k.i);
+                    }
+                }
+                if (ok) {
+                    void *out = nullptr;
+                    PL_CHECK(palloc(p, n_in * 4, &out));
+                    int64_t m = 0;
+                    const int rc = vals.empty() ? PH_OK : ph_filter_select_in(ctx, &v, N, vals.data(), (int32_t)vals.size(), sel_in, n_in, (int32_t *)out, &m);
+                    if (rc == PH_OK) { *sel_out = (const int32_t *)out; *n_out = m; return PH_OK; }
+                    if (rc != PH_EUNSUPPORTED) return rc;
+                }
+            }
+        }
         std::vector<const int32_t *> sels;
         std::vector<int64_t> counts;
         for (int c = 0; c < b.nchildren; c++) {
@@ -780,6 +822,25 @@ int const_code(ph_plan *p, ph_strdict *d, const char *s, int32_t *code) {
     c.type = PH_STR; c.data = off; c.aux = bytes; c.aux_bytes = len;
     PL_CHECK(ph_strdict_lookup(d, &c, nullptr, 1, (int32_t *)out));
     return p->ctx->download(code, out, 4);
+}
+
+// the codes of several constants in one lookup (an IN list over a computed VARCHAR column): -2 = not in the dictionary
+int const_codes(ph_plan *p, ph_strdict *d, const std::vector<const char *> &strs, std::vector<int32_t> *codes) {
+    const int64_t k = (int64_t)strs.size();
+    std::vector<int32_t> offs((size_t)k + 1, 0);
+    std::string bytes;
+    for (int64_t i = 0; i < k; i++) { bytes += strs[(size_t)i] ? strs[(size_t)i] : ""; offs[(size_t)i + 1] = (int32_t)bytes.size(); }
+    void *off = nullptr, *by = nullptr, *out = nullptr;
+    PL_CHECK(palloc(p, (k + 1) * 4 + 8, &off));
+    PL_CHECK(palloc(p, (int64_t)bytes.size() + 64, &by));
+    PL_CHECK(palloc(p, k * 4 + 8, &out));
+    PL_CHECK(ph_dev_upload(p->ctx, off, offs.data(), (k + 1) * 4));
+    if (!bytes.empty()) PL_CHECK(ph_dev_upload(p->ctx, by, bytes.data(), (int64_t)bytes.size()));
+    ph_col c{};
+    c.type = PH_STR; c.data = off; c.aux = by; c.aux_bytes = (int64_t)bytes.size();
+    PL_CHECK(ph_strdict_lookup(d, &c, nullptr, k, (int32_t *)out));
+    codes->assign((size_t)k, -2);
+    return p->ctx->download(codes->data(), out, k * 4);
 }
 
 // ---- VARCHAR keys: a PH_STR column of the relation becomes a positional int32 column of string codes (ph_strdict_*):

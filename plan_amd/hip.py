@@ -457,6 +457,22 @@ def filter_select_and(ctx, col, n, op1, k1, op2, k2, sel_in=None, n_in=None):
     return out, cnt.value
 
 
+def filter_select_in(ctx, col, n, values, sel_in=None, n_in=None):
+    """ph_filter_select_in: col IN (values) in one pass over an INTEGER or dictionary-code column; (sel_out_dev, count)"""
+    if n_in is None:
+        n_in = n
+    out = ctx.alloc(max(n_in, 1) * 4)
+    cnt = i64()
+    c = col.col() if isinstance(col, DevColumn) else col
+    vals = (ctypes.c_int64 * max(len(values), 1))(*values)
+    try:
+        check(lib().ph_filter_select_in(ctx.h, ctypes.byref(c), i64(n), vals, i32(len(values)), sel_in, i64(n_in), out, ctypes.byref(cnt)))
+    except PlanHipError:
+        ctx.free(out)
+        raise
+    return out, cnt.value
+
+
 def sel_union(ctx, sels, counts, n_rows):
     """OR of predicates: ascending union of the children's selections (device pointers).
     Returns (sel_out_dev, count)."""

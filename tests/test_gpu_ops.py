@@ -143,6 +143,34 @@ def test_two_conjuncts_over_one_column_in_one_pass(ctx):
     col.free(); ctx.free(ds)
 
 
+def test_in_list_in_one_pass(ctx):
+    """ph_filter_select_in = the union of the equalities (execSelectOr over InExpr's children): INTEGER values incl. negatives, repeated and
+    absent ones, dictionary codes incl. a code no row can hold, NULL rows, a selection; DATE columns are refused (the reference has no DATE '=')"""
+    rng = np.random.default_rng(12)
+    n = 250_003
+    v = rng.integers(-50, 50, n).astype(np.int32)
+    codes = rng.integers(0, 40, n).astype(np.uint8)
+    valid = rng.random(n) > 0.02
+    vb = np.packbits(valid, bitorder="little")
+    sel_in = np.sort(rng.choice(n, 90_000, replace=False)).astype(np.int32)
+    ds = ctx.upload(sel_in)
+    for typ, data, lists in ((hip.PH_I32, v, [[14, 7, 21, 24, 35, 33, 2, 20], [-50, 49, 49, 1000], [3], [2**40]]),
+                             (hip.PH_CODE8, codes, [[1, 5, 39], [999, 7], [300]])):
+        col = hip.DevColumn(ctx, typ, data, validity=vb)
+        for vals in lists:
+            for s_in, rows in ((None, np.arange(n)), (ds, sel_in)):
+                want = rows[np.isin(data[rows].astype(np.int64), vals) & valid[rows]]
+                s, c = hip.filter_select_in(ctx, col, n, vals, s_in, len(rows))
+                assert c == len(want) and np.array_equal(dl(ctx, s, np.int32, c), want.astype(np.int32)), (typ, vals)
+                ctx.free(s)
+        col.free()
+    col = hip.DevColumn(ctx, hip.PH_DATE, v)
+    with pytest.raises(hip.PlanHipError) as e:
+        hip.filter_select_in(ctx, col, n, [1, 2])
+    assert e.value.code == hip.PH_EUNSUPPORTED
+    col.free(); ctx.free(ds)
+
+
 def test_filter_like_contains_edge_cases(ctx):
     """%literal% takes the position-parallel substring path: literals that span two rows must not
     match, matches at the first/last byte of a row must, empty and shorter-than-literal rows never
