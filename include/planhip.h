@@ -859,6 +859,11 @@ int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nnodes, ph_pl
  * ph_plan_set_having: HAVING runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263) — the k best groups
  * could fail it while later ones pass — so a plan carries one or the other, and with a HAVING the caller sorts the survivors. */
 int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descending, int64_t k);
+/* The same announcement for a JOIN-rooted plan (ph_plan_fetch_rows) under `ORDER BY <column col of the rows> [DESC] ... LIMIT k` (orderExecutor +
+ * limit above the join, executor_order.go:56-138, executor_limit.go:105-238): only the rows whose key is at least as good as the k-th best come
+ * back (>= k with ties; all rows when the key can be NULL, is a VARCHAR / BIGINT, or a DECIMAL in ascending order or of a scale above 2 — the
+ * orderings the reference's selection and sort encoder do not share). The caller applies the full ORDER BY and the LIMIT to those rows. */
+int ph_plan_set_rows_topk(ph_plan *p, int32_t col, int32_t descending, int64_t k);
 /* HAVING conjuncts `result column OP constant` over the root's AGGREGATE columns (ph_pred.col counts the result's columns: group keys first,
  * then the aggregates), applied on the device when the groups are fetched (ph_agg_fetch_where): only the surviving groups come back.
  * PH_EUNSUPPORTED — and the caller filters the fetched rows itself — for a conjunct over a key column or an AVG, for Agg <- Scan plans

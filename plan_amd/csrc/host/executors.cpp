@@ -870,6 +870,9 @@ std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return 
 static const int64_t kHostSortRows = getenv("PH_ORDER_HOST_ROWS") ? atoll(getenv("PH_ORDER_HOST_ROWS")) : (1 << 17);
 
 std::string gpuOrderExecutor::sortAll() {
+    static const bool timing = getenv("PH_HOST_TIMING") != nullptr;
+    struct Tm { bool on; double t0; ~Tm() { if (on) fprintf(stderr, "  order: sortAll %.1f us (incl. the child's Execute)\n", (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e6); } }
+        tm{timing, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()};
     // VARCHAR keys do not go through the batch (its VARCHAR staging is the <= 256-value dictionary of a group column): their rows
     // are ranked on the host (rank = position of the string among the distinct strings in byte order) and the ranks are the key
     std::vector<int> cols, batchPos(keys_.size(), -1);
@@ -1719,6 +1722,7 @@ std::string gpuResidentPlanExecutor::Init() {
     // HAVING runs in the aggregate's output phase, before Order and Limit (executor_aggr.go:143-263): with a HAVING the top-k
     // preselection is not announced — the k best groups could fail it while later ones pass — and the Order above sorts the survivors
     if (topkAgg_ >= 0 && having_.empty() && ph_plan_set_topk(plan_, topkAgg_, topkDesc_ ? 1 : 0, topkK_) != PH_OK) return herr("ph_plan_set_topk");
+    if (rowsRoot_ && rowsTopkCol_ >= 0 && rowsTopkK_ > 0 && ph_plan_set_rows_topk(plan_, rowsTopkCol_, rowsTopkDesc_ ? 1 : 0, rowsTopkK_) != PH_OK) return herr("ph_plan_set_rows_topk");
     for (auto &h : having_) if (h.col < 0 || h.col >= (int)outTypes_.size()) return "HAVING column out of range";
     if (!having_.empty()) {   // numeric conjuncts over aggregate columns: filtered on the device, only the survivors are fetched
         std::vector<ph_pred> hp;
@@ -1739,7 +1743,14 @@ std::string gpuResidentPlanExecutor::Close() {
 OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::string *err) {
     if (!built_ && rowsRoot_) {
         ph_rows_result *r = nullptr;
-        if (ph_plan_run(plan_) != PH_OK || ph_plan_fetch_rows(plan_, &r) != PH_OK) { *err = herr("ph_plan_run/fetch_rows"); return InvalidOpResult; }
+        static const bool timing_rows = getenv("PH_HOST_TIMING") != nullptr;
+        auto now_r = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tr0 = now_r();
+        int prc = ph_plan_run(plan_);
+        const double tr1 = now_r();
+        if (prc == PH_OK) prc = ph_plan_fetch_rows(plan_, &r);
+        if (timing_rows) fprintf(stderr, "  resident plan (rows): ph_plan_run %.1f us, ph_plan_fetch_rows %.1f us\n", (tr1 - tr0) * 1e6, (now_r() - tr1) * 1e6);
+        if (prc != PH_OK) { *err = herr("ph_plan_run/fetch_rows"); return InvalidOpResult; }
         const ResidentPlan::Node &root = rp_.nodes.back();
         if (r->ncols != (int32_t)outTypes_.size()) { ph_rows_result_free(r); *err = "row plan: column count differs from the plan's typing"; return InvalidOpResult; }
         for (int64_t base = 0; base < r->nrows; base += DefaultVectorSize) {
@@ -1772,6 +1783,7 @@ OperatorResult gpuResidentPlanExecutor::Execute(Chunk *, Chunk *output, std::str
             results_.push_back(c);
         }
         ph_rows_result_free(r);
+        if (timing_rows) fprintf(stderr, "  resident plan (rows): %zu chunks built in %.1f us\n", results_.size(), (now_r() - tr1) * 1e6);
         built_ = true;
     }
     if (!built_) {

@@ -461,6 +461,8 @@ public:
     // Order <- Limit above the aggregate with an aggregate as the first ORDER BY key (what the shim sees when it
     // walks up from the Agg): only the groups that can reach the first k rows come back from the device
     void SetTopK(int aggIndex, bool descending, int64_t k) { topkAgg_ = aggIndex; topkDesc_ = descending; topkK_ = k; }
+    // a join-rooted plan below Order(first key = output column `col`) + Limit(k): ph_plan_set_rows_topk
+    void SetRowsTopK(int col, bool descending, int64_t k) { rowsTopkCol_ = col; rowsTopkDesc_ = descending; rowsTopkK_ = k; }
     // multi-rank execution: every rank builds this executor over its shard of the resident tables and announces the ranks' communicator; the
     // library inserts the exchanges (ph_plan_set_comm) and every rank's executor emits the complete result
     void SetComm(ph_comm *comm) { comm_ = comm; }
@@ -474,6 +476,9 @@ private:
     std::vector<ProjExpr> outputs_;
     std::vector<LType> outTypes_, finalTypes_, argType_;
     int topkAgg_ = -1;
+    int rowsTopkCol_ = -1;
+    bool rowsTopkDesc_ = false;
+    int64_t rowsTopkK_ = 0;
     bool topkDesc_ = false;
     int64_t topkK_ = 0;
     ph_plan *plan_ = nullptr;

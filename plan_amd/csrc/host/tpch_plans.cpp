@@ -680,6 +680,7 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
         q->order = {{0, true}, {2, false}, {1, false}, {3, false}};
         q->limit = 100;
         q->ncols = 8;
+        q->rowsTopkCol = 0; q->rowsTopkDesc = true;   // ORDER BY s_acctbal DESC .. LIMIT 100: the rows that can be among the first hundred
         break;
     }
     case 10: {
@@ -746,6 +747,7 @@ std::string RunTpchQuery(ph_ctx *ctx, const TpchQuery &q, std::vector<std::strin
     if (!having.empty()) agg.SetHaving(having);
     if (!q.outputs.empty()) agg.SetOutputs(q.outputs);
     if (q.topkAgg >= 0 && q.limit > 0) agg.SetTopK(q.topkAgg, q.topkDesc, q.limit);
+    if (q.rowsTopkCol >= 0 && q.limit > 0) agg.SetRowsTopK(q.rowsTopkCol, q.rowsTopkDesc, q.limit);
     std::string e = agg.Init();
     if (!e.empty()) return "Init: " + e;
     std::unique_ptr<gpuOrderExecutor> ord;

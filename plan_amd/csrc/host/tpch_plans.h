@@ -47,6 +47,8 @@ struct TpchQuery {
     int64_t limit = -1;                   // limitExecutor above that (-1 = none)
     int topkAgg = -1;                     // ORDER BY's first key is aggregate topkAgg (index into the plan's aggregates)
     bool topkDesc = false;
+    int rowsTopkCol = -1;                 // a join-rooted plan: ORDER BY's first key is this output column (with `limit`): ph_plan_set_rows_topk
+    bool rowsTopkDesc = false;
     int ncols = 0;                        // result columns (the headline's tab count)
     // an UNCORRELATED scalar subquery in HAVING (Q11: sum > (select sum(..) * 0.0001 ..)): the reference plans it as a cross product
     // with a one-row relation and a Filter above; here its plan runs first and its one value, cast and multiplied as the binder types

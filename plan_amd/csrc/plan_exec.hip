@@ -109,6 +109,8 @@ struct ph_plan {
     std::vector<Node> nodes;
     int32_t topk_agg = -1, topk_desc = 0;
     int64_t topk_k = 0;
+    int32_t rows_topk_col = -1, rows_topk_desc = 0;   // a join-rooted plan under ORDER BY <column> LIMIT k (ph_plan_set_rows_topk)
+    int64_t rows_topk_k = 0;
     bool conservative = false;          // statistics are not trusted (after a broken claim)
     bool no_stream_agg = false;         // only the streaming aggregate's order claim broke (rows ordered by the first key, not by the key TUPLE): the
                                         // hash aggregate from then on — the joins keep their optimistic forms
@@ -2725,6 +2727,50 @@ void retire_broken_claim(ph_plan *p) {
     }
 }
 
+// ---- ORDER BY <column> [DESC] LIMIT k above a join-rooted plan: only rows whose key is at least as good as the k-th best can be among the first k
+// (ties kept; the host orders those few rows by the full key list). The k-th key: one device sort of the key column; then a threshold
+// selection and a compaction — before any VARCHAR column is gathered and before 4 673 rows become chunks on the host (Q2 at SF10: 100 of them).
+int rows_topk(ph_plan *p, Rel *R) {
+    ph_ctx *ctx = p->ctx;
+    const int c = p->rows_topk_col;
+    const int64_t k = p->rows_topk_k, n = R->n;
+    if (c < 0 || c >= (int)R->cols.size() || n <= std::max<int64_t>(4 * k, 256)) return PH_OK;
+    const PCol &pc0 = R->cols[(size_t)c];
+    const bool desc = p->rows_topk_desc != 0;
+    // the orderings the selection has for the type (selectOperation): INTEGER and DATE all four, DECIMAL only '>' — and ORDER BY compares a
+    // DECIMAL at two digits (sort_encoder.go:65-70), which is its value only up to scale 2
+    const bool okt = pc0.type == PH_I32 || pc0.type == PH_DATE || (pc0.type == PH_DEC64 && desc && pc0.scale <= 2);
+    if (!okt || pc0.sdict) return PH_OK;
+    PL_CHECK(positional(p, R, {c}));
+    const PCol &pc = R->cols[(size_t)c];
+    if (pc.validity) return PH_OK;   // NULLs sort first whatever the direction: not a threshold's business
+    const int32_t *s0 = nullptr;
+    ph_col v = col_view(*R, pc, &s0);
+    void *order = nullptr, *kth = nullptr, *keep = nullptr;
+    PL_CHECK(palloc(p, n * 4, &order));
+    PL_CHECK(palloc(p, 16, &kth));
+    PL_CHECK(palloc(p, n * 4, &keep));
+    const int32_t d = desc ? 1 : 0;
+    int rc = ph_sort_rows(ctx, &v, &d, 1, nullptr, n, (int32_t *)order);
+    if (rc == PH_EUNSUPPORTED) return PH_OK;
+    PL_CHECK(rc);
+    PL_CHECK(ph_gather(ctx, &v, (const int32_t *)order + (k - 1), 1, kth));
+    int64_t kv = 0;
+    if (width_of(pc.type) == 4) { int32_t x = 0; PL_CHECK(ctx->download(&x, kth, 4)); kv = x; } else PL_CHECK(ctx->download(&kv, kth, 8));
+    ph_const kc{};
+    kc.type = pc.type; kc.scale = pc.scale;
+    int32_t op = desc ? PH_GE : PH_LE;
+    kc.i = kv;
+    if (pc.type == PH_DEC64) { op = PH_GT; kc.i = kv - 1; if (kv == INT64_MIN) return PH_OK; }   // unscaled integers: v > kth - 1  <=>  v >= kth
+    int64_t m = 0;
+    PL_CHECK(ph_filter_select(ctx, &v, n, op, &kc, nullptr, n, (int32_t *)keep, &m));
+    if (m < k) { set_error("ph_plan: top-k preselection of the rows kept %lld of %lld rows for k = %lld", (long long)m, (long long)n, (long long)k); return PH_EHIP; }
+    PL_CHECK(compact(p, R, (const int32_t *)keep, m));
+    note(p, "rows: ORDER BY column %d %s LIMIT %lld — %lld of %lld rows are at least as good as the k-th (the host orders those)", c, desc ? "DESC" : "ASC", (long long)k,
+         (long long)m, (long long)n);
+    return PH_OK;
+}
+
 int run_once(ph_plan *p) {
     release_run(p, false);
     if (p->scan) { ph_scan_plan_free(p->scan); p->scan = nullptr; }
@@ -2737,6 +2783,7 @@ int run_once(ph_plan *p) {
         rc = lower(p, (int)p->nodes.size() - 1, false, &R);
         if (rc == PH_OK) rc = apply_pending(p, &R);
         if (rc == PH_OK && multi(p) && !R.replicated) rc = replicate_rel(p, &R, "the root relation's rows");   // every rank returns all rows
+        if (rc == PH_OK && p->rows_topk_col >= 0) rc = rows_topk(p, &R);
         if (rc == PH_OK) p->rows_rel = std::make_shared<Rel>(R);
     } else rc = lower_agg(p);
     if (rc != PH_OK) { release_run(p, false); (void)ph_ctx_set_deferred_errors(p->ctx, 0); return rc; }
@@ -2988,6 +3035,14 @@ extern "C" int ph_plan_set_topk(ph_plan *p, int32_t agg_index, int32_t descendin
     p->topk_agg = agg_index;
     p->topk_desc = descending ? 1 : 0;
     p->topk_k = k;
+    return PH_OK;
+}
+
+extern "C" int ph_plan_set_rows_topk(ph_plan *p, int32_t col, int32_t descending, int64_t k) {
+    PH_REQUIRE(p && p->rows_root && k > 0 && col >= 0, "ph_plan_set_rows_topk: a join-rooted plan, a column of its rows, k > 0");
+    p->rows_topk_col = col;
+    p->rows_topk_desc = descending ? 1 : 0;
+    p->rows_topk_k = k;
     return PH_OK;
 }
 
