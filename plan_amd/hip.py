@@ -1105,6 +1105,10 @@ class Plan:
     def set_topk(self, agg_index, k, descending=True):
         check(lib().ph_plan_set_topk(self.h, i32(agg_index), i32(1 if descending else 0), i64(k)))
 
+    def set_rows_topk(self, col, k, descending=True):
+        """ph_plan_set_rows_topk: a join-rooted plan under ORDER BY <column col> [DESC] LIMIT k returns only the rows that can be among the first k"""
+        check(lib().ph_plan_set_rows_topk(self.h, i32(col), i32(1 if descending else 0), i64(k)))
+
     def run(self):
         check(lib().ph_plan_run(self.h))
 

@@ -650,6 +650,26 @@ def test_q2_minimum_joined_back_with_text_columns_matches_golden(ctx, db):
     ex = p.explain()
     p.free()
     assert tpch.q2_text(r) == golden("plan_q2.txt"), ex
+    # ORDER BY s_acctbal DESC .. LIMIT k announced (ph_plan_set_rows_topk): exactly the rows at least as good as the k-th come back — ties
+    # of the k-th value included — and the text is the same; ascending over an INTEGER column (p_partkey) likewise
+    bal = np.asarray(r["columns"][0], dtype=np.int64)
+    for k in (100, 7, 1):
+        p = tpch.q2_plan(db)
+        p.set_rows_topk(0, k, descending=True)
+        p.run()
+        rk = p.fetch_rows()
+        ex = p.explain()
+        p.free()
+        kth = np.sort(bal)[::-1][k - 1]
+        assert "LIMIT" in ex and rk["nrows"] == int((bal >= kth).sum()) and int(np.asarray(rk["columns"][0], dtype=np.int64).min()) == kth, ex
+        assert tpch.q2_text(rk, limit=k) == tpch.q2_text(r, limit=k)
+    pk = np.asarray(r["columns"][3], dtype=np.int64)
+    p = tpch.q2_plan(db)
+    p.set_rows_topk(3, 50, descending=False)
+    p.run()
+    rk = p.fetch_rows()
+    p.free()
+    assert rk["nrows"] == int((pk <= np.sort(pk)[49]).sum()) and sorted(np.asarray(rk["columns"][3]).tolist()) == sorted(pk[pk <= np.sort(pk)[49]].tolist())
 
 
 def test_q10_seven_group_keys_match_golden(ctx, db):
