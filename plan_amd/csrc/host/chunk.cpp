@@ -443,39 +443,50 @@ static std::string go_float(double v) {
 
 double DecimalToDouble(const Decimal &d) { return strtod(DecimalString(d).c_str(), nullptr); }   // correctly rounded, like the Go parse
 
-std::string ValueString(const Vector &v, int row) {
-    Vector::Unified u;
-    v.ToUnifiedFormat(row + 1, &u);
+// one value's text appended to *out; u = the vector's unified format over at least row + 1 rows
+static void AppendValue(std::string *out, const Vector &v, const Vector::Unified &u, int row) {
     int64_t idx = u.sel->GetIndex(row);
-    if (!u.mask->RowIsValid((uint64_t)idx)) return "NULL";
+    if (!u.mask->RowIsValid((uint64_t)idx)) { *out += "NULL"; return; }
     char buf[64];
     switch (v._Typ.Id) {
-    case LTID_INTEGER: snprintf(buf, sizeof buf, "%d", reinterpret_cast<const int32_t *>(u.data)[idx]); return buf;
-    case LTID_BIGINT: snprintf(buf, sizeof buf, "%lld", (long long)reinterpret_cast<const int64_t *>(u.data)[idx]); return buf;
-    case LTID_VARCHAR: { const String &s = reinterpret_cast<const String *>(u.data)[idx]; return std::string(s.Data, (size_t)s.Len); }
-    case LTID_DECIMAL: return DecimalValueString(reinterpret_cast<const Decimal *>(u.data)[idx], v._Typ.Scale);
-    case LTID_DATE: { const Date &d = reinterpret_cast<const Date *>(u.data)[idx]; snprintf(buf, sizeof buf, "%04d-%02d-%02d", d.Year, d.Month, d.Day); return buf; }
-    case LTID_DOUBLE: return go_float(reinterpret_cast<const double *>(u.data)[idx]);
-    case LTID_FLOAT: return go_float((double)reinterpret_cast<const float *>(u.data)[idx]);   // Value.F64 = float64(float32), printed %v
+    case LTID_INTEGER: out->append(buf, (size_t)snprintf(buf, sizeof buf, "%d", reinterpret_cast<const int32_t *>(u.data)[idx])); return;
+    case LTID_BIGINT: out->append(buf, (size_t)snprintf(buf, sizeof buf, "%lld", (long long)reinterpret_cast<const int64_t *>(u.data)[idx])); return;
+    case LTID_VARCHAR: { const String &s = reinterpret_cast<const String *>(u.data)[idx]; out->append(s.Data, (size_t)s.Len); return; }
+    case LTID_DECIMAL: *out += DecimalValueString(reinterpret_cast<const Decimal *>(u.data)[idx], v._Typ.Scale); return;
+    case LTID_DATE: { const Date &d = reinterpret_cast<const Date *>(u.data)[idx]; out->append(buf, (size_t)snprintf(buf, sizeof buf, "%04d-%02d-%02d", d.Year, d.Month, d.Day)); return; }
+    case LTID_DOUBLE: *out += go_float(reinterpret_cast<const double *>(u.data)[idx]); return;
+    case LTID_FLOAT: *out += go_float((double)reinterpret_cast<const float *>(u.data)[idx]); return;   // Value.F64 = float64(float32), printed %v
     case LTID_HUGEINT: {
         const Hugeint &h = reinterpret_cast<const Hugeint *>(u.data)[idx];
         __int128 x = ((__int128)h.Upper << 64) + (__int128)(u128)h.Lower;
         bool neg = x < 0;
         u128 a = neg ? (u128)(-x) : (u128)x;
-        std::string s;
-        do { s += (char)('0' + (int)(a % 10)); a /= 10; } while (a);
-        if (neg) s += '-';
-        std::reverse(s.begin(), s.end());
-        return s;
+        int n = 0;
+        do { buf[n++] = (char)('0' + (int)(a % 10)); a /= 10; } while (a);
+        if (neg) buf[n++] = '-';
+        std::reverse(buf, buf + n);
+        out->append(buf, (size_t)n);
+        return;
     }
-    default: return "?";
+    default: *out += '?';
     }
 }
 
+std::string ValueString(const Vector &v, int row) {
+    Vector::Unified u;
+    v.ToUnifiedFormat(row + 1, &u);
+    std::string s;
+    AppendValue(&s, v, u, row);
+    return s;
+}
+
 void Chunk::AppendText(std::string *out) const {
+    // the unified format once per column (a constant vector's is a selection of Card() zeros), then row by row
+    std::vector<Vector::Unified> us((size_t)ColumnCount());
+    for (int j = 0; j < ColumnCount(); j++) Data[(size_t)j]->ToUnifiedFormat(Card(), &us[(size_t)j]);
     for (int i = 0; i < Card(); i++) {
         for (int j = 0; j < ColumnCount(); j++) {
-            *out += ValueString(*Data[(size_t)j], i);
+            AppendValue(out, *Data[(size_t)j], us[(size_t)j], i);
             if (j + 1 < ColumnCount()) *out += '\t';
         }
         *out += '\n';
