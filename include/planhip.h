@@ -253,6 +253,11 @@ int ph_filter_select_in(ph_ctx *ctx, const ph_col *col, int64_t n, const int64_t
 int ph_filter_select_cols(ph_ctx *ctx, const ph_col *a, const ph_col *b, int64_t n, int32_t op, const int32_t *sel_in,
                           int64_t n_in, int32_t *sel_out, int64_t *n_out);
 
+/* out_dev[i] = i for i < n; marks_dev[sel_dev[i]] = 1 for i < n (bytes; the caller clears them first): the two small device helpers a shim needs to
+ * turn a filtered pair list into marks of its probe rows (a join with a residual condition, as ph_plan does it) */
+int ph_dev_iota(ph_ctx *ctx, int32_t *out_dev, int64_t n);
+int ph_sel_mark(ph_ctx *ctx, const int32_t *sel_dev, int64_t n, uint8_t *marks_dev);
+
 /* OR of predicates = union of their selections: execSelectOr (expr_exec.go:488-530), which is
  * also how `a IN (x, y, ...)` runs (in(a,x) OR in(a,y) ..., `in` selecting like `=`,
  * function_operator_boolean.go:419-429). sels_dev[i] (device, counts[i] ascending row ids < n_rows)
@@ -829,7 +834,10 @@ typedef struct {
     int32_t nbools;
     const ph_bool *bools;
     /* PH_PN_JOIN: equi-join on nkeys column pairs; the output picks from [probe child's columns | build
-       child's columns] (SEMI / ANTI: probe columns only) */
+       child's columns] (SEMI / ANTI: probe columns only). A join's `bools` is its RESIDUAL condition — the non-equi
+       conjuncts of the ON clause (Q21's `l2.l_suppkey <> l1.l_suppkey` inside EXISTS: the reference's HashJoin keeps them
+       as join conditions beside the keys), a tree over [probe columns | build columns]: an INNER join keeps the pairs that
+       satisfy it, a SEMI (ANTI) join the probe rows with at least one (without any) such pair. Not with PH_JT_LEFT. */
     int32_t join_type;           /* ph_plan_join_type */
     int32_t nkeys;
     const int32_t *probe_keys;   /* probe child's output columns */

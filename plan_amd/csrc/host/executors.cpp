@@ -1455,11 +1455,12 @@ int ResidentPlan::Filter(int child, std::vector<Compare> conjuncts, BoolExpr whe
     return (int)nodes.size() - 1;
 }
 
-int ResidentPlan::Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type) {
+int ResidentPlan::Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type, BoolExpr residual) {
     Node n;
     n.kind = PH_PN_JOIN;
     n.child[0] = probe; n.child[1] = build;
     n.joinType = type;
+    n.where = std::move(residual);
     std::vector<LType> all = nodes[(size_t)probe].types;
     std::vector<const ResidentColumn *> src = nodes[(size_t)probe].source;
     for (auto &t : nodes[(size_t)build].types) all.push_back(t);

@@ -426,7 +426,10 @@ public:
     int Scan(const ResidentTable *t, std::vector<int> cols, std::vector<Compare> conjuncts = {}, BoolExpr where = BoolExpr());
     int Filter(int child, std::vector<Compare> conjuncts, BoolExpr where = BoolExpr());
     // output = the listed columns of [probe child's columns | build child's columns] (SEMI / ANTI: probe columns)
-    int Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type = JoinInner);
+    // residual: the join's non-equi condition over [probe columns | build columns] (HashJoin's conditions beside the keys); INNER keeps the
+    // pairs that satisfy it, SEMI / ANTI the probe rows with / without such a pair
+    int Join(int probe, int build, std::vector<int> probeKeys, std::vector<int> buildKeys, std::vector<int> out, JoinType type = JoinInner,
+             BoolExpr residual = BoolExpr());
     int Project(int child, std::vector<ProjExpr> exprs);
     // the root — or an aggregate BELOW other operators (a subquery's GROUP BY; its HAVING is a Filter above it): its output
     // columns are [group columns | aggregate results] with FinalizeStates' types (SUM(INTEGER) / COUNT are HUGEINT)

@@ -591,11 +591,23 @@ std::string BuildTpchQuery(const TpchDatabase &db, int id, TpchQuery *q) {
             int differ = p.Filter(pairs, {}, BoolExpr::CC(2, PH_NE, 3));
             return p.Agg(differ, {ProjExpr::Col(0), ProjExpr::Col(1)}, {{PH_A_COUNT_STAR, {}}});
         };
-        int l1 = l1Side();                                                    // two parents each: ph_plan lowers such a node once per run
-        int e2 = withOtherSupplier(l1, false);
-        int j3 = p.Join(l1, e2, {0, 2}, {0, 1}, {0, 1, 2, 3}, JoinSemi);
-        int n3 = withOtherSupplier(j3, true);
-        int j4 = p.Join(j3, n3, {0, 2}, {0, 1}, {3}, JoinAnti);               // s_name
+        int l1 = l1Side();
+        int j4;
+        if (!getenv("PH_Q21_NO_RESIDUAL")) {
+            // the EXISTS / NOT EXISTS as joins with a RESIDUAL condition (the library filters the key matches and marks the l1 rows that keep one)
+            BoolExpr otherSupplier = BoolExpr::CC(5, PH_NE, 1);                   // [l1: 0..3 | other: 4 l_orderkey, 5 l_suppkey]
+            int l2 = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY});
+            int j3 = p.Join(l1, l2, {0}, {0}, {0, 1, 2, 3}, JoinSemi, otherSupplier);
+            int l3 = p.Scan(&db.lineitem, {L_ORDERKEY, L_SUPPKEY}, {}, late);
+            j4 = p.Join(j3, l3, {0}, {0}, {3}, JoinAnti, otherSupplier);         // s_name
+        } else {
+            // (round 3's form, kept for the A/B: pairs + Filter + an aggregate by lineitem's primary key below a two-key SEMI / ANTI join; the l1
+            // subtree has two parents per step and is lowered once per run)
+            int e2 = withOtherSupplier(l1, false);
+            int j3 = p.Join(l1, e2, {0, 2}, {0, 1}, {0, 1, 2, 3}, JoinSemi);
+            int n3 = withOtherSupplier(j3, true);
+            j4 = p.Join(j3, n3, {0, 2}, {0, 1}, {3}, JoinAnti);                   // s_name
+        }
         p.Agg(j4, {ProjExpr::Col(0)}, {{PH_A_COUNT_STAR, {}}});
         q->order = {{1, true}, {0, false}};
         q->limit = 100;

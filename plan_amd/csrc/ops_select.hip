@@ -1017,6 +1017,28 @@ __global__ __launch_bounds__(256) void sel_flag_kernel(const int32_t *__restrict
 }
 }  // namespace ph
 
+namespace ph {
+__global__ __launch_bounds__(256) void iota_kernel(int32_t *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (int32_t)i;
+}
+}  // namespace ph
+
+extern "C" int ph_dev_iota(ph_ctx *ctx, int32_t *out_dev, int64_t n) {
+    PH_REQUIRE(ctx && n >= 0 && (n == 0 || out_dev) && n < (1ll << 31), "ph_dev_iota: bad arguments");
+    if (n == 0) return PH_OK;
+    ph::iota_kernel<<<(int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8), 256, 0, ctx->stream>>>(out_dev, n);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
+extern "C" int ph_sel_mark(ph_ctx *ctx, const int32_t *sel_dev, int64_t n, uint8_t *marks_dev) {
+    PH_REQUIRE(ctx && n >= 0 && (n == 0 || (sel_dev && marks_dev)), "ph_sel_mark: bad arguments");
+    if (n == 0) return PH_OK;
+    ph::sel_flag_kernel<<<(int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8), 256, 0, ctx->stream>>>(sel_dev, n, marks_dev);
+    PH_HIP(hipGetLastError());
+    return PH_OK;
+}
+
 extern "C" int ph_sel_union(ph_ctx *ctx, const int32_t *const *sels_dev, const int64_t *counts, int32_t k,
                             int64_t n_rows, int32_t *out_sel_dev, int64_t *n_out) {
     PH_REQUIRE(ctx && n_out && k >= 0 && n_rows >= 0 && (k == 0 || (sels_dev && counts)), "ph_sel_union: bad arguments");

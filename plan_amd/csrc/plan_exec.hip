@@ -1458,6 +1458,98 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
         const int a = P.cols[(size_t)nd.pkeys[k]].type, b = B.cols[(size_t)nd.bkeys[k]].type;
         if (width_of(a) == 0 || width_of(a) != width_of(b)) { set_error("ph_plan: join key %zu types differ or are VARCHAR (%d / %d)", k, a, b); return PH_EUNSUPPORTED; }
     }
+    // ---- a residual condition (the join's non-equi conjuncts over [probe | build] columns: `l2.l_suppkey <> l1.l_suppkey` inside Q21's EXISTS):
+    // the equi-join's PAIRS carry the columns it reads and the probe row's position; the condition filters the pairs; an INNER join keeps those,
+    // a SEMI / ANTI join marks the probe rows that kept a pair (one scattered byte per surviving pair) and selects the marked / unmarked rows.
+    if (!nd.bools.empty()) {
+        if (nd.join_type == PH_JT_LEFT) { set_error("ph_plan: a LEFT join with a residual condition"); return PH_EUNSUPPORTED; }
+        PL_CHECK(apply_pending(p, &P));
+        const bool exists = nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI;
+        Rel P2 = P;
+        if (exists) {   // the probe row's position rides along as one more column
+            void *pos = nullptr;
+            PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &pos));
+            if (P.n > 0) PL_CHECK(ph_dev_iota(ctx, (int32_t *)pos, P.n));
+            PCol c; c.type = PH_I32; c.data = pos;
+            P2.cols.push_back(c);
+        }
+        const size_t nP2 = P2.cols.size();
+        Node in = nd;
+        in.join_type = PH_JT_INNER;
+        in.bools = BoolTree{};
+        in.out.clear();
+        std::vector<int> where((size_t)(nP + nB), -1);   // original [P | B] column -> its position among the pairs' columns
+        auto carried = [&](int oc) -> int {
+            if (oc < 0 || (size_t)oc >= nP + nB) return -1;
+            if (where[(size_t)oc] < 0) { in.out.push_back((size_t)oc < nP ? oc : (int32_t)((size_t)oc - nP + nP2)); where[(size_t)oc] = (int)in.out.size() - 1; }
+            return where[(size_t)oc];
+        };
+        if (!exists) for (int32_t o : nd.out) { if (carried(o) < 0) { set_error("ph_plan: join output column out of range"); return PH_EINVAL; } }
+        BoolTree tree = nd.bools;
+        for (auto &b : tree.nodes) {
+            if (b.kind != PH_B_CMP) continue;
+            b.col = carried(b.col);
+            if (b.k.type == PH_COLREF) b.k.i = carried((int)b.k.i);
+            if (b.col < 0 || (b.k.type == PH_COLREF && b.k.i < 0)) { set_error("ph_plan: residual condition column out of range"); return PH_EINVAL; }
+        }
+        tree.fix();
+        int poscol = -1;
+        if (exists) { in.out.push_back((int32_t)nP); poscol = (int)in.out.size() - 1; }   // (nP = the position column's index in P2)
+        Rel J;
+        PL_CHECK(join_rels_local(p, idx, in, P2, B, false, &J));
+        PL_CHECK(apply_pending(p, &J));
+        const int64_t pairs = J.n;
+        const int32_t *keep = nullptr;
+        int64_t nkeep = 0;
+        if (J.n > 0) PL_CHECK(eval_bool(p, &J, false, tree, 0, nullptr, J.n, &keep, &nkeep));
+        if (!exists) {
+            if (nkeep == 0) J.n = 0; else PL_CHECK(compact(p, &J, keep, nkeep));
+            // the pairs' columns in the order of nd.out
+            std::vector<PCol> cols;
+            for (int32_t o : nd.out) cols.push_back(J.cols[(size_t)where[(size_t)o]]);
+            J.cols = cols;
+            J.covers = false;
+            drop_unused_lanes(&J);
+            note(p, "join#%d: residual condition over the pairs: %lld of %lld kept", idx, (long long)nkeep, (long long)pairs);
+            *out = J;
+            return PH_OK;
+        }
+        // marks: a byte per probe row, set by every surviving pair
+        void *marks = nullptr, *sel = nullptr;
+        PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) + 64, &marks));
+        PL_CHECK(palloc(p, std::max<int64_t>(P.n, 1) * 4, &sel));
+        PL_CHECK(ph_dev_memset(ctx, marks, 0, std::max<int64_t>(P.n, 1)));
+        if (nkeep > 0) {
+            PL_CHECK(positional(p, &J, {poscol}));
+            const int32_t *s0 = nullptr;
+            ph_col pv = col_view(J, J.cols[(size_t)poscol], &s0);
+            void *kept = nullptr;
+            PL_CHECK(palloc(p, nkeep * 4, &kept));
+            PL_CHECK(ph_gather(ctx, &pv, keep, nkeep, kept));
+            PL_CHECK(ph_sel_mark(ctx, (const int32_t *)kept, nkeep, (uint8_t *)marks));
+        }
+        int64_t m = 0;
+        if (P.n > 0) {
+            ph_col fc{};
+            fc.type = PH_CODE8; fc.data = marks;
+            ph_const want{};
+            want.type = PH_I32; want.i = nd.join_type == PH_JT_ANTI ? 0 : 1;
+            PL_CHECK(ph_filter_select(ctx, &fc, P.n, PH_EQ, &want, nullptr, P.n, (int32_t *)sel, &m));
+        }
+        *out = P;
+        PL_CHECK(compact(p, out, (const int32_t *)sel, m));
+        std::vector<PCol> cols;
+        for (int32_t o : nd.out) {
+            if (o < 0 || (size_t)o >= nP) { set_error("ph_plan: a SEMI / ANTI join emits probe columns only"); return PH_EINVAL; }
+            cols.push_back(out->cols[(size_t)o]);
+        }
+        out->cols = cols;
+        out->covers = false;
+        drop_unused_lanes(out);
+        note(p, "join#%d: %s with a residual condition: %lld of %lld pairs kept it, %lld of %lld probe rows %s", idx, nd.join_type == PH_JT_ANTI ? "ANTI" : "SEMI",
+             (long long)nkeep, (long long)pairs, (long long)m, (long long)P.n, nd.join_type == PH_JT_ANTI ? "have none" : "have one");
+        return PH_OK;
+    }
     bool need_build_cols = false;
     for (int32_t o : nd.out) {
         if (o < 0 || (size_t)o >= nP + nB) { set_error("ph_plan: join output column out of range"); return PH_EINVAL; }
@@ -2991,7 +3083,7 @@ extern "C" int ph_plan_create(ph_ctx *ctx, const ph_plan_node *nodes, int32_t nn
                 n.preds.back().k.s = nullptr;
             }
         }
-        if (s.kind == PH_PN_SCAN || s.kind == PH_PN_FILTER) {
+        if (s.kind == PH_PN_SCAN || s.kind == PH_PN_FILTER || s.kind == PH_PN_JOIN) {   // (a join's tree: its residual condition over [probe | build] columns)
             if (s.nbools < 0 || (s.nbools && !s.bools)) { set_error("ph_plan_create: node %d: bad boolean tree", i); return fail(PH_EINVAL); }
             n.bools = copy_bools(s.bools, s.nbools);
             // children FOLLOW their parent in the flat array: a node that named itself or an earlier node would make eval_bool recurse forever

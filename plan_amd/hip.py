@@ -1051,11 +1051,15 @@ class Plan:
             n.nbools, n.bools = len(bools), bools
         return self._add(n)
 
-    def join(self, probe, build, probe_keys, build_keys, out, join_type=PH_JT_INNER):
+    def join(self, probe, build, probe_keys, build_keys, out, join_type=PH_JT_INNER, residual=None):
+        """residual: a bool_tree over [probe columns | build columns] — the join's non-equi condition (INNER keeps the pairs that satisfy it,
+        SEMI / ANTI the probe rows with / without such a pair)"""
         n = PlanNode()
         n.kind, n.child[0], n.child[1] = PH_PN_JOIN, probe, build
         pk, bk, oa = _i32arr(probe_keys), _i32arr(build_keys), _i32arr(out)
-        self._keep += [pk, bk, oa]
+        self._keep += [pk, bk, oa, residual]
+        if residual is not None:
+            n.nbools, n.bools = len(residual), residual
         n.join_type, n.nkeys, n.probe_keys, n.build_keys = join_type, len(probe_keys), pk, bk
         n.nout, n.out = len(out), oa
         return self._add(n)

@@ -472,11 +472,12 @@ def q20_text(db, keys, supp_keys):
     return "#\t\n" + "".join(f"{a}\t{b}\n" for a, b in zip(*cols))
 
 
-def q21_plan(db, nation="BRAZIL"):
-    """cases/tpch/query/q21.sql. A join's non-equi conjunct (l2.l_suppkey <> l1.l_suppkey) is evaluated over the key matches: the INNER join on
-       l_orderkey emits the pairs, a Filter compares the two supplier columns, and the l1 rows that keep a pair — identified by lineitem's primary
-       key (l_orderkey, l_linenumber) — are an aggregate below the SEMI (EXISTS) / ANTI (NOT EXISTS) join that closes the step. The l1 side is
-       referenced by both the pair join and the closing join: a node with two parents, which the library lowers once per run"""
+def q21_plan(db, nation="BRAZIL", residual=True):
+    """cases/tpch/query/q21.sql. EXISTS / NOT EXISTS carry a non-equi conjunct beside the key (l2.l_suppkey <> l1.l_suppkey): a SEMI / ANTI join on
+       l_orderkey with that RESIDUAL condition (the library filters the key matches and marks the l1 rows that keep one).
+       residual=False: the same query without residual conditions, as round 3 expressed it — the INNER join on l_orderkey emits the pairs, a Filter
+       compares the two supplier columns, and the l1 rows that keep a pair, identified by lineitem's primary key (l_orderkey, l_linenumber), are an
+       aggregate below the SEMI / ANTI join that closes the step (the l1 side has two parents there: lowered once per run)"""
     p = hip.Plan(db.ctx)
     late = hip.bool_tree(("colcmp", db.c("lineitem", "l_receiptdate")[0], hip.PH_GT, db.c("lineitem", "l_commitdate")[0]))
 
@@ -495,11 +496,18 @@ def q21_plan(db, nation="BRAZIL"):
         differ = p.filter(pairs, bools=hip.bool_tree(("colcmp", 2, hip.PH_NE, 3)))
         return p.agg(differ, [hip.pe_col(0), hip.pe_col(1)], [(hip.PH_A_COUNT_STAR, None)])       # the l1 rows with such a line
 
-    l1 = l1_side()                                                                                # two parents each: lowered once per run
-    e = with_other_supplier(l1, False)
-    j3 = p.join(l1, e, [0, 2], [0, 1], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
-    n = with_other_supplier(j3, True)
-    j4 = p.join(j3, n, [0, 2], [0, 1], [3], join_type=hip.PH_JT_ANTI)                          # s_name
+    l1 = l1_side()
+    if residual:
+        other_supplier = hip.bool_tree(("colcmp", 5, hip.PH_NE, 1))                               # [l1: 0..3 | other: 4 l_orderkey, 5 l_suppkey]
+        l2 = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey"))
+        j3 = p.join(l1, l2, [0], [0], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI, residual=other_supplier)
+        l3 = p.scan(db.t("lineitem"), db.c("lineitem", "l_orderkey", "l_suppkey"), bools=late)
+        j4 = p.join(j3, l3, [0], [0], [3], join_type=hip.PH_JT_ANTI, residual=other_supplier)   # s_name
+    else:
+        e = with_other_supplier(l1, False)                                                        # (l1: two parents each, lowered once per run)
+        j3 = p.join(l1, e, [0, 2], [0, 1], [0, 1, 2, 3], join_type=hip.PH_JT_SEMI)
+        n = with_other_supplier(j3, True)
+        j4 = p.join(j3, n, [0, 2], [0, 1], [3], join_type=hip.PH_JT_ANTI)                      # s_name
     p.agg(j4, [hip.pe_col(0)], [(hip.PH_A_COUNT_STAR, None)])
     return p.create()
 

@@ -364,10 +364,13 @@ def test_q20_two_key_join_with_the_subquery_aggregate_matches_golden(ctx, db, sf
     assert "groups stay on the device" in ex
 
 
-def test_q21_exists_with_a_non_equi_condition_matches_golden(ctx, db, sf1):
-    """Q21: the pairs of an N:M join on l_orderkey filtered by a column-vs-column <>, the l1 rows that keep a pair as an aggregate by
-    lineitem's primary key below a two-key SEMI / ANTI join, a VARCHAR group key: the oracle's groups and cases/tpch/1g/plan/q21.txt"""
-    p = tpch.q21_plan(db)
+@pytest.mark.parametrize("residual", [True, False])
+def test_q21_exists_with_a_non_equi_condition_matches_golden(ctx, db, sf1, residual):
+    """Q21's EXISTS / NOT EXISTS with `l2.l_suppkey <> l1.l_suppkey`, two ways: SEMI / ANTI joins with a RESIDUAL condition (the key matches
+    filtered, the l1 rows that keep one marked), and without residual conditions (the pairs of an N:M join on l_orderkey filtered by a
+    column-vs-column <>, the l1 rows that keep a pair as an aggregate by lineitem's primary key below a two-key SEMI / ANTI join). A VARCHAR
+    group key: the oracle's groups and cases/tpch/1g/plan/q21.txt"""
+    p = tpch.q21_plan(db, residual=residual)
     p.run()
     r = p.fetch()
     ex = p.explain()
@@ -376,6 +379,35 @@ def test_q21_exists_with_a_non_equi_condition_matches_golden(ctx, db, sf1):
     orows, n = O.q21_rows(sf1)
     assert r["ngroups"] == n, ex
     assert text == golden("plan_q21.txt"), ex
+    assert ("with a residual condition" in ex) == residual, ex
+
+
+def test_residual_condition_of_an_inner_join_filters_its_pairs(ctx, db, sf1):
+    """an INNER join with a residual condition = the join, then a Filter over its rows (two plans, the same rows): partsupp x part[p_size >= 40] on
+    the part key where ps_availqty < p_size (a quarter of a percent of the pairs)"""
+    def plan(as_residual):
+        p = hip.Plan(db.ctx)
+        part = p.scan(db.t("part"), db.c("part", "p_partkey", "p_size"), [tpch._pred(db, "part", "p_size", hip.PH_GE, hip.const(hip.PH_I32, i=40))])
+        ps = p.scan(db.t("partsupp"), db.c("partsupp", "ps_partkey", "ps_availqty", "ps_suppkey"))
+        cond = hip.bool_tree(("colcmp", 1, hip.PH_LT, 4))                                           # ps_availqty < p_size  [partsupp 0..2 | part 3, 4]
+        if as_residual:
+            j = p.join(ps, part, [0], [0], [0, 2, 4], residual=cond)
+        else:
+            j0 = p.join(ps, part, [0], [0], [0, 1, 2, 3, 4])
+            f = p.filter(j0, bools=cond)
+            j = p.project(f, [hip.pe_col(0), hip.pe_col(2), hip.pe_col(4)])
+        p.agg(j, [hip.pe_col(2)], [(hip.PH_A_COUNT_STAR, None), (hip.PH_A_SUM, hip.pe_col(1))])
+        return p.create()
+    res = []
+    for as_residual in (True, False):
+        p = plan(as_residual)
+        p.run()
+        r = p.fetch()
+        ex = p.explain()
+        p.free()
+        res.append(sorted((int(r["keys"][g][0]), int(r["count"][g][0]), int(r["sum"][g][1])) for g in range(r["ngroups"])))
+        assert ("residual condition over the pairs" in ex) == as_residual, ex
+    assert res[0] == res[1] and len(res[0]) > 0
 
 
 def test_q22_substring_keys_anti_join_and_scalar_average_match_golden(ctx, db, sf1):
