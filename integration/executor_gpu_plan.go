@@ -456,20 +456,30 @@ func (b *planBuilder) lower(op *PhysicalOperator) (int, bool) {
 		}
 		nLeft := len(b.meta[l].types)
 		var pk, bk []int
-		for _, cond := range op.getOnConds() { // equality of a probe-side and a build-side column per condition
-			if cond.Typ != ET_Func || cond.FuncName() != FuncEqual || len(cond.Children) != 2 {
-				return 0, false
+		var residual []*Expr // the ON clause's non-equi conjuncts (Q21: l2.l_suppkey <> l1.l_suppkey): the join node's residual condition
+		for _, cond := range op.getOnConds() {
+			// equality of a probe-side and a build-side column: a key pair; anything else: residual
+			if cond.Typ == ET_Func && cond.FuncName() == FuncEqual && len(cond.Children) == 2 {
+				lc, ok1 := childColumn(cond.Children[0], nLeft)
+				rc, ok2 := childColumn(cond.Children[1], nLeft)
+				if ok1 && ok2 && lc < nLeft && rc >= nLeft {
+					pk = append(pk, lc)
+					bk = append(bk, rc-nLeft)
+					continue
+				}
 			}
-			lc, ok1 := childColumn(cond.Children[0], nLeft)
-			rc, ok2 := childColumn(cond.Children[1], nLeft)
-			if !ok1 || !ok2 || lc >= nLeft || rc < nLeft {
-				return 0, false
-			}
-			pk = append(pk, lc)
-			bk = append(bk, rc-nLeft)
+			residual = append(residual, cond)
 		}
-		if len(pk) == 0 {
+		if len(pk) == 0 || (len(residual) > 0 && jt == C.PH_JT_LEFT) {
 			return 0, false
+		}
+		var residualBools []C.ph_bool
+		if len(residual) > 0 { // one tree over [probe columns | build columns]: the column numbering the ON clause already uses
+			root := &Expr{Typ: ET_Func, Children: residual}
+			residualBools = make([]C.ph_bool, 1)
+			if !b.flattenBool(root, true, 0, nLeft, &residualBools) {
+				return 0, false
+			}
 		}
 		all := planNodeMeta{types: append(append([]common.LType{}, b.meta[l].types...), b.meta[r].types...),
 			dicts: append(append([][]string{}, b.meta[l].dicts...), b.meta[r].dicts...)}
@@ -491,6 +501,7 @@ func (b *planBuilder) lower(op *PhysicalOperator) (int, bool) {
 		n.nkeys = C.int32_t(len(pk))
 		n.probe_keys, n.build_keys = b.arena.i32s(pk), b.arena.i32s(bk)
 		n.nout, n.out = C.int32_t(len(out)), b.arena.i32s(out)
+		b.setPreds(&n, nil, residualBools)
 		return b.add(n, m), true
 
 	case POT_Project:
