@@ -144,6 +144,7 @@ struct ph_plan {
     ph_comm *comm = nullptr;
     int64_t bcast_rows = 4ll << 20;     // build sides up to this many rows IN ALL are replicated (all-gather) instead of hash-partitioned
     bool root_disjoint = false;         // the root aggregate's groups of this rank are nobody else's (no merge of partial states at fetch)
+    bool no_sideways = false;           // (transient) a join lowered with its roles swapped for the table-less form: the build table is NOT to be reduced first
     bool topk_off = false;              // this run leaves the top-k preselection out (across ranks its groups could not be made whole): all groups come back
     bool root_replicated = false;       // every rank computed the whole result
 };
@@ -1673,7 +1674,7 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
 
     // ---- sideways information passing: a big, unfiltered build table whose key the probe side has already joined
     // against a small table is reduced to the rows that can match (marks from a probe of that small table)
-    if (B.single_identity() && !B.lazy() && B.n >= (1 << 18)) {
+    if (B.single_identity() && !B.lazy() && B.n >= (1 << 18) && !p->no_sideways) {
         for (size_t k = 0; k < nk; k++) {
             const int d = P.cols[(size_t)nd.pkeys[k]].domain;
             const PCol &bc = B.cols[(size_t)nd.bkeys[k]];
@@ -1715,6 +1716,30 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
                 return PH_OK;
             }
             if (rc != PH_EUNSUPPORTED) return rc;
+        }
+    }
+
+    // ---- roles swapped: the PROBE side is a big base table clustered by the key and the BUILD side a handful of rows (Q18: sixty million lines against
+    // the 624 orders that pass the HAVING) — an INNER join's pairs are the same either way, and with the roles swapped they are the table-less
+    // form below (a few hundred binary searches) instead of a pass over the whole key column (163 us at 2.9 TB/s)
+    if (nd.join_type == PH_JT_INNER && nk == 1 && P.single_identity() && !P.flags && !getenv("PH_PLAN_NO_SORTED_PAIRS") && !getenv("PH_PLAN_NO_SWAP")) {
+        const PCol &pc = P.cols[(size_t)nd.pkeys[0]];
+        const ph_table *pt = P.lanes[0].t;
+        bool all_lane0 = pc.lane == 0;
+        for (auto &c : P.cols) all_lane0 = all_lane0 && c.lane == 0;
+        if (all_lane0 && pc.tcol >= 0 && pt->cols[(size_t)pc.tcol].ascending && !pt->cols[(size_t)pc.tcol].strict && pt->nrows >= (1 << 22)) {
+            if (B.lazy() && B.single_identity() && B.lanes[0].t->nrows * 64 <= pt->nrows) PL_CHECK(apply_pending(p, &B));
+            if (!B.lazy() && B.n * 32 <= pt->nrows) {
+                Node sw = nd;
+                sw.pkeys = nd.bkeys;
+                sw.bkeys = nd.pkeys;
+                for (auto &o : sw.out) o = (size_t)o < nP ? (int32_t)(nB + (size_t)o) : (int32_t)((size_t)o - nP);
+                note(p, "join#%d: roles swapped (the probe side is a table clustered by the key, the build side %lld rows)", idx, (long long)B.n);
+                p->no_sideways = true;
+                const int src = join_rels_local(p, idx, sw, B, P, as_build, out);
+                p->no_sideways = false;
+                return src;
+            }
         }
     }
 
