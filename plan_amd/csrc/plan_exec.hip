@@ -1462,7 +1462,22 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
     // ---- a residual condition (the join's non-equi conjuncts over [probe | build] columns: `l2.l_suppkey <> l1.l_suppkey` inside Q21's EXISTS):
     // the equi-join's PAIRS carry the columns it reads and the probe row's position; the condition filters the pairs; an INNER join keeps those,
     // a SEMI / ANTI join marks the probe rows that kept a pair (one scattered byte per surviving pair) and selects the marked / unmarked rows.
-    if (!nd.bools.empty()) {
+    // ... and the same path WITHOUT a condition for a SEMI / ANTI join whose build side is a big table clustered by the key and whose probe side is a
+    // sliver of it (Q4: 570 k orders of one quarter against the 38 M late lines): the pairs of the table-less join (a binary search per probe row,
+    // the build table's own filters applied to the pairs) mark their probe rows — instead of an existence table over every qualifying build row
+    bool exists_by_pairs = false;
+    if (nd.bools.empty() && (nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI) && nk == 1 && B.single_identity() && !B.flags && !p->conservative &&
+        !getenv("PH_PLAN_NO_SORTED_PAIRS") && !getenv("PH_PLAN_NO_EXISTS_PAIRS")) {
+        const PCol &bc = B.cols[(size_t)nd.bkeys[0]];
+        const ph_table *bt = B.lanes[0].t;
+        bool all_lane0 = bc.lane == 0 && bc.tcol >= 0;
+        for (auto &c : B.cols) all_lane0 = all_lane0 && c.lane == 0;
+        if (all_lane0 && bt->cols[(size_t)bc.tcol].ascending && !bt->cols[(size_t)bc.tcol].strict && bt->nrows >= (1 << 22)) {
+            PL_CHECK(apply_pending(p, &P));
+            exists_by_pairs = P.n * 32 <= bt->nrows;
+        }
+    }
+    if (!nd.bools.empty() || exists_by_pairs) {
         if (nd.join_type == PH_JT_LEFT) { set_error("ph_plan: a LEFT join with a residual condition"); return PH_EUNSUPPORTED; }
         PL_CHECK(apply_pending(p, &P));
         const bool exists = nd.join_type == PH_JT_SEMI || nd.join_type == PH_JT_ANTI;
@@ -1497,12 +1512,16 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
         int poscol = -1;
         if (exists) { in.out.push_back((int32_t)nP); poscol = (int)in.out.size() - 1; }   // (nP = the position column's index in P2)
         Rel J;
-        PL_CHECK(join_rels_local(p, idx, in, P2, B, false, &J));
+        const bool was = p->no_sideways;
+        if (exists_by_pairs) p->no_sideways = true;   // (the clustered build table is searched, not reduced)
+        const int jrc = join_rels_local(p, idx, in, P2, B, false, &J);
+        p->no_sideways = was;
+        PL_CHECK(jrc);
         PL_CHECK(apply_pending(p, &J));
         const int64_t pairs = J.n;
         const int32_t *keep = nullptr;
-        int64_t nkeep = 0;
-        if (J.n > 0) PL_CHECK(eval_bool(p, &J, false, tree, 0, nullptr, J.n, &keep, &nkeep));
+        int64_t nkeep = J.n;   // (no condition: every pair counts)
+        if (J.n > 0 && !tree.empty()) PL_CHECK(eval_bool(p, &J, false, tree, 0, nullptr, J.n, &keep, &nkeep));
         if (!exists) {
             if (nkeep == 0) J.n = 0; else PL_CHECK(compact(p, &J, keep, nkeep));
             // the pairs' columns in the order of nd.out
@@ -1524,9 +1543,13 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
             PL_CHECK(positional(p, &J, {poscol}));
             const int32_t *s0 = nullptr;
             ph_col pv = col_view(J, J.cols[(size_t)poscol], &s0);
-            void *kept = nullptr;
-            PL_CHECK(palloc(p, nkeep * 4, &kept));
-            PL_CHECK(ph_gather(ctx, &pv, keep, nkeep, kept));
+            const void *kept = pv.data;
+            if (keep) {
+                void *g = nullptr;
+                PL_CHECK(palloc(p, nkeep * 4, &g));
+                PL_CHECK(ph_gather(ctx, &pv, keep, nkeep, g));
+                kept = g;
+            }
             PL_CHECK(ph_sel_mark(ctx, (const int32_t *)kept, nkeep, (uint8_t *)marks));
         }
         int64_t m = 0;
@@ -1547,8 +1570,10 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
         out->cols = cols;
         out->covers = false;
         drop_unused_lanes(out);
-        note(p, "join#%d: %s with a residual condition: %lld of %lld pairs kept it, %lld of %lld probe rows %s", idx, nd.join_type == PH_JT_ANTI ? "ANTI" : "SEMI",
-             (long long)nkeep, (long long)pairs, (long long)m, (long long)P.n, nd.join_type == PH_JT_ANTI ? "have none" : "have one");
+        if (tree.empty()) note(p, "join#%d: %s through the pairs of the table-less join: %lld pairs mark %lld of %lld probe rows", idx, nd.join_type == PH_JT_ANTI ? "ANTI" : "SEMI",
+                               (long long)pairs, (long long)(nd.join_type == PH_JT_ANTI ? P.n - m : m), (long long)P.n);
+        else note(p, "join#%d: %s with a residual condition: %lld of %lld pairs kept it, %lld of %lld probe rows %s", idx, nd.join_type == PH_JT_ANTI ? "ANTI" : "SEMI",
+                  (long long)nkeep, (long long)pairs, (long long)m, (long long)P.n, nd.join_type == PH_JT_ANTI ? "have none" : "have one");
         return PH_OK;
     }
     bool need_build_cols = false;

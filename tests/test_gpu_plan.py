@@ -233,15 +233,20 @@ def q12_text(r):
     return "#\t\t\n" + "".join(f"{dic[c]}\t{h}\t{l}\n" for c, h, l in _by_name(rows, dic))
 
 
-def test_q4_semi_join_plan_matches_golden(ctx, db):
-    """SEMI join against a build side with duplicate keys (lineitem rows per order) behind a column-vs-column filter"""
-    p = tpch.q4_plan(db)
-    p.run()
-    r = p.fetch()
-    ex = p.explain()
-    p.free()
-    assert q4_text(r) == golden("plan_q4.txt"), ex
-    assert "semi (marks + selection)" in ex
+def test_q4_semi_join_plan_matches_golden(ctx, db, monkeypatch):
+    """SEMI join against a build side with duplicate keys (lineitem rows per order) behind a column-vs-column filter, two ways: the orders of the
+    quarter binary-search lineitem (clustered by the order key), the pairs — the late-line filter applied to them — mark their orders; and, with
+    that switched off, an existence table over every late line, probed by the orders"""
+    for off, phrase in ((False, "through the pairs of the table-less join"), (True, "semi (marks + selection)")):
+        if off:
+            monkeypatch.setenv("PH_PLAN_NO_EXISTS_PAIRS", "1")
+        p = tpch.q4_plan(db)
+        p.run()
+        r = p.fetch()
+        ex = p.explain()
+        p.free()
+        assert q4_text(r) == golden("plan_q4.txt"), ex
+        assert phrase in ex, ex
 
 
 def test_q5_six_table_chain_matches_golden(ctx, db):
