@@ -1902,7 +1902,11 @@ int join_rels_local(ph_plan *p, int idx, const Node &nd, Rel P, Rel B, bool as_b
             // key domain has reduced): no Bloom bitmap, node table for composite keys
             if (B.covers && uniq == 2 && !(flags & PH_JOIN_KEY_RANGE)) flags |= PH_JOIN_FK_PROBES;
             int rc = PH_EUNSUPPORTED;
-            if (B.single_identity() && (flags & PH_JOIN_KEY_RANGE) && B.complex.empty() && B.pending.size() + (B.flags ? 1 : 0) == 1) {
+            // (a small filtered table probed by a table sixteen times its size is selected first: what a selective filter keeps — Q8's 13 k parts of one
+            // type — builds the table whose occupied slot groups fit an LDS bitmap, and the 60 M-row probe reads that instead of the L2 bitmap of
+            // the gated fill: 238 -> ~120 us)
+            const bool small_under_big = B.single_identity() && !B.flags && t->nrows <= (4 << 20) && t->nrows * 16 <= P.n && P.n >= (32ll << 20) && !getenv("PH_PLAN_GATED_SMALL");   // (the gain is ~2 us per million probe rows, the selection's count a round trip)
+            if (B.single_identity() && (flags & PH_JOIN_KEY_RANGE) && B.complex.empty() && B.pending.size() + (B.flags ? 1 : 0) == 1 && !small_under_big) {
                 // Filter (or a semi-join's marks) under the build child rides along in the build
                 ph_pred w{};
                 ph_col wv{};
