@@ -552,8 +552,6 @@ extern "C" int ph_date_extract(ph_ctx *ctx, int32_t part, const ph_col *col, con
 // from the end, a negative length reads leftwards, offset 0 shortens the length by one. Two passes:
 // every row's (start, length) -> exclusive scan of the lengths -> byte copy.
 namespace ph {
-int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev);
-
 __device__ __forceinline__ bool substr_range(long long slen, long long offset, long long length, long long *start, long long *end) {
     if (length == 0) return false;
     if (offset > 0) *start = slen < offset - 1 ? slen : offset - 1;

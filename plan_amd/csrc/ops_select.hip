@@ -396,9 +396,16 @@ __global__ __launch_bounds__(256) void like_contains2_count_kernel(SelParams P, 
     if (threadIdx.x == 0) block_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+__device__ __forceinline__ void scan_publish(const ScanPublish &S, long long total) {   // one thread: the word, then the number
+    if (!S.mbox) return;
+    S.mbox[0] = (unsigned long long)total;
+    __threadfence_system();
+    __hip_atomic_store(S.flag, S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // exclusive scan of n ints in place, total to out_total; one workgroup
 __global__ __launch_bounds__(1024) void scan_kernel(int32_t *__restrict__ v, int64_t n,
-                                                    int64_t *__restrict__ out_total) {
+                                                    int64_t *__restrict__ out_total, ScanPublish S) {
     __shared__ long long wsum[16];
     __shared__ long long carry;
     if (threadIdx.x == 0) carry = 0;
@@ -422,12 +429,12 @@ __global__ __launch_bounds__(1024) void scan_kernel(int32_t *__restrict__ v, int
         if (threadIdx.x == 1023) carry = c + woff + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out_total = carry;
+    if (threadIdx.x == 0) { *out_total = carry; scan_publish(S, carry); }
 }
 
 // the same for n <= 16384 in ONE step: a thread owns 16 consecutive elements (the loop above pays three
 // barriers per 1024 elements: 12 us for the 7 324 block totals of a 15 M-row probe, 3 us here)
-__global__ __launch_bounds__(1024) void scan_small_kernel(int32_t *__restrict__ v, int n, int64_t *__restrict__ out_total) {
+__global__ __launch_bounds__(1024) void scan_small_kernel(int32_t *__restrict__ v, int n, int64_t *__restrict__ out_total, ScanPublish S) {
     constexpr int E = 16;
     __shared__ long long wsum[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(int32_t *__restrict__ 
         if (i0 + e < n) v[i0 + e] = (int32_t)run;
         run += x[e];
     }
-    if (threadIdx.x == 1023) *out_total = run;
+    if (threadIdx.x == 1023) { *out_total = run; scan_publish(S, run); }
 }
 
 __global__ __launch_bounds__(256) void select_write_kernel(SelParams P, const int32_t *__restrict__ sel_in,
@@ -595,10 +602,10 @@ __global__ __launch_bounds__(256) void vsel_write_kernel(const T *__restrict__ d
 
 template <typename T>
 static int run_vsel(ph_ctx *ctx, const SelParams &P, int64_t n, int32_t *sel_out, int32_t *counts, int64_t nb,
-                    int64_t *total) {
+                    int64_t *total, const ScanPublish *pub) {
     vsel_count_kernel<T><<<(int)nb, 256, 0, ctx->stream>>>((const T *)P.data, P.validity, P.lo, P.hi, n, counts);
     PH_HIP(hipGetLastError());
-    PH_CHECK(exclusive_scan_i32(ctx, counts, nb, total));
+    PH_CHECK(exclusive_scan_i32(ctx, counts, nb, total, pub));
     vsel_write_kernel<T><<<(int)nb, 256, 0, ctx->stream>>>((const T *)P.data, P.validity, P.lo, P.hi, n, counts, sel_out);
     PH_HIP(hipGetLastError());
     return PH_OK;
@@ -772,7 +779,7 @@ constexpr unsigned long long SC_AGG = 1ull, SC_INCL = 2ull;
 
 __global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ state,
                                                              unsigned *__restrict__ ticket, unsigned ticket_base,
-                                                             unsigned long long epoch, int64_t *__restrict__ total) {
+                                                             unsigned long long epoch, int64_t *__restrict__ total, ScanPublish S) {
     __shared__ int wsum[16];
     __shared__ unsigned s_tile;
     __shared__ long long s_prefix;
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict
             __hip_atomic_store(&state[tile], tag | (SC_INCL << 32) | (unsigned)(prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_prefix = prefix;
-        if ((int64_t)(tile + 1) * SCAN_TILE >= n) *total = prefix + agg;   // the last tile
+        if ((int64_t)(tile + 1) * SCAN_TILE >= n) { *total = prefix + agg; scan_publish(S, prefix + agg); }   // the last tile
     }
     __syncthreads();
     off += (int)s_prefix;
@@ -830,10 +837,11 @@ __global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict
     }
 }
 
-int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev) {
+int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev, const ScanPublish *pub) {
+    const ScanPublish S = pub ? *pub : ScanPublish{};
     if (n <= 4 * SCAN_TILE) {
-        if (n > 1024) scan_small_kernel<<<1, 1024, 0, ctx->stream>>>(dev, (int)n, total_dev);
-        else scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev);
+        if (n > 1024) scan_small_kernel<<<1, 1024, 0, ctx->stream>>>(dev, (int)n, total_dev, S);
+        else scan_kernel<<<1, 1024, 0, ctx->stream>>>(dev, n, total_dev, S);
         PH_HIP(hipGetLastError());
         return PH_OK;
     }
@@ -851,7 +859,7 @@ int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev)
         unsigned long long *state = (unsigned long long *)ctx->scan_state;
         unsigned *ticket = (unsigned *)(state + ctx->scan_tiles);
         ctx->scan_epoch = (ctx->scan_epoch % ((1ull << 30) - 1)) + 1;   // 1 .. 2^30-1, never 0
-        scan_lookback_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, state, ticket, ctx->scan_ticket_base, ctx->scan_epoch, total_dev);
+        scan_lookback_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, state, ticket, ctx->scan_ticket_base, ctx->scan_epoch, total_dev, S);
         PH_HIP(hipGetLastError());
         ctx->scan_ticket_base += (unsigned)nt;   // wraps like the device counter
         return PH_OK;
@@ -859,7 +867,7 @@ int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev)
     int32_t *tiles = nullptr;
     PH_CHECK(ctx->pool_alloc(nt * 4, (void **)&tiles));
     scan_tile_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, tiles);
-    int rc = exclusive_scan_i32(ctx, tiles, nt, total_dev);
+    int rc = exclusive_scan_i32(ctx, tiles, nt, total_dev, pub);
     scan_add_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, tiles);
     if (rc == PH_OK && hipGetLastError() != hipSuccess) rc = PH_EHIP;
     ctx->pool_release(tiles);
@@ -950,12 +958,26 @@ static int run_select(ph_ctx *ctx, ph::SelParams &P, const int32_t *sel_in, int6
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
     unsigned long long *flags = memo ? (unsigned long long *)((char *)ctx->scratch + ph::round_up(nb * 4, 8) + 64) : nullptr;
-    if (vec) {
-        int rc = P.kind == ph::SK_RANGE_I32   ? ph::run_vsel<int32_t>(ctx, P, n_in, sel_out, counts, nb, total)
-                 : P.kind == ph::SK_RANGE_I64 ? ph::run_vsel<int64_t>(ctx, P, n_in, sel_out, counts, nb, total)
-                                              : ph::run_vsel<uint8_t>(ctx, P, n_in, sel_out, counts, nb, total);
-        PH_CHECK(rc);
+    // the count travels with the scan (ScanPublish): the host has it while the write pass runs, and no publish launch follows. Not with deferred
+    // counts (Ctx.set_async_counts: several counts collected later) — those keep their slots.
+    ph::ScanPublish pub;
+    unsigned long long armed = 0;
+    static const bool early_count = !(getenv("PH_EARLY_COUNT") && getenv("PH_EARLY_COUNT")[0] == '0');
+    if (early_count && !ctx->async_counts) PH_CHECK(ctx->arm_publish(8, &pub.mbox, &pub.flag, &armed));
+    pub.seq = armed;
+    auto count_back = [&]() -> int {
+        if (armed) {
+            const int rc = ctx->collect_armed(n_out, 8, armed);
+            if (rc <= 0) return rc;   // (1: the mailbox has been used since — cannot happen inside this call, but the ordinary path is right anyway)
+        }
         return ctx->download_count(n_out, total, -1, "ph_filter_select");
+    };
+    if (vec) {
+        int rc = P.kind == ph::SK_RANGE_I32   ? ph::run_vsel<int32_t>(ctx, P, n_in, sel_out, counts, nb, total, armed ? &pub : nullptr)
+                 : P.kind == ph::SK_RANGE_I64 ? ph::run_vsel<int64_t>(ctx, P, n_in, sel_out, counts, nb, total, armed ? &pub : nullptr)
+                                              : ph::run_vsel<uint8_t>(ctx, P, n_in, sel_out, counts, nb, total, armed ? &pub : nullptr);
+        PH_CHECK(rc);
+        return count_back();
     }
     static const bool no_direct_like = getenv("PH_LIKE_STAGED") != nullptr;   // the staged form, for the parity test
     if (P.kind == ph::SK_STR && P.contains && sel_in == nullptr && P.plen >= 3 && !no_direct_like &&
@@ -967,10 +989,10 @@ static int run_select(ph_ctx *ctx, ph::SelParams &P, const int32_t *sel_in, int6
     else
         ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, flags);
     PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total, armed ? &pub : nullptr));
     ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, flags);
     PH_HIP(hipGetLastError());
-    return ctx->download_count(n_out, total, -1, "ph_filter_select");
+    return count_back();
 }
 
 // column OP column (selectBinary with two FLAT vectors, function_operator_boolean.go:506-521): the (type, op) pairs
