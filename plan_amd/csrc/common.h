@@ -61,6 +61,11 @@ inline int type_width(int32_t t) {
 
 }  // namespace ph
 
+namespace ph {
+// what a scan needs to publish its total itself (ops.h exclusive_scan_i32): the mapped mailbox, its sequence word and the number to store there
+struct ScanPublish { unsigned long long *mbox = nullptr, *flag = nullptr; unsigned long long seq = 0; };
+}  // namespace ph
+
 struct ph_ctx {
     int device = 0;
     int cu_count = ph::CU_COUNT;  // multiProcessorCount of the device
@@ -92,6 +97,10 @@ struct ph_ctx {
     int arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq);
     int collect_armed(void *host, int64_t bytes, unsigned long long seq);
     int ensure_mailbox();
+    // A row count that travels with the scan that produces it: arm_count before the scan is launched (pub is left empty when the count has to take
+    // the ordinary way: deferred counts, PH_EARLY_COUNT=0), count_back instead of download_count behind the kernels that consume the offsets.
+    int arm_count(ph::ScanPublish *pub);
+    int count_back(const ph::ScanPublish &pub, int64_t *host, const void *total_dev, int64_t cap, const char *what);
     unsigned *scan_done_dev = nullptr;    // the ticket counter of fused scans' last-workgroup tails (zero between launches)
     // single-pass scan (ops_select.hip): tile states + ticket counter, reused across calls by epoch
     void *scan_state = nullptr;

@@ -161,6 +161,25 @@ int ph_ctx::collect_armed(void *host, int64_t bytes, unsigned long long seq) {
     return PH_OK;
 }
 
+int ph_ctx::arm_count(ph::ScanPublish *pub) {
+    *pub = ph::ScanPublish{};
+    static const bool early_count = !(getenv("PH_EARLY_COUNT") && getenv("PH_EARLY_COUNT")[0] == '0');
+    if (!early_count || async_counts) return PH_OK;
+    return arm_publish(8, &pub->mbox, &pub->flag, &pub->seq);
+}
+
+int ph_ctx::count_back(const ph::ScanPublish &pub, int64_t *host, const void *total_dev, int64_t cap, const char *what) {
+    if (pub.seq) {
+        const int rc = collect_armed(host, 8, pub.seq);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (cap >= 0 && *host > cap) { ph::set_error("%s: %lld rows, output capacity %lld", what, (long long)*host, (long long)cap); return PH_ECAPACITY; }
+            return PH_OK;
+        }
+    }
+    return download_count(host, total_dev, cap, what);
+}
+
 int ph_ctx::download(void *host, const void *dev, int64_t bytes, bool with_deferred) {
     if (bytes <= 0) return PH_OK;
     const int64_t MB = PH_MAILBOX;

@@ -6,7 +6,6 @@ namespace ph {
 // in-place exclusive scan of n int32 on the ctx stream; *total_dev receives the sum
 // pub (optional, from ph_ctx::arm_publish): the thread that stores the total also stores it into the mapped mailbox and then the sequence
 // number — the host learns a selection's count while the write pass that follows the scan is still running, and without a publish launch
-struct ScanPublish { unsigned long long *mbox = nullptr, *flag = nullptr; unsigned long long seq = 0; };
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev, const ScanPublish *pub = nullptr);
 
 // A `column OP constant` comparison lowered to an integer range test, for kernels that evaluate a

@@ -3296,7 +3296,9 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     if (j->dkw == 4) { PH_DC_K(4) } else { PH_DC_K(8) }
 #undef PH_DC_K
     PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    ph::ScanPublish pub;   // the pair count travels with the scan: the host has it while the pairs are still being written
+    PH_CHECK(ctx->arm_count(&pub));
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total, pub.seq ? &pub : nullptr));
     const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
     const int32_t *bsel = j->build.sel;
 #define PH_DE_ARGS P.sel, j->next, bsel, cand, cmatch, ccnt, ccount, counts, j->count_dev, bflags, nb, cap, out_probe_dev, out_build_dev
@@ -3306,7 +3308,7 @@ static int direct_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, cons
     else ph::direct_emit_kernel<false, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_DE_ARGS);
 #undef PH_DE_ARGS
     PH_HIP(hipGetLastError());
-    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
+    return ctx->count_back(pub, n_out, total, cap, "ph_join_probe_inner");
 }
 
 // probe-side shape check of a node table: same packing as the build side, no other key shape
@@ -3341,7 +3343,9 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
     int32_t *cmatch = (int32_t *)((char *)ctx->scratch + o_cmatch);
     launch_big_probe<1>(j, P, n, (int)std::min<int64_t>(nb, (int64_t)ctx->cu_count * 16), cmatch, ccnt, counts, nullptr, nullptr);
     PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    ph::ScanPublish pub;
+    PH_CHECK(ctx->arm_count(&pub));
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total, pub.seq ? &pub : nullptr));
     const int wave_grid = (int)std::min<int64_t>((nb + 3) / 4, (int64_t)ctx->cu_count * 8);
     const uint64_t mask = (uint64_t)j->cap - 1;
 #define PH_BE_ARGS P.key[0].data, P.key[1].data, P.sel, n, j->head, mask, j->nodes, ccnt, cmatch, counts, nb, cap, out_probe_dev, out_build_dev
@@ -3350,7 +3354,7 @@ static int big_probe_inner(ph_join *j, const ph::JoinSide &P, int64_t n, int32_t
     else { if (P.sel) ph::big_emit_kernel<8, 1, true><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); else ph::big_emit_kernel<8, 1, false><<<wave_grid, 256, 0, ctx->stream>>>(PH_BE_ARGS); }
 #undef PH_BE_ARGS
     PH_HIP(hipGetLastError());
-    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
+    return ctx->count_back(pub, n_out, total, cap, "ph_join_probe_inner");
 }
 
 // the radix form answers inner probes; marks and lookups go through the node table, built here on first use
@@ -3746,6 +3750,7 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
     uint64_t mask = (uint64_t)j->cap - 1;
+    ph::ScanPublish pub;
     {
         int32_t *ccount = (int32_t *)((char *)ctx->scratch + o_ccount);
         uint16_t *cand = (uint16_t *)((char *)ctx->scratch + o_cand), *ccnt = (uint16_t *)((char *)ctx->scratch + o_ccnt);
@@ -3757,12 +3762,13 @@ static int probe_inner_impl(ph_join *j, const ph_col *keys, const int32_t *sel, 
         if (!ph::try_chain_fast(wave_grid, ctx->stream, j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb))
             ph::join_chain_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb);
         PH_HIP(hipGetLastError());
-        PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+        PH_CHECK(ctx->arm_count(&pub));
+        PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total, pub.seq ? &pub : nullptr));
         ph::join_emit_kernel<<<wave_grid, 256, 0, ctx->stream>>>(j->build, P, j->head, mask, j->next, cand, ccount, ccnt, cmatch, counts, nb, cap,
                                                                  out_probe_dev, out_build_dev);
         PH_HIP(hipGetLastError());
     }
-    return ctx->download_count(n_out, total, cap, "ph_join_probe_inner");
+    return ctx->count_back(pub, n_out, total, cap, "ph_join_probe_inner");
 }
 
 // Filter -> semi-join mark in one pass: found_dev[i] = (row i passes the comparison) && (its key is in the

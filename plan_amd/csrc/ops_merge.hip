@@ -240,13 +240,15 @@ extern "C" int ph_join_sorted_pairs(ph_ctx *ctx, const ph_col *build_key, int64_
         else ph::sorted_pairs_count_kernel<8><<<grid, 256, 0, ctx->stream>>>(build_key->data, n_build, probe_key->data, probe_key->validity, sel, n, first, counts);
         if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
     }
-    if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, n, total);
+    ph::ScanPublish pub;
+    if (rc == PH_OK) rc = ctx->arm_count(&pub);
+    if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, n, total, pub.seq ? &pub : nullptr);
     if (rc == PH_OK) {
         ph::sorted_pairs_emit_kernel<<<grid, 256, 0, ctx->stream>>>(first, counts, total, sel, n, 1, cap, out_probe_dev, out_build_dev);
         if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
     }
     int64_t m = 0;
-    if (rc == PH_OK) rc = ctx->download(&m, total, 8);
+    if (rc == PH_OK) rc = pub.seq ? ctx->count_back(pub, &m, total, -1, "ph_join_sorted_pairs") : ctx->download(&m, total, 8);   // (the count is needed here: never deferred)
     ctx->pool_release(first);
     if (counts) ctx->pool_release(counts);
     if (total) ctx->pool_release(total);

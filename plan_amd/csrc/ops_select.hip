@@ -958,20 +958,11 @@ static int run_select(ph_ctx *ctx, ph::SelParams &P, const int32_t *sel_in, int6
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
     unsigned long long *flags = memo ? (unsigned long long *)((char *)ctx->scratch + ph::round_up(nb * 4, 8) + 64) : nullptr;
-    // the count travels with the scan (ScanPublish): the host has it while the write pass runs, and no publish launch follows. Not with deferred
-    // counts (Ctx.set_async_counts: several counts collected later) — those keep their slots.
+    // the count travels with the scan (ScanPublish): the host has it while the write pass runs, and no publish launch follows
     ph::ScanPublish pub;
-    unsigned long long armed = 0;
-    static const bool early_count = !(getenv("PH_EARLY_COUNT") && getenv("PH_EARLY_COUNT")[0] == '0');
-    if (early_count && !ctx->async_counts) PH_CHECK(ctx->arm_publish(8, &pub.mbox, &pub.flag, &armed));
-    pub.seq = armed;
-    auto count_back = [&]() -> int {
-        if (armed) {
-            const int rc = ctx->collect_armed(n_out, 8, armed);
-            if (rc <= 0) return rc;   // (1: the mailbox has been used since — cannot happen inside this call, but the ordinary path is right anyway)
-        }
-        return ctx->download_count(n_out, total, -1, "ph_filter_select");
-    };
+    PH_CHECK(ctx->arm_count(&pub));
+    const unsigned long long armed = pub.seq;
+    auto count_back = [&]() -> int { return ctx->count_back(pub, n_out, total, -1, "ph_filter_select"); };
     if (vec) {
         int rc = P.kind == ph::SK_RANGE_I32   ? ph::run_vsel<int32_t>(ctx, P, n_in, sel_out, counts, nb, total, armed ? &pub : nullptr)
                  : P.kind == ph::SK_RANGE_I64 ? ph::run_vsel<int64_t>(ctx, P, n_in, sel_out, counts, nb, total, armed ? &pub : nullptr)
@@ -1023,12 +1014,14 @@ extern "C" int ph_filter_select_cols(ph_ctx *ctx, const ph_col *a, const ph_col 
     PH_CHECK(ctx->ensure_scratch(ph::round_up(nb * 4, 8) + 64));
     int32_t *counts = (int32_t *)ctx->scratch;
     int64_t *total = (int64_t *)((char *)ctx->scratch + ph::round_up(nb * 4, 8));
+    ph::ScanPublish pub;
+    PH_CHECK(ctx->arm_count(&pub));
     ph::select_count_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, nullptr);
     PH_HIP(hipGetLastError());
-    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total));
+    PH_CHECK(ph::exclusive_scan_i32(ctx, counts, nb, total, pub.seq ? &pub : nullptr));
     ph::select_write_kernel<<<(int)nb, 256, 0, ctx->stream>>>(P, sel_in, n_in, counts, sel_out, nullptr);
     PH_HIP(hipGetLastError());
-    return ctx->download_count(n_out, total, -1, "ph_filter_select_cols");
+    return ctx->count_back(pub, n_out, total, -1, "ph_filter_select_cols");
 }
 
 // ------------------------------------------------------------------ union (OR / IN lists)
