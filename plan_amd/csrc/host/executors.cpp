@@ -863,7 +863,7 @@ std::string gpuOrderExecutor::Init() {
     return "";
 }
 
-std::string gpuOrderExecutor::Close() { chunks_.clear(); order_.clear(); return ""; }
+std::string gpuOrderExecutor::Close() { unified_.clear(); chunks_.clear(); order_.clear(); return ""; }
 
 // inputs up to this many rows are ordered on the host (PH_ORDER_HOST_ROWS moves it; 0 = always the device sort, which the
 // parity tests use to run both forms over the same rows)
@@ -1082,11 +1082,27 @@ OperatorResult gpuOrderExecutor::Execute(Chunk *, Chunk *output, std::string *er
     int card = (int)std::min<size_t>((size_t)DefaultVectorSize, order_.size() - next_);
     output->Init(OutputTypes(), ChunkCapacityFor(card));
     int ncol = (int)OutputTypes().size();
+    if (unified_.empty()) {   // every input vector's unified format once (CopyCell builds one per cell); sized first: a Unified may point into itself
+        unified_.resize(chunks_.size());
+        for (size_t ci = 0; ci < chunks_.size(); ci++) {
+            unified_[ci] = std::vector<Vector::Unified>((size_t)ncol);
+            for (int c = 0; c < ncol; c++) chunks_[ci]->Data[(size_t)c]->ToUnifiedFormat(chunks_[ci]->Card(), &unified_[ci][(size_t)c]);
+        }
+    }
     for (int r = 0; r < card; r++) {
         int64_t row = order_[next_ + (size_t)r];
         size_t ci = (size_t)(std::upper_bound(start_.begin(), start_.end(), row) - start_.begin()) - 1;
         int local = (int)(row - start_[ci]);
-        for (int c = 0; c < ncol; c++) CopyCell(*chunks_[ci]->Data[(size_t)c], local, output->Data[(size_t)c].get(), r);
+        for (int c = 0; c < ncol; c++) {
+            const Vector &src = *chunks_[ci]->Data[(size_t)c];
+            const Vector::Unified &u = unified_[ci][(size_t)c];
+            Vector *dst = output->Data[(size_t)c].get();
+            const int64_t idx = u.sel->GetIndex(local);
+            if (!u.mask->RowIsValid((uint64_t)idx)) { dst->Mask.SetInvalid((uint64_t)r, DefaultVectorSize); continue; }
+            // a VARCHAR cell references the input chunk's bytes: the input chunks live until Close, after every consumer of this output
+            if (src._Typ.GetInternalType() == PT_VARCHAR) dst->Slice<String>()[r] = reinterpret_cast<const String *>(u.data)[idx];
+            else { const size_t w = src._Typ.Size(); memcpy(dst->Data.data() + (size_t)r * w, u.data + (size_t)idx * w, w); }
+        }
     }
     output->SetCard(card);
     next_ += (size_t)card;

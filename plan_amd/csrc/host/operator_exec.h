@@ -307,6 +307,7 @@ private:
     std::vector<std::shared_ptr<Chunk>> chunks_;
     std::vector<int64_t> start_;          // first row id of each chunk
     std::vector<int32_t> order_;          // sorted row ids
+    std::vector<std::vector<Vector::Unified>> unified_;   // per input chunk and column (built with the first output chunk)
     size_t next_ = 0;
     bool sorted_ = false;
 };
