@@ -578,7 +578,11 @@ def bench_operator_interface(h, sf, steps, warmup):
     lib.planhost_tpch_rows.restype = ctypes.c_int64
     db = ctypes.c_void_p()
     t0 = time.time()
-    if lib.planhost_tpch_load(h.ctx.h, ctypes.c_int64(sf), ctypes.c_int64(1), ctypes.byref(db)) != 0:
+    # a context of its own (ph_ctx_create: the library's own non-blocking stream), as the shim gives every executor one and as
+    # host_tester runs — not the torch stream the Python pipelines are timed on (Q3 measured ~35 us slower per query on that one)
+    from plan_amd import hip as _hip
+    octx = _hip.Ctx(h.local_rank)
+    if lib.planhost_tpch_load(octx.h, ctypes.c_int64(sf), ctypes.c_int64(1), ctypes.byref(db)) != 0:
         raise RuntimeError(lib.planhost_last_error().decode())
     load_s = time.time() - t0
     out = {}
@@ -634,6 +638,7 @@ def bench_operator_interface(h, sf, steps, warmup):
                                           "queries": others}
     finally:
         lib.planhost_tpch_free(db)
+        octx.close()
     return out
 
 
