@@ -63,7 +63,12 @@ inline int type_width(int32_t t) {
 
 namespace ph {
 // what a scan needs to publish its total itself (ops.h exclusive_scan_i32): the mapped mailbox, its sequence word and the number to store there
-struct ScanPublish { unsigned long long *mbox = nullptr, *flag = nullptr; unsigned long long seq = 0; };
+struct ScanPublish {
+    unsigned long long *mbox = nullptr, *flag = nullptr;
+    unsigned long long seq = 0;
+    const int *deferred = nullptr;   // the ctx's deferred-error words ride along (as with publish_kernel) when some are pending
+    int *mbox_deferred = nullptr;
+};
 }  // namespace ph
 
 struct ph_ctx {
@@ -94,8 +99,8 @@ struct ph_ctx {
     // A kernel that publishes its own result (ScanTail): arm_publish hands out the mailbox, the sequence word and the next number BEFORE the launch;
     // collect_armed waits for that number and copies the bytes out — unless another publish has used the mailbox since (returns 1: download as usual)
     // or the arming was refused (seq 0: PH_NO_PUBLISH, deferred words pending).
-    int arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq);
-    int collect_armed(void *host, int64_t bytes, unsigned long long seq);
+    int arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq, bool deferred_ok = false);
+    int collect_armed(void *host, int64_t bytes, unsigned long long seq, bool deferred_ok = false);
     int ensure_mailbox();
     // A row count that travels with the scan that produces it: arm_count before the scan is launched (pub is left empty when the count has to take
     // the ordinary way: deferred counts, PH_EARLY_COUNT=0), count_back instead of download_count behind the kernels that consume the offsets.

@@ -141,12 +141,12 @@ int ph_ctx::ensure_mailbox() {
     return PH_OK;
 }
 
-int ph_ctx::arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq) {
+int ph_ctx::arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned long long **flag_dev, unsigned long long *seq, bool deferred_ok) {
     *seq = 0;
     *mbox_dev = nullptr;
     *flag_dev = nullptr;
     static const bool no_publish = getenv("PH_NO_PUBLISH") != nullptr || getenv("PH_NO_SCAN_TAIL_PUBLISH") != nullptr;
-    if (no_publish || bytes > (int64_t)PH_MAILBOX || (deferred_pending && deferred_dev && !defer_hold)) return PH_OK;
+    if (no_publish || bytes > (int64_t)PH_MAILBOX || (!deferred_ok && deferred_pending && deferred_dev && !defer_hold)) return PH_OK;
     PH_CHECK(ensure_mailbox());
     *mbox_dev = reinterpret_cast<unsigned long long *>(mailbox_dev);
     *flag_dev = reinterpret_cast<unsigned long long *>((char *)mailbox_dev + PH_MAILBOX + 64);
@@ -154,8 +154,8 @@ int ph_ctx::arm_publish(int64_t bytes, unsigned long long **mbox_dev, unsigned l
     return PH_OK;
 }
 
-int ph_ctx::collect_armed(void *host, int64_t bytes, unsigned long long seq) {
-    if (!seq || seq != publish_seq || (deferred_pending && deferred_dev && !defer_hold)) return 1;
+int ph_ctx::collect_armed(void *host, int64_t bytes, unsigned long long seq, bool deferred_ok) {
+    if (!seq || seq != publish_seq || (!deferred_ok && deferred_pending && deferred_dev && !defer_hold)) return 1;
     PH_CHECK(poll_flag(reinterpret_cast<const unsigned long long *>((const char *)mailbox + PH_MAILBOX + 64), seq, stream));
     memcpy(host, mailbox, (size_t)bytes);
     return PH_OK;
@@ -165,13 +165,22 @@ int ph_ctx::arm_count(ph::ScanPublish *pub) {
     *pub = ph::ScanPublish{};
     static const bool early_count = !(getenv("PH_EARLY_COUNT") && getenv("PH_EARLY_COUNT")[0] == '0');
     if (!early_count || async_counts) return PH_OK;
-    return arm_publish(8, &pub->mbox, &pub->flag, &pub->seq);
+    PH_CHECK(arm_publish(8, &pub->mbox, &pub->flag, &pub->seq, true));
+    if (pub->seq && deferred_pending && deferred_dev && !defer_hold) {   // pending deferred-error words: checked with this count, as a publish would
+        pub->deferred = deferred_dev;
+        pub->mbox_deferred = reinterpret_cast<int *>((char *)mailbox_dev + PH_MAILBOX);
+    }
+    return PH_OK;
 }
 
 int ph_ctx::count_back(const ph::ScanPublish &pub, int64_t *host, const void *total_dev, int64_t cap, const char *what) {
     if (pub.seq) {
-        const int rc = collect_armed(host, 8, pub.seq);
+        // (the words were copied only if they were pending at arming time: pending ones that were NOT copied — a kernel between arming and the
+        // scan set the mode — take the ordinary way)
+        const bool pending_now = deferred_pending && deferred_dev && !defer_hold;
+        const int rc = pending_now && !pub.deferred ? 1 : collect_armed(host, 8, pub.seq, true);
         if (rc < 0) return rc;
+        if (rc == 0 && pub.deferred) PH_CHECK(finish_deferred());
         if (rc == 0) {
             if (cap >= 0 && *host > cap) { ph::set_error("%s: %lld rows, output capacity %lld", what, (long long)*host, (long long)cap); return PH_ECAPACITY; }
             return PH_OK;

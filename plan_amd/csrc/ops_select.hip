@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void like_contains2_count_kernel(SelParams P, 
 __device__ __forceinline__ void scan_publish(const ScanPublish &S, long long total) {   // one thread: the word, then the number
     if (!S.mbox) return;
     S.mbox[0] = (unsigned long long)total;
+    if (S.deferred) for (int k = 0; k < 4; k++) S.mbox_deferred[k] = S.deferred[k];
     __threadfence_system();
     __hip_atomic_store(S.flag, S.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
