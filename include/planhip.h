@@ -243,7 +243,8 @@ int ph_filter_select_and(ph_ctx *ctx, const ph_col *col, int64_t n, int32_t op1,
                          const int32_t *sel_in, int64_t n_in, int32_t *sel_out, int64_t *n_out);
 
 /* `col IN (v1 .. vk)` in one pass (InExpr = an OR of equalities: execSelectOr, expr_exec.go:488-530, runs k passes and a union). INTEGER columns and
- * dictionary-code columns (values = codes), k <= 16; PH_EUNSUPPORTED otherwise (the caller unites ph_filter_select results with ph_sel_union). */
+ * (k <= 16) and dictionary-code columns (values = codes, any number: what a LIKE over a dictionary selects); PH_EUNSUPPORTED otherwise (the
+ * caller unites ph_filter_select results with ph_sel_union). */
 int ph_filter_select_in(ph_ctx *ctx, const ph_col *col, int64_t n, const int64_t *values, int32_t nvalues, const int32_t *sel_in, int64_t n_in,
                         int32_t *sel_out, int64_t *n_out);
 

@@ -50,8 +50,9 @@ struct SelParams {
     char pat[96];
     const void *data2;          // SK_CMP2_*: the right-hand column
     const uint8_t *validity2;
-    int nin;                    // SK_IN_*: the list
+    int nin;                    // SK_IN_I32: the list
     int inv[16];
+    unsigned inbits[8];         // SK_IN_U8: one bit per dictionary code
 };
 
 __device__ __forceinline__ bool icmp(int op, long long a, long long b) {
@@ -109,10 +110,8 @@ __device__ __forceinline__ bool sel_pred(const SelParams &P, int64_t r) {
         return hit;
     }
     case SK_IN_U8: {
-        const int v = ((const uint8_t *)P.data)[r];
-        bool hit = false;
-        for (int q = 0; q < P.nin; q++) hit = hit || v == P.inv[q];
-        return hit;
+        const unsigned v = ((const uint8_t *)P.data)[r];
+        return (P.inbits[v >> 5] >> (v & 31)) & 1u;
     }
     case SK_CMP2_I32: return bit_valid(P.validity2, r) && icmp(P.op, ((const int32_t *)P.data)[r], ((const int32_t *)P.data2)[r]);
     case SK_CMP2_I64: return bit_valid(P.validity2, r) && icmp(P.op, ((const int64_t *)P.data)[r], ((const int64_t *)P.data2)[r]);
@@ -920,8 +919,8 @@ extern "C" int ph_filter_select_and(ph_ctx *ctx, const ph_col *col, int64_t n, i
 }
 
 // `col IN (v1, .., vk)` in one pass: InExpr is `in(a,x) OR in(a,y) ..` — execSelectOr (expr_exec.go:488-530) evaluates every child over the input
-// and unites the selections: k passes, k counts, one union. INTEGER columns and dictionary codes ('=' exists for both: selectOperation); up to 16
-// values; a value outside the column's type matches nothing.
+// and unites the selections: k passes, k counts, one union. INTEGER columns (up to 16 values) and dictionary codes (any set of codes: a bitmap) — '=' exists for both (selectOperation); a value outside
+// the column's type matches nothing.
 extern "C" int ph_filter_select_in(ph_ctx *ctx, const ph_col *col, int64_t n, const int64_t *values, int32_t nvalues, const int32_t *sel_in, int64_t n_in,
                                    int32_t *sel_out, int64_t *n_out) {
     PH_REQUIRE(ctx && col && n_out && n >= 0 && n_in >= 0 && nvalues >= 0 && (nvalues == 0 || values), "ph_filter_select_in: bad arguments");
@@ -929,7 +928,7 @@ extern "C" int ph_filter_select_in(ph_ctx *ctx, const ph_col *col, int64_t n, co
     PH_REQUIRE(n_in == 0 || sel_out, "ph_filter_select_in: sel_out is NULL");
     *n_out = 0;
     if (col->type != PH_I32 && col->type != PH_CODE8) { ph::set_error("ph_filter_select_in: INTEGER or dictionary-code columns"); return PH_EUNSUPPORTED; }
-    if (nvalues > 16) { ph::set_error("ph_filter_select_in: at most 16 values"); return PH_EUNSUPPORTED; }
+    if (nvalues > (col->type == PH_CODE8 ? 256 : 16)) { ph::set_error("ph_filter_select_in: at most 16 INTEGER values / 256 codes"); return PH_EUNSUPPORTED; }
     if (n_in == 0 || nvalues == 0) return PH_OK;
     ph::SelParams P;
     memset(&P, 0, sizeof P);
@@ -939,7 +938,8 @@ extern "C" int ph_filter_select_in(ph_ctx *ctx, const ph_col *col, int64_t n, co
     for (int32_t q = 0; q < nvalues; q++) {
         const int64_t v = values[q];
         if (col->type == PH_I32 ? (v < INT32_MIN || v > INT32_MAX) : (v < 0 || v > 255)) continue;
-        P.inv[P.nin++] = (int)v;
+        if (col->type == PH_I32) P.inv[P.nin++] = (int)v;
+        else { P.inbits[v >> 5] |= 1u << (v & 31); P.nin++; }   // a set of codes: one bit each (any number of them)
     }
     if (P.nin == 0) return PH_OK;
     return run_select(ctx, P, sel_in, n_in, sel_out, n_out);

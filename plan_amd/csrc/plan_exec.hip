@@ -302,6 +302,13 @@ int eval_bool(ph_plan *p, Rel *r, bool table_mode, const BoolTree &bt, int idx, 
             }
             std::vector<const int32_t *> sels;
             std::vector<int64_t> counts;
+            if (runs.size() > 1 && !getenv("PH_PLAN_NO_IN_LIST")) {   // scattered codes ('%TIN' over p_type: 30 of 150): ONE pass over a bitmap of the codes
+                std::vector<int64_t> codes;
+                for (auto &rn : runs) for (int c = rn.first; c <= rn.second; c++) codes.push_back(c);
+                PL_CHECK(ph_filter_select_in(ctx, &v, N, codes.data(), (int32_t)codes.size(), sel_in, n_in, (int32_t *)out, &m));
+                runs.clear();
+                sels.push_back((const int32_t *)out); counts.push_back(m);
+            }
             for (auto &rn : runs) {
                 ph_const kr{};
                 kr.type = PH_CODE8; kr.i = rn.first; kr.scale = rn.second;

@@ -155,7 +155,7 @@ def test_in_list_in_one_pass(ctx):
     sel_in = np.sort(rng.choice(n, 90_000, replace=False)).astype(np.int32)
     ds = ctx.upload(sel_in)
     for typ, data, lists in ((hip.PH_I32, v, [[14, 7, 21, 24, 35, 33, 2, 20], [-50, 49, 49, 1000], [3], [2**40]]),
-                             (hip.PH_CODE8, codes, [[1, 5, 39], [999, 7], [300]])):
+                             (hip.PH_CODE8, codes, [[1, 5, 39], [999, 7], [300], list(range(0, 40, 2)) + [255]])):   # (any number of codes: a bitmap)
         col = hip.DevColumn(ctx, typ, data, validity=vb)
         for vals in lists:
             for s_in, rows in ((None, np.arange(n)), (ds, sel_in)):
