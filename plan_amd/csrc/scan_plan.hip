@@ -269,6 +269,8 @@ struct ph_scan_plan {
     int64_t last_rows = 0;
     int last_grid = 0;
     unsigned long long armed_seq = 0;   // the last run's own publish (ScanTail), 0 = none: fetch downloads
+    bool unfetched = false;             // the last run's result was never fetched: a caller that runs back to back (a throughput loop, the N-rank
+                                        // path reading the partials on the device) gets no publish armed — the mailbox store is a system fence per run
     // PK_GENERIC: the descriptor itself, run through the operator-granular kernels
     std::vector<ph_pred> g_preds;
     std::vector<std::string> g_pred_strs;
@@ -853,7 +855,9 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
     // kernel's last wave publishes — two launches (a single workgroup folding 42 words x 256 workgroups was slower than the 42-wave merge launch).
     ph::ScanTail tail = {};
     static const bool fused_tail = !(getenv("PH_SCAN_TAIL") && getenv("PH_SCAN_TAIL")[0] == '0');
-    if (fused_tail && p->nacc <= ph::SCAN_TAIL_MAX_ACC) {
+    const bool back_to_back = p->unfetched;
+    p->unfetched = true;
+    if (fused_tail && p->nacc <= ph::SCAN_TAIL_MAX_ACC && !(back_to_back && p->kind != PK_FILTER_SUMPROD)) {
         ph_ctx *ctx = p->ctx;
         if (!ctx->scan_done_dev) {   // the ticket: zero between launches
             PH_HIP(hipMalloc((void **)&ctx->scan_done_dev, 64));
@@ -863,7 +867,7 @@ extern "C" int ph_scan_plan_run(ph_scan_plan *p, int64_t row_begin, int64_t row_
         tail.out_lo = p->out_lo;
         tail.out_hi = p->out_hi;
         tail.nacc = p->nacc;
-        PH_CHECK(ctx->arm_publish((int64_t)p->nacc * 16, &tail.mbox, &tail.flag, &tail.seq));
+        if (!back_to_back) PH_CHECK(ctx->arm_publish((int64_t)p->nacc * 16, &tail.mbox, &tail.flag, &tail.seq));
         p->armed_seq = tail.seq;
     }
     if (p->kind == PK_FILTER_SUMPROD) {
@@ -957,6 +961,7 @@ extern "C" int ph_scan_plan_fetch(ph_scan_plan *p, ph_agg_result **out) {
     std::vector<unsigned long long> words((size_t)p->nacc * 2);
     const int armed = p->ctx->collect_armed(words.data(), (int64_t)words.size() * 8, p->armed_seq);   // 1: the mailbox has been used since
     p->armed_seq = 0;
+    p->unfetched = false;
     if (armed < 0) return armed;
     if (armed == 1) PH_CHECK(p->ctx->download(words.data(), p->out_lo, (int64_t)words.size() * 8));
     std::vector<unsigned long long> lo(words.begin(), words.begin() + p->nacc);
