@@ -407,14 +407,13 @@ static std::string go_float(double v) {
     if (v != v) return "NaN";
     if (v == 0) return "0";
     char tmp[64];
-    // the shortest digit string that parses back to v: if p digits do, p + 1 do too, so the smallest such p is found by bisection (17 always does)
-    int lo = 1, hi = 17;
-    while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        snprintf(tmp, sizeof tmp, "%.*e", mid - 1, v);
-        if (strtod(tmp, nullptr) == v) hi = mid; else lo = mid + 1;
+    // the shortest digit string that parses back to v. Fifteen digits first: if they do, every shorter string that does is those digits with
+    // their trailing zeros cut (a shorter round-tripping string differs from v by less than half an ulp, far below the fifteenth digit) — the
+    // zeros are stripped below; else sixteen, else seventeen (which always do). One to three conversions instead of a search over 1..17.
+    for (int prec = 15; prec <= 17; prec++) {
+        snprintf(tmp, sizeof tmp, "%.*e", prec - 1, v);
+        if (prec == 17 || strtod(tmp, nullptr) == v) break;
     }
-    snprintf(tmp, sizeof tmp, "%.*e", lo - 1, v);
     std::string digits;
     const char *p = tmp;
     bool neg = false;
