@@ -236,7 +236,21 @@ bool Chunk::Deserialize(const std::string &in, size_t *pos, std::string *err) {
 // ------------------------------------------------------------------ decimal (product side)
 
 static u128 p10(int k) { u128 r = 1; while (k-- > 0) r *= 10; return r; }
-static int ndig(u128 v) { int n = 0; while (v) { v /= 10; n++; } return n ? n : 1; }
+// decimal digits of v: values below 2^64 (every coefficient the device path produces) by comparison with the powers of ten, no division
+static int ndig(u128 v) {
+    static const uint64_t P[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull, 10000000000ull,
+                                   100000000000ull, 1000000000000ull, 10000000000000ull, 100000000000000ull, 1000000000000000ull, 10000000000000000ull,
+                                   100000000000000000ull, 1000000000000000000ull, 10000000000000000000ull};
+    if ((v >> 64) == 0) {
+        const uint64_t x = (uint64_t)v;
+        int n = 1;
+        while (n < 20 && x >= P[n]) n++;
+        return n;
+    }
+    int n = 0;
+    while (v) { v /= 10; n++; }
+    return n;
+}
 
 Decimal DecimalFromUnscaled(int64_t unscaled, int scale) {
     Decimal d{};
