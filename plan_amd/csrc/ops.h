@@ -7,6 +7,9 @@ namespace ph {
 // pub (optional, from ph_ctx::arm_publish): the thread that stores the total also stores it into the mapped mailbox and then the sequence
 // number — the host learns a selection's count while the write pass that follows the scan is still running, and without a publish launch
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev, const ScanPublish *pub = nullptr);
+// The decoupled look-back's per-context tile states for ONE kernel of `tiles` tiles (see scan_lookback_kernel: entries carry the epoch of the call
+// that wrote them, the ticket counter keeps counting across calls): state[tiles], the ticket word, its base for this call and the call's epoch.
+int scan_state_acquire(ph_ctx *ctx, int64_t tiles, unsigned long long **state, unsigned **ticket, unsigned *ticket_base, unsigned long long *epoch);
 
 // A `column OP constant` comparison lowered to an integer range test, for kernels that evaluate a
 // pushed-down filter inline (the fused filter+probe). kind 0 = no predicate.

@@ -1812,16 +1812,37 @@ __device__ __forceinline__ void sorted_heads_body(const SortedAgg &S, int32_t *_
 __global__ __launch_bounds__(256) void sorted_heads_kernel(const SortedAgg *__restrict__ Sp, int32_t *__restrict__ counts) { sorted_heads_body(*Sp, counts); }
 __global__ __launch_bounds__(256) void sorted_heads_kernel_v(const SortedAgg S, int32_t *__restrict__ counts) { sorted_heads_body(S, counts); }
 
+// One pass (round 4, late): the tile's first group id comes from a decoupled look-back over the tiles' head counts INSIDE the groups kernel — the
+// heads pass (a second read of the key columns) and the scan launch between the two are gone. Tiles are taken from a ticket counter, so a tile
+// only ever waits for tiles that already run; states as in scan_lookback_kernel (ops_select.hip). state == nullptr: the two-pass form.
+struct SaLook {
+    unsigned long long *state;
+    unsigned *ticket;
+    unsigned ticket_base;
+    unsigned long long epoch;
+    int32_t *block_off;   // out: every tile's first group id (the fix-up kernel reads it)
+    int64_t *total;       // out: the number of groups
+};
+constexpr unsigned long long SA_AGG = 1ull, SA_INCL = 2ull;
+
 // side[(tile * naggs + a) * 2 + 0] = the partial of the rows before the tile's first head (the whole tile when it has none),
 // side[.. + 1] = the partial from the tile's last head to its end (unused without a head)
 template <bool ONE>
 __device__ __forceinline__ void sorted_groups_body(const SortedAgg &S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
-                                                   SaPart *__restrict__ side) {
+                                                   SaPart *__restrict__ side, const SaLook &L) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * SA_TILE + (int64_t)tid * SA_V;
+    __shared__ unsigned s_tile;
+    __shared__ long long s_prefix;
+    if (L.state) {
+        if (tid == 0) s_tile = atomicAdd(L.ticket, 1u) - L.ticket_base;
+        __syncthreads();
+    }
+    const unsigned tile = L.state ? s_tile : blockIdx.x;
+    const int64_t base = (int64_t)tile * SA_TILE + (int64_t)tid * SA_V;
     bool bad = false;
     long long k0[SA_V];
     const unsigned h = sa_lane_heads(S, base, &bad, k0);
+    if (L.state && bad) atomicOr(S.violation, 4);   // (the two-pass form checks the order in its heads pass)
     const int nh = __popc(h);
     // exclusive scan of the head counts over the workgroup -> the lane's first group id
     __shared__ int wc[4];
@@ -1834,8 +1855,43 @@ __device__ __forceinline__ void sorted_groups_body(const SortedAgg &S, const int
     int excl = incl - nh;
     for (int q = 0; q < wv; q++) excl += wc[q];
     const int tile_heads = wc[0] + wc[1] + wc[2] + wc[3];
-    const int64_t goff = (int64_t)block_off[blockIdx.x] + excl;     // group id of the lane's first head; goff - 1: the run its leading rows continue
-    if (blockIdx.x == 0 && tid == 0) S.counters[0] = (int)*total;
+    if (L.state) {   // the tile's first group id: look back over the predecessors' published head counts / inclusive prefixes
+        // The FIRST WAVE looks at 64 predecessors at a time (one lane each): up to the nearest inclusive prefix everything must be published; the
+        // window's counts are added with one wave reduction. (One thread walking back tile by tile made 58 k tiles a serial chain: 1.09 ms.)
+        if (wv == 0) {
+            const unsigned long long tag = L.epoch << 34;
+            if (lane == 0) __hip_atomic_store(&L.state[tile], tag | ((tile == 0 ? SA_INCL : SA_AGG) << 32) | (unsigned)tile_heads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long prefix = 0;
+            long long hi = (long long)tile - 1;   // the window is tiles hi, hi - 1, .., hi - 63
+            unsigned spins = 0;
+            while (hi >= 0) {
+                const long long q = hi - lane;
+                unsigned long long st = 0;
+                if (q >= 0) st = __hip_atomic_load(&L.state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long flag = (q >= 0 && (st >> 34) == L.epoch) ? (st >> 32) & 3ull : 0ull;
+                const unsigned long long incl_mask = __ballot(flag == SA_INCL);
+                const unsigned long long ready_mask = __ballot(flag != 0 || q < 0);
+                // lanes 0 .. first (the nearest inclusive prefix, or the whole window) must all be published
+                const int first = incl_mask ? __ffsll((long long)incl_mask) - 1 : 63;
+                const unsigned long long need = first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull);
+                if ((ready_mask & need) != need) { if (++spins > (1u << 24)) break; continue; }   // not all published in this call yet: look again
+                long long v = (q >= 0 && lane <= first) ? (long long)(unsigned)st : 0;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                prefix += v;
+                if (incl_mask) break;
+                hi -= 64;
+            }
+            if (lane == 0) {
+                if (tile != 0) __hip_atomic_store(&L.state[tile], tag | (SA_INCL << 32) | (unsigned)(prefix + tile_heads), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = prefix;
+                L.block_off[tile] = (int32_t)prefix;
+                if ((int64_t)(tile + 1) * SA_TILE >= S.n) { *L.total = prefix + tile_heads; S.counters[0] = (int)(prefix + tile_heads); }   // the last tile
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t goff = (L.state ? s_prefix : (int64_t)block_off[tile]) + excl;     // group id of the lane's first head; goff - 1: the run its leading rows continue
+    if (!L.state && tile == 0 && tid == 0) S.counters[0] = (int)*total;
     // the heads' keys and first rows
     {
         int k = 0;
@@ -1906,24 +1962,24 @@ __device__ __forceinline__ void sorted_groups_body(const SortedAgg &S, const int
         if (seen_head && rows_here > 0) {
             const SaPart done = sa_combine(kind, carry, pre);
             if (cflag) sa_store(S, goff - 1, a, kind, done);                                   // its head lies in this tile: whole here? only if it began here
-            else side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 0] = done;                      // it began in an earlier tile: the tile's leading partial
+            else side[((int64_t)tile * S.naggs + a) * 2 + 0] = done;                      // it began in an earlier tile: the tile's leading partial
         }
         // the tile's trailing partial: the last lane's inclusive value
         if (tid == 255) {
             const SaPart incl_all = f ? x : sa_combine(kind, wcarry, x);
             const bool any = f || wcf;
             // (x of the last lane already folds its wave's tail; wcarry folds the earlier waves' when no head sits in between)
-            if (tile_heads == 0) side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 0] = incl_all;  // the whole tile inside one run
-            else side[((int64_t)blockIdx.x * S.naggs + a) * 2 + 1] = any ? incl_all : incl_all;
+            if (tile_heads == 0) side[((int64_t)tile * S.naggs + a) * 2 + 0] = incl_all;  // the whole tile inside one run
+            else side[((int64_t)tile * S.naggs + a) * 2 + 1] = any ? incl_all : incl_all;
         }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void sorted_groups_kernel(const SortedAgg *__restrict__ Sp, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
-                                                            SaPart *__restrict__ side) { sorted_groups_body<false>(*Sp, block_off, total, side); }
+                                                            SaPart *__restrict__ side, SaLook L) { sorted_groups_body<false>(*Sp, block_off, total, side, L); }
 __global__ __launch_bounds__(256) void sorted_groups_kernel_v(const SortedAgg S, const int32_t *__restrict__ block_off, const int64_t *__restrict__ total,
-                                                              SaPart *__restrict__ side) { sorted_groups_body<true>(S, block_off, total, side); }
+                                                              SaPart *__restrict__ side, SaLook L) { sorted_groups_body<true>(S, block_off, total, side, L); }
 
 // one lane per tile with a head: its last run = its trailing partial + the following tiles without a head + the next tile's leading partial
 template <bool ONE>
@@ -1996,26 +2052,39 @@ extern "C" int ph_agg_sink_sorted(ph_agg *a, const ph_col *keys, const ph_col *a
     ph::SortedAgg *Sd = nullptr;
     int rc = PH_OK;
     const bool one = a->naggs == 1;
+    // Up to 8192 tiles (8 M rows) ONE pass: the tiles' first group ids from a look-back inside the groups kernel — two launches and a second read of
+    // the keys less (Q3's 298 k rows: -10 us). Above that the heads pass + scan + groups pass: with 58 k tiles in flight every workgroup idles
+    // through its look-back's round trips while holding its registers (60 M rows: 0.82 ms in one pass, 0.49 ms in two). PH_STREAM_AGG_TWO_PASS=1 /
+    // PH_STREAM_AGG_ONE_PASS=1 force either form (the parity tests run both).
+    ph::SaLook L{};
+    const bool two_pass = getenv("PH_STREAM_AGG_TWO_PASS") != nullptr, one_pass = getenv("PH_STREAM_AGG_ONE_PASS") != nullptr;
+    if (!two_pass && nb < (1ll << 31) && (nb <= 8192 || one_pass)) {
+        PH_CHECK(ph::scan_state_acquire(ctx, nb, &L.state, &L.ticket, &L.ticket_base, &L.epoch));
+        L.block_off = counts;
+        L.total = total;
+    }
     if (one) {   // the by-value entries: the one aggregate's argument first, every descriptor index a constant
         if (S.agg_kind[0] != PH_A_COUNT_STAR && S.agg_arg[0] != 0) { S.arg[0] = S.arg[S.agg_arg[0]]; S.agg_arg[0] = 0; }
-        ph::sorted_heads_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
-        if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
-        if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
+        if (!L.state) {
+            ph::sorted_heads_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts);
+            if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+            if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
+        }
         if (rc == PH_OK) {
-            ph::sorted_groups_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total, side);
+            ph::sorted_groups_kernel_v<<<(int)nb, 256, 0, ctx->stream>>>(S, counts, total, side, L);
             ph::sorted_fixup_kernel_v<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(S, counts, total, nb, side);
             if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
         }
     } else {
         rc = ctx->pool_alloc((int64_t)sizeof(ph::SortedAgg), (void **)&Sd);
         if (rc == PH_OK && hipMemcpyAsync(Sd, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PH_EHIP;   // (pageable source: staged before the call returns)
-        if (rc == PH_OK) {
+        if (rc == PH_OK && !L.state) {
             ph::sorted_heads_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts);
             if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
+            if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
         }
-        if (rc == PH_OK) rc = ph::exclusive_scan_i32(ctx, counts, nb, total);
         if (rc == PH_OK) {
-            ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts, total, side);
+            ph::sorted_groups_kernel<<<(int)nb, 256, 0, ctx->stream>>>(Sd, counts, total, side, L);
             ph::sorted_fixup_kernel<<<(int)((nb + 255) / 256), 256, 0, ctx->stream>>>(Sd, counts, total, nb, side);
             if (hipGetLastError() != hipSuccess) rc = PH_EHIP;
         }

@@ -837,6 +837,24 @@ __global__ __launch_bounds__(1024) void scan_lookback_kernel(int32_t *__restrict
     }
 }
 
+int scan_state_acquire(ph_ctx *ctx, int64_t nt, unsigned long long **state, unsigned **ticket, unsigned *ticket_base, unsigned long long *epoch) {
+    if (nt > ctx->scan_tiles) {   // (re)allocate the state buffer: zero = epoch 0, which no call uses
+        if (ctx->scan_state) { PH_HIP(hipStreamSynchronize(ctx->stream)); PH_HIP(hipFree(ctx->scan_state)); ctx->scan_state = nullptr; }
+        const int64_t cap = std::max<int64_t>(nt * 2, 4096);
+        PH_HIP(hipMalloc(&ctx->scan_state, (size_t)cap * 8 + 64));
+        PH_HIP(hipMemsetAsync(ctx->scan_state, 0, (size_t)cap * 8 + 64, ctx->stream));
+        ctx->scan_tiles = cap;
+        ctx->scan_ticket_base = 0;
+    }
+    *state = (unsigned long long *)ctx->scan_state;
+    *ticket = (unsigned *)(*state + ctx->scan_tiles);
+    ctx->scan_epoch = (ctx->scan_epoch % ((1ull << 30) - 1)) + 1;   // 1 .. 2^30-1, never 0
+    *epoch = ctx->scan_epoch;
+    *ticket_base = ctx->scan_ticket_base;
+    ctx->scan_ticket_base += (unsigned)nt;   // wraps like the device counter
+    return PH_OK;
+}
+
 int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev, const ScanPublish *pub) {
     const ScanPublish S = pub ? *pub : ScanPublish{};
     if (n <= 4 * SCAN_TILE) {
@@ -848,20 +866,11 @@ int exclusive_scan_i32(ph_ctx *ctx, int32_t *dev, int64_t n, int64_t *total_dev,
     const int64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
     static const bool three_pass = getenv("PH_SCAN_THREE_PASS") != nullptr;
     if (!three_pass && nt < (1ll << 31)) {
-        if (nt > ctx->scan_tiles) {   // (re)allocate the state buffer: zero = epoch 0, which no call uses
-            if (ctx->scan_state) { PH_HIP(hipStreamSynchronize(ctx->stream)); PH_HIP(hipFree(ctx->scan_state)); ctx->scan_state = nullptr; }
-            const int64_t cap = std::max<int64_t>(nt * 2, 4096);
-            PH_HIP(hipMalloc(&ctx->scan_state, (size_t)cap * 8 + 64));
-            PH_HIP(hipMemsetAsync(ctx->scan_state, 0, (size_t)cap * 8 + 64, ctx->stream));
-            ctx->scan_tiles = cap;
-            ctx->scan_ticket_base = 0;
-        }
-        unsigned long long *state = (unsigned long long *)ctx->scan_state;
-        unsigned *ticket = (unsigned *)(state + ctx->scan_tiles);
-        ctx->scan_epoch = (ctx->scan_epoch % ((1ull << 30) - 1)) + 1;   // 1 .. 2^30-1, never 0
-        scan_lookback_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, state, ticket, ctx->scan_ticket_base, ctx->scan_epoch, total_dev, S);
+        unsigned long long *state = nullptr, epoch = 0;
+        unsigned *ticket = nullptr, ticket_base = 0;
+        PH_CHECK(scan_state_acquire(ctx, nt, &state, &ticket, &ticket_base, &epoch));
+        scan_lookback_kernel<<<(int)nt, 1024, 0, ctx->stream>>>(dev, n, state, ticket, ticket_base, epoch, total_dev, S);
         PH_HIP(hipGetLastError());
-        ctx->scan_ticket_base += (unsigned)nt;   // wraps like the device counter
         return PH_OK;
     }
     int32_t *tiles = nullptr;

@@ -1853,11 +1853,14 @@ def test_join_lookup_matches_inner_probe_on_unique_keys(ctx):
         c.free()
 
 
-def test_streaming_aggregate_over_sorted_input_equals_hash_aggregate(ctx):
-    """ph_agg_sink_sorted: rows ordered by the group-key tuple (runs of 1..40 rows, one run of 100 000
+@pytest.mark.parametrize("form", ["PH_STREAM_AGG_ONE_PASS", "PH_STREAM_AGG_TWO_PASS"])
+def test_streaming_aggregate_over_sorted_input_equals_hash_aggregate(ctx, form, monkeypatch):
+    """(both forms: the tiles' first group ids from a look-back inside the groups kernel, and from a heads pass + scan)
+    ph_agg_sink_sorted: rows ordered by the group-key tuple (runs of 1..40 rows, one run of 100 000
     rows, a run across a 2048-row block boundary; two keys; SUM / AVG / COUNT / MIN / MAX / COUNT(*) with
     a NULL-able argument) give the groups ph_agg_sink gives, record for record and in first-seen order;
     a further sink is refused; rows that are NOT ordered are a deferred PH_ECONSTRAINT."""
+    monkeypatch.setenv(form, "1")
     rng = np.random.default_rng(101)
     lens = rng.integers(1, 41, 60_000)
     lens[1000] = 100_000
@@ -2279,11 +2282,13 @@ def test_existence_only_table_marks_like_the_oracle(ctx, kw):
 
 
 @pytest.mark.gpu
-def test_streaming_aggregate_long_runs_are_reduced_tile_by_tile(ctx):
-    """Round 4: the streaming aggregate reduces every 1024-row tile as a segmented scan and joins the pieces of a run that crosses
+@pytest.mark.parametrize("form", ["PH_STREAM_AGG_ONE_PASS", "PH_STREAM_AGG_TWO_PASS"])
+def test_streaming_aggregate_long_runs_are_reduced_tile_by_tile(ctx, form, monkeypatch):
+    """(both forms) Round 4: the streaming aggregate reduces every 1024-row tile as a segmented scan and joins the pieces of a run that crosses
     tiles in a fix-up pass, one step per TILE — so the shapes round 3 withdrew from (a table clustered by a low-cardinality key: 8 runs of
     50 000 rows) and the one it still walked row by row (ONE long run among short ones) both give the hash aggregate's groups, record for
     record: SUM, MIN, MAX, COUNT(*) and a NULL-able argument, runs that end exactly at a tile boundary, a last partial tile."""
+    monkeypatch.setenv(form, "1")
     rng = np.random.default_rng(9)
     cases = {
         "low cardinality": np.repeat(np.arange(8, dtype=np.int64), 50_000),
