@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
                                                           const int *__restrict__ ngroups, int descending, int is_sum, long long k,
                                                           int *__restrict__ cand_ids, unsigned long long *__restrict__ cand_keys,
                                                           int *__restrict__ cand_count, int *__restrict__ done,
-                                                          int *__restrict__ out_ids, int *__restrict__ meta, int cap) {
+                                                          int *__restrict__ out_ids, int *__restrict__ meta, int cap,
+                                                          unsigned long long *__restrict__ wg_kth) {
     __shared__ unsigned long long skeys[TOPK_FINAL];
     __shared__ unsigned lh[256];
     __shared__ unsigned long long s_state[8];
@@ -145,6 +146,9 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
     if (n > 0) {
         bool all;
         const unsigned long long kth = wg_radix_select(skeys, n, k, lh, s_state, &all);
+        // this workgroup's k-th best key bounds the GLOBAL k-th best from above (it holds k keys at least that good): the last workgroup prunes
+        // the candidate list with the smallest of these bounds before it selects
+        if (threadIdx.x == 0) __hip_atomic_store(&wg_kth[blockIdx.x], all ? ~0ull : kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ONE reserving add on the global candidate counter per workgroup (its candidates are counted in LDS first): adds on one
         // address execute one after the other at the memory side (~12 ns each), and 111 workgroups x ~11 candidates were 14 of
         // this kernel's 33 us
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
             __hip_atomic_store(&cand_keys[pos], skeys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    else if (threadIdx.x == 0) __hip_atomic_store(&wg_kth[blockIdx.x], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a workgroup past the groups: no bound)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's candidate stores are performed
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
@@ -180,7 +185,40 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
     const int m = __hip_atomic_load(cand_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long kth = ~0ull;
     bool all = k >= m;
-    if (!all) {
+    if (!all && m > TOPK_FINAL) {
+        // Many workgroups (Q10: 560 x ~20 candidates): only candidates at least as good as the smallest of the workgroups' own k-th keys can be
+        // among the global k best — usually a few dozen. They are selected from in LDS; the select straight from memory over all 11 k
+        // candidates was 50 of this kernel's 82 us.
+        unsigned long long bound = ~0ull;
+        for (int w = threadIdx.x; w < (int)gridDim.x; w += 256) {
+            const unsigned long long b = __hip_atomic_load(&wg_kth[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bound = b < bound ? b : bound;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(bound, o); bound = y < bound ? y : bound; }
+        if ((threadIdx.x & 63) == 0) s_state[4 + (threadIdx.x >> 6)] = bound;
+        __shared__ int s_kept;
+        if (threadIdx.x == 0) s_kept = 0;
+        __syncthreads();
+        for (int w = 0; w < 4; w++) bound = s_state[4 + w] < bound ? s_state[4 + w] : bound;
+        __syncthreads();
+        for (int i0 = 0; i0 < m; i0 += 256 * 8) {   // (eight loads in flight per thread: one after the other they were most of this stage)
+            unsigned long long key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * 256 + (int)threadIdx.x;
+                key[u] = i < m ? __hip_atomic_load(&cand_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * 256 + (int)threadIdx.x;
+                if (i < m && key[u] <= bound) { const int pos = atomicAdd(&s_kept, 1); if (pos < TOPK_FINAL) skeys[pos] = key[u]; }
+            }
+        }
+        __syncthreads();
+        const int kept = s_kept;
+        if (kept <= TOPK_FINAL && kept >= k) { kth = wg_radix_select(skeys, kept, k, lh, s_state, &all); }
+        else kth = wg_radix_select(cand_keys, m, k, lh, s_state, &all);   // (ties by the thousand: the select straight from memory)
+    } else if (!all) {
         if (m <= TOPK_FINAL) {
             for (int i = threadIdx.x; i < m; i += 256)
                 skeys[i] = __hip_atomic_load(&cand_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,11 +230,20 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const unsigned long lo
             kth = wg_radix_select(cand_keys, m, k, lh, s_state, &all);
         }
     }
-    for (int i = threadIdx.x; i < m; i += 256) {
-        const unsigned long long key = __hip_atomic_load(&cand_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (all || key <= kth) {
-            const int pos = atomicAdd(meta, 1);
-            if (pos < cap) out_ids[pos] = __hip_atomic_load(&cand_ids[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = 0; i0 < m; i0 += 256 * 8) {
+        unsigned long long key[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 256 + (int)threadIdx.x;
+            key[u] = i < m ? __hip_atomic_load(&cand_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 256 + (int)threadIdx.x;
+            if (i < m && (all || key[u] <= kth)) {
+                const int pos = atomicAdd(meta, 1);
+                if (pos < cap) out_ids[pos] = __hip_atomic_load(&cand_ids[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -2516,9 +2563,11 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     PH_CHECK(ctx->pool_alloc((int64_t)(2 + (size_t)cap * rec) * 8, (void **)&pack));
     int *meta = state + 2;
     const int tg = (int)((a->gcap + ph::TOPK_CHUNK - 1) / ph::TOPK_CHUNK);   // grid from the capacity: the count stays on the device
+    unsigned long long *wg_kth = nullptr;   // every workgroup's own k-th best key (the last workgroup prunes the candidates with their minimum)
+    PH_CHECK(ctx->pool_alloc((int64_t)tg * 8 + 64, (void **)&wg_kth));
     ph::topk_select_kernel<<<tg, 256, 0, ctx->stream>>>(a->sum_lo, a->sum_hi, a->cnt, a->naggs, agg_index, a->counters, descending,
                                                         kind == PH_A_SUM ? 1 : (kind == PH_A_COUNT || kind == PH_A_COUNT_STAR) ? 2 : 0, (long long)k, cand_ids, cand_keys, state, state + 1,
-                                                        ids, meta, cap);
+                                                        ids, meta, cap, wg_kth);
     ph::agg_pack_kernel<<<std::max(1, std::min((cap + 255) / 256, 64)), 256, 0, ctx->stream>>>(
         ids, meta, a->counters, cap, a->nkeys, a->naggs, a->first_row, a->gkeys, a->gnull, a->sum_lo, a->sum_hi, a->cnt, pack);
     int rc = hipGetLastError() == hipSuccess ? PH_OK : PH_EHIP;
@@ -2540,6 +2589,7 @@ extern "C" int ph_agg_topk(ph_agg *a, int32_t agg_index, int32_t descending, int
     ctx->pool_release(cand_ids);
     ctx->pool_release(cand_keys);
     ctx->pool_release(pack);
+    ctx->pool_release(wg_kth);
     if (rc != PH_OK) return rc;
     struct Row { long long fr; std::vector<unsigned long long> k, lo, cn; std::vector<long long> hi; unsigned null; };
     std::vector<Row> rows(n);

@@ -1673,6 +1673,30 @@ def test_agg_topk_preselection(ctx):
     agg.free(); dk.free(); dv.free()
 
 
+def test_agg_topk_many_groups_prunes_candidates(ctx):
+    """ph_agg_topk over 1.5 M groups: thousands of workgroups each hand in their k best (more candidates than the last workgroup holds in LDS);
+    it prunes them with the smallest of the workgroups' own k-th keys before it selects — same groups as a full sort, ties of the k-th
+    value included, descending and ascending, SUM and COUNT(*)"""
+    rng = np.random.default_rng(47)
+    n = 4_000_000
+    k = rng.integers(0, 1_500_000, n).astype(np.int64)
+    v = rng.integers(-10**5, 10**5, n).astype(np.int64)
+    dk, dv = hip.DevColumn(ctx, hip.PH_I64, k), hip.DevColumn(ctx, hip.PH_I64, v)
+    agg = hip.Agg(ctx, [hip.PH_I64], [(hip.PH_A_SUM, 0), (hip.PH_A_COUNT_STAR, -1)], 1_500_000)
+    agg.sink([dk], [dv], None, n)
+    full = agg.finalize(python_ints=False)
+    sums = full["sum_lo"][:, 0].view(np.int64)
+    counts = full["count"][:, 1].astype(np.int64)
+    for a, vals in ((0, sums), (1, counts)):
+        for kk, desc in [(20, True), (100, False), (3, True)]:
+            r = agg.topk(a, kk, descending=desc, cap=full["ngroups"])
+            order = np.sort(vals)[::-1] if desc else np.sort(vals)
+            kth = order[kk - 1]
+            want = set(full["keys"][:, 0][(vals >= kth) if desc else (vals <= kth)].tolist())
+            assert set(r["keys"][:, 0].tolist()) == want and r["ngroups"] == len(want), (a, kk, desc, r["ngroups"], len(want))
+    agg.free(); dk.free(); dv.free()
+
+
 def test_filter_select_unaligned_column_pointer(ctx):
     """a column view that starts in the middle of an allocation (not 16-byte aligned) must take the
     scalar path and still give the right, ordered selection"""
